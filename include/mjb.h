@@ -1,0 +1,189 @@
+/* mjb.h — C-ABI of the MI355X-native batched MuJoCo-style step engine (libmjb.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of ubi-agni/mujoco_ros_pkgs: the `mj_step` loop
+ * inside `MujocoEnv::physicsLoop` (/root/reference mujoco_ros/src/mujoco_env.cpp:436-639).  In the
+ * reference that path sits behind the MuJoCo 2.3.7 C API (un-vendored third-party library,
+ * mujoco_ros/CMakeLists.txt:61).  Every entry point below names the MuJoCo call, and the reference
+ * call site(s), it takes the place of for a batch of N independent env instances that share one
+ * constant model.  Plain C: pointers and sizes only, no torch / HIP types in any signature.
+ *
+ * Error convention: MuJoCo aborts through mju_error; this ABI never aborts or throws.  Functions
+ * returning int give 0 on success and a negative MJB_E* code on failure; functions returning a
+ * pointer give NULL on failure; mjb_last_error() returns the message of the calling thread's last
+ * failure.  The engine has NO CPU fallback: without a usable HIP device every compute entry point
+ * fails with MJB_ENODEVICE.
+ */
+#ifndef MJB_H_
+#define MJB_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MJB_VERSION 100
+
+/* error codes */
+#define MJB_OK 0
+#define MJB_EINVAL (-1)    /* bad argument / inconsistent model */
+#define MJB_ENODEVICE (-2) /* no HIP device / HIP runtime failure */
+#define MJB_ENOMEM (-3)
+#define MJB_EUNSUPPORTED (-4) /* model uses a feature the engine does not implement */
+#define MJB_ERANGE (-5)
+
+/* MuJoCo 2.3.7 enum values used in mjb_model_desc (mjtJoint, mjtGeom, ...) */
+enum { MJB_JNT_FREE = 0, MJB_JNT_BALL = 1, MJB_JNT_SLIDE = 2, MJB_JNT_HINGE = 3 };
+enum { MJB_GEOM_PLANE = 0, MJB_GEOM_SPHERE = 2, MJB_GEOM_CAPSULE = 3, MJB_GEOM_BOX = 6 };
+enum { MJB_INT_EULER = 0 };
+enum { MJB_CONE_PYRAMIDAL = 0, MJB_CONE_ELLIPTIC = 1 };
+enum { MJB_SOL_PGS = 0, MJB_SOL_CG = 1, MJB_SOL_NEWTON = 2 };
+enum { MJB_GAIN_FIXED = 0, MJB_GAIN_AFFINE = 1 };
+enum { MJB_BIAS_NONE = 0, MJB_BIAS_AFFINE = 1 };
+enum { MJB_TRN_JOINT = 0 };
+enum { MJB_DYN_NONE = 0 };
+enum { /* mjtDisableBit */
+	MJB_DSBL_CONSTRAINT = 1 << 0, MJB_DSBL_EQUALITY = 1 << 1, MJB_DSBL_FRICTIONLOSS = 1 << 2,
+	MJB_DSBL_LIMIT = 1 << 3, MJB_DSBL_CONTACT = 1 << 4, MJB_DSBL_PASSIVE = 1 << 5,
+	MJB_DSBL_GRAVITY = 1 << 6, MJB_DSBL_CLAMPCTRL = 1 << 7, MJB_DSBL_WARMSTART = 1 << 8,
+	MJB_DSBL_FILTERPARENT = 1 << 9, MJB_DSBL_ACTUATION = 1 << 10, MJB_DSBL_REFSAFE = 1 << 11,
+	MJB_DSBL_SENSOR = 1 << 12, MJB_DSBL_EULERDAMP = 1 << 14
+};
+enum { /* mjtObj */
+	MJB_OBJ_UNKNOWN = 0, MJB_OBJ_BODY = 1, MJB_OBJ_XBODY = 2, MJB_OBJ_JOINT = 3, MJB_OBJ_GEOM = 5,
+	MJB_OBJ_SITE = 6, MJB_OBJ_ACTUATOR = 18
+};
+enum { /* mjtSensor (subset implemented; values are MuJoCo's) */
+	MJB_SENS_TOUCH = 0, MJB_SENS_ACCELEROMETER = 1, MJB_SENS_VELOCIMETER = 2, MJB_SENS_GYRO = 3,
+	MJB_SENS_JOINTPOS = 8, MJB_SENS_JOINTVEL = 9, MJB_SENS_ACTUATORPOS = 12, MJB_SENS_ACTUATORVEL = 13,
+	MJB_SENS_ACTUATORFRC = 14, MJB_SENS_BALLQUAT = 15, MJB_SENS_BALLANGVEL = 16, MJB_SENS_FRAMEPOS = 23,
+	MJB_SENS_FRAMEQUAT = 24, MJB_SENS_FRAMEXAXIS = 25, MJB_SENS_FRAMEYAXIS = 26, MJB_SENS_FRAMEZAXIS = 27,
+	MJB_SENS_FRAMELINVEL = 28, MJB_SENS_FRAMEANGVEL = 29, MJB_SENS_SUBTREECOM = 32, MJB_SENS_CLOCK = 35
+};
+enum { MJB_STAGE_NONE = 0, MJB_STAGE_POS = 1, MJB_STAGE_VEL = 2, MJB_STAGE_ACC = 3 };
+enum { /* mjtConstraint */
+	MJB_CNSTR_LIMIT_JOINT = 3, MJB_CNSTR_CONTACT_FRICTIONLESS = 5, MJB_CNSTR_CONTACT_PYRAMIDAL = 6,
+	MJB_CNSTR_CONTACT_ELLIPTIC = 7
+};
+
+/* ---- model description: the mjModel arrays the path reads (see mjb_model_fields.def) ---- */
+typedef struct mjb_model_desc {
+#define MJB_SIZE(name) int name;
+#define MJB_OPT_I(name) int name;
+#define MJB_OPT_D(name, n) double name[n];
+#define MJB_ARR_I(name, rows, cols) const int *name;
+#define MJB_ARR_D(name, rows, cols) const double *name;
+#include "mjb_model_fields.def"
+#undef MJB_SIZE
+#undef MJB_OPT_I
+#undef MJB_OPT_D
+#undef MJB_ARR_I
+#undef MJB_ARR_D
+} mjb_model_desc;
+
+/* ---- per-env data field ids (order of mjb_data_fields.def) ---- */
+typedef enum mjb_field {
+#define MJB_DS(name, rows, cols) MJB_F_##name,
+#define MJB_DD(name, rows, cols) MJB_F_##name,
+#define MJB_DD2(name, rows, cols) MJB_F_##name,
+#define MJB_DI(name, rows, cols) MJB_F_##name,
+#include "mjb_data_fields.def"
+#undef MJB_DS
+#undef MJB_DD
+#undef MJB_DD2
+#undef MJB_DI
+	MJB_F_COUNT
+} mjb_field;
+
+typedef struct mjb_model mjb_model; /* compiled, immutable model (host copy + device blob) */
+typedef struct mjb_batch mjb_batch; /* N env instances on one GPU */
+
+/* Message of the calling thread's last failed call ("" if none). */
+const char *mjb_last_error(void);
+int mjb_version(void);
+/* Number of usable HIP devices (0 when there is none; never fails). */
+int mjb_device_count(void);
+
+/* Validate + copy a model description.  Takes the place of `mj_loadXML`/`mj_loadModel` for the
+ * batched path (reference: mujoco_env.cpp:836-843); the arrays are copied, `desc` may be freed. */
+mjb_model *mjb_compile(const mjb_model_desc *desc);
+void mjb_free_model(mjb_model *m); /* mj_deleteModel, mujoco_env.cpp:747 */
+
+/* Dimension (doubles or ints per env) of a data field for this model; <0 on error. */
+int mjb_field_size(const mjb_model *m, int field);
+/* 1 if the field is an int field (MJB_DI), 0 if double. */
+int mjb_field_is_int(int field);
+/* 1 if the field is persistent state (MJB_DS). */
+int mjb_field_is_state(int field);
+const char *mjb_field_name(int field);
+/* Doubles in one per-env LDS frame (all double fields) — layout documented in DESIGN.md. */
+int mjb_frame_doubles(const mjb_model *m);
+
+/* Allocate N env instances on HIP device `device`, all at the reset state (qpos = qpos0).
+ * Takes the place of `mj_makeData` (mujoco_env.cpp:872), once per env. */
+mjb_batch *mjb_make_batch(const mjb_model *m, int nenv, int device);
+void mjb_free_batch(mjb_batch *b); /* mj_deleteData, mujoco_env.cpp:748 */
+int mjb_nenv(const mjb_batch *b);
+
+/* Launch geometry: lanes of a wavefront that cooperate on one env (8,16,32,64) and envs per
+ * workgroup.  0 selects the engine default for the model.  Results do not depend on it. */
+int mjb_set_launch(mjb_batch *b, int lanes_per_env, int envs_per_block);
+
+/* Advance every env by `nsteps` full steps, fused in ONE kernel launch with the state held in LDS
+ * between steps.  Takes the place of `nsteps` x `mj_step(model, data)` per env
+ * (mujoco_env.cpp:498, :552, :593).  Asynchronous on the batch's stream. */
+int mjb_step(mjb_batch *b, int nsteps);
+
+/* Split step for host callbacks.  mjb_step1 runs position + velocity stages (everything `mj_step`
+ * does before it invokes `mjcb_control`, incl. passive forces) and leaves the full frame in the
+ * HBM workspace; the caller may then read/modify ctrl, qfrc_applied, xfrc_applied, qfrc_passive
+ * (mjb_get/mjb_set) — this is where controlCallback / passiveCallback run (mujoco_env.h:242-251) —
+ * and mjb_step2 finishes the step (actuation, acceleration, constraint solve, acc sensors,
+ * integration).  step1+step2 == one mjb_step(b,1). */
+int mjb_step1(mjb_batch *b);
+int mjb_step2(mjb_batch *b);
+
+/* Recompute all derived quantities without integrating (mj_forward: mujoco_env.cpp:329, :621;
+ * callbacks.cpp:573) and leave the full frame in the HBM workspace for mjb_get. */
+int mjb_forward(mjb_batch *b);
+
+/* Reset envs with mask[i] != 0 (mask == NULL: all) to qpos0 / zero velocity, activation, control,
+ * applied forces, warmstart, time (mj_resetData: mujoco_env.cpp:252). */
+int mjb_reset(mjb_batch *b, const uint8_t *mask);
+
+/* Copy a field for envs [env_lo, env_hi) between host memory (env-major, field_size per env) and
+ * the device.  Derived fields are readable after mjb_forward / mjb_step1 / mjb_step2 (they come
+ * from the frame workspace); only state fields and the callback-writable force fields can be set.
+ * Synchronous. */
+int mjb_get(mjb_batch *b, int field, int env_lo, int env_hi, double *host);
+int mjb_set(mjb_batch *b, int field, int env_lo, int env_hi, const double *host);
+int mjb_get_int(mjb_batch *b, int field, int env_lo, int env_hi, int *host);
+
+/* Raw HBM pointer of a state field's env-major array [nenv][field_size] (for RCCL gathers and
+ * zero-copy tensor wrappers).  NULL for derived fields. */
+void *mjb_device_ptr(mjb_batch *b, int field);
+
+/* Device-side control noise, the reference's Ornstein-Uhlenbeck injector (mujoco_env.cpp:469-481):
+ * before every step  noise = rate*noise + scale*N(0,1),  ctrl = noise  with
+ * rate = exp(-dt/max(ctrl_noise_rate, mjMINVAL)), scale = ctrl_noise_std*sqrt(1-rate^2).
+ * N(0,1) comes from a counter-based Philox-4x32-10 stream keyed (seed, global env id, step,
+ * actuator), so a CPU oracle regenerates the identical sequence.  std == 0 disables it.
+ * `env_offset` is the global index of this batch's env 0 (multi-GPU sharding). */
+int mjb_set_ctrl_noise(mjb_batch *b, double ctrl_noise_std, double ctrl_noise_rate, uint64_t seed,
+                       int64_t env_offset);
+
+/* Stream control: the hipStream_t (as void*) kernels are launched on; default is a stream the
+ * batch owns.  mjb_synchronize waits for it. */
+void *mjb_get_stream(mjb_batch *b);
+int mjb_set_stream(mjb_batch *b, void *hip_stream);
+int mjb_synchronize(mjb_batch *b);
+
+/* Timing helper for bench.py: run `nlaunch` launches of mjb_step(b, nsteps) bracketed by HIP
+ * events recorded on the batch's stream; returns the mean per-launch duration in milliseconds
+ * through *ms_per_launch. */
+int mjb_time_steps(mjb_batch *b, int nsteps, int nlaunch, double *ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MJB_H_ */

@@ -1,0 +1,162 @@
+"""ctypes mirror of the C-ABI in ``include/mjb.h`` (libmjb.so).
+
+The struct layouts are generated from the same X-macro tables the C side includes
+(``include/mjb_model_fields.def``, ``include/mjb_data_fields.def``), so the two cannot drift.
+There is no Python/CPU fallback: if the shared library is missing, importing the engine raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(_HERE)
+INCLUDE = os.path.join(REPO, "include")
+LIB_PATH = os.path.join(_HERE, "csrc", "libmjb.so")
+
+_MODEL_RE = re.compile(r"^\s*MJB_(SIZE|OPT_I|OPT_D|ARR_I|ARR_D)\(\s*([A-Za-z0-9_]+)\s*(?:,\s*([A-Za-z0-9_]+)\s*)?(?:,\s*([A-Za-z0-9_]+)\s*)?\)")
+_DATA_RE = re.compile(r"^\s*MJB_(DS|DD|DD2|DI)\(\s*([A-Za-z0-9_]+)\s*,\s*([A-Za-z0-9_]+)\s*,\s*([A-Za-z0-9_]+)\s*\)")
+
+
+def _parse(path, rx):
+    out = []
+    with open(path) as f:
+        for line in f:
+            mm = rx.match(line)
+            if mm:
+                out.append(mm.groups())
+    return out
+
+
+MODEL_FIELDS = _parse(os.path.join(INCLUDE, "mjb_model_fields.def"), _MODEL_RE)
+DATA_FIELDS = _parse(os.path.join(INCLUDE, "mjb_data_fields.def"), _DATA_RE)
+
+SIZE_NAMES = [n for k, n, _, _ in MODEL_FIELDS if k == "SIZE"]
+
+
+def _model_struct_fields():
+    fl = []
+    for kind, name, a, b in MODEL_FIELDS:
+        if kind in ("SIZE", "OPT_I"):
+            fl.append((name, C.c_int))
+        elif kind == "OPT_D":
+            fl.append((name, C.c_double * int(a)))
+        elif kind == "ARR_I":
+            fl.append((name, C.POINTER(C.c_int)))
+        else:
+            fl.append((name, C.POINTER(C.c_double)))
+    return fl
+
+
+class ModelDesc(C.Structure):
+    _fields_ = _model_struct_fields()
+
+
+class Field:
+    """Data-field ids and metadata (order of mjb_data_fields.def == enum mjb_field)."""
+
+    names = [n for _, n, _, _ in DATA_FIELDS]
+    ids = {n: i for i, n in enumerate(names)}
+    kinds = {n: k for k, n, _, _ in DATA_FIELDS}
+
+    @staticmethod
+    def dim(model, name):
+        for k, n, rows, cols in DATA_FIELDS:
+            if n == name:
+                r = 1 if rows == "one" else int(model[rows])
+                c = int(model[cols]) if k == "DD2" else int(cols)
+                return r * c
+        raise KeyError(name)
+
+
+def make_desc(model):
+    """Build a ``ModelDesc`` pointing at (contiguous copies of) the arrays of a compiled model dict.
+    Returns (desc, keepalive)."""
+    d = ModelDesc()
+    keep = []
+    for kind, name, a, b in MODEL_FIELDS:
+        if kind in ("SIZE", "OPT_I"):
+            setattr(d, name, int(model[name]))
+        elif kind == "OPT_D":
+            v = np.atleast_1d(np.asarray(model[name], dtype=np.float64))
+            arr = getattr(d, name)
+            for i in range(int(a)):
+                arr[i] = float(v[i])
+        else:
+            rows = int(model[a])
+            cols = int(b)
+            dt = np.int32 if kind == "ARR_I" else np.float64
+            arr = np.ascontiguousarray(np.asarray(model[name], dtype=dt).reshape(-1))
+            if arr.size != rows * cols:
+                raise ValueError(f"model field {name}: expected {rows}x{cols}, got {arr.size}")
+            if arr.size == 0:
+                arr = np.zeros(1, dt)
+            keep.append(arr)
+            ct = C.c_int if kind == "ARR_I" else C.c_double
+            setattr(d, name, arr.ctypes.data_as(C.POINTER(ct)))
+    return d, keep
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libmjb.so and declare every entry point of include/mjb.h.  Raises OSError if missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise OSError(
+            f"{p} not found: the HIP engine is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback).")
+    lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    vp, ci, cd = C.c_void_p, C.c_int, C.c_double
+    sig = {
+        "mjb_last_error": (C.c_char_p, []),
+        "mjb_version": (ci, []),
+        "mjb_device_count": (ci, []),
+        "mjb_compile": (vp, [C.POINTER(ModelDesc)]),
+        "mjb_free_model": (None, [vp]),
+        "mjb_field_size": (ci, [vp, ci]),
+        "mjb_field_is_int": (ci, [ci]),
+        "mjb_field_is_state": (ci, [ci]),
+        "mjb_field_name": (C.c_char_p, [ci]),
+        "mjb_frame_doubles": (ci, [vp]),
+        "mjb_make_batch": (vp, [vp, ci, ci]),
+        "mjb_free_batch": (None, [vp]),
+        "mjb_nenv": (ci, [vp]),
+        "mjb_set_launch": (ci, [vp, ci, ci]),
+        "mjb_step": (ci, [vp, ci]),
+        "mjb_step1": (ci, [vp]),
+        "mjb_step2": (ci, [vp]),
+        "mjb_forward": (ci, [vp]),
+        "mjb_reset": (ci, [vp, C.POINTER(C.c_uint8)]),
+        "mjb_get": (ci, [vp, ci, ci, ci, C.POINTER(cd)]),
+        "mjb_set": (ci, [vp, ci, ci, ci, C.POINTER(cd)]),
+        "mjb_get_int": (ci, [vp, ci, ci, ci, C.POINTER(ci)]),
+        "mjb_device_ptr": (vp, [vp, ci]),
+        "mjb_set_ctrl_noise": (ci, [vp, cd, cd, C.c_uint64, C.c_int64]),
+        "mjb_get_stream": (vp, [vp]),
+        "mjb_set_stream": (ci, [vp, vp]),
+        "mjb_synchronize": (ci, [vp]),
+        "mjb_time_steps": (ci, [vp, ci, ci, C.POINTER(cd)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    lib._mjb_symbols = sorted(sig)
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def header_symbols():
+    """Every function name declared in include/mjb.h (for the symbol-export test)."""
+    txt = open(os.path.join(INCLUDE, "mjb.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mjb_[a-z0-9_]+)\s*\(", txt)))

@@ -1,0 +1,952 @@
+"""MJCF-subset model compiler: XML -> the mjModel-shaped flat arrays of ``include/mjb_model_fields.def``.
+
+The reference never compiles models itself: it calls MuJoCo's ``mj_loadXML``
+(/root/reference mujoco_ros/src/mujoco_env.cpp:836-843) and hands the resulting ``mjModel`` to the
+step.  MuJoCo is an un-vendored dependency that is absent here, so this module
+restates the part of MuJoCo 2.3.7's model compiler (user_model.cc / user_objects.cc /
+engine_setconst.c, [UPSTREAM]) that the hot path's inputs need, for the element subset the shipped
+worlds and the BASELINE configs use: bodies, inertial, free/ball/hinge/slide joints, plane / sphere
+/ capsule / box geoms (incl. ``fromto``), sites, motor / position / velocity / general actuators with
+joint transmission, the sensor subset of ``mjb.h`` and ``<contact><exclude>``.  Anything else raises
+``MjcfError`` -- nothing is silently dropped except purely visual elements (asset, visual, light,
+camera, material attributes).
+
+Output: ``Model`` -- a dict-like of numpy arrays named exactly as in ``mjModel`` plus name tables.
+"""
+from __future__ import annotations
+
+import math
+import os
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+mjMINVAL = 1e-15
+
+JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
+GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX = 0, 2, 3, 6
+GEOM_TYPES = {"plane": GEOM_PLANE, "sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE, "box": GEOM_BOX}
+JNT_TYPES = {"free": JNT_FREE, "ball": JNT_BALL, "slide": JNT_SLIDE, "hinge": JNT_HINGE}
+OBJ = {"body": 1, "xbody": 2, "joint": 3, "geom": 5, "site": 6, "actuator": 18}
+SENSORS = {  # name -> (mjtSensor, dim, needstage, default objtype)
+    "touch": (0, 1, 3, "site"),
+    "velocimeter": (2, 3, 2, "site"),
+    "gyro": (3, 3, 2, "site"),
+    "jointpos": (8, 1, 1, "joint"),
+    "jointvel": (9, 1, 2, "joint"),
+    "actuatorpos": (12, 1, 1, "actuator"),
+    "actuatorvel": (13, 1, 2, "actuator"),
+    "actuatorfrc": (14, 1, 3, "actuator"),
+    "ballquat": (15, 4, 1, "joint"),
+    "ballangvel": (16, 3, 2, "joint"),
+    "framepos": (23, 3, 1, None),
+    "framequat": (24, 4, 1, None),
+    "framexaxis": (25, 3, 1, None),
+    "frameyaxis": (26, 3, 1, None),
+    "framezaxis": (27, 3, 1, None),
+    "framelinvel": (28, 3, 2, None),
+    "frameangvel": (29, 3, 2, None),
+    "subtreecom": (32, 3, 1, "body"),
+    "clock": (35, 1, 1, None),
+}
+DISABLE_BITS = {
+    "constraint": 1 << 0, "equality": 1 << 1, "frictionloss": 1 << 2, "limit": 1 << 3,
+    "contact": 1 << 4, "passive": 1 << 5, "gravity": 1 << 6, "clampctrl": 1 << 7,
+    "warmstart": 1 << 8, "filterparent": 1 << 9, "actuation": 1 << 10, "refsafe": 1 << 11,
+    "sensor": 1 << 12, "eulerdamp": 1 << 14,
+}
+IGNORED_TOP = {"asset", "visual", "statistic", "size", "custom", "keyframe", "extension"}
+
+
+class MjcfError(ValueError):
+    pass
+
+
+# --------------------------------------------------------------------------- small math helpers
+def _floats(s, n=None, what=""):
+    v = np.array([float(x) for x in s.split()], dtype=np.float64)
+    if n is not None and v.size != n:
+        raise MjcfError(f"{what}: expected {n} numbers, got '{s}'")
+    return v
+
+
+def quat_mul(a, b):
+    return np.array([
+        a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+        a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+        a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1],
+        a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+
+
+def quat2mat(q):
+    q = np.asarray(q, dtype=np.float64)
+    q00, q11, q22, q33 = q[0] * q[0], q[1] * q[1], q[2] * q[2], q[3] * q[3]
+    q01, q02, q03 = q[0] * q[1], q[0] * q[2], q[0] * q[3]
+    q12, q13, q23 = q[1] * q[2], q[1] * q[3], q[2] * q[3]
+    return np.array([[q00 + q11 - q22 - q33, 2 * (q12 - q03), 2 * (q13 + q02)],
+                     [2 * (q12 + q03), q00 - q11 + q22 - q33, 2 * (q23 - q01)],
+                     [2 * (q13 - q02), 2 * (q23 + q01), q00 - q11 - q22 + q33]])
+
+
+def mat2quat(R):
+    """Rotation matrix -> unit quaternion (w>=0)."""
+    R = np.asarray(R, dtype=np.float64)
+    tr = R[0, 0] + R[1, 1] + R[2, 2]
+    if tr > 0:
+        s = math.sqrt(tr + 1.0) * 2
+        q = np.array([0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s])
+    elif R[0, 0] > R[1, 1] and R[0, 0] > R[2, 2]:
+        s = math.sqrt(1.0 + R[0, 0] - R[1, 1] - R[2, 2]) * 2
+        q = np.array([(R[2, 1] - R[1, 2]) / s, 0.25 * s, (R[0, 1] + R[1, 0]) / s, (R[0, 2] + R[2, 0]) / s])
+    elif R[1, 1] > R[2, 2]:
+        s = math.sqrt(1.0 + R[1, 1] - R[0, 0] - R[2, 2]) * 2
+        q = np.array([(R[0, 2] - R[2, 0]) / s, (R[0, 1] + R[1, 0]) / s, 0.25 * s, (R[1, 2] + R[2, 1]) / s])
+    else:
+        s = math.sqrt(1.0 + R[2, 2] - R[0, 0] - R[1, 1]) * 2
+        q = np.array([(R[1, 0] - R[0, 1]) / s, (R[0, 2] + R[2, 0]) / s, (R[1, 2] + R[2, 1]) / s, 0.25 * s])
+    if q[0] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def z2quat(vec):
+    """Quaternion rotating the z axis onto ``vec`` (MuJoCo's mjuu_z2quat, used for ``fromto``)."""
+    v = np.asarray(vec, dtype=np.float64)
+    v = v / np.linalg.norm(v)
+    axis = np.cross([0.0, 0.0, 1.0], v)
+    s = np.linalg.norm(axis)
+    if s < 1e-10:
+        # parallel or anti-parallel
+        return np.array([1.0, 0, 0, 0]) if v[2] > 0 else np.array([0.0, 1.0, 0, 0])
+    axis = axis / s
+    ang = math.atan2(s, v[2])
+    return np.concatenate([[math.cos(ang / 2)], axis * math.sin(ang / 2)])
+
+
+def euler2quat(e, seq="xyz"):
+    q = np.array([1.0, 0, 0, 0])
+    for i, ch in enumerate(seq):
+        ax = "xyz".index(ch.lower())
+        r = np.zeros(4)
+        r[0] = math.cos(e[i] / 2)
+        r[1 + ax] = math.sin(e[i] / 2)
+        # lower case: intrinsic (rotating frame) -> post-multiply; upper case: extrinsic
+        q = quat_mul(q, r) if ch.islower() else quat_mul(r, q)
+    return q
+
+
+# --------------------------------------------------------------------------- defaults handling
+class _Defaults:
+    """MJCF <default> classes: per element-tag attribute dicts with inheritance."""
+
+    def __init__(self):
+        self.classes = {"main": {}}
+        self.parent = {"main": None}
+
+    def load(self, node, cls="main"):
+        if cls not in self.classes:
+            self.classes[cls] = {}
+        for ch in node:
+            if ch.tag == "default":
+                name = ch.get("class")
+                if name is None:
+                    raise MjcfError("nested <default> needs a class")
+                self.parent[name] = cls
+                self.load(ch, name)
+            else:
+                self.classes[cls].setdefault(ch.tag, {}).update(ch.attrib)
+
+    def resolve(self, tag, cls):
+        chain = []
+        c = cls if cls in self.classes else "main"
+        while c is not None:
+            chain.append(c)
+            c = self.parent.get(c)
+        out = {}
+        for c in reversed(chain):
+            out.update(self.classes[c].get(tag, {}))
+        return out
+
+
+class Model(dict):
+    """mjModel-shaped dict of numpy arrays (+ ``names`` tables). Attribute access allowed."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def name2id(self, kind, name):
+        try:
+            return self["names"][kind].index(name)
+        except ValueError:
+            return -1
+
+
+# --------------------------------------------------------------------------- the compiler
+class _Compiler:
+    def __init__(self, root, nconmax=None, nefcmax=None):
+        self.root = root
+        self.nconmax_req = nconmax
+        self.nefcmax_req = nefcmax
+        self.angle_scale = math.pi / 180.0  # MJCF default: degrees
+        self.eulerseq = "xyz"
+        self.inertiafromgeom = "auto"
+        self.autolimits = False
+        self.defaults = _Defaults()
+        self.bodies = []  # dicts
+        self.joints = []
+        self.geoms = []
+        self.sites = []
+        self.actuators = []
+        self.sensors = []
+        self.excludes = []
+        self.opt = dict(timestep=0.002, gravity=np.array([0, 0, -9.81]), tolerance=1e-8, impratio=1.0,
+                        integrator=0, cone=0, solver=2, iterations=100, disableflags=0)
+
+    # ---- attribute helpers
+    def _merged(self, node, childclass):
+        cls = node.get("class", childclass or "main")
+        a = self.defaults.resolve(node.tag if node.tag != "freejoint" else "joint", cls)
+        a = dict(a)
+        a.update(node.attrib)
+        return a
+
+    def _orientation(self, a, what):
+        given = [k for k in ("quat", "euler", "axisangle", "xyaxes", "zaxis") if k in a]
+        if len(given) > 1:
+            raise MjcfError(f"{what}: multiple orientation specifiers {given}")
+        if not given:
+            return np.array([1.0, 0, 0, 0])
+        k = given[0]
+        if k == "quat":
+            q = _floats(a["quat"], 4, what)
+            n = np.linalg.norm(q)
+            if n < mjMINVAL:
+                raise MjcfError(f"{what}: zero quaternion")
+            return q / n
+        if k == "euler":
+            return euler2quat(_floats(a["euler"], 3, what) * self.angle_scale, self.eulerseq)
+        if k == "axisangle":
+            v = _floats(a["axisangle"], 4, what)
+            ax = v[:3] / np.linalg.norm(v[:3])
+            ang = v[3] * self.angle_scale
+            return np.concatenate([[math.cos(ang / 2)], ax * math.sin(ang / 2)])
+        if k == "zaxis":
+            return z2quat(_floats(a["zaxis"], 3, what))
+        v = _floats(a["xyaxes"], 6, what)
+        x = v[:3] / np.linalg.norm(v[:3])
+        y = v[3:] - x * np.dot(x, v[3:])
+        y = y / np.linalg.norm(y)
+        return mat2quat(np.stack([x, y, np.cross(x, y)], axis=1))
+
+    # ---- top level
+    def compile(self):
+        root = self.root
+        if root.tag != "mujoco":
+            raise MjcfError("root element must be <mujoco>")
+        for node in root:
+            if node.tag == "compiler":
+                self._compiler(node)
+        for node in root:
+            if node.tag == "default":
+                self.defaults.load(node)
+        for node in root:
+            t = node.tag
+            if t in ("compiler", "default") or t in IGNORED_TOP:
+                continue
+            if t == "option":
+                self._option(node)
+            elif t == "worldbody":
+                self._body(node, parent=-1, childclass=None, is_world=True)
+            elif t == "actuator":
+                for a in node:
+                    self._actuator(a)
+            elif t == "sensor":
+                for s in node:
+                    self._sensor(s)
+            elif t == "contact":
+                for c in node:
+                    if c.tag == "exclude":
+                        self.excludes.append((c.get("body1"), c.get("body2")))
+                    else:
+                        raise MjcfError(f"<contact><{c.tag}> is not supported")
+            else:
+                raise MjcfError(f"unsupported top-level element <{t}>")
+        if not self.bodies:
+            self._body(ET.Element("worldbody"), parent=-1, childclass=None, is_world=True)
+        return self._finalize()
+
+    def _compiler(self, node):
+        ang = node.get("angle", "degree")
+        if ang not in ("degree", "radian"):
+            raise MjcfError("compiler angle must be degree or radian")
+        self.angle_scale = 1.0 if ang == "radian" else math.pi / 180.0
+        self.eulerseq = node.get("eulerseq", "xyz")
+        self.inertiafromgeom = node.get("inertiafromgeom", "auto")
+        self.autolimits = node.get("autolimits", "false") == "true"
+
+    def _option(self, node):
+        o = self.opt
+        a = node.attrib
+        for k in ("timestep", "tolerance", "impratio"):
+            if k in a:
+                o[k] = float(a[k])
+        if "gravity" in a:
+            o["gravity"] = _floats(a["gravity"], 3, "option gravity")
+        if "iterations" in a:
+            o["iterations"] = int(a["iterations"])
+        if "integrator" in a:
+            if a["integrator"] != "Euler":
+                raise MjcfError("only the Euler integrator is implemented")
+        if "cone" in a:
+            o["cone"] = {"pyramidal": 0, "elliptic": 1}[a["cone"]]
+        if "solver" in a:
+            o["solver"] = {"PGS": 0, "CG": 1, "Newton": 2}[a["solver"]]
+        if "collision" in a and a["collision"] not in ("all", "dynamic"):
+            raise MjcfError("option collision='predefined' is not supported")
+        for fl in node:
+            if fl.tag != "flag":
+                raise MjcfError(f"<option><{fl.tag}> not supported")
+            for k, v in fl.attrib.items():
+                if k in DISABLE_BITS:
+                    if v == "disable":
+                        o["disableflags"] |= DISABLE_BITS[k]
+                elif v == "enable" and k in ("override", "energy", "fwdinv", "sensornoise", "multiccd"):
+                    raise MjcfError(f"enable flag {k} not supported")
+
+    # ---- kinematic tree
+    def _body(self, node, parent, childclass, is_world=False):
+        bid = len(self.bodies)
+        if is_world:
+            b = dict(name="world", parent=0, pos=np.zeros(3), quat=np.array([1.0, 0, 0, 0]), inertial=None,
+                     joints=[], geoms=[], sites=[])
+        else:
+            a = node.attrib
+            b = dict(name=a.get("name", f"body{bid}"), parent=parent,
+                     pos=_floats(a.get("pos", "0 0 0"), 3, "body pos"),
+                     quat=self._orientation(a, "body"), inertial=None, joints=[], geoms=[], sites=[])
+            if a.get("mocap", "false") == "true":
+                raise MjcfError("mocap bodies are not supported")
+            childclass = a.get("childclass", childclass)
+        self.bodies.append(b)
+        for ch in node:
+            t = ch.tag
+            if t == "body":
+                continue
+            if t == "inertial":
+                ia = ch.attrib
+                I = dict(pos=_floats(ia["pos"], 3, "inertial pos"), quat=self._orientation(ia, "inertial"),
+                         mass=float(ia["mass"]))
+                if "diaginertia" in ia:
+                    I["inertia"] = _floats(ia["diaginertia"], 3, "diaginertia")
+                elif "fullinertia" in ia:
+                    f = _floats(ia["fullinertia"], 6, "fullinertia")
+                    Im = np.array([[f[0], f[3], f[4]], [f[3], f[1], f[5]], [f[4], f[5], f[2]]])
+                    I["inertia"], I["quat"] = _principal(Im)
+                else:
+                    raise MjcfError("inertial needs diaginertia or fullinertia")
+                b["inertial"] = I
+            elif t in ("joint", "freejoint"):
+                if is_world:
+                    raise MjcfError("joint in worldbody")
+                b["joints"].append(self._joint(ch, bid, childclass))
+            elif t == "geom":
+                b["geoms"].append(self._geom(ch, bid, childclass))
+            elif t == "site":
+                b["sites"].append(self._site(ch, bid, childclass))
+            elif t in ("light", "camera"):
+                pass
+            else:
+                raise MjcfError(f"unsupported element <{t}> in body '{b['name']}'")
+        for ch in node:
+            if ch.tag == "body":
+                self._body(ch, bid, childclass)
+
+    def _joint(self, node, bid, childclass):
+        a = self._merged(node, childclass)
+        typ = JNT_FREE if node.tag == "freejoint" else JNT_TYPES[a.get("type", "hinge")]
+        j = dict(name=a.get("name", f"joint{len(self.joints)}_{bid}"), type=typ, body=bid)
+        j["pos"] = _floats(a.get("pos", "0 0 0"), 3, "joint pos")
+        ax = _floats(a.get("axis", "0 0 1"), 3, "joint axis")
+        if typ in (JNT_HINGE, JNT_SLIDE):
+            n = np.linalg.norm(ax)
+            if n < mjMINVAL:
+                raise MjcfError("zero joint axis")
+            ax = ax / n
+        else:
+            ax = np.array([0.0, 0, 1.0])
+        if typ == JNT_FREE:
+            j["pos"] = np.zeros(3)
+        j["axis"] = ax
+        scale = self.angle_scale if typ in (JNT_HINGE, JNT_BALL) else 1.0
+        rng = _floats(a.get("range", "0 0"), 2, "joint range") * scale
+        lim = a.get("limited", "auto")
+        if lim == "auto":
+            limited = self.autolimits and "range" in a
+        else:
+            limited = lim == "true"
+        if limited and typ == JNT_FREE:
+            raise MjcfError("free joint cannot be limited")
+        j.update(range=rng, limited=int(limited), stiffness=float(a.get("stiffness", 0)),
+                 damping=float(a.get("damping", 0)), armature=float(a.get("armature", 0)),
+                 margin=float(a.get("margin", 0)) * (scale if typ == JNT_HINGE else 1.0),
+                 ref=float(a.get("ref", 0)) * (scale if typ == JNT_HINGE else 1.0),
+                 springref=float(a.get("springref", 0)) * (scale if typ == JNT_HINGE else 1.0),
+                 solref=_floats(a.get("solreflimit", "0.02 1"), 2, "solreflimit"),
+                 solimp=_solimp(a.get("solimplimit")))
+        if float(a.get("frictionloss", 0)) != 0:
+            raise MjcfError("joint frictionloss is not supported")
+        self.joints.append(j)
+        return j
+
+    def _geom(self, node, bid, childclass):
+        a = self._merged(node, childclass)
+        tname = a.get("type", "sphere")
+        if tname not in GEOM_TYPES:
+            raise MjcfError(f"geom type '{tname}' is not supported (plane/sphere/capsule/box only)")
+        typ = GEOM_TYPES[tname]
+        g = dict(name=a.get("name", ""), type=typ, body=bid)
+        size = _floats(a.get("size", "0 0 0")) if "size" in a else np.zeros(0)
+        pos = _floats(a.get("pos", "0 0 0"), 3, "geom pos")
+        quat = self._orientation(a, "geom")
+        if "fromto" in a:
+            if typ != GEOM_CAPSULE and typ != GEOM_BOX:
+                raise MjcfError("fromto only supported for capsule/box")
+            ft = _floats(a["fromto"], 6, "fromto")
+            p0, p1 = ft[:3], ft[3:]
+            pos = 0.5 * (p0 + p1)
+            half = 0.5 * np.linalg.norm(p1 - p0)
+            quat = z2quat(p1 - p0)
+            if typ == GEOM_CAPSULE:
+                size = np.array([size[0], half, 0.0])
+            else:
+                size = np.array([size[0], size[0], half])
+        s3 = np.zeros(3)
+        s3[:min(3, size.size)] = size[:3]
+        need = {GEOM_PLANE: 0, GEOM_SPHERE: 1, GEOM_CAPSULE: 2, GEOM_BOX: 3}[typ]
+        if typ != GEOM_PLANE and (size.size < need and "fromto" not in a):
+            raise MjcfError(f"geom '{g['name']}' of type {tname} needs {need} size values")
+        if typ != GEOM_PLANE and np.any(s3[:need] <= 0):
+            raise MjcfError(f"geom '{g['name']}': sizes must be positive")
+        if typ == GEOM_PLANE and bid != 0 and False:
+            pass
+        g.update(size=s3, pos=pos, quat=quat,
+                 contype=int(a.get("contype", 1)), conaffinity=int(a.get("conaffinity", 1)),
+                 condim=int(a.get("condim", 3)), priority=int(a.get("priority", 0)),
+                 friction=_pad_friction(a.get("friction")), solmix=float(a.get("solmix", 1)),
+                 solref=_floats(a.get("solref", "0.02 1"), 2, "geom solref"), solimp=_solimp(a.get("solimp")),
+                 margin=float(a.get("margin", 0)), gap=float(a.get("gap", 0)),
+                 density=float(a.get("density", 1000)), mass=(float(a["mass"]) if "mass" in a else None))
+        if g["condim"] not in (1, 3, 4, 6):
+            raise MjcfError("condim must be 1, 3, 4 or 6")
+        self.geoms.append(g)
+        return g
+
+    def _site(self, node, bid, childclass):
+        a = self._merged(node, childclass)
+        s = dict(name=a.get("name", f"site{len(self.sites)}"), body=bid,
+                 pos=_floats(a.get("pos", "0 0 0"), 3, "site pos"), quat=self._orientation(a, "site"))
+        self.sites.append(s)
+        return s
+
+    # ---- actuators / sensors
+    def _actuator(self, node):
+        a = self._merged(node, None)
+        t = node.tag
+        if "joint" not in a:
+            raise MjcfError(f"actuator <{t}> needs joint transmission (only joint transmission supported)")
+        act = dict(name=a.get("name", f"actuator{len(self.actuators)}"), joint=a["joint"])
+        gear = np.zeros(6)
+        gv = _floats(a.get("gear", "1"))
+        gear[:gv.size] = gv
+        gain = np.zeros(3)
+        bias = np.zeros(3)
+        gaintype, biastype = 0, 0
+        if t == "motor":
+            gain[0] = 1.0
+        elif t == "position":
+            kp = float(a.get("kp", 1))
+            gain[0] = kp
+            bias[1] = -kp
+            biastype = 1
+            if "kv" in a:
+                bias[2] = -float(a["kv"])
+        elif t == "velocity":
+            kv = float(a.get("kv", 1))
+            gain[0] = kv
+            bias[2] = -kv
+            biastype = 1
+        elif t == "general":
+            gaintype = {"fixed": 0, "affine": 1}[a.get("gaintype", "fixed")]
+            biastype = {"none": 0, "affine": 1}[a.get("biastype", "none")]
+            gp = _floats(a.get("gainprm", "1"))
+            bp = _floats(a.get("biasprm", "0"))
+            gain[:min(3, gp.size)] = gp[:3]
+            bias[:min(3, bp.size)] = bp[:3]
+            if a.get("dyntype", "none") != "none":
+                raise MjcfError("actuator dynamics (dyntype) not supported")
+        else:
+            raise MjcfError(f"actuator type <{t}> not supported")
+        cr = _floats(a.get("ctrlrange", "0 0"), 2, "ctrlrange")
+        fr = _floats(a.get("forcerange", "0 0"), 2, "forcerange")
+
+        def lim(key, rng_key):
+            v = a.get(key, "auto")
+            if v == "auto":
+                return int(self.autolimits and rng_key in a)
+            return int(v == "true")
+
+        act.update(gear=gear, gainprm=gain, biasprm=bias, gaintype=gaintype, biastype=biastype, ctrlrange=cr,
+                   forcerange=fr, ctrllimited=lim("ctrllimited", "ctrlrange"),
+                   forcelimited=lim("forcelimited", "forcerange"))
+        self.actuators.append(act)
+
+    def _sensor(self, node):
+        t = node.tag
+        if t not in SENSORS:
+            raise MjcfError(f"sensor <{t}> not supported")
+        typ, dim, stage, objkind = SENSORS[t]
+        a = node.attrib
+        s = dict(name=a.get("name", f"sensor{len(self.sensors)}"), type=typ, dim=dim, stage=stage,
+                 cutoff=float(a.get("cutoff", 0)), reftype=None, refname=None)
+        if t == "clock":
+            s.update(objtype=None, objname=None)
+        elif objkind is None:
+            s.update(objtype=a["objtype"], objname=a["objname"], reftype=a.get("reftype"), refname=a.get("refname"))
+        else:
+            key = {"site": "site", "joint": "joint", "actuator": "actuator", "body": "body"}[objkind]
+            s.update(objtype=objkind, objname=a[key])
+        self.sensors.append(s)
+
+    # ---- finalisation: flat arrays
+    def _finalize(self):
+        B, J, Gm, S = self.bodies, self.joints, self.geoms, self.sites
+        nbody = len(B)
+        m = Model()
+        names = dict(body=[b["name"] for b in B], joint=[j["name"] for j in J], geom=[g["name"] for g in Gm],
+                     site=[s["name"] for s in S], actuator=[a["name"] for a in self.actuators],
+                     sensor=[s["name"] for s in self.sensors])
+        for kind in ("body", "joint", "site", "actuator"):
+            nn = [n for n in names[kind] if n]
+            if len(set(nn)) != len(nn):
+                raise MjcfError(f"duplicate {kind} names")
+        m["names"] = names
+
+        # joints are stored in body order already (depth-first creation == MuJoCo id order)
+        # re-index joints grouped by body in body order
+        J_sorted = []
+        for bi, b in enumerate(B):
+            for j in b["joints"]:
+                J_sorted.append(j)
+        J = J_sorted
+        names["joint"] = [j["name"] for j in J]
+        G_sorted, S_sorted = [], []
+        for b in B:
+            G_sorted += b["geoms"]
+            S_sorted += b["sites"]
+        Gm, S = G_sorted, S_sorted
+        names["geom"] = [g["name"] for g in Gm]
+        names["site"] = [s["name"] for s in S]
+        njnt, ngeom, nsite = len(J), len(Gm), len(S)
+
+        qn = {JNT_FREE: 7, JNT_BALL: 4, JNT_SLIDE: 1, JNT_HINGE: 1}
+        vn = {JNT_FREE: 6, JNT_BALL: 3, JNT_SLIDE: 1, JNT_HINGE: 1}
+        nq = sum(qn[j["type"]] for j in J)
+        nv = sum(vn[j["type"]] for j in J)
+
+        I, D = np.int32, np.float64
+        m["body_parentid"] = np.array([b["parent"] for b in B], I)
+        m["body_pos"] = np.array([b["pos"] for b in B], D).reshape(nbody, 3)
+        m["body_quat"] = np.array([b["quat"] for b in B], D).reshape(nbody, 4)
+        body_jntnum = np.zeros(nbody, I)
+        body_jntadr = -np.ones(nbody, I)
+        body_dofnum = np.zeros(nbody, I)
+        body_dofadr = -np.ones(nbody, I)
+        jnt_type = np.zeros(njnt, I)
+        jnt_qposadr = np.zeros(njnt, I)
+        jnt_dofadr = np.zeros(njnt, I)
+        jnt_bodyid = np.zeros(njnt, I)
+        dof_bodyid = np.zeros(nv, I)
+        dof_jntid = np.zeros(nv, I)
+        dof_parentid = -np.ones(nv, I)
+        dof_armature = np.zeros(nv, D)
+        dof_damping = np.zeros(nv, D)
+        qpos0 = np.zeros(nq, D)
+        qpos_spring = np.zeros(nq, D)
+        body_id = {id(b): i for i, b in enumerate(B)}
+        last_dof_of_body = -np.ones(nbody, I)  # last dof on the path root->body (inclusive)
+        ji = qa = da = 0
+        for bi, b in enumerate(B):
+            if bi > 0:
+                last_dof_of_body[bi] = last_dof_of_body[b["parent"]]
+            if b["joints"]:
+                body_jntadr[bi] = ji
+                body_dofadr[bi] = da
+                if any(j["type"] == JNT_FREE for j in b["joints"]) and (len(b["joints"]) > 1 or b["parent"] != 0):
+                    raise MjcfError("free joint must be the only joint of a top-level body")
+            for j in b["joints"]:
+                t = j["type"]
+                jnt_type[ji] = t
+                jnt_qposadr[ji] = qa
+                jnt_dofadr[ji] = da
+                jnt_bodyid[ji] = bi
+                j["id"] = ji
+                if t == JNT_FREE:
+                    qpos0[qa:qa + 3] = b["pos"]
+                    qpos0[qa + 3:qa + 7] = b["quat"]
+                elif t == JNT_BALL:
+                    qpos0[qa:qa + 4] = [1, 0, 0, 0]
+                else:
+                    qpos0[qa] = j["ref"]
+                qpos_spring[qa:qa + qn[t]] = qpos0[qa:qa + qn[t]]
+                if t in (JNT_HINGE, JNT_SLIDE):
+                    qpos_spring[qa] = j["springref"]
+                for k in range(vn[t]):
+                    dof_bodyid[da] = bi
+                    dof_jntid[da] = ji
+                    dof_parentid[da] = last_dof_of_body[bi]
+                    last_dof_of_body[bi] = da
+                    dof_armature[da] = j["armature"]
+                    dof_damping[da] = j["damping"]
+                    da += 1
+                qa += qn[t]
+                ji += 1
+            body_jntnum[bi] = len(b["joints"])
+            body_dofnum[bi] = sum(vn[j["type"]] for j in b["joints"])
+        dof_Madr = np.zeros(nv, I)
+        nM = 0
+        for i in range(nv):
+            dof_Madr[i] = nM
+            k = i
+            while k >= 0:
+                nM += 1
+                k = dof_parentid[k]
+        m.update(nq=nq, nv=nv, nbody=nbody, njnt=njnt, ngeom=ngeom, nsite=nsite, nM=nM, na=0)
+        m.update(body_jntnum=body_jntnum, body_jntadr=body_jntadr, body_dofnum=body_dofnum, body_dofadr=body_dofadr,
+                 jnt_type=jnt_type, jnt_qposadr=jnt_qposadr, jnt_dofadr=jnt_dofadr, jnt_bodyid=jnt_bodyid,
+                 dof_bodyid=dof_bodyid, dof_jntid=dof_jntid, dof_parentid=dof_parentid, dof_Madr=dof_Madr,
+                 dof_armature=dof_armature, dof_damping=dof_damping, qpos0=qpos0, qpos_spring=qpos_spring)
+        m["jnt_pos"] = np.array([j["pos"] for j in J], D).reshape(njnt, 3)
+        m["jnt_axis"] = np.array([j["axis"] for j in J], D).reshape(njnt, 3)
+        m["jnt_limited"] = np.array([j["limited"] for j in J], I)
+        m["jnt_stiffness"] = np.array([j["stiffness"] for j in J], D)
+        m["jnt_range"] = np.array([j["range"] for j in J], D).reshape(njnt, 2)
+        m["jnt_margin"] = np.array([j["margin"] for j in J], D)
+        m["jnt_solref"] = np.array([j["solref"] for j in J], D).reshape(njnt, 2)
+        m["jnt_solimp"] = np.array([j["solimp"] for j in J], D).reshape(njnt, 5)
+
+        # root / weld ids
+        rootid = np.zeros(nbody, I)
+        weldid = np.zeros(nbody, I)
+        for bi in range(1, nbody):
+            p = B[bi]["parent"]
+            rootid[bi] = bi if p == 0 else rootid[p]
+            weldid[bi] = bi if body_jntnum[bi] > 0 else weldid[p]
+        m["body_rootid"] = rootid
+        m["body_weldid"] = weldid
+
+        # geoms
+        for gi, g in enumerate(Gm):
+            g["id"] = gi
+        m["geom_type"] = np.array([g["type"] for g in Gm], I)
+        m["geom_contype"] = np.array([g["contype"] for g in Gm], I)
+        m["geom_conaffinity"] = np.array([g["conaffinity"] for g in Gm], I)
+        m["geom_condim"] = np.array([g["condim"] for g in Gm], I)
+        m["geom_bodyid"] = np.array([g["body"] for g in Gm], I)
+        m["geom_priority"] = np.array([g["priority"] for g in Gm], I)
+        m["geom_size"] = np.array([g["size"] for g in Gm], D).reshape(ngeom, 3)
+        m["geom_pos"] = np.array([g["pos"] for g in Gm], D).reshape(ngeom, 3)
+        m["geom_quat"] = np.array([g["quat"] for g in Gm], D).reshape(ngeom, 4)
+        m["geom_friction"] = np.array([g["friction"] for g in Gm], D).reshape(ngeom, 3)
+        m["geom_solmix"] = np.array([g["solmix"] for g in Gm], D)
+        m["geom_solref"] = np.array([g["solref"] for g in Gm], D).reshape(ngeom, 2)
+        m["geom_solimp"] = np.array([g["solimp"] for g in Gm], D).reshape(ngeom, 5)
+        m["geom_margin"] = np.array([g["margin"] for g in Gm], D)
+        m["geom_gap"] = np.array([g["gap"] for g in Gm], D)
+        rb = np.zeros(ngeom, D)
+        for gi, g in enumerate(Gm):
+            s = g["size"]
+            rb[gi] = {GEOM_PLANE: 0.0, GEOM_SPHERE: s[0], GEOM_CAPSULE: s[0] + s[1],
+                      GEOM_BOX: float(np.linalg.norm(s))}[g["type"]]
+        m["geom_rbound"] = rb
+        m["geom_sameframe"] = np.array(
+            [int(np.all(g["pos"] == 0) and np.all(g["quat"] == [1, 0, 0, 0])) for g in Gm], I)
+
+        # body inertial properties
+        body_mass = np.zeros(nbody, D)
+        body_inertia = np.zeros((nbody, 3), D)
+        body_ipos = np.zeros((nbody, 3), D)
+        body_iquat = np.tile(np.array([1.0, 0, 0, 0]), (nbody, 1))
+        for bi, b in enumerate(B):
+            use_geoms = self.inertiafromgeom == "true" or (self.inertiafromgeom == "auto" and b["inertial"] is None)
+            if b["inertial"] is not None and not use_geoms:
+                Iin = b["inertial"]
+                body_mass[bi] = Iin["mass"]
+                body_inertia[bi] = Iin["inertia"]
+                body_ipos[bi] = Iin["pos"]
+                body_iquat[bi] = Iin["quat"]
+            elif b["geoms"] and bi > 0 and self.inertiafromgeom != "false":
+                body_mass[bi], body_ipos[bi], body_iquat[bi], body_inertia[bi] = _inertia_from_geoms(b["geoms"])
+            if bi > 0 and body_dofnum[bi] > 0 or (bi > 0 and weldid[bi] != 0):
+                if body_mass[bi] < mjMINVAL or np.any(body_inertia[bi] < mjMINVAL):
+                    if weldid[bi] == bi and not self._has_massive_descendant(bi, body_mass):
+                        raise MjcfError(f"mass and inertia of moving body '{b['name']}' must be positive")
+        m.update(body_mass=body_mass, body_inertia=body_inertia, body_ipos=body_ipos, body_iquat=body_iquat)
+        m["body_sameframe"] = np.array(
+            [int(np.all(body_ipos[i] == 0) and np.all(body_iquat[i] == [1, 0, 0, 0])) for i in range(nbody)], I)
+        sub = body_mass.copy()
+        for bi in range(nbody - 1, 0, -1):
+            sub[B[bi]["parent"]] += sub[bi]
+        m["body_subtreemass"] = sub
+
+        # sites
+        m["site_bodyid"] = np.array([s["body"] for s in S], I)
+        m["site_pos"] = np.array([s["pos"] for s in S], D).reshape(nsite, 3)
+        m["site_quat"] = np.array([s["quat"] for s in S], D).reshape(nsite, 4)
+        m["site_sameframe"] = np.array(
+            [int(np.all(s["pos"] == 0) and np.all(s["quat"] == [1, 0, 0, 0])) for s in S], I)
+
+        # actuators
+        A = self.actuators
+        nu = len(A)
+        m["nu"] = nu
+        trnid = -np.ones((nu, 2), I)
+        for i, a in enumerate(A):
+            jid = m.name2id("joint", a["joint"])
+            if jid < 0:
+                raise MjcfError(f"actuator '{a['name']}': unknown joint '{a['joint']}'")
+            if jnt_type[jid] not in (JNT_HINGE, JNT_SLIDE):
+                raise MjcfError("actuators are only supported on hinge/slide joints")
+            trnid[i, 0] = jid
+        m["actuator_trnid"] = trnid
+        m["actuator_trntype"] = np.zeros(nu, I)
+        m["actuator_dyntype"] = np.zeros(nu, I)
+        m["actuator_gaintype"] = np.array([a["gaintype"] for a in A], I)
+        m["actuator_biastype"] = np.array([a["biastype"] for a in A], I)
+        m["actuator_ctrllimited"] = np.array([a["ctrllimited"] for a in A], I)
+        m["actuator_forcelimited"] = np.array([a["forcelimited"] for a in A], I)
+        m["actuator_gainprm"] = np.array([a["gainprm"] for a in A], D).reshape(nu, 3)
+        m["actuator_biasprm"] = np.array([a["biasprm"] for a in A], D).reshape(nu, 3)
+        m["actuator_ctrlrange"] = np.array([a["ctrlrange"] for a in A], D).reshape(nu, 2)
+        m["actuator_forcerange"] = np.array([a["forcerange"] for a in A], D).reshape(nu, 2)
+        m["actuator_gear"] = np.array([a["gear"] for a in A], D).reshape(nu, 6)
+
+        # sensors
+        SS = self.sensors
+        ns = len(SS)
+        adr = 0
+        s_type, s_stage, s_objtype, s_objid = (np.zeros(ns, I) for _ in range(4))
+        s_reftype, s_refid, s_dim, s_adr = np.zeros(ns, I), -np.ones(ns, I), np.zeros(ns, I), np.zeros(ns, I)
+        for i, s in enumerate(SS):
+            s_type[i], s_dim[i], s_stage[i], s_adr[i] = s["type"], s["dim"], s["stage"], adr
+            adr += s["dim"]
+            if s["objtype"] is None:
+                s_objtype[i], s_objid[i] = 0, -1
+            else:
+                if s["objtype"] not in OBJ:
+                    raise MjcfError(f"sensor objtype '{s['objtype']}' not supported")
+                s_objtype[i] = OBJ[s["objtype"]]
+                kind = "body" if s["objtype"] == "xbody" else s["objtype"]
+                s_objid[i] = m.name2id(kind, s["objname"])
+                if s_objid[i] < 0:
+                    raise MjcfError(f"sensor '{s['name']}': unknown {kind} '{s['objname']}'")
+            if s["reftype"] is not None:
+                s_reftype[i] = OBJ[s["reftype"]]
+                kind = "body" if s["reftype"] == "xbody" else s["reftype"]
+                s_refid[i] = m.name2id(kind, s["refname"])
+                if s_refid[i] < 0:
+                    raise MjcfError(f"sensor '{s['name']}': unknown ref {kind} '{s['refname']}'")
+        m.update(nsensor=ns, nsensordata=adr, sensor_type=s_type, sensor_needstage=s_stage, sensor_objtype=s_objtype,
+                 sensor_objid=s_objid, sensor_reftype=s_reftype, sensor_refid=s_refid, sensor_dim=s_dim,
+                 sensor_adr=s_adr, sensor_cutoff=np.array([s["cutoff"] for s in SS], D))
+
+        # options
+        o = self.opt
+        m.update(timestep=np.array([o["timestep"]], D), gravity=np.asarray(o["gravity"], D),
+                 tolerance=np.array([o["tolerance"]], D), impratio=np.array([o["impratio"]], D),
+                 integrator=o["integrator"], cone=o["cone"], solver=o["solver"], iterations=o["iterations"],
+                 disableflags=o["disableflags"])
+
+        # static collision candidates (restates the body/geom filters of MuJoCo's mj_collision)
+        pairs = self._collision_pairs(m)
+        m["collpair_geom"] = np.array(pairs, I).reshape(len(pairs), 2)
+        m["ncollpair"] = len(pairs)
+        # capacities: worst case contacts per pair type
+        maxcon = 0
+        for g1, g2 in pairs:
+            t1, t2 = m["geom_type"][g1], m["geom_type"][g2]
+            maxcon += _max_contacts(t1, t2)
+        nconmax = maxcon if self.nconmax_req is None else int(self.nconmax_req)
+        nlimit = int(np.sum(m["jnt_limited"] * np.where(jnt_type == JNT_BALL, 1, 1)))
+        rows_per_con = 0
+        if pairs:
+            maxdim = max(int(max(m["geom_condim"][g1], m["geom_condim"][g2])) for g1, g2 in pairs)
+            rows_per_con = 1 if maxdim == 1 else (2 * (maxdim - 1) if o["cone"] == 0 else maxdim)
+        nefcmax = nlimit + rows_per_con * nconmax if self.nefcmax_req is None else int(self.nefcmax_req)
+        if o["disableflags"] & (DISABLE_BITS["constraint"]):
+            nconmax, nefcmax = 0, 0
+        m["nconmax"], m["nefcmax"] = int(nconmax), int(nefcmax)
+
+        # mj_setConst: inverse weights at qpos0 (independent numpy dynamics, see refdyn.py)
+        from . import refdyn
+        dof_inv, body_inv = refdyn.invweight0(m)
+        m["dof_invweight0"] = dof_inv
+        m["body_invweight0"] = body_inv
+        return m
+
+    def _has_massive_descendant(self, bi, mass):
+        for ci, c in enumerate(self.bodies):
+            if ci > bi and c["parent"] == bi and (mass[ci] >= mjMINVAL or self._has_massive_descendant(ci, mass)):
+                return True
+        return False
+
+    def _collision_pairs(self, m):
+        if m["disableflags"] & (DISABLE_BITS["contact"] | DISABLE_BITS["constraint"]):
+            return []
+        B = self.bodies
+        nbody = len(B)
+        weld = m["body_weldid"]
+        parent = m["body_parentid"]
+        excl = set()
+        for b1, b2 in self.excludes:
+            i1, i2 = m.name2id("body", b1), m.name2id("body", b2)
+            if i1 < 0 or i2 < 0:
+                raise MjcfError("contact exclude: unknown body")
+            excl.add((min(i1, i2), max(i1, i2)))
+        filterparent = not (m["disableflags"] & DISABLE_BITS["filterparent"])
+        geoms_of = [[g["id"] for g in b["geoms"]] for b in B]
+        pairs = []
+        for b1 in range(nbody):
+            for b2 in range(b1 + 1, nbody):
+                if not geoms_of[b1] or not geoms_of[b2]:
+                    continue
+                if (b1, b2) in excl:
+                    continue
+                w1, w2 = weld[b1], weld[b2]
+                if w1 == w2:
+                    continue
+                if filterparent and w1 != 0 and w2 != 0:
+                    wp1, wp2 = weld[parent[w1]], weld[parent[w2]]
+                    if w1 == wp2 or w2 == wp1:
+                        continue
+                for g1 in geoms_of[b1]:
+                    for g2 in geoms_of[b2]:
+                        ct1, ca1 = m["geom_contype"][g1], m["geom_conaffinity"][g1]
+                        ct2, ca2 = m["geom_contype"][g2], m["geom_conaffinity"][g2]
+                        if not ((ct1 & ca2) or (ct2 & ca1)):
+                            continue
+                        t1, t2 = m["geom_type"][g1], m["geom_type"][g2]
+                        a, b = (g1, g2) if t1 <= t2 else (g2, g1)
+                        ta, tb = m["geom_type"][a], m["geom_type"][b]
+                        if ta == GEOM_PLANE and tb == GEOM_PLANE:
+                            continue
+                        if _max_contacts(ta, tb) == 0:
+                            raise MjcfError(
+                                f"collision between geom types {ta} and {tb} is not implemented; "
+                                "filter the pair with contype/conaffinity or <exclude>")
+                        pairs.append((a, b))
+        return pairs
+
+
+def _max_contacts(t1, t2):
+    if t1 > t2:
+        t1, t2 = t2, t1
+    table = {
+        (GEOM_PLANE, GEOM_SPHERE): 1, (GEOM_PLANE, GEOM_CAPSULE): 2, (GEOM_PLANE, GEOM_BOX): 4,
+        (GEOM_SPHERE, GEOM_SPHERE): 1, (GEOM_SPHERE, GEOM_CAPSULE): 1, (GEOM_SPHERE, GEOM_BOX): 1,
+        (GEOM_CAPSULE, GEOM_CAPSULE): 1,
+    }
+    return table.get((int(t1), int(t2)), 0)
+
+
+def _solimp(s):
+    v = np.array([0.9, 0.95, 0.001, 0.5, 2.0])
+    if s is not None:
+        x = _floats(s)
+        v[:x.size] = x
+    return v
+
+
+def _pad_friction(s):
+    v = np.array([1.0, 0.005, 0.0001])
+    if s is not None:
+        x = _floats(s)
+        v[:x.size] = x
+    return v
+
+
+def _principal(Im):
+    """Principal axes of a symmetric inertia matrix: (eigenvalues descending, quaternion of the frame)."""
+    w, V = np.linalg.eigh(Im)
+    order = np.argsort(-w)
+    w, V = w[order], V[:, order]
+    if np.linalg.det(V) < 0:
+        V[:, 2] = -V[:, 2]
+    return w, mat2quat(V)
+
+
+def _geom_mass_inertia(g):
+    s = g["size"]
+    t = g["type"]
+    if t == GEOM_SPHERE:
+        vol = 4.0 / 3.0 * math.pi * s[0] ** 3
+    elif t == GEOM_CAPSULE:
+        vol = math.pi * s[0] ** 2 * (2 * s[1]) + 4.0 / 3.0 * math.pi * s[0] ** 3
+    elif t == GEOM_BOX:
+        vol = 8.0 * s[0] * s[1] * s[2]
+    else:
+        return 0.0, np.zeros(3)
+    mass = g["mass"] if g["mass"] is not None else g["density"] * vol
+    if t == GEOM_SPHERE:
+        I = np.full(3, 0.4 * mass * s[0] ** 2)
+    elif t == GEOM_BOX:
+        I = mass / 3.0 * np.array([s[1] ** 2 + s[2] ** 2, s[0] ** 2 + s[2] ** 2, s[0] ** 2 + s[1] ** 2])
+    else:
+        r, h = s[0], 2 * s[1]
+        ms = mass * 4 * r / (4 * r + 3 * h)  # two hemispheres
+        mc = mass - ms
+        Ixy = mc * (3 * r * r + h * h) / 12.0 + 0.4 * ms * r * r + ms * h * (3 * r + 2 * h) / 8.0
+        I = np.array([Ixy, Ixy, mc * r * r / 2.0 + 0.4 * ms * r * r])
+    return mass, I
+
+
+def _inertia_from_geoms(geoms):
+    parts = []
+    for g in geoms:
+        mass, I = _geom_mass_inertia(g)
+        if mass > 0:
+            parts.append((mass, I, g["pos"], g["quat"]))
+    if not parts:
+        return 0.0, np.zeros(3), np.array([1.0, 0, 0, 0]), np.zeros(3)
+    if len(parts) == 1:
+        mass, I, pos, quat = parts[0]
+        return mass, pos.copy(), quat.copy(), I
+    M = sum(p[0] for p in parts)
+    com = sum(p[0] * p[2] for p in parts) / M
+    Im = np.zeros((3, 3))
+    for mass, I, pos, quat in parts:
+        R = quat2mat(quat)
+        d = pos - com
+        Im += R @ np.diag(I) @ R.T + mass * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+    w, q = _principal(Im)
+    return M, com, q, w
+
+
+# --------------------------------------------------------------------------- public entry points
+def compile_xml_string(xml, nconmax=None, nefcmax=None):
+    return _Compiler(ET.fromstring(xml), nconmax, nefcmax).compile()
+
+
+def compile_xml_file(path, nconmax=None, nefcmax=None):
+    with open(path, "r") as f:
+        return compile_xml_string(f.read(), nconmax, nefcmax)
+
+
+ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+
+
+def load_asset(name, **kw):
+    """Compile one of the models shipped with the package (``assets/<name>.xml``)."""
+    return compile_xml_file(os.path.join(ASSET_DIR, name + ".xml"), **kw)

@@ -1,0 +1,107 @@
+/* mjo.h — CPU ORACLE of the batched step engine.  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C fp64, single-env restatement of what `mj_step(model, data)` computes at the reference's
+ * three call sites (/root/reference mujoco_ros/src/mujoco_env.cpp:498, :552, :593) and of
+ * `mj_forward` / `mj_resetData` (mujoco_env.cpp:329, :621, :252).  The arithmetic itself lives in the
+ * third-party dependency google-deepmind/mujoco, pinned 2.3.7 (mujoco_ros/CMakeLists.txt:61,
+ * .github/workflows/ci.yaml:23), which is NOT vendored under /root/reference and is absent from
+ * this image.  Each function therefore restates the published algorithm of
+ * the named MuJoCo 2.3.7 engine function ([UPSTREAM] engine_*.c) and is anchored on the
+ * reference's call sites and on what the reference's own tests pin at that boundary
+ * (SURVEY.md §8c).
+ *
+ * PARITY UNPINNED: the reference holds no golden vector for any dynamic quantity and libmujoco
+ * cannot be built or loaded here, so this oracle is pinned only by (a) the reference-test facts of
+ * SURVEY.md §8c (time advance, reset state, rest equilibrium), (b) closed-form / independently
+ * derived dynamics (tests/test_oracle_*.py), (c) internal identities.  It has not been compared with
+ * real MuJoCo output.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this library.
+ */
+#ifndef MJO_H_
+#define MJO_H_
+
+#include <stdint.h>
+
+#include "../include/mjb.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MJO_MINVAL 1e-15 /* mjMINVAL */
+
+typedef struct mjo_data {
+#define MJB_DS(name, rows, cols) double *name;
+#define MJB_DD(name, rows, cols) double *name;
+#define MJB_DD2(name, rows, cols) double *name;
+#define MJB_DI(name, rows, cols) int *name;
+#include "../include/mjb_data_fields.def"
+#undef MJB_DS
+#undef MJB_DD
+#undef MJB_DD2
+#undef MJB_DI
+	/* scratch for the Euler implicit-damping solve */
+	double *scratch_MM;
+	double *scratch_nv;
+	double *scratch_nv2;
+} mjo_data;
+
+mjo_data *mjo_make_data(const mjb_model_desc *m); /* mj_makeData  */
+void mjo_free_data(mjo_data *d);                  /* mj_deleteData */
+void mjo_reset_data(const mjb_model_desc *m, mjo_data *d); /* mj_resetData */
+
+/* field access by mjb_field id (NULL if unknown); *n receives the element count */
+double *mjo_field(const mjb_model_desc *m, mjo_data *d, int field, int *n);
+int *mjo_field_int(const mjb_model_desc *m, mjo_data *d, int field, int *n);
+
+/* ---- stages, one per row of SURVEY.md §8a ---- */
+void mjo_kinematics(const mjb_model_desc *m, mjo_data *d);       /* A1 mj_kinematics      */
+void mjo_com_pos(const mjb_model_desc *m, mjo_data *d);          /* A1 mj_comPos          */
+void mjo_crb(const mjb_model_desc *m, mjo_data *d);              /* A2 mj_crb             */
+void mjo_factor_m(const mjb_model_desc *m, mjo_data *d);         /* A3 mj_factorM         */
+void mjo_solve_m(const mjb_model_desc *m, mjo_data *d, double *x); /* mj_solveM (in place) */
+void mjo_transmission(const mjb_model_desc *m, mjo_data *d);     /* mj_transmission (joint) */
+void mjo_com_vel(const mjb_model_desc *m, mjo_data *d);          /* A8 mj_comVel          */
+void mjo_passive(const mjb_model_desc *m, mjo_data *d);          /* A8 mj_passive         */
+void mjo_rne(const mjb_model_desc *m, mjo_data *d);              /* A9 mj_rne(flg_acc=0)  */
+void mjo_fwd_actuation(const mjb_model_desc *m, mjo_data *d);    /* A12 mj_fwdActuation   */
+void mjo_fwd_acceleration(const mjb_model_desc *m, mjo_data *d); /* A12 mj_fwdAcceleration*/
+void mjo_sensor(const mjb_model_desc *m, mjo_data *d, int stage); /* A15 mj_sensorPos/Vel/Acc */
+void mjo_euler(const mjb_model_desc *m, mjo_data *d);            /* A16 mj_Euler          */
+
+/* constraint path (mjo_constraint.c) */
+void mjo_collision(const mjb_model_desc *m, mjo_data *d);         /* A4+A5 mj_collision      */
+void mjo_make_constraint(const mjb_model_desc *m, mjo_data *d);   /* A6 mj_makeConstraint    */
+void mjo_project_constraint(const mjb_model_desc *m, mjo_data *d);/* A7 mj_projectConstraint */
+void mjo_reference_constraint(const mjb_model_desc *m, mjo_data *d); /* A8 mj_referenceConstraint */
+void mjo_fwd_constraint(const mjb_model_desc *m, mjo_data *d);    /* A13 mj_fwdConstraint (PGS) */
+
+/* composite entry points */
+void mjo_fwd_position(const mjb_model_desc *m, mjo_data *d);
+void mjo_fwd_velocity(const mjb_model_desc *m, mjo_data *d);
+void mjo_forward(const mjb_model_desc *m, mjo_data *d); /* mj_forward */
+void mjo_step(const mjb_model_desc *m, mjo_data *d);    /* mj_step    */
+/* split halves used to emulate the control-callback point: step1 = up to (excl.) mjcb_control */
+void mjo_step1(const mjb_model_desc *m, mjo_data *d);
+void mjo_step2(const mjb_model_desc *m, mjo_data *d);
+
+/* The reference's ctrl-noise injector (mujoco_env.cpp:469-481) with the engine's counter-based
+ * normal generator: Philox-4x32-10 keyed by seed, counter (env, step, actuator) + Box-Muller. */
+void mjo_philox4x32(uint32_t ctr[4], const uint32_t key[2]);
+double mjo_normal(uint64_t seed, uint64_t env, uint32_t step, uint32_t idx);
+void mjo_ctrl_noise(const mjb_model_desc *m, mjo_data *d, double noise_std, double noise_rate, uint64_t seed,
+                    uint64_t env, uint32_t step);
+
+/* Roll out `nsteps` steps for envs [0,nenv) starting from env-major host arrays qpos/qvel (updated in
+ * place), with OU ctrl noise as above (std==0: ctrl taken from `ctrl` [nenv][nu], held constant).
+ * Uses `nthreads` OS threads (one env per thread at a time).  Returns 0.  For the cpu_baseline leg
+ * of bench.py and for parity rollouts. */
+int mjo_rollout(const mjb_model_desc *m, int nenv, int nsteps, double *qpos, double *qvel, const double *ctrl,
+                double *sensordata, double noise_std, double noise_rate, uint64_t seed, int64_t env_offset,
+                int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

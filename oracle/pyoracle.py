@@ -1,0 +1,134 @@
+"""ctypes wrapper of the C oracle (oracle/libmjo.so) -- TEST INFRASTRUCTURE, "parity unpinned" (mjo.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from mujoco_ros_pkgs_amd import binding
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+
+
+def build(force=False):
+    """Compile oracle/libmjo.so (+ libmjo_fast.so) with gcc via oracle/Makefile."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", _DIR, "clean"])
+    subprocess.check_call(["make", "-s", "-C", _DIR, "all"])
+
+
+_libs = {}
+
+
+def lib(fast=False):
+    name = "libmjo_fast.so" if fast else "libmjo.so"
+    if name in _libs:
+        return _libs[name]
+    path = os.path.join(_DIR, name)
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    vp, ci, cd = C.c_void_p, C.c_int, C.c_double
+    pd = C.POINTER(binding.ModelDesc)
+    L.mjo_make_data.restype = vp
+    L.mjo_make_data.argtypes = [pd]
+    L.mjo_free_data.argtypes = [vp]
+    L.mjo_reset_data.argtypes = [pd, vp]
+    L.mjo_field.restype = C.POINTER(cd)
+    L.mjo_field.argtypes = [pd, vp, ci, C.POINTER(ci)]
+    L.mjo_field_int.restype = C.POINTER(ci)
+    L.mjo_field_int.argtypes = [pd, vp, ci, C.POINTER(ci)]
+    for fn in ("kinematics", "com_pos", "crb", "factor_m", "transmission", "com_vel", "passive", "rne",
+               "fwd_actuation", "fwd_acceleration", "euler", "collision", "make_constraint",
+               "project_constraint", "reference_constraint", "fwd_constraint", "fwd_position", "fwd_velocity",
+               "forward", "step", "step1", "step2"):
+        f = getattr(L, "mjo_" + fn)
+        f.argtypes = [pd, vp]
+        f.restype = None
+    L.mjo_sensor.argtypes = [pd, vp, ci]
+    L.mjo_solve_m.argtypes = [pd, vp, C.POINTER(cd)]
+    L.mjo_normal.restype = cd
+    L.mjo_normal.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+    L.mjo_ctrl_noise.argtypes = [pd, vp, cd, cd, C.c_uint64, C.c_uint64, C.c_uint32]
+    L.mjo_rollout.restype = ci
+    L.mjo_rollout.argtypes = [pd, ci, ci, C.POINTER(cd), C.POINTER(cd), C.POINTER(cd), C.POINTER(cd), cd, cd,
+                              C.c_uint64, C.c_int64, ci]
+    _libs[name] = L
+    return L
+
+
+class OracleData:
+    """One env's mjData-like state in the C oracle; fields are numpy views into C memory."""
+
+    def __init__(self, model, fast=False):
+        self.model = model
+        self.L = lib(fast)
+        self.desc, self._keep = binding.make_desc(model)
+        self.ptr = self.L.mjo_make_data(C.byref(self.desc))
+        if not self.ptr:
+            raise MemoryError("mjo_make_data failed")
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.L.mjo_free_data(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+    def field(self, name):
+        fid = binding.Field.ids[name]
+        n = C.c_int(0)
+        if binding.Field.kinds[name] == "DI":
+            p = self.L.mjo_field_int(C.byref(self.desc), self.ptr, fid, C.byref(n))
+        else:
+            p = self.L.mjo_field(C.byref(self.desc), self.ptr, fid, C.byref(n))
+        if not p:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, shape=(max(n.value, 0),)) if n.value > 0 else np.zeros(0)
+
+    def __getattr__(self, name):
+        if name in binding.Field.ids:
+            return self.field(name)
+        raise AttributeError(name)
+
+    def call(self, fn, *args):
+        getattr(self.L, "mjo_" + fn)(C.byref(self.desc), self.ptr, *args)
+
+    def reset(self):
+        self.call("reset_data")
+
+    def forward(self):
+        self.call("forward")
+
+    def step(self, n=1):
+        for _ in range(n):
+            self.call("step")
+
+    def ctrl_noise(self, std, rate, seed, env, step):
+        self.L.mjo_ctrl_noise(C.byref(self.desc), self.ptr, std, rate, seed, env, step)
+
+    def solve_m(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64).copy()
+        self.L.mjo_solve_m(C.byref(self.desc), self.ptr, x.ctypes.data_as(C.POINTER(C.c_double)))
+        return x
+
+
+def rollout(model, qpos, qvel, nsteps, ctrl=None, noise_std=0.0, noise_rate=0.0, seed=0, env_offset=0, nthreads=1,
+            fast=False):
+    """Batched CPU rollout (env-major arrays). Returns (qpos, qvel, sensordata) after nsteps."""
+    L = lib(fast)
+    desc, keep = binding.make_desc(model)
+    qpos = np.ascontiguousarray(qpos, dtype=np.float64).copy()
+    qvel = np.ascontiguousarray(qvel, dtype=np.float64).copy()
+    nenv = qpos.shape[0]
+    sens = np.zeros((nenv, max(1, model["nsensordata"])))
+    pd = C.POINTER(C.c_double)
+    cp = ctrl if ctrl is None else np.ascontiguousarray(ctrl, dtype=np.float64)
+    rc = L.mjo_rollout(C.byref(desc), nenv, nsteps, qpos.ctypes.data_as(pd), qvel.ctypes.data_as(pd),
+                       cp.ctypes.data_as(pd) if cp is not None else None, sens.ctypes.data_as(pd), noise_std,
+                       noise_rate, seed, env_offset, nthreads)
+    assert rc == 0
+    return qpos, qvel, sens[:, :model["nsensordata"]]
