@@ -1,0 +1,771 @@
+// mjb_api.hip — host side of the C-ABI declared in include/mjb.h (libmjb.so).
+// Owns model validation, the device model blob, HBM state arrays, launches and host<->device copies.
+// No CPU compute path exists here: every compute entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "mjb_dev.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	g_err = buf;
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+	do {                                                                                                \
+		hipError_t _e = (expr);                                                                         \
+		if (_e != hipSuccess) return fail(MJB_ENODEVICE, "%s: %s", #expr, hipGetErrorString(_e));     \
+	} while (0)
+
+struct FieldInfo {
+	const char *name;
+	const char *rows;
+	const char *cols;  // literal or size name (DD2)
+	int kind;          // 0 state, 1 derived double, 2 derived double (2 size names), 3 int
+};
+
+const FieldInfo kFields[] = {
+#define MJB_DS(name, rows, cols) { #name, #rows, #cols, 0 },
+#define MJB_DD(name, rows, cols) { #name, #rows, #cols, 1 },
+#define MJB_DD2(name, rows, cols) { #name, #rows, #cols, 2 },
+#define MJB_DI(name, rows, cols) { #name, #rows, #cols, 3 },
+#include "../../include/mjb_data_fields.def"
+#undef MJB_DS
+#undef MJB_DD
+#undef MJB_DD2
+#undef MJB_DI
+};
+
+int size_by_name(const mjb_model_desc &d, const char *n)
+{
+#define MJB_SIZE(name) if (!strcmp(n, #name)) return d.name;
+#define MJB_OPT_I(name)
+#define MJB_OPT_D(name, k)
+#define MJB_ARR_I(name, rows, cols)
+#define MJB_ARR_D(name, rows, cols)
+#include "../../include/mjb_model_fields.def"
+#undef MJB_SIZE
+#undef MJB_OPT_I
+#undef MJB_OPT_D
+#undef MJB_ARR_I
+#undef MJB_ARR_D
+	if (!strcmp(n, "one")) return 1;
+	return atoi(n);
+}
+
+}  // namespace
+
+struct mjb_model {
+	mjb_model_desc h{};               // host copy (pointers into hint / hdbl)
+	std::vector<int> hint;            // all int arrays, concatenated
+	std::vector<double> hdbl;         // all double arrays, concatenated
+	std::vector<size_t> ioff, doff;   // offsets of each array inside hint / hdbl (declaration order)
+	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart;
+	int eulerdamp = 0, maxdepth = 0;
+	int field_size[MJB_F_COUNT]{};
+	FrameLayout L{};
+};
+
+struct mjb_batch {
+	const mjb_model *model = nullptr;
+	int device = 0, nenv = 0;
+	void *blob = nullptr;  // device model blob
+	DevModel dm{};
+	DevState st{};
+	FrameLayout L{};
+	NoiseCfg nz{};
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	int lanes = 0, epb = 0;
+	unsigned int step_counter = 0;
+	bool frame_valid = false;
+	unsigned char *mask_dev = nullptr;
+	KernelParams *params_dev = nullptr;  // device copy of {dm, L, st, nz}
+	bool params_dirty = true;
+};
+
+namespace {
+
+void compute_layout(mjb_model *M, bool use_xfrc)
+{
+	const mjb_model_desc &d = M->h;
+	FrameLayout &L = M->L;
+	int off = 0, ioff = 0, nstate = 0;
+	int idx = 0;
+	auto dim = [&](const FieldInfo &fi) {
+		int r = size_by_name(d, fi.rows);
+		int c = size_by_name(d, fi.cols);
+		return r * c;
+	};
+	int *slots[] = {
+#define MJB_DS(name, rows, cols) &L.name,
+#define MJB_DD(name, rows, cols) &L.name,
+#define MJB_DD2(name, rows, cols) &L.name,
+#define MJB_DI(name, rows, cols) &L.name,
+#include "../../include/mjb_data_fields.def"
+#undef MJB_DS
+#undef MJB_DD
+#undef MJB_DD2
+#undef MJB_DI
+	};
+	(void)use_xfrc;
+	for (const FieldInfo &fi : kFields) {
+		int n = dim(fi);
+		M->field_size[idx] = n;
+		if (fi.kind == 3) {
+			*slots[idx] = ioff;
+			ioff += n;
+		} else {
+			*slots[idx] = off;
+			off += n;
+			if (fi.kind == 0) nstate = off;
+		}
+		idx++;
+	}
+	L.scratch = off;
+	off += 2 * d.nM + d.nv + d.nv + 6 * d.nv;
+	if (off & 1) off++;
+	L.ndouble = off;
+	L.nint = (ioff + 1) & ~1;
+	L.nstate = nstate;
+}
+
+template <typename T> T *dev_alloc(size_t n)
+{
+	void *p = nullptr;
+	if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+	hipMemset(p, 0, (n ? n : 1) * sizeof(T));
+	return static_cast<T *>(p);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mjb_last_error(void) { return g_err.c_str(); }
+int mjb_version(void) { return MJB_VERSION; }
+
+int mjb_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+mjb_model *mjb_compile(const mjb_model_desc *desc)
+{
+	if (!desc) {
+		fail(MJB_EINVAL, "mjb_compile: null desc");
+		return nullptr;
+	}
+	const mjb_model_desc &d = *desc;
+	if (d.nq < 0 || d.nv < 0 || d.nbody < 1 || d.njnt < 0 || d.nu < 0 || d.nM < 0) {
+		fail(MJB_EINVAL, "mjb_compile: negative size");
+		return nullptr;
+	}
+	if (d.na != 0) {
+		fail(MJB_EUNSUPPORTED, "mjb_compile: actuator activations (na > 0) are not supported");
+		return nullptr;
+	}
+	if (d.integrator != MJB_INT_EULER) {
+		fail(MJB_EUNSUPPORTED, "mjb_compile: only the Euler integrator is implemented");
+		return nullptr;
+	}
+	if (!(d.timestep[0] > 0)) {
+		fail(MJB_EINVAL, "mjb_compile: timestep must be positive");
+		return nullptr;
+	}
+	if (d.nefcmax > 0 || d.nconmax > 0) {
+		fail(MJB_EUNSUPPORTED, "mjb_compile: contact/limit constraints are not implemented in this build "
+		                       "(disable them with <flag contact=\"disable\"/> or nconmax = nefcmax = 0)");
+		return nullptr;
+	}
+	mjb_model *M = new (std::nothrow) mjb_model;
+	if (!M) {
+		fail(MJB_ENOMEM, "mjb_compile: out of memory");
+		return nullptr;
+	}
+	M->h = d;
+	// copy arrays (declaration order)
+#define MJB_SIZE(name)
+#define MJB_OPT_I(name)
+#define MJB_OPT_D(name, n)
+#define MJB_ARR_I(name, rows, cols)                                                       \
+	{                                                                                     \
+		size_t n = (size_t)d.rows * (cols);                                               \
+		if (n && !d.name) {                                                               \
+			fail(MJB_EINVAL, "mjb_compile: array %s is NULL", #name);                     \
+			delete M;                                                                     \
+			return nullptr;                                                               \
+		}                                                                                 \
+		M->ioff.push_back(M->hint.size());                                                \
+		M->hint.insert(M->hint.end(), d.name, d.name + n);                                \
+		if ((M->hint.size() & 1)) M->hint.push_back(0);                                   \
+	}
+#define MJB_ARR_D(name, rows, cols)                                                       \
+	{                                                                                     \
+		size_t n = (size_t)d.rows * (cols);                                               \
+		if (n && !d.name) {                                                               \
+			fail(MJB_EINVAL, "mjb_compile: array %s is NULL", #name);                     \
+			delete M;                                                                     \
+			return nullptr;                                                               \
+		}                                                                                 \
+		M->doff.push_back(M->hdbl.size());                                                \
+		M->hdbl.insert(M->hdbl.end(), d.name, d.name + n);                                \
+	}
+#include "../../include/mjb_model_fields.def"
+#undef MJB_ARR_I
+#undef MJB_ARR_D
+	// re-point the host copy
+	{
+		size_t ii = 0, di = 0;
+#define MJB_ARR_I(name, rows, cols) M->h.name = M->hint.data() + M->ioff[ii++];
+#define MJB_ARR_D(name, rows, cols) M->h.name = M->hdbl.data() + M->doff[di++];
+#include "../../include/mjb_model_fields.def"
+#undef MJB_SIZE
+#undef MJB_OPT_I
+#undef MJB_OPT_D
+#undef MJB_ARR_I
+#undef MJB_ARR_D
+	}
+	const mjb_model_desc &h = M->h;
+	// ---- validation of the tree tables the kernels index with
+	for (int b = 1; b < h.nbody; b++)
+		if (h.body_parentid[b] < 0 || h.body_parentid[b] >= b) {
+			fail(MJB_EINVAL, "mjb_compile: body_parentid[%d] must precede the body", b);
+			delete M;
+			return nullptr;
+		}
+	int nM = 0;
+	for (int i = 0; i < h.nv; i++) {
+		if (h.dof_parentid[i] >= i || h.dof_Madr[i] != nM) {
+			fail(MJB_EINVAL, "mjb_compile: inconsistent dof_parentid / dof_Madr at dof %d", i);
+			delete M;
+			return nullptr;
+		}
+		int depth = 0;
+		for (int j = i; j >= 0; j = h.dof_parentid[j]) {
+			M->M_rowdof.push_back(i);
+			M->M_coldof.push_back(j);
+			depth++;
+		}
+		M->dof_depth.push_back(depth);
+		if (depth > M->maxdepth) M->maxdepth = depth;
+		nM += depth;
+	}
+	if (nM != h.nM) {
+		fail(MJB_EINVAL, "mjb_compile: nM = %d does not match the dof tree (%d)", h.nM, nM);
+		delete M;
+		return nullptr;
+	}
+	for (int j = 0; j < h.njnt; j++) {
+		int t = h.jnt_type[j];
+		if (t < 0 || t > 3) {
+			fail(MJB_EINVAL, "mjb_compile: bad jnt_type[%d]", j);
+			delete M;
+			return nullptr;
+		}
+	}
+	for (int i = 0; i < h.nu; i++) {
+		int j = h.actuator_trnid[2 * i];
+		if (h.actuator_trntype[i] != MJB_TRN_JOINT || h.actuator_dyntype[i] != MJB_DYN_NONE || j < 0 || j >= h.njnt ||
+		    h.jnt_type[j] < MJB_JNT_SLIDE) {
+			fail(MJB_EUNSUPPORTED, "mjb_compile: actuator %d: only joint transmission on hinge/slide joints "
+			                       "without activation dynamics is supported", i);
+			delete M;
+			return nullptr;
+		}
+	}
+	// velocity-group start of each dof (hinge/slide: itself; ball: first of 3; free: first of each triple)
+	M->dof_jstart.resize(h.nv);
+	for (int dd = 0; dd < h.nv; dd++) {
+		int j = h.dof_jntid[dd], t = h.jnt_type[j], da = h.jnt_dofadr[j];
+		if (t == MJB_JNT_HINGE || t == MJB_JNT_SLIDE) M->dof_jstart[dd] = dd;
+		else if (t == MJB_JNT_BALL) M->dof_jstart[dd] = da;
+		else M->dof_jstart[dd] = (dd - da < 3) ? da : da + 3;
+	}
+	M->eulerdamp = 0;
+	if (!(h.disableflags & MJB_DSBL_EULERDAMP))
+		for (int i = 0; i < h.nv; i++)
+			if (h.dof_damping[i] > 0) M->eulerdamp = 1;
+	compute_layout(M, true);
+	g_err.clear();
+	return M;
+}
+
+void mjb_free_model(mjb_model *m) { delete m; }
+
+int mjb_field_size(const mjb_model *m, int field)
+{
+	if (!m || field < 0 || field >= MJB_F_COUNT) return fail(MJB_EINVAL, "mjb_field_size: bad argument");
+	return m->field_size[field];
+}
+int mjb_field_is_int(int field) { return field >= 0 && field < MJB_F_COUNT && kFields[field].kind == 3; }
+int mjb_field_is_state(int field) { return field >= 0 && field < MJB_F_COUNT && kFields[field].kind == 0; }
+const char *mjb_field_name(int field) { return field >= 0 && field < MJB_F_COUNT ? kFields[field].name : ""; }
+int mjb_frame_doubles(const mjb_model *m) { return m ? m->L.ndouble + m->L.nint / 2 : fail(MJB_EINVAL, "null model"); }
+
+void mjb_free_batch(mjb_batch *b)
+{
+	if (!b) return;
+	hipSetDevice(b->device);
+	if (b->stream) hipStreamSynchronize(b->stream);
+#define MJB_DS(name, rows, cols) if (b->st.name) hipFree(b->st.name);
+#define MJB_DD(name, rows, cols)
+#define MJB_DD2(name, rows, cols)
+#define MJB_DI(name, rows, cols)
+#include "../../include/mjb_data_fields.def"
+#undef MJB_DS
+#undef MJB_DD
+#undef MJB_DD2
+#undef MJB_DI
+	if (b->st.frame_ws) hipFree(b->st.frame_ws);
+	if (b->st.nwarn) hipFree(b->st.nwarn);
+	if (b->blob) hipFree(b->blob);
+	if (b->mask_dev) hipFree(b->mask_dev);
+	if (b->params_dev) hipFree(b->params_dev);
+	if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
+	delete b;
+}
+
+mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
+{
+	if (!M || nenv <= 0) {
+		fail(MJB_EINVAL, "mjb_make_batch: bad argument");
+		return nullptr;
+	}
+	int ndev = mjb_device_count();
+	if (ndev <= 0) {
+		fail(MJB_ENODEVICE, "mjb_make_batch: no HIP device available (this engine has no CPU fallback)");
+		return nullptr;
+	}
+	if (device < 0 || device >= ndev) {
+		fail(MJB_EINVAL, "mjb_make_batch: device %d out of range (%d devices)", device, ndev);
+		return nullptr;
+	}
+	if (hipSetDevice(device) != hipSuccess) {
+		fail(MJB_ENODEVICE, "mjb_make_batch: hipSetDevice(%d) failed", device);
+		return nullptr;
+	}
+	mjb_batch *b = new (std::nothrow) mjb_batch;
+	if (!b) {
+		fail(MJB_ENOMEM, "mjb_make_batch: out of memory");
+		return nullptr;
+	}
+	b->model = M;
+	b->device = device;
+	b->nenv = nenv;
+	b->L = M->L;
+	const mjb_model_desc &h = M->h;
+
+	// ---- device model blob: [ints | doubles | derived int tables]
+	size_t ni = M->hint.size(), nd = M->hdbl.size();
+	size_t nt = M->M_rowdof.size() + M->M_coldof.size() + M->dof_depth.size() + M->dof_jstart.size();
+	size_t bytes_i = ((ni + nt) * sizeof(int) + 15) & ~size_t(15);
+	size_t bytes = bytes_i + nd * sizeof(double) + 16;
+	if (hipMalloc(&b->blob, bytes) != hipSuccess) {
+		fail(MJB_ENOMEM, "mjb_make_batch: hipMalloc(model blob) failed");
+		mjb_free_batch(b);
+		return nullptr;
+	}
+	std::vector<unsigned char> hostblob(bytes, 0);
+	int *hi = reinterpret_cast<int *>(hostblob.data());
+	double *hd = reinterpret_cast<double *>(hostblob.data() + bytes_i);
+	if (ni) memcpy(hi, M->hint.data(), ni * sizeof(int));
+	size_t t0 = ni;
+	auto put = [&](const std::vector<int> &v) {
+		size_t at = t0;
+		if (!v.empty()) memcpy(hi + t0, v.data(), v.size() * sizeof(int));
+		t0 += v.size();
+		return at;
+	};
+	size_t o_row = put(M->M_rowdof), o_col = put(M->M_coldof), o_dep = put(M->dof_depth), o_js = put(M->dof_jstart);
+	if (nd) memcpy(hd, M->hdbl.data(), nd * sizeof(double));
+	if (hipMemcpy(b->blob, hostblob.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+		fail(MJB_ENODEVICE, "mjb_make_batch: model upload failed");
+		mjb_free_batch(b);
+		return nullptr;
+	}
+	int *di = reinterpret_cast<int *>(b->blob);
+	double *dd = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(b->blob) + bytes_i);
+	DevModel &dm = b->dm;
+	{
+		size_t ii = 0, dj = 0;
+#define MJB_SIZE(name) dm.name = h.name;
+#define MJB_OPT_I(name) dm.name = h.name;
+#define MJB_OPT_D(name, n) for (int k = 0; k < n; k++) dm.name[k] = h.name[k];
+#define MJB_ARR_I(name, rows, cols) dm.name = (mjb_ciptr)(di + M->ioff[ii++]);
+#define MJB_ARR_D(name, rows, cols) dm.name = (mjb_cdptr)(dd + M->doff[dj++]);
+#include "../../include/mjb_model_fields.def"
+#undef MJB_SIZE
+#undef MJB_OPT_I
+#undef MJB_OPT_D
+#undef MJB_ARR_I
+#undef MJB_ARR_D
+	}
+	dm.M_rowdof = (mjb_ciptr)(di + o_row);
+	dm.M_coldof = (mjb_ciptr)(di + o_col);
+	dm.dof_depth = (mjb_ciptr)(di + o_dep);
+	dm.dof_jstart = (mjb_ciptr)(di + o_js);
+	dm.eulerdamp = M->eulerdamp;
+	dm.maxdepth = M->maxdepth;
+
+	// ---- state arrays
+	DevState &s = b->st;
+	s.nenv = nenv;
+	bool ok = true;
+	int fidx = 0;
+#define MJB_DS(name, rows, cols)                                                        \
+	s.name = dev_alloc<double>((size_t)nenv * M->field_size[fidx]);                     \
+	ok = ok && s.name;                                                                  \
+	fidx++;
+#define MJB_DD(name, rows, cols) fidx++;
+#define MJB_DD2(name, rows, cols) fidx++;
+#define MJB_DI(name, rows, cols) fidx++;
+#include "../../include/mjb_data_fields.def"
+#undef MJB_DS
+#undef MJB_DD
+#undef MJB_DD2
+#undef MJB_DI
+	s.nwarn = dev_alloc<unsigned long long>(1);
+	ok = ok && s.nwarn;
+	s.frame_ws = nullptr;
+	s.frame_stride = b->L.ndouble + b->L.nint / 2;
+	s.use_xfrc = 0;
+	if (!ok) {
+		fail(MJB_ENOMEM, "mjb_make_batch: hipMalloc(state) failed for %d envs", nenv);
+		mjb_free_batch(b);
+		return nullptr;
+	}
+	if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) {
+		fail(MJB_ENODEVICE, "mjb_make_batch: hipStreamCreate failed");
+		mjb_free_batch(b);
+		return nullptr;
+	}
+	b->own_stream = true;
+	mjb_set_launch(b, 0, 0);
+	if (mjb_reset(b, nullptr) != MJB_OK || mjb_synchronize(b) != MJB_OK) {
+		mjb_free_batch(b);
+		return nullptr;
+	}
+	g_err.clear();
+	return b;
+}
+
+int mjb_nenv(const mjb_batch *b) { return b ? b->nenv : fail(MJB_EINVAL, "null batch"); }
+
+int mjb_set_launch(mjb_batch *b, int lanes_per_env, int envs_per_block)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	if (lanes_per_env == 0) lanes_per_env = 16;
+	if (lanes_per_env != 8 && lanes_per_env != 16 && lanes_per_env != 32 && lanes_per_env != 64)
+		return fail(MJB_EINVAL, "mjb_set_launch: lanes_per_env must be 8, 16, 32 or 64");
+	if (envs_per_block <= 0) envs_per_block = 64 / lanes_per_env;  // one wavefront per workgroup
+	if (envs_per_block * lanes_per_env > 256) envs_per_block = 256 / lanes_per_env;
+	b->lanes = lanes_per_env;
+	b->epb = envs_per_block;
+	return MJB_OK;
+}
+
+static int ensure_ws(mjb_batch *b)
+{
+	if (b->st.frame_ws) return MJB_OK;
+	b->st.frame_ws = dev_alloc<double>((size_t)b->nenv * b->st.frame_stride);
+	if (!b->st.frame_ws) return fail(MJB_ENOMEM, "frame workspace allocation failed");
+	b->params_dirty = true;
+	return MJB_OK;
+}
+
+// (re)upload the launch parameters when anything in them changed; ordered on the batch's stream
+static int sync_params(mjb_batch *b)
+{
+	if (!b->params_dev) {
+		HIP_TRY(hipMalloc((void **)&b->params_dev, sizeof(KernelParams)));
+		b->params_dirty = true;
+	}
+	if (b->params_dirty) {
+		KernelParams kp;
+		kp.m = b->dm;
+		kp.L = b->L;
+		kp.s = b->st;
+		kp.nz = b->nz;
+		// pageable source: the copy is staged before the call returns, so the local may go out of scope
+		HIP_TRY(hipStreamSynchronize(b->stream));
+		HIP_TRY(hipMemcpy(b->params_dev, &kp, sizeof kp, hipMemcpyHostToDevice));
+		b->params_dirty = false;
+	}
+	return MJB_OK;
+}
+
+static int launch(mjb_batch *b, int mode, int nsteps)
+{
+	HIP_TRY(hipSetDevice(b->device));
+	int prc = sync_params(b);
+	if (prc) return prc;
+	int rc = mjb_launch_step(b->params_dev, b->L, b->nenv, mode, nsteps, b->step_counter, b->lanes, b->epb, b->stream);
+	if (rc != 0) return fail(MJB_ENODEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+	return MJB_OK;
+}
+
+int mjb_step(mjb_batch *b, int nsteps)
+{
+	if (!b || nsteps < 0) return fail(MJB_EINVAL, "mjb_step: bad argument");
+	if (nsteps == 0) return MJB_OK;
+	int rc = launch(b, MJB_MODE_STEP, nsteps);
+	if (rc == MJB_OK) {
+		b->step_counter += (unsigned int)nsteps;
+		b->frame_valid = false;
+	}
+	return rc;
+}
+
+int mjb_step1(mjb_batch *b)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	int rc = ensure_ws(b);
+	if (rc) return rc;
+	rc = launch(b, MJB_MODE_STEP1, 1);
+	if (rc == MJB_OK) b->frame_valid = true;
+	return rc;
+}
+
+int mjb_step2(mjb_batch *b)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	if (!b->frame_valid || !b->st.frame_ws) return fail(MJB_EINVAL, "mjb_step2 without a preceding mjb_step1");
+	int rc = launch(b, MJB_MODE_STEP2, 1);
+	if (rc == MJB_OK) b->step_counter += 1;
+	return rc;
+}
+
+int mjb_forward(mjb_batch *b)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	int rc = ensure_ws(b);
+	if (rc) return rc;
+	rc = launch(b, MJB_MODE_FORWARD, 1);
+	if (rc == MJB_OK) b->frame_valid = true;
+	return rc;
+}
+
+int mjb_reset(mjb_batch *b, const uint8_t *mask)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	HIP_TRY(hipSetDevice(b->device));
+	const unsigned char *md = nullptr;
+	if (mask) {
+		if (!b->mask_dev) HIP_TRY(hipMalloc((void **)&b->mask_dev, (size_t)b->nenv));
+		HIP_TRY(hipMemcpyAsync(b->mask_dev, mask, (size_t)b->nenv, hipMemcpyHostToDevice, b->stream));
+		md = b->mask_dev;
+	}
+	int prc = sync_params(b);
+	if (prc) return prc;
+	int rc = mjb_launch_reset(b->params_dev, b->nenv, md, b->stream);
+	if (rc != 0) return fail(MJB_ENODEVICE, "reset launch failed: %s", hipGetErrorString((hipError_t)rc));
+	if (mask) HIP_TRY(hipStreamSynchronize(b->stream));
+	b->frame_valid = false;
+	return MJB_OK;
+}
+
+static double *state_ptr(mjb_batch *b, int field)
+{
+	switch (field) {
+#define MJB_DS(name, rows, cols) case MJB_F_##name: return b->st.name;
+#define MJB_DD(name, rows, cols)
+#define MJB_DD2(name, rows, cols)
+#define MJB_DI(name, rows, cols)
+#include "../../include/mjb_data_fields.def"
+#undef MJB_DS
+#undef MJB_DD
+#undef MJB_DD2
+#undef MJB_DI
+	default: return nullptr;
+	}
+}
+
+static int frame_offset(const mjb_batch *b, int field)
+{
+	const int *slots[] = {
+#define MJB_DS(name, rows, cols) &b->L.name,
+#define MJB_DD(name, rows, cols) &b->L.name,
+#define MJB_DD2(name, rows, cols) &b->L.name,
+#define MJB_DI(name, rows, cols) &b->L.name,
+#include "../../include/mjb_data_fields.def"
+#undef MJB_DS
+#undef MJB_DD
+#undef MJB_DD2
+#undef MJB_DI
+	};
+	return *slots[field];
+}
+
+static int check_range(mjb_batch *b, int field, int lo, int hi)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	if (field < 0 || field >= MJB_F_COUNT) return fail(MJB_EINVAL, "bad field id %d", field);
+	if (lo < 0 || hi > b->nenv || lo > hi) return fail(MJB_ERANGE, "env range [%d,%d) outside [0,%d)", lo, hi, b->nenv);
+	return MJB_OK;
+}
+
+int mjb_get(mjb_batch *b, int field, int env_lo, int env_hi, double *host)
+{
+	int rc = check_range(b, field, env_lo, env_hi);
+	if (rc) return rc;
+	if (kFields[field].kind == 3) return fail(MJB_EINVAL, "field %s is an int field; use mjb_get_int", kFields[field].name);
+	const int n = b->model->field_size[field];
+	if (n == 0 || env_lo == env_hi) return MJB_OK;
+	if (!host) return fail(MJB_EINVAL, "null host buffer");
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	if (kFields[field].kind == 0) {
+		double *p = state_ptr(b, field);
+		HIP_TRY(hipMemcpy(host, p + (size_t)env_lo * n, (size_t)(env_hi - env_lo) * n * sizeof(double),
+		                  hipMemcpyDeviceToHost));
+		return MJB_OK;
+	}
+	if (!b->frame_valid || !b->st.frame_ws)
+		return fail(MJB_EINVAL, "derived field %s is only readable after mjb_forward / mjb_step1 / mjb_step2",
+		            kFields[field].name);
+	const int off = frame_offset(b, field);
+	HIP_TRY(hipMemcpy2D(host, (size_t)n * sizeof(double), b->st.frame_ws + (size_t)env_lo * b->st.frame_stride + off,
+	                    (size_t)b->st.frame_stride * sizeof(double), (size_t)n * sizeof(double),
+	                    (size_t)(env_hi - env_lo), hipMemcpyDeviceToHost));
+	return MJB_OK;
+}
+
+int mjb_get_int(mjb_batch *b, int field, int env_lo, int env_hi, int *host)
+{
+	int rc = check_range(b, field, env_lo, env_hi);
+	if (rc) return rc;
+	if (kFields[field].kind != 3) return fail(MJB_EINVAL, "field %s is not an int field", kFields[field].name);
+	const int n = b->model->field_size[field];
+	if (n == 0 || env_lo == env_hi) return MJB_OK;
+	if (!host) return fail(MJB_EINVAL, "null host buffer");
+	if (!b->frame_valid || !b->st.frame_ws)
+		return fail(MJB_EINVAL, "int field %s is only readable after mjb_forward / mjb_step1 / mjb_step2",
+		            kFields[field].name);
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	const int off = frame_offset(b, field);
+	const int *base = reinterpret_cast<const int *>(b->st.frame_ws + (size_t)env_lo * b->st.frame_stride + b->L.ndouble) + off;
+	HIP_TRY(hipMemcpy2D(host, (size_t)n * sizeof(int), base, (size_t)b->st.frame_stride * sizeof(double),
+	                    (size_t)n * sizeof(int), (size_t)(env_hi - env_lo), hipMemcpyDeviceToHost));
+	return MJB_OK;
+}
+
+int mjb_set(mjb_batch *b, int field, int env_lo, int env_hi, const double *host)
+{
+	int rc = check_range(b, field, env_lo, env_hi);
+	if (rc) return rc;
+	const int n = b->model->field_size[field];
+	if (n == 0 || env_lo == env_hi) return MJB_OK;
+	if (!host) return fail(MJB_EINVAL, "null host buffer");
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	if (kFields[field].kind == 0) {
+		double *p = state_ptr(b, field);
+		HIP_TRY(hipMemcpy(p + (size_t)env_lo * n, host, (size_t)(env_hi - env_lo) * n * sizeof(double),
+		                  hipMemcpyHostToDevice));
+		if (field == MJB_F_xfrc_applied && !b->st.use_xfrc) {
+			b->st.use_xfrc = 1;
+			b->params_dirty = true;
+		}
+		return MJB_OK;
+	}
+	if (field != MJB_F_qfrc_passive)
+		return fail(MJB_EINVAL, "field %s is derived and cannot be set (only state fields and qfrc_passive can)",
+		            kFields[field].name);
+	if (!b->frame_valid || !b->st.frame_ws)
+		return fail(MJB_EINVAL, "qfrc_passive can only be modified between mjb_step1 and mjb_step2");
+	const int off = frame_offset(b, field);
+	HIP_TRY(hipMemcpy2D(b->st.frame_ws + (size_t)env_lo * b->st.frame_stride + off,
+	                    (size_t)b->st.frame_stride * sizeof(double), host, (size_t)n * sizeof(double),
+	                    (size_t)n * sizeof(double), (size_t)(env_hi - env_lo), hipMemcpyHostToDevice));
+	return MJB_OK;
+}
+
+void *mjb_device_ptr(mjb_batch *b, int field)
+{
+	if (!b || field < 0 || field >= MJB_F_COUNT || kFields[field].kind != 0) {
+		fail(MJB_EINVAL, "mjb_device_ptr: not a state field");
+		return nullptr;
+	}
+	return state_ptr(b, field);
+}
+
+int mjb_set_ctrl_noise(mjb_batch *b, double ctrl_noise_std, double ctrl_noise_rate, uint64_t seed, int64_t env_offset)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	if (ctrl_noise_std < 0) return fail(MJB_EINVAL, "ctrl_noise_std must be >= 0");
+	const double dt = b->model->h.timestep[0];
+	const double rate = std::exp(-dt / std::fmax(ctrl_noise_rate, 1e-15));
+	b->nz.rate = rate;
+	b->nz.scale = ctrl_noise_std * std::sqrt(1 - rate * rate);
+	b->nz.seed = seed;
+	b->nz.env_offset = env_offset;
+	b->nz.enabled = ctrl_noise_std > 0;
+	b->params_dirty = true;
+	return MJB_OK;
+}
+
+void *mjb_get_stream(mjb_batch *b) { return b ? (void *)b->stream : nullptr; }
+
+int mjb_set_stream(mjb_batch *b, void *hip_stream)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	HIP_TRY(hipSetDevice(b->device));
+	if (b->stream) HIP_TRY(hipStreamSynchronize(b->stream));
+	if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
+	b->stream = (hipStream_t)hip_stream;
+	b->own_stream = false;
+	return MJB_OK;
+}
+
+int mjb_synchronize(mjb_batch *b)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return MJB_OK;
+}
+
+int mjb_time_steps(mjb_batch *b, int nsteps, int nlaunch, double *ms_per_launch)
+{
+	if (!b || nsteps <= 0 || nlaunch <= 0 || !ms_per_launch) return fail(MJB_EINVAL, "mjb_time_steps: bad argument");
+	HIP_TRY(hipSetDevice(b->device));
+	hipEvent_t e0, e1;
+	HIP_TRY(hipEventCreate(&e0));
+	HIP_TRY(hipEventCreate(&e1));
+	HIP_TRY(hipEventRecord(e0, b->stream));
+	for (int i = 0; i < nlaunch; i++) {
+		int rc = mjb_step(b, nsteps);
+		if (rc) return rc;
+	}
+	HIP_TRY(hipEventRecord(e1, b->stream));
+	HIP_TRY(hipEventSynchronize(e1));
+	float ms = 0;
+	HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	hipEventDestroy(e0);
+	hipEventDestroy(e1);
+	*ms_per_launch = (double)ms / nlaunch;
+	return MJB_OK;
+}
+
+}  // extern "C"

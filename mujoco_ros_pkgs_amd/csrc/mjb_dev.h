@@ -1,0 +1,97 @@
+// mjb_dev.h — structures shared by the host API (mjb_api.hip) and the gfx950 kernels (mjb_step.hip).
+//
+// DevModel mirrors mjb_model_desc (include/mjb_model_fields.def) with every array living in one
+// device blob.  The pointers are declared in the AMDGPU *constant* address space (4): model data is
+// immutable and wave-uniformly indexed, so the compiler fetches it with scalar loads (s_load_*)
+// into SGPRs instead of spending vector-memory issue slots and VGPRs on it.
+#pragma once
+
+#include <stdint.h>
+
+#include "../../include/mjb.h"
+
+#define MJB_AS4 __attribute__((address_space(4)))
+typedef const int MJB_AS4 *mjb_ciptr;
+typedef const double MJB_AS4 *mjb_cdptr;
+
+struct DevModel {
+#define MJB_SIZE(name) int name;
+#define MJB_OPT_I(name) int name;
+#define MJB_OPT_D(name, n) double name[n];
+#define MJB_ARR_I(name, rows, cols) mjb_ciptr name;
+#define MJB_ARR_D(name, rows, cols) mjb_cdptr name;
+#include "../../include/mjb_model_fields.def"
+#undef MJB_SIZE
+#undef MJB_OPT_I
+#undef MJB_OPT_D
+#undef MJB_ARR_I
+#undef MJB_ARR_D
+	// engine-derived constant tables (built in mjb_compile)
+	mjb_ciptr M_rowdof;    // [nM] dof i of qM entry e
+	mjb_ciptr M_coldof;    // [nM] ancestor dof j of qM entry e
+	mjb_ciptr dof_depth;   // [nv] number of entries in row i of qM (self + ancestors)
+	mjb_ciptr dof_jstart;  // [nv] first dof of the "velocity group" the dof belongs to (see com_vel)
+	int eulerdamp;         // any dof_damping > 0 and EULERDAMP not disabled
+	int maxdepth;          // max dof_depth
+};
+
+// Offsets (in doubles / ints) of every data field inside one per-env frame.
+struct FrameLayout {
+#define MJB_DS(name, rows, cols) int name;
+#define MJB_DD(name, rows, cols) int name;
+#define MJB_DD2(name, rows, cols) int name;
+#define MJB_DI(name, rows, cols) int name;
+#include "../../include/mjb_data_fields.def"
+#undef MJB_DS
+#undef MJB_DD
+#undef MJB_DD2
+#undef MJB_DI
+	int scratch;   // Euler implicit-damping scratch: MhB[nM] qH[nM] qHDiagInv[nv] + tmp[6*nv]
+	int ndouble;   // doubles per frame
+	int nint;      // ints per frame (follow the doubles)
+	int nstate;    // doubles in the persistent prefix
+};
+
+// HBM arrays of the persistent state, env-major [nenv][dim]
+struct DevState {
+#define MJB_DS(name, rows, cols) double *name;
+#define MJB_DD(name, rows, cols)
+#define MJB_DD2(name, rows, cols)
+#define MJB_DI(name, rows, cols)
+#include "../../include/mjb_data_fields.def"
+#undef MJB_DS
+#undef MJB_DD
+#undef MJB_DD2
+#undef MJB_DI
+	double *frame_ws;              // optional [nenv][ndouble + nint/2 padded] full-frame workspace
+	unsigned long long *nwarn;     // [1] auto-reset counter (mj_checkPos/Vel/Acc warnings)
+	int nenv;
+	int frame_stride;              // doubles per env in frame_ws
+	int use_xfrc;                  // xfrc_applied has ever been written
+};
+
+struct NoiseCfg {
+	double rate;   // exp(-dt / max(ctrl_noise_rate, mjMINVAL))
+	double scale;  // ctrl_noise_std * sqrt(1 - rate^2)
+	unsigned long long seed;
+	long long env_offset;
+	int enabled;
+	int pad;
+};
+
+// Everything a launch needs, resident in device memory (uploaded when it changes); kernels get one
+// constant-address-space pointer to it.
+struct KernelParams {
+	DevModel m;
+	FrameLayout L;
+	DevState s;
+	NoiseCfg nz;
+};
+
+enum { MJB_MODE_STEP = 0, MJB_MODE_FORWARD = 1, MJB_MODE_STEP1 = 2, MJB_MODE_STEP2 = 3 };
+
+// launches (implemented in mjb_step.hip); returns hipError_t as int
+int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0,
+                    int lanes_per_env, int envs_per_block, void *stream);
+int mjb_launch_reset(const KernelParams *Pdev, int nenv, const unsigned char *mask_dev, void *stream);
+int mjb_max_lds_bytes();

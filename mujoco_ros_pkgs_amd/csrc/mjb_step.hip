@@ -1,0 +1,1115 @@
+// mjb_step.hip — gfx950 (MI355X / CDNA4) kernels of the batched step engine.
+//
+// One kernel advances every env of a batch by K full steps (the work of K x `mj_step(model,data)` per
+// env; reference call sites /root/reference mujoco_ros/src/mujoco_env.cpp:498,552,593).
+//
+// Mapping.  G lanes of ONE wavefront (G = 8/16/32/64, template) cooperate on one env; a workgroup
+// holds EPB envs.  Each env owns a frame in LDS that holds its whole mjData-like working set
+// (layout: FrameLayout, mjb_dev.h) for all K steps; HBM is touched only for the persistent state
+// (env-major arrays, one contiguous segment per env and field) at launch begin/end.  A group never
+// spans wavefronts, so lanes of a group run in lockstep and LDS ops of a wave retire in order:
+// `gsync` is a compiler-level fence + wave_barrier, never an s_barrier, and waves never wait for
+// each other.  Tree recursions run component-per-lane (no cross-lane dependency along the chain),
+// everything else item-per-lane (body / dof / joint / qM entry / sensor / actuator).
+// The model is immutable and indexed wave-uniformly wherever possible, so it is read through
+// constant-address-space pointers (scalar loads).
+//
+// Stage functions are named after the MuJoCo 2.3.7 stage whose result they produce.
+#include <hip/hip_runtime.h>
+
+#include "mjb_dev.h"
+#include "mjb_math.h"
+
+namespace {
+
+typedef const DevModel MJB_AS4 &CModel;
+typedef const FrameLayout MJB_AS4 &CLayout;
+typedef const DevState MJB_AS4 &CState;
+typedef const NoiseCfg MJB_AS4 &CNoise;
+
+#define STAGE static __device__ __noinline__
+
+template <int G> DEVI void gsync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct Env {
+	double *f;  // LDS frame (doubles)
+	int *fi;    // LDS frame (ints)
+	int lane;   // 0..G-1
+	int env;    // batch-local env index
+};
+
+// ------------------------------------------------------------------------------------------------
+// A1  kinematics: body frames, joint anchors/axes, inertial / geom / site frames
+// ------------------------------------------------------------------------------------------------
+DEVI void local2global(const double *xpos_b, const double *xquat_b, const double *xmat_b, double *opos,
+                       double *omat, const double *pos, const double *quat, int sameframe)
+{
+	if (sameframe) {
+		double p[3], M[9];
+		ld3(p, xpos_b);
+		ld9(M, xmat_b);
+		st3(opos, p);
+		st9(omat, M);
+	} else {
+		double p[3], M[9], q[4], bq[4], v[3], r[9];
+		ld3(p, xpos_b);
+		ld9(M, xmat_b);
+		ld4(bq, xquat_b);
+		matvec3(v, M, pos);
+		v[0] += p[0]; v[1] += p[1]; v[2] += p[2];
+		qmul(q, bq, quat);
+		quat2mat(r, q);
+		st3(opos, v);
+		st9(omat, r);
+	}
+}
+
+template <int G> STAGE void kinematics(CModel m, CLayout L, const Env &e)
+{
+	double *f = e.f;
+	double *qpos = f + L.qpos, *xpos = f + L.xpos, *xquat = f + L.xquat, *xmat = f + L.xmat;
+	double *xanchor = f + L.xanchor, *xaxis = f + L.xaxis;
+	const int lane = e.lane;
+
+	// normalise quaternions held in qpos (ball / free joints)
+	for (int j = lane; j < m.njnt; j += G) {
+		int t = m.jnt_type[j];
+		if (t == MJB_JNT_BALL || t == MJB_JNT_FREE) {
+			double *qq = qpos + m.jnt_qposadr[j] + (t == MJB_JNT_FREE ? 3 : 0);
+			double q[4];
+			ld4(q, qq);
+			normalize4(q);
+			st4(qq, q);
+		}
+	}
+	if (lane == 0) {
+		xpos[0] = xpos[1] = xpos[2] = 0;
+		xquat[0] = 1; xquat[1] = xquat[2] = xquat[3] = 0;
+		for (int k = 0; k < 9; k++) xmat[k] = (k % 4 == 0) ? 1.0 : 0.0;
+		double *xipos = f + L.xipos, *ximat = f + L.ximat;
+		xipos[0] = xipos[1] = xipos[2] = 0;
+		for (int k = 0; k < 9; k++) ximat[k] = (k % 4 == 0) ? 1.0 : 0.0;
+	}
+	gsync<G>();
+
+	// tree walk, replicated in every lane of the group (values in registers), lane 0 stores
+	for (int i = 1; i < m.nbody; i++) {
+		const int pid = m.body_parentid[i];
+		const int jntadr = m.body_jntadr[i], jntnum = m.body_jntnum[i];
+		double p[3], q[4];
+		if (jntnum == 1 && m.jnt_type[jntadr] == MJB_JNT_FREE) {
+			const int qa = m.jnt_qposadr[jntadr];
+			ld3(p, qpos + qa);
+			ld4(q, qpos + qa + 3);
+			normalize4(q);
+			if (lane == 0) {
+				st3(xanchor + 3 * jntadr, p);
+				double ax[3];
+				ldc3(ax, m.jnt_axis + 3 * jntadr);
+				st3(xaxis + 3 * jntadr, ax);
+			}
+		} else {
+			ldc3(p, m.body_pos + 3 * i);
+			ldc4(q, m.body_quat + 4 * i);
+			if (pid) {
+				double pm[9], pp[3], pq[4], v[3];
+				ld9(pm, xmat + 9 * pid);
+				ld3(pp, xpos + 3 * pid);
+				ld4(pq, xquat + 4 * pid);
+				matvec3(v, pm, p);
+				p[0] = v[0] + pp[0]; p[1] = v[1] + pp[1]; p[2] = v[2] + pp[2];
+				qmul(q, pq, q);
+			}
+			for (int j = jntadr; j < jntadr + jntnum; j++) {
+				const int qa = m.jnt_qposadr[j];
+				const int jt = m.jnt_type[j];
+				double jaxis[3], jpos[3], ax[3], an[3];
+				ldc3(jaxis, m.jnt_axis + 3 * j);
+				ldc3(jpos, m.jnt_pos + 3 * j);
+				rotvec_quat(ax, jaxis, q);
+				rotvec_quat(an, jpos, q);
+				an[0] += p[0]; an[1] += p[1]; an[2] += p[2];
+				if (lane == 0) {
+					st3(xaxis + 3 * j, ax);
+					st3(xanchor + 3 * j, an);
+				}
+				if (jt == MJB_JNT_SLIDE) {
+					double s = qpos[qa] - m.qpos0[qa];
+					p[0] += ax[0] * s; p[1] += ax[1] * s; p[2] += ax[2] * s;
+				} else {
+					double ql[4], v[3];
+					if (jt == MJB_JNT_BALL) {
+						ld4(ql, qpos + qa);
+						normalize4(ql);
+					} else {
+						axis_angle_quat(ql, jaxis, qpos[qa] - m.qpos0[qa]);
+					}
+					qmul(q, q, ql);
+					rotvec_quat(v, jpos, q);
+					p[0] = an[0] - v[0]; p[1] = an[1] - v[1]; p[2] = an[2] - v[2];
+				}
+			}
+		}
+		normalize4(q);
+		if (lane == 0) {
+			double M[9];
+			quat2mat(M, q);
+			st3(xpos + 3 * i, p);
+			st4(xquat + 4 * i, q);
+			st9(xmat + 9 * i, M);
+		}
+		gsync<G>();
+	}
+
+	// inertial, geom and site frames: one item per lane
+	const int nitem = (m.nbody - 1) + m.ngeom + m.nsite;
+	for (int it = lane; it < nitem; it += G) {
+		if (it < m.nbody - 1) {
+			const int b = it + 1;
+			double pos[3], quat[4];
+			ldc3(pos, m.body_ipos + 3 * b);
+			ldc4(quat, m.body_iquat + 4 * b);
+			local2global(xpos + 3 * b, xquat + 4 * b, xmat + 9 * b, f + L.xipos + 3 * b, f + L.ximat + 9 * b, pos,
+			             quat, m.body_sameframe[b]);
+		} else if (it < m.nbody - 1 + m.ngeom) {
+			const int g = it - (m.nbody - 1), b = m.geom_bodyid[g];
+			double pos[3], quat[4];
+			ldc3(pos, m.geom_pos + 3 * g);
+			ldc4(quat, m.geom_quat + 4 * g);
+			local2global(xpos + 3 * b, xquat + 4 * b, xmat + 9 * b, f + L.geom_xpos + 3 * g, f + L.geom_xmat + 9 * g,
+			             pos, quat, m.geom_sameframe[g]);
+		} else {
+			const int s = it - (m.nbody - 1) - m.ngeom, b = m.site_bodyid[s];
+			double pos[3], quat[4];
+			ldc3(pos, m.site_pos + 3 * s);
+			ldc4(quat, m.site_quat + 4 * s);
+			local2global(xpos + 3 * b, xquat + 4 * b, xmat + 9 * b, f + L.site_xpos + 3 * s, f + L.site_xmat + 9 * s,
+			             pos, quat, m.site_sameframe[s]);
+		}
+	}
+	gsync<G>();
+}
+
+// ------------------------------------------------------------------------------------------------
+// A1  comPos: subtree centres of mass, com-based body inertias (cinert) and motion dofs (cdof)
+// ------------------------------------------------------------------------------------------------
+template <int G> STAGE void com_pos(CModel m, CLayout L, const Env &e)
+{
+	double *f = e.f;
+	double *sc = f + L.subtree_com, *xipos = f + L.xipos;
+	const int lane = e.lane;
+	// component-per-lane backward accumulation (lane c only ever touches component c)
+	for (int c = lane; c < 3; c += G) {
+		for (int i = 0; i < m.nbody; i++) sc[3 * i + c] = 0;
+		for (int i = m.nbody - 1; i >= 0; i--) {
+			double own = sc[3 * i + c] + xipos[3 * i + c] * m.body_mass[i];
+			if (i) sc[3 * m.body_parentid[i] + c] += own;
+			const double stm = m.body_subtreemass[i];
+			sc[3 * i + c] = (stm < MJB_MINVAL) ? xipos[3 * i + c] : own * (1.0 / fmax(MJB_MINVAL, stm));
+		}
+	}
+	gsync<G>();
+	// cinert: one body per lane
+	for (int b = lane; b < m.nbody; b += G) {
+		double r[10];
+		if (b == 0) {
+			for (int k = 0; k < 10; k++) r[k] = 0;
+		} else {
+			double ip[3], root[3], off[3], im[9], inert[3];
+			ld3(ip, xipos + 3 * b);
+			ld3(root, sc + 3 * m.body_rootid[b]);
+			off[0] = ip[0] - root[0]; off[1] = ip[1] - root[1]; off[2] = ip[2] - root[2];
+			ld9(im, f + L.ximat + 9 * b);
+			ldc3(inert, m.body_inertia + 3 * b);
+			inert_com(r, inert, im, off, m.body_mass[b]);
+		}
+		double *o = f + L.cinert + 10 * b;
+		for (int k = 0; k < 10; k++) o[k] = r[k];
+	}
+	// cdof: one joint per lane
+	for (int j = lane; j < m.njnt; j += G) {
+		const int bi = m.jnt_bodyid[j], jt = m.jnt_type[j];
+		double *cd = f + L.cdof + 6 * m.jnt_dofadr[j];
+		double root[3], an[3], off[3];
+		ld3(root, sc + 3 * m.body_rootid[bi]);
+		ld3(an, f + L.xanchor + 3 * j);
+		off[0] = root[0] - an[0]; off[1] = root[1] - an[1]; off[2] = root[2] - an[2];
+		if (jt == MJB_JNT_FREE || jt == MJB_JNT_BALL) {
+			if (jt == MJB_JNT_FREE) {
+				for (int k = 0; k < 18; k++) cd[k] = 0;
+				cd[3] = 1; cd[10] = 1; cd[17] = 1;
+				cd += 18;
+			}
+			double M[9];
+			ld9(M, f + L.xmat + 9 * bi);
+			for (int k = 0; k < 3; k++) {
+				double ax[3] = { M[k], M[k + 3], M[k + 6] }, cr[3];
+				cross3(cr, ax, off);
+				cd[6 * k + 0] = ax[0]; cd[6 * k + 1] = ax[1]; cd[6 * k + 2] = ax[2];
+				cd[6 * k + 3] = cr[0]; cd[6 * k + 4] = cr[1]; cd[6 * k + 5] = cr[2];
+			}
+		} else {
+			double ax[3];
+			ld3(ax, f + L.xaxis + 3 * j);
+			if (jt == MJB_JNT_SLIDE) {
+				cd[0] = cd[1] = cd[2] = 0;
+				st3(cd + 3, ax);
+			} else {
+				double cr[3];
+				cross3(cr, ax, off);
+				st3(cd, ax);
+				st3(cd + 3, cr);
+			}
+		}
+	}
+	gsync<G>();
+}
+
+// ------------------------------------------------------------------------------------------------
+// A2  crb: composite inertias and the sparse joint-space inertia qM
+// ------------------------------------------------------------------------------------------------
+template <int G> STAGE void crb(CModel m, CLayout L, const Env &e)
+{
+	double *f = e.f;
+	double *crbv = f + L.crb, *cinert = f + L.cinert, *buf = f + L.scratch;
+	const int lane = e.lane;
+	for (int c = lane; c < 10; c += G) {
+		for (int i = 0; i < m.nbody; i++) crbv[10 * i + c] = cinert[10 * i + c];
+		for (int i = m.nbody - 1; i > 0; i--) {
+			const int p = m.body_parentid[i];
+			if (p > 0) crbv[10 * p + c] += crbv[10 * i + c];
+		}
+	}
+	gsync<G>();
+	// buf_i = crb[body(i)] * cdof_i, one dof per lane
+	for (int i = lane; i < m.nv; i += G) {
+		double I[10], v[6], r[6];
+		ld10(I, crbv + 10 * m.dof_bodyid[i]);
+		ld6(v, f + L.cdof + 6 * i);
+		mul_inert_vec(r, I, v);
+		st6(buf + 6 * i, r);
+	}
+	gsync<G>();
+	// qM entries, one per lane: M(i,j) = cdof_j . buf_i  (+ armature on the diagonal)
+	for (int en = lane; en < m.nM; en += G) {
+		const int i = m.M_rowdof[en], j = m.M_coldof[en];
+		double a[6], b[6];
+		ld6(a, f + L.cdof + 6 * j);
+		ld6(b, buf + 6 * i);
+		double v = (i == j) ? m.dof_armature[i] : 0.0;
+		v += dot6r(a, b);
+		f[L.qM + en] = v;
+	}
+	gsync<G>();
+}
+
+// ------------------------------------------------------------------------------------------------
+// A3  sparse L'DL factorisation in qM layout and the matching triangular solves
+// ------------------------------------------------------------------------------------------------
+template <int G> STAGE void factor(CModel m, const Env &e, const double *M, double *LD, double *diaginv)
+{
+	const int lane = e.lane;
+	for (int en = lane; en < m.nM; en += G) LD[en] = M[en];
+	gsync<G>();
+	for (int k = m.nv - 1; k >= 0; k--) {
+		const int na = m.dof_depth[k] - 1;  // ancestors of k
+		if (na <= 0) continue;
+		const int kk = m.dof_Madr[k];
+		const double dkk = LD[kk];
+		// update rows of all ancestors: pairs (a <= b)
+		for (int a = 0; a < na; a++) {
+			const int i = m.M_coldof[kk + 1 + a];
+			const int ia = m.dof_Madr[i];
+			const double tmp = LD[kk + 1 + a] / dkk;
+			for (int b = a + lane; b < na; b += G) LD[ia + (b - a)] -= tmp * LD[kk + 1 + b];
+		}
+		gsync<G>();
+		for (int a = lane; a < na; a += G) LD[kk + 1 + a] = LD[kk + 1 + a] / dkk;
+		gsync<G>();
+	}
+	for (int i = lane; i < m.nv; i += G) diaginv[i] = 1.0 / LD[m.dof_Madr[i]];
+	gsync<G>();
+}
+
+template <int G> STAGE void solve(CModel m, const Env &e, double *x, const double *LD, const double *diaginv)
+{
+	const int lane = e.lane;
+	// x <- inv(L') x
+	for (int i = m.nv - 1; i >= 0; i--) {
+		const int na = m.dof_depth[i] - 1;
+		if (na <= 0) continue;
+		const int ii = m.dof_Madr[i];
+		const double xi = x[i];
+		for (int a = lane; a < na; a += G) x[m.M_coldof[ii + 1 + a]] -= LD[ii + 1 + a] * xi;
+		gsync<G>();
+	}
+	for (int i = lane; i < m.nv; i += G) x[i] *= diaginv[i];
+	gsync<G>();
+	// x <- inv(L) x   (row i depends on its ancestors only; replicated serial sum keeps the order)
+	for (int i = 0; i < m.nv; i++) {
+		const int na = m.dof_depth[i] - 1;
+		if (na <= 0) continue;
+		const int ii = m.dof_Madr[i];
+		double acc = x[i];
+		for (int a = 0; a < na; a++) acc -= LD[ii + 1 + a] * x[m.M_coldof[ii + 1 + a]];
+		if (lane == 0) x[i] = acc;
+		gsync<G>();
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// transmission (joint) : actuator_length
+// ------------------------------------------------------------------------------------------------
+template <int G> STAGE void transmission(CModel m, CLayout L, const Env &e)
+{
+	for (int i = e.lane; i < m.nu; i += G) {
+		const int j = m.actuator_trnid[2 * i];
+		e.f[L.actuator_length + i] = e.f[L.qpos + m.jnt_qposadr[j]] * m.actuator_gear[6 * i];
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// A8  comVel: body spatial velocities (cvel) and dof time-derivatives (cdof_dot)
+// ------------------------------------------------------------------------------------------------
+// velocity of body b "before" dof d's group is applied: parent's cvel + earlier groups of the body
+DEVI void cvel_before(CModel m, CLayout L, const double *f, int b, int dstop, double *v)
+{
+	ld6(v, f + L.cvel + 6 * m.body_parentid[b]);
+	const int bda = m.body_dofadr[b];
+	int d = bda;
+	while (d < dstop) {
+		const int gs = d;
+		const int jt = m.jnt_type[m.dof_jntid[d]];
+		const int glen = (jt == MJB_JNT_HINGE || jt == MJB_JNT_SLIDE) ? 1 : 3;
+		double tmp[6] = { 0, 0, 0, 0, 0, 0 };
+		for (int k = 0; k < glen; k++) {
+			const double qv = f[L.qvel + gs + k];
+			for (int c = 0; c < 6; c++) tmp[c] += f[L.cdof + 6 * (gs + k) + c] * qv;
+		}
+		for (int c = 0; c < 6; c++) v[c] += tmp[c];
+		d += glen;
+	}
+}
+
+template <int G> STAGE void com_vel(CModel m, CLayout L, const Env &e)
+{
+	double *f = e.f;
+	double *cvel = f + L.cvel, *cdof = f + L.cdof, *qvel = f + L.qvel;
+	const int lane = e.lane;
+	// component-per-lane chain: cvel[i] = cvel[parent] + sum over velocity groups (cdof * qvel)
+	for (int c = lane; c < 6; c += G) {
+		cvel[c] = 0;
+		for (int i = 1; i < m.nbody; i++) {
+			double v = cvel[6 * m.body_parentid[i] + c];
+			const int bda = m.body_dofadr[i], nd = m.body_dofnum[i];
+			int d = bda;
+			while (d < bda + nd) {
+				const int jt = m.jnt_type[m.dof_jntid[d]];
+				const int glen = (jt == MJB_JNT_HINGE || jt == MJB_JNT_SLIDE) ? 1 : 3;
+				double tmp = 0;
+				for (int k = 0; k < glen; k++) tmp += cdof[6 * (d + k) + c] * qvel[d + k];
+				v += tmp;
+				d += glen;
+			}
+			cvel[6 * i + c] = v;
+		}
+	}
+	gsync<G>();
+	// cdof_dot: one dof per lane
+	for (int d = lane; d < m.nv; d += G) {
+		const int j = m.dof_jntid[d];
+		double r[6];
+		if (m.jnt_type[j] == MJB_JNT_FREE && d - m.jnt_dofadr[j] < 3) {
+			for (int k = 0; k < 6; k++) r[k] = 0;
+		} else {
+			double v[6], cd[6];
+			cvel_before(m, L, f, m.dof_bodyid[d], m.dof_jstart[d], v);
+			ld6(cd, cdof + 6 * d);
+			cross_motion(r, v, cd);
+		}
+		st6(f + L.cdof_dot + 6 * d, r);
+	}
+	for (int i = lane; i < m.nu; i += G) {
+		const int j = m.actuator_trnid[2 * i];
+		f[L.actuator_velocity + i] = m.actuator_gear[6 * i] * qvel[m.jnt_dofadr[j]];
+	}
+	gsync<G>();
+}
+
+// ------------------------------------------------------------------------------------------------
+// A8  passive forces: joint springs and dof dampers
+// ------------------------------------------------------------------------------------------------
+template <int G> STAGE void passive(CModel m, CLayout L, const Env &e)
+{
+	double *f = e.f;
+	double *qp = f + L.qfrc_passive;
+	const bool off = (m.disableflags & MJB_DSBL_PASSIVE) != 0;
+	for (int j = e.lane; j < m.njnt; j += G) {
+		const int jt = m.jnt_type[j];
+		int pa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+		const int nd = jt == MJB_JNT_FREE ? 6 : (jt == MJB_JNT_BALL ? 3 : 1);
+		double frc[6] = { 0, 0, 0, 0, 0, 0 };
+		const double k = m.jnt_stiffness[j];
+		if (k != 0 && !off) {
+			int o = 0;
+			if (jt == MJB_JNT_FREE) {
+				for (int c = 0; c < 3; c++) frc[c] = -k * (f[L.qpos + pa + c] - m.qpos_spring[pa + c]);
+				pa += 3;
+				o = 3;
+			}
+			if (jt == MJB_JNT_FREE || jt == MJB_JNT_BALL) {
+				double q[4], qs[4], dif[3];
+				ld4(q, f + L.qpos + pa);
+				normalize4(q);
+				ldc4(qs, m.qpos_spring + pa);
+				quat_sub(dif, q, qs);
+				for (int c = 0; c < 3; c++) frc[o + c] = -k * dif[c];
+			} else {
+				frc[0] = -k * (f[L.qpos + pa] - m.qpos_spring[pa]);
+			}
+		}
+		for (int c = 0; c < nd; c++) {
+			double v = frc[c];
+			if (!off) v -= m.dof_damping[da + c] * f[L.qvel + da + c];
+			qp[da + c] = v;
+		}
+	}
+	gsync<G>();
+}
+
+// ------------------------------------------------------------------------------------------------
+// A9  RNE with zero acceleration: qfrc_bias
+// ------------------------------------------------------------------------------------------------
+template <int G> STAGE void rne(CModel m, CLayout L, const Env &e)
+{
+	double *f = e.f;
+	double *cacc = f + L.cacc, *cfrc = f + L.cfrc_body, *cdd = f + L.cdof_dot, *qvel = f + L.qvel;
+	const int lane = e.lane;
+	const bool grav = !(m.disableflags & MJB_DSBL_GRAVITY);
+	for (int c = lane; c < 6; c += G) {
+		cacc[c] = (c >= 3 && grav) ? -m.gravity[c - 3] : 0.0;
+		for (int i = 1; i < m.nbody; i++) {
+			const int bda = m.body_dofadr[i], nd = m.body_dofnum[i];
+			double tmp = 0;
+			for (int k = 0; k < nd; k++) tmp += cdd[6 * (bda + k) + c] * qvel[bda + k];
+			cacc[6 * i + c] = cacc[6 * m.body_parentid[i] + c] + tmp;
+		}
+	}
+	gsync<G>();
+	for (int b = lane; b < m.nbody; b += G) {
+		double r[6];
+		if (b == 0) {
+			for (int k = 0; k < 6; k++) r[k] = 0;
+		} else {
+			double I[10], a[6], v[6], t[6], t1[6];
+			ld10(I, f + L.cinert + 10 * b);
+			ld6(a, cacc + 6 * b);
+			ld6(v, f + L.cvel + 6 * b);
+			mul_inert_vec(r, I, a);
+			mul_inert_vec(t, I, v);
+			cross_force(t1, v, t);
+			for (int k = 0; k < 6; k++) r[k] += t1[k];
+		}
+		st6(cfrc + 6 * b, r);
+	}
+	gsync<G>();
+	for (int c = lane; c < 6; c += G)
+		for (int i = m.nbody - 1; i > 0; i--) {
+			const int p = m.body_parentid[i];
+			if (p) cfrc[6 * p + c] += cfrc[6 * i + c];
+		}
+	gsync<G>();
+	for (int d = lane; d < m.nv; d += G) {
+		double a[6], b[6];
+		ld6(a, f + L.cdof + 6 * d);
+		ld6(b, cfrc + 6 * m.dof_bodyid[d]);
+		f[L.qfrc_bias + d] = dot6r(a, b);
+	}
+	gsync<G>();
+}
+
+// ------------------------------------------------------------------------------------------------
+// A15 sensors, one sensor per lane
+// ------------------------------------------------------------------------------------------------
+DEVI void frame_of(CModel m, CLayout L, const double *f, int objtype, int id, const double **pos,
+                   const double **mat, double *quat)
+{
+	double bq[4], lq[4];
+	switch (objtype) {
+	case MJB_OBJ_BODY:
+		*pos = f + L.xipos + 3 * id; *mat = f + L.ximat + 9 * id;
+		ld4(bq, f + L.xquat + 4 * id);
+		ldc4(lq, m.body_iquat + 4 * id);
+		qmul(quat, bq, lq);
+		break;
+	case MJB_OBJ_XBODY:
+		*pos = f + L.xpos + 3 * id; *mat = f + L.xmat + 9 * id;
+		ld4(quat, f + L.xquat + 4 * id);
+		break;
+	case MJB_OBJ_GEOM:
+		*pos = f + L.geom_xpos + 3 * id; *mat = f + L.geom_xmat + 9 * id;
+		ld4(bq, f + L.xquat + 4 * m.geom_bodyid[id]);
+		ldc4(lq, m.geom_quat + 4 * id);
+		qmul(quat, bq, lq);
+		break;
+	default:
+		*pos = f + L.site_xpos + 3 * id; *mat = f + L.site_xmat + 9 * id;
+		ld4(bq, f + L.xquat + 4 * m.site_bodyid[id]);
+		ldc4(lq, m.site_quat + 4 * id);
+		qmul(quat, bq, lq);
+	}
+}
+
+DEVI void object_velocity(CModel m, CLayout L, const double *f, int objtype, int id, double *res,
+                          bool local)
+{
+	const double *pos, *mat;
+	double q[4], v[6], np[3], op[3], dif[3], cr[3];
+	const int body = objtype == MJB_OBJ_GEOM ? m.geom_bodyid[id] : (objtype == MJB_OBJ_SITE ? m.site_bodyid[id] : id);
+	frame_of(m, L, f, objtype, id, &pos, &mat, q);
+	ld6(v, f + L.cvel + 6 * body);
+	ld3(np, pos);
+	ld3(op, f + L.subtree_com + 3 * m.body_rootid[body]);
+	dif[0] = np[0] - op[0]; dif[1] = np[1] - op[1]; dif[2] = np[2] - op[2];
+	cross3(cr, dif, v);
+	double lin[3] = { v[3] - cr[0], v[4] - cr[1], v[5] - cr[2] };
+	if (local) {
+		double M[9];
+		ld9(M, mat);
+		matTvec3(res, M, v);
+		matTvec3(res + 3, M, lin);
+	} else {
+		res[0] = v[0]; res[1] = v[1]; res[2] = v[2];
+		res[3] = lin[0]; res[4] = lin[1]; res[5] = lin[2];
+	}
+}
+
+template <int G> STAGE void sensors(CModel m, CLayout L, const Env &e, int stage)
+{
+	if (m.disableflags & MJB_DSBL_SENSOR) return;
+	double *f = e.f;
+	for (int i = e.lane; i < m.nsensor; i += G) {
+		if (m.sensor_needstage[i] != stage) continue;
+		const int type = m.sensor_type[i], id = m.sensor_objid[i], ot = m.sensor_objtype[i];
+		const int rid = m.sensor_refid[i], rt = m.sensor_reftype[i];
+		double out[4] = { 0, 0, 0, 0 };
+		bool real = true;
+		switch (type) {
+		case MJB_SENS_JOINTPOS: out[0] = f[L.qpos + m.jnt_qposadr[id]]; break;
+		case MJB_SENS_ACTUATORPOS: out[0] = f[L.actuator_length + id]; break;
+		case MJB_SENS_BALLQUAT:
+			ld4(out, f + L.qpos + m.jnt_qposadr[id]);
+			normalize4(out);
+			real = false;
+			break;
+		case MJB_SENS_FRAMEPOS: case MJB_SENS_FRAMEQUAT: case MJB_SENS_FRAMEXAXIS: case MJB_SENS_FRAMEYAXIS:
+		case MJB_SENS_FRAMEZAXIS: {
+			const double *pos, *mat, *rpos = nullptr, *rmat = nullptr;
+			double q[4], rq[4], RM[9];
+			frame_of(m, L, f, ot, id, &pos, &mat, q);
+			if (rid >= 0) {
+				frame_of(m, L, f, rt, rid, &rpos, &rmat, rq);
+				ld9(RM, rmat);
+			}
+			if (type == MJB_SENS_FRAMEPOS) {
+				double p[3];
+				ld3(p, pos);
+				if (rid < 0) {
+					out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
+				} else {
+					double rp[3];
+					ld3(rp, rpos);
+					double dif[3] = { p[0] - rp[0], p[1] - rp[1], p[2] - rp[2] };
+					matTvec3(out, RM, dif);
+				}
+			} else if (type == MJB_SENS_FRAMEQUAT) {
+				if (rid < 0) {
+					out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3];
+				} else {
+					double neg[4] = { rq[0], -rq[1], -rq[2], -rq[3] };
+					qmul(out, neg, q);
+				}
+				real = false;
+			} else {
+				const int c = type - MJB_SENS_FRAMEXAXIS;
+				double ax[3] = { mat[c], mat[3 + c], mat[6 + c] };
+				if (rid < 0) {
+					out[0] = ax[0]; out[1] = ax[1]; out[2] = ax[2];
+				} else {
+					matTvec3(out, RM, ax);
+				}
+				real = false;
+			}
+			break;
+		}
+		case MJB_SENS_SUBTREECOM: ld3(out, f + L.subtree_com + 3 * id); break;
+		case MJB_SENS_CLOCK: out[0] = f[L.time]; break;
+		case MJB_SENS_JOINTVEL: out[0] = f[L.qvel + m.jnt_dofadr[id]]; break;
+		case MJB_SENS_ACTUATORVEL: out[0] = f[L.actuator_velocity + id]; break;
+		case MJB_SENS_BALLANGVEL: ld3(out, f + L.qvel + m.jnt_dofadr[id]); break;
+		case MJB_SENS_VELOCIMETER: case MJB_SENS_GYRO: {
+			double xv[6];
+			object_velocity(m, L, f, MJB_OBJ_SITE, id, xv, true);
+			const int o = type == MJB_SENS_GYRO ? 0 : 3;
+			out[0] = xv[o]; out[1] = xv[o + 1]; out[2] = xv[o + 2];
+			break;
+		}
+		case MJB_SENS_FRAMELINVEL: case MJB_SENS_FRAMEANGVEL: {
+			double xv[6];
+			const int o = type == MJB_SENS_FRAMELINVEL ? 3 : 0;
+			object_velocity(m, L, f, ot, id, xv, false);
+			if (rid >= 0) {
+				const double *pos, *mat, *rpos, *rmat;
+				double q[4], rq[4], rv[6], RM[9];
+				frame_of(m, L, f, ot, id, &pos, &mat, q);
+				frame_of(m, L, f, rt, rid, &rpos, &rmat, rq);
+				object_velocity(m, L, f, rt, rid, rv, false);
+				for (int k = 0; k < 6; k++) xv[k] -= rv[k];
+				if (type == MJB_SENS_FRAMELINVEL) {
+					double rel[3] = { pos[0] - rpos[0], pos[1] - rpos[1], pos[2] - rpos[2] }, cr[3];
+					cross3(cr, rel, rv);
+					xv[3] += cr[0]; xv[4] += cr[1]; xv[5] += cr[2];
+				}
+				ld9(RM, rmat);
+				matTvec3(out, RM, xv + o);
+			} else {
+				out[0] = xv[o]; out[1] = xv[o + 1]; out[2] = xv[o + 2];
+			}
+			break;
+		}
+		case MJB_SENS_ACTUATORFRC: out[0] = f[L.actuator_force + id]; break;
+		default: break;
+		}
+		const double cutoff = m.sensor_cutoff[i];
+		const int dim = m.sensor_dim[i];
+		double *dst = f + L.sensordata + m.sensor_adr[i];
+		for (int k = 0; k < 4; k++) {
+			if (k >= dim) break;
+			double v = out[k];
+			if (cutoff > 0 && real) {
+				if (type == MJB_SENS_TOUCH) v = v > cutoff ? cutoff : v;
+				else v = v < -cutoff ? -cutoff : (v > cutoff ? cutoff : v);
+			}
+			dst[k] = v;
+		}
+	}
+	gsync<G>();
+}
+
+// ------------------------------------------------------------------------------------------------
+// A12 actuation and smooth acceleration
+// ------------------------------------------------------------------------------------------------
+template <int G> STAGE void fwd_actuation(CModel m, CLayout L, const Env &e)
+{
+	double *f = e.f;
+	const bool off = m.nu == 0 || (m.disableflags & MJB_DSBL_ACTUATION);
+	for (int i = e.lane; i < m.nu; i += G) {
+		double force = 0;
+		if (!off) {
+			double ctrl = f[L.ctrl + i];
+			if (m.actuator_ctrllimited[i] && !(m.disableflags & MJB_DSBL_CLAMPCTRL)) {
+				const double lo = m.actuator_ctrlrange[2 * i], hi = m.actuator_ctrlrange[2 * i + 1];
+				ctrl = ctrl < lo ? lo : (ctrl > hi ? hi : ctrl);
+			}
+			const double len = f[L.actuator_length + i], vel = f[L.actuator_velocity + i];
+			double gain = m.actuator_gainprm[3 * i], bias = 0;
+			if (m.actuator_gaintype[i] == MJB_GAIN_AFFINE)
+				gain = m.actuator_gainprm[3 * i] + m.actuator_gainprm[3 * i + 1] * len + m.actuator_gainprm[3 * i + 2] * vel;
+			if (m.actuator_biastype[i] == MJB_BIAS_AFFINE)
+				bias = m.actuator_biasprm[3 * i] + m.actuator_biasprm[3 * i + 1] * len + m.actuator_biasprm[3 * i + 2] * vel;
+			force = gain * ctrl + bias;
+			if (m.actuator_forcelimited[i]) {
+				const double lo = m.actuator_forcerange[2 * i], hi = m.actuator_forcerange[2 * i + 1];
+				force = force < lo ? lo : (force > hi ? hi : force);
+			}
+		}
+		f[L.actuator_force + i] = force;
+	}
+	gsync<G>();
+	for (int d = e.lane; d < m.nv; d += G) {
+		double acc = 0;
+		if (!off)
+			for (int i = 0; i < m.nu; i++)
+				if (m.jnt_dofadr[m.actuator_trnid[2 * i]] == d) acc += m.actuator_gear[6 * i] * f[L.actuator_force + i];
+		f[L.qfrc_actuator + d] = acc;
+	}
+	gsync<G>();
+}
+
+template <int G> STAGE void fwd_acceleration(CModel m, CLayout L, const Env &e, bool use_xfrc)
+{
+	double *f = e.f;
+	for (int d = e.lane; d < m.nv; d += G) {
+		double v = f[L.qfrc_passive + d] - f[L.qfrc_bias + d];
+		v += f[L.qfrc_applied + d];
+		v += f[L.qfrc_actuator + d];
+		if (use_xfrc) {
+			// Cartesian wrenches at body coms, projected with the cdof Jacobian, in body order
+			const int bd = m.dof_bodyid[d];
+			double cd[6];
+			ld6(cd, f + L.cdof + 6 * d);
+			for (int b = 1; b < m.nbody; b++) {
+				const double *x = f + L.xfrc_applied + 6 * b;
+				if (x[0] == 0 && x[1] == 0 && x[2] == 0 && x[3] == 0 && x[4] == 0 && x[5] == 0) continue;
+				// is dof d on the path from b to the root?  (bd must be an ancestor-or-self of b)
+				int a = b;
+				while (a > bd) a = m.body_parentid[a];
+				if (a != bd) continue;
+				double ip[3], rc[3];
+				ld3(ip, f + L.xipos + 3 * b);
+				ld3(rc, f + L.subtree_com + 3 * m.body_rootid[b]);
+				double off[3] = { ip[0] - rc[0], ip[1] - rc[1], ip[2] - rc[2] }, jp[3];
+				cross3(jp, cd, off);
+				jp[0] += cd[3]; jp[1] += cd[4]; jp[2] += cd[5];
+				v += dot3(jp, x) + dot3(cd, x + 3);
+			}
+		}
+		f[L.qfrc_smooth + d] = v;
+		f[L.qacc_smooth + d] = v;
+	}
+	gsync<G>();
+	solve<G>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv);
+}
+
+// A13 constraint solve (no active constraint rows: the unconstrained acceleration is the answer)
+template <int G> STAGE void fwd_constraint(CModel m, CLayout L, const Env &e)
+{
+	double *f = e.f;
+	for (int d = e.lane; d < m.nv; d += G) {
+		const double a = f[L.qacc_smooth + d];
+		f[L.qacc + d] = a;
+		f[L.qacc_warmstart + d] = a;
+		f[L.qfrc_constraint + d] = 0;
+	}
+	if (e.lane == 0) {
+		e.fi[L.ncon] = 0;
+		e.fi[L.nefc] = 0;
+		e.fi[L.solver_iter] = 0;
+	}
+	gsync<G>();
+}
+
+// ------------------------------------------------------------------------------------------------
+// A16 semi-implicit Euler with implicit joint damping
+// ------------------------------------------------------------------------------------------------
+template <int G> STAGE void euler(CModel m, CLayout L, const Env &e)
+{
+	double *f = e.f;
+	const double dt = m.timestep[0];
+	double *MhB = f + L.scratch, *qH = MhB + m.nM, *qHdi = qH + m.nM, *x = qHdi + m.nv;
+	if (m.eulerdamp) {
+		for (int en = e.lane; en < m.nM; en += G) {
+			const int i = m.M_rowdof[en];
+			double v = f[L.qM + en];
+			if (m.M_coldof[en] == i) v += dt * m.dof_damping[i];
+			MhB[en] = v;
+		}
+		for (int d = e.lane; d < m.nv; d += G) x[d] = f[L.qfrc_smooth + d] + f[L.qfrc_constraint + d];
+		gsync<G>();
+		factor<G>(m, e, MhB, qH, qHdi);
+		solve<G>(m, e, x, qH, qHdi);
+	} else {
+		for (int d = e.lane; d < m.nv; d += G) x[d] = f[L.qacc + d];
+		gsync<G>();
+	}
+	for (int d = e.lane; d < m.nv; d += G) f[L.qvel + d] += dt * x[d];
+	gsync<G>();
+	for (int j = e.lane; j < m.njnt; j += G) {
+		const int jt = m.jnt_type[j];
+		int pa = m.jnt_qposadr[j], va = m.jnt_dofadr[j];
+		if (jt == MJB_JNT_HINGE || jt == MJB_JNT_SLIDE) {
+			f[L.qpos + pa] += dt * f[L.qvel + va];
+		} else {
+			if (jt == MJB_JNT_FREE) {
+				for (int k = 0; k < 3; k++) f[L.qpos + pa + k] += dt * f[L.qvel + va + k];
+				pa += 3;
+				va += 3;
+			}
+			double q[4], w[3];
+			ld4(q, f + L.qpos + pa);
+			ld3(w, f + L.qvel + va);
+			quat_integrate(q, w, dt);
+			st4(f + L.qpos + pa, q);
+		}
+	}
+	if (e.lane == 0) f[L.time] += dt;
+	gsync<G>();
+}
+
+// ------------------------------------------------------------------------------------------------
+// state <-> HBM, frame <-> HBM workspace
+// ------------------------------------------------------------------------------------------------
+template <int G> DEVI void copy_in(double *dst, const double *src, int n, int lane)
+{
+	for (int k = lane; k < n; k += G) dst[k] = src[k];
+}
+template <int G> DEVI void copy_out(double *dst, const double *src, int n, int lane)
+{
+	for (int k = lane; k < n; k += G) dst[k] = src[k];
+}
+
+template <int G> STAGE void load_state(CModel m, CLayout L, CState s, const Env &e)
+{
+	const size_t env = (size_t)e.env;
+	copy_in<G>(e.f + L.qpos, s.qpos + env * m.nq, m.nq, e.lane);
+	copy_in<G>(e.f + L.qvel, s.qvel + env * m.nv, m.nv, e.lane);
+	copy_in<G>(e.f + L.act, s.act + env * m.na, m.na, e.lane);
+	copy_in<G>(e.f + L.ctrl, s.ctrl + env * m.nu, m.nu, e.lane);
+	copy_in<G>(e.f + L.qacc_warmstart, s.qacc_warmstart + env * m.nv, m.nv, e.lane);
+	copy_in<G>(e.f + L.qfrc_applied, s.qfrc_applied + env * m.nv, m.nv, e.lane);
+	if (s.use_xfrc) copy_in<G>(e.f + L.xfrc_applied, s.xfrc_applied + env * 6 * m.nbody, 6 * m.nbody, e.lane);
+	copy_in<G>(e.f + L.ctrlnoise, s.ctrlnoise + env * m.nu, m.nu, e.lane);
+	if (e.lane == 0) e.f[L.time] = s.time[env];
+}
+
+template <int G> STAGE void store_state(CModel m, CLayout L, CState s, const Env &e)
+{
+	const size_t env = (size_t)e.env;
+	copy_out<G>(s.qpos + env * m.nq, e.f + L.qpos, m.nq, e.lane);
+	copy_out<G>(s.qvel + env * m.nv, e.f + L.qvel, m.nv, e.lane);
+	copy_out<G>(s.act + env * m.na, e.f + L.act, m.na, e.lane);
+	copy_out<G>(s.ctrl + env * m.nu, e.f + L.ctrl, m.nu, e.lane);
+	copy_out<G>(s.qacc_warmstart + env * m.nv, e.f + L.qacc_warmstart, m.nv, e.lane);
+	copy_out<G>(s.qacc + env * m.nv, e.f + L.qacc, m.nv, e.lane);
+	copy_out<G>(s.sensordata + env * m.nsensordata, e.f + L.sensordata, m.nsensordata, e.lane);
+	copy_out<G>(s.ctrlnoise + env * m.nu, e.f + L.ctrlnoise, m.nu, e.lane);
+	if (e.lane == 0) s.time[env] = e.f[L.time];
+}
+
+// mj_checkPos / mj_checkVel / mj_checkAcc: NaN or |x| > mjMAXVAL -> flag in the int frame
+template <int G> DEVI bool any_bad(const Env &e, CLayout L, const double *a, int na, const double *b, int nb)
+{
+	int *flag = e.fi + L.solver_iter;  // reused as a transient flag; rewritten by fwd_constraint
+	if (e.lane == 0) *flag = 0;
+	gsync<G>();
+	bool bad = false;
+	for (int k = e.lane; k < na; k += G) bad |= !(a[k] == a[k]) || fabs(a[k]) > MJB_MAXVAL;
+	for (int k = e.lane; k < nb; k += G) bad |= !(b[k] == b[k]) || fabs(b[k]) > MJB_MAXVAL;
+	if (bad) *flag = 1;
+	gsync<G>();
+	return *flag != 0;
+}
+
+template <int G> STAGE void reset_frame_state(CModel m, CLayout L, CState s, const Env &e)
+{
+	double *f = e.f;
+	for (int k = e.lane; k < L.nstate; k += G) f[k] = 0;  // state prefix starts at offset 0
+	gsync<G>();
+	for (int k = e.lane; k < m.nq; k += G) f[L.qpos + k] = m.qpos0[k];
+	if (e.lane == 0) atomicAdd(s.nwarn, 1ull);
+	gsync<G>();
+}
+
+// ------------------------------------------------------------------------------------------------
+// pipeline pieces
+// ------------------------------------------------------------------------------------------------
+template <int G> DEVI void fwd_position(CModel m, CLayout L, const Env &e)
+{
+	kinematics<G>(m, L, e);
+	com_pos<G>(m, L, e);
+	crb<G>(m, L, e);
+	factor<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv);
+	transmission<G>(m, L, e);
+}
+
+template <int G> DEVI void fwd_velocity(CModel m, CLayout L, const Env &e)
+{
+	com_vel<G>(m, L, e);
+	passive<G>(m, L, e);
+	rne<G>(m, L, e);
+}
+
+template <int G> DEVI void forward_first(CModel m, CLayout L, const Env &e)
+{
+	fwd_position<G>(m, L, e);
+	sensors<G>(m, L, e, MJB_STAGE_POS);
+	fwd_velocity<G>(m, L, e);
+	sensors<G>(m, L, e, MJB_STAGE_VEL);
+}
+
+template <int G> DEVI void forward_rest(CModel m, CLayout L, CState s, const Env &e)
+{
+	fwd_actuation<G>(m, L, e);
+	fwd_acceleration<G>(m, L, e, s.use_xfrc != 0);
+	fwd_constraint<G>(m, L, e);
+	sensors<G>(m, L, e, MJB_STAGE_ACC);
+}
+
+template <int G> STAGE void ctrl_noise(CModel m, CLayout L, CNoise nz, const Env &e,
+                                      unsigned int step)
+{
+	for (int i = e.lane; i < m.nu; i += G) {
+		const double z = philox_normal(nz.seed, (unsigned long long)(nz.env_offset + e.env), step, (unsigned int)i);
+		const double v = nz.rate * e.f[L.ctrlnoise + i] + nz.scale * z;
+		e.f[L.ctrlnoise + i] = v;
+		e.f[L.ctrl + i] = v;
+	}
+	gsync<G>();
+}
+
+// ------------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------------
+template <int G>
+__global__ void __launch_bounds__(256, (G == 64 ? 4 : (G == 32 ? 2 : 1)))
+    mjb_step_kernel(const KernelParams MJB_AS4 *__restrict__ P, const int mode, const int nsteps,
+                    const unsigned int step0, const int epb, const int frame_bytes)
+{
+	// launch parameters live in device memory behind a constant-address-space pointer: every field is
+	// fetched with a scalar load where it is used instead of pinning ~300 SGPRs for the whole kernel
+	const DevModel MJB_AS4 &m = P->m;
+	const FrameLayout MJB_AS4 &L = P->L;
+	const DevState MJB_AS4 &s = P->s;
+	const NoiseCfg MJB_AS4 &nz = P->nz;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int slot = threadIdx.x / G;
+	Env e;
+	e.lane = threadIdx.x % G;
+	e.f = reinterpret_cast<double *>(smem + (size_t)slot * frame_bytes);
+	e.fi = reinterpret_cast<int *>(e.f + L.ndouble);
+
+	// grid-stride over env groups so any batch size runs with a bounded grid
+	for (int base = blockIdx.x * epb; base < s.nenv; base += gridDim.x * epb) {
+		e.env = base + slot;
+		if (e.env >= s.nenv) continue;  // whole group idles together (group == slot)
+		double *ws = s.frame_ws ? s.frame_ws + (size_t)e.env * s.frame_stride : nullptr;
+
+		if (mode == MJB_MODE_STEP2) {
+			// resume: full frame from the workspace, then the (possibly host-modified) state on top
+			for (int k = e.lane; k < L.ndouble; k += G) e.f[k] = ws[k];
+			int *wsi = reinterpret_cast<int *>(ws + L.ndouble);
+			for (int k = e.lane; k < L.nint; k += G) e.fi[k] = wsi[k];
+			gsync<G>();
+		} else {
+			// derived part of the frame starts undefined; zero it once so dumps are deterministic
+			if (mode != MJB_MODE_STEP)
+				for (int k = e.lane; k < L.ndouble; k += G) e.f[k] = 0;
+			for (int k = e.lane; k < L.nint; k += G) e.fi[k] = 0;
+			gsync<G>();
+		}
+		load_state<G>(m, L, s, e);
+		gsync<G>();
+
+		if (mode == MJB_MODE_STEP) {
+			for (int st = 0; st < nsteps; st++) {
+				if (nz.enabled) ctrl_noise<G>(m, L, nz, e, step0 + (unsigned int)st);
+				if (any_bad<G>(e, L, e.f + L.qpos, m.nq, e.f + L.qvel, m.nv)) reset_frame_state<G>(m, L, s, e);
+				forward_first<G>(m, L, e);
+				forward_rest<G>(m, L, s, e);
+				if (any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0)) {
+					reset_frame_state<G>(m, L, s, e);
+					forward_first<G>(m, L, e);
+					forward_rest<G>(m, L, s, e);
+				}
+				euler<G>(m, L, e);
+			}
+		} else if (mode == MJB_MODE_FORWARD) {
+			forward_first<G>(m, L, e);
+			forward_rest<G>(m, L, s, e);
+		} else if (mode == MJB_MODE_STEP1) {
+			if (nz.enabled) ctrl_noise<G>(m, L, nz, e, step0);
+			if (any_bad<G>(e, L, e.f + L.qpos, m.nq, e.f + L.qvel, m.nv)) reset_frame_state<G>(m, L, s, e);
+			forward_first<G>(m, L, e);
+		} else {  // STEP2
+			forward_rest<G>(m, L, s, e);
+			if (any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0)) {
+				reset_frame_state<G>(m, L, s, e);
+				forward_first<G>(m, L, e);
+				forward_rest<G>(m, L, s, e);
+			}
+			euler<G>(m, L, e);
+		}
+
+		store_state<G>(m, L, s, e);
+		if (ws && mode != MJB_MODE_STEP) {
+			for (int k = e.lane; k < L.ndouble; k += G) ws[k] = e.f[k];
+			int *wsi = reinterpret_cast<int *>(ws + L.ndouble);
+			for (int k = e.lane; k < L.nint; k += G) wsi[k] = e.fi[k];
+		}
+		gsync<G>();
+	}
+}
+
+__global__ void mjb_reset_kernel(const KernelParams MJB_AS4 *__restrict__ P, const unsigned char *mask)
+{
+	const DevModel MJB_AS4 &m = P->m;
+	const DevState MJB_AS4 &s = P->s;
+	const int env = blockIdx.x * blockDim.x + threadIdx.x;
+	if (env >= s.nenv) return;
+	if (mask && !mask[env]) return;
+	const size_t e = (size_t)env;
+	for (int k = 0; k < m.nq; k++) s.qpos[e * m.nq + k] = m.qpos0[k];
+	for (int k = 0; k < m.nv; k++) {
+		s.qvel[e * m.nv + k] = 0;
+		s.qacc_warmstart[e * m.nv + k] = 0;
+		s.qfrc_applied[e * m.nv + k] = 0;
+		s.qacc[e * m.nv + k] = 0;
+	}
+	for (int k = 0; k < m.na; k++) s.act[e * m.na + k] = 0;
+	for (int k = 0; k < m.nu; k++) {
+		s.ctrl[e * m.nu + k] = 0;
+		s.ctrlnoise[e * m.nu + k] = 0;
+	}
+	for (int k = 0; k < 6 * m.nbody; k++) s.xfrc_applied[e * 6 * m.nbody + k] = 0;
+	for (int k = 0; k < m.nsensordata; k++) s.sensordata[e * m.nsensordata + k] = 0;
+	s.time[e] = 0;
+}
+
+template <int G>
+int launch_g(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0,
+             int epb, void *stream)
+{
+	const int frame_bytes = ((L.ndouble * 8 + L.nint * 4) + 15) & ~15;
+	const int maxlds = mjb_max_lds_bytes();
+	int threads = epb * G;
+	if (threads > 256) {
+		epb = 256 / G;
+		threads = epb * G;
+	}
+	while (epb > 1 && epb * frame_bytes > maxlds) {
+		epb--;
+		threads = epb * G;
+	}
+	const size_t lds = (size_t)epb * frame_bytes;
+	if ((int)lds > maxlds) return (int)hipErrorInvalidValue;
+	auto kern = mjb_step_kernel<G>;
+	hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+	                                     (int)lds);
+	if (err != hipSuccess) return (int)err;
+	int blocks = (nenv + epb - 1) / epb;
+	const int maxblocks = 256 * 16;
+	if (blocks > maxblocks) blocks = maxblocks;
+	hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, (hipStream_t)stream,
+	                   (const KernelParams MJB_AS4 *)Pdev, mode, nsteps, step0, epb, frame_bytes);
+	return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int mjb_max_lds_bytes() { return 160 * 1024; }
+
+int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0,
+                    int lanes_per_env, int envs_per_block, void *stream)
+{
+	switch (lanes_per_env) {
+	case 8: return launch_g<8>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+	case 16: return launch_g<16>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+	case 32: return launch_g<32>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+	case 64: return launch_g<64>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+	default: return (int)hipErrorInvalidValue;
+	}
+}
+
+int mjb_launch_reset(const KernelParams *Pdev, int nenv, const unsigned char *mask_dev, void *stream)
+{
+	const int threads = 256;
+	const int blocks = (nenv + threads - 1) / threads;
+	hipLaunchKernelGGL(mjb_reset_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream,
+	                   (const KernelParams MJB_AS4 *)Pdev, mask_dev);
+	return (int)hipGetLastError();
+}

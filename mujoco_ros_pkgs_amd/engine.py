@@ -1,0 +1,150 @@
+"""Python face of the C-ABI engine (libmjb.so): thin, typed wrappers -- no compute happens here.
+
+``CompiledModel`` <-> ``mjb_model``  (takes the place of the reference's ``mjModelPtr model_``,
+/root/reference mujoco_ros/include/mujoco_ros/mujoco_env.h:298), ``Batch`` <-> ``mjb_batch`` (N x
+``mjDataPtr data_``, mujoco_env.h:300).  Every method maps 1:1 onto an entry point of include/mjb.h and
+raises ``EngineError`` with ``mjb_last_error()`` on a non-zero return.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import binding
+from .binding import Field
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _lib():
+    return binding.load_library()
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise EngineError(f"{what} failed ({rc}): {_lib().mjb_last_error().decode()}")
+
+
+def device_count():
+    return _lib().mjb_device_count()
+
+
+class CompiledModel:
+    def __init__(self, model):
+        self.model = model
+        self.lib = _lib()
+        desc, self._keep = binding.make_desc(model)
+        self.ptr = self.lib.mjb_compile(C.byref(desc))
+        if not self.ptr:
+            raise EngineError("mjb_compile failed: " + self.lib.mjb_last_error().decode())
+
+    def field_size(self, name):
+        return self.lib.mjb_field_size(self.ptr, Field.ids[name])
+
+    @property
+    def frame_doubles(self):
+        return self.lib.mjb_frame_doubles(self.ptr)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.lib.mjb_free_model(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """N env instances of one model on one GPU."""
+
+    def __init__(self, cmodel: CompiledModel, nenv: int, device: int = 0):
+        self.cm = cmodel
+        self.lib = cmodel.lib
+        self.nenv = int(nenv)
+        self.ptr = self.lib.mjb_make_batch(cmodel.ptr, self.nenv, int(device))
+        if not self.ptr:
+            raise EngineError("mjb_make_batch failed: " + self.lib.mjb_last_error().decode())
+
+    # ---- stepping
+    def step(self, nsteps=1):
+        _check(self.lib.mjb_step(self.ptr, int(nsteps)), "mjb_step")
+
+    def step1(self):
+        _check(self.lib.mjb_step1(self.ptr), "mjb_step1")
+
+    def step2(self):
+        _check(self.lib.mjb_step2(self.ptr), "mjb_step2")
+
+    def forward(self):
+        _check(self.lib.mjb_forward(self.ptr), "mjb_forward")
+
+    def reset(self, mask=None):
+        if mask is None:
+            _check(self.lib.mjb_reset(self.ptr, None), "mjb_reset")
+        else:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+            if m.shape != (self.nenv,):
+                raise ValueError("mask must have shape (nenv,)")
+            _check(self.lib.mjb_reset(self.ptr, m.ctypes.data_as(C.POINTER(C.c_uint8))), "mjb_reset")
+
+    def synchronize(self):
+        _check(self.lib.mjb_synchronize(self.ptr), "mjb_synchronize")
+
+    def set_launch(self, lanes_per_env=0, envs_per_block=0):
+        _check(self.lib.mjb_set_launch(self.ptr, lanes_per_env, envs_per_block), "mjb_set_launch")
+
+    def set_ctrl_noise(self, std, rate, seed=0, env_offset=0):
+        _check(self.lib.mjb_set_ctrl_noise(self.ptr, float(std), float(rate), int(seed), int(env_offset)),
+               "mjb_set_ctrl_noise")
+
+    def time_steps(self, nsteps, nlaunch):
+        ms = C.c_double(0)
+        _check(self.lib.mjb_time_steps(self.ptr, int(nsteps), int(nlaunch), C.byref(ms)), "mjb_time_steps")
+        return ms.value
+
+    # ---- data access (env-major numpy arrays)
+    def get(self, name, lo=0, hi=None):
+        hi = self.nenv if hi is None else hi
+        fid = Field.ids[name]
+        n = self.cm.field_size(name)
+        if Field.kinds[name] == "DI":
+            out = np.zeros((hi - lo, n), dtype=np.int32)
+            _check(self.lib.mjb_get_int(self.ptr, fid, lo, hi, out.ctypes.data_as(C.POINTER(C.c_int))), "mjb_get_int")
+        else:
+            out = np.zeros((hi - lo, n), dtype=np.float64)
+            _check(self.lib.mjb_get(self.ptr, fid, lo, hi, out.ctypes.data_as(C.POINTER(C.c_double))), "mjb_get")
+        return out
+
+    def set(self, name, value, lo=0, hi=None):
+        hi = self.nenv if hi is None else hi
+        n = self.cm.field_size(name)
+        v = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=np.float64).reshape(-1, n) if np.ndim(value) > 1
+                                                 else np.asarray(value, dtype=np.float64), (hi - lo, n)))
+        _check(self.lib.mjb_set(self.ptr, Field.ids[name], lo, hi, v.ctypes.data_as(C.POINTER(C.c_double))), "mjb_set")
+
+    def device_ptr(self, name):
+        p = self.lib.mjb_device_ptr(self.ptr, Field.ids[name])
+        if not p:
+            raise EngineError(self.lib.mjb_last_error().decode())
+        return p
+
+    @property
+    def stream(self):
+        return self.lib.mjb_get_stream(self.ptr)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.lib.mjb_free_batch(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
