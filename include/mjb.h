@@ -178,6 +178,14 @@ void *mjb_get_stream(mjb_batch *b);
 int mjb_set_stream(mjb_batch *b, void *hip_stream);
 int mjb_synchronize(mjb_batch *b);
 
+/* Number of env auto-resets so far (MuJoCo's mj_checkPos / mj_checkVel / mj_checkAcc warnings: a state
+ * that went NaN or beyond mjMAXVAL is reset to qpos0 exactly as mj_step does). */
+int mjb_warning_count(mjb_batch *b, unsigned long long *count);
+
+/* Profiling builds only (libmjb_prof.so): per-stage shader-cycle sums [0..31] and call counts [32..63] of
+ * env 0; all zero in the production build. */
+int mjb_debug_profile(mjb_batch *b, unsigned long long *out64, int clear);
+
 /* Timing helper for bench.py: run `nlaunch` launches of mjb_step(b, nsteps) bracketed by HIP
  * events recorded on the batch's stream; returns the mean per-launch duration in milliseconds
  * through *ms_per_launch. */

@@ -144,6 +144,8 @@ def load_library(path=None):
         "mjb_set_stream": (ci, [vp, vp]),
         "mjb_synchronize": (ci, [vp]),
         "mjb_time_steps": (ci, [vp, ci, ci, C.POINTER(cd)]),
+        "mjb_warning_count": (ci, [vp, C.POINTER(C.c_uint64)]),
+        "mjb_debug_profile": (ci, [vp, C.POINTER(C.c_uint64), ci]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

@@ -338,6 +338,7 @@ void mjb_free_batch(mjb_batch *b)
 #undef MJB_DI
 	if (b->st.frame_ws) hipFree(b->st.frame_ws);
 	if (b->st.nwarn) hipFree(b->st.nwarn);
+	if (b->st.prof) hipFree(b->st.prof);
 	if (b->blob) hipFree(b->blob);
 	if (b->mask_dev) hipFree(b->mask_dev);
 	if (b->params_dev) hipFree(b->params_dev);
@@ -446,6 +447,8 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 #undef MJB_DI
 	s.nwarn = dev_alloc<unsigned long long>(1);
 	ok = ok && s.nwarn;
+	s.prof = dev_alloc<unsigned long long>(64);
+	ok = ok && s.prof;
 	s.frame_ws = nullptr;
 	s.frame_stride = b->L.ndouble + b->L.nint / 2;
 	s.use_xfrc = 0;
@@ -743,6 +746,25 @@ int mjb_synchronize(mjb_batch *b)
 	if (!b) return fail(MJB_EINVAL, "null batch");
 	HIP_TRY(hipSetDevice(b->device));
 	HIP_TRY(hipStreamSynchronize(b->stream));
+	return MJB_OK;
+}
+
+int mjb_debug_profile(mjb_batch *b, unsigned long long *out64, int clear)
+{
+	if (!b || !out64) return fail(MJB_EINVAL, "mjb_debug_profile: bad argument");
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	HIP_TRY(hipMemcpy(out64, b->st.prof, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	if (clear) HIP_TRY(hipMemset(b->st.prof, 0, 64 * sizeof(unsigned long long)));
+	return MJB_OK;
+}
+
+int mjb_warning_count(mjb_batch *b, unsigned long long *count)
+{
+	if (!b || !count) return fail(MJB_EINVAL, "mjb_warning_count: bad argument");
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	HIP_TRY(hipMemcpy(count, b->st.nwarn, sizeof(unsigned long long), hipMemcpyDeviceToHost));
 	return MJB_OK;
 }
 

@@ -65,6 +65,7 @@ struct DevState {
 #undef MJB_DI
 	double *frame_ws;              // optional [nenv][ndouble + nint/2 padded] full-frame workspace
 	unsigned long long *nwarn;     // [1] auto-reset counter (mj_checkPos/Vel/Acc warnings)
+	unsigned long long *prof;      // [64] per-stage cycle sums + call counts (profiling build only), else NULL
 	int nenv;
 	int frame_stride;              // doubles per env in frame_ws
 	int use_xfrc;                  // xfrc_applied has ever been written

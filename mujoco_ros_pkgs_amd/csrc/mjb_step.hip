@@ -27,7 +27,11 @@ typedef const FrameLayout MJB_AS4 &CLayout;
 typedef const DevState MJB_AS4 &CState;
 typedef const NoiseCfg MJB_AS4 &CNoise;
 
+#ifdef MJB_STAGE_NOINLINE
 #define STAGE static __device__ __noinline__
+#else
+#define STAGE static __device__ __forceinline__
+#endif
 
 template <int G> DEVI void gsync()
 {
@@ -35,6 +39,21 @@ template <int G> DEVI void gsync()
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// Optional per-stage cycle accounting (build with -DMJB_PROFILE -> libmjb_prof.so): env 0 / lane 0 adds the
+// s_memtime delta of every stage to DevState::prof[stage].
+#ifdef MJB_PROFILE
+#define PROF_BEGIN() unsigned long long _t0 = __builtin_readcyclecounter()
+#define PROF(id)                                                                      \
+	do {                                                                              \
+		unsigned long long _t1 = __builtin_readcyclecounter();                        \
+		if (e.env == 0 && e.lane == 0 && s.prof) { s.prof[id] += _t1 - _t0; s.prof[32 + id] += 1; } \
+		_t0 = __builtin_readcyclecounter();                                           \
+	} while (0)
+#else
+#define PROF_BEGIN() do { } while (0)
+#define PROF(id) do { } while (0)
+#endif
 
 struct Env {
 	double *f;  // LDS frame (doubles)
@@ -908,36 +927,41 @@ template <int G> STAGE void reset_frame_state(CModel m, CLayout L, CState s, con
 // ------------------------------------------------------------------------------------------------
 // pipeline pieces
 // ------------------------------------------------------------------------------------------------
-template <int G> DEVI void fwd_position(CModel m, CLayout L, const Env &e)
+template <int G> DEVI void forward_first(CModel m, CLayout L, CState s, const Env &e)
 {
+	PROF_BEGIN();
 	kinematics<G>(m, L, e);
+	PROF(0);
 	com_pos<G>(m, L, e);
+	PROF(1);
 	crb<G>(m, L, e);
+	PROF(2);
 	factor<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv);
+	PROF(3);
 	transmission<G>(m, L, e);
-}
-
-template <int G> DEVI void fwd_velocity(CModel m, CLayout L, const Env &e)
-{
-	com_vel<G>(m, L, e);
-	passive<G>(m, L, e);
-	rne<G>(m, L, e);
-}
-
-template <int G> DEVI void forward_first(CModel m, CLayout L, const Env &e)
-{
-	fwd_position<G>(m, L, e);
 	sensors<G>(m, L, e, MJB_STAGE_POS);
-	fwd_velocity<G>(m, L, e);
+	PROF(4);
+	com_vel<G>(m, L, e);
+	PROF(5);
+	passive<G>(m, L, e);
+	PROF(6);
+	rne<G>(m, L, e);
+	PROF(7);
 	sensors<G>(m, L, e, MJB_STAGE_VEL);
+	PROF(8);
 }
 
 template <int G> DEVI void forward_rest(CModel m, CLayout L, CState s, const Env &e)
 {
+	PROF_BEGIN();
 	fwd_actuation<G>(m, L, e);
+	PROF(9);
 	fwd_acceleration<G>(m, L, e, s.use_xfrc != 0);
+	PROF(10);
 	fwd_constraint<G>(m, L, e);
+	PROF(11);
 	sensors<G>(m, L, e, MJB_STAGE_ACC);
+	PROF(12);
 }
 
 template <int G> STAGE void ctrl_noise(CModel m, CLayout L, CNoise nz, const Env &e,
@@ -995,34 +1019,33 @@ __global__ void __launch_bounds__(256, (G == 64 ? 4 : (G == 32 ? 2 : 1)))
 		load_state<G>(m, L, s, e);
 		gsync<G>();
 
-		if (mode == MJB_MODE_STEP) {
-			for (int st = 0; st < nsteps; st++) {
-				if (nz.enabled) ctrl_noise<G>(m, L, nz, e, step0 + (unsigned int)st);
-				if (any_bad<G>(e, L, e.f + L.qpos, m.nq, e.f + L.qvel, m.nv)) reset_frame_state<G>(m, L, s, e);
-				forward_first<G>(m, L, e);
-				forward_rest<G>(m, L, s, e);
-				if (any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0)) {
-					reset_frame_state<G>(m, L, s, e);
-					forward_first<G>(m, L, e);
-					forward_rest<G>(m, L, s, e);
+		// One copy of every stage in the instruction stream (the whole kernel must stay I-cache
+		// resident): modes only switch stage groups on and off.
+		const bool do_first = mode != MJB_MODE_STEP2, do_rest = mode != MJB_MODE_STEP1;
+		const bool do_euler = mode == MJB_MODE_STEP || mode == MJB_MODE_STEP2;
+		const bool checks = mode != MJB_MODE_FORWARD;
+		const int nst = mode == MJB_MODE_STEP ? nsteps : 1;
+#pragma nounroll
+		for (int st = 0; st < nst; st++) {
+			PROF_BEGIN();
+			if (do_first && checks && nz.enabled) ctrl_noise<G>(m, L, nz, e, step0 + (unsigned int)st);
+			PROF(13);
+			// attempt 1 only runs after mj_checkAcc found a bad qacc: reset, full forward, integrate
+#pragma nounroll
+			for (int attempt = 0; attempt < 2; attempt++) {
+				if (do_first || attempt) {
+					if (attempt == 0 && checks && any_bad<G>(e, L, e.f + L.qpos, m.nq, e.f + L.qvel, m.nv))
+						reset_frame_state<G>(m, L, s, e);
+					forward_first<G>(m, L, s, e);
 				}
-				euler<G>(m, L, e);
-			}
-		} else if (mode == MJB_MODE_FORWARD) {
-			forward_first<G>(m, L, e);
-			forward_rest<G>(m, L, s, e);
-		} else if (mode == MJB_MODE_STEP1) {
-			if (nz.enabled) ctrl_noise<G>(m, L, nz, e, step0);
-			if (any_bad<G>(e, L, e.f + L.qpos, m.nq, e.f + L.qvel, m.nv)) reset_frame_state<G>(m, L, s, e);
-			forward_first<G>(m, L, e);
-		} else {  // STEP2
-			forward_rest<G>(m, L, s, e);
-			if (any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0)) {
-				reset_frame_state<G>(m, L, s, e);
-				forward_first<G>(m, L, e);
+				if (!do_rest) break;
 				forward_rest<G>(m, L, s, e);
+				if (attempt || !checks || !any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0)) break;
+				reset_frame_state<G>(m, L, s, e);
 			}
-			euler<G>(m, L, e);
+			PROF(14);  // whole forward (incl. checks)
+			if (do_euler) euler<G>(m, L, e);
+			PROF(15);
 		}
 
 		store_state<G>(m, L, s, e);

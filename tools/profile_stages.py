@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Per-stage shader-cycle breakdown of the step kernel (profiling build libmjb_prof.so, env 0 / lane 0).
+Usage: python tools/profile_stages.py [--lanes G] [--envs E] [--steps K]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mujoco_ros_pkgs_amd import binding  # noqa: E402
+
+STAGES = ["kinematics", "com_pos", "crb", "factorM", "transm+sens_pos", "com_vel", "passive", "rne", "sens_vel",
+          "actuation", "acceleration", "constraint", "sens_acc", "ctrl_noise", "forward(total)", "euler"]
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--lanes", type=int, default=16)
+ap.add_argument("--epb", type=int, default=0)
+ap.add_argument("--envs", type=int, default=4096)
+ap.add_argument("--steps", type=int, default=200)
+ap.add_argument("--model", default="franka_like")
+a = ap.parse_args()
+
+binding.LIB_PATH = os.path.join(ROOT, "mujoco_ros_pkgs_amd", "csrc", "libmjb_prof.so")
+from mujoco_ros_pkgs_amd import engine, mjcf  # noqa: E402
+
+model = mjcf.load_asset(a.model)
+cm = engine.CompiledModel(model)
+b = engine.Batch(cm, a.envs)
+b.set_launch(a.lanes, a.epb)
+rng = np.random.default_rng(0)
+b.set("qvel", rng.uniform(-0.1, 0.1, (a.envs, model["nv"])))
+b.set_ctrl_noise(43.5, 0.1, 12345, 0)
+b.step(a.steps)
+b.synchronize()
+out = (C.c_uint64 * 64)()
+b.lib.mjb_debug_profile(b.ptr, out, 1)
+ms = b.time_steps(a.steps, 2)
+b.lib.mjb_debug_profile(b.ptr, out, 1)
+tot = 0
+print(f"lanes={a.lanes} envs={a.envs} steps={a.steps}: {ms:.3f} ms/launch -> {a.envs*a.steps/ms/1e3:.1f} M env-steps/s")
+for i, n in enumerate(STAGES):
+    cnt = max(1, out[32 + i])
+    cyc = out[i] / cnt
+    if n != "forward(total)":
+        tot += cyc
+    print(f"  {n:18s} {cyc:10.0f} cycles/call  ({out[32+i]} calls)")
+print(f"  sum (excl. total)  {tot:10.0f} cycles/step  = {tot/2.4e3:.1f} us @2.4GHz (s_memtime ticks at 100 MHz? see note)")
