@@ -1,0 +1,117 @@
+/* mjr_host.h — C interface of the host runtime (libmjr_host.so): the batched, ROS-free mirror of the
+ * reference's MujocoEnv / MujocoPlugin layer that drives the step engine of mjb.h.
+ *
+ * Two parts:
+ *  1. `mjr_backend`: the stepper vtable MujocoEnv talks to.  The product implementation wraps libmjb
+ *     (mjr_make_mjb_backend); it needs a HIP device and has no fallback.
+ *  2. `mjr_env_*`: a flat C face of the C++ class mujoco_ros::MujocoEnv (host/mujoco_env.h) so that
+ *     bindings and tests can drive it; each function names the reference member it forwards to
+ *     (/root/reference mujoco_ros/src/mujoco_env.cpp, callbacks.cpp).
+ */
+#ifndef MJR_HOST_H_
+#define MJR_HOST_H_
+
+#include <stdint.h>
+
+#include "mjb.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mjr_backend {
+	void *self;
+	int (*nenv)(void *self);
+	int (*field_size)(void *self, int field);
+	int (*step)(void *self, int nsteps);            /* nsteps fused full steps              */
+	int (*step1)(void *self);                       /* up to the control-callback point     */
+	int (*step2)(void *self);                       /* rest of the step + integration       */
+	int (*forward)(void *self);                     /* mj_forward                           */
+	int (*reset)(void *self, const uint8_t *mask);  /* mj_resetData (mask NULL: all)        */
+	int (*get)(void *self, int field, int env_lo, int env_hi, double *host);
+	int (*set)(void *self, int field, int env_lo, int env_hi, const double *host);
+	int (*set_ctrl_noise)(void *self, double std, double rate, uint64_t seed, int64_t env_offset);
+	int (*synchronize)(void *self);
+	const char *(*last_error)(void *self);
+	void (*destroy)(void *self);
+} mjr_backend;
+
+/* creates a backend for (model, nenv, device); NULL on failure */
+typedef mjr_backend *(*mjr_backend_factory)(const mjb_model_desc *desc, int nenv, int device, void *user);
+
+/* The product backend: mjb_compile + mjb_make_batch on HIP device `device`.  NULL (and mjr_last_error())
+ * when no GPU is usable — there is no CPU path. */
+mjr_backend *mjr_make_mjb_backend(const mjb_model_desc *desc, int nenv, int device, void *unused);
+const char *mjr_last_error(void);
+
+/* ---- flat face of mujoco_ros::MujocoEnv ---- */
+typedef struct mjr_env mjr_env;
+
+/* Name tables (mj_name2id): arrays of NUL-terminated strings, counts taken from desc */
+typedef struct mjr_names {
+	const char *const *body;
+	const char *const *joint;
+	const char *const *geom;
+	const char *const *site;
+	const char *const *sensor;
+	const char *const *actuator;
+} mjr_names;
+
+/* MujocoEnv::MujocoEnv(admin_hash) (mujoco_env.cpp:68-161).  `params_json` is a JSON object holding the
+ * private node parameters the constructor reads (eval_mode, unpause, num_steps, MujocoPlugins, ...).
+ * NULL on failure (e.g. eval_mode without a hash: the reference throws std::runtime_error). */
+mjr_env *mjr_env_create(const char *admin_hash, const char *params_json);
+void mjr_env_destroy(mjr_env *e);
+/* nh->setParam / deleteParam on the env's private parameter store */
+int mjr_env_set_param(mjr_env *e, const char *key, const char *json_value);
+int mjr_env_delete_param(mjr_env *e, const char *key);
+
+/* queue a model (settings_.load_request = 2, main.cpp:150-151); factory NULL = the HIP engine */
+int mjr_env_queue_model(mjr_env *e, const mjb_model_desc *desc, const mjr_names *names, int nenv, int device,
+                        mjr_backend_factory factory, void *factory_user);
+int mjr_env_start(mjr_env *e);    /* startPhysicsLoop + startEventLoop (main.cpp:154-155) */
+int mjr_env_shutdown(mjr_env *e); /* exit_request = 1, join both threads                   */
+
+int mjr_env_operational_status(mjr_env *e); /* getOperationalStatus()        */
+int mjr_env_pending_steps(mjr_env *e);      /* num_steps_until_exit_         */
+int mjr_env_is_physics_running(mjr_env *e);
+int mjr_env_is_event_running(mjr_env *e);
+int mjr_env_model_valid(mjr_env *e);
+const char *mjr_env_load_error(mjr_env *e);
+
+int mjr_env_step(mjr_env *e, int num_steps, int blocking);           /* MujocoEnv::step -> 1 true / 0 false */
+int mjr_env_toggle_paused(mjr_env *e, int paused, const char *hash); /* togglePaused                        */
+/* Step action (callbacks.cpp:94-129): returns 1 success, 0 failed/preempted; *preempted set accordingly */
+int mjr_env_step_goal(mjr_env *e, int num_steps, int *preempted);
+int mjr_env_reset_request(mjr_env *e);   /* resetCB: reset_request = 1  */
+int mjr_env_set_pause(mjr_env *e, int paused, const char *hash); /* setPauseCB -> success field */
+
+/* atomics of settings_ (name in {"run","exit_request","load_request","reset_request","env_steps_request"}) */
+int mjr_env_get_setting(mjr_env *e, const char *name);
+int mjr_env_set_setting(mjr_env *e, const char *name, int value);
+int mjr_env_set_ctrl_noise(mjr_env *e, double std, double rate);
+
+double mjr_env_sim_time(mjr_env *e);  /* last published /clock value */
+unsigned long long mjr_env_step_count(mjr_env *e);
+int mjr_env_nenv(mjr_env *e);
+int mjr_env_name2id(mjr_env *e, int objtype, const char *name);
+/* copy a field of one env between the host and the device (takes physics_thread_mutex_) */
+int mjr_env_get_field(mjr_env *e, int field, int env, double *out);
+int mjr_env_set_field(mjr_env *e, int field, int env, const double *in);
+
+/* plugins */
+int mjr_env_num_plugins(mjr_env *e);
+int mjr_env_num_cb_ready_plugins(mjr_env *e);
+/* flags of the i-th plugin if it is the built-in "mujoco_ros/TestPlugin" (test_plugin.h:62-73):
+ * name in {"ran_reset","ran_control_cb","ran_passive_cb","ran_render_cb","ran_last_cb",
+ * "ran_on_geom_changed_cb","got_config_param","got_lvl1_nested_array","got_lvl2_nested_array",
+ * "got_lvl1_nested_struct","got_lvl2_nested_struct","should_fail","control_calls","last_env"};
+ * -1 if unknown */
+int mjr_env_test_plugin_flag(mjr_env *e, int i, const char *name, int clear);
+int mjr_env_notify_geom_changed(mjr_env *e, int geom_id);
+int mjr_env_set_callback_envs(mjr_env *e, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -77,7 +77,7 @@ struct mjb_model {
 	std::vector<int> hint;            // all int arrays, concatenated
 	std::vector<double> hdbl;         // all double arrays, concatenated
 	std::vector<size_t> ioff, doff;   // offsets of each array inside hint / hdbl (declaration order)
-	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart;
+	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg;
 	int eulerdamp = 0, maxdepth = 0;
 	int field_size[MJB_F_COUNT]{};
 	FrameLayout L{};
@@ -139,8 +139,17 @@ void compute_layout(mjb_model *M, bool use_xfrc)
 		}
 		idx++;
 	}
+	L.MhB = off;
+	off += d.nM;
+	L.qH = off;
+	off += d.nM;
+	L.qHdi = off;
+	off += d.nv;
 	L.scratch = off;
-	off += 2 * d.nM + d.nv + d.nv + 6 * d.nv;
+	{
+		int a = 7 * d.nbody + 6 * d.njnt, b = 7 * d.nv;
+		off += a > b ? a : b;
+	}
 	if (off & 1) off++;
 	L.ndouble = off;
 	L.nint = (ioff + 1) & ~1;
@@ -301,6 +310,29 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		else if (t == MJB_JNT_BALL) M->dof_jstart[dd] = da;
 		else M->dof_jstart[dd] = (dd - da < 3) ? da : da + 3;
 	}
+	// packed per-body / per-dof records and the factorisation micro-program
+	for (int b = 0; b < h.nbody; b++) {
+		int rec[4] = { h.body_parentid[b], h.body_dofadr[b], h.body_dofnum[b], h.body_rootid[b] };
+		int rec2[4] = { h.body_jntadr[b], h.body_jntnum[b], h.body_sameframe[b], h.body_weldid[b] };
+		M->body_rec.insert(M->body_rec.end(), rec, rec + 4);
+		M->body_rec2.insert(M->body_rec2.end(), rec2, rec2 + 4);
+	}
+	for (int dd = 0; dd < h.nv; dd++) {
+		int rec[4] = { h.dof_Madr[dd], M->dof_depth[dd] - 1, h.dof_bodyid[dd], h.dof_parentid[dd] };
+		M->dof_rec.insert(M->dof_rec.end(), rec, rec + 4);
+	}
+	for (int k = 0; k < h.nv; k++) {
+		M->fac_beg.push_back((int)M->fac_ops.size() / 4);
+		const int kk = h.dof_Madr[k], na = M->dof_depth[k] - 1;
+		for (int a = 0; a < na; a++) {
+			const int i = M->M_coldof[kk + 1 + a];
+			for (int bb = a; bb < na; bb++) {
+				int op[4] = { h.dof_Madr[i] + (bb - a), kk + 1 + a, kk + 1 + bb, 0 };
+				M->fac_ops.insert(M->fac_ops.end(), op, op + 4);
+			}
+		}
+	}
+	M->fac_beg.push_back((int)M->fac_ops.size() / 4);
 	M->eulerdamp = 0;
 	if (!(h.disableflags & MJB_DSBL_EULERDAMP))
 		for (int i = 0; i < h.nv; i++)
@@ -378,7 +410,8 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 
 	// ---- device model blob: [ints | doubles | derived int tables]
 	size_t ni = M->hint.size(), nd = M->hdbl.size();
-	size_t nt = M->M_rowdof.size() + M->M_coldof.size() + M->dof_depth.size() + M->dof_jstart.size();
+	size_t nt = M->M_rowdof.size() + M->M_coldof.size() + M->dof_depth.size() + M->dof_jstart.size() +
+	            M->body_rec.size() + M->body_rec2.size() + M->dof_rec.size() + M->fac_ops.size() + M->fac_beg.size() + 64;
 	size_t bytes_i = ((ni + nt) * sizeof(int) + 15) & ~size_t(15);
 	size_t bytes = bytes_i + nd * sizeof(double) + 16;
 	if (hipMalloc(&b->blob, bytes) != hipSuccess) {
@@ -392,12 +425,15 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	if (ni) memcpy(hi, M->hint.data(), ni * sizeof(int));
 	size_t t0 = ni;
 	auto put = [&](const std::vector<int> &v) {
+		t0 = (t0 + 3) & ~size_t(3);  // 16-byte aligned tables (wide scalar loads)
 		size_t at = t0;
 		if (!v.empty()) memcpy(hi + t0, v.data(), v.size() * sizeof(int));
 		t0 += v.size();
 		return at;
 	};
 	size_t o_row = put(M->M_rowdof), o_col = put(M->M_coldof), o_dep = put(M->dof_depth), o_js = put(M->dof_jstart);
+	size_t o_br = put(M->body_rec), o_br2 = put(M->body_rec2), o_dr = put(M->dof_rec), o_fo = put(M->fac_ops),
+	       o_fb = put(M->fac_beg);
 	if (nd) memcpy(hd, M->hdbl.data(), nd * sizeof(double));
 	if (hipMemcpy(b->blob, hostblob.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
 		fail(MJB_ENODEVICE, "mjb_make_batch: model upload failed");
@@ -425,6 +461,11 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	dm.M_coldof = (mjb_ciptr)(di + o_col);
 	dm.dof_depth = (mjb_ciptr)(di + o_dep);
 	dm.dof_jstart = (mjb_ciptr)(di + o_js);
+	dm.body_rec = (mjb_ciptr)(di + o_br);
+	dm.body_rec2 = (mjb_ciptr)(di + o_br2);
+	dm.dof_rec = (mjb_ciptr)(di + o_dr);
+	dm.fac_ops = (mjb_ciptr)(di + o_fo);
+	dm.fac_beg = (mjb_ciptr)(di + o_fb);
 	dm.eulerdamp = M->eulerdamp;
 	dm.maxdepth = M->maxdepth;
 

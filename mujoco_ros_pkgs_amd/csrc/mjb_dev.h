@@ -31,6 +31,11 @@ struct DevModel {
 	mjb_ciptr M_coldof;    // [nM] ancestor dof j of qM entry e
 	mjb_ciptr dof_depth;   // [nv] number of entries in row i of qM (self + ancestors)
 	mjb_ciptr dof_jstart;  // [nv] first dof of the "velocity group" the dof belongs to (see com_vel)
+	mjb_ciptr body_rec;    // [nbody][4] packed {parentid, dofadr, dofnum, rootid}   (one s_load_dwordx4 per body)
+	mjb_ciptr body_rec2;   // [nbody][4] packed {jntadr, jntnum, sameframe, weldid}
+	mjb_ciptr dof_rec;     // [nv][4]    packed {Madr, nancestor, bodyid, parentid}
+	mjb_ciptr fac_ops;     // [nfac][4]  factorisation micro-ops {dst, srcA, srcB, 0}: LD[dst] -= LD[srcA]/LD[kk]*LD[srcB]
+	mjb_ciptr fac_beg;     // [nv+1]     first micro-op of pivot k
 	int eulerdamp;         // any dof_damping > 0 and EULERDAMP not disabled
 	int maxdepth;          // max dof_depth
 };
@@ -46,7 +51,10 @@ struct FrameLayout {
 #undef MJB_DD
 #undef MJB_DD2
 #undef MJB_DI
-	int scratch;   // Euler implicit-damping scratch: MhB[nM] qH[nM] qHDiagInv[nv] + tmp[6*nv]
+	int MhB;       // [nM]  M + h*diag(damping) (Euler implicit damping), built and factorised next to qM
+	int qH;        // [nM]  its L'DL factor
+	int qHdi;      // [nv]  1 / diag
+	int scratch;   // transient scratch: max(7*nbody + 6*njnt (kinematics locals), 7*nv (crb buf / euler rhs))
 	int ndouble;   // doubles per frame
 	int nint;      // ints per frame (follow the doubles)
 	int nstate;    // doubles in the persistent prefix

@@ -93,122 +93,159 @@ template <int G> STAGE void kinematics(CModel m, CLayout L, const Env &e)
 	double *f = e.f;
 	double *qpos = f + L.qpos, *xpos = f + L.xpos, *xquat = f + L.xquat, *xmat = f + L.xmat;
 	double *xanchor = f + L.xanchor, *xaxis = f + L.xaxis;
+	double *loc = f + L.scratch;  // [nbody][7] local pose (pos, quat) of each body in its parent's frame
 	const int lane = e.lane;
 
-	// normalise quaternions held in qpos (ball / free joints)
-	for (int j = lane; j < m.njnt; j += G) {
-		int t = m.jnt_type[j];
-		if (t == MJB_JNT_BALL || t == MJB_JNT_FREE) {
-			double *qq = qpos + m.jnt_qposadr[j] + (t == MJB_JNT_FREE ? 3 : 0);
-			double q[4];
-			ld4(q, qq);
-			normalize4(q);
-			st4(qq, q);
+	// Phase A -- one body per lane: pose relative to the parent INCLUDING the joint motion, plus joint anchors
+	// and axes in the parent's frame (parked in xanchor / xaxis until phase D).  Also normalises the
+	// quaternions stored in qpos (ball / free joints), as mj_kinematics does.
+	for (int b = lane; b < m.nbody; b += G) {
+		double p[3], q[4];
+		if (b == 0) {
+			p[0] = p[1] = p[2] = 0;
+			q[0] = 1; q[1] = q[2] = q[3] = 0;
+		} else {
+			const int jntadr = m.body_rec2[4 * b], jntnum = m.body_rec2[4 * b + 1];
+			if (jntnum == 1 && m.jnt_type[jntadr] == MJB_JNT_FREE) {
+				const int qa = m.jnt_qposadr[jntadr];
+				ld3(p, qpos + qa);
+				ld4(q, qpos + qa + 3);
+				normalize4(q);
+				st4(qpos + qa + 3, q);
+				double ax[3];
+				ldc3(ax, m.jnt_axis + 3 * jntadr);
+				st3(xanchor + 3 * jntadr, p);
+				st3(xaxis + 3 * jntadr, ax);
+			} else {
+				ldc3(p, m.body_pos + 3 * b);
+				ldc4(q, m.body_quat + 4 * b);
+				for (int j = jntadr; j < jntadr + jntnum; j++) {
+					const int qa = m.jnt_qposadr[j], jt = m.jnt_type[j];
+					double jaxis[3], jpos[3], ax[3], an[3];
+					ldc3(jaxis, m.jnt_axis + 3 * j);
+					ldc3(jpos, m.jnt_pos + 3 * j);
+					rotvec_quat(ax, jaxis, q);
+					rotvec_quat(an, jpos, q);
+					an[0] += p[0]; an[1] += p[1]; an[2] += p[2];
+					st3(xaxis + 3 * j, ax);
+					st3(xanchor + 3 * j, an);
+					if (jt == MJB_JNT_SLIDE) {
+						const double sl = qpos[qa] - m.qpos0[qa];
+						p[0] += ax[0] * sl; p[1] += ax[1] * sl; p[2] += ax[2] * sl;
+					} else {
+						double ql[4], v[3];
+						if (jt == MJB_JNT_BALL) {
+							ld4(ql, qpos + qa);
+							normalize4(ql);
+							st4(qpos + qa, ql);
+						} else {
+							axis_angle_quat(ql, jaxis, qpos[qa] - m.qpos0[qa]);
+						}
+						qmul(q, q, ql);
+						rotvec_quat(v, jpos, q);
+						p[0] = an[0] - v[0]; p[1] = an[1] - v[1]; p[2] = an[2] - v[2];
+					}
+				}
+			}
 		}
-	}
-	if (lane == 0) {
-		xpos[0] = xpos[1] = xpos[2] = 0;
-		xquat[0] = 1; xquat[1] = xquat[2] = xquat[3] = 0;
-		for (int k = 0; k < 9; k++) xmat[k] = (k % 4 == 0) ? 1.0 : 0.0;
-		double *xipos = f + L.xipos, *ximat = f + L.ximat;
-		xipos[0] = xipos[1] = xipos[2] = 0;
-		for (int k = 0; k < 9; k++) ximat[k] = (k % 4 == 0) ? 1.0 : 0.0;
+		st3(loc + 7 * b, p);
+		st4(loc + 7 * b + 3, q);
 	}
 	gsync<G>();
 
-	// tree walk, replicated in every lane of the group (values in registers), lane 0 stores
-	for (int i = 1; i < m.nbody; i++) {
-		const int pid = m.body_parentid[i];
-		const int jntadr = m.body_jntadr[i], jntnum = m.body_jntnum[i];
-		double p[3], q[4];
-		if (jntnum == 1 && m.jnt_type[jntadr] == MJB_JNT_FREE) {
-			const int qa = m.jnt_qposadr[jntadr];
-			ld3(p, qpos + qa);
-			ld4(q, qpos + qa + 3);
-			normalize4(q);
-			if (lane == 0) {
-				st3(xanchor + 3 * jntadr, p);
-				double ax[3];
-				ldc3(ax, m.jnt_axis + 3 * jntadr);
-				st3(xaxis + 3 * jntadr, ax);
-			}
-		} else {
-			ldc3(p, m.body_pos + 3 * i);
-			ldc4(q, m.body_quat + 4 * i);
-			if (pid) {
-				double pm[9], pp[3], pq[4], v[3];
-				ld9(pm, xmat + 9 * pid);
-				ld3(pp, xpos + 3 * pid);
-				ld4(pq, xquat + 4 * pid);
-				matvec3(v, pm, p);
-				p[0] = v[0] + pp[0]; p[1] = v[1] + pp[1]; p[2] = v[2] + pp[2];
-				qmul(q, pq, q);
-			}
-			for (int j = jntadr; j < jntadr + jntnum; j++) {
-				const int qa = m.jnt_qposadr[j];
-				const int jt = m.jnt_type[j];
-				double jaxis[3], jpos[3], ax[3], an[3];
-				ldc3(jaxis, m.jnt_axis + 3 * j);
-				ldc3(jpos, m.jnt_pos + 3 * j);
-				rotvec_quat(ax, jaxis, q);
-				rotvec_quat(an, jpos, q);
-				an[0] += p[0]; an[1] += p[1]; an[2] += p[2];
-				if (lane == 0) {
-					st3(xaxis + 3 * j, ax);
-					st3(xanchor + 3 * j, an);
-				}
-				if (jt == MJB_JNT_SLIDE) {
-					double s = qpos[qa] - m.qpos0[qa];
-					p[0] += ax[0] * s; p[1] += ax[1] * s; p[2] += ax[2] * s;
-				} else {
-					double ql[4], v[3];
-					if (jt == MJB_JNT_BALL) {
-						ld4(ql, qpos + qa);
-						normalize4(ql);
-					} else {
-						axis_angle_quat(ql, jaxis, qpos[qa] - m.qpos0[qa]);
-					}
-					qmul(q, q, ql);
-					rotvec_quat(v, jpos, q);
-					p[0] = an[0] - v[0]; p[1] = an[1] - v[1]; p[2] = an[2] - v[2];
-				}
-			}
-		}
-		normalize4(q);
+	// Phase B -- thin serial chain, replicated in every lane with the running parent pose in registers:
+	// xquat_i = xquat_p * lq_i,  xpos_i = xpos_p + R_p lp_i.  Quaternions are re-normalised in phase C.
+	{
+		double cp[3] = { 0, 0, 0 }, cq[4] = { 1, 0, 0, 0 }, cM[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
 		if (lane == 0) {
-			double M[9];
-			quat2mat(M, q);
-			st3(xpos + 3 * i, p);
-			st4(xquat + 4 * i, q);
-			st9(xmat + 9 * i, M);
+			st3(xpos, cp);
+			st4(xquat, cq);
+			st9(xmat, cM);
 		}
-		gsync<G>();
+#pragma nounroll
+		for (int i = 1; i < m.nbody; i++) {
+			const int pid = m.body_rec[4 * i];
+			double lp[3], lq[4];
+			ld3(lp, loc + 7 * i);
+			ld4(lq, loc + 7 * i + 3);
+			if (pid != i - 1) {
+				ld3(cp, xpos + 3 * pid);
+				ld4(cq, xquat + 4 * pid);
+				ld9(cM, xmat + 9 * pid);
+			}
+			double v[3];
+			matvec3(v, cM, lp);
+			cp[0] += v[0]; cp[1] += v[1]; cp[2] += v[2];
+			qmul(cq, cq, lq);
+			quat2mat(cM, cq);
+			if (lane == 0) {
+				st3(xpos + 3 * i, cp);
+				st4(xquat + 4 * i, cq);
+				st9(xmat + 9 * i, cM);
+			}
+		}
 	}
+	gsync<G>();
 
-	// inertial, geom and site frames: one item per lane
-	const int nitem = (m.nbody - 1) + m.ngeom + m.nsite;
+	// Phase C -- one body per lane: normalise xquat, final xmat, inertial frame
+	for (int b = lane; b < m.nbody; b += G) {
+		double q[4], M[9], p[3];
+		ld4(q, xquat + 4 * b);
+		ld3(p, xpos + 3 * b);
+		normalize4(q);
+		quat2mat(M, q);
+		st4(xquat + 4 * b, q);
+		st9(xmat + 9 * b, M);
+		double *oip = f + L.xipos + 3 * b, *oim = f + L.ximat + 9 * b;
+		if (b == 0 || m.body_rec2[4 * b + 2]) {
+			st3(oip, p);
+			st9(oim, M);
+		} else {
+			double ip[3], iq[4], v[3], r[9];
+			ldc3(ip, m.body_ipos + 3 * b);
+			ldc4(iq, m.body_iquat + 4 * b);
+			matvec3(v, M, ip);
+			v[0] += p[0]; v[1] += p[1]; v[2] += p[2];
+			qmul(iq, q, iq);
+			quat2mat(r, iq);
+			st3(oip, v);
+			st9(oim, r);
+		}
+	}
+	gsync<G>();
+
+	// Phase D -- joints (anchor / axis to the world frame through the PARENT body's frame), geoms, sites
+	const int nitem = m.njnt + m.ngeom + m.nsite;
 	for (int it = lane; it < nitem; it += G) {
-		if (it < m.nbody - 1) {
-			const int b = it + 1;
-			double pos[3], quat[4];
-			ldc3(pos, m.body_ipos + 3 * b);
-			ldc4(quat, m.body_iquat + 4 * b);
-			local2global(xpos + 3 * b, xquat + 4 * b, xmat + 9 * b, f + L.xipos + 3 * b, f + L.ximat + 9 * b, pos,
-			             quat, m.body_sameframe[b]);
-		} else if (it < m.nbody - 1 + m.ngeom) {
-			const int g = it - (m.nbody - 1), b = m.geom_bodyid[g];
+		if (it < m.njnt) {
+			const int j = it, b = m.jnt_bodyid[j];
+			if (m.jnt_type[j] != MJB_JNT_FREE) {
+				const int pid = m.body_rec[4 * b];
+				double M[9], pp[3], an[3], ax[3], v[3];
+				ld9(M, xmat + 9 * pid);
+				ld3(pp, xpos + 3 * pid);
+				ld3(an, xanchor + 3 * j);
+				ld3(ax, xaxis + 3 * j);
+				matvec3(v, M, an);
+				v[0] += pp[0]; v[1] += pp[1]; v[2] += pp[2];
+				st3(xanchor + 3 * j, v);
+				matvec3(v, M, ax);
+				st3(xaxis + 3 * j, v);
+			}
+		} else if (it < m.njnt + m.ngeom) {
+			const int g = it - m.njnt, b = m.geom_bodyid[g];
 			double pos[3], quat[4];
 			ldc3(pos, m.geom_pos + 3 * g);
 			ldc4(quat, m.geom_quat + 4 * g);
 			local2global(xpos + 3 * b, xquat + 4 * b, xmat + 9 * b, f + L.geom_xpos + 3 * g, f + L.geom_xmat + 9 * g,
 			             pos, quat, m.geom_sameframe[g]);
 		} else {
-			const int s = it - (m.nbody - 1) - m.ngeom, b = m.site_bodyid[s];
+			const int st = it - m.njnt - m.ngeom, b = m.site_bodyid[st];
 			double pos[3], quat[4];
-			ldc3(pos, m.site_pos + 3 * s);
-			ldc4(quat, m.site_quat + 4 * s);
-			local2global(xpos + 3 * b, xquat + 4 * b, xmat + 9 * b, f + L.site_xpos + 3 * s, f + L.site_xmat + 9 * s,
-			             pos, quat, m.site_sameframe[s]);
+			ldc3(pos, m.site_pos + 3 * st);
+			ldc4(quat, m.site_quat + 4 * st);
+			local2global(xpos + 3 * b, xquat + 4 * b, xmat + 9 * b, f + L.site_xpos + 3 * st, f + L.site_xmat + 9 * st,
+			             pos, quat, m.site_sameframe[st]);
 		}
 	}
 	gsync<G>();
@@ -323,6 +360,7 @@ template <int G> STAGE void crb(CModel m, CLayout L, const Env &e)
 		double v = (i == j) ? m.dof_armature[i] : 0.0;
 		v += dot6r(a, b);
 		f[L.qM + en] = v;
+		if (m.eulerdamp) f[L.MhB + en] = (i == j) ? v + m.timestep[0] * m.dof_damping[i] : v;
 	}
 	gsync<G>();
 }
@@ -330,53 +368,92 @@ template <int G> STAGE void crb(CModel m, CLayout L, const Env &e)
 // ------------------------------------------------------------------------------------------------
 // A3  sparse L'DL factorisation in qM layout and the matching triangular solves
 // ------------------------------------------------------------------------------------------------
-template <int G> STAGE void factor(CModel m, const Env &e, const double *M, double *LD, double *diaginv)
+// Two matrices with the same sparsity are factorised in the same rounds (qM -> qLD for mj_factorM and,
+// when Euler's implicit damping is on, MhB = M + h diag(B) -> qH), so the second factorisation rides on
+// the first one's latency chain.  Per pivot k (descending) ONE round applies every row update
+// LD[dst] -= LD[srcA] / LD[kk] * LD[srcB] listed in the host-built micro-program (one op per lane), a
+// second round scales row k.
+template <int G>
+STAGE void factor2(CModel m, const Env &e, const double *M, double *LD, double *di, const double *M2, double *LD2,
+                   double *di2, bool dual)
 {
 	const int lane = e.lane;
-	for (int en = lane; en < m.nM; en += G) LD[en] = M[en];
+	for (int en = lane; en < m.nM; en += G) {
+		LD[en] = M[en];
+		if (dual) LD2[en] = M2[en];
+	}
 	gsync<G>();
+#pragma nounroll
 	for (int k = m.nv - 1; k >= 0; k--) {
-		const int na = m.dof_depth[k] - 1;  // ancestors of k
+		const int na = m.dof_rec[4 * k + 1];
 		if (na <= 0) continue;
-		const int kk = m.dof_Madr[k];
+		const int kk = m.dof_rec[4 * k];
+		const int beg = m.fac_beg[k], end = m.fac_beg[k + 1];
 		const double dkk = LD[kk];
-		// update rows of all ancestors: pairs (a <= b)
-		for (int a = 0; a < na; a++) {
-			const int i = m.M_coldof[kk + 1 + a];
-			const int ia = m.dof_Madr[i];
-			const double tmp = LD[kk + 1 + a] / dkk;
-			for (int b = a + lane; b < na; b += G) LD[ia + (b - a)] -= tmp * LD[kk + 1 + b];
+		const double dkk2 = dual ? LD2[kk] : 1.0;
+		for (int t = beg + lane; t < end; t += G) {
+			const int dst = m.fac_ops[4 * t], sa = m.fac_ops[4 * t + 1], sb = m.fac_ops[4 * t + 2];
+			LD[dst] -= LD[sa] / dkk * LD[sb];
+			if (dual) LD2[dst] -= LD2[sa] / dkk2 * LD2[sb];
 		}
 		gsync<G>();
-		for (int a = lane; a < na; a += G) LD[kk + 1 + a] = LD[kk + 1 + a] / dkk;
+		for (int a = lane; a < na; a += G) {
+			LD[kk + 1 + a] = LD[kk + 1 + a] / dkk;
+			if (dual) LD2[kk + 1 + a] = LD2[kk + 1 + a] / dkk2;
+		}
 		gsync<G>();
 	}
-	for (int i = lane; i < m.nv; i += G) diaginv[i] = 1.0 / LD[m.dof_Madr[i]];
+	for (int i = lane; i < m.nv; i += G) {
+		const int ii = m.dof_rec[4 * i];
+		di[i] = 1.0 / LD[ii];
+		if (dual) di2[i] = 1.0 / LD2[ii];
+	}
 	gsync<G>();
+}
+
+// sum over the 16 lanes of a DPP row; every lane of the row receives the total (butterfly: xor 1, xor 2,
+// half-mirror, mirror)
+DEVI double dpp_add(double v, const int lo2, const int hi2) { return v + __hiloint2double(hi2, lo2); }
+#define MJB_DPP_STEP(v, ctrl)                                                                        \
+	v = dpp_add(v, __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xF, 0xF, true),          \
+	            __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xF, 0xF, true))
+template <int W> DEVI double row_sum(double v)  // W = 8 or 16 participating lanes
+{
+	MJB_DPP_STEP(v, 0xB1);   // quad_perm [1,0,3,2]
+	MJB_DPP_STEP(v, 0x4E);   // quad_perm [2,3,0,1]
+	MJB_DPP_STEP(v, 0x141);  // row_half_mirror
+	if (W == 16) MJB_DPP_STEP(v, 0x140);  // row_mirror
+	return v;
 }
 
 template <int G> STAGE void solve(CModel m, const Env &e, double *x, const double *LD, const double *diaginv)
 {
 	const int lane = e.lane;
-	// x <- inv(L') x
+	// x <- inv(L') x : column sweep, one ancestor per lane
+#pragma nounroll
 	for (int i = m.nv - 1; i >= 0; i--) {
-		const int na = m.dof_depth[i] - 1;
+		const int na = m.dof_rec[4 * i + 1];
 		if (na <= 0) continue;
-		const int ii = m.dof_Madr[i];
+		const int ii = m.dof_rec[4 * i];
 		const double xi = x[i];
 		for (int a = lane; a < na; a += G) x[m.M_coldof[ii + 1 + a]] -= LD[ii + 1 + a] * xi;
 		gsync<G>();
 	}
 	for (int i = lane; i < m.nv; i += G) x[i] *= diaginv[i];
 	gsync<G>();
-	// x <- inv(L) x   (row i depends on its ancestors only; replicated serial sum keeps the order)
+	// x <- inv(L) x : row i needs its ancestors only; products one per lane (first min(G,16) lanes of the group),
+	// summed with a DPP row butterfly
+#pragma nounroll
 	for (int i = 0; i < m.nv; i++) {
-		const int na = m.dof_depth[i] - 1;
+		const int na = m.dof_rec[4 * i + 1];
 		if (na <= 0) continue;
-		const int ii = m.dof_Madr[i];
-		double acc = x[i];
-		for (int a = 0; a < na; a++) acc -= LD[ii + 1 + a] * x[m.M_coldof[ii + 1 + a]];
-		if (lane == 0) x[i] = acc;
+		const int ii = m.dof_rec[4 * i];
+		constexpr int W = G < 16 ? G : 16;
+		double part = 0;
+		if (lane < W)
+			for (int a = lane; a < na; a += W) part += LD[ii + 1 + a] * x[m.M_coldof[ii + 1 + a]];
+		part = row_sum<W>(part);
+		if (lane == 0) x[i] -= part;
 		gsync<G>();
 	}
 }
@@ -820,18 +897,12 @@ template <int G> STAGE void euler(CModel m, CLayout L, const Env &e)
 {
 	double *f = e.f;
 	const double dt = m.timestep[0];
-	double *MhB = f + L.scratch, *qH = MhB + m.nM, *qHdi = qH + m.nM, *x = qHdi + m.nv;
+	double *x = f + L.scratch;
 	if (m.eulerdamp) {
-		for (int en = e.lane; en < m.nM; en += G) {
-			const int i = m.M_rowdof[en];
-			double v = f[L.qM + en];
-			if (m.M_coldof[en] == i) v += dt * m.dof_damping[i];
-			MhB[en] = v;
-		}
+		// (M + h B) x = qfrc_smooth + qfrc_constraint, factor qH prepared next to qLD in fwd_position
 		for (int d = e.lane; d < m.nv; d += G) x[d] = f[L.qfrc_smooth + d] + f[L.qfrc_constraint + d];
 		gsync<G>();
-		factor<G>(m, e, MhB, qH, qHdi);
-		solve<G>(m, e, x, qH, qHdi);
+		solve<G>(m, e, x, f + L.qH, f + L.qHdi);
 	} else {
 		for (int d = e.lane; d < m.nv; d += G) x[d] = f[L.qacc + d];
 		gsync<G>();
@@ -936,7 +1007,8 @@ template <int G> DEVI void forward_first(CModel m, CLayout L, CState s, const En
 	PROF(1);
 	crb<G>(m, L, e);
 	PROF(2);
-	factor<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv);
+	factor2<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi,
+	           m.eulerdamp != 0);
 	PROF(3);
 	transmission<G>(m, L, e);
 	sensors<G>(m, L, e, MJB_STAGE_POS);

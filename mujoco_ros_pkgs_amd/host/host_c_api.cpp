@@ -1,0 +1,261 @@
+// host_c_api.cpp — flat C face of mujoco_ros::MujocoEnv (include/mjr_host.h) + the libmjb-backed stepper.
+#include <cstring>
+#include <map>
+#include <string>
+
+#include "mujoco_env.h"
+#include "test_plugin.h"
+
+using namespace mujoco_ros;
+
+namespace {
+thread_local std::string g_err;
+
+struct MjbBackend {
+	mjb_model *model = nullptr;
+	mjb_batch *batch = nullptr;
+	mjr_backend vt{};
+};
+#define B(self) (static_cast<MjbBackend *>(self))
+int be_nenv(void *s) { return mjb_nenv(B(s)->batch); }
+int be_field_size(void *s, int f) { return mjb_field_size(B(s)->model, f); }
+int be_step(void *s, int n) { int rc = mjb_step(B(s)->batch, n); return rc ? rc : mjb_synchronize(B(s)->batch); }
+int be_step1(void *s) { return mjb_step1(B(s)->batch); }
+int be_step2(void *s) { return mjb_step2(B(s)->batch); }
+int be_forward(void *s) { return mjb_forward(B(s)->batch); }
+int be_reset(void *s, const uint8_t *m) { return mjb_reset(B(s)->batch, m); }
+int be_get(void *s, int f, int lo, int hi, double *h) { return mjb_get(B(s)->batch, f, lo, hi, h); }
+int be_set(void *s, int f, int lo, int hi, const double *h) { return mjb_set(B(s)->batch, f, lo, hi, h); }
+int be_noise(void *s, double a, double b, uint64_t seed, int64_t off) { return mjb_set_ctrl_noise(B(s)->batch, a, b, seed, off); }
+int be_sync(void *s) { return mjb_synchronize(B(s)->batch); }
+const char *be_err(void *) { return mjb_last_error(); }
+void be_destroy(void *s)
+{
+	MjbBackend *b = B(s);
+	if (b->batch) mjb_free_batch(b->batch);
+	if (b->model) mjb_free_model(b->model);
+	delete b;
+}
+}  // namespace
+
+struct mjr_env {
+	MujocoEnv *env = nullptr;
+};
+
+extern "C" {
+
+const char *mjr_last_error(void) { return g_err.c_str(); }
+
+mjr_backend *mjr_make_mjb_backend(const mjb_model_desc *desc, int nenv, int device, void *)
+{
+	MjbBackend *b = new MjbBackend;
+	b->model = mjb_compile(desc);
+	if (!b->model) {
+		g_err = mjb_last_error();
+		delete b;
+		return nullptr;
+	}
+	b->batch = mjb_make_batch(b->model, nenv, device);
+	if (!b->batch) {
+		g_err = mjb_last_error();
+		mjb_free_model(b->model);
+		delete b;
+		return nullptr;
+	}
+	b->vt = mjr_backend{ b, be_nenv, be_field_size, be_step, be_step1, be_step2, be_forward, be_reset, be_get, be_set,
+		                 be_noise, be_sync, be_err, be_destroy };
+	return &b->vt;
+}
+
+mjr_env *mjr_env_create(const char *admin_hash, const char *params_json)
+{
+	try {
+		ParamServer ps;
+		if (params_json && params_json[0]) {
+			ConfigValue v = ConfigValue::fromJson(params_json);
+			if (v.getType() != ConfigValue::TypeStruct) throw std::runtime_error("params must be a JSON object");
+			for (const auto &kv : v.members()) ps.set(kv.first, kv.second);
+		}
+		mjr_env *e = new mjr_env;
+		e->env = new MujocoEnv(admin_hash ? admin_hash : "", &ps);
+		return e;
+	} catch (const std::exception &ex) {
+		g_err = ex.what();
+		return nullptr;
+	}
+}
+
+void mjr_env_destroy(mjr_env *e)
+{
+	if (!e) return;
+	delete e->env;
+	delete e;
+}
+
+int mjr_env_set_param(mjr_env *e, const char *key, const char *json_value)
+{
+	try {
+		e->env->params_.set(key, ConfigValue::fromJson(json_value));
+		return 0;
+	} catch (const std::exception &ex) {
+		g_err = ex.what();
+		return -1;
+	}
+}
+int mjr_env_delete_param(mjr_env *e, const char *key)
+{
+	e->env->params_.erase(key);
+	return 0;
+}
+
+int mjr_env_queue_model(mjr_env *e, const mjb_model_desc *desc, const mjr_names *names, int nenv, int device,
+                        mjr_backend_factory factory, void *factory_user)
+{
+	if (!e || !desc || nenv <= 0) return -1;
+	ModelNames n;
+	auto fill = [](std::vector<std::string> &dst, const char *const *src, int cnt) {
+		for (int i = 0; i < cnt; i++) dst.emplace_back(src && src[i] ? src[i] : "");
+	};
+	if (names) {
+		fill(n.body, names->body, desc->nbody);
+		fill(n.joint, names->joint, desc->njnt);
+		fill(n.geom, names->geom, desc->ngeom);
+		fill(n.site, names->site, desc->nsite);
+		fill(n.sensor, names->sensor, desc->nsensor);
+		fill(n.actuator, names->actuator, desc->nu);
+	}
+	e->env->queueModel(desc, n, nenv, device, factory, factory_user);
+	return 0;
+}
+
+int mjr_env_start(mjr_env *e)
+{
+	e->env->startPhysicsLoop();
+	e->env->startEventLoop();
+	return 0;
+}
+int mjr_env_shutdown(mjr_env *e)
+{
+	e->env->shutdown();
+	return 0;
+}
+int mjr_env_operational_status(mjr_env *e) { return e->env->getOperationalStatus(); }
+int mjr_env_pending_steps(mjr_env *e) { return e->env->getPendingSteps(); }
+int mjr_env_is_physics_running(mjr_env *e) { return e->env->isPhysicsRunning(); }
+int mjr_env_is_event_running(mjr_env *e) { return e->env->isEventRunning(); }
+int mjr_env_model_valid(mjr_env *e) { return e->env->getModelPtr() != nullptr; }
+const char *mjr_env_load_error(mjr_env *e) { return e->env->loadError().c_str(); }
+int mjr_env_step(mjr_env *e, int n, int blocking) { return e->env->step(n, blocking != 0) ? 1 : 0; }
+int mjr_env_toggle_paused(mjr_env *e, int paused, const char *hash) { return e->env->togglePaused(paused != 0, hash ? hash : "") ? 1 : 0; }
+int mjr_env_step_goal(mjr_env *e, int n, int *preempted)
+{
+	MujocoEnv::StepResult r = e->env->onStepGoal(n);
+	if (preempted) *preempted = r.preempted;
+	return r.success ? 1 : 0;
+}
+int mjr_env_reset_request(mjr_env *e)
+{
+	e->env->resetCB();
+	return 1;
+}
+int mjr_env_set_pause(mjr_env *e, int paused, const char *hash) { return e->env->setPauseCB(paused != 0, hash ? hash : "").success ? 1 : 0; }
+
+static std::atomic_int *setting(mjr_env *e, const char *name)
+{
+	auto &s = e->env->settings_;
+	if (!strcmp(name, "run")) return &s.run;
+	if (!strcmp(name, "exit_request")) return &s.exit_request;
+	if (!strcmp(name, "load_request")) return &s.load_request;
+	if (!strcmp(name, "reset_request")) return &s.reset_request;
+	if (!strcmp(name, "env_steps_request")) return &s.env_steps_request;
+	return nullptr;
+}
+int mjr_env_get_setting(mjr_env *e, const char *name)
+{
+	auto *a = setting(e, name);
+	return a ? a->load() : -1;
+}
+int mjr_env_set_setting(mjr_env *e, const char *name, int value)
+{
+	auto *a = setting(e, name);
+	if (!a) return -1;
+	a->store(value);
+	return 0;
+}
+int mjr_env_set_ctrl_noise(mjr_env *e, double std, double rate)
+{
+	std::lock_guard<MujocoEnvMutex> lock(e->env->physics_thread_mutex_);
+	e->env->ctrl_noise_std = std;
+	e->env->ctrl_noise_rate = rate;
+	if (e->env->backend()) return e->env->backend()->set_ctrl_noise(e->env->backend()->self, std, rate, 12345, 0);
+	return 0;
+}
+double mjr_env_sim_time(mjr_env *e) { return e->env->simTime(); }
+unsigned long long mjr_env_step_count(mjr_env *e) { return e->env->stepCount(); }
+int mjr_env_nenv(mjr_env *e) { return e->env->nenv(); }
+int mjr_env_name2id(mjr_env *e, int objtype, const char *name)
+{
+	const mjModel *m = e->env->getModelPtr();
+	return m ? mj_name2id(m, objtype, name) : -1;
+}
+int mjr_env_get_field(mjr_env *e, int field, int env, double *out)
+{
+	std::lock_guard<MujocoEnvMutex> lock(e->env->physics_thread_mutex_);
+	mjr_backend *b = e->env->backend();
+	if (!b) return -1;
+	return b->get(b->self, field, env, env + 1, out);
+}
+int mjr_env_set_field(mjr_env *e, int field, int env, const double *in)
+{
+	std::lock_guard<MujocoEnvMutex> lock(e->env->physics_thread_mutex_);
+	mjr_backend *b = e->env->backend();
+	if (!b) return -1;
+	return b->set(b->self, field, env, env + 1, in);
+}
+int mjr_env_num_plugins(mjr_env *e) { return (int)e->env->getPlugins().size(); }
+int mjr_env_num_cb_ready_plugins(mjr_env *e)
+{
+	int n = 0;
+	for (const auto &p : e->env->getPlugins()) n += p->loadingSuccessful() ? 1 : 0;
+	return n;
+}
+int mjr_env_test_plugin_flag(mjr_env *e, int i, const char *name, int clear)
+{
+	const auto &pl = e->env->getPlugins();
+	if (i < 0 || i >= (int)pl.size()) return -1;
+	TestPlugin *t = dynamic_cast<TestPlugin *>(pl[i].get());
+	if (!t) return -1;
+	std::map<std::string, std::atomic_bool *> flags = {
+		{ "ran_reset", &t->ran_reset }, { "ran_control_cb", &t->ran_control_cb }, { "ran_passive_cb", &t->ran_passive_cb },
+		{ "ran_render_cb", &t->ran_render_cb }, { "ran_last_cb", &t->ran_last_cb },
+		{ "ran_on_geom_changed_cb", &t->ran_on_geom_changed_cb }, { "got_config_param", &t->got_config_param },
+		{ "got_lvl1_nested_array", &t->got_lvl1_nested_array }, { "got_lvl2_nested_array", &t->got_lvl2_nested_array },
+		{ "got_lvl1_nested_struct", &t->got_lvl1_nested_struct }, { "got_lvl2_nested_struct", &t->got_lvl2_nested_struct },
+		{ "should_fail", &t->should_fail }
+	};
+	auto it = flags.find(name);
+	if (it != flags.end()) {
+		int v = it->second->load() ? 1 : 0;
+		if (clear) it->second->store(false);
+		return v;
+	}
+	if (!strcmp(name, "control_calls")) {
+		int v = t->control_calls.load();
+		if (clear) t->control_calls.store(0);
+		return v;
+	}
+	if (!strcmp(name, "last_env")) return t->last_env.load();
+	return -1;
+}
+int mjr_env_notify_geom_changed(mjr_env *e, int geom_id)
+{
+	e->env->notifyGeomChanged(geom_id);
+	return 0;
+}
+int mjr_env_set_callback_envs(mjr_env *e, int n)
+{
+	e->env->setCallbackEnvs(n);
+	return 0;
+}
+
+}  // extern "C"

@@ -186,8 +186,9 @@ class Model(dict):
 
 # --------------------------------------------------------------------------- the compiler
 class _Compiler:
-    def __init__(self, root, nconmax=None, nefcmax=None):
+    def __init__(self, root, nconmax=None, nefcmax=None, disable=()):
         self.root = root
+        self.extra_disable = tuple(disable)
         self.nconmax_req = nconmax
         self.nefcmax_req = nefcmax
         self.angle_scale = math.pi / 180.0  # MJCF default: degrees
@@ -276,6 +277,8 @@ class _Compiler:
                 raise MjcfError(f"unsupported top-level element <{t}>")
         if not self.bodies:
             self._body(ET.Element("worldbody"), parent=-1, childclass=None, is_world=True)
+        for k in self.extra_disable:
+            self.opt["disableflags"] |= DISABLE_BITS[k]
         return self._finalize()
 
     def _compiler(self, node):
@@ -689,10 +692,6 @@ class _Compiler:
                 body_iquat[bi] = Iin["quat"]
             elif b["geoms"] and bi > 0 and self.inertiafromgeom != "false":
                 body_mass[bi], body_ipos[bi], body_iquat[bi], body_inertia[bi] = _inertia_from_geoms(b["geoms"])
-            if bi > 0 and body_dofnum[bi] > 0 or (bi > 0 and weldid[bi] != 0):
-                if body_mass[bi] < mjMINVAL or np.any(body_inertia[bi] < mjMINVAL):
-                    if weldid[bi] == bi and not self._has_massive_descendant(bi, body_mass):
-                        raise MjcfError(f"mass and inertia of moving body '{b['name']}' must be positive")
         m.update(body_mass=body_mass, body_inertia=body_inertia, body_ipos=body_ipos, body_iquat=body_iquat)
         m["body_sameframe"] = np.array(
             [int(np.all(body_ipos[i] == 0) and np.all(body_iquat[i] == [1, 0, 0, 0])) for i in range(nbody)], I)
@@ -700,6 +699,9 @@ class _Compiler:
         for bi in range(nbody - 1, 0, -1):
             sub[B[bi]["parent"]] += sub[bi]
         m["body_subtreemass"] = sub
+        for bi in range(1, nbody):
+            if body_dofnum[bi] > 0 and sub[bi] < mjMINVAL:
+                raise MjcfError(f"mass and inertia of moving body '{B[bi]['name']}' must be larger than mjMINVAL")
 
         # sites
         m["site_bodyid"] = np.array([s["body"] for s in S], I)
@@ -795,12 +797,6 @@ class _Compiler:
         m["dof_invweight0"] = dof_inv
         m["body_invweight0"] = body_inv
         return m
-
-    def _has_massive_descendant(self, bi, mass):
-        for ci, c in enumerate(self.bodies):
-            if ci > bi and c["parent"] == bi and (mass[ci] >= mjMINVAL or self._has_massive_descendant(ci, mass)):
-                return True
-        return False
 
     def _collision_pairs(self, m):
         if m["disableflags"] & (DISABLE_BITS["contact"] | DISABLE_BITS["constraint"]):
@@ -935,13 +931,14 @@ def _inertia_from_geoms(geoms):
 
 
 # --------------------------------------------------------------------------- public entry points
-def compile_xml_string(xml, nconmax=None, nefcmax=None):
-    return _Compiler(ET.fromstring(xml), nconmax, nefcmax).compile()
+def compile_xml_string(xml, nconmax=None, nefcmax=None, disable=()):
+    """``disable``: extra mjtDisableBit names (e.g. ("contact",)) OR-ed into opt.disableflags."""
+    return _Compiler(ET.fromstring(xml), nconmax, nefcmax, disable).compile()
 
 
-def compile_xml_file(path, nconmax=None, nefcmax=None):
+def compile_xml_file(path, nconmax=None, nefcmax=None, disable=()):
     with open(path, "r") as f:
-        return compile_xml_string(f.read(), nconmax, nefcmax)
+        return compile_xml_string(f.read(), nconmax, nefcmax, disable)
 
 
 ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")

@@ -1,0 +1,82 @@
+"""C-ABI checks that need no GPU: the libraries load, export every symbol the headers declare, validate
+models on the host, and refuse to compute without a HIP device (no CPU fallback)."""
+import ctypes as C
+import re
+import os
+
+import numpy as np
+import pytest
+
+from mujoco_ros_pkgs_amd import binding, mjcf
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    if not os.path.exists(binding.LIB_PATH):
+        g.build()
+    return binding.load_library()
+
+
+def test_libmjb_exports_every_declared_symbol(lib):
+    declared = binding.header_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"libmjb.so does not export {name} (declared in include/mjb.h)"
+    # and the ctypes mirror declares each of them
+    assert set(declared) == set(lib._mjb_symbols)
+
+
+def test_libmjr_host_exports_every_declared_symbol(lib):
+    from mujoco_ros_pkgs_amd import host_binding
+    L = host_binding.load_library()
+    txt = open(os.path.join(binding.INCLUDE, "mjr_host.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(mjr_[a-z0-9_]+)\s*\(", txt)) - {"mjr_backend_factory"})
+    for name in declared:
+        assert hasattr(L, name), f"libmjr_host.so does not export {name}"
+    assert set(declared) == set(L._mjr_symbols)
+
+
+def test_field_tables_consistent(lib, franka):
+    from mujoco_ros_pkgs_amd import engine
+    cm = engine.CompiledModel(franka)
+    assert binding.Field.names[0] == "qpos"
+    for i, name in enumerate(binding.Field.names):
+        assert lib.mjb_field_name(i).decode() == name
+        assert lib.mjb_field_size(cm.ptr, i) == binding.Field.dim(franka, name), name
+        assert bool(lib.mjb_field_is_int(i)) == (binding.Field.kinds[name] == "DI")
+        assert bool(lib.mjb_field_is_state(i)) == (binding.Field.kinds[name] == "DS")
+    assert cm.frame_doubles * 8 <= 16 * 1024  # one env's LDS frame
+
+
+def test_compile_rejects_bad_models(lib, franka):
+    from mujoco_ros_pkgs_amd import engine
+    bad = dict(franka)
+    bad["nM"] = franka["nM"] + 1
+    with pytest.raises(engine.EngineError, match="nM"):
+        engine.CompiledModel(mjcf.Model(bad))
+    bad = dict(franka)
+    bad["timestep"] = np.array([0.0])
+    with pytest.raises(engine.EngineError, match="timestep"):
+        engine.CompiledModel(mjcf.Model(bad))
+    bad = dict(franka)
+    bad["integrator"] = 1
+    with pytest.raises(engine.EngineError, match="Euler"):
+        engine.CompiledModel(mjcf.Model(bad))
+    assert lib.mjb_compile(None) is None
+
+
+def test_no_cpu_fallback(lib, franka):
+    """Without a HIP device every compute entry point fails loudly (MJB_ENODEVICE), it never computes on the CPU."""
+    from mujoco_ros_pkgs_amd import engine
+    if lib.mjb_device_count() > 0:
+        pytest.skip("a GPU is present")
+    cm = engine.CompiledModel(franka)
+    with pytest.raises(engine.EngineError, match="no HIP device"):
+        engine.Batch(cm, 4)
+    from mujoco_ros_pkgs_amd import host_binding
+    L = host_binding.load_library()
+    desc, keep = binding.make_desc(franka)
+    assert not L.mjr_make_mjb_backend(C.byref(desc), 4, 0, None)
+    assert b"no HIP device" in L.mjr_last_error()
