@@ -105,7 +105,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from mujoco_ros_pkgs_amd import engine, mjcf
+    from mujoco_ros_pkgs_amd import engine, mjcf, sharding
 
     model = mjcf.load_asset(args.model)
     cm = engine.CompiledModel(model)
@@ -116,7 +116,8 @@ def main():
     batch.set("qpos", qpos)
     batch.set("qvel", qvel)
     # reference injector: tau = 0.1 s, std = 0.5 * ctrlrange (87 N m on the big joints), seed 12345
-    batch.set_ctrl_noise(0.5 * 87.0, 0.1, 12345, rank * E)
+    env_lo, _ = sharding.shard_range(rank, world, E)
+    batch.set_ctrl_noise(0.5 * 87.0, 0.1, 12345, env_lo)
     batch.synchronize()
 
     nsd = model["nsensordata"]
@@ -127,7 +128,7 @@ def main():
         batch.step(S)
         if world > 1:
             batch.synchronize()  # kernel ran on the engine's stream; the gather runs on torch's
-            dist.all_gather_into_tensor(sens_all, sens_local)
+            sharding.gather_sensordata(sens_local, sens_all)
 
     def fence():
         if world > 1:
@@ -154,6 +155,13 @@ def main():
     kern_ms = batch.time_steps(S, max(1, min(args.steps, 5)))
 
     if rank == 0:
+        traffic = None
+        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, 4096 envs x 1000 steps)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.json")))
+            if (E, S) == (4096, 1000):
+                traffic = (pmc["FETCH_SIZE"]["mean_per_dispatch"] + pmc["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
+        except Exception:
+            traffic = None
         value = world * E * S * args.steps / elapsed
         bytes_per_launch = ALGO_BYTES_PER_ENV_STEP.get(args.model, 712) * E * S
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
@@ -168,7 +176,7 @@ def main():
                        "parallelism": f"env-sharded x{world}, RCCL all-gather of sensordata per launch" if world > 1
                        else "single GPU", "state_finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mjb_step_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
