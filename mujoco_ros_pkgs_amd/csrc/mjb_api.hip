@@ -77,7 +77,7 @@ struct mjb_model {
 	std::vector<int> hint;            // all int arrays, concatenated
 	std::vector<double> hdbl;         // all double arrays, concatenated
 	std::vector<size_t> ioff, doff;   // offsets of each array inside hint / hdbl (declaration order)
-	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg;
+	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask;
 	int eulerdamp = 0, maxdepth = 0;
 	int field_size[MJB_F_COUNT]{};
 	FrameLayout L{};
@@ -128,6 +128,7 @@ void compute_layout(mjb_model *M, bool use_xfrc)
 	(void)use_xfrc;
 	for (const FieldInfo &fi : kFields) {
 		int n = dim(fi);
+		if (idx == MJB_F_efc_AR) n = 0;  // the GPU solver is AR-free
 		M->field_size[idx] = n;
 		if (fi.kind == 3) {
 			*slots[idx] = ioff;
@@ -152,6 +153,11 @@ void compute_layout(mjb_model *M, bool use_xfrc)
 	}
 	if (off & 1) off++;
 	L.ndouble = off;
+	L.iscratch = ioff;
+	{
+		int a = d.ncollpair, b = d.njnt + d.nconmax;
+		ioff += a > b ? a : b;
+	}
 	L.nint = (ioff + 1) & ~1;
 	L.nstate = nstate;
 }
@@ -202,9 +208,20 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		return nullptr;
 	}
 	if (d.nefcmax > 0 || d.nconmax > 0) {
-		fail(MJB_EUNSUPPORTED, "mjb_compile: contact/limit constraints are not implemented in this build "
-		                       "(disable them with <flag contact=\"disable\"/> or nconmax = nefcmax = 0)");
-		return nullptr;
+		if (d.solver != MJB_SOL_PGS || d.cone != MJB_CONE_PYRAMIDAL) {
+			fail(MJB_EUNSUPPORTED, "mjb_compile: models with constraint rows need solver=PGS and cone=pyramidal "
+			                       "(Newton / CG / elliptic cones are not implemented)");
+			return nullptr;
+		}
+		if (d.nefcmax > 64 || d.nv > 64) {
+			fail(MJB_EUNSUPPORTED, "mjb_compile: the constraint solver maps rows to the 64 lanes of one wavefront: "
+			                       "nefcmax = %d, nv = %d (both must be <= 64)", d.nefcmax, d.nv);
+			return nullptr;
+		}
+		if (!(d.meaninertia[0] > 0)) {
+			fail(MJB_EINVAL, "mjb_compile: meaninertia must be positive");
+			return nullptr;
+		}
 	}
 	mjb_model *M = new (std::nothrow) mjb_model;
 	if (!M) {
@@ -333,6 +350,16 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		}
 	}
 	M->fac_beg.push_back((int)M->fac_ops.size() / 4);
+	// ancestor-dof bit masks per body (contact Jacobians)
+	M->body_dofmask.assign((size_t)2 * h.nbody, 0);
+	if (h.nv <= 64)
+		for (int b = 1; b < h.nbody; b++) {
+			int bb = b;
+			while (bb > 0 && h.body_dofnum[bb] == 0) bb = h.body_parentid[bb];
+			if (bb == 0) continue;
+			for (int i = h.body_dofadr[bb] + h.body_dofnum[bb] - 1; i >= 0; i = h.dof_parentid[i])
+				M->body_dofmask[2 * b + (i >> 5)] |= (int)(1u << (i & 31));
+		}
 	M->eulerdamp = 0;
 	if (!(h.disableflags & MJB_DSBL_EULERDAMP))
 		for (int i = 0; i < h.nv; i++)
@@ -411,7 +438,8 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	// ---- device model blob: [ints | doubles | derived int tables]
 	size_t ni = M->hint.size(), nd = M->hdbl.size();
 	size_t nt = M->M_rowdof.size() + M->M_coldof.size() + M->dof_depth.size() + M->dof_jstart.size() +
-	            M->body_rec.size() + M->body_rec2.size() + M->dof_rec.size() + M->fac_ops.size() + M->fac_beg.size() + 64;
+	            M->body_rec.size() + M->body_rec2.size() + M->dof_rec.size() + M->fac_ops.size() + M->fac_beg.size() +
+	            M->body_dofmask.size() + 64;
 	size_t bytes_i = ((ni + nt) * sizeof(int) + 15) & ~size_t(15);
 	size_t bytes = bytes_i + nd * sizeof(double) + 16;
 	if (hipMalloc(&b->blob, bytes) != hipSuccess) {
@@ -433,7 +461,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	};
 	size_t o_row = put(M->M_rowdof), o_col = put(M->M_coldof), o_dep = put(M->dof_depth), o_js = put(M->dof_jstart);
 	size_t o_br = put(M->body_rec), o_br2 = put(M->body_rec2), o_dr = put(M->dof_rec), o_fo = put(M->fac_ops),
-	       o_fb = put(M->fac_beg);
+	       o_fb = put(M->fac_beg), o_dm = put(M->body_dofmask);
 	if (nd) memcpy(hd, M->hdbl.data(), nd * sizeof(double));
 	if (hipMemcpy(b->blob, hostblob.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
 		fail(MJB_ENODEVICE, "mjb_make_batch: model upload failed");
@@ -466,6 +494,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	dm.dof_rec = (mjb_ciptr)(di + o_dr);
 	dm.fac_ops = (mjb_ciptr)(di + o_fo);
 	dm.fac_beg = (mjb_ciptr)(di + o_fb);
+	dm.body_dofmask = (mjb_ciptr)(di + o_dm);
 	dm.eulerdamp = M->eulerdamp;
 	dm.maxdepth = M->maxdepth;
 
@@ -518,7 +547,10 @@ int mjb_nenv(const mjb_batch *b) { return b ? b->nenv : fail(MJB_EINVAL, "null b
 int mjb_set_launch(mjb_batch *b, int lanes_per_env, int envs_per_block)
 {
 	if (!b) return fail(MJB_EINVAL, "null batch");
-	if (lanes_per_env == 0) lanes_per_env = 16;
+	const bool constrained = b->model->h.nefcmax > 0;
+	if (lanes_per_env == 0) lanes_per_env = constrained ? 64 : 16;
+	if (constrained && lanes_per_env != 64)
+		return fail(MJB_EINVAL, "mjb_set_launch: models with constraint rows run one env per wavefront (lanes_per_env = 64)");
 	if (lanes_per_env != 8 && lanes_per_env != 16 && lanes_per_env != 32 && lanes_per_env != 64)
 		return fail(MJB_EINVAL, "mjb_set_launch: lanes_per_env must be 8, 16, 32 or 64");
 	if (envs_per_block <= 0) envs_per_block = 64 / lanes_per_env;  // one wavefront per workgroup

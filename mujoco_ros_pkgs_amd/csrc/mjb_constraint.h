@@ -1,0 +1,737 @@
+// mjb_constraint.h — contact / limit constraint path of the step kernel (included by mjb_step.hip).
+//
+// SURVEY.md §8a rows A4-A7 and A13 for the primitive subset of include/mjb.h: plane / sphere / capsule /
+// box geoms (pairs of collpair_geom), hinge / slide joint limits, frictionless + pyramidal contacts, PGS.
+// ONE env per wavefront (G = 64): constraint rows map to lanes (nefcmax <= 64), the dual variables live in
+// registers and are exchanged with v_readlane, so the Gauss-Seidel sweep touches LDS only for the two
+// nv-long rows J_i and B_i = (M^-1 J')_i it needs per row.  The solver is AR-free: the residual
+// A_i f + b_i is evaluated as  J_i . w + R_i f_i + b_i  with  w = M^-1 J' f  kept per lane (lane k holds
+// w[k]) and updated by  w += B_i * delta  -- O(nv) per row instead of O(nefc), and no nefc^2 matrix in LDS.
+#pragma once
+
+struct RawCon {
+	double dist, pos[3], frame[6];  // normal, first-tangent hint (zero: none)
+};
+
+DEVI void make_frame(double *fr)  // fr[9]: normal, tangent hint -> orthonormal frame (mju_makeFrame)
+{
+	normalize3(fr);
+	if (sqrt(dot3(fr + 3, fr + 3)) < 0.5) {
+		fr[3] = fr[4] = fr[5] = 0;
+		if (fr[1] < 0.5 && fr[1] > -0.5) fr[4] = 1;
+		else fr[5] = 1;
+	}
+	const double t = dot3(fr, fr + 3);
+	fr[3] -= t * fr[0]; fr[4] -= t * fr[1]; fr[5] -= t * fr[2];
+	normalize3(fr + 3);
+	cross3(fr + 6, fr, fr + 3);
+}
+
+DEVI int raw_sphere_sphere(RawCon &c, const double *p1, double r1, const double *p2, double r2, double margin)
+{
+	double dif[3] = { p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2] };
+	const double cdist = sqrt(dot3(dif, dif));
+	if (cdist > margin + r1 + r2) return 0;
+	c.dist = cdist - r1 - r2;
+	c.frame[0] = dif[0]; c.frame[1] = dif[1]; c.frame[2] = dif[2];
+	c.frame[3] = c.frame[4] = c.frame[5] = 0;
+	normalize3(c.frame);
+	for (int k = 0; k < 3; k++) c.pos[k] = p1[k] + c.frame[k] * (r1 + 0.5 * c.dist);
+	return 1;
+}
+
+DEVI int raw_plane_sphere(RawCon &c, const double *pos1, const double *n, const double *p, double r, double margin)
+{
+	double tmp[3] = { p[0] - pos1[0], p[1] - pos1[1], p[2] - pos1[2] };
+	const double cdist = dot3(tmp, n);
+	if (cdist > margin + r) return 0;
+	c.dist = cdist - r;
+	c.frame[0] = n[0]; c.frame[1] = n[1]; c.frame[2] = n[2];
+	c.frame[3] = c.frame[4] = c.frame[5] = 0;
+	for (int k = 0; k < 3; k++) c.pos[k] = p[k] - n[k] * (r + 0.5 * c.dist);
+	return 1;
+}
+
+DEVI double clipd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// narrow phase of one candidate pair; returns the number of raw contacts (<= 4)
+DEVI int narrowphase(int t1, int t2, const double *pos1, const double *mat1, const double *size1, const double *pos2,
+                     const double *mat2, const double *size2, double margin, RawCon *rc)
+{
+	int n = 0;
+	if (t1 == MJB_GEOM_PLANE) {
+		const double nrm[3] = { mat1[2], mat1[5], mat1[8] };
+		if (t2 == MJB_GEOM_SPHERE) {
+			n = raw_plane_sphere(rc[0], pos1, nrm, pos2, size2[0], margin);
+		} else if (t2 == MJB_GEOM_CAPSULE) {
+			const double axis[3] = { mat2[2], mat2[5], mat2[8] };
+			double p[3] = { pos2[0] + axis[0] * size2[1], pos2[1] + axis[1] * size2[1], pos2[2] + axis[2] * size2[1] };
+			n = raw_plane_sphere(rc[0], pos1, nrm, p, size2[0], margin);
+			p[0] = pos2[0] - axis[0] * size2[1]; p[1] = pos2[1] - axis[1] * size2[1]; p[2] = pos2[2] - axis[2] * size2[1];
+			if (n) n += raw_plane_sphere(rc[1], pos1, nrm, p, size2[0], margin);
+			else n += raw_plane_sphere(rc[0], pos1, nrm, p, size2[0], margin);
+			for (int i = 0; i < 2; i++)
+				if (i < n) { rc[i].frame[3] = axis[0]; rc[i].frame[4] = axis[1]; rc[i].frame[5] = axis[2]; }
+		} else if (t2 == MJB_GEOM_BOX) {
+			const double dif[3] = { pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2] };
+			const double dist = dot3(dif, nrm);
+			for (int i = 0; i < 8; i++) {
+				if (n >= 4) break;
+				const double vec[3] = { (i & 1) ? size2[0] : -size2[0], (i & 2) ? size2[1] : -size2[1],
+					                    (i & 4) ? size2[2] : -size2[2] };
+				double corner[3];
+				matvec3(corner, mat2, vec);
+				const double ldist = dot3(nrm, corner);
+				if (dist + ldist > margin || ldist > 0) continue;
+				RawCon c;
+				c.dist = dist + ldist;
+				c.frame[0] = nrm[0]; c.frame[1] = nrm[1]; c.frame[2] = nrm[2];
+				c.frame[3] = c.frame[4] = c.frame[5] = 0;
+				for (int k = 0; k < 3; k++) c.pos[k] = corner[k] + pos2[k] - nrm[k] * c.dist * 0.5;
+				// (n is lane-varying: select the slot without dynamic register indexing)
+				if (n == 0) rc[0] = c;
+				else if (n == 1) rc[1] = c;
+				else if (n == 2) rc[2] = c;
+				else rc[3] = c;
+				n++;
+			}
+		}
+	} else if (t1 == MJB_GEOM_SPHERE) {
+		if (t2 == MJB_GEOM_SPHERE) {
+			n = raw_sphere_sphere(rc[0], pos1, size1[0], pos2, size2[0], margin);
+		} else if (t2 == MJB_GEOM_CAPSULE) {
+			const double axis[3] = { mat2[2], mat2[5], mat2[8] };
+			const double vec[3] = { pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2] };
+			const double x = clipd(dot3(axis, vec), -size2[1], size2[1]);
+			const double p[3] = { pos2[0] + axis[0] * x, pos2[1] + axis[1] * x, pos2[2] + axis[2] * x };
+			n = raw_sphere_sphere(rc[0], pos1, size1[0], p, size2[0], margin);
+		} else if (t2 == MJB_GEOM_BOX) {
+			const double r1 = size1[0];
+			const double tmp[3] = { pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2] };
+			double center[3], clamped[3], dv[3];
+			matTvec3(center, mat2, tmp);
+			for (int i = 0; i < 3; i++) {
+				clamped[i] = clipd(center[i], -size2[i], size2[i]);
+				dv[i] = clamped[i] - center[i];
+			}
+			const double dist = sqrt(dot3(dv, dv));
+			if (!(dist - r1 > margin)) {
+				double nloc[3] = { 0, 0, 0 }, ploc[3];
+				RawCon &c = rc[0];
+				if (dist <= MJB_MINVAL) {
+					double closest = 2 * fmax(size2[0], fmax(size2[1], size2[2]));
+					int kk = 0;
+					for (int i = 0; i < 6; i++) {
+						const double fd = fabs(((i % 2) ? 1 : -1) * size2[i / 2] - center[i / 2]);
+						if (closest > fd) {
+							closest = fd;
+							kk = i;
+						}
+					}
+					const double sgn = (kk % 2) ? -1.0 : 1.0;
+					nloc[0] = (kk / 2 == 0) ? sgn : 0.0; nloc[1] = (kk / 2 == 1) ? sgn : 0.0; nloc[2] = (kk / 2 == 2) ? sgn : 0.0;
+					for (int i = 0; i < 3; i++) ploc[i] = center[i] + nloc[i] * (r1 - closest) / 2;
+					c.dist = -closest - r1;
+				} else {
+					for (int i = 0; i < 3; i++) {
+						const double deepest = center[i] + dv[i] * (r1 / dist);
+						ploc[i] = 0.5 * (clamped[i] + deepest);
+						nloc[i] = dv[i] / dist;
+					}
+					c.dist = dist - r1;
+				}
+				matvec3(c.frame, mat2, nloc);
+				c.frame[3] = c.frame[4] = c.frame[5] = 0;
+				matvec3(c.pos, mat2, ploc);
+				c.pos[0] += pos2[0]; c.pos[1] += pos2[1]; c.pos[2] += pos2[2];
+				n = 1;
+			}
+		}
+	} else if (t1 == MJB_GEOM_CAPSULE && t2 == MJB_GEOM_CAPSULE) {
+		const double a1[3] = { mat1[2], mat1[5], mat1[8] }, a2[3] = { mat2[2], mat2[5], mat2[8] };
+		const double dif[3] = { pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2] };
+		const double ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2);
+		const double u = -dot3(a1, dif), v = dot3(a2, dif);
+		const double det = ma * mc - mb * mb;
+		double p1[3], p2[3];
+		if (fabs(det) >= MJB_MINVAL) {
+			double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+			if (x1 > size1[1]) {
+				x1 = size1[1];
+				x2 = (v - mb * size1[1]) / mc;
+			} else if (x1 < -size1[1]) {
+				x1 = -size1[1];
+				x2 = (v + mb * size1[1]) / mc;
+			}
+			if (x2 > size2[1]) {
+				x2 = size2[1];
+				x1 = clipd((u - mb * size2[1]) / ma, -size1[1], size1[1]);
+			} else if (x2 < -size2[1]) {
+				x2 = -size2[1];
+				x1 = clipd((u + mb * size2[1]) / ma, -size1[1], size1[1]);
+			}
+			for (int k = 0; k < 3; k++) {
+				p1[k] = pos1[k] + a1[k] * x1;
+				p2[k] = pos2[k] + a2[k] * x2;
+			}
+			n = raw_sphere_sphere(rc[0], p1, size1[0], p2, size2[0], margin);
+		} else {
+			for (int s = 1; s >= -1; s -= 2) {
+				if (n >= 2) break;
+				for (int k = 0; k < 3; k++) p1[k] = pos1[k] + a1[k] * s * size1[1];
+				const double d2[3] = { p1[0] - pos2[0], p1[1] - pos2[1], p1[2] - pos2[2] };
+				const double x2 = clipd(dot3(a2, d2) / mc, -size2[1], size2[1]);
+				for (int k = 0; k < 3; k++) p2[k] = pos2[k] + a2[k] * x2;
+				RawCon c;
+				if (raw_sphere_sphere(c, p1, size1[0], p2, size2[0], margin)) {
+					if (n == 0) rc[0] = c; else rc[1] = c;
+					n++;
+				}
+			}
+			for (int s = 1; s >= -1; s -= 2) {
+				if (n >= 2) break;
+				for (int k = 0; k < 3; k++) p2[k] = pos2[k] + a2[k] * s * size2[1];
+				const double d1[3] = { p2[0] - pos1[0], p2[1] - pos1[1], p2[2] - pos1[2] };
+				const double x1 = clipd(dot3(a1, d1) / ma, -size1[1], size1[1]);
+				if (fabs(fabs(x1) - size1[1]) < MJB_MINVAL) continue;
+				for (int k = 0; k < 3; k++) p1[k] = pos1[k] + a1[k] * x1;
+				RawCon c;
+				if (raw_sphere_sphere(c, p1, size1[0], p2, size2[0], margin)) {
+					if (n == 0) rc[0] = c; else rc[1] = c;
+					n++;
+				}
+			}
+		}
+	}
+	return n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A4 + A5  collision: one candidate pair per lane, contacts compacted in pair order
+// ------------------------------------------------------------------------------------------------
+template <int G> STAGE void collision(CModel m, CLayout L, const Env &e)
+{
+	double *f = e.f;
+	int *fi = e.fi;
+	const int lane = e.lane;
+	if (lane == 0) fi[L.ncon] = 0;
+	if (m.nconmax <= 0 || (m.disableflags & (MJB_DSBL_CONSTRAINT | MJB_DSBL_CONTACT))) {
+		gsync<G>();
+		return;
+	}
+	int *cnt = fi + L.iscratch;  // transient per-pair contact counts
+	int base = 0;
+	for (int p0 = 0; p0 < m.ncollpair; p0 += G) {
+		const int p = p0 + lane;
+		RawCon rc[4];
+		int n = 0, g1 = 0, g2 = 0;
+		double margin = 0, gap = 0;
+		if (p < m.ncollpair) {
+			g1 = m.collpair_geom[2 * p];
+			g2 = m.collpair_geom[2 * p + 1];
+			const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+			double pos1[3], pos2[3], mat1[9], mat2[9], size1[3], size2[3];
+			ld3(pos1, f + L.geom_xpos + 3 * g1);
+			ld3(pos2, f + L.geom_xpos + 3 * g2);
+			ld9(mat1, f + L.geom_xmat + 9 * g1);
+			ld9(mat2, f + L.geom_xmat + 9 * g2);
+			ldc3(size1, m.geom_size + 3 * g1);
+			ldc3(size2, m.geom_size + 3 * g2);
+			margin = fmax(m.geom_margin[g1], m.geom_margin[g2]);
+			gap = fmax(m.geom_gap[g1], m.geom_gap[g2]);
+			const double rb1 = m.geom_rbound[g1], rb2 = m.geom_rbound[g2];
+			bool cull = false;
+			const double dv[3] = { pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2] };
+			if (rb1 > 0 && rb2 > 0) {
+				const double bound = margin + rb1 + rb2;
+				cull = dot3(dv, dv) > bound * bound;
+			} else if (t1 == MJB_GEOM_PLANE && rb2 > 0) {
+				const double nrm[3] = { mat1[2], mat1[5], mat1[8] };
+				cull = dot3(dv, nrm) > margin + rb2;
+			}
+			if (!cull) {
+				const int nr = narrowphase(t1, t2, pos1, mat1, size1, pos2, mat2, size2, margin, rc);
+				// keep contacts with dist < margin, preserving order
+				RawCon keep[4];
+				for (int i = 0; i < 4; i++) {
+					if (i < nr && rc[i].dist < margin) {
+						if (n == 0) keep[0] = rc[i];
+						else if (n == 1) keep[1] = rc[i];
+						else if (n == 2) keep[2] = rc[i];
+						else keep[3] = rc[i];
+						n++;
+					}
+				}
+				for (int i = 0; i < 4; i++) rc[i] = keep[i];
+			}
+			cnt[p] = n;
+		}
+		gsync<G>();
+		if (p < m.ncollpair && n > 0) {
+			int off = base;
+			for (int q = p0; q < p; q++) off += cnt[q];
+			int condim;
+			double solref[2], solimp[5], fri[3];
+			{  // mj_contactParam
+				const int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];
+				if (pr1 != pr2) {
+					const int g = pr1 > pr2 ? g1 : g2;
+					condim = m.geom_condim[g];
+					for (int k = 0; k < 2; k++) solref[k] = m.geom_solref[2 * g + k];
+					for (int k = 0; k < 5; k++) solimp[k] = m.geom_solimp[5 * g + k];
+					for (int k = 0; k < 3; k++) fri[k] = m.geom_friction[3 * g + k];
+				} else {
+					const int c1 = m.geom_condim[g1], c2 = m.geom_condim[g2];
+					condim = c1 > c2 ? c1 : c2;
+					const double s1 = m.geom_solmix[g1], s2 = m.geom_solmix[g2];
+					double mix;
+					if (s1 >= MJB_MINVAL && s2 >= MJB_MINVAL) mix = s1 / (s1 + s2);
+					else if (s1 < MJB_MINVAL && s2 < MJB_MINVAL) mix = 0.5;
+					else if (s1 < MJB_MINVAL) mix = 0.0;
+					else mix = 1.0;
+					const double r10 = m.geom_solref[2 * g1], r20 = m.geom_solref[2 * g2];
+					for (int k = 0; k < 2; k++) {
+						const double a = m.geom_solref[2 * g1 + k], b = m.geom_solref[2 * g2 + k];
+						solref[k] = (r10 > 0 && r20 > 0) ? mix * a + (1 - mix) * b : fmin(a, b);
+					}
+					for (int k = 0; k < 5; k++) solimp[k] = mix * m.geom_solimp[5 * g1 + k] + (1 - mix) * m.geom_solimp[5 * g2 + k];
+					for (int k = 0; k < 3; k++) fri[k] = fmax(m.geom_friction[3 * g1 + k], m.geom_friction[3 * g2 + k]);
+				}
+			}
+			for (int i = 0; i < 4; i++) {
+				if (i >= n) break;
+				const int c = off + i;
+				if (c >= m.nconmax) break;
+				double fr[9];
+				for (int k = 0; k < 6; k++) fr[k] = rc[i].frame[k];
+				make_frame(fr);
+				f[L.contact_dist + c] = rc[i].dist;
+				st3(f + L.contact_pos + 3 * c, rc[i].pos);
+				st9(f + L.contact_frame + 9 * c, fr);
+				f[L.contact_includemargin + c] = margin - gap;
+				double *f5 = f + L.contact_friction + 5 * c;
+				f5[0] = fri[0]; f5[1] = fri[0]; f5[2] = fri[1]; f5[3] = fri[2]; f5[4] = fri[2];
+				f[L.contact_solref + 2 * c] = solref[0];
+				f[L.contact_solref + 2 * c + 1] = solref[1];
+				for (int k = 0; k < 5; k++) f[L.contact_solimp + 5 * c + k] = solimp[k];
+				fi[L.contact_geom + 2 * c] = g1;
+				fi[L.contact_geom + 2 * c + 1] = g2;
+				fi[L.contact_dim + c] = condim;
+				fi[L.contact_efc_address + c] = -1;
+			}
+		}
+		const int hi = (p0 + G < m.ncollpair) ? p0 + G : m.ncollpair;
+		for (int q = p0; q < hi; q++) base += cnt[q];
+		gsync<G>();
+	}
+	if (lane == 0) fi[L.ncon] = base < m.nconmax ? base : m.nconmax;
+	gsync<G>();
+}
+
+// getimpedance
+DEVI void impedance(const double *solimp, double pos, double margin, double &imp, double &impP)
+{
+	if (solimp[0] == solimp[1] || solimp[2] <= MJB_MINVAL) {
+		imp = 0.5 * (solimp[0] + solimp[1]);
+		impP = 0;
+		return;
+	}
+	double x = (pos - margin) / solimp[2], sgn = 1;
+	if (x < 0) {
+		x = -x;
+		sgn = -1;
+	}
+	if (x >= 1 || x <= 0) {
+		imp = x >= 1 ? solimp[1] : solimp[0];
+		impP = 0;
+		return;
+	}
+	double y, yP;
+	if (solimp[4] == 1) {
+		y = x;
+		yP = 1;
+	} else if (x <= solimp[3]) {
+		const double a = 1 / pow(solimp[3], solimp[4] - 1);
+		y = a * pow(x, solimp[4]);
+		yP = solimp[4] * a * pow(x, solimp[4] - 1);
+	} else {
+		const double b = 1 / pow(1 - solimp[3], solimp[4] - 1);
+		y = 1 - b * pow(1 - x, solimp[4]);
+		yP = solimp[4] * b * pow(1 - x, solimp[4] - 1);
+	}
+	imp = solimp[0] + y * (solimp[1] - solimp[0]);
+	impP = yP * sgn * (solimp[1] - solimp[0]) / solimp[2];
+}
+
+// R and KBIP of one row (mj_makeImpedance)
+DEVI void row_params(CModel m, CLayout L, double *f, int i, double pos, double margin, const double *solref_in,
+                     const double *solimp, double diag_approx)
+{
+	double sr0 = solref_in[0];
+	const double sr1 = solref_in[1];
+	if (!(m.disableflags & MJB_DSBL_REFSAFE) && sr0 > 0) sr0 = fmax(sr0, 2 * m.timestep[0]);
+	double imp, impP;
+	impedance(solimp, pos, margin, imp, impP);
+	f[L.efc_R + i] = fmax(MJB_MINVAL, (1 - imp) * diag_approx / imp);
+	const double dmax = solimp[1];
+	double K, B;
+	if (sr0 > 0) {
+		K = 1 / fmax(MJB_MINVAL, dmax * dmax * sr0 * sr0 * sr1 * sr1);
+		B = 2 / fmax(MJB_MINVAL, dmax * sr0);
+	} else {
+		K = -sr0 / fmax(MJB_MINVAL, dmax * dmax);
+		B = -sr1 / fmax(MJB_MINVAL, dmax);
+	}
+	f[L.efc_KBIP + 4 * i] = K;
+	f[L.efc_KBIP + 4 * i + 1] = B;
+	f[L.efc_KBIP + 4 * i + 2] = imp;
+	f[L.efc_KBIP + 4 * i + 3] = impP;
+	f[L.efc_pos + i] = pos;
+	f[L.efc_margin + i] = margin;
+}
+
+// does dof `i` move body `b`?  (bit i of the body's ancestor-dof mask, built on the host; nv <= 64)
+DEVI bool dof_moves_body(CModel m, int b, int i)
+{
+	const unsigned int w = (unsigned int)m.body_dofmask[2 * b + (i >> 5)];
+	return (w >> (i & 31)) & 1u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A6  make_constraint: rows for joint limits then contacts (frictionless / pyramidal)
+// ------------------------------------------------------------------------------------------------
+template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
+{
+	double *f = e.f;
+	int *fi = e.fi;
+	const int lane = e.lane, nv = m.nv;
+	if (lane == 0) fi[L.nefc] = 0;
+	if (m.nefcmax <= 0 || (m.disableflags & MJB_DSBL_CONSTRAINT)) {
+		gsync<G>();
+		return;
+	}
+	const int ncon = fi[L.ncon];
+	const bool do_lim = !(m.disableflags & MJB_DSBL_LIMIT), do_con = !(m.disableflags & MJB_DSBL_CONTACT);
+	const int nitem = m.njnt + ncon;   // item = joint (limit rows) or contact
+	int *cnt = fi + L.iscratch;        // transient per-item row counts
+	// pass 1: rows per item
+	for (int it = lane; it < nitem; it += G) {
+		int n = 0;
+		if (it < m.njnt) {
+			const int j = it;
+			if (do_lim && m.jnt_limited[j] && m.jnt_type[j] >= MJB_JNT_SLIDE) {
+				const double value = f[L.qpos + m.jnt_qposadr[j]], margin = m.jnt_margin[j];
+				if (value - m.jnt_range[2 * j] < margin) n++;
+				if (m.jnt_range[2 * j + 1] - value < margin) n++;
+			}
+		} else if (do_con) {
+			const int c = it - m.njnt;
+			if (f[L.contact_dist + c] < f[L.contact_includemargin + c]) {
+				const int dim = fi[L.contact_dim + c];
+				n = dim == 1 ? 1 : 2 * (dim - 1);
+			}
+		}
+		cnt[it] = n;
+	}
+	gsync<G>();
+	// row budget: the first item that does not fit, and everything after it, is dropped
+	int nefc = 0, cut = nitem;
+	for (int it = 0; it < nitem; it++) {
+		const int n = cnt[it];
+		if (nefc + n > m.nefcmax) {
+			cut = it;
+			break;
+		}
+		nefc += n;
+	}
+	// pass 2: row parameters, one item per lane (item order == row order)
+	for (int it0 = 0; it0 < cut; it0 += G) {
+		const int it = it0 + lane;
+		if (it >= cut) continue;
+		int off = 0;
+		for (int q = 0; q < it; q++) off += cnt[q];
+		const int n = cnt[it];
+		if (n == 0) continue;
+		if (it < m.njnt) {
+			const int j = it, da = m.jnt_dofadr[j];
+			const double value = f[L.qpos + m.jnt_qposadr[j]], margin = m.jnt_margin[j];
+			double solref[2] = { m.jnt_solref[2 * j], m.jnt_solref[2 * j + 1] }, solimp[5];
+			for (int k = 0; k < 5; k++) solimp[k] = m.jnt_solimp[5 * j + k];
+			int r = off;
+			for (int side = -1; side <= 1; side += 2) {
+				const double dist = side * (m.jnt_range[2 * j + (side + 1) / 2] - value);
+				if (dist < margin) {
+					double *row = f + L.efc_J + r * nv;
+					for (int k = 0; k < nv; k++) row[k] = 0;
+					row[da] = -side;
+					row_params(m, L, f, r, dist, margin, solref, solimp, m.dof_invweight0[da]);
+					fi[L.efc_id + r] = j;
+					fi[L.efc_type + r] = MJB_CNSTR_LIMIT_JOINT;
+					r++;
+				}
+			}
+		} else {
+			const int c = it - m.njnt;
+			const int dim = fi[L.contact_dim + c];
+			const double dist = f[L.contact_dist + c], cm = f[L.contact_includemargin + c];
+			const int b1 = m.geom_bodyid[fi[L.contact_geom + 2 * c]], b2 = m.geom_bodyid[fi[L.contact_geom + 2 * c + 1]];
+			const double tran = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
+			const double rot = m.body_invweight0[2 * b1 + 1] + m.body_invweight0[2 * b2 + 1];
+			double solref[2] = { f[L.contact_solref + 2 * c], f[L.contact_solref + 2 * c + 1] }, solimp[5], fri[5];
+			for (int k = 0; k < 5; k++) {
+				solimp[k] = f[L.contact_solimp + 5 * c + k];
+				fri[k] = f[L.contact_friction + 5 * c + k];
+			}
+			fi[L.contact_efc_address + c] = off;
+			if (dim == 1) {
+				row_params(m, L, f, off, dist, cm, solref, solimp, tran);
+				fi[L.efc_id + off] = c;
+				fi[L.efc_type + off] = MJB_CNSTR_CONTACT_FRICTIONLESS;
+			} else {
+				int r = off;
+				for (int k = 1; k < dim; k++)
+					for (int sg = 0; sg < 2; sg++) {
+						const double da = tran + fri[k - 1] * fri[k - 1] * ((k - 1) < 2 ? tran : rot);
+						row_params(m, L, f, r, dist, cm, solref, solimp, da);
+						fi[L.efc_id + r] = c;
+						fi[L.efc_type + r] = MJB_CNSTR_CONTACT_PYRAMIDAL;
+						r++;
+					}
+				const double mu = fri[0] / sqrt(fmax(MJB_MINVAL, m.impratio[0]));
+				const double Rpy = fmax(MJB_MINVAL, 2 * mu * mu * f[L.efc_R + off]);
+				for (int q = off; q < r; q++) f[L.efc_R + q] = Rpy;
+			}
+		}
+	}
+	gsync<G>();
+	for (int r = lane; r < nefc; r += G) {
+		f[L.efc_D + r] = 1.0 / f[L.efc_R + r];
+		f[L.efc_force + r] = 0;
+	}
+	if (lane == 0) fi[L.nefc] = nefc;
+	gsync<G>();
+	// contact Jacobian rows: one (contact, dof) pair per lane
+	const int npair = ncon * nv;
+	for (int t = lane; t < npair; t += G) {
+		const int c = t / nv, i = t - c * nv;
+		const int adr = fi[L.contact_efc_address + c];
+		if (adr < 0) continue;
+		const int dim = fi[L.contact_dim + c];
+		const int nrow = dim == 1 ? 1 : 2 * (dim - 1);
+		if (adr + nrow > nefc) continue;
+		const int b1 = m.geom_bodyid[fi[L.contact_geom + 2 * c]], b2 = m.geom_bodyid[fi[L.contact_geom + 2 * c + 1]];
+		const bool in2 = dof_moves_body(m, b2, i), in1 = dof_moves_body(m, b1, i);
+		double jdp[3] = { 0, 0, 0 }, jdr[3] = { 0, 0, 0 };
+		if (in1 != in2) {  // a dof moving both bodies cancels exactly in the reference too (same point, same dof)
+			double cd[6], pos[3], root[3];
+			ld6(cd, f + L.cdof + 6 * i);
+			ld3(pos, f + L.contact_pos + 3 * c);
+			ld3(root, f + L.subtree_com + 3 * m.body_rootid[m.dof_bodyid[i]]);
+			const double off[3] = { pos[0] - root[0], pos[1] - root[1], pos[2] - root[2] };
+			cross3(jdp, cd, off);
+			const double sg = in2 ? 1.0 : -1.0;
+			jdp[0] = sg * (jdp[0] + cd[3]); jdp[1] = sg * (jdp[1] + cd[4]); jdp[2] = sg * (jdp[2] + cd[5]);
+			jdr[0] = sg * cd[0]; jdr[1] = sg * cd[1]; jdr[2] = sg * cd[2];
+		}
+		double fr[9];
+		ld9(fr, f + L.contact_frame + 9 * c);
+		const double j0 = dot3(fr, jdp);
+		if (dim == 1) {
+			f[L.efc_J + adr * nv + i] = j0;
+		} else {
+			int r = adr;
+			for (int k = 1; k < dim; k++) {
+				const double jk = k < 3 ? dot3(fr + 3 * k, jdp) : dot3(fr + 3 * (k - 3), jdr);
+				const double mu = f[L.contact_friction + 5 * c + (k - 1)];
+				f[L.efc_J + r * nv + i] = j0 + mu * jk;
+				f[L.efc_J + (r + 1) * nv + i] = j0 - mu * jk;
+				r += 2;
+			}
+		}
+	}
+	gsync<G>();
+}
+
+// ------------------------------------------------------------------------------------------------
+// A7  project: B = (M^-1 J')' row by row -- one ROW per lane, each lane runs the sparse solve serially on
+// its own row (loop structure is wave-uniform: the scalar table loads are shared by all rows)
+// ------------------------------------------------------------------------------------------------
+template <int G> STAGE void project_constraint(CModel m, CLayout L, const Env &e)
+{
+	double *f = e.f;
+	const int nefc = e.fi[L.nefc], nv = m.nv;
+	if (nefc == 0) return;
+	const double *LD = f + L.qLD, *di = f + L.qLDiagInv;
+	for (int r0 = 0; r0 < nefc; r0 += G) {
+		const int r = r0 + e.lane;
+		const bool act = r < nefc;
+		double *x = f + L.efc_B + (act ? r : 0) * nv;
+		if (act)
+			for (int k = 0; k < nv; k++) x[k] = f[L.efc_J + r * nv + k];
+#pragma nounroll
+		for (int i = nv - 1; i >= 0; i--) {
+			const int na = m.dof_rec[4 * i + 1], ii = m.dof_rec[4 * i];
+			if (na <= 0 || !act) continue;
+			const double xi = x[i];
+			for (int a = 0; a < na; a++) x[m.M_coldof[ii + 1 + a]] -= LD[ii + 1 + a] * xi;
+		}
+		if (act)
+			for (int k = 0; k < nv; k++) x[k] *= di[k];
+#pragma nounroll
+		for (int i = 0; i < nv; i++) {
+			const int na = m.dof_rec[4 * i + 1], ii = m.dof_rec[4 * i];
+			if (na <= 0 || !act) continue;
+			double acc = x[i];
+			for (int a = 0; a < na; a++) acc -= LD[ii + 1 + a] * x[m.M_coldof[ii + 1 + a]];
+			x[i] = acc;
+		}
+	}
+	gsync<G>();
+}
+
+// A8  reference accelerations: efc_vel = J qvel, aref = -B vel - K imp (pos - margin)
+template <int G> STAGE void reference_constraint(CModel m, CLayout L, const Env &e)
+{
+	double *f = e.f;
+	const int nefc = e.fi[L.nefc], nv = m.nv;
+	for (int r = e.lane; r < nefc; r += G) {
+		double s = 0;
+		for (int k = 0; k < nv; k++) s += f[L.efc_J + r * nv + k] * f[L.qvel + k];
+		f[L.efc_vel + r] = s;
+		const double *kb = f + L.efc_KBIP + 4 * r;
+		f[L.efc_aref + r] = -kb[1] * s - kb[0] * kb[2] * (f[L.efc_pos + r] - f[L.efc_margin + r]);
+	}
+	gsync<G>();
+}
+
+// wave-wide sum (G == 64: the env owns the whole wavefront)
+DEVI double wave_sum(double v)
+{
+	v = row_sum<16>(v);
+	// combine the four rows: readlane the row totals (lanes 0,16,32,48 hold them after the butterfly)
+	double t = 0;
+	for (int r = 0; r < 4; r++)
+		t += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * r),
+		                      __builtin_amdgcn_readlane(__double2loint(v), 16 * r));
+	return t;
+}
+DEVI double wave_bcast(double v, int srclane)  // srclane must be wave-uniform
+{
+	return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), srclane),
+	                        __builtin_amdgcn_readlane(__double2loint(v), srclane));
+}
+
+// ------------------------------------------------------------------------------------------------
+// A13 constraint solve: warmstart + projected Gauss-Seidel (dual), one env per wavefront
+// ------------------------------------------------------------------------------------------------
+template <int G> STAGE void fwd_constraint_pgs(CModel m, CLayout L, const Env &e)
+{
+	static_assert(G == 64, "the constraint solver maps rows to the 64 lanes of one wavefront");
+	double *f = e.f;
+	int *fi = e.fi;
+	const int lane = e.lane, nv = m.nv;
+	const int nefc = fi[L.nefc];
+	if (nefc == 0) {
+		for (int d = lane; d < nv; d += G) {
+			const double a = f[L.qacc_smooth + d];
+			f[L.qacc + d] = a;
+			f[L.qacc_warmstart + d] = a;
+			f[L.qfrc_constraint + d] = 0;
+		}
+		if (lane == 0) fi[L.solver_iter] = 0;
+		gsync<G>();
+		return;
+	}
+	const bool rowact = lane < nefc;
+	const int r = rowact ? lane : 0;
+	const double *Jr = f + L.efc_J + r * nv, *Br = f + L.efc_B + r * nv;
+	// per-row scalars in the row's lane
+	double b = 0, R = 1, ARinv = 0, Aii = 1, frc = 0;
+	{
+		double jq = 0, jb = 0, jw = 0;
+		for (int k = 0; k < nv; k++) {
+			const double j = Jr[k];
+			jq += j * f[L.qacc_smooth + k];
+			jb += j * Br[k];
+			jw += j * f[L.qacc_warmstart + k];
+		}
+		const double aref = f[L.efc_aref + r];
+		b = jq - aref;
+		R = f[L.efc_R + r];
+		Aii = jb + R;
+		ARinv = 1.0 / Aii;
+		if (!(m.disableflags & MJB_DSBL_WARMSTART)) {
+			const double jar = jw - aref;
+			frc = jar < 0 ? -f[L.efc_D + r] * jar : 0.0;
+		}
+		if (!rowact) { b = 0; frc = 0; }
+		f[L.efc_b + r] = rowact ? b : f[L.efc_b + r];
+	}
+	// w = M^-1 J' f  (lane k < nv holds w[k]); warmstart cost 0.5 f'ARf + f'b = sum_i f_i (0.5 (J_i.w + R_i f_i) + b_i)
+	if (rowact) f[L.efc_force + r] = frc;
+	gsync<G>();
+	double w = 0;
+	const bool dofact = lane < nv;
+	if (dofact)
+		for (int i = 0; i < nefc; i++) w += f[L.efc_B + i * nv + lane] * f[L.efc_force + i];
+	if (dofact) f[L.qfrc_constraint + lane] = w;  // parked so that rows can read w
+	gsync<G>();
+	{
+		double jw = 0;
+		for (int k = 0; k < nv; k++) jw += Jr[k] * f[L.qfrc_constraint + k];
+		double ci = rowact ? frc * (0.5 * (jw + R * frc) + b) : 0.0;
+		const double cost = wave_sum(ci);
+		if (cost > 0 || (m.disableflags & MJB_DSBL_WARMSTART)) {
+			frc = 0;
+			w = 0;
+		}
+	}
+	gsync<G>();
+	// Gauss-Seidel sweeps
+	const double scale = 1.0 / (m.meaninertia[0] * (nv > 1 ? nv : 1));
+	const double tol = m.tolerance[0];
+	int iter = 0;
+	while (iter < m.iterations) {
+		double improvement = 0;
+#pragma nounroll
+		for (int i = 0; i < nefc; i++) {
+			// J_i . w  over the nv dof lanes
+			const double ji = dofact ? f[L.efc_J + i * nv + lane] : 0.0;
+			const double bi_ = dofact ? f[L.efc_B + i * nv + lane] : 0.0;
+			double part = ji * w;
+			if (nv <= 16) part = wave_bcast(row_sum<16>(part), 0);
+			else part = wave_sum(part);
+			const double fi_ = wave_bcast(frc, i), bi = wave_bcast(b, i), Ri = wave_bcast(R, i);
+			const double Ai = wave_bcast(ARinv, i), Aii_i = wave_bcast(Aii, i);
+			const double res = bi + part + Ri * fi_;
+			double fn = fi_ - res * Ai;
+			if (fn < 0) fn = 0;
+			double delta = fn - fi_;
+			double change = 0.5 * delta * delta * Aii_i + delta * res;
+			if (change > 1e-10) {
+				fn = fi_;
+				delta = 0;
+				change = 0;
+			}
+			improvement -= change;
+			if (lane == i) frc = fn;
+			w += bi_ * delta;
+		}
+		improvement *= scale;
+		iter++;
+		if (improvement < tol) break;
+	}
+	if (lane == 0) fi[L.solver_iter] = iter;
+	if (rowact) f[L.efc_force + r] = frc;
+	gsync<G>();
+	// qfrc_constraint = J' f,  qacc = qacc_smooth + M^-1 J' f = qacc_smooth + w
+	if (dofact) {
+		double s = 0;
+		for (int i = 0; i < nefc; i++) s += f[L.efc_J + i * nv + lane] * f[L.efc_force + i];
+		f[L.qfrc_constraint + lane] = s;
+		const double a = f[L.qacc_smooth + lane] + w;
+		f[L.qacc + lane] = a;
+		f[L.qacc_warmstart + lane] = a;
+	}
+	gsync<G>();
+}

@@ -36,6 +36,7 @@ struct DevModel {
 	mjb_ciptr dof_rec;     // [nv][4]    packed {Madr, nancestor, bodyid, parentid}
 	mjb_ciptr fac_ops;     // [nfac][4]  factorisation micro-ops {dst, srcA, srcB, 0}: LD[dst] -= LD[srcA]/LD[kk]*LD[srcB]
 	mjb_ciptr fac_beg;     // [nv+1]     first micro-op of pivot k
+	mjb_ciptr body_dofmask;  // [nbody][2] bit i set: dof i moves the body (ancestor-or-self dofs), nv <= 64
 	int eulerdamp;         // any dof_damping > 0 and EULERDAMP not disabled
 	int maxdepth;          // max dof_depth
 };
@@ -54,6 +55,7 @@ struct FrameLayout {
 	int MhB;       // [nM]  M + h*diag(damping) (Euler implicit damping), built and factorised next to qM
 	int qH;        // [nM]  its L'DL factor
 	int qHdi;      // [nv]  1 / diag
+	int iscratch;  // transient int scratch: max(ncollpair, njnt + nconmax)
 	int scratch;   // transient scratch: max(7*nbody + 6*njnt (kinematics locals), 7*nv (crb buf / euler rhs))
 	int ndouble;   // doubles per frame
 	int nint;      // ints per frame (follow the doubles)

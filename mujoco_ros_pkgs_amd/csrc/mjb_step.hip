@@ -872,7 +872,9 @@ template <int G> STAGE void fwd_acceleration(CModel m, CLayout L, const Env &e, 
 	solve<G>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv);
 }
 
-// A13 constraint solve (no active constraint rows: the unconstrained acceleration is the answer)
+#include "mjb_constraint.h"
+
+// A13 constraint solve when the model has no constraint rows: the unconstrained acceleration is the answer
 template <int G> STAGE void fwd_constraint(CModel m, CLayout L, const Env &e)
 {
 	double *f = e.f;
@@ -1010,6 +1012,14 @@ template <int G> DEVI void forward_first(CModel m, CLayout L, CState s, const En
 	factor2<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi,
 	           m.eulerdamp != 0);
 	PROF(3);
+	if (m.nefcmax > 0) {
+		collision<G>(m, L, e);
+		PROF(16);
+		make_constraint<G>(m, L, e);
+		PROF(17);
+		project_constraint<G>(m, L, e);
+		PROF(18);
+	}
 	transmission<G>(m, L, e);
 	sensors<G>(m, L, e, MJB_STAGE_POS);
 	PROF(4);
@@ -1017,6 +1027,7 @@ template <int G> DEVI void forward_first(CModel m, CLayout L, CState s, const En
 	PROF(5);
 	passive<G>(m, L, e);
 	PROF(6);
+	if (m.nefcmax > 0) reference_constraint<G>(m, L, e);
 	rne<G>(m, L, e);
 	PROF(7);
 	sensors<G>(m, L, e, MJB_STAGE_VEL);
@@ -1030,7 +1041,12 @@ template <int G> DEVI void forward_rest(CModel m, CLayout L, CState s, const Env
 	PROF(9);
 	fwd_acceleration<G>(m, L, e, s.use_xfrc != 0);
 	PROF(10);
-	fwd_constraint<G>(m, L, e);
+	if constexpr (G == 64) {
+		if (m.nefcmax > 0) fwd_constraint_pgs<G>(m, L, e);
+		else fwd_constraint<G>(m, L, e);
+	} else {
+		fwd_constraint<G>(m, L, e);
+	}
 	PROF(11);
 	sensors<G>(m, L, e, MJB_STAGE_ACC);
 	PROF(12);

@@ -209,8 +209,8 @@ class _Compiler:
     # ---- attribute helpers
     def _merged(self, node, childclass):
         cls = node.get("class", childclass or "main")
-        a = self.defaults.resolve(node.tag if node.tag != "freejoint" else "joint", cls)
-        a = dict(a)
+        # <freejoint> takes no defaults (MJCF reference: "does not use defaults")
+        a = {} if node.tag == "freejoint" else dict(self.defaults.resolve(node.tag, cls))
         a.update(node.attrib)
         return a
 
@@ -781,7 +781,15 @@ class _Compiler:
             t1, t2 = m["geom_type"][g1], m["geom_type"][g2]
             maxcon += _max_contacts(t1, t2)
         nconmax = maxcon if self.nconmax_req is None else int(self.nconmax_req)
-        nlimit = int(np.sum(m["jnt_limited"] * np.where(jnt_type == JNT_BALL, 1, 1)))
+        nlimit = 0
+        for j in range(njnt):
+            if m["jnt_limited"][j]:
+                if jnt_type[j] < JNT_SLIDE:
+                    raise MjcfError("joint limits are only supported on hinge / slide joints")
+                r = m["jnt_range"][j]
+                nlimit += 1 if (r[1] - r[0]) > 2 * m["jnt_margin"][j] else 2
+        if o["disableflags"] & DISABLE_BITS["limit"]:
+            nlimit = 0
         rows_per_con = 0
         if pairs:
             maxdim = max(int(max(m["geom_condim"][g1], m["geom_condim"][g2])) for g1, g2 in pairs)
@@ -793,9 +801,10 @@ class _Compiler:
 
         # mj_setConst: inverse weights at qpos0 (independent numpy dynamics, see refdyn.py)
         from . import refdyn
-        dof_inv, body_inv = refdyn.invweight0(m)
+        dof_inv, body_inv, meaninertia = refdyn.invweight0(m)
         m["dof_invweight0"] = dof_inv
         m["body_invweight0"] = body_inv
+        m["meaninertia"] = np.array([meaninertia], D)
         return m
 
     def _collision_pairs(self, m):
@@ -852,7 +861,7 @@ def _max_contacts(t1, t2):
     table = {
         (GEOM_PLANE, GEOM_SPHERE): 1, (GEOM_PLANE, GEOM_CAPSULE): 2, (GEOM_PLANE, GEOM_BOX): 4,
         (GEOM_SPHERE, GEOM_SPHERE): 1, (GEOM_SPHERE, GEOM_CAPSULE): 1, (GEOM_SPHERE, GEOM_BOX): 1,
-        (GEOM_CAPSULE, GEOM_CAPSULE): 1,
+        (GEOM_CAPSULE, GEOM_CAPSULE): 2,
     }
     return table.get((int(t1), int(t2)), 0)
 

@@ -151,12 +151,12 @@ def bias_lagrange(m, qpos, qvel, eps=1e-6):
 
 
 def invweight0(m):
-    """dof_invweight0[nv], body_invweight0[nbody,2] at qpos0 (restates mj_setConst's set0)."""
+    """dof_invweight0[nv], body_invweight0[nbody,2], stat.meaninertia at qpos0 (restates mj_setConst's set0)."""
     nv, nb = m["nv"], m["nbody"]
     dof_inv = np.zeros(nv)
     body_inv = np.zeros((nb, 2))
     if nv == 0:
-        return dof_inv, body_inv
+        return dof_inv, body_inv, 1.0
     kin = kinematics(m, np.asarray(m["qpos0"], dtype=np.float64))
     M = mass_matrix(m, m["qpos0"], kin)
     Minv = np.linalg.inv(M)
@@ -177,4 +177,4 @@ def invweight0(m):
         else:
             dof_inv[d:d + 3] = np.trace(Minv[d:d + 3, d:d + 3]) / 3
             dof_inv[d + 3:d + 6] = np.trace(Minv[d + 3:d + 6, d + 3:d + 6]) / 3
-    return dof_inv, body_inv
+    return dof_inv, body_inv, float(np.mean(np.diag(M)))

@@ -2,9 +2,10 @@
  * See mjo.h for provenance ("parity unpinned") and usage restrictions.
  *
  * Restates MuJoCo 2.3.7 [UPSTREAM] engine_collision_driver.c / engine_collision_primitive.c /
- * engine_core_constraint.c / engine_solver.c for the primitive subset of include/mjb.h; reached in
- * the reference only through mj_step / mj_forward (/root/reference
- * mujoco_ros/src/mujoco_env.cpp:498,552,593,329,621).
+ * engine_core_constraint.c / engine_solver.c / engine_forward.c (warmstart) for the primitive subset
+ * of include/mjb.h: geoms plane / sphere / capsule / box (pairs listed in collpair_geom), joint
+ * limits on hinge / slide joints, frictionless and pyramidal contacts, PGS.  Reached in the reference
+ * only through mj_step / mj_forward (/root/reference mujoco_ros/src/mujoco_env.cpp:498,552,593,329,621).
  */
 #include <math.h>
 #include <string.h>
@@ -12,39 +13,577 @@
 #include "mjo.h"
 #include "mjo_math.h"
 
+/* ------------------------------------------------------------------ contact frame (mju_makeFrame) */
+static void make_frame(double *frame)
+{
+	v3_normalize(frame);
+	if (sqrt(v3_dot(frame + 3, frame + 3)) < 0.5) {
+		v3_zero(frame + 3);
+		if (frame[1] < 0.5 && frame[1] > -0.5) frame[4] = 1;
+		else frame[5] = 1;
+	}
+	double t = v3_dot(frame, frame + 3);
+	frame[3] -= t * frame[0];
+	frame[4] -= t * frame[1];
+	frame[5] -= t * frame[2];
+	v3_normalize(frame + 3);
+	v3_cross(frame + 6, frame, frame + 3);
+}
+
+typedef struct {
+	double dist, pos[3], frame[9];
+} rawcon;
+
+/* ------------------------------------------------------------------ A5: primitive narrow phase */
+/* sphere-sphere core (mjraw_SphereSphere): centres p1/p2, radii r1/r2 */
+static int raw_sphere_sphere(rawcon *c, const double *p1, double r1, const double *p2, double r2, double margin)
+{
+	double dif[3];
+	v3_sub(dif, p2, p1);
+	double cdist = sqrt(v3_dot(dif, dif));
+	if (cdist > margin + r1 + r2) return 0;
+	c->dist = cdist - r1 - r2;
+	memset(c->frame, 0, sizeof c->frame);
+	v3_copy(c->frame, dif);
+	v3_normalize(c->frame); /* degenerate -> (1,0,0) */
+	for (int k = 0; k < 3; k++) c->pos[k] = p1[k] + c->frame[k] * (r1 + 0.5 * c->dist);
+	return 1;
+}
+
+/* plane (pos1, normal = mat1 z-axis) vs sphere centre p, radius r (mjc_PlaneSphere) */
+static int raw_plane_sphere(rawcon *c, const double *pos1, const double *mat1, const double *p, double r, double margin)
+{
+	double n[3] = { mat1[2], mat1[5], mat1[8] }, tmp[3];
+	v3_sub(tmp, p, pos1);
+	double cdist = v3_dot(tmp, n);
+	if (cdist > margin + r) return 0;
+	c->dist = cdist - r;
+	memset(c->frame, 0, sizeof c->frame);
+	v3_copy(c->frame, n);
+	for (int k = 0; k < 3; k++) c->pos[k] = p[k] - n[k] * (r + 0.5 * c->dist);
+	return 1;
+}
+
+static int plane_capsule(rawcon *c, const double *pos1, const double *mat1, const double *pos2, const double *mat2,
+                         const double *size2, double margin)
+{
+	double axis[3] = { mat2[2], mat2[5], mat2[8] }, seg[3], p[3];
+	v3_scl(seg, axis, size2[1]);
+	v3_add(p, pos2, seg);
+	int n = raw_plane_sphere(c, pos1, mat1, p, size2[0], margin);
+	v3_sub(p, pos2, seg);
+	n += raw_plane_sphere(c + n, pos1, mat1, p, size2[0], margin);
+	/* align the first tangent with the capsule axis (made orthogonal by make_frame) */
+	for (int i = 0; i < n; i++) v3_copy(c[i].frame + 3, axis);
+	return n;
+}
+
+static int plane_box(rawcon *c, const double *pos1, const double *mat1, const double *pos2, const double *mat2,
+                     const double *size2, double margin)
+{
+	double n[3] = { mat1[2], mat1[5], mat1[8] }, dif[3];
+	v3_sub(dif, pos2, pos1);
+	double dist = v3_dot(dif, n);
+	int cnt = 0;
+	for (int i = 0; i < 8; i++) {
+		double vec[3] = { (i & 1) ? size2[0] : -size2[0], (i & 2) ? size2[1] : -size2[1], (i & 4) ? size2[2] : -size2[2] };
+		double corner[3];
+		m3_mulvec(corner, mat2, vec);
+		double ldist = v3_dot(n, corner);
+		if (dist + ldist > margin || ldist > 0) continue;
+		c[cnt].dist = dist + ldist;
+		memset(c[cnt].frame, 0, sizeof c[cnt].frame);
+		v3_copy(c[cnt].frame, n);
+		v3_addto(corner, pos2);
+		for (int k = 0; k < 3; k++) c[cnt].pos[k] = corner[k] - n[k] * c[cnt].dist * 0.5;
+		if (++cnt >= 4) return 4;
+	}
+	return cnt;
+}
+
+static int sphere_capsule(rawcon *c, const double *pos1, double r1, const double *pos2, const double *mat2,
+                          const double *size2, double margin)
+{
+	double axis[3] = { mat2[2], mat2[5], mat2[8] }, vec[3], p[3];
+	v3_sub(vec, pos1, pos2);
+	double x = v3_dot(axis, vec);
+	x = x < -size2[1] ? -size2[1] : (x > size2[1] ? size2[1] : x);
+	for (int k = 0; k < 3; k++) p[k] = pos2[k] + axis[k] * x;
+	return raw_sphere_sphere(c, pos1, r1, p, size2[0], margin);
+}
+
+static double clipd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+static int capsule_capsule(rawcon *c, const double *pos1, const double *mat1, const double *size1, const double *pos2,
+                           const double *mat2, const double *size2, double margin)
+{
+	double a1[3] = { mat1[2], mat1[5], mat1[8] }, a2[3] = { mat2[2], mat2[5], mat2[8] }, dif[3];
+	v3_sub(dif, pos1, pos2);
+	double ma = v3_dot(a1, a1), mb = -v3_dot(a1, a2), mc = v3_dot(a2, a2);
+	double u = -v3_dot(a1, dif), v = v3_dot(a2, dif);
+	double det = ma * mc - mb * mb;
+	double p1[3], p2[3];
+	if (fabs(det) >= MJO_MINVAL) {
+		double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+		if (x1 > size1[1]) {
+			x1 = size1[1];
+			x2 = (v - mb * size1[1]) / mc;
+		} else if (x1 < -size1[1]) {
+			x1 = -size1[1];
+			x2 = (v + mb * size1[1]) / mc;
+		}
+		if (x2 > size2[1]) {
+			x2 = size2[1];
+			x1 = clipd((u - mb * size2[1]) / ma, -size1[1], size1[1]);
+		} else if (x2 < -size2[1]) {
+			x2 = -size2[1];
+			x1 = clipd((u + mb * size2[1]) / ma, -size1[1], size1[1]);
+		}
+		for (int k = 0; k < 3; k++) {
+			p1[k] = pos1[k] + a1[k] * x1;
+			p2[k] = pos2[k] + a2[k] * x2;
+		}
+		return raw_sphere_sphere(c, p1, size1[0], p2, size2[0], margin);
+	}
+	/* parallel axes: the two ends of capsule 1 against segment 2, then (if fewer than 2) the ends of 2 against 1 */
+	int n = 0;
+	for (int s = 1; s >= -1 && n < 2; s -= 2) {
+		for (int k = 0; k < 3; k++) p1[k] = pos1[k] + a1[k] * s * size1[1];
+		double d2[3];
+		v3_sub(d2, p1, pos2);
+		double x2 = clipd(v3_dot(a2, d2) / mc, -size2[1], size2[1]);
+		for (int k = 0; k < 3; k++) p2[k] = pos2[k] + a2[k] * x2;
+		n += raw_sphere_sphere(c + n, p1, size1[0], p2, size2[0], margin);
+	}
+	for (int s = 1; s >= -1 && n < 2; s -= 2) {
+		for (int k = 0; k < 3; k++) p2[k] = pos2[k] + a2[k] * s * size2[1];
+		double d1[3];
+		v3_sub(d1, p2, pos1);
+		double x1 = clipd(v3_dot(a1, d1) / ma, -size1[1], size1[1]);
+		if (fabs(fabs(x1) - size1[1]) < MJO_MINVAL) continue; /* already produced by the first loop */
+		for (int k = 0; k < 3; k++) p1[k] = pos1[k] + a1[k] * x1;
+		n += raw_sphere_sphere(c + n, p1, size1[0], p2, size2[0], margin);
+	}
+	return n;
+}
+
+static int sphere_box(rawcon *c, const double *pos1, double r1, const double *pos2, const double *mat2,
+                      const double *size2, double margin)
+{
+	double tmp[3], center[3], clamped[3];
+	v3_sub(tmp, pos1, pos2);
+	m3_mulvecT(center, mat2, tmp);
+	for (int i = 0; i < 3; i++) clamped[i] = clipd(center[i], -size2[i], size2[i]);
+	double dv[3];
+	v3_sub(dv, clamped, center);
+	double dist = sqrt(v3_dot(dv, dv));
+	if (dist - r1 > margin) return 0;
+	double nloc[3] = { 0, 0, 0 }, ploc[3];
+	memset(c->frame, 0, sizeof c->frame);
+	if (dist <= MJO_MINVAL) {
+		/* centre inside the box: push out through the nearest face */
+		double closest = 2 * fmax(size2[0], fmax(size2[1], size2[2]));
+		int k = 0;
+		for (int i = 0; i < 6; i++) {
+			double fd = fabs(((i % 2) ? 1 : -1) * size2[i / 2] - center[i / 2]);
+			if (closest > fd) {
+				closest = fd;
+				k = i;
+			}
+		}
+		nloc[k / 2] = (k % 2) ? -1 : 1;
+		for (int i = 0; i < 3; i++) ploc[i] = center[i] + nloc[i] * (r1 - closest) / 2;
+		c->dist = -closest - r1;
+	} else {
+		double deepest[3];
+		for (int i = 0; i < 3; i++) {
+			deepest[i] = center[i] + dv[i] * (r1 / dist);
+			ploc[i] = 0.5 * (clamped[i] + deepest[i]);
+			nloc[i] = dv[i] / dist;
+		}
+		c->dist = dist - r1;
+	}
+	m3_mulvec(c->frame, mat2, nloc);
+	m3_mulvec(c->pos, mat2, ploc);
+	v3_addto(c->pos, pos2);
+	return 1;
+}
+
+/* mj_contactParam: mix the two geoms' contact parameters */
+static void contact_param(const mjb_model_desc *m, int g1, int g2, int *condim, double *solref, double *solimp,
+                          double *friction)
+{
+	int p1 = m->geom_priority[g1], p2 = m->geom_priority[g2];
+	if (p1 != p2) {
+		int g = p1 > p2 ? g1 : g2;
+		*condim = m->geom_condim[g];
+		memcpy(solref, m->geom_solref + 2 * g, 2 * sizeof(double));
+		memcpy(solimp, m->geom_solimp + 5 * g, 5 * sizeof(double));
+		for (int k = 0; k < 3; k++) friction[k] = m->geom_friction[3 * g + k];
+		return;
+	}
+	*condim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
+	double s1 = m->geom_solmix[g1], s2 = m->geom_solmix[g2], mix;
+	if (s1 >= MJO_MINVAL && s2 >= MJO_MINVAL) mix = s1 / (s1 + s2);
+	else if (s1 < MJO_MINVAL && s2 < MJO_MINVAL) mix = 0.5;
+	else if (s1 < MJO_MINVAL) mix = 0.0;
+	else mix = 1.0;
+	const double *r1 = m->geom_solref + 2 * g1, *r2 = m->geom_solref + 2 * g2;
+	if (r1[0] > 0 && r2[0] > 0) {
+		for (int k = 0; k < 2; k++) solref[k] = mix * r1[k] + (1 - mix) * r2[k];
+	} else {
+		for (int k = 0; k < 2; k++) solref[k] = fmin(r1[k], r2[k]);
+	}
+	for (int k = 0; k < 5; k++) solimp[k] = mix * m->geom_solimp[5 * g1 + k] + (1 - mix) * m->geom_solimp[5 * g2 + k];
+	for (int k = 0; k < 3; k++) friction[k] = fmax(m->geom_friction[3 * g1 + k], m->geom_friction[3 * g2 + k]);
+}
+
+/* ------------------------------------------------------------------ A4+A5: mj_collision */
 void mjo_collision(const mjb_model_desc *m, mjo_data *d)
 {
-	(void)m;
 	d->ncon[0] = 0;
+	if (m->nconmax <= 0 || (m->disableflags & (MJB_DSBL_CONSTRAINT | MJB_DSBL_CONTACT))) return;
+	int ncon = 0;
+	for (int p = 0; p < m->ncollpair; p++) {
+		int g1 = m->collpair_geom[2 * p], g2 = m->collpair_geom[2 * p + 1];
+		int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+		const double *pos1 = d->geom_xpos + 3 * g1, *pos2 = d->geom_xpos + 3 * g2;
+		const double *mat1 = d->geom_xmat + 9 * g1, *mat2 = d->geom_xmat + 9 * g2;
+		const double *size1 = m->geom_size + 3 * g1, *size2 = m->geom_size + 3 * g2;
+		double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
+		double gap = fmax(m->geom_gap[g1], m->geom_gap[g2]);
+		/* broad phase: bounding spheres (plane: signed distance of the other geom's sphere) */
+		double rb1 = m->geom_rbound[g1], rb2 = m->geom_rbound[g2];
+		if (rb1 > 0 && rb2 > 0) {
+			double dv[3];
+			v3_sub(dv, pos2, pos1);
+			double bound = margin + rb1 + rb2;
+			if (v3_dot(dv, dv) > bound * bound) continue;
+		} else if (t1 == MJB_GEOM_PLANE && rb2 > 0) {
+			double n[3] = { mat1[2], mat1[5], mat1[8] }, dv[3];
+			v3_sub(dv, pos2, pos1);
+			if (v3_dot(dv, n) > margin + rb2) continue;
+		}
+		rawcon rc[4];
+		int n = 0;
+		if (t1 == MJB_GEOM_PLANE && t2 == MJB_GEOM_SPHERE) n = raw_plane_sphere(rc, pos1, mat1, pos2, size2[0], margin);
+		else if (t1 == MJB_GEOM_PLANE && t2 == MJB_GEOM_CAPSULE) n = plane_capsule(rc, pos1, mat1, pos2, mat2, size2, margin);
+		else if (t1 == MJB_GEOM_PLANE && t2 == MJB_GEOM_BOX) n = plane_box(rc, pos1, mat1, pos2, mat2, size2, margin);
+		else if (t1 == MJB_GEOM_SPHERE && t2 == MJB_GEOM_SPHERE) n = raw_sphere_sphere(rc, pos1, size1[0], pos2, size2[0], margin);
+		else if (t1 == MJB_GEOM_SPHERE && t2 == MJB_GEOM_CAPSULE) n = sphere_capsule(rc, pos1, size1[0], pos2, mat2, size2, margin);
+		else if (t1 == MJB_GEOM_SPHERE && t2 == MJB_GEOM_BOX) n = sphere_box(rc, pos1, size1[0], pos2, mat2, size2, margin);
+		else if (t1 == MJB_GEOM_CAPSULE && t2 == MJB_GEOM_CAPSULE) n = capsule_capsule(rc, pos1, mat1, size1, pos2, mat2, size2, margin);
+		if (n == 0) continue;
+		int condim;
+		double solref[2], solimp[5], fri[3];
+		contact_param(m, g1, g2, &condim, solref, solimp, fri);
+		for (int i = 0; i < n && ncon < m->nconmax; i++) {
+			if (rc[i].dist >= margin) continue;
+			make_frame(rc[i].frame);
+			d->contact_dist[ncon] = rc[i].dist;
+			v3_copy(d->contact_pos + 3 * ncon, rc[i].pos);
+			memcpy(d->contact_frame + 9 * ncon, rc[i].frame, 9 * sizeof(double));
+			d->contact_includemargin[ncon] = margin - gap;
+			double *f5 = d->contact_friction + 5 * ncon;
+			f5[0] = f5[1] = fri[0]; f5[2] = fri[1]; f5[3] = f5[4] = fri[2];
+			memcpy(d->contact_solref + 2 * ncon, solref, sizeof solref);
+			memcpy(d->contact_solimp + 5 * ncon, solimp, sizeof solimp);
+			d->contact_geom[2 * ncon] = g1;
+			d->contact_geom[2 * ncon + 1] = g2;
+			d->contact_dim[ncon] = condim;
+			d->contact_efc_address[ncon] = -1;
+			ncon++;
+		}
+	}
+	d->ncon[0] = ncon;
+}
+
+/* ------------------------------------------------------------------ A6: mj_makeConstraint */
+/* translational Jacobian row of a world point attached to `body`, projected on `dir`, ADDED with sign */
+static void add_jac_point(const mjb_model_desc *m, const mjo_data *d, double *row, int body, const double *point,
+                          const double *dir, double sign)
+{
+	while (body > 0 && m->body_dofnum[body] == 0) body = m->body_parentid[body];
+	if (body == 0) return;
+	double offset[3];
+	v3_sub(offset, point, d->subtree_com + 3 * m->body_rootid[body]);
+	for (int i = m->body_dofadr[body] + m->body_dofnum[body] - 1; i >= 0; i = m->dof_parentid[i]) {
+		const double *cd = d->cdof + 6 * i;
+		double jp[3];
+		v3_cross(jp, cd, offset);
+		v3_addto(jp, cd + 3);
+		row[i] += sign * v3_dot(dir, jp);
+	}
+}
+
+/* rotational Jacobian row projected on `dir` */
+static void add_jac_rot(const mjb_model_desc *m, const mjo_data *d, double *row, int body, const double *dir, double sign)
+{
+	while (body > 0 && m->body_dofnum[body] == 0) body = m->body_parentid[body];
+	if (body == 0) return;
+	for (int i = m->body_dofadr[body] + m->body_dofnum[body] - 1; i >= 0; i = m->dof_parentid[i])
+		row[i] += sign * v3_dot(dir, d->cdof + 6 * i);
+}
+
+/* getimpedance */
+static void impedance(const double *solimp, double pos, double margin, double *imp, double *impP)
+{
+	if (solimp[0] == solimp[1] || solimp[2] <= MJO_MINVAL) {
+		*imp = 0.5 * (solimp[0] + solimp[1]);
+		*impP = 0;
+		return;
+	}
+	double x = (pos - margin) / solimp[2], sgn = 1;
+	if (x < 0) {
+		x = -x;
+		sgn = -1;
+	}
+	if (x >= 1 || x <= 0) {
+		*imp = x >= 1 ? solimp[1] : solimp[0];
+		*impP = 0;
+		return;
+	}
+	double y, yP;
+	if (solimp[4] == 1) {
+		y = x;
+		yP = 1;
+	} else if (x <= solimp[3]) {
+		double a = 1 / pow(solimp[3], solimp[4] - 1);
+		y = a * pow(x, solimp[4]);
+		yP = solimp[4] * a * pow(x, solimp[4] - 1);
+	} else {
+		double b = 1 / pow(1 - solimp[3], solimp[4] - 1);
+		y = 1 - b * pow(1 - x, solimp[4]);
+		yP = solimp[4] * b * pow(1 - x, solimp[4] - 1);
+	}
+	*imp = solimp[0] + y * (solimp[1] - solimp[0]);
+	*impP = yP * sgn * (solimp[1] - solimp[0]) / solimp[2];
+}
+
+/* R, D, KBIP of one row (mj_makeImpedance) */
+static void row_params(const mjb_model_desc *m, mjo_data *d, int i, const double *solref_in, const double *solimp,
+                       double diag_approx)
+{
+	double solref[2] = { solref_in[0], solref_in[1] };
+	if (!(m->disableflags & MJB_DSBL_REFSAFE) && solref[0] > 0) solref[0] = fmax(solref[0], 2 * m->timestep[0]);
+	double imp, impP;
+	impedance(solimp, d->efc_pos[i], d->efc_margin[i], &imp, &impP);
+	d->efc_R[i] = fmax(MJO_MINVAL, (1 - imp) * diag_approx / imp);
+	double dmax = solimp[1], K, B;
+	if (solref[0] > 0) {
+		K = 1 / fmax(MJO_MINVAL, dmax * dmax * solref[0] * solref[0] * solref[1] * solref[1]);
+		B = 2 / fmax(MJO_MINVAL, dmax * solref[0]);
+	} else {
+		K = -solref[0] / fmax(MJO_MINVAL, dmax * dmax);
+		B = -solref[1] / fmax(MJO_MINVAL, dmax);
+	}
+	d->efc_KBIP[4 * i] = K;
+	d->efc_KBIP[4 * i + 1] = B;
+	d->efc_KBIP[4 * i + 2] = imp;
+	d->efc_KBIP[4 * i + 3] = impP;
 }
 
 void mjo_make_constraint(const mjb_model_desc *m, mjo_data *d)
 {
-	(void)m;
+	int nv = m->nv, nefc = 0;
 	d->nefc[0] = 0;
+	if (m->nefcmax <= 0 || (m->disableflags & MJB_DSBL_CONSTRAINT)) return;
+	/* joint limits (mj_instantiateLimit), hinge / slide */
+	if (!(m->disableflags & MJB_DSBL_LIMIT)) {
+		for (int j = 0; j < m->njnt; j++) {
+			if (!m->jnt_limited[j] || m->jnt_type[j] < MJB_JNT_SLIDE) continue;
+			double value = d->qpos[m->jnt_qposadr[j]], margin = m->jnt_margin[j];
+			for (int side = -1; side <= 1; side += 2) {
+				double dist = side * (m->jnt_range[2 * j + (side + 1) / 2] - value);
+				if (dist < margin && nefc < m->nefcmax) {
+					double *row = d->efc_J + (size_t)nefc * nv;
+					memset(row, 0, sizeof(double) * (size_t)nv);
+					row[m->jnt_dofadr[j]] = -side;
+					d->efc_pos[nefc] = dist;
+					d->efc_margin[nefc] = margin;
+					d->efc_type[nefc] = MJB_CNSTR_LIMIT_JOINT;
+					d->efc_id[nefc] = j;
+					row_params(m, d, nefc, m->jnt_solref + 2 * j, m->jnt_solimp + 5 * j, m->dof_invweight0[m->jnt_dofadr[j]]);
+					nefc++;
+				}
+			}
+		}
+	}
+	/* contacts (mj_instantiateContact), frictionless or pyramidal */
+	if (!(m->disableflags & MJB_DSBL_CONTACT)) {
+		for (int c = 0; c < d->ncon[0]; c++) {
+			if (!(d->contact_dist[c] < d->contact_includemargin[c])) continue;
+			int dim = d->contact_dim[c];
+			int nrow = dim == 1 ? 1 : 2 * (dim - 1);
+			if (nefc + nrow > m->nefcmax) break;
+			int b1 = m->geom_bodyid[d->contact_geom[2 * c]], b2 = m->geom_bodyid[d->contact_geom[2 * c + 1]];
+			const double *frame = d->contact_frame + 9 * c, *pos = d->contact_pos + 3 * c, *fri = d->contact_friction + 5 * c;
+			/* Jacobian difference (body2 - body1) in the contact frame: up to 6 rows */
+			double jac[6][64];
+			if (nv > 64) return; /* oracle capacity */
+			for (int k = 0; k < dim && k < 6; k++) {
+				memset(jac[k], 0, sizeof(double) * (size_t)nv);
+				if (k < 3) {
+					add_jac_point(m, d, jac[k], b2, pos, frame + 3 * k, 1.0);
+					add_jac_point(m, d, jac[k], b1, pos, frame + 3 * k, -1.0);
+				} else {
+					add_jac_rot(m, d, jac[k], b2, frame + 3 * (k - 3), 1.0);
+					add_jac_rot(m, d, jac[k], b1, frame + 3 * (k - 3), -1.0);
+				}
+			}
+			double tran = m->body_invweight0[2 * b1] + m->body_invweight0[2 * b2];
+			double rot = m->body_invweight0[2 * b1 + 1] + m->body_invweight0[2 * b2 + 1];
+			d->contact_efc_address[c] = nefc;
+			if (dim == 1) {
+				memcpy(d->efc_J + (size_t)nefc * nv, jac[0], sizeof(double) * (size_t)nv);
+				d->efc_pos[nefc] = d->contact_dist[c];
+				d->efc_margin[nefc] = d->contact_includemargin[c];
+				d->efc_type[nefc] = MJB_CNSTR_CONTACT_FRICTIONLESS;
+				d->efc_id[nefc] = c;
+				row_params(m, d, nefc, d->contact_solref + 2 * c, d->contact_solimp + 5 * c, tran);
+				nefc++;
+			} else {
+				int first = nefc;
+				for (int k = 1; k < dim; k++)
+					for (int s = 0; s < 2; s++) {
+						double *row = d->efc_J + (size_t)nefc * nv;
+						double f = s == 0 ? fri[k - 1] : -fri[k - 1];
+						for (int i = 0; i < nv; i++) row[i] = jac[0][i] + f * jac[k][i];
+						d->efc_pos[nefc] = d->contact_dist[c];
+						d->efc_margin[nefc] = d->contact_includemargin[c];
+						d->efc_type[nefc] = MJB_CNSTR_CONTACT_PYRAMIDAL;
+						d->efc_id[nefc] = c;
+						double da = tran + fri[k - 1] * fri[k - 1] * ((k - 1) < 2 ? tran : rot);
+						row_params(m, d, nefc, d->contact_solref + 2 * c, d->contact_solimp + 5 * c, da);
+						nefc++;
+					}
+				/* pyramidal regularisation: Rpy = 2 mu^2 R[first], mu = friction[0] / sqrt(impratio) */
+				double mu = fri[0] / sqrt(fmax(MJO_MINVAL, m->impratio[0]));
+				double Rpy = 2 * mu * mu * d->efc_R[first];
+				for (int r = first; r < nefc; r++) d->efc_R[r] = fmax(MJO_MINVAL, Rpy);
+			}
+		}
+	}
+	for (int i = 0; i < nefc; i++) d->efc_D[i] = 1 / d->efc_R[i];
+	d->nefc[0] = nefc;
 }
 
+/* A7: mj_projectConstraint: AR = J M^-1 J' + diag(R) */
 void mjo_project_constraint(const mjb_model_desc *m, mjo_data *d)
 {
-	(void)m;
-	(void)d;
+	int nv = m->nv, nefc = d->nefc[0], ld = m->nefcmax;
+	if (nefc == 0) return;
+	double *tmp = d->scratch_nv2;
+	for (int i = 0; i < nefc; i++) {
+		memcpy(tmp, d->efc_J + (size_t)i * nv, sizeof(double) * (size_t)nv);
+		mjo_solve_m(m, d, tmp);
+		memcpy(d->efc_B + (size_t)i * nv, tmp, sizeof(double) * (size_t)nv);
+		for (int j = 0; j < nefc; j++) {
+			double s = 0;
+			const double *rj = d->efc_J + (size_t)j * nv;
+			for (int k = 0; k < nv; k++) s += rj[k] * tmp[k];
+			d->efc_AR[(size_t)j * ld + i] = s;
+		}
+	}
+	/* symmetrise exactly (the two triangles differ by rounding) and add R */
+	for (int i = 0; i < nefc; i++) {
+		for (int j = 0; j < i; j++) {
+			double s = 0.5 * (d->efc_AR[(size_t)i * ld + j] + d->efc_AR[(size_t)j * ld + i]);
+			d->efc_AR[(size_t)i * ld + j] = d->efc_AR[(size_t)j * ld + i] = s;
+		}
+		d->efc_AR[(size_t)i * ld + i] += d->efc_R[i];
+	}
 }
 
+/* A8: mj_referenceConstraint */
 void mjo_reference_constraint(const mjb_model_desc *m, mjo_data *d)
 {
-	(void)m;
-	(void)d;
+	int nv = m->nv, nefc = d->nefc[0];
+	for (int i = 0; i < nefc; i++) {
+		double s = 0;
+		const double *row = d->efc_J + (size_t)i * nv;
+		for (int k = 0; k < nv; k++) s += row[k] * d->qvel[k];
+		d->efc_vel[i] = s;
+		const double *kb = d->efc_KBIP + 4 * i;
+		d->efc_aref[i] = -kb[1] * s - kb[0] * kb[2] * (d->efc_pos[i] - d->efc_margin[i]);
+	}
 }
 
-/* A13: mj_fwdConstraint */
+/* A13: mj_fwdConstraint with the PGS solver (mj_solPGS) */
 void mjo_fwd_constraint(const mjb_model_desc *m, mjo_data *d)
 {
-	int nv = m->nv;
-	if (d->nefc[0] == 0) {
+	int nv = m->nv, nefc = d->nefc[0], ld = m->nefcmax;
+	if (nefc == 0) {
 		memcpy(d->qacc, d->qacc_smooth, sizeof(double) * (size_t)nv);
 		memcpy(d->qacc_warmstart, d->qacc_smooth, sizeof(double) * (size_t)nv);
 		memset(d->qfrc_constraint, 0, sizeof(double) * (size_t)nv);
 		d->solver_iter[0] = 0;
 		return;
+	}
+	double *f = d->efc_force, *b = d->efc_b;
+	/* b = J qacc_smooth - aref */
+	for (int i = 0; i < nefc; i++) {
+		double s = 0;
+		const double *row = d->efc_J + (size_t)i * nv;
+		for (int k = 0; k < nv; k++) s += row[k] * d->qacc_smooth[k];
+		b[i] = s - d->efc_aref[i];
+	}
+	/* warmstart (engine_forward.c warmstart()): forces implied by qacc_warmstart, kept only if their dual
+	 * cost 0.5 f'ARf + f'b is negative */
+	int warm = !(m->disableflags & MJB_DSBL_WARMSTART);
+	if (warm) {
+		for (int i = 0; i < nefc; i++) {
+			double jar = -d->efc_aref[i];
+			const double *row = d->efc_J + (size_t)i * nv;
+			for (int k = 0; k < nv; k++) jar += row[k] * d->qacc_warmstart[k];
+			f[i] = jar < 0 ? -d->efc_D[i] * jar : 0.0; /* limit / contact rows are one-sided */
+		}
+		double cost = 0;
+		for (int i = 0; i < nefc; i++) {
+			double s = 0;
+			for (int j = 0; j < nefc; j++) s += d->efc_AR[(size_t)i * ld + j] * f[j];
+			cost += 0.5 * f[i] * s + f[i] * b[i];
+		}
+		if (cost > 0) warm = 0;
+	}
+	if (!warm) memset(f, 0, sizeof(double) * (size_t)nefc);
+
+	double scale = 1.0 / (m->meaninertia[0] * (nv > 1 ? nv : 1));
+	double ARinv[nefc]; /* 1 / diag(AR) (mj_solPGS precomputes it) */
+	for (int i = 0; i < nefc; i++) ARinv[i] = 1.0 / d->efc_AR[(size_t)i * ld + i];
+	int iter = 0;
+	while (iter < m->iterations) {
+		double improvement = 0;
+		for (int i = 0; i < nefc; i++) {
+			double res = b[i];
+			for (int j = 0; j < nefc; j++) res += d->efc_AR[(size_t)i * ld + j] * f[j];
+			double old = f[i];
+			double Aii = d->efc_AR[(size_t)i * ld + i];
+			f[i] -= res * ARinv[i];
+			if (f[i] < 0) f[i] = 0;
+			double delta = f[i] - old;
+			double change = 0.5 * delta * delta * Aii + delta * res;
+			if (change > 1e-10) {
+				f[i] = old;
+				change = 0;
+			}
+			improvement -= change;
+		}
+		improvement *= scale;
+		iter++;
+		if (improvement < m->tolerance[0]) break;
+	}
+	d->solver_iter[0] = iter;
+	/* qfrc_constraint = J' f ;  qacc = qacc_smooth + M^-1 qfrc_constraint */
+	for (int k = 0; k < nv; k++) {
+		double s = 0;
+		for (int i = 0; i < nefc; i++) s += d->efc_J[(size_t)i * nv + k] * f[i];
+		d->qfrc_constraint[k] = s;
+		d->qacc[k] = s;
+	}
+	mjo_solve_m(m, d, d->qacc);
+	for (int k = 0; k < nv; k++) {
+		d->qacc[k] += d->qacc_smooth[k];
+		d->qacc_warmstart[k] = d->qacc[k];
 	}
 }
