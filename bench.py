@@ -22,7 +22,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_ENV_STEP = {"franka_like": 712}  # 8*(2nq+2nv+2nv+nu+S)+8 for cfg 2
+ALGO_BYTES_PER_ENV_STEP = {"franka_like": 712, "franka_table": 1072}  # 8*(2nq+2nv+2nv+nu+S)+8
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable)
 
 
@@ -32,13 +32,20 @@ def synthetic_state(model, nenv, seed):
     rngj = np.asarray(model["jnt_range"])
     mid = 0.5 * (rngj[:, 0] + rngj[:, 1])
     qpos = np.tile(np.asarray(model["qpos0"]), (nenv, 1))
+    qvel = np.zeros((nenv, model["nv"]))
     for j in range(model["njnt"]):
-        t, qa = model["jnt_type"][j], model["jnt_qposadr"][j]
+        t, qa, da = model["jnt_type"][j], model["jnt_qposadr"][j], model["jnt_dofadr"][j]
         if t == 3:
             qpos[:, qa] = mid[j] + rng.uniform(-0.1, 0.1, nenv)
+            qvel[:, da] = rng.uniform(-0.1, 0.1, nenv)
         elif t == 2:
             qpos[:, qa] = rng.uniform(rngj[j, 0], rngj[j, 1], nenv)
-    qvel = rng.uniform(-0.1, 0.1, (nenv, model["nv"]))
+            qvel[:, da] = rng.uniform(-0.1, 0.1, nenv)
+        elif t == 0:  # free object: at rest 1 cm above contact, identity quat + yaw U(-pi, pi)
+            yaw = rng.uniform(-np.pi, np.pi, nenv)
+            qpos[:, qa + 3] = np.cos(yaw / 2)
+            qpos[:, qa + 4:qa + 6] = 0
+            qpos[:, qa + 6] = np.sin(yaw / 2)
     return qpos, qvel
 
 
@@ -158,7 +165,7 @@ def main():
         traffic = None
         try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, 4096 envs x 1000 steps)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.json")))
-            if (E, S) == (4096, 1000):
+            if (E, S, args.model) == (4096, 1000, "franka_like"):
                 traffic = (pmc["FETCH_SIZE"]["mean_per_dispatch"] + pmc["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
         except Exception:
             traffic = None
@@ -169,8 +176,9 @@ def main():
             "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: Franka-Panda-like 9-DoF arm, no contacts, "
-                                   f"{E} envs per GPU, fp64, Euler dt={model['timestep'][0]}",
+            "config": {"workload": ("BASELINE configs[1]: Franka-Panda-like 9-DoF arm, no contacts, " if args.model == "franka_like"
+                                    else "BASELINE configs[2]: Franka-like arm + table + cube contacts (PGS, pyramidal), ")
+                                   + f"{E} envs per GPU, fp64, Euler dt={model['timestep'][0]}",
                        "envs_per_gpu": E, "physics_steps_per_launch": S, "model": args.model,
                        "ctrl": "on-device OU noise (Philox seed 12345, tau 0.1 s, std 43.5)",
                        "parallelism": f"env-sharded x{world}, RCCL all-gather of sensordata per launch" if world > 1

@@ -56,7 +56,9 @@ struct FrameLayout {
 	int qH;        // [nM]  its L'DL factor
 	int qHdi;      // [nv]  1 / diag
 	int iscratch;  // transient int scratch: max(ncollpair, njnt + nconmax)
-	int scratch;   // transient scratch: max(7*nbody + 6*njnt (kinematics locals), 7*nv (crb buf / euler rhs))
+	int kinloc;    // [7*nbody] kinematics: pose of each body in its parent frame (transient)
+	int crbbuf;    // [6*nv]    crb: crb[body(i)] * cdof_i (transient)
+	int eulerx;    // [nv]      Euler: velocity-update right-hand side / solution (transient)
 	int ndouble;   // doubles per frame
 	int nint;      // ints per frame (follow the doubles)
 	int nstate;    // doubles in the persistent prefix
@@ -94,7 +96,10 @@ struct NoiseCfg {
 // constant-address-space pointer to it.
 struct KernelParams {
 	DevModel m;
-	FrameLayout L;
+	FrameLayout L;    // full layout: every field has its own storage (forward / split step / dumps)
+	FrameLayout Lc;   // compact layout of the fused step: fields with disjoint lifetimes share storage
+	int use_compact;  // fused launches use Lc
+	int pad0;
 	DevState s;
 	NoiseCfg nz;
 };

@@ -93,7 +93,7 @@ template <int G> STAGE void kinematics(CModel m, CLayout L, const Env &e)
 	double *f = e.f;
 	double *qpos = f + L.qpos, *xpos = f + L.xpos, *xquat = f + L.xquat, *xmat = f + L.xmat;
 	double *xanchor = f + L.xanchor, *xaxis = f + L.xaxis;
-	double *loc = f + L.scratch;  // [nbody][7] local pose (pos, quat) of each body in its parent's frame
+	double *loc = f + L.kinloc;  // [nbody][7] local pose (pos, quat) of each body in its parent's frame
 	const int lane = e.lane;
 
 	// Phase A -- one body per lane: pose relative to the parent INCLUDING the joint motion, plus joint anchors
@@ -332,7 +332,7 @@ template <int G> STAGE void com_pos(CModel m, CLayout L, const Env &e)
 template <int G> STAGE void crb(CModel m, CLayout L, const Env &e)
 {
 	double *f = e.f;
-	double *crbv = f + L.crb, *cinert = f + L.cinert, *buf = f + L.scratch;
+	double *crbv = f + L.crb, *cinert = f + L.cinert, *buf = f + L.crbbuf;
 	const int lane = e.lane;
 	for (int c = lane; c < 10; c += G) {
 		for (int i = 0; i < m.nbody; i++) crbv[10 * i + c] = cinert[10 * i + c];
@@ -899,7 +899,7 @@ template <int G> STAGE void euler(CModel m, CLayout L, const Env &e)
 {
 	double *f = e.f;
 	const double dt = m.timestep[0];
-	double *x = f + L.scratch;
+	double *x = f + L.eulerx;
 	if (m.eulerdamp) {
 		// (M + h B) x = qfrc_smooth + qfrc_constraint, factor qH prepared next to qLD in fwd_position
 		for (int d = e.lane; d < m.nv; d += G) x[d] = f[L.qfrc_smooth + d] + f[L.qfrc_constraint + d];
@@ -1075,7 +1075,7 @@ __global__ void __launch_bounds__(256, (G == 64 ? 4 : (G == 32 ? 2 : 1)))
 	// launch parameters live in device memory behind a constant-address-space pointer: every field is
 	// fetched with a scalar load where it is used instead of pinning ~300 SGPRs for the whole kernel
 	const DevModel MJB_AS4 &m = P->m;
-	const FrameLayout MJB_AS4 &L = P->L;
+	const FrameLayout MJB_AS4 &L = (mode == MJB_MODE_STEP && P->use_compact) ? P->Lc : P->L;
 	const DevState MJB_AS4 &s = P->s;
 	const NoiseCfg MJB_AS4 &nz = P->nz;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

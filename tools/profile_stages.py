@@ -12,8 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mujoco_ros_pkgs_amd import binding  # noqa: E402
 
-STAGES = ["kinematics", "com_pos", "crb", "factorM", "transm+sens_pos", "com_vel", "passive", "rne", "sens_vel",
-          "actuation", "acceleration", "constraint", "sens_acc", "ctrl_noise", "forward(total)", "euler"]
+STAGES = ["kinematics", "com_pos", "crb", "factorM", "transm+sens_pos", "com_vel", "passive", "rne(+aref)", "sens_vel",
+          "actuation", "acceleration", "constraint(PGS)", "sens_acc", "ctrl_noise", "forward(total)", "euler",
+          "collision", "make_constraint", "project(B)"]
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--lanes", type=int, default=16)
@@ -31,7 +32,10 @@ cm = engine.CompiledModel(model)
 b = engine.Batch(cm, a.envs)
 b.set_launch(a.lanes, a.epb)
 rng = np.random.default_rng(0)
-b.set("qvel", rng.uniform(-0.1, 0.1, (a.envs, model["nv"])))
+from bench import synthetic_state  # noqa: E402
+qp, qv = synthetic_state(model, a.envs, 1000)
+b.set("qpos", qp)
+b.set("qvel", qv)
 b.set_ctrl_noise(43.5, 0.1, 12345, 0)
 b.step(a.steps)
 b.synchronize()
