@@ -78,6 +78,8 @@ struct mjb_model {
 	std::vector<double> hdbl;         // all double arrays, concatenated
 	std::vector<size_t> ioff, doff;   // offsets of each array inside hint / hdbl (declaration order)
 	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask;
+	std::vector<int> sens_copy, sens_slow, dof_act_adr, dof_act_id;
+	int sens_ncopy[3] = { 0, 0, 0 }, sens_nslow[3] = { 0, 0, 0 }, sens_ncopy_max = 0;
 	int eulerdamp = 0, maxdepth = 0;
 	int field_size[MJB_F_COUNT]{};
 	FrameLayout L{}, Lc{};
@@ -199,6 +201,64 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	}
 	L.nint = (ioff + 1) & ~1;
 	L.nstate = nstate;
+}
+
+// Sensors whose value is a plain copy of frame doubles (joint / actuator scalars, clock, subtree com, global
+// frame positions) become {dst, src} pairs resolved against both layouts; the rest stay on the general path.
+void build_sensor_tables(mjb_model *M)
+{
+	const mjb_model_desc &h = M->h;
+	std::vector<std::pair<int, int>> cp[2][3];
+	std::vector<int> slow[3];
+	for (int i = 0; i < h.nsensor; i++) {
+		const int st = h.sensor_needstage[i] - 1;
+		if (st < 0 || st > 2) continue;
+		const int type = h.sensor_type[i], id = h.sensor_objid[i], ot = h.sensor_objtype[i];
+		bool simple = h.sensor_cutoff[i] <= 0;
+		for (int lay = 0; lay < 2 && simple; lay++) {
+			const FrameLayout &L = lay ? M->Lc : M->L;
+			int src = -1, n = 1;
+			switch (type) {
+			case MJB_SENS_JOINTPOS: src = L.qpos + h.jnt_qposadr[id]; break;
+			case MJB_SENS_JOINTVEL: src = L.qvel + h.jnt_dofadr[id]; break;
+			case MJB_SENS_ACTUATORPOS: src = L.actuator_length + id; break;
+			case MJB_SENS_ACTUATORVEL: src = L.actuator_velocity + id; break;
+			case MJB_SENS_ACTUATORFRC: src = L.actuator_force + id; break;
+			case MJB_SENS_CLOCK: src = L.time; break;
+			case MJB_SENS_SUBTREECOM: src = L.subtree_com + 3 * id; n = 3; break;
+			case MJB_SENS_BALLANGVEL: src = L.qvel + h.jnt_dofadr[id]; n = 3; break;
+			case MJB_SENS_FRAMEPOS:
+				if (h.sensor_refid[i] >= 0) { simple = false; break; }
+				n = 3;
+				if (ot == MJB_OBJ_BODY) src = L.xipos + 3 * id;
+				else if (ot == MJB_OBJ_XBODY) src = L.xpos + 3 * id;
+				else if (ot == MJB_OBJ_GEOM) src = L.geom_xpos + 3 * id;
+				else src = L.site_xpos + 3 * id;
+				break;
+			default: simple = false;
+			}
+			if (simple)
+				for (int k = 0; k < n; k++) cp[lay][st].push_back({ h.sensor_adr[i] + k, src + k });
+		}
+		if (!simple) slow[st].push_back(i);
+	}
+	int mx = 0;
+	for (int st = 0; st < 3; st++) {
+		M->sens_ncopy[st] = (int)cp[0][st].size();
+		M->sens_nslow[st] = (int)slow[st].size();
+		if (M->sens_ncopy[st] > mx) mx = M->sens_ncopy[st];
+	}
+	M->sens_ncopy_max = mx;
+	M->sens_copy.assign((size_t)2 * 3 * (mx ? mx : 1) * 2, 0);
+	for (int lay = 0; lay < 2; lay++)
+		for (int st = 0; st < 3; st++)
+			for (size_t k = 0; k < cp[lay][st].size() && (int)k < M->sens_ncopy[st]; k++) {
+				M->sens_copy[((size_t)(lay * 3 + st) * (mx ? mx : 1) + k) * 2] = cp[lay][st][k].first;
+				M->sens_copy[((size_t)(lay * 3 + st) * (mx ? mx : 1) + k) * 2 + 1] = cp[lay][st][k].second;
+			}
+	M->sens_slow.assign((size_t)3 * (h.nsensor ? h.nsensor : 1), 0);
+	for (int st = 0; st < 3; st++)
+		for (size_t k = 0; k < slow[st].size(); k++) M->sens_slow[(size_t)st * (h.nsensor ? h.nsensor : 1) + k] = slow[st][k];
 }
 
 template <typename T> T *dev_alloc(size_t n)
@@ -405,6 +465,16 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 			if (h.dof_damping[i] > 0) M->eulerdamp = 1;
 	compute_layout(M, M->L, false);
 	compute_layout(M, M->Lc, true);
+	build_sensor_tables(M);
+	// actuators per dof (CSR, ascending actuator id)
+	M->dof_act_adr.assign((size_t)h.nv + 1, 0);
+	for (int i = 0; i < h.nu; i++) M->dof_act_adr[h.jnt_dofadr[h.actuator_trnid[2 * i]] + 1]++;
+	for (int dd = 0; dd < h.nv; dd++) M->dof_act_adr[dd + 1] += M->dof_act_adr[dd];
+	M->dof_act_id.assign((size_t)h.nu, 0);
+	{
+		std::vector<int> fill(M->dof_act_adr.begin(), M->dof_act_adr.end() - 1);
+		for (int i = 0; i < h.nu; i++) M->dof_act_id[fill[h.jnt_dofadr[h.actuator_trnid[2 * i]]]++] = i;
+	}
 	g_err.clear();
 	return M;
 }
@@ -479,7 +549,8 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	size_t ni = M->hint.size(), nd = M->hdbl.size();
 	size_t nt = M->M_rowdof.size() + M->M_coldof.size() + M->dof_depth.size() + M->dof_jstart.size() +
 	            M->body_rec.size() + M->body_rec2.size() + M->dof_rec.size() + M->fac_ops.size() + M->fac_beg.size() +
-	            M->body_dofmask.size() + 64;
+	            M->body_dofmask.size() + M->sens_copy.size() + M->sens_slow.size() + M->dof_act_adr.size() +
+	            M->dof_act_id.size() + 96;
 	size_t bytes_i = ((ni + nt) * sizeof(int) + 15) & ~size_t(15);
 	size_t bytes = bytes_i + nd * sizeof(double) + 16;
 	if (hipMalloc(&b->blob, bytes) != hipSuccess) {
@@ -501,7 +572,8 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	};
 	size_t o_row = put(M->M_rowdof), o_col = put(M->M_coldof), o_dep = put(M->dof_depth), o_js = put(M->dof_jstart);
 	size_t o_br = put(M->body_rec), o_br2 = put(M->body_rec2), o_dr = put(M->dof_rec), o_fo = put(M->fac_ops),
-	       o_fb = put(M->fac_beg), o_dm = put(M->body_dofmask);
+	       o_fb = put(M->fac_beg), o_dm = put(M->body_dofmask), o_sc = put(M->sens_copy), o_ss = put(M->sens_slow),
+	       o_aa = put(M->dof_act_adr), o_ai = put(M->dof_act_id);
 	if (nd) memcpy(hd, M->hdbl.data(), nd * sizeof(double));
 	if (hipMemcpy(b->blob, hostblob.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
 		fail(MJB_ENODEVICE, "mjb_make_batch: model upload failed");
@@ -535,6 +607,15 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	dm.fac_ops = (mjb_ciptr)(di + o_fo);
 	dm.fac_beg = (mjb_ciptr)(di + o_fb);
 	dm.body_dofmask = (mjb_ciptr)(di + o_dm);
+	dm.sens_copy = (mjb_ciptr)(di + o_sc);
+	dm.sens_slow = (mjb_ciptr)(di + o_ss);
+	dm.dof_act_adr = (mjb_ciptr)(di + o_aa);
+	dm.dof_act_id = (mjb_ciptr)(di + o_ai);
+	for (int k = 0; k < 3; k++) {
+		dm.sens_ncopy[k] = M->sens_ncopy[k];
+		dm.sens_nslow[k] = M->sens_nslow[k];
+	}
+	dm.sens_ncopy_max = M->sens_ncopy_max ? M->sens_ncopy_max : 1;
 	dm.eulerdamp = M->eulerdamp;
 	dm.maxdepth = M->maxdepth;
 

@@ -36,6 +36,13 @@ struct DevModel {
 	mjb_ciptr dof_rec;     // [nv][4]    packed {Madr, nancestor, bodyid, parentid}
 	mjb_ciptr fac_ops;     // [nfac][4]  factorisation micro-ops {dst, srcA, srcB, 0}: LD[dst] -= LD[srcA]/LD[kk]*LD[srcB]
 	mjb_ciptr fac_beg;     // [nv+1]     first micro-op of pivot k
+	mjb_ciptr sens_copy;     // [2][3][sens_ncopy_max][2] (layout full/compact, stage-1): {dst offset in sensordata, src frame offset}
+	mjb_ciptr sens_slow;     // [3][nsensor] ids of the sensors of each stage that need real work
+	mjb_ciptr dof_act_adr;   // [nv+1] CSR: actuators (joint transmission) driving each dof
+	mjb_ciptr dof_act_id;    // [nu]
+	int sens_ncopy[3];       // plain-copy elements per stage
+	int sens_nslow[3];       // complex sensors per stage
+	int sens_ncopy_max;
 	mjb_ciptr body_dofmask;  // [nbody][2] bit i set: dof i moves the body (ancestor-or-self dofs), nv <= 64
 	int eulerdamp;         // any dof_damping > 0 and EULERDAMP not disabled
 	int maxdepth;          // max dof_depth

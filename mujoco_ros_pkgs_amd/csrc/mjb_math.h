@@ -83,6 +83,22 @@ DEVI void quat2mat(double *r, const double *q)
 	r[6] = 2 * (q13 - q02);
 	r[7] = 2 * (q23 + q01);
 }
+// same map without the exact-identity shortcut (value-identical: the formula yields exactly I for (1,0,0,0))
+DEVI void quat2mat_nocheck(double *r, const double *q)
+{
+	const double q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
+	const double q11 = q[1] * q[1], q12 = q[1] * q[2], q13 = q[1] * q[3];
+	const double q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
+	r[0] = q00 + q11 - q22 - q33;
+	r[4] = q00 - q11 + q22 - q33;
+	r[8] = q00 - q11 - q22 + q33;
+	r[1] = 2 * (q12 - q03);
+	r[2] = 2 * (q13 + q02);
+	r[3] = 2 * (q12 + q03);
+	r[5] = 2 * (q23 - q01);
+	r[6] = 2 * (q13 - q02);
+	r[7] = 2 * (q23 + q01);
+}
 DEVI void matvec3(double *r, const double *M, const double *v)
 {
 	double t0 = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];

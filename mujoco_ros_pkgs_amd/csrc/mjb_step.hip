@@ -88,8 +88,9 @@ DEVI void local2global(const double *xpos_b, const double *xquat_b, const double
 	}
 }
 
-template <int G> STAGE void kinematics(CModel m, CLayout L, const Env &e)
+template <int G> STAGE void kinematics(CModel m, CLayout L, CState s, const Env &e)
 {
+	PROF_BEGIN();
 	double *f = e.f;
 	double *qpos = f + L.qpos, *xpos = f + L.xpos, *xquat = f + L.xquat, *xmat = f + L.xmat;
 	double *xanchor = f + L.xanchor, *xaxis = f + L.xaxis;
@@ -152,41 +153,46 @@ template <int G> STAGE void kinematics(CModel m, CLayout L, const Env &e)
 		st4(loc + 7 * b + 3, q);
 	}
 	gsync<G>();
+	PROF(20);
 
 	// Phase B -- thin serial chain, replicated in every lane with the running parent pose in registers:
-	// xquat_i = xquat_p * lq_i,  xpos_i = xpos_p + R_p lp_i.  Quaternions are re-normalised in phase C.
+	// xquat_i = xquat_p * lq_i,  xpos_i = xpos_p + R_p lp_i.  Only xpos / xquat are stored (7 doubles per body);
+	// phase C re-normalises the quaternions and derives xmat.
 	{
 		double cp[3] = { 0, 0, 0 }, cq[4] = { 1, 0, 0, 0 }, cM[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
 		if (lane == 0) {
 			st3(xpos, cp);
 			st4(xquat, cq);
-			st9(xmat, cM);
 		}
+		double lp[3], lq[4];
+		ld3(lp, loc + 7);
+		ld4(lq, loc + 10);
 #pragma nounroll
 		for (int i = 1; i < m.nbody; i++) {
 			const int pid = m.body_rec[4 * i];
-			double lp[3], lq[4];
-			ld3(lp, loc + 7 * i);
-			ld4(lq, loc + 7 * i + 3);
 			if (pid != i - 1) {
 				ld3(cp, xpos + 3 * pid);
 				ld4(cq, xquat + 4 * pid);
-				ld9(cM, xmat + 9 * pid);
+				quat2mat_nocheck(cM, cq);
 			}
 			double v[3];
 			matvec3(v, cM, lp);
 			cp[0] += v[0]; cp[1] += v[1]; cp[2] += v[2];
 			qmul(cq, cq, lq);
-			quat2mat(cM, cq);
+			// prefetch the next body's local pose before this body's stores enter the LDS queue
+			const int nx = (i + 1 < m.nbody) ? i + 1 : i;
+			ld3(lp, loc + 7 * nx);
+			ld4(lq, loc + 7 * nx + 3);
 			if (lane == 0) {
 				st3(xpos + 3 * i, cp);
 				st4(xquat + 4 * i, cq);
-				st9(xmat + 9 * i, cM);
 			}
+			quat2mat_nocheck(cM, cq);
 		}
 	}
 	gsync<G>();
 
+	PROF(21);
 	// Phase C -- one body per lane: normalise xquat, final xmat, inertial frame
 	for (int b = lane; b < m.nbody; b += G) {
 		double q[4], M[9], p[3];
@@ -214,6 +220,7 @@ template <int G> STAGE void kinematics(CModel m, CLayout L, const Env &e)
 	}
 	gsync<G>();
 
+	PROF(22);
 	// Phase D -- joints (anchor / axis to the world frame through the PARENT body's frame), geoms, sites
 	const int nitem = m.njnt + m.ngeom + m.nsite;
 	for (int it = lane; it < nitem; it += G) {
@@ -249,6 +256,7 @@ template <int G> STAGE void kinematics(CModel m, CLayout L, const Env &e)
 		}
 	}
 	gsync<G>();
+	PROF(23);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -383,25 +391,49 @@ STAGE void factor2(CModel m, const Env &e, const double *M, double *LD, double *
 		if (dual) LD2[en] = M2[en];
 	}
 	gsync<G>();
+	{
+		int k = m.nv - 1;
+		int na = k >= 0 ? m.dof_rec[4 * k + 1] : 0, kk = k >= 0 ? m.dof_rec[4 * k] : 0;
+		int beg = k >= 0 ? m.fac_beg[k] : 0, end = k >= 0 ? m.fac_beg[k + 1] : 0;
+		int o0 = 0, o1 = 0, o2 = 0;  // this lane's first micro-op of the pivot
+		if (beg + lane < end) {
+			o0 = m.fac_ops[4 * (beg + lane)];
+			o1 = m.fac_ops[4 * (beg + lane) + 1];
+			o2 = m.fac_ops[4 * (beg + lane) + 2];
+		}
 #pragma nounroll
-	for (int k = m.nv - 1; k >= 0; k--) {
-		const int na = m.dof_rec[4 * k + 1];
-		if (na <= 0) continue;
-		const int kk = m.dof_rec[4 * k];
-		const int beg = m.fac_beg[k], end = m.fac_beg[k + 1];
-		const double dkk = LD[kk];
-		const double dkk2 = dual ? LD2[kk] : 1.0;
-		for (int t = beg + lane; t < end; t += G) {
-			const int dst = m.fac_ops[4 * t], sa = m.fac_ops[4 * t + 1], sb = m.fac_ops[4 * t + 2];
-			LD[dst] -= LD[sa] / dkk * LD[sb];
-			if (dual) LD2[dst] -= LD2[sa] / dkk2 * LD2[sb];
+		for (; k >= 0; k--) {
+			const int na_c = na, kk_c = kk, beg_c = beg, end_c = end, dst = o0, sa = o1, sb = o2;
+			if (k > 0) {
+				na = m.dof_rec[4 * (k - 1) + 1];
+				kk = m.dof_rec[4 * (k - 1)];
+				beg = m.fac_beg[k - 1];
+				end = beg_c;  // fac_beg[k]
+				if (beg + lane < end) {
+					o0 = m.fac_ops[4 * (beg + lane)];
+					o1 = m.fac_ops[4 * (beg + lane) + 1];
+					o2 = m.fac_ops[4 * (beg + lane) + 2];
+				}
+			}
+			if (na_c <= 0) continue;
+			const double dkk = LD[kk_c];
+			const double dkk2 = dual ? LD2[kk_c] : 1.0;
+			if (beg_c + lane < end_c) {
+				LD[dst] -= LD[sa] / dkk * LD[sb];
+				if (dual) LD2[dst] -= LD2[sa] / dkk2 * LD2[sb];
+			}
+			for (int t = beg_c + lane + G; t < end_c; t += G) {
+				const int d2 = m.fac_ops[4 * t], a2 = m.fac_ops[4 * t + 1], b2 = m.fac_ops[4 * t + 2];
+				LD[d2] -= LD[a2] / dkk * LD[b2];
+				if (dual) LD2[d2] -= LD2[a2] / dkk2 * LD2[b2];
+			}
+			gsync<G>();
+			for (int a = lane; a < na_c; a += G) {
+				LD[kk_c + 1 + a] = LD[kk_c + 1 + a] / dkk;
+				if (dual) LD2[kk_c + 1 + a] = LD2[kk_c + 1 + a] / dkk2;
+			}
+			gsync<G>();
 		}
-		gsync<G>();
-		for (int a = lane; a < na; a += G) {
-			LD[kk + 1 + a] = LD[kk + 1 + a] / dkk;
-			if (dual) LD2[kk + 1 + a] = LD2[kk + 1 + a] / dkk2;
-		}
-		gsync<G>();
 	}
 	for (int i = lane; i < m.nv; i += G) {
 		const int ii = m.dof_rec[4 * i];
@@ -426,36 +458,60 @@ template <int W> DEVI double row_sum(double v)  // W = 8 or 16 participating lan
 	return v;
 }
 
-template <int G> STAGE void solve(CModel m, const Env &e, double *x, const double *LD, const double *diaginv)
+// Two right-hand sides with two factors of the same sparsity are solved in the same rounds (dual == true):
+// qacc_smooth = M^-1 f  and, when nothing can change the force in between (no constraint rows), Euler's
+// (M + hB)^-1 f -- the second solve rides on the latency chain of the first.
+template <int G>
+STAGE void solve2(CModel m, const Env &e, double *x, const double *LD, const double *diaginv, double *x2,
+                  const double *LD2, const double *diaginv2, bool dual)
 {
 	const int lane = e.lane;
+	constexpr int W = G < 16 ? G : 16;
 	// x <- inv(L') x : column sweep, one ancestor per lane
 #pragma nounroll
 	for (int i = m.nv - 1; i >= 0; i--) {
-		const int na = m.dof_rec[4 * i + 1];
+		const int na = m.dof_rec[4 * i + 1], ii = m.dof_rec[4 * i];
 		if (na <= 0) continue;
-		const int ii = m.dof_rec[4 * i];
 		const double xi = x[i];
-		for (int a = lane; a < na; a += G) x[m.M_coldof[ii + 1 + a]] -= LD[ii + 1 + a] * xi;
+		const double xi2 = dual ? x2[i] : 0.0;
+		for (int a = lane; a < na; a += G) {
+			const int j = m.M_coldof[ii + 1 + a];
+			x[j] -= LD[ii + 1 + a] * xi;
+			if (dual) x2[j] -= LD2[ii + 1 + a] * xi2;
+		}
 		gsync<G>();
 	}
-	for (int i = lane; i < m.nv; i += G) x[i] *= diaginv[i];
+	for (int i = lane; i < m.nv; i += G) {
+		x[i] *= diaginv[i];
+		if (dual) x2[i] *= diaginv2[i];
+	}
 	gsync<G>();
 	// x <- inv(L) x : row i needs its ancestors only; products one per lane (first min(G,16) lanes of the group),
 	// summed with a DPP row butterfly
 #pragma nounroll
 	for (int i = 0; i < m.nv; i++) {
-		const int na = m.dof_rec[4 * i + 1];
+		const int na = m.dof_rec[4 * i + 1], ii = m.dof_rec[4 * i];
 		if (na <= 0) continue;
-		const int ii = m.dof_rec[4 * i];
-		constexpr int W = G < 16 ? G : 16;
-		double part = 0;
+		double part = 0, part2 = 0;
 		if (lane < W)
-			for (int a = lane; a < na; a += W) part += LD[ii + 1 + a] * x[m.M_coldof[ii + 1 + a]];
+			for (int a = lane; a < na; a += W) {
+				const int j = m.M_coldof[ii + 1 + a];
+				part += LD[ii + 1 + a] * x[j];
+				if (dual) part2 += LD2[ii + 1 + a] * x2[j];
+			}
 		part = row_sum<W>(part);
-		if (lane == 0) x[i] -= part;
+		if (dual) part2 = row_sum<W>(part2);
+		if (lane == 0) {
+			x[i] -= part;
+			if (dual) x2[i] -= part2;
+		}
 		gsync<G>();
 	}
+}
+
+template <int G> DEVI void solve(CModel m, const Env &e, double *x, const double *LD, const double *diaginv)
+{
+	solve2<G>(m, e, x, LD, diaginv, x, LD, diaginv, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -685,12 +741,22 @@ DEVI void object_velocity(CModel m, CLayout L, const double *f, int objtype, int
 	}
 }
 
-template <int G> STAGE void sensors(CModel m, CLayout L, const Env &e, int stage)
+template <int G> STAGE void sensors(CModel m, CLayout L, const Env &e, int stage, int compact)
 {
 	if (m.disableflags & MJB_DSBL_SENSOR) return;
+	const int ncopy = m.sens_ncopy[stage - 1], nslow = m.sens_nslow[stage - 1];
+	if (ncopy == 0 && nslow == 0) return;
 	double *f = e.f;
-	for (int i = e.lane; i < m.nsensor; i += G) {
-		if (m.sensor_needstage[i] != stage) continue;
+	// plain copies: host-resolved {dst, src} pairs (table of the layout in use)
+	{
+		const int tb = ((compact ? 3 : 0) + stage - 1) * m.sens_ncopy_max;
+		for (int t = e.lane; t < ncopy; t += G) {
+			const int dst = m.sens_copy[2 * (tb + t)], src = m.sens_copy[2 * (tb + t) + 1];
+			f[L.sensordata + dst] = f[src];
+		}
+	}
+	for (int t = e.lane; t < nslow; t += G) {
+		const int i = m.sens_slow[(stage - 1) * (m.nsensor ? m.nsensor : 1) + t];
 		const int type = m.sensor_type[i], id = m.sensor_objid[i], ot = m.sensor_objtype[i];
 		const int rid = m.sensor_refid[i], rt = m.sensor_reftype[i];
 		double out[4] = { 0, 0, 0, 0 };
@@ -804,34 +870,34 @@ template <int G> STAGE void fwd_actuation(CModel m, CLayout L, const Env &e)
 {
 	double *f = e.f;
 	const bool off = m.nu == 0 || (m.disableflags & MJB_DSBL_ACTUATION);
-	for (int i = e.lane; i < m.nu; i += G) {
-		double force = 0;
-		if (!off) {
-			double ctrl = f[L.ctrl + i];
-			if (m.actuator_ctrllimited[i] && !(m.disableflags & MJB_DSBL_CLAMPCTRL)) {
-				const double lo = m.actuator_ctrlrange[2 * i], hi = m.actuator_ctrlrange[2 * i + 1];
-				ctrl = ctrl < lo ? lo : (ctrl > hi ? hi : ctrl);
-			}
-			const double len = f[L.actuator_length + i], vel = f[L.actuator_velocity + i];
-			double gain = m.actuator_gainprm[3 * i], bias = 0;
-			if (m.actuator_gaintype[i] == MJB_GAIN_AFFINE)
-				gain = m.actuator_gainprm[3 * i] + m.actuator_gainprm[3 * i + 1] * len + m.actuator_gainprm[3 * i + 2] * vel;
-			if (m.actuator_biastype[i] == MJB_BIAS_AFFINE)
-				bias = m.actuator_biasprm[3 * i] + m.actuator_biasprm[3 * i + 1] * len + m.actuator_biasprm[3 * i + 2] * vel;
-			force = gain * ctrl + bias;
-			if (m.actuator_forcelimited[i]) {
-				const double lo = m.actuator_forcerange[2 * i], hi = m.actuator_forcerange[2 * i + 1];
-				force = force < lo ? lo : (force > hi ? hi : force);
-			}
-		}
-		f[L.actuator_force + i] = force;
-	}
-	gsync<G>();
+	// one dof per lane: forces of the actuators driving it (host-built CSR lists, ascending actuator id)
 	for (int d = e.lane; d < m.nv; d += G) {
 		double acc = 0;
-		if (!off)
-			for (int i = 0; i < m.nu; i++)
-				if (m.jnt_dofadr[m.actuator_trnid[2 * i]] == d) acc += m.actuator_gear[6 * i] * f[L.actuator_force + i];
+		const int t0 = m.dof_act_adr[d], t1 = m.dof_act_adr[d + 1];
+		for (int t = t0; t < t1; t++) {
+			const int i = m.dof_act_id[t];
+			double force = 0;
+			if (!off) {
+				double ctrl = f[L.ctrl + i];
+				if (m.actuator_ctrllimited[i] && !(m.disableflags & MJB_DSBL_CLAMPCTRL)) {
+					const double lo = m.actuator_ctrlrange[2 * i], hi = m.actuator_ctrlrange[2 * i + 1];
+					ctrl = ctrl < lo ? lo : (ctrl > hi ? hi : ctrl);
+				}
+				const double len = f[L.actuator_length + i], vel = f[L.actuator_velocity + i];
+				double gain = m.actuator_gainprm[3 * i], bias = 0;
+				if (m.actuator_gaintype[i] == MJB_GAIN_AFFINE)
+					gain = m.actuator_gainprm[3 * i] + m.actuator_gainprm[3 * i + 1] * len + m.actuator_gainprm[3 * i + 2] * vel;
+				if (m.actuator_biastype[i] == MJB_BIAS_AFFINE)
+					bias = m.actuator_biasprm[3 * i] + m.actuator_biasprm[3 * i + 1] * len + m.actuator_biasprm[3 * i + 2] * vel;
+				force = gain * ctrl + bias;
+				if (m.actuator_forcelimited[i]) {
+					const double lo = m.actuator_forcerange[2 * i], hi = m.actuator_forcerange[2 * i + 1];
+					force = force < lo ? lo : (force > hi ? hi : force);
+				}
+				acc += m.actuator_gear[6 * i] * force;
+			}
+			f[L.actuator_force + i] = force;
+		}
 		f[L.qfrc_actuator + d] = acc;
 	}
 	gsync<G>();
@@ -867,9 +933,11 @@ template <int G> STAGE void fwd_acceleration(CModel m, CLayout L, const Env &e, 
 		}
 		f[L.qfrc_smooth + d] = v;
 		f[L.qacc_smooth + d] = v;
+		f[L.eulerx + d] = v;  // rhs of Euler's implicit-damping solve when no constraint force can be added
 	}
 	gsync<G>();
-	solve<G>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv);
+	const bool dual = m.eulerdamp && m.nefcmax == 0;
+	solve2<G>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual);
 }
 
 #include "mjb_constraint.h"
@@ -900,7 +968,9 @@ template <int G> STAGE void euler(CModel m, CLayout L, const Env &e)
 	double *f = e.f;
 	const double dt = m.timestep[0];
 	double *x = f + L.eulerx;
-	if (m.eulerdamp) {
+	if (m.eulerdamp && m.nefcmax == 0) {
+		// (M + h B) x = qfrc_smooth was already solved next to qacc_smooth (fwd_acceleration, dual solve)
+	} else if (m.eulerdamp) {
 		// (M + h B) x = qfrc_smooth + qfrc_constraint, factor qH prepared next to qLD in fwd_position
 		for (int d = e.lane; d < m.nv; d += G) x[d] = f[L.qfrc_smooth + d] + f[L.qfrc_constraint + d];
 		gsync<G>();
@@ -1000,10 +1070,10 @@ template <int G> STAGE void reset_frame_state(CModel m, CLayout L, CState s, con
 // ------------------------------------------------------------------------------------------------
 // pipeline pieces
 // ------------------------------------------------------------------------------------------------
-template <int G> DEVI void forward_first(CModel m, CLayout L, CState s, const Env &e)
+template <int G> DEVI void forward_first(CModel m, CLayout L, CState s, const Env &e, int compact)
 {
 	PROF_BEGIN();
-	kinematics<G>(m, L, e);
+	kinematics<G>(m, L, s, e);
 	PROF(0);
 	com_pos<G>(m, L, e);
 	PROF(1);
@@ -1021,7 +1091,7 @@ template <int G> DEVI void forward_first(CModel m, CLayout L, CState s, const En
 		PROF(18);
 	}
 	transmission<G>(m, L, e);
-	sensors<G>(m, L, e, MJB_STAGE_POS);
+	sensors<G>(m, L, e, MJB_STAGE_POS, compact);
 	PROF(4);
 	com_vel<G>(m, L, e);
 	PROF(5);
@@ -1030,11 +1100,11 @@ template <int G> DEVI void forward_first(CModel m, CLayout L, CState s, const En
 	if (m.nefcmax > 0) reference_constraint<G>(m, L, e);
 	rne<G>(m, L, e);
 	PROF(7);
-	sensors<G>(m, L, e, MJB_STAGE_VEL);
+	sensors<G>(m, L, e, MJB_STAGE_VEL, compact);
 	PROF(8);
 }
 
-template <int G> DEVI void forward_rest(CModel m, CLayout L, CState s, const Env &e)
+template <int G> DEVI void forward_rest(CModel m, CLayout L, CState s, const Env &e, int compact)
 {
 	PROF_BEGIN();
 	fwd_actuation<G>(m, L, e);
@@ -1048,7 +1118,7 @@ template <int G> DEVI void forward_rest(CModel m, CLayout L, CState s, const Env
 		fwd_constraint<G>(m, L, e);
 	}
 	PROF(11);
-	sensors<G>(m, L, e, MJB_STAGE_ACC);
+	sensors<G>(m, L, e, MJB_STAGE_ACC, compact);
 	PROF(12);
 }
 
@@ -1075,7 +1145,8 @@ __global__ void __launch_bounds__(256, (G == 64 ? 4 : (G == 32 ? 2 : 1)))
 	// launch parameters live in device memory behind a constant-address-space pointer: every field is
 	// fetched with a scalar load where it is used instead of pinning ~300 SGPRs for the whole kernel
 	const DevModel MJB_AS4 &m = P->m;
-	const FrameLayout MJB_AS4 &L = (mode == MJB_MODE_STEP && P->use_compact) ? P->Lc : P->L;
+	const int compact = (mode == MJB_MODE_STEP && P->use_compact) ? 1 : 0;
+	const FrameLayout MJB_AS4 &L = compact ? P->Lc : P->L;
 	const DevState MJB_AS4 &s = P->s;
 	const NoiseCfg MJB_AS4 &nz = P->nz;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1124,10 +1195,10 @@ __global__ void __launch_bounds__(256, (G == 64 ? 4 : (G == 32 ? 2 : 1)))
 				if (do_first || attempt) {
 					if (attempt == 0 && checks && any_bad<G>(e, L, e.f + L.qpos, m.nq, e.f + L.qvel, m.nv))
 						reset_frame_state<G>(m, L, s, e);
-					forward_first<G>(m, L, s, e);
+					forward_first<G>(m, L, s, e, compact);
 				}
 				if (!do_rest) break;
-				forward_rest<G>(m, L, s, e);
+				forward_rest<G>(m, L, s, e, compact);
 				if (attempt || !checks || !any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0)) break;
 				reset_frame_state<G>(m, L, s, e);
 			}

@@ -14,7 +14,7 @@ from mujoco_ros_pkgs_amd import binding  # noqa: E402
 
 STAGES = ["kinematics", "com_pos", "crb", "factorM", "transm+sens_pos", "com_vel", "passive", "rne(+aref)", "sens_vel",
           "actuation", "acceleration", "constraint(PGS)", "sens_acc", "ctrl_noise", "forward(total)", "euler",
-          "collision", "make_constraint", "project(B)"]
+          "collision", "make_constraint", "project(B)", "-", "kin.A local poses", "kin.B chain", "kin.C normalise+inertial", "kin.D joints/geoms/sites"]
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--lanes", type=int, default=16)
