@@ -428,17 +428,20 @@ STAGE void factor2(CModel m, const Env &e, const double *M, double *LD, double *
 				if (dual) LD2[d2] -= LD2[a2] / dkk2 * LD2[b2];
 			}
 			gsync<G>();
-			for (int a = lane; a < na_c; a += G) {
-				LD[kk_c + 1 + a] = LD[kk_c + 1 + a] / dkk;
-				if (dual) LD2[kk_c + 1 + a] = LD2[kk_c + 1 + a] / dkk2;
-			}
-			gsync<G>();
 		}
 	}
-	for (int i = lane; i < m.nv; i += G) {
-		const int ii = m.dof_rec[4 * i];
-		di[i] = 1.0 / LD[ii];
-		if (dual) di2[i] = 1.0 / LD2[ii];
+	// Row scaling is deferred: pivot k's updates only need the UNSCALED row k and its diagonal, and no later pivot
+	// reads row k, so  L(k,a) = U(k,a) / D(k)  is applied to all entries at once here (one round instead of nv).
+	for (int en = lane; en < m.nM; en += G) {
+		const int row = m.M_rowdof[en];
+		if (m.M_coldof[en] != row) {
+			const int kk = m.dof_rec[4 * row];
+			LD[en] = LD[en] / LD[kk];
+			if (dual) LD2[en] = LD2[en] / LD2[kk];
+		} else {
+			di[row] = 1.0 / LD[en];
+			if (dual) di2[row] = 1.0 / LD2[en];
+		}
 	}
 	gsync<G>();
 }
