@@ -108,8 +108,12 @@ def main():
         print("bench.py: no GPU visible; the engine has no CPU fallback", file=sys.stderr)
         sys.exit(3)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_gather = os.environ.get("MJB_BENCH_FORCE_GATHER", "0") == "1"  # exercise the RCCL path on one GPU
+    if world > 1 or force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from mujoco_ros_pkgs_amd import engine, mjcf, sharding
@@ -129,16 +133,20 @@ def main():
 
     nsd = model["nsensordata"]
     sens_local = torch.as_tensor(DevArray(batch.device_ptr("sensordata"), (E, nsd)), device=f"cuda:{local_rank}")
-    sens_all = torch.empty((world * E, nsd), dtype=torch.float64, device=f"cuda:{local_rank}") if world > 1 else None
+    gather = world > 1 or force_gather
+    sens_all = torch.empty((world * E, nsd), dtype=torch.float64, device=f"cuda:{local_rank}") if gather else None
 
     def one_step():
         batch.step(S)
-        if world > 1:
+        if gather:
             batch.synchronize()  # kernel ran on the engine's stream; the gather runs on torch's
-            sharding.gather_sensordata(sens_local, sens_all)
+            if world > 1:
+                sharding.gather_sensordata(sens_local, sens_all)
+            else:
+                dist.all_gather_into_tensor(sens_all, sens_local)
 
     def fence():
-        if world > 1:
+        if gather:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -191,7 +199,14 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(out))
-    if world > 1:
+    if gather:
+        if force_gather and rank == 0:
+            batch.synchronize()
+            dist.all_gather_into_tensor(sens_all, sens_local)
+            torch.cuda.synchronize()
+            host = torch.from_numpy(batch.get("sensordata")).to(sens_all.device)
+            ok = bool(torch.equal(sens_all[:E], host)) and bool(torch.isfinite(sens_all).all())
+            print(f"forced single-rank gather: sensordata round trip {'ok' if ok else 'MISMATCH'}", file=sys.stderr)
         dist.barrier()
         dist.destroy_process_group()
 
