@@ -139,6 +139,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	for (const FieldInfo &fi : kFields) {
 		int n = dim(fi);
 		if (idx == MJB_F_efc_AR) n = 0;  // the GPU solver is AR-free
+		if (idx == MJB_F_efc_B && d.solver == MJB_SOL_NEWTON) n = 0;  // the primal solver needs no J M^-1
 		if (!compact) M->field_size[idx] = n;
 		const bool in_a = compact && (idx == MJB_F_crb || idx == MJB_F_cacc || idx == MJB_F_cfrc_body);
 		const bool in_b = alias_b && (idx == MJB_F_ximat || idx == MJB_F_cvel || idx == MJB_F_cdof_dot);
@@ -155,6 +156,13 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		}
 		idx++;
 	}
+	const bool newton = d.nefcmax > 0 && d.solver == MJB_SOL_NEWTON;
+	L.nwt_M = off;
+	off += newton ? d.nv * d.nv : 0;
+	L.nwt_H = off;
+	off += newton ? d.nv * d.nv : 0;
+	L.nwt_vec = off;
+	off += newton ? 5 * d.nv : 0;
 	L.MhB = off;
 	off += d.nM;
 	L.qH = off;
@@ -307,9 +315,9 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		return nullptr;
 	}
 	if (d.nefcmax > 0 || d.nconmax > 0) {
-		if (d.solver != MJB_SOL_PGS || d.cone != MJB_CONE_PYRAMIDAL) {
-			fail(MJB_EUNSUPPORTED, "mjb_compile: models with constraint rows need solver=PGS and cone=pyramidal "
-			                       "(Newton / CG / elliptic cones are not implemented)");
+		if ((d.solver != MJB_SOL_PGS && d.solver != MJB_SOL_NEWTON) || d.cone != MJB_CONE_PYRAMIDAL) {
+			fail(MJB_EUNSUPPORTED, "mjb_compile: models with constraint rows need solver=PGS or Newton and cone=pyramidal "
+			                       "(CG and elliptic cones are not implemented)");
 			return nullptr;
 		}
 		if (d.nefcmax > 64 || d.nv > 64) {

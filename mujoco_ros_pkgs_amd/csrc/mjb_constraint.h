@@ -735,3 +735,254 @@ template <int G> STAGE void fwd_constraint_pgs(CModel m, CLayout L, const Env &e
 	}
 	gsync<G>();
 }
+
+// ------------------------------------------------------------------------------------------------
+// A14 Newton solver (primal), one env per wavefront.
+//   minimise over a:  0.5 (a - a0)' M (a - a0) + sum_i s_i(J_i a - aref_i),  s_i(x) = 0.5 D_i x^2 for x < 0
+// Rows live in lanes (jaref, jv, D in registers), dof vectors in LDS; the nv x nv Hessian
+// H = M + J' diag(D[active]) J is rebuilt each iteration (entry per lane), factorised by a column Cholesky
+// whose pivot is exchanged with v_readlane, and the exact line search evaluates the piecewise-quadratic cost
+// with three wave-wide sums per trial point.
+// ------------------------------------------------------------------------------------------------
+struct LsPoint {
+	double alpha, cost, d0, d1;
+};
+
+DEVI void ls_eval(LsPoint &p, bool rowact, double jaref, double jv, double q0r, double q1r, double q2r, double g0,
+                  double g1, double g2)
+{
+	const double a = p.alpha;
+	const bool act = rowact && (jaref + a * jv < 0);
+	const double s0 = wave_sum(act ? q0r : 0.0), s1 = wave_sum(act ? q1r : 0.0), s2 = wave_sum(act ? q2r : 0.0);
+	const double q0 = g0 + s0, q1 = g1 + s1, q2 = g2 + s2;
+	p.cost = a * a * q2 + a * q1 + q0;
+	p.d0 = 2 * a * q2 + q1;
+	p.d1 = 2 * q2;
+	if (p.d1 <= 0) p.d1 = MJB_MINVAL;
+}
+
+template <int G> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e)
+{
+	static_assert(G == 64, "the Newton solver maps rows / Hessian columns to the 64 lanes of one wavefront");
+	double *f = e.f;
+	int *fi = e.fi;
+	const int lane = e.lane, nv = m.nv;
+	const int nefc = fi[L.nefc];
+	if (nefc == 0) {
+		for (int d = lane; d < nv; d += G) {
+			const double a = f[L.qacc_smooth + d];
+			f[L.qacc + d] = a;
+			f[L.qacc_warmstart + d] = a;
+			f[L.qfrc_constraint + d] = 0;
+		}
+		if (lane == 0) fi[L.solver_iter] = 0;
+		gsync<G>();
+		return;
+	}
+	double *Md = f + L.nwt_M, *H = f + L.nwt_H;
+	double *qa = f + L.nwt_vec, *Ma = qa + nv, *grad = Ma + nv, *srch = grad + nv, *Mv = srch + nv;
+	const bool rowact = lane < nefc, dofact = lane < nv;
+	const int r = rowact ? lane : 0, k = dofact ? lane : 0;
+	const double *Jr = f + L.efc_J + r * nv;
+	const double D = rowact ? f[L.efc_D + r] : 0.0, aref = rowact ? f[L.efc_aref + r] : 0.0;
+	const double tol = m.tolerance[0];
+	const double scale = 1.0 / (m.meaninertia[0] * (nv > 1 ? nv : 1));
+
+	// dense symmetric M from the qM layout (entry per lane)
+	for (int t = lane; t < nv * nv; t += G) Md[t] = 0;
+	gsync<G>();
+	for (int en = lane; en < m.nM; en += G) {
+		const int i = m.M_rowdof[en], j = m.M_coldof[en];
+		const double v = f[L.qM + en];
+		Md[i * nv + j] = v;
+		Md[j * nv + i] = v;
+	}
+	gsync<G>();
+
+	// warmstart: the cheaper of qacc_warmstart and qacc_smooth
+	{
+		double best = 0;
+		for (int pass = 0; pass < 2; pass++) {
+			const double *q0 = f + (pass == 0 ? L.qacc_warmstart : L.qacc_smooth);
+			double t = 0;
+			if (dofact)
+				for (int c = 0; c < nv; c++) t += Md[k * nv + c] * q0[c];
+			const double gk = dofact ? 0.5 * (t - f[L.qfrc_smooth + k]) * (q0[k] - f[L.qacc_smooth + k]) : 0.0;
+			double x = -aref;
+			for (int c = 0; c < nv; c++) x += Jr[c] * q0[c];
+			const double ck = (rowact && x < 0) ? 0.5 * D * x * x : 0.0;
+			const double cost = wave_sum(gk) + wave_sum(ck);
+			bool take;
+			if (pass == 0) {
+				best = (m.disableflags & MJB_DSBL_WARMSTART) ? 1e300 : cost;
+				take = true;
+			} else {
+				take = cost < best;
+			}
+			if (take && dofact) qa[k] = q0[k];
+			gsync<G>();
+		}
+	}
+
+	double cost = 0, prev_cost = 0;
+	int iter = 0;
+	for (;;) {
+		// Ma = M qacc, jaref = J qacc - aref, forces, cost, gradient
+		double ma = 0;
+		if (dofact)
+			for (int c = 0; c < nv; c++) ma += Md[k * nv + c] * qa[c];
+		const double gk = dofact ? 0.5 * (ma - f[L.qfrc_smooth + k]) * (qa[k] - f[L.qacc_smooth + k]) : 0.0;
+		double jaref = -aref;
+		for (int c = 0; c < nv; c++) jaref += Jr[c] * qa[c];
+		const bool active = rowact && jaref < 0;
+		const double frc = active ? -D * jaref : 0.0;
+		const double gauss = wave_sum(gk);
+		prev_cost = cost;
+		cost = gauss + wave_sum(active ? 0.5 * D * jaref * jaref : 0.0);
+		if (rowact) f[L.efc_force + r] = frc;
+		if (dofact) Ma[k] = ma;
+		gsync<G>();
+		double gr = 0;
+		if (dofact) {
+			double s = 0;
+			for (int i = 0; i < nefc; i++) s += f[L.efc_J + i * nv + k] * f[L.efc_force + i];
+			f[L.qfrc_constraint + k] = s;
+			gr = ma - f[L.qfrc_smooth + k] - s;
+			grad[k] = gr;
+		}
+		if (iter > 0) {
+			const double improvement = scale * (prev_cost - cost);
+			const double gnorm = scale * sqrt(wave_sum(gr * gr));
+			if (improvement < tol || gnorm < tol || iter >= m.iterations) break;
+		}
+		// H = M + J' D_active J  (lower + upper, entry per lane); active flags parked in efc_b
+		if (rowact) f[L.efc_b + r] = active ? D : 0.0;
+		gsync<G>();
+		for (int t = lane; t < nv * nv; t += G) {
+			const int rr = t / nv, cc = t - rr * nv;
+			double s = Md[t];
+			for (int i = 0; i < nefc; i++) {
+				const double di = f[L.efc_b + i];
+				if (di != 0) s += di * f[L.efc_J + i * nv + rr] * f[L.efc_J + i * nv + cc];
+			}
+			H[t] = s;
+		}
+		gsync<G>();
+		// column Cholesky, lane = row of H (nv <= 64)
+		for (int j = 0; j < nv; j++) {
+			double s = 0;
+			if (dofact && k >= j) {
+				s = H[k * nv + j];
+				for (int c = 0; c < j; c++) s -= H[k * nv + c] * H[j * nv + c];
+			}
+			double sj = wave_bcast(s, j);
+			if (sj < MJB_MINVAL) sj = MJB_MINVAL;
+			const double ljj = sqrt(sj);
+			if (dofact && k >= j) H[k * nv + j] = (k == j) ? ljj : s / ljj;
+			gsync<G>();
+		}
+		// search = -H^-1 grad : lane k holds element k
+		double x = gr;
+		for (int i = 0; i < nv; i++) {
+			const double lii = H[i * nv + i];
+			const double xi = wave_bcast(x, i) / lii;
+			if (dofact && k == i) x = xi;
+			else if (dofact && k > i) x -= H[k * nv + i] * xi;
+		}
+		for (int i = nv - 1; i >= 0; i--) {
+			const double lii = H[i * nv + i];
+			const double xi = wave_bcast(x, i) / lii;
+			if (dofact && k == i) x = xi;
+			else if (dofact && k < i) x -= H[i * nv + k] * xi;
+		}
+		const double sk = dofact ? -x : 0.0;
+		const double snorm = sqrt(wave_sum(sk * sk));
+		if (snorm < MJB_MINVAL) break;
+		if (dofact) srch[k] = sk;
+		gsync<G>();
+		// line search along the Newton direction
+		double mv = 0;
+		if (dofact)
+			for (int c = 0; c < nv; c++) mv += Md[k * nv + c] * srch[c];
+		double jv = 0;
+		for (int c = 0; c < nv; c++) jv += Jr[c] * srch[c];
+		const double g0 = gauss;
+		const double g1 = wave_sum(dofact ? sk * (ma - f[L.qfrc_smooth + k]) : 0.0);
+		const double g2 = wave_sum(dofact ? 0.5 * sk * mv : 0.0);
+		const double q0r = 0.5 * D * jaref * jaref, q1r = D * jaref * jv, q2r = 0.5 * D * jv * jv;
+		const double gtol = tol * 0.01 * snorm / scale;  // mjOption.ls_tolerance = 0.01
+		double alpha;
+		{
+			LsPoint p0, p1, p2, pmid, p1n, p2n;
+			int lsit = 0;
+			const int maxls = 50;  // mjOption.ls_iterations
+			bool done = false;
+			p0.alpha = 0;
+			ls_eval(p0, rowact, jaref, jv, q0r, q1r, q2r, g0, g1, g2);
+			p1.alpha = p0.alpha - p0.d0 / p0.d1;
+			ls_eval(p1, rowact, jaref, jv, q0r, q1r, q2r, g0, g1, g2);
+			if (p0.cost < p1.cost) p1 = p0;
+			alpha = p1.alpha;
+			if (fabs(p1.d0) < gtol) done = true;
+			const int dir = p1.d0 < 0 ? 1 : -1;
+			bool p2update = false;
+			p2 = p1;
+			while (!done && p1.d0 * dir <= -gtol && lsit < maxls) {
+				p2 = p1;
+				p2update = true;
+				p1.alpha = p1.alpha - p1.d0 / p1.d1;
+				ls_eval(p1, rowact, jaref, jv, q0r, q1r, q2r, g0, g1, g2);
+				lsit++;
+				alpha = p1.alpha;
+				if (fabs(p1.d0) < gtol) done = true;
+			}
+			if (!done && !(lsit >= maxls || !p2update)) {
+				p1n.alpha = p1.alpha - p1.d0 / p1.d1;
+				p2n.alpha = p2.alpha - p2.d0 / p2.d1;
+				while (lsit < maxls) {
+					pmid.alpha = 0.5 * (p1.alpha + p2.alpha);
+					ls_eval(pmid, rowact, jaref, jv, q0r, q1r, q2r, g0, g1, g2);
+					ls_eval(p1n, rowact, jaref, jv, q0r, q1r, q2r, g0, g1, g2);
+					ls_eval(p2n, rowact, jaref, jv, q0r, q1r, q2r, g0, g1, g2);
+					lsit++;
+					// converged candidate with the lowest cost wins (order p1n, p2n, pmid)
+					bool have = false;
+					double bc = 0, ba = 0;
+					if (fabs(p1n.d0) < gtol) { have = true; bc = p1n.cost; ba = p1n.alpha; }
+					if (fabs(p2n.d0) < gtol && (!have || p2n.cost < bc)) { have = true; bc = p2n.cost; ba = p2n.alpha; }
+					if (fabs(pmid.d0) < gtol && (!have || pmid.cost < bc)) { have = true; bc = pmid.cost; ba = pmid.alpha; }
+					if (have) {
+						alpha = ba;
+						done = true;
+						break;
+					}
+					bool updated = false;
+					for (int c = 0; c < 3; c++) {
+						const LsPoint q = c == 0 ? p1n : (c == 1 ? p2n : pmid);
+						const double lo = p1.alpha < p2.alpha ? p1.alpha : p2.alpha;
+						const double hi = p1.alpha < p2.alpha ? p2.alpha : p1.alpha;
+						if (!(q.alpha > lo && q.alpha < hi)) continue;
+						if ((q.d0 < 0) == (p1.d0 < 0)) p1 = q;
+						else p2 = q;
+						updated = true;
+					}
+					if (!updated) break;
+					p1n.alpha = p1.alpha - p1.d0 / p1.d1;
+					p2n.alpha = p2.alpha - p2.d0 / p2.d1;
+				}
+				if (!done) alpha = p1.cost < p2.cost ? p1.alpha : p2.alpha;
+			}
+		}
+		if (alpha == 0) break;
+		if (dofact) qa[k] += alpha * sk;
+		iter++;
+		gsync<G>();
+	}
+	if (lane == 0) fi[L.solver_iter] = iter;
+	if (dofact) {
+		const double a = qa[k];
+		f[L.qacc + k] = a;
+		f[L.qacc_warmstart + k] = a;
+	}
+	gsync<G>();
+}

@@ -62,6 +62,9 @@ struct FrameLayout {
 	int MhB;       // [nM]  M + h*diag(damping) (Euler implicit damping), built and factorised next to qM
 	int qH;        // [nM]  its L'DL factor
 	int qHdi;      // [nv]  1 / diag
+	int nwt_M;     // [nv*nv] Newton: dense M          (size 0 unless solver == Newton with constraint rows)
+	int nwt_H;     // [nv*nv] Newton: Hessian / its Cholesky factor
+	int nwt_vec;   // [5*nv]  Newton: qacc, Ma, grad, search, Mv
 	int iscratch;  // transient int scratch: max(ncollpair, njnt + nconmax)
 	int kinloc;    // [7*nbody] kinematics: pose of each body in its parent frame (transient)
 	int crbbuf;    // [6*nv]    crb: crb[body(i)] * cdof_i (transient)

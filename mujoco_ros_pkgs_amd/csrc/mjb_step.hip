@@ -1090,7 +1090,7 @@ template <int G> DEVI void forward_first(CModel m, CLayout L, CState s, const En
 		PROF(16);
 		make_constraint<G>(m, L, e);
 		PROF(17);
-		project_constraint<G>(m, L, e);
+		if (m.solver == MJB_SOL_PGS) project_constraint<G>(m, L, e);
 		PROF(18);
 	}
 	transmission<G>(m, L, e);
@@ -1115,7 +1115,8 @@ template <int G> DEVI void forward_rest(CModel m, CLayout L, CState s, const Env
 	fwd_acceleration<G>(m, L, e, s.use_xfrc != 0);
 	PROF(10);
 	if constexpr (G == 64) {
-		if (m.nefcmax > 0) fwd_constraint_pgs<G>(m, L, e);
+		if (m.nefcmax > 0 && m.solver == MJB_SOL_NEWTON) fwd_constraint_newton<G>(m, L, e);
+		else if (m.nefcmax > 0) fwd_constraint_pgs<G>(m, L, e);
 		else fwd_constraint<G>(m, L, e);
 	} else {
 		fwd_constraint<G>(m, L, e);

@@ -509,9 +509,15 @@ void mjo_reference_constraint(const mjb_model_desc *m, mjo_data *d)
 	}
 }
 
-/* A13: mj_fwdConstraint with the PGS solver (mj_solPGS) */
+static void fwd_constraint_newton(const mjb_model_desc *m, mjo_data *d);
+
+/* A13: mj_fwdConstraint with the PGS solver (mj_solPGS); A14 (Newton) below */
 void mjo_fwd_constraint(const mjb_model_desc *m, mjo_data *d)
 {
+	if (d->nefc[0] > 0 && m->solver == MJB_SOL_NEWTON) {
+		fwd_constraint_newton(m, d);
+		return;
+	}
 	int nv = m->nv, nefc = d->nefc[0], ld = m->nefcmax;
 	if (nefc == 0) {
 		memcpy(d->qacc, d->qacc_smooth, sizeof(double) * (size_t)nv);
@@ -586,4 +592,254 @@ void mjo_fwd_constraint(const mjb_model_desc *m, mjo_data *d)
 		d->qacc[k] += d->qacc_smooth[k];
 		d->qacc_warmstart[k] = d->qacc[k];
 	}
+}
+
+
+/* ------------------------------------------------------------------ A14: Newton (mj_solPrimal, flg_Newton) */
+/* Primal problem: minimise over qacc  0.5 (a - a0)' M (a - a0) + sum_i s_i(J_i a - aref_i),
+ * s_i(x) = 0.5 D_i x^2 for x < 0 (limit / pyramidal contact rows), 0 otherwise.
+ * Hessian H = M + J' diag(D_i [active]) J is rebuilt and Cholesky-factorised every iteration (MuJoCo updates
+ * it incrementally with rank-1 up/down-dates when rows change state: same matrix up to rounding). */
+
+/* res = M * vec with M in qM layout (mj_mulM) */
+static void mul_m(const mjb_model_desc *m, const mjo_data *d, double *res, const double *vec)
+{
+	for (int i = 0; i < m->nv; i++) res[i] = 0;
+	for (int i = 0; i < m->nv; i++) {
+		int adr = m->dof_Madr[i];
+		res[i] += d->qM[adr] * vec[i];
+		int j = m->dof_parentid[i];
+		adr++;
+		while (j >= 0) {
+			res[i] += d->qM[adr] * vec[j];
+			res[j] += d->qM[adr] * vec[i];
+			adr++;
+			j = m->dof_parentid[j];
+		}
+	}
+}
+
+typedef struct {
+	double alpha, cost, deriv[2];
+} lspoint;
+
+typedef struct {
+	int nefc;
+	const double *quad;      /* [nefc][3] */
+	const double *jaref, *jv;
+	double quadGauss[3];
+	int evals;
+} lsctx;
+
+/* PrimalEval: cost and first two derivatives along the search line at alpha */
+static void ls_eval(lsctx *c, lspoint *p)
+{
+	double a = p->alpha;
+	double q0 = c->quadGauss[0], q1 = c->quadGauss[1], q2 = c->quadGauss[2];
+	for (int i = 0; i < c->nefc; i++) {
+		double x = c->jaref[i] + a * c->jv[i];
+		if (x < 0) {
+			q0 += c->quad[3 * i];
+			q1 += c->quad[3 * i + 1];
+			q2 += c->quad[3 * i + 2];
+		}
+	}
+	p->cost = a * a * q2 + a * q1 + q0;
+	p->deriv[0] = 2 * a * q2 + q1;
+	p->deriv[1] = 2 * q2;
+	if (p->deriv[1] <= 0) p->deriv[1] = MJO_MINVAL;
+	c->evals++;
+}
+
+/* PrimalSearch: exact 1-D minimisation (Newton steps, then bracketing with midpoint / Newton candidates) */
+static double primal_search(lsctx *c, double gtol, int maxlsiter)
+{
+	lspoint p0, p1, p2, pmid, p1n, p2n;
+	int iter = 0;
+	p0.alpha = 0;
+	ls_eval(c, &p0);
+	p1.alpha = p0.alpha - p0.deriv[0] / p0.deriv[1];
+	ls_eval(c, &p1);
+	if (p0.cost < p1.cost) p1 = p0;
+	if (fabs(p1.deriv[0]) < gtol) return p1.alpha;
+	int dir = p1.deriv[0] < 0 ? 1 : -1;
+	int p2update = 0;
+	p2 = p1;
+	while (p1.deriv[0] * dir <= -gtol && iter < maxlsiter) {
+		p2 = p1;
+		p2update = 1;
+		p1.alpha = p1.alpha - p1.deriv[0] / p1.deriv[1];
+		ls_eval(c, &p1);
+		iter++;
+		if (fabs(p1.deriv[0]) < gtol) return p1.alpha;
+	}
+	if (iter >= maxlsiter || !p2update) return p1.alpha;
+	/* bracketed: p1 and p2 have derivatives of opposite sign */
+	p1n.alpha = p1.alpha - p1.deriv[0] / p1.deriv[1];
+	p2n.alpha = p2.alpha - p2.deriv[0] / p2.deriv[1];
+	while (iter < maxlsiter) {
+		pmid.alpha = 0.5 * (p1.alpha + p2.alpha);
+		ls_eval(c, &pmid);
+		ls_eval(c, &p1n);
+		ls_eval(c, &p2n);
+		iter++;
+		lspoint *cand[3] = { &p1n, &p2n, &pmid };
+		/* converged candidate with the lowest cost wins */
+		lspoint *best = NULL;
+		for (int k = 0; k < 3; k++)
+			if (fabs(cand[k]->deriv[0]) < gtol && (!best || cand[k]->cost < best->cost)) best = cand[k];
+		if (best) return best->alpha;
+		/* tighten the bracket with every candidate that lies inside it */
+		int updated = 0;
+		double lo = p1.alpha < p2.alpha ? p1.alpha : p2.alpha, hi = p1.alpha < p2.alpha ? p2.alpha : p1.alpha;
+		for (int k = 0; k < 3; k++) {
+			lspoint *q = cand[k];
+			if (!(q->alpha > lo && q->alpha < hi)) continue;
+			if ((q->deriv[0] < 0) == (p1.deriv[0] < 0)) p1 = *q;
+			else p2 = *q;
+			lo = p1.alpha < p2.alpha ? p1.alpha : p2.alpha;
+			hi = p1.alpha < p2.alpha ? p2.alpha : p1.alpha;
+			updated = 1;
+		}
+		if (!updated) break;
+		p1n.alpha = p1.alpha - p1.deriv[0] / p1.deriv[1];
+		p2n.alpha = p2.alpha - p2.deriv[0] / p2.deriv[1];
+	}
+	return p1.cost < p2.cost ? p1.alpha : p2.alpha;
+}
+
+static void fwd_constraint_newton(const mjb_model_desc *m, mjo_data *d)
+{
+	const int nv = m->nv, nefc = d->nefc[0];
+	const double tol = m->tolerance[0], ls_tol = 0.01; /* mjOption.ls_tolerance default */
+	const int ls_iter = 50;                               /* mjOption.ls_iterations default */
+	const double scale = 1.0 / (m->meaninertia[0] * (nv > 1 ? nv : 1));
+	double qacc[nv], Ma[nv], jaref[nefc], grad[nv], search[nv], Mv[nv], jv[nefc], quad[3 * nefc], H[nv * nv];
+	double *f = d->efc_force;
+
+	/* warmstart: qacc_warmstart unless qacc_smooth has the lower cost (engine_forward.c warmstart()) */
+	for (int pass = 0; pass < 2; pass++) {
+		const double *q0 = pass == 0 ? d->qacc_warmstart : d->qacc_smooth;
+		double tmp[nv], cost = 0;
+		mul_m(m, d, tmp, q0);
+		for (int k = 0; k < nv; k++) cost += 0.5 * (tmp[k] - d->qfrc_smooth[k]) * (q0[k] - d->qacc_smooth[k]);
+		for (int i = 0; i < nefc; i++) {
+			double x = -d->efc_aref[i];
+			for (int k = 0; k < nv; k++) x += d->efc_J[(size_t)i * nv + k] * q0[k];
+			if (x < 0) cost += 0.5 * d->efc_D[i] * x * x;
+		}
+		if (pass == 0) {
+			memcpy(qacc, q0, sizeof qacc);
+			Ma[0] = cost; /* stash */
+			if (m->disableflags & MJB_DSBL_WARMSTART) Ma[0] = 1e300;
+		} else if (cost < Ma[0]) {
+			memcpy(qacc, q0, sizeof qacc);
+		}
+	}
+
+	double cost = 0, prev_cost;
+	int iter = 0;
+	for (;;) {
+		/* Ma, jaref, constraint update (forces, cost), gradient */
+		mul_m(m, d, Ma, qacc);
+		double gauss = 0;
+		for (int k = 0; k < nv; k++) gauss += 0.5 * (Ma[k] - d->qfrc_smooth[k]) * (qacc[k] - d->qacc_smooth[k]);
+		prev_cost = cost;
+		cost = gauss;
+		for (int i = 0; i < nefc; i++) {
+			double x = -d->efc_aref[i];
+			for (int k = 0; k < nv; k++) x += d->efc_J[(size_t)i * nv + k] * qacc[k];
+			jaref[i] = x;
+			if (x < 0) {
+				f[i] = -d->efc_D[i] * x;
+				cost += 0.5 * d->efc_D[i] * x * x;
+			} else {
+				f[i] = 0;
+			}
+		}
+		for (int k = 0; k < nv; k++) {
+			double s = 0;
+			for (int i = 0; i < nefc; i++) s += d->efc_J[(size_t)i * nv + k] * f[i];
+			d->qfrc_constraint[k] = s;
+			grad[k] = Ma[k] - d->qfrc_smooth[k] - s;
+		}
+		if (iter > 0) {
+			double improvement = scale * (prev_cost - cost), gnorm = 0;
+			for (int k = 0; k < nv; k++) gnorm += grad[k] * grad[k];
+			gnorm = scale * sqrt(gnorm);
+			if (improvement < tol || gnorm < tol || iter >= m->iterations) break;
+		}
+		/* Hessian H = M + J' D_active J, Cholesky (lower), search = -H^-1 grad */
+		memset(H, 0, sizeof H);
+		for (int i = 0; i < nv; i++) {
+			int adr = m->dof_Madr[i];
+			for (int j = i; j >= 0; j = m->dof_parentid[j]) {
+				H[i * nv + j] = H[j * nv + i] = d->qM[adr];
+				adr++;
+			}
+		}
+		for (int i = 0; i < nefc; i++) {
+			if (!(jaref[i] < 0)) continue;
+			const double *row = d->efc_J + (size_t)i * nv;
+			for (int r = 0; r < nv; r++) {
+				double dr = d->efc_D[i] * row[r];
+				if (dr == 0) continue;
+				for (int c2 = 0; c2 <= r; c2++) H[r * nv + c2] += dr * row[c2];
+			}
+		}
+		for (int r = 0; r < nv; r++)
+			for (int c2 = 0; c2 < r; c2++) H[c2 * nv + r] = H[r * nv + c2];
+		/* mju_cholFactor (in place, lower) */
+		for (int j = 0; j < nv; j++) {
+			double s = H[j * nv + j];
+			for (int k = 0; k < j; k++) s -= H[j * nv + k] * H[j * nv + k];
+			if (s < MJO_MINVAL) s = MJO_MINVAL;
+			double ljj = sqrt(s);
+			H[j * nv + j] = ljj;
+			for (int i = j + 1; i < nv; i++) {
+				double t = H[i * nv + j];
+				for (int k = 0; k < j; k++) t -= H[i * nv + k] * H[j * nv + k];
+				H[i * nv + j] = t / ljj;
+			}
+		}
+		for (int i = 0; i < nv; i++) {
+			double t = grad[i];
+			for (int k = 0; k < i; k++) t -= H[i * nv + k] * search[k];
+			search[i] = t / H[i * nv + i];
+		}
+		for (int i = nv - 1; i >= 0; i--) {
+			double t = search[i];
+			for (int k = i + 1; k < nv; k++) t -= H[k * nv + i] * search[k];
+			search[i] = t / H[i * nv + i];
+		}
+		for (int k = 0; k < nv; k++) search[k] = -search[k];
+		/* line search */
+		double snorm = 0;
+		for (int k = 0; k < nv; k++) snorm += search[k] * search[k];
+		snorm = sqrt(snorm);
+		if (snorm < MJO_MINVAL) break;
+		mul_m(m, d, Mv, search);
+		lsctx c = { nefc, quad, jaref, jv, { 0, 0, 0 }, 0 };
+		c.quadGauss[0] = gauss;
+		for (int k = 0; k < nv; k++) {
+			c.quadGauss[1] += search[k] * (Ma[k] - d->qfrc_smooth[k]);
+			c.quadGauss[2] += 0.5 * search[k] * Mv[k];
+		}
+		for (int i = 0; i < nefc; i++) {
+			double s = 0;
+			for (int k = 0; k < nv; k++) s += d->efc_J[(size_t)i * nv + k] * search[k];
+			jv[i] = s;
+			quad[3 * i] = 0.5 * d->efc_D[i] * jaref[i] * jaref[i];
+			quad[3 * i + 1] = d->efc_D[i] * jaref[i] * s;
+			quad[3 * i + 2] = 0.5 * d->efc_D[i] * s * s;
+		}
+		double gtol = tol * ls_tol * snorm / scale;
+		double alpha = primal_search(&c, gtol, ls_iter);
+		if (alpha == 0) break;
+		for (int k = 0; k < nv; k++) qacc[k] += alpha * search[k];
+		iter++;
+	}
+	d->solver_iter[0] = iter;
+	memcpy(d->qacc, qacc, sizeof qacc);
+	memcpy(d->qacc_warmstart, qacc, sizeof qacc);
 }
