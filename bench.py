@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per env (0 = engine default)")
     ap.add_argument("--epb", type=int, default=0, help="envs per workgroup (0 = engine default)")
     ap.add_argument("--model", default="franka_like")
+    ap.add_argument("--solver", default="", choices=["", "PGS", "Newton"], help="override the model's constraint solver")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -119,6 +120,9 @@ def main():
     from mujoco_ros_pkgs_amd import engine, mjcf, sharding
 
     model = mjcf.load_asset(args.model)
+    if args.solver:
+        model = mjcf.Model(dict(model))
+        model["solver"] = {"PGS": 0, "Newton": 2}[args.solver]
     cm = engine.CompiledModel(model)
     E, S = args.envs, args.substeps
     batch = engine.Batch(cm, E, local_rank)
@@ -188,6 +192,7 @@ def main():
                                     else "BASELINE configs[2]: Franka-like arm + table + cube contacts (PGS, pyramidal), ")
                                    + f"{E} envs per GPU, fp64, Euler dt={model['timestep'][0]}",
                        "envs_per_gpu": E, "physics_steps_per_launch": S, "model": args.model,
+                       "solver": {0: "PGS", 1: "CG", 2: "Newton"}[int(model["solver"])] if model["nefcmax"] else "none",
                        "ctrl": "on-device OU noise (Philox seed 12345, tau 0.1 s, std 43.5)",
                        "parallelism": f"env-sharded x{world}, RCCL all-gather of sensordata per launch" if world > 1
                        else "single GPU", "state_finite": finite},

@@ -186,9 +186,12 @@ class Model(dict):
 
 # --------------------------------------------------------------------------- the compiler
 class _Compiler:
-    def __init__(self, root, nconmax=None, nefcmax=None, disable=()):
+    def __init__(self, root, nconmax=None, nefcmax=None, disable=(), override=None, skip_unsupported_pairs=False):
         self.root = root
         self.extra_disable = tuple(disable)
+        self.override = dict(override or {})
+        self.skip_unsupported_pairs = skip_unsupported_pairs
+        self.skipped_pairs = []
         self.nconmax_req = nconmax
         self.nefcmax_req = nefcmax
         self.angle_scale = math.pi / 180.0  # MJCF default: degrees
@@ -279,7 +282,18 @@ class _Compiler:
             self._body(ET.Element("worldbody"), parent=-1, childclass=None, is_world=True)
         for k in self.extra_disable:
             self.opt["disableflags"] |= DISABLE_BITS[k]
-        return self._finalize()
+        for k, v in self.override.items():  # e.g. {"cone": "pyramidal", "solver": "PGS"}
+            if k == "cone":
+                self.opt["cone"] = {"pyramidal": 0, "elliptic": 1}[v]
+            elif k == "solver":
+                self.opt["solver"] = {"PGS": 0, "CG": 1, "Newton": 2}[v]
+            elif k in ("timestep", "tolerance", "impratio", "iterations"):
+                self.opt[k] = v
+            else:
+                raise MjcfError(f"cannot override option '{k}'")
+        m = self._finalize()
+        m["skipped_collision_pairs"] = list(self.skipped_pairs)
+        return m
 
     def _compiler(self, node):
         ang = node.get("angle", "degree")
@@ -847,6 +861,9 @@ class _Compiler:
                         ta, tb = m["geom_type"][a], m["geom_type"][b]
                         if ta == GEOM_PLANE and tb == GEOM_PLANE:
                             continue
+                        if _max_contacts(ta, tb) == 0 and self.skip_unsupported_pairs:
+                            self.skipped_pairs.append((m["names"]["geom"][a] or str(a), m["names"]["geom"][b] or str(b)))
+                            continue
                         if _max_contacts(ta, tb) == 0:
                             raise MjcfError(
                                 f"collision between geom types {ta} and {tb} is not implemented; "
@@ -940,14 +957,17 @@ def _inertia_from_geoms(geoms):
 
 
 # --------------------------------------------------------------------------- public entry points
-def compile_xml_string(xml, nconmax=None, nefcmax=None, disable=()):
-    """``disable``: extra mjtDisableBit names (e.g. ("contact",)) OR-ed into opt.disableflags."""
-    return _Compiler(ET.fromstring(xml), nconmax, nefcmax, disable).compile()
+def compile_xml_string(xml, nconmax=None, nefcmax=None, disable=(), override=None, skip_unsupported_pairs=False):
+    """``disable``: extra mjtDisableBit names (e.g. ("contact",)) OR-ed into opt.disableflags.
+    ``override``: option overrides, e.g. {"cone": "pyramidal", "solver": "PGS"}.
+    ``skip_unsupported_pairs``: drop geom pairs whose narrow phase is not implemented (capsule-box, box-box)
+    instead of raising; the dropped pairs are listed in ``model["skipped_collision_pairs"]``."""
+    return _Compiler(ET.fromstring(xml), nconmax, nefcmax, disable, override, skip_unsupported_pairs).compile()
 
 
-def compile_xml_file(path, nconmax=None, nefcmax=None, disable=()):
+def compile_xml_file(path, **kw):
     with open(path, "r") as f:
-        return compile_xml_string(f.read(), nconmax, nefcmax, disable)
+        return compile_xml_string(f.read(), **kw)
 
 
 ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")

@@ -22,12 +22,16 @@ ap.add_argument("--epb", type=int, default=0)
 ap.add_argument("--envs", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--model", default="franka_like")
+ap.add_argument("--solver", default="")
 a = ap.parse_args()
 
 binding.LIB_PATH = os.path.join(ROOT, "mujoco_ros_pkgs_amd", "csrc", "libmjb_prof.so")
 from mujoco_ros_pkgs_amd import engine, mjcf  # noqa: E402
 
 model = mjcf.load_asset(a.model)
+if a.solver:
+    model = mjcf.Model(dict(model))
+    model["solver"] = {"PGS": 0, "Newton": 2}[a.solver]
 cm = engine.CompiledModel(model)
 b = engine.Batch(cm, a.envs)
 b.set_launch(a.lanes, a.epb)
