@@ -163,6 +163,10 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	off += newton ? d.nv * d.nv : 0;
 	L.nwt_vec = off;
 	off += newton ? 5 * d.nv : 0;
+	L.nwt_row = off;
+	off += newton ? 3 * d.nefcmax : 0;
+	L.nwt_hc = off;
+	off += (newton && d.cone == MJB_CONE_ELLIPTIC) ? 36 * d.nconmax : 0;
 	L.MhB = off;
 	off += d.nM;
 	L.qH = off;
@@ -315,9 +319,10 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		return nullptr;
 	}
 	if (d.nefcmax > 0 || d.nconmax > 0) {
-		if ((d.solver != MJB_SOL_PGS && d.solver != MJB_SOL_NEWTON) || d.cone != MJB_CONE_PYRAMIDAL) {
-			fail(MJB_EUNSUPPORTED, "mjb_compile: models with constraint rows need solver=PGS or Newton and cone=pyramidal "
-			                       "(CG and elliptic cones are not implemented)");
+		if ((d.solver != MJB_SOL_PGS && d.solver != MJB_SOL_NEWTON) ||
+		    (d.cone == MJB_CONE_ELLIPTIC && d.solver != MJB_SOL_NEWTON)) {
+			fail(MJB_EUNSUPPORTED, "mjb_compile: models with constraint rows need solver=Newton (pyramidal or elliptic cones) "
+			                       "or solver=PGS with cone=pyramidal (CG and PGS with elliptic cones are not implemented)");
 			return nullptr;
 		}
 		if (d.nefcmax > 64 || d.nv > 64) {

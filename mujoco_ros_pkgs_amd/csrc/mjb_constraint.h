@@ -428,7 +428,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 			const int c = it - m.njnt;
 			if (f[L.contact_dist + c] < f[L.contact_includemargin + c]) {
 				const int dim = fi[L.contact_dim + c];
-				n = dim == 1 ? 1 : 2 * (dim - 1);
+				n = dim == 1 ? 1 : (m.cone == MJB_CONE_ELLIPTIC ? dim : 2 * (dim - 1));
 			}
 		}
 		cnt[it] = n;
@@ -487,6 +487,17 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 				row_params(m, L, f, off, dist, cm, solref, solimp, tran);
 				fi[L.efc_id + off] = c;
 				fi[L.efc_type + off] = MJB_CNSTR_CONTACT_FRICTIONLESS;
+			} else if (m.cone == MJB_CONE_ELLIPTIC) {
+				// row 0 = normal (pos = dist), rows 1.. = friction directions (pos = margin = 0);
+				// R_j = R_0 mu^2 / friction_j^2 with mu = friction_0 / sqrt(impratio)
+				for (int k = 0; k < dim; k++) {
+					row_params(m, L, f, off + k, k == 0 ? dist : 0.0, k == 0 ? cm : 0.0, solref, solimp, k < 3 ? tran : rot);
+					fi[L.efc_id + off + k] = c;
+					fi[L.efc_type + off + k] = MJB_CNSTR_CONTACT_ELLIPTIC;
+				}
+				const double mu = fri[0] / sqrt(fmax(MJB_MINVAL, m.impratio[0]));
+				const double R0 = f[L.efc_R + off];
+				for (int k = 1; k < dim; k++) f[L.efc_R + off + k] = fmax(MJB_MINVAL, R0 * mu * mu / (fri[k - 1] * fri[k - 1]));
 			} else {
 				int r = off;
 				for (int k = 1; k < dim; k++)
@@ -517,7 +528,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 		const int adr = fi[L.contact_efc_address + c];
 		if (adr < 0) continue;
 		const int dim = fi[L.contact_dim + c];
-		const int nrow = dim == 1 ? 1 : 2 * (dim - 1);
+		const int nrow = dim == 1 ? 1 : (m.cone == MJB_CONE_ELLIPTIC ? dim : 2 * (dim - 1));
 		if (adr + nrow > nefc) continue;
 		const int b1 = m.geom_bodyid[fi[L.contact_geom + 2 * c]], b2 = m.geom_bodyid[fi[L.contact_geom + 2 * c + 1]];
 		const bool in2 = dof_moves_body(m, b2, i), in1 = dof_moves_body(m, b1, i);
@@ -538,6 +549,10 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 		const double j0 = dot3(fr, jdp);
 		if (dim == 1) {
 			f[L.efc_J + adr * nv + i] = j0;
+		} else if (m.cone == MJB_CONE_ELLIPTIC) {
+			f[L.efc_J + adr * nv + i] = j0;
+			for (int k = 1; k < dim; k++)
+				f[L.efc_J + (adr + k) * nv + i] = k < 3 ? dot3(fr + 3 * k, jdp) : dot3(fr + 3 * (k - 3), jdr);
 		} else {
 			int r = adr;
 			for (int k = 1; k < dim; k++) {
@@ -748,16 +763,47 @@ struct LsPoint {
 	double alpha, cost, d0, d1;
 };
 
-DEVI void ls_eval(LsPoint &p, bool rowact, double jaref, double jv, double q0r, double q1r, double q2r, double g0,
-                  double g1, double g2)
+// Elliptic cone of one contact in the scaled space U_0 = mu x_0, U_j = friction_j x_j (x = jar of its rows),
+// N = U_0, T = |U_1..|; with R_j = R_0 mu^2 / friction_j^2 the primal cost is (oracle/mjo_constraint.c):
+//   top (N >= mu T): 0 | bottom (mu N + T <= 0): 0.5 sum D_j x_j^2 | middle: 0.5 Dm (N - mu T)^2, Dm = D_0 / (mu^2 (1 + mu^2))
+struct ConeLine {  // per-contact constants of the line search, held by the contact's leader lane
+	double N0, N1, TT, UV, VV, q0b, q1b, q2b, mu, Dm;
+};
+
+DEVI void ls_eval(LsPoint &p, bool scalar_row, bool leader, double jaref, double jv, double D, const ConeLine &cl,
+                  double g0, double g1, double g2)
 {
 	const double a = p.alpha;
-	const bool act = rowact && (jaref + a * jv < 0);
-	const double s0 = wave_sum(act ? q0r : 0.0), s1 = wave_sum(act ? q1r : 0.0), s2 = wave_sum(act ? q2r : 0.0);
-	const double q0 = g0 + s0, q1 = g1 + s1, q2 = g2 + s2;
-	p.cost = a * a * q2 + a * q1 + q0;
-	p.d0 = 2 * a * q2 + q1;
-	p.d1 = 2 * q2;
+	double c0 = 0, c1 = 0, c2 = 0;
+	if (scalar_row) {
+		const double x = jaref + a * jv;
+		if (x < 0) {
+			c0 = 0.5 * D * x * x;
+			c1 = D * x * jv;
+			c2 = D * jv * jv;
+		}
+	} else if (leader) {
+		const double N = cl.N0 + a * cl.N1;
+		const double T2 = cl.TT + a * (2 * cl.UV + a * cl.VV);
+		const double T = sqrt(T2 > 0 ? T2 : 0.0);
+		if (N >= cl.mu * T) {
+			// top zone: nothing
+		} else if (cl.mu * N + T <= 0) {
+			c0 = cl.q0b + a * (cl.q1b + a * cl.q2b);
+			c1 = cl.q1b + 2 * a * cl.q2b;
+			c2 = 2 * cl.q2b;
+		} else {
+			const double NmT = N - cl.mu * T, T1 = (cl.UV + a * cl.VV) / T, T2d = (cl.VV - T1 * T1) / T;
+			const double s1 = cl.N1 - cl.mu * T1;
+			c0 = 0.5 * cl.Dm * NmT * NmT;
+			c1 = cl.Dm * NmT * s1;
+			c2 = cl.Dm * (s1 * s1 - NmT * cl.mu * T2d);
+		}
+	}
+	const double s0 = wave_sum(c0), s1 = wave_sum(c1), s2 = wave_sum(c2);
+	p.cost = a * a * g2 + a * g1 + g0 + s0;
+	p.d0 = 2 * a * g2 + g1 + s1;
+	p.d1 = 2 * g2 + s2;
 	if (p.d1 <= 0) p.d1 = MJB_MINVAL;
 }
 
@@ -779,14 +825,27 @@ template <int G> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env
 		gsync<G>();
 		return;
 	}
-	double *Md = f + L.nwt_M, *H = f + L.nwt_H;
+	double *Md = f + L.nwt_M, *H = f + L.nwt_H, *Hc = f + L.nwt_hc;
 	double *qa = f + L.nwt_vec, *Ma = qa + nv, *grad = Ma + nv, *srch = grad + nv, *Mv = srch + nv;
+	double *jar_s = f + L.nwt_row, *jv_s = jar_s + m.nefcmax, *hw = jv_s + m.nefcmax;  // per-row jaref, jv, Hessian weight
 	const bool rowact = lane < nefc, dofact = lane < nv;
 	const int r = rowact ? lane : 0, k = dofact ? lane : 0;
 	const double *Jr = f + L.efc_J + r * nv;
 	const double D = rowact ? f[L.efc_D + r] : 0.0, aref = rowact ? f[L.efc_aref + r] : 0.0;
 	const double tol = m.tolerance[0];
 	const double scale = 1.0 / (m.meaninertia[0] * (nv > 1 ? nv : 1));
+	// row kind: scalar (limit / frictionless / pyramidal), cone leader (first row of an elliptic contact), cone member
+	const int rtype = rowact ? fi[L.efc_type + r] : 0;
+	const int rcon = rowact ? fi[L.efc_id + r] : 0;
+	const bool is_cone = rowact && rtype == MJB_CNSTR_CONTACT_ELLIPTIC;
+	const bool scalar_row = rowact && !is_cone;
+	const bool leader = is_cone && fi[L.contact_efc_address + rcon] == r;
+	const int cdim = is_cone ? fi[L.contact_dim + rcon] : 0;
+	double cfri[5] = { 0, 0, 0, 0, 0 }, cmu = 1;
+	if (leader) {
+		for (int j = 0; j < 5; j++) cfri[j] = f[L.contact_friction + 5 * rcon + j];
+		cmu = cfri[0] / sqrt(fmax(MJB_MINVAL, m.impratio[0]));
+	}
 
 	// dense symmetric M from the qM layout (entry per lane)
 	for (int t = lane; t < nv * nv; t += G) Md[t] = 0;
@@ -799,6 +858,74 @@ template <int G> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env
 	}
 	gsync<G>();
 
+	// constraint update at the jaref values parked in jar_s: returns this lane's cost share; forces (and, when
+	// `hess`, the Hessian weights: efc_force slot for scalar rows is reused... see below) written to LDS
+	auto cone_update = [&](bool hess) -> double {
+		// leaders evaluate their contact (rows r .. r+cdim-1); scalar rows evaluate themselves
+		double cost = 0;
+		if (scalar_row) {
+			const double x = jar_s[r];
+			const bool act = x < 0;
+			f[L.efc_force + r] = act ? -D * x : 0.0;
+			if (hess) hw[r] = act ? D : 0.0;
+			cost = act ? 0.5 * D * x * x : 0.0;
+		} else if (leader) {
+			double U[6], x[6], Dj[6], TT = 0;
+			for (int j = 0; j < 6; j++) {
+				if (j < cdim) {
+					x[j] = jar_s[r + j];
+					Dj[j] = f[L.efc_D + r + j];
+					U[j] = (j == 0 ? cmu : cfri[j - 1]) * x[j];
+					if (j > 0) TT += U[j] * U[j];
+				} else {
+					x[j] = 0; Dj[j] = 0; U[j] = 0;
+				}
+			}
+			const double N = U[0], T = sqrt(TT);
+			double *hc = Hc + 36 * rcon;
+			if (hess)
+				for (int j = 0; j < 36; j++) hc[j] = 0;
+			if (N >= cmu * T) {
+				for (int j = 0; j < 6; j++)
+					if (j < cdim) f[L.efc_force + r + j] = 0;
+			} else if (cmu * N + T <= 0) {
+				for (int j = 0; j < 6; j++)
+					if (j < cdim) {
+						f[L.efc_force + r + j] = -Dj[j] * x[j];
+						cost += 0.5 * Dj[j] * x[j] * x[j];
+						if (hess) hc[j * 6 + j] = Dj[j];
+					}
+			} else {
+				const double Dm = Dj[0] / (cmu * cmu * (1 + cmu * cmu)), NmT = N - cmu * T;
+				cost = 0.5 * Dm * NmT * NmT;
+				const double f0 = -Dm * NmT * cmu;
+				f[L.efc_force + r] = f0;
+				double g[6];
+				g[0] = cmu;
+				for (int j = 1; j < 6; j++) {
+					g[j] = 0;
+					if (j < cdim) {
+						f[L.efc_force + r + j] = -f0 / T * U[j] * cfri[j - 1];
+						g[j] = -cmu * cfri[j - 1] * U[j] / T;
+					}
+				}
+				if (hess)
+					for (int j = 0; j < 6; j++)
+						for (int c2 = 0; c2 < 6; c2++) {
+							if (j >= cdim || c2 >= cdim) continue;
+							double v = Dm * g[j] * g[c2];
+							if (j >= 1 && c2 >= 1)
+								v += -Dm * NmT * cmu * cfri[j - 1] * cfri[c2 - 1] * ((j == c2 ? 1.0 / T : 0.0) - U[j] * U[c2] / (T * T * T));
+							hc[j * 6 + c2] = v;
+						}
+			}
+			if (hess)
+				for (int j = 0; j < 6; j++)
+					if (j < cdim) hw[r + j] = 0;
+		}
+		return cost;
+	};
+
 	// warmstart: the cheaper of qacc_warmstart and qacc_smooth
 	{
 		double best = 0;
@@ -810,7 +937,9 @@ template <int G> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env
 			const double gk = dofact ? 0.5 * (t - f[L.qfrc_smooth + k]) * (q0[k] - f[L.qacc_smooth + k]) : 0.0;
 			double x = -aref;
 			for (int c = 0; c < nv; c++) x += Jr[c] * q0[c];
-			const double ck = (rowact && x < 0) ? 0.5 * D * x * x : 0.0;
+			if (rowact) jar_s[r] = x;
+			gsync<G>();
+			const double ck = cone_update(false);
 			const double cost = wave_sum(gk) + wave_sum(ck);
 			bool take;
 			if (pass == 0) {
@@ -834,13 +963,13 @@ template <int G> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env
 		const double gk = dofact ? 0.5 * (ma - f[L.qfrc_smooth + k]) * (qa[k] - f[L.qacc_smooth + k]) : 0.0;
 		double jaref = -aref;
 		for (int c = 0; c < nv; c++) jaref += Jr[c] * qa[c];
-		const bool active = rowact && jaref < 0;
-		const double frc = active ? -D * jaref : 0.0;
+		if (rowact) jar_s[r] = jaref;
+		if (dofact) Ma[k] = ma;
+		gsync<G>();
+		const double ck = cone_update(true);
 		const double gauss = wave_sum(gk);
 		prev_cost = cost;
-		cost = gauss + wave_sum(active ? 0.5 * D * jaref * jaref : 0.0);
-		if (rowact) f[L.efc_force + r] = frc;
-		if (dofact) Ma[k] = ma;
+		cost = gauss + wave_sum(ck);
 		gsync<G>();
 		double gr = 0;
 		if (dofact) {
@@ -855,15 +984,24 @@ template <int G> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env
 			const double gnorm = scale * sqrt(wave_sum(gr * gr));
 			if (improvement < tol || gnorm < tol || iter >= m.iterations) break;
 		}
-		// H = M + J' D_active J  (lower + upper, entry per lane); active flags parked in efc_b
-		if (rowact) f[L.efc_b + r] = active ? D : 0.0;
-		gsync<G>();
+		// H = M + J' W J  (lower triangle used), entry per lane; W = per-row weights + per-cone blocks
 		for (int t = lane; t < nv * nv; t += G) {
 			const int rr = t / nv, cc = t - rr * nv;
 			double s = Md[t];
 			for (int i = 0; i < nefc; i++) {
-				const double di = f[L.efc_b + i];
-				if (di != 0) s += di * f[L.efc_J + i * nv + rr] * f[L.efc_J + i * nv + cc];
+				if (fi[L.efc_type + i] != MJB_CNSTR_CONTACT_ELLIPTIC) {
+					const double di = hw[i];
+					if (di != 0) s += di * f[L.efc_J + i * nv + rr] * f[L.efc_J + i * nv + cc];
+				} else {
+					const int con = fi[L.efc_id + i], dim = fi[L.contact_dim + con];
+					const double *hc = Hc + 36 * con;
+					for (int a = 0; a < dim; a++)
+						for (int b2 = 0; b2 < dim; b2++) {
+							const double w = hc[a * 6 + b2];
+							if (w != 0) s += w * f[L.efc_J + (i + a) * nv + rr] * f[L.efc_J + (i + b2) * nv + cc];
+						}
+					i += dim - 1;
+				}
 			}
 			H[t] = s;
 		}
@@ -906,21 +1044,44 @@ template <int G> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env
 			for (int c = 0; c < nv; c++) mv += Md[k * nv + c] * srch[c];
 		double jv = 0;
 		for (int c = 0; c < nv; c++) jv += Jr[c] * srch[c];
+		if (rowact) jv_s[r] = jv;
+		gsync<G>();
+		ConeLine cl = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 0 };
+		if (leader) {
+			cl.mu = cmu;
+			cl.N0 = cmu * jaref;
+			cl.N1 = cmu * jv;
+			const double D0 = D;
+			cl.Dm = D0 / (cmu * cmu * (1 + cmu * cmu));
+			for (int j = 0; j < 6; j++) {
+				if (j >= cdim) break;
+				const double xj = jar_s[r + j], vj = jv_s[r + j], Dj = f[L.efc_D + r + j];
+				cl.q0b += 0.5 * Dj * xj * xj;
+				cl.q1b += Dj * xj * vj;
+				cl.q2b += 0.5 * Dj * vj * vj;
+				if (j > 0) {
+					const double U = cfri[j - 1] * xj, V = cfri[j - 1] * vj;
+					cl.TT += U * U;
+					cl.UV += U * V;
+					cl.VV += V * V;
+				}
+			}
+		}
 		const double g0 = gauss;
 		const double g1 = wave_sum(dofact ? sk * (ma - f[L.qfrc_smooth + k]) : 0.0);
 		const double g2 = wave_sum(dofact ? 0.5 * sk * mv : 0.0);
-		const double q0r = 0.5 * D * jaref * jaref, q1r = D * jaref * jv, q2r = 0.5 * D * jv * jv;
 		const double gtol = tol * 0.01 * snorm / scale;  // mjOption.ls_tolerance = 0.01
 		double alpha;
+#define LS_EVAL(P) ls_eval(P, scalar_row, leader, jaref, jv, D, cl, g0, g1, g2)
 		{
 			LsPoint p0, p1, p2, pmid, p1n, p2n;
 			int lsit = 0;
 			const int maxls = 50;  // mjOption.ls_iterations
 			bool done = false;
 			p0.alpha = 0;
-			ls_eval(p0, rowact, jaref, jv, q0r, q1r, q2r, g0, g1, g2);
+			LS_EVAL(p0);
 			p1.alpha = p0.alpha - p0.d0 / p0.d1;
-			ls_eval(p1, rowact, jaref, jv, q0r, q1r, q2r, g0, g1, g2);
+			LS_EVAL(p1);
 			if (p0.cost < p1.cost) p1 = p0;
 			alpha = p1.alpha;
 			if (fabs(p1.d0) < gtol) done = true;
@@ -931,7 +1092,7 @@ template <int G> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env
 				p2 = p1;
 				p2update = true;
 				p1.alpha = p1.alpha - p1.d0 / p1.d1;
-				ls_eval(p1, rowact, jaref, jv, q0r, q1r, q2r, g0, g1, g2);
+				LS_EVAL(p1);
 				lsit++;
 				alpha = p1.alpha;
 				if (fabs(p1.d0) < gtol) done = true;
@@ -941,9 +1102,9 @@ template <int G> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env
 				p2n.alpha = p2.alpha - p2.d0 / p2.d1;
 				while (lsit < maxls) {
 					pmid.alpha = 0.5 * (p1.alpha + p2.alpha);
-					ls_eval(pmid, rowact, jaref, jv, q0r, q1r, q2r, g0, g1, g2);
-					ls_eval(p1n, rowact, jaref, jv, q0r, q1r, q2r, g0, g1, g2);
-					ls_eval(p2n, rowact, jaref, jv, q0r, q1r, q2r, g0, g1, g2);
+					LS_EVAL(pmid);
+					LS_EVAL(p1n);
+					LS_EVAL(p2n);
 					lsit++;
 					// converged candidate with the lowest cost wins (order p1n, p2n, pmid)
 					bool have = false;
@@ -973,6 +1134,7 @@ template <int G> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env
 				if (!done) alpha = p1.cost < p2.cost ? p1.alpha : p2.alpha;
 			}
 		}
+#undef LS_EVAL
 		if (alpha == 0) break;
 		if (dofact) qa[k] += alpha * sk;
 		iter++;

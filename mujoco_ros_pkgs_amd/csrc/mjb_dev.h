@@ -65,6 +65,8 @@ struct FrameLayout {
 	int nwt_M;     // [nv*nv] Newton: dense M          (size 0 unless solver == Newton with constraint rows)
 	int nwt_H;     // [nv*nv] Newton: Hessian / its Cholesky factor
 	int nwt_vec;   // [5*nv]  Newton: qacc, Ma, grad, search, Mv
+	int nwt_row;   // [3*nefcmax] Newton: per-row jaref, jv, Hessian weight
+	int nwt_hc;    // [36*nconmax] Newton: Hessian blocks of the elliptic cones (size 0 unless cone == elliptic)
 	int iscratch;  // transient int scratch: max(ncollpair, njnt + nconmax)
 	int kinloc;    // [7*nbody] kinematics: pose of each body in its parent frame (transient)
 	int crbbuf;    // [6*nv]    crb: crb[body(i)] * cdof_i (transient)

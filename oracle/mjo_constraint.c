@@ -414,7 +414,7 @@ void mjo_make_constraint(const mjb_model_desc *m, mjo_data *d)
 		for (int c = 0; c < d->ncon[0]; c++) {
 			if (!(d->contact_dist[c] < d->contact_includemargin[c])) continue;
 			int dim = d->contact_dim[c];
-			int nrow = dim == 1 ? 1 : 2 * (dim - 1);
+			int nrow = dim == 1 ? 1 : (m->cone == MJB_CONE_ELLIPTIC ? dim : 2 * (dim - 1));
 			if (nefc + nrow > m->nefcmax) break;
 			int b1 = m->geom_bodyid[d->contact_geom[2 * c]], b2 = m->geom_bodyid[d->contact_geom[2 * c + 1]];
 			const double *frame = d->contact_frame + 9 * c, *pos = d->contact_pos + 3 * c, *fri = d->contact_friction + 5 * c;
@@ -442,6 +442,22 @@ void mjo_make_constraint(const mjb_model_desc *m, mjo_data *d)
 				d->efc_id[nefc] = c;
 				row_params(m, d, nefc, d->contact_solref + 2 * c, d->contact_solimp + 5 * c, tran);
 				nefc++;
+			} else if (m->cone == MJB_CONE_ELLIPTIC) {
+				/* elliptic cone: row 0 = normal (pos = dist), rows 1..dim-1 = tangential / torsional / rolling
+				 * directions (pos = margin = 0); regularisation R_j = R_0 mu^2 / friction_j^2, mu = friction_0 / sqrt(impratio) */
+				int first = nefc;
+				for (int k = 0; k < dim; k++) {
+					memcpy(d->efc_J + (size_t)nefc * nv, jac[k], sizeof(double) * (size_t)nv);
+					d->efc_pos[nefc] = k == 0 ? d->contact_dist[c] : 0.0;
+					d->efc_margin[nefc] = k == 0 ? d->contact_includemargin[c] : 0.0;
+					d->efc_type[nefc] = MJB_CNSTR_CONTACT_ELLIPTIC;
+					d->efc_id[nefc] = c;
+					row_params(m, d, nefc, d->contact_solref + 2 * c, d->contact_solimp + 5 * c, k < 3 ? tran : rot);
+					nefc++;
+				}
+				double mu = fri[0] / sqrt(fmax(MJO_MINVAL, m->impratio[0]));
+				for (int k = 1; k < dim; k++)
+					d->efc_R[first + k] = fmax(MJO_MINVAL, d->efc_R[first] * mu * mu / (fri[k - 1] * fri[k - 1]));
 			} else {
 				int first = nefc;
 				for (int k = 1; k < dim; k++)
@@ -623,36 +639,82 @@ typedef struct {
 	double alpha, cost, deriv[2];
 } lspoint;
 
+/* Elliptic cone in the scaled space U_0 = mu x_0, U_j = friction_j x_j  (x = jar of the contact's rows):
+ * N = U_0, T = |U_1..|.  With R_j = R_0 mu^2 / friction_j^2 the dual problem is isotropic there and the primal
+ * cost is  s(x) = 0.5 (D_0 / mu^2) |Proj_C(-U)|^2,  C = { |v_t| <= mu v_0 }:
+ *   top    (N >= mu T)     : s = 0
+ *   bottom (mu N + T <= 0) : s = 0.5 sum_j D_j x_j^2                        (all rows quadratic)
+ *   middle                 : s = 0.5 Dm (N - mu T)^2,  Dm = D_0 / (mu^2 (1 + mu^2))
+ * (C1 across both boundaries; tests/test_oracle_contact.py checks it numerically). */
+enum { ZONE_TOP = 0, ZONE_MIDDLE = 1, ZONE_BOTTOM = 2 };
+
+static int cone_zone(double N, double T, double mu)
+{
+	if (N >= mu * T) return ZONE_TOP;
+	if (mu * N + T <= 0) return ZONE_BOTTOM;
+	return ZONE_MIDDLE;
+}
+
 typedef struct {
-	int nefc;
-	const double *quad;      /* [nefc][3] */
-	const double *jaref, *jv;
+	int nefc, nv;
+	const int *type, *id;
+	const double *D, *jaref, *jv;
+	const mjo_data *d;
+	double impratio;
 	double quadGauss[3];
-	int evals;
 } lsctx;
 
 /* PrimalEval: cost and first two derivatives along the search line at alpha */
-static void ls_eval(lsctx *c, lspoint *p)
+static void ls_eval(const lsctx *c, lspoint *p)
 {
-	double a = p->alpha;
-	double q0 = c->quadGauss[0], q1 = c->quadGauss[1], q2 = c->quadGauss[2];
+	const double a = p->alpha;
+	double cost = a * a * c->quadGauss[2] + a * c->quadGauss[1] + c->quadGauss[0];
+	double d1 = 2 * a * c->quadGauss[2] + c->quadGauss[1], d2 = 2 * c->quadGauss[2];
 	for (int i = 0; i < c->nefc; i++) {
-		double x = c->jaref[i] + a * c->jv[i];
-		if (x < 0) {
-			q0 += c->quad[3 * i];
-			q1 += c->quad[3 * i + 1];
-			q2 += c->quad[3 * i + 2];
+		if (c->type[i] != MJB_CNSTR_CONTACT_ELLIPTIC) {
+			double x = c->jaref[i] + a * c->jv[i];
+			if (x < 0) {
+				cost += 0.5 * c->D[i] * x * x;
+				d1 += c->D[i] * x * c->jv[i];
+				d2 += c->D[i] * c->jv[i] * c->jv[i];
+			}
+			continue;
 		}
+		const int con = c->id[i], dim = c->d->contact_dim[con];
+		const double *fri = c->d->contact_friction + 5 * con;
+		const double mu = fri[0] / sqrt(fmax(MJO_MINVAL, c->impratio));
+		double N = mu * (c->jaref[i] + a * c->jv[i]), N1 = mu * c->jv[i], TT = 0, UV = 0, VV = 0;
+		for (int j = 1; j < dim; j++) {
+			double U = fri[j - 1] * (c->jaref[i + j] + a * c->jv[i + j]), V = fri[j - 1] * c->jv[i + j];
+			TT += U * U;
+			UV += U * V;
+			VV += V * V;
+		}
+		double T = sqrt(TT);
+		int zone = cone_zone(N, T, mu);
+		if (zone == ZONE_BOTTOM) {
+			for (int j = 0; j < dim; j++) {
+				double x = c->jaref[i + j] + a * c->jv[i + j];
+				cost += 0.5 * c->D[i + j] * x * x;
+				d1 += c->D[i + j] * x * c->jv[i + j];
+				d2 += c->D[i + j] * c->jv[i + j] * c->jv[i + j];
+			}
+		} else if (zone == ZONE_MIDDLE) {
+			double Dm = c->D[i] / (mu * mu * (1 + mu * mu)), NmT = N - mu * T;
+			double T1 = UV / T, T2 = (VV - T1 * T1) / T;
+			cost += 0.5 * Dm * NmT * NmT;
+			d1 += Dm * NmT * (N1 - mu * T1);
+			d2 += Dm * ((N1 - mu * T1) * (N1 - mu * T1) - NmT * mu * T2);
+		}
+		i += dim - 1;
 	}
-	p->cost = a * a * q2 + a * q1 + q0;
-	p->deriv[0] = 2 * a * q2 + q1;
-	p->deriv[1] = 2 * q2;
-	if (p->deriv[1] <= 0) p->deriv[1] = MJO_MINVAL;
-	c->evals++;
+	p->cost = cost;
+	p->deriv[0] = d1;
+	p->deriv[1] = d2 <= 0 ? MJO_MINVAL : d2;
 }
 
 /* PrimalSearch: exact 1-D minimisation (Newton steps, then bracketing with midpoint / Newton candidates) */
-static double primal_search(lsctx *c, double gtol, int maxlsiter)
+static double primal_search(const lsctx *c, double gtol, int maxlsiter)
 {
 	lspoint p0, p1, p2, pmid, p1n, p2n;
 	int iter = 0;
@@ -684,21 +746,17 @@ static double primal_search(lsctx *c, double gtol, int maxlsiter)
 		ls_eval(c, &p2n);
 		iter++;
 		lspoint *cand[3] = { &p1n, &p2n, &pmid };
-		/* converged candidate with the lowest cost wins */
 		lspoint *best = NULL;
 		for (int k = 0; k < 3; k++)
 			if (fabs(cand[k]->deriv[0]) < gtol && (!best || cand[k]->cost < best->cost)) best = cand[k];
 		if (best) return best->alpha;
-		/* tighten the bracket with every candidate that lies inside it */
 		int updated = 0;
-		double lo = p1.alpha < p2.alpha ? p1.alpha : p2.alpha, hi = p1.alpha < p2.alpha ? p2.alpha : p1.alpha;
 		for (int k = 0; k < 3; k++) {
 			lspoint *q = cand[k];
+			double lo = p1.alpha < p2.alpha ? p1.alpha : p2.alpha, hi = p1.alpha < p2.alpha ? p2.alpha : p1.alpha;
 			if (!(q->alpha > lo && q->alpha < hi)) continue;
 			if ((q->deriv[0] < 0) == (p1.deriv[0] < 0)) p1 = *q;
 			else p2 = *q;
-			lo = p1.alpha < p2.alpha ? p1.alpha : p2.alpha;
-			hi = p1.alpha < p2.alpha ? p2.alpha : p1.alpha;
 			updated = 1;
 		}
 		if (!updated) break;
@@ -708,16 +766,98 @@ static double primal_search(lsctx *c, double gtol, int maxlsiter)
 	return p1.cost < p2.cost ? p1.alpha : p2.alpha;
 }
 
+/* cost, force (= -ds/dx) and optionally the dim x dim Hessian block (row stride 6) of one elliptic contact */
+static double cone_eval(double mu, const double *fri, const double *D, int dim, const double *jar, double *force, double *Hc)
+{
+	double U[6], TT = 0, cost = 0;
+	U[0] = mu * jar[0];
+	for (int j = 1; j < dim; j++) {
+		U[j] = fri[j - 1] * jar[j];
+		TT += U[j] * U[j];
+	}
+	const double N = U[0], T = sqrt(TT);
+	const int zone = cone_zone(N, T, mu);
+	if (Hc) memset(Hc, 0, 36 * sizeof(double));
+	if (zone == ZONE_TOP) {
+		for (int j = 0; j < dim; j++) force[j] = 0;
+	} else if (zone == ZONE_BOTTOM) {
+		for (int j = 0; j < dim; j++) {
+			force[j] = -D[j] * jar[j];
+			cost += 0.5 * D[j] * jar[j] * jar[j];
+			if (Hc) Hc[j * 6 + j] = D[j];
+		}
+	} else {
+		const double Dm = D[0] / (mu * mu * (1 + mu * mu)), NmT = N - mu * T;
+		cost += 0.5 * Dm * NmT * NmT;
+		force[0] = -Dm * NmT * mu;
+		for (int j = 1; j < dim; j++) force[j] = -force[0] / T * U[j] * fri[j - 1];
+		if (Hc) {
+			/* g = d(NmT)/dx: g_0 = mu, g_j = -mu friction_j U_j / T;  H = Dm (g g' + NmT d g/dx) */
+			double g[6];
+			g[0] = mu;
+			for (int j = 1; j < dim; j++) g[j] = -mu * fri[j - 1] * U[j] / T;
+			for (int j = 0; j < dim; j++)
+				for (int k = 0; k < dim; k++) Hc[j * 6 + k] = Dm * g[j] * g[k];
+			for (int j = 1; j < dim; j++)
+				for (int k = 1; k < dim; k++)
+					Hc[j * 6 + k] += -Dm * NmT * mu * fri[j - 1] * fri[k - 1] * ((j == k ? 1.0 / T : 0.0) - U[j] * U[k] / (T * T * T));
+		}
+	}
+	return cost;
+}
+
+/* test hook: the cone function by itself (D_j = D_0 friction_j^2 / mu^2 as make_constraint sets it) */
+double mjo_debug_cone(const double *friction5, double impratio, double D0, int dim, const double *jar, double *force,
+                      double *H36)
+{
+	double mu = friction5[0] / sqrt(fmax(MJO_MINVAL, impratio)), D[6];
+	D[0] = D0;
+	for (int j = 1; j < dim; j++) D[j] = D0 * friction5[j - 1] * friction5[j - 1] / (mu * mu);
+	return cone_eval(mu, friction5, D, dim, jar, force, H36);
+}
+
+/* constraint update at jar: forces, constraint cost, and the per-row / per-cone Hessian weights:
+ * hrow[i] = D_i for an active scalar row (else 0); for an elliptic contact starting at row i, hcone[36*con..]
+ * holds the dim x dim block of d2s/dx2 (zero in the top zone, diag(D) in the bottom zone). */
+static double constraint_update(const mjb_model_desc *m, const mjo_data *d, int nefc, const double *jar, double *force,
+                                double *hrow, double *hcone)
+{
+	double cost = 0;
+	for (int i = 0; i < nefc; i++) {
+		if (d->efc_type[i] != MJB_CNSTR_CONTACT_ELLIPTIC) {
+			if (jar[i] < 0) {
+				force[i] = -d->efc_D[i] * jar[i];
+				cost += 0.5 * d->efc_D[i] * jar[i] * jar[i];
+				if (hrow) hrow[i] = d->efc_D[i];
+			} else {
+				force[i] = 0;
+				if (hrow) hrow[i] = 0;
+			}
+			continue;
+		}
+		const int con = d->efc_id[i], dim = d->contact_dim[con];
+		const double *fri = d->contact_friction + 5 * con;
+		const double mu = fri[0] / sqrt(fmax(MJO_MINVAL, m->impratio[0]));
+		cost += cone_eval(mu, fri, d->efc_D + i, dim, jar + i, force + i, hcone ? hcone + 36 * con : NULL);
+		if (hrow)
+			for (int j = 0; j < dim; j++) hrow[i + j] = 0;
+		i += dim - 1;
+	}
+	return cost;
+}
+
 static void fwd_constraint_newton(const mjb_model_desc *m, mjo_data *d)
 {
-	const int nv = m->nv, nefc = d->nefc[0];
+	const int nv = m->nv, nefc = d->nefc[0], ncon = d->ncon[0];
 	const double tol = m->tolerance[0], ls_tol = 0.01; /* mjOption.ls_tolerance default */
 	const int ls_iter = 50;                               /* mjOption.ls_iterations default */
 	const double scale = 1.0 / (m->meaninertia[0] * (nv > 1 ? nv : 1));
-	double qacc[nv], Ma[nv], jaref[nefc], grad[nv], search[nv], Mv[nv], jv[nefc], quad[3 * nefc], H[nv * nv];
+	double qacc[nv], Ma[nv], jaref[nefc], grad[nv], search[nv], Mv[nv], jv[nefc], hrow[nefc], H[nv * nv];
+	double hcone[36 * (ncon > 0 ? ncon : 1)], tmpf[nefc];
 	double *f = d->efc_force;
 
 	/* warmstart: qacc_warmstart unless qacc_smooth has the lower cost (engine_forward.c warmstart()) */
+	double best = 0;
 	for (int pass = 0; pass < 2; pass++) {
 		const double *q0 = pass == 0 ? d->qacc_warmstart : d->qacc_smooth;
 		double tmp[nv], cost = 0;
@@ -726,13 +866,13 @@ static void fwd_constraint_newton(const mjb_model_desc *m, mjo_data *d)
 		for (int i = 0; i < nefc; i++) {
 			double x = -d->efc_aref[i];
 			for (int k = 0; k < nv; k++) x += d->efc_J[(size_t)i * nv + k] * q0[k];
-			if (x < 0) cost += 0.5 * d->efc_D[i] * x * x;
+			jaref[i] = x;
 		}
+		cost += constraint_update(m, d, nefc, jaref, tmpf, NULL, NULL);
 		if (pass == 0) {
 			memcpy(qacc, q0, sizeof qacc);
-			Ma[0] = cost; /* stash */
-			if (m->disableflags & MJB_DSBL_WARMSTART) Ma[0] = 1e300;
-		} else if (cost < Ma[0]) {
+			best = (m->disableflags & MJB_DSBL_WARMSTART) ? 1e300 : cost;
+		} else if (cost < best) {
 			memcpy(qacc, q0, sizeof qacc);
 		}
 	}
@@ -740,23 +880,17 @@ static void fwd_constraint_newton(const mjb_model_desc *m, mjo_data *d)
 	double cost = 0, prev_cost;
 	int iter = 0;
 	for (;;) {
-		/* Ma, jaref, constraint update (forces, cost), gradient */
+		/* Ma, jaref, constraint update (forces, cost, Hessian weights), gradient */
 		mul_m(m, d, Ma, qacc);
 		double gauss = 0;
 		for (int k = 0; k < nv; k++) gauss += 0.5 * (Ma[k] - d->qfrc_smooth[k]) * (qacc[k] - d->qacc_smooth[k]);
-		prev_cost = cost;
-		cost = gauss;
 		for (int i = 0; i < nefc; i++) {
 			double x = -d->efc_aref[i];
 			for (int k = 0; k < nv; k++) x += d->efc_J[(size_t)i * nv + k] * qacc[k];
 			jaref[i] = x;
-			if (x < 0) {
-				f[i] = -d->efc_D[i] * x;
-				cost += 0.5 * d->efc_D[i] * x * x;
-			} else {
-				f[i] = 0;
-			}
 		}
+		prev_cost = cost;
+		cost = gauss + constraint_update(m, d, nefc, jaref, f, hrow, hcone);
 		for (int k = 0; k < nv; k++) {
 			double s = 0;
 			for (int i = 0; i < nefc; i++) s += d->efc_J[(size_t)i * nv + k] * f[i];
@@ -769,7 +903,7 @@ static void fwd_constraint_newton(const mjb_model_desc *m, mjo_data *d)
 			gnorm = scale * sqrt(gnorm);
 			if (improvement < tol || gnorm < tol || iter >= m->iterations) break;
 		}
-		/* Hessian H = M + J' D_active J, Cholesky (lower), search = -H^-1 grad */
+		/* Hessian H = M + J' W J  (W: D on active scalar rows, cone blocks on elliptic contacts) */
 		memset(H, 0, sizeof H);
 		for (int i = 0; i < nv; i++) {
 			int adr = m->dof_Madr[i];
@@ -779,13 +913,30 @@ static void fwd_constraint_newton(const mjb_model_desc *m, mjo_data *d)
 			}
 		}
 		for (int i = 0; i < nefc; i++) {
-			if (!(jaref[i] < 0)) continue;
 			const double *row = d->efc_J + (size_t)i * nv;
-			for (int r = 0; r < nv; r++) {
-				double dr = d->efc_D[i] * row[r];
-				if (dr == 0) continue;
-				for (int c2 = 0; c2 <= r; c2++) H[r * nv + c2] += dr * row[c2];
+			if (d->efc_type[i] != MJB_CNSTR_CONTACT_ELLIPTIC) {
+				if (hrow[i] == 0) continue;
+				for (int r = 0; r < nv; r++) {
+					double dr = hrow[i] * row[r];
+					if (dr == 0) continue;
+					for (int c2 = 0; c2 <= r; c2++) H[r * nv + c2] += dr * row[c2];
+				}
+				continue;
 			}
+			const int con = d->efc_id[i], dim = d->contact_dim[con];
+			const double *Hc = hcone + 36 * con;
+			for (int a = 0; a < dim; a++)
+				for (int b2 = 0; b2 < dim; b2++) {
+					double w = Hc[a * 6 + b2];
+					if (w == 0) continue;
+					const double *ra = d->efc_J + (size_t)(i + a) * nv, *rb = d->efc_J + (size_t)(i + b2) * nv;
+					for (int r = 0; r < nv; r++) {
+						double dr = w * ra[r];
+						if (dr == 0) continue;
+						for (int c2 = 0; c2 <= r; c2++) H[r * nv + c2] += dr * rb[c2];
+					}
+				}
+			i += dim - 1;
 		}
 		for (int r = 0; r < nv; r++)
 			for (int c2 = 0; c2 < r; c2++) H[c2 * nv + r] = H[r * nv + c2];
@@ -819,8 +970,7 @@ static void fwd_constraint_newton(const mjb_model_desc *m, mjo_data *d)
 		snorm = sqrt(snorm);
 		if (snorm < MJO_MINVAL) break;
 		mul_m(m, d, Mv, search);
-		lsctx c = { nefc, quad, jaref, jv, { 0, 0, 0 }, 0 };
-		c.quadGauss[0] = gauss;
+		lsctx c = { nefc, nv, d->efc_type, d->efc_id, d->efc_D, jaref, jv, d, m->impratio[0], { gauss, 0, 0 } };
 		for (int k = 0; k < nv; k++) {
 			c.quadGauss[1] += search[k] * (Ma[k] - d->qfrc_smooth[k]);
 			c.quadGauss[2] += 0.5 * search[k] * Mv[k];
@@ -829,9 +979,6 @@ static void fwd_constraint_newton(const mjb_model_desc *m, mjo_data *d)
 			double s = 0;
 			for (int k = 0; k < nv; k++) s += d->efc_J[(size_t)i * nv + k] * search[k];
 			jv[i] = s;
-			quad[3 * i] = 0.5 * d->efc_D[i] * jaref[i] * jaref[i];
-			quad[3 * i + 1] = d->efc_D[i] * jaref[i] * s;
-			quad[3 * i + 2] = 0.5 * d->efc_D[i] * s * s;
 		}
 		double gtol = tol * ls_tol * snorm / scale;
 		double alpha = primal_search(&c, gtol, ls_iter);

@@ -43,13 +43,18 @@ def scenario_states(model, nenv, seed):
     return qpos, qvel
 
 
-@pytest.fixture(scope="module", params=["PGS", "Newton"])
+@pytest.fixture(scope="module", params=["PGS", "Newton", "Newton-elliptic"])
 def setup(request, oracle_built):
+    import os
     from mujoco_ros_pkgs_amd import engine, mjcf
-    model = mjcf.load_asset("franka_table")
-    if request.param == "Newton":
-        model = mjcf.Model(dict(model))
-        model["solver"] = 2
+    if request.param == "PGS":
+        model = mjcf.load_asset("franka_table")
+    else:
+        path = os.path.join(mjcf.ASSET_DIR, "franka_table.xml")
+        over = {"solver": "Newton"}
+        if request.param == "Newton-elliptic":
+            over["cone"] = "elliptic"
+        model = mjcf.compile_xml_file(path, override=over)
     return model, engine.CompiledModel(model), engine, oracle_built
 
 

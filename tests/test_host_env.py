@@ -42,11 +42,10 @@ def factory(request, oracle_factory):
 
 
 def pendulum():
-    # the reference's world as shipped (contacts on, Newton solver); two documented deviations: the elliptic
-    # cone is compiled as pyramidal and the capsule-box pairs (pendulum links vs the static box, never in
-    # contact in these tests) are skipped because that narrow phase is not implemented
-    return mjcf.compile_xml_file(os.path.join(GOLDEN, "pendulum_world.xml"), override={"cone": "pyramidal"},
-                                 skip_unsupported_pairs=True)
+    # the reference's world as shipped (contacts on, elliptic cones, Newton solver); one documented deviation:
+    # the capsule-box pairs (pendulum links vs the static box, never in contact in these tests) are skipped
+    # because that narrow phase is not implemented
+    return mjcf.compile_xml_file(os.path.join(GOLDEN, "pendulum_world.xml"), skip_unsupported_pairs=True)
 
 
 def empty():

@@ -144,3 +144,101 @@ def test_joint_limit_row(oracle_built):
         d.step()
         qmax = max(qmax, abs(d.qpos[0]))
     assert qmax < 0.52
+
+
+# ------------------------------------------------------------------ elliptic cones + Newton
+def _cone(L, fri, impratio, D0, dim, x):
+    import ctypes as C
+    f = (C.c_double * 6)()
+    H = (C.c_double * 36)()
+    fr = (C.c_double * 5)(*fri)
+    xx = (C.c_double * 6)(*list(x) + [0] * (6 - len(x)))
+    L.mjo_debug_cone.restype = C.c_double
+    cost = L.mjo_debug_cone(fr, C.c_double(impratio), C.c_double(D0), dim, xx, f, H)
+    return cost, np.array(f[:dim]), np.array(H[:]).reshape(6, 6)[:dim, :dim]
+
+
+def test_elliptic_cone_cost_is_c1_and_force_in_cone(oracle_built):
+    """(iv) the primal cone cost: force == -grad(cost) and Hessian == jacobian(-force) by finite differences on
+    random points of all three zones and ACROSS the zone boundaries (C1); forces lie in the friction cone."""
+    L = oracle_built.lib()
+    rng = np.random.default_rng(5)
+    zones = set()
+    for trial in range(300):
+        dim = [3, 4, 6][trial % 3]
+        fri = [rng.uniform(0.3, 1.5)] * 2 + [rng.uniform(0.002, 0.01)] + [rng.uniform(1e-4, 1e-3)] * 2
+        impratio = rng.choice([1.0, 4.0])
+        D0 = rng.uniform(50, 500)
+        x = rng.normal(size=dim) * np.array([1.0] + [rng.uniform(0.2, 3)] * (dim - 1))
+        if trial % 5 == 0:  # put the point (almost) on a zone boundary
+            mu = fri[0] / np.sqrt(impratio)
+            T = np.linalg.norm(np.array(fri[:dim - 1]) * x[1:])
+            x[0] = (T * mu + 1e-9 * (1 if trial % 2 else -1)) / mu if trial % 10 == 0 else (-T / mu - 1e-9) / mu
+        cost, f, H = _cone(L, fri, impratio, D0, dim, x)
+        zones.add("top" if cost == 0 and np.all(f == 0) else "other")
+        eps = 1e-6
+        g = np.zeros(dim)
+        for k in range(dim):
+            e = np.zeros(dim)
+            e[k] = eps
+            g[k] = (_cone(L, fri, impratio, D0, dim, x + e)[0] - _cone(L, fri, impratio, D0, dim, x - e)[0]) / (2 * eps)
+        # (central differences straddling a zone boundary see the jump of the second derivative: error <= eps*D)
+        assert np.allclose(-f, g, rtol=2e-5, atol=4 * eps * D0 * (1 + max(fri[:2]) ** 2)), (trial, f, g)
+        if trial % 5 != 0 and cost > 0:
+            Hfd = np.zeros((dim, dim))
+            for k in range(dim):
+                e = np.zeros(dim)
+                e[k] = eps
+                Hfd[:, k] = -(_cone(L, fri, impratio, D0, dim, x + e)[1] - _cone(L, fri, impratio, D0, dim, x - e)[1]) / (2 * eps)
+            assert np.allclose(H, Hfd, rtol=1e-4, atol=1e-4 * np.abs(H).max()), (trial, H, Hfd)
+            assert np.all(np.linalg.eigvalsh(0.5 * (H + H.T)) > -1e-9 * np.abs(H).max())  # convex
+        # friction cone feasibility: sum (f_j / friction_j)^2 <= f_0^2, f_0 >= 0
+        assert f[0] >= 0 and np.sum((f[1:] / np.array(fri[:dim - 1])) ** 2) <= f[0] ** 2 * (1 + 1e-9) + 1e-18
+    assert zones == {"top", "other"}
+
+
+BOX_ON_PLANE = """
+<mujoco><compiler angle="radian"/>
+<option timestep="0.001" cone="{cone}" solver="Newton" gravity="{gx} 0 {gz}" tolerance="1e-10"/>
+<worldbody><geom type="plane" size="5 5 0.1" friction="{mu} 0.005 0.0001"/>
+<body name="b" pos="0 0 0.01"><freejoint/><geom type="box" size="0.2 0.2 0.01" mass="1.0" friction="{mu} 0.005 0.0001"/></body>
+</worldbody></mujoco>
+"""
+
+
+@pytest.mark.parametrize("cone", ["elliptic", "pyramidal"])
+def test_coulomb_friction_stick_and_slide(oracle_built, cone):
+    """Tilted gravity on a box resting on a plane, mu = 0.5: below the friction angle it sticks, above it slides
+    with a = g (sin(theta) - mu cos(theta)) (elliptic: exact Coulomb law; pyramidal: within its known ~10% anisotropy)."""
+    mu, g = 0.5, 9.81
+    for theta, slides in ((0.35, False), (0.75, True)):
+        xml = BOX_ON_PLANE.format(cone=cone, gx=g * np.sin(theta), gz=-g * np.cos(theta), mu=mu)
+        m = mjcf.compile_xml_string(xml)
+        d = oracle_built.OracleData(m)
+        for _ in range(300):
+            d.step()
+        v0 = d.qvel[0]
+        for _ in range(200):
+            d.step()
+        acc = (d.qvel[0] - v0) / 0.2
+        if slides:
+            expect = g * (np.sin(theta) - mu * np.cos(theta))
+            assert abs(acc - expect) < (0.02 if cone == "elliptic" else 0.12) * expect, (cone, acc, expect)
+        else:
+            assert abs(d.qvel[0]) < 2e-3 and abs(acc) < 1e-2, (cone, d.qvel[0], acc)
+        assert abs(d.qpos[2] - 0.01) < 1e-3  # stays flat on the plane (a low, wide slab does not rock)
+
+
+def test_shipped_world_runs_as_shipped(oracle_built):
+    """pendulum_world.xml with its own options (cone=elliptic, default Newton): ball drops 1 cm and rests with
+    normal force m g, pendulum stays exactly at rest (only the capsule-box pairs are skipped)."""
+    import os
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    m = mjcf.compile_xml_file(os.path.join(golden, "pendulum_world.xml"), skip_unsupported_pairs=True)
+    assert m["cone"] == 1 and m["solver"] == 2
+    d = oracle_built.OracleData(m)
+    for _ in range(600):
+        d.step()
+    assert d.nefc[0] == 3 and list(d.efc_type[:3]) == [7, 7, 7]
+    assert abs(d.efc_force[0] - 0.1 * 9.81) < 1e-6 and abs(d.qvel).max() < 1e-9
+    assert np.all(d.qvel[:5] == 0)
