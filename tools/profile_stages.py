@@ -55,4 +55,4 @@ for i, n in enumerate(STAGES):
     if n != "forward(total)":
         tot += cyc
     print(f"  {n:18s} {cyc:10.0f} cycles/call  ({out[32+i]} calls)")
-print(f"  sum (excl. total)  {tot:10.0f} cycles/step  = {tot/2.4e3:.1f} us @2.4GHz (s_memtime ticks at 100 MHz? see note)")
+print(f"  sum (excl. total, incl. kin.* sub-phases twice)  {tot:10.0f} shader cycles/step  = {tot/2.4e3:.1f} us at 2.4 GHz")
