@@ -182,6 +182,13 @@ int mjb_synchronize(mjb_batch *b);
  * that went NaN or beyond mjMAXVAL is reset to qpos0 exactly as mj_step does). */
 int mjb_warning_count(mjb_batch *b, unsigned long long *count);
 
+/* mjData after mj_step holds the derived quantities of the last forward pass (xpos, contacts, efc_*, ...), which
+ * the reference's lastStageCallback / renderCallback read (mujoco_env.cpp:506-515, 430-436).  Fused mjb_step
+ * keeps them in LDS only; with keep_frame on, every launch also stores the full frame of its LAST step so that
+ * mjb_get / mjb_get_int serve derived fields afterwards (costs the compact LDS layout and one frame store per
+ * launch).  Off by default. */
+int mjb_set_keep_frame(mjb_batch *b, int on);
+
 /* Profiling builds only (libmjb_prof.so): per-stage shader-cycle sums [0..31] and call counts [32..63] of
  * env 0; all zero in the production build. */
 int mjb_debug_profile(mjb_batch *b, unsigned long long *out64, int clear);

@@ -108,7 +108,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("MJB_LIBRARY") or LIB_PATH  # MJB_LIBRARY: an alternative build (e.g. libmjb_prof.so)
     if not os.path.exists(p):
         raise OSError(
             f"{p} not found: the HIP engine is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -130,6 +130,7 @@ def load_library(path=None):
         "mjb_free_batch": (None, [vp]),
         "mjb_nenv": (ci, [vp]),
         "mjb_set_launch": (ci, [vp, ci, ci]),
+        "mjb_set_keep_frame": (ci, [vp, ci]),
         "mjb_step": (ci, [vp, ci]),
         "mjb_step1": (ci, [vp]),
         "mjb_step2": (ci, [vp]),

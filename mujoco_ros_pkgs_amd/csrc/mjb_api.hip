@@ -656,6 +656,8 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	s.frame_ws = nullptr;
 	s.frame_stride = b->L.ndouble + b->L.nint / 2;
 	s.use_xfrc = 0;
+	s.keep_frame = 0;
+	s.pad1 = 0;
 	if (!ok) {
 		fail(MJB_ENOMEM, "mjb_make_batch: hipMalloc(state) failed for %d envs", nenv);
 		mjb_free_batch(b);
@@ -715,7 +717,7 @@ static int sync_params(mjb_batch *b)
 		kp.m = b->dm;
 		kp.L = b->L;
 		kp.Lc = b->model->Lc;
-		kp.use_compact = b->st.use_xfrc ? 0 : 1;
+		kp.use_compact = (b->st.use_xfrc || b->st.keep_frame) ? 0 : 1;
 		kp.pad0 = 0;
 		kp.s = b->st;
 		kp.nz = b->nz;
@@ -732,9 +734,9 @@ static int launch(mjb_batch *b, int mode, int nsteps)
 	HIP_TRY(hipSetDevice(b->device));
 	int prc = sync_params(b);
 	if (prc) return prc;
-	const bool compact = mode == MJB_MODE_STEP && !b->st.use_xfrc;
+	const bool compact = mode == MJB_MODE_STEP && !b->st.use_xfrc && !b->st.keep_frame;
 	int rc = mjb_launch_step(b->params_dev, compact ? b->model->Lc : b->L, b->nenv, mode, nsteps, b->step_counter, b->lanes,
-	                         b->epb, b->stream);
+	                         b->epb, b->model->h.nefcmax > 0 ? (b->model->h.solver == MJB_SOL_NEWTON ? 2 : 1) : 0, b->stream);
 	if (rc != 0) return fail(MJB_ENODEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
 	return MJB_OK;
 }
@@ -746,9 +748,24 @@ int mjb_step(mjb_batch *b, int nsteps)
 	int rc = launch(b, MJB_MODE_STEP, nsteps);
 	if (rc == MJB_OK) {
 		b->step_counter += (unsigned int)nsteps;
-		b->frame_valid = false;
+		b->frame_valid = b->st.keep_frame != 0;
 	}
 	return rc;
+}
+
+int mjb_set_keep_frame(mjb_batch *b, int on)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	if (on) {
+		int rc = ensure_ws(b);
+		if (rc) return rc;
+	}
+	if ((b->st.keep_frame != 0) != (on != 0)) {
+		b->st.keep_frame = on ? 1 : 0;
+		b->params_dirty = true;
+		b->frame_valid = false;
+	}
+	return MJB_OK;
 }
 
 int mjb_step1(mjb_batch *b)

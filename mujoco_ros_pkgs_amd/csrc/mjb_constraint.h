@@ -826,7 +826,7 @@ template <int G> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env
 		return;
 	}
 	double *Md = f + L.nwt_M, *H = f + L.nwt_H, *Hc = f + L.nwt_hc;
-	double *qa = f + L.nwt_vec, *Ma = qa + nv, *grad = Ma + nv, *srch = grad + nv, *Mv = srch + nv;
+	double *qa = f + L.nwt_vec, *Ma = qa + nv, *grad = Ma + nv, *srch = grad + nv;
 	double *jar_s = f + L.nwt_row, *jv_s = jar_s + m.nefcmax, *hw = jv_s + m.nefcmax;  // per-row jaref, jv, Hessian weight
 	const bool rowact = lane < nefc, dofact = lane < nv;
 	const int r = rowact ? lane : 0, k = dofact ? lane : 0;

@@ -93,6 +93,8 @@ struct DevState {
 	int nenv;
 	int frame_stride;              // doubles per env in frame_ws
 	int use_xfrc;                  // xfrc_applied has ever been written
+	int keep_frame;                // fused mjb_step also dumps the last step's full frame to frame_ws
+	int pad1;
 };
 
 struct NoiseCfg {
@@ -120,6 +122,6 @@ enum { MJB_MODE_STEP = 0, MJB_MODE_FORWARD = 1, MJB_MODE_STEP1 = 2, MJB_MODE_STE
 
 // launches (implemented in mjb_step.hip); returns hipError_t as int
 int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0,
-                    int lanes_per_env, int envs_per_block, void *stream);
+                    int lanes_per_env, int envs_per_block, int constrained, void *stream);
 int mjb_launch_reset(const KernelParams *Pdev, int nenv, const unsigned char *mask_dev, void *stream);
 int mjb_max_lds_bytes();

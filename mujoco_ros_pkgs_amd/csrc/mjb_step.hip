@@ -1073,56 +1073,79 @@ template <int G> STAGE void reset_frame_state(CModel m, CLayout L, CState s, con
 // ------------------------------------------------------------------------------------------------
 // pipeline pieces
 // ------------------------------------------------------------------------------------------------
-template <int G> DEVI void forward_first(CModel m, CLayout L, CState s, const Env &e, int compact)
+// Every stage sees the model / layout through a freshly laundered copy of the parameter pointer: values derived
+// from them (frame addresses, per-lane table entries) then live inside one stage only instead of being hoisted to
+// the top of the step and kept in registers -- or spilled -- across all stages.  MJB_LAUNDER=0 disables it.
+#ifndef MJB_LAUNDER
+#define MJB_LAUNDER 1
+#endif
+DEVI const KernelParams MJB_AS4 *launder_params(const KernelParams MJB_AS4 *p)
 {
+	if (MJB_LAUNDER) asm volatile("" : "+s"(p));
+	return p;
+}
+#define VIEW(P, compact, ...)                                              \
+	do {                                                                   \
+		const KernelParams MJB_AS4 *Pq_ = launder_params(P);              \
+		CModel m = Pq_->m;                                                 \
+		CLayout L = (compact) ? Pq_->Lc : Pq_->L;                          \
+		CState s = Pq_->s;                                                 \
+		(void)s;                                                           \
+		__VA_ARGS__;                                                       \
+	} while (0)
+
+template <int G, int CON> DEVI void forward_first(const KernelParams MJB_AS4 *P, const Env &e, int compact)
+{
+	[[maybe_unused]] CState s = P->s;  // (profiling macros)
 	PROF_BEGIN();
-	kinematics<G>(m, L, s, e);
+	VIEW(P, compact, kinematics<G>(m, L, s, e));
 	PROF(0);
-	com_pos<G>(m, L, e);
+	VIEW(P, compact, com_pos<G>(m, L, e));
 	PROF(1);
-	crb<G>(m, L, e);
+	VIEW(P, compact, crb<G>(m, L, e));
 	PROF(2);
-	factor2<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi,
-	           m.eulerdamp != 0);
+	VIEW(P, compact, factor2<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi,
+	                            m.eulerdamp != 0));
 	PROF(3);
-	if (m.nefcmax > 0) {
-		collision<G>(m, L, e);
+	if constexpr (CON) {
+		VIEW(P, compact, collision<G>(m, L, e));
 		PROF(16);
-		make_constraint<G>(m, L, e);
+		VIEW(P, compact, make_constraint<G>(m, L, e));
 		PROF(17);
-		if (m.solver == MJB_SOL_PGS) project_constraint<G>(m, L, e);
+		if constexpr (CON == 1) VIEW(P, compact, project_constraint<G>(m, L, e));
 		PROF(18);
 	}
-	transmission<G>(m, L, e);
-	sensors<G>(m, L, e, MJB_STAGE_POS, compact);
+	VIEW(P, compact, transmission<G>(m, L, e));
+	VIEW(P, compact, sensors<G>(m, L, e, MJB_STAGE_POS, compact));
 	PROF(4);
-	com_vel<G>(m, L, e);
+	VIEW(P, compact, com_vel<G>(m, L, e));
 	PROF(5);
-	passive<G>(m, L, e);
+	VIEW(P, compact, passive<G>(m, L, e));
 	PROF(6);
-	if (m.nefcmax > 0) reference_constraint<G>(m, L, e);
-	rne<G>(m, L, e);
+	if constexpr (CON) VIEW(P, compact, reference_constraint<G>(m, L, e));
+	VIEW(P, compact, rne<G>(m, L, e));
 	PROF(7);
-	sensors<G>(m, L, e, MJB_STAGE_VEL, compact);
+	VIEW(P, compact, sensors<G>(m, L, e, MJB_STAGE_VEL, compact));
 	PROF(8);
 }
 
-template <int G> DEVI void forward_rest(CModel m, CLayout L, CState s, const Env &e, int compact)
+template <int G, int CON> DEVI void forward_rest(const KernelParams MJB_AS4 *P, const Env &e, int compact)
 {
+	[[maybe_unused]] CState s = P->s;  // (profiling macros)
 	PROF_BEGIN();
-	fwd_actuation<G>(m, L, e);
+	VIEW(P, compact, fwd_actuation<G>(m, L, e));
 	PROF(9);
-	fwd_acceleration<G>(m, L, e, s.use_xfrc != 0);
+	VIEW(P, compact, fwd_acceleration<G>(m, L, e, s.use_xfrc != 0));
 	PROF(10);
-	if constexpr (G == 64) {
-		if (m.nefcmax > 0 && m.solver == MJB_SOL_NEWTON) fwd_constraint_newton<G>(m, L, e);
-		else if (m.nefcmax > 0) fwd_constraint_pgs<G>(m, L, e);
-		else fwd_constraint<G>(m, L, e);
+	if constexpr (CON == 2 && G == 64) {
+		VIEW(P, compact, fwd_constraint_newton<G>(m, L, e));
+	} else if constexpr (CON == 1 && G == 64) {
+		VIEW(P, compact, fwd_constraint_pgs<G>(m, L, e));
 	} else {
-		fwd_constraint<G>(m, L, e);
+		VIEW(P, compact, fwd_constraint<G>(m, L, e));
 	}
 	PROF(11);
-	sensors<G>(m, L, e, MJB_STAGE_ACC, compact);
+	VIEW(P, compact, sensors<G>(m, L, e, MJB_STAGE_ACC, compact));
 	PROF(12);
 }
 
@@ -1141,8 +1164,12 @@ template <int G> STAGE void ctrl_noise(CModel m, CLayout L, CNoise nz, const Env
 // ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
-template <int G>
-__global__ void __launch_bounds__(256, (G == 64 ? 4 : (G == 32 ? 2 : 1)))
+// CON: 0 = model without constraint rows; 1 = PGS, 2 = Newton (collision / rows / solver stages compiled in;
+// one env per wavefront) -- separate kernels keep each instruction stream and register budget small.
+// Constrained kernels are capped at 256 VGPRs (2 blocks/CU): with the 512-register budget ROCm 7.2's LLVM
+// spills VGPRs to AGPRs ahead of an exec restore and loses lanes (tools/check_spill_exec.py, `make lint`).
+template <int G, int CON>
+__global__ void __launch_bounds__(256, (CON ? 2 : (G == 64 ? 4 : (G == 32 ? 2 : 1))))
     mjb_step_kernel(const KernelParams MJB_AS4 *__restrict__ P, const int mode, const int nsteps,
                     const unsigned int step0, const int epb, const int frame_bytes)
 {
@@ -1199,20 +1226,20 @@ __global__ void __launch_bounds__(256, (G == 64 ? 4 : (G == 32 ? 2 : 1)))
 				if (do_first || attempt) {
 					if (attempt == 0 && checks && any_bad<G>(e, L, e.f + L.qpos, m.nq, e.f + L.qvel, m.nv))
 						reset_frame_state<G>(m, L, s, e);
-					forward_first<G>(m, L, s, e, compact);
+					forward_first<G, CON>(P, e, compact);
 				}
 				if (!do_rest) break;
-				forward_rest<G>(m, L, s, e, compact);
+				forward_rest<G, CON>(P, e, compact);
 				if (attempt || !checks || !any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0)) break;
 				reset_frame_state<G>(m, L, s, e);
 			}
 			PROF(14);  // whole forward (incl. checks)
-			if (do_euler) euler<G>(m, L, e);
+			if (do_euler) VIEW(P, compact, euler<G>(m, L, e));
 			PROF(15);
 		}
 
 		store_state<G>(m, L, s, e);
-		if (ws && mode != MJB_MODE_STEP) {
+		if (ws && (mode != MJB_MODE_STEP || s.keep_frame)) {
 			for (int k = e.lane; k < L.ndouble; k += G) ws[k] = e.f[k];
 			int *wsi = reinterpret_cast<int *>(ws + L.ndouble);
 			for (int k = e.lane; k < L.nint; k += G) wsi[k] = e.fi[k];
@@ -1246,7 +1273,7 @@ __global__ void mjb_reset_kernel(const KernelParams MJB_AS4 *__restrict__ P, con
 	s.time[e] = 0;
 }
 
-template <int G>
+template <int G, int CON>
 int launch_g(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0,
              int epb, void *stream)
 {
@@ -1263,7 +1290,7 @@ int launch_g(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode,
 	}
 	const size_t lds = (size_t)epb * frame_bytes;
 	if ((int)lds > maxlds) return (int)hipErrorInvalidValue;
-	auto kern = mjb_step_kernel<G>;
+	auto kern = mjb_step_kernel<G, CON>;
 	hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
 	                                     (int)lds);
 	if (err != hipSuccess) return (int)err;
@@ -1280,13 +1307,18 @@ int launch_g(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode,
 int mjb_max_lds_bytes() { return 160 * 1024; }
 
 int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0,
-                    int lanes_per_env, int envs_per_block, void *stream)
+                    int lanes_per_env, int envs_per_block, int constrained, void *stream)
 {
+	if (constrained) {
+		if (lanes_per_env != 64) return (int)hipErrorInvalidValue;
+		if (constrained == 2) return launch_g<64, 2>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+		return launch_g<64, 1>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+	}
 	switch (lanes_per_env) {
-	case 8: return launch_g<8>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
-	case 16: return launch_g<16>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
-	case 32: return launch_g<32>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
-	case 64: return launch_g<64>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+	case 8: return launch_g<8, 0>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+	case 16: return launch_g<16, 0>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+	case 32: return launch_g<32, 0>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+	case 64: return launch_g<64, 0>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 	default: return (int)hipErrorInvalidValue;
 	}
 }

@@ -99,6 +99,10 @@ class Batch:
     def set_launch(self, lanes_per_env=0, envs_per_block=0):
         _check(self.lib.mjb_set_launch(self.ptr, lanes_per_env, envs_per_block), "mjb_set_launch")
 
+    def set_keep_frame(self, on=True):
+        """Fused step() also leaves the derived fields of its last step readable through get()."""
+        _check(self.lib.mjb_set_keep_frame(self.ptr, 1 if on else 0), "mjb_set_keep_frame")
+
     def set_ctrl_noise(self, std, rate, seed=0, env_offset=0):
         _check(self.lib.mjb_set_ctrl_noise(self.ptr, float(std), float(rate), int(seed), int(env_offset)),
                "mjb_set_ctrl_noise")
