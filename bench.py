@@ -176,7 +176,7 @@ def main():
     if rank == 0:
         traffic = None
         try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, 4096 envs x 1000 steps)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
             if (E, S, args.model) == (4096, 1000, "franka_like"):
                 traffic = (pmc["FETCH_SIZE"]["mean_per_dispatch"] + pmc["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
         except Exception:

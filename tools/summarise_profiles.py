@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>/ (written by tools/collect_profiles.sh on the GPU box) into profiles/:
+   <tag>_bench_line.json, <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), <tag>_pmc_summary.json
+   (mean counter value per dispatch of the step kernel; FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them).
+usage: summarise_profiles.py <tag> [name-suffix]"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+suffix = sys.argv[2] if len(sys.argv) > 2 else ""
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "prof_" + tag)
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+name = tag + suffix
+
+
+def first(pattern):
+    g = glob.glob(os.path.join(src, pattern), recursive=True)
+    return g[0] if g else None
+
+
+for f, t in (("bench_line.json", "_bench_line.json"), ("bench_line_under_rocprof.json", "_bench_line_under_rocprof.json")):
+    p = os.path.join(src, f)
+    if os.path.exists(p):
+        lines = [l for l in open(p).read().splitlines() if l.startswith("{")]
+        if lines:
+            open(os.path.join(dst, name + t), "w").write(lines[-1] + "\n")
+ks = first("trace/**/*kernel_stats.csv")
+if ks:
+    shutil.copy(ks, os.path.join(dst, name + "_kernel_stats.csv"))
+summary = {}
+meta = None
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    cc = first(d + "/**/*counter_collection.csv")
+    if not cc:
+        continue
+    acc = {}
+    for row in csv.DictReader(open(cc)):
+        if "mjb_step_kernel" not in row["Kernel_Name"]:
+            continue
+        acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+        if meta is None:
+            meta = {k: row[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size",
+                                        "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
+    for k, v in acc.items():
+        summary[k] = {"dispatches": len(v), "mean_per_dispatch": sum(v) / len(v)}
+if summary:
+    summary["dispatch_meta"] = meta
+    bl = os.path.join(dst, name + "_bench_line_under_rocprof.json")
+    if os.path.exists(bl):
+        summary["bench_config"] = json.loads(open(bl).read())["config"]
+    summary["notes"] = ("rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and two SQ passes, each its own run, no tracing "
+                        "domains) of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline ...`; means over the step-kernel "
+                        "dispatches.  FETCH_SIZE / WRITE_SIZE are KiB (HBM bytes = value * 1024); per MI355X_MICROARCH.md "
+                        "the gfx950 x2 correction applies to wide (16 B/lane) streaming reads only -- this kernel reads 8 B/lane, "
+                        "uncalibrated, so the raw value is reported.")
+    json.dump(summary, open(os.path.join(dst, name + "_pmc_summary.json"), "w"), indent=1)
+print("wrote", sorted(f for f in os.listdir(dst) if f.startswith(name)))
