@@ -325,9 +325,10 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 			                       "or solver=PGS with cone=pyramidal (CG and PGS with elliptic cones are not implemented)");
 			return nullptr;
 		}
-		if (d.nefcmax > 64 || d.nv > 64) {
-			fail(MJB_EUNSUPPORTED, "mjb_compile: the constraint solver maps rows to the 64 lanes of one wavefront: "
-			                       "nefcmax = %d, nv = %d (both must be <= 64)", d.nefcmax, d.nv);
+		const int rowcap = d.solver == MJB_SOL_NEWTON ? 256 : 64;
+		if (d.nefcmax > rowcap || d.nv > 64) {
+			fail(MJB_EUNSUPPORTED, "mjb_compile: one env per wavefront: nv <= 64 and nefcmax <= 64 (PGS) / 256 (Newton, up to "
+			                       "4 rows per lane); got nefcmax = %d, nv = %d", d.nefcmax, d.nv);
 			return nullptr;
 		}
 		if (!(d.meaninertia[0] > 0)) {
@@ -487,6 +488,15 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 	{
 		std::vector<int> fill(M->dof_act_adr.begin(), M->dof_act_adr.end() - 1);
 		for (int i = 0; i < h.nu; i++) M->dof_act_id[fill[h.jnt_dofadr[h.actuator_trnid[2 * i]]]++] = i;
+	}
+	{
+		const int frame_bytes = ((M->L.ndouble * 8 + M->L.nint * 4) + 15) & ~15;
+		if (frame_bytes > mjb_max_lds_bytes()) {
+			fail(MJB_EUNSUPPORTED, "mjb_compile: the per-env working set (%d bytes) exceeds one CU's LDS (%d bytes); "
+			                       "lower nconmax / nefcmax", frame_bytes, mjb_max_lds_bytes());
+			delete M;
+			return nullptr;
+		}
 	}
 	g_err.clear();
 	return M;
@@ -729,6 +739,14 @@ static int sync_params(mjb_batch *b)
 	return MJB_OK;
 }
 
+// 0: no constraint rows; 1: PGS; 2 / 3 / 4: Newton with 1 / 2 / 4 rows per lane
+static int kernel_variant(const mjb_model_desc &h)
+{
+	if (h.nefcmax <= 0) return 0;
+	if (h.solver != MJB_SOL_NEWTON) return 1;
+	return h.nefcmax <= 64 ? 2 : (h.nefcmax <= 128 ? 3 : 4);
+}
+
 static int launch(mjb_batch *b, int mode, int nsteps)
 {
 	HIP_TRY(hipSetDevice(b->device));
@@ -736,7 +754,7 @@ static int launch(mjb_batch *b, int mode, int nsteps)
 	if (prc) return prc;
 	const bool compact = mode == MJB_MODE_STEP && !b->st.use_xfrc && !b->st.keep_frame;
 	int rc = mjb_launch_step(b->params_dev, compact ? b->model->Lc : b->L, b->nenv, mode, nsteps, b->step_counter, b->lanes,
-	                         b->epb, b->model->h.nefcmax > 0 ? (b->model->h.solver == MJB_SOL_NEWTON ? 2 : 1) : 0, b->stream);
+	                         b->epb, kernel_variant(b->model->h), b->stream);
 	if (rc != 0) return fail(MJB_ENODEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
 	return MJB_OK;
 }

@@ -770,17 +770,16 @@ struct ConeLine {  // per-contact constants of the line search, held by the cont
 	double N0, N1, TT, UV, VV, q0b, q1b, q2b, mu, Dm;
 };
 
-DEVI void ls_eval(LsPoint &p, bool scalar_row, bool leader, double jaref, double jv, double D, const ConeLine &cl,
-                  double g0, double g1, double g2)
+// one lane's share of the line-search cost and its first two derivatives at step `a`
+DEVI void ls_row(double a, bool scalar_row, bool leader, double jaref, double jv, double D, const ConeLine &cl,
+                 double &c0, double &c1, double &c2)
 {
-	const double a = p.alpha;
-	double c0 = 0, c1 = 0, c2 = 0;
 	if (scalar_row) {
 		const double x = jaref + a * jv;
 		if (x < 0) {
-			c0 = 0.5 * D * x * x;
-			c1 = D * x * jv;
-			c2 = D * jv * jv;
+			c0 += 0.5 * D * x * x;
+			c1 += D * x * jv;
+			c2 += D * jv * jv;
 		}
 	} else if (leader) {
 		const double N = cl.N0 + a * cl.N1;
@@ -789,25 +788,24 @@ DEVI void ls_eval(LsPoint &p, bool scalar_row, bool leader, double jaref, double
 		if (N >= cl.mu * T) {
 			// top zone: nothing
 		} else if (cl.mu * N + T <= 0) {
-			c0 = cl.q0b + a * (cl.q1b + a * cl.q2b);
-			c1 = cl.q1b + 2 * a * cl.q2b;
-			c2 = 2 * cl.q2b;
+			c0 += cl.q0b + a * (cl.q1b + a * cl.q2b);
+			c1 += cl.q1b + 2 * a * cl.q2b;
+			c2 += 2 * cl.q2b;
 		} else {
 			const double NmT = N - cl.mu * T, T1 = (cl.UV + a * cl.VV) / T, T2d = (cl.VV - T1 * T1) / T;
 			const double s1 = cl.N1 - cl.mu * T1;
-			c0 = 0.5 * cl.Dm * NmT * NmT;
-			c1 = cl.Dm * NmT * s1;
-			c2 = cl.Dm * (s1 * s1 - NmT * cl.mu * T2d);
+			c0 += 0.5 * cl.Dm * NmT * NmT;
+			c1 += cl.Dm * NmT * s1;
+			c2 += cl.Dm * (s1 * s1 - NmT * cl.mu * T2d);
 		}
 	}
-	const double s0 = wave_sum(c0), s1 = wave_sum(c1), s2 = wave_sum(c2);
-	p.cost = a * a * g2 + a * g1 + g0 + s0;
-	p.d0 = 2 * a * g2 + g1 + s1;
-	p.d1 = 2 * g2 + s2;
-	if (p.d1 <= 0) p.d1 = MJB_MINVAL;
 }
 
-template <int G> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e)
+typedef double mjb_d4 __attribute__((ext_vector_type(4)));
+
+// R = rows per lane: row r lives in lane r % 64, slot r / 64 (nefcmax <= 64 R).  R == 1 is BASELINE config 3,
+// R == 4 covers the ~200 rows of config 5.
+template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e)
 {
 	static_assert(G == 64, "the Newton solver maps rows / Hessian columns to the 64 lanes of one wavefront");
 	double *f = e.f;
@@ -828,25 +826,10 @@ template <int G> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env
 	double *Md = f + L.nwt_M, *H = f + L.nwt_H, *Hc = f + L.nwt_hc;
 	double *qa = f + L.nwt_vec, *Ma = qa + nv, *grad = Ma + nv, *srch = grad + nv;
 	double *jar_s = f + L.nwt_row, *jv_s = jar_s + m.nefcmax, *hw = jv_s + m.nefcmax;  // per-row jaref, jv, Hessian weight
-	const bool rowact = lane < nefc, dofact = lane < nv;
-	const int r = rowact ? lane : 0, k = dofact ? lane : 0;
-	const double *Jr = f + L.efc_J + r * nv;
-	const double D = rowact ? f[L.efc_D + r] : 0.0, aref = rowact ? f[L.efc_aref + r] : 0.0;
+	const bool dofact = lane < nv;
+	const int k = dofact ? lane : 0;
 	const double tol = m.tolerance[0];
 	const double scale = 1.0 / (m.meaninertia[0] * (nv > 1 ? nv : 1));
-	// row kind: scalar (limit / frictionless / pyramidal), cone leader (first row of an elliptic contact), cone member
-	const int rtype = rowact ? fi[L.efc_type + r] : 0;
-	const int rcon = rowact ? fi[L.efc_id + r] : 0;
-	const bool is_cone = rowact && rtype == MJB_CNSTR_CONTACT_ELLIPTIC;
-	const bool scalar_row = rowact && !is_cone;
-	const bool leader = is_cone && fi[L.contact_efc_address + rcon] == r;
-	const int cdim = is_cone ? fi[L.contact_dim + rcon] : 0;
-	double cfri[5] = { 0, 0, 0, 0, 0 }, cmu = 1;
-	if (leader) {
-		for (int j = 0; j < 5; j++) cfri[j] = f[L.contact_friction + 5 * rcon + j];
-		cmu = cfri[0] / sqrt(fmax(MJB_MINVAL, m.impratio[0]));
-	}
-
 	// dense symmetric M from the qM layout (entry per lane)
 	for (int t = lane; t < nv * nv; t += G) Md[t] = 0;
 	gsync<G>();
@@ -858,70 +841,108 @@ template <int G> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env
 	}
 	gsync<G>();
 
+	// row kind: scalar (limit / frictionless / pyramidal), cone leader (first row of an elliptic contact), cone member
+	bool rowact[R], scalar_row[R], leader[R];
+	int rr[R], cdim[R], rcon[R];
+	double D[R], aref[R], cmu[R];
+#pragma unroll
+	for (int i = 0; i < R; i++) {
+		const int r = lane + 64 * i;
+		rowact[i] = r < nefc;
+		rr[i] = rowact[i] ? r : 0;
+		const int rtype = rowact[i] ? fi[L.efc_type + r] : 0;
+		rcon[i] = rowact[i] ? fi[L.efc_id + r] : 0;
+		const bool is_cone = rowact[i] && rtype == MJB_CNSTR_CONTACT_ELLIPTIC;
+		scalar_row[i] = rowact[i] && !is_cone;
+		leader[i] = is_cone && fi[L.contact_efc_address + rcon[i]] == r;
+		cdim[i] = is_cone ? fi[L.contact_dim + rcon[i]] : 0;
+		D[i] = rowact[i] ? f[L.efc_D + r] : 0.0;
+		aref[i] = rowact[i] ? f[L.efc_aref + r] : 0.0;
+		cmu[i] = leader[i] ? f[L.contact_friction + 5 * rcon[i]] / sqrt(fmax(MJB_MINVAL, m.impratio[0])) : 1.0;
+	}
+
+
+	// J_r . x - aref_r for the lane's rows (x: nv doubles in LDS)
+	auto row_dots = [&](const double *x, double sub, double *out) {
+#pragma unroll
+		for (int i = 0; i < R; i++) {
+			const double *Jr = f + L.efc_J + rr[i] * nv;
+			double s = -sub * aref[i];
+			for (int c = 0; c < nv; c++) s += Jr[c] * x[c];
+			out[i] = s;
+		}
+	};
+
 	// constraint update at the jaref values parked in jar_s: returns this lane's cost share; forces (and, when
-	// `hess`, the Hessian weights: efc_force slot for scalar rows is reused... see below) written to LDS
+	// `hess`, the Hessian weights hw / cone blocks Hc) written to LDS
 	auto cone_update = [&](bool hess) -> double {
-		// leaders evaluate their contact (rows r .. r+cdim-1); scalar rows evaluate themselves
 		double cost = 0;
-		if (scalar_row) {
-			const double x = jar_s[r];
-			const bool act = x < 0;
-			f[L.efc_force + r] = act ? -D * x : 0.0;
-			if (hess) hw[r] = act ? D : 0.0;
-			cost = act ? 0.5 * D * x * x : 0.0;
-		} else if (leader) {
-			double U[6], x[6], Dj[6], TT = 0;
-			for (int j = 0; j < 6; j++) {
-				if (j < cdim) {
-					x[j] = jar_s[r + j];
-					Dj[j] = f[L.efc_D + r + j];
-					U[j] = (j == 0 ? cmu : cfri[j - 1]) * x[j];
-					if (j > 0) TT += U[j] * U[j];
-				} else {
-					x[j] = 0; Dj[j] = 0; U[j] = 0;
+#pragma unroll
+		for (int i = 0; i < R; i++) {
+			const int r = rr[i];
+			if (scalar_row[i]) {
+				const double x = jar_s[r];
+				const bool act = x < 0;
+				f[L.efc_force + r] = act ? -D[i] * x : 0.0;
+				if (hess) hw[r] = act ? D[i] : 0.0;
+				cost += act ? 0.5 * D[i] * x * x : 0.0;
+			} else if (leader[i]) {
+				const int dim = cdim[i];
+				const double mu = cmu[i];
+				const double *cfri = f + L.contact_friction + 5 * rcon[i];
+				double U[6], x[6], Dj[6], TT = 0;
+				for (int j = 0; j < 6; j++) {
+					if (j < dim) {
+						x[j] = jar_s[r + j];
+						Dj[j] = f[L.efc_D + r + j];
+						U[j] = (j == 0 ? mu : cfri[j > 0 ? j - 1 : 0]) * x[j];
+						if (j > 0) TT += U[j] * U[j];
+					} else {
+						x[j] = 0; Dj[j] = 0; U[j] = 0;
+					}
 				}
-			}
-			const double N = U[0], T = sqrt(TT);
-			double *hc = Hc + 36 * rcon;
-			if (hess)
-				for (int j = 0; j < 36; j++) hc[j] = 0;
-			if (N >= cmu * T) {
-				for (int j = 0; j < 6; j++)
-					if (j < cdim) f[L.efc_force + r + j] = 0;
-			} else if (cmu * N + T <= 0) {
-				for (int j = 0; j < 6; j++)
-					if (j < cdim) {
-						f[L.efc_force + r + j] = -Dj[j] * x[j];
-						cost += 0.5 * Dj[j] * x[j] * x[j];
-						if (hess) hc[j * 6 + j] = Dj[j];
+				const double N = U[0], T = sqrt(TT);
+				double *hc = Hc + 36 * rcon[i];
+				if (hess)
+					for (int j = 0; j < 36; j++) hc[j] = 0;
+				if (N >= mu * T) {
+					for (int j = 0; j < 6; j++)
+						if (j < dim) f[L.efc_force + r + j] = 0;
+				} else if (mu * N + T <= 0) {
+					for (int j = 0; j < 6; j++)
+						if (j < dim) {
+							f[L.efc_force + r + j] = -Dj[j] * x[j];
+							cost += 0.5 * Dj[j] * x[j] * x[j];
+							if (hess) hc[j * 6 + j] = Dj[j];
+						}
+				} else {
+					const double Dm = Dj[0] / (mu * mu * (1 + mu * mu)), NmT = N - mu * T;
+					cost += 0.5 * Dm * NmT * NmT;
+					const double f0 = -Dm * NmT * mu;
+					f[L.efc_force + r] = f0;
+					double g[6];
+					g[0] = mu;
+					for (int j = 1; j < 6; j++) {
+						g[j] = 0;
+						if (j < dim) {
+							f[L.efc_force + r + j] = -f0 / T * U[j] * cfri[j - 1];
+							g[j] = -mu * cfri[j - 1] * U[j] / T;
+						}
 					}
-			} else {
-				const double Dm = Dj[0] / (cmu * cmu * (1 + cmu * cmu)), NmT = N - cmu * T;
-				cost = 0.5 * Dm * NmT * NmT;
-				const double f0 = -Dm * NmT * cmu;
-				f[L.efc_force + r] = f0;
-				double g[6];
-				g[0] = cmu;
-				for (int j = 1; j < 6; j++) {
-					g[j] = 0;
-					if (j < cdim) {
-						f[L.efc_force + r + j] = -f0 / T * U[j] * cfri[j - 1];
-						g[j] = -cmu * cfri[j - 1] * U[j] / T;
-					}
+					if (hess)
+						for (int j = 0; j < 6; j++)
+							for (int c2 = 0; c2 < 6; c2++) {
+								if (j >= dim || c2 >= dim) continue;
+								double v = Dm * g[j] * g[c2];
+								if (j >= 1 && c2 >= 1)
+									v += -Dm * NmT * mu * cfri[j - 1] * cfri[c2 - 1] * ((j == c2 ? 1.0 / T : 0.0) - U[j] * U[c2] / (T * T * T));
+								hc[j * 6 + c2] = v;
+							}
 				}
 				if (hess)
 					for (int j = 0; j < 6; j++)
-						for (int c2 = 0; c2 < 6; c2++) {
-							if (j >= cdim || c2 >= cdim) continue;
-							double v = Dm * g[j] * g[c2];
-							if (j >= 1 && c2 >= 1)
-								v += -Dm * NmT * cmu * cfri[j - 1] * cfri[c2 - 1] * ((j == c2 ? 1.0 / T : 0.0) - U[j] * U[c2] / (T * T * T));
-							hc[j * 6 + c2] = v;
-						}
+						if (j < dim) hw[r + j] = 0;
 			}
-			if (hess)
-				for (int j = 0; j < 6; j++)
-					if (j < cdim) hw[r + j] = 0;
 		}
 		return cost;
 	};
@@ -935,9 +956,11 @@ template <int G> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env
 			if (dofact)
 				for (int c = 0; c < nv; c++) t += Md[k * nv + c] * q0[c];
 			const double gk = dofact ? 0.5 * (t - f[L.qfrc_smooth + k]) * (q0[k] - f[L.qacc_smooth + k]) : 0.0;
-			double x = -aref;
-			for (int c = 0; c < nv; c++) x += Jr[c] * q0[c];
-			if (rowact) jar_s[r] = x;
+			double x[R];
+			row_dots(q0, 1.0, x);
+#pragma unroll
+			for (int i = 0; i < R; i++)
+				if (rowact[i]) jar_s[rr[i]] = x[i];
 			gsync<G>();
 			const double ck = cone_update(false);
 			const double cost = wave_sum(gk) + wave_sum(ck);
@@ -961,9 +984,11 @@ template <int G> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env
 		if (dofact)
 			for (int c = 0; c < nv; c++) ma += Md[k * nv + c] * qa[c];
 		const double gk = dofact ? 0.5 * (ma - f[L.qfrc_smooth + k]) * (qa[k] - f[L.qacc_smooth + k]) : 0.0;
-		double jaref = -aref;
-		for (int c = 0; c < nv; c++) jaref += Jr[c] * qa[c];
-		if (rowact) jar_s[r] = jaref;
+		double jaref[R];
+		row_dots(qa, 1.0, jaref);
+#pragma unroll
+		for (int i = 0; i < R; i++)
+			if (rowact[i]) jar_s[rr[i]] = jaref[i];
 		if (dofact) Ma[k] = ma;
 		gsync<G>();
 		const double ck = cone_update(true);
@@ -984,26 +1009,46 @@ template <int G> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env
 			const double gnorm = scale * sqrt(wave_sum(gr * gr));
 			if (improvement < tol || gnorm < tol || iter >= m.iterations) break;
 		}
-		// H = M + J' W J  (lower triangle used), entry per lane; W = per-row weights + per-cone blocks
-		for (int t = lane; t < nv * nv; t += G) {
-			const int rr = t / nv, cc = t - rr * nv;
-			double s = Md[t];
-			for (int i = 0; i < nefc; i++) {
-				if (fi[L.efc_type + i] != MJB_CNSTR_CONTACT_ELLIPTIC) {
-					const double di = hw[i];
-					if (di != 0) s += di * f[L.efc_J + i * nv + rr] * f[L.efc_J + i * nv + cc];
-				} else {
-					const int con = fi[L.efc_id + i], dim = fi[L.contact_dim + con];
-					const double *hc = Hc + 36 * con;
-					for (int a = 0; a < dim; a++)
-						for (int b2 = 0; b2 < dim; b2++) {
-							const double w = hc[a * 6 + b2];
-							if (w != 0) s += w * f[L.efc_J + (i + a) * nv + rr] * f[L.efc_J + (i + b2) * nv + cc];
+		// H = M + J' W J on the matrix cores: 16x16 tiles of v_mfma_f64_16x16x4_f64 over 4-row slabs of J.
+		// A[i][kk] = (W J)[r0+kk][a0+i] (row weight, or the contact's cone block times its rows), B[kk][j] = J[r0+kk][b0+j];
+		// lane l feeds A[l&15][l>>4], B[l>>4][l&15] and receives D[(l>>4) + 4 q][l&15], q = 0..3.
+		{
+			const int li = lane & 15, lk = lane >> 4;
+			const int ntile = (nv + 15) >> 4;
+			for (int ta = 0; ta < ntile; ta++)
+				for (int tb = 0; tb <= ta; tb++) {
+					mjb_d4 acc = { 0, 0, 0, 0 };
+					const int ca = 16 * ta + li, cb = 16 * tb + li;
+					const bool ina = ca < nv, inb = cb < nv;
+					for (int r0 = 0; r0 < nefc; r0 += 4) {
+						const int r = r0 + lk;
+						double av = 0, bv = 0;
+						if (r < nefc) {
+							const double *Jr = f + L.efc_J + r * nv;
+							if (inb) bv = Jr[cb];
+							if (ina) {
+								if (fi[L.efc_type + r] != MJB_CNSTR_CONTACT_ELLIPTIC) {
+									const double w = hw[r];
+									av = (w != 0) ? w * Jr[ca] : 0.0;
+								} else {
+									const int con = fi[L.efc_id + r], adr = fi[L.contact_efc_address + con];
+									const int dim = fi[L.contact_dim + con];
+									const double *hc = Hc + 36 * con + 6 * (r - adr);
+									for (int s2 = 0; s2 < dim; s2++) {
+										const double w = hc[s2];
+										if (w != 0) av += w * f[L.efc_J + (adr + s2) * nv + ca];
+									}
+								}
+							}
 						}
-					i += dim - 1;
+						acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+					}
+#pragma unroll
+					for (int q = 0; q < 4; q++) {
+						const int row = 16 * ta + lk + 4 * q, col = 16 * tb + li;
+						if (row < nv && col < nv) H[row * nv + col] = Md[row * nv + col] + acc[q];
+					}
 				}
-			}
-			H[t] = s;
 		}
 		gsync<G>();
 		// column Cholesky, lane = row of H (nv <= 64)
@@ -1042,28 +1087,35 @@ template <int G> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env
 		double mv = 0;
 		if (dofact)
 			for (int c = 0; c < nv; c++) mv += Md[k * nv + c] * srch[c];
-		double jv = 0;
-		for (int c = 0; c < nv; c++) jv += Jr[c] * srch[c];
-		if (rowact) jv_s[r] = jv;
+		double jv[R];
+		row_dots(srch, 0.0, jv);
+#pragma unroll
+		for (int i = 0; i < R; i++)
+			if (rowact[i]) jv_s[rr[i]] = jv[i];
 		gsync<G>();
-		ConeLine cl = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 0 };
-		if (leader) {
-			cl.mu = cmu;
-			cl.N0 = cmu * jaref;
-			cl.N1 = cmu * jv;
-			const double D0 = D;
-			cl.Dm = D0 / (cmu * cmu * (1 + cmu * cmu));
-			for (int j = 0; j < 6; j++) {
-				if (j >= cdim) break;
-				const double xj = jar_s[r + j], vj = jv_s[r + j], Dj = f[L.efc_D + r + j];
-				cl.q0b += 0.5 * Dj * xj * xj;
-				cl.q1b += Dj * xj * vj;
-				cl.q2b += 0.5 * Dj * vj * vj;
-				if (j > 0) {
-					const double U = cfri[j - 1] * xj, V = cfri[j - 1] * vj;
-					cl.TT += U * U;
-					cl.UV += U * V;
-					cl.VV += V * V;
+		ConeLine cl[R];
+#pragma unroll
+		for (int i = 0; i < R; i++) {
+			cl[i] = ConeLine{ 0, 0, 0, 0, 0, 0, 0, 0, 1, 0 };
+			if (leader[i]) {
+				const double mu = cmu[i];
+				const double *cfri = f + L.contact_friction + 5 * rcon[i];
+				cl[i].mu = mu;
+				cl[i].N0 = mu * jaref[i];
+				cl[i].N1 = mu * jv[i];
+				cl[i].Dm = D[i] / (mu * mu * (1 + mu * mu));
+				for (int j = 0; j < 6; j++) {
+					if (j >= cdim[i]) break;
+					const double xj = jar_s[rr[i] + j], vj = jv_s[rr[i] + j], Dj = f[L.efc_D + rr[i] + j];
+					cl[i].q0b += 0.5 * Dj * xj * xj;
+					cl[i].q1b += Dj * xj * vj;
+					cl[i].q2b += 0.5 * Dj * vj * vj;
+					if (j > 0) {
+						const double U = cfri[j - 1] * xj, V = cfri[j - 1] * vj;
+						cl[i].TT += U * U;
+						cl[i].UV += U * V;
+						cl[i].VV += V * V;
+					}
 				}
 			}
 		}
@@ -1071,8 +1123,19 @@ template <int G> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env
 		const double g1 = wave_sum(dofact ? sk * (ma - f[L.qfrc_smooth + k]) : 0.0);
 		const double g2 = wave_sum(dofact ? 0.5 * sk * mv : 0.0);
 		const double gtol = tol * 0.01 * snorm / scale;  // mjOption.ls_tolerance = 0.01
+		auto ls_eval = [&](LsPoint &p) {
+			const double a = p.alpha;
+			double c0 = 0, c1 = 0, c2 = 0;
+#pragma unroll
+			for (int i = 0; i < R; i++) ls_row(a, scalar_row[i], leader[i], jaref[i], jv[i], D[i], cl[i], c0, c1, c2);
+			const double s0 = wave_sum(c0), s1 = wave_sum(c1), s2 = wave_sum(c2);
+			p.cost = a * a * g2 + a * g1 + g0 + s0;
+			p.d0 = 2 * a * g2 + g1 + s1;
+			p.d1 = 2 * g2 + s2;
+			if (p.d1 <= 0) p.d1 = MJB_MINVAL;
+		};
 		double alpha;
-#define LS_EVAL(P) ls_eval(P, scalar_row, leader, jaref, jv, D, cl, g0, g1, g2)
+#define LS_EVAL(P) ls_eval(P)
 		{
 			LsPoint p0, p1, p2, pmid, p1n, p2n;
 			int lsit = 0;

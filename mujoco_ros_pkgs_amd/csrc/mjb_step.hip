@@ -1137,8 +1137,8 @@ template <int G, int CON> DEVI void forward_rest(const KernelParams MJB_AS4 *P, 
 	PROF(9);
 	VIEW(P, compact, fwd_acceleration<G>(m, L, e, s.use_xfrc != 0));
 	PROF(10);
-	if constexpr (CON == 2 && G == 64) {
-		VIEW(P, compact, fwd_constraint_newton<G>(m, L, e));
+	if constexpr (CON >= 2 && G == 64) {
+		VIEW(P, compact, fwd_constraint_newton<G, (CON == 2 ? 1 : (CON == 3 ? 2 : 4))>(m, L, e));
 	} else if constexpr (CON == 1 && G == 64) {
 		VIEW(P, compact, fwd_constraint_pgs<G>(m, L, e));
 	} else {
@@ -1164,7 +1164,7 @@ template <int G> STAGE void ctrl_noise(CModel m, CLayout L, CNoise nz, const Env
 // ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
-// CON: 0 = model without constraint rows; 1 = PGS, 2 = Newton (collision / rows / solver stages compiled in;
+// CON: 0 = model without constraint rows; 1 = PGS, 2 / 3 / 4 = Newton with 1 / 2 / 4 rows per lane (collision / rows / solver stages compiled in;
 // one env per wavefront) -- separate kernels keep each instruction stream and register budget small.
 // Constrained kernels are capped at 256 VGPRs (2 blocks/CU): with the 512-register budget ROCm 7.2's LLVM
 // spills VGPRs to AGPRs ahead of an exec restore and loses lanes (tools/check_spill_exec.py, `make lint`).
@@ -1312,6 +1312,8 @@ int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, in
 	if (constrained) {
 		if (lanes_per_env != 64) return (int)hipErrorInvalidValue;
 		if (constrained == 2) return launch_g<64, 2>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+		if (constrained == 3) return launch_g<64, 3>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+		if (constrained == 4) return launch_g<64, 4>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 		return launch_g<64, 1>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 	}
 	switch (lanes_per_env) {
