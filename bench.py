@@ -22,7 +22,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_ENV_STEP = {"franka_like": 712, "franka_table": 1072}  # 8*(2nq+2nv+2nv+nu+S)+8
+ALGO_BYTES_PER_ENV_STEP = {"franka_like": 712, "franka_table": 1072, "shadow_hand_like": 2136}  # 8*(2nq+2nv+2nv+nu+S)+8
+# per-model workload: (BASELINE config label, OU ctrl-noise std [= 0.5 * ctrlrange of the big actuators], default envs per GPU)
+WORKLOADS = {
+    "franka_like": ("BASELINE configs[1]: Franka-Panda-like 9-DoF arm, no contacts", 0.5 * 87.0, 4096),
+    "franka_table": ("BASELINE configs[2]: Franka-like arm + table + cube contacts", 0.5 * 87.0, 4096),
+    "shadow_hand_like": ("BASELINE configs[4]: Shadow-Hand-like 24-DoF hand + in-hand cube (Newton, elliptic cones)", 0.1, 1024),
+}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable)
 
 
@@ -57,15 +63,22 @@ class DevArray:
                                          "version": 2, "strides": None}
 
 
-def cpu_baseline(model, nsteps_total_target_s=12.0):
+def initial_state(name, model, nenv, seed):
+    if name == "shadow_hand_like":
+        from mujoco_ros_pkgs_amd import workloads
+        return workloads.hand_grasp_states(model, nenv, seed)
+    return synthetic_state(model, nenv, seed)
+
+
+def cpu_baseline(name, model, noise_std, nsteps_total_target_s=12.0):
     """Time the CPU oracle ("port": from-scratch restatement, -O3 -march=native) on a bounded sample of the
     same workload, all host cores, one env per thread at a time."""
     from oracle import pyoracle
     pyoracle.build()
     cores = os.cpu_count() or 1
     nenv, nsteps = 4 * cores, 200
-    qpos, qvel = synthetic_state(model, nenv, seed=999)
-    kw = dict(noise_std=0.5 * 87.0, noise_rate=0.1, seed=12345, nthreads=cores, fast=True)
+    qpos, qvel = initial_state(name, model, nenv, seed=999)
+    kw = dict(noise_std=noise_std, noise_rate=0.1, seed=12345, nthreads=cores, fast=True)
     t0 = time.perf_counter()
     pyoracle.rollout(model, qpos, qvel, nsteps, **kw)
     dt = time.perf_counter() - t0
@@ -76,7 +89,7 @@ def cpu_baseline(model, nsteps_total_target_s=12.0):
     pyoracle.rollout(model, qpos, qvel, nsteps2, **kw)
     dt = time.perf_counter() - t0
     return {"value": nenv * nsteps2 / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{nenv} envs x {nsteps2} steps of the same Franka workload (OU ctrl noise), oracle/libmjo_fast.so "
+            "sample": f"{nenv} envs x {nsteps2} steps of the same {name} workload (OU ctrl noise), oracle/libmjo_fast.so "
                       f"(gcc -O3 -march=native), {cores} threads, {dt:.1f} s"}
 
 
@@ -86,11 +99,12 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--substeps", type=int, default=1000, help="physics steps fused into one launch")
-    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU (weak scaling)")
+    ap.add_argument("--envs", type=int, default=0, help="envs per GPU (weak scaling); 0 = the config's own (4096; 1024 for the hand)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per env (0 = engine default)")
     ap.add_argument("--epb", type=int, default=0, help="envs per workgroup (0 = engine default)")
     ap.add_argument("--model", default="franka_like")
     ap.add_argument("--solver", default="", choices=["", "PGS", "Newton"], help="override the model's constraint solver")
+    ap.add_argument("--nefcmax", type=int, default=0, help="override the model's constraint-row capacity")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -119,20 +133,21 @@ def main():
 
     from mujoco_ros_pkgs_amd import engine, mjcf, sharding
 
-    model = mjcf.load_asset(args.model)
+    model = mjcf.load_asset(args.model, **({"nefcmax": args.nefcmax} if args.nefcmax else {}))
     if args.solver:
         model = mjcf.Model(dict(model))
         model["solver"] = {"PGS": 0, "Newton": 2}[args.solver]
     cm = engine.CompiledModel(model)
-    E, S = args.envs, args.substeps
+    label, noise_std, default_envs = WORKLOADS.get(args.model, (args.model, 1.0, 4096))
+    E, S = (args.envs or default_envs), args.substeps
     batch = engine.Batch(cm, E, local_rank)
     batch.set_launch(args.lanes, args.epb)
-    qpos, qvel = synthetic_state(model, E, seed=1000 + rank)
+    qpos, qvel = initial_state(args.model, model, E, seed=1000 + rank)
     batch.set("qpos", qpos)
     batch.set("qvel", qvel)
     # reference injector: tau = 0.1 s, std = 0.5 * ctrlrange (87 N m on the big joints), seed 12345
     env_lo, _ = sharding.shard_range(rank, world, E)
-    batch.set_ctrl_noise(0.5 * 87.0, 0.1, 12345, env_lo)
+    batch.set_ctrl_noise(noise_std, 0.1, 12345, env_lo)
     batch.synchronize()
 
     nsd = model["nsensordata"]
@@ -188,12 +203,10 @@ def main():
             "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: Franka-Panda-like 9-DoF arm, no contacts, " if args.model == "franka_like"
-                                    else "BASELINE configs[2]: Franka-like arm + table + cube contacts (PGS, pyramidal), ")
-                                   + f"{E} envs per GPU, fp64, Euler dt={model['timestep'][0]}",
+            "config": {"workload": f"{label}, {E} envs per GPU, fp64, Euler dt={model['timestep'][0]}",
                        "envs_per_gpu": E, "physics_steps_per_launch": S, "model": args.model,
                        "solver": {0: "PGS", 1: "CG", 2: "Newton"}[int(model["solver"])] if model["nefcmax"] else "none",
-                       "ctrl": "on-device OU noise (Philox seed 12345, tau 0.1 s, std 43.5)",
+                       "ctrl": f"on-device OU noise (Philox seed 12345, tau 0.1 s, std {noise_std:g})",
                        "parallelism": f"env-sharded x{world}, RCCL all-gather of sensordata per launch" if world > 1
                        else "single GPU", "state_finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -202,7 +215,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model)
+            out["cpu_baseline"] = cpu_baseline(args.model, model, noise_std)
         print(json.dumps(out))
     if gather:
         if force_gather and rank == 0:

@@ -54,6 +54,138 @@ DEVI int raw_plane_sphere(RawCon &c, const double *pos1, const double *n, const 
 
 DEVI double clipd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+DEVI int raw_sphere_box(RawCon &c, const double *pos1, double r1, const double *pos2, const double *mat2,
+                        const double *size2, double margin)
+{
+	const double tmp[3] = { pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2] };
+	double center[3], clamped[3], dv[3];
+	matTvec3(center, mat2, tmp);
+	for (int i = 0; i < 3; i++) {
+		clamped[i] = clipd(center[i], -size2[i], size2[i]);
+		dv[i] = clamped[i] - center[i];
+	}
+	const double dist = sqrt(dot3(dv, dv));
+	if (dist - r1 > margin) return 0;
+	double nloc[3] = { 0, 0, 0 }, ploc[3];
+	if (dist <= MJB_MINVAL) {
+		double closest = 2 * fmax(size2[0], fmax(size2[1], size2[2]));
+		int kk = 0;
+		for (int i = 0; i < 6; i++) {
+			const double fd = fabs(((i % 2) ? 1 : -1) * size2[i / 2] - center[i / 2]);
+			if (closest > fd) {
+				closest = fd;
+				kk = i;
+			}
+		}
+		const double sgn = (kk % 2) ? -1.0 : 1.0;
+		nloc[0] = (kk / 2 == 0) ? sgn : 0.0; nloc[1] = (kk / 2 == 1) ? sgn : 0.0; nloc[2] = (kk / 2 == 2) ? sgn : 0.0;
+		for (int i = 0; i < 3; i++) ploc[i] = center[i] + nloc[i] * (r1 - closest) / 2;
+		c.dist = -closest - r1;
+	} else {
+		for (int i = 0; i < 3; i++) {
+			const double deepest = center[i] + dv[i] * (r1 / dist);
+			ploc[i] = 0.5 * (clamped[i] + deepest);
+			nloc[i] = dv[i] / dist;
+		}
+		c.dist = dist - r1;
+	}
+	matvec3(c.frame, mat2, nloc);
+	c.frame[3] = c.frame[4] = c.frame[5] = 0;
+	matvec3(c.pos, mat2, ploc);
+	c.pos[0] += pos2[0]; c.pos[1] += pos2[1]; c.pos[2] += pos2[2];
+	return 1;
+}
+
+// capsule - box: same steps as oracle/mjo_constraint.c capsule_box (see the derivation there): minimiser set of
+// the convex axis-to-box distance by bisection on its slope, candidate axis points from the closest feature
+// (face: ends of the stretch over the face; inside: ends of the inside stretch; edge / vertex: the minimiser
+// set), each candidate through the sphere-box contact
+DEVI double capbox_slope(const double *p0, const double *d, const double *s, double t)
+{
+	double g = 0;
+	for (int i = 0; i < 3; i++) {
+		const double p = p0[i] + t * d[i];
+		g += (p - clipd(p, -s[i], s[i])) * d[i];
+	}
+	return g;
+}
+
+DEVI int capsule_box(RawCon *rc, const double *pos1, const double *mat1, const double *size1, const double *pos2,
+                     const double *mat2, const double *size2, double margin)
+{
+	const double r = size1[0], h = size1[1];
+	const double axis[3] = { mat1[2], mat1[5], mat1[8] };
+	const double tmp[3] = { pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2] };
+	double p0[3], d[3];
+	matTvec3(p0, mat2, tmp);
+	matTvec3(d, mat2, axis);
+	const double glo = capbox_slope(p0, d, size2, -h), ghi = capbox_slope(p0, d, size2, h);
+	double tlo, thi;
+	if (glo >= 0) tlo = -h;
+	else if (ghi < 0) tlo = h;
+	else {
+		double lo = -h, hi = h;
+#pragma nounroll
+		for (int it = 0; it < 60; it++) {
+			const double mid = 0.5 * (lo + hi);
+			if (capbox_slope(p0, d, size2, mid) >= 0) hi = mid;
+			else lo = mid;
+		}
+		tlo = hi;
+	}
+	if (ghi <= 0) thi = h;
+	else if (glo > 0) thi = -h;
+	else {
+		double lo = -h, hi = h;
+#pragma nounroll
+		for (int it = 0; it < 60; it++) {
+			const double mid = 0.5 * (lo + hi);
+			if (capbox_slope(p0, d, size2, mid) > 0) hi = mid;
+			else lo = mid;
+		}
+		thi = lo;
+	}
+	if (thi < tlo) thi = tlo;
+	const double ts = 0.5 * (tlo + thi);
+	int nout = 0, face = 0;
+	for (int i = 0; i < 3; i++)
+		if (fabs(p0[i] + ts * d[i]) > size2[i]) {
+			nout++;
+			face = i;
+		}
+	double ta = tlo, tb = thi;
+	if (nout <= 1) {
+		ta = -h;
+		tb = h;
+		for (int j = 0; j < 3; j++) {
+			if (nout == 1 && j == face) continue;
+			if (fabs(d[j]) <= MJB_MINVAL) continue;
+			double t1 = (-size2[j] - p0[j]) / d[j], t2 = (size2[j] - p0[j]) / d[j];
+			if (t1 > t2) {
+				const double sw = t1;
+				t1 = t2;
+				t2 = sw;
+			}
+			if (t1 > ta) ta = t1;
+			if (t2 < tb) tb = t2;
+		}
+		if (ta > tb) ta = tb = ts;
+	}
+	int n = 0;
+	double ctr[3] = { pos1[0] + axis[0] * ta, pos1[1] + axis[1] * ta, pos1[2] + axis[2] * ta };
+	n += raw_sphere_box(rc[0], ctr, r, pos2, mat2, size2, margin);
+	if (tb - ta > 1e-6 * h) {
+		ctr[0] = pos1[0] + axis[0] * tb; ctr[1] = pos1[1] + axis[1] * tb; ctr[2] = pos1[2] + axis[2] * tb;
+		RawCon c2;
+		if (raw_sphere_box(c2, ctr, r, pos2, mat2, size2, margin)) {
+			if (n == 0) rc[0] = c2;
+			else rc[1] = c2;
+			n++;
+		}
+	}
+	return n;
+}
+
 // narrow phase of one candidate pair; returns the number of raw contacts (<= 4)
 DEVI int narrowphase(int t1, int t2, const double *pos1, const double *mat1, const double *size1, const double *pos2,
                      const double *mat2, const double *size2, double margin, RawCon *rc)
@@ -106,47 +238,10 @@ DEVI int narrowphase(int t1, int t2, const double *pos1, const double *mat1, con
 			const double p[3] = { pos2[0] + axis[0] * x, pos2[1] + axis[1] * x, pos2[2] + axis[2] * x };
 			n = raw_sphere_sphere(rc[0], pos1, size1[0], p, size2[0], margin);
 		} else if (t2 == MJB_GEOM_BOX) {
-			const double r1 = size1[0];
-			const double tmp[3] = { pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2] };
-			double center[3], clamped[3], dv[3];
-			matTvec3(center, mat2, tmp);
-			for (int i = 0; i < 3; i++) {
-				clamped[i] = clipd(center[i], -size2[i], size2[i]);
-				dv[i] = clamped[i] - center[i];
-			}
-			const double dist = sqrt(dot3(dv, dv));
-			if (!(dist - r1 > margin)) {
-				double nloc[3] = { 0, 0, 0 }, ploc[3];
-				RawCon &c = rc[0];
-				if (dist <= MJB_MINVAL) {
-					double closest = 2 * fmax(size2[0], fmax(size2[1], size2[2]));
-					int kk = 0;
-					for (int i = 0; i < 6; i++) {
-						const double fd = fabs(((i % 2) ? 1 : -1) * size2[i / 2] - center[i / 2]);
-						if (closest > fd) {
-							closest = fd;
-							kk = i;
-						}
-					}
-					const double sgn = (kk % 2) ? -1.0 : 1.0;
-					nloc[0] = (kk / 2 == 0) ? sgn : 0.0; nloc[1] = (kk / 2 == 1) ? sgn : 0.0; nloc[2] = (kk / 2 == 2) ? sgn : 0.0;
-					for (int i = 0; i < 3; i++) ploc[i] = center[i] + nloc[i] * (r1 - closest) / 2;
-					c.dist = -closest - r1;
-				} else {
-					for (int i = 0; i < 3; i++) {
-						const double deepest = center[i] + dv[i] * (r1 / dist);
-						ploc[i] = 0.5 * (clamped[i] + deepest);
-						nloc[i] = dv[i] / dist;
-					}
-					c.dist = dist - r1;
-				}
-				matvec3(c.frame, mat2, nloc);
-				c.frame[3] = c.frame[4] = c.frame[5] = 0;
-				matvec3(c.pos, mat2, ploc);
-				c.pos[0] += pos2[0]; c.pos[1] += pos2[1]; c.pos[2] += pos2[2];
-				n = 1;
-			}
+			n = raw_sphere_box(rc[0], pos1, size1[0], pos2, mat2, size2, margin);
 		}
+	} else if (t1 == MJB_GEOM_CAPSULE && t2 == MJB_GEOM_BOX) {
+		n = capsule_box(rc, pos1, mat1, size1, pos2, mat2, size2, margin);
 	} else if (t1 == MJB_GEOM_CAPSULE && t2 == MJB_GEOM_CAPSULE) {
 		const double a1[3] = { mat1[2], mat1[5], mat1[8] }, a2[3] = { mat2[2], mat2[5], mat2[8] };
 		const double dif[3] = { pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2] };
@@ -823,6 +918,7 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 		gsync<G>();
 		return;
 	}
+	EPROF_BEGIN();
 	double *Md = f + L.nwt_M, *H = f + L.nwt_H, *Hc = f + L.nwt_hc;
 	double *qa = f + L.nwt_vec, *Ma = qa + nv, *grad = Ma + nv, *srch = grad + nv;
 	double *jar_s = f + L.nwt_row, *jv_s = jar_s + m.nefcmax, *hw = jv_s + m.nefcmax;  // per-row jaref, jv, Hessian weight
@@ -866,8 +962,11 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 	auto row_dots = [&](const double *x, double sub, double *out) {
 #pragma unroll
 		for (int i = 0; i < R; i++) {
+			out[i] = 0;
+			if (64 * i >= nefc) continue;  // wave-uniform: no row of this slot exists
 			const double *Jr = f + L.efc_J + rr[i] * nv;
 			double s = -sub * aref[i];
+#pragma unroll 5
 			for (int c = 0; c < nv; c++) s += Jr[c] * x[c];
 			out[i] = s;
 		}
@@ -880,6 +979,7 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 #pragma unroll
 		for (int i = 0; i < R; i++) {
 			const int r = rr[i];
+			if (64 * i >= nefc) continue;
 			if (scalar_row[i]) {
 				const double x = jar_s[r];
 				const bool act = x < 0;
@@ -947,14 +1047,17 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 		return cost;
 	};
 
+	EPROF(24);
 	// warmstart: the cheaper of qacc_warmstart and qacc_smooth
 	{
 		double best = 0;
 		for (int pass = 0; pass < 2; pass++) {
 			const double *q0 = f + (pass == 0 ? L.qacc_warmstart : L.qacc_smooth);
 			double t = 0;
-			if (dofact)
+			if (dofact) {
+#pragma unroll 5
 				for (int c = 0; c < nv; c++) t += Md[k * nv + c] * q0[c];
+			}
 			const double gk = dofact ? 0.5 * (t - f[L.qfrc_smooth + k]) * (q0[k] - f[L.qacc_smooth + k]) : 0.0;
 			double x[R];
 			row_dots(q0, 1.0, x);
@@ -976,13 +1079,17 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 		}
 	}
 
+	EPROF(25);
 	double cost = 0, prev_cost = 0;
 	int iter = 0;
 	for (;;) {
+		EPROF(30);
 		// Ma = M qacc, jaref = J qacc - aref, forces, cost, gradient
 		double ma = 0;
-		if (dofact)
+		if (dofact) {
+#pragma unroll 5
 			for (int c = 0; c < nv; c++) ma += Md[k * nv + c] * qa[c];
+		}
 		const double gk = dofact ? 0.5 * (ma - f[L.qfrc_smooth + k]) * (qa[k] - f[L.qacc_smooth + k]) : 0.0;
 		double jaref[R];
 		row_dots(qa, 1.0, jaref);
@@ -999,6 +1106,7 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 		double gr = 0;
 		if (dofact) {
 			double s = 0;
+#pragma unroll 4
 			for (int i = 0; i < nefc; i++) s += f[L.efc_J + i * nv + k] * f[L.efc_force + i];
 			f[L.qfrc_constraint + k] = s;
 			gr = ma - f[L.qfrc_smooth + k] - s;
@@ -1009,6 +1117,7 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 			const double gnorm = scale * sqrt(wave_sum(gr * gr));
 			if (improvement < tol || gnorm < tol || iter >= m.iterations) break;
 		}
+		EPROF(26);
 		// H = M + J' W J on the matrix cores: 16x16 tiles of v_mfma_f64_16x16x4_f64 over 4-row slabs of J.
 		// A[i][kk] = (W J)[r0+kk][a0+i] (row weight, or the contact's cone block times its rows), B[kk][j] = J[r0+kk][b0+j];
 		// lane l feeds A[l&15][l>>4], B[l>>4][l&15] and receives D[(l>>4) + 4 q][l&15], q = 0..3.
@@ -1051,33 +1160,42 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 				}
 		}
 		gsync<G>();
-		// column Cholesky, lane = row of H (nv <= 64)
+		EPROF(27);
+		// column Cholesky, lane = row of H (nv <= 64); lane j keeps 1 / L_jj so that the substitutions below
+		// multiply instead of divide and never read the diagonal back
+		double myrinv = 1.0;
 		for (int j = 0; j < nv; j++) {
 			double s = 0;
 			if (dofact && k >= j) {
 				s = H[k * nv + j];
+#pragma unroll 4
 				for (int c = 0; c < j; c++) s -= H[k * nv + c] * H[j * nv + c];
 			}
 			double sj = wave_bcast(s, j);
 			if (sj < MJB_MINVAL) sj = MJB_MINVAL;
-			const double ljj = sqrt(sj);
-			if (dofact && k >= j) H[k * nv + j] = (k == j) ? ljj : s / ljj;
+			const double rinv = rsqrt(sj);
+			if (dofact && k >= j) H[k * nv + j] = (k == j) ? sj * rinv : s * rinv;
+			if (k == j) myrinv = rinv;
 			gsync<G>();
 		}
+		EPROF(31);
 		// search = -H^-1 grad : lane k holds element k
 		double x = gr;
+#pragma unroll 4
 		for (int i = 0; i < nv; i++) {
-			const double lii = H[i * nv + i];
-			const double xi = wave_bcast(x, i) / lii;
-			if (dofact && k == i) x = xi;
-			else if (dofact && k > i) x -= H[k * nv + i] * xi;
+			const double xi = wave_bcast(x * myrinv, i);
+			const double lki = (dofact && k > i) ? H[k * nv + i] : 0.0;
+			if (k == i) x = xi;
+			else x -= lki * xi;
 		}
+#pragma unroll 4
 		for (int i = nv - 1; i >= 0; i--) {
-			const double lii = H[i * nv + i];
-			const double xi = wave_bcast(x, i) / lii;
-			if (dofact && k == i) x = xi;
-			else if (dofact && k < i) x -= H[i * nv + k] * xi;
+			const double xi = wave_bcast(x * myrinv, i);
+			const double lik = (dofact && k < i) ? H[i * nv + k] : 0.0;
+			if (k == i) x = xi;
+			else x -= lik * xi;
 		}
+		EPROF(28);
 		const double sk = dofact ? -x : 0.0;
 		const double snorm = sqrt(wave_sum(sk * sk));
 		if (snorm < MJB_MINVAL) break;
@@ -1085,37 +1203,48 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 		gsync<G>();
 		// line search along the Newton direction
 		double mv = 0;
-		if (dofact)
+		if (dofact) {
+#pragma unroll 5
 			for (int c = 0; c < nv; c++) mv += Md[k * nv + c] * srch[c];
+		}
 		double jv[R];
 		row_dots(srch, 0.0, jv);
 #pragma unroll
 		for (int i = 0; i < R; i++)
 			if (rowact[i]) jv_s[rr[i]] = jv[i];
 		gsync<G>();
-		ConeLine cl[R];
+		// per-contact line-search constants: registers of the leader lane (R == 1), or parked in the contact's cone
+		// block Hc (free once H is built) when a lane owns several rows and registers are scarce
+		ConeLine cl1 = ConeLine{ 0, 0, 0, 0, 0, 0, 0, 0, 1, 0 };
 #pragma unroll
 		for (int i = 0; i < R; i++) {
-			cl[i] = ConeLine{ 0, 0, 0, 0, 0, 0, 0, 0, 1, 0 };
 			if (leader[i]) {
+				ConeLine c = ConeLine{ 0, 0, 0, 0, 0, 0, 0, 0, 1, 0 };
 				const double mu = cmu[i];
 				const double *cfri = f + L.contact_friction + 5 * rcon[i];
-				cl[i].mu = mu;
-				cl[i].N0 = mu * jaref[i];
-				cl[i].N1 = mu * jv[i];
-				cl[i].Dm = D[i] / (mu * mu * (1 + mu * mu));
+				c.mu = mu;
+				c.N0 = mu * jaref[i];
+				c.N1 = mu * jv[i];
+				c.Dm = D[i] / (mu * mu * (1 + mu * mu));
 				for (int j = 0; j < 6; j++) {
 					if (j >= cdim[i]) break;
 					const double xj = jar_s[rr[i] + j], vj = jv_s[rr[i] + j], Dj = f[L.efc_D + rr[i] + j];
-					cl[i].q0b += 0.5 * Dj * xj * xj;
-					cl[i].q1b += Dj * xj * vj;
-					cl[i].q2b += 0.5 * Dj * vj * vj;
+					c.q0b += 0.5 * Dj * xj * xj;
+					c.q1b += Dj * xj * vj;
+					c.q2b += 0.5 * Dj * vj * vj;
 					if (j > 0) {
 						const double U = cfri[j - 1] * xj, V = cfri[j - 1] * vj;
-						cl[i].TT += U * U;
-						cl[i].UV += U * V;
-						cl[i].VV += V * V;
+						c.TT += U * U;
+						c.UV += U * V;
+						c.VV += V * V;
 					}
+				}
+				if constexpr (R == 1) {
+					cl1 = c;
+				} else {
+					double *o = Hc + 36 * rcon[i];
+					o[0] = c.N0; o[1] = c.N1; o[2] = c.TT; o[3] = c.UV; o[4] = c.VV;
+					o[5] = c.q0b; o[6] = c.q1b; o[7] = c.q2b; o[8] = c.mu; o[9] = c.Dm;
 				}
 			}
 		}
@@ -1127,7 +1256,19 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 			const double a = p.alpha;
 			double c0 = 0, c1 = 0, c2 = 0;
 #pragma unroll
-			for (int i = 0; i < R; i++) ls_row(a, scalar_row[i], leader[i], jaref[i], jv[i], D[i], cl[i], c0, c1, c2);
+			for (int i = 0; i < R; i++) {
+				if (64 * i >= nefc) continue;
+				if constexpr (R == 1) {
+					ls_row(a, scalar_row[i], leader[i], jaref[i], jv[i], D[i], cl1, c0, c1, c2);
+				} else {
+					ConeLine c = cl1;
+					if (leader[i]) {
+						const double *o = Hc + 36 * rcon[i];
+						c = ConeLine{ o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9] };
+					}
+					ls_row(a, scalar_row[i], leader[i], jaref[i], jv[i], D[i], c, c0, c1, c2);
+				}
+			}
 			const double s0 = wave_sum(c0), s1 = wave_sum(c1), s2 = wave_sum(c2);
 			p.cost = a * a * g2 + a * g1 + g0 + s0;
 			p.d0 = 2 * a * g2 + g1 + s1;
@@ -1198,6 +1339,7 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 			}
 		}
 #undef LS_EVAL
+		EPROF(29);
 		if (alpha == 0) break;
 		if (dofact) qa[k] += alpha * sk;
 		iter++;

@@ -50,9 +50,19 @@ template <int G> DEVI void gsync()
 		if (e.env == 0 && e.lane == 0 && s.prof) { s.prof[id] += _t1 - _t0; s.prof[32 + id] += 1; } \
 		_t0 = __builtin_readcyclecounter();                                           \
 	} while (0)
+// sub-stage accounting inside stages that do not see DevState (the solvers): through Env::prof
+#define EPROF_BEGIN() unsigned long long _et0 = __builtin_readcyclecounter()
+#define EPROF(id)                                                                     \
+	do {                                                                              \
+		unsigned long long _et1 = __builtin_readcyclecounter();                       \
+		if (e.env == 0 && e.lane == 0 && e.prof) { e.prof[id] += _et1 - _et0; e.prof[32 + id] += 1; } \
+		_et0 = __builtin_readcyclecounter();                                          \
+	} while (0)
 #else
 #define PROF_BEGIN() do { } while (0)
 #define PROF(id) do { } while (0)
+#define EPROF_BEGIN() do { } while (0)
+#define EPROF(id) do { } while (0)
 #endif
 
 struct Env {
@@ -60,6 +70,9 @@ struct Env {
 	int *fi;    // LDS frame (ints)
 	int lane;   // 0..G-1
 	int env;    // batch-local env index
+#ifdef MJB_PROFILE
+	unsigned long long *prof;
+#endif
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1183,6 +1196,9 @@ __global__ void __launch_bounds__(256, (CON ? 2 : (G == 64 ? 4 : (G == 32 ? 2 : 
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int slot = threadIdx.x / G;
 	Env e;
+#ifdef MJB_PROFILE
+	e.prof = s.prof;
+#endif
 	e.lane = threadIdx.x % G;
 	e.f = reinterpret_cast<double *>(smem + (size_t)slot * frame_bytes);
 	e.fi = reinterpret_cast<int *>(e.f + L.ndouble);

@@ -99,6 +99,12 @@ class Batch:
     def set_launch(self, lanes_per_env=0, envs_per_block=0):
         _check(self.lib.mjb_set_launch(self.ptr, lanes_per_env, envs_per_block), "mjb_set_launch")
 
+    def warning_count(self):
+        """Number of auto-resets (mj_checkPos / Vel / Acc warnings) since the batch was made."""
+        n = C.c_uint64(0)
+        _check(self.lib.mjb_warning_count(self.ptr, C.byref(n)), "mjb_warning_count")
+        return int(n.value)
+
     def set_keep_frame(self, on=True):
         """Fused step() also leaves the derived fields of its last step readable through get()."""
         _check(self.lib.mjb_set_keep_frame(self.ptr, 1 if on else 0), "mjb_set_keep_frame")

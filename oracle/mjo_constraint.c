@@ -209,6 +209,95 @@ static int sphere_box(rawcon *c, const double *pos1, double r1, const double *po
 	return 1;
 }
 
+/* capsule - box.  MuJoCo's own routine (engine_collision_box.c, mjc_CapsuleBox) is not available in this
+ * environment; this is a geometric restatement of its contract (at most two contacts, each one the sphere-box
+ * contact of a point of the capsule axis) built on the convex function g(t) = dist(axis point t, box)^2:
+ *   1. [tlo, thi] = the minimiser set of g on [-h, h], found by bisection on the monotone slope g'(t);
+ *   2. the closest feature at its midpoint decides the candidate axis points: a FACE -> the two ends of the axis
+ *      stretch lying over that face (a capsule resting flat or tilted on a face gets both ends, each with its own
+ *      depth); axis INSIDE the box -> the ends of the inside stretch; an EDGE / VERTEX -> the ends of the
+ *      minimiser set (one point unless the axis is parallel to the edge);
+ *   3. each candidate goes through sphere_box(); candidates closer than 1e-6 h collapse into one.
+ * The HIP narrow phase (mjb_constraint.h, capsule_box) follows the same steps operation for operation. */
+static double capbox_slope(const double *p0, const double *d, const double *s, double t)
+{
+	double g = 0;
+	for (int i = 0; i < 3; i++) {
+		double p = p0[i] + t * d[i];
+		g += (p - clipd(p, -s[i], s[i])) * d[i];
+	}
+	return g;
+}
+
+static int capsule_box(rawcon *c, const double *pos1, const double *mat1, const double *size1, const double *pos2,
+                       const double *mat2, const double *size2, double margin)
+{
+	const double r = size1[0], h = size1[1];
+	double axis[3] = { mat1[2], mat1[5], mat1[8] }, tmp[3], p0[3], d[3];
+	v3_sub(tmp, pos1, pos2);
+	m3_mulvecT(p0, mat2, tmp);
+	m3_mulvecT(d, mat2, axis);
+	const double glo = capbox_slope(p0, d, size2, -h), ghi = capbox_slope(p0, d, size2, h);
+	double tlo, thi;
+	if (glo >= 0) tlo = -h;
+	else if (ghi < 0) tlo = h;
+	else {
+		double lo = -h, hi = h;
+		for (int it = 0; it < 60; it++) {
+			double mid = 0.5 * (lo + hi);
+			if (capbox_slope(p0, d, size2, mid) >= 0) hi = mid;
+			else lo = mid;
+		}
+		tlo = hi;
+	}
+	if (ghi <= 0) thi = h;
+	else if (glo > 0) thi = -h;
+	else {
+		double lo = -h, hi = h;
+		for (int it = 0; it < 60; it++) {
+			double mid = 0.5 * (lo + hi);
+			if (capbox_slope(p0, d, size2, mid) > 0) hi = mid;
+			else lo = mid;
+		}
+		thi = lo;
+	}
+	if (thi < tlo) thi = tlo;
+	const double ts = 0.5 * (tlo + thi);
+	int nout = 0, face = 0;
+	for (int i = 0; i < 3; i++)
+		if (fabs(p0[i] + ts * d[i]) > size2[i]) {
+			nout++;
+			face = i;
+		}
+	double ta = tlo, tb = thi;
+	if (nout <= 1) {
+		ta = -h;
+		tb = h;
+		for (int j = 0; j < 3; j++) {
+			if (nout == 1 && j == face) continue;
+			if (fabs(d[j]) <= MJO_MINVAL) continue;
+			double t1 = (-size2[j] - p0[j]) / d[j], t2 = (size2[j] - p0[j]) / d[j];
+			if (t1 > t2) {
+				double sw = t1;
+				t1 = t2;
+				t2 = sw;
+			}
+			if (t1 > ta) ta = t1;
+			if (t2 < tb) tb = t2;
+		}
+		if (ta > tb) ta = tb = ts;
+	}
+	int n = 0;
+	double ctr[3];
+	for (int k = 0; k < 3; k++) ctr[k] = pos1[k] + axis[k] * ta;
+	n += sphere_box(c + n, ctr, r, pos2, mat2, size2, margin);
+	if (tb - ta > 1e-6 * h) {
+		for (int k = 0; k < 3; k++) ctr[k] = pos1[k] + axis[k] * tb;
+		n += sphere_box(c + n, ctr, r, pos2, mat2, size2, margin);
+	}
+	return n;
+}
+
 /* mj_contactParam: mix the two geoms' contact parameters */
 static void contact_param(const mjb_model_desc *m, int g1, int g2, int *condim, double *solref, double *solimp,
                           double *friction)
@@ -273,6 +362,7 @@ void mjo_collision(const mjb_model_desc *m, mjo_data *d)
 		else if (t1 == MJB_GEOM_SPHERE && t2 == MJB_GEOM_CAPSULE) n = sphere_capsule(rc, pos1, size1[0], pos2, mat2, size2, margin);
 		else if (t1 == MJB_GEOM_SPHERE && t2 == MJB_GEOM_BOX) n = sphere_box(rc, pos1, size1[0], pos2, mat2, size2, margin);
 		else if (t1 == MJB_GEOM_CAPSULE && t2 == MJB_GEOM_CAPSULE) n = capsule_capsule(rc, pos1, mat1, size1, pos2, mat2, size2, margin);
+		else if (t1 == MJB_GEOM_CAPSULE && t2 == MJB_GEOM_BOX) n = capsule_box(rc, pos1, mat1, size1, pos2, mat2, size2, margin);
 		if (n == 0) continue;
 		int condim;
 		double solref[2], solimp[5], fri[3];

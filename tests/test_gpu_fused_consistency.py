@@ -22,6 +22,7 @@ STATE = ["qpos", "qvel", "qacc", "qacc_warmstart", "sensordata", "ctrl", "time"]
 def _variants():
     out = [("franka_like", None, lanes) for lanes in (8, 16, 32, 64)]
     out += [("franka_table", s, 64) for s in ("PGS", "Newton", "Newton-elliptic")]
+    out += [("shadow_hand_like", "hand-128", 64), ("shadow_hand_like", "hand-160", 64)]
     return out
 
 
@@ -29,6 +30,8 @@ def _model(name, solver):
     from mujoco_ros_pkgs_amd import mjcf
     if solver in (None, "PGS"):
         return mjcf.load_asset(name)
+    if solver.startswith("hand-"):
+        return mjcf.load_asset(name, nefcmax=int(solver[5:]))
     over = {"solver": "Newton"}
     if solver == "Newton-elliptic":
         over["cone"] = "elliptic"
@@ -38,6 +41,9 @@ def _model(name, solver):
 def _initial(model, name, nenv):
     if name == "franka_like":
         return random_franka_state(model, nenv, seed=11)
+    if name == "shadow_hand_like":
+        from mujoco_ros_pkgs_amd import workloads
+        return workloads.hand_grasp_states(model, nenv, seed=5)
     from test_gpu_contact import scenario_states
     return scenario_states(model, nenv, seed=5)
 
@@ -58,7 +64,7 @@ def test_fused_steps_equal_single_steps(name, solver, lanes, keep):
         b.set_keep_frame(keep)
         b.set("qpos", qpos)
         b.set("qvel", qvel)
-        b.set_ctrl_noise(2.0, 0.1, 77, 0)
+        b.set_ctrl_noise(0.1 if name == "shadow_hand_like" else 2.0, 0.1, 77, 0)
         for k in plan:
             b.step(k)
         res.append({f: b.get(f).copy() for f in STATE})

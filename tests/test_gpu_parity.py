@@ -208,7 +208,7 @@ def pendulum_setup(oracle_built):
                       '<joint name="balljoint" type="ball" pos="0 0 1" stiffness="3.0" damping="0.2"/>')
     xml = xml.replace('<joint name="joint1" type="hinge" pos="0 0 0.6" axis="0 1 0"/>',
                       '<joint name="joint1" type="hinge" pos="0 0 0.6" axis="0 1 0" stiffness="1.5" springref="0.3"/>')
-    model = mjcf.compile_xml_string(xml, skip_unsupported_pairs=True)
+    model = mjcf.compile_xml_string(xml)
     return model, engine.CompiledModel(model), engine, oracle_built
 
 

@@ -45,7 +45,7 @@ def pendulum():
     # the reference's world as shipped (contacts on, elliptic cones, Newton solver); one documented deviation:
     # the capsule-box pairs (pendulum links vs the static box, never in contact in these tests) are skipped
     # because that narrow phase is not implemented
-    return mjcf.compile_xml_file(os.path.join(GOLDEN, "pendulum_world.xml"), skip_unsupported_pairs=True)
+    return mjcf.compile_xml_file(os.path.join(GOLDEN, "pendulum_world.xml"))
 
 
 def empty():

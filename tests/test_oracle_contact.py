@@ -234,7 +234,7 @@ def test_shipped_world_runs_as_shipped(oracle_built):
     normal force m g, pendulum stays exactly at rest (only the capsule-box pairs are skipped)."""
     import os
     golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    m = mjcf.compile_xml_file(os.path.join(golden, "pendulum_world.xml"), skip_unsupported_pairs=True)
+    m = mjcf.compile_xml_file(os.path.join(golden, "pendulum_world.xml"))
     assert m["cone"] == 1 and m["solver"] == 2
     d = oracle_built.OracleData(m)
     for _ in range(600):
@@ -242,3 +242,72 @@ def test_shipped_world_runs_as_shipped(oracle_built):
     assert d.nefc[0] == 3 and list(d.efc_type[:3]) == [7, 7, 7]
     assert abs(d.efc_force[0] - 0.1 * 9.81) < 1e-6 and abs(d.qvel).max() < 1e-9
     assert np.all(d.qvel[:5] == 0)
+
+
+CAPBOX = """
+<mujoco><compiler angle="radian"/>
+<option timestep="0.001" cone="elliptic" solver="Newton" tolerance="1e-10"/>
+<worldbody>
+  <body name="slab" pos="0 0 0"><geom name="slab" type="box" size="{bx} {by} 0.05"/></body>
+  <body name="cap" pos="{pos}" {rot}><freejoint/><geom name="cap" type="capsule" size="0.02 {half}" mass="0.2"/></body>
+</worldbody></mujoco>
+"""
+
+
+def _capbox(pos, rot="", half=0.1, bx=0.5, by=0.5):
+    return mjcf.compile_xml_string(CAPBOX.format(pos=pos, rot=rot, half=half, bx=bx, by=by))
+
+
+def test_capsule_box_known_answers(oracle_built):
+    """capsule - box (oracle/mjo_constraint.c capsule_box; not MuJoCo's own routine, see there): geometry-defined
+    answers.  Box top face at z = 0.05, capsule radius 0.02."""
+    lie = 'euler="0 1.5707963267948966 0"'   # capsule axis along x
+    # flat on the face, 1 mm deep: both ends, same answer as capsule on a plane
+    d = oracle_built.OracleData(_capbox("0 0 0.069", lie))
+    d.forward()
+    n, dist, pos, frame = contacts(d)
+    assert n == 2 and np.allclose(dist, -0.001, atol=1e-12)
+    np.testing.assert_allclose(sorted(pos[:, 0]), [-0.1, 0.1], atol=1e-9)
+    np.testing.assert_allclose(pos[:, 2], 0.05 - 0.0005, atol=1e-12)          # midway between the two surfaces
+    np.testing.assert_allclose(frame[:, :3], [[0, 0, -1]] * 2, atol=1e-12)    # from the capsule (geom 1) to the box
+    # capsule longer than the box: the contacts sit where the axis leaves the face
+    d = oracle_built.OracleData(_capbox("0 0 0.069", lie, half=0.3, bx=0.15))
+    d.forward()
+    n, dist, pos, frame = contacts(d)
+    assert n == 2 and np.allclose(dist, -0.001, atol=1e-12)
+    np.testing.assert_allclose(sorted(pos[:, 0]), [-0.15, 0.15], atol=1e-9)
+    # standing on the face: one contact under the lower cap
+    d = oracle_built.OracleData(_capbox("0.1 -0.2 0.1695"))
+    d.forward()
+    n, dist, pos, frame = contacts(d)
+    assert n == 1 and abs(dist[0] + 0.0005) < 1e-12
+    np.testing.assert_allclose(pos[0], [0.1, -0.2, 0.05 - 0.00025], atol=1e-12)
+    # tilted by 0.01 rad about y: both ends, the lower one deeper by 2 h sin(0.01)
+    a = np.pi / 2 + 0.01
+    d = oracle_built.OracleData(_capbox("0 0 0.069", f'euler="0 {a} 0"'))
+    d.forward()
+    n, dist, pos, frame = contacts(d)
+    assert n == 2
+    assert abs(abs(dist[0] - dist[1]) - 0.2 * np.sin(0.01)) < 1e-9 and abs(dist.mean() + 0.001) < 1e-9
+    # across an edge of the box, axis along y, centred above the edge x = 0.5 at 45 degrees: one contact, diagonal normal
+    s = 0.018 / np.sqrt(2)
+    d = oracle_built.OracleData(_capbox(f"{0.5 + s} 0 {0.05 + s}", 'euler="1.5707963267948966 0 0"'))
+    d.forward()
+    n, dist, pos, frame = contacts(d)
+    assert n >= 1 and np.allclose(dist[:n], -0.002, atol=1e-9)
+    np.testing.assert_allclose(frame[0][:3], [-np.sqrt(0.5), 0, -np.sqrt(0.5)], atol=1e-9)
+    # out of reach
+    d = oracle_built.OracleData(_capbox("0 0 0.08", lie))
+    d.forward()
+    assert d.ncon[0] == 0
+
+
+def test_capsule_rests_on_box(oracle_built):
+    """A capsule dropped flat on a box comes to rest on it and carries its weight (two contacts sharing m g)."""
+    m = _capbox("0 0 0.0705", 'euler="0 1.5707963267948966 0"')
+    d = oracle_built.OracleData(m)
+    d.step(600)
+    assert d.ncon[0] == 2
+    assert abs(d.qpos[2] - 0.07) < 2e-3 and np.abs(d.qvel).max() < 1e-3
+    fn = [d.efc_force[d.contact_efc_address[c]] for c in range(2)]
+    assert abs(sum(fn) - 0.2 * 9.81) < 0.02 * 0.2 * 9.81 and min(fn) > 0.3 * 0.2 * 9.81

@@ -139,9 +139,9 @@ def test_energy_and_momentum_free_body(oracle_built):
 def test_pendulum_world_equilibrium_stays_at_rest(oracle_built):
     """Reference fact (7): a pendulum released at its stable equilibrium stays EXACTLY at rest
     (mujoco_sensors_test.cpp:389-391: ground-truth variance == 0 over 1001 steps)."""
-    m = mjcf.compile_xml_file(os.path.join(GOLDEN, "pendulum_world.xml"), skip_unsupported_pairs=True)
+    m = mjcf.compile_xml_file(os.path.join(GOLDEN, "pendulum_world.xml"))
     assert (m["nq"], m["nv"], m["nbody"]) == (13, 11, 6)  # SURVEY.md §8 model table, config 1
-    assert m["solver"] == 2 and len(m["skipped_collision_pairs"]) == 3  # Newton as shipped; capsule-box pairs skipped
+    assert m["solver"] == 2 and len(m.get("skipped_collision_pairs", [])) == 0  # Newton as shipped, every geom pair handled
     d = oracle_built.OracleData(m)
     q0 = d.qpos.copy()
     for _ in range(1001):

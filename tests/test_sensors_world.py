@@ -14,7 +14,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def world():
-    return mjcf.compile_xml_file(os.path.join(GOLDEN, "sensors_world.xml"), skip_unsupported_pairs=True)
+    return mjcf.compile_xml_file(os.path.join(GOLDEN, "sensors_world.xml"))
 
 
 def expected_static(m):

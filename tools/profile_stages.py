@@ -14,10 +14,11 @@ from mujoco_ros_pkgs_amd import binding  # noqa: E402
 
 STAGES = ["kinematics", "com_pos", "crb", "factorM", "transm+sens_pos", "com_vel", "passive", "rne(+aref)", "sens_vel",
           "actuation", "acceleration", "constraint(PGS)", "sens_acc", "ctrl_noise", "forward(total)", "euler",
-          "collision", "make_constraint", "project(B)", "-", "kin.A local poses", "kin.B chain", "kin.C normalise+inertial", "kin.D joints/geoms/sites"]
+          "collision", "make_constraint", "project(B)", "-", "kin.A local poses", "kin.B chain", "kin.C normalise+inertial", "kin.D joints/geoms/sites",
+          "nwt.setup (M, rows)", "nwt.warmstart", "nwt.grad+update /iter", "nwt.H (MFMA) /iter", "nwt.solve /iter", "nwt.linesearch /iter", "nwt.(loop overhead)", "nwt.chol /iter"]
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--lanes", type=int, default=16)
+ap.add_argument("--lanes", type=int, default=0)
 ap.add_argument("--epb", type=int, default=0)
 ap.add_argument("--envs", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=200)
@@ -36,11 +37,12 @@ cm = engine.CompiledModel(model)
 b = engine.Batch(cm, a.envs)
 b.set_launch(a.lanes, a.epb)
 rng = np.random.default_rng(0)
-from bench import synthetic_state  # noqa: E402
-qp, qv = synthetic_state(model, a.envs, 1000)
+from bench import WORKLOADS, initial_state  # noqa: E402
+qp, qv = initial_state(a.model, model, a.envs, 1000)
 b.set("qpos", qp)
 b.set("qvel", qv)
-b.set_ctrl_noise(43.5, 0.1, 12345, 0)
+b.set_ctrl_noise(WORKLOADS.get(a.model, ("", 1.0, 0))[1], 0.1, 12345, 0)
+print("frame bytes:", 8 * b.lib.mjb_frame_doubles(cm.ptr) if hasattr(b.lib, "mjb_frame_doubles") else "?")
 b.step(a.steps)
 b.synchronize()
 out = (C.c_uint64 * 64)()
