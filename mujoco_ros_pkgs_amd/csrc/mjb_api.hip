@@ -208,7 +208,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	L.ndouble = off;
 	L.iscratch = ioff;
 	{
-		int a = d.ncollpair, b = d.njnt + d.nconmax;
+		int a = d.ncollpair, b = d.neq + d.njnt + d.nconmax;
 		ioff += a > b ? a : b;
 	}
 	L.nint = (ioff + 1) & ~1;
@@ -316,6 +316,20 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 	}
 	if (!(d.timestep[0] > 0)) {
 		fail(MJB_EINVAL, "mjb_compile: timestep must be positive");
+		return nullptr;
+	}
+	for (int i = 0; i < d.neq; i++) {
+		const int t = d.eq_type[i], a = d.eq_obj1id[i], b = d.eq_obj2id[i];
+		const bool body_ok = a >= 0 && a < d.nbody && b >= 0 && b < d.nbody;
+		const bool jnt_ok = a >= 0 && a < d.njnt && b >= -1 && b < d.njnt;
+		if (!((t == MJB_EQ_CONNECT || t == MJB_EQ_WELD) ? body_ok : (t == MJB_EQ_JOINT && jnt_ok))) {
+			fail(MJB_EUNSUPPORTED, "mjb_compile: equality %d: type %d with objects (%d, %d) is not supported "
+			                       "(connect / weld between bodies, joint between hinge / slide joints)", i, t, a, b);
+			return nullptr;
+		}
+	}
+	if (d.neq > 0 && d.nefcmax <= 0) {
+		fail(MJB_EINVAL, "mjb_compile: equality constraints need nefcmax > 0");
 		return nullptr;
 	}
 	if (d.nefcmax > 0 || d.nconmax > 0) {

@@ -459,14 +459,22 @@ DEVI void impedance(const double *solimp, double pos, double margin, double &imp
 }
 
 // R and KBIP of one row (mj_makeImpedance)
+DEVI void row_params_x(CModel m, CLayout L, double *f, int i, double pos, double margin, const double *solref_in,
+                       const double *solimp, double diag_approx, double imp_pos);
 DEVI void row_params(CModel m, CLayout L, double *f, int i, double pos, double margin, const double *solref_in,
                      const double *solimp, double diag_approx)
+{
+	row_params_x(m, L, f, i, pos, margin, solref_in, solimp, diag_approx, pos);
+}
+// imp_pos: the position the impedance is evaluated at (rows of a connect / weld share the norm of their residual)
+DEVI void row_params_x(CModel m, CLayout L, double *f, int i, double pos, double margin, const double *solref_in,
+                       const double *solimp, double diag_approx, double imp_pos)
 {
 	double sr0 = solref_in[0];
 	const double sr1 = solref_in[1];
 	if (!(m.disableflags & MJB_DSBL_REFSAFE) && sr0 > 0) sr0 = fmax(sr0, 2 * m.timestep[0]);
 	double imp, impP;
-	impedance(solimp, pos, margin, imp, impP);
+	impedance(solimp, imp_pos, margin, imp, impP);
 	f[L.efc_R + i] = fmax(MJB_MINVAL, (1 - imp) * diag_approx / imp);
 	const double dmax = solimp[1];
 	double K, B;
@@ -492,8 +500,41 @@ DEVI bool dof_moves_body(CModel m, int b, int i)
 	return (w >> (i & 31)) & 1u;
 }
 
+// connect / weld geometry shared by the row and the Jacobian passes (oracle/mjo_constraint.c make_equality):
+// world anchor points of both bodies, and for a weld quat = q1 * relpose, quat1 = neg(q2)
+struct EqGeom {
+	double pos0[3], pos1[3], quat[4], quat1[4];
+};
+DEVI void eq_geometry(CModel m, CLayout L, const double *f, int e, EqGeom &g)
+{
+	const int type = m.eq_type[e], id0 = m.eq_obj1id[e], id1 = m.eq_obj2id[e];
+	double a0[3], a1[3], M0[9], M1[9];
+	for (int k = 0; k < 3; k++) {
+		a0[k] = m.eq_data[11 * e + (type == MJB_EQ_CONNECT ? 0 : 3) + k];
+		a1[k] = m.eq_data[11 * e + (type == MJB_EQ_CONNECT ? 3 : 0) + k];
+	}
+	ld9(M0, f + L.xmat + 9 * id0);
+	ld9(M1, f + L.xmat + 9 * id1);
+	matvec3(g.pos0, M0, a0);
+	matvec3(g.pos1, M1, a1);
+	for (int k = 0; k < 3; k++) {
+		g.pos0[k] += f[L.xpos + 3 * id0 + k];
+		g.pos1[k] += f[L.xpos + 3 * id1 + k];
+	}
+	if (type == MJB_EQ_WELD) {
+		double q0[4], rel[4];
+		for (int k = 0; k < 4; k++) {
+			q0[k] = f[L.xquat + 4 * id0 + k];
+			rel[k] = m.eq_data[11 * e + 6 + k];
+		}
+		qmul(g.quat, q0, rel);
+		g.quat1[0] = f[L.xquat + 4 * id1];
+		for (int k = 1; k < 4; k++) g.quat1[k] = -f[L.xquat + 4 * id1 + k];
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
-// A6  make_constraint: rows for joint limits then contacts (frictionless / pyramidal)
+// A6  make_constraint: rows for equalities (connect / weld / joint), joint limits, then contacts
 // ------------------------------------------------------------------------------------------------
 template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 {
@@ -507,20 +548,23 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 	}
 	const int ncon = fi[L.ncon];
 	const bool do_lim = !(m.disableflags & MJB_DSBL_LIMIT), do_con = !(m.disableflags & MJB_DSBL_CONTACT);
-	const int nitem = m.njnt + ncon;   // item = joint (limit rows) or contact
-	int *cnt = fi + L.iscratch;        // transient per-item row counts
+	const int neq = (m.disableflags & MJB_DSBL_EQUALITY) ? 0 : m.neq;
+	const int nitem = neq + m.njnt + ncon;   // item = equality, joint (limit rows) or contact -- MuJoCo's row order
+	int *cnt = fi + L.iscratch;              // transient per-item row counts
 	// pass 1: rows per item
 	for (int it = lane; it < nitem; it += G) {
 		int n = 0;
-		if (it < m.njnt) {
-			const int j = it;
+		if (it < neq) {
+			if (m.eq_active[it]) n = m.eq_type[it] == MJB_EQ_CONNECT ? 3 : (m.eq_type[it] == MJB_EQ_WELD ? 6 : 1);
+		} else if (it < neq + m.njnt) {
+			const int j = it - neq;
 			if (do_lim && m.jnt_limited[j] && m.jnt_type[j] >= MJB_JNT_SLIDE) {
 				const double value = f[L.qpos + m.jnt_qposadr[j]], margin = m.jnt_margin[j];
 				if (value - m.jnt_range[2 * j] < margin) n++;
 				if (m.jnt_range[2 * j + 1] - value < margin) n++;
 			}
 		} else if (do_con) {
-			const int c = it - m.njnt;
+			const int c = it - neq - m.njnt;
 			if (f[L.contact_dist + c] < f[L.contact_includemargin + c]) {
 				const int dim = fi[L.contact_dim + c];
 				n = dim == 1 ? 1 : (m.cone == MJB_CONE_ELLIPTIC ? dim : 2 * (dim - 1));
@@ -547,8 +591,57 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 		for (int q = 0; q < it; q++) off += cnt[q];
 		const int n = cnt[it];
 		if (n == 0) continue;
-		if (it < m.njnt) {
-			const int j = it, da = m.jnt_dofadr[j];
+		if (it < neq) {
+			const int eq = it, type = m.eq_type[eq], id0 = m.eq_obj1id[eq], id1 = m.eq_obj2id[eq];
+			double cpos[6] = { 0, 0, 0, 0, 0, 0 }, diag[6] = { 0, 0, 0, 0, 0, 0 };
+			if (type == MJB_EQ_JOINT) {
+				const int a1 = m.jnt_qposadr[id0], d1 = m.jnt_dofadr[id0];
+				const double *pc = nullptr;
+				double c5[5];
+				for (int k = 0; k < 5; k++) c5[k] = m.eq_data[11 * eq + k];
+				(void)pc;
+				double poly = c5[0], deriv = 0;
+				double *row = f + L.efc_J + off * nv;
+				for (int k = 0; k < nv; k++) row[k] = 0;
+				diag[0] = m.dof_invweight0[d1];
+				if (id1 >= 0) {
+					const int a2 = m.jnt_qposadr[id1], d2 = m.jnt_dofadr[id1];
+					const double x = f[L.qpos + a2] - m.qpos0[a2];
+					poly = c5[0] + x * (c5[1] + x * (c5[2] + x * (c5[3] + x * c5[4])));
+					deriv = c5[1] + x * (2 * c5[2] + x * (3 * c5[3] + x * 4 * c5[4]));
+					row[d2] = -deriv;
+					diag[0] += m.dof_invweight0[d2];
+				}
+				row[d1] += 1;
+				cpos[0] = f[L.qpos + a1] - m.qpos0[a1] - poly;
+			} else {
+				EqGeom g;
+				eq_geometry(m, L, f, eq, g);
+				for (int k = 0; k < 3; k++) cpos[k] = g.pos0[k] - g.pos1[k];
+				const double tran = m.body_invweight0[2 * id0] + m.body_invweight0[2 * id1];
+				diag[0] = diag[1] = diag[2] = tran;
+				if (type == MJB_EQ_WELD) {
+					const double ts = m.eq_data[11 * eq + 10];
+					double q2[4];
+					qmul(q2, g.quat1, g.quat);
+					for (int k = 0; k < 3; k++) cpos[3 + k] = ts * q2[1 + k];
+					diag[3] = diag[4] = diag[5] = m.body_invweight0[2 * id0 + 1] + m.body_invweight0[2 * id1 + 1];
+				}
+			}
+			double nrm = 0;
+			for (int k = 0; k < 6; k++) nrm += cpos[k] * cpos[k];
+			nrm = sqrt(nrm);
+			const double solref[2] = { m.eq_solref[2 * eq], m.eq_solref[2 * eq + 1] };
+			double solimp[5];
+			for (int k = 0; k < 5; k++) solimp[k] = m.eq_solimp[5 * eq + k];
+			for (int k = 0; k < 6; k++) {
+				if (k >= n) break;
+				row_params_x(m, L, f, off + k, cpos[k], 0.0, solref, solimp, diag[k], n > 1 ? nrm : cpos[0]);
+				fi[L.efc_id + off + k] = eq;
+				fi[L.efc_type + off + k] = MJB_CNSTR_EQUALITY;
+			}
+		} else if (it < neq + m.njnt) {
+			const int j = it - neq, da = m.jnt_dofadr[j];
 			const double value = f[L.qpos + m.jnt_qposadr[j]], margin = m.jnt_margin[j];
 			double solref[2] = { m.jnt_solref[2 * j], m.jnt_solref[2 * j + 1] }, solimp[5];
 			for (int k = 0; k < 5; k++) solimp[k] = m.jnt_solimp[5 * j + k];
@@ -566,7 +659,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 				}
 			}
 		} else {
-			const int c = it - m.njnt;
+			const int c = it - neq - m.njnt;
 			const int dim = fi[L.contact_dim + c];
 			const double dist = f[L.contact_dist + c], cm = f[L.contact_includemargin + c];
 			const int b1 = m.geom_bodyid[fi[L.contact_geom + 2 * c]], b2 = m.geom_bodyid[fi[L.contact_geom + 2 * c + 1]];
@@ -616,6 +709,47 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 	}
 	if (lane == 0) fi[L.nefc] = nefc;
 	gsync<G>();
+	// connect / weld Jacobian columns: one (equality, dof) pair per lane.  J = body1 - body2 (points differ, so a
+	// dof moving both bodies does not cancel); weld rotation rows 0.5 ts imag(neg(q2) (0, w1 - w2) q1 relpose)
+	for (int t = lane; t < neq * nv; t += G) {
+		const int eq = t / nv, i = t - eq * nv;
+		const int type = m.eq_type[eq];
+		if (eq >= cut || cnt[eq] == 0 || type == MJB_EQ_JOINT) continue;
+		int adr = 0;
+		for (int q = 0; q < eq; q++) adr += cnt[q];
+		const int id0 = m.eq_obj1id[eq], id1 = m.eq_obj2id[eq];
+		const bool in0 = dof_moves_body(m, id0, i), in1 = dof_moves_body(m, id1, i);
+		double jp[3] = { 0, 0, 0 }, jr[3] = { 0, 0, 0 };
+		EqGeom g;
+		eq_geometry(m, L, f, eq, g);
+		if (in0 || in1) {
+			double cd[6], root[3];
+			ld6(cd, f + L.cdof + 6 * i);
+			ld3(root, f + L.subtree_com + 3 * m.body_rootid[m.dof_bodyid[i]]);
+			if (in0) {
+				const double off3[3] = { g.pos0[0] - root[0], g.pos0[1] - root[1], g.pos0[2] - root[2] };
+				double c3[3];
+				cross3(c3, cd, off3);
+				for (int k = 0; k < 3; k++) { jp[k] += c3[k] + cd[3 + k]; jr[k] += cd[k]; }
+			}
+			if (in1) {
+				const double off3[3] = { g.pos1[0] - root[0], g.pos1[1] - root[1], g.pos1[2] - root[2] };
+				double c3[3];
+				cross3(c3, cd, off3);
+				for (int k = 0; k < 3; k++) { jp[k] -= c3[k] + cd[3 + k]; jr[k] -= cd[k]; }
+			}
+		}
+		for (int k = 0; k < 3; k++) f[L.efc_J + (adr + k) * nv + i] = jp[k];
+		if (type == MJB_EQ_WELD) {
+			const double ts = m.eq_data[11 * eq + 10];
+			const double *q = g.quat1;
+			const double qa[4] = { -q[1] * jr[0] - q[2] * jr[1] - q[3] * jr[2], q[0] * jr[0] + q[2] * jr[2] - q[3] * jr[1],
+				                   q[0] * jr[1] + q[3] * jr[0] - q[1] * jr[2], q[0] * jr[2] + q[1] * jr[1] - q[2] * jr[0] };
+			double q3[4];
+			qmul(q3, qa, g.quat);
+			for (int k = 0; k < 3; k++) f[L.efc_J + (adr + 3 + k) * nv + i] = 0.5 * ts * q3[1 + k];
+		}
+	}
 	// contact Jacobian rows: one (contact, dof) pair per lane
 	const int npair = ncon * nv;
 	for (int t = lane; t < npair; t += G) {
@@ -755,6 +889,7 @@ template <int G> STAGE void fwd_constraint_pgs(CModel m, CLayout L, const Env &e
 	const bool rowact = lane < nefc;
 	const int r = rowact ? lane : 0;
 	const double *Jr = f + L.efc_J + r * nv, *Br = f + L.efc_B + r * nv;
+	const bool bilateral = rowact && fi[L.efc_type + r] == MJB_CNSTR_EQUALITY;
 	// per-row scalars in the row's lane
 	double b = 0, R = 1, ARinv = 0, Aii = 1, frc = 0;
 	{
@@ -772,7 +907,7 @@ template <int G> STAGE void fwd_constraint_pgs(CModel m, CLayout L, const Env &e
 		ARinv = 1.0 / Aii;
 		if (!(m.disableflags & MJB_DSBL_WARMSTART)) {
 			const double jar = jw - aref;
-			frc = jar < 0 ? -f[L.efc_D + r] * jar : 0.0;
+			frc = (jar < 0 || bilateral) ? -f[L.efc_D + r] * jar : 0.0;
 		}
 		if (!rowact) { b = 0; frc = 0; }
 		f[L.efc_b + r] = rowact ? b : f[L.efc_b + r];
@@ -815,7 +950,7 @@ template <int G> STAGE void fwd_constraint_pgs(CModel m, CLayout L, const Env &e
 			const double Ai = wave_bcast(ARinv, i), Aii_i = wave_bcast(Aii, i);
 			const double res = bi + part + Ri * fi_;
 			double fn = fi_ - res * Ai;
-			if (fn < 0) fn = 0;
+			if (fn < 0 && !(bool)__builtin_amdgcn_readlane((int)bilateral, i)) fn = 0;  // equality rows are two-sided
 			double delta = fn - fi_;
 			double change = 0.5 * delta * delta * Aii_i + delta * res;
 			if (change > 1e-10) {
@@ -866,12 +1001,12 @@ struct ConeLine {  // per-contact constants of the line search, held by the cont
 };
 
 // one lane's share of the line-search cost and its first two derivatives at step `a`
-DEVI void ls_row(double a, bool scalar_row, bool leader, double jaref, double jv, double D, const ConeLine &cl,
-                 double &c0, double &c1, double &c2)
+DEVI void ls_row(double a, bool scalar_row, bool bilateral, bool leader, double jaref, double jv, double D,
+                 const ConeLine &cl, double &c0, double &c1, double &c2)
 {
 	if (scalar_row) {
 		const double x = jaref + a * jv;
-		if (x < 0) {
+		if (x < 0 || bilateral) {
 			c0 += 0.5 * D * x * x;
 			c1 += D * x * jv;
 			c2 += D * jv * jv;
@@ -938,7 +1073,7 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 	gsync<G>();
 
 	// row kind: scalar (limit / frictionless / pyramidal), cone leader (first row of an elliptic contact), cone member
-	bool rowact[R], scalar_row[R], leader[R];
+	bool rowact[R], scalar_row[R], leader[R], bilat[R];
 	int rr[R], cdim[R], rcon[R];
 	double D[R], aref[R], cmu[R];
 #pragma unroll
@@ -950,6 +1085,7 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 		rcon[i] = rowact[i] ? fi[L.efc_id + r] : 0;
 		const bool is_cone = rowact[i] && rtype == MJB_CNSTR_CONTACT_ELLIPTIC;
 		scalar_row[i] = rowact[i] && !is_cone;
+		bilat[i] = rowact[i] && rtype == MJB_CNSTR_EQUALITY;
 		leader[i] = is_cone && fi[L.contact_efc_address + rcon[i]] == r;
 		cdim[i] = is_cone ? fi[L.contact_dim + rcon[i]] : 0;
 		D[i] = rowact[i] ? f[L.efc_D + r] : 0.0;
@@ -982,7 +1118,7 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 			if (64 * i >= nefc) continue;
 			if (scalar_row[i]) {
 				const double x = jar_s[r];
-				const bool act = x < 0;
+				const bool act = x < 0 || bilat[i];
 				f[L.efc_force + r] = act ? -D[i] * x : 0.0;
 				if (hess) hw[r] = act ? D[i] : 0.0;
 				cost += act ? 0.5 * D[i] * x * x : 0.0;
@@ -1259,14 +1395,14 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 			for (int i = 0; i < R; i++) {
 				if (64 * i >= nefc) continue;
 				if constexpr (R == 1) {
-					ls_row(a, scalar_row[i], leader[i], jaref[i], jv[i], D[i], cl1, c0, c1, c2);
+					ls_row(a, scalar_row[i], bilat[i], leader[i], jaref[i], jv[i], D[i], cl1, c0, c1, c2);
 				} else {
 					ConeLine c = cl1;
 					if (leader[i]) {
 						const double *o = Hc + 36 * rcon[i];
 						c = ConeLine{ o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9] };
 					}
-					ls_row(a, scalar_row[i], leader[i], jaref[i], jv[i], D[i], c, c0, c1, c2);
+					ls_row(a, scalar_row[i], bilat[i], leader[i], jaref[i], jv[i], D[i], c, c0, c1, c2);
 				}
 			}
 			const double s0 = wave_sum(c0), s1 = wave_sum(c1), s2 = wave_sum(c2);

@@ -191,6 +191,7 @@ class _Compiler:
         self.extra_disable = tuple(disable)
         self.override = dict(override or {})
         self.skip_unsupported_pairs = skip_unsupported_pairs
+        self.equalities = []
         self.skipped_pairs = []
         self.nconmax_req = nconmax
         self.nefcmax_req = nefcmax
@@ -270,6 +271,9 @@ class _Compiler:
             elif t == "sensor":
                 for s in node:
                     self._sensor(s)
+            elif t == "equality":
+                for c in node:
+                    self._equality(c)
             elif t == "contact":
                 for c in node:
                     if c.tag == "exclude":
@@ -469,6 +473,15 @@ class _Compiler:
         return s
 
     # ---- actuators / sensors
+    def _equality(self, node):
+        """<equality><connect|weld|joint>: stored raw; body / joint ids and eq_data are resolved in _finalize (they need
+        the kinematics at qpos0).  Tendon and distance equalities are not implemented."""
+        if node.tag not in ("connect", "weld", "joint"):
+            raise MjcfError(f"<equality><{node.tag}> is not supported (connect / weld / joint only)")
+        a = self.defaults.resolve("equality", node.get("class", "main"))
+        a.update(node.attrib)
+        self.equalities.append((node.tag, a))
+
     def _actuator(self, node):
         a = self._merged(node, None)
         t = node.tag
@@ -785,6 +798,9 @@ class _Compiler:
                  integrator=o["integrator"], cone=o["cone"], solver=o["solver"], iterations=o["iterations"],
                  disableflags=o["disableflags"])
 
+        # equality constraints (mjCEquality::Compile, [UPSTREAM] user_objects.cc): ids + eq_data at qpos0
+        self._compile_equalities(m)
+
         # static collision candidates (restates the body/geom filters of MuJoCo's mj_collision)
         pairs = self._collision_pairs(m)
         m["collpair_geom"] = np.array(pairs, I).reshape(len(pairs), 2)
@@ -808,7 +824,10 @@ class _Compiler:
         if pairs:
             maxdim = max(int(max(m["geom_condim"][g1], m["geom_condim"][g2])) for g1, g2 in pairs)
             rows_per_con = 1 if maxdim == 1 else (2 * (maxdim - 1) if o["cone"] == 0 else maxdim)
-        nefcmax = nlimit + rows_per_con * nconmax if self.nefcmax_req is None else int(self.nefcmax_req)
+        neqrow = 0
+        if not (o["disableflags"] & DISABLE_BITS["equality"]):
+            neqrow = int(sum({0: 3, 1: 6, 2: 1}[int(t)] for t in m["eq_type"]))
+        nefcmax = neqrow + nlimit + rows_per_con * nconmax if self.nefcmax_req is None else int(self.nefcmax_req)
         if o["disableflags"] & (DISABLE_BITS["constraint"]):
             nconmax, nefcmax = 0, 0
         m["nconmax"], m["nefcmax"] = int(nconmax), int(nefcmax)
@@ -820,6 +839,61 @@ class _Compiler:
         m["body_invweight0"] = body_inv
         m["meaninertia"] = np.array([meaninertia], D)
         return m
+
+    def _compile_equalities(self, m):
+        from . import refdyn
+        I, D = np.int32, np.float64
+        E = self.equalities
+        n = len(E)
+        eq_type, o1, o2, act = np.zeros(n, I), np.zeros(n, I), np.zeros(n, I), np.ones(n, I)
+        solref, solimp, data = np.zeros((n, 2)), np.zeros((n, 5)), np.zeros((n, 11))
+        names = []
+        kin = refdyn.kinematics(m, np.asarray(m["qpos0"], D)) if n else None
+        for i, (tag, a) in enumerate(E):
+            names.append(a.get("name", ""))
+            act[i] = 0 if a.get("active", "true") == "false" else 1
+            solref[i] = _floats(a.get("solref", "0.02 1"), 2, "equality solref")
+            solimp[i] = _solimp(a.get("solimp"))
+            if tag in ("connect", "weld"):
+                b1 = m.name2id("body", a.get("body1", ""))
+                b2 = m.name2id("body", a["body2"]) if "body2" in a else 0
+                if b1 < 0 or b2 < 0:
+                    raise MjcfError(f"equality '{names[-1]}': unknown body")
+                o1[i], o2[i] = b1, b2
+                x1, R1, q1 = kin["xpos"][b1], kin["xmat"][b1].reshape(3, 3), kin["xquat"][b1]
+                x2, R2, q2 = kin["xpos"][b2], kin["xmat"][b2].reshape(3, 3), kin["xquat"][b2]
+                anchor = _floats(a.get("anchor", "0 0 0"), 3, "equality anchor")
+                if tag == "connect":
+                    eq_type[i] = 0
+                    data[i, 0:3] = anchor                                  # in body1
+                    data[i, 3:6] = R2.T @ (x1 + R1 @ anchor - x2)           # the same world point in body2 at qpos0
+                else:
+                    eq_type[i] = 1
+                    rel = _floats(a.get("relpose", "0 1 0 0 0 0 0"), 7, "weld relpose")
+                    if np.all(rel[3:] == 0):                               # unspecified: the reference pose of qpos0
+                        qc = np.array([q1[0], -q1[1], -q1[2], -q1[3]])
+                        relpos, relquat = R1.T @ (x2 - x1), quat_mul(qc, q2)
+                    else:
+                        relpos, relquat = rel[:3], rel[3:] / np.linalg.norm(rel[3:])
+                    data[i, 0:3] = anchor                                  # in body2
+                    data[i, 3:6] = relpos + quat2mat(relquat) @ anchor      # the same point in body1
+                    data[i, 6:10] = relquat
+                    data[i, 10] = float(a.get("torquescale", 1))
+            else:
+                eq_type[i] = 2
+                j1 = m.name2id("joint", a.get("joint1", ""))
+                j2 = m.name2id("joint", a["joint2"]) if "joint2" in a else -1
+                if j1 < 0 or ("joint2" in a and j2 < 0):
+                    raise MjcfError(f"equality '{names[-1]}': unknown joint")
+                for j in (j1, j2):
+                    if j >= 0 and m["jnt_type"][j] < JNT_SLIDE:
+                        raise MjcfError("joint equality needs hinge / slide joints")
+                o1[i], o2[i] = j1, j2
+                pc = _floats(a.get("polycoef", "0 1 0 0 0"))
+                data[i, :pc.size] = pc
+        m.update(neq=n, eq_type=eq_type, eq_obj1id=o1, eq_obj2id=o2, eq_active=act, eq_solref=solref.reshape(n, 2),
+                 eq_solimp=solimp.reshape(n, 5), eq_data=data.reshape(n, 11))
+        m["names"]["equality"] = names
 
     def _collision_pairs(self, m):
         if m["disableflags"] & (DISABLE_BITS["contact"] | DISABLE_BITS["constraint"]):

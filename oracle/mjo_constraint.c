@@ -451,13 +451,13 @@ static void impedance(const double *solimp, double pos, double margin, double *i
 }
 
 /* R, D, KBIP of one row (mj_makeImpedance) */
-static void row_params(const mjb_model_desc *m, mjo_data *d, int i, const double *solref_in, const double *solimp,
-                       double diag_approx)
+static void row_params_x(const mjb_model_desc *m, mjo_data *d, int i, const double *solref_in, const double *solimp,
+                         double diag_approx, double imp_pos, double imp_margin)
 {
 	double solref[2] = { solref_in[0], solref_in[1] };
 	if (!(m->disableflags & MJB_DSBL_REFSAFE) && solref[0] > 0) solref[0] = fmax(solref[0], 2 * m->timestep[0]);
 	double imp, impP;
-	impedance(solimp, d->efc_pos[i], d->efc_margin[i], &imp, &impP);
+	impedance(solimp, imp_pos, imp_margin, &imp, &impP);
 	d->efc_R[i] = fmax(MJO_MINVAL, (1 - imp) * diag_approx / imp);
 	double dmax = solimp[1], K, B;
 	if (solref[0] > 0) {
@@ -473,11 +473,117 @@ static void row_params(const mjb_model_desc *m, mjo_data *d, int i, const double
 	d->efc_KBIP[4 * i + 3] = impP;
 }
 
+static void row_params(const mjb_model_desc *m, mjo_data *d, int i, const double *solref_in, const double *solimp,
+                       double diag_approx)
+{
+	row_params_x(m, d, i, solref_in, solimp, diag_approx, d->efc_pos[i], d->efc_margin[i]);
+}
+
+/* res = quat * (0, axis)   (mju_mulQuatAxis) */
+static void quat_mul_axis(double *res, const double *q, const double *a)
+{
+	res[0] = -q[1] * a[0] - q[2] * a[1] - q[3] * a[2];
+	res[1] = q[0] * a[0] + q[2] * a[2] - q[3] * a[1];
+	res[2] = q[0] * a[1] + q[3] * a[0] - q[1] * a[2];
+	res[3] = q[0] * a[2] + q[1] * a[1] - q[2] * a[0];
+}
+
+/* mj_instantiateEquality (restated from memory of MuJoCo 2.3.7 engine_core_constraint.c -- the library is absent):
+ * connect (3 rows: the anchor seen from both bodies must coincide), weld (6 rows: that plus the relative
+ * orientation neg(q2) * q1 * relpose, axis part scaled by torquescale, with the Jacobian correction
+ * 0.5 neg(q2) (w1 - w2) q1 relpose), joint (1 row: q1 - q1_0 = poly(q2 - q2_0)).  All rows of a connect / weld share
+ * one impedance evaluated at the norm of the residual (getposdim).  Residual sign and Jacobian: body1 - body2. */
+static int make_equality(const mjb_model_desc *m, mjo_data *d, int nefc)
+{
+	const int nv = m->nv;
+	static const double unit[3][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
+	if (nv > 64) return nefc;
+	for (int e = 0; e < m->neq; e++) {
+		if (!m->eq_active[e]) continue;
+		const double *data = m->eq_data + 11 * e;
+		const int type = m->eq_type[e], id1 = m->eq_obj1id[e], id2 = m->eq_obj2id[e];
+		double cpos[6] = { 0 }, jac[6][64], diag[6];
+		int dim = 0;
+		for (int k = 0; k < 6; k++) memset(jac[k], 0, sizeof(double) * (size_t)nv);
+		if (type == MJB_EQ_CONNECT || type == MJB_EQ_WELD) {
+			const int id[2] = { id1, id2 };
+			double pos[2][3];
+			for (int j = 0; j < 2; j++) {
+				const double *anchor = type == MJB_EQ_CONNECT ? data + 3 * j : data + 3 * (1 - j);
+				m3_mulvec(pos[j], d->xmat + 9 * id[j], anchor);
+				v3_addto(pos[j], d->xpos + 3 * id[j]);
+			}
+			v3_sub(cpos, pos[0], pos[1]);
+			for (int k = 0; k < 3; k++) {
+				add_jac_point(m, d, jac[k], id[0], pos[0], unit[k], 1.0);
+				add_jac_point(m, d, jac[k], id[1], pos[1], unit[k], -1.0);
+			}
+			const double tran = m->body_invweight0[2 * id1] + m->body_invweight0[2 * id2];
+			const double rot = m->body_invweight0[2 * id1 + 1] + m->body_invweight0[2 * id2 + 1];
+			diag[0] = diag[1] = diag[2] = tran;
+			dim = 3;
+			if (type == MJB_EQ_WELD) {
+				const double ts = data[10];
+				double quat[4], quat1[4], quat2[4];
+				q_mul(quat, d->xquat + 4 * id[0], data + 6);
+				quat1[0] = d->xquat[4 * id[1]];
+				for (int k = 1; k < 4; k++) quat1[k] = -d->xquat[4 * id[1] + k];
+				q_mul(quat2, quat1, quat);
+				for (int k = 0; k < 3; k++) cpos[3 + k] = ts * quat2[1 + k];
+				for (int k = 0; k < 3; k++) {
+					add_jac_rot(m, d, jac[3 + k], id[0], unit[k], 1.0);
+					add_jac_rot(m, d, jac[3 + k], id[1], unit[k], -1.0);
+				}
+				for (int i = 0; i < nv; i++) {
+					const double axis[3] = { jac[3][i], jac[4][i], jac[5][i] };
+					double qa[4], q3[4];
+					quat_mul_axis(qa, quat1, axis);
+					q_mul(q3, qa, quat);
+					for (int k = 0; k < 3; k++) jac[3 + k][i] = 0.5 * ts * q3[1 + k];
+				}
+				diag[3] = diag[4] = diag[5] = rot;
+				dim = 6;
+			}
+		} else if (type == MJB_EQ_JOINT) {
+			const int a1 = m->jnt_qposadr[id1], d1 = m->jnt_dofadr[id1];
+			double x = 0, deriv = 0, poly = data[0];
+			if (id2 >= 0) {
+				const int a2 = m->jnt_qposadr[id2];
+				x = d->qpos[a2] - m->qpos0[a2];
+				poly = data[0] + x * (data[1] + x * (data[2] + x * (data[3] + x * data[4])));
+				deriv = data[1] + x * (2 * data[2] + x * (3 * data[3] + x * 4 * data[4]));
+				jac[0][m->jnt_dofadr[id2]] = -deriv;
+			}
+			cpos[0] = d->qpos[a1] - m->qpos0[a1] - poly;
+			jac[0][d1] += 1;
+			diag[0] = m->dof_invweight0[d1] + (id2 >= 0 ? m->dof_invweight0[m->jnt_dofadr[id2]] : 0.0);
+			dim = 1;
+		} else {
+			continue;
+		}
+		if (nefc + dim > m->nefcmax) break;
+		double nrm = 0;
+		for (int k = 0; k < dim; k++) nrm += cpos[k] * cpos[k];
+		nrm = sqrt(nrm);
+		for (int k = 0; k < dim; k++) {
+			memcpy(d->efc_J + (size_t)nefc * nv, jac[k], sizeof(double) * (size_t)nv);
+			d->efc_pos[nefc] = cpos[k];
+			d->efc_margin[nefc] = 0;
+			d->efc_type[nefc] = MJB_CNSTR_EQUALITY;
+			d->efc_id[nefc] = e;
+			row_params_x(m, d, nefc, m->eq_solref + 2 * e, m->eq_solimp + 5 * e, diag[k], dim > 1 ? nrm : cpos[0], 0.0);
+			nefc++;
+		}
+	}
+	return nefc;
+}
+
 void mjo_make_constraint(const mjb_model_desc *m, mjo_data *d)
 {
 	int nv = m->nv, nefc = 0;
 	d->nefc[0] = 0;
 	if (m->nefcmax <= 0 || (m->disableflags & MJB_DSBL_CONSTRAINT)) return;
+	if (!(m->disableflags & MJB_DSBL_EQUALITY)) nefc = make_equality(m, d, nefc);
 	/* joint limits (mj_instantiateLimit), hinge / slide */
 	if (!(m->disableflags & MJB_DSBL_LIMIT)) {
 		for (int j = 0; j < m->njnt; j++) {
@@ -648,7 +754,7 @@ void mjo_fwd_constraint(const mjb_model_desc *m, mjo_data *d)
 			double jar = -d->efc_aref[i];
 			const double *row = d->efc_J + (size_t)i * nv;
 			for (int k = 0; k < nv; k++) jar += row[k] * d->qacc_warmstart[k];
-			f[i] = jar < 0 ? -d->efc_D[i] * jar : 0.0; /* limit / contact rows are one-sided */
+			f[i] = (jar < 0 || d->efc_type[i] == MJB_CNSTR_EQUALITY) ? -d->efc_D[i] * jar : 0.0; /* limit / contact rows are one-sided */
 		}
 		double cost = 0;
 		for (int i = 0; i < nefc; i++) {
@@ -672,7 +778,7 @@ void mjo_fwd_constraint(const mjb_model_desc *m, mjo_data *d)
 			double old = f[i];
 			double Aii = d->efc_AR[(size_t)i * ld + i];
 			f[i] -= res * ARinv[i];
-			if (f[i] < 0) f[i] = 0;
+			if (f[i] < 0 && d->efc_type[i] != MJB_CNSTR_EQUALITY) f[i] = 0;
 			double delta = f[i] - old;
 			double change = 0.5 * delta * delta * Aii + delta * res;
 			if (change > 1e-10) {
@@ -763,7 +869,7 @@ static void ls_eval(const lsctx *c, lspoint *p)
 	for (int i = 0; i < c->nefc; i++) {
 		if (c->type[i] != MJB_CNSTR_CONTACT_ELLIPTIC) {
 			double x = c->jaref[i] + a * c->jv[i];
-			if (x < 0) {
+			if (x < 0 || c->type[i] == MJB_CNSTR_EQUALITY) {
 				cost += 0.5 * c->D[i] * x * x;
 				d1 += c->D[i] * x * c->jv[i];
 				d2 += c->D[i] * c->jv[i] * c->jv[i];
@@ -915,7 +1021,7 @@ static double constraint_update(const mjb_model_desc *m, const mjo_data *d, int 
 	double cost = 0;
 	for (int i = 0; i < nefc; i++) {
 		if (d->efc_type[i] != MJB_CNSTR_CONTACT_ELLIPTIC) {
-			if (jar[i] < 0) {
+			if (jar[i] < 0 || d->efc_type[i] == MJB_CNSTR_EQUALITY) {
 				force[i] = -d->efc_D[i] * jar[i];
 				cost += 0.5 * d->efc_D[i] * jar[i] * jar[i];
 				if (hrow) hrow[i] = d->efc_D[i];
