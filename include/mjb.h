@@ -190,6 +190,22 @@ int mjb_warning_count(mjb_batch *b, unsigned long long *count);
  * launch).  Off by default. */
 int mjb_set_keep_frame(mjb_batch *b, int on);
 
+/* ---- sensors-plugin equivalent ----
+ * What MujocoRosSensorsPlugin::lastStageCallback publishes from sensordata after a step
+ * (/root/reference mujoco_ros_sensors/src/mujoco_sensor_handler_plugin.cpp:175-437), for every env at once, on the
+ * device, as float32 in sensordata layout ([nenv][nsensordata], quaternions stay (w, x, y, z)):
+ *   which = 1 "ground truth" = sensordata / cutoff           (the plugin's gt publisher)
+ *   which = 0 "value"        = the same when the sensor has no noise model, else sensordata + noise / cutoff
+ *                              (scalars / vectors; per-axis N(mean, sigma)) or setRPY(noise) * q (quaternions).
+ * mjb_sensor_set_noise is registerNoiseModelsCB (:123-173): bit k of set_flag enables noise on component k, the
+ * n-th set bit reads mean3[n] / sigma3[n], flags accumulate; set_flag = 0 clears the sensor's model (extension).
+ * The plugin's std::mt19937 is replaced by the engine's counter-based Philox stream keyed
+ * (seed, global env, steps taken so far, component), so values are reproducible and identical on CPU and GPU. */
+int mjb_sensor_set_noise(mjb_batch *b, int sensor, int set_flag, const double *mean3, const double *sigma3);
+int mjb_sensor_pack(mjb_batch *b, uint64_t seed);
+int mjb_sensor_get(mjb_batch *b, int which, int env_lo, int env_hi, float *host);
+void *mjb_sensor_device_ptr(mjb_batch *b, int which);
+
 /* Profiling builds only (libmjb_prof.so): per-stage shader-cycle sums [0..31] and call counts [32..63] of
  * env 0; all zero in the production build. */
 int mjb_debug_profile(mjb_batch *b, unsigned long long *out64, int clear);

@@ -131,6 +131,10 @@ def load_library(path=None):
         "mjb_nenv": (ci, [vp]),
         "mjb_set_launch": (ci, [vp, ci, ci]),
         "mjb_set_keep_frame": (ci, [vp, ci]),
+        "mjb_sensor_set_noise": (ci, [vp, ci, ci, C.POINTER(cd), C.POINTER(cd)]),
+        "mjb_sensor_pack": (ci, [vp, C.c_uint64]),
+        "mjb_sensor_get": (ci, [vp, ci, ci, ci, C.POINTER(C.c_float)]),
+        "mjb_sensor_device_ptr": (vp, [vp, ci]),
         "mjb_step": (ci, [vp, ci]),
         "mjb_step1": (ci, [vp]),
         "mjb_step2": (ci, [vp]),

@@ -101,6 +101,13 @@ struct mjb_batch {
 	unsigned char *mask_dev = nullptr;
 	KernelParams *params_dev = nullptr;  // device copy of {dm, L, st, nz}
 	bool params_dirty = true;
+	// sensors-plugin equivalent (mjb_sensor_*): noise models (host mirror + device copy) and the packed messages
+	std::vector<int> sens_flag;
+	std::vector<double> sens_mean, sens_sigma;
+	int *sens_flag_dev = nullptr;
+	double *sens_mean_dev = nullptr, *sens_sigma_dev = nullptr;
+	float *sens_value = nullptr, *sens_truth = nullptr;
+	bool sens_dirty = true, sens_packed = false;
 };
 
 namespace {
@@ -548,6 +555,11 @@ void mjb_free_batch(mjb_batch *b)
 	if (b->blob) hipFree(b->blob);
 	if (b->mask_dev) hipFree(b->mask_dev);
 	if (b->params_dev) hipFree(b->params_dev);
+	if (b->sens_flag_dev) hipFree(b->sens_flag_dev);
+	if (b->sens_mean_dev) hipFree(b->sens_mean_dev);
+	if (b->sens_sigma_dev) hipFree(b->sens_sigma_dev);
+	if (b->sens_value) hipFree(b->sens_value);
+	if (b->sens_truth) hipFree(b->sens_truth);
 	if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
 	delete b;
 }
@@ -1027,6 +1039,94 @@ int mjb_warning_count(mjb_batch *b, unsigned long long *count)
 	HIP_TRY(hipStreamSynchronize(b->stream));
 	HIP_TRY(hipMemcpy(count, b->st.nwarn, sizeof(unsigned long long), hipMemcpyDeviceToHost));
 	return MJB_OK;
+}
+
+// ---- sensors-plugin equivalent (kernel in mjb_sensor_pack.hip) ----
+static int sensor_buffers(mjb_batch *b)
+{
+	const mjb_model_desc &h = b->model->h;
+	const size_t ns = (size_t)(h.nsensor > 0 ? h.nsensor : 1), nd = (size_t)b->nenv * (size_t)(h.nsensordata > 0 ? h.nsensordata : 1);
+	if (b->sens_flag.empty()) {
+		b->sens_flag.assign(ns, 0);
+		b->sens_mean.assign(3 * ns, 0.0);
+		b->sens_sigma.assign(3 * ns, 0.0);
+	}
+	if (!b->sens_value) {
+		b->sens_flag_dev = dev_alloc<int>(ns);
+		b->sens_mean_dev = dev_alloc<double>(3 * ns);
+		b->sens_sigma_dev = dev_alloc<double>(3 * ns);
+		b->sens_value = dev_alloc<float>(nd);
+		b->sens_truth = dev_alloc<float>(nd);
+		if (!b->sens_flag_dev || !b->sens_mean_dev || !b->sens_sigma_dev || !b->sens_value || !b->sens_truth)
+			return fail(MJB_ENOMEM, "sensor message buffers: allocation failed");
+		b->sens_dirty = true;
+	}
+	return MJB_OK;
+}
+
+int mjb_sensor_set_noise(mjb_batch *b, int sensor, int set_flag, const double *mean3, const double *sigma3)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	const mjb_model_desc &h = b->model->h;
+	if (sensor < 0 || sensor >= h.nsensor) return fail(MJB_EINVAL, "mjb_sensor_set_noise: no sensor %d", sensor);
+	if (set_flag < 0 || set_flag > 7 || (set_flag && (!mean3 || !sigma3))) return fail(MJB_EINVAL, "mjb_sensor_set_noise: bad argument");
+	HIP_TRY(hipSetDevice(b->device));
+	int rc = sensor_buffers(b);
+	if (rc) return rc;
+	// registerNoiseModelsCB: the n-th SET bit of this request takes mean[n] / std[n]; bits accumulate (is_set |= flag)
+	int idx = 0;
+	for (int k = 0; k < 3; k++)
+		if (set_flag & (1 << k)) {
+			b->sens_mean[3 * sensor + idx] = mean3[idx];
+			b->sens_sigma[3 * sensor + idx] = sigma3[idx];
+			idx++;
+		}
+	if (set_flag == 0) b->sens_flag[sensor] = 0;  // (extension: a zero flag clears the model)
+	else b->sens_flag[sensor] |= set_flag;
+	b->sens_dirty = true;
+	return MJB_OK;
+}
+
+int mjb_sensor_pack(mjb_batch *b, uint64_t seed)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	const mjb_model_desc &h = b->model->h;
+	HIP_TRY(hipSetDevice(b->device));
+	int rc = sensor_buffers(b);
+	if (rc) return rc;
+	rc = sync_params(b);
+	if (rc) return rc;
+	if (b->sens_dirty) {
+		HIP_TRY(hipStreamSynchronize(b->stream));
+		HIP_TRY(hipMemcpy(b->sens_flag_dev, b->sens_flag.data(), b->sens_flag.size() * sizeof(int), hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(b->sens_mean_dev, b->sens_mean.data(), b->sens_mean.size() * sizeof(double), hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(b->sens_sigma_dev, b->sens_sigma.data(), b->sens_sigma.size() * sizeof(double), hipMemcpyHostToDevice));
+		b->sens_dirty = false;
+	}
+	rc = mjb_launch_sensor_pack(b->params_dev, b->nenv, h.nsensor, b->sens_flag_dev, b->sens_mean_dev, b->sens_sigma_dev, seed,
+	                            b->nz.env_offset, b->step_counter, b->sens_value, b->sens_truth, b->stream);
+	if (rc != 0) return fail(MJB_ENODEVICE, "sensor pack launch failed: %s", hipGetErrorString((hipError_t)rc));
+	b->sens_packed = true;
+	return MJB_OK;
+}
+
+int mjb_sensor_get(mjb_batch *b, int which, int env_lo, int env_hi, float *host)
+{
+	if (!b || !host || which < 0 || which > 1) return fail(MJB_EINVAL, "mjb_sensor_get: bad argument");
+	if (!b->sens_packed) return fail(MJB_EINVAL, "mjb_sensor_get before mjb_sensor_pack");
+	if (env_lo < 0 || env_hi > b->nenv || env_lo > env_hi) return fail(MJB_EINVAL, "mjb_sensor_get: bad env range");
+	const size_t S = (size_t)b->model->h.nsensordata;
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	const float *src = (which == 0 ? b->sens_value : b->sens_truth) + (size_t)env_lo * S;
+	HIP_TRY(hipMemcpy(host, src, (size_t)(env_hi - env_lo) * S * sizeof(float), hipMemcpyDeviceToHost));
+	return MJB_OK;
+}
+
+void *mjb_sensor_device_ptr(mjb_batch *b, int which)
+{
+	if (!b || which < 0 || which > 1 || sensor_buffers(b) != MJB_OK) return nullptr;
+	return which == 0 ? (void *)b->sens_value : (void *)b->sens_truth;
 }
 
 int mjb_time_steps(mjb_batch *b, int nsteps, int nlaunch, double *ms_per_launch)

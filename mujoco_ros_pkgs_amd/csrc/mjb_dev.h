@@ -125,3 +125,7 @@ int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, in
                     int lanes_per_env, int envs_per_block, int constrained, void *stream);
 int mjb_launch_reset(const KernelParams *Pdev, int nenv, const unsigned char *mask_dev, void *stream);
 int mjb_max_lds_bytes();
+// sensors-plugin equivalent (mjb_sensor_pack.hip)
+int mjb_launch_sensor_pack(const KernelParams *Pdev, int nenv, int nsensor, const int *set_flag, const double *mean,
+                           const double *sigma, unsigned long long seed, long long env_offset, unsigned int step,
+                           float *value, float *truth, void *stream);

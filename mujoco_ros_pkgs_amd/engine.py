@@ -105,6 +105,30 @@ class Batch:
         _check(self.lib.mjb_warning_count(self.ptr, C.byref(n)), "mjb_warning_count")
         return int(n.value)
 
+    # ---- sensors-plugin equivalent (mjb_sensor_*) ----
+    def sensor_set_noise(self, sensor, set_flag, mean=(0, 0, 0), sigma=(0, 0, 0)):
+        """registerNoiseModels: bit k of set_flag = noise on component k; the n-th set bit uses mean[n], sigma[n]."""
+        import numpy as np
+        mu = np.zeros(3)
+        sg = np.zeros(3)
+        mu[:len(mean)] = mean
+        sg[:len(sigma)] = sigma
+        pd = C.POINTER(C.c_double)
+        _check(self.lib.mjb_sensor_set_noise(self.ptr, int(sensor), int(set_flag), mu.ctypes.data_as(pd), sg.ctypes.data_as(pd)),
+               "mjb_sensor_set_noise")
+
+    def sensor_pack(self, seed=0):
+        _check(self.lib.mjb_sensor_pack(self.ptr, int(seed)), "mjb_sensor_pack")
+
+    def sensor_messages(self, which="value", lo=0, hi=None):
+        """float32 [hi-lo, nsensordata]: 'value' (with noise models applied) or 'truth' (sensordata / cutoff)."""
+        import numpy as np
+        hi = self.nenv if hi is None else hi
+        out = np.empty((hi - lo, self.cm.model["nsensordata"]), dtype=np.float32)
+        _check(self.lib.mjb_sensor_get(self.ptr, 0 if which == "value" else 1, lo, hi, out.ctypes.data_as(C.POINTER(C.c_float))),
+               "mjb_sensor_get")
+        return out
+
     def set_keep_frame(self, on=True):
         """Fused step() also leaves the derived fields of its last step readable through get()."""
         _check(self.lib.mjb_set_keep_frame(self.ptr, 1 if on else 0), "mjb_set_keep_frame")

@@ -52,6 +52,9 @@ def lib(fast=False):
     L.mjo_normal.restype = cd
     L.mjo_normal.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
     L.mjo_ctrl_noise.argtypes = [pd, vp, cd, cd, C.c_uint64, C.c_uint64, C.c_uint32]
+    L.mjo_sensor_pack.restype = None
+    L.mjo_sensor_pack.argtypes = [pd, C.POINTER(cd), C.POINTER(ci), C.POINTER(cd), C.POINTER(cd), C.c_uint64, C.c_uint64,
+                                  C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.mjo_rollout.restype = ci
     L.mjo_rollout.argtypes = [pd, ci, ci, C.POINTER(cd), C.POINTER(cd), C.POINTER(cd), C.POINTER(cd), cd, cd,
                               C.c_uint64, C.c_int64, ci]
@@ -132,3 +135,19 @@ def rollout(model, qpos, qvel, nsteps, ctrl=None, noise_std=0.0, noise_rate=0.0,
                        noise_rate, seed, env_offset, nthreads)
     assert rc == 0
     return qpos, qvel, sens[:, :model["nsensordata"]]
+
+
+def sensor_pack(model, sensordata, set_flag, mean, sigma, seed, env, step):
+    """The sensors plugin's per-step messages for ONE env (oracle/mjo_sensor_pack.c): returns (value, truth) float32."""
+    L = lib()
+    desc, keep = binding.make_desc(model)
+    sd = np.ascontiguousarray(sensordata, dtype=np.float64)
+    fl = np.ascontiguousarray(set_flag, dtype=np.int32)
+    mu = np.ascontiguousarray(mean, dtype=np.float64)
+    sg = np.ascontiguousarray(sigma, dtype=np.float64)
+    val = np.zeros(model["nsensordata"], dtype=np.float32)
+    tru = np.zeros(model["nsensordata"], dtype=np.float32)
+    pd, pf = C.POINTER(C.c_double), C.POINTER(C.c_float)
+    L.mjo_sensor_pack(C.byref(desc), sd.ctypes.data_as(pd), fl.ctypes.data_as(C.POINTER(C.c_int)), mu.ctypes.data_as(pd),
+                      sg.ctypes.data_as(pd), seed, env, step, val.ctypes.data_as(pf), tru.ctypes.data_as(pf))
+    return val, tru
