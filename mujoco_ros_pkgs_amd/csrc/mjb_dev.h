@@ -44,6 +44,8 @@ struct DevModel {
 	int sens_nslow[3];       // complex sensors per stage
 	int sens_ncopy_max;
 	mjb_ciptr body_dofmask;  // [nbody][2] bit i set: dof i moves the body (ancestor-or-self dofs), nv <= 64
+	mjb_ciptr M_dense;       // [16][16] qM address of entry (i, j) (dof j ancestor-or-self of dof i) or -1; nv <= 16 only
+	mjb_ciptr body_submask;  // [nbody][2] bit i set: body i belongs to the body's subtree (incl. itself), nbody <= 64
 	int eulerdamp;         // any dof_damping > 0 and EULERDAMP not disabled
 	int maxdepth;          // max dof_depth
 };
@@ -122,7 +124,7 @@ enum { MJB_MODE_STEP = 0, MJB_MODE_FORWARD = 1, MJB_MODE_STEP1 = 2, MJB_MODE_STE
 
 // launches (implemented in mjb_step.hip); returns hipError_t as int
 int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0,
-                    int lanes_per_env, int envs_per_block, int constrained, void *stream);
+                    int lanes_per_env, int envs_per_block, int constrained, int dense, void *stream);
 int mjb_launch_reset(const KernelParams *Pdev, int nenv, const unsigned char *mask_dev, void *stream);
 int mjb_max_lds_bytes();
 // sensors-plugin equivalent (mjb_sensor_pack.hip)

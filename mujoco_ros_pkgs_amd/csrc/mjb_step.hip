@@ -70,6 +70,7 @@ struct Env {
 	int *fi;    // LDS frame (ints)
 	int lane;   // 0..G-1
 	int env;    // batch-local env index
+	int dadr[16];  // dense kernels only: qM address of entry (i, lane) of the joint-space inertia, or -1
 #ifdef MJB_PROFILE
 	unsigned long long *prof;
 #endif
@@ -275,19 +276,32 @@ template <int G> STAGE void kinematics(CModel m, CLayout L, CState s, const Env 
 // ------------------------------------------------------------------------------------------------
 // A1  comPos: subtree centres of mass, com-based body inertias (cinert) and motion dofs (cdof)
 // ------------------------------------------------------------------------------------------------
+// bit i of a 64-bit mask stored as two ints (host-built ancestor-dof / subtree-body masks; nv, nbody <= 64)
+DEVI bool maskbit(unsigned int lo, unsigned int hi, int i) { return ((i < 32 ? lo >> i : hi >> (i - 32)) & 1u) != 0; }
+
 template <int G> STAGE void com_pos(CModel m, CLayout L, const Env &e)
 {
 	double *f = e.f;
 	double *sc = f + L.subtree_com, *xipos = f + L.xipos;
 	const int lane = e.lane;
-	// component-per-lane backward accumulation (lane c only ever touches component c)
-	for (int c = lane; c < 3; c += G) {
-		for (int i = 0; i < m.nbody; i++) sc[3 * i + c] = 0;
-		for (int i = m.nbody - 1; i >= 0; i--) {
-			double own = sc[3 * i + c] + xipos[3 * i + c] * m.body_mass[i];
-			if (i) sc[3 * m.body_parentid[i] + c] += own;
-			const double stm = m.body_subtreemass[i];
-			sc[3 * i + c] = (stm < MJB_MINVAL) ? xipos[3 * i + c] : own * (1.0 / fmax(MJB_MINVAL, stm));
+	// lane = body: mass-weighted sum over the bodies of its subtree (host-built mask) -- no walk up the tree, every
+	// lane reads the same xipos / mass sequence (LDS broadcast + scalar loads) and keeps what its mask selects
+	for (int b = lane; b < m.nbody; b += G) {
+		const unsigned int lo = (unsigned int)m.body_submask[2 * b], hi = (unsigned int)m.body_submask[2 * b + 1];
+		double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll 4
+		for (int i = 0; i < m.nbody; i++) {
+			const double mi = maskbit(lo, hi, i) ? m.body_mass[i] : 0.0;
+			s0 += xipos[3 * i] * mi;
+			s1 += xipos[3 * i + 1] * mi;
+			s2 += xipos[3 * i + 2] * mi;
+		}
+		const double stm = m.body_subtreemass[b];
+		if (stm < MJB_MINVAL) {
+			sc[3 * b] = xipos[3 * b]; sc[3 * b + 1] = xipos[3 * b + 1]; sc[3 * b + 2] = xipos[3 * b + 2];
+		} else {
+			const double inv = 1.0 / fmax(MJB_MINVAL, stm);
+			sc[3 * b] = s0 * inv; sc[3 * b + 1] = s1 * inv; sc[3 * b + 2] = s2 * inv;
 		}
 	}
 	gsync<G>();
@@ -525,6 +539,162 @@ STAGE void solve2(CModel m, const Env &e, double *x, const double *LD, const dou
 	}
 }
 
+// ---- register-resident L'DL for small trees (nv <= 16, G == 16: one column of M per lane) -------------------------
+// Lane j keeps column j of the matrix (entries (i, j), i >= j, zero where dof j is not an ancestor of dof i) in 16
+// statically indexed registers; pivots run k = nv-1 .. 0 like mj_factorM, the pivot row and the multipliers travel
+// between the lanes of the env's 16-lane group through ds_bpermute (no LDS storage, no barrier inside the
+// factorisation).  `dadr[i]` = qM-layout address of entry (i, lane) or -1 (host table M_dense, fetched once per kernel).
+DEVI double group_bcast16(double v, int src)  // value of lane `src` of this lane's 16-lane group
+{
+	const int addr = (int)(((threadIdx.x & 48u) | (unsigned int)src) << 2);  // (1-D blocks: lane in wave = threadIdx.x & 63)
+	return __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, __double2hiint(v)),
+	                        __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)));
+}
+
+// (the `asm volatile("")` inside wave-uniform branches keeps them real scalar branches: without it the compiler
+//  if-converts the unrolled pivots into selects over the whole register matrix)
+#define MJB_KEEP_BRANCH() asm volatile("" ::: "memory")
+
+template <int G, bool DUAL>
+DEVI void factor_dense16_impl(CModel m, const Env &e, const double *M, double *LD, double *di, const double *M2, double *LD2,
+                              double *di2, const int (&dadr)[16])
+{
+	const int lane = e.lane, nv = m.nv;
+	double A[16], B[16];
+#pragma unroll
+	for (int i = 0; i < 16; i++) {
+		// unconditional loads (clamped address) + select: no divergent branch per entry
+		const int a = dadr[i], ac = a >= 0 ? a : 0;
+		const double va = M[ac], vb = DUAL ? M2[ac] : 0.0;
+		A[i] = a >= 0 ? va : 0.0;
+		B[i] = a >= 0 ? vb : 0.0;
+	}
+	double myinv = 0, myinv2 = 0;
+#pragma unroll
+	for (int k = 15; k >= 0; k--) {
+		if (k < nv) {
+			MJB_KEEP_BRANCH();
+			// everything that crosses lanes for this pivot first (independent shuffles), arithmetic after
+			const double dk = group_bcast16(A[k], k), dk2 = DUAL ? group_bcast16(B[k], k) : 1.0;
+			double mk[16], mk2[16];
+#pragma unroll
+			for (int i = 0; i < 16; i++) {
+				mk[i] = i < k ? group_bcast16(A[k], i) : 0.0;  // unscaled M(k, i), held by lane i
+				mk2[i] = (DUAL && i < k) ? group_bcast16(B[k], i) : 0.0;
+			}
+			const double inv = 1.0 / dk, inv2 = DUAL ? 1.0 / dk2 : 0.0;
+			const double lkj = A[k] * inv, lkj2 = B[k] * inv2;  // scaled pivot-row entry of this lane's column (lane < k)
+#pragma unroll
+			for (int i = 0; i < 16; i++) {
+				if (i >= k) continue;
+				if (lane <= i) {
+					A[i] -= mk[i] * lkj;
+					if (DUAL) B[i] -= mk2[i] * lkj2;
+				}
+			}
+			if (lane == k) {
+				myinv = inv;
+				myinv2 = inv2;
+			} else {
+				A[k] = lkj;
+				B[k] = lkj2;
+			}
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < 16; i++) {
+		const int a = dadr[i];
+		if (a >= 0) {
+			LD[a] = A[i];
+			if (DUAL) LD2[a] = B[i];
+		}
+	}
+	if (lane < nv) {
+		di[lane] = myinv;
+		if (DUAL) di2[lane] = myinv2;
+	}
+	gsync<G>();
+}
+
+template <int G>
+STAGE void factor_dense16(CModel m, const Env &e, const double *M, double *LD, double *di, const double *M2, double *LD2,
+                          double *di2, bool dual, const int (&dadr)[16])
+{
+	static_assert(G == 16, "one matrix column per lane of a 16-lane env group");
+	if (dual) {
+		MJB_KEEP_BRANCH();
+		factor_dense16_impl<G, true>(m, e, M, LD, di, M2, LD2, di2, dadr);
+	} else {
+		MJB_KEEP_BRANCH();
+		factor_dense16_impl<G, false>(m, e, M, LD, di, M2, LD2, di2, dadr);
+	}
+}
+
+// x <- M^-1 x with the factor's columns re-read from LDS into registers; x lives one element per lane
+template <int G, bool DUAL>
+DEVI void solve_dense16_impl(CModel m, const Env &e, double *x, const double *LD, const double *diaginv, double *x2,
+                             const double *LD2, const double *diaginv2, const int (&dadr)[16])
+{
+	const int lane = e.lane, nv = m.nv;
+	const bool act = lane < nv;
+	double A[16], B[16];
+#pragma unroll
+	for (int i = 0; i < 16; i++) {
+		const int a = dadr[i], ac = a >= 0 ? a : 0;
+		const double va = LD[ac], vb = DUAL ? LD2[ac] : 0.0;
+		A[i] = (a >= 0 && i != lane) ? va : 0.0;
+		B[i] = (a >= 0 && i != lane) ? vb : 0.0;
+	}
+	double xj = act ? x[lane] : 0.0, xj2 = (DUAL && act) ? x2[lane] : 0.0;
+	const double dinv = act ? diaginv[lane] : 0.0, dinv2 = (DUAL && act) ? diaginv2[lane] : 0.0;
+	// x <- inv(L') x : dof i pushes its value down to its ancestors j < i
+#pragma unroll
+	for (int i = 15; i >= 1; i--) {
+		if (i < nv) {
+			MJB_KEEP_BRANCH();
+			const double xi = group_bcast16(xj, i), xi2 = DUAL ? group_bcast16(xj2, i) : 0.0;
+			if (lane < i) {
+				xj -= A[i] * xi;
+				if (DUAL) xj2 -= B[i] * xi2;
+			}
+		}
+	}
+	xj *= dinv;
+	xj2 *= dinv2;
+	// x <- inv(L) x : row i gathers L(i, j) x_j from the lanes j < i with a 16-lane butterfly sum
+#pragma unroll
+	for (int i = 1; i < 16; i++) {
+		if (i < nv) {
+			MJB_KEEP_BRANCH();
+			const double s = row_sum<16>(lane < i ? A[i] * xj : 0.0);
+			const double s2 = DUAL ? row_sum<16>(lane < i ? B[i] * xj2 : 0.0) : 0.0;
+			if (lane == i) {
+				xj -= s;
+				xj2 -= s2;
+			}
+		}
+	}
+	if (act) {
+		x[lane] = xj;
+		if (DUAL) x2[lane] = xj2;
+	}
+	gsync<G>();
+}
+
+template <int G>
+STAGE void solve_dense16(CModel m, const Env &e, double *x, const double *LD, const double *diaginv, double *x2,
+                         const double *LD2, const double *diaginv2, bool dual, const int (&dadr)[16])
+{
+	static_assert(G == 16, "one matrix column per lane of a 16-lane env group");
+	if (dual) {
+		MJB_KEEP_BRANCH();
+		solve_dense16_impl<G, true>(m, e, x, LD, diaginv, x2, LD2, diaginv2, dadr);
+	} else {
+		MJB_KEEP_BRANCH();
+		solve_dense16_impl<G, false>(m, e, x, LD, diaginv, x2, LD2, diaginv2, dadr);
+	}
+}
+
 template <int G> DEVI void solve(CModel m, const Env &e, double *x, const double *LD, const double *diaginv)
 {
 	solve2<G>(m, e, x, LD, diaginv, x, LD, diaginv, false);
@@ -569,23 +739,16 @@ template <int G> STAGE void com_vel(CModel m, CLayout L, const Env &e)
 	double *f = e.f;
 	double *cvel = f + L.cvel, *cdof = f + L.cdof, *qvel = f + L.qvel;
 	const int lane = e.lane;
-	// component-per-lane chain: cvel[i] = cvel[parent] + sum over velocity groups (cdof * qvel)
-	for (int c = lane; c < 6; c += G) {
-		cvel[c] = 0;
-		for (int i = 1; i < m.nbody; i++) {
-			double v = cvel[6 * m.body_parentid[i] + c];
-			const int bda = m.body_dofadr[i], nd = m.body_dofnum[i];
-			int d = bda;
-			while (d < bda + nd) {
-				const int jt = m.jnt_type[m.dof_jntid[d]];
-				const int glen = (jt == MJB_JNT_HINGE || jt == MJB_JNT_SLIDE) ? 1 : 3;
-				double tmp = 0;
-				for (int k = 0; k < glen; k++) tmp += cdof[6 * (d + k) + c] * qvel[d + k];
-				v += tmp;
-				d += glen;
-			}
-			cvel[6 * i + c] = v;
+	// lane = body: cvel = sum of cdof_d qvel_d over the dofs that move the body (ancestor mask, root to leaf order)
+	for (int b = lane; b < m.nbody; b += G) {
+		const unsigned int lo = (unsigned int)m.body_dofmask[2 * b], hi = (unsigned int)m.body_dofmask[2 * b + 1];
+		double v[6] = { 0, 0, 0, 0, 0, 0 };
+#pragma unroll 3
+		for (int d = 0; d < m.nv; d++) {
+			const double qd = maskbit(lo, hi, d) ? qvel[d] : 0.0;
+			for (int c = 0; c < 6; c++) v[c] += cdof[6 * d + c] * qd;
 		}
+		st6(cvel + 6 * b, v);
 	}
 	gsync<G>();
 	// cdof_dot: one dof per lane
@@ -659,24 +822,23 @@ template <int G> STAGE void rne(CModel m, CLayout L, const Env &e)
 	double *cacc = f + L.cacc, *cfrc = f + L.cfrc_body, *cdd = f + L.cdof_dot, *qvel = f + L.qvel;
 	const int lane = e.lane;
 	const bool grav = !(m.disableflags & MJB_DSBL_GRAVITY);
-	for (int c = lane; c < 6; c += G) {
-		cacc[c] = (c >= 3 && grav) ? -m.gravity[c - 3] : 0.0;
-		for (int i = 1; i < m.nbody; i++) {
-			const int bda = m.body_dofadr[i], nd = m.body_dofnum[i];
-			double tmp = 0;
-			for (int k = 0; k < nd; k++) tmp += cdd[6 * (bda + k) + c] * qvel[bda + k];
-			cacc[6 * i + c] = cacc[6 * m.body_parentid[i] + c] + tmp;
-		}
-	}
-	gsync<G>();
+	// lane = body: cacc = -gravity + sum of cdof_dot_d qvel_d over the dofs that move the body, then the body's own
+	// inertial force  I a + v x* (I v)   (cfrc_body holds the per-body force, not its subtree sum)
 	for (int b = lane; b < m.nbody; b += G) {
+		const unsigned int lo = (unsigned int)m.body_dofmask[2 * b], hi = (unsigned int)m.body_dofmask[2 * b + 1];
+		double a[6] = { 0, 0, 0, grav ? -m.gravity[0] : 0.0, grav ? -m.gravity[1] : 0.0, grav ? -m.gravity[2] : 0.0 };
+#pragma unroll 3
+		for (int d = 0; d < m.nv; d++) {
+			const double qd = maskbit(lo, hi, d) ? qvel[d] : 0.0;
+			for (int c = 0; c < 6; c++) a[c] += cdd[6 * d + c] * qd;
+		}
+		st6(cacc + 6 * b, a);
 		double r[6];
 		if (b == 0) {
 			for (int k = 0; k < 6; k++) r[k] = 0;
 		} else {
-			double I[10], a[6], v[6], t[6], t1[6];
+			double I[10], v[6], t[6], t1[6];
 			ld10(I, f + L.cinert + 10 * b);
-			ld6(a, cacc + 6 * b);
 			ld6(v, f + L.cvel + 6 * b);
 			mul_inert_vec(r, I, a);
 			mul_inert_vec(t, I, v);
@@ -686,17 +848,20 @@ template <int G> STAGE void rne(CModel m, CLayout L, const Env &e)
 		st6(cfrc + 6 * b, r);
 	}
 	gsync<G>();
-	for (int c = lane; c < 6; c += G)
-		for (int i = m.nbody - 1; i > 0; i--) {
-			const int p = m.body_parentid[i];
-			if (p) cfrc[6 * p + c] += cfrc[6 * i + c];
-		}
-	gsync<G>();
+	// lane = dof: qfrc_bias_d = cdof_d . (sum of the forces of the bodies that dof d moves)
 	for (int d = lane; d < m.nv; d += G) {
-		double a[6], b[6];
+		double acc[6] = { 0, 0, 0, 0, 0, 0 };
+#pragma unroll 3
+		for (int b = 1; b < m.nbody; b++) {
+			const bool on = maskbit((unsigned int)m.body_dofmask[2 * b], (unsigned int)m.body_dofmask[2 * b + 1], d);
+			for (int c = 0; c < 6; c++) {
+				const double v = cfrc[6 * b + c];
+				acc[c] += on ? v : 0.0;
+			}
+		}
+		double a[6];
 		ld6(a, f + L.cdof + 6 * d);
-		ld6(b, cfrc + 6 * m.dof_bodyid[d]);
-		f[L.qfrc_bias + d] = dot6r(a, b);
+		f[L.qfrc_bias + d] = dot6r(a, acc);
 	}
 	gsync<G>();
 }
@@ -919,7 +1084,7 @@ template <int G> STAGE void fwd_actuation(CModel m, CLayout L, const Env &e)
 	gsync<G>();
 }
 
-template <int G> STAGE void fwd_acceleration(CModel m, CLayout L, const Env &e, bool use_xfrc)
+template <int G, bool DENSE> STAGE void fwd_acceleration(CModel m, CLayout L, const Env &e, bool use_xfrc)
 {
 	double *f = e.f;
 	for (int d = e.lane; d < m.nv; d += G) {
@@ -953,7 +1118,10 @@ template <int G> STAGE void fwd_acceleration(CModel m, CLayout L, const Env &e, 
 	}
 	gsync<G>();
 	const bool dual = m.eulerdamp && m.nefcmax == 0;
-	solve2<G>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual);
+	if constexpr (DENSE)
+		solve_dense16<G>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual, e.dadr);
+	else
+		solve2<G>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual);
 }
 
 #include "mjb_constraint.h"
@@ -1107,7 +1275,7 @@ DEVI const KernelParams MJB_AS4 *launder_params(const KernelParams MJB_AS4 *p)
 		__VA_ARGS__;                                                       \
 	} while (0)
 
-template <int G, int CON> DEVI void forward_first(const KernelParams MJB_AS4 *P, const Env &e, int compact)
+template <int G, int CON, bool DENSE> DEVI void forward_first(const KernelParams MJB_AS4 *P, const Env &e, int compact)
 {
 	[[maybe_unused]] CState s = P->s;  // (profiling macros)
 	PROF_BEGIN();
@@ -1117,8 +1285,12 @@ template <int G, int CON> DEVI void forward_first(const KernelParams MJB_AS4 *P,
 	PROF(1);
 	VIEW(P, compact, crb<G>(m, L, e));
 	PROF(2);
-	VIEW(P, compact, factor2<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi,
-	                            m.eulerdamp != 0));
+	if constexpr (DENSE)
+		VIEW(P, compact, factor_dense16<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH,
+		                                   e.f + L.qHdi, m.eulerdamp != 0, e.dadr));
+	else
+		VIEW(P, compact, factor2<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi,
+		                            m.eulerdamp != 0));
 	PROF(3);
 	if constexpr (CON) {
 		VIEW(P, compact, collision<G>(m, L, e));
@@ -1142,13 +1314,13 @@ template <int G, int CON> DEVI void forward_first(const KernelParams MJB_AS4 *P,
 	PROF(8);
 }
 
-template <int G, int CON> DEVI void forward_rest(const KernelParams MJB_AS4 *P, const Env &e, int compact)
+template <int G, int CON, bool DENSE> DEVI void forward_rest(const KernelParams MJB_AS4 *P, const Env &e, int compact)
 {
 	[[maybe_unused]] CState s = P->s;  // (profiling macros)
 	PROF_BEGIN();
 	VIEW(P, compact, fwd_actuation<G>(m, L, e));
 	PROF(9);
-	VIEW(P, compact, fwd_acceleration<G>(m, L, e, s.use_xfrc != 0));
+	VIEW(P, compact, fwd_acceleration<G, DENSE>(m, L, e, s.use_xfrc != 0));
 	PROF(10);
 	if constexpr (CON >= 2 && G == 64) {
 		VIEW(P, compact, fwd_constraint_newton<G, (CON == 2 ? 1 : (CON == 3 ? 2 : 4))>(m, L, e));
@@ -1181,7 +1353,7 @@ template <int G> STAGE void ctrl_noise(CModel m, CLayout L, CNoise nz, const Env
 // one env per wavefront) -- separate kernels keep each instruction stream and register budget small.
 // Constrained kernels are capped at 256 VGPRs (2 blocks/CU): with the 512-register budget ROCm 7.2's LLVM
 // spills VGPRs to AGPRs ahead of an exec restore and loses lanes (tools/check_spill_exec.py, `make lint`).
-template <int G, int CON>
+template <int G, int CON, bool DENSE>
 __global__ void __launch_bounds__(256, (CON ? 2 : (G == 64 ? 4 : (G == 32 ? 2 : 1))))
     mjb_step_kernel(const KernelParams MJB_AS4 *__restrict__ P, const int mode, const int nsteps,
                     const unsigned int step0, const int epb, const int frame_bytes)
@@ -1200,6 +1372,10 @@ __global__ void __launch_bounds__(256, (CON ? 2 : (G == 64 ? 4 : (G == 32 ? 2 : 
 	e.prof = s.prof;
 #endif
 	e.lane = threadIdx.x % G;
+	if constexpr (DENSE) {
+#pragma unroll
+		for (int i = 0; i < 16; i++) e.dadr[i] = m.M_dense[16 * i + e.lane];
+	}
 	e.f = reinterpret_cast<double *>(smem + (size_t)slot * frame_bytes);
 	e.fi = reinterpret_cast<int *>(e.f + L.ndouble);
 
@@ -1242,10 +1418,10 @@ __global__ void __launch_bounds__(256, (CON ? 2 : (G == 64 ? 4 : (G == 32 ? 2 : 
 				if (do_first || attempt) {
 					if (attempt == 0 && checks && any_bad<G>(e, L, e.f + L.qpos, m.nq, e.f + L.qvel, m.nv))
 						reset_frame_state<G>(m, L, s, e);
-					forward_first<G, CON>(P, e, compact);
+					forward_first<G, CON, DENSE>(P, e, compact);
 				}
 				if (!do_rest) break;
-				forward_rest<G, CON>(P, e, compact);
+				forward_rest<G, CON, DENSE>(P, e, compact);
 				if (attempt || !checks || !any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0)) break;
 				reset_frame_state<G>(m, L, s, e);
 			}
@@ -1289,7 +1465,7 @@ __global__ void mjb_reset_kernel(const KernelParams MJB_AS4 *__restrict__ P, con
 	s.time[e] = 0;
 }
 
-template <int G, int CON>
+template <int G, int CON, bool DENSE = false>
 int launch_g(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0,
              int epb, void *stream)
 {
@@ -1306,7 +1482,7 @@ int launch_g(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode,
 	}
 	const size_t lds = (size_t)epb * frame_bytes;
 	if ((int)lds > maxlds) return (int)hipErrorInvalidValue;
-	auto kern = mjb_step_kernel<G, CON>;
+	auto kern = mjb_step_kernel<G, CON, DENSE>;
 	hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
 	                                     (int)lds);
 	if (err != hipSuccess) return (int)err;
@@ -1323,7 +1499,7 @@ int launch_g(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode,
 int mjb_max_lds_bytes() { return 160 * 1024; }
 
 int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0,
-                    int lanes_per_env, int envs_per_block, int constrained, void *stream)
+                    int lanes_per_env, int envs_per_block, int constrained, int dense, void *stream)
 {
 	if (constrained) {
 		if (lanes_per_env != 64) return (int)hipErrorInvalidValue;
@@ -1334,7 +1510,9 @@ int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, in
 	}
 	switch (lanes_per_env) {
 	case 8: return launch_g<8, 0>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
-	case 16: return launch_g<16, 0>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+	case 16:
+		if (dense) return launch_g<16, 0, true>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+		return launch_g<16, 0>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 	case 32: return launch_g<32, 0>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 	case 64: return launch_g<64, 0>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 	default: return (int)hipErrorInvalidValue;

