@@ -77,10 +77,10 @@ struct mjb_model {
 	std::vector<int> hint;            // all int arrays, concatenated
 	std::vector<double> hdbl;         // all double arrays, concatenated
 	std::vector<size_t> ioff, doff;   // offsets of each array inside hint / hdbl (declaration order)
-	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense;
+	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense, body_anc;
 	std::vector<int> sens_copy, sens_slow, dof_act_adr, dof_act_id;
 	int sens_ncopy[3] = { 0, 0, 0 }, sens_nslow[3] = { 0, 0, 0 }, sens_ncopy_max = 0;
-	int eulerdamp = 0, maxdepth = 0;
+	int eulerdamp = 0, maxdepth = 0, kin_rounds = 0;
 	int field_size[MJB_F_COUNT]{};
 	FrameLayout L{}, Lc{};
 };
@@ -502,6 +502,24 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 	M->M_dense.assign(256, -1);
 	if (h.nv <= 16)
 		for (int en = 0; en < h.nM; en++) M->M_dense[16 * M->M_rowdof[en] + M->M_coldof[en]] = en;
+	// ancestors at distance 2^r for the pointer-jumping kinematics (0 = world or beyond the root)
+	{
+		int maxd = 0;
+		std::vector<int> depth((size_t)h.nbody, 0);
+		for (int b = 1; b < h.nbody; b++) {
+			depth[b] = depth[h.body_parentid[b]] + 1;
+			if (depth[b] > maxd) maxd = depth[b];
+		}
+		M->kin_rounds = 0;
+		while ((1 << M->kin_rounds) < maxd) M->kin_rounds++;
+		M->body_anc.assign((size_t)(M->kin_rounds + 2) * h.nbody, 0);
+		for (int b = 1; b < h.nbody; b++) M->body_anc[b] = h.body_parentid[b];
+		for (int r = 1; r < M->kin_rounds + 2; r++)
+			for (int b = 1; b < h.nbody; b++) {
+				const int a = M->body_anc[(size_t)(r - 1) * h.nbody + b];
+				M->body_anc[(size_t)r * h.nbody + b] = a ? M->body_anc[(size_t)(r - 1) * h.nbody + a] : 0;
+			}
+	}
 	// subtree membership masks (subtree com, composite inertia)
 	M->body_submask.assign((size_t)2 * h.nbody, 0);
 	for (int b = 0; b < h.nbody && h.nbody <= 64; b++)
@@ -613,7 +631,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	size_t ni = M->hint.size(), nd = M->hdbl.size();
 	size_t nt = M->M_rowdof.size() + M->M_coldof.size() + M->dof_depth.size() + M->dof_jstart.size() +
 	            M->body_rec.size() + M->body_rec2.size() + M->dof_rec.size() + M->fac_ops.size() + M->fac_beg.size() +
-	            M->body_dofmask.size() + M->body_submask.size() + M->M_dense.size() + M->sens_copy.size() + M->sens_slow.size() + M->dof_act_adr.size() +
+	            M->body_dofmask.size() + M->body_submask.size() + M->M_dense.size() + M->body_anc.size() + M->sens_copy.size() + M->sens_slow.size() + M->dof_act_adr.size() +
 	            M->dof_act_id.size() + 96;
 	size_t bytes_i = ((ni + nt) * sizeof(int) + 15) & ~size_t(15);
 	size_t bytes = bytes_i + nd * sizeof(double) + 16;
@@ -636,7 +654,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	};
 	size_t o_row = put(M->M_rowdof), o_col = put(M->M_coldof), o_dep = put(M->dof_depth), o_js = put(M->dof_jstart);
 	size_t o_br = put(M->body_rec), o_br2 = put(M->body_rec2), o_dr = put(M->dof_rec), o_fo = put(M->fac_ops),
-	       o_fb = put(M->fac_beg), o_dm = put(M->body_dofmask), o_sm = put(M->body_submask), o_md = put(M->M_dense), o_sc = put(M->sens_copy), o_ss = put(M->sens_slow),
+	       o_fb = put(M->fac_beg), o_dm = put(M->body_dofmask), o_sm = put(M->body_submask), o_md = put(M->M_dense), o_an = put(M->body_anc), o_sc = put(M->sens_copy), o_ss = put(M->sens_slow),
 	       o_aa = put(M->dof_act_adr), o_ai = put(M->dof_act_id);
 	if (nd) memcpy(hd, M->hdbl.data(), nd * sizeof(double));
 	if (hipMemcpy(b->blob, hostblob.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
@@ -673,6 +691,8 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	dm.body_dofmask = (mjb_ciptr)(di + o_dm);
 	dm.body_submask = (mjb_ciptr)(di + o_sm);
 	dm.M_dense = (mjb_ciptr)(di + o_md);
+	dm.body_anc = (mjb_ciptr)(di + o_an);
+	dm.kin_rounds = M->kin_rounds;
 	dm.sens_copy = (mjb_ciptr)(di + o_sc);
 	dm.sens_slow = (mjb_ciptr)(di + o_ss);
 	dm.dof_act_adr = (mjb_ciptr)(di + o_aa);
@@ -797,7 +817,7 @@ static int launch(mjb_batch *b, int mode, int nsteps)
 	if (prc) return prc;
 	const bool compact = mode == MJB_MODE_STEP && !b->st.use_xfrc && !b->st.keep_frame;
 	int rc = mjb_launch_step(b->params_dev, compact ? b->model->Lc : b->L, b->nenv, mode, nsteps, b->step_counter, b->lanes,
-	                         b->epb, kernel_variant(b->model->h), (b->lanes == 16 && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16) ? 1 : 0, b->stream);
+	                         b->epb, kernel_variant(b->model->h), (b->lanes == 16 && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16) ? 1 : 0, b->stream);
 	if (rc != 0) return fail(MJB_ENODEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
 	return MJB_OK;
 }

@@ -102,7 +102,7 @@ DEVI void local2global(const double *xpos_b, const double *xquat_b, const double
 	}
 }
 
-template <int G> STAGE void kinematics(CModel m, CLayout L, CState s, const Env &e)
+template <int G, bool SCAN> STAGE void kinematics(CModel m, CLayout L, CState s, const Env &e)
 {
 	PROF_BEGIN();
 	double *f = e.f;
@@ -169,42 +169,79 @@ template <int G> STAGE void kinematics(CModel m, CLayout L, CState s, const Env 
 	gsync<G>();
 	PROF(20);
 
-	// Phase B -- thin serial chain, replicated in every lane with the running parent pose in registers:
-	// xquat_i = xquat_p * lq_i,  xpos_i = xpos_p + R_p lp_i.  Only xpos / xquat are stored (7 doubles per body);
-	// phase C re-normalises the quaternions and derives xmat.
-	{
-		double cp[3] = { 0, 0, 0 }, cq[4] = { 1, 0, 0, 0 }, cM[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
-		if (lane == 0) {
-			st3(xpos, cp);
-			st4(xquat, cq);
-		}
-		double lp[3], lq[4];
-		ld3(lp, loc + 7);
-		ld4(lq, loc + 10);
+	if constexpr (SCAN) {
+		// Phase B (nbody <= G) -- pointer jumping over the tree: every body composes its pose with the pose of its
+		// ancestor at distance 1, 2, 4, ... (host table body_anc), so a chain of depth d takes ceil(log2 d) rounds
+		// instead of d.  Pose composition is associative; only the rounding differs from the serial walk.
+		const bool act = lane < m.nbody;
+		const int b = act ? lane : 0;
+		double p[3], q[4];
+		ld3(p, loc + 7 * b);
+		ld4(q, loc + 7 * b + 3);
+		int A = b ? m.body_anc[b] : 0;
 #pragma nounroll
-		for (int i = 1; i < m.nbody; i++) {
-			const int pid = m.body_rec[4 * i];
-			if (pid != i - 1) {
-				ld3(cp, xpos + 3 * pid);
-				ld4(cq, xquat + 4 * pid);
+		for (int r = 0; r < m.kin_rounds; r++) {
+			if (r && act) {
+				st3(loc + 7 * b, p);
+				st4(loc + 7 * b + 3, q);
+			}
+			gsync<G>();
+			const int An = A ? m.body_anc[(r + 1) * m.nbody + b] : 0;
+			if (A) {
+				double pa[3], qa[4], Ma[9], v[3];
+				ld3(pa, loc + 7 * A);
+				ld4(qa, loc + 7 * A + 3);
+				quat2mat_nocheck(Ma, qa);
+				matvec3(v, Ma, p);
+				p[0] = pa[0] + v[0]; p[1] = pa[1] + v[1]; p[2] = pa[2] + v[2];
+				qmul(q, qa, q);
+			}
+			A = An;
+			gsync<G>();
+		}
+		if (act) {
+			st3(xpos + 3 * b, p);
+			st4(xquat + 4 * b, q);
+		}
+		gsync<G>();
+	} else {
+		// Phase B -- thin serial chain, replicated in every lane with the running parent pose in registers:
+		// xquat_i = xquat_p * lq_i,  xpos_i = xpos_p + R_p lp_i.  Only xpos / xquat are stored (7 doubles per body);
+		// phase C re-normalises the quaternions and derives xmat.
+		{
+			double cp[3] = { 0, 0, 0 }, cq[4] = { 1, 0, 0, 0 }, cM[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+			if (lane == 0) {
+				st3(xpos, cp);
+				st4(xquat, cq);
+			}
+			double lp[3], lq[4];
+			ld3(lp, loc + 7);
+			ld4(lq, loc + 10);
+#pragma nounroll
+			for (int i = 1; i < m.nbody; i++) {
+				const int pid = m.body_rec[4 * i];
+				if (pid != i - 1) {
+					ld3(cp, xpos + 3 * pid);
+					ld4(cq, xquat + 4 * pid);
+					quat2mat_nocheck(cM, cq);
+				}
+				double v[3];
+				matvec3(v, cM, lp);
+				cp[0] += v[0]; cp[1] += v[1]; cp[2] += v[2];
+				qmul(cq, cq, lq);
+				// prefetch the next body's local pose before this body's stores enter the LDS queue
+				const int nx = (i + 1 < m.nbody) ? i + 1 : i;
+				ld3(lp, loc + 7 * nx);
+				ld4(lq, loc + 7 * nx + 3);
+				if (lane == 0) {
+					st3(xpos + 3 * i, cp);
+					st4(xquat + 4 * i, cq);
+				}
 				quat2mat_nocheck(cM, cq);
 			}
-			double v[3];
-			matvec3(v, cM, lp);
-			cp[0] += v[0]; cp[1] += v[1]; cp[2] += v[2];
-			qmul(cq, cq, lq);
-			// prefetch the next body's local pose before this body's stores enter the LDS queue
-			const int nx = (i + 1 < m.nbody) ? i + 1 : i;
-			ld3(lp, loc + 7 * nx);
-			ld4(lq, loc + 7 * nx + 3);
-			if (lane == 0) {
-				st3(xpos + 3 * i, cp);
-				st4(xquat + 4 * i, cq);
-			}
-			quat2mat_nocheck(cM, cq);
 		}
+		gsync<G>();
 	}
-	gsync<G>();
 
 	PROF(21);
 	// Phase C -- one body per lane: normalise xquat, final xmat, inertial frame
@@ -1279,7 +1316,7 @@ template <int G, int CON, bool DENSE> DEVI void forward_first(const KernelParams
 {
 	[[maybe_unused]] CState s = P->s;  // (profiling macros)
 	PROF_BEGIN();
-	VIEW(P, compact, kinematics<G>(m, L, s, e));
+	VIEW(P, compact, kinematics<G, (G == 64 || DENSE)>(m, L, s, e));
 	PROF(0);
 	VIEW(P, compact, com_pos<G>(m, L, e));
 	PROF(1);
