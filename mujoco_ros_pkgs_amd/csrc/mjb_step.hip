@@ -592,14 +592,23 @@ DEVI double group_bcast16(double v, int src)  // value of lane `src` of this lan
 //  if-converts the unrolled pivots into selects over the whole register matrix)
 #define MJB_KEEP_BRANCH() asm volatile("" ::: "memory")
 
-template <int G, bool DUAL>
+// 1 / x to ~1 ulp: hardware seed + two Newton steps (the correctly rounded division costs 12 dependent instructions)
+DEVI double fast_rcp(double x)
+{
+	double r = __builtin_amdgcn_rcp(x);
+	r = fma(fma(-x, r, 1.0), r, r);
+	r = fma(fma(-x, r, 1.0), r, r);
+	return r;
+}
+
+template <int G, bool DUAL, int NVM>
 DEVI void factor_dense16_impl(CModel m, const Env &e, const double *M, double *LD, double *di, const double *M2, double *LD2,
                               double *di2, const int (&dadr)[16])
 {
 	const int lane = e.lane, nv = m.nv;
-	double A[16], B[16];
+	double A[NVM], B[NVM];
 #pragma unroll
-	for (int i = 0; i < 16; i++) {
+	for (int i = 0; i < NVM; i++) {
 		// unconditional loads (clamped address) + select: no divergent branch per entry
 		const int a = dadr[i], ac = a >= 0 ? a : 0;
 		const double va = M[ac], vb = DUAL ? M2[ac] : 0.0;
@@ -608,26 +617,25 @@ DEVI void factor_dense16_impl(CModel m, const Env &e, const double *M, double *L
 	}
 	double myinv = 0, myinv2 = 0;
 #pragma unroll
-	for (int k = 15; k >= 0; k--) {
+	for (int k = NVM - 1; k >= 0; k--) {
 		if (k < nv) {
 			MJB_KEEP_BRANCH();
 			// everything that crosses lanes for this pivot first (independent shuffles), arithmetic after
 			const double dk = group_bcast16(A[k], k), dk2 = DUAL ? group_bcast16(B[k], k) : 1.0;
-			double mk[16], mk2[16];
+			double mk[NVM], mk2[NVM];
 #pragma unroll
-			for (int i = 0; i < 16; i++) {
+			for (int i = 0; i < NVM; i++) {
 				mk[i] = i < k ? group_bcast16(A[k], i) : 0.0;  // unscaled M(k, i), held by lane i
 				mk2[i] = (DUAL && i < k) ? group_bcast16(B[k], i) : 0.0;
 			}
-			const double inv = 1.0 / dk, inv2 = DUAL ? 1.0 / dk2 : 0.0;
+			const double inv = fast_rcp(dk), inv2 = DUAL ? fast_rcp(dk2) : 0.0;
 			const double lkj = A[k] * inv, lkj2 = B[k] * inv2;  // scaled pivot-row entry of this lane's column (lane < k)
+			// (entries above the diagonal -- register i of a lane > i -- are never read or stored: no lane predicate)
 #pragma unroll
-			for (int i = 0; i < 16; i++) {
+			for (int i = 0; i < NVM; i++) {
 				if (i >= k) continue;
-				if (lane <= i) {
-					A[i] -= mk[i] * lkj;
-					if (DUAL) B[i] -= mk2[i] * lkj2;
-				}
+				A[i] -= mk[i] * lkj;
+				if (DUAL) B[i] -= mk2[i] * lkj2;
 			}
 			if (lane == k) {
 				myinv = inv;
@@ -639,7 +647,7 @@ DEVI void factor_dense16_impl(CModel m, const Env &e, const double *M, double *L
 		}
 	}
 #pragma unroll
-	for (int i = 0; i < 16; i++) {
+	for (int i = 0; i < NVM; i++) {
 		const int a = dadr[i];
 		if (a >= 0) {
 			LD[a] = A[i];
@@ -653,30 +661,30 @@ DEVI void factor_dense16_impl(CModel m, const Env &e, const double *M, double *L
 	gsync<G>();
 }
 
-template <int G>
+template <int G, int NVM>
 STAGE void factor_dense16(CModel m, const Env &e, const double *M, double *LD, double *di, const double *M2, double *LD2,
                           double *di2, bool dual, const int (&dadr)[16])
 {
 	static_assert(G == 16, "one matrix column per lane of a 16-lane env group");
 	if (dual) {
 		MJB_KEEP_BRANCH();
-		factor_dense16_impl<G, true>(m, e, M, LD, di, M2, LD2, di2, dadr);
+		factor_dense16_impl<G, true, NVM>(m, e, M, LD, di, M2, LD2, di2, dadr);
 	} else {
 		MJB_KEEP_BRANCH();
-		factor_dense16_impl<G, false>(m, e, M, LD, di, M2, LD2, di2, dadr);
+		factor_dense16_impl<G, false, NVM>(m, e, M, LD, di, M2, LD2, di2, dadr);
 	}
 }
 
 // x <- M^-1 x with the factor's columns re-read from LDS into registers; x lives one element per lane
-template <int G, bool DUAL>
+template <int G, bool DUAL, int NVM>
 DEVI void solve_dense16_impl(CModel m, const Env &e, double *x, const double *LD, const double *diaginv, double *x2,
                              const double *LD2, const double *diaginv2, const int (&dadr)[16])
 {
 	const int lane = e.lane, nv = m.nv;
 	const bool act = lane < nv;
-	double A[16], B[16];
+	double A[NVM], B[NVM];
 #pragma unroll
-	for (int i = 0; i < 16; i++) {
+	for (int i = 0; i < NVM; i++) {
 		const int a = dadr[i], ac = a >= 0 ? a : 0;
 		const double va = LD[ac], vb = DUAL ? LD2[ac] : 0.0;
 		A[i] = (a >= 0 && i != lane) ? va : 0.0;
@@ -686,25 +694,23 @@ DEVI void solve_dense16_impl(CModel m, const Env &e, double *x, const double *LD
 	const double dinv = act ? diaginv[lane] : 0.0, dinv2 = (DUAL && act) ? diaginv2[lane] : 0.0;
 	// x <- inv(L') x : dof i pushes its value down to its ancestors j < i
 #pragma unroll
-	for (int i = 15; i >= 1; i--) {
+	for (int i = NVM - 1; i >= 1; i--) {
 		if (i < nv) {
 			MJB_KEEP_BRANCH();
 			const double xi = group_bcast16(xj, i), xi2 = DUAL ? group_bcast16(xj2, i) : 0.0;
-			if (lane < i) {
-				xj -= A[i] * xi;
-				if (DUAL) xj2 -= B[i] * xi2;
-			}
+			xj -= A[i] * xi;  // A[i] == 0 in the lanes >= i
+			if (DUAL) xj2 -= B[i] * xi2;
 		}
 	}
 	xj *= dinv;
 	xj2 *= dinv2;
 	// x <- inv(L) x : row i gathers L(i, j) x_j from the lanes j < i with a 16-lane butterfly sum
 #pragma unroll
-	for (int i = 1; i < 16; i++) {
+	for (int i = 1; i < NVM; i++) {
 		if (i < nv) {
 			MJB_KEEP_BRANCH();
-			const double s = row_sum<16>(lane < i ? A[i] * xj : 0.0);
-			const double s2 = DUAL ? row_sum<16>(lane < i ? B[i] * xj2 : 0.0) : 0.0;
+			const double s = row_sum<16>(A[i] * xj);
+			const double s2 = DUAL ? row_sum<16>(B[i] * xj2) : 0.0;
 			if (lane == i) {
 				xj -= s;
 				xj2 -= s2;
@@ -718,17 +724,17 @@ DEVI void solve_dense16_impl(CModel m, const Env &e, double *x, const double *LD
 	gsync<G>();
 }
 
-template <int G>
+template <int G, int NVM>
 STAGE void solve_dense16(CModel m, const Env &e, double *x, const double *LD, const double *diaginv, double *x2,
                          const double *LD2, const double *diaginv2, bool dual, const int (&dadr)[16])
 {
 	static_assert(G == 16, "one matrix column per lane of a 16-lane env group");
 	if (dual) {
 		MJB_KEEP_BRANCH();
-		solve_dense16_impl<G, true>(m, e, x, LD, diaginv, x2, LD2, diaginv2, dadr);
+		solve_dense16_impl<G, true, NVM>(m, e, x, LD, diaginv, x2, LD2, diaginv2, dadr);
 	} else {
 		MJB_KEEP_BRANCH();
-		solve_dense16_impl<G, false>(m, e, x, LD, diaginv, x2, LD2, diaginv2, dadr);
+		solve_dense16_impl<G, false, NVM>(m, e, x, LD, diaginv, x2, LD2, diaginv2, dadr);
 	}
 }
 
@@ -1121,7 +1127,7 @@ template <int G> STAGE void fwd_actuation(CModel m, CLayout L, const Env &e)
 	gsync<G>();
 }
 
-template <int G, bool DENSE> STAGE void fwd_acceleration(CModel m, CLayout L, const Env &e, bool use_xfrc)
+template <int G, int DENSE> STAGE void fwd_acceleration(CModel m, CLayout L, const Env &e, bool use_xfrc)
 {
 	double *f = e.f;
 	for (int d = e.lane; d < m.nv; d += G) {
@@ -1156,7 +1162,7 @@ template <int G, bool DENSE> STAGE void fwd_acceleration(CModel m, CLayout L, co
 	gsync<G>();
 	const bool dual = m.eulerdamp && m.nefcmax == 0;
 	if constexpr (DENSE)
-		solve_dense16<G>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual, e.dadr);
+		solve_dense16<G, DENSE>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual, e.dadr);
 	else
 		solve2<G>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual);
 }
@@ -1312,18 +1318,18 @@ DEVI const KernelParams MJB_AS4 *launder_params(const KernelParams MJB_AS4 *p)
 		__VA_ARGS__;                                                       \
 	} while (0)
 
-template <int G, int CON, bool DENSE> DEVI void forward_first(const KernelParams MJB_AS4 *P, const Env &e, int compact)
+template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams MJB_AS4 *P, const Env &e, int compact)
 {
 	[[maybe_unused]] CState s = P->s;  // (profiling macros)
 	PROF_BEGIN();
-	VIEW(P, compact, kinematics<G, (G == 64 || DENSE)>(m, L, s, e));
+	VIEW(P, compact, kinematics<G, (G == 64 || DENSE != 0)>(m, L, s, e));
 	PROF(0);
 	VIEW(P, compact, com_pos<G>(m, L, e));
 	PROF(1);
 	VIEW(P, compact, crb<G>(m, L, e));
 	PROF(2);
 	if constexpr (DENSE)
-		VIEW(P, compact, factor_dense16<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH,
+		VIEW(P, compact, factor_dense16<G, DENSE>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH,
 		                                   e.f + L.qHdi, m.eulerdamp != 0, e.dadr));
 	else
 		VIEW(P, compact, factor2<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi,
@@ -1351,7 +1357,7 @@ template <int G, int CON, bool DENSE> DEVI void forward_first(const KernelParams
 	PROF(8);
 }
 
-template <int G, int CON, bool DENSE> DEVI void forward_rest(const KernelParams MJB_AS4 *P, const Env &e, int compact)
+template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams MJB_AS4 *P, const Env &e, int compact)
 {
 	[[maybe_unused]] CState s = P->s;  // (profiling macros)
 	PROF_BEGIN();
@@ -1390,7 +1396,7 @@ template <int G> STAGE void ctrl_noise(CModel m, CLayout L, CNoise nz, const Env
 // one env per wavefront) -- separate kernels keep each instruction stream and register budget small.
 // Constrained kernels are capped at 256 VGPRs (2 blocks/CU): with the 512-register budget ROCm 7.2's LLVM
 // spills VGPRs to AGPRs ahead of an exec restore and loses lanes (tools/check_spill_exec.py, `make lint`).
-template <int G, int CON, bool DENSE>
+template <int G, int CON, int DENSE>
 __global__ void __launch_bounds__(256, (CON ? 2 : (G == 64 ? 4 : (G == 32 ? 2 : 1))))
     mjb_step_kernel(const KernelParams MJB_AS4 *__restrict__ P, const int mode, const int nsteps,
                     const unsigned int step0, const int epb, const int frame_bytes)
@@ -1502,7 +1508,7 @@ __global__ void mjb_reset_kernel(const KernelParams MJB_AS4 *__restrict__ P, con
 	s.time[e] = 0;
 }
 
-template <int G, int CON, bool DENSE = false>
+template <int G, int CON, int DENSE = 0>
 int launch_g(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0,
              int epb, void *stream)
 {
@@ -1548,7 +1554,9 @@ int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, in
 	switch (lanes_per_env) {
 	case 8: return launch_g<8, 0>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 	case 16:
-		if (dense) return launch_g<16, 0, true>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+		if (dense == 8) return launch_g<16, 0, 8>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+		if (dense == 12) return launch_g<16, 0, 12>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+		if (dense) return launch_g<16, 0, 16>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 		return launch_g<16, 0>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 	case 32: return launch_g<32, 0>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 	case 64: return launch_g<64, 0>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
