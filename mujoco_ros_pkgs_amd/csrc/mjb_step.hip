@@ -65,12 +65,21 @@ template <int G> DEVI void gsync()
 #define EPROF(id) do { } while (0)
 #endif
 
+// Model constants of body `lane`, fetched once per kernel by the one-body-per-lane kernels (nbody <= G) instead of
+// once per stage and step (per-lane table reads are vector-memory loads: ~0.5 us of exposed latency per step each)
+struct LaneConst {
+	unsigned int dmlo, dmhi, smlo, smhi;  // ancestor-dof and subtree-body masks
+	int jntadr, jntnum, jtype, qa, simple;
+	double bpos[3], bquat[4], jaxis[3], jpos[3], q0, ipos[3], iquat[4];
+};
+
 struct Env {
 	double *f;  // LDS frame (doubles)
 	int *fi;    // LDS frame (ints)
 	int lane;   // 0..G-1
 	int env;    // batch-local env index
 	int dadr[16];  // dense kernels only: qM address of entry (i, lane) of the joint-space inertia, or -1
+	LaneConst lc;  // one-body-per-lane kernels only
 #ifdef MJB_PROFILE
 	unsigned long long *prof;
 #endif
@@ -120,32 +129,47 @@ template <int G, bool SCAN> STAGE void kinematics(CModel m, CLayout L, CState s,
 			p[0] = p[1] = p[2] = 0;
 			q[0] = 1; q[1] = q[2] = q[3] = 0;
 		} else {
-			const int jntadr = m.body_rec2[4 * b], jntnum = m.body_rec2[4 * b + 1];
-			if (jntnum == 1 && m.jnt_type[jntadr] == MJB_JNT_FREE) {
-				const int qa = m.jnt_qposadr[jntadr];
+			const int jntadr = SCAN ? e.lc.jntadr : m.body_rec2[4 * b], jntnum = SCAN ? e.lc.jntnum : m.body_rec2[4 * b + 1];
+			if (jntnum == 1 && (SCAN ? e.lc.jtype : m.jnt_type[jntadr]) == MJB_JNT_FREE) {
+				const int qa = SCAN ? e.lc.qa : m.jnt_qposadr[jntadr];
 				ld3(p, qpos + qa);
 				ld4(q, qpos + qa + 3);
 				normalize4(q);
 				st4(qpos + qa + 3, q);
 				double ax[3];
-				ldc3(ax, m.jnt_axis + 3 * jntadr);
+				if constexpr (SCAN) {
+					ax[0] = e.lc.jaxis[0]; ax[1] = e.lc.jaxis[1]; ax[2] = e.lc.jaxis[2];
+				} else {
+					ldc3(ax, m.jnt_axis + 3 * jntadr);
+				}
 				st3(xanchor + 3 * jntadr, p);
 				st3(xaxis + 3 * jntadr, ax);
 			} else {
-				ldc3(p, m.body_pos + 3 * b);
-				ldc4(q, m.body_quat + 4 * b);
+				if constexpr (SCAN) {
+					for (int k = 0; k < 3; k++) p[k] = e.lc.bpos[k];
+					for (int k = 0; k < 4; k++) q[k] = e.lc.bquat[k];
+				} else {
+					ldc3(p, m.body_pos + 3 * b);
+					ldc4(q, m.body_quat + 4 * b);
+				}
 				for (int j = jntadr; j < jntadr + jntnum; j++) {
-					const int qa = m.jnt_qposadr[j], jt = m.jnt_type[j];
+					const bool hit = SCAN && j == jntadr;  // the body's first joint sits in the lane's registers
+					const int qa = hit ? e.lc.qa : m.jnt_qposadr[j], jt = hit ? e.lc.jtype : m.jnt_type[j];
+					const double q0 = hit ? e.lc.q0 : m.qpos0[qa];
 					double jaxis[3], jpos[3], ax[3], an[3];
-					ldc3(jaxis, m.jnt_axis + 3 * j);
-					ldc3(jpos, m.jnt_pos + 3 * j);
+					if (hit) {
+						for (int k = 0; k < 3; k++) { jaxis[k] = e.lc.jaxis[k]; jpos[k] = e.lc.jpos[k]; }
+					} else {
+						ldc3(jaxis, m.jnt_axis + 3 * j);
+						ldc3(jpos, m.jnt_pos + 3 * j);
+					}
 					rotvec_quat(ax, jaxis, q);
 					rotvec_quat(an, jpos, q);
 					an[0] += p[0]; an[1] += p[1]; an[2] += p[2];
 					st3(xaxis + 3 * j, ax);
 					st3(xanchor + 3 * j, an);
 					if (jt == MJB_JNT_SLIDE) {
-						const double sl = qpos[qa] - m.qpos0[qa];
+						const double sl = qpos[qa] - q0;
 						p[0] += ax[0] * sl; p[1] += ax[1] * sl; p[2] += ax[2] * sl;
 					} else {
 						double ql[4], v[3];
@@ -154,7 +178,7 @@ template <int G, bool SCAN> STAGE void kinematics(CModel m, CLayout L, CState s,
 							normalize4(ql);
 							st4(qpos + qa, ql);
 						} else {
-							axis_angle_quat(ql, jaxis, qpos[qa] - m.qpos0[qa]);
+							axis_angle_quat(ql, jaxis, qpos[qa] - q0);
 						}
 						qmul(q, q, ql);
 						rotvec_quat(v, jpos, q);
@@ -254,13 +278,18 @@ template <int G, bool SCAN> STAGE void kinematics(CModel m, CLayout L, CState s,
 		st4(xquat + 4 * b, q);
 		st9(xmat + 9 * b, M);
 		double *oip = f + L.xipos + 3 * b, *oim = f + L.ximat + 9 * b;
-		if (b == 0 || m.body_rec2[4 * b + 2]) {
+		if (b == 0 || (SCAN ? e.lc.simple : m.body_rec2[4 * b + 2])) {
 			st3(oip, p);
 			st9(oim, M);
 		} else {
 			double ip[3], iq[4], v[3], r[9];
-			ldc3(ip, m.body_ipos + 3 * b);
-			ldc4(iq, m.body_iquat + 4 * b);
+			if constexpr (SCAN) {
+				for (int k = 0; k < 3; k++) ip[k] = e.lc.ipos[k];
+				for (int k = 0; k < 4; k++) iq[k] = e.lc.iquat[k];
+			} else {
+				ldc3(ip, m.body_ipos + 3 * b);
+				ldc4(iq, m.body_iquat + 4 * b);
+			}
 			matvec3(v, M, ip);
 			v[0] += p[0]; v[1] += p[1]; v[2] += p[2];
 			qmul(iq, q, iq);
@@ -316,7 +345,7 @@ template <int G, bool SCAN> STAGE void kinematics(CModel m, CLayout L, CState s,
 // bit i of a 64-bit mask stored as two ints (host-built ancestor-dof / subtree-body masks; nv, nbody <= 64)
 DEVI bool maskbit(unsigned int lo, unsigned int hi, int i) { return ((i < 32 ? lo >> i : hi >> (i - 32)) & 1u) != 0; }
 
-template <int G> STAGE void com_pos(CModel m, CLayout L, const Env &e)
+template <int G, bool OBL> STAGE void com_pos(CModel m, CLayout L, const Env &e)
 {
 	double *f = e.f;
 	double *sc = f + L.subtree_com, *xipos = f + L.xipos;
@@ -324,7 +353,7 @@ template <int G> STAGE void com_pos(CModel m, CLayout L, const Env &e)
 	// lane = body: mass-weighted sum over the bodies of its subtree (host-built mask) -- no walk up the tree, every
 	// lane reads the same xipos / mass sequence (LDS broadcast + scalar loads) and keeps what its mask selects
 	for (int b = lane; b < m.nbody; b += G) {
-		const unsigned int lo = (unsigned int)m.body_submask[2 * b], hi = (unsigned int)m.body_submask[2 * b + 1];
+		const unsigned int lo = OBL ? e.lc.smlo : (unsigned int)m.body_submask[2 * b], hi = OBL ? e.lc.smhi : (unsigned int)m.body_submask[2 * b + 1];
 		double s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll 4
 		for (int i = 0; i < m.nbody; i++) {
@@ -777,14 +806,14 @@ DEVI void cvel_before(CModel m, CLayout L, const double *f, int b, int dstop, do
 	}
 }
 
-template <int G> STAGE void com_vel(CModel m, CLayout L, const Env &e)
+template <int G, bool OBL> STAGE void com_vel(CModel m, CLayout L, const Env &e)
 {
 	double *f = e.f;
 	double *cvel = f + L.cvel, *cdof = f + L.cdof, *qvel = f + L.qvel;
 	const int lane = e.lane;
 	// lane = body: cvel = sum of cdof_d qvel_d over the dofs that move the body (ancestor mask, root to leaf order)
 	for (int b = lane; b < m.nbody; b += G) {
-		const unsigned int lo = (unsigned int)m.body_dofmask[2 * b], hi = (unsigned int)m.body_dofmask[2 * b + 1];
+		const unsigned int lo = OBL ? e.lc.dmlo : (unsigned int)m.body_dofmask[2 * b], hi = OBL ? e.lc.dmhi : (unsigned int)m.body_dofmask[2 * b + 1];
 		double v[6] = { 0, 0, 0, 0, 0, 0 };
 #pragma unroll 3
 		for (int d = 0; d < m.nv; d++) {
@@ -859,7 +888,7 @@ template <int G> STAGE void passive(CModel m, CLayout L, const Env &e)
 // ------------------------------------------------------------------------------------------------
 // A9  RNE with zero acceleration: qfrc_bias
 // ------------------------------------------------------------------------------------------------
-template <int G> STAGE void rne(CModel m, CLayout L, const Env &e)
+template <int G, bool OBL> STAGE void rne(CModel m, CLayout L, const Env &e)
 {
 	double *f = e.f;
 	double *cacc = f + L.cacc, *cfrc = f + L.cfrc_body, *cdd = f + L.cdof_dot, *qvel = f + L.qvel;
@@ -868,7 +897,7 @@ template <int G> STAGE void rne(CModel m, CLayout L, const Env &e)
 	// lane = body: cacc = -gravity + sum of cdof_dot_d qvel_d over the dofs that move the body, then the body's own
 	// inertial force  I a + v x* (I v)   (cfrc_body holds the per-body force, not its subtree sum)
 	for (int b = lane; b < m.nbody; b += G) {
-		const unsigned int lo = (unsigned int)m.body_dofmask[2 * b], hi = (unsigned int)m.body_dofmask[2 * b + 1];
+		const unsigned int lo = OBL ? e.lc.dmlo : (unsigned int)m.body_dofmask[2 * b], hi = OBL ? e.lc.dmhi : (unsigned int)m.body_dofmask[2 * b + 1];
 		double a[6] = { 0, 0, 0, grav ? -m.gravity[0] : 0.0, grav ? -m.gravity[1] : 0.0, grav ? -m.gravity[2] : 0.0 };
 #pragma unroll 3
 		for (int d = 0; d < m.nv; d++) {
@@ -1324,7 +1353,7 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 	PROF_BEGIN();
 	VIEW(P, compact, kinematics<G, (G == 64 || DENSE != 0)>(m, L, s, e));
 	PROF(0);
-	VIEW(P, compact, com_pos<G>(m, L, e));
+	VIEW(P, compact, com_pos<G, (G == 64 || DENSE != 0)>(m, L, e));
 	PROF(1);
 	VIEW(P, compact, crb<G>(m, L, e));
 	PROF(2);
@@ -1346,12 +1375,12 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 	VIEW(P, compact, transmission<G>(m, L, e));
 	VIEW(P, compact, sensors<G>(m, L, e, MJB_STAGE_POS, compact));
 	PROF(4);
-	VIEW(P, compact, com_vel<G>(m, L, e));
+	VIEW(P, compact, com_vel<G, (G == 64 || DENSE != 0)>(m, L, e));
 	PROF(5);
 	VIEW(P, compact, passive<G>(m, L, e));
 	PROF(6);
 	if constexpr (CON) VIEW(P, compact, reference_constraint<G>(m, L, e));
-	VIEW(P, compact, rne<G>(m, L, e));
+	VIEW(P, compact, rne<G, (G == 64 || DENSE != 0)>(m, L, e));
 	PROF(7);
 	VIEW(P, compact, sensors<G>(m, L, e, MJB_STAGE_VEL, compact));
 	PROF(8);
@@ -1418,6 +1447,27 @@ __global__ void __launch_bounds__(256, (CON ? 2 : (G == 64 ? 4 : (G == 32 ? 2 : 
 	if constexpr (DENSE) {
 #pragma unroll
 		for (int i = 0; i < 16; i++) e.dadr[i] = m.M_dense[16 * i + e.lane];
+	}
+	if constexpr (G == 64 || DENSE != 0) {
+		const int b = e.lane < m.nbody ? e.lane : 0;
+		LaneConst &c = e.lc;
+		c.dmlo = (unsigned int)m.body_dofmask[2 * b]; c.dmhi = (unsigned int)m.body_dofmask[2 * b + 1];
+		c.smlo = (unsigned int)m.body_submask[2 * b]; c.smhi = (unsigned int)m.body_submask[2 * b + 1];
+		c.jntadr = m.body_rec2[4 * b]; c.jntnum = m.body_rec2[4 * b + 1]; c.simple = m.body_rec2[4 * b + 2];
+		const int j = (b && c.jntnum > 0) ? c.jntadr : 0;
+		c.jtype = m.njnt ? m.jnt_type[j] : 0;
+		c.qa = m.njnt ? m.jnt_qposadr[j] : 0;
+		c.q0 = m.njnt ? m.qpos0[c.qa] : 0.0;
+		for (int k = 0; k < 3; k++) {
+			c.bpos[k] = m.body_pos[3 * b + k];
+			c.ipos[k] = m.body_ipos[3 * b + k];
+			c.jaxis[k] = m.njnt ? m.jnt_axis[3 * j + k] : 0.0;
+			c.jpos[k] = m.njnt ? m.jnt_pos[3 * j + k] : 0.0;
+		}
+		for (int k = 0; k < 4; k++) {
+			c.bquat[k] = m.body_quat[4 * b + k];
+			c.iquat[k] = m.body_iquat[4 * b + k];
+		}
 	}
 	e.f = reinterpret_cast<double *>(smem + (size_t)slot * frame_bytes);
 	e.fi = reinterpret_cast<int *>(e.f + L.ndouble);
