@@ -65,7 +65,7 @@ template <int G> DEVI void gsync()
 #define EPROF(id) do { } while (0)
 #endif
 
-// Model constants of body `lane`, fetched once per kernel by the one-body-per-lane kernels (nbody <= G) instead of
+// Model constants of body `lane`, fetched once per kernel by the dense kernels (nbody <= 16 = G; 512 VGPRs to spend) instead of
 // once per stage and step (per-lane table reads are vector-memory loads: ~0.5 us of exposed latency per step each)
 struct LaneConst {
 	unsigned int dmlo, dmhi, smlo, smhi;  // ancestor-dof and subtree-body masks
@@ -111,7 +111,7 @@ DEVI void local2global(const double *xpos_b, const double *xquat_b, const double
 	}
 }
 
-template <int G, bool SCAN> STAGE void kinematics(CModel m, CLayout L, CState s, const Env &e)
+template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout L, CState s, const Env &e)
 {
 	PROF_BEGIN();
 	double *f = e.f;
@@ -129,15 +129,15 @@ template <int G, bool SCAN> STAGE void kinematics(CModel m, CLayout L, CState s,
 			p[0] = p[1] = p[2] = 0;
 			q[0] = 1; q[1] = q[2] = q[3] = 0;
 		} else {
-			const int jntadr = SCAN ? e.lc.jntadr : m.body_rec2[4 * b], jntnum = SCAN ? e.lc.jntnum : m.body_rec2[4 * b + 1];
-			if (jntnum == 1 && (SCAN ? e.lc.jtype : m.jnt_type[jntadr]) == MJB_JNT_FREE) {
-				const int qa = SCAN ? e.lc.qa : m.jnt_qposadr[jntadr];
+			const int jntadr = CACHE ? e.lc.jntadr : m.body_rec2[4 * b], jntnum = CACHE ? e.lc.jntnum : m.body_rec2[4 * b + 1];
+			if (jntnum == 1 && (CACHE ? e.lc.jtype : m.jnt_type[jntadr]) == MJB_JNT_FREE) {
+				const int qa = CACHE ? e.lc.qa : m.jnt_qposadr[jntadr];
 				ld3(p, qpos + qa);
 				ld4(q, qpos + qa + 3);
 				normalize4(q);
 				st4(qpos + qa + 3, q);
 				double ax[3];
-				if constexpr (SCAN) {
+				if constexpr (CACHE) {
 					ax[0] = e.lc.jaxis[0]; ax[1] = e.lc.jaxis[1]; ax[2] = e.lc.jaxis[2];
 				} else {
 					ldc3(ax, m.jnt_axis + 3 * jntadr);
@@ -145,7 +145,7 @@ template <int G, bool SCAN> STAGE void kinematics(CModel m, CLayout L, CState s,
 				st3(xanchor + 3 * jntadr, p);
 				st3(xaxis + 3 * jntadr, ax);
 			} else {
-				if constexpr (SCAN) {
+				if constexpr (CACHE) {
 					for (int k = 0; k < 3; k++) p[k] = e.lc.bpos[k];
 					for (int k = 0; k < 4; k++) q[k] = e.lc.bquat[k];
 				} else {
@@ -153,7 +153,7 @@ template <int G, bool SCAN> STAGE void kinematics(CModel m, CLayout L, CState s,
 					ldc4(q, m.body_quat + 4 * b);
 				}
 				for (int j = jntadr; j < jntadr + jntnum; j++) {
-					const bool hit = SCAN && j == jntadr;  // the body's first joint sits in the lane's registers
+					const bool hit = CACHE && j == jntadr;  // the body's first joint sits in the lane's registers
 					const int qa = hit ? e.lc.qa : m.jnt_qposadr[j], jt = hit ? e.lc.jtype : m.jnt_type[j];
 					const double q0 = hit ? e.lc.q0 : m.qpos0[qa];
 					double jaxis[3], jpos[3], ax[3], an[3];
@@ -278,12 +278,12 @@ template <int G, bool SCAN> STAGE void kinematics(CModel m, CLayout L, CState s,
 		st4(xquat + 4 * b, q);
 		st9(xmat + 9 * b, M);
 		double *oip = f + L.xipos + 3 * b, *oim = f + L.ximat + 9 * b;
-		if (b == 0 || (SCAN ? e.lc.simple : m.body_rec2[4 * b + 2])) {
+		if (b == 0 || (CACHE ? e.lc.simple : m.body_rec2[4 * b + 2])) {
 			st3(oip, p);
 			st9(oim, M);
 		} else {
 			double ip[3], iq[4], v[3], r[9];
-			if constexpr (SCAN) {
+			if constexpr (CACHE) {
 				for (int k = 0; k < 3; k++) ip[k] = e.lc.ipos[k];
 				for (int k = 0; k < 4; k++) iq[k] = e.lc.iquat[k];
 			} else {
@@ -1351,9 +1351,9 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 {
 	[[maybe_unused]] CState s = P->s;  // (profiling macros)
 	PROF_BEGIN();
-	VIEW(P, compact, kinematics<G, (G == 64 || DENSE != 0)>(m, L, s, e));
+	VIEW(P, compact, kinematics<G, (G == 64 || DENSE != 0), (DENSE != 0)>(m, L, s, e));
 	PROF(0);
-	VIEW(P, compact, com_pos<G, (G == 64 || DENSE != 0)>(m, L, e));
+	VIEW(P, compact, com_pos<G, (DENSE != 0)>(m, L, e));
 	PROF(1);
 	VIEW(P, compact, crb<G>(m, L, e));
 	PROF(2);
@@ -1375,12 +1375,12 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 	VIEW(P, compact, transmission<G>(m, L, e));
 	VIEW(P, compact, sensors<G>(m, L, e, MJB_STAGE_POS, compact));
 	PROF(4);
-	VIEW(P, compact, com_vel<G, (G == 64 || DENSE != 0)>(m, L, e));
+	VIEW(P, compact, com_vel<G, (DENSE != 0)>(m, L, e));
 	PROF(5);
 	VIEW(P, compact, passive<G>(m, L, e));
 	PROF(6);
 	if constexpr (CON) VIEW(P, compact, reference_constraint<G>(m, L, e));
-	VIEW(P, compact, rne<G, (G == 64 || DENSE != 0)>(m, L, e));
+	VIEW(P, compact, rne<G, (DENSE != 0)>(m, L, e));
 	PROF(7);
 	VIEW(P, compact, sensors<G>(m, L, e, MJB_STAGE_VEL, compact));
 	PROF(8);
@@ -1448,7 +1448,7 @@ __global__ void __launch_bounds__(256, (CON ? 2 : (G == 64 ? 4 : (G == 32 ? 2 : 
 #pragma unroll
 		for (int i = 0; i < 16; i++) e.dadr[i] = m.M_dense[16 * i + e.lane];
 	}
-	if constexpr (G == 64 || DENSE != 0) {
+	if constexpr (DENSE != 0) {
 		const int b = e.lane < m.nbody ? e.lane : 0;
 		LaneConst &c = e.lc;
 		c.dmlo = (unsigned int)m.body_dofmask[2 * b]; c.dmhi = (unsigned int)m.body_dofmask[2 * b + 1];
