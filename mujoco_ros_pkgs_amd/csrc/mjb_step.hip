@@ -130,7 +130,12 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 			q[0] = 1; q[1] = q[2] = q[3] = 0;
 		} else {
 			const int jntadr = CACHE ? e.lc.jntadr : m.body_rec2[4 * b], jntnum = CACHE ? e.lc.jntnum : m.body_rec2[4 * b + 1];
-			if (jntnum == 1 && (CACHE ? e.lc.jtype : m.jnt_type[jntadr]) == MJB_JNT_FREE) {
+			const int mid = m.nmocap > 0 ? m.body_mocapid[b] : -1;
+			if (mid >= 0) {  // mocap body: pose straight from the (normalised) mocap fields, as mj_kinematics does
+				ld3(p, f + L.mocap_pos + 3 * mid);
+				ld4(q, f + L.mocap_quat + 4 * mid);
+				normalize4(q);
+			} else if (jntnum == 1 && (CACHE ? e.lc.jtype : m.jnt_type[jntadr]) == MJB_JNT_FREE) {
 				const int qa = CACHE ? e.lc.qa : m.jnt_qposadr[jntadr];
 				ld3(p, qpos + qa);
 				ld4(q, qpos + qa + 3);
@@ -1282,6 +1287,8 @@ template <int G> STAGE void load_state(CModel m, CLayout L, CState s, const Env 
 	copy_in<G>(e.f + L.qfrc_applied, s.qfrc_applied + env * m.nv, m.nv, e.lane);
 	if (s.use_xfrc) copy_in<G>(e.f + L.xfrc_applied, s.xfrc_applied + env * 6 * m.nbody, 6 * m.nbody, e.lane);
 	copy_in<G>(e.f + L.ctrlnoise, s.ctrlnoise + env * m.nu, m.nu, e.lane);
+	copy_in<G>(e.f + L.mocap_pos, s.mocap_pos + env * 3 * m.nmocap, 3 * m.nmocap, e.lane);
+	copy_in<G>(e.f + L.mocap_quat, s.mocap_quat + env * 4 * m.nmocap, 4 * m.nmocap, e.lane);
 	if (e.lane == 0) e.f[L.time] = s.time[env];
 }
 
@@ -1319,6 +1326,12 @@ template <int G> STAGE void reset_frame_state(CModel m, CLayout L, CState s, con
 	for (int k = e.lane; k < L.nstate; k += G) f[k] = 0;  // state prefix starts at offset 0
 	gsync<G>();
 	for (int k = e.lane; k < m.nq; k += G) f[L.qpos + k] = m.qpos0[k];
+	for (int b = e.lane; b < m.nbody; b += G) {
+		const int mid = m.body_mocapid[b];
+		if (mid < 0) continue;
+		for (int k = 0; k < 3; k++) f[L.mocap_pos + 3 * mid + k] = m.body_pos[3 * b + k];
+		for (int k = 0; k < 4; k++) f[L.mocap_quat + 4 * mid + k] = m.body_quat[4 * b + k];
+	}
 	if (e.lane == 0) atomicAdd(s.nwarn, 1ull);
 	gsync<G>();
 }
@@ -1555,6 +1568,12 @@ __global__ void mjb_reset_kernel(const KernelParams MJB_AS4 *__restrict__ P, con
 	}
 	for (int k = 0; k < 6 * m.nbody; k++) s.xfrc_applied[e * 6 * m.nbody + k] = 0;
 	for (int k = 0; k < m.nsensordata; k++) s.sensordata[e * m.nsensordata + k] = 0;
+	for (int b = 0; b < m.nbody; b++) {
+		const int mid = m.body_mocapid[b];
+		if (mid < 0) continue;
+		for (int k = 0; k < 3; k++) s.mocap_pos[(e * m.nmocap + mid) * 3 + k] = m.body_pos[3 * b + k];
+		for (int k = 0; k < 4; k++) s.mocap_quat[(e * m.nmocap + mid) * 4 + k] = m.body_quat[4 * b + k];
+	}
 	s.time[e] = 0;
 }
 

@@ -348,8 +348,9 @@ class _Compiler:
             b = dict(name=a.get("name", f"body{bid}"), parent=parent,
                      pos=_floats(a.get("pos", "0 0 0"), 3, "body pos"),
                      quat=self._orientation(a, "body"), inertial=None, joints=[], geoms=[], sites=[])
-            if a.get("mocap", "false") == "true":
-                raise MjcfError("mocap bodies are not supported")
+            b["mocap"] = a.get("mocap", "false") == "true"
+            if b["mocap"] and parent != 0:
+                raise MjcfError(f"mocap body '{b['name']}' must be a child of the world")
             childclass = a.get("childclass", childclass)
         self.bodies.append(b)
         for ch in node:
@@ -588,6 +589,17 @@ class _Compiler:
 
         I, D = np.int32, np.float64
         m["body_parentid"] = np.array([b["parent"] for b in B], I)
+        mocapid, nmocap = [], 0
+        for b in B:
+            if b.get("mocap"):
+                if b["joints"]:
+                    raise MjcfError(f"mocap body '{b['name']}' cannot have joints")
+                mocapid.append(nmocap)
+                nmocap += 1
+            else:
+                mocapid.append(-1)
+        m["body_mocapid"] = np.array(mocapid, I)
+        m["nmocap"] = nmocap
         m["body_pos"] = np.array([b["pos"] for b in B], D).reshape(nbody, 3)
         m["body_quat"] = np.array([b["quat"] for b in B], D).reshape(nbody, 4)
         body_jntnum = np.zeros(nbody, I)

@@ -119,6 +119,12 @@ void mjo_reset_data(const mjb_model_desc *m, mjo_data *d)
 #undef MJB_DD2
 #undef MJB_DI
 	memcpy(d->qpos, m->qpos0, sizeof(double) * (size_t)m->nq);
+	for (int b = 0; b < m->nbody && m->nmocap > 0; b++) {
+		int mid = m->body_mocapid[b];
+		if (mid < 0) continue;
+		memcpy(d->mocap_pos + 3 * mid, m->body_pos + 3 * b, 3 * sizeof(double));
+		memcpy(d->mocap_quat + 4 * mid, m->body_quat + 4 * b, 4 * sizeof(double));
+	}
 }
 
 /* ------------------------------------------------------------------ A1: mj_kinematics */
@@ -160,7 +166,13 @@ void mjo_kinematics(const mjb_model_desc *m, mjo_data *d)
 		double xpos[3], xquat[4];
 		int pid = m->body_parentid[i];
 		int jntadr = m->body_jntadr[i], jntnum = m->body_jntnum[i];
-		if (jntnum == 1 && m->jnt_type[jntadr] == MJB_JNT_FREE) {
+		int mid = m->nmocap > 0 ? m->body_mocapid[i] : -1;
+		if (mid >= 0) {
+			/* mocap body (child of the world, no joints): pose from the mocap fields, quaternion normalised */
+			v3_copy(xpos, d->mocap_pos + 3 * mid);
+			memcpy(xquat, d->mocap_quat + 4 * mid, 4 * sizeof(double));
+			q_normalize(xquat);
+		} else if (jntnum == 1 && m->jnt_type[jntadr] == MJB_JNT_FREE) {
 			int qadr = m->jnt_qposadr[jntadr];
 			v3_copy(xpos, d->qpos + qadr);
 			memcpy(xquat, d->qpos + qadr + 3, 4 * sizeof(double));
