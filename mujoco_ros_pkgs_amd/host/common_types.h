@@ -47,6 +47,7 @@ struct mjData {
 	mjtNum *qpos, *qvel, *ctrl, *qacc, *qacc_warmstart;
 	mjtNum *qfrc_applied, *xfrc_applied, *qfrc_passive;  // callback-writable force fields (plugin_utils.h:91,101)
 	mjtNum *sensordata;
+	mjtNum *mocap_pos, *mocap_quat;  // written by the mocap plugin (mocap_plugin.cpp:102-103)
 	mjtNum *xpos, *xquat, *xmat, *xipos, *ximat, *cvel, *subtree_com, *site_xpos, *site_xmat, *geom_xpos, *geom_xmat;
 	mjtNum *actuator_force, *qfrc_bias, *qfrc_actuator;
 };
