@@ -186,6 +186,199 @@ DEVI int capsule_box(RawCon *rc, const double *pos1, const double *mat1, const d
 	return n;
 }
 
+// box - box: same steps as oracle/mjo_constraint.c box_box (separating axes, then either the incident face clipped
+// against the reference face -- up to 4 contacts after reduction -- or one edge-edge contact)
+DEVI int box_box(RawCon *rc, const double *pos1, const double *mat1, const double *size1, const double *pos2,
+                 const double *mat2, const double *size2, double margin)
+{
+	double A[3][3], B[3][3], C[3][3], Q[3][3], tA[3], tB[3];
+	for (int i = 0; i < 3; i++)
+		for (int k = 0; k < 3; k++) {
+			A[i][k] = mat1[3 * k + i];
+			B[i][k] = mat2[3 * k + i];
+		}
+	const double t[3] = { pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2] };
+	for (int i = 0; i < 3; i++) {
+		tA[i] = dot3(t, A[i]);
+		tB[i] = dot3(t, B[i]);
+		for (int j = 0; j < 3; j++) {
+			C[i][j] = dot3(A[i], B[j]);
+			Q[i][j] = fabs(C[i][j]) + 1e-12;
+		}
+	}
+	double best = -1e300;
+	int code = -1;
+	for (int i = 0; i < 3; i++) {
+		const double s = fabs(tA[i]) - (size1[i] + size2[0] * Q[i][0] + size2[1] * Q[i][1] + size2[2] * Q[i][2]);
+		if (s > margin) return 0;
+		if (s > best) { best = s; code = i; }
+	}
+	for (int j = 0; j < 3; j++) {
+		const double s = fabs(tB[j]) - (size2[j] + size1[0] * Q[0][j] + size1[1] * Q[1][j] + size1[2] * Q[2][j]);
+		if (s > margin) return 0;
+		if (s > best) { best = s; code = 3 + j; }
+	}
+	double ebest = -1e300;
+	int ecode = -1;
+	for (int i = 0; i < 3; i++)
+		for (int j = 0; j < 3; j++) {
+			const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+			const double l = sqrt(fmax(0.0, 1.0 - C[i][j] * C[i][j]));
+			if (l < 1e-6) continue;
+			double s = fabs(tA[i2] * C[i1][j] - tA[i1] * C[i2][j]) -
+			           (size1[i1] * Q[i2][j] + size1[i2] * Q[i1][j] + size2[j1] * Q[i][j2] + size2[j2] * Q[i][j1]);
+			s /= l;
+			if (s > margin) return 0;
+			if (s > ebest) { ebest = s; ecode = 6 + 3 * i + j; }
+		}
+	if (ecode >= 0 && ebest > best + 0.05 * fabs(best) + 1e-9) {
+		const int i = (ecode - 6) / 3, j = (ecode - 6) % 3;
+		double n[3];
+		cross3(n, A[i], B[j]);
+		normalize3(n);
+		if (dot3(n, t) < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+		double pa[3] = { pos1[0], pos1[1], pos1[2] }, pb[3] = { pos2[0], pos2[1], pos2[2] };
+		for (int k = 0; k < 3; k++) {
+			if (k != i) {
+				const double sg = dot3(n, A[k]) > 0 ? 1.0 : -1.0;
+				for (int q = 0; q < 3; q++) pa[q] += sg * size1[k] * A[k][q];
+			}
+			if (k != j) {
+				const double sg = dot3(n, B[k]) > 0 ? -1.0 : 1.0;
+				for (int q = 0; q < 3; q++) pb[q] += sg * size2[k] * B[k][q];
+			}
+		}
+		const double d[3] = { pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2] };
+		const double uaub = C[i][j], q1 = dot3(A[i], d), q2 = -dot3(B[j], d), den = 1 - uaub * uaub;
+		double al = 0, be = 0;
+		if (den > 1e-12) {
+			al = (q1 + uaub * q2) / den;
+			be = (uaub * q1 + q2) / den;
+		}
+		al = clipd(al, -size1[i], size1[i]);
+		be = clipd(be, -size2[j], size2[j]);
+		double xa[3], xb[3];
+		for (int q = 0; q < 3; q++) {
+			xa[q] = pa[q] + al * A[i][q];
+			xb[q] = pb[q] + be * B[j][q];
+		}
+		const double dv[3] = { xb[0] - xa[0], xb[1] - xa[1], xb[2] - xa[2] };
+		RawCon &c = rc[0];
+		c.dist = dot3(dv, n);
+		if (c.dist > margin) return 0;
+		c.frame[0] = n[0]; c.frame[1] = n[1]; c.frame[2] = n[2];
+		c.frame[3] = c.frame[4] = c.frame[5] = 0;
+		for (int q = 0; q < 3; q++) c.pos[q] = 0.5 * (xa[q] + xb[q]);
+		return 1;
+	}
+	const bool ref1 = code < 3;
+	const int ax = ref1 ? code : code - 3;
+	double R[3][3], O[3][3], pr[3], po[3], hr[3], ho[3];
+	for (int i = 0; i < 3; i++) {
+		pr[i] = ref1 ? pos1[i] : pos2[i];
+		po[i] = ref1 ? pos2[i] : pos1[i];
+		hr[i] = ref1 ? size1[i] : size2[i];
+		ho[i] = ref1 ? size2[i] : size1[i];
+		for (int k = 0; k < 3; k++) {
+			R[i][k] = ref1 ? A[i][k] : B[i][k];
+			O[i][k] = ref1 ? B[i][k] : A[i][k];
+		}
+	}
+	double nref[3];
+	{
+		const double sg = (ref1 ? tA[ax] : -tB[ax]) >= 0 ? 1.0 : -1.0;
+		for (int q = 0; q < 3; q++) nref[q] = sg * R[ax][q];
+	}
+	int k = 0;
+	double kbest = -1;
+	for (int q = 0; q < 3; q++) {
+		const double a = fabs(dot3(O[q], nref));
+		if (a > kbest) { kbest = a; k = q; }
+	}
+	const double fs = dot3(O[k], nref) > 0 ? -1.0 : 1.0;
+	const int u = (k + 1) % 3, v = (k + 2) % 3, sx = (ax + 1) % 3, sy = (ax + 2) % 3;
+	double poly[8][3], tmp[8][3];
+	int np = 4;
+	for (int w = 0; w < 4; w++) {
+		const double su = (w == 0 || w == 3) ? 1.0 : -1.0, sv = (w < 2) ? 1.0 : -1.0;
+		double d[3];
+		for (int q = 0; q < 3; q++) d[q] = po[q] + fs * ho[k] * O[k][q] + su * ho[u] * O[u][q] + sv * ho[v] * O[v][q] - pr[q];
+		poly[w][0] = dot3(d, R[sx]);
+		poly[w][1] = dot3(d, R[sy]);
+		poly[w][2] = dot3(d, nref) - hr[ax];
+	}
+	for (int side = 0; side < 4; side++) {
+		const int cax = side >> 1;
+		const double sgn = (side & 1) ? -1.0 : 1.0, lim = cax == 0 ? hr[sx] : hr[sy];
+		int nn = 0;
+		for (int w = 0; w < np; w++) {
+			const int w1 = (w + 1 == np) ? 0 : w + 1;
+			const double d0 = sgn * poly[w][cax] - lim, d1 = sgn * poly[w1][cax] - lim;
+			if (d0 <= 0 && nn < 8) {
+				for (int q = 0; q < 3; q++) tmp[nn][q] = poly[w][q];
+				nn++;
+			}
+			if (((d0 < 0 && d1 > 0) || (d0 > 0 && d1 < 0)) && nn < 8) {
+				const double fr = d0 / (d0 - d1);
+				for (int q = 0; q < 3; q++) tmp[nn][q] = poly[w][q] + fr * (poly[w1][q] - poly[w][q]);
+				nn++;
+			}
+		}
+		np = nn;
+		for (int w = 0; w < 8; w++)
+			for (int q = 0; q < 3; q++) poly[w][q] = tmp[w][q];
+		if (np == 0) return 0;
+	}
+	int nk = 0;
+	for (int w = 0; w < np; w++)
+		if (poly[w][2] < margin) {
+			for (int q = 0; q < 3; q++) tmp[nk][q] = poly[w][q];
+			nk++;
+		}
+	if (nk == 0) return 0;
+	int pick[4] = { 0, 0, 0, 0 }, npick = 0;
+	if (nk <= 4) {
+		for (int w = 0; w < nk; w++) pick[npick++] = w;
+	} else {
+		int a = 0;
+		for (int w = 1; w < nk; w++)
+			if (tmp[w][2] < tmp[a][2]) a = w;
+		int b = a;
+		double far = -1;
+		for (int w = 0; w < nk; w++) {
+			const double dx = tmp[w][0] - tmp[a][0], dy = tmp[w][1] - tmp[a][1], dd = dx * dx + dy * dy;
+			if (dd > far) { far = dd; b = w; }
+		}
+		int cpos = -1, cneg = -1;
+		double apos = 0, aneg = 0;
+		for (int w = 0; w < nk; w++) {
+			if (w == a || w == b) continue;
+			const double cr = (tmp[b][0] - tmp[a][0]) * (tmp[w][1] - tmp[a][1]) - (tmp[b][1] - tmp[a][1]) * (tmp[w][0] - tmp[a][0]);
+			if (cr > apos) { apos = cr; cpos = w; }
+			if (cr < aneg) { aneg = cr; cneg = w; }
+		}
+		pick[npick++] = a;
+		pick[npick++] = b;
+		if (cpos >= 0) pick[npick++] = cpos;
+		if (cneg >= 0) pick[npick++] = cneg;
+	}
+	for (int w = 0; w < 4; w++) {
+		if (w >= npick) break;
+		const double *pv = tmp[pick[w]];
+		RawCon c;
+		c.dist = pv[2];
+		for (int q = 0; q < 3; q++) c.frame[q] = ref1 ? nref[q] : -nref[q];
+		c.frame[3] = c.frame[4] = c.frame[5] = 0;
+		const double hgt = hr[ax] + 0.5 * pv[2];
+		for (int q = 0; q < 3; q++) c.pos[q] = pr[q] + pv[0] * R[sx][q] + pv[1] * R[sy][q] + hgt * nref[q];
+		if (w == 0) rc[0] = c;
+		else if (w == 1) rc[1] = c;
+		else if (w == 2) rc[2] = c;
+		else rc[3] = c;
+	}
+	return npick;
+}
+
 // narrow phase of one candidate pair; returns the number of raw contacts (<= 4)
 DEVI int narrowphase(int t1, int t2, const double *pos1, const double *mat1, const double *size1, const double *pos2,
                      const double *mat2, const double *size2, double margin, RawCon *rc)
@@ -242,6 +435,8 @@ DEVI int narrowphase(int t1, int t2, const double *pos1, const double *mat1, con
 		}
 	} else if (t1 == MJB_GEOM_CAPSULE && t2 == MJB_GEOM_BOX) {
 		n = capsule_box(rc, pos1, mat1, size1, pos2, mat2, size2, margin);
+	} else if (t1 == MJB_GEOM_BOX && t2 == MJB_GEOM_BOX) {
+		n = box_box(rc, pos1, mat1, size1, pos2, mat2, size2, margin);
 	} else if (t1 == MJB_GEOM_CAPSULE && t2 == MJB_GEOM_CAPSULE) {
 		const double a1[3] = { mat1[2], mat1[5], mat1[8] }, a2[3] = { mat2[2], mat2[5], mat2[8] };
 		const double dif[3] = { pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2] };

@@ -298,6 +298,206 @@ static int capsule_box(rawcon *c, const double *pos1, const double *mat1, const 
 	return n;
 }
 
+/* box - box.  MuJoCo's own routine (engine_collision_box.c, mjc_BoxBox) is not available in this environment; this
+ * is the classical separating-axis + face-clipping construction with the same contract (contacts on the feature pair
+ * of least penetration, frame normal from geom 1 to geom 2, position midway between the surfaces), capped at 4
+ * contacts per pair:
+ *   1. separation along the 15 candidate axes (3 + 3 face normals, 9 edge x edge); any separation > margin: no
+ *      contact; the axis of least penetration wins, edge axes only when they beat the best face axis by 5 %;
+ *   2. face axis: the most anti-parallel face of the other box (4 vertices) is clipped against the side planes of
+ *      the reference face (Sutherland-Hodgman, <= 8 vertices); vertices closer than margin to the reference face
+ *      become contacts (dist = signed height above the face); more than 4 are reduced to the deepest one, the one
+ *      farthest from it, and the two extreme ones on either side of that line;
+ *   3. edge x edge axis: one contact at the closest points of the two supporting edges.
+ * The HIP narrow phase (mjb_constraint.h, box_box) follows the same steps operation for operation. */
+static int box_box(rawcon *c, const double *pos1, const double *mat1, const double *size1, const double *pos2,
+                   const double *mat2, const double *size2, double margin)
+{
+	double A[3][3], B[3][3], C[3][3], Q[3][3], t[3], tA[3], tB[3];
+	for (int i = 0; i < 3; i++)
+		for (int k = 0; k < 3; k++) {
+			A[i][k] = mat1[3 * k + i]; /* axis i of box 1 in the world = column i */
+			B[i][k] = mat2[3 * k + i];
+		}
+	v3_sub(t, pos2, pos1);
+	for (int i = 0; i < 3; i++) {
+		tA[i] = v3_dot(t, A[i]);
+		tB[i] = v3_dot(t, B[i]);
+		for (int j = 0; j < 3; j++) {
+			C[i][j] = v3_dot(A[i], B[j]);
+			Q[i][j] = fabs(C[i][j]) + 1e-12;
+		}
+	}
+	/* 1. separating axes */
+	double best = -1e300;
+	int code = -1; /* 0..2 face of box 1, 3..5 face of box 2, 6.. edge pair 6 + 3 i + j */
+	for (int i = 0; i < 3; i++) {
+		double s = fabs(tA[i]) - (size1[i] + size2[0] * Q[i][0] + size2[1] * Q[i][1] + size2[2] * Q[i][2]);
+		if (s > margin) return 0;
+		if (s > best) { best = s; code = i; }
+	}
+	for (int j = 0; j < 3; j++) {
+		double s = fabs(tB[j]) - (size2[j] + size1[0] * Q[0][j] + size1[1] * Q[1][j] + size1[2] * Q[2][j]);
+		if (s > margin) return 0;
+		if (s > best) { best = s; code = 3 + j; }
+	}
+	double ebest = -1e300;
+	int ecode = -1;
+	for (int i = 0; i < 3; i++)
+		for (int j = 0; j < 3; j++) {
+			const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+			double l = sqrt(fmax(0.0, 1.0 - C[i][j] * C[i][j]));
+			if (l < 1e-6) continue;
+			double s = fabs(tA[i2] * C[i1][j] - tA[i1] * C[i2][j]) -
+			           (size1[i1] * Q[i2][j] + size1[i2] * Q[i1][j] + size2[j1] * Q[i][j2] + size2[j2] * Q[i][j1]);
+			s /= l;
+			if (s > margin) return 0;
+			if (s > ebest) { ebest = s; ecode = 6 + 3 * i + j; }
+		}
+	if (ecode >= 0 && ebest > best + 0.05 * fabs(best) + 1e-9) {
+		/* 3. edge x edge */
+		const int i = (ecode - 6) / 3, j = (ecode - 6) % 3;
+		double n[3];
+		v3_cross(n, A[i], B[j]);
+		v3_normalize(n);
+		if (v3_dot(n, t) < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+		double pa[3], pb[3];
+		v3_copy(pa, pos1);
+		v3_copy(pb, pos2);
+		for (int k = 0; k < 3; k++) {
+			if (k != i) {
+				double sg = v3_dot(n, A[k]) > 0 ? 1.0 : -1.0;
+				for (int q = 0; q < 3; q++) pa[q] += sg * size1[k] * A[k][q];
+			}
+			if (k != j) {
+				double sg = v3_dot(n, B[k]) > 0 ? -1.0 : 1.0;
+				for (int q = 0; q < 3; q++) pb[q] += sg * size2[k] * B[k][q];
+			}
+		}
+		/* closest points of the lines pa + al A_i, pb + be B_j, clamped to the edges */
+		double d[3];
+		v3_sub(d, pb, pa);
+		double uaub = C[i][j], q1 = v3_dot(A[i], d), q2 = -v3_dot(B[j], d), den = 1 - uaub * uaub;
+		double al = 0, be = 0;
+		if (den > 1e-12) {
+			al = (q1 + uaub * q2) / den;
+			be = (uaub * q1 + q2) / den;
+		}
+		al = clipd(al, -size1[i], size1[i]);
+		be = clipd(be, -size2[j], size2[j]);
+		double xa[3], xb[3];
+		for (int q = 0; q < 3; q++) {
+			xa[q] = pa[q] + al * A[i][q];
+			xb[q] = pb[q] + be * B[j][q];
+		}
+		double dv[3];
+		v3_sub(dv, xb, xa);
+		c->dist = v3_dot(dv, n);
+		if (c->dist > margin) return 0;
+		memset(c->frame, 0, sizeof c->frame);
+		v3_copy(c->frame, n);
+		for (int q = 0; q < 3; q++) c->pos[q] = 0.5 * (xa[q] + xb[q]);
+		return 1;
+	}
+	/* 2. face contact: reference box r (axis ax), incident box o */
+	const int ref1 = code < 3, ax = ref1 ? code : code - 3;
+	const double(*R)[3] = ref1 ? A : B, (*O)[3] = ref1 ? B : A;
+	const double *pr = ref1 ? pos1 : pos2, *po = ref1 ? pos2 : pos1, *hr = ref1 ? size1 : size2, *ho = ref1 ? size2 : size1;
+	double nref[3]; /* outward normal of the reference face, pointing to the incident box */
+	{
+		double sg = (ref1 ? tA[ax] : -tB[ax]) >= 0 ? 1.0 : -1.0;
+		for (int q = 0; q < 3; q++) nref[q] = sg * R[ax][q];
+	}
+	int k = 0;
+	double kbest = -1;
+	for (int q = 0; q < 3; q++) {
+		double a = fabs(v3_dot(O[q], nref));
+		if (a > kbest) { kbest = a; k = q; }
+	}
+	const double fs = v3_dot(O[k], nref) > 0 ? -1.0 : 1.0; /* incident face normal = fs O_k (against nref) */
+	const int u = (k + 1) % 3, v = (k + 2) % 3, sx = (ax + 1) % 3, sy = (ax + 2) % 3;
+	double poly[8][3], tmp[8][3];
+	int np = 4;
+	for (int w = 0; w < 4; w++) {
+		const double su = (w == 0 || w == 3) ? 1.0 : -1.0, sv = (w < 2) ? 1.0 : -1.0;
+		double d[3];
+		for (int q = 0; q < 3; q++) d[q] = po[q] + fs * ho[k] * O[k][q] + su * ho[u] * O[u][q] + sv * ho[v] * O[v][q] - pr[q];
+		poly[w][0] = v3_dot(d, R[sx]);
+		poly[w][1] = v3_dot(d, R[sy]);
+		poly[w][2] = v3_dot(d, nref) - hr[ax];
+	}
+	for (int side = 0; side < 4; side++) {
+		const int cax = side >> 1;
+		const double sgn = (side & 1) ? -1.0 : 1.0, lim = cax == 0 ? hr[sx] : hr[sy];
+		int nn = 0;
+		for (int w = 0; w < np; w++) {
+			const double *p0 = poly[w], *p1 = poly[(w + 1) % np];
+			double d0 = sgn * p0[cax] - lim, d1 = sgn * p1[cax] - lim;
+			if (d0 <= 0) {
+				if (nn < 8) { memcpy(tmp[nn], p0, sizeof tmp[0]); nn++; }
+			}
+			if ((d0 < 0 && d1 > 0) || (d0 > 0 && d1 < 0)) {
+				double f = d0 / (d0 - d1);
+				if (nn < 8) {
+					for (int q = 0; q < 3; q++) tmp[nn][q] = p0[q] + f * (p1[q] - p0[q]);
+					nn++;
+				}
+			}
+		}
+		np = nn;
+		memcpy(poly, tmp, sizeof poly);
+		if (np == 0) return 0;
+	}
+	/* keep the vertices within margin of the reference face */
+	int nk = 0;
+	for (int w = 0; w < np; w++)
+		if (poly[w][2] < margin) {
+			memcpy(tmp[nk], poly[w], sizeof tmp[0]);
+			nk++;
+		}
+	if (nk == 0) return 0;
+	int pick[4], npick = 0;
+	if (nk <= 4) {
+		for (int w = 0; w < nk; w++) pick[npick++] = w;
+	} else {
+		int a = 0;
+		for (int w = 1; w < nk; w++)
+			if (tmp[w][2] < tmp[a][2]) a = w;
+		int b = a;
+		double far = -1;
+		for (int w = 0; w < nk; w++) {
+			double dx = tmp[w][0] - tmp[a][0], dy = tmp[w][1] - tmp[a][1], dd = dx * dx + dy * dy;
+			if (dd > far) { far = dd; b = w; }
+		}
+		int cpos = -1, cneg = -1;
+		double apos = 0, aneg = 0;
+		for (int w = 0; w < nk; w++) {
+			if (w == a || w == b) continue;
+			double cr = (tmp[b][0] - tmp[a][0]) * (tmp[w][1] - tmp[a][1]) - (tmp[b][1] - tmp[a][1]) * (tmp[w][0] - tmp[a][0]);
+			if (cr > apos) { apos = cr; cpos = w; }
+			if (cr < aneg) { aneg = cr; cneg = w; }
+		}
+		pick[npick++] = a;
+		pick[npick++] = b;
+		if (cpos >= 0) pick[npick++] = cpos;
+		if (cneg >= 0) pick[npick++] = cneg;
+	}
+	/* geom1 -> geom2 normal */
+	double nrm[3];
+	for (int q = 0; q < 3; q++) nrm[q] = ref1 ? nref[q] : -nref[q];
+	for (int w = 0; w < npick; w++) {
+		const double *pv = tmp[pick[w]];
+		rawcon *o = c + w;
+		o->dist = pv[2];
+		memset(o->frame, 0, sizeof o->frame);
+		v3_copy(o->frame, nrm);
+		/* vertex on the incident face, moved half way towards the reference face */
+		const double hgt = hr[ax] + 0.5 * pv[2];
+		for (int q = 0; q < 3; q++) o->pos[q] = pr[q] + pv[0] * R[sx][q] + pv[1] * R[sy][q] + hgt * nref[q];
+	}
+	return npick;
+}
+
 /* mj_contactParam: mix the two geoms' contact parameters */
 static void contact_param(const mjb_model_desc *m, int g1, int g2, int *condim, double *solref, double *solimp,
                           double *friction)
@@ -363,6 +563,7 @@ void mjo_collision(const mjb_model_desc *m, mjo_data *d)
 		else if (t1 == MJB_GEOM_SPHERE && t2 == MJB_GEOM_BOX) n = sphere_box(rc, pos1, size1[0], pos2, mat2, size2, margin);
 		else if (t1 == MJB_GEOM_CAPSULE && t2 == MJB_GEOM_CAPSULE) n = capsule_capsule(rc, pos1, mat1, size1, pos2, mat2, size2, margin);
 		else if (t1 == MJB_GEOM_CAPSULE && t2 == MJB_GEOM_BOX) n = capsule_box(rc, pos1, mat1, size1, pos2, mat2, size2, margin);
+		else if (t1 == MJB_GEOM_BOX && t2 == MJB_GEOM_BOX) n = box_box(rc, pos1, mat1, size1, pos2, mat2, size2, margin);
 		if (n == 0) continue;
 		int condim;
 		double solref[2], solimp[5], fri[3];
