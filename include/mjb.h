@@ -61,9 +61,9 @@ enum { /* mjtSensor (subset implemented; values are MuJoCo's) */
 	MJB_SENS_FRAMELINVEL = 28, MJB_SENS_FRAMEANGVEL = 29, MJB_SENS_SUBTREECOM = 32, MJB_SENS_CLOCK = 35
 };
 enum { MJB_STAGE_NONE = 0, MJB_STAGE_POS = 1, MJB_STAGE_VEL = 2, MJB_STAGE_ACC = 3 };
-enum { MJB_EQ_CONNECT = 0, MJB_EQ_WELD = 1, MJB_EQ_JOINT = 2 }; /* mjtEq (tendon / distance not implemented) */
+enum { MJB_EQ_CONNECT = 0, MJB_EQ_WELD = 1, MJB_EQ_JOINT = 2, MJB_EQ_TENDON = 3 }; /* mjtEq (distance not implemented) */
 enum { /* mjtConstraint */
-	MJB_CNSTR_EQUALITY = 0, MJB_CNSTR_LIMIT_JOINT = 3, MJB_CNSTR_CONTACT_FRICTIONLESS = 5, MJB_CNSTR_CONTACT_PYRAMIDAL = 6,
+	MJB_CNSTR_EQUALITY = 0, MJB_CNSTR_LIMIT_JOINT = 3, MJB_CNSTR_LIMIT_TENDON = 4, MJB_CNSTR_CONTACT_FRICTIONLESS = 5, MJB_CNSTR_CONTACT_PYRAMIDAL = 6,
 	MJB_CNSTR_CONTACT_ELLIPTIC = 7
 };
 

@@ -215,7 +215,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	L.ndouble = off;
 	L.iscratch = ioff;
 	{
-		int a = d.ncollpair, b = d.neq + d.njnt + d.nconmax;
+		int a = d.ncollpair, b = d.neq + d.njnt + d.ntendon + d.nconmax;
 		ioff += a > b ? a : b;
 	}
 	L.nint = (ioff + 1) & ~1;
@@ -334,7 +334,8 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		const int t = d.eq_type[i], a = d.eq_obj1id[i], b = d.eq_obj2id[i];
 		const bool body_ok = a >= 0 && a < d.nbody && b >= 0 && b < d.nbody;
 		const bool jnt_ok = a >= 0 && a < d.njnt && b >= -1 && b < d.njnt;
-		if (!((t == MJB_EQ_CONNECT || t == MJB_EQ_WELD) ? body_ok : (t == MJB_EQ_JOINT && jnt_ok))) {
+		const bool ten_ok = a >= 0 && a < d.ntendon && b >= -1 && b < d.ntendon;
+		if (!((t == MJB_EQ_CONNECT || t == MJB_EQ_WELD) ? body_ok : ((t == MJB_EQ_JOINT && jnt_ok) || (t == MJB_EQ_TENDON && ten_ok)))) {
 			fail(MJB_EUNSUPPORTED, "mjb_compile: equality %d: type %d with objects (%d, %d) is not supported "
 			                       "(connect / weld between bodies, joint between hinge / slide joints)", i, t, a, b);
 			return nullptr;

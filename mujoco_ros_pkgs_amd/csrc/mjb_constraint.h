@@ -744,13 +744,14 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 	const int ncon = fi[L.ncon];
 	const bool do_lim = !(m.disableflags & MJB_DSBL_LIMIT), do_con = !(m.disableflags & MJB_DSBL_CONTACT);
 	const int neq = (m.disableflags & MJB_DSBL_EQUALITY) ? 0 : m.neq;
-	const int nitem = neq + m.njnt + ncon;   // item = equality, joint (limit rows) or contact -- MuJoCo's row order
+	const int nten = do_lim ? m.ntendon : 0;
+	const int nitem = neq + m.njnt + nten + ncon;  // item = equality, joint limit, tendon limit or contact -- MuJoCo's row order
 	int *cnt = fi + L.iscratch;              // transient per-item row counts
 	// pass 1: rows per item
 	for (int it = lane; it < nitem; it += G) {
 		int n = 0;
 		if (it < neq) {
-			if (m.eq_active[it]) n = m.eq_type[it] == MJB_EQ_CONNECT ? 3 : (m.eq_type[it] == MJB_EQ_WELD ? 6 : 1);
+			if (m.eq_active[it]) n = m.eq_type[it] == MJB_EQ_CONNECT ? 3 : (m.eq_type[it] == MJB_EQ_WELD ? 6 : 1);  // joint, tendon: 1
 		} else if (it < neq + m.njnt) {
 			const int j = it - neq;
 			if (do_lim && m.jnt_limited[j] && m.jnt_type[j] >= MJB_JNT_SLIDE) {
@@ -758,8 +759,15 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 				if (value - m.jnt_range[2 * j] < margin) n++;
 				if (m.jnt_range[2 * j + 1] - value < margin) n++;
 			}
+		} else if (it < neq + m.njnt + nten) {
+			const int t = it - neq - m.njnt;
+			if (m.tendon_limited[t]) {
+				const double value = f[L.ten_length + t], margin = m.tendon_margin[t];
+				if (value - m.tendon_range[2 * t] < margin) n++;
+				if (m.tendon_range[2 * t + 1] - value < margin) n++;
+			}
 		} else if (do_con) {
-			const int c = it - neq - m.njnt;
+			const int c = it - neq - m.njnt - nten;
 			if (f[L.contact_dist + c] < f[L.contact_includemargin + c]) {
 				const int dim = fi[L.contact_dim + c];
 				n = dim == 1 ? 1 : (m.cone == MJB_CONE_ELLIPTIC ? dim : 2 * (dim - 1));
@@ -809,6 +817,24 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 				}
 				row[d1] += 1;
 				cpos[0] = f[L.qpos + a1] - m.qpos0[a1] - poly;
+			} else if (type == MJB_EQ_TENDON) {
+				double c5[5];
+				for (int k = 0; k < 5; k++) c5[k] = m.eq_data[11 * eq + k];
+				double poly = c5[0], deriv = 0;
+				double *row = f + L.efc_J + off * nv;
+				for (int k = 0; k < nv; k++) row[k] = 0;
+				diag[0] = m.tendon_invweight0[id0];
+				if (id1 >= 0) {
+					const double x = f[L.ten_length + id1] - m.tendon_length0[id1];
+					poly = c5[0] + x * (c5[1] + x * (c5[2] + x * (c5[3] + x * c5[4])));
+					deriv = c5[1] + x * (2 * c5[2] + x * (3 * c5[3] + x * 4 * c5[4]));
+					for (int w = m.tendon_adr[id1]; w < m.tendon_adr[id1] + m.tendon_num[id1]; w++)
+						row[m.jnt_dofadr[m.wrap_objid[w]]] -= deriv * m.wrap_prm[w];
+					diag[0] += m.tendon_invweight0[id1];
+				}
+				for (int w = m.tendon_adr[id0]; w < m.tendon_adr[id0] + m.tendon_num[id0]; w++)
+					row[m.jnt_dofadr[m.wrap_objid[w]]] += m.wrap_prm[w];
+				cpos[0] = f[L.ten_length + id0] - m.tendon_length0[id0] - poly;
 			} else {
 				EqGeom g;
 				eq_geometry(m, L, f, eq, g);
@@ -853,8 +879,27 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 					r++;
 				}
 			}
+		} else if (it < neq + m.njnt + nten) {
+			const int t = it - neq - m.njnt;
+			const double value = f[L.ten_length + t], margin = m.tendon_margin[t];
+			double solref[2] = { m.tendon_solref_lim[2 * t], m.tendon_solref_lim[2 * t + 1] }, solimp[5];
+			for (int k = 0; k < 5; k++) solimp[k] = m.tendon_solimp_lim[5 * t + k];
+			int r = off;
+			for (int side = -1; side <= 1; side += 2) {
+				const double dist = side * (m.tendon_range[2 * t + (side + 1) / 2] - value);
+				if (dist < margin) {
+					double *row = f + L.efc_J + r * nv;
+					for (int k = 0; k < nv; k++) row[k] = 0;
+					for (int w = m.tendon_adr[t]; w < m.tendon_adr[t] + m.tendon_num[t]; w++)
+						row[m.jnt_dofadr[m.wrap_objid[w]]] += -side * m.wrap_prm[w];
+					row_params(m, L, f, r, dist, margin, solref, solimp, m.tendon_invweight0[t]);
+					fi[L.efc_id + r] = t;
+					fi[L.efc_type + r] = MJB_CNSTR_LIMIT_TENDON;
+					r++;
+				}
+			}
 		} else {
-			const int c = it - neq - m.njnt;
+			const int c = it - neq - m.njnt - nten;
 			const int dim = fi[L.contact_dim + c];
 			const double dist = f[L.contact_dist + c], cm = f[L.contact_includemargin + c];
 			const int b1 = m.geom_bodyid[fi[L.contact_geom + 2 * c]], b2 = m.geom_bodyid[fi[L.contact_geom + 2 * c + 1]];
@@ -909,7 +954,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 	for (int t = lane; t < neq * nv; t += G) {
 		const int eq = t / nv, i = t - eq * nv;
 		const int type = m.eq_type[eq];
-		if (eq >= cut || cnt[eq] == 0 || type == MJB_EQ_JOINT) continue;
+		if (eq >= cut || cnt[eq] == 0 || type == MJB_EQ_JOINT || type == MJB_EQ_TENDON) continue;
 		int adr = 0;
 		for (int q = 0; q < eq; q++) adr += cnt[q];
 		const int id0 = m.eq_obj1id[eq], id1 = m.eq_obj2id[eq];

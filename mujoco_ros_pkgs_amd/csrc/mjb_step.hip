@@ -429,6 +429,13 @@ template <int G, bool OBL> STAGE void com_pos(CModel m, CLayout L, const Env &e)
 			}
 		}
 	}
+	// mj_tendon (fixed tendons): length = sum coef * qpos[joint]
+	for (int t = lane; t < m.ntendon; t += G) {
+		double len = 0;
+		for (int w = m.tendon_adr[t]; w < m.tendon_adr[t] + m.tendon_num[t]; w++)
+			len += m.wrap_prm[w] * f[L.qpos + m.jnt_qposadr[m.wrap_objid[w]]];
+		f[L.ten_length + t] = len;
+	}
 	gsync<G>();
 }
 
@@ -888,6 +895,26 @@ template <int G> STAGE void passive(CModel m, CLayout L, const Env &e)
 		}
 	}
 	gsync<G>();
+	if (m.ntendon > 0) {
+		// fixed tendons: velocity = J qvel (lane = tendon), then springs / dampers  qfrc_passive += J' frc  (tendons
+		// may share dofs: one lane walks them in order, as mj_passive does)
+		for (int t = e.lane; t < m.ntendon; t += G) {
+			double v = 0;
+			for (int w = m.tendon_adr[t]; w < m.tendon_adr[t] + m.tendon_num[t]; w++)
+				v += m.wrap_prm[w] * f[L.qvel + m.jnt_dofadr[m.wrap_objid[w]]];
+			f[L.ten_velocity + t] = v;
+		}
+		gsync<G>();
+		if (e.lane == 0 && !off)
+			for (int t = 0; t < m.ntendon; t++) {
+				const double frc = -m.tendon_stiffness[t] * (f[L.ten_length + t] - m.tendon_lengthspring[t]) -
+				                   m.tendon_damping[t] * f[L.ten_velocity + t];
+				if (frc == 0) continue;
+				for (int w = m.tendon_adr[t]; w < m.tendon_adr[t] + m.tendon_num[t]; w++)
+					qp[m.jnt_dofadr[m.wrap_objid[w]]] += m.wrap_prm[w] * frc;
+			}
+		gsync<G>();
+	}
 }
 
 // ------------------------------------------------------------------------------------------------

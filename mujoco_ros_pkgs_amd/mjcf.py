@@ -192,6 +192,7 @@ class _Compiler:
         self.override = dict(override or {})
         self.skip_unsupported_pairs = skip_unsupported_pairs
         self.equalities = []
+        self.tendons = []
         self.skipped_pairs = []
         self.nconmax_req = nconmax
         self.nefcmax_req = nefcmax
@@ -274,6 +275,9 @@ class _Compiler:
             elif t == "equality":
                 for c in node:
                     self._equality(c)
+            elif t == "tendon":
+                for c in node:
+                    self._tendon(c)
             elif t == "contact":
                 for c in node:
                     if c.tag == "exclude":
@@ -477,11 +481,26 @@ class _Compiler:
     def _equality(self, node):
         """<equality><connect|weld|joint>: stored raw; body / joint ids and eq_data are resolved in _finalize (they need
         the kinematics at qpos0).  Tendon and distance equalities are not implemented."""
-        if node.tag not in ("connect", "weld", "joint"):
-            raise MjcfError(f"<equality><{node.tag}> is not supported (connect / weld / joint only)")
+        if node.tag not in ("connect", "weld", "joint", "tendon"):
+            raise MjcfError(f"<equality><{node.tag}> is not supported (connect / weld / joint / tendon only)")
         a = self.defaults.resolve("equality", node.get("class", "main"))
         a.update(node.attrib)
         self.equalities.append((node.tag, a))
+
+    def _tendon(self, node):
+        """<tendon><fixed>: length = sum coef_i * qpos[joint_i] (hinge / slide joints).  Spatial tendons are refused."""
+        if node.tag != "fixed":
+            raise MjcfError(f"<tendon><{node.tag}> is not supported (fixed tendons only)")
+        a = self.defaults.resolve("tendon", node.get("class", "main"))
+        a.update(node.attrib)
+        wraps = []
+        for w in node:
+            if w.tag != "joint":
+                raise MjcfError("fixed tendons take <joint> entries only")
+            wraps.append((w.get("joint"), float(w.get("coef", 1))))
+        if float(a.get("frictionloss", 0)) != 0:
+            raise MjcfError("tendon frictionloss is not supported")
+        self.tendons.append((a, wraps))
 
     def _actuator(self, node):
         a = self._merged(node, None)
@@ -810,7 +829,8 @@ class _Compiler:
                  integrator=o["integrator"], cone=o["cone"], solver=o["solver"], iterations=o["iterations"],
                  disableflags=o["disableflags"])
 
-        # equality constraints (mjCEquality::Compile, [UPSTREAM] user_objects.cc): ids + eq_data at qpos0
+        # fixed tendons, then equality constraints (mjCEquality::Compile, [UPSTREAM] user_objects.cc): ids + eq_data at qpos0
+        self._compile_tendons(m)
         self._compile_equalities(m)
 
         # static collision candidates (restates the body/geom filters of MuJoCo's mj_collision)
@@ -830,6 +850,10 @@ class _Compiler:
                     raise MjcfError("joint limits are only supported on hinge / slide joints")
                 r = m["jnt_range"][j]
                 nlimit += 1 if (r[1] - r[0]) > 2 * m["jnt_margin"][j] else 2
+        for t in range(m["ntendon"]):
+            if m["tendon_limited"][t]:
+                r = m["tendon_range"][t]
+                nlimit += 1 if (r[1] - r[0]) > 2 * m["tendon_margin"][t] else 2
         if o["disableflags"] & DISABLE_BITS["limit"]:
             nlimit = 0
         rows_per_con = 0
@@ -838,7 +862,7 @@ class _Compiler:
             rows_per_con = 1 if maxdim == 1 else (2 * (maxdim - 1) if o["cone"] == 0 else maxdim)
         neqrow = 0
         if not (o["disableflags"] & DISABLE_BITS["equality"]):
-            neqrow = int(sum({0: 3, 1: 6, 2: 1}[int(t)] for t in m["eq_type"]))
+            neqrow = int(sum({0: 3, 1: 6, 2: 1, 3: 1}[int(t)] for t in m["eq_type"]))
         nefcmax = neqrow + nlimit + rows_per_con * nconmax if self.nefcmax_req is None else int(self.nefcmax_req)
         if o["disableflags"] & (DISABLE_BITS["constraint"]):
             nconmax, nefcmax = 0, 0
@@ -851,6 +875,54 @@ class _Compiler:
         m["body_invweight0"] = body_inv
         m["meaninertia"] = np.array([meaninertia], D)
         return m
+
+    def _compile_tendons(self, m):
+        from . import refdyn
+        I, D = np.int32, np.float64
+        T = self.tendons
+        nt = len(T)
+        adr, num, objid, prm, names = [], [], [], [], []
+        lim, rng, margin = np.zeros(nt, I), np.zeros((nt, 2)), np.zeros(nt)
+        solref, solimp = np.zeros((nt, 2)), np.zeros((nt, 5))
+        stiff, damp, lspring = np.zeros(nt), np.zeros(nt), np.zeros(nt)
+        for i, (a, wraps) in enumerate(T):
+            names.append(a.get("name", f"tendon{i}"))
+            adr.append(len(objid))
+            num.append(len(wraps))
+            for jn, coef in wraps:
+                j = m.name2id("joint", jn or "")
+                if j < 0 or m["jnt_type"][j] < JNT_SLIDE:
+                    raise MjcfError(f"tendon '{names[-1]}': joint '{jn}' must be an existing hinge / slide joint")
+                objid.append(j)
+                prm.append(coef)
+            r = _floats(a.get("range", "0 0"), 2, "tendon range")
+            limited = a.get("limited", "auto")
+            lim[i] = 1 if (limited == "true" or (limited == "auto" and "range" in a and self.autolimits)) else 0
+            rng[i], margin[i] = r, float(a.get("margin", 0))
+            solref[i] = _floats(a.get("solreflimit", "0.02 1"), 2, "tendon solreflimit")
+            solimp[i] = _solimp(a.get("solimplimit"))
+            stiff[i], damp[i] = float(a.get("stiffness", 0)), float(a.get("damping", 0))
+            lspring[i] = float(a.get("springlength", -1))
+        nv = m["nv"]
+        J = np.zeros((nt, nv))
+        q0 = np.asarray(m["qpos0"], D)
+        len0 = np.zeros(nt)
+        for i in range(nt):
+            for w in range(adr[i], adr[i] + num[i]):
+                j = objid[w]
+                J[i, m["jnt_dofadr"][j]] += prm[w]
+                len0[i] += prm[w] * q0[m["jnt_qposadr"][j]]
+        inv0 = np.zeros(nt)
+        if nt and nv:
+            Minv = np.linalg.inv(refdyn.mass_matrix(m, q0))
+            inv0 = np.einsum("ti,ij,tj->t", J, Minv, J)
+        lspring = np.where(lspring < 0, len0, lspring)   # springlength = -1: the length at qpos0
+        m.update(ntendon=nt, nwrap=len(objid), tendon_adr=np.array(adr, I), tendon_num=np.array(num, I),
+                 tendon_limited=lim, wrap_objid=np.array(objid, I), wrap_prm=np.array(prm, D),
+                 tendon_range=rng.reshape(nt, 2), tendon_margin=margin, tendon_solref_lim=solref.reshape(nt, 2),
+                 tendon_solimp_lim=solimp.reshape(nt, 5), tendon_length0=len0, tendon_invweight0=inv0,
+                 tendon_stiffness=stiff, tendon_damping=damp, tendon_lengthspring=lspring)
+        m["names"]["tendon"] = names
 
     def _compile_equalities(self, m):
         from . import refdyn
@@ -891,6 +963,16 @@ class _Compiler:
                     data[i, 3:6] = relpos + quat2mat(relquat) @ anchor      # the same point in body1
                     data[i, 6:10] = relquat
                     data[i, 10] = float(a.get("torquescale", 1))
+            elif tag == "tendon":
+                eq_type[i] = 3
+                t1 = m["names"]["tendon"].index(a["tendon1"]) if a.get("tendon1") in m["names"]["tendon"] else -1
+                t2 = (m["names"]["tendon"].index(a["tendon2"]) if a.get("tendon2") in m["names"]["tendon"] else -2) \
+                    if "tendon2" in a else -1
+                if t1 < 0 or t2 == -2:
+                    raise MjcfError(f"equality '{names[-1]}': unknown tendon")
+                o1[i], o2[i] = t1, t2
+                pc = _floats(a.get("polycoef", "0 1 0 0 0"))
+                data[i, :pc.size] = pc
             else:
                 eq_type[i] = 2
                 j1 = m.name2id("joint", a.get("joint1", ""))

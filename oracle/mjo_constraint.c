@@ -759,6 +759,21 @@ static int make_equality(const mjb_model_desc *m, mjo_data *d, int nefc)
 			jac[0][d1] += 1;
 			diag[0] = m->dof_invweight0[d1] + (id2 >= 0 ? m->dof_invweight0[m->jnt_dofadr[id2]] : 0.0);
 			dim = 1;
+		} else if (type == MJB_EQ_TENDON) {
+			/* (L1 - L1_0) - poly(L2 - L2_0) = 0 on tendon lengths; J = J1 - poly' J2 */
+			double x = 0, deriv = 0, poly = data[0];
+			if (id2 >= 0) {
+				x = d->ten_length[id2] - m->tendon_length0[id2];
+				poly = data[0] + x * (data[1] + x * (data[2] + x * (data[3] + x * data[4])));
+				deriv = data[1] + x * (2 * data[2] + x * (3 * data[3] + x * 4 * data[4]));
+				for (int w = m->tendon_adr[id2]; w < m->tendon_adr[id2] + m->tendon_num[id2]; w++)
+					jac[0][m->jnt_dofadr[m->wrap_objid[w]]] -= deriv * m->wrap_prm[w];
+			}
+			for (int w = m->tendon_adr[id1]; w < m->tendon_adr[id1] + m->tendon_num[id1]; w++)
+				jac[0][m->jnt_dofadr[m->wrap_objid[w]]] += m->wrap_prm[w];
+			cpos[0] = d->ten_length[id1] - m->tendon_length0[id1] - poly;
+			diag[0] = m->tendon_invweight0[id1] + (id2 >= 0 ? m->tendon_invweight0[id2] : 0.0);
+			dim = 1;
 		} else {
 			continue;
 		}
@@ -801,6 +816,28 @@ void mjo_make_constraint(const mjb_model_desc *m, mjo_data *d)
 					d->efc_type[nefc] = MJB_CNSTR_LIMIT_JOINT;
 					d->efc_id[nefc] = j;
 					row_params(m, d, nefc, m->jnt_solref + 2 * j, m->jnt_solimp + 5 * j, m->dof_invweight0[m->jnt_dofadr[j]]);
+					nefc++;
+				}
+			}
+		}
+	}
+	/* tendon limits (mj_instantiateLimit, tendon part): rows after the joint limits */
+	if (!(m->disableflags & MJB_DSBL_LIMIT)) {
+		for (int t = 0; t < m->ntendon; t++) {
+			if (!m->tendon_limited[t]) continue;
+			double value = d->ten_length[t], margin = m->tendon_margin[t];
+			for (int side = -1; side <= 1; side += 2) {
+				double dist = side * (m->tendon_range[2 * t + (side + 1) / 2] - value);
+				if (dist < margin && nefc < m->nefcmax) {
+					double *row = d->efc_J + (size_t)nefc * nv;
+					memset(row, 0, sizeof(double) * (size_t)nv);
+					for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++)
+						row[m->jnt_dofadr[m->wrap_objid[w]]] += -side * m->wrap_prm[w];
+					d->efc_pos[nefc] = dist;
+					d->efc_margin[nefc] = margin;
+					d->efc_type[nefc] = MJB_CNSTR_LIMIT_TENDON;
+					d->efc_id[nefc] = t;
+					row_params(m, d, nefc, m->tendon_solref_lim + 2 * t, m->tendon_solimp_lim + 5 * t, m->tendon_invweight0[t]);
 					nefc++;
 				}
 			}

@@ -410,6 +410,35 @@ void mjo_passive(const mjb_model_desc *m, mjo_data *d)
 		}
 	}
 	for (int i = 0; i < m->nv; i++) d->qfrc_passive[i] -= m->dof_damping[i] * d->qvel[i];
+	/* tendon springs and dampers: qfrc_passive += J' (-k (L - L_spring) - b v) */
+	for (int t = 0; t < m->ntendon; t++) {
+		double frc = -m->tendon_stiffness[t] * (d->ten_length[t] - m->tendon_lengthspring[t]) -
+		             m->tendon_damping[t] * d->ten_velocity[t];
+		if (frc == 0) continue;
+		for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++)
+			d->qfrc_passive[m->jnt_dofadr[m->wrap_objid[w]]] += m->wrap_prm[w] * frc;
+	}
+}
+
+/* mj_tendon for fixed tendons: length = sum coef * qpos[joint]; mj_fwdVelocity: velocity = J qvel */
+void mjo_tendon(const mjb_model_desc *m, mjo_data *d)
+{
+	for (int t = 0; t < m->ntendon; t++) {
+		double len = 0;
+		for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++)
+			len += m->wrap_prm[w] * d->qpos[m->jnt_qposadr[m->wrap_objid[w]]];
+		d->ten_length[t] = len;
+	}
+}
+
+void mjo_tendon_vel(const mjb_model_desc *m, mjo_data *d)
+{
+	for (int t = 0; t < m->ntendon; t++) {
+		double v = 0;
+		for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++)
+			v += m->wrap_prm[w] * d->qvel[m->jnt_dofadr[m->wrap_objid[w]]];
+		d->ten_velocity[t] = v;
+	}
 }
 
 /* ------------------------------------------------------------------ A9: mj_rne (flg_acc = 0) */
@@ -676,6 +705,7 @@ void mjo_fwd_position(const mjb_model_desc *m, mjo_data *d)
 {
 	mjo_kinematics(m, d);
 	mjo_com_pos(m, d);
+	mjo_tendon(m, d);
 	mjo_crb(m, d);
 	mjo_factor_m(m, d);
 	mjo_collision(m, d);
@@ -687,6 +717,7 @@ void mjo_fwd_position(const mjb_model_desc *m, mjo_data *d)
 void mjo_fwd_velocity(const mjb_model_desc *m, mjo_data *d)
 {
 	mjo_com_vel(m, d);
+	mjo_tendon_vel(m, d);
 	mjo_passive(m, d);
 	mjo_reference_constraint(m, d);
 	mjo_rne(m, d);
