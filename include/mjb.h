@@ -54,11 +54,13 @@ enum { /* mjtObj */
 	MJB_OBJ_SITE = 6, MJB_OBJ_ACTUATOR = 18
 };
 enum { /* mjtSensor (subset implemented; values are MuJoCo's) */
-	MJB_SENS_TOUCH = 0, MJB_SENS_ACCELEROMETER = 1, MJB_SENS_VELOCIMETER = 2, MJB_SENS_GYRO = 3,
+	MJB_SENS_TOUCH = 0, MJB_SENS_ACCELEROMETER = 1, MJB_SENS_VELOCIMETER = 2, MJB_SENS_GYRO = 3, MJB_SENS_FORCE = 4,
+	MJB_SENS_TORQUE = 5, MJB_SENS_TENDONPOS = 10, MJB_SENS_TENDONVEL = 11,
 	MJB_SENS_JOINTPOS = 8, MJB_SENS_JOINTVEL = 9, MJB_SENS_ACTUATORPOS = 12, MJB_SENS_ACTUATORVEL = 13,
 	MJB_SENS_ACTUATORFRC = 14, MJB_SENS_BALLQUAT = 15, MJB_SENS_BALLANGVEL = 16, MJB_SENS_FRAMEPOS = 23,
 	MJB_SENS_FRAMEQUAT = 24, MJB_SENS_FRAMEXAXIS = 25, MJB_SENS_FRAMEYAXIS = 26, MJB_SENS_FRAMEZAXIS = 27,
-	MJB_SENS_FRAMELINVEL = 28, MJB_SENS_FRAMEANGVEL = 29, MJB_SENS_SUBTREECOM = 32, MJB_SENS_CLOCK = 35
+	MJB_SENS_FRAMELINVEL = 28, MJB_SENS_FRAMEANGVEL = 29, MJB_SENS_FRAMELINACC = 30, MJB_SENS_FRAMEANGACC = 31,
+	MJB_SENS_SUBTREECOM = 32, MJB_SENS_CLOCK = 35
 };
 enum { MJB_STAGE_NONE = 0, MJB_STAGE_POS = 1, MJB_STAGE_VEL = 2, MJB_STAGE_ACC = 3 };
 enum { MJB_EQ_CONNECT = 0, MJB_EQ_WELD = 1, MJB_EQ_JOINT = 2, MJB_EQ_TENDON = 3 }; /* mjtEq (distance not implemented) */

@@ -80,7 +80,7 @@ struct mjb_model {
 	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense, body_anc;
 	std::vector<int> sens_copy, sens_slow, dof_act_adr, dof_act_id;
 	int sens_ncopy[3] = { 0, 0, 0 }, sens_nslow[3] = { 0, 0, 0 }, sens_ncopy_max = 0;
-	int eulerdamp = 0, maxdepth = 0, kin_rounds = 0;
+	int eulerdamp = 0, maxdepth = 0, kin_rounds = 0, need_rnepost = 0;
 	int field_size[MJB_F_COUNT]{};
 	FrameLayout L{}, Lc{};
 };
@@ -143,12 +143,22 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	for (int i = 0; i < d.nsensor; i++)
 		if (d.sensor_objtype[i] == MJB_OBJ_BODY || d.sensor_reftype[i] == MJB_OBJ_BODY) body_sensor = true;
 	const bool alias_b = compact && !body_sensor;
+	bool need_post = false;
+	for (int i = 0; i < d.nsensor; i++) {
+		const int t = d.sensor_type[i];
+		if (t == MJB_SENS_TOUCH || t == MJB_SENS_ACCELEROMETER || t == MJB_SENS_FORCE || t == MJB_SENS_TORQUE ||
+		    t == MJB_SENS_FRAMELINACC || t == MJB_SENS_FRAMEANGACC)
+			need_post = true;
+	}
+	M->need_rnepost = need_post ? 1 : 0;
 	for (const FieldInfo &fi : kFields) {
 		int n = dim(fi);
 		if (idx == MJB_F_efc_AR) n = 0;  // the GPU solver is AR-free
 		if (idx == MJB_F_efc_B && d.solver == MJB_SOL_NEWTON) n = 0;  // the primal solver needs no J M^-1
 		if (!compact) M->field_size[idx] = n;
-		const bool in_a = compact && (idx == MJB_F_crb || idx == MJB_F_cacc || idx == MJB_F_cfrc_body);
+		if ((idx == MJB_F_cfrc_int || idx == MJB_F_cfrc_ext) && !need_post) n = 0;  // computed only when a sensor needs them
+		// (with rne_post the true cacc is written between fwd_acceleration and Euler, whose rhs shares region A)
+		const bool in_a = compact && (idx == MJB_F_crb || (idx == MJB_F_cacc && !need_post) || idx == MJB_F_cfrc_body);
 		const bool in_b = alias_b && (idx == MJB_F_ximat || idx == MJB_F_cvel || idx == MJB_F_cdof_dot);
 		if (compact && idx == MJB_F_xfrc_applied) n = 0;
 		if (fi.kind == 3) {
@@ -174,6 +184,8 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	off += newton ? 3 * d.nefcmax : 0;
 	L.nwt_hc = off;
 	off += (newton && d.cone == MJB_CONE_ELLIPTIC) ? 36 * d.nconmax : 0;
+	L.cwrench = off;
+	off += need_post ? 6 * d.nconmax : 0;
 	L.MhB = off;
 	off += d.nM;
 	L.qH = off;
@@ -186,7 +198,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		L.kinloc = a0;
 		L.crb = a0;
 		L.crbbuf = a0 + n_crb;
-		L.cacc = a0;
+		if (!need_post) L.cacc = a0;
 		L.cfrc_body = a0 + n_c6;
 		L.eulerx = a0;
 		int sz = n_kin;
@@ -329,6 +341,20 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		fail(MJB_EUNSUPPORTED, "mjb_compile: nv = %d, nbody = %d: the tree stages use 64-bit ancestor / subtree masks "
 		                       "(nv <= 64, nbody <= 64)", d.nv, d.nbody);
 		return nullptr;
+	}
+	for (int i = 0; i < d.nsensor; i++) {
+		static const int ok[] = { MJB_SENS_TOUCH, MJB_SENS_ACCELEROMETER, MJB_SENS_VELOCIMETER, MJB_SENS_GYRO, MJB_SENS_FORCE,
+			                      MJB_SENS_TORQUE, MJB_SENS_JOINTPOS, MJB_SENS_JOINTVEL, MJB_SENS_TENDONPOS, MJB_SENS_TENDONVEL,
+			                      MJB_SENS_ACTUATORPOS, MJB_SENS_ACTUATORVEL, MJB_SENS_ACTUATORFRC, MJB_SENS_BALLQUAT,
+			                      MJB_SENS_BALLANGVEL, MJB_SENS_FRAMEPOS, MJB_SENS_FRAMEQUAT, MJB_SENS_FRAMEXAXIS,
+			                      MJB_SENS_FRAMEYAXIS, MJB_SENS_FRAMEZAXIS, MJB_SENS_FRAMELINVEL, MJB_SENS_FRAMEANGVEL,
+			                      MJB_SENS_FRAMELINACC, MJB_SENS_FRAMEANGACC, MJB_SENS_SUBTREECOM, MJB_SENS_CLOCK };
+		bool found = false;
+		for (int t : ok) found = found || t == d.sensor_type[i];
+		if (!found) {
+			fail(MJB_EUNSUPPORTED, "mjb_compile: sensor %d has type %d, which is not implemented", i, d.sensor_type[i]);
+			return nullptr;
+		}
 	}
 	for (int i = 0; i < d.neq; i++) {
 		const int t = d.eq_type[i], a = d.eq_obj1id[i], b = d.eq_obj2id[i];
@@ -694,6 +720,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	dm.M_dense = (mjb_ciptr)(di + o_md);
 	dm.body_anc = (mjb_ciptr)(di + o_an);
 	dm.kin_rounds = M->kin_rounds;
+	dm.need_rnepost = M->need_rnepost;
 	dm.sens_copy = (mjb_ciptr)(di + o_sc);
 	dm.sens_slow = (mjb_ciptr)(di + o_ss);
 	dm.dof_act_adr = (mjb_ciptr)(di + o_aa);

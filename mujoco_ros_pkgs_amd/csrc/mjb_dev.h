@@ -48,6 +48,7 @@ struct DevModel {
 	mjb_ciptr body_anc;      // [kin_rounds + 1][nbody] ancestor at distance 2^r (0 = world / beyond the root)
 	mjb_ciptr body_submask;  // [nbody][2] bit i set: body i belongs to the body's subtree (incl. itself), nbody <= 64
 	int eulerdamp;           // any dof_damping > 0 and EULERDAMP not disabled
+	int need_rnepost;        // an acceleration-stage sensor needs mj_rnePostConstraint (cacc / cfrc_int / cfrc_ext)
 	int kin_rounds;          // ceil(log2(max body depth)): rounds of the pointer-jumping kinematics
 	int maxdepth;          // max dof_depth
 };
@@ -72,6 +73,7 @@ struct FrameLayout {
 	int nwt_row;   // [3*nefcmax] Newton: per-row jaref, jv, Hessian weight
 	int nwt_hc;    // [36*nconmax] Newton: Hessian blocks of the elliptic cones (size 0 unless cone == elliptic)
 	int iscratch;  // transient int scratch: max(ncollpair, njnt + nconmax)
+	int cwrench;  // [nconmax][6] world contact wrenches (rne_post scratch)
 	int kinloc;    // [7*nbody] kinematics: pose of each body in its parent frame (transient)
 	int crbbuf;    // [6*nv]    crb: crb[body(i)] * cdof_i (transient)
 	int eulerx;    // [nv]      Euler: velocity-update right-hand side / solution (transient)

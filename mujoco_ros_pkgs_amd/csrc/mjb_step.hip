@@ -1002,14 +1002,14 @@ DEVI void frame_of(CModel m, CLayout L, const double *f, int objtype, int id, co
 	}
 }
 
-DEVI void object_velocity(CModel m, CLayout L, const double *f, int objtype, int id, double *res,
-                          bool local)
+// com-based spatial motion vector (cvel or cacc) of the object's body moved to the object's frame origin
+DEVI void object_motion(CModel m, CLayout L, const double *f, int field_off, int objtype, int id, double *res, bool local)
 {
 	const double *pos, *mat;
 	double q[4], v[6], np[3], op[3], dif[3], cr[3];
 	const int body = objtype == MJB_OBJ_GEOM ? m.geom_bodyid[id] : (objtype == MJB_OBJ_SITE ? m.site_bodyid[id] : id);
 	frame_of(m, L, f, objtype, id, &pos, &mat, q);
-	ld6(v, f + L.cvel + 6 * body);
+	ld6(v, f + field_off + 6 * body);
 	ld3(np, pos);
 	ld3(op, f + L.subtree_com + 3 * m.body_rootid[body]);
 	dif[0] = np[0] - op[0]; dif[1] = np[1] - op[1]; dif[2] = np[2] - op[2];
@@ -1024,6 +1024,159 @@ DEVI void object_velocity(CModel m, CLayout L, const double *f, int objtype, int
 		res[0] = v[0]; res[1] = v[1]; res[2] = v[2];
 		res[3] = lin[0]; res[4] = lin[1]; res[5] = lin[2];
 	}
+}
+DEVI void object_velocity(CModel m, CLayout L, const double *f, int objtype, int id, double *res, bool local)
+{
+	object_motion(m, L, f, L.cvel, objtype, id, res, local);
+}
+// mj_objectAcceleration: cacc moved to the object + the rotating-frame term omega x v
+DEVI void object_acceleration(CModel m, CLayout L, const double *f, int objtype, int id, double *res, bool local)
+{
+	double vel[6], cr[3];
+	object_motion(m, L, f, L.cacc, objtype, id, res, local);
+	object_motion(m, L, f, L.cvel, objtype, id, vel, local);
+	cross3(cr, vel, vel + 3);
+	res[3] += cr[0]; res[4] += cr[1]; res[5] += cr[2];
+}
+
+// mj_contactForce: force / torque of contact c in its own frame (normal first); zero if it has no rows
+DEVI void contact_force(CModel m, CLayout L, const double *f, const int *fi, int c, double *res)
+{
+	for (int k = 0; k < 6; k++) res[k] = 0;
+	const int adr = fi[L.contact_efc_address + c], dim = fi[L.contact_dim + c];
+	if (adr < 0) return;
+	if (dim == 1) {
+		res[0] = f[L.efc_force + adr];
+	} else if (m.cone == MJB_CONE_ELLIPTIC) {
+		for (int k = 0; k < 6; k++)
+			if (k < dim) res[k] = f[L.efc_force + adr + k];
+	} else {
+		for (int k = 0; k < 10; k++)
+			if (k < 2 * (dim - 1)) res[0] += f[L.efc_force + adr + k];
+		for (int k = 0; k < 5; k++)
+			if (k < dim - 1)
+				res[1 + k] = (f[L.efc_force + adr + 2 * k] - f[L.efc_force + adr + 2 * k + 1]) * f[L.contact_friction + 5 * c + k];
+	}
+}
+
+// (torque, force) about `oldpos` re-expressed about `newpos`
+DEVI void move_force(double *res, const double *vec, const double *newpos, const double *oldpos)
+{
+	const double dif[3] = { newpos[0] - oldpos[0], newpos[1] - oldpos[1], newpos[2] - oldpos[2] };
+	double cr[3];
+	cross3(cr, dif, vec + 3);
+	res[0] = vec[0] - cr[0]; res[1] = vec[1] - cr[1]; res[2] = vec[2] - cr[2];
+	res[3] = vec[3]; res[4] = vec[4]; res[5] = vec[5];
+}
+
+// ------------------------------------------------------------------------------------------------
+// mj_rnePostConstraint (only for models with touch / accelerometer / force / torque / frame*acc sensors): cacc with
+// qacc, cfrc_ext = xfrc_applied + contact forces, cfrc_int = subtree sum of (inertial force - cfrc_ext).  Flat mask
+// sums like rne: lane = contact (world wrench), lane = body (cacc, own force), lane = body (subtree sum).
+// ------------------------------------------------------------------------------------------------
+template <int G> STAGE void rne_post(CModel m, CLayout L, const Env &e, bool use_xfrc)
+{
+	double *f = e.f;
+	int *fi = e.fi;
+	const int lane = e.lane, ncon = m.nconmax > 0 ? fi[L.ncon] : 0;
+	double *wr = f + L.cwrench;  // [ncon][6] world (torque, force) of every contact at its position
+	for (int c = lane; c < ncon; c += G) {
+		double lf[6], fr[9], w[6];
+		contact_force(m, L, f, fi, c, lf);
+		ld9(fr, f + L.contact_frame + 9 * c);
+		matTvec3(w + 3, fr, lf);
+		matTvec3(w, fr, lf + 3);
+		st6(wr + 6 * c, w);
+	}
+	gsync<G>();
+	const bool grav = !(m.disableflags & MJB_DSBL_GRAVITY);
+	for (int b = lane; b < m.nbody; b += G) {
+		double ext[6] = { 0, 0, 0, 0, 0, 0 }, com[3];
+		ld3(com, f + L.subtree_com + 3 * m.body_rootid[b]);
+		if (b > 0 && use_xfrc) {
+			const double *x = f + L.xfrc_applied + 6 * b;
+			const double cf[6] = { x[3], x[4], x[5], x[0], x[1], x[2] };
+			double ip[3], r[6];
+			ld3(ip, f + L.xipos + 3 * b);
+			move_force(r, cf, com, ip);
+			for (int k = 0; k < 6; k++) ext[k] += r[k];
+		}
+		for (int c = 0; c < ncon; c++) {
+			if (b == 0 || fi[L.contact_efc_address + c] < 0) continue;
+			const int b1 = m.geom_bodyid[fi[L.contact_geom + 2 * c]], b2 = m.geom_bodyid[fi[L.contact_geom + 2 * c + 1]];
+			if (b1 != b && b2 != b) continue;
+			double w[6], cp[3], r[6];
+			ld6(w, wr + 6 * c);
+			ld3(cp, f + L.contact_pos + 3 * c);
+			move_force(r, w, com, cp);
+			const double sg = (b2 == b ? 1.0 : 0.0) - (b1 == b ? 1.0 : 0.0);
+			for (int k = 0; k < 6; k++) ext[k] += sg * r[k];
+		}
+		st6(f + L.cfrc_ext + 6 * b, ext);
+		const unsigned int lo = (unsigned int)m.body_dofmask[2 * b], hi = (unsigned int)m.body_dofmask[2 * b + 1];
+		double a[6] = { 0, 0, 0, grav ? -m.gravity[0] : 0.0, grav ? -m.gravity[1] : 0.0, grav ? -m.gravity[2] : 0.0 };
+		for (int d = 0; d < m.nv; d++) {
+			const bool on = maskbit(lo, hi, d);
+			const double qv = on ? f[L.qvel + d] : 0.0, qa = on ? f[L.qacc + d] : 0.0;
+			for (int c = 0; c < 6; c++) a[c] += f[L.cdof_dot + 6 * d + c] * qv + f[L.cdof + 6 * d + c] * qa;
+		}
+		st6(f + L.cacc + 6 * b, a);
+		double own[6] = { 0, 0, 0, 0, 0, 0 };
+		if (b > 0) {
+			double I[10], v[6], t[6], t1[6];
+			ld10(I, f + L.cinert + 10 * b);
+			ld6(v, f + L.cvel + 6 * b);
+			mul_inert_vec(own, I, a);
+			mul_inert_vec(t, I, v);
+			cross_force(t1, v, t);
+			for (int k = 0; k < 6; k++) own[k] += t1[k] - ext[k];
+		}
+		st6(f + L.cfrc_body + 6 * b, own);
+	}
+	gsync<G>();
+	for (int b = lane; b < m.nbody; b += G) {
+		const unsigned int lo = (unsigned int)m.body_submask[2 * b], hi = (unsigned int)m.body_submask[2 * b + 1];
+		double acc[6] = { 0, 0, 0, 0, 0, 0 };
+		for (int i = 1; i < m.nbody; i++) {
+			const bool on = maskbit(lo, hi, i);
+			for (int k = 0; k < 6; k++) {
+				const double v = f[L.cfrc_body + 6 * i + k];
+				acc[k] += on ? v : 0.0;
+			}
+		}
+		st6(f + L.cfrc_int + 6 * b, acc);
+	}
+	gsync<G>();
+}
+
+// does the ray p + s dir (s >= 0) meet the site volume (sphere / box)?  -- the touch sensor's zone test
+DEVI bool ray_hits_site(CModel m, CLayout L, const double *f, int site, const double *p, const double *dir)
+{
+	double M[9], rel[3], lp[3], ld[3];
+	ld9(M, f + L.site_xmat + 9 * site);
+	for (int k = 0; k < 3; k++) rel[k] = p[k] - f[L.site_xpos + 3 * site + k];
+	matTvec3(lp, M, rel);
+	matTvec3(ld, M, dir);
+	const double sz[3] = { m.site_size[3 * site], m.site_size[3 * site + 1], m.site_size[3 * site + 2] };
+	if (m.site_type[site] == MJB_GEOM_SPHERE) {
+		const double b = dot3(lp, ld), c = dot3(lp, lp) - sz[0] * sz[0], a = dot3(ld, ld);
+		if (c <= 0) return true;
+		const double det = b * b - a * c;
+		return det >= 0 && -b + sqrt(det) >= 0 && a > 0;
+	}
+	double tmin = 0, tmax = 1e300;
+	for (int k = 0; k < 3; k++) {
+		if (fabs(ld[k]) < MJB_MINVAL) {
+			if (fabs(lp[k]) > sz[k]) return false;
+			continue;
+		}
+		double t1 = (-sz[k] - lp[k]) / ld[k], t2 = (sz[k] - lp[k]) / ld[k];
+		if (t1 > t2) { const double sw = t1; t1 = t2; t2 = sw; }
+		if (t1 > tmin) tmin = t1;
+		if (t2 < tmax) tmax = t2;
+		if (tmin > tmax) return false;
+	}
+	return true;
 }
 
 template <int G> STAGE void sensors(CModel m, CLayout L, const Env &e, int stage, int compact)
@@ -1130,6 +1283,50 @@ template <int G> STAGE void sensors(CModel m, CLayout L, const Env &e, int stage
 			break;
 		}
 		case MJB_SENS_ACTUATORFRC: out[0] = f[L.actuator_force + id]; break;
+		case MJB_SENS_TENDONPOS: out[0] = f[L.ten_length + id]; break;
+		case MJB_SENS_TENDONVEL: out[0] = f[L.ten_velocity + id]; break;
+		case MJB_SENS_ACCELEROMETER: {
+			double acc[6];
+			object_acceleration(m, L, f, MJB_OBJ_SITE, id, acc, true);
+			out[0] = acc[3]; out[1] = acc[4]; out[2] = acc[5];
+			break;
+		}
+		case MJB_SENS_FORCE: case MJB_SENS_TORQUE: {
+			const int body = m.site_bodyid[id];
+			double ci[6], sp[3], com[3], r[6], SM[9];
+			ld6(ci, f + L.cfrc_int + 6 * body);
+			ld3(sp, f + L.site_xpos + 3 * id);
+			ld3(com, f + L.subtree_com + 3 * m.body_rootid[body]);
+			move_force(r, ci, sp, com);
+			ld9(SM, f + L.site_xmat + 9 * id);
+			matTvec3(out, SM, type == MJB_SENS_FORCE ? r + 3 : r);
+			break;
+		}
+		case MJB_SENS_TOUCH: {
+			const int body = m.site_bodyid[id];
+			const int ncon = m.nconmax > 0 ? e.fi[L.ncon] : 0;
+			double tot = 0;
+			for (int c = 0; c < ncon; c++) {
+				const int b1 = m.geom_bodyid[e.fi[L.contact_geom + 2 * c]], b2 = m.geom_bodyid[e.fi[L.contact_geom + 2 * c + 1]];
+				if (e.fi[L.contact_efc_address + c] < 0 || (body != b1 && body != b2)) continue;
+				double lf[6], cp[3];
+				contact_force(m, L, f, e.fi, c, lf);
+				if (lf[0] <= 0) continue;
+				const double sg = body == b2 ? -1.0 : 1.0;
+				const double ray[3] = { sg * f[L.contact_frame + 9 * c], sg * f[L.contact_frame + 9 * c + 1], sg * f[L.contact_frame + 9 * c + 2] };
+				ld3(cp, f + L.contact_pos + 3 * c);
+				if (ray_hits_site(m, L, f, id, cp, ray)) tot += lf[0];
+			}
+			out[0] = tot;
+			break;
+		}
+		case MJB_SENS_FRAMELINACC: case MJB_SENS_FRAMEANGACC: {
+			double acc[6];
+			object_acceleration(m, L, f, ot, id, acc, false);
+			const int o = type == MJB_SENS_FRAMELINACC ? 3 : 0;
+			out[0] = acc[o]; out[1] = acc[o + 1]; out[2] = acc[o + 2];
+			break;
+		}
 		default: break;
 		}
 		const double cutoff = m.sensor_cutoff[i];
@@ -1442,6 +1639,7 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 		VIEW(P, compact, fwd_constraint<G>(m, L, e));
 	}
 	PROF(11);
+	VIEW(P, compact, if (m.need_rnepost) rne_post<G>(m, L, e, s.use_xfrc != 0));
 	VIEW(P, compact, sensors<G>(m, L, e, MJB_STAGE_ACC, compact));
 	PROF(12);
 }

@@ -27,11 +27,16 @@ JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
 GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX = 0, 2, 3, 6
 GEOM_TYPES = {"plane": GEOM_PLANE, "sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE, "box": GEOM_BOX}
 JNT_TYPES = {"free": JNT_FREE, "ball": JNT_BALL, "slide": JNT_SLIDE, "hinge": JNT_HINGE}
-OBJ = {"body": 1, "xbody": 2, "joint": 3, "geom": 5, "site": 6, "actuator": 18}
+OBJ = {"body": 1, "xbody": 2, "joint": 3, "geom": 5, "site": 6, "tendon": 17, "actuator": 18}
 SENSORS = {  # name -> (mjtSensor, dim, needstage, default objtype)
     "touch": (0, 1, 3, "site"),
+    "accelerometer": (1, 3, 3, "site"),
     "velocimeter": (2, 3, 2, "site"),
     "gyro": (3, 3, 2, "site"),
+    "force": (4, 3, 3, "site"),
+    "torque": (5, 3, 3, "site"),
+    "tendonpos": (10, 1, 1, "tendon"),
+    "tendonvel": (11, 1, 2, "tendon"),
     "jointpos": (8, 1, 1, "joint"),
     "jointvel": (9, 1, 2, "joint"),
     "actuatorpos": (12, 1, 1, "actuator"),
@@ -46,6 +51,8 @@ SENSORS = {  # name -> (mjtSensor, dim, needstage, default objtype)
     "framezaxis": (27, 3, 1, None),
     "framelinvel": (28, 3, 2, None),
     "frameangvel": (29, 3, 2, None),
+    "framelinacc": (30, 3, 3, None),
+    "frameangacc": (31, 3, 3, None),
     "subtreecom": (32, 3, 1, "body"),
     "clock": (35, 1, 1, None),
 }
@@ -472,7 +479,13 @@ class _Compiler:
 
     def _site(self, node, bid, childclass):
         a = self._merged(node, childclass)
-        s = dict(name=a.get("name", f"site{len(self.sites)}"), body=bid,
+        styp = a.get("type", "sphere")
+        if styp not in ("sphere", "box"):
+            raise MjcfError(f"site type '{styp}' is not supported (sphere / box)")
+        size = np.full(3, 0.005)
+        sz = _floats(a.get("size", "0.005"))
+        size[:sz.size] = sz
+        s = dict(name=a.get("name", f"site{len(self.sites)}"), body=bid, type=GEOM_TYPES[styp], size=size,
                  pos=_floats(a.get("pos", "0 0 0"), 3, "site pos"), quat=self._orientation(a, "site"))
         self.sites.append(s)
         return s
@@ -566,7 +579,7 @@ class _Compiler:
         elif objkind is None:
             s.update(objtype=a["objtype"], objname=a["objname"], reftype=a.get("reftype"), refname=a.get("refname"))
         else:
-            key = {"site": "site", "joint": "joint", "actuator": "actuator", "body": "body"}[objkind]
+            key = {"site": "site", "joint": "joint", "actuator": "actuator", "body": "body", "tendon": "tendon"}[objkind]
             s.update(objtype=objkind, objname=a[key])
         self.sensors.append(s)
 
@@ -577,7 +590,8 @@ class _Compiler:
         m = Model()
         names = dict(body=[b["name"] for b in B], joint=[j["name"] for j in J], geom=[g["name"] for g in Gm],
                      site=[s["name"] for s in S], actuator=[a["name"] for a in self.actuators],
-                     sensor=[s["name"] for s in self.sensors])
+                     sensor=[s["name"] for s in self.sensors],
+                     tendon=[a.get("name", f"tendon{i}") for i, (a, _) in enumerate(self.tendons)])
         for kind in ("body", "joint", "site", "actuator"):
             nn = [n for n in names[kind] if n]
             if len(set(nn)) != len(nn):
@@ -765,6 +779,8 @@ class _Compiler:
         m["site_bodyid"] = np.array([s["body"] for s in S], I)
         m["site_pos"] = np.array([s["pos"] for s in S], D).reshape(nsite, 3)
         m["site_quat"] = np.array([s["quat"] for s in S], D).reshape(nsite, 4)
+        m["site_type"] = np.array([s["type"] for s in S], I)
+        m["site_size"] = np.array([s["size"] for s in S], D).reshape(nsite, 3)
         m["site_sameframe"] = np.array(
             [int(np.all(s["pos"] == 0) and np.all(s["quat"] == [1, 0, 0, 0])) for s in S], I)
 

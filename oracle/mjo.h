@@ -93,6 +93,8 @@ double mjo_normal(uint64_t seed, uint64_t env, uint32_t step, uint32_t idx);
 /* the sensors plugin's per-step messages (mjo_sensor_pack.c) */
 void mjo_sensor_pack(const mjb_model_desc *m, const double *sensordata, const int *set_flag, const double *mean,
                      const double *sigma, uint64_t seed, uint64_t env, uint32_t step, float *value, float *truth);
+void mjo_rne_post_constraint(const mjb_model_desc *m, mjo_data *d);
+int mjo_needs_rne_post(const mjb_model_desc *m);
 void mjo_tendon(const mjb_model_desc *m, mjo_data *d);
 void mjo_tendon_vel(const mjb_model_desc *m, mjo_data *d);
 void mjo_ctrl_noise(const mjb_model_desc *m, mjo_data *d, double noise_std, double noise_rate, uint64_t seed,

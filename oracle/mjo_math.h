@@ -250,4 +250,21 @@ static inline void transform_spatial_motion(double *res, const double *vec, cons
 	}
 }
 
+/* mju_transformSpatial with flg_force = 1: (torque, force) moved from `oldpos` to `newpos`, optionally rotated */
+static inline void transform_spatial_force(double *res, const double *vec, const double *newpos, const double *oldpos,
+                                           const double *rotnew2old)
+{
+	double cros[3], dif[3], tran[6];
+	memcpy(tran, vec, 6 * sizeof(double));
+	v3_sub(dif, newpos, oldpos);
+	v3_cross(cros, dif, vec + 3);
+	v3_sub(tran, vec, cros);
+	if (rotnew2old) {
+		m3_mulvecT(res, rotnew2old, tran);
+		m3_mulvecT(res + 3, rotnew2old, tran + 3);
+	} else {
+		memcpy(res, tran, 6 * sizeof(double));
+	}
+}
+
 #endif

@@ -567,6 +567,137 @@ static void object_velocity(const mjb_model_desc *m, const mjo_data *d, int objt
 	                         local ? mat : NULL);
 }
 
+/* mj_contactForce: contact force / torque in the contact frame (normal first) from the solver's row forces */
+static void contact_force(const mjb_model_desc *m, const mjo_data *d, int c, double *res)
+{
+	for (int k = 0; k < 6; k++) res[k] = 0;
+	int adr = d->contact_efc_address[c], dim = d->contact_dim[c];
+	if (adr < 0) return;
+	if (dim == 1) {
+		res[0] = d->efc_force[adr];
+	} else if (m->cone == MJB_CONE_ELLIPTIC) {
+		for (int k = 0; k < dim; k++) res[k] = d->efc_force[adr + k];
+	} else {
+		const double *fri = d->contact_friction + 5 * c;
+		for (int k = 0; k < 2 * (dim - 1); k++) res[0] += d->efc_force[adr + k];
+		for (int k = 0; k < dim - 1; k++) res[1 + k] = (d->efc_force[adr + 2 * k] - d->efc_force[adr + 2 * k + 1]) * fri[k];
+	}
+}
+
+/* rows of this contact exist?  (contact_efc_address is only meaningful for contacts that made it into the rows) */
+static int contact_active(const mjb_model_desc *m, const mjo_data *d, int c)
+{
+	if (!(d->contact_dist[c] < d->contact_includemargin[c])) return 0;
+	int adr = d->contact_efc_address[c], dim = d->contact_dim[c];
+	int nrow = dim == 1 ? 1 : (m->cone == MJB_CONE_ELLIPTIC ? dim : 2 * (dim - 1));
+	return adr >= 0 && adr + nrow <= d->nefc[0] && (d->efc_type[adr] >= MJB_CNSTR_CONTACT_FRICTIONLESS) && d->efc_id[adr] == c;
+}
+
+/* mj_rnePostConstraint (restated from memory of MuJoCo 2.3.7 engine_core_smooth.c): body accelerations cacc with
+ * qacc included, external forces cfrc_ext (xfrc_applied + contact forces) and the interaction force cfrc_int each
+ * body exchanges with its parent, all as spatial vectors (rotation first) about the subtree com of the tree root */
+void mjo_rne_post_constraint(const mjb_model_desc *m, mjo_data *d)
+{
+	int nb = m->nbody;
+	memset(d->cfrc_ext, 0, sizeof(double) * 6 * (size_t)nb);
+	for (int i = 1; i < nb; i++) {
+		const double *x = d->xfrc_applied + 6 * i;
+		if (x[0] == 0 && x[1] == 0 && x[2] == 0 && x[3] == 0 && x[4] == 0 && x[5] == 0) continue;
+		double cf[6] = { x[3], x[4], x[5], x[0], x[1], x[2] }, r[6];
+		transform_spatial_force(r, cf, d->subtree_com + 3 * m->body_rootid[i], d->xipos + 3 * i, NULL);
+		for (int k = 0; k < 6; k++) d->cfrc_ext[6 * i + k] += r[k];
+	}
+	for (int c = 0; c < d->ncon[0]; c++) {
+		if (!contact_active(m, d, c)) continue;
+		double lf[6], cf[6], r[6];
+		contact_force(m, d, c, lf);
+		m3_mulvecT(cf + 3, d->contact_frame + 9 * c, lf);   /* force  = frame' * lf[0:3] */
+		m3_mulvecT(cf, d->contact_frame + 9 * c, lf + 3);   /* torque = frame' * lf[3:6] */
+		int b1 = m->geom_bodyid[d->contact_geom[2 * c]], b2 = m->geom_bodyid[d->contact_geom[2 * c + 1]];
+		if (b1) {
+			transform_spatial_force(r, cf, d->subtree_com + 3 * m->body_rootid[b1], d->contact_pos + 3 * c, NULL);
+			for (int k = 0; k < 6; k++) d->cfrc_ext[6 * b1 + k] -= r[k];
+		}
+		if (b2) {
+			transform_spatial_force(r, cf, d->subtree_com + 3 * m->body_rootid[b2], d->contact_pos + 3 * c, NULL);
+			for (int k = 0; k < 6; k++) d->cfrc_ext[6 * b2 + k] += r[k];
+		}
+	}
+	memset(d->cacc, 0, 6 * sizeof(double));
+	if (!(m->disableflags & MJB_DSBL_GRAVITY))
+		for (int k = 0; k < 3; k++) d->cacc[3 + k] = -m->gravity[k];
+	memset(d->cfrc_int, 0, 6 * sizeof(double));
+	for (int i = 1; i < nb; i++) {
+		int bda = m->body_dofadr[i], nd = m->body_dofnum[i];
+		double t1[6], t2[6], fb[6];
+		mul_dof_vec(t1, d->cdof_dot + 6 * bda, d->qvel + bda, nd);
+		mul_dof_vec(t2, d->cdof + 6 * bda, d->qacc + bda, nd);
+		for (int k = 0; k < 6; k++) d->cacc[6 * i + k] = d->cacc[6 * m->body_parentid[i] + k] + t1[k] + t2[k];
+		mul_inert_vec(fb, d->cinert + 10 * i, d->cacc + 6 * i);
+		mul_inert_vec(t1, d->cinert + 10 * i, d->cvel + 6 * i);
+		cross_force(t2, d->cvel + 6 * i, t1);
+		for (int k = 0; k < 6; k++) d->cfrc_int[6 * i + k] = fb[k] + t2[k] - d->cfrc_ext[6 * i + k];
+	}
+	for (int i = nb - 1; i > 0; i--)
+		for (int k = 0; k < 6; k++) d->cfrc_int[6 * m->body_parentid[i] + k] += d->cfrc_int[6 * i + k];
+}
+
+int mjo_needs_rne_post(const mjb_model_desc *m)
+{
+	for (int i = 0; i < m->nsensor; i++) {
+		int t = m->sensor_type[i];
+		if (t == MJB_SENS_TOUCH || t == MJB_SENS_ACCELEROMETER || t == MJB_SENS_FORCE || t == MJB_SENS_TORQUE ||
+		    t == MJB_SENS_FRAMELINACC || t == MJB_SENS_FRAMEANGACC)
+			return 1;
+	}
+	return 0;
+}
+
+/* mj_objectAcceleration */
+static void object_acceleration(const mjb_model_desc *m, const mjo_data *d, int objtype, int id, double *res, int local)
+{
+	const double *pos, *mat;
+	double q[4], vel[6], cr[3];
+	int body = objtype == MJB_OBJ_GEOM ? m->geom_bodyid[id] : (objtype == MJB_OBJ_SITE ? m->site_bodyid[id] : id);
+	frame_of(m, d, objtype, id, &pos, &mat, q);
+	const double *com = d->subtree_com + 3 * m->body_rootid[body];
+	transform_spatial_motion(res, d->cacc + 6 * body, pos, com, local ? mat : NULL);
+	transform_spatial_motion(vel, d->cvel + 6 * body, pos, com, local ? mat : NULL);
+	v3_cross(cr, vel, vel + 3);   /* rotating-frame correction: omega x v */
+	v3_addto(res + 3, cr);
+}
+
+/* does the ray p + s dir (s >= 0) meet the site volume?  sphere / box sites (mju_rayGeom restricted to what the touch
+ * sensor needs: a hit / no-hit answer) */
+static int ray_hits_site(const mjb_model_desc *m, const mjo_data *d, int site, const double *p, const double *dir)
+{
+	double rel[3], lp[3], ld[3];
+	v3_sub(rel, p, d->site_xpos + 3 * site);
+	m3_mulvecT(lp, d->site_xmat + 9 * site, rel);
+	m3_mulvecT(ld, d->site_xmat + 9 * site, dir);
+	const double *sz = m->site_size + 3 * site;
+	if (m->site_type[site] == MJB_GEOM_SPHERE) {
+		double b = v3_dot(lp, ld), c = v3_dot(lp, lp) - sz[0] * sz[0], a = v3_dot(ld, ld);
+		if (c <= 0) return 1;              /* origin inside */
+		double det = b * b - a * c;
+		return det >= 0 && -b + sqrt(det) >= 0 && a > 0;
+	}
+	/* box: slab test */
+	double tmin = 0, tmax = 1e300;
+	for (int k = 0; k < 3; k++) {
+		if (fabs(ld[k]) < MJO_MINVAL) {
+			if (fabs(lp[k]) > sz[k]) return 0;
+			continue;
+		}
+		double t1 = (-sz[k] - lp[k]) / ld[k], t2 = (sz[k] - lp[k]) / ld[k];
+		if (t1 > t2) { double sw = t1; t1 = t2; t2 = sw; }
+		if (t1 > tmin) tmin = t1;
+		if (t2 < tmax) tmax = t2;
+		if (tmin > tmax) return 0;
+	}
+	return 1;
+}
+
 void mjo_sensor(const mjb_model_desc *m, mjo_data *d, int stage)
 {
 	if (m->disableflags & MJB_DSBL_SENSOR) return;
@@ -647,6 +778,43 @@ void mjo_sensor(const mjb_model_desc *m, mjo_data *d, int stage)
 			break;
 		}
 		case MJB_SENS_ACTUATORFRC: out[0] = d->actuator_force[id]; break;
+		case MJB_SENS_TENDONPOS: out[0] = d->ten_length[id]; break;
+		case MJB_SENS_TENDONVEL: out[0] = d->ten_velocity[id]; break;
+		case MJB_SENS_ACCELEROMETER: {
+			double acc[6];
+			object_acceleration(m, d, MJB_OBJ_SITE, id, acc, 1);
+			v3_copy(out, acc + 3);
+			break;
+		}
+		case MJB_SENS_FORCE: case MJB_SENS_TORQUE: {
+			int body = m->site_bodyid[id];
+			double tmp[6];
+			transform_spatial_force(tmp, d->cfrc_int + 6 * body, d->site_xpos + 3 * id,
+			                        d->subtree_com + 3 * m->body_rootid[body], d->site_xmat + 9 * id);
+			v3_copy(out, type == MJB_SENS_FORCE ? tmp + 3 : tmp);
+			break;
+		}
+		case MJB_SENS_TOUCH: {
+			int body = m->site_bodyid[id];
+			out[0] = 0;
+			for (int c = 0; c < d->ncon[0]; c++) {
+				int b1 = m->geom_bodyid[d->contact_geom[2 * c]], b2 = m->geom_bodyid[d->contact_geom[2 * c + 1]];
+				if (!contact_active(m, d, c) || (body != b1 && body != b2)) continue;
+				double lf[6], ray[3];
+				contact_force(m, d, c, lf);
+				if (lf[0] <= 0) continue;
+				double sg = body == b2 ? -1.0 : 1.0;
+				for (int k = 0; k < 3; k++) ray[k] = sg * d->contact_frame[9 * c + k];
+				if (ray_hits_site(m, d, id, d->contact_pos + 3 * c, ray)) out[0] += lf[0];
+			}
+			break;
+		}
+		case MJB_SENS_FRAMELINACC: case MJB_SENS_FRAMEANGACC: {
+			double acc[6];
+			object_acceleration(m, d, ot, id, acc, 0);
+			v3_copy(out, type == MJB_SENS_FRAMELINACC ? acc + 3 : acc);
+			break;
+		}
 		default: break;
 		}
 		double cutoff = m->sensor_cutoff[i];
@@ -745,6 +913,7 @@ static void forward_rest(const mjb_model_desc *m, mjo_data *d)
 	mjo_fwd_actuation(m, d);
 	mjo_fwd_acceleration(m, d);
 	mjo_fwd_constraint(m, d);
+	if (mjo_needs_rne_post(m)) mjo_rne_post_constraint(m, d);
 	mjo_sensor(m, d, MJB_STAGE_ACC);
 }
 
