@@ -208,6 +208,36 @@ int mjb_sensor_pack(mjb_batch *b, uint64_t seed);
 int mjb_sensor_get(mjb_batch *b, int which, int env_lo, int env_hi, float *host);
 void *mjb_sensor_device_ptr(mjb_batch *b, int which);
 
+/* ---- device-side DefaultRobotHWSim::writeSim ----
+ * The reference's ros_control bridge writes the controllers' joint commands into mjData on every control callback
+ * (/root/reference mujoco_ros_control/src/default_robot_hw_sim.cpp:248-326): EFFORT -> qfrc_applied, POSITION -> qpos
+ * (qvel = 0), VELOCITY -> qvel, POSITION_PID / VELOCITY_PID -> qfrc_applied = clamp(PID(error, dt), +-effort_limit),
+ * with the e-stop rules (:251-261, :275, :305, :313-316).  Here the same write runs on the device at the start of
+ * every step of every env, from per-env command arrays resident in HBM, so closed-loop batches need no host
+ * callback.  PID = control_toolbox::Pid::computeCommand (absent dependency; restated from its documented algorithm:
+ * p e + clamp(i int(e), i_min, i_max) + d de/dt, anti-windup variant clamps the integral).  Position errors:
+ * prismatic cmd - q; continuous shortest angular distance; revolute: cmd clamped to [lower, upper] minus q (the
+ * reference calls angles::shortest_angular_distance_with_limits, equal to this whenever both lie inside the limits).
+ * Deviations, deliberate: joints are addressed by their MuJoCo joint id and qposadr (the reference indexes
+ * jnt_dofadr with the transmission index, which only coincides for hinge / slide-only models in URDF order). */
+enum { MJB_HW_EFFORT = 0, MJB_HW_POSITION = 1, MJB_HW_POSITION_PID = 2, MJB_HW_VELOCITY = 3, MJB_HW_VELOCITY_PID = 4 };
+enum { MJB_HW_REVOLUTE = 0, MJB_HW_CONTINUOUS = 1, MJB_HW_PRISMATIC = 2 };
+typedef struct mjb_hwsim_joint {
+	int joint;            /* MuJoCo joint id (hinge or slide) */
+	int method;           /* MJB_HW_* control method */
+	int kind;             /* MJB_HW_REVOLUTE / CONTINUOUS / PRISMATIC */
+	int antiwindup;
+	double p, i, d, i_max, i_min;
+	double effort_limit;  /* <= 0: unlimited */
+	double lower, upper;  /* joint limits (revolute / prismatic) */
+} mjb_hwsim_joint;
+/* Register the controlled joints (replaces any previous set; n = 0 switches the stage off).  Commands start at 0. */
+int mjb_hwsim_configure(mjb_batch *b, int n, const mjb_hwsim_joint *joints);
+/* which: 0 position, 1 velocity, 2 effort commands; cmd is [env_hi - env_lo][n] in registration order */
+int mjb_hwsim_set_command(mjb_batch *b, int which, int env_lo, int env_hi, const double *cmd);
+void *mjb_hwsim_command_ptr(mjb_batch *b, int which); /* device [nenv][n] */
+int mjb_hwsim_estop(mjb_batch *b, int active);
+
 /* Profiling builds only (libmjb_prof.so): per-stage shader-cycle sums [0..31] and call counts [32..63] of
  * env 0; all zero in the production build. */
 int mjb_debug_profile(mjb_batch *b, unsigned long long *out64, int clear);

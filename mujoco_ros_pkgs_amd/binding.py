@@ -100,6 +100,16 @@ def make_desc(model):
     return d, keep
 
 
+class HwsimJoint(C.Structure):
+    """mjb_hwsim_joint of include/mjb.h"""
+    _fields_ = [("joint", C.c_int), ("method", C.c_int), ("kind", C.c_int), ("antiwindup", C.c_int),
+                ("p", C.c_double), ("i", C.c_double), ("d", C.c_double), ("i_max", C.c_double), ("i_min", C.c_double),
+                ("effort_limit", C.c_double), ("lower", C.c_double), ("upper", C.c_double)]
+
+
+HW_METHODS = {"effort": 0, "position": 1, "position_pid": 2, "velocity": 3, "velocity_pid": 4}
+HW_KINDS = {"revolute": 0, "continuous": 1, "prismatic": 2}
+
 _lib = None
 
 
@@ -131,6 +141,10 @@ def load_library(path=None):
         "mjb_nenv": (ci, [vp]),
         "mjb_set_launch": (ci, [vp, ci, ci]),
         "mjb_set_keep_frame": (ci, [vp, ci]),
+        "mjb_hwsim_configure": (ci, [vp, ci, C.POINTER(HwsimJoint)]),
+        "mjb_hwsim_set_command": (ci, [vp, ci, ci, ci, C.POINTER(cd)]),
+        "mjb_hwsim_command_ptr": (vp, [vp, ci]),
+        "mjb_hwsim_estop": (ci, [vp, ci]),
         "mjb_sensor_set_noise": (ci, [vp, ci, ci, C.POINTER(cd), C.POINTER(cd)]),
         "mjb_sensor_pack": (ci, [vp, C.c_uint64]),
         "mjb_sensor_get": (ci, [vp, ci, ci, ci, C.POINTER(C.c_float)]),

@@ -108,6 +108,12 @@ struct mjb_batch {
 	double *sens_mean_dev = nullptr, *sens_sigma_dev = nullptr;
 	float *sens_value = nullptr, *sens_truth = nullptr;
 	bool sens_dirty = true, sens_packed = false;
+	// device-side DefaultRobotHWSim (mjb_hwsim_*)
+	HwSim hw{};
+	int *hw_ints = nullptr;        // joint | method | kind | antiwindup, [4][n]
+	double *hw_gains = nullptr;    // [n][8]
+	double *hw_cmd = nullptr;      // pos | vel | eff | hold, [4][nenv][n]
+	double *hw_pid = nullptr;      // [nenv][n][2]
 };
 
 namespace {
@@ -615,6 +621,10 @@ void mjb_free_batch(mjb_batch *b)
 	if (b->blob) hipFree(b->blob);
 	if (b->mask_dev) hipFree(b->mask_dev);
 	if (b->params_dev) hipFree(b->params_dev);
+	if (b->hw_ints) hipFree(b->hw_ints);
+	if (b->hw_gains) hipFree(b->hw_gains);
+	if (b->hw_cmd) hipFree(b->hw_cmd);
+	if (b->hw_pid) hipFree(b->hw_pid);
 	if (b->sens_flag_dev) hipFree(b->sens_flag_dev);
 	if (b->sens_mean_dev) hipFree(b->sens_mean_dev);
 	if (b->sens_sigma_dev) hipFree(b->sens_sigma_dev);
@@ -822,6 +832,7 @@ static int sync_params(mjb_batch *b)
 		kp.pad0 = 0;
 		kp.s = b->st;
 		kp.nz = b->nz;
+		kp.hw = b->hw;
 		// pageable source: the copy is staged before the call returns, so the local may go out of scope
 		HIP_TRY(hipStreamSynchronize(b->stream));
 		HIP_TRY(hipMemcpy(b->params_dev, &kp, sizeof kp, hipMemcpyHostToDevice));
@@ -1103,6 +1114,91 @@ int mjb_warning_count(mjb_batch *b, unsigned long long *count)
 	HIP_TRY(hipSetDevice(b->device));
 	HIP_TRY(hipStreamSynchronize(b->stream));
 	HIP_TRY(hipMemcpy(count, b->st.nwarn, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	return MJB_OK;
+}
+
+// ---- device-side DefaultRobotHWSim::writeSim (stage hwsim_write in mjb_step.hip) ----
+int mjb_hwsim_configure(mjb_batch *b, int n, const mjb_hwsim_joint *joints)
+{
+	if (!b || n < 0 || (n > 0 && !joints)) return fail(MJB_EINVAL, "mjb_hwsim_configure: bad argument");
+	const mjb_model_desc &h = b->model->h;
+	for (int k = 0; k < n; k++) {
+		const mjb_hwsim_joint &j = joints[k];
+		if (j.joint < 0 || j.joint >= h.njnt || h.jnt_type[j.joint] < MJB_JNT_SLIDE)
+			return fail(MJB_EINVAL, "mjb_hwsim_configure: entry %d: joint %d is not a hinge / slide joint of the model", k, j.joint);
+		if (j.method < MJB_HW_EFFORT || j.method > MJB_HW_VELOCITY_PID || j.kind < MJB_HW_REVOLUTE || j.kind > MJB_HW_PRISMATIC)
+			return fail(MJB_EINVAL, "mjb_hwsim_configure: entry %d: bad control method / joint kind", k);
+	}
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	if (b->hw_ints) hipFree(b->hw_ints);
+	if (b->hw_gains) hipFree(b->hw_gains);
+	if (b->hw_cmd) hipFree(b->hw_cmd);
+	if (b->hw_pid) hipFree(b->hw_pid);
+	b->hw_ints = nullptr; b->hw_gains = nullptr; b->hw_cmd = nullptr; b->hw_pid = nullptr;
+	b->hw = HwSim{};
+	b->params_dirty = true;
+	if (n == 0) return MJB_OK;
+	std::vector<int> ints((size_t)4 * n);
+	std::vector<double> gains((size_t)8 * n);
+	for (int k = 0; k < n; k++) {
+		const mjb_hwsim_joint &j = joints[k];
+		ints[k] = j.joint; ints[n + k] = j.method; ints[2 * n + k] = j.kind; ints[3 * n + k] = j.antiwindup ? 1 : 0;
+		const double g[8] = { j.p, j.i, j.d, j.i_max, j.i_min, j.effort_limit, j.lower, j.upper };
+		for (int q = 0; q < 8; q++) gains[(size_t)8 * k + q] = g[q];
+	}
+	const size_t per = (size_t)b->nenv * n;
+	b->hw_ints = dev_alloc<int>(ints.size());
+	b->hw_gains = dev_alloc<double>(gains.size());
+	b->hw_cmd = dev_alloc<double>(4 * per);
+	b->hw_pid = dev_alloc<double>(2 * per);
+	if (!b->hw_ints || !b->hw_gains || !b->hw_cmd || !b->hw_pid) return fail(MJB_ENOMEM, "mjb_hwsim_configure: allocation failed");
+	HIP_TRY(hipMemcpy(b->hw_ints, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(b->hw_gains, gains.data(), gains.size() * sizeof(double), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemset(b->hw_cmd, 0, 4 * per * sizeof(double)));
+	HIP_TRY(hipMemset(b->hw_pid, 0, 2 * per * sizeof(double)));
+	b->hw.n = n;
+	b->hw.estop = 0;
+	b->hw.joint = b->hw_ints; b->hw.method = b->hw_ints + n; b->hw.kind = b->hw_ints + 2 * n; b->hw.antiwindup = b->hw_ints + 3 * n;
+	b->hw.gains = b->hw_gains;
+	b->hw.cmd_pos = b->hw_cmd; b->hw.cmd_vel = b->hw_cmd + per; b->hw.cmd_eff = b->hw_cmd + 2 * per; b->hw.cmd_hold = b->hw_cmd + 3 * per;
+	b->hw.pid = b->hw_pid;
+	return MJB_OK;
+}
+
+int mjb_hwsim_set_command(mjb_batch *b, int which, int env_lo, int env_hi, const double *cmd)
+{
+	if (!b || !cmd || which < 0 || which > 2) return fail(MJB_EINVAL, "mjb_hwsim_set_command: bad argument");
+	if (b->hw.n <= 0) return fail(MJB_EINVAL, "mjb_hwsim_set_command before mjb_hwsim_configure");
+	if (env_lo < 0 || env_hi > b->nenv || env_lo > env_hi) return fail(MJB_EINVAL, "mjb_hwsim_set_command: bad env range");
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	const size_t per = (size_t)b->nenv * b->hw.n;
+	HIP_TRY(hipMemcpy(b->hw_cmd + which * per + (size_t)env_lo * b->hw.n, cmd, (size_t)(env_hi - env_lo) * b->hw.n * sizeof(double),
+	                  hipMemcpyHostToDevice));
+	return MJB_OK;
+}
+
+void *mjb_hwsim_command_ptr(mjb_batch *b, int which)
+{
+	if (!b || which < 0 || which > 2 || b->hw.n <= 0) return nullptr;
+	return b->hw_cmd + (size_t)which * b->nenv * b->hw.n;
+}
+
+int mjb_hwsim_estop(mjb_batch *b, int active)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	if (b->hw.n <= 0) return fail(MJB_EINVAL, "mjb_hwsim_estop before mjb_hwsim_configure");
+	const int on = active ? 1 : 0;
+	if (on == b->hw.estop) return MJB_OK;
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	if (on) {  // position-controlled joints hold the command they had when the e-stop came (default_robot_hw_sim.cpp:251-258)
+		const size_t per = (size_t)b->nenv * b->hw.n;
+		HIP_TRY(hipMemcpy(b->hw_cmd + 3 * per, b->hw_cmd, per * sizeof(double), hipMemcpyDeviceToDevice));
+	}
+	b->hw.estop = on;
+	b->params_dirty = true;
 	return MJB_OK;
 }
 

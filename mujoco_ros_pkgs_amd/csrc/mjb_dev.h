@@ -112,6 +112,16 @@ struct NoiseCfg {
 	int pad;
 };
 
+// device-side DefaultRobotHWSim::writeSim (mjb_hwsim_*): controlled joints and their per-env commands / PID state
+struct HwSim {
+	int n;             // controlled joints (0: stage off)
+	int estop;         // e-stop active
+	const int *joint, *method, *kind, *antiwindup;          // [n]
+	const double *gains;                                     // [n][8]: p, i, d, i_max, i_min, effort_limit, lower, upper
+	const double *cmd_pos, *cmd_vel, *cmd_eff, *cmd_hold;    // [nenv][n]; cmd_hold = position commands frozen at e-stop
+	double *pid;                                             // [nenv][n][2]: integral of the error, previous error
+};
+
 // Everything a launch needs, resident in device memory (uploaded when it changes); kernels get one
 // constant-address-space pointer to it.
 struct KernelParams {
@@ -122,6 +132,7 @@ struct KernelParams {
 	int pad0;
 	DevState s;
 	NoiseCfg nz;
+	HwSim hw;
 };
 
 enum { MJB_MODE_STEP = 0, MJB_MODE_FORWARD = 1, MJB_MODE_STEP1 = 2, MJB_MODE_STEP2 = 3 };

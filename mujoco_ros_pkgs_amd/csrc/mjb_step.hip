@@ -1074,7 +1074,8 @@ DEVI void move_force(double *res, const double *vec, const double *newpos, const
 // qacc, cfrc_ext = xfrc_applied + contact forces, cfrc_int = subtree sum of (inertial force - cfrc_ext).  Flat mask
 // sums like rne: lane = contact (world wrench), lane = body (cacc, own force), lane = body (subtree sum).
 // ------------------------------------------------------------------------------------------------
-template <int G> STAGE void rne_post(CModel m, CLayout L, const Env &e, bool use_xfrc)
+// (rarely used: kept out of line so that it costs the common kernels neither registers nor instruction-cache lines)
+template <int G> __device__ __attribute__((noinline)) void rne_post(CModel m, CLayout L, const Env &e, bool use_xfrc)
 {
 	double *f = e.f;
 	int *fi = e.fi;
@@ -1544,7 +1545,7 @@ template <int G> DEVI bool any_bad(const Env &e, CLayout L, const double *a, int
 	return *flag != 0;
 }
 
-template <int G> STAGE void reset_frame_state(CModel m, CLayout L, CState s, const Env &e)
+template <int G> __device__ __attribute__((noinline)) void reset_frame_state(CModel m, CLayout L, CState s, const Env &e)
 {
 	double *f = e.f;
 	for (int k = e.lane; k < L.nstate; k += G) f[k] = 0;  // state prefix starts at offset 0
@@ -1644,6 +1645,73 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 	PROF(12);
 }
 
+// device-side DefaultRobotHWSim::writeSim (include/mjb.h, mjb_hwsim_*): lane = controlled joint
+template <int G> __device__ __attribute__((noinline)) void hwsim_write(CModel m, CLayout L, const HwSim MJB_AS4 &hw, const Env &e)
+{
+	double *f = e.f;
+	const double dt = m.timestep[0];
+	const bool estop = hw.estop != 0;
+	for (int k = e.lane; k < hw.n; k += G) {
+		const int j = hw.joint[k], method = hw.method[k], qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+		const size_t at = (size_t)e.env * hw.n + k;
+		const double *gn = hw.gains + 8 * k;
+		const double pos = f[L.qpos + qa], vel = f[L.qvel + da];
+		const double cpos = estop ? hw.cmd_hold[at] : hw.cmd_pos[at];
+		double error = 0;
+		bool pid = false;
+		switch (method) {
+		case MJB_HW_EFFORT: f[L.qfrc_applied + da] = estop ? 0.0 : hw.cmd_eff[at]; break;
+		case MJB_HW_POSITION:
+			f[L.qpos + qa] = cpos;
+			f[L.qvel + da] = 0;
+			f[L.qfrc_applied + da] = 0;
+			break;
+		case MJB_HW_VELOCITY:
+			f[L.qvel + da] = estop ? 0.0 : hw.cmd_vel[at];
+			f[L.qfrc_applied + da] = 0;
+			break;
+		case MJB_HW_POSITION_PID: {
+			const int kind = hw.kind[k];
+			if (kind == MJB_HW_REVOLUTE) {
+				const double c = (gn[7] > gn[6]) ? fmin(fmax(cpos, gn[6]), gn[7]) : cpos;
+				error = c - pos;
+			} else if (kind == MJB_HW_CONTINUOUS) {
+				const double two_pi = 6.283185307179586476925;
+				double a = fmod(fmod(cpos - pos, two_pi) + two_pi, two_pi);  // normalize_angle_positive
+				if (a > 0.5 * two_pi) a -= two_pi;
+				error = a;
+			} else {
+				error = cpos - pos;
+			}
+			pid = true;
+			break;
+		}
+		case MJB_HW_VELOCITY_PID:
+			error = estop ? -vel : hw.cmd_vel[at] - vel;
+			pid = true;
+			break;
+		default: break;
+		}
+		if (pid) {
+			double ierr = hw.pid[2 * at], last = hw.pid[2 * at + 1];
+			const double derr = (error - last) / dt;
+			ierr += dt * error;
+			if (hw.antiwindup[k] && gn[1] != 0) {
+				const double lo = gn[4] / fabs(gn[1]), hi = gn[3] / fabs(gn[1]);
+				ierr = fmin(fmax(ierr, lo), hi);
+			}
+			double iterm = gn[1] * ierr;
+			if (!hw.antiwindup[k]) iterm = fmin(fmax(iterm, gn[4]), gn[3]);
+			double cmd = gn[0] * error + iterm + gn[2] * derr;
+			if (gn[5] > 0) cmd = fmin(fmax(cmd, -gn[5]), gn[5]);
+			hw.pid[2 * at] = ierr;
+			hw.pid[2 * at + 1] = error;
+			f[L.qfrc_applied + da] = cmd;
+		}
+	}
+	gsync<G>();
+}
+
 template <int G> STAGE void ctrl_noise(CModel m, CLayout L, CNoise nz, const Env &e,
                                       unsigned int step)
 {
@@ -1738,10 +1806,12 @@ __global__ void __launch_bounds__(256, (CON ? 2 : (G == 64 ? 4 : (G == 32 ? 2 : 
 		const bool do_euler = mode == MJB_MODE_STEP || mode == MJB_MODE_STEP2;
 		const bool checks = mode != MJB_MODE_FORWARD;
 		const int nst = mode == MJB_MODE_STEP ? nsteps : 1;
+		const bool hw_on = do_first && checks && P->hw.n > 0;  // device-side DefaultRobotHWSim stage registered
 #pragma nounroll
 		for (int st = 0; st < nst; st++) {
 			PROF_BEGIN();
 			if (do_first && checks && nz.enabled) ctrl_noise<G>(m, L, nz, e, step0 + (unsigned int)st);
+			if (hw_on) VIEW(P, compact, hwsim_write<G>(m, L, Pq_->hw, e));
 			PROF(13);
 			// attempt 1 only runs after mj_checkAcc found a bad qacc: reset, full forward, integrate
 #pragma nounroll
@@ -1762,6 +1832,8 @@ __global__ void __launch_bounds__(256, (CON ? 2 : (G == 64 ? 4 : (G == 32 ? 2 : 
 		}
 
 		store_state<G>(m, L, s, e);
+		if (P->hw.n > 0)  // the device-side hwsim stage writes qfrc_applied: keep mjData's view of it current
+			copy_out<G>(s.qfrc_applied + (size_t)e.env * m.nv, e.f + L.qfrc_applied, m.nv, e.lane);
 		if (ws && (mode != MJB_MODE_STEP || s.keep_frame)) {
 			for (int k = e.lane; k < L.ndouble; k += G) ws[k] = e.f[k];
 			int *wsi = reinterpret_cast<int *>(ws + L.ndouble);

@@ -105,6 +105,29 @@ class Batch:
         _check(self.lib.mjb_warning_count(self.ptr, C.byref(n)), "mjb_warning_count")
         return int(n.value)
 
+    # ---- device-side DefaultRobotHWSim (mjb_hwsim_*) ----
+    def hwsim_configure(self, joints):
+        """joints: list of dicts(joint=<id>, method=..., kind=..., p, i, d, i_max, i_min, antiwindup, effort_limit, lower, upper)."""
+        arr = (binding.HwsimJoint * max(1, len(joints)))()
+        for k, j in enumerate(joints):
+            arr[k] = binding.HwsimJoint(int(j["joint"]), binding.HW_METHODS[j.get("method", "effort")],
+                                        binding.HW_KINDS[j.get("kind", "revolute")], int(j.get("antiwindup", 0)),
+                                        float(j.get("p", 0)), float(j.get("i", 0)), float(j.get("d", 0)),
+                                        float(j.get("i_max", 0)), float(j.get("i_min", 0)), float(j.get("effort_limit", 0)),
+                                        float(j.get("lower", 0)), float(j.get("upper", 0)))
+        _check(self.lib.mjb_hwsim_configure(self.ptr, len(joints), arr), "mjb_hwsim_configure")
+        self._hw_n = len(joints)
+
+    def hwsim_set_command(self, which, cmd, lo=0, hi=None):
+        import numpy as np
+        hi = self.nenv if hi is None else hi
+        a = np.ascontiguousarray(cmd, dtype=np.float64).reshape(hi - lo, self._hw_n)
+        _check(self.lib.mjb_hwsim_set_command(self.ptr, {"position": 0, "velocity": 1, "effort": 2}[which], lo, hi,
+                                              a.ctypes.data_as(C.POINTER(C.c_double))), "mjb_hwsim_set_command")
+
+    def hwsim_estop(self, active):
+        _check(self.lib.mjb_hwsim_estop(self.ptr, 1 if active else 0), "mjb_hwsim_estop")
+
     # ---- sensors-plugin equivalent (mjb_sensor_*) ----
     def sensor_set_noise(self, sensor, set_flag, mean=(0, 0, 0), sigma=(0, 0, 0)):
         """registerNoiseModels: bit k of set_flag = noise on component k; the n-th set bit uses mean[n], sigma[n]."""

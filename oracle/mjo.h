@@ -93,6 +93,10 @@ double mjo_normal(uint64_t seed, uint64_t env, uint32_t step, uint32_t idx);
 /* the sensors plugin's per-step messages (mjo_sensor_pack.c) */
 void mjo_sensor_pack(const mjb_model_desc *m, const double *sensordata, const int *set_flag, const double *mean,
                      const double *sigma, uint64_t seed, uint64_t env, uint32_t step, float *value, float *truth);
+/* DefaultRobotHWSim::writeSim for one env (mjo_hwsim.c) */
+void mjo_hwsim_write(const mjb_model_desc *m, mjo_data *d, int n, const int *joint, const int *method, const int *kind,
+                     const int *antiwindup, const double *gains, const double *cmd_pos, const double *cmd_vel,
+                     const double *cmd_eff, const double *cmd_hold, double *pid, int estop);
 void mjo_rne_post_constraint(const mjb_model_desc *m, mjo_data *d);
 int mjo_needs_rne_post(const mjb_model_desc *m);
 void mjo_tendon(const mjb_model_desc *m, mjo_data *d);

@@ -52,6 +52,8 @@ def lib(fast=False):
     L.mjo_normal.restype = cd
     L.mjo_normal.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
     L.mjo_ctrl_noise.argtypes = [pd, vp, cd, cd, C.c_uint64, C.c_uint64, C.c_uint32]
+    L.mjo_hwsim_write.restype = None
+    L.mjo_hwsim_write.argtypes = [pd, vp, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)] + [C.POINTER(cd)] * 6 + [ci]
     L.mjo_sensor_pack.restype = None
     L.mjo_sensor_pack.argtypes = [pd, C.POINTER(cd), C.POINTER(ci), C.POINTER(cd), C.POINTER(cd), C.c_uint64, C.c_uint64,
                                   C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -112,6 +114,16 @@ class OracleData:
 
     def ctrl_noise(self, std, rate, seed, env, step):
         self.L.mjo_ctrl_noise(C.byref(self.desc), self.ptr, std, rate, seed, env, step)
+
+    def hwsim_write(self, cfg, cmd_pos, cmd_vel, cmd_eff, cmd_hold, pid, estop):
+        """DefaultRobotHWSim::writeSim on this env.  cfg = dict(joint, method, kind, antiwindup: int32 [n]; gains: [n,8]);
+        pid ([n,2] float64) is updated in place."""
+        pi, pdd = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        arrs = [np.ascontiguousarray(cfg[k], dtype=np.int32) for k in ("joint", "method", "kind", "antiwindup")]
+        dbl = [np.ascontiguousarray(a, dtype=np.float64) for a in (cfg["gains"], cmd_pos, cmd_vel, cmd_eff, cmd_hold)]
+        assert pid.dtype == np.float64 and pid.flags["C_CONTIGUOUS"]
+        self.L.mjo_hwsim_write(C.byref(self.desc), self.ptr, len(arrs[0]), *[a.ctypes.data_as(pi) for a in arrs],
+                               *[a.ctypes.data_as(pdd) for a in dbl], pid.ctypes.data_as(pdd), int(estop))
 
     def solve_m(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64).copy()
