@@ -1570,14 +1570,17 @@ template <int G> __device__ __attribute__((noinline)) void reset_frame_state(CMo
 #ifndef MJB_LAUNDER
 #define MJB_LAUNDER 1
 #endif
-DEVI const KernelParams MJB_AS4 *launder_params(const KernelParams MJB_AS4 *p)
+#ifndef MJB_LAUNDER_DENSE
+#define MJB_LAUNDER_DENSE 1  // (0: let the dense kernels hoist across stages -- measured no faster on MI355X)
+#endif
+template <bool ON> DEVI const KernelParams MJB_AS4 *launder_params(const KernelParams MJB_AS4 *p)
 {
-	if (MJB_LAUNDER) asm volatile("" : "+s"(p));
+	if (MJB_LAUNDER && ON) asm volatile("" : "+s"(p));
 	return p;
 }
 #define VIEW(P, compact, ...)                                              \
 	do {                                                                   \
-		const KernelParams MJB_AS4 *Pq_ = launder_params(P);              \
+		const KernelParams MJB_AS4 *Pq_ = launder_params<MJB_LAUNDER_HERE>(P); \
 		CModel m = Pq_->m;                                                 \
 		CLayout L = (compact) ? Pq_->Lc : Pq_->L;                          \
 		CState s = Pq_->s;                                                 \
@@ -1587,6 +1590,7 @@ DEVI const KernelParams MJB_AS4 *launder_params(const KernelParams MJB_AS4 *p)
 
 template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams MJB_AS4 *P, const Env &e, int compact)
 {
+	constexpr bool MJB_LAUNDER_HERE = MJB_LAUNDER_DENSE || DENSE == 0;
 	[[maybe_unused]] CState s = P->s;  // (profiling macros)
 	PROF_BEGIN();
 	VIEW(P, compact, kinematics<G, (G == 64 || DENSE != 0), (DENSE != 0)>(m, L, s, e));
@@ -1626,6 +1630,7 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 
 template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams MJB_AS4 *P, const Env &e, int compact)
 {
+	constexpr bool MJB_LAUNDER_HERE = MJB_LAUNDER_DENSE || DENSE == 0;
 	[[maybe_unused]] CState s = P->s;  // (profiling macros)
 	PROF_BEGIN();
 	VIEW(P, compact, fwd_actuation<G>(m, L, e));
@@ -1743,6 +1748,7 @@ __global__ void __launch_bounds__(256, (CON ? 2 : (G == 64 ? 4 : (G == 32 ? 2 : 
 	const FrameLayout MJB_AS4 &L = compact ? P->Lc : P->L;
 	const DevState MJB_AS4 &s = P->s;
 	const NoiseCfg MJB_AS4 &nz = P->nz;
+	constexpr bool MJB_LAUNDER_HERE = MJB_LAUNDER_DENSE || DENSE == 0;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int slot = threadIdx.x / G;
 	Env e;
