@@ -264,6 +264,11 @@ void build_sensor_tables(mjb_model *M)
 			case MJB_SENS_CLOCK: src = L.time; break;
 			case MJB_SENS_SUBTREECOM: src = L.subtree_com + 3 * id; n = 3; break;
 			case MJB_SENS_BALLANGVEL: src = L.qvel + h.jnt_dofadr[id]; n = 3; break;
+			case MJB_SENS_FRAMEQUAT:
+				if (h.sensor_refid[i] >= 0 || (ot != MJB_OBJ_XBODY && ot != MJB_OBJ_SITE)) { simple = false; break; }
+				n = 4;
+				src = ot == MJB_OBJ_XBODY ? L.xquat + 4 * id : L.site_xquat + 4 * id;
+				break;
 			case MJB_SENS_FRAMEPOS:
 				if (h.sensor_refid[i] >= 0) { simple = false; break; }
 				n = 3;

@@ -89,7 +89,7 @@ struct Env {
 // A1  kinematics: body frames, joint anchors/axes, inertial / geom / site frames
 // ------------------------------------------------------------------------------------------------
 DEVI void local2global(const double *xpos_b, const double *xquat_b, const double *xmat_b, double *opos,
-                       double *omat, const double *pos, const double *quat, int sameframe)
+                       double *omat, const double *pos, const double *quat, int sameframe, double *oquat = nullptr)
 {
 	if (sameframe) {
 		double p[3], M[9];
@@ -97,6 +97,11 @@ DEVI void local2global(const double *xpos_b, const double *xquat_b, const double
 		ld9(M, xmat_b);
 		st3(opos, p);
 		st9(omat, M);
+		if (oquat) {
+			double bq[4];
+			ld4(bq, xquat_b);
+			st4(oquat, bq);
+		}
 	} else {
 		double p[3], M[9], q[4], bq[4], v[3], r[9];
 		ld3(p, xpos_b);
@@ -108,6 +113,7 @@ DEVI void local2global(const double *xpos_b, const double *xquat_b, const double
 		quat2mat(r, q);
 		st3(opos, v);
 		st9(omat, r);
+		if (oquat) st4(oquat, q);
 	}
 }
 
@@ -337,7 +343,7 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 			ldc3(pos, m.site_pos + 3 * st);
 			ldc4(quat, m.site_quat + 4 * st);
 			local2global(xpos + 3 * b, xquat + 4 * b, xmat + 9 * b, f + L.site_xpos + 3 * st, f + L.site_xmat + 9 * st,
-			             pos, quat, m.site_sameframe[st]);
+			             pos, quat, m.site_sameframe[st], f + L.site_xquat + 4 * st);
 		}
 	}
 	gsync<G>();

@@ -224,9 +224,11 @@ void mjo_kinematics(const mjb_model_desc *m, mjo_data *d)
 	for (int i = 0; i < m->ngeom; i++)
 		local2global(d, d->geom_xpos + 3 * i, d->geom_xmat + 9 * i, m->geom_pos + 3 * i, m->geom_quat + 4 * i,
 		             m->geom_bodyid[i], m->geom_sameframe[i]);
-	for (int i = 0; i < m->nsite; i++)
+	for (int i = 0; i < m->nsite; i++) {
 		local2global(d, d->site_xpos + 3 * i, d->site_xmat + 9 * i, m->site_pos + 3 * i, m->site_quat + 4 * i,
 		             m->site_bodyid[i], m->site_sameframe[i]);
+		q_mul(d->site_xquat + 4 * i, d->xquat + 4 * m->site_bodyid[i], m->site_quat + 4 * i); /* engine-side field */
+	}
 }
 
 /* ------------------------------------------------------------------ A1: mj_comPos */
