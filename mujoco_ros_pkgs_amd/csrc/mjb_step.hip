@@ -69,8 +69,10 @@ template <int G> DEVI void gsync()
 // once per stage and step (per-lane table reads are vector-memory loads: ~0.5 us of exposed latency per step each)
 struct LaneConst {
 	unsigned int dmlo, dmhi, smlo, smhi;  // ancestor-dof and subtree-body masks
-	int jntadr, jntnum, jtype, qa, simple;
-	double bpos[3], bquat[4], jaxis[3], jpos[3], q0, ipos[3], iquat[4];
+	int jntadr, jntnum, jtype, qa, simple, rootid;
+	double bpos[3], bquat[4], jaxis[3], jpos[3], q0, ipos[3], iquat[4], mass, inertia[3];
+	// ... and of dof `lane` (nv <= 16): its body, and where the body velocity "before" the dof's joint comes from
+	int d_body, d_zero, d_simple, d_parent;  // d_zero: translational dof of a free joint; d_simple: first joint of its body
 };
 
 struct Env {
@@ -390,11 +392,15 @@ template <int G, bool OBL> STAGE void com_pos(CModel m, CLayout L, const Env &e)
 		} else {
 			double ip[3], root[3], off[3], im[9], inert[3];
 			ld3(ip, xipos + 3 * b);
-			ld3(root, sc + 3 * m.body_rootid[b]);
+			ld3(root, sc + 3 * (OBL ? e.lc.rootid : m.body_rootid[b]));
 			off[0] = ip[0] - root[0]; off[1] = ip[1] - root[1]; off[2] = ip[2] - root[2];
 			ld9(im, f + L.ximat + 9 * b);
-			ldc3(inert, m.body_inertia + 3 * b);
-			inert_com(r, inert, im, off, m.body_mass[b]);
+			if constexpr (OBL) {
+				inert[0] = e.lc.inertia[0]; inert[1] = e.lc.inertia[1]; inert[2] = e.lc.inertia[2];
+			} else {
+				ldc3(inert, m.body_inertia + 3 * b);
+			}
+			inert_com(r, inert, im, off, OBL ? e.lc.mass : m.body_mass[b]);
 		}
 		double *o = f + L.cinert + 10 * b;
 		for (int k = 0; k < 10; k++) o[k] = r[k];
@@ -448,7 +454,7 @@ template <int G, bool OBL> STAGE void com_pos(CModel m, CLayout L, const Env &e)
 // ------------------------------------------------------------------------------------------------
 // A2  crb: composite inertias and the sparse joint-space inertia qM
 // ------------------------------------------------------------------------------------------------
-template <int G> STAGE void crb(CModel m, CLayout L, const Env &e)
+template <int G, bool OBL> STAGE void crb(CModel m, CLayout L, const Env &e)
 {
 	double *f = e.f;
 	double *crbv = f + L.crb, *cinert = f + L.cinert, *buf = f + L.crbbuf;
@@ -464,7 +470,7 @@ template <int G> STAGE void crb(CModel m, CLayout L, const Env &e)
 	// buf_i = crb[body(i)] * cdof_i, one dof per lane
 	for (int i = lane; i < m.nv; i += G) {
 		double I[10], v[6], r[6];
-		ld10(I, crbv + 10 * m.dof_bodyid[i]);
+		ld10(I, crbv + 10 * (OBL ? e.lc.d_body : m.dof_bodyid[i]));
 		ld6(v, f + L.cdof + 6 * i);
 		mul_inert_vec(r, I, v);
 		st6(buf + 6 * i, r);
@@ -843,13 +849,19 @@ template <int G, bool OBL> STAGE void com_vel(CModel m, CLayout L, const Env &e)
 	gsync<G>();
 	// cdof_dot: one dof per lane
 	for (int d = lane; d < m.nv; d += G) {
-		const int j = m.dof_jntid[d];
 		double r[6];
-		if (m.jnt_type[j] == MJB_JNT_FREE && d - m.jnt_dofadr[j] < 3) {
+		bool zero;
+		if constexpr (OBL) zero = e.lc.d_zero != 0;
+		else {
+			const int j = m.dof_jntid[d];
+			zero = m.jnt_type[j] == MJB_JNT_FREE && d - m.jnt_dofadr[j] < 3;
+		}
+		if (zero) {
 			for (int k = 0; k < 6; k++) r[k] = 0;
 		} else {
 			double v[6], cd[6];
-			cvel_before(m, L, f, m.dof_bodyid[d], m.dof_jstart[d], v);
+			if (OBL && e.lc.d_simple) ld6(v, cvel + 6 * e.lc.d_parent);  // first joint of its body: the parent's velocity
+			else cvel_before(m, L, f, m.dof_bodyid[d], m.dof_jstart[d], v);
 			ld6(cd, cdof + 6 * d);
 			cross_motion(r, v, cd);
 		}
@@ -1603,7 +1615,7 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 	PROF(0);
 	VIEW(P, compact, com_pos<G, (DENSE != 0)>(m, L, e));
 	PROF(1);
-	VIEW(P, compact, crb<G>(m, L, e));
+	VIEW(P, compact, crb<G, (DENSE != 0)>(m, L, e));
 	PROF(2);
 	if constexpr (DENSE)
 		VIEW(P, compact, factor_dense16<G, DENSE>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH,
@@ -1786,6 +1798,15 @@ __global__ void __launch_bounds__(256, (CON ? 2 : (G == 64 ? 4 : (G == 32 ? 2 : 
 			c.bquat[k] = m.body_quat[4 * b + k];
 			c.iquat[k] = m.body_iquat[4 * b + k];
 		}
+		c.rootid = m.body_rootid[b];
+		c.mass = m.body_mass[b];
+		for (int k = 0; k < 3; k++) c.inertia[k] = m.body_inertia[3 * b + k];
+		const int dd = e.lane < m.nv ? e.lane : 0;
+		c.d_body = m.nv ? m.dof_bodyid[dd] : 0;
+		c.d_parent = m.body_parentid[c.d_body];
+		const int dj = m.nv ? m.dof_jntid[dd] : 0;
+		c.d_zero = (m.nv && m.jnt_type[dj] == MJB_JNT_FREE && dd - m.jnt_dofadr[dj] < 3) ? 1 : 0;
+		c.d_simple = (m.nv && m.dof_jstart[dd] == m.body_dofadr[c.d_body]) ? 1 : 0;
 	}
 	e.f = reinterpret_cast<double *>(smem + (size_t)slot * frame_bytes);
 	e.fi = reinterpret_cast<int *>(e.f + L.ndouble);
