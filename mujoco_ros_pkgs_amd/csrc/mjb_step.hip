@@ -43,19 +43,22 @@ template <int G> DEVI void gsync()
 // Optional per-stage cycle accounting (build with -DMJB_PROFILE -> libmjb_prof.so): env 0 / lane 0 adds the
 // s_memtime delta of every stage to DevState::prof[stage].
 #ifdef MJB_PROFILE
+// (sums are kept in LDS by the recording lane and flushed to DevState::prof once per launch: a global
+//  read-modify-write per probe costs ~1 k cycles, more than the small stages it measures)
+__shared__ unsigned long long mjb_prof_lds[64];
 #define PROF_BEGIN() unsigned long long _t0 = __builtin_readcyclecounter()
 #define PROF(id)                                                                      \
 	do {                                                                              \
 		unsigned long long _t1 = __builtin_readcyclecounter();                        \
-		if (e.env == 0 && e.lane == 0 && s.prof) { s.prof[id] += _t1 - _t0; s.prof[32 + id] += 1; } \
+		if (e.env == 0 && e.lane == 0) { mjb_prof_lds[id] += _t1 - _t0; mjb_prof_lds[32 + id] += 1; } \
 		_t0 = __builtin_readcyclecounter();                                           \
 	} while (0)
-// sub-stage accounting inside stages that do not see DevState (the solvers): through Env::prof
+// sub-stage accounting inside stages that do not see DevState (the solvers)
 #define EPROF_BEGIN() unsigned long long _et0 = __builtin_readcyclecounter()
 #define EPROF(id)                                                                     \
 	do {                                                                              \
 		unsigned long long _et1 = __builtin_readcyclecounter();                       \
-		if (e.env == 0 && e.lane == 0 && e.prof) { e.prof[id] += _et1 - _et0; e.prof[32 + id] += 1; } \
+		if (e.env == 0 && e.lane == 0) { mjb_prof_lds[id] += _et1 - _et0; mjb_prof_lds[32 + id] += 1; } \
 		_et0 = __builtin_readcyclecounter();                                          \
 	} while (0)
 #else
@@ -1772,6 +1775,8 @@ __global__ void __launch_bounds__(256, (CON ? 2 : (G == 64 ? 4 : (G == 32 ? 2 : 
 	Env e;
 #ifdef MJB_PROFILE
 	e.prof = s.prof;
+	if (blockIdx.x == 0 && threadIdx.x < 64) mjb_prof_lds[threadIdx.x] = 0;
+	__syncthreads();
 #endif
 	e.lane = threadIdx.x % G;
 	if constexpr (DENSE) {
@@ -1874,6 +1879,10 @@ __global__ void __launch_bounds__(256, (CON ? 2 : (G == 64 ? 4 : (G == 32 ? 2 : 
 		}
 		gsync<G>();
 	}
+#ifdef MJB_PROFILE
+	__syncthreads();
+	if (blockIdx.x == 0 && threadIdx.x < 64 && s.prof) s.prof[threadIdx.x] += mjb_prof_lds[threadIdx.x];
+#endif
 }
 
 __global__ void mjb_reset_kernel(const KernelParams MJB_AS4 *__restrict__ P, const unsigned char *mask)
