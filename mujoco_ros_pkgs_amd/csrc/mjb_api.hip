@@ -198,7 +198,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	off += d.nM;
 	L.qHdi = off;
 	off += d.nv;
-	const int n_kin = 7 * d.nbody, n_crb = 10 * d.nbody, n_buf = 6 * d.nv, n_c6 = 6 * d.nbody;
+	const int n_kin = 7 * d.nbody, n_crb = 10 * d.nbody, n_buf = 6 * d.nv < 32 ? 32 : 6 * d.nv, n_c6 = 6 * d.nbody;  // (crbbuf doubles as the 32-double pivot-row scratch of the dense factor)
 	if (compact) {
 		const int a0 = off;
 		L.kinloc = a0;

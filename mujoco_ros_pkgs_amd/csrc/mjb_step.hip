@@ -659,7 +659,7 @@ DEVI double fast_rcp(double x)
 
 template <int G, bool DUAL, int NVM>
 DEVI void factor_dense16_impl(CModel m, const Env &e, const double *M, double *LD, double *di, const double *M2, double *LD2,
-                              double *di2, const int (&dadr)[16])
+                              double *di2, const int (&dadr)[16], double *scr)
 {
 	const int lane = e.lane, nv = m.nv;
 	double A[NVM], B[NVM];
@@ -676,14 +676,19 @@ DEVI void factor_dense16_impl(CModel m, const Env &e, const double *M, double *L
 	for (int k = NVM - 1; k >= 0; k--) {
 		if (k < nv) {
 			MJB_KEEP_BRANCH();
-			// everything that crosses lanes for this pivot first (independent shuffles), arithmetic after
-			const double dk = group_bcast16(A[k], k), dk2 = DUAL ? group_bcast16(B[k], k) : 1.0;
+			// the pivot row crosses lanes through LDS: every lane publishes its entry, then all read the row at uniform
+			// addresses (one broadcast read per double; ds_bpermute costs two slower operations per double)
+			scr[lane] = A[k];
+			if (DUAL) scr[16 + lane] = B[k];
+			gsync<G>();
+			const double dk = scr[k], dk2 = DUAL ? scr[16 + k] : 1.0;
 			double mk[NVM], mk2[NVM];
 #pragma unroll
 			for (int i = 0; i < NVM; i++) {
-				mk[i] = i < k ? group_bcast16(A[k], i) : 0.0;  // unscaled M(k, i), held by lane i
-				mk2[i] = (DUAL && i < k) ? group_bcast16(B[k], i) : 0.0;
+				mk[i] = i < k ? scr[i] : 0.0;  // unscaled M(k, i), held by lane i
+				mk2[i] = (DUAL && i < k) ? scr[16 + i] : 0.0;
 			}
+			gsync<G>();
 			const double inv = fast_rcp(dk), inv2 = DUAL ? fast_rcp(dk2) : 0.0;
 			const double lkj = A[k] * inv, lkj2 = B[k] * inv2;  // scaled pivot-row entry of this lane's column (lane < k)
 			// (entries above the diagonal -- register i of a lane > i -- are never read or stored: no lane predicate)
@@ -719,15 +724,15 @@ DEVI void factor_dense16_impl(CModel m, const Env &e, const double *M, double *L
 
 template <int G, int NVM>
 STAGE void factor_dense16(CModel m, const Env &e, const double *M, double *LD, double *di, const double *M2, double *LD2,
-                          double *di2, bool dual, const int (&dadr)[16])
+                          double *di2, bool dual, const int (&dadr)[16], double *scr)
 {
 	static_assert(G == 16, "one matrix column per lane of a 16-lane env group");
 	if (dual) {
 		MJB_KEEP_BRANCH();
-		factor_dense16_impl<G, true, NVM>(m, e, M, LD, di, M2, LD2, di2, dadr);
+		factor_dense16_impl<G, true, NVM>(m, e, M, LD, di, M2, LD2, di2, dadr, scr);
 	} else {
 		MJB_KEEP_BRANCH();
-		factor_dense16_impl<G, false, NVM>(m, e, M, LD, di, M2, LD2, di2, dadr);
+		factor_dense16_impl<G, false, NVM>(m, e, M, LD, di, M2, LD2, di2, dadr, scr);
 	}
 }
 
@@ -1622,7 +1627,7 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 	PROF(2);
 	if constexpr (DENSE)
 		VIEW(P, compact, factor_dense16<G, DENSE>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH,
-		                                   e.f + L.qHdi, m.eulerdamp != 0, e.dadr));
+		                                   e.f + L.qHdi, m.eulerdamp != 0, e.dadr, e.f + L.crbbuf));
 	else
 		VIEW(P, compact, factor2<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi,
 		                            m.eulerdamp != 0));
