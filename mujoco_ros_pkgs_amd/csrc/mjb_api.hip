@@ -77,7 +77,7 @@ struct mjb_model {
 	std::vector<int> hint;            // all int arrays, concatenated
 	std::vector<double> hdbl;         // all double arrays, concatenated
 	std::vector<size_t> ioff, doff;   // offsets of each array inside hint / hdbl (declaration order)
-	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense, body_anc;
+	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense, body_anc, dof_bodymask;
 	std::vector<int> sens_copy, sens_slow, dof_act_adr, dof_act_id;
 	int sens_ncopy[3] = { 0, 0, 0 }, sens_nslow[3] = { 0, 0, 0 }, sens_ncopy_max = 0;
 	int eulerdamp = 0, maxdepth = 0, kin_rounds = 0, need_rnepost = 0;
@@ -565,6 +565,10 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 			M->body_submask[2 * a + (b >> 5)] |= (int)(1u << (b & 31));
 			if (a == 0) break;
 		}
+	M->dof_bodymask.assign((size_t)2 * (h.nv > 0 ? h.nv : 1), 0);
+	for (int b = 1; b < h.nbody; b++)
+		for (int i = 0; i < h.nv; i++)
+			if ((M->body_dofmask[2 * b + (i >> 5)] >> (i & 31)) & 1) M->dof_bodymask[2 * i + (b >> 5)] |= (int)(1u << (b & 31));
 	M->eulerdamp = 0;
 	if (!(h.disableflags & MJB_DSBL_EULERDAMP))
 		for (int i = 0; i < h.nv; i++)
@@ -673,7 +677,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	size_t ni = M->hint.size(), nd = M->hdbl.size();
 	size_t nt = M->M_rowdof.size() + M->M_coldof.size() + M->dof_depth.size() + M->dof_jstart.size() +
 	            M->body_rec.size() + M->body_rec2.size() + M->dof_rec.size() + M->fac_ops.size() + M->fac_beg.size() +
-	            M->body_dofmask.size() + M->body_submask.size() + M->M_dense.size() + M->body_anc.size() + M->sens_copy.size() + M->sens_slow.size() + M->dof_act_adr.size() +
+	            M->body_dofmask.size() + M->body_submask.size() + M->M_dense.size() + M->body_anc.size() + M->dof_bodymask.size() + M->sens_copy.size() + M->sens_slow.size() + M->dof_act_adr.size() +
 	            M->dof_act_id.size() + 96;
 	size_t bytes_i = ((ni + nt) * sizeof(int) + 15) & ~size_t(15);
 	size_t bytes = bytes_i + nd * sizeof(double) + 16;
@@ -696,7 +700,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	};
 	size_t o_row = put(M->M_rowdof), o_col = put(M->M_coldof), o_dep = put(M->dof_depth), o_js = put(M->dof_jstart);
 	size_t o_br = put(M->body_rec), o_br2 = put(M->body_rec2), o_dr = put(M->dof_rec), o_fo = put(M->fac_ops),
-	       o_fb = put(M->fac_beg), o_dm = put(M->body_dofmask), o_sm = put(M->body_submask), o_md = put(M->M_dense), o_an = put(M->body_anc), o_sc = put(M->sens_copy), o_ss = put(M->sens_slow),
+	       o_fb = put(M->fac_beg), o_dm = put(M->body_dofmask), o_sm = put(M->body_submask), o_md = put(M->M_dense), o_an = put(M->body_anc), o_db = put(M->dof_bodymask), o_sc = put(M->sens_copy), o_ss = put(M->sens_slow),
 	       o_aa = put(M->dof_act_adr), o_ai = put(M->dof_act_id);
 	if (nd) memcpy(hd, M->hdbl.data(), nd * sizeof(double));
 	if (hipMemcpy(b->blob, hostblob.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
@@ -735,6 +739,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	dm.M_dense = (mjb_ciptr)(di + o_md);
 	dm.body_anc = (mjb_ciptr)(di + o_an);
 	dm.kin_rounds = M->kin_rounds;
+	dm.dof_bodymask = (mjb_ciptr)(di + o_db);
 	dm.need_rnepost = M->need_rnepost;
 	dm.sens_copy = (mjb_ciptr)(di + o_sc);
 	dm.sens_slow = (mjb_ciptr)(di + o_ss);

@@ -46,6 +46,7 @@ struct DevModel {
 	mjb_ciptr body_dofmask;  // [nbody][2] bit i set: dof i moves the body (ancestor-or-self dofs), nv <= 64
 	mjb_ciptr M_dense;       // [16][16] qM address of entry (i, j) (dof j ancestor-or-self of dof i) or -1; nv <= 16 only
 	mjb_ciptr body_anc;      // [kin_rounds + 1][nbody] ancestor at distance 2^r (0 = world / beyond the root)
+	mjb_ciptr dof_bodymask;  // [nv][2] bit b set: dof i moves body b (transpose of body_dofmask), nbody <= 64
 	mjb_ciptr body_submask;  // [nbody][2] bit i set: body i belongs to the body's subtree (incl. itself), nbody <= 64
 	int eulerdamp;           // any dof_damping > 0 and EULERDAMP not disabled
 	int need_rnepost;        // an acceleration-stage sensor needs mj_rnePostConstraint (cacc / cfrc_int / cfrc_ext)

@@ -75,7 +75,8 @@ struct LaneConst {
 	int jntadr, jntnum, jtype, qa, simple, rootid;
 	double bpos[3], bquat[4], jaxis[3], jpos[3], q0, ipos[3], iquat[4], mass, inertia[3];
 	// ... and of dof `lane` (nv <= 16): its body, and where the body velocity "before" the dof's joint comes from
-	int d_body, d_zero, d_simple, d_parent;  // d_zero: translational dof of a free joint; d_simple: first joint of its body
+	int d_body, d_zero, d_simple, d_parent;
+	unsigned int d_bmlo, d_bmhi;  // bodies moved by the dof  // d_zero: translational dof of a free joint; d_simple: first joint of its body
 };
 
 struct Env {
@@ -739,7 +740,7 @@ STAGE void factor_dense16(CModel m, const Env &e, const double *M, double *LD, d
 // x <- M^-1 x with the factor's columns re-read from LDS into registers; x lives one element per lane
 template <int G, bool DUAL, int NVM>
 DEVI void solve_dense16_impl(CModel m, const Env &e, double *x, const double *LD, const double *diaginv, double *x2,
-                             const double *LD2, const double *diaginv2, const int (&dadr)[16])
+                             const double *LD2, const double *diaginv2, const int (&dadr)[16], double *scr)
 {
 	const int lane = e.lane, nv = m.nv;
 	const bool act = lane < nv;
@@ -758,7 +759,12 @@ DEVI void solve_dense16_impl(CModel m, const Env &e, double *x, const double *LD
 	for (int i = NVM - 1; i >= 1; i--) {
 		if (i < nv) {
 			MJB_KEEP_BRANCH();
-			const double xi = group_bcast16(xj, i), xi2 = DUAL ? group_bcast16(xj2, i) : 0.0;
+			// x_i crosses lanes through the LDS scratch (publish, then a wave-uniform broadcast read)
+			scr[lane] = xj;
+			if (DUAL) scr[16 + lane] = xj2;
+			gsync<G>();
+			const double xi = scr[i], xi2 = DUAL ? scr[16 + i] : 0.0;
+			gsync<G>();
 			xj -= A[i] * xi;  // A[i] == 0 in the lanes >= i
 			if (DUAL) xj2 -= B[i] * xi2;
 		}
@@ -787,15 +793,15 @@ DEVI void solve_dense16_impl(CModel m, const Env &e, double *x, const double *LD
 
 template <int G, int NVM>
 STAGE void solve_dense16(CModel m, const Env &e, double *x, const double *LD, const double *diaginv, double *x2,
-                         const double *LD2, const double *diaginv2, bool dual, const int (&dadr)[16])
+                         const double *LD2, const double *diaginv2, bool dual, const int (&dadr)[16], double *scr)
 {
 	static_assert(G == 16, "one matrix column per lane of a 16-lane env group");
 	if (dual) {
 		MJB_KEEP_BRANCH();
-		solve_dense16_impl<G, true, NVM>(m, e, x, LD, diaginv, x2, LD2, diaginv2, dadr);
+		solve_dense16_impl<G, true, NVM>(m, e, x, LD, diaginv, x2, LD2, diaginv2, dadr, scr);
 	} else {
 		MJB_KEEP_BRANCH();
-		solve_dense16_impl<G, false, NVM>(m, e, x, LD, diaginv, x2, LD2, diaginv2, dadr);
+		solve_dense16_impl<G, false, NVM>(m, e, x, LD, diaginv, x2, LD2, diaginv2, dadr, scr);
 	}
 }
 
@@ -981,9 +987,11 @@ template <int G, bool OBL> STAGE void rne(CModel m, CLayout L, const Env &e)
 	// lane = dof: qfrc_bias_d = cdof_d . (sum of the forces of the bodies that dof d moves)
 	for (int d = lane; d < m.nv; d += G) {
 		double acc[6] = { 0, 0, 0, 0, 0, 0 };
+		// bodies moved by dof d: the transpose of the ancestor-dof masks, one 64-bit word per dof (per-lane constant)
+		const unsigned int blo = OBL ? e.lc.d_bmlo : (unsigned int)m.dof_bodymask[2 * d], bhi = OBL ? e.lc.d_bmhi : (unsigned int)m.dof_bodymask[2 * d + 1];
 #pragma unroll 3
 		for (int b = 1; b < m.nbody; b++) {
-			const bool on = maskbit((unsigned int)m.body_dofmask[2 * b], (unsigned int)m.body_dofmask[2 * b + 1], d);
+			const bool on = maskbit(blo, bhi, b);
 			for (int c = 0; c < 6; c++) {
 				const double v = cfrc[6 * b + c];
 				acc[c] += on ? v : 0.0;
@@ -1447,7 +1455,8 @@ template <int G, int DENSE> STAGE void fwd_acceleration(CModel m, CLayout L, con
 	gsync<G>();
 	const bool dual = m.eulerdamp && m.nefcmax == 0;
 	if constexpr (DENSE)
-		solve_dense16<G, DENSE>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual, e.dadr);
+		solve_dense16<G, DENSE>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual, e.dadr,
+		                        f + L.crbbuf);
 	else
 		solve2<G>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual);
 }
@@ -1817,6 +1826,8 @@ __global__ void __launch_bounds__(256, (CON ? 2 : (G == 64 ? 4 : (G == 32 ? 2 : 
 		const int dj = m.nv ? m.dof_jntid[dd] : 0;
 		c.d_zero = (m.nv && m.jnt_type[dj] == MJB_JNT_FREE && dd - m.jnt_dofadr[dj] < 3) ? 1 : 0;
 		c.d_simple = (m.nv && m.dof_jstart[dd] == m.body_dofadr[c.d_body]) ? 1 : 0;
+		c.d_bmlo = m.nv ? (unsigned int)m.dof_bodymask[2 * dd] : 0u;
+		c.d_bmhi = m.nv ? (unsigned int)m.dof_bodymask[2 * dd + 1] : 0u;
 	}
 	e.f = reinterpret_cast<double *>(smem + (size_t)slot * frame_bytes);
 	e.fi = reinterpret_cast<int *>(e.f + L.ndouble);
