@@ -208,6 +208,14 @@ int mjb_sensor_pack(mjb_batch *b, uint64_t seed);
 int mjb_sensor_get(mjb_batch *b, int which, int env_lo, int env_hi, float *host);
 void *mjb_sensor_device_ptr(mjb_batch *b, int which);
 
+/* ---- per-env model parameters (the subset that needs no mj_setConst) ----
+ * The reference mutates its single mjModel through services (setGravity, setGeomProperties friction:
+ * /root/reference mujoco_ros/src/callbacks.cpp:462-592, 641-884); in a batch every env may carry its own value (domain
+ * randomisation).  Envs never written keep the model's value.  gravity: [env][3]; friction: [env][ngeom][3].
+ * (Mass / size / type changes need mj_setConst per env and are not implemented.) */
+int mjb_set_env_gravity(mjb_batch *b, int env_lo, int env_hi, const double *gravity);
+int mjb_set_env_geom_friction(mjb_batch *b, int env_lo, int env_hi, const double *friction);
+
 /* ---- device-side DefaultRobotHWSim::writeSim ----
  * The reference's ros_control bridge writes the controllers' joint commands into mjData on every control callback
  * (/root/reference mujoco_ros_control/src/default_robot_hw_sim.cpp:248-326): EFFORT -> qfrc_applied, POSITION -> qpos

@@ -108,6 +108,7 @@ struct mjb_batch {
 	double *sens_mean_dev = nullptr, *sens_sigma_dev = nullptr;
 	float *sens_value = nullptr, *sens_truth = nullptr;
 	bool sens_dirty = true, sens_packed = false;
+	double *env_gravity = nullptr, *env_geom_friction = nullptr;  // per-env model parameter overrides (mjb_set_env_*)
 	// device-side DefaultRobotHWSim (mjb_hwsim_*)
 	HwSim hw{};
 	int *hw_ints = nullptr;        // joint | method | kind | antiwindup, [4][n]
@@ -190,6 +191,10 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	off += newton ? 3 * d.nefcmax : 0;
 	L.nwt_hc = off;
 	off += (newton && d.cone == MJB_CONE_ELLIPTIC) ? 36 * d.nconmax : 0;
+	L.gravity = off;
+	off += 3;
+	L.gfriction = off;
+	off += d.nconmax > 0 ? 3 * d.ngeom : 0;
 	L.cwrench = off;
 	off += need_post ? 6 * d.nconmax : 0;
 	L.MhB = off;
@@ -630,6 +635,8 @@ void mjb_free_batch(mjb_batch *b)
 	if (b->blob) hipFree(b->blob);
 	if (b->mask_dev) hipFree(b->mask_dev);
 	if (b->params_dev) hipFree(b->params_dev);
+	if (b->env_gravity) hipFree(b->env_gravity);
+	if (b->env_geom_friction) hipFree(b->env_geom_friction);
 	if (b->hw_ints) hipFree(b->hw_ints);
 	if (b->hw_gains) hipFree(b->hw_gains);
 	if (b->hw_cmd) hipFree(b->hw_cmd);
@@ -777,6 +784,8 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	s.frame_ws = nullptr;
 	s.frame_stride = b->L.ndouble + b->L.nint / 2;
 	s.use_xfrc = 0;
+	s.env_gravity = nullptr;
+	s.env_geom_friction = nullptr;
 	s.keep_frame = 0;
 	s.pad1 = 0;
 	if (!ok) {
@@ -1125,6 +1134,42 @@ int mjb_warning_count(mjb_batch *b, unsigned long long *count)
 	HIP_TRY(hipStreamSynchronize(b->stream));
 	HIP_TRY(hipMemcpy(count, b->st.nwarn, sizeof(unsigned long long), hipMemcpyDeviceToHost));
 	return MJB_OK;
+}
+
+// ---- per-env model parameters (the subset that needs no mj_setConst) ----
+static int env_param(mjb_batch *b, double **arr, const double **slot, int per_env, const double *model_vals, int env_lo, int env_hi,
+                     const double *vals, const char *what)
+{
+	if (!b || !vals) return fail(MJB_EINVAL, "%s: bad argument", what);
+	if (env_lo < 0 || env_hi > b->nenv || env_lo > env_hi) return fail(MJB_EINVAL, "%s: bad env range", what);
+	if (per_env <= 0) return fail(MJB_EINVAL, "%s: the model has nothing to override", what);
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	if (!*arr) {  // first use: every env starts from the model's values
+		*arr = dev_alloc<double>((size_t)b->nenv * per_env);
+		if (!*arr) return fail(MJB_ENOMEM, "%s: allocation failed", what);
+		std::vector<double> init((size_t)b->nenv * per_env);
+		for (int e = 0; e < b->nenv; e++) memcpy(init.data() + (size_t)e * per_env, model_vals, (size_t)per_env * sizeof(double));
+		HIP_TRY(hipMemcpy(*arr, init.data(), init.size() * sizeof(double), hipMemcpyHostToDevice));
+		*slot = *arr;
+		b->params_dirty = true;
+	}
+	HIP_TRY(hipMemcpy(*arr + (size_t)env_lo * per_env, vals, (size_t)(env_hi - env_lo) * per_env * sizeof(double), hipMemcpyHostToDevice));
+	return MJB_OK;
+}
+
+int mjb_set_env_gravity(mjb_batch *b, int env_lo, int env_hi, const double *gravity)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	return env_param(b, &b->env_gravity, &b->st.env_gravity, 3, b->model->h.gravity, env_lo, env_hi, gravity, "mjb_set_env_gravity");
+}
+
+int mjb_set_env_geom_friction(mjb_batch *b, int env_lo, int env_hi, const double *friction)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	const mjb_model_desc &h = b->model->h;
+	return env_param(b, &b->env_geom_friction, &b->st.env_geom_friction, h.nconmax > 0 ? 3 * h.ngeom : 0, h.geom_friction, env_lo,
+	                 env_hi, friction, "mjb_set_env_geom_friction");
 }
 
 // ---- device-side DefaultRobotHWSim::writeSim (stage hwsim_write in mjb_step.hip) ----

@@ -569,7 +569,7 @@ template <int G> STAGE void collision(CModel m, CLayout L, const Env &e)
 					condim = m.geom_condim[g];
 					for (int k = 0; k < 2; k++) solref[k] = m.geom_solref[2 * g + k];
 					for (int k = 0; k < 5; k++) solimp[k] = m.geom_solimp[5 * g + k];
-					for (int k = 0; k < 3; k++) fri[k] = m.geom_friction[3 * g + k];
+					for (int k = 0; k < 3; k++) fri[k] = f[L.gfriction + 3 * g + k];
 				} else {
 					const int c1 = m.geom_condim[g1], c2 = m.geom_condim[g2];
 					condim = c1 > c2 ? c1 : c2;
@@ -585,7 +585,7 @@ template <int G> STAGE void collision(CModel m, CLayout L, const Env &e)
 						solref[k] = (r10 > 0 && r20 > 0) ? mix * a + (1 - mix) * b : fmin(a, b);
 					}
 					for (int k = 0; k < 5; k++) solimp[k] = mix * m.geom_solimp[5 * g1 + k] + (1 - mix) * m.geom_solimp[5 * g2 + k];
-					for (int k = 0; k < 3; k++) fri[k] = fmax(m.geom_friction[3 * g1 + k], m.geom_friction[3 * g2 + k]);
+					for (int k = 0; k < 3; k++) fri[k] = fmax(f[L.gfriction + 3 * g1 + k], f[L.gfriction + 3 * g2 + k]);
 				}
 			}
 			for (int i = 0; i < 4; i++) {

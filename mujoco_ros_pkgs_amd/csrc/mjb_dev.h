@@ -74,6 +74,8 @@ struct FrameLayout {
 	int nwt_row;   // [3*nefcmax] Newton: per-row jaref, jv, Hessian weight
 	int nwt_hc;    // [36*nconmax] Newton: Hessian blocks of the elliptic cones (size 0 unless cone == elliptic)
 	int iscratch;  // transient int scratch: max(ncollpair, njnt + nconmax)
+	int gravity;   // [3] this env's gravity (model value or per-env override, loaded with the state)
+	int gfriction; // [3*ngeom] this env's geom friction (models with contacts only)
 	int cwrench;  // [nconmax][6] world contact wrenches (rne_post scratch)
 	int kinloc;    // [7*nbody] kinematics: pose of each body in its parent frame (transient)
 	int crbbuf;    // [6*nv]    crb: crb[body(i)] * cdof_i (transient)
@@ -99,6 +101,8 @@ struct DevState {
 	unsigned long long *prof;      // [64] per-stage cycle sums + call counts (profiling build only), else NULL
 	int nenv;
 	int frame_stride;              // doubles per env in frame_ws
+	const double *env_gravity;       // [nenv][3] per-env gravity override (NULL: the model's)
+	const double *env_geom_friction; // [nenv][ngeom][3] per-env geom friction override (NULL: the model's)
 	int use_xfrc;                  // xfrc_applied has ever been written
 	int keep_frame;                // fused mjb_step also dumps the last step's full frame to frame_ws
 	int pad1;

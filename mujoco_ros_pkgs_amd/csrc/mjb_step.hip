@@ -962,7 +962,7 @@ template <int G, bool OBL> STAGE void rne(CModel m, CLayout L, const Env &e)
 	// inertial force  I a + v x* (I v)   (cfrc_body holds the per-body force, not its subtree sum)
 	for (int b = lane; b < m.nbody; b += G) {
 		const unsigned int lo = OBL ? e.lc.dmlo : (unsigned int)m.body_dofmask[2 * b], hi = OBL ? e.lc.dmhi : (unsigned int)m.body_dofmask[2 * b + 1];
-		double a[6] = { 0, 0, 0, grav ? -m.gravity[0] : 0.0, grav ? -m.gravity[1] : 0.0, grav ? -m.gravity[2] : 0.0 };
+		double a[6] = { 0, 0, 0, grav ? -f[L.gravity] : 0.0, grav ? -f[L.gravity + 1] : 0.0, grav ? -f[L.gravity + 2] : 0.0 };
 #pragma unroll 3
 		for (int d = 0; d < m.nv; d++) {
 			const double qd = maskbit(lo, hi, d) ? qvel[d] : 0.0;
@@ -1149,7 +1149,7 @@ template <int G> __device__ __attribute__((noinline)) void rne_post(CModel m, CL
 		}
 		st6(f + L.cfrc_ext + 6 * b, ext);
 		const unsigned int lo = (unsigned int)m.body_dofmask[2 * b], hi = (unsigned int)m.body_dofmask[2 * b + 1];
-		double a[6] = { 0, 0, 0, grav ? -m.gravity[0] : 0.0, grav ? -m.gravity[1] : 0.0, grav ? -m.gravity[2] : 0.0 };
+		double a[6] = { 0, 0, 0, grav ? -f[L.gravity] : 0.0, grav ? -f[L.gravity + 1] : 0.0, grav ? -f[L.gravity + 2] : 0.0 };
 		for (int d = 0; d < m.nv; d++) {
 			const bool on = maskbit(lo, hi, d);
 			const double qv = on ? f[L.qvel + d] : 0.0, qa = on ? f[L.qacc + d] : 0.0;
@@ -1550,6 +1550,11 @@ template <int G> STAGE void load_state(CModel m, CLayout L, CState s, const Env 
 	copy_in<G>(e.f + L.mocap_pos, s.mocap_pos + env * 3 * m.nmocap, 3 * m.nmocap, e.lane);
 	copy_in<G>(e.f + L.mocap_quat, s.mocap_quat + env * 4 * m.nmocap, 4 * m.nmocap, e.lane);
 	if (e.lane == 0) e.f[L.time] = s.time[env];
+	// this env's gravity / geom friction: the model's values or the per-env overrides (mjb_set_env_*)
+	for (int k = e.lane; k < 3; k += G) e.f[L.gravity + k] = s.env_gravity ? s.env_gravity[env * 3 + k] : m.gravity[k];
+	if (m.nconmax > 0)
+		for (int k = e.lane; k < 3 * m.ngeom; k += G)
+			e.f[L.gfriction + k] = s.env_geom_friction ? s.env_geom_friction[env * 3 * m.ngeom + k] : m.geom_friction[k];
 }
 
 template <int G> STAGE void store_state(CModel m, CLayout L, CState s, const Env &e)

@@ -105,6 +105,18 @@ class Batch:
         _check(self.lib.mjb_warning_count(self.ptr, C.byref(n)), "mjb_warning_count")
         return int(n.value)
 
+    # ---- per-env model parameters ----
+    def set_env_gravity(self, gravity, lo=0, hi=None):
+        hi = self.nenv if hi is None else hi
+        a = np.ascontiguousarray(gravity, dtype=np.float64).reshape(hi - lo, 3)
+        _check(self.lib.mjb_set_env_gravity(self.ptr, lo, hi, a.ctypes.data_as(C.POINTER(C.c_double))), "mjb_set_env_gravity")
+
+    def set_env_geom_friction(self, friction, lo=0, hi=None):
+        hi = self.nenv if hi is None else hi
+        a = np.ascontiguousarray(friction, dtype=np.float64).reshape(hi - lo, self.cm.model["ngeom"] * 3)
+        _check(self.lib.mjb_set_env_geom_friction(self.ptr, lo, hi, a.ctypes.data_as(C.POINTER(C.c_double))),
+               "mjb_set_env_geom_friction")
+
     # ---- device-side DefaultRobotHWSim (mjb_hwsim_*) ----
     def hwsim_configure(self, joints):
         """joints: list of dicts(joint=<id>, method=..., kind=..., p, i, d, i_max, i_min, antiwindup, effort_limit, lower, upper)."""

@@ -1,0 +1,42 @@
+"""Per-env model parameters (SURVEY.md §8f rank 4 subset: gravity and geom friction, what the reference's setGravity /
+setGeomProperties services change on its single model): every env of the batch may carry its own value; each env must
+then match the oracle run on a model compiled with that value."""
+import os
+
+import numpy as np
+import pytest
+
+from mujoco_ros_pkgs_amd import mjcf
+
+pytestmark = pytest.mark.gpu
+
+
+def test_per_env_gravity_and_friction(oracle_built):
+    from mujoco_ros_pkgs_amd import engine
+    from test_gpu_contact import scenario_states
+    path = os.path.join(mjcf.ASSET_DIR, "franka_table.xml")
+    base = mjcf.compile_xml_file(path, override={"solver": "Newton"})
+    cm = engine.CompiledModel(base)
+    nenv = 6
+    qpos, qvel = scenario_states(base, nenv, seed=8)
+    grav = np.tile(np.asarray(base["gravity"], dtype=np.float64), (nenv, 1))
+    fric = np.tile(np.asarray(base["geom_friction"], dtype=np.float64).reshape(1, -1), (nenv, 1))
+    grav[1] = [0, 0, 0]            # env 1 floats
+    grav[2] = [1.0, 0, -3.7]       # env 2 on a tilted Mars
+    fric[3] *= 0.05                # env 3 on ice
+    fric[4, :3] = [2.0, 0.01, 0.001]
+    b = engine.Batch(cm, nenv)
+    b.set("qpos", qpos)
+    b.set("qvel", qvel)
+    b.set_env_gravity(grav[1:3], 1, 3)
+    b.set_env_geom_friction(fric[3:5], 3, 5)
+    b.step(120)
+    for e in range(nenv):
+        m = mjcf.Model(dict(base))
+        m["gravity"] = grav[e].copy()
+        m["geom_friction"] = fric[e].reshape(-1, 3).copy()
+        oq, ov, _ = oracle_built.rollout(m, qpos[e:e + 1], qvel[e:e + 1], 120)
+        np.testing.assert_allclose(b.get("qpos")[e], oq[0], rtol=0, atol=1e-6, err_msg=f"env {e}")
+    # the overrides matter: the floating env kept its cube where it was, the default env dropped / settled it
+    assert abs(b.get("qpos")[1, 2] - qpos[1, 2]) < 0.02 and not np.allclose(b.get("qpos")[0], b.get("qpos")[1])
+    b.close()
