@@ -111,6 +111,21 @@ int mjr_env_test_plugin_flag(mjr_env *e, int i, const char *name, int clear);
 int mjr_env_notify_geom_changed(mjr_env *e, int geom_id);
 int mjr_env_set_callback_envs(mjr_env *e, int n);
 
+/* ---- sensors plugin ("mujoco_ros_sensors/MujocoRosSensorsPlugin"): the typed records it would publish
+ * (reference: mujoco_ros_sensors/src/mujoco_sensor_handler_plugin.cpp:175-436 lastStageCallback, :123-173
+ * registerNoiseModelsCB).  kind: 0 ScalarStamped, 1 Vector3Stamped, 2 PointStamped, 3 QuaternionStamped. */
+typedef struct mjr_sensor_record {
+	char name[64], frame_id[64];
+	int kind, env, has_truth;
+	double stamp;
+	float value[4], truth[4];
+} mjr_sensor_record;
+int mjr_sensors_num_records(mjr_env *e, int plugin, int env);                       /* -1: not a sensors plugin */
+int mjr_sensors_get_record(mjr_env *e, int plugin, int env, int k, mjr_sensor_record *out);
+/* 1 success, 0 refused (eval mode and wrong admin hash), -1 not a sensors plugin */
+int mjr_sensors_register_noise(mjr_env *e, int plugin, const char *sensor_name, int set_flag, const double *mean,
+                               const double *std, const char *admin_hash);
+
 #ifdef __cplusplus
 }
 #endif

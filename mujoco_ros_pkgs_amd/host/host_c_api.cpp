@@ -5,6 +5,7 @@
 
 #include "mujoco_env.h"
 #include "test_plugin.h"
+#include "sensors_plugin.h"
 
 using namespace mujoco_ros;
 
@@ -256,6 +257,45 @@ int mjr_env_set_callback_envs(mjr_env *e, int n)
 {
 	e->env->setCallbackEnvs(n);
 	return 0;
+}
+
+// ---- MujocoRosSensorsPlugin accessors (sensors_plugin.h) ----
+static mujoco_ros::sensors::MujocoRosSensorsPlugin *sensors_plugin(mjr_env *e, int i)
+{
+	const auto &pl = e->env->getPlugins();
+	if (i < 0 || i >= (int)pl.size()) return nullptr;
+	return dynamic_cast<mujoco_ros::sensors::MujocoRosSensorsPlugin *>(pl[i].get());
+}
+int mjr_sensors_num_records(mjr_env *e, int plugin, int env)
+{
+	auto *p = sensors_plugin(e, plugin);
+	return p ? (int)p->records(env).size() : -1;
+}
+int mjr_sensors_get_record(mjr_env *e, int plugin, int env, int k, mjr_sensor_record *out)
+{
+	auto *p = sensors_plugin(e, plugin);
+	if (!p || !out) return -1;
+	const auto &r = p->records(env);
+	if (k < 0 || k >= (int)r.size()) return -1;
+	memset(out, 0, sizeof(*out));
+	snprintf(out->name, sizeof(out->name), "%s", r[k].name.c_str());
+	snprintf(out->frame_id, sizeof(out->frame_id), "%s", r[k].frame_id.c_str());
+	out->kind = r[k].kind;
+	out->env = r[k].env;
+	out->has_truth = r[k].has_truth ? 1 : 0;
+	out->stamp = r[k].stamp;
+	for (int c = 0; c < 4; c++) {
+		out->value[c] = r[k].value[c];
+		out->truth[c] = r[k].truth[c];
+	}
+	return 0;
+}
+int mjr_sensors_register_noise(mjr_env *e, int plugin, const char *sensor_name, int set_flag, const double *mean, const double *std,
+                               const char *admin_hash)
+{
+	auto *p = sensors_plugin(e, plugin);
+	if (!p) return -1;
+	return p->registerNoiseModel(sensor_name ? sensor_name : "", (unsigned char)set_flag, mean, std, admin_hash ? admin_hash : "") ? 1 : 0;
 }
 
 }  // extern "C"

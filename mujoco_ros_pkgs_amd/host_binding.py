@@ -20,6 +20,14 @@ class Names(C.Structure):
     _fields_ = [(k, C.POINTER(C.c_char_p)) for k in ("body", "joint", "geom", "site", "sensor", "actuator")]
 
 
+class SensorRecord(C.Structure):
+    """mjr_sensor_record (include/mjr_host.h)."""
+    _fields_ = [("name", C.c_char * 64), ("frame_id", C.c_char * 64), ("kind", C.c_int), ("env", C.c_int),
+                ("has_truth", C.c_int), ("stamp", C.c_double), ("value", C.c_float * 4), ("truth", C.c_float * 4)]
+
+
+SENSOR_KINDS = ("scalar", "vector3", "point", "quaternion")
+
 BACKEND_FACTORY = C.CFUNCTYPE(C.c_void_p, C.POINTER(binding.ModelDesc), C.c_int, C.c_int, C.c_void_p)
 
 _lib = None
@@ -69,6 +77,9 @@ def load_library():
         "mjr_env_test_plugin_flag": (ci, [vp, ci, cs, ci]),
         "mjr_env_notify_geom_changed": (ci, [vp, ci]),
         "mjr_env_set_callback_envs": (ci, [vp, ci]),
+        "mjr_sensors_num_records": (ci, [vp, ci, ci]),
+        "mjr_sensors_get_record": (ci, [vp, ci, ci, ci, C.POINTER(SensorRecord)]),
+        "mjr_sensors_register_noise": (ci, [vp, ci, cs, ci, C.POINTER(C.c_double), C.POINTER(C.c_double), cs]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -196,3 +207,33 @@ class HostEnv:
 
     def set_callback_envs(self, n):
         self.L.mjr_env_set_callback_envs(self.ptr, n)
+
+    # ---- sensors plugin (mujoco_ros_sensors/MujocoRosSensorsPlugin)
+    def sensor_records(self, plugin=0, env=0):
+        """The messages the plugin would have published in its last lastStageCallback: {name: dict}."""
+        n = self.L.mjr_sensors_num_records(self.ptr, plugin, env)
+        if n < 0:
+            raise RuntimeError("plugin %d is not a sensors plugin" % plugin)
+        out = {}
+        for k in range(n):
+            r = SensorRecord()
+            if self.L.mjr_sensors_get_record(self.ptr, plugin, env, k, C.byref(r)) != 0:
+                raise RuntimeError("mjr_sensors_get_record failed")
+            dim = {0: 1, 1: 3, 2: 3, 3: 4}[r.kind]
+            out[r.name.decode()] = dict(frame_id=r.frame_id.decode(), kind=SENSOR_KINDS[r.kind], stamp=r.stamp, env=r.env,
+                                        value=np.array(r.value[:dim], dtype=np.float32),
+                                        truth=np.array(r.truth[:dim], dtype=np.float32) if r.has_truth else None)
+        return out
+
+    def register_noise_model(self, sensor_name, set_flag, mean, std, admin_hash="", plugin=0):
+        """RegisterSensorNoiseModels for one model; returns the service's `success`."""
+        mu = np.zeros(3)
+        sg = np.zeros(3)
+        mu[:len(mean)] = mean
+        sg[:len(std)] = std
+        pd = C.POINTER(C.c_double)
+        rc = self.L.mjr_sensors_register_noise(self.ptr, plugin, sensor_name.encode(), int(set_flag), mu.ctypes.data_as(pd),
+                                               sg.ctypes.data_as(pd), admin_hash.encode())
+        if rc < 0:
+            raise RuntimeError("plugin %d is not a sensors plugin" % plugin)
+        return bool(rc)

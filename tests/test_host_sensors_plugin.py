@@ -1,0 +1,141 @@
+"""Host-side MujocoRosSensorsPlugin mirror (mujoco_ros_pkgs_amd/host/sensors_plugin.cpp): the reference's
+mujoco_ros_sensors/test/mujoco_sensors_test.cpp replayed on the ROS-free records the plugin produces instead of
+topics.  Each test names the reference test it restates."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from mujoco_ros_pkgs_amd import mjcf
+from test_host_env import GOLDEN, factory, host, oracle_factory, start, wait  # noqa: F401 (fixtures)
+
+SENSORS = [{"type": "mujoco_ros_sensors/MujocoRosSensorsPlugin", "seed": 7}]
+
+
+def world():
+    return mjcf.compile_xml_file(os.path.join(GOLDEN, "sensors_world.xml"))
+
+
+def sensor_slice(m, name):
+    n = m["names"]["sensor"].index(name)
+    adr, dim = int(m["sensor_adr"][n]), int(m["sensor_dim"][n])
+    cutoff = float(m["sensor_cutoff"][n]) if m["sensor_cutoff"][n] > 0 else 1.0
+    return adr, dim, cutoff
+
+
+def rpy(q):
+    w, x, y, z = [float(v) for v in q]
+    return (math.atan2(2 * (w * x + y * z), 1 - 2 * (x * x + y * y)), math.asin(max(-1, min(1, 2 * (w * y - z * x)))),
+            math.atan2(2 * (w * z + x * y), 1 - 2 * (y * y + z * z)))
+
+
+def test_sensor_created_train_and_eval(host, factory):
+    """mujoco_sensors_test.cpp:184-215 (SensorCreatedTrain: value + GT per named sensor), :217-248
+    (SensorCreatedEval: value only) and the frame ids / message kinds of initSensors (:438-606)."""
+    m = world()
+    env = start(host, factory, m, {"unpause": False, "MujocoPlugins": SENSORS})
+    assert env.num_plugins == 1 and env.num_cb_ready_plugins == 1
+    assert env.step(1)
+    rec = env.sensor_records()
+    assert set(rec) == set(m["names"]["sensor"])
+    assert all(r["truth"] is not None for r in rec.values())
+    assert rec["immovable_pos"]["kind"] == "point" and rec["immovable_pos"]["frame_id"] == "world"
+    assert rec["immovable_quat"]["kind"] == "quaternion" and rec["immovable_quat"]["frame_id"] == "world"
+    assert rec["vel_EE"]["kind"] == "vector3" and rec["vel_EE"]["frame_id"] == "end_link"
+    assert rec["vel_joint2"]["kind"] == "scalar"
+    assert rec["vel_EE"]["stamp"] == pytest.approx(0.001)
+    env.shutdown()
+    env = start(host, factory, m, {"unpause": False, "eval_mode": True, "MujocoPlugins": SENSORS}, admin_hash="example_hash")
+    assert env.step(1)
+    rec = env.sensor_records()
+    assert set(rec) == set(m["names"]["sensor"]) and all(r["truth"] is None for r in rec.values())
+    # registerNoiseModelsCB :126-135: eval mode needs the admin hash
+    assert env.register_noise_model("vel_EE", 1, [0.0], [0.1], admin_hash="wrong") is False
+    assert env.register_noise_model("vel_EE", 1, [0.0], [0.1], admin_hash="example_hash") is True
+    env.shutdown()
+
+
+def running_stats(samples):
+    a = np.asarray(samples, dtype=np.float64)
+    return a.mean(axis=0), a.var(axis=0, ddof=1)
+
+
+@pytest.mark.parametrize("name,flag,mean,std,exp_mean", [
+    ("vel_EE", 3, [0.0, 1.0], [0.025, 0.0], [0, 1, 0]),           # Sensor3DOF :281-392
+    ("immovable_pos", 3, [0.0, 1.0], [0.025, 0.0], [0, 1, 0]),    # Framepos :394-506
+])
+def test_vector_noise_statistics(host, factory, name, flag, mean, std, exp_mean):
+    m = world()
+    env = start(host, factory, m, {"unpause": False, "MujocoPlugins": SENSORS})
+    adr, dim, cutoff = sensor_slice(m, name)
+    assert env.step(1)
+    r = env.sensor_records()[name]
+    np.testing.assert_allclose(r["value"], r["truth"], atol=1e-4)  # without noise value == GT
+    assert env.register_noise_model(name, flag, mean, std, admin_hash="example_hash")
+    diffs, truths = [], []
+    for _ in range(1001):
+        assert env.step(1)
+        r = env.sensor_records()[name]
+        sd = env.get_field("sensordata")[adr:adr + dim]
+        np.testing.assert_allclose(r["truth"], sd / cutoff, atol=1e-4)  # GT == sensor reading
+        diffs.append(r["value"].astype(np.float64) - r["truth"])
+        truths.append(r["truth"])
+    mu, var = running_stats(diffs)
+    assert abs(mu[0] - exp_mean[0]) < 0.02 and abs(mu[1] - exp_mean[1]) < 1e-4 and mu[2] == 0
+    assert abs(var[0] - 0.000625) < 1e-4 and var[1] < 1e-9 and var[2] == 0
+    env.shutdown()
+
+
+def test_scalar_noise_statistics(host, factory):
+    """mujoco_sensors_test.cpp:508-585 (scalar_stamped): mean 1, sigma 0.025 on vel_joint2."""
+    m = world()
+    env = start(host, factory, m, {"unpause": False, "MujocoPlugins": SENSORS})
+    adr, dim, cutoff = sensor_slice(m, "vel_joint2")
+    assert env.step(1)
+    r = env.sensor_records()["vel_joint2"]
+    assert abs(r["value"][0] - r["truth"][0]) < 1e-4
+    assert env.register_noise_model("vel_joint2", 1, [1.0], [0.025], admin_hash="example_hash")
+    diffs = []
+    for _ in range(1001):
+        assert env.step(1)
+        r = env.sensor_records()["vel_joint2"]
+        assert abs(r["truth"][0] - env.get_field("sensordata")[adr] / cutoff) < 1e-4
+        diffs.append(float(r["value"][0]) - float(r["truth"][0]))
+    assert abs(np.mean(diffs) - 1) < 0.01 and abs(np.var(diffs, ddof=1) - 0.000625) < 1e-4
+    env.shutdown()
+
+
+def test_quaternion_noise_statistics(host, factory):
+    """mujoco_sensors_test.cpp:587-712 (quaternion): set_flag 4 -> yaw noise with mean 1, sigma 0.025."""
+    m = world()
+    env = start(host, factory, m, {"unpause": False, "MujocoPlugins": SENSORS})
+    assert env.step(1)
+    r = env.sensor_records()["immovable_quat"]
+    np.testing.assert_allclose(r["value"], r["truth"], atol=1e-4)
+    assert env.register_noise_model("immovable_quat", 4, [1.0], [0.025], admin_hash="example_hash")
+    d = []
+    for _ in range(1001):
+        assert env.step(1)
+        r = env.sensor_records()["immovable_quat"]
+        a, b = rpy(r["value"]), rpy(r["truth"])
+        d.append([a[k] - b[k] for k in range(3)])
+    mu, var = running_stats(d)
+    assert abs(mu[0]) < 1e-6 and abs(mu[1]) < 1e-6 and abs(mu[2] - 1) < 0.01
+    assert var[0] < 1e-10 and var[1] < 1e-10 and abs(var[2] - 0.000625) < 1e-4
+    env.shutdown()
+
+
+def test_records_per_env(host, factory):
+    """Batched extension: one record list per env instance, stamped with that env's readings."""
+    m = world()
+    env = start(host, factory, m, {"unpause": False, "MujocoPlugins": SENSORS}, nenv=3)
+    env.set_callback_envs(3)
+    qv = np.zeros(m["nv"])
+    qv[4] = 0.5  # joint2 velocity differs in env 2
+    env.set_field("qvel", qv, env=2)
+    assert env.step(1)
+    r0, r2 = env.sensor_records(env=0), env.sensor_records(env=2)
+    assert r0["vel_joint2"]["env"] == 0 and r2["vel_joint2"]["env"] == 2
+    assert abs(r2["vel_joint2"]["truth"][0] - r0["vel_joint2"]["truth"][0]) > 0.1
+    env.shutdown()
