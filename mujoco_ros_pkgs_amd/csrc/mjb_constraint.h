@@ -1105,6 +1105,33 @@ DEVI double wave_bcast(double v, int srclane)  // srclane must be wave-uniform
 	                        __builtin_amdgcn_readlane(__double2loint(v), srclane));
 }
 
+// One Gauss-Seidel sweep over the rows: row i lives in lane i together with its row of AR (registers).  Every lane
+// proposes the update of ITS row from its running residual (only lane i's proposal at step i is ever used, so the
+// lanes can work from the force they had at the start of the sweep); lane i's delta is broadcast with v_readlane,
+// filed into lane i of `dvec` with v_writelane, and every lane does res += AR[.][i] * delta.  Dependent chain per row:
+// fma, max, add, readlane, fma.
+// The reference's guard "undo the update if it RAISES the cost by more than 1e-10" is dead code here: with
+// Aii = J M^-1 J' + R > 0 the unclipped step changes the cost by -0.5 res^2 / Aii and the clipped one by
+// -f (res - 0.5 f Aii) with res >= f Aii, both <= 0 beyond any rounding, so it is not evaluated.
+DEVI void pgs_sweep(const double (&AR)[64], const int nefc, const double lo, const double ARinv, double &res,
+                    const double frc, double &dvec)
+{
+#pragma unroll
+	for (int i = 0; i < 64; i++) {
+		if ((i & 3) == 0) {
+			if (i >= nefc) break;  // rows beyond nefc in a group of four propose delta == 0
+			MJB_KEEP_BRANCH();
+		}
+		const double delta = __builtin_fmax(frc - res * ARinv, lo) - frc;
+		const int dh = __builtin_amdgcn_readlane(__double2hiint(delta), i), dl = __builtin_amdgcn_readlane(__double2loint(delta), i);
+		res += AR[i] * __hiloint2double(dh, dl);
+		int vh = __double2hiint(dvec), vl = __double2loint(dvec);  // (clang has no writelane builtin)
+		asm("v_writelane_b32 %0, %1, %2" : "+v"(vh) : "s"(dh), "n"(i));
+		asm("v_writelane_b32 %0, %1, %2" : "+v"(vl) : "s"(dl), "n"(i));
+		dvec = __hiloint2double(vh, vl);
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // A13 constraint solve: warmstart + projected Gauss-Seidel (dual), one env per wavefront
 // ------------------------------------------------------------------------------------------------
@@ -1126,12 +1153,15 @@ template <int G> STAGE void fwd_constraint_pgs(CModel m, CLayout L, const Env &e
 		gsync<G>();
 		return;
 	}
+	// Row r lives in lane r together with ITS ROW OF AR = J M^-1 J' + diag(R) in registers (64 doubles): a
+	// Gauss-Seidel update of row i is then "every lane proposes the update of its own row from its running residual,
+	// lane i's proposal is broadcast with v_readlane, every lane does res += AR[.][i] * delta" -- no reduction and no
+	// LDS access inside the sweep (the dependent chain per row is ~9 fp64 ops + one readlane pair).
 	const bool rowact = lane < nefc;
 	const int r = rowact ? lane : 0;
 	const double *Jr = f + L.efc_J + r * nv, *Br = f + L.efc_B + r * nv;
 	const bool bilateral = rowact && fi[L.efc_type + r] == MJB_CNSTR_EQUALITY;
-	// per-row scalars in the row's lane
-	double b = 0, R = 1, ARinv = 0, Aii = 1, frc = 0;
+	double b = 0, Aii = 1, ARinv = 0, frc = 0;
 	{
 		double jq = 0, jb = 0, jw = 0;
 		for (int k = 0; k < nv; k++) {
@@ -1140,79 +1170,78 @@ template <int G> STAGE void fwd_constraint_pgs(CModel m, CLayout L, const Env &e
 			jb += j * Br[k];
 			jw += j * f[L.qacc_warmstart + k];
 		}
-		const double aref = f[L.efc_aref + r];
-		b = jq - aref;
-		R = f[L.efc_R + r];
-		Aii = jb + R;
-		ARinv = 1.0 / Aii;
-		if (!(m.disableflags & MJB_DSBL_WARMSTART)) {
-			const double jar = jw - aref;
-			frc = (jar < 0 || bilateral) ? -f[L.efc_D + r] * jar : 0.0;
+		const double aref = f[L.efc_aref + r], R = f[L.efc_R + r];
+		if (rowact) {
+			b = jq - aref;
+			Aii = jb + R;
+			ARinv = 1.0 / Aii;
+			f[L.efc_b + r] = b;
+			if (!(m.disableflags & MJB_DSBL_WARMSTART)) {
+				const double jar = jw - aref;
+				frc = (jar < 0 || bilateral) ? -f[L.efc_D + r] * jar : 0.0;
+			}
 		}
-		if (!rowact) { b = 0; frc = 0; }
-		f[L.efc_b + r] = rowact ? b : f[L.efc_b + r];
 	}
-	// w = M^-1 J' f  (lane k < nv holds w[k]); warmstart cost 0.5 f'ARf + f'b = sum_i f_i (0.5 (J_i.w + R_i f_i) + b_i)
-	if (rowact) f[L.efc_force + r] = frc;
-	gsync<G>();
-	double w = 0;
-	const bool dofact = lane < nv;
-	if (dofact)
-		for (int i = 0; i < nefc; i++) w += f[L.efc_B + i * nv + lane] * f[L.efc_force + i];
-	if (dofact) f[L.qfrc_constraint + lane] = w;  // parked so that rows can read w
-	gsync<G>();
+	// AR[i] = J_r . B_i: k outermost so that the 64 accumulators are independent (every load of one k is in flight
+	// together); row groups beyond nefc accumulate stale rows and are zeroed afterwards
+	double AR[64];
+#pragma unroll
+	for (int i = 0; i < 64; i++) AR[i] = 0;
+#pragma nounroll
+	for (int k = 0; k < nv; k++) {
+		const double jk = Jr[k];
+		const double *Bk = f + L.efc_B + k;
+#pragma unroll
+		for (int i = 0; i < 64; i++) {
+			if ((i & 3) == 0) {
+				if (i >= nefc) break;
+				MJB_KEEP_BRANCH();
+			}
+			AR[i] += jk * Bk[i * nv];
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < 64; i++) AR[i] = (rowact && i < nefc) ? (lane == i ? Aii : AR[i]) : 0.0;
+	// residual of the warmstart forces, res = b + AR f, and their cost 0.5 f'ARf + f'b = sum_i 0.5 f_i (res_i + b_i)
+	double res = b;
+#pragma unroll
+	for (int i = 0; i < 64; i++)
+		if (i < nefc) res += AR[i] * wave_bcast(frc, i);
 	{
-		double jw = 0;
-		for (int k = 0; k < nv; k++) jw += Jr[k] * f[L.qfrc_constraint + k];
-		double ci = rowact ? frc * (0.5 * (jw + R * frc) + b) : 0.0;
-		const double cost = wave_sum(ci);
+		const double cost = wave_sum(rowact ? 0.5 * frc * (res + b) : 0.0);
 		if (cost > 0 || (m.disableflags & MJB_DSBL_WARMSTART)) {
 			frc = 0;
-			w = 0;
+			res = b;
 		}
 	}
-	gsync<G>();
-	// Gauss-Seidel sweeps
+	// Gauss-Seidel sweeps; the cost decrease of a sweep (the reference sums the per-row changes, which telescope to
+	// exactly this) is cost(before) - cost(after) with cost = 0.5 f'ARf + f'b = sum_i 0.5 f_i (res_i + b_i)
 	const double scale = 1.0 / (m.meaninertia[0] * (nv > 1 ? nv : 1));
 	const double tol = m.tolerance[0];
+	const double lo = bilateral ? -__builtin_huge_val() : 0.0;  // equality rows are two-sided
+	double cost = wave_sum(0.5 * frc * (res + b));
 	int iter = 0;
 	while (iter < m.iterations) {
-		double improvement = 0;
-#pragma nounroll
-		for (int i = 0; i < nefc; i++) {
-			// J_i . w  over the nv dof lanes
-			const double ji = dofact ? f[L.efc_J + i * nv + lane] : 0.0;
-			const double bi_ = dofact ? f[L.efc_B + i * nv + lane] : 0.0;
-			double part = ji * w;
-			if (nv <= 16) part = wave_bcast(row_sum<16>(part), 0);
-			else part = wave_sum(part);
-			const double fi_ = wave_bcast(frc, i), bi = wave_bcast(b, i), Ri = wave_bcast(R, i);
-			const double Ai = wave_bcast(ARinv, i), Aii_i = wave_bcast(Aii, i);
-			const double res = bi + part + Ri * fi_;
-			double fn = fi_ - res * Ai;
-			if (fn < 0 && !(bool)__builtin_amdgcn_readlane((int)bilateral, i)) fn = 0;  // equality rows are two-sided
-			double delta = fn - fi_;
-			double change = 0.5 * delta * delta * Aii_i + delta * res;
-			if (change > 1e-10) {
-				fn = fi_;
-				delta = 0;
-				change = 0;
-			}
-			improvement -= change;
-			if (lane == i) frc = fn;
-			w += bi_ * delta;
-		}
-		improvement *= scale;
+		double dvec = 0;
+		pgs_sweep(AR, nefc, lo, ARinv, res, frc, dvec);
+		frc += dvec;
+		const double cost1 = wave_sum(0.5 * frc * (res + b));
+		const double improvement = (cost - cost1) * scale;
+		cost = cost1;
 		iter++;
 		if (improvement < tol) break;
 	}
 	if (lane == 0) fi[L.solver_iter] = iter;
 	if (rowact) f[L.efc_force + r] = frc;
 	gsync<G>();
-	// qfrc_constraint = J' f,  qacc = qacc_smooth + M^-1 J' f = qacc_smooth + w
-	if (dofact) {
-		double s = 0;
-		for (int i = 0; i < nefc; i++) s += f[L.efc_J + i * nv + lane] * f[L.efc_force + i];
+	// qfrc_constraint = J' f,  qacc = qacc_smooth + M^-1 J' f = qacc_smooth + B' f
+	if (lane < nv) {
+		double s = 0, w = 0;
+		for (int i = 0; i < nefc; i++) {
+			const double fr = f[L.efc_force + i];
+			s += f[L.efc_J + i * nv + lane] * fr;
+			w += f[L.efc_B + i * nv + lane] * fr;
+		}
 		f[L.qfrc_constraint + lane] = s;
 		const double a = f[L.qacc_smooth + lane] + w;
 		f[L.qacc + lane] = a;
