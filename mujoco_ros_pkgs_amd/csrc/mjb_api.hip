@@ -176,6 +176,8 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		} else {
 			*slots[idx] = off;
 			off += n;
+			// (project_constraint_dense16 parks the packed 16 x 16 triangle of L in the efc_B region)
+			if (idx == MJB_F_efc_B && n > 0 && n < 120) off += 120 - n;
 			if (fi.kind == 0) nstate = off;
 		}
 		idx++;

@@ -1073,6 +1073,58 @@ template <int G> STAGE void project_constraint(CModel m, CLayout L, const Env &e
 	gsync<G>();
 }
 
+// A7 for nv <= 16: the solve of row r runs in lane r's REGISTERS.  The sparse L'DL factor is first spread into a
+// packed dense strictly-lower triangle (entry (i, j) at i (i - 1) / 2 + j, zeros where j is no ancestor of i) parked in
+// the efc_B region itself, so that the fully unrolled substitution reads every L entry at a compile-time offset and a
+// wave-uniform address (one LDS broadcast per entry) and x never leaves the registers: 240 fma per row with no
+// load-modify-store chain, against two dependent LDS round trips per factor entry in the generic version.
+// Rows / columns >= nv of the triangle are zero and x[k >= nv] = 0, so the unrolled sweeps need no guards.
+template <int G> STAGE void project_constraint_dense16(CModel m, CLayout L, const Env &e)
+{
+	static_assert(G == 64, "one constraint row per lane of the wavefront");
+	double *f = e.f;
+	const int nefc = e.fi[L.nefc], nv = m.nv, lane = e.lane;
+	if (nefc == 0) return;
+	double *Ld = f + L.efc_B;
+	for (int t = lane; t < 120; t += G) Ld[t] = 0;
+	gsync<G>();
+	for (int en = lane; en < m.nM; en += G) {
+		const int i = m.M_rowdof[en], j = m.M_coldof[en];
+		if (i != j) Ld[i * (i - 1) / 2 + j] = f[L.qLD + en];
+	}
+	gsync<G>();
+	const bool act = lane < nefc;  // (PGS keeps nefc <= 64)
+	const double *Jr = f + L.efc_J + (act ? lane : 0) * nv, *di = f + L.qLDiagInv;
+	double x[16];
+#pragma unroll
+	for (int k = 0; k < 16; k++) {
+		const double v = Jr[k < nv ? k : 0];
+		x[k] = (k < nv && act) ? v : 0.0;
+	}
+	// x <- L^-T x: once x[i] is final, every x[j < i] takes its share (independent fma)
+#pragma unroll
+	for (int i = 15; i >= 1; i--) {
+#pragma unroll
+		for (int j = 0; j < i; j++) x[j] -= Ld[i * (i - 1) / 2 + j] * x[i];
+	}
+#pragma unroll
+	for (int k = 0; k < 16; k++) x[k] *= di[k < nv ? k : 0];
+	// x <- L^-1 x, column by column (same summation order as the row form)
+#pragma unroll
+	for (int j = 0; j < 15; j++) {
+#pragma unroll
+		for (int i = j + 1; i < 16; i++) x[i] -= Ld[i * (i - 1) / 2 + j] * x[j];
+	}
+	gsync<G>();  // every lane is done with the triangle: the B rows may overwrite it
+	if (act) {
+		double *Br = f + L.efc_B + lane * nv;
+#pragma unroll
+		for (int k = 0; k < 16; k++)
+			if (k < nv) Br[k] = x[k];
+	}
+	gsync<G>();
+}
+
 // A8  reference accelerations: efc_vel = J qvel, aref = -B vel - K imp (pos - margin)
 template <int G> STAGE void reference_constraint(CModel m, CLayout L, const Env &e)
 {

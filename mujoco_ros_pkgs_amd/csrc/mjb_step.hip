@@ -1651,7 +1651,10 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 		PROF(16);
 		VIEW(P, compact, make_constraint<G>(m, L, e));
 		PROF(17);
-		if constexpr (CON == 1) VIEW(P, compact, project_constraint<G>(m, L, e));
+		if constexpr (CON == 1) {
+			if (P->m.nv <= 16) VIEW(P, compact, project_constraint_dense16<G>(m, L, e));
+			else VIEW(P, compact, project_constraint<G>(m, L, e));
+		}
 		PROF(18);
 	}
 	VIEW(P, compact, transmission<G>(m, L, e));
@@ -1777,7 +1780,7 @@ template <int G> STAGE void ctrl_noise(CModel m, CLayout L, CNoise nz, const Env
 // Constrained kernels are capped at 256 VGPRs (2 blocks/CU): with the 512-register budget ROCm 7.2's LLVM
 // spills VGPRs to AGPRs ahead of an exec restore and loses lanes (tools/check_spill_exec.py, `make lint`).
 template <int G, int CON, int DENSE>
-__global__ void __launch_bounds__(256, (CON ? 2 : (G == 64 ? 4 : (G == 32 ? 2 : 1))))
+__global__ void __launch_bounds__(256, (CON ? 1 : (G == 64 ? 4 : (G == 32 ? 2 : 1))))
     mjb_step_kernel(const KernelParams MJB_AS4 *__restrict__ P, const int mode, const int nsteps,
                     const unsigned int step0, const int epb, const int frame_bytes)
 {
