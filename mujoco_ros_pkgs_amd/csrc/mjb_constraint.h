@@ -1352,6 +1352,39 @@ DEVI void ls_row(double a, bool scalar_row, bool bilateral, bool leader, double 
 	}
 }
 
+// columns J0 .. J0+15 of the right-looking Cholesky with one row of H per lane in registers (see fwd_constraint_newton)
+template <int J0> DEVI void chol_cols16(double (&Hr)[32], const int nv, const int lane, double &myrinv)
+{
+#pragma unroll
+	for (int j = J0; j < J0 + 16; j++) {
+		if (j >= nv) continue;  // (`break` here keeps LLVM from unrolling the nest: Hr would land in scratch)
+		MJB_KEEP_BRANCH();
+		double sj = wave_bcast(Hr[j], j);
+		if (sj < MJB_MINVAL) sj = MJB_MINVAL;
+		const double rinv = rsqrt(sj);
+		const double lkj = (lane == j) ? sj * rinv : Hr[j] * rinv;
+		Hr[j] = lkj;
+		if (lane == j) myrinv = rinv;
+		// groups of four columns: the four v_readlane pairs are issued together, then the four fma (constant loop
+		// bounds -- the nest only unrolls fully that way; entries c >= nv of a group belong to idle lanes: l_cj == 0)
+#pragma unroll
+		for (int c0 = 0; c0 < 32; c0 += 4) {
+			if (c0 + 3 <= j) continue;
+			if (c0 > j) {
+				if (c0 >= nv) continue;
+				MJB_KEEP_BRANCH();
+			}
+			double l4[4];
+#pragma unroll
+			for (int q = 0; q < 4; q++) l4[q] = wave_bcast(lkj, c0 + q);
+			asm volatile("" : "+s"(l4[0]), "+s"(l4[1]), "+s"(l4[2]), "+s"(l4[3]));
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+				if (c0 + q > j) Hr[c0 + q] -= lkj * l4[q];
+		}
+	}
+}
+
 typedef double mjb_d4 __attribute__((ext_vector_type(4)));
 
 // R = rows per lane: row r lives in lane r % 64, slot r / 64 (nefcmax <= 64 R).  R == 1 is BASELINE config 3,
@@ -1618,33 +1651,67 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 		}
 		gsync<G>();
 		EPROF(27);
-		// column Cholesky, lane = row of H (nv <= 64); lane j keeps 1 / L_jj so that the substitutions below
-		// multiply instead of divide and never read the diagonal back
+		// Cholesky, lane = row of H; lane j keeps 1 / L_jj so that the substitutions multiply instead of divide and never
+		// read the diagonal back.  nv <= 32: right-looking with the lane's ROW IN REGISTERS -- column j is scaled in
+		// place, then every lane subtracts l_kj * l_cj from its entries c > j with l_cj fetched from lane c by
+		// v_readlane: no LDS traffic and no serial inner product (the subtractions hit each entry in the same order
+		// as the left-looking column form below, so the factor is bit-identical).  The forward substitution reads the
+		// row from the same registers; the rows are parked in H for the backward one (which needs columns).
 		double myrinv = 1.0;
-		for (int j = 0; j < nv; j++) {
-			double s = 0;
-			if (dofact && k >= j) {
-				s = H[k * nv + j];
-#pragma unroll 4
-				for (int c = 0; c < j; c++) s -= H[k * nv + c] * H[j * nv + c];
+		double x = gr;
+		if (nv <= 32) {
+			MJB_KEEP_BRANCH();
+			double Hr[32];
+#pragma unroll
+			for (int c = 0; c < 32; c++) {
+				const double v = H[k * nv + (c < nv ? c : 0)];
+				Hr[c] = (dofact && c < nv) ? v : 0.0;
 			}
-			double sj = wave_bcast(s, j);
-			if (sj < MJB_MINVAL) sj = MJB_MINVAL;
-			const double rinv = rsqrt(sj);
-			if (dofact && k >= j) H[k * nv + j] = (k == j) ? sj * rinv : s * rinv;
-			if (k == j) myrinv = rinv;
+			// (two half-loops: one 32-column nest exceeds LLVM's pragma-unroll size cap and would leave Hr in scratch)
+			chol_cols16<0>(Hr, nv, lane, myrinv);
+			if (nv > 16) {
+				MJB_KEEP_BRANCH();
+				chol_cols16<16>(Hr, nv, lane, myrinv);
+			}
+			if (dofact) {
+#pragma unroll
+				for (int c = 0; c < 32; c++)
+					if (c < nv) H[k * nv + c] = Hr[c];
+			}
+			// search = -H^-1 grad : lane k holds element k
+#pragma unroll
+			for (int i = 0; i < 32; i++) {
+				if (i >= nv) continue;  // (not `break`: see chol_cols16)
+				MJB_KEEP_BRANCH();
+				const double xi = wave_bcast(x * myrinv, i);
+				if (lane == i) x = xi;
+				else x -= ((dofact && lane > i) ? Hr[i] : 0.0) * xi;
+			}
 			gsync<G>();
+		} else {
+			for (int j = 0; j < nv; j++) {
+				double s = 0;
+				if (dofact && k >= j) {
+					s = H[k * nv + j];
+#pragma unroll 4
+					for (int c = 0; c < j; c++) s -= H[k * nv + c] * H[j * nv + c];
+				}
+				double sj = wave_bcast(s, j);
+				if (sj < MJB_MINVAL) sj = MJB_MINVAL;
+				const double rinv = rsqrt(sj);
+				if (dofact && k >= j) H[k * nv + j] = (k == j) ? sj * rinv : s * rinv;
+				if (k == j) myrinv = rinv;
+				gsync<G>();
+			}
+#pragma unroll 4
+			for (int i = 0; i < nv; i++) {
+				const double xi = wave_bcast(x * myrinv, i);
+				const double lki = (dofact && k > i) ? H[k * nv + i] : 0.0;
+				if (k == i) x = xi;
+				else x -= lki * xi;
+			}
 		}
 		EPROF(31);
-		// search = -H^-1 grad : lane k holds element k
-		double x = gr;
-#pragma unroll 4
-		for (int i = 0; i < nv; i++) {
-			const double xi = wave_bcast(x * myrinv, i);
-			const double lki = (dofact && k > i) ? H[k * nv + i] : 0.0;
-			if (k == i) x = xi;
-			else x -= lki * xi;
-		}
 #pragma unroll 4
 		for (int i = nv - 1; i >= 0; i--) {
 			const double xi = wave_bcast(x * myrinv, i);
