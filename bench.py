@@ -30,6 +30,7 @@ WORKLOADS = {
     "shadow_hand_like": ("BASELINE configs[4]: Shadow-Hand-like 24-DoF hand + in-hand cube (Newton, elliptic cones)", 0.1, 1024),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable)
+FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 vector peak; replaced by the measured fma rate when the profile holds one
 
 
 def synthetic_state(model, nenv, seed):
@@ -189,13 +190,21 @@ def main():
     kern_ms = batch.time_steps(S, max(1, min(args.steps, 5)))
 
     if rank == 0:
-        traffic = None
-        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, 4096 envs x 1000 steps)
+        traffic, fp64 = None, None
+        try:  # HBM bytes and executed fp64 flops per launch from the committed rocprofv3 PMC passes (same kernel, same config)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
             if (E, S, args.model) == (4096, 1000, "franka_like"):
                 traffic = (pmc["FETCH_SIZE"]["mean_per_dispatch"] + pmc["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
+                if "fp64_executed_flops_per_dispatch" in pmc:
+                    flops = pmc["fp64_executed_flops_per_dispatch"]
+                    peak = pmc.get("fp64_peak_measured", {}).get("fp64_fma_tflops", FP64_PEAK_TFLOPS)
+                    ach = flops / (kern_ms * 1e-3) / 1e12
+                    fp64 = {"bound": "fp64-valu", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                            "executed_flops_per_launch": flops,
+                            "note": "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes (profiles/r01_pmc_summary.json); "
+                                    "peak = tools/ubench/fp64_peak on the same box"}
         except Exception:
-            traffic = None
+            traffic, fp64 = None, None
         value = world * E * S * args.steps / elapsed
         bytes_per_launch = ALGO_BYTES_PER_ENV_STEP.get(args.model, 712) * E * S
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
@@ -214,6 +223,8 @@ def main():
                          "kernel": "mjb_step_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
+        if fp64:
+            out["roofline"]["fp64"] = fp64  # second view: with K fused steps the kernel is VALU / latency bound
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, model, noise_std)
         print(json.dumps(out))

@@ -1777,8 +1777,10 @@ template <int G> STAGE void ctrl_noise(CModel m, CLayout L, CNoise nz, const Env
 // ------------------------------------------------------------------------------------------------
 // CON: 0 = model without constraint rows; 1 = PGS, 2 / 3 / 4 = Newton with 1 / 2 / 4 rows per lane (collision / rows / solver stages compiled in;
 // one env per wavefront) -- separate kernels keep each instruction stream and register budget small.
-// Constrained kernels are capped at 256 VGPRs (2 blocks/CU): with the 512-register budget ROCm 7.2's LLVM
-// spills VGPRs to AGPRs ahead of an exec restore and loses lanes (tools/check_spill_exec.py, `make lint`).
+// Constrained kernels get the full 512-register budget (1 block of 256 per CU by registers; their frames limit the
+// CU to 1 - 4 envs anyway): no spills, and room for the register-resident AR rows / Hessian rows of the solvers.
+// ROCm 7.2's LLVM can place a spill ahead of an exec restore and lose lanes (tools/check_spill_exec.py, `make lint`
+// guards every build): an earlier revision had to cap these kernels at 256 VGPRs because of it.
 template <int G, int CON, int DENSE>
 __global__ void __launch_bounds__(256, (CON ? 1 : (G == 64 ? 4 : (G == 32 ? 2 : 1))))
     mjb_step_kernel(const KernelParams MJB_AS4 *__restrict__ P, const int mode, const int nsteps,

@@ -35,7 +35,7 @@ if ks:
     shutil.copy(ks, os.path.join(dst, name + "_kernel_stats.csv"))
 summary = {}
 meta = None
-for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_f64"):
     cc = first(d + "/**/*counter_collection.csv")
     if not cc:
         continue
@@ -50,6 +50,18 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     for k, v in acc.items():
         summary[k] = {"dispatches": len(v), "mean_per_dispatch": sum(v) / len(v)}
 if summary:
+    pk = os.path.join(src, "fp64_peak.json")
+    if os.path.exists(pk):
+        try:
+            summary["fp64_peak_measured"] = json.loads(open(pk).read().splitlines()[-1])
+        except Exception:
+            pass
+    f64 = {k: summary[k]["mean_per_dispatch"] for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64",
+                                                       "SQ_INSTS_VALU_TRANS_F64") if k in summary}
+    if len(f64) == 4:
+        # wave-level instruction counts; one instruction = 64 lanes (idle lanes of a partially filled stage included)
+        summary["fp64_executed_flops_per_dispatch"] = 64.0 * (f64["SQ_INSTS_VALU_ADD_F64"] + f64["SQ_INSTS_VALU_MUL_F64"] +
+                                                              2.0 * f64["SQ_INSTS_VALU_FMA_F64"] + f64["SQ_INSTS_VALU_TRANS_F64"])
     summary["dispatch_meta"] = meta
     bl = os.path.join(dst, name + "_bench_line_under_rocprof.json")
     if os.path.exists(bl):
