@@ -679,8 +679,10 @@ DEVI void factor_dense16_impl(CModel m, const Env &e, const double *M, double *L
 			MJB_KEEP_BRANCH();
 			// the pivot row crosses lanes through LDS: every lane publishes its entry, then all read the row at uniform
 			// addresses (one broadcast read per double; ds_bpermute costs two slower operations per double)
-			scr[lane] = A[k];
-			if (DUAL) scr[16 + lane] = B[k];
+			if (G == 16 || lane < 16) {  // (G == 64: the first 16 lanes of the wavefront carry the matrix)
+				scr[lane] = A[k];
+				if (DUAL) scr[16 + lane] = B[k];
+			}
 			gsync<G>();
 			const double dk = scr[k], dk2 = DUAL ? scr[16 + k] : 1.0;
 			double mk[NVM], mk2[NVM];
@@ -727,7 +729,7 @@ template <int G, int NVM>
 STAGE void factor_dense16(CModel m, const Env &e, const double *M, double *LD, double *di, const double *M2, double *LD2,
                           double *di2, bool dual, const int (&dadr)[16], double *scr)
 {
-	static_assert(G == 16, "one matrix column per lane of a 16-lane env group");
+	static_assert(G == 16 || G == 64, "one matrix column per lane of a 16-lane env group (G == 64: lanes 0-15 of the wavefront)");
 	if (dual) {
 		MJB_KEEP_BRANCH();
 		factor_dense16_impl<G, true, NVM>(m, e, M, LD, di, M2, LD2, di2, dadr, scr);
@@ -760,8 +762,10 @@ DEVI void solve_dense16_impl(CModel m, const Env &e, double *x, const double *LD
 		if (i < nv) {
 			MJB_KEEP_BRANCH();
 			// x_i crosses lanes through the LDS scratch (publish, then a wave-uniform broadcast read)
-			scr[lane] = xj;
-			if (DUAL) scr[16 + lane] = xj2;
+			if (G == 16 || lane < 16) {
+				scr[lane] = xj;
+				if (DUAL) scr[16 + lane] = xj2;
+			}
 			gsync<G>();
 			const double xi = scr[i], xi2 = DUAL ? scr[16 + i] : 0.0;
 			gsync<G>();
@@ -795,7 +799,7 @@ template <int G, int NVM>
 STAGE void solve_dense16(CModel m, const Env &e, double *x, const double *LD, const double *diaginv, double *x2,
                          const double *LD2, const double *diaginv2, bool dual, const int (&dadr)[16], double *scr)
 {
-	static_assert(G == 16, "one matrix column per lane of a 16-lane env group");
+	static_assert(G == 16 || G == 64, "one matrix column per lane of a 16-lane env group (G == 64: lanes 0-15 of the wavefront)");
 	if (dual) {
 		MJB_KEEP_BRANCH();
 		solve_dense16_impl<G, true, NVM>(m, e, x, LD, diaginv, x2, LD2, diaginv2, dadr, scr);
@@ -1454,10 +1458,16 @@ template <int G, int DENSE> STAGE void fwd_acceleration(CModel m, CLayout L, con
 	}
 	gsync<G>();
 	const bool dual = m.eulerdamp && m.nefcmax == 0;
-	if constexpr (DENSE)
+	if constexpr (DENSE > 0)
 		solve_dense16<G, DENSE>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual, e.dadr,
 		                        f + L.crbbuf);
-	else
+	else if constexpr (DENSE < 0) {  // constrained kernel: a small system is solved by lanes 0-15 of the wavefront
+		if (m.nv <= 16)
+			solve_dense16<G, 16>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual, e.dadr,
+			                     f + L.crbbuf);
+		else
+			solve2<G>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual);
+	} else
 		solve2<G>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual);
 }
 
@@ -1484,7 +1494,7 @@ template <int G> STAGE void fwd_constraint(CModel m, CLayout L, const Env &e)
 // ------------------------------------------------------------------------------------------------
 // A16 semi-implicit Euler with implicit joint damping
 // ------------------------------------------------------------------------------------------------
-template <int G> STAGE void euler(CModel m, CLayout L, const Env &e)
+template <int G, bool CAN16> STAGE void euler(CModel m, CLayout L, const Env &e)
 {
 	double *f = e.f;
 	const double dt = m.timestep[0];
@@ -1495,7 +1505,11 @@ template <int G> STAGE void euler(CModel m, CLayout L, const Env &e)
 		// (M + h B) x = qfrc_smooth + qfrc_constraint, factor qH prepared next to qLD in fwd_position
 		for (int d = e.lane; d < m.nv; d += G) x[d] = f[L.qfrc_smooth + d] + f[L.qfrc_constraint + d];
 		gsync<G>();
-		solve<G>(m, e, x, f + L.qH, f + L.qHdi);
+		if constexpr (CAN16) {
+			if (m.nv <= 16) solve_dense16<G, 16>(m, e, x, f + L.qH, f + L.qHdi, x, f + L.qH, f + L.qHdi, false, e.dadr, f + L.crbbuf);
+			else solve<G>(m, e, x, f + L.qH, f + L.qHdi);
+		} else
+			solve<G>(m, e, x, f + L.qH, f + L.qHdi);
 	} else {
 		for (int d = e.lane; d < m.nv; d += G) x[d] = f[L.qacc + d];
 		gsync<G>();
@@ -1642,7 +1656,14 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 	if constexpr (DENSE)
 		VIEW(P, compact, factor_dense16<G, DENSE>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH,
 		                                   e.f + L.qHdi, m.eulerdamp != 0, e.dadr, e.f + L.crbbuf));
-	else
+	else if constexpr (CON != 0) {
+		if (P->m.nv <= 16)
+			VIEW(P, compact, factor_dense16<G, 16>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH,
+			                                       e.f + L.qHdi, m.eulerdamp != 0, e.dadr, e.f + L.crbbuf));
+		else
+			VIEW(P, compact, factor2<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi,
+			                            m.eulerdamp != 0));
+	} else
 		VIEW(P, compact, factor2<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi,
 		                            m.eulerdamp != 0));
 	PROF(3);
@@ -1678,7 +1699,7 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 	PROF_BEGIN();
 	VIEW(P, compact, fwd_actuation<G>(m, L, e));
 	PROF(9);
-	VIEW(P, compact, fwd_acceleration<G, DENSE>(m, L, e, s.use_xfrc != 0));
+	VIEW(P, compact, fwd_acceleration<G, (CON != 0 ? -1 : DENSE)>(m, L, e, s.use_xfrc != 0));
 	PROF(10);
 	if constexpr (CON >= 2 && G == 64) {
 		VIEW(P, compact, fwd_constraint_newton<G, (CON == 2 ? 1 : (CON == 3 ? 2 : 4))>(m, L, e));
@@ -1806,6 +1827,10 @@ __global__ void __launch_bounds__(256, (CON ? 1 : (G == 64 ? 4 : (G == 32 ? 2 : 
 	if constexpr (DENSE) {
 #pragma unroll
 		for (int i = 0; i < 16; i++) e.dadr[i] = m.M_dense[16 * i + e.lane];
+	} else if constexpr (CON != 0) {
+		// constrained kernels (one env per wavefront): nv <= 16 runs the same register-resident factor / solve on lanes 0-15
+#pragma unroll
+		for (int i = 0; i < 16; i++) e.dadr[i] = (m.nv <= 16 && e.lane < 16) ? m.M_dense[16 * i + (e.lane & 15)] : -1;
 	}
 	if constexpr (DENSE != 0) {
 		const int b = e.lane < m.nbody ? e.lane : 0;
@@ -1891,7 +1916,7 @@ __global__ void __launch_bounds__(256, (CON ? 1 : (G == 64 ? 4 : (G == 32 ? 2 : 
 				reset_frame_state<G>(m, L, s, e);
 			}
 			PROF(14);  // whole forward (incl. checks)
-			if (do_euler) VIEW(P, compact, euler<G>(m, L, e));
+			if (do_euler) VIEW(P, compact, euler<G, (CON != 0)>(m, L, e));
 			PROF(15);
 		}
 
