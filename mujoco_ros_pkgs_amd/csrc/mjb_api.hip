@@ -80,7 +80,7 @@ struct mjb_model {
 	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense, body_anc, dof_bodymask;
 	std::vector<int> sens_copy, sens_slow, dof_act_adr, dof_act_id;
 	int sens_ncopy[3] = { 0, 0, 0 }, sens_nslow[3] = { 0, 0, 0 }, sens_ncopy_max = 0;
-	int eulerdamp = 0, maxdepth = 0, kin_rounds = 0, need_rnepost = 0;
+	int eulerdamp = 0, maxdepth = 0, kin_rounds = 0, need_rnepost = 0, nfriction = 0;
 	int field_size[MJB_F_COUNT]{};
 	FrameLayout L{}, Lc{};
 };
@@ -240,7 +240,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	L.ndouble = off;
 	L.iscratch = ioff;
 	{
-		int a = d.ncollpair, b = d.neq + d.njnt + d.ntendon + d.nconmax;
+		int a = d.ncollpair, b = d.neq + d.nv + d.njnt + d.ntendon + d.nconmax;
 		ioff += a > b ? a : b;
 	}
 	L.nint = (ioff + 1) & ~1;
@@ -580,6 +580,10 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 	if (!(h.disableflags & MJB_DSBL_EULERDAMP))
 		for (int i = 0; i < h.nv; i++)
 			if (h.dof_damping[i] > 0) M->eulerdamp = 1;
+	M->nfriction = 0;
+	if (!(h.disableflags & MJB_DSBL_FRICTIONLOSS))
+		for (int i = 0; i < h.nv; i++)
+			if (h.dof_frictionloss[i] > 0) M->nfriction++;
 	compute_layout(M, M->L, false);
 	compute_layout(M, M->Lc, true);
 	build_sensor_tables(M);
@@ -760,6 +764,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	}
 	dm.sens_ncopy_max = M->sens_ncopy_max ? M->sens_ncopy_max : 1;
 	dm.eulerdamp = M->eulerdamp;
+	dm.nfriction = M->nfriction;
 	dm.maxdepth = M->maxdepth;
 
 	// ---- state arrays

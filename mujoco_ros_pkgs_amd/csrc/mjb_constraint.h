@@ -745,29 +745,32 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 	const bool do_lim = !(m.disableflags & MJB_DSBL_LIMIT), do_con = !(m.disableflags & MJB_DSBL_CONTACT);
 	const int neq = (m.disableflags & MJB_DSBL_EQUALITY) ? 0 : m.neq;
 	const int nten = do_lim ? m.ntendon : 0;
-	const int nitem = neq + m.njnt + nten + ncon;  // item = equality, joint limit, tendon limit or contact -- MuJoCo's row order
+	const int nfr = m.nfriction > 0 ? nv : 0;  // (models without dry friction keep the shorter item list)
+	const int nitem = neq + nfr + m.njnt + nten + ncon;  // item = equality, dof friction, joint limit, tendon limit or contact -- MuJoCo's row order
 	int *cnt = fi + L.iscratch;              // transient per-item row counts
 	// pass 1: rows per item
 	for (int it = lane; it < nitem; it += G) {
 		int n = 0;
 		if (it < neq) {
 			if (m.eq_active[it]) n = m.eq_type[it] == MJB_EQ_CONNECT ? 3 : (m.eq_type[it] == MJB_EQ_WELD ? 6 : 1);  // joint, tendon: 1
-		} else if (it < neq + m.njnt) {
-			const int j = it - neq;
+		} else if (it < neq + nfr) {
+			n = m.dof_frictionloss[it - neq] > 0 ? 1 : 0;
+		} else if (it < neq + nfr + m.njnt) {
+			const int j = it - neq - nfr;
 			if (do_lim && m.jnt_limited[j] && m.jnt_type[j] >= MJB_JNT_SLIDE) {
 				const double value = f[L.qpos + m.jnt_qposadr[j]], margin = m.jnt_margin[j];
 				if (value - m.jnt_range[2 * j] < margin) n++;
 				if (m.jnt_range[2 * j + 1] - value < margin) n++;
 			}
-		} else if (it < neq + m.njnt + nten) {
-			const int t = it - neq - m.njnt;
+		} else if (it < neq + nfr + m.njnt + nten) {
+			const int t = it - neq - nfr - m.njnt;
 			if (m.tendon_limited[t]) {
 				const double value = f[L.ten_length + t], margin = m.tendon_margin[t];
 				if (value - m.tendon_range[2 * t] < margin) n++;
 				if (m.tendon_range[2 * t + 1] - value < margin) n++;
 			}
 		} else if (do_con) {
-			const int c = it - neq - m.njnt - nten;
+			const int c = it - neq - nfr - m.njnt - nten;
 			if (f[L.contact_dist + c] < f[L.contact_includemargin + c]) {
 				const int dim = fi[L.contact_dim + c];
 				n = dim == 1 ? 1 : (m.cone == MJB_CONE_ELLIPTIC ? dim : 2 * (dim - 1));
@@ -775,6 +778,8 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 		}
 		cnt[it] = n;
 	}
+	if (nfr)
+		for (int r = lane; r < m.nefcmax; r += G) f[L.efc_frictionloss + r] = 0;
 	gsync<G>();
 	// row budget: the first item that does not fit, and everything after it, is dropped
 	int nefc = 0, cut = nitem;
@@ -861,8 +866,21 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 				fi[L.efc_id + off + k] = eq;
 				fi[L.efc_type + off + k] = MJB_CNSTR_EQUALITY;
 			}
-		} else if (it < neq + m.njnt) {
-			const int j = it - neq, da = m.jnt_dofadr[j];
+		} else if (it < neq + nfr) {
+			// dry joint friction (mj_instantiateFriction): J = e_dof, pos = margin = 0, |force| <= frictionloss
+			const int i = it - neq;
+			double *row = f + L.efc_J + off * nv;
+			for (int k = 0; k < nv; k++) row[k] = 0;
+			row[i] = 1;
+			const double solref[2] = { m.dof_solref[2 * i], m.dof_solref[2 * i + 1] };
+			double solimp[5];
+			for (int k = 0; k < 5; k++) solimp[k] = m.dof_solimp[5 * i + k];
+			row_params(m, L, f, off, 0.0, 0.0, solref, solimp, m.dof_invweight0[i]);
+			f[L.efc_frictionloss + off] = m.dof_frictionloss[i];
+			fi[L.efc_id + off] = i;
+			fi[L.efc_type + off] = MJB_CNSTR_FRICTION_DOF;
+		} else if (it < neq + nfr + m.njnt) {
+			const int j = it - neq - nfr, da = m.jnt_dofadr[j];
 			const double value = f[L.qpos + m.jnt_qposadr[j]], margin = m.jnt_margin[j];
 			double solref[2] = { m.jnt_solref[2 * j], m.jnt_solref[2 * j + 1] }, solimp[5];
 			for (int k = 0; k < 5; k++) solimp[k] = m.jnt_solimp[5 * j + k];
@@ -879,8 +897,8 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 					r++;
 				}
 			}
-		} else if (it < neq + m.njnt + nten) {
-			const int t = it - neq - m.njnt;
+		} else if (it < neq + nfr + m.njnt + nten) {
+			const int t = it - neq - nfr - m.njnt;
 			const double value = f[L.ten_length + t], margin = m.tendon_margin[t];
 			double solref[2] = { m.tendon_solref_lim[2 * t], m.tendon_solref_lim[2 * t + 1] }, solimp[5];
 			for (int k = 0; k < 5; k++) solimp[k] = m.tendon_solimp_lim[5 * t + k];
@@ -899,7 +917,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 				}
 			}
 		} else {
-			const int c = it - neq - m.njnt - nten;
+			const int c = it - neq - nfr - m.njnt - nten;
 			const int dim = fi[L.contact_dim + c];
 			const double dist = f[L.contact_dist + c], cm = f[L.contact_includemargin + c];
 			const int b1 = m.geom_bodyid[fi[L.contact_geom + 2 * c]], b2 = m.geom_bodyid[fi[L.contact_geom + 2 * c + 1]];
@@ -1162,10 +1180,12 @@ DEVI double wave_bcast(double v, int srclane)  // srclane must be wave-uniform
 // lanes can work from the force they had at the start of the sweep); lane i's delta is broadcast with v_readlane,
 // filed into lane i of `dvec` with v_writelane, and every lane does res += AR[.][i] * delta.  Dependent chain per row:
 // fma, max, add, readlane, fma.
-// The reference's guard "undo the update if it RAISES the cost by more than 1e-10" is dead code here: with
+// The reference's guard "undo the update if it RAISES the cost by more than 1e-10" is dead code here (a 1-D minimiser
+// clipped to an interval never raises a convex cost; in numbers:) with
 // Aii = J M^-1 J' + R > 0 the unclipped step changes the cost by -0.5 res^2 / Aii and the clipped one by
 // -f (res - 0.5 f Aii) with res >= f Aii, both <= 0 beyond any rounding, so it is not evaluated.
-DEVI void pgs_sweep(const double (&AR)[64], const int nefc, const double lo, const double ARinv, double &res,
+template <bool BOX>  // BOX: some row has an upper force limit too (dry friction: |f| <= frictionloss)
+DEVI void pgs_sweep(const double (&AR)[64], const int nefc, const double lo, const double hi, const double ARinv, double &res,
                     const double frc, double &dvec)
 {
 #pragma unroll
@@ -1174,7 +1194,9 @@ DEVI void pgs_sweep(const double (&AR)[64], const int nefc, const double lo, con
 			if (i >= nefc) break;  // rows beyond nefc in a group of four propose delta == 0
 			MJB_KEEP_BRANCH();
 		}
-		const double delta = __builtin_fmax(frc - res * ARinv, lo) - frc;
+		double fn = __builtin_fmax(frc - res * ARinv, lo);
+		if (BOX) fn = __builtin_fmin(fn, hi);
+		const double delta = fn - frc;
 		const int dh = __builtin_amdgcn_readlane(__double2hiint(delta), i), dl = __builtin_amdgcn_readlane(__double2loint(delta), i);
 		res += AR[i] * __hiloint2double(dh, dl);
 		int vh = __double2hiint(dvec), vl = __double2loint(dvec);  // (clang has no writelane builtin)
@@ -1213,6 +1235,8 @@ template <int G> STAGE void fwd_constraint_pgs(CModel m, CLayout L, const Env &e
 	const int r = rowact ? lane : 0;
 	const double *Jr = f + L.efc_J + r * nv, *Br = f + L.efc_B + r * nv;
 	const bool bilateral = rowact && fi[L.efc_type + r] == MJB_CNSTR_EQUALITY;
+	const bool friction = rowact && m.nfriction > 0 && fi[L.efc_type + r] == MJB_CNSTR_FRICTION_DOF;
+	const double floss = friction ? f[L.efc_frictionloss + r] : 0.0;
 	double b = 0, Aii = 1, ARinv = 0, frc = 0;
 	{
 		double jq = 0, jb = 0, jw = 0;
@@ -1230,7 +1254,8 @@ template <int G> STAGE void fwd_constraint_pgs(CModel m, CLayout L, const Env &e
 			f[L.efc_b + r] = b;
 			if (!(m.disableflags & MJB_DSBL_WARMSTART)) {
 				const double jar = jw - aref;
-				frc = (jar < 0 || bilateral) ? -f[L.efc_D + r] * jar : 0.0;
+				frc = (jar < 0 || bilateral || friction) ? -f[L.efc_D + r] * jar : 0.0;
+				if (friction) frc = __builtin_fmin(__builtin_fmax(frc, -floss), floss);
 			}
 		}
 	}
@@ -1270,12 +1295,20 @@ template <int G> STAGE void fwd_constraint_pgs(CModel m, CLayout L, const Env &e
 	// exactly this) is cost(before) - cost(after) with cost = 0.5 f'ARf + f'b = sum_i 0.5 f_i (res_i + b_i)
 	const double scale = 1.0 / (m.meaninertia[0] * (nv > 1 ? nv : 1));
 	const double tol = m.tolerance[0];
-	const double lo = bilateral ? -__builtin_huge_val() : 0.0;  // equality rows are two-sided
+	// equality rows are two-sided, dry-friction rows live in [-frictionloss, frictionloss], the rest in [0, inf)
+	const double lo = bilateral ? -__builtin_huge_val() : (friction ? -floss : 0.0);
+	const double hi = friction ? floss : __builtin_huge_val();
 	double cost = wave_sum(0.5 * frc * (res + b));
 	int iter = 0;
 	while (iter < m.iterations) {
 		double dvec = 0;
-		pgs_sweep(AR, nefc, lo, ARinv, res, frc, dvec);
+		if (m.nfriction > 0) {
+			MJB_KEEP_BRANCH();
+			pgs_sweep<true>(AR, nefc, lo, hi, ARinv, res, frc, dvec);
+		} else {
+			MJB_KEEP_BRANCH();
+			pgs_sweep<false>(AR, nefc, lo, hi, ARinv, res, frc, dvec);
+		}
 		frc += dvec;
 		const double cost1 = wave_sum(0.5 * frc * (res + b));
 		const double improvement = (cost - cost1) * scale;
@@ -1322,12 +1355,25 @@ struct ConeLine {  // per-contact constants of the line search, held by the cont
 };
 
 // one lane's share of the line-search cost and its first two derivatives at step `a`
-DEVI void ls_row(double a, bool scalar_row, bool bilateral, bool leader, double jaref, double jv, double D,
+DEVI void ls_row(double a, bool scalar_row, bool bilateral, bool leader, double jaref, double jv, double D, double fl,
                  const ConeLine &cl, double &c0, double &c1, double &c2)
 {
 	if (scalar_row) {
 		const double x = jaref + a * jv;
-		if (x < 0 || bilateral) {
+		if (fl > 0) {  // dry friction (Huber): quadratic for |x| < R fl, linear with slope -+fl outside
+			const double rf = fl / D;
+			if (x <= -rf) {
+				c0 += fl * (-0.5 * rf - x);
+				c1 -= fl * jv;
+			} else if (x >= rf) {
+				c0 += fl * (-0.5 * rf + x);
+				c1 += fl * jv;
+			} else {
+				c0 += 0.5 * D * x * x;
+				c1 += D * x * jv;
+				c2 += D * jv * jv;
+			}
+		} else if (x < 0 || bilateral) {
 			c0 += 0.5 * D * x * x;
 			c1 += D * x * jv;
 			c2 += D * jv * jv;
@@ -1429,7 +1475,7 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 	// row kind: scalar (limit / frictionless / pyramidal), cone leader (first row of an elliptic contact), cone member
 	bool rowact[R], scalar_row[R], leader[R], bilat[R];
 	int rr[R], cdim[R], rcon[R];
-	double D[R], aref[R], cmu[R];
+	double D[R], aref[R], cmu[R], fl[R];  // fl: force limit of a dry-friction row, 0 for every other row
 #pragma unroll
 	for (int i = 0; i < R; i++) {
 		const int r = lane + 64 * i;
@@ -1443,6 +1489,7 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 		leader[i] = is_cone && fi[L.contact_efc_address + rcon[i]] == r;
 		cdim[i] = is_cone ? fi[L.contact_dim + rcon[i]] : 0;
 		D[i] = rowact[i] ? f[L.efc_D + r] : 0.0;
+		fl[i] = (rowact[i] && m.nfriction > 0 && rtype == MJB_CNSTR_FRICTION_DOF) ? f[L.efc_frictionloss + r] : 0.0;
 		aref[i] = rowact[i] ? f[L.efc_aref + r] : 0.0;
 		cmu[i] = leader[i] ? f[L.contact_friction + 5 * rcon[i]] / sqrt(fmax(MJB_MINVAL, m.impratio[0])) : 1.0;
 	}
@@ -1470,7 +1517,13 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 		for (int i = 0; i < R; i++) {
 			const int r = rr[i];
 			if (64 * i >= nefc) continue;
-			if (scalar_row[i]) {
+			if (scalar_row[i] && fl[i] > 0) {
+				const double x = jar_s[r], rf = fl[i] / D[i];
+				const bool quad = x > -rf && x < rf;
+				f[L.efc_force + r] = quad ? -D[i] * x : (x < 0 ? fl[i] : -fl[i]);
+				if (hess) hw[r] = quad ? D[i] : 0.0;
+				cost += quad ? 0.5 * D[i] * x * x : fl[i] * (-0.5 * rf + fabs(x));
+			} else if (scalar_row[i]) {
 				const double x = jar_s[r];
 				const bool act = x < 0 || bilat[i];
 				f[L.efc_force + r] = act ? -D[i] * x : 0.0;
@@ -1783,14 +1836,14 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 			for (int i = 0; i < R; i++) {
 				if (64 * i >= nefc) continue;
 				if constexpr (R == 1) {
-					ls_row(a, scalar_row[i], bilat[i], leader[i], jaref[i], jv[i], D[i], cl1, c0, c1, c2);
+					ls_row(a, scalar_row[i], bilat[i], leader[i], jaref[i], jv[i], D[i], fl[i], cl1, c0, c1, c2);
 				} else {
 					ConeLine c = cl1;
 					if (leader[i]) {
 						const double *o = Hc + 36 * rcon[i];
 						c = ConeLine{ o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9] };
 					}
-					ls_row(a, scalar_row[i], bilat[i], leader[i], jaref[i], jv[i], D[i], c, c0, c1, c2);
+					ls_row(a, scalar_row[i], bilat[i], leader[i], jaref[i], jv[i], D[i], fl[i], c, c0, c1, c2);
 				}
 			}
 			const double s0 = wave_sum(c0), s1 = wave_sum(c1), s2 = wave_sum(c2);

@@ -429,8 +429,11 @@ class _Compiler:
                  springref=float(a.get("springref", 0)) * (scale if typ == JNT_HINGE else 1.0),
                  solref=_floats(a.get("solreflimit", "0.02 1"), 2, "solreflimit"),
                  solimp=_solimp(a.get("solimplimit")))
-        if float(a.get("frictionloss", 0)) != 0:
-            raise MjcfError("joint frictionloss is not supported")
+        j.update(frictionloss=float(a.get("frictionloss", 0)),
+                 solref_fri=_floats(a.get("solreffriction", "0.02 1"), 2, "solreffriction"),
+                 solimp_fri=_solimp(a.get("solimpfriction")))
+        if j["frictionloss"] < 0:
+            raise MjcfError("joint frictionloss must be >= 0")
         self.joints.append(j)
         return j
 
@@ -648,6 +651,9 @@ class _Compiler:
         dof_parentid = -np.ones(nv, I)
         dof_armature = np.zeros(nv, D)
         dof_damping = np.zeros(nv, D)
+        dof_frictionloss = np.zeros(nv, D)
+        dof_solref = np.zeros((nv, 2), D)
+        dof_solimp = np.zeros((nv, 5), D)
         qpos0 = np.zeros(nq, D)
         qpos_spring = np.zeros(nq, D)
         body_id = {id(b): i for i, b in enumerate(B)}
@@ -685,6 +691,9 @@ class _Compiler:
                     last_dof_of_body[bi] = da
                     dof_armature[da] = j["armature"]
                     dof_damping[da] = j["damping"]
+                    dof_frictionloss[da] = j["frictionloss"]
+                    dof_solref[da] = j["solref_fri"]
+                    dof_solimp[da] = j["solimp_fri"]
                     da += 1
                 qa += qn[t]
                 ji += 1
@@ -702,7 +711,8 @@ class _Compiler:
         m.update(body_jntnum=body_jntnum, body_jntadr=body_jntadr, body_dofnum=body_dofnum, body_dofadr=body_dofadr,
                  jnt_type=jnt_type, jnt_qposadr=jnt_qposadr, jnt_dofadr=jnt_dofadr, jnt_bodyid=jnt_bodyid,
                  dof_bodyid=dof_bodyid, dof_jntid=dof_jntid, dof_parentid=dof_parentid, dof_Madr=dof_Madr,
-                 dof_armature=dof_armature, dof_damping=dof_damping, qpos0=qpos0, qpos_spring=qpos_spring)
+                 dof_armature=dof_armature, dof_damping=dof_damping, dof_frictionloss=dof_frictionloss, dof_solref=dof_solref,
+                 dof_solimp=dof_solimp, qpos0=qpos0, qpos_spring=qpos_spring)
         m["jnt_pos"] = np.array([j["pos"] for j in J], D).reshape(njnt, 3)
         m["jnt_axis"] = np.array([j["axis"] for j in J], D).reshape(njnt, 3)
         m["jnt_limited"] = np.array([j["limited"] for j in J], I)
@@ -879,7 +889,8 @@ class _Compiler:
         neqrow = 0
         if not (o["disableflags"] & DISABLE_BITS["equality"]):
             neqrow = int(sum({0: 3, 1: 6, 2: 1, 3: 1}[int(t)] for t in m["eq_type"]))
-        nefcmax = neqrow + nlimit + rows_per_con * nconmax if self.nefcmax_req is None else int(self.nefcmax_req)
+        nfric = 0 if (o["disableflags"] & DISABLE_BITS["frictionloss"]) else int(np.count_nonzero(m["dof_frictionloss"] > 0))
+        nefcmax = neqrow + nfric + nlimit + rows_per_con * nconmax if self.nefcmax_req is None else int(self.nefcmax_req)
         if o["disableflags"] & (DISABLE_BITS["constraint"]):
             nconmax, nefcmax = 0, 0
         m["nconmax"], m["nefcmax"] = int(nconmax), int(nefcmax)

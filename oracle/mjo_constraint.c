@@ -800,6 +800,24 @@ void mjo_make_constraint(const mjb_model_desc *m, mjo_data *d)
 	d->nefc[0] = 0;
 	if (m->nefcmax <= 0 || (m->disableflags & MJB_DSBL_CONSTRAINT)) return;
 	if (!(m->disableflags & MJB_DSBL_EQUALITY)) nefc = make_equality(m, d, nefc);
+	for (int i = 0; i < m->nefcmax; i++) d->efc_frictionloss[i] = 0;
+	/* dry joint friction (mj_instantiateFriction, dof part): one row per dof with frictionloss > 0, J = e_dof,
+	 * pos = margin = 0; the row's force is limited to +-frictionloss by the solvers */
+	if (!(m->disableflags & MJB_DSBL_FRICTIONLOSS)) {
+		for (int i = 0; i < nv; i++) {
+			if (m->dof_frictionloss[i] <= 0 || nefc >= m->nefcmax) continue;
+			double *row = d->efc_J + (size_t)nefc * nv;
+			memset(row, 0, sizeof(double) * (size_t)nv);
+			row[i] = 1;
+			d->efc_pos[nefc] = 0;
+			d->efc_margin[nefc] = 0;
+			d->efc_frictionloss[nefc] = m->dof_frictionloss[i];
+			d->efc_type[nefc] = MJB_CNSTR_FRICTION_DOF;
+			d->efc_id[nefc] = i;
+			row_params(m, d, nefc, m->dof_solref + 2 * i, m->dof_solimp + 5 * i, m->dof_invweight0[i]);
+			nefc++;
+		}
+	}
 	/* joint limits (mj_instantiateLimit), hinge / slide */
 	if (!(m->disableflags & MJB_DSBL_LIMIT)) {
 		for (int j = 0; j < m->njnt; j++) {
@@ -993,6 +1011,12 @@ void mjo_fwd_constraint(const mjb_model_desc *m, mjo_data *d)
 			const double *row = d->efc_J + (size_t)i * nv;
 			for (int k = 0; k < nv; k++) jar += row[k] * d->qacc_warmstart[k];
 			f[i] = (jar < 0 || d->efc_type[i] == MJB_CNSTR_EQUALITY) ? -d->efc_D[i] * jar : 0.0; /* limit / contact rows are one-sided */
+			if (d->efc_type[i] == MJB_CNSTR_FRICTION_DOF) { /* two-sided, saturating at +-frictionloss (mj_constraintUpdate) */
+				const double fl = d->efc_frictionloss[i];
+				f[i] = -d->efc_D[i] * jar;
+				if (f[i] > fl) f[i] = fl;
+				if (f[i] < -fl) f[i] = -fl;
+			}
 		}
 		double cost = 0;
 		for (int i = 0; i < nefc; i++) {
@@ -1016,7 +1040,11 @@ void mjo_fwd_constraint(const mjb_model_desc *m, mjo_data *d)
 			double old = f[i];
 			double Aii = d->efc_AR[(size_t)i * ld + i];
 			f[i] -= res * ARinv[i];
-			if (f[i] < 0 && d->efc_type[i] != MJB_CNSTR_EQUALITY) f[i] = 0;
+			if (d->efc_type[i] == MJB_CNSTR_FRICTION_DOF) { /* box: |f| <= frictionloss */
+				const double fl = d->efc_frictionloss[i];
+				if (f[i] < -fl) f[i] = -fl;
+				if (f[i] > fl) f[i] = fl;
+			} else if (f[i] < 0 && d->efc_type[i] != MJB_CNSTR_EQUALITY) f[i] = 0;
 			double delta = f[i] - old;
 			double change = 0.5 * delta * delta * Aii + delta * res;
 			if (change > 1e-10) {
@@ -1107,6 +1135,21 @@ static void ls_eval(const lsctx *c, lspoint *p)
 	for (int i = 0; i < c->nefc; i++) {
 		if (c->type[i] != MJB_CNSTR_CONTACT_ELLIPTIC) {
 			double x = c->jaref[i] + a * c->jv[i];
+			if (c->type[i] == MJB_CNSTR_FRICTION_DOF) { /* Huber: quadratic inside |x| < R f, linear outside */
+				const double fl = c->d->efc_frictionloss[i], rf = fl / c->D[i];
+				if (x <= -rf) {
+					cost += fl * (-0.5 * rf - x);
+					d1 += -fl * c->jv[i];
+				} else if (x >= rf) {
+					cost += fl * (-0.5 * rf + x);
+					d1 += fl * c->jv[i];
+				} else {
+					cost += 0.5 * c->D[i] * x * x;
+					d1 += c->D[i] * x * c->jv[i];
+					d2 += c->D[i] * c->jv[i] * c->jv[i];
+				}
+				continue;
+			}
 			if (x < 0 || c->type[i] == MJB_CNSTR_EQUALITY) {
 				cost += 0.5 * c->D[i] * x * x;
 				d1 += c->D[i] * x * c->jv[i];
@@ -1258,6 +1301,23 @@ static double constraint_update(const mjb_model_desc *m, const mjo_data *d, int 
 {
 	double cost = 0;
 	for (int i = 0; i < nefc; i++) {
+		if (d->efc_type[i] == MJB_CNSTR_FRICTION_DOF) {
+			const double fl = d->efc_frictionloss[i], rf = fl / d->efc_D[i], x = jar[i];
+			if (x <= -rf) {
+				force[i] = fl;
+				cost += fl * (-0.5 * rf - x);
+				if (hrow) hrow[i] = 0;
+			} else if (x >= rf) {
+				force[i] = -fl;
+				cost += fl * (-0.5 * rf + x);
+				if (hrow) hrow[i] = 0;
+			} else {
+				force[i] = -d->efc_D[i] * x;
+				cost += 0.5 * d->efc_D[i] * x * x;
+				if (hrow) hrow[i] = d->efc_D[i];
+			}
+			continue;
+		}
 		if (d->efc_type[i] != MJB_CNSTR_CONTACT_ELLIPTIC) {
 			if (jar[i] < 0 || d->efc_type[i] == MJB_CNSTR_EQUALITY) {
 				force[i] = -d->efc_D[i] * jar[i];
