@@ -65,7 +65,7 @@ enum { /* mjtSensor (subset implemented; values are MuJoCo's) */
 enum { MJB_STAGE_NONE = 0, MJB_STAGE_POS = 1, MJB_STAGE_VEL = 2, MJB_STAGE_ACC = 3 };
 enum { MJB_EQ_CONNECT = 0, MJB_EQ_WELD = 1, MJB_EQ_JOINT = 2, MJB_EQ_TENDON = 3 }; /* mjtEq (distance not implemented) */
 enum { /* mjtConstraint */
-	MJB_CNSTR_EQUALITY = 0, MJB_CNSTR_FRICTION_DOF = 1, MJB_CNSTR_LIMIT_JOINT = 3, MJB_CNSTR_LIMIT_TENDON = 4, MJB_CNSTR_CONTACT_FRICTIONLESS = 5, MJB_CNSTR_CONTACT_PYRAMIDAL = 6,
+	MJB_CNSTR_EQUALITY = 0, MJB_CNSTR_FRICTION_DOF = 1, MJB_CNSTR_FRICTION_TENDON = 2, MJB_CNSTR_LIMIT_JOINT = 3, MJB_CNSTR_LIMIT_TENDON = 4, MJB_CNSTR_CONTACT_FRICTIONLESS = 5, MJB_CNSTR_CONTACT_PYRAMIDAL = 6,
 	MJB_CNSTR_CONTACT_ELLIPTIC = 7
 };
 

@@ -240,7 +240,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	L.ndouble = off;
 	L.iscratch = ioff;
 	{
-		int a = d.ncollpair, b = d.neq + d.nv + d.njnt + d.ntendon + d.nconmax;
+		int a = d.ncollpair, b = d.neq + d.nv + d.njnt + 2 * d.ntendon + d.nconmax;
 		ioff += a > b ? a : b;
 	}
 	L.nint = (ioff + 1) & ~1;
@@ -584,6 +584,9 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 	if (!(h.disableflags & MJB_DSBL_FRICTIONLOSS))
 		for (int i = 0; i < h.nv; i++)
 			if (h.dof_frictionloss[i] > 0) M->nfriction++;
+	if (!(h.disableflags & MJB_DSBL_FRICTIONLOSS))
+		for (int t = 0; t < h.ntendon; t++)
+			if (h.tendon_frictionloss[t] > 0) M->nfriction++;
 	compute_layout(M, M->L, false);
 	compute_layout(M, M->Lc, true);
 	build_sensor_tables(M);

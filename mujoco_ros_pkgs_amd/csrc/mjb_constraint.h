@@ -745,8 +745,9 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 	const bool do_lim = !(m.disableflags & MJB_DSBL_LIMIT), do_con = !(m.disableflags & MJB_DSBL_CONTACT);
 	const int neq = (m.disableflags & MJB_DSBL_EQUALITY) ? 0 : m.neq;
 	const int nten = do_lim ? m.ntendon : 0;
-	const int nfr = m.nfriction > 0 ? nv : 0;  // (models without dry friction keep the shorter item list)
-	const int nitem = neq + nfr + m.njnt + nten + ncon;  // item = equality, dof friction, joint limit, tendon limit or contact -- MuJoCo's row order
+	const int nfd = m.nfriction > 0 ? nv : 0;  // dof friction items, then tendon friction items (models without dry friction keep the shorter list)
+	const int nfr = m.nfriction > 0 ? nv + m.ntendon : 0;
+	const int nitem = neq + nfr + m.njnt + nten + ncon;  // item = equality, dof / tendon friction, joint limit, tendon limit or contact -- MuJoCo's row order
 	int *cnt = fi + L.iscratch;              // transient per-item row counts
 	// pass 1: rows per item
 	for (int it = lane; it < nitem; it += G) {
@@ -754,7 +755,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 		if (it < neq) {
 			if (m.eq_active[it]) n = m.eq_type[it] == MJB_EQ_CONNECT ? 3 : (m.eq_type[it] == MJB_EQ_WELD ? 6 : 1);  // joint, tendon: 1
 		} else if (it < neq + nfr) {
-			n = m.dof_frictionloss[it - neq] > 0 ? 1 : 0;
+			n = (it < neq + nfd ? m.dof_frictionloss[it - neq] : m.tendon_frictionloss[it - neq - nfd]) > 0 ? 1 : 0;
 		} else if (it < neq + nfr + m.njnt) {
 			const int j = it - neq - nfr;
 			if (do_lim && m.jnt_limited[j] && m.jnt_type[j] >= MJB_JNT_SLIDE) {
@@ -867,18 +868,26 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 				fi[L.efc_type + off + k] = MJB_CNSTR_EQUALITY;
 			}
 		} else if (it < neq + nfr) {
-			// dry joint friction (mj_instantiateFriction): J = e_dof, pos = margin = 0, |force| <= frictionloss
-			const int i = it - neq;
+			// dry friction (mj_instantiateFriction): J = e_dof or the tendon's moment arms, pos = margin = 0, |force| <= frictionloss
+			const bool isdof = it < neq + nfd;
+			const int i = isdof ? it - neq : it - neq - nfd;
 			double *row = f + L.efc_J + off * nv;
 			for (int k = 0; k < nv; k++) row[k] = 0;
-			row[i] = 1;
-			const double solref[2] = { m.dof_solref[2 * i], m.dof_solref[2 * i + 1] };
+			if (isdof) {
+				row[i] = 1;
+			} else {
+				for (int w = m.tendon_adr[i]; w < m.tendon_adr[i] + m.tendon_num[i]; w++)
+					row[m.jnt_dofadr[m.wrap_objid[w]]] += m.wrap_prm[w];
+			}
+			const mjb_cdptr sr = isdof ? m.dof_solref + 2 * i : m.tendon_solref_fri + 2 * i;
+			const mjb_cdptr si = isdof ? m.dof_solimp + 5 * i : m.tendon_solimp_fri + 5 * i;
+			const double solref[2] = { sr[0], sr[1] };
 			double solimp[5];
-			for (int k = 0; k < 5; k++) solimp[k] = m.dof_solimp[5 * i + k];
-			row_params(m, L, f, off, 0.0, 0.0, solref, solimp, m.dof_invweight0[i]);
-			f[L.efc_frictionloss + off] = m.dof_frictionloss[i];
+			for (int k = 0; k < 5; k++) solimp[k] = si[k];
+			row_params(m, L, f, off, 0.0, 0.0, solref, solimp, isdof ? m.dof_invweight0[i] : m.tendon_invweight0[i]);
+			f[L.efc_frictionloss + off] = isdof ? m.dof_frictionloss[i] : m.tendon_frictionloss[i];
 			fi[L.efc_id + off] = i;
-			fi[L.efc_type + off] = MJB_CNSTR_FRICTION_DOF;
+			fi[L.efc_type + off] = isdof ? MJB_CNSTR_FRICTION_DOF : MJB_CNSTR_FRICTION_TENDON;
 		} else if (it < neq + nfr + m.njnt) {
 			const int j = it - neq - nfr, da = m.jnt_dofadr[j];
 			const double value = f[L.qpos + m.jnt_qposadr[j]], margin = m.jnt_margin[j];
@@ -1235,8 +1244,8 @@ template <int G> STAGE void fwd_constraint_pgs(CModel m, CLayout L, const Env &e
 	const int r = rowact ? lane : 0;
 	const double *Jr = f + L.efc_J + r * nv, *Br = f + L.efc_B + r * nv;
 	const bool bilateral = rowact && fi[L.efc_type + r] == MJB_CNSTR_EQUALITY;
-	const bool friction = rowact && m.nfriction > 0 && fi[L.efc_type + r] == MJB_CNSTR_FRICTION_DOF;
-	const double floss = friction ? f[L.efc_frictionloss + r] : 0.0;
+	const double floss = (rowact && m.nfriction > 0) ? f[L.efc_frictionloss + r] : 0.0;  // > 0: dry-friction row (dof or tendon)
+	const bool friction = floss > 0;
 	double b = 0, Aii = 1, ARinv = 0, frc = 0;
 	{
 		double jq = 0, jb = 0, jw = 0;
@@ -1489,7 +1498,7 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 		leader[i] = is_cone && fi[L.contact_efc_address + rcon[i]] == r;
 		cdim[i] = is_cone ? fi[L.contact_dim + rcon[i]] : 0;
 		D[i] = rowact[i] ? f[L.efc_D + r] : 0.0;
-		fl[i] = (rowact[i] && m.nfriction > 0 && rtype == MJB_CNSTR_FRICTION_DOF) ? f[L.efc_frictionloss + r] : 0.0;
+		fl[i] = (rowact[i] && m.nfriction > 0) ? f[L.efc_frictionloss + r] : 0.0;
 		aref[i] = rowact[i] ? f[L.efc_aref + r] : 0.0;
 		cmu[i] = leader[i] ? f[L.contact_friction + 5 * rcon[i]] / sqrt(fmax(MJB_MINVAL, m.impratio[0])) : 1.0;
 	}

@@ -49,7 +49,7 @@ struct DevModel {
 	mjb_ciptr dof_bodymask;  // [nv][2] bit b set: dof i moves body b (transpose of body_dofmask), nbody <= 64
 	mjb_ciptr body_submask;  // [nbody][2] bit i set: body i belongs to the body's subtree (incl. itself), nbody <= 64
 	int eulerdamp;           // any dof_damping > 0 and EULERDAMP not disabled
-	int nfriction;           // number of dofs with frictionloss > 0 (0 when FRICTIONLOSS is disabled): friction rows exist
+	int nfriction;           // number of dofs + tendons with frictionloss > 0 (0 when FRICTIONLOSS is disabled): friction rows exist
 	int need_rnepost;        // an acceleration-stage sensor needs mj_rnePostConstraint (cacc / cfrc_int / cfrc_ext)
 	int kin_rounds;          // ceil(log2(max body depth)): rounds of the pointer-jumping kinematics
 	int maxdepth;          // max dof_depth

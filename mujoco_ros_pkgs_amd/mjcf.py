@@ -514,8 +514,8 @@ class _Compiler:
             if w.tag != "joint":
                 raise MjcfError("fixed tendons take <joint> entries only")
             wraps.append((w.get("joint"), float(w.get("coef", 1))))
-        if float(a.get("frictionloss", 0)) != 0:
-            raise MjcfError("tendon frictionloss is not supported")
+        if float(a.get("frictionloss", 0)) < 0:
+            raise MjcfError("tendon frictionloss must be >= 0")
         self.tendons.append((a, wraps))
 
     def _actuator(self, node):
@@ -889,7 +889,8 @@ class _Compiler:
         neqrow = 0
         if not (o["disableflags"] & DISABLE_BITS["equality"]):
             neqrow = int(sum({0: 3, 1: 6, 2: 1, 3: 1}[int(t)] for t in m["eq_type"]))
-        nfric = 0 if (o["disableflags"] & DISABLE_BITS["frictionloss"]) else int(np.count_nonzero(m["dof_frictionloss"] > 0))
+        nfric = 0 if (o["disableflags"] & DISABLE_BITS["frictionloss"]) else int(
+            np.count_nonzero(m["dof_frictionloss"] > 0) + np.count_nonzero(m["tendon_frictionloss"] > 0))
         nefcmax = neqrow + nfric + nlimit + rows_per_con * nconmax if self.nefcmax_req is None else int(self.nefcmax_req)
         if o["disableflags"] & (DISABLE_BITS["constraint"]):
             nconmax, nefcmax = 0, 0
@@ -912,6 +913,7 @@ class _Compiler:
         lim, rng, margin = np.zeros(nt, I), np.zeros((nt, 2)), np.zeros(nt)
         solref, solimp = np.zeros((nt, 2)), np.zeros((nt, 5))
         stiff, damp, lspring = np.zeros(nt), np.zeros(nt), np.zeros(nt)
+        floss, solref_f, solimp_f = np.zeros(nt), np.zeros((nt, 2)), np.zeros((nt, 5))
         for i, (a, wraps) in enumerate(T):
             names.append(a.get("name", f"tendon{i}"))
             adr.append(len(objid))
@@ -930,6 +932,9 @@ class _Compiler:
             solimp[i] = _solimp(a.get("solimplimit"))
             stiff[i], damp[i] = float(a.get("stiffness", 0)), float(a.get("damping", 0))
             lspring[i] = float(a.get("springlength", -1))
+            floss[i] = float(a.get("frictionloss", 0))
+            solref_f[i] = _floats(a.get("solreffriction", "0.02 1"), 2, "tendon solreffriction")
+            solimp_f[i] = _solimp(a.get("solimpfriction"))
         nv = m["nv"]
         J = np.zeros((nt, nv))
         q0 = np.asarray(m["qpos0"], D)
@@ -948,7 +953,8 @@ class _Compiler:
                  tendon_limited=lim, wrap_objid=np.array(objid, I), wrap_prm=np.array(prm, D),
                  tendon_range=rng.reshape(nt, 2), tendon_margin=margin, tendon_solref_lim=solref.reshape(nt, 2),
                  tendon_solimp_lim=solimp.reshape(nt, 5), tendon_length0=len0, tendon_invweight0=inv0,
-                 tendon_stiffness=stiff, tendon_damping=damp, tendon_lengthspring=lspring)
+                 tendon_stiffness=stiff, tendon_damping=damp, tendon_lengthspring=lspring, tendon_frictionloss=floss,
+                 tendon_solref_fri=solref_f.reshape(nt, 2), tendon_solimp_fri=solimp_f.reshape(nt, 5))
         m["names"]["tendon"] = names
 
     def _compile_equalities(self, m):

@@ -817,6 +817,21 @@ void mjo_make_constraint(const mjb_model_desc *m, mjo_data *d)
 			row_params(m, d, nefc, m->dof_solref + 2 * i, m->dof_solimp + 5 * i, m->dof_invweight0[i]);
 			nefc++;
 		}
+		/* tendon part: J = the tendon's moment arm row */
+		for (int t = 0; t < m->ntendon; t++) {
+			if (m->tendon_frictionloss[t] <= 0 || nefc >= m->nefcmax) continue;
+			double *row = d->efc_J + (size_t)nefc * nv;
+			memset(row, 0, sizeof(double) * (size_t)nv);
+			for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++)
+				row[m->jnt_dofadr[m->wrap_objid[w]]] += m->wrap_prm[w];
+			d->efc_pos[nefc] = 0;
+			d->efc_margin[nefc] = 0;
+			d->efc_frictionloss[nefc] = m->tendon_frictionloss[t];
+			d->efc_type[nefc] = MJB_CNSTR_FRICTION_TENDON;
+			d->efc_id[nefc] = t;
+			row_params(m, d, nefc, m->tendon_solref_fri + 2 * t, m->tendon_solimp_fri + 5 * t, m->tendon_invweight0[t]);
+			nefc++;
+		}
 	}
 	/* joint limits (mj_instantiateLimit), hinge / slide */
 	if (!(m->disableflags & MJB_DSBL_LIMIT)) {
@@ -1011,7 +1026,7 @@ void mjo_fwd_constraint(const mjb_model_desc *m, mjo_data *d)
 			const double *row = d->efc_J + (size_t)i * nv;
 			for (int k = 0; k < nv; k++) jar += row[k] * d->qacc_warmstart[k];
 			f[i] = (jar < 0 || d->efc_type[i] == MJB_CNSTR_EQUALITY) ? -d->efc_D[i] * jar : 0.0; /* limit / contact rows are one-sided */
-			if (d->efc_type[i] == MJB_CNSTR_FRICTION_DOF) { /* two-sided, saturating at +-frictionloss (mj_constraintUpdate) */
+			if (d->efc_type[i] == MJB_CNSTR_FRICTION_DOF || d->efc_type[i] == MJB_CNSTR_FRICTION_TENDON) { /* two-sided, saturating at +-frictionloss (mj_constraintUpdate) */
 				const double fl = d->efc_frictionloss[i];
 				f[i] = -d->efc_D[i] * jar;
 				if (f[i] > fl) f[i] = fl;
@@ -1040,7 +1055,7 @@ void mjo_fwd_constraint(const mjb_model_desc *m, mjo_data *d)
 			double old = f[i];
 			double Aii = d->efc_AR[(size_t)i * ld + i];
 			f[i] -= res * ARinv[i];
-			if (d->efc_type[i] == MJB_CNSTR_FRICTION_DOF) { /* box: |f| <= frictionloss */
+			if (d->efc_type[i] == MJB_CNSTR_FRICTION_DOF || d->efc_type[i] == MJB_CNSTR_FRICTION_TENDON) { /* box: |f| <= frictionloss */
 				const double fl = d->efc_frictionloss[i];
 				if (f[i] < -fl) f[i] = -fl;
 				if (f[i] > fl) f[i] = fl;
@@ -1135,7 +1150,7 @@ static void ls_eval(const lsctx *c, lspoint *p)
 	for (int i = 0; i < c->nefc; i++) {
 		if (c->type[i] != MJB_CNSTR_CONTACT_ELLIPTIC) {
 			double x = c->jaref[i] + a * c->jv[i];
-			if (c->type[i] == MJB_CNSTR_FRICTION_DOF) { /* Huber: quadratic inside |x| < R f, linear outside */
+			if (c->type[i] == MJB_CNSTR_FRICTION_DOF || c->type[i] == MJB_CNSTR_FRICTION_TENDON) { /* Huber: quadratic inside |x| < R f, linear outside */
 				const double fl = c->d->efc_frictionloss[i], rf = fl / c->D[i];
 				if (x <= -rf) {
 					cost += fl * (-0.5 * rf - x);
@@ -1301,7 +1316,7 @@ static double constraint_update(const mjb_model_desc *m, const mjo_data *d, int 
 {
 	double cost = 0;
 	for (int i = 0; i < nefc; i++) {
-		if (d->efc_type[i] == MJB_CNSTR_FRICTION_DOF) {
+		if (d->efc_type[i] == MJB_CNSTR_FRICTION_DOF || d->efc_type[i] == MJB_CNSTR_FRICTION_TENDON) {
 			const double fl = d->efc_frictionloss[i], rf = fl / d->efc_D[i], x = jar[i];
 			if (x <= -rf) {
 				force[i] = fl;

@@ -62,3 +62,31 @@ def test_frictionloss_disable_flag_and_attributes():
     assert tuple(m["dof_solref"][0]) == (0.05, 0.8) and tuple(m["dof_solimp"][0][:3]) == (0.8, 0.9, 0.002)
     m = mjcf.compile_xml_string(arm_xml(1.0, "Newton"), disable=("frictionloss",))
     assert m["nefcmax"] == 0
+
+
+def coupled_xml(solver, tfl):
+    # two horizontal arms coupled by a fixed tendon L = q0 + q1; friction on the tendon only
+    return f"""<mujoco><option timestep="0.001" solver="{solver}" tolerance="1e-12" iterations="200" gravity="0 0 0"/>
+    <worldbody>
+      <body name="a"><joint name="ja" type="hinge" axis="0 0 1"/><geom type="sphere" size="0.01" pos="0.3 0 0" mass="1" contype="0" conaffinity="0"/></body>
+      <body name="b" pos="0 1 0"><joint name="jb" type="hinge" axis="0 0 1"/><geom type="sphere" size="0.01" pos="0.3 0 0" mass="1" contype="0" conaffinity="0"/></body>
+    </worldbody>
+    <tendon><fixed name="t" frictionloss="{tfl}"><joint joint="ja" coef="1"/><joint joint="jb" coef="1"/></fixed></tendon></mujoco>"""
+
+
+@pytest.mark.parametrize("solver", ["PGS", "Newton"])
+def test_tendon_friction_acts_along_the_moment_arms(oracle_built, solver):
+    m = mjcf.compile_xml_string(coupled_xml(solver, 0.2))
+    assert m["nefcmax"] == 1
+    d = oracle_built.OracleData(m)
+    d.qvel[:] = [2.0, 1.0]  # tendon velocity +3: friction saturates at -0.2 along J = (1, 1)
+    d.forward()
+    assert int(d.nefc[0]) == 1 and int(d.efc_type[0]) == 2
+    np.testing.assert_allclose(np.asarray(d.efc_J)[:2], [1, 1])
+    assert abs(d.efc_force[0] + 0.2) < 1e-9
+    np.testing.assert_allclose(np.asarray(d.qfrc_constraint)[:2], [-0.2, -0.2], atol=1e-9)
+    # antisymmetric motion leaves the tendon length unchanged: the row is at rest and carries (almost) no force
+    d.reset()
+    d.qvel[:] = [1.0, -1.0]
+    d.forward()
+    assert abs(d.efc_force[0]) < 1e-9
