@@ -993,8 +993,124 @@ void mjo_reference_constraint(const mjb_model_desc *m, mjo_data *d)
 }
 
 static void fwd_constraint_newton(const mjb_model_desc *m, mjo_data *d);
+static double constraint_update(const mjb_model_desc *m, const mjo_data *d, int nefc, const double *jar, double *force,
+                                double *hrow, double *hcone);
 
 /* A13: mj_fwdConstraint with the PGS solver (mj_solPGS); A14 (Newton) below */
+/* Friction part of an elliptic-cone block (the role of mju_QCQP2 / 3 / N in mj_solPGS):
+ *   minimise 0.5 y'A y + y'b  subject to  sum_j (y_j / d_j)^2 <= r^2          (n <= 5, A symmetric positive definite).
+ * In the scaled variable z_j = y_j / d_j the constraint is the ball |z| <= r; if the free minimiser violates it the
+ * multiplier la >= 0 of (A_s + la I) z = -b_s, |z| = r is found by Newton's method on phi(la) = |z|^2 - r^2
+ * (phi' = -2 z'(A_s + la I)^-1 z, at most 20 steps, 1e-10 stopping thresholds).  Returns 1 when the constraint is active. */
+static int chol_solve_small(int n, const double *A, double la, const double *rhs, double *x)
+{
+	double Lc[25];
+	for (int i = 0; i < n; i++)
+		for (int j = 0; j <= i; j++) {
+			double sum = A[i * n + j] + (i == j ? la : 0.0);
+			for (int k = 0; k < j; k++) sum -= Lc[i * n + k] * Lc[j * n + k];
+			if (i == j) {
+				if (sum < MJO_MINVAL) return 0;
+				Lc[i * n + i] = sqrt(sum);
+			} else {
+				Lc[i * n + j] = sum / Lc[j * n + j];
+			}
+		}
+	for (int i = 0; i < n; i++) {
+		double sum = rhs[i];
+		for (int k = 0; k < i; k++) sum -= Lc[i * n + k] * x[k];
+		x[i] = sum / Lc[i * n + i];
+	}
+	for (int i = n - 1; i >= 0; i--) {
+		double sum = x[i];
+		for (int k = i + 1; k < n; k++) sum -= Lc[k * n + i] * x[k];
+		x[i] = sum / Lc[i * n + i];
+	}
+	return 1;
+}
+
+static int cone_qcqp(int n, double *y, const double *A, const double *b, const double *dsc, double r)
+{
+	double As[25], bs[5], z[5], w[5], nb[5];
+	for (int i = 0; i < n; i++) {
+		bs[i] = b[i] * dsc[i];
+		nb[i] = -bs[i];
+		for (int j = 0; j < n; j++) As[i * n + j] = A[i * n + j] * dsc[i] * dsc[j];
+	}
+	double la = 0;
+	int ok = 1;
+	for (int iter = 0; iter < 20; iter++) {
+		ok = chol_solve_small(n, As, la, nb, z);
+		if (!ok) break;
+		double val = -r * r;
+		for (int i = 0; i < n; i++) val += z[i] * z[i];
+		if (val < 1e-10) break;
+		chol_solve_small(n, As, la, z, w);
+		double deriv = 0;
+		for (int i = 0; i < n; i++) deriv -= 2 * z[i] * w[i];
+		const double delta = -val / deriv;
+		if (delta < 1e-10) break;
+		la += delta;
+	}
+	if (!ok) {
+		for (int i = 0; i < n; i++) y[i] = 0;
+		return 0;
+	}
+	for (int i = 0; i < n; i++) y[i] = z[i] * dsc[i];
+	return la != 0;
+}
+
+/* One Gauss-Seidel update of an elliptic contact block (rows i .. i+dim-1) of the dual problem, the structure of
+ * mj_solPGS: (1) with (almost) no normal force, a plain update of the normal row and zero friction; otherwise an exact
+ * step along the current force ray, stopped where the normal force would turn negative; (2) with the normal force
+ * fixed, the friction forces minimise the block cost inside the cone section sum (f_j / mu_j)^2 <= f_n^2.
+ * res = residual of the block rows at the old forces, Ac = the block of AR.  Forces are updated in place. */
+static void pgs_cone_block(int dim, double *fc, const double *res, const double *Ac, const double *mu)
+{
+	double old[6];
+	for (int a = 0; a < dim; a++) old[a] = fc[a];
+	if (fc[0] < MJO_MINVAL) {
+		fc[0] -= res[0] / Ac[0];
+		if (fc[0] < 0) fc[0] = 0;
+		for (int a = 1; a < dim; a++) fc[a] = 0;
+	} else {
+		double denom = 0, vr = 0;
+		for (int a = 0; a < dim; a++) {
+			double sa = 0;
+			for (int c = 0; c < dim; c++) sa += Ac[a * dim + c] * old[c];
+			denom += old[a] * sa;
+			vr += old[a] * res[a];
+		}
+		if (denom >= MJO_MINVAL) {
+			double x = -vr / denom;
+			if (fc[0] + x * old[0] < 0) x = -fc[0] / old[0];
+			for (int a = 0; a < dim; a++) fc[a] += x * old[a];
+		}
+	}
+	if (fc[0] < MJO_MINVAL) {
+		for (int a = 1; a < dim; a++) fc[a] = 0;
+		return;
+	}
+	/* friction sub-problem: constant part of the residual bc = res - Ac old, then b_f = bc_f + Ac_f0 f_n */
+	const int n = dim - 1;
+	double Af[25], bf[5], y[5];
+	for (int a = 1; a < dim; a++) {
+		double bc = res[a];
+		for (int c = 0; c < dim; c++) bc -= Ac[a * dim + c] * old[c];
+		bf[a - 1] = bc + Ac[a * dim] * fc[0];
+		for (int c = 1; c < dim; c++) Af[(a - 1) * n + (c - 1)] = Ac[a * dim + c];
+	}
+	const int active = cone_qcqp(n, y, Af, bf, mu, fc[0]);
+	if (active) { /* put the result exactly on the cone */
+		double sn = 0;
+		for (int a = 0; a < n; a++) sn += (y[a] / mu[a]) * (y[a] / mu[a]);
+		sn = sqrt(sn);
+		if (sn > MJO_MINVAL)
+			for (int a = 0; a < n; a++) y[a] *= fc[0] / sn;
+	}
+	for (int a = 0; a < n; a++) fc[1 + a] = y[a];
+}
+
 void mjo_fwd_constraint(const mjb_model_desc *m, mjo_data *d)
 {
 	if (d->nefc[0] > 0 && m->solver == MJB_SOL_NEWTON) {
@@ -1033,6 +1149,15 @@ void mjo_fwd_constraint(const mjb_model_desc *m, mjo_data *d)
 				if (f[i] < -fl) f[i] = -fl;
 			}
 		}
+		if (m->cone == MJB_CONE_ELLIPTIC) { /* cone blocks: the primal update gives the forces of whole contacts */
+			double jar[nefc];
+			for (int i = 0; i < nefc; i++) {
+				jar[i] = -d->efc_aref[i];
+				const double *row = d->efc_J + (size_t)i * nv;
+				for (int k = 0; k < nv; k++) jar[i] += row[k] * d->qacc_warmstart[k];
+			}
+			constraint_update(m, d, nefc, jar, f, NULL, NULL);
+		}
 		double cost = 0;
 		for (int i = 0; i < nefc; i++) {
 			double s = 0;
@@ -1050,6 +1175,30 @@ void mjo_fwd_constraint(const mjb_model_desc *m, mjo_data *d)
 	while (iter < m->iterations) {
 		double improvement = 0;
 		for (int i = 0; i < nefc; i++) {
+			if (d->efc_type[i] == MJB_CNSTR_CONTACT_ELLIPTIC) {
+				const int con = d->efc_id[i], dim = d->contact_dim[con];
+				double resb[6], Ac[36], oldf[6], change = 0;
+				for (int a = 0; a < dim; a++) {
+					resb[a] = b[i + a];
+					for (int j = 0; j < nefc; j++) resb[a] += d->efc_AR[(size_t)(i + a) * ld + j] * f[j];
+					oldf[a] = f[i + a];
+					for (int c = 0; c < dim; c++) Ac[a * dim + c] = d->efc_AR[(size_t)(i + a) * ld + i + c];
+				}
+				pgs_cone_block(dim, f + i, resb, Ac, d->contact_friction + 5 * con);
+				for (int a = 0; a < dim; a++) {
+					const double da = f[i + a] - oldf[a];
+					double sa = 0;
+					for (int c = 0; c < dim; c++) sa += Ac[a * dim + c] * (f[i + c] - oldf[c]);
+					change += 0.5 * da * sa + da * resb[a];
+				}
+				if (change > 1e-10) {
+					for (int a = 0; a < dim; a++) f[i + a] = oldf[a];
+					change = 0;
+				}
+				improvement -= change;
+				i += dim - 1;
+				continue;
+			}
 			double res = b[i];
 			for (int j = 0; j < nefc; j++) res += d->efc_AR[(size_t)i * ld + j] * f[j];
 			double old = f[i];
