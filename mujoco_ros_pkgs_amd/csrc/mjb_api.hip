@@ -192,7 +192,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	L.nwt_row = off;
 	off += newton ? 3 * d.nefcmax : 0;
 	L.nwt_hc = off;
-	off += (newton && d.cone == MJB_CONE_ELLIPTIC) ? 36 * d.nconmax : 0;
+	off += ((newton || (d.nefcmax > 0 && d.solver == MJB_SOL_PGS)) && d.cone == MJB_CONE_ELLIPTIC) ? 36 * d.nconmax : 0;  // (PGS: the contacts' blocks of AR)
 	L.gravity = off;
 	off += 3;
 	L.gfriction = off;
@@ -390,10 +390,8 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		return nullptr;
 	}
 	if (d.nefcmax > 0 || d.nconmax > 0) {
-		if ((d.solver != MJB_SOL_PGS && d.solver != MJB_SOL_NEWTON) ||
-		    (d.cone == MJB_CONE_ELLIPTIC && d.solver != MJB_SOL_NEWTON)) {
-			fail(MJB_EUNSUPPORTED, "mjb_compile: models with constraint rows need solver=Newton (pyramidal or elliptic cones) "
-			                       "or solver=PGS with cone=pyramidal (CG and PGS with elliptic cones are not implemented)");
+		if (d.solver != MJB_SOL_PGS && d.solver != MJB_SOL_NEWTON) {
+			fail(MJB_EUNSUPPORTED, "mjb_compile: models with constraint rows need solver=Newton or solver=PGS (CG is not implemented)");
 			return nullptr;
 		}
 		const int rowcap = d.solver == MJB_SOL_NEWTON ? 256 : 64;
@@ -870,11 +868,11 @@ static int sync_params(mjb_batch *b)
 	return MJB_OK;
 }
 
-// 0: no constraint rows; 1: PGS; 2 / 3 / 4: Newton with 1 / 2 / 4 rows per lane
+// 0: no constraint rows; 1: PGS (5: PGS with elliptic contacts); 2 / 3 / 4: Newton with 1 / 2 / 4 rows per lane
 static int kernel_variant(const mjb_model_desc &h)
 {
 	if (h.nefcmax <= 0) return 0;
-	if (h.solver != MJB_SOL_NEWTON) return 1;
+	if (h.solver != MJB_SOL_NEWTON) return (h.cone == MJB_CONE_ELLIPTIC && h.nconmax > 0) ? 5 : 1;
 	return h.nefcmax <= 64 ? 2 : (h.nefcmax <= 128 ? 3 : 4);
 }
 

@@ -1216,9 +1216,255 @@ DEVI void pgs_sweep(const double (&AR)[64], const int nefc, const double lo, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// PGS with elliptic cones: block update of one contact (oracle/mjo_constraint.c pgs_cone_block, cone_qcqp; the role
+// of mj_solPGS's ray step and mju_QCQP2 / 3 / N).  All values are wave-uniform; DIM = condim (3, 4 or 6) is a template
+// parameter so that every small array stays in statically indexed registers.
+// ------------------------------------------------------------------------------------------------
+template <int N> DEVI bool chol_solve_small(const double (&A)[N * N], const double la, const double (&rhs)[N], double (&x)[N])
+{
+	double Lc[N * N];
+#pragma unroll
+	for (int i = 0; i < N; i++) {
+#pragma unroll
+		for (int j = 0; j <= i; j++) {
+			double sum = A[i * N + j] + (i == j ? la : 0.0);
+#pragma unroll
+			for (int k = 0; k < j; k++) sum -= Lc[i * N + k] * Lc[j * N + k];
+			if (i == j) {
+				if (sum < MJB_MINVAL) return false;
+				Lc[i * N + i] = sqrt(sum);
+			} else {
+				Lc[i * N + j] = sum / Lc[j * N + j];
+			}
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < N; i++) {
+		double sum = rhs[i];
+#pragma unroll
+		for (int k = 0; k < i; k++) sum -= Lc[i * N + k] * x[k];
+		x[i] = sum / Lc[i * N + i];
+	}
+#pragma unroll
+	for (int i = N - 1; i >= 0; i--) {
+		double sum = x[i];
+#pragma unroll
+		for (int k = i + 1; k < N; k++) sum -= Lc[k * N + i] * x[k];
+		x[i] = sum / Lc[i * N + i];
+	}
+	return true;
+}
+
+// minimise 0.5 y'Ay + y'b  s.t.  sum (y_j / d_j)^2 <= r^2 : Newton's method on the multiplier in the scaled variable
+template <int N> DEVI bool cone_qcqp(double (&y)[N], const double (&A)[N * N], const double (&b)[N], const double (&dsc)[N], const double r)
+{
+	double As[N * N], nb[N], z[N], w[N];
+#pragma unroll
+	for (int i = 0; i < N; i++) {
+		nb[i] = -(b[i] * dsc[i]);
+		z[i] = 0;
+		w[i] = 0;
+#pragma unroll
+		for (int j = 0; j < N; j++) As[i * N + j] = A[i * N + j] * dsc[i] * dsc[j];
+	}
+	double la = 0;
+	bool ok = true;
+#pragma nounroll
+	for (int iter = 0; iter < 20; iter++) {
+		ok = chol_solve_small<N>(As, la, nb, z);
+		if (!ok) break;
+		double val = -r * r;
+#pragma unroll
+		for (int i = 0; i < N; i++) val += z[i] * z[i];
+		if (val < 1e-10) break;
+		chol_solve_small<N>(As, la, z, w);
+		double deriv = 0;
+#pragma unroll
+		for (int i = 0; i < N; i++) deriv -= 2 * z[i] * w[i];
+		const double delta = -val / deriv;
+		if (delta < 1e-10) break;
+		la += delta;
+	}
+#pragma unroll
+	for (int i = 0; i < N; i++) y[i] = ok ? z[i] * dsc[i] : 0.0;
+	return ok && la != 0;
+}
+
+// forces fc[0..DIM) updated in place from the block residual res (at the old forces) and the block Ac of AR (row stride 6)
+template <int DIM> DEVI void pgs_cone_block(double (&fc)[6], const double (&res)[6], const double *Ac, const double *mu5)
+{
+	double old[DIM], A[DIM * DIM];
+#pragma unroll
+	for (int a = 0; a < DIM; a++) {
+		old[a] = fc[a];
+#pragma unroll
+		for (int c = 0; c < DIM; c++) A[a * DIM + c] = Ac[6 * a + c];
+	}
+	if (fc[0] < MJB_MINVAL) {
+		fc[0] -= res[0] / A[0];
+		if (fc[0] < 0) fc[0] = 0;
+#pragma unroll
+		for (int a = 1; a < DIM; a++) fc[a] = 0;
+	} else {
+		double denom = 0, vr = 0;
+#pragma unroll
+		for (int a = 0; a < DIM; a++) {
+			double sa = 0;
+#pragma unroll
+			for (int c = 0; c < DIM; c++) sa += A[a * DIM + c] * old[c];
+			denom += old[a] * sa;
+			vr += old[a] * res[a];
+		}
+		if (denom >= MJB_MINVAL) {
+			double x = -vr / denom;
+			if (fc[0] + x * old[0] < 0) x = -fc[0] / old[0];
+#pragma unroll
+			for (int a = 0; a < DIM; a++) fc[a] += x * old[a];
+		}
+	}
+	if (fc[0] < MJB_MINVAL) {
+#pragma unroll
+		for (int a = 1; a < DIM; a++) fc[a] = 0;
+		return;
+	}
+	constexpr int N = DIM - 1;
+	double Af[N * N], bf[N], y[N], mu[N];
+#pragma unroll
+	for (int a = 1; a < DIM; a++) {
+		double bc = res[a];
+#pragma unroll
+		for (int c = 0; c < DIM; c++) bc -= A[a * DIM + c] * old[c];
+		bf[a - 1] = bc + A[a * DIM] * fc[0];
+		mu[a - 1] = mu5[a - 1];
+#pragma unroll
+		for (int c = 1; c < DIM; c++) Af[(a - 1) * N + (c - 1)] = A[a * DIM + c];
+	}
+	const bool active = cone_qcqp<N>(y, Af, bf, mu, fc[0]);
+	if (active) {  // put the result exactly on the cone
+		double sn = 0;
+#pragma unroll
+		for (int a = 0; a < N; a++) sn += (y[a] / mu[a]) * (y[a] / mu[a]);
+		sn = sqrt(sn);
+		if (sn > MJB_MINVAL) {
+#pragma unroll
+			for (int a = 0; a < N; a++) y[a] *= fc[0] / sn;
+		}
+	}
+#pragma unroll
+	for (int a = 0; a < N; a++) fc[1 + a] = y[a];
+}
+
+// primal cone update of one contact (forces only; oracle cone_eval): used by the PGS warmstart
+DEVI void cone_force(const double mu, const double *fri, const double *D, const int dim, const double *jar, double *force)
+{
+	double U[6], TT = 0;
+	U[0] = mu * jar[0];
+	for (int j = 1; j < 6; j++) {
+		U[j] = 0;
+		if (j < dim) {
+			U[j] = fri[j - 1] * jar[j];
+			TT += U[j] * U[j];
+		}
+	}
+	const double N = U[0], T = sqrt(TT);
+	if (N >= mu * T) {
+		for (int j = 0; j < 6; j++)
+			if (j < dim) force[j] = 0;
+	} else if (mu * N + T <= 0) {
+		for (int j = 0; j < 6; j++)
+			if (j < dim) force[j] = -D[j] * jar[j];
+	} else {
+		const double Dm = D[0] / (mu * mu * (1 + mu * mu)), NmT = N - mu * T;
+		force[0] = -Dm * NmT * mu;
+		for (int j = 1; j < 6; j++)
+			if (j < dim) force[j] = -force[0] / T * U[j] * fri[j - 1];
+	}
+}
+
+// res += sum_a AR[i + a] * d[a] with a statically indexed AR for a wave-uniform, dynamic i (a switch over the 64 rows)
+#define MJB_APPLY_CASE(I)                                                                      \
+	case I:                                                                                    \
+		res += AR[I] * d[0];                                                                   \
+		if (multi) {                                                                           \
+			res += AR[(I) + 1 < 64 ? (I) + 1 : 63] * ((I) + 1 < 64 ? d[1] : 0.0);              \
+			res += AR[(I) + 2 < 64 ? (I) + 2 : 63] * ((I) + 2 < 64 ? d[2] : 0.0);              \
+			res += AR[(I) + 3 < 64 ? (I) + 3 : 63] * ((I) + 3 < 64 ? d[3] : 0.0);              \
+			res += AR[(I) + 4 < 64 ? (I) + 4 : 63] * ((I) + 4 < 64 ? d[4] : 0.0);              \
+			res += AR[(I) + 5 < 64 ? (I) + 5 : 63] * ((I) + 5 < 64 ? d[5] : 0.0);              \
+		}                                                                                      \
+		break;
+#define MJB_APPLY_CASE4(I) MJB_APPLY_CASE(I) MJB_APPLY_CASE((I) + 1) MJB_APPLY_CASE((I) + 2) MJB_APPLY_CASE((I) + 3)
+#define MJB_APPLY_CASE16(I) MJB_APPLY_CASE4(I) MJB_APPLY_CASE4((I) + 4) MJB_APPLY_CASE4((I) + 8) MJB_APPLY_CASE4((I) + 12)
+DEVI void pgs_apply_rows(const double (&AR)[64], const int i, const double (&d)[6], const bool multi, double &res)
+{
+	switch (i) {
+		MJB_APPLY_CASE16(0) MJB_APPLY_CASE16(16) MJB_APPLY_CASE16(32) MJB_APPLY_CASE16(48)
+	default: break;
+	}
+}
+
+// one sweep over a model with elliptic contacts: scalar rows as in pgs_sweep, contacts as blocks; forces updated in place
+DEVI void pgs_sweep_elliptic(const double (&AR)[64], const int nefc, const int lane, const double lo, const double hi,
+                             const double ARinv, const int rtype, const int rcon, const int rdim, double &res, double &frc,
+                             const double *Hc, const double *cfriction)
+{
+	int i = 0;
+#pragma nounroll
+	while (i < nefc) {
+		const int ti = __builtin_amdgcn_readlane(rtype, i);
+		double d[6] = { 0, 0, 0, 0, 0, 0 };
+		if (ti != MJB_CNSTR_CONTACT_ELLIPTIC) {
+			MJB_KEEP_BRANCH();
+			const double fn = __builtin_fmin(__builtin_fmax(frc - res * ARinv, lo), hi);
+			const double delta = fn - frc;
+			d[0] = wave_bcast(delta, i);
+			pgs_apply_rows(AR, i, d, false, res);
+			if (lane == i) frc += delta;
+			i++;
+		} else {
+			MJB_KEEP_BRANCH();
+			const int con = __builtin_amdgcn_readlane(rcon, i), dim = __builtin_amdgcn_readlane(rdim, i);
+			double fc[6], rb[6], old[6];
+#pragma unroll
+			for (int a = 0; a < 6; a++) {
+				const int src = i + a < 64 ? i + a : 63;
+				rb[a] = a < dim ? wave_bcast(res, src) : 0.0;
+				fc[a] = a < dim ? wave_bcast(frc, src) : 0.0;
+				old[a] = fc[a];
+			}
+			const double *Ac = Hc + 36 * con, *mu5 = cfriction + 5 * con;
+			if (dim == 3) pgs_cone_block<3>(fc, rb, Ac, mu5);
+			else if (dim == 4) pgs_cone_block<4>(fc, rb, Ac, mu5);
+			else pgs_cone_block<6>(fc, rb, Ac, mu5);
+			// the reference's guard: an update that raises the block cost 0.5 d'Ac d + d'res by more than 1e-10 is dropped
+			double change = 0;
+#pragma unroll
+			for (int a = 0; a < 6; a++) {
+				d[a] = a < dim ? fc[a] - old[a] : 0.0;
+			}
+#pragma unroll
+			for (int a = 0; a < 6; a++) {
+				double sa = 0;
+#pragma unroll
+				for (int c = 0; c < 6; c++) sa += (a < dim && c < dim) ? Ac[6 * a + c] * d[c] : 0.0;
+				change += 0.5 * d[a] * sa + d[a] * rb[a];
+			}
+			if (!(change > 1e-10)) {
+				MJB_KEEP_BRANCH();
+				pgs_apply_rows(AR, i, d, true, res);
+#pragma unroll
+				for (int a = 0; a < 6; a++)
+					if (lane == i + a) frc += d[a];
+			}
+			i += dim;
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
 // A13 constraint solve: warmstart + projected Gauss-Seidel (dual), one env per wavefront
 // ------------------------------------------------------------------------------------------------
-template <int G> STAGE void fwd_constraint_pgs(CModel m, CLayout L, const Env &e)
+template <int G, bool ELL> STAGE void fwd_constraint_pgs(CModel m, CLayout L, const Env &e)
 {
 	static_assert(G == 64, "the constraint solver maps rows to the 64 lanes of one wavefront");
 	double *f = e.f;
@@ -1246,6 +1492,13 @@ template <int G> STAGE void fwd_constraint_pgs(CModel m, CLayout L, const Env &e
 	const bool bilateral = rowact && fi[L.efc_type + r] == MJB_CNSTR_EQUALITY;
 	const double floss = (rowact && m.nfriction > 0) ? f[L.efc_frictionloss + r] : 0.0;  // > 0: dry-friction row (dof or tendon)
 	const bool friction = floss > 0;
+	// elliptic cones (uniform per model): a contact's rows are consecutive lanes starting at its leader row i0
+	const bool ellmodel = ELL;  // (own kernel variant: the plain PGS kernel carries none of the block code)
+	const int rtype = rowact ? fi[L.efc_type + r] : -1;
+	const bool ell = ellmodel && rtype == MJB_CNSTR_CONTACT_ELLIPTIC;
+	const int rcon = ell ? fi[L.efc_id + r] : 0;
+	const int rdim = ell ? fi[L.contact_dim + rcon] : 0, ri0 = ell ? fi[L.contact_efc_address + rcon] : 0;
+	double *Hc = f + L.nwt_hc;  // [36 nconmax] the contacts' diagonal blocks of AR (allocated for PGS + elliptic)
 	double b = 0, Aii = 1, ARinv = 0, frc = 0;
 	{
 		double jq = 0, jb = 0, jw = 0;
@@ -1265,8 +1518,28 @@ template <int G> STAGE void fwd_constraint_pgs(CModel m, CLayout L, const Env &e
 				const double jar = jw - aref;
 				frc = (jar < 0 || bilateral || friction) ? -f[L.efc_D + r] * jar : 0.0;
 				if (friction) frc = __builtin_fmin(__builtin_fmax(frc, -floss), floss);
+				if (ellmodel) f[L.efc_force + r] = ell ? jar : frc;  // (cone rows: jar parked for the contact's leader)
 			}
 		}
+	}
+	if (ellmodel && !(m.disableflags & MJB_DSBL_WARMSTART)) {
+		// warmstart forces of whole contacts from the primal cone update (mj_constraintUpdate), by the leader lanes
+		MJB_KEEP_BRANCH();
+		gsync<G>();
+		if (ell && ri0 == r) {
+			double jar6[6], D6[6], fo[6];
+			for (int a = 0; a < 6; a++) {
+				jar6[a] = a < rdim ? f[L.efc_force + r + a] : 0.0;
+				D6[a] = a < rdim ? f[L.efc_D + r + a] : 0.0;
+				fo[a] = 0;
+			}
+			const double *cfri = f + L.contact_friction + 5 * rcon;
+			cone_force(cfri[0] / sqrt(fmax(MJB_MINVAL, m.impratio[0])), cfri, D6, rdim, jar6, fo);
+			for (int a = 0; a < 6; a++)
+				if (a < rdim) f[L.efc_force + r + a] = fo[a];
+		}
+		gsync<G>();
+		if (ell) frc = f[L.efc_force + r];
 	}
 	// AR[i] = J_r . B_i: k outermost so that the 64 accumulators are independent (every load of one k is in flight
 	// together); row groups beyond nefc accumulate stale rows and are zeroed afterwards
@@ -1288,6 +1561,13 @@ template <int G> STAGE void fwd_constraint_pgs(CModel m, CLayout L, const Env &e
 	}
 #pragma unroll
 	for (int i = 0; i < 64; i++) AR[i] = (rowact && i < nefc) ? (lane == i ? Aii : AR[i]) : 0.0;
+	if (ellmodel) {  // the contacts' diagonal blocks, for the block updates: row r of contact c -> Hc[36 c + 6 (r - i0) + .]
+		MJB_KEEP_BRANCH();
+#pragma unroll
+		for (int i = 0; i < 64; i++)
+			if (ell && i >= ri0 && i < ri0 + rdim) Hc[36 * rcon + 6 * (r - ri0) + (i - ri0)] = AR[i];
+		gsync<G>();
+	}
 	// residual of the warmstart forces, res = b + AR f, and their cost 0.5 f'ARf + f'b = sum_i 0.5 f_i (res_i + b_i)
 	double res = b;
 #pragma unroll
@@ -1311,7 +1591,10 @@ template <int G> STAGE void fwd_constraint_pgs(CModel m, CLayout L, const Env &e
 	int iter = 0;
 	while (iter < m.iterations) {
 		double dvec = 0;
-		if (m.nfriction > 0) {
+		if (ellmodel) {
+			MJB_KEEP_BRANCH();
+			pgs_sweep_elliptic(AR, nefc, lane, lo, hi, ARinv, rtype, rcon, rdim, res, frc, Hc, f + L.contact_friction);
+		} else if (m.nfriction > 0) {
 			MJB_KEEP_BRANCH();
 			pgs_sweep<true>(AR, nefc, lo, hi, ARinv, res, frc, dvec);
 		} else {

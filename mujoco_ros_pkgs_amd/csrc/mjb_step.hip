@@ -1672,7 +1672,7 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 		PROF(16);
 		VIEW(P, compact, make_constraint<G>(m, L, e));
 		PROF(17);
-		if constexpr (CON == 1) {
+		if constexpr (CON == 1 || CON == 5) {
 			if (P->m.nv <= 16) VIEW(P, compact, project_constraint_dense16<G>(m, L, e));
 			else VIEW(P, compact, project_constraint<G>(m, L, e));
 		}
@@ -1701,10 +1701,10 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 	PROF(9);
 	VIEW(P, compact, fwd_acceleration<G, (CON != 0 ? -1 : DENSE)>(m, L, e, s.use_xfrc != 0));
 	PROF(10);
-	if constexpr (CON >= 2 && G == 64) {
+	if constexpr (CON >= 2 && CON <= 4 && G == 64) {
 		VIEW(P, compact, fwd_constraint_newton<G, (CON == 2 ? 1 : (CON == 3 ? 2 : 4))>(m, L, e));
-	} else if constexpr (CON == 1 && G == 64) {
-		VIEW(P, compact, fwd_constraint_pgs<G>(m, L, e));
+	} else if constexpr ((CON == 1 || CON == 5) && G == 64) {
+		VIEW(P, compact, fwd_constraint_pgs<G, (CON == 5)>(m, L, e));
 	} else {
 		VIEW(P, compact, fwd_constraint<G>(m, L, e));
 	}
@@ -1796,7 +1796,7 @@ template <int G> STAGE void ctrl_noise(CModel m, CLayout L, CNoise nz, const Env
 // ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
-// CON: 0 = model without constraint rows; 1 = PGS, 2 / 3 / 4 = Newton with 1 / 2 / 4 rows per lane (collision / rows / solver stages compiled in;
+// CON: 0 = model without constraint rows; 1 = PGS (5 = PGS with elliptic cone blocks), 2 / 3 / 4 = Newton with 1 / 2 / 4 rows per lane (collision / rows / solver stages compiled in;
 // one env per wavefront) -- separate kernels keep each instruction stream and register budget small.
 // Constrained kernels get the full 512-register budget (1 block of 256 per CU by registers; their frames limit the
 // CU to 1 - 4 envs anyway): no spills, and room for the register-resident AR rows / Hessian rows of the solvers.
@@ -2008,6 +2008,7 @@ int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, in
 		if (constrained == 2) return launch_g<64, 2>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 		if (constrained == 3) return launch_g<64, 3>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 		if (constrained == 4) return launch_g<64, 4>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+		if (constrained == 5) return launch_g<64, 5>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 		return launch_g<64, 1>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 	}
 	switch (lanes_per_env) {

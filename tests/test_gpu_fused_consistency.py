@@ -21,7 +21,7 @@ STATE = ["qpos", "qvel", "qacc", "qacc_warmstart", "sensordata", "ctrl", "time"]
 
 def _variants():
     out = [("franka_like", None, lanes) for lanes in (8, 16, 32, 64)]
-    out += [("franka_table", s, 64) for s in ("PGS", "Newton", "Newton-elliptic")]
+    out += [("franka_table", s, 64) for s in ("PGS", "PGS-elliptic", "Newton", "Newton-elliptic")]
     out += [("shadow_hand_like", "hand-128", 64), ("shadow_hand_like", "hand-160", 64)]
     return out
 
@@ -32,8 +32,8 @@ def _model(name, solver):
         return mjcf.load_asset(name)
     if solver.startswith("hand-"):
         return mjcf.load_asset(name, nefcmax=int(solver[5:]))
-    over = {"solver": "Newton"}
-    if solver == "Newton-elliptic":
+    over = {"solver": solver.split("-")[0]}
+    if solver.endswith("-elliptic"):
         over["cone"] = "elliptic"
     return mjcf.compile_xml_file(os.path.join(mjcf.ASSET_DIR, name + ".xml"), override=over)
 
