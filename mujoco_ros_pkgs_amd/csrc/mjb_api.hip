@@ -161,6 +161,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	for (const FieldInfo &fi : kFields) {
 		int n = dim(fi);
 		if (idx == MJB_F_efc_AR) n = 0;  // the GPU solver is AR-free
+		if (idx == MJB_F_efc_frictionloss && M->nfriction == 0) n = 0;  // no dry-friction rows in this model
 		if (idx == MJB_F_efc_B && d.solver == MJB_SOL_NEWTON) n = 0;  // the primal solver needs no J M^-1
 		if (!compact) M->field_size[idx] = n;
 		if ((idx == MJB_F_cfrc_int || idx == MJB_F_cfrc_ext) && !need_post) n = 0;  // computed only when a sensor needs them

@@ -1832,7 +1832,7 @@ __global__ void __launch_bounds__(256, (CON ? 1 : (G == 64 ? 4 : (G == 32 ? 2 : 
 #pragma unroll
 		for (int i = 0; i < 16; i++) e.dadr[i] = (m.nv <= 16 && e.lane < 16) ? m.M_dense[16 * i + (e.lane & 15)] : -1;
 	}
-	if constexpr (DENSE != 0) {
+	if constexpr (DENSE != 0) {  // (tried in the constrained kernels too: no gain, the PGS kernel loses 8 % to register pressure)
 		const int b = e.lane < m.nbody ? e.lane : 0;
 		LaneConst &c = e.lc;
 		c.dmlo = (unsigned int)m.body_dofmask[2 * b]; c.dmhi = (unsigned int)m.body_dofmask[2 * b + 1];
