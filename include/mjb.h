@@ -215,6 +215,10 @@ void *mjb_sensor_device_ptr(mjb_batch *b, int which);
  * (Mass / size / type changes need mj_setConst per env and are not implemented.) */
 int mjb_set_env_gravity(mjb_batch *b, int env_lo, int env_hi, const double *gravity);
 int mjb_set_env_geom_friction(mjb_batch *b, int env_lo, int env_hi, const double *friction);
+/* setEqualityConstraintParameters (/root/reference mujoco_ros/src/callbacks.cpp:641-884: active flag, solref, solimp and the
+ * type's data -- anchor / relpose / torquescale / polycoef) per env: params[env][neq][19] =
+ * { active (0 / 1), eq_data[11], solref[2], solimp[5] } for every equality of the model, in model order. */
+int mjb_set_env_equality(mjb_batch *b, int env_lo, int env_hi, const double *params);
 
 /* ---- device-side DefaultRobotHWSim::writeSim ----
  * The reference's ros_control bridge writes the controllers' joint commands into mjData on every control callback

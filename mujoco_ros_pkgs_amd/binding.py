@@ -143,6 +143,7 @@ def load_library(path=None):
         "mjb_set_keep_frame": (ci, [vp, ci]),
         "mjb_set_env_gravity": (ci, [vp, ci, ci, C.POINTER(cd)]),
         "mjb_set_env_geom_friction": (ci, [vp, ci, ci, C.POINTER(cd)]),
+        "mjb_set_env_equality": (ci, [vp, ci, ci, C.POINTER(cd)]),
         "mjb_hwsim_configure": (ci, [vp, ci, C.POINTER(HwsimJoint)]),
         "mjb_hwsim_set_command": (ci, [vp, ci, ci, ci, C.POINTER(cd)]),
         "mjb_hwsim_command_ptr": (vp, [vp, ci]),

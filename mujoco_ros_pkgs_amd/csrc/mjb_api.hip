@@ -108,7 +108,7 @@ struct mjb_batch {
 	double *sens_mean_dev = nullptr, *sens_sigma_dev = nullptr;
 	float *sens_value = nullptr, *sens_truth = nullptr;
 	bool sens_dirty = true, sens_packed = false;
-	double *env_gravity = nullptr, *env_geom_friction = nullptr;  // per-env model parameter overrides (mjb_set_env_*)
+	double *env_gravity = nullptr, *env_geom_friction = nullptr, *env_equality = nullptr;  // per-env model parameter overrides (mjb_set_env_*)
 	// device-side DefaultRobotHWSim (mjb_hwsim_*)
 	HwSim hw{};
 	int *hw_ints = nullptr;        // joint | method | kind | antiwindup, [4][n]
@@ -198,6 +198,8 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	off += 3;
 	L.gfriction = off;
 	off += d.nconmax > 0 ? 3 * d.ngeom : 0;
+	L.eqparam = off;
+	off += 19 * d.neq;
 	L.cwrench = off;
 	off += need_post ? 6 * d.nconmax : 0;
 	L.MhB = off;
@@ -645,6 +647,7 @@ void mjb_free_batch(mjb_batch *b)
 	if (b->params_dev) hipFree(b->params_dev);
 	if (b->env_gravity) hipFree(b->env_gravity);
 	if (b->env_geom_friction) hipFree(b->env_geom_friction);
+	if (b->env_equality) hipFree(b->env_equality);
 	if (b->hw_ints) hipFree(b->hw_ints);
 	if (b->hw_gains) hipFree(b->hw_gains);
 	if (b->hw_cmd) hipFree(b->hw_cmd);
@@ -795,6 +798,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	s.use_xfrc = 0;
 	s.env_gravity = nullptr;
 	s.env_geom_friction = nullptr;
+	s.env_equality = nullptr;
 	s.keep_frame = 0;
 	s.pad1 = 0;
 	if (!ok) {
@@ -1179,6 +1183,21 @@ int mjb_set_env_geom_friction(mjb_batch *b, int env_lo, int env_hi, const double
 	const mjb_model_desc &h = b->model->h;
 	return env_param(b, &b->env_geom_friction, &b->st.env_geom_friction, h.nconmax > 0 ? 3 * h.ngeom : 0, h.geom_friction, env_lo,
 	                 env_hi, friction, "mjb_set_env_geom_friction");
+}
+
+int mjb_set_env_equality(mjb_batch *b, int env_lo, int env_hi, const double *params)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	const mjb_model_desc &h = b->model->h;
+	std::vector<double> packed((size_t)19 * (h.neq > 0 ? h.neq : 1));
+	for (int q = 0; q < h.neq; q++) {
+		double *o = packed.data() + 19 * q;
+		o[0] = h.eq_active[q] ? 1.0 : 0.0;
+		for (int k = 0; k < 11; k++) o[1 + k] = h.eq_data[11 * q + k];
+		for (int k = 0; k < 2; k++) o[12 + k] = h.eq_solref[2 * q + k];
+		for (int k = 0; k < 5; k++) o[14 + k] = h.eq_solimp[5 * q + k];
+	}
+	return env_param(b, &b->env_equality, &b->st.env_equality, 19 * h.neq, packed.data(), env_lo, env_hi, params, "mjb_set_env_equality");
 }
 
 // ---- device-side DefaultRobotHWSim::writeSim (stage hwsim_write in mjb_step.hip) ----

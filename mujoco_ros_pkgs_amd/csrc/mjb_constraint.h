@@ -705,8 +705,8 @@ DEVI void eq_geometry(CModel m, CLayout L, const double *f, int e, EqGeom &g)
 	const int type = m.eq_type[e], id0 = m.eq_obj1id[e], id1 = m.eq_obj2id[e];
 	double a0[3], a1[3], M0[9], M1[9];
 	for (int k = 0; k < 3; k++) {
-		a0[k] = m.eq_data[11 * e + (type == MJB_EQ_CONNECT ? 0 : 3) + k];
-		a1[k] = m.eq_data[11 * e + (type == MJB_EQ_CONNECT ? 3 : 0) + k];
+		a0[k] = f[L.eqparam + 19 * e + 1 + (type == MJB_EQ_CONNECT ? 0 : 3) + k];
+		a1[k] = f[L.eqparam + 19 * e + 1 + (type == MJB_EQ_CONNECT ? 3 : 0) + k];
 	}
 	ld9(M0, f + L.xmat + 9 * id0);
 	ld9(M1, f + L.xmat + 9 * id1);
@@ -720,7 +720,7 @@ DEVI void eq_geometry(CModel m, CLayout L, const double *f, int e, EqGeom &g)
 		double q0[4], rel[4];
 		for (int k = 0; k < 4; k++) {
 			q0[k] = f[L.xquat + 4 * id0 + k];
-			rel[k] = m.eq_data[11 * e + 6 + k];
+			rel[k] = f[L.eqparam + 19 * e + 1 + 6 + k];
 		}
 		qmul(g.quat, q0, rel);
 		g.quat1[0] = f[L.xquat + 4 * id1];
@@ -753,7 +753,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 	for (int it = lane; it < nitem; it += G) {
 		int n = 0;
 		if (it < neq) {
-			if (m.eq_active[it]) n = m.eq_type[it] == MJB_EQ_CONNECT ? 3 : (m.eq_type[it] == MJB_EQ_WELD ? 6 : 1);  // joint, tendon: 1
+			if (f[L.eqparam + 19 * it] != 0) n = m.eq_type[it] == MJB_EQ_CONNECT ? 3 : (m.eq_type[it] == MJB_EQ_WELD ? 6 : 1);  // joint, tendon: 1
 		} else if (it < neq + nfr) {
 			n = (it < neq + nfd ? m.dof_frictionloss[it - neq] : m.tendon_frictionloss[it - neq - nfd]) > 0 ? 1 : 0;
 		} else if (it < neq + nfr + m.njnt) {
@@ -807,7 +807,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 				const int a1 = m.jnt_qposadr[id0], d1 = m.jnt_dofadr[id0];
 				const double *pc = nullptr;
 				double c5[5];
-				for (int k = 0; k < 5; k++) c5[k] = m.eq_data[11 * eq + k];
+				for (int k = 0; k < 5; k++) c5[k] = f[L.eqparam + 19 * eq + 1 + k];
 				(void)pc;
 				double poly = c5[0], deriv = 0;
 				double *row = f + L.efc_J + off * nv;
@@ -825,7 +825,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 				cpos[0] = f[L.qpos + a1] - m.qpos0[a1] - poly;
 			} else if (type == MJB_EQ_TENDON) {
 				double c5[5];
-				for (int k = 0; k < 5; k++) c5[k] = m.eq_data[11 * eq + k];
+				for (int k = 0; k < 5; k++) c5[k] = f[L.eqparam + 19 * eq + 1 + k];
 				double poly = c5[0], deriv = 0;
 				double *row = f + L.efc_J + off * nv;
 				for (int k = 0; k < nv; k++) row[k] = 0;
@@ -848,7 +848,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 				const double tran = m.body_invweight0[2 * id0] + m.body_invweight0[2 * id1];
 				diag[0] = diag[1] = diag[2] = tran;
 				if (type == MJB_EQ_WELD) {
-					const double ts = m.eq_data[11 * eq + 10];
+					const double ts = f[L.eqparam + 19 * eq + 1 + 10];
 					double q2[4];
 					qmul(q2, g.quat1, g.quat);
 					for (int k = 0; k < 3; k++) cpos[3 + k] = ts * q2[1 + k];
@@ -858,9 +858,9 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 			double nrm = 0;
 			for (int k = 0; k < 6; k++) nrm += cpos[k] * cpos[k];
 			nrm = sqrt(nrm);
-			const double solref[2] = { m.eq_solref[2 * eq], m.eq_solref[2 * eq + 1] };
+			const double solref[2] = { f[L.eqparam + 19 * eq + 12], f[L.eqparam + 19 * eq + 13] };
 			double solimp[5];
-			for (int k = 0; k < 5; k++) solimp[k] = m.eq_solimp[5 * eq + k];
+			for (int k = 0; k < 5; k++) solimp[k] = f[L.eqparam + 19 * eq + 14 + k];
 			for (int k = 0; k < 6; k++) {
 				if (k >= n) break;
 				row_params_x(m, L, f, off + k, cpos[k], 0.0, solref, solimp, diag[k], n > 1 ? nrm : cpos[0]);
@@ -1008,7 +1008,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 		}
 		for (int k = 0; k < 3; k++) f[L.efc_J + (adr + k) * nv + i] = jp[k];
 		if (type == MJB_EQ_WELD) {
-			const double ts = m.eq_data[11 * eq + 10];
+			const double ts = f[L.eqparam + 19 * eq + 1 + 10];
 			const double *q = g.quat1;
 			const double qa[4] = { -q[1] * jr[0] - q[2] * jr[1] - q[3] * jr[2], q[0] * jr[0] + q[2] * jr[2] - q[3] * jr[1],
 				                   q[0] * jr[1] + q[3] * jr[0] - q[1] * jr[2], q[0] * jr[2] + q[1] * jr[1] - q[2] * jr[0] };

@@ -77,6 +77,7 @@ struct FrameLayout {
 	int iscratch;  // transient int scratch: max(ncollpair, njnt + nconmax)
 	int gravity;   // [3] this env's gravity (model value or per-env override, loaded with the state)
 	int gfriction; // [3*ngeom] this env's geom friction (models with contacts only)
+	int eqparam;   // [19*neq] this env's equality parameters: active | eq_data[11] | solref[2] | solimp[5] per equality
 	int cwrench;  // [nconmax][6] world contact wrenches (rne_post scratch)
 	int kinloc;    // [7*nbody] kinematics: pose of each body in its parent frame (transient)
 	int crbbuf;    // [6*nv]    crb: crb[body(i)] * cdof_i (transient)
@@ -104,6 +105,7 @@ struct DevState {
 	int frame_stride;              // doubles per env in frame_ws
 	const double *env_gravity;       // [nenv][3] per-env gravity override (NULL: the model's)
 	const double *env_geom_friction; // [nenv][ngeom][3] per-env geom friction override (NULL: the model's)
+	const double *env_equality;      // [nenv][neq][19] per-env equality parameters (NULL: the model's)
 	int use_xfrc;                  // xfrc_applied has ever been written
 	int keep_frame;                // fused mjb_step also dumps the last step's full frame to frame_ws
 	int pad1;

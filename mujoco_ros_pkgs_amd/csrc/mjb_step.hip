@@ -1569,6 +1569,17 @@ template <int G> STAGE void load_state(CModel m, CLayout L, CState s, const Env 
 	if (m.nconmax > 0)
 		for (int k = e.lane; k < 3 * m.ngeom; k += G)
 			e.f[L.gfriction + k] = s.env_geom_friction ? s.env_geom_friction[env * 3 * m.ngeom + k] : m.geom_friction[k];
+	// equality parameters (active | data | solref | solimp): the model's or this env's (mjb_set_env_equality)
+	for (int k = e.lane; k < 19 * m.neq; k += G) {
+		const int q = k / 19, j = k - 19 * q;
+		double v;
+		if (s.env_equality) v = s.env_equality[env * 19 * m.neq + k];
+		else if (j == 0) v = m.eq_active[q] ? 1.0 : 0.0;
+		else if (j < 12) v = m.eq_data[11 * q + j - 1];
+		else if (j < 14) v = m.eq_solref[2 * q + j - 12];
+		else v = m.eq_solimp[5 * q + j - 14];
+		e.f[L.eqparam + k] = v;
+	}
 }
 
 template <int G> STAGE void store_state(CModel m, CLayout L, CState s, const Env &e)

@@ -117,6 +117,19 @@ class Batch:
         _check(self.lib.mjb_set_env_geom_friction(self.ptr, lo, hi, a.ctypes.data_as(C.POINTER(C.c_double))),
                "mjb_set_env_geom_friction")
 
+    def set_env_equality(self, active=None, data=None, solref=None, solimp=None, lo=0, hi=None):
+        """Per-env equality parameters (setEqualityConstraintParameters per env).  Each argument is None (the model's
+        values) or an array [hi-lo, neq(, 11 | 2 | 5)]."""
+        hi = self.nenv if hi is None else hi
+        m, n, neq = self.cm.model, hi - lo, int(self.cm.model["neq"])
+        p = np.zeros((n, neq, 19))
+        p[:, :, 0] = np.asarray(m["eq_active"], dtype=np.float64) if active is None else np.asarray(active, dtype=np.float64).reshape(n, neq)
+        p[:, :, 1:12] = np.asarray(m["eq_data"]).reshape(neq, 11) if data is None else np.asarray(data, dtype=np.float64).reshape(n, neq, 11)
+        p[:, :, 12:14] = np.asarray(m["eq_solref"]).reshape(neq, 2) if solref is None else np.asarray(solref, dtype=np.float64).reshape(n, neq, 2)
+        p[:, :, 14:19] = np.asarray(m["eq_solimp"]).reshape(neq, 5) if solimp is None else np.asarray(solimp, dtype=np.float64).reshape(n, neq, 5)
+        p = np.ascontiguousarray(p)
+        _check(self.lib.mjb_set_env_equality(self.ptr, lo, hi, p.ctypes.data_as(C.POINTER(C.c_double))), "mjb_set_env_equality")
+
     # ---- device-side DefaultRobotHWSim (mjb_hwsim_*) ----
     def hwsim_configure(self, joints):
         """joints: list of dicts(joint=<id>, method=..., kind=..., p, i, d, i_max, i_min, antiwindup, effort_limit, lower, upper)."""

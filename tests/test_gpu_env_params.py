@@ -40,3 +40,39 @@ def test_per_env_gravity_and_friction(oracle_built):
     # the overrides matter: the floating env kept its cube where it was, the default env dropped / settled it
     assert abs(b.get("qpos")[1, 2] - qpos[1, 2]) < 0.02 and not np.allclose(b.get("qpos")[0], b.get("qpos")[1])
     b.close()
+
+
+def test_per_env_equality_parameters(oracle_built):
+    """setEqualityConstraintParameters per env on the shipped equality world: one env with a constraint switched off,
+    one with a moved anchor / stiffer solref, the rest untouched -- each must match the oracle on the edited model."""
+    from mujoco_ros_pkgs_amd import engine
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    base = mjcf.compile_xml_file(os.path.join(golden, "equality_world.xml"))
+    neq = int(base["neq"])
+    assert neq >= 2
+    cm = engine.CompiledModel(base)
+    nenv = 4
+    rng = np.random.default_rng(2)
+    qpos = np.tile(base["qpos0"], (nenv, 1))
+    qvel = rng.uniform(-0.05, 0.05, (nenv, base["nv"]))
+    active = np.tile(np.asarray(base["eq_active"], dtype=np.float64), (nenv, 1))
+    data = np.tile(np.asarray(base["eq_data"], dtype=np.float64).reshape(1, neq, 11), (nenv, 1, 1))
+    solref = np.tile(np.asarray(base["eq_solref"], dtype=np.float64).reshape(1, neq, 2), (nenv, 1, 1))
+    active[1, 0] = 0                      # env 1: first equality released
+    data[2, 1, 0:3] += [0.01, -0.02, 0.0]  # env 2: second equality's anchor / first data entries moved
+    solref[2, :, 0] = 0.005                # ... and every equality stiffer
+    active[3, :] = 0                       # env 3: everything released
+    b = engine.Batch(cm, nenv)
+    b.set("qpos", qpos)
+    b.set("qvel", qvel)
+    b.set_env_equality(active=active[1:], data=data[1:], solref=solref[1:], lo=1, hi=nenv)
+    b.step(60)
+    for e in range(nenv):
+        m = mjcf.Model(dict(base))
+        m["eq_active"] = active[e].astype(np.int32)
+        m["eq_data"] = data[e].copy()
+        m["eq_solref"] = solref[e].copy()
+        oq, ov, _ = oracle_built.rollout(m, qpos[e:e + 1], qvel[e:e + 1], 60)
+        np.testing.assert_allclose(b.get("qpos")[e], oq[0], rtol=0, atol=1e-6, err_msg=f"env {e}")
+    assert not np.allclose(b.get("qpos")[0], b.get("qpos")[1], atol=1e-5)  # the released constraint matters
+    b.close()
