@@ -160,7 +160,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	M->need_rnepost = need_post ? 1 : 0;
 	for (const FieldInfo &fi : kFields) {
 		int n = dim(fi);
-		if (idx == MJB_F_efc_AR) n = 0;  // the GPU solver is AR-free
+		if (idx == MJB_F_efc_AR) n = 0;  // (the PGS kernel keeps each row of AR in its lane's registers)
 		if (idx == MJB_F_efc_frictionloss && M->nfriction == 0) n = 0;  // no dry-friction rows in this model
 		if (idx == MJB_F_efc_B && d.solver == MJB_SOL_NEWTON) n = 0;  // the primal solver needs no J M^-1
 		if (!compact) M->field_size[idx] = n;
