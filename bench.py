@@ -185,6 +185,7 @@ def main():
 
     # sanity: state still finite (non-finite envs are auto-reset and counted by the engine)
     finite = bool(np.all(np.isfinite(batch.get("qpos"))))
+    resets = batch.warning_count()  # mj_check* auto-resets since the batch was made (must be 0 on config 2)
 
     # dominant-kernel duration measured with HIP events on the engine's own stream
     kern_ms = batch.time_steps(S, max(1, min(args.steps, 5)))
@@ -217,7 +218,7 @@ def main():
                        "solver": {0: "PGS", 1: "CG", 2: "Newton"}[int(model["solver"])] if model["nefcmax"] else "none",
                        "ctrl": f"on-device OU noise (Philox seed 12345, tau 0.1 s, std {noise_std:g})",
                        "parallelism": f"env-sharded x{world}, RCCL all-gather of sensordata per launch" if world > 1
-                       else "single GPU", "state_finite": finite},
+                       else "single GPU", "state_finite": finite, "auto_resets": resets},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mjb_step_kernel", "kernel_ms": kern_ms,

@@ -101,7 +101,11 @@ def test_internal_identities(oracle_built, franka):
         x = rng.normal(size=nv)
         np.testing.assert_allclose(M @ d.solve_m(x), x, atol=1e-11)
         np.testing.assert_allclose(d.qfrc_smooth, d.qfrc_passive - d.qfrc_bias + d.qfrc_actuator, atol=1e-13)
-        np.testing.assert_allclose(d.qfrc_passive, -np.asarray(franka["dof_damping"]) * d.qvel, atol=1e-14)
+        spring = np.zeros(nv)  # (the finger slides carry a centring spring: -k (q - springref))
+        for j in range(franka["njnt"]):
+            qa, da = franka["jnt_qposadr"][j], franka["jnt_dofadr"][j]
+            spring[da] = -franka["jnt_stiffness"][j] * (d.qpos[qa] - franka["qpos_spring"][qa])
+        np.testing.assert_allclose(d.qfrc_passive, spring - np.asarray(franka["dof_damping"]) * d.qvel, atol=1e-12)
         s = d.sensordata
         np.testing.assert_array_equal(s[:9], d.qpos)
         np.testing.assert_array_equal(s[9:18], d.qvel)
