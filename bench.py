@@ -125,6 +125,12 @@ def main():
         sys.exit(3)
     torch.cuda.set_device(local_rank)
     force_gather = os.environ.get("MJB_BENCH_FORCE_GATHER", "0") == "1"  # exercise the RCCL path on one GPU
+    # The contract is ONE JSON line on stdout: RCCL prints a version banner through C stdio (flushed at exit, i.e. after
+    # anything Python prints), so everything written to fd 1 from here on goes to stderr and the line is written to the
+    # saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if world > 1 or force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -228,7 +234,7 @@ def main():
             out["roofline"]["fp64"] = fp64  # second view: with K fused steps the kernel is VALU / latency bound
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, model, noise_std)
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if gather:
         if force_gather and rank == 0:
             batch.synchronize()
