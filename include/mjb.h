@@ -212,13 +212,20 @@ void *mjb_sensor_device_ptr(mjb_batch *b, int which);
  * The reference mutates its single mjModel through services (setGravity, setGeomProperties friction:
  * /root/reference mujoco_ros/src/callbacks.cpp:462-592, 641-884); in a batch every env may carry its own value (domain
  * randomisation).  Envs never written keep the model's value.  gravity: [env][3]; friction: [env][ngeom][3].
- * (Mass / size / type changes need mj_setConst per env and are not implemented.) */
+ * (Geom size / type changes are not implemented; masses: mjb_set_env_mass_params below.) */
 int mjb_set_env_gravity(mjb_batch *b, int env_lo, int env_hi, const double *gravity);
 int mjb_set_env_geom_friction(mjb_batch *b, int env_lo, int env_hi, const double *friction);
 /* setEqualityConstraintParameters (/root/reference mujoco_ros/src/callbacks.cpp:641-884: active flag, solref, solimp and the
  * type's data -- anchor / relpose / torquescale / polycoef) per env: params[env][neq][19] =
  * { active (0 / 1), eq_data[11], solref[2], solimp[5] } for every equality of the model, in model order. */
 int mjb_set_env_equality(mjb_batch *b, int env_lo, int env_hi, const double *params);
+/* setBodyState's mass (callbacks.cpp:210-370) followed by mj_setConst (:251-256): the engine takes, per env, the masses AND
+ * what mj_setConst derives from them -- the caller computes those (the reference has libmujoco: mj_setConst on a scratch
+ * mjModel; mujoco_ros_pkgs_amd/engine.py does it with its own numpy dynamics).  params[env][mjb_env_mass_stride(model)] =
+ * body_mass[nbody] | body_subtreemass[nbody] | body_inertia[nbody][3] | dof_invweight0[nv] | body_invweight0[nbody][2] |
+ * tendon_invweight0[ntendon] | meaninertia.  (Batches carrying these overrides run the generic kernels.) */
+int mjb_env_mass_stride(const mjb_model *m);
+int mjb_set_env_mass_params(mjb_batch *b, int env_lo, int env_hi, const double *params);
 
 /* ---- device-side DefaultRobotHWSim::writeSim ----
  * The reference's ros_control bridge writes the controllers' joint commands into mjData on every control callback

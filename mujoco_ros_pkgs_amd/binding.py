@@ -144,6 +144,8 @@ def load_library(path=None):
         "mjb_set_env_gravity": (ci, [vp, ci, ci, C.POINTER(cd)]),
         "mjb_set_env_geom_friction": (ci, [vp, ci, ci, C.POINTER(cd)]),
         "mjb_set_env_equality": (ci, [vp, ci, ci, C.POINTER(cd)]),
+        "mjb_env_mass_stride": (ci, [vp]),
+        "mjb_set_env_mass_params": (ci, [vp, ci, ci, C.POINTER(cd)]),
         "mjb_hwsim_configure": (ci, [vp, ci, C.POINTER(HwsimJoint)]),
         "mjb_hwsim_set_command": (ci, [vp, ci, ci, ci, C.POINTER(cd)]),
         "mjb_hwsim_command_ptr": (vp, [vp, ci]),

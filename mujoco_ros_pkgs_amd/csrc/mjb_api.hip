@@ -108,7 +108,7 @@ struct mjb_batch {
 	double *sens_mean_dev = nullptr, *sens_sigma_dev = nullptr;
 	float *sens_value = nullptr, *sens_truth = nullptr;
 	bool sens_dirty = true, sens_packed = false;
-	double *env_gravity = nullptr, *env_geom_friction = nullptr, *env_equality = nullptr;  // per-env model parameter overrides (mjb_set_env_*)
+	double *env_gravity = nullptr, *env_geom_friction = nullptr, *env_equality = nullptr, *env_mass = nullptr;  // per-env model parameter overrides (mjb_set_env_*)
 	// device-side DefaultRobotHWSim (mjb_hwsim_*)
 	HwSim hw{};
 	int *hw_ints = nullptr;        // joint | method | kind | antiwindup, [4][n]
@@ -648,6 +648,7 @@ void mjb_free_batch(mjb_batch *b)
 	if (b->env_gravity) hipFree(b->env_gravity);
 	if (b->env_geom_friction) hipFree(b->env_geom_friction);
 	if (b->env_equality) hipFree(b->env_equality);
+	if (b->env_mass) hipFree(b->env_mass);
 	if (b->hw_ints) hipFree(b->hw_ints);
 	if (b->hw_gains) hipFree(b->hw_gains);
 	if (b->hw_cmd) hipFree(b->hw_cmd);
@@ -799,6 +800,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	s.env_gravity = nullptr;
 	s.env_geom_friction = nullptr;
 	s.env_equality = nullptr;
+	s.env_mass = nullptr;
 	s.keep_frame = 0;
 	s.pad1 = 0;
 	if (!ok) {
@@ -888,7 +890,7 @@ static int launch(mjb_batch *b, int mode, int nsteps)
 	if (prc) return prc;
 	const bool compact = mode == MJB_MODE_STEP && !b->st.use_xfrc && !b->st.keep_frame;
 	int rc = mjb_launch_step(b->params_dev, compact ? b->model->Lc : b->L, b->nenv, mode, nsteps, b->step_counter, b->lanes,
-	                         b->epb, kernel_variant(b->model->h), (b->lanes == 16 && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, b->stream);
+	                         b->epb, kernel_variant(b->model->h), (b->lanes == 16 && !b->env_mass && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, b->stream);
 	if (rc != 0) return fail(MJB_ENODEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
 	return MJB_OK;
 }
@@ -1198,6 +1200,29 @@ int mjb_set_env_equality(mjb_batch *b, int env_lo, int env_hi, const double *par
 		for (int k = 0; k < 5; k++) o[14 + k] = h.eq_solimp[5 * q + k];
 	}
 	return env_param(b, &b->env_equality, &b->st.env_equality, 19 * h.neq, packed.data(), env_lo, env_hi, params, "mjb_set_env_equality");
+}
+
+int mjb_env_mass_stride(const mjb_model *m)
+{
+	if (!m) return fail(MJB_EINVAL, "null model");
+	return 7 * m->h.nbody + m->h.nv + m->h.ntendon + 1;
+}
+
+int mjb_set_env_mass_params(mjb_batch *b, int env_lo, int env_hi, const double *params)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	const mjb_model_desc &h = b->model->h;
+	const int n = 7 * h.nbody + h.nv + h.ntendon + 1;
+	std::vector<double> packed((size_t)n);
+	double *o = packed.data();
+	for (int i = 0; i < h.nbody; i++) o[i] = h.body_mass[i];
+	for (int i = 0; i < h.nbody; i++) o[h.nbody + i] = h.body_subtreemass[i];
+	for (int i = 0; i < 3 * h.nbody; i++) o[2 * h.nbody + i] = h.body_inertia[i];
+	for (int i = 0; i < h.nv; i++) o[5 * h.nbody + i] = h.dof_invweight0[i];
+	for (int i = 0; i < 2 * h.nbody; i++) o[5 * h.nbody + h.nv + i] = h.body_invweight0[i];
+	for (int i = 0; i < h.ntendon; i++) o[7 * h.nbody + h.nv + i] = h.tendon_invweight0[i];
+	o[7 * h.nbody + h.nv + h.ntendon] = h.meaninertia[0];
+	return env_param(b, &b->env_mass, &b->st.env_mass, n, packed.data(), env_lo, env_hi, params, "mjb_set_env_mass_params");
 }
 
 // ---- device-side DefaultRobotHWSim::writeSim (stage hwsim_write in mjb_step.hip) ----

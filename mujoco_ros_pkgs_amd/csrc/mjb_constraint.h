@@ -812,14 +812,14 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 				double poly = c5[0], deriv = 0;
 				double *row = f + L.efc_J + off * nv;
 				for (int k = 0; k < nv; k++) row[k] = 0;
-				diag[0] = m.dof_invweight0[d1];
+				diag[0] = MP_DOF_INVW(m, e, d1);
 				if (id1 >= 0) {
 					const int a2 = m.jnt_qposadr[id1], d2 = m.jnt_dofadr[id1];
 					const double x = f[L.qpos + a2] - m.qpos0[a2];
 					poly = c5[0] + x * (c5[1] + x * (c5[2] + x * (c5[3] + x * c5[4])));
 					deriv = c5[1] + x * (2 * c5[2] + x * (3 * c5[3] + x * 4 * c5[4]));
 					row[d2] = -deriv;
-					diag[0] += m.dof_invweight0[d2];
+					diag[0] += MP_DOF_INVW(m, e, d2);
 				}
 				row[d1] += 1;
 				cpos[0] = f[L.qpos + a1] - m.qpos0[a1] - poly;
@@ -829,14 +829,14 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 				double poly = c5[0], deriv = 0;
 				double *row = f + L.efc_J + off * nv;
 				for (int k = 0; k < nv; k++) row[k] = 0;
-				diag[0] = m.tendon_invweight0[id0];
+				diag[0] = MP_TEN_INVW(m, e, id0);
 				if (id1 >= 0) {
 					const double x = f[L.ten_length + id1] - m.tendon_length0[id1];
 					poly = c5[0] + x * (c5[1] + x * (c5[2] + x * (c5[3] + x * c5[4])));
 					deriv = c5[1] + x * (2 * c5[2] + x * (3 * c5[3] + x * 4 * c5[4]));
 					for (int w = m.tendon_adr[id1]; w < m.tendon_adr[id1] + m.tendon_num[id1]; w++)
 						row[m.jnt_dofadr[m.wrap_objid[w]]] -= deriv * m.wrap_prm[w];
-					diag[0] += m.tendon_invweight0[id1];
+					diag[0] += MP_TEN_INVW(m, e, id1);
 				}
 				for (int w = m.tendon_adr[id0]; w < m.tendon_adr[id0] + m.tendon_num[id0]; w++)
 					row[m.jnt_dofadr[m.wrap_objid[w]]] += m.wrap_prm[w];
@@ -845,14 +845,14 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 				EqGeom g;
 				eq_geometry(m, L, f, eq, g);
 				for (int k = 0; k < 3; k++) cpos[k] = g.pos0[k] - g.pos1[k];
-				const double tran = m.body_invweight0[2 * id0] + m.body_invweight0[2 * id1];
+				const double tran = MP_BODY_INVW(m, e, 2 * id0) + MP_BODY_INVW(m, e, 2 * id1);
 				diag[0] = diag[1] = diag[2] = tran;
 				if (type == MJB_EQ_WELD) {
 					const double ts = f[L.eqparam + 19 * eq + 1 + 10];
 					double q2[4];
 					qmul(q2, g.quat1, g.quat);
 					for (int k = 0; k < 3; k++) cpos[3 + k] = ts * q2[1 + k];
-					diag[3] = diag[4] = diag[5] = m.body_invweight0[2 * id0 + 1] + m.body_invweight0[2 * id1 + 1];
+					diag[3] = diag[4] = diag[5] = MP_BODY_INVW(m, e, 2 * id0 + 1) + MP_BODY_INVW(m, e, 2 * id1 + 1);
 				}
 			}
 			double nrm = 0;
@@ -884,7 +884,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 			const double solref[2] = { sr[0], sr[1] };
 			double solimp[5];
 			for (int k = 0; k < 5; k++) solimp[k] = si[k];
-			row_params(m, L, f, off, 0.0, 0.0, solref, solimp, isdof ? m.dof_invweight0[i] : m.tendon_invweight0[i]);
+			row_params(m, L, f, off, 0.0, 0.0, solref, solimp, isdof ? MP_DOF_INVW(m, e, i) : MP_TEN_INVW(m, e, i));
 			f[L.efc_frictionloss + off] = isdof ? m.dof_frictionloss[i] : m.tendon_frictionloss[i];
 			fi[L.efc_id + off] = i;
 			fi[L.efc_type + off] = isdof ? MJB_CNSTR_FRICTION_DOF : MJB_CNSTR_FRICTION_TENDON;
@@ -900,7 +900,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 					double *row = f + L.efc_J + r * nv;
 					for (int k = 0; k < nv; k++) row[k] = 0;
 					row[da] = -side;
-					row_params(m, L, f, r, dist, margin, solref, solimp, m.dof_invweight0[da]);
+					row_params(m, L, f, r, dist, margin, solref, solimp, MP_DOF_INVW(m, e, da));
 					fi[L.efc_id + r] = j;
 					fi[L.efc_type + r] = MJB_CNSTR_LIMIT_JOINT;
 					r++;
@@ -919,7 +919,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 					for (int k = 0; k < nv; k++) row[k] = 0;
 					for (int w = m.tendon_adr[t]; w < m.tendon_adr[t] + m.tendon_num[t]; w++)
 						row[m.jnt_dofadr[m.wrap_objid[w]]] += -side * m.wrap_prm[w];
-					row_params(m, L, f, r, dist, margin, solref, solimp, m.tendon_invweight0[t]);
+					row_params(m, L, f, r, dist, margin, solref, solimp, MP_TEN_INVW(m, e, t));
 					fi[L.efc_id + r] = t;
 					fi[L.efc_type + r] = MJB_CNSTR_LIMIT_TENDON;
 					r++;
@@ -930,8 +930,8 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 			const int dim = fi[L.contact_dim + c];
 			const double dist = f[L.contact_dist + c], cm = f[L.contact_includemargin + c];
 			const int b1 = m.geom_bodyid[fi[L.contact_geom + 2 * c]], b2 = m.geom_bodyid[fi[L.contact_geom + 2 * c + 1]];
-			const double tran = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
-			const double rot = m.body_invweight0[2 * b1 + 1] + m.body_invweight0[2 * b2 + 1];
+			const double tran = MP_BODY_INVW(m, e, 2 * b1) + MP_BODY_INVW(m, e, 2 * b2);
+			const double rot = MP_BODY_INVW(m, e, 2 * b1 + 1) + MP_BODY_INVW(m, e, 2 * b2 + 1);
 			double solref[2] = { f[L.contact_solref + 2 * c], f[L.contact_solref + 2 * c + 1] }, solimp[5], fri[5];
 			for (int k = 0; k < 5; k++) {
 				solimp[k] = f[L.contact_solimp + 5 * c + k];
@@ -1582,7 +1582,7 @@ template <int G, bool ELL> STAGE void fwd_constraint_pgs(CModel m, CLayout L, co
 	}
 	// Gauss-Seidel sweeps; the cost decrease of a sweep (the reference sums the per-row changes, which telescope to
 	// exactly this) is cost(before) - cost(after) with cost = 0.5 f'ARf + f'b = sum_i 0.5 f_i (res_i + b_i)
-	const double scale = 1.0 / (m.meaninertia[0] * (nv > 1 ? nv : 1));
+	const double scale = 1.0 / (MP_MEANINERTIA(m, e) * (nv > 1 ? nv : 1));
 	const double tol = m.tolerance[0];
 	// equality rows are two-sided, dry-friction rows live in [-frictionloss, frictionloss], the rest in [0, inf)
 	const double lo = bilateral ? -__builtin_huge_val() : (friction ? -floss : 0.0);
@@ -1752,7 +1752,7 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 	const bool dofact = lane < nv;
 	const int k = dofact ? lane : 0;
 	const double tol = m.tolerance[0];
-	const double scale = 1.0 / (m.meaninertia[0] * (nv > 1 ? nv : 1));
+	const double scale = 1.0 / (MP_MEANINERTIA(m, e) * (nv > 1 ? nv : 1));
 	// dense symmetric M from the qM layout (entry per lane)
 	for (int t = lane; t < nv * nv; t += G) Md[t] = 0;
 	gsync<G>();

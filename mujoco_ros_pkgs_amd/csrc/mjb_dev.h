@@ -106,6 +106,8 @@ struct DevState {
 	const double *env_gravity;       // [nenv][3] per-env gravity override (NULL: the model's)
 	const double *env_geom_friction; // [nenv][ngeom][3] per-env geom friction override (NULL: the model's)
 	const double *env_equality;      // [nenv][neq][19] per-env equality parameters (NULL: the model's)
+	const double *env_mass;          // [nenv][7 nbody + nv + ntendon + 1] per-env inertial constants (NULL: the model's):
+	                                 // body_mass | body_subtreemass | body_inertia[3] | dof_invweight0 | body_invweight0[2] | tendon_invweight0 | meaninertia
 	int use_xfrc;                  // xfrc_applied has ever been written
 	int keep_frame;                // fused mjb_step also dumps the last step's full frame to frame_ws
 	int pad1;

@@ -130,6 +130,20 @@ class Batch:
         p = np.ascontiguousarray(p)
         _check(self.lib.mjb_set_env_equality(self.ptr, lo, hi, p.ctypes.data_as(C.POINTER(C.c_double))), "mjb_set_env_equality")
 
+    def set_env_body_mass(self, body_mass, body_inertia=None, lo=0, hi=None):
+        """Per-env body masses [hi-lo, nbody] (and optionally principal inertias [hi-lo, nbody, 3]): derives what
+        mj_setConst would (mjcf.with_body_mass) and hands the packed constants to mjb_set_env_mass_params."""
+        from . import mjcf
+        hi = self.nenv if hi is None else hi
+        n = hi - lo
+        bm = np.asarray(body_mass, dtype=np.float64).reshape(n, -1)
+        bi = None if body_inertia is None else np.asarray(body_inertia, dtype=np.float64).reshape(n, -1, 3)
+        stride = self.lib.mjb_env_mass_stride(self.cm.ptr)
+        p = np.zeros((n, stride))
+        for e in range(n):
+            p[e] = mjcf.mass_params(mjcf.with_body_mass(self.cm.model, bm[e], None if bi is None else bi[e]))
+        _check(self.lib.mjb_set_env_mass_params(self.ptr, lo, hi, p.ctypes.data_as(C.POINTER(C.c_double))), "mjb_set_env_mass_params")
+
     # ---- device-side DefaultRobotHWSim (mjb_hwsim_*) ----
     def hwsim_configure(self, joints):
         """joints: list of dicts(joint=<id>, method=..., kind=..., p, i, d, i_max, i_min, antiwindup, effort_limit, lower, upper)."""

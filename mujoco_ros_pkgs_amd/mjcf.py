@@ -1158,6 +1158,41 @@ def _inertia_from_geoms(geoms):
 
 
 # --------------------------------------------------------------------------- public entry points
+def with_body_mass(model, body_mass, body_inertia=None):
+    """A copy of a compiled model with new body masses (and optionally principal inertias) and everything mj_setConst
+    derives from them: body_subtreemass, dof_invweight0, body_invweight0, tendon_invweight0, meaninertia
+    (the reference: setBodyState sets body_mass then calls mj_setConst, mujoco_ros/src/callbacks.cpp:251-256)."""
+    from . import refdyn
+    m = Model(dict(model))
+    nbody, nv = int(m["nbody"]), int(m["nv"])
+    mass = np.asarray(body_mass, dtype=np.float64).reshape(nbody).copy()
+    m["body_mass"] = mass
+    if body_inertia is not None:
+        m["body_inertia"] = np.asarray(body_inertia, dtype=np.float64).reshape(nbody, 3).copy()
+    sub = mass.copy()
+    parent = np.asarray(m["body_parentid"])
+    for b in range(nbody - 1, 0, -1):
+        sub[parent[b]] += sub[b]
+    m["body_subtreemass"] = sub
+    dof_inv, body_inv, mean = refdyn.invweight0(m)
+    m["dof_invweight0"], m["body_invweight0"], m["meaninertia"] = dof_inv, body_inv, np.array([mean])
+    nt = int(m["ntendon"])
+    if nt and nv:
+        J = np.zeros((nt, nv))
+        for t in range(nt):
+            for w in range(int(m["tendon_adr"][t]), int(m["tendon_adr"][t]) + int(m["tendon_num"][t])):
+                J[t, m["jnt_dofadr"][m["wrap_objid"][w]]] += m["wrap_prm"][w]
+        Minv = np.linalg.inv(refdyn.mass_matrix(m, np.asarray(m["qpos0"], dtype=np.float64)))
+        m["tendon_invweight0"] = np.einsum("ti,ij,tj->t", J, Minv, J)
+    return m
+
+
+def mass_params(model):
+    """The packed per-env block of mjb_set_env_mass_params for a (possibly re-massed) compiled model."""
+    return np.concatenate([np.asarray(model[k], dtype=np.float64).reshape(-1) for k in (
+        "body_mass", "body_subtreemass", "body_inertia", "dof_invweight0", "body_invweight0", "tendon_invweight0", "meaninertia")])
+
+
 def compile_xml_string(xml, nconmax=None, nefcmax=None, disable=(), override=None, skip_unsupported_pairs=False):
     """``disable``: extra mjtDisableBit names (e.g. ("contact",)) OR-ed into opt.disableflags.
     ``override``: option overrides, e.g. {"cone": "pyramidal", "solver": "PGS"}.
