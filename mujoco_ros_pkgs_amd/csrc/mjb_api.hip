@@ -162,7 +162,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		int n = dim(fi);
 		if (idx == MJB_F_efc_AR) n = 0;  // (the PGS kernel keeps each row of AR in its lane's registers)
 		if (idx == MJB_F_efc_frictionloss && M->nfriction == 0) n = 0;  // no dry-friction rows in this model
-		if (idx == MJB_F_efc_B && d.solver == MJB_SOL_NEWTON) n = 0;  // the primal solver needs no J M^-1
+		if (idx == MJB_F_efc_B && d.solver != MJB_SOL_PGS) n = 0;  // the primal solvers need no J M^-1
 		if (!compact) M->field_size[idx] = n;
 		if ((idx == MJB_F_cfrc_int || idx == MJB_F_cfrc_ext) && !need_post) n = 0;  // computed only when a sensor needs them
 		// (with rne_post the true cacc is written between fwd_acceleration and Euler, whose rhs shares region A)
@@ -183,13 +183,13 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		}
 		idx++;
 	}
-	const bool newton = d.nefcmax > 0 && d.solver == MJB_SOL_NEWTON;
+	const bool newton = d.nefcmax > 0 && (d.solver == MJB_SOL_NEWTON || d.solver == MJB_SOL_CG);  // primal solvers
 	L.nwt_M = off;
 	off += newton ? d.nv * d.nv : 0;
 	L.nwt_H = off;
 	off += newton ? d.nv * d.nv : 0;
 	L.nwt_vec = off;
-	off += newton ? 5 * d.nv : 0;
+	off += newton ? 5 * d.nv : 0;  // qacc | M qacc | grad | search | (CG: M^-1 grad)
 	L.nwt_row = off;
 	off += newton ? 3 * d.nefcmax : 0;
 	L.nwt_hc = off;
@@ -393,11 +393,11 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		return nullptr;
 	}
 	if (d.nefcmax > 0 || d.nconmax > 0) {
-		if (d.solver != MJB_SOL_PGS && d.solver != MJB_SOL_NEWTON) {
-			fail(MJB_EUNSUPPORTED, "mjb_compile: models with constraint rows need solver=Newton or solver=PGS (CG is not implemented)");
+		if (d.solver != MJB_SOL_PGS && d.solver != MJB_SOL_NEWTON && d.solver != MJB_SOL_CG) {
+			fail(MJB_EUNSUPPORTED, "mjb_compile: unknown solver (PGS = 0, CG = 1, Newton = 2)");
 			return nullptr;
 		}
-		const int rowcap = d.solver == MJB_SOL_NEWTON ? 256 : 64;
+		const int rowcap = d.solver != MJB_SOL_PGS ? 256 : 64;
 		if (d.nefcmax > rowcap || d.nv > 64) {
 			fail(MJB_EUNSUPPORTED, "mjb_compile: one env per wavefront: nv <= 64 and nefcmax <= 64 (PGS) / 256 (Newton, up to "
 			                       "4 rows per lane); got nefcmax = %d, nv = %d", d.nefcmax, d.nv);
@@ -875,12 +875,12 @@ static int sync_params(mjb_batch *b)
 	return MJB_OK;
 }
 
-// 0: no constraint rows; 1: PGS (5: PGS with elliptic contacts); 2 / 3 / 4: Newton with 1 / 2 / 4 rows per lane
+// 0: no constraint rows; 1: PGS (5: PGS with elliptic contacts); 2 / 3 / 4: Newton with 1 / 2 / 4 rows per lane; 6 / 7 / 8: CG
 static int kernel_variant(const mjb_model_desc &h)
 {
 	if (h.nefcmax <= 0) return 0;
-	if (h.solver != MJB_SOL_NEWTON) return (h.cone == MJB_CONE_ELLIPTIC && h.nconmax > 0) ? 5 : 1;
-	return h.nefcmax <= 64 ? 2 : (h.nefcmax <= 128 ? 3 : 4);
+	if (h.solver == MJB_SOL_PGS) return (h.cone == MJB_CONE_ELLIPTIC && h.nconmax > 0) ? 5 : 1;
+	return (h.solver == MJB_SOL_CG ? 4 : 0) + (h.nefcmax <= 64 ? 2 : (h.nefcmax <= 128 ? 3 : 4));
 }
 
 static int launch(mjb_batch *b, int mode, int nsteps)

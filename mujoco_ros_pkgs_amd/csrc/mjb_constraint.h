@@ -1727,7 +1727,8 @@ typedef double mjb_d4 __attribute__((ext_vector_type(4)));
 
 // R = rows per lane: row r lives in lane r % 64, slot r / 64 (nefcmax <= 64 R).  R == 1 is BASELINE config 3,
 // R == 4 covers the ~200 rows of config 5.
-template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e)
+template <int G, int R, bool CGS = false>  // CGS: conjugate gradient (no Hessian; Polak-Ribiere directions preconditioned by M^-1)
+STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e)
 {
 	static_assert(G == 64, "the Newton solver maps rows / Hessian columns to the 64 lanes of one wavefront");
 	double *f = e.f;
@@ -1916,6 +1917,7 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 
 	EPROF(25);
 	double cost = 0, prev_cost = 0;
+	double cg_gold = 0, cg_mgold = 0, cg_sold = 0;  // CG: this lane's element of the previous gradient, M^-1 gradient and search
 	int iter = 0;
 	for (;;) {
 		EPROF(30);
@@ -1953,6 +1955,25 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 			if (improvement < tol || gnorm < tol || iter >= m.iterations) break;
 		}
 		EPROF(26);
+		double x = 0;
+		if constexpr (CGS) {
+			// mj_solPrimal without the Hessian: Mgrad = M^-1 grad (sparse L'DL solve in LDS), beta = grad.(Mgrad - Mgrad_old) /
+			// max(MINVAL, grad_old.Mgrad_old) clipped at 0, search = -Mgrad + beta search_old
+			double *mg = srch + nv;
+			if (dofact) mg[k] = gr;
+			gsync<G>();
+			solve<G>(m, e, mg, f + L.qLD, f + L.qLDiagInv);
+			const double mgk = dofact ? mg[k] : 0.0;
+			double beta = 0;
+			if (iter > 0) {
+				const double num = wave_sum(gr * (mgk - cg_mgold)), den = wave_sum(cg_gold * cg_mgold);
+				beta = num / fmax(MJB_MINVAL, den);
+				if (beta < 0) beta = 0;
+			}
+			x = mgk - beta * cg_sold;  // (the search direction is -x)
+			cg_gold = gr;
+			cg_mgold = mgk;
+		} else {
 		// H = M + J' W J on the matrix cores: 16x16 tiles of v_mfma_f64_16x16x4_f64 over 4-row slabs of J.
 		// A[i][kk] = (W J)[r0+kk][a0+i] (row weight, or the contact's cone block times its rows), B[kk][j] = J[r0+kk][b0+j];
 		// lane l feeds A[l&15][l>>4], B[l>>4][l&15] and receives D[(l>>4) + 4 q][l&15], q = 0..3.
@@ -2003,7 +2024,7 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 		// as the left-looking column form below, so the factor is bit-identical).  The forward substitution reads the
 		// row from the same registers; the rows are parked in H for the backward one (which needs columns).
 		double myrinv = 1.0;
-		double x = gr;
+		x = gr;
 		if (nv <= 32) {
 			MJB_KEEP_BRANCH();
 			double Hr[32];
@@ -2064,8 +2085,10 @@ template <int G, int R> STAGE void fwd_constraint_newton(CModel m, CLayout L, co
 			if (k == i) x = xi;
 			else x -= lik * xi;
 		}
+		}
 		EPROF(28);
 		const double sk = dofact ? -x : 0.0;
+		cg_sold = sk;
 		const double snorm = sqrt(wave_sum(sk * sk));
 		if (snorm < MJB_MINVAL) break;
 		if (dofact) srch[k] = sk;

@@ -1727,6 +1727,8 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 	PROF(10);
 	if constexpr (CON >= 2 && CON <= 4 && G == 64) {
 		VIEW(P, compact, fwd_constraint_newton<G, (CON == 2 ? 1 : (CON == 3 ? 2 : 4))>(m, L, e));
+	} else if constexpr (CON >= 6 && CON <= 8 && G == 64) {
+		VIEW(P, compact, fwd_constraint_newton<G, (CON == 6 ? 1 : (CON == 7 ? 2 : 4)), true>(m, L, e));
 	} else if constexpr ((CON == 1 || CON == 5) && G == 64) {
 		VIEW(P, compact, fwd_constraint_pgs<G, (CON == 5)>(m, L, e));
 	} else {
@@ -1820,7 +1822,8 @@ template <int G> STAGE void ctrl_noise(CModel m, CLayout L, CNoise nz, const Env
 // ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
-// CON: 0 = model without constraint rows; 1 = PGS (5 = PGS with elliptic cone blocks), 2 / 3 / 4 = Newton with 1 / 2 / 4 rows per lane (collision / rows / solver stages compiled in;
+// CON: 0 = model without constraint rows; 1 = PGS (5 = PGS with elliptic cone blocks), 2 / 3 / 4 = Newton with 1 / 2 / 4 rows per lane,
+// 6 / 7 / 8 = CG with 1 / 2 / 4 rows per lane (the Newton solver without its Hessian) (collision / rows / solver stages compiled in;
 // one env per wavefront) -- separate kernels keep each instruction stream and register budget small.
 // Constrained kernels get the full 512-register budget (1 block of 256 per CU by registers; their frames limit the
 // CU to 1 - 4 envs anyway): no spills, and room for the register-resident AR rows / Hessian rows of the solvers.
@@ -2049,6 +2052,9 @@ int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, in
 	if (constrained == 3) return launch_g<64, 3>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 	if (constrained == 4) return launch_g<64, 4>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 	if (constrained == 5) return launch_g<64, 5>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+	if (constrained == 6) return launch_g<64, 6>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+	if (constrained == 7) return launch_g<64, 7>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+	if (constrained == 8) return launch_g<64, 8>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 	return launch_g<64, 1>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 }
 

@@ -1113,7 +1113,7 @@ static void pgs_cone_block(int dim, double *fc, const double *res, const double 
 
 void mjo_fwd_constraint(const mjb_model_desc *m, mjo_data *d)
 {
-	if (d->nefc[0] > 0 && m->solver == MJB_SOL_NEWTON) {
+	if (d->nefc[0] > 0 && (m->solver == MJB_SOL_NEWTON || m->solver == MJB_SOL_CG)) { /* both primal (mj_solPrimal) */
 		fwd_constraint_newton(m, d);
 		return;
 	}
@@ -1513,6 +1513,9 @@ static void fwd_constraint_newton(const mjb_model_desc *m, mjo_data *d)
 	double qacc[nv], Ma[nv], jaref[nefc], grad[nv], search[nv], Mv[nv], jv[nefc], hrow[nefc], H[nv * nv];
 	double hcone[36 * (ncon > 0 ? ncon : 1)], tmpf[nefc];
 	double *f = d->efc_force;
+	const int cg = m->solver == MJB_SOL_CG; /* conjugate gradient: same cost, line search and stopping rules; the search
+	                                         * direction is Polak-Ribiere with the preconditioner M^-1 instead of -H^-1 grad */
+	double Mgrad[nv], gradold[nv], Mgradold[nv];
 
 	/* warmstart: qacc_warmstart unless qacc_smooth has the lower cost (engine_forward.c warmstart()) */
 	double best = 0;
@@ -1560,6 +1563,25 @@ static void fwd_constraint_newton(const mjb_model_desc *m, mjo_data *d)
 			for (int k = 0; k < nv; k++) gnorm += grad[k] * grad[k];
 			gnorm = scale * sqrt(gnorm);
 			if (improvement < tol || gnorm < tol || iter >= m->iterations) break;
+		}
+		if (cg) {
+			memcpy(Mgrad, grad, sizeof Mgrad);
+			mjo_solve_m(m, d, Mgrad);
+			if (iter == 0) {
+				for (int k = 0; k < nv; k++) search[k] = -Mgrad[k];
+			} else {
+				double num = 0, den = 0;
+				for (int k = 0; k < nv; k++) {
+					num += grad[k] * (Mgrad[k] - Mgradold[k]);
+					den += gradold[k] * Mgradold[k];
+				}
+				double beta = num / fmax(MJO_MINVAL, den);
+				if (beta < 0) beta = 0;
+				for (int k = 0; k < nv; k++) search[k] = -Mgrad[k] + beta * search[k];
+			}
+			memcpy(gradold, grad, sizeof gradold);
+			memcpy(Mgradold, Mgrad, sizeof Mgradold);
+			goto linesearch;
 		}
 		/* Hessian H = M + J' W J  (W: D on active scalar rows, cone blocks on elliptic contacts) */
 		memset(H, 0, sizeof H);
@@ -1622,6 +1644,7 @@ static void fwd_constraint_newton(const mjb_model_desc *m, mjo_data *d)
 			search[i] = t / H[i * nv + i];
 		}
 		for (int k = 0; k < nv; k++) search[k] = -search[k];
+	linesearch:;
 		/* line search */
 		double snorm = 0;
 		for (int k = 0; k < nv; k++) snorm += search[k] * search[k];

@@ -21,7 +21,7 @@ STATE = ["qpos", "qvel", "qacc", "qacc_warmstart", "sensordata", "ctrl", "time"]
 
 def _variants():
     out = [("franka_like", None, lanes) for lanes in (8, 16, 32, 64)]
-    out += [("franka_table", s, 64) for s in ("PGS", "PGS-elliptic", "Newton", "Newton-elliptic")]
+    out += [("franka_table", s, 64) for s in ("PGS", "PGS-elliptic", "Newton", "Newton-elliptic", "CG")]
     out += [("shadow_hand_like", "hand-128", 64), ("shadow_hand_like", "hand-160", 64)]
     return out
 
