@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Wide randomised parity sweep (not part of the test suite: minutes of CPU oracle time): many random states of the contact
+scenes under every solver / cone combination, N steps on the GPU against the oracle, worst absolute state error per case.
+usage: tools/parity_sweep.py [--envs 256] [--steps 30]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from mujoco_ros_pkgs_amd import engine, mjcf, workloads  # noqa: E402
+from oracle import pyoracle  # noqa: E402
+from test_gpu_contact import scenario_states  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--envs", type=int, default=256)
+ap.add_argument("--steps", type=int, default=30)
+args = ap.parse_args()
+pyoracle.build()
+CASES = [("franka_table", {"solver": s, "cone": c}) for s in ("PGS", "Newton", "CG") for c in ("pyramidal", "elliptic")]
+CASES += [("shadow_hand_like", {"solver": s}) for s in ("Newton", "CG")]
+for name, over in CASES:
+    m = mjcf.compile_xml_file(os.path.join(mjcf.ASSET_DIR, name + ".xml"), override=over)
+    n = args.envs if name == "franka_table" else max(16, args.envs // 8)
+    if name == "franka_table":
+        qpos, qvel = scenario_states(m, n, seed=123)
+    else:
+        qpos, qvel = workloads.hand_grasp_states(m, n, seed=123)
+    b = engine.Batch(engine.CompiledModel(m), n)
+    b.set("qpos", qpos)
+    b.set("qvel", qvel)
+    b.step(args.steps)
+    gq, gv = b.get("qpos"), b.get("qvel")
+    oq, ov, _ = pyoracle.rollout(m, qpos, qvel, args.steps, nthreads=os.cpu_count() or 1)
+    eq, ev = np.abs(gq - oq).max(axis=1), np.abs(gv - ov).max(axis=1)
+    print(json.dumps({"model": name, **over, "envs": n, "steps": args.steps, "auto_resets": b.warning_count(),
+                      "max_err_qpos": float(eq.max()), "p99_err_qpos": float(np.percentile(eq, 99)),
+                      "max_err_qvel": float(ev.max()), "p99_err_qvel": float(np.percentile(ev, 99))}))
+    b.close()
