@@ -2,18 +2,25 @@
 """bench.py -- env-steps/s of the batched step engine on BASELINE.json's configs[1]
 ("Franka Panda 9-DoF no-contact, 4096 envs, 1xMI355X fp64"), weak-scaled to N GPUs of one node.
 
-One bench "step" = ONE fused kernel launch that advances every env of the rank's batch by
-``--substeps`` physics steps (rollouts of K = 1000 steps), driven by the reference's
-Ornstein-Uhlenbeck ctrl-noise injector generated on device (counter-based Philox, seed 12345), followed
--- when N > 1 -- by the RCCL all-gather of ``sensordata`` over the node.
-Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+One bench "step" = ONE fused kernel launch that advances every env of the rank's batch by ``--substeps`` physics
+steps (rollouts of K = 1000 steps), driven by the reference's Ornstein-Uhlenbeck ctrl-noise injector
+generated on device (counter-based Philox, seed 12345), followed by the engine's metrics reduction and -- when
+N > 1 -- by the RCCL all-gather of ``sensordata`` + the 16-double metrics all-reduce over the node,
+issued on a side stream so that they overlap the next launch.  Inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--substeps S] [--envs E] [--lanes G]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|5] [--substeps S] [--envs E] [--lanes G]
+
+With N > 1 and no torch.distributed environment the script spawns its own ranks (one process per GPU through
+``python -m torch.distributed.run`` on 127.0.0.1); under torchrun it uses the environment it is given.
+``--config`` selects the BASELINE workload: 2 = configs[1] (default, the headline metric), 3 = configs[2]
+(Franka + table + cube, PGS), 5 = configs[4] (Shadow-Hand-like, Newton + elliptic cones; per-GPU shard of 1024 envs).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,12 +30,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_ENV_STEP = {"franka_like": 712, "franka_table": 1072, "shadow_hand_like": 2136}  # 8*(2nq+2nv+2nv+nu+S)+8
-# per-model workload: (BASELINE config label, OU ctrl-noise std [= 0.5 * ctrlrange of the big actuators], default envs per GPU)
+# per-model workload: (BASELINE config label, OU ctrl-noise std [= 0.5 * ctrlrange of the big actuators], default envs per GPU,
+#                      default physics steps per launch, BASELINE config number)
 WORKLOADS = {
-    "franka_like": ("BASELINE configs[1]: Franka-Panda-like 9-DoF arm, no contacts", 0.5 * 87.0, 4096),
-    "franka_table": ("BASELINE configs[2]: Franka-like arm + table + cube contacts", 0.5 * 87.0, 4096),
-    "shadow_hand_like": ("BASELINE configs[4]: Shadow-Hand-like 24-DoF hand + in-hand cube (Newton, elliptic cones)", 0.1, 1024),
+    "franka_like": ("BASELINE configs[1]: Franka-Panda-like 9-DoF arm, no contacts", 0.5 * 87.0, 4096, 1000, 2),
+    "franka_table": ("BASELINE configs[2]: Franka-like arm + table + cube contacts", 0.5 * 87.0, 4096, 200, 3),
+    "shadow_hand_like": ("BASELINE configs[4]: Shadow-Hand-like 24-DoF hand + in-hand cube (Newton, elliptic cones)", 0.1, 1024, 100, 5),
 }
+CONFIG_MODEL = {2: "franka_like", 3: "franka_table", 4: "franka_table", 5: "shadow_hand_like"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable)
 FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 vector peak; replaced by the measured fma rate when the profile holds one
 
@@ -71,27 +80,79 @@ def initial_state(name, model, nenv, seed):
     return synthetic_state(model, nenv, seed)
 
 
-def cpu_baseline(name, model, noise_std, nsteps_total_target_s=12.0):
-    """Time the CPU oracle ("port": from-scratch restatement, -O3 -march=native) on a bounded sample of the
-    same workload, all host cores, one env per thread at a time."""
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _time_oracle(name, model, noise_std, nenv, threads, target_s, pin=False):
+    """Env-steps/s of oracle/libmjo_fast.so on `threads` host threads over ~target_s seconds of the same workload."""
+    from oracle import pyoracle
+    qpos, qvel = initial_state(name, model, nenv, seed=999)
+    kw = dict(noise_std=noise_std, noise_rate=0.1, seed=12345, nthreads=threads, fast=True)
+    old_aff = None
+    if pin and hasattr(os, "sched_getaffinity"):
+        old_aff = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, {sorted(old_aff)[0]})
+    try:
+        nsteps = 100
+        t0 = time.perf_counter()
+        pyoracle.rollout(model, qpos, qvel, nsteps, **kw)
+        rate = nenv * nsteps / (time.perf_counter() - t0)
+        nsteps2 = int(min(max(nsteps, rate * target_s / nenv), 200000))
+        t0 = time.perf_counter()
+        pyoracle.rollout(model, qpos, qvel, nsteps2, **kw)
+        dt = time.perf_counter() - t0
+    finally:
+        if old_aff is not None:
+            os.sched_setaffinity(0, old_aff)
+    return nenv * nsteps2 / dt, nsteps2, dt
+
+
+def cpu_baseline(name, model, noise_std):
+    """CPU figures beside the GPU number, all on a bounded sample of the same workload:
+    the oracle ("port": from-scratch restatement, gcc -O3 -march=native) on all host threads and on ONE pinned thread,
+    and real MuJoCo through $MUJOCO_DIR when that library exists on the box (else the literal NOT MEASURED)."""
     from oracle import pyoracle
     pyoracle.build()
     cores = os.cpu_count() or 1
-    nenv, nsteps = 4 * cores, 200
-    qpos, qvel = initial_state(name, model, nenv, seed=999)
-    kw = dict(noise_std=noise_std, noise_rate=0.1, seed=12345, nthreads=cores, fast=True)
-    t0 = time.perf_counter()
-    pyoracle.rollout(model, qpos, qvel, nsteps, **kw)
-    dt = time.perf_counter() - t0
-    rate = nenv * nsteps / dt
-    # scale the sample to ~target seconds
-    nsteps2 = int(min(max(nsteps, rate * nsteps_total_target_s / nenv), 200000))
-    t0 = time.perf_counter()
-    pyoracle.rollout(model, qpos, qvel, nsteps2, **kw)
-    dt = time.perf_counter() - t0
-    return {"value": nenv * nsteps2 / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{nenv} envs x {nsteps2} steps of the same {name} workload (OU ctrl noise), oracle/libmjo_fast.so "
-                      f"(gcc -O3 -march=native), {cores} threads, {dt:.1f} s"}
+    v_all, n_all, dt_all = _time_oracle(name, model, noise_std, 4 * cores, cores, 10.0)
+    v_one, n_one, dt_one = _time_oracle(name, model, noise_std, 4, 1, 6.0, pin=True)
+    out = {"value": v_all, "unit": "env-steps/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_string(),
+           "sample": f"{4 * cores} envs x {n_all} steps of the same {name} workload (OU ctrl noise), oracle/libmjo_fast.so "
+                     f"(gcc -O3 -march=native), {cores} threads, {dt_all:.1f} s",
+           "single_thread": {"value": v_one, "unit": "env-steps/s", "cores": 1,
+                             "sample": f"4 envs x {n_one} steps, one thread pinned to one core, {dt_one:.1f} s"}}
+    try:
+        from oracle import mujoco_ref
+        out["mujoco"] = mujoco_ref.time_reference(name, noise_std)
+    except Exception as exc:  # the leg is optional by construction: never let it take the bench line down
+        out["mujoco"] = f"NOT MEASURED ({type(exc).__name__}: {exc})"
+    return out
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _load_json(*names):
+    for n in names:
+        p = os.path.join(ROOT, "profiles", n)
+        if os.path.exists(p):
+            try:
+                return json.load(open(p)), n
+            except Exception:
+                pass
+    return None, None
 
 
 def main():
@@ -99,15 +160,26 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--substeps", type=int, default=1000, help="physics steps fused into one launch")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="BASELINE config number (2 = configs[1], the headline; 3; 5)")
+    ap.add_argument("--substeps", type=int, default=0, help="physics steps fused into one launch (0 = the config's own)")
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (weak scaling); 0 = the config's own (4096; 1024 for the hand)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per env (0 = engine default)")
     ap.add_argument("--epb", type=int, default=0, help="envs per workgroup (0 = engine default)")
-    ap.add_argument("--model", default="franka_like")
+    ap.add_argument("--model", default="")
     ap.add_argument("--solver", default="", choices=["", "PGS", "Newton"], help="override the model's constraint solver")
     ap.add_argument("--nefcmax", type=int, default=0, help="override the model's constraint-row capacity")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    name = args.model or CONFIG_MODEL[args.config or 2]
+
+    # ---- one process per GPU: spawn the ranks ourselves when nobody did (bare `python bench.py --gpus N`)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
 
     import torch
     import torch.distributed as dist
@@ -115,15 +187,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
-        sys.exit(2)
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running with the {world} rank(s) of the environment",
+              file=sys.stderr)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the engine has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    if local_rank >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} are visible", file=sys.stderr)
+        sys.exit(3)
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     force_gather = os.environ.get("MJB_BENCH_FORCE_GATHER", "0") == "1"  # exercise the RCCL path on one GPU
     # The contract is ONE JSON line on stdout: RCCL prints a version banner through C stdio (flushed at exit, i.e. after
     # anything Python prints), so everything written to fd 1 from here on goes to stderr and the line is written to the
@@ -136,20 +210,21 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=dev)
 
-    from mujoco_ros_pkgs_amd import engine, mjcf, sharding
+    from mujoco_ros_pkgs_amd import binding, engine, mjcf, sharding
 
-    model = mjcf.load_asset(args.model, **({"nefcmax": args.nefcmax} if args.nefcmax else {}))
+    model = mjcf.load_asset(name, **({"nefcmax": args.nefcmax} if args.nefcmax else {}))
+    model = mjcf.Model(dict(model))
+    model["enableflags"] = int(model["enableflags"]) | 2  # mjENBL_ENERGY: the metrics vector carries the energies
     if args.solver:
-        model = mjcf.Model(dict(model))
         model["solver"] = {"PGS": 0, "Newton": 2}[args.solver]
     cm = engine.CompiledModel(model)
-    label, noise_std, default_envs = WORKLOADS.get(args.model, (args.model, 1.0, 4096))
-    E, S = (args.envs or default_envs), args.substeps
+    label, noise_std, default_envs, default_sub, cfgno = WORKLOADS.get(name, (name, 1.0, 4096, 200, 0))
+    E, S = (args.envs or default_envs), (args.substeps or default_sub)
     batch = engine.Batch(cm, E, local_rank)
     batch.set_launch(args.lanes, args.epb)
-    qpos, qvel = initial_state(args.model, model, E, seed=1000 + rank)
+    qpos, qvel = initial_state(name, model, E, seed=1000 + rank)
     batch.set("qpos", qpos)
     batch.set("qvel", qvel)
     # reference injector: tau = 0.1 s, std = 0.5 * ctrlrange (87 N m on the big joints), seed 12345
@@ -158,21 +233,17 @@ def main():
     batch.synchronize()
 
     nsd = model["nsensordata"]
-    sens_local = torch.as_tensor(DevArray(batch.device_ptr("sensordata"), (E, nsd)), device=f"cuda:{local_rank}")
-    gather = world > 1 or force_gather
-    sens_all = torch.empty((world * E, nsd), dtype=torch.float64, device=f"cuda:{local_rank}") if gather else None
+    sens_local = torch.as_tensor(DevArray(batch.device_ptr("sensordata"), (E, nsd)), device=dev)
+    metrics_local = torch.as_tensor(DevArray(batch.metrics_device_ptr(), (16,)), device=dev)
+    xch = sharding.OverlappedExchange(sens_local, metrics_local, batch.stream, dev, force=force_gather)
 
     def one_step():
-        batch.step(S)
-        if gather:
-            batch.synchronize()  # kernel ran on the engine's stream; the gather runs on torch's
-            if world > 1:
-                sharding.gather_sensordata(sens_local, sens_all)
-            else:
-                dist.all_gather_into_tensor(sens_all, sens_local)
+        batch.step(S)                # K fused physics steps, asynchronous on the engine's stream
+        batch.metrics_device_ptr()   # the 16-double metrics reduction, same stream
+        xch.issue()                  # staging copy (engine stream) + all-gather / all-reduce (side stream): overlaps the next launch
 
     def fence():
-        if gather:
+        if xch.active:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -185,63 +256,80 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    sens_all, met = xch.finish()
+    met = met.cpu().numpy()
+    metrics = dict(zip(binding.METRIC_NAMES, (float(x) for x in met)))
 
     # sanity: state still finite (non-finite envs are auto-reset and counted by the engine)
-    finite = bool(np.all(np.isfinite(batch.get("qpos"))))
-    resets = batch.warning_count()  # mj_check* auto-resets since the batch was made (must be 0 on config 2)
+    finite = bool(np.all(np.isfinite(batch.get("qpos")))) and bool(torch.isfinite(sens_all).all())
+    resets = batch.warning_count()  # mj_check* auto-resets of THIS rank (must be 0 on config 2)
 
-    # dominant-kernel duration measured with HIP events on the engine's own stream
-    kern_ms = batch.time_steps(S, max(1, min(args.steps, 5)))
+    # dominant-kernel duration measured with HIP events on the engine's own stream: 5 single-launch samples
+    samples = sorted(batch.time_steps(S, 1) for _ in range(5))
+    kern_ms = samples[len(samples) // 2]
 
     if rank == 0:
         traffic, fp64 = None, None
+        pmc, pmc_file = _load_json(f"r02_cfg{cfgno}_pmc_summary.json", "r01_pmc_summary.json" if cfgno == 2 else f"r01_cfg{cfgno}_pmc_summary.json")
+        flops, flops_file = _load_json("r02_oracle_flops.json")
         try:  # HBM bytes and executed fp64 flops per launch from the committed rocprofv3 PMC passes (same kernel, same config)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-            if (E, S, args.model) == (4096, 1000, "franka_like"):
+            pm_E, pm_S = pmc.get("envs", default_envs), pmc.get("substeps", default_sub)
+            if (E, S) == (pm_E, pm_S):
                 traffic = (pmc["FETCH_SIZE"]["mean_per_dispatch"] + pmc["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
                 if "fp64_executed_flops_per_dispatch" in pmc:
-                    flops = pmc["fp64_executed_flops_per_dispatch"]
+                    fl = pmc["fp64_executed_flops_per_dispatch"]
                     peak = pmc.get("fp64_peak_measured", {}).get("fp64_fma_tflops", FP64_PEAK_TFLOPS)
-                    ach = flops / (kern_ms * 1e-3) / 1e12
+                    ach = fl / (kern_ms * 1e-3) / 1e12
                     fp64 = {"bound": "fp64-valu", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                            "executed_flops_per_launch": flops,
-                            "note": "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes (profiles/r01_pmc_summary.json); "
+                            "executed_flops_per_launch": fl,
+                            "note": f"SQ_INSTS_VALU_{{ADD,MUL,FMA,TRANS}}_F64 x 64 lanes, idle lanes included (profiles/{pmc_file}); "
                                     "peak = tools/ubench/fp64_peak on the same box"}
         except Exception:
             traffic, fp64 = None, None
+        if flops and name in flops:  # the oracle's instrumented operation count (THE flop figure)
+            per = float(flops[name]["flops_per_env_step"])
+            ach = per * E * S / (kern_ms * 1e-3) / 1e12
+            fp64 = fp64 or {"bound": "fp64-valu", "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s"}
+            fp64.update(algorithmic_flops_per_env_step=per, useful_achieved=ach, useful_frac=ach / fp64["peak"],
+                        useful_note=f"oracle op counter, add / mul / div / sqrt = 1, fma = 2 (profiles/{flops_file})")
         value = world * E * S * args.steps / elapsed
-        bytes_per_launch = ALGO_BYTES_PER_ENV_STEP.get(args.model, 712) * E * S
+        bytes_per_launch = ALGO_BYTES_PER_ENV_STEP.get(name, 712) * E * S
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{label}, {E} envs per GPU, fp64, Euler dt={model['timestep'][0]}",
-                       "envs_per_gpu": E, "physics_steps_per_launch": S, "model": args.model,
+                       "baseline_config": cfgno, "envs_per_gpu": E, "physics_steps_per_launch": S, "model": name,
                        "solver": {0: "PGS", 1: "CG", 2: "Newton"}[int(model["solver"])] if model["nefcmax"] else "none",
+                       "nconmax": int(model["nconmax"]), "nefcmax": int(model["nefcmax"]),
                        "ctrl": f"on-device OU noise (Philox seed 12345, tau 0.1 s, std {noise_std:g})",
-                       "parallelism": f"env-sharded x{world}, RCCL all-gather of sensordata per launch" if world > 1
-                       else "single GPU", "state_finite": finite, "auto_resets": resets},
+                       "parallelism": f"env-sharded x{world}, RCCL all-gather of sensordata + 16-double metrics all-reduce per launch, "
+                                      "side stream (overlaps the next launch)" if world > 1 else "single GPU",
+                       "rccl_ranks": world if xch.active else 0, "state_finite": finite, "auto_resets": resets},
+            "metrics": metrics,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": f"profiles/{pmc_file}" if traffic else None,
                          "kernel": "mjb_step_kernel", "kernel_ms": kern_ms,
+                         "kernel_ms_samples": {"n": len(samples), "median": kern_ms, "min": samples[0], "max": samples[-1]},
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if fp64:
             out["roofline"]["fp64"] = fp64  # second view: with K fused steps the kernel is VALU / latency bound
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.model, model, noise_std)
+            out["cpu_baseline"] = cpu_baseline(name, model, noise_std)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    if gather:
+    if xch.active:
         if force_gather and rank == 0:
-            batch.synchronize()
-            dist.all_gather_into_tensor(sens_all, sens_local)
+            host = torch.from_numpy(batch.get("sensordata")).to(dev)
+            one_step()
+            sa, _ = xch.finish()
             torch.cuda.synchronize()
-            host = torch.from_numpy(batch.get("sensordata")).to(sens_all.device)
-            ok = bool(torch.equal(sens_all[:E], host)) and bool(torch.isfinite(sens_all).all())
+            host = torch.from_numpy(batch.get("sensordata")).to(dev)
+            ok = bool(torch.equal(sa[:E], host)) and bool(torch.isfinite(sa).all())
             print(f"forced single-rank gather: sensordata round trip {'ok' if ok else 'MISMATCH'}", file=sys.stderr)
         dist.barrier()
         dist.destroy_process_group()

@@ -49,6 +49,11 @@ enum { /* mjtDisableBit */
 	MJB_DSBL_FILTERPARENT = 1 << 9, MJB_DSBL_ACTUATION = 1 << 10, MJB_DSBL_REFSAFE = 1 << 11,
 	MJB_DSBL_SENSOR = 1 << 12, MJB_DSBL_EULERDAMP = 1 << 14
 };
+enum { MJB_ENBL_ENERGY = 1 << 1 }; /* mjtEnableBit (the only one implemented) */
+enum { /* mjtWarning: index of mjData.warning[] -- see mjb_warning() */
+	MJB_WARN_INERTIA = 0, MJB_WARN_CONTACTFULL = 1, MJB_WARN_CNSTRFULL = 2, MJB_WARN_VGEOMFULL = 3, MJB_WARN_BADQPOS = 4,
+	MJB_WARN_BADQVEL = 5, MJB_WARN_BADQACC = 6, MJB_WARN_BADCTRL = 7, MJB_NWARNING = 8
+};
 enum { /* mjtObj */
 	MJB_OBJ_UNKNOWN = 0, MJB_OBJ_BODY = 1, MJB_OBJ_XBODY = 2, MJB_OBJ_JOINT = 3, MJB_OBJ_GEOM = 5,
 	MJB_OBJ_SITE = 6, MJB_OBJ_ACTUATOR = 18
@@ -184,6 +189,29 @@ int mjb_synchronize(mjb_batch *b);
 /* Number of env auto-resets so far (MuJoCo's mj_checkPos / mj_checkVel / mj_checkAcc warnings: a state
  * that went NaN or beyond mjMAXVAL is reset to qpos0 exactly as mj_step does). */
 int mjb_warning_count(mjb_batch *b, unsigned long long *count);
+/* mjData.warning[which].number summed over the batch's envs (which = MJB_WARN_*):
+ *   BADQPOS / BADQVEL / BADQACC  mj_checkPos / mj_checkVel / mj_checkAcc found NaN or |x| > mjMAXVAL and reset the env
+ *                                (mjb_warning_count is their sum);
+ *   CONTACTFULL                  an env produced more contacts than nconmax in one step: the contacts past the capacity,
+ *                                in pair order, were dropped (mj_addContact's rule);
+ *   CNSTRFULL                    an env's constraint rows exceeded nefcmax in one step: the first item (equality, friction
+ *                                row, limit, contact -- MuJoCo's row order) that did not fit and every item after it were
+ *                                dropped.  (MuJoCo 2.3.7 sizes its rows from the arena and drops ALL rows when that fails;
+ *                                with a fixed per-env capacity the engine keeps the prefix that fits -- the oracle applies the
+ *                                same rule.)
+ * The other entries stay 0. */
+int mjb_warning(mjb_batch *b, int which, unsigned long long *count);
+
+/* Aggregate metrics of the batch (the <= 16-double vector the RCCL all-reduce carries), computed on the
+ * device from the state arrays on the batch's stream:
+ *   out[0..7]  additive:  env-steps taken, auto-resets (BADQPOS + BADQVEL + BADQACC), CONTACTFULL, CNSTRFULL,
+ *                         sum of potential energy, sum of kinetic energy (both 0 unless mjENBL_ENERGY), nenv, 0
+ *   out[8..15] maxima:    max |qacc|, max |qvel|, max time, 0 ...
+ * so that a job-wide vector is one SUM all-reduce of the first half and one MAX all-reduce of the second.
+ * mjb_metrics copies the vector to the host (synchronous); mjb_metrics_device enqueues the reduction and returns the
+ * device pointer of the 16 doubles (valid until the next call; ordered on the batch's stream). */
+int mjb_metrics(mjb_batch *b, double *out16);
+void *mjb_metrics_device(mjb_batch *b);
 
 /* mjData after mj_step holds the derived quantities of the last forward pass (xpos, contacts, efc_*, ...), which
  * the reference's lastStageCallback / renderCallback read (mujoco_env.cpp:506-515, 430-436).  Fused mjb_step

@@ -91,7 +91,8 @@ int mjr_env_get_setting(mjr_env *e, const char *name);
 int mjr_env_set_setting(mjr_env *e, const char *name, int value);
 int mjr_env_set_ctrl_noise(mjr_env *e, double std, double rate);
 
-double mjr_env_sim_time(mjr_env *e);  /* last published /clock value */
+double mjr_env_sim_time(mjr_env *e);  /* last published /clock value (stays 0 with use_sim_time = false, mujoco_env.cpp:701-703) */
+double mjr_env_data_time(mjr_env *e); /* env 0's data_->time after the latest step: what the physics loop paces on */
 unsigned long long mjr_env_step_count(mjr_env *e);
 int mjr_env_nenv(mjr_env *e);
 int mjr_env_name2id(mjr_env *e, int objtype, const char *name);

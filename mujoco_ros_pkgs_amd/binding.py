@@ -107,6 +107,11 @@ class HwsimJoint(C.Structure):
                 ("effort_limit", C.c_double), ("lower", C.c_double), ("upper", C.c_double)]
 
 
+WARN = {"inertia": 0, "contactfull": 1, "cnstrfull": 2, "vgeomfull": 3, "badqpos": 4, "badqvel": 5, "badqacc": 6, "badctrl": 7}
+# layout of the mjb_metrics vector: [0:8] additive, [8:16] maxima
+METRIC_NAMES = ["env_steps", "auto_resets", "contactfull", "cnstrfull", "energy_potential", "energy_kinetic", "nenv", "sum_reserved",
+                "max_abs_qacc", "max_abs_qvel", "max_time", "max_r3", "max_r4", "max_r5", "max_r6", "max_r7"]
+
 HW_METHODS = {"effort": 0, "position": 1, "position_pid": 2, "velocity": 3, "velocity_pid": 4}
 HW_KINDS = {"revolute": 0, "continuous": 1, "prismatic": 2}
 
@@ -169,6 +174,9 @@ def load_library(path=None):
         "mjb_synchronize": (ci, [vp]),
         "mjb_time_steps": (ci, [vp, ci, ci, C.POINTER(cd)]),
         "mjb_warning_count": (ci, [vp, C.POINTER(C.c_uint64)]),
+        "mjb_warning": (ci, [vp, ci, C.POINTER(C.c_uint64)]),
+        "mjb_metrics": (ci, [vp, C.POINTER(cd)]),
+        "mjb_metrics_device": (vp, [vp]),
         "mjb_debug_profile": (ci, [vp, C.POINTER(C.c_uint64), ci]),
     }
     for name, (res, args) in sig.items():

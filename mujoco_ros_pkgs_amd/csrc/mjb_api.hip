@@ -100,6 +100,8 @@ struct mjb_batch {
 	bool frame_valid = false;
 	unsigned char *mask_dev = nullptr;
 	KernelParams *params_dev = nullptr;  // device copy of {dm, L, st, nz}
+	double *metrics_dev = nullptr;       // [16] mjb_metrics
+	unsigned long long steps_taken = 0;  // steps since the batch was made (step_counter is the 32-bit Philox counter)
 	bool params_dirty = true;
 	// sensors-plugin equivalent (mjb_sensor_*): noise models (host mirror + device copy) and the packed messages
 	std::vector<int> sens_flag;
@@ -363,6 +365,26 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		                       "(nv <= 64, nbody <= 64)", d.nv, d.nbody);
 		return nullptr;
 	}
+	// every array the description declares must be there before anything below reads it
+#define MJB_SIZE(name)                                                                    \
+	if (d.name < 0) {                                                                     \
+		fail(MJB_EINVAL, "mjb_compile: negative size %s", #name);                         \
+		return nullptr;                                                                   \
+	}
+#define MJB_OPT_I(name)
+#define MJB_OPT_D(name, n)
+#define MJB_ARR_I(name, rows, cols)                                                       \
+	if ((size_t)d.rows * (cols) && !d.name) {                                             \
+		fail(MJB_EINVAL, "mjb_compile: array %s is NULL", #name);                         \
+		return nullptr;                                                                   \
+	}
+#define MJB_ARR_D(name, rows, cols) MJB_ARR_I(name, rows, cols)
+#include "../../include/mjb_model_fields.def"
+#undef MJB_SIZE
+#undef MJB_OPT_I
+#undef MJB_OPT_D
+#undef MJB_ARR_I
+#undef MJB_ARR_D
 	for (int i = 0; i < d.nsensor; i++) {
 		static const int ok[] = { MJB_SENS_TOUCH, MJB_SENS_ACCELEROMETER, MJB_SENS_VELOCIMETER, MJB_SENS_GYRO, MJB_SENS_FORCE,
 			                      MJB_SENS_TORQUE, MJB_SENS_JOINTPOS, MJB_SENS_JOINTVEL, MJB_SENS_TENDONPOS, MJB_SENS_TENDONVEL,
@@ -457,6 +479,75 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 #undef MJB_ARR_D
 	}
 	const mjb_model_desc &h = M->h;
+	// ---- every index table a kernel uses as an LDS / HBM offset must stay inside its target
+	{
+		auto in = [](int v, int lo, int hi) { return v >= lo && v < hi; };
+		const char *bad = nullptr;
+		for (int b = 0; b < h.nbody && !bad; b++) {
+			if (!in(h.body_mocapid[b], -1, h.nmocap)) bad = "body_mocapid";
+			if (!in(h.body_rootid[b], 0, h.nbody) || !in(h.body_weldid[b], 0, h.nbody)) bad = "body_rootid / body_weldid";
+			if (h.body_jntnum[b] < 0 || h.body_dofnum[b] < 0 || (h.body_jntnum[b] && !in(h.body_jntadr[b], 0, h.njnt)) ||
+			    h.body_jntnum[b] + (h.body_jntnum[b] ? h.body_jntadr[b] : 0) > h.njnt || (h.body_dofnum[b] && !in(h.body_dofadr[b], 0, h.nv)) ||
+			    h.body_dofnum[b] + (h.body_dofnum[b] ? h.body_dofadr[b] : 0) > h.nv)
+				bad = "body_jntadr / body_jntnum / body_dofadr / body_dofnum";
+		}
+		for (int j = 0; j < h.njnt && !bad; j++) {
+			const int t = h.jnt_type[j], nq = t == MJB_JNT_FREE ? 7 : (t == MJB_JNT_BALL ? 4 : 1), nd = t == MJB_JNT_FREE ? 6 : (t == MJB_JNT_BALL ? 3 : 1);
+			if (!in(t, 0, 4)) bad = "jnt_type";
+			else if (!in(h.jnt_bodyid[j], 0, h.nbody)) bad = "jnt_bodyid";
+			else if (h.jnt_qposadr[j] < 0 || h.jnt_qposadr[j] + nq > h.nq) bad = "jnt_qposadr";
+			else if (h.jnt_dofadr[j] < 0 || h.jnt_dofadr[j] + nd > h.nv) bad = "jnt_dofadr";
+		}
+		for (int i = 0; i < h.nv && !bad; i++) {
+			if (!in(h.dof_bodyid[i], 0, h.nbody)) bad = "dof_bodyid";
+			if (!in(h.dof_jntid[i], 0, h.njnt)) bad = "dof_jntid";
+			if (!in(h.dof_parentid[i], -1, i)) bad = "dof_parentid";
+		}
+		for (int g = 0; g < h.ngeom && !bad; g++) {
+			if (!in(h.geom_bodyid[g], 0, h.nbody)) bad = "geom_bodyid";
+			const int t = h.geom_type[g];
+			if (t != MJB_GEOM_PLANE && t != MJB_GEOM_SPHERE && t != MJB_GEOM_CAPSULE && t != MJB_GEOM_BOX) bad = "geom_type (plane / sphere / capsule / box)";
+			if (!in(h.geom_condim[g], 1, 7) || h.geom_condim[g] == 2 || h.geom_condim[g] == 5) bad = "geom_condim (1, 3, 4, 6)";
+		}
+		for (int p = 0; p < 2 * h.ncollpair && !bad; p++)
+			if (!in(h.collpair_geom[p], 0, h.ngeom)) bad = "collpair_geom";
+		for (int st = 0; st < h.nsite && !bad; st++)
+			if (!in(h.site_bodyid[st], 0, h.nbody)) bad = "site_bodyid";
+		for (int t = 0; t < h.ntendon && !bad; t++)
+			if (h.tendon_num[t] < 0 || h.tendon_adr[t] < 0 || h.tendon_adr[t] + h.tendon_num[t] > h.nwrap) bad = "tendon_adr / tendon_num";
+		for (int w = 0; w < h.nwrap && !bad; w++)
+			if (!in(h.wrap_objid[w], 0, h.njnt) || h.jnt_type[h.wrap_objid[w]] < MJB_JNT_SLIDE) bad = "wrap_objid (hinge / slide joints)";
+		auto objcount = [&](int ot) {
+			switch (ot) {
+			case MJB_OBJ_BODY: case MJB_OBJ_XBODY: return h.nbody;
+			case MJB_OBJ_JOINT: return h.njnt;
+			case MJB_OBJ_GEOM: return h.ngeom;
+			case MJB_OBJ_SITE: return h.nsite;
+			case MJB_OBJ_ACTUATOR: return h.nu;
+			default: return 0;
+			}
+		};
+		for (int i = 0; i < h.nsensor && !bad; i++) {
+			const int t = h.sensor_type[i];
+			int cnt;
+			if (t == MJB_SENS_JOINTPOS || t == MJB_SENS_JOINTVEL || t == MJB_SENS_BALLQUAT || t == MJB_SENS_BALLANGVEL) cnt = h.njnt;
+			else if (t == MJB_SENS_TENDONPOS || t == MJB_SENS_TENDONVEL) cnt = h.ntendon;
+			else if (t == MJB_SENS_ACTUATORPOS || t == MJB_SENS_ACTUATORVEL || t == MJB_SENS_ACTUATORFRC) cnt = h.nu;
+			else if (t == MJB_SENS_SUBTREECOM) cnt = h.nbody;
+			else if (t == MJB_SENS_CLOCK) cnt = 1 << 30;
+			else if (t >= MJB_SENS_FRAMEPOS && t <= MJB_SENS_FRAMEANGACC) cnt = objcount(h.sensor_objtype[i]);
+			else cnt = h.nsite;  // touch, accelerometer, velocimeter, gyro, force, torque
+			if (t != MJB_SENS_CLOCK && !in(h.sensor_objid[i], 0, cnt)) bad = "sensor_objid";
+			if (h.sensor_refid[i] >= 0 && !in(h.sensor_refid[i], 0, objcount(h.sensor_reftype[i]))) bad = "sensor_refid";
+			if (!in(h.sensor_dim[i], 1, 5) || h.sensor_adr[i] < 0 || h.sensor_adr[i] + h.sensor_dim[i] > h.nsensordata) bad = "sensor_adr / sensor_dim";
+			if (!in(h.sensor_needstage[i], 1, 4)) bad = "sensor_needstage";
+		}
+		if (bad) {
+			fail(MJB_EINVAL, "mjb_compile: index table %s is out of range", bad);
+			delete M;
+			return nullptr;
+		}
+	}
 	// ---- validation of the tree tables the kernels index with
 	for (int b = 1; b < h.nbody; b++)
 		if (h.body_parentid[b] < 0 || h.body_parentid[b] >= b) {
@@ -641,6 +732,7 @@ void mjb_free_batch(mjb_batch *b)
 #undef MJB_DI
 	if (b->st.frame_ws) hipFree(b->st.frame_ws);
 	if (b->st.nwarn) hipFree(b->st.nwarn);
+	if (b->metrics_dev) hipFree(b->metrics_dev);
 	if (b->st.prof) hipFree(b->st.prof);
 	if (b->blob) hipFree(b->blob);
 	if (b->mask_dev) hipFree(b->mask_dev);
@@ -790,7 +882,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 #undef MJB_DD
 #undef MJB_DD2
 #undef MJB_DI
-	s.nwarn = dev_alloc<unsigned long long>(1);
+	s.nwarn = dev_alloc<unsigned long long>(MJB_NWARNING);
 	ok = ok && s.nwarn;
 	s.prof = dev_alloc<unsigned long long>(64);
 	ok = ok && s.prof;
@@ -902,6 +994,7 @@ int mjb_step(mjb_batch *b, int nsteps)
 	int rc = launch(b, MJB_MODE_STEP, nsteps);
 	if (rc == MJB_OK) {
 		b->step_counter += (unsigned int)nsteps;
+		b->steps_taken += (unsigned long long)nsteps;
 		b->frame_valid = b->st.keep_frame != 0;
 	}
 	return rc;
@@ -937,7 +1030,10 @@ int mjb_step2(mjb_batch *b)
 	if (!b) return fail(MJB_EINVAL, "null batch");
 	if (!b->frame_valid || !b->st.frame_ws) return fail(MJB_EINVAL, "mjb_step2 without a preceding mjb_step1");
 	int rc = launch(b, MJB_MODE_STEP2, 1);
-	if (rc == MJB_OK) b->step_counter += 1;
+	if (rc == MJB_OK) {
+		b->step_counter += 1;
+		b->steps_taken += 1;
+	}
 	return rc;
 }
 
@@ -1142,12 +1238,105 @@ int mjb_debug_profile(mjb_batch *b, unsigned long long *out64, int clear)
 	return MJB_OK;
 }
 
+int mjb_warning(mjb_batch *b, int which, unsigned long long *count)
+{
+	if (!b || !count || which < 0 || which >= MJB_NWARNING) return fail(MJB_EINVAL, "mjb_warning: bad argument");
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	HIP_TRY(hipMemcpy(count, b->st.nwarn + which, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	return MJB_OK;
+}
+
 int mjb_warning_count(mjb_batch *b, unsigned long long *count)
 {
 	if (!b || !count) return fail(MJB_EINVAL, "mjb_warning_count: bad argument");
+	unsigned long long w[MJB_NWARNING];
 	HIP_TRY(hipSetDevice(b->device));
 	HIP_TRY(hipStreamSynchronize(b->stream));
-	HIP_TRY(hipMemcpy(count, b->st.nwarn, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(w, b->st.nwarn, sizeof w, hipMemcpyDeviceToHost));
+	*count = w[MJB_WARN_BADQPOS] + w[MJB_WARN_BADQVEL] + w[MJB_WARN_BADQACC];
+	return MJB_OK;
+}
+
+}  // extern "C"
+
+// ---- aggregate metrics (mjb_metrics): one workgroup reduces the state arrays of the batch ----
+__global__ void mjb_metrics_kernel(const double *qacc, const double *qvel, const double *time, const double *energy,
+                                   const unsigned long long *nwarn, int nenv, int nv, double env_steps, double *out)
+{
+	__shared__ double red[4][256];
+	double mq = 0, mv = 0, mt = 0, pe = 0, ke = 0;
+	for (size_t k = threadIdx.x; k < (size_t)nenv * nv; k += blockDim.x) {
+		mq = fmax(mq, fabs(qacc[k]));
+		mv = fmax(mv, fabs(qvel[k]));
+	}
+	for (int e = threadIdx.x; e < nenv; e += blockDim.x) {
+		mt = fmax(mt, time[e]);
+		pe += energy[2 * e];
+		ke += energy[2 * e + 1];
+	}
+	// (fmax drops NaNs: an env that went non-finite inside a launch has been reset before the state was stored)
+	double v[5] = { mq, mv, mt, pe, ke };
+	double res[5];
+	for (int q = 0; q < 5; q++) {
+		red[0][threadIdx.x] = v[q];
+		__syncthreads();
+		for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+			if ((int)threadIdx.x < s)
+				red[0][threadIdx.x] = q < 3 ? fmax(red[0][threadIdx.x], red[0][threadIdx.x + s]) : red[0][threadIdx.x] + red[0][threadIdx.x + s];
+			__syncthreads();
+		}
+		res[q] = red[0][0];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		out[0] = env_steps;
+		out[1] = (double)(nwarn[MJB_WARN_BADQPOS] + nwarn[MJB_WARN_BADQVEL] + nwarn[MJB_WARN_BADQACC]);
+		out[2] = (double)nwarn[MJB_WARN_CONTACTFULL];
+		out[3] = (double)nwarn[MJB_WARN_CNSTRFULL];
+		out[4] = res[3];
+		out[5] = res[4];
+		out[6] = (double)nenv;
+		out[7] = 0;
+		out[8] = res[0];
+		out[9] = res[1];
+		out[10] = res[2];
+		for (int k = 11; k < 16; k++) out[k] = 0;
+	}
+}
+
+extern "C" {
+
+void *mjb_metrics_device(mjb_batch *b)
+{
+	if (!b) {
+		fail(MJB_EINVAL, "null batch");
+		return nullptr;
+	}
+	if (hipSetDevice(b->device) != hipSuccess) return nullptr;
+	if (!b->metrics_dev) {
+		b->metrics_dev = dev_alloc<double>(16);
+		if (!b->metrics_dev) {
+			fail(MJB_ENOMEM, "mjb_metrics: allocation failed");
+			return nullptr;
+		}
+	}
+	hipLaunchKernelGGL(mjb_metrics_kernel, dim3(1), dim3(256), 0, b->stream, b->st.qacc, b->st.qvel, b->st.time, b->st.energy,
+	                   b->st.nwarn, b->nenv, b->model->h.nv, (double)b->nenv * (double)b->steps_taken, b->metrics_dev);
+	if (hipGetLastError() != hipSuccess) {
+		fail(MJB_ENODEVICE, "mjb_metrics: launch failed");
+		return nullptr;
+	}
+	return b->metrics_dev;
+}
+
+int mjb_metrics(mjb_batch *b, double *out16)
+{
+	if (!b || !out16) return fail(MJB_EINVAL, "mjb_metrics: bad argument");
+	void *p = mjb_metrics_device(b);
+	if (!p) return MJB_ENODEVICE;
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	HIP_TRY(hipMemcpy(out16, p, 16 * sizeof(double), hipMemcpyDeviceToHost));
 	return MJB_OK;
 }
 

@@ -499,7 +499,7 @@ DEVI int narrowphase(int t1, int t2, const double *pos1, const double *mat1, con
 // ------------------------------------------------------------------------------------------------
 // A4 + A5  collision: one candidate pair per lane, contacts compacted in pair order
 // ------------------------------------------------------------------------------------------------
-template <int G> STAGE void collision(CModel m, CLayout L, const Env &e)
+template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &e)
 {
 	double *f = e.f;
 	int *fi = e.fi;
@@ -614,7 +614,10 @@ template <int G> STAGE void collision(CModel m, CLayout L, const Env &e)
 		for (int q = p0; q < hi; q++) base += cnt[q];
 		gsync<G>();
 	}
-	if (lane == 0) fi[L.ncon] = base < m.nconmax ? base : m.nconmax;
+	if (lane == 0) {
+		fi[L.ncon] = base < m.nconmax ? base : m.nconmax;
+		if (base > m.nconmax) atomicAdd(s.nwarn + MJB_WARN_CONTACTFULL, 1ull);  // mjWARN_CONTACTFULL: the contacts past nconmax were dropped
+	}
 	gsync<G>();
 }
 
@@ -663,11 +666,17 @@ DEVI void row_params(CModel m, CLayout L, double *f, int i, double pos, double m
 }
 // imp_pos: the position the impedance is evaluated at (rows of a connect / weld share the norm of their residual)
 DEVI void row_params_x(CModel m, CLayout L, double *f, int i, double pos, double margin, const double *solref_in,
-                       const double *solimp, double diag_approx, double imp_pos)
+                       const double *solimp_in, double diag_approx, double imp_pos)
 {
-	double sr0 = solref_in[0];
-	const double sr1 = solref_in[1];
+	// getsolparam: mixed-sign solref falls back to the default (0.02, 1); refsafe; solimp clamped to its legal ranges
+	double sr0 = solref_in[0], sr1 = solref_in[1];
+	if ((sr0 > 0) != (sr1 > 0)) {
+		sr0 = 0.02;
+		sr1 = 1.0;
+	}
 	if (!(m.disableflags & MJB_DSBL_REFSAFE) && sr0 > 0) sr0 = fmax(sr0, 2 * m.timestep[0]);
+	const double solimp[5] = { fmin(MJB_MAXIMP, fmax(MJB_MINIMP, solimp_in[0])), fmin(MJB_MAXIMP, fmax(MJB_MINIMP, solimp_in[1])),
+		                       fmax(0.0, solimp_in[2]), fmin(MJB_MAXIMP, fmax(MJB_MINIMP, solimp_in[3])), fmax(1.0, solimp_in[4]) };
 	double imp, impP;
 	impedance(solimp, imp_pos, margin, imp, impP);
 	f[L.efc_R + i] = fmax(MJB_MINVAL, (1 - imp) * diag_approx / imp);
@@ -731,7 +740,7 @@ DEVI void eq_geometry(CModel m, CLayout L, const double *f, int e, EqGeom &g)
 // ------------------------------------------------------------------------------------------------
 // A6  make_constraint: rows for equalities (connect / weld / joint), joint limits, then contacts
 // ------------------------------------------------------------------------------------------------
-template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
+template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const Env &e)
 {
 	double *f = e.f;
 	int *fi = e.fi;
@@ -792,6 +801,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, const Env &e)
 		}
 		nefc += n;
 	}
+	if (cut < nitem && lane == 0) atomicAdd(s.nwarn + MJB_WARN_CNSTRFULL, 1ull);  // mjWARN_CNSTRFULL (rule: include/mjb.h, mjb_warning)
 	// pass 2: row parameters, one item per lane (item order == row order)
 	for (int it0 = 0; it0 < cut; it0 += G) {
 		const int it = it0 + lane;

@@ -99,7 +99,7 @@ struct DevState {
 #undef MJB_DD2
 #undef MJB_DI
 	double *frame_ws;              // optional [nenv][ndouble + nint/2 padded] full-frame workspace
-	unsigned long long *nwarn;     // [1] auto-reset counter (mj_checkPos/Vel/Acc warnings)
+	unsigned long long *nwarn;     // [MJB_NWARNING] mjData.warning[].number summed over the envs (mjb_warning)
 	unsigned long long *prof;      // [64] per-stage cycle sums + call counts (profiling build only), else NULL
 	int nenv;
 	int frame_stride;              // doubles per env in frame_ws

@@ -8,6 +8,8 @@
 #define DEVI static __device__ __forceinline__
 #define MJB_MINVAL 1e-15
 #define MJB_MAXVAL 1e10
+#define MJB_MINIMP 0.0001  // mjMINIMP / mjMAXIMP: legal range of the solimp impedances (getsolparam)
+#define MJB_MAXIMP 0.9999
 
 DEVI void ld3(double *r, const double *p) { r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; }
 DEVI void ld4(double *r, const double *p) { r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; r[3] = p[3]; }

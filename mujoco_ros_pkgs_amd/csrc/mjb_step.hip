@@ -1607,23 +1607,26 @@ template <int G> STAGE void store_state(CModel m, CLayout L, CState s, const Env
 	copy_out<G>(s.sensordata + env * m.nsensordata, e.f + L.sensordata, m.nsensordata, e.lane);
 	copy_out<G>(s.ctrlnoise + env * m.nu, e.f + L.ctrlnoise, m.nu, e.lane);
 	if (e.lane == 0) s.time[env] = e.f[L.time];
+	if (m.enableflags & MJB_ENBL_ENERGY) copy_out<G>(s.energy + env * 2, e.f + L.energy, 2, e.lane);
 }
 
-// mj_checkPos / mj_checkVel / mj_checkAcc: NaN or |x| > mjMAXVAL -> flag in the int frame
-template <int G> DEVI bool any_bad(const Env &e, CLayout L, const double *a, int na, const double *b, int nb)
+// mj_checkPos / mj_checkVel / mj_checkAcc: NaN or |x| > mjMAXVAL -> flag in the int frame.  Returns 0 (fine), 1 (array a is
+// bad) or 2 (only array b is bad): mj_step checks qpos first and resets on it, so a bad qpos hides a bad qvel.
+template <int G> DEVI int any_bad(const Env &e, CLayout L, const double *a, int na, const double *b, int nb)
 {
 	int *flag = e.fi + L.solver_iter;  // reused as a transient flag; rewritten by fwd_constraint
 	if (e.lane == 0) *flag = 0;
 	gsync<G>();
-	bool bad = false;
-	for (int k = e.lane; k < na; k += G) bad |= !(a[k] == a[k]) || fabs(a[k]) > MJB_MAXVAL;
-	for (int k = e.lane; k < nb; k += G) bad |= !(b[k] == b[k]) || fabs(b[k]) > MJB_MAXVAL;
-	if (bad) *flag = 1;
+	bool bad_a = false, bad_b = false;
+	for (int k = e.lane; k < na; k += G) bad_a |= !(a[k] == a[k]) || fabs(a[k]) > MJB_MAXVAL;
+	for (int k = e.lane; k < nb; k += G) bad_b |= !(b[k] == b[k]) || fabs(b[k]) > MJB_MAXVAL;
+	if (bad_b) *flag = 2;
+	if (bad_a) *flag = 1;  // (lanes of a group run in lockstep: this store lands after the one above)
 	gsync<G>();
-	return *flag != 0;
+	return *flag;
 }
 
-template <int G> __device__ __attribute__((noinline)) void reset_frame_state(CModel m, CLayout L, CState s, const Env &e)
+template <int G> __device__ __attribute__((noinline)) void reset_frame_state(CModel m, CLayout L, CState s, const Env &e, int warning)
 {
 	double *f = e.f;
 	for (int k = e.lane; k < L.nstate; k += G) f[k] = 0;  // state prefix starts at offset 0
@@ -1635,7 +1638,7 @@ template <int G> __device__ __attribute__((noinline)) void reset_frame_state(CMo
 		for (int k = 0; k < 3; k++) f[L.mocap_pos + 3 * mid + k] = m.body_pos[3 * b + k];
 		for (int k = 0; k < 4; k++) f[L.mocap_quat + 4 * mid + k] = m.body_quat[4 * b + k];
 	}
-	if (e.lane == 0) atomicAdd(s.nwarn, 1ull);
+	if (e.lane == 0) atomicAdd(s.nwarn + warning, 1ull);  // mjData.warning[mjWARN_BADQPOS / BADQVEL / BADQACC].number
 	gsync<G>();
 }
 
@@ -1692,9 +1695,9 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 		                            m.eulerdamp != 0));
 	PROF(3);
 	if constexpr (CON) {
-		VIEW(P, compact, collision<G>(m, L, e));
+		VIEW(P, compact, collision<G>(m, L, s, e));
 		PROF(16);
-		VIEW(P, compact, make_constraint<G>(m, L, e));
+		VIEW(P, compact, make_constraint<G>(m, L, s, e));
 		PROF(17);
 		if constexpr (CON == 1 || CON == 5) {
 			if (P->m.nv <= 16) VIEW(P, compact, project_constraint_dense16<G>(m, L, e));
@@ -1740,6 +1743,121 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 	PROF(12);
 }
 
+// ---- angles:: helpers of the reference's ros_control bridge (ROS package `angles`, a dependency absent from
+// /root/reference; restated from its published header angles/angles.h) ----
+DEVI double angdist(double from, double to)  // shortest_angular_distance
+{
+	const double two_pi = 6.283185307179586476925;
+	double a = fmod(fmod(to - from, two_pi) + two_pi, two_pi);  // normalize_angle_positive
+	if (a > 0.5 * two_pi) a -= two_pi;
+	return a;
+}
+DEVI double two_pi_complement(double a)
+{
+	const double two_pi = 6.283185307179586476925;
+	if (a > two_pi || a < -two_pi) a = fmod(a, two_pi);
+	if (a < 0) return two_pi + a;
+	if (a > 0) return -two_pi + a;
+	return two_pi;
+}
+DEVI bool find_min_max_delta(double from, double left, double right, double &dmin, double &dmax)
+{
+	const double pi = 3.14159265358979323846;
+	const double d0 = angdist(from, left), d1 = angdist(from, right), d2 = two_pi_complement(d0), d3 = two_pi_complement(d1);
+	if (d0 == 0) {
+		dmin = d0;
+		dmax = fmax(d1, d3);
+		return true;
+	}
+	if (d1 == 0) {
+		dmax = d1;
+		dmin = fmin(d0, d2);
+		return true;
+	}
+	double lo = d0, lo2 = d2, hi = d1, hi2 = d3;
+	if (d2 < lo) { lo = d2; lo2 = d0; }
+	if (d3 > hi) { hi = d3; hi2 = d1; }
+	if (lo <= hi2 || hi >= lo2) {
+		dmin = hi2;
+		dmax = lo2;
+		return left == -pi && right == pi;
+	}
+	dmin = lo;
+	dmax = hi;
+	return true;
+}
+DEVI double angdist_with_limits(double from, double to, double left, double right)  // shortest_angular_distance_with_limits
+{
+	const double two_pi = 6.283185307179586476925;
+	double dmin = -two_pi, dmax = two_pi, tmin = -two_pi, tmax = two_pi;
+	const bool inside = find_min_max_delta(from, left, right, dmin, dmax);
+	const double delta = angdist(from, to), comp = two_pi_complement(delta);
+	if (inside) {
+		if (delta >= dmin && delta <= dmax) return delta;
+		if (comp >= dmin && comp <= dmax) return comp;
+		find_min_max_delta(to, left, right, tmin, tmax);
+		if (fabs(tmin) < fabs(tmax)) return fmax(delta, comp);
+		if (fabs(tmin) > fabs(tmax)) return fmin(delta, comp);
+		return fabs(delta) < fabs(comp) ? delta : comp;
+	}
+	find_min_max_delta(to, left, right, tmin, tmax);
+	if (fabs(dmin) < fabs(dmax)) return fmin(delta, comp);
+	if (fabs(dmin) > fabs(dmax)) return fmax(delta, comp);
+	return fabs(delta) < fabs(comp) ? delta : comp;
+}
+
+// mj_energyPos / mj_energyVel (mjENBL_ENERGY): potential = -sum m g.xipos + joint / tendon spring energy, kinetic =
+// 0.5 qvel' M qvel.  Evaluated for the LAST step of a launch only (intermediate values are not observable), by one lane:
+// a few hundred dependent LDS reads once per launch.
+template <int G> __device__ __attribute__((noinline)) void energy(CModel m, CLayout L, const Env &e)
+{
+	double *f = e.f;
+	if (e.lane == 0) {
+		double pe = 0, ke = 0;
+		if (!(m.disableflags & MJB_DSBL_GRAVITY))
+			for (int b = 1; b < m.nbody; b++)
+				pe -= MP_BODY_MASS(m, e, b) * (f[L.gravity] * f[L.xipos + 3 * b] + f[L.gravity + 1] * f[L.xipos + 3 * b + 1] +
+				                               f[L.gravity + 2] * f[L.xipos + 3 * b + 2]);
+		if (!(m.disableflags & MJB_DSBL_PASSIVE)) {
+			for (int j = 0; j < m.njnt; j++) {
+				const double k = m.jnt_stiffness[j];
+				if (k == 0) continue;
+				int pa = m.jnt_qposadr[j];
+				const int jt = m.jnt_type[j];
+				if (jt == MJB_JNT_FREE) {
+					for (int c = 0; c < 3; c++) {
+						const double dq = f[L.qpos + pa + c] - m.qpos_spring[pa + c];
+						pe += 0.5 * k * dq * dq;
+					}
+					pa += 3;
+				}
+				if (jt == MJB_JNT_FREE || jt == MJB_JNT_BALL) {
+					double q[4], qs[4], dif[3];
+					ld4(q, f + L.qpos + pa);
+					normalize4(q);
+					ldc4(qs, m.qpos_spring + pa);
+					quat_sub(dif, q, qs);
+					pe += 0.5 * k * dot3(dif, dif);
+				} else {
+					const double dq = f[L.qpos + pa] - m.qpos_spring[pa];
+					pe += 0.5 * k * dq * dq;
+				}
+			}
+			for (int t = 0; t < m.ntendon; t++) {
+				const double dl = f[L.ten_length + t] - m.tendon_lengthspring[t];
+				pe += 0.5 * m.tendon_stiffness[t] * dl * dl;
+			}
+		}
+		for (int en = 0; en < m.nM; en++) {
+			const int i = m.M_rowdof[en], j = m.M_coldof[en];
+			ke += (i == j ? 0.5 : 1.0) * f[L.qM + en] * f[L.qvel + i] * f[L.qvel + j];
+		}
+		f[L.energy] = pe;
+		f[L.energy + 1] = ke;
+	}
+	gsync<G>();
+}
+
 // device-side DefaultRobotHWSim::writeSim (include/mjb.h, mjb_hwsim_*): lane = controlled joint
 template <int G> __device__ __attribute__((noinline)) void hwsim_write(CModel m, CLayout L, const HwSim MJB_AS4 &hw, const Env &e)
 {
@@ -1768,13 +1886,13 @@ template <int G> __device__ __attribute__((noinline)) void hwsim_write(CModel m,
 		case MJB_HW_POSITION_PID: {
 			const int kind = hw.kind[k];
 			if (kind == MJB_HW_REVOLUTE) {
-				const double c = (gn[7] > gn[6]) ? fmin(fmax(cpos, gn[6]), gn[7]) : cpos;
-				error = c - pos;
+				// position command saturated to the joint limits (pj_sat_interface_.enforceLimits, :263), then the error the
+				// reference takes with angles::shortest_angular_distance_with_limits (:289-291)
+				const bool lim = gn[7] > gn[6];
+				const double c = lim ? fmin(fmax(cpos, gn[6]), gn[7]) : cpos;
+				error = lim ? angdist_with_limits(pos, c, gn[6], gn[7]) : c - pos;
 			} else if (kind == MJB_HW_CONTINUOUS) {
-				const double two_pi = 6.283185307179586476925;
-				double a = fmod(fmod(cpos - pos, two_pi) + two_pi, two_pi);  // normalize_angle_positive
-				if (a > 0.5 * two_pi) a -= two_pi;
-				error = a;
+				error = angdist(pos, cpos);
 			} else {
 				error = cpos - pos;
 			}
@@ -1924,25 +2042,30 @@ __global__ void __launch_bounds__(256, (CON ? 1 : (G == 64 ? 4 : (G == 32 ? 2 : 
 		const bool do_euler = mode == MJB_MODE_STEP || mode == MJB_MODE_STEP2;
 		const bool checks = mode != MJB_MODE_FORWARD;
 		const int nst = mode == MJB_MODE_STEP ? nsteps : 1;
-		const bool hw_on = do_first && checks && P->hw.n > 0;  // device-side DefaultRobotHWSim stage registered
+		const bool hw_on = do_rest && checks && P->hw.n > 0;  // device-side DefaultRobotHWSim stage registered
 #pragma nounroll
 		for (int st = 0; st < nst; st++) {
 			PROF_BEGIN();
 			if (do_first && checks && nz.enabled) ctrl_noise<G>(m, L, nz, e, step0 + (unsigned int)st);
-			if (hw_on) VIEW(P, compact, hwsim_write<G>(m, L, Pq_->hw, e));
 			PROF(13);
 			// attempt 1 only runs after mj_checkAcc found a bad qacc: reset, full forward, integrate
 #pragma nounroll
 			for (int attempt = 0; attempt < 2; attempt++) {
 				if (do_first || attempt) {
-					if (attempt == 0 && checks && any_bad<G>(e, L, e.f + L.qpos, m.nq, e.f + L.qvel, m.nv))
-						reset_frame_state<G>(m, L, s, e);
+					if (attempt == 0 && checks) {
+						const int bad = any_bad<G>(e, L, e.f + L.qpos, m.nq, e.f + L.qvel, m.nv);
+						if (bad) reset_frame_state<G>(m, L, s, e, bad == 1 ? MJB_WARN_BADQPOS : MJB_WARN_BADQVEL);
+					}
 					forward_first<G, CON, DENSE>(P, e, compact);
+					if (st == nst - 1 && P->m.enableflags & MJB_ENBL_ENERGY) VIEW(P, compact, energy<G>(m, L, e));
 				}
 				if (!do_rest) break;
+				// device-side DefaultRobotHWSim::writeSim runs where the reference's control callback fires: after the position
+				// and velocity stages, before actuation (mjcb_control inside mj_forward; mujoco_ros_control_plugin.cpp:153-194)
+				if (hw_on) VIEW(P, compact, hwsim_write<G>(m, L, Pq_->hw, e));
 				forward_rest<G, CON, DENSE>(P, e, compact);
 				if (attempt || !checks || !any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0)) break;
-				reset_frame_state<G>(m, L, s, e);
+				reset_frame_state<G>(m, L, s, e, MJB_WARN_BADQACC);
 			}
 			PROF(14);  // whole forward (incl. checks)
 			if (do_euler) VIEW(P, compact, euler<G, (CON != 0)>(m, L, e));
@@ -1994,6 +2117,7 @@ __global__ void mjb_reset_kernel(const KernelParams MJB_AS4 *__restrict__ P, con
 		for (int k = 0; k < 4; k++) s.mocap_quat[(e * m.nmocap + mid) * 4 + k] = m.body_quat[4 * b + k];
 	}
 	s.time[e] = 0;
+	s.energy[2 * e] = s.energy[2 * e + 1] = 0;
 }
 
 template <int G, int CON, int DENSE = 0>

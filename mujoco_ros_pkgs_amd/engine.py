@@ -105,6 +105,24 @@ class Batch:
         _check(self.lib.mjb_warning_count(self.ptr, C.byref(n)), "mjb_warning_count")
         return int(n.value)
 
+    def warning(self, which):
+        """mjData.warning[which].number summed over the envs (mjb_warning; which = binding.WARN[...] or its int value)."""
+        n = C.c_uint64(0)
+        _check(self.lib.mjb_warning(self.ptr, binding.WARN.get(which, which), C.byref(n)), "mjb_warning")
+        return int(n.value)
+
+    def metrics(self):
+        """The 16-double metrics vector of include/mjb.h (mjb_metrics) as a dict + the raw array."""
+        out = np.zeros(16)
+        _check(self.lib.mjb_metrics(self.ptr, out.ctypes.data_as(C.POINTER(C.c_double))), "mjb_metrics")
+        return dict(zip(binding.METRIC_NAMES, out)), out
+
+    def metrics_device_ptr(self):
+        p = self.lib.mjb_metrics_device(self.ptr)
+        if not p:
+            raise EngineError(self.lib.mjb_last_error().decode())
+        return p
+
     # ---- per-env model parameters ----
     def set_env_gravity(self, gravity, lo=0, hi=None):
         hi = self.nenv if hi is None else hi

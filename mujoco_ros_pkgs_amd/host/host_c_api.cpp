@@ -192,6 +192,7 @@ int mjr_env_set_ctrl_noise(mjr_env *e, double std, double rate)
 	return 0;
 }
 double mjr_env_sim_time(mjr_env *e) { return e->env->simTime(); }
+double mjr_env_data_time(mjr_env *e) { return e->env->dataTime(); }
 unsigned long long mjr_env_step_count(mjr_env *e) { return e->env->stepCount(); }
 int mjr_env_nenv(mjr_env *e) { return e->env->nenv(); }
 int mjr_env_name2id(mjr_env *e, int objtype, const char *name)

@@ -89,6 +89,9 @@ int MujocoEnv::getOperationalStatus()
 
 void MujocoEnv::publishSimTime(mjtNum time)
 {
+	// the loop paces itself on data_->time whatever use_sim_time says (mujoco_env.cpp:466-467, :536, :560); only the
+	// /clock publication is gated by it (:701-703)
+	data_time_.store(time);
 	if (!settings_.use_sim_time) return;
 	sim_time_.store(time);  // the reference publishes /clock and spins until ros::Time::now() >= time (:699-714)
 }
@@ -416,7 +419,7 @@ void MujocoEnv::physicsLoop()
 		if (settings_.run.load()) {
 			const auto startCPU = Clock::now();
 			const auto elapsedCPU = startCPU - syncCPU;
-			const double simtime = sim_time_.load();
+			const double simtime = data_time_.load();
 			const double elapsedSim = simtime - syncSim;
 			// ctrl noise (mujoco_env.cpp:469-481) is generated on the device right before each step
 			const double slowdown = settings_.real_time_index == 0 ? 1.0 : 100.0 / percentRealTime[settings_.real_time_index];
@@ -436,7 +439,7 @@ void MujocoEnv::physicsLoop()
 				bool measured = false;
 				const double dt = model_.opt.timestep;
 				while ((settings_.real_time_index == 0 ||
-				        Seconds((sim_time_.load() - syncSim) * slowdown) < Clock::now() - syncCPU) &&
+				        Seconds((data_time_.load() - syncSim) * slowdown) < Clock::now() - syncCPU) &&
 				       Clock::now() - startCPU < Seconds(render_ui_rate_lower_bound_) && !settings_.exit_request.load() &&
 				       num_steps_until_exit_ != 0 && settings_.run.load()) {
 					if (!measured && elapsedSim != 0) {
@@ -446,24 +449,24 @@ void MujocoEnv::physicsLoop()
 					int n = 1;
 					if (settings_.real_time_index == 0) n = kFuseChunk;
 					else {
-						const double behind = Seconds(Clock::now() - syncCPU).count() / slowdown - (sim_time_.load() - syncSim);
+						const double behind = Seconds(Clock::now() - syncCPU).count() / slowdown - (data_time_.load() - syncSim);
 						n = std::max(1, std::min(kFuseChunk, (int)(behind / dt)));
 					}
 					if (num_steps_until_exit_ > 0) n = std::min(n, num_steps_until_exit_);
-					const double prev = sim_time_.load();
+					const double prev = data_time_.load();
 					if (stepBurst(n, false) == 0) break;
-					if (sim_time_.load() < prev) break;  // reset
+					if (data_time_.load() < prev) break;  // reset
 				}
 			}
 		} else {
 			// paused (mujoco_env.cpp:584-623)
 			if (settings_.env_steps_request.load() > 0) {
-				syncSim = sim_time_.load();
+				syncSim = data_time_.load();
 				while (settings_.env_steps_request.load() > 0 && !settings_.exit_request.load()) {
 					int n = std::min(settings_.env_steps_request.load(), kFuseChunk);
 					if (num_steps_until_exit_ > 0) n = std::min(n, num_steps_until_exit_);
 					if (n <= 0 || stepBurst(n, true) == 0) break;
-					if (sim_time_.load() < syncSim) break;
+					if (data_time_.load() < syncSim) break;
 					if (num_steps_until_exit_ == 0) break;
 				}
 			} else {

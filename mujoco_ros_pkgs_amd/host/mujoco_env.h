@@ -127,6 +127,7 @@ public:
 	void commitData(int env = 0);     // pushes qpos / qvel / ctrl / qfrc_applied / xfrc_applied of `env` back
 	int nenv() const { return nenv_; }
 	double simTime() const { return sim_time_.load(); }  // what /clock carries (publishSimTime, :699-714)
+	double dataTime() const { return data_time_.load(); }  // data_->time of env 0
 	mjr_backend *backend() { return backend_; }
 	unsigned long long stepCount() const { return step_count_.load(); }
 	// envs [0, n) get host callbacks each step; default: all
@@ -181,7 +182,8 @@ protected:
 
 	int num_steps_until_exit_ = -1;
 	std::atomic_int is_physics_running_ = { 0 }, is_event_running_ = { 0 };
-	std::atomic<double> sim_time_ = { 0.0 };
+	std::atomic<double> sim_time_ = { 0.0 };   // the /clock equivalent: only advances with use_sim_time
+	std::atomic<double> data_time_ = { 0.0 };  // env 0's data->time after the latest step / forward: what the loop paces on
 	std::atomic<unsigned long long> step_count_ = { 0 };
 	std::string load_error_;
 	std::thread physics_thread_handle_, event_thread_handle_;

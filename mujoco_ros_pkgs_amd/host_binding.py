@@ -67,6 +67,7 @@ def load_library():
         "mjr_env_set_setting": (ci, [vp, cs, ci]),
         "mjr_env_set_ctrl_noise": (ci, [vp, C.c_double, C.c_double]),
         "mjr_env_sim_time": (C.c_double, [vp]),
+        "mjr_env_data_time": (C.c_double, [vp]),
         "mjr_env_step_count": (C.c_ulonglong, [vp]),
         "mjr_env_nenv": (ci, [vp]),
         "mjr_env_name2id": (ci, [vp, ci, cs]),
@@ -149,6 +150,7 @@ class HostEnv:
     model_valid = property(lambda self: bool(self.L.mjr_env_model_valid(self.ptr)))
     load_error = property(lambda self: self.L.mjr_env_load_error(self.ptr).decode())
     sim_time = property(lambda self: self.L.mjr_env_sim_time(self.ptr))
+    data_time = property(lambda self: self.L.mjr_env_data_time(self.ptr))
     step_count = property(lambda self: self.L.mjr_env_step_count(self.ptr))
     nenv = property(lambda self: self.L.mjr_env_nenv(self.ptr))
 

@@ -216,7 +216,7 @@ class _Compiler:
         self.sensors = []
         self.excludes = []
         self.opt = dict(timestep=0.002, gravity=np.array([0, 0, -9.81]), tolerance=1e-8, impratio=1.0,
-                        integrator=0, cone=0, solver=2, iterations=100, disableflags=0)
+                        integrator=0, cone=0, solver=2, iterations=100, disableflags=0, enableflags=0)
 
     # ---- attribute helpers
     def _merged(self, node, childclass):
@@ -345,7 +345,10 @@ class _Compiler:
                 if k in DISABLE_BITS:
                     if v == "disable":
                         o["disableflags"] |= DISABLE_BITS[k]
-                elif v == "enable" and k in ("override", "energy", "fwdinv", "sensornoise", "multiccd"):
+                elif k == "energy":
+                    if v == "enable":
+                        o["enableflags"] |= 1 << 1  # mjENBL_ENERGY
+                elif v == "enable" and k in ("override", "fwdinv", "sensornoise", "multiccd"):
                     raise MjcfError(f"enable flag {k} not supported")
 
     # ---- kinematic tree
@@ -853,7 +856,7 @@ class _Compiler:
         m.update(timestep=np.array([o["timestep"]], D), gravity=np.asarray(o["gravity"], D),
                  tolerance=np.array([o["tolerance"]], D), impratio=np.array([o["impratio"]], D),
                  integrator=o["integrator"], cone=o["cone"], solver=o["solver"], iterations=o["iterations"],
-                 disableflags=o["disableflags"])
+                 disableflags=o["disableflags"], enableflags=o["enableflags"])
 
         # fixed tendons, then equality constraints (mjCEquality::Compile, [UPSTREAM] user_objects.cc): ids + eq_data at qpos0
         self._compile_tendons(m)

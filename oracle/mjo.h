@@ -41,6 +41,9 @@ typedef struct mjo_data {
 #undef MJB_DD
 #undef MJB_DD2
 #undef MJB_DI
+	/* mjData.warning[].number, accumulated over the life of the data (not cleared by mjo_reset_data -- the engine's batch
+	 * counters, mjb_warning, accumulate the same way) */
+	unsigned long long warning[MJB_NWARNING];
 	/* scratch for the Euler implicit-damping solve */
 	double *scratch_MM;
 	double *scratch_nv;
@@ -99,6 +102,8 @@ void mjo_hwsim_write(const mjb_model_desc *m, mjo_data *d, int n, const int *joi
                      const double *cmd_eff, const double *cmd_hold, double *pid, int estop);
 void mjo_rne_post_constraint(const mjb_model_desc *m, mjo_data *d);
 int mjo_needs_rne_post(const mjb_model_desc *m);
+unsigned long long mjo_warning(const mjo_data *d, int which); /* mjData.warning[which].number */
+void mjo_energy(const mjb_model_desc *m, mjo_data *d);          /* mj_energyPos + mj_energyVel (mjENBL_ENERGY) */
 void mjo_tendon(const mjb_model_desc *m, mjo_data *d);
 void mjo_tendon_vel(const mjb_model_desc *m, mjo_data *d);
 void mjo_ctrl_noise(const mjb_model_desc *m, mjo_data *d, double noise_std, double noise_rate, uint64_t seed,

@@ -532,7 +532,7 @@ void mjo_collision(const mjb_model_desc *m, mjo_data *d)
 {
 	d->ncon[0] = 0;
 	if (m->nconmax <= 0 || (m->disableflags & (MJB_DSBL_CONSTRAINT | MJB_DSBL_CONTACT))) return;
-	int ncon = 0;
+	int ncon = 0, overflow = 0;
 	for (int p = 0; p < m->ncollpair; p++) {
 		int g1 = m->collpair_geom[2 * p], g2 = m->collpair_geom[2 * p + 1];
 		int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
@@ -568,8 +568,12 @@ void mjo_collision(const mjb_model_desc *m, mjo_data *d)
 		int condim;
 		double solref[2], solimp[5], fri[3];
 		contact_param(m, g1, g2, &condim, solref, solimp, fri);
-		for (int i = 0; i < n && ncon < m->nconmax; i++) {
+		for (int i = 0; i < n; i++) {
 			if (rc[i].dist >= margin) continue;
+			if (ncon >= m->nconmax) {  /* mj_addContact: full -> the contact is dropped, mjWARN_CONTACTFULL */
+				overflow = 1;
+				continue;
+			}
 			make_frame(rc[i].frame);
 			d->contact_dist[ncon] = rc[i].dist;
 			v3_copy(d->contact_pos + 3 * ncon, rc[i].pos);
@@ -587,6 +591,7 @@ void mjo_collision(const mjb_model_desc *m, mjo_data *d)
 		}
 	}
 	d->ncon[0] = ncon;
+	if (overflow) d->warning[MJB_WARN_CONTACTFULL]++;
 }
 
 /* ------------------------------------------------------------------ A6: mj_makeConstraint */
@@ -652,11 +657,19 @@ static void impedance(const double *solimp, double pos, double margin, double *i
 }
 
 /* R, D, KBIP of one row (mj_makeImpedance) */
-static void row_params_x(const mjb_model_desc *m, mjo_data *d, int i, const double *solref_in, const double *solimp,
+static void row_params_x(const mjb_model_desc *m, mjo_data *d, int i, const double *solref_in, const double *solimp_in,
                          double diag_approx, double imp_pos, double imp_margin)
 {
+	/* getsolparam: a mixed-sign solref is replaced by the default (0.02, 1); refsafe; solimp clamped to its legal ranges
+	 * (mjMINIMP = 0.0001, mjMAXIMP = 0.9999, width >= 0, power >= 1) */
 	double solref[2] = { solref_in[0], solref_in[1] };
+	if ((solref[0] > 0) != (solref[1] > 0)) {
+		solref[0] = 0.02;
+		solref[1] = 1.0;
+	}
 	if (!(m->disableflags & MJB_DSBL_REFSAFE) && solref[0] > 0) solref[0] = fmax(solref[0], 2 * m->timestep[0]);
+	const double solimp[5] = { fmin(0.9999, fmax(0.0001, solimp_in[0])), fmin(0.9999, fmax(0.0001, solimp_in[1])),
+		                       fmax(0.0, solimp_in[2]), fmin(0.9999, fmax(0.0001, solimp_in[3])), fmax(1.0, solimp_in[4]) };
 	double imp, impP;
 	impedance(solimp, imp_pos, imp_margin, &imp, &impP);
 	d->efc_R[i] = fmax(MJO_MINVAL, (1 - imp) * diag_approx / imp);
@@ -694,7 +707,7 @@ static void quat_mul_axis(double *res, const double *q, const double *a)
  * orientation neg(q2) * q1 * relpose, axis part scaled by torquescale, with the Jacobian correction
  * 0.5 neg(q2) (w1 - w2) q1 relpose), joint (1 row: q1 - q1_0 = poly(q2 - q2_0)).  All rows of a connect / weld share
  * one impedance evaluated at the norm of the residual (getposdim).  Residual sign and Jacobian: body1 - body2. */
-static int make_equality(const mjb_model_desc *m, mjo_data *d, int nefc)
+static int make_equality(const mjb_model_desc *m, mjo_data *d, int nefc, int *full)
 {
 	const int nv = m->nv;
 	static const double unit[3][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
@@ -777,7 +790,10 @@ static int make_equality(const mjb_model_desc *m, mjo_data *d, int nefc)
 		} else {
 			continue;
 		}
-		if (nefc + dim > m->nefcmax) break;
+		if (nefc + dim > m->nefcmax) {
+			*full = 1;
+			break;
+		}
 		double nrm = 0;
 		for (int k = 0; k < dim; k++) nrm += cpos[k] * cpos[k];
 		nrm = sqrt(nrm);
@@ -797,15 +813,23 @@ static int make_equality(const mjb_model_desc *m, mjo_data *d, int nefc)
 void mjo_make_constraint(const mjb_model_desc *m, mjo_data *d)
 {
 	int nv = m->nv, nefc = 0;
+	/* Capacity rule (include/mjb.h, mjb_warning): items are taken in MuJoCo's row order -- equality, dof / tendon friction,
+	 * joint limit (both sides of a joint are one item), tendon limit, contact; the first item whose rows do not fit in
+	 * nefcmax and EVERY item after it are dropped, and mjWARN_CNSTRFULL is raised. */
+	int full = 0;
 	d->nefc[0] = 0;
 	if (m->nefcmax <= 0 || (m->disableflags & MJB_DSBL_CONSTRAINT)) return;
-	if (!(m->disableflags & MJB_DSBL_EQUALITY)) nefc = make_equality(m, d, nefc);
+	if (!(m->disableflags & MJB_DSBL_EQUALITY)) nefc = make_equality(m, d, nefc, &full);
 	for (int i = 0; i < m->nefcmax; i++) d->efc_frictionloss[i] = 0;
 	/* dry joint friction (mj_instantiateFriction, dof part): one row per dof with frictionloss > 0, J = e_dof,
 	 * pos = margin = 0; the row's force is limited to +-frictionloss by the solvers */
 	if (!(m->disableflags & MJB_DSBL_FRICTIONLOSS)) {
 		for (int i = 0; i < nv; i++) {
-			if (m->dof_frictionloss[i] <= 0 || nefc >= m->nefcmax) continue;
+			if (m->dof_frictionloss[i] <= 0 || full) continue;
+			if (nefc >= m->nefcmax) {
+				full = 1;
+				continue;
+			}
 			double *row = d->efc_J + (size_t)nefc * nv;
 			memset(row, 0, sizeof(double) * (size_t)nv);
 			row[i] = 1;
@@ -819,7 +843,11 @@ void mjo_make_constraint(const mjb_model_desc *m, mjo_data *d)
 		}
 		/* tendon part: J = the tendon's moment arm row */
 		for (int t = 0; t < m->ntendon; t++) {
-			if (m->tendon_frictionloss[t] <= 0 || nefc >= m->nefcmax) continue;
+			if (m->tendon_frictionloss[t] <= 0 || full) continue;
+			if (nefc >= m->nefcmax) {
+				full = 1;
+				continue;
+			}
 			double *row = d->efc_J + (size_t)nefc * nv;
 			memset(row, 0, sizeof(double) * (size_t)nv);
 			for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++)
@@ -838,9 +866,15 @@ void mjo_make_constraint(const mjb_model_desc *m, mjo_data *d)
 		for (int j = 0; j < m->njnt; j++) {
 			if (!m->jnt_limited[j] || m->jnt_type[j] < MJB_JNT_SLIDE) continue;
 			double value = d->qpos[m->jnt_qposadr[j]], margin = m->jnt_margin[j];
+			int nside = (value - m->jnt_range[2 * j] < margin) + (m->jnt_range[2 * j + 1] - value < margin);
+			if (nside == 0 || full) continue;
+			if (nefc + nside > m->nefcmax) {
+				full = 1;
+				continue;
+			}
 			for (int side = -1; side <= 1; side += 2) {
 				double dist = side * (m->jnt_range[2 * j + (side + 1) / 2] - value);
-				if (dist < margin && nefc < m->nefcmax) {
+				if (dist < margin) {
 					double *row = d->efc_J + (size_t)nefc * nv;
 					memset(row, 0, sizeof(double) * (size_t)nv);
 					row[m->jnt_dofadr[j]] = -side;
@@ -859,9 +893,15 @@ void mjo_make_constraint(const mjb_model_desc *m, mjo_data *d)
 		for (int t = 0; t < m->ntendon; t++) {
 			if (!m->tendon_limited[t]) continue;
 			double value = d->ten_length[t], margin = m->tendon_margin[t];
+			int nside = (value - m->tendon_range[2 * t] < margin) + (m->tendon_range[2 * t + 1] - value < margin);
+			if (nside == 0 || full) continue;
+			if (nefc + nside > m->nefcmax) {
+				full = 1;
+				continue;
+			}
 			for (int side = -1; side <= 1; side += 2) {
 				double dist = side * (m->tendon_range[2 * t + (side + 1) / 2] - value);
-				if (dist < margin && nefc < m->nefcmax) {
+				if (dist < margin) {
 					double *row = d->efc_J + (size_t)nefc * nv;
 					memset(row, 0, sizeof(double) * (size_t)nv);
 					for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++)
@@ -882,7 +922,11 @@ void mjo_make_constraint(const mjb_model_desc *m, mjo_data *d)
 			if (!(d->contact_dist[c] < d->contact_includemargin[c])) continue;
 			int dim = d->contact_dim[c];
 			int nrow = dim == 1 ? 1 : (m->cone == MJB_CONE_ELLIPTIC ? dim : 2 * (dim - 1));
-			if (nefc + nrow > m->nefcmax) break;
+			if (full) break;
+			if (nefc + nrow > m->nefcmax) {
+				full = 1;
+				break;
+			}
 			int b1 = m->geom_bodyid[d->contact_geom[2 * c]], b2 = m->geom_bodyid[d->contact_geom[2 * c + 1]];
 			const double *frame = d->contact_frame + 9 * c, *pos = d->contact_pos + 3 * c, *fri = d->contact_friction + 5 * c;
 			/* Jacobian difference (body2 - body1) in the contact frame: up to 6 rows */
@@ -949,6 +993,7 @@ void mjo_make_constraint(const mjb_model_desc *m, mjo_data *d)
 	}
 	for (int i = 0; i < nefc; i++) d->efc_D[i] = 1 / d->efc_R[i];
 	d->nefc[0] = nefc;
+	if (full) d->warning[MJB_WARN_CNSTRFULL]++;
 }
 
 /* A7: mj_projectConstraint: AR = J M^-1 J' + diag(R) */

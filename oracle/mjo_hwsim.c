@@ -7,6 +7,71 @@
 
 #include "mjo.h"
 
+/* ---- ROS package `angles` (angles/angles.h; a dependency of the reference that is absent from /root/reference), restated
+ * from its published header: shortest_angular_distance, two_pi_complement, find_min_max_delta,
+ * shortest_angular_distance_with_limits ---- */
+#define TWO_PI 6.283185307179586476925
+static double angdist(double from, double to)
+{
+	double a = fmod(fmod(to - from, TWO_PI) + TWO_PI, TWO_PI); /* normalize_angle_positive */
+	if (a > 0.5 * TWO_PI) a -= TWO_PI;
+	return a;
+}
+
+static double two_pi_complement(double a)
+{
+	if (a > TWO_PI || a < -TWO_PI) a = fmod(a, TWO_PI);
+	if (a < 0) return TWO_PI + a;
+	if (a > 0) return -TWO_PI + a;
+	return TWO_PI;
+}
+
+static int find_min_max_delta(double from, double left, double right, double *dmin, double *dmax)
+{
+	const double pi = 3.14159265358979323846;
+	double d0 = angdist(from, left), d1 = angdist(from, right), d2 = two_pi_complement(d0), d3 = two_pi_complement(d1);
+	if (d0 == 0) {
+		*dmin = d0;
+		*dmax = fmax(d1, d3);
+		return 1;
+	}
+	if (d1 == 0) {
+		*dmax = d1;
+		*dmin = fmin(d0, d2);
+		return 1;
+	}
+	double lo = d0, lo2 = d2, hi = d1, hi2 = d3;
+	if (d2 < lo) { lo = d2; lo2 = d0; }
+	if (d3 > hi) { hi = d3; hi2 = d1; }
+	if (lo <= hi2 || hi >= lo2) {
+		*dmin = hi2;
+		*dmax = lo2;
+		return left == -pi && right == pi;
+	}
+	*dmin = lo;
+	*dmax = hi;
+	return 1;
+}
+
+static double angdist_with_limits(double from, double to, double left, double right)
+{
+	double dmin = -TWO_PI, dmax = TWO_PI, tmin = -TWO_PI, tmax = TWO_PI;
+	int inside = find_min_max_delta(from, left, right, &dmin, &dmax);
+	double delta = angdist(from, to), comp = two_pi_complement(delta);
+	if (inside) {
+		if (delta >= dmin && delta <= dmax) return delta;
+		if (comp >= dmin && comp <= dmax) return comp;
+		find_min_max_delta(to, left, right, &tmin, &tmax);
+		if (fabs(tmin) < fabs(tmax)) return fmax(delta, comp);
+		if (fabs(tmin) > fabs(tmax)) return fmin(delta, comp);
+		return fabs(delta) < fabs(comp) ? delta : comp;
+	}
+	find_min_max_delta(to, left, right, &tmin, &tmax);
+	if (fabs(dmin) < fabs(dmax)) return fmin(delta, comp);
+	if (fabs(dmin) > fabs(dmax)) return fmax(delta, comp);
+	return fabs(delta) < fabs(comp) ? delta : comp;
+}
+
 void mjo_hwsim_write(const mjb_model_desc *m, mjo_data *d, int n, const int *joint, const int *method, const int *kind,
                      const int *antiwindup, const double *gains, const double *cmd_pos, const double *cmd_vel,
                      const double *cmd_eff, const double *cmd_hold, double *pid, int estop)
@@ -32,13 +97,13 @@ void mjo_hwsim_write(const mjb_model_desc *m, mjo_data *d, int n, const int *joi
 			break;
 		case MJB_HW_POSITION_PID:
 			if (kind[k] == MJB_HW_REVOLUTE) {
-				double c = (gn[7] > gn[6]) ? fmin(fmax(cpos, gn[6]), gn[7]) : cpos;
-				error = c - pos;
+				/* command saturated to the joint limits (pj_sat_interface_.enforceLimits, :263), error by
+				 * angles::shortest_angular_distance_with_limits (:289-291) */
+				int lim = gn[7] > gn[6];
+				double c = lim ? fmin(fmax(cpos, gn[6]), gn[7]) : cpos;
+				error = lim ? angdist_with_limits(pos, c, gn[6], gn[7]) : c - pos;
 			} else if (kind[k] == MJB_HW_CONTINUOUS) {
-				const double two_pi = 6.283185307179586476925;
-				double a = fmod(fmod(cpos - pos, two_pi) + two_pi, two_pi);
-				if (a > 0.5 * two_pi) a -= two_pi;
-				error = a;
+				error = angdist(pos, cpos);
 			} else {
 				error = cpos - pos;
 			}

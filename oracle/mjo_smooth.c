@@ -900,14 +900,69 @@ static int bad(const double *x, int n)
 	return 0;
 }
 
+unsigned long long mjo_warning(const mjo_data *d, int which)
+{
+	return (which >= 0 && which < MJB_NWARNING) ? d->warning[which] : 0;
+}
+
+/* mj_energyPos + mj_energyVel: potential = -sum m g.xipos + spring energies, kinetic = 0.5 qvel' M qvel */
+void mjo_energy(const mjb_model_desc *m, mjo_data *d)
+{
+	double pe = 0, ke = 0;
+	if (!(m->disableflags & MJB_DSBL_GRAVITY))
+		for (int b = 1; b < m->nbody; b++) pe -= m->body_mass[b] * v3_dot(m->gravity, d->xipos + 3 * b);
+	if (!(m->disableflags & MJB_DSBL_PASSIVE)) {
+		for (int j = 0; j < m->njnt; j++) {
+			double k = m->jnt_stiffness[j];
+			if (k == 0) continue;
+			int pa = m->jnt_qposadr[j], jt = m->jnt_type[j];
+			if (jt == MJB_JNT_FREE) {
+				for (int c = 0; c < 3; c++) {
+					double dq = d->qpos[pa + c] - m->qpos_spring[pa + c];
+					pe += 0.5 * k * dq * dq;
+				}
+				pa += 3;
+			}
+			if (jt == MJB_JNT_FREE || jt == MJB_JNT_BALL) {
+				double q[4], dif[3];
+				memcpy(q, d->qpos + pa, sizeof q);
+				q_normalize(q);
+				q_sub(dif, q, m->qpos_spring + pa);
+				pe += 0.5 * k * v3_dot(dif, dif);
+			} else {
+				double dq = d->qpos[pa] - m->qpos_spring[pa];
+				pe += 0.5 * k * dq * dq;
+			}
+		}
+		for (int t = 0; t < m->ntendon; t++) {
+			double dl = d->ten_length[t] - m->tendon_lengthspring[t];
+			pe += 0.5 * m->tendon_stiffness[t] * dl * dl;
+		}
+	}
+	for (int i = 0; i < m->nv; i++) {
+		int adr = m->dof_Madr[i];
+		for (int j = i; j >= 0; j = m->dof_parentid[j], adr++)
+			ke += (i == j ? 0.5 : 1.0) * d->qM[adr] * d->qvel[i] * d->qvel[j];
+	}
+	d->energy[0] = pe;
+	d->energy[1] = ke;
+}
+
 void mjo_step1(const mjb_model_desc *m, mjo_data *d)
 {
-	/* mj_checkPos / mj_checkVel: reset on NaN / huge */
-	if (bad(d->qpos, m->nq) || bad(d->qvel, m->nv)) mjo_reset_data(m, d);
+	/* mj_checkPos / mj_checkVel: warning + reset on NaN / huge (qpos first: its reset clears qvel) */
+	if (bad(d->qpos, m->nq)) {
+		d->warning[MJB_WARN_BADQPOS]++;
+		mjo_reset_data(m, d);
+	} else if (bad(d->qvel, m->nv)) {
+		d->warning[MJB_WARN_BADQVEL]++;
+		mjo_reset_data(m, d);
+	}
 	mjo_fwd_position(m, d);
 	mjo_sensor(m, d, MJB_STAGE_POS);
 	mjo_fwd_velocity(m, d);
 	mjo_sensor(m, d, MJB_STAGE_VEL);
+	if (m->enableflags & MJB_ENBL_ENERGY) mjo_energy(m, d);
 }
 
 static void forward_rest(const mjb_model_desc *m, mjo_data *d)
@@ -925,6 +980,7 @@ void mjo_forward(const mjb_model_desc *m, mjo_data *d)
 	mjo_sensor(m, d, MJB_STAGE_POS);
 	mjo_fwd_velocity(m, d);
 	mjo_sensor(m, d, MJB_STAGE_VEL);
+	if (m->enableflags & MJB_ENBL_ENERGY) mjo_energy(m, d);
 	forward_rest(m, d);
 }
 
@@ -933,6 +989,7 @@ void mjo_step2(const mjb_model_desc *m, mjo_data *d)
 	forward_rest(m, d);
 	/* mj_checkAcc */
 	if (bad(d->qacc, m->nv)) {
+		d->warning[MJB_WARN_BADQACC]++;
 		mjo_reset_data(m, d);
 		mjo_forward(m, d);
 	}

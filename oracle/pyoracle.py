@@ -52,6 +52,10 @@ def lib(fast=False):
     L.mjo_normal.restype = cd
     L.mjo_normal.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
     L.mjo_ctrl_noise.argtypes = [pd, vp, cd, cd, C.c_uint64, C.c_uint64, C.c_uint32]
+    L.mjo_warning.restype = C.c_ulonglong
+    L.mjo_warning.argtypes = [vp, ci]
+    L.mjo_energy.argtypes = [pd, vp]
+    L.mjo_energy.restype = None
     L.mjo_hwsim_write.restype = None
     L.mjo_hwsim_write.argtypes = [pd, vp, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)] + [C.POINTER(cd)] * 6 + [ci]
     L.mjo_sensor_pack.restype = None
@@ -111,6 +115,10 @@ class OracleData:
     def step(self, n=1):
         for _ in range(n):
             self.call("step")
+
+    def warning(self, which):
+        """mjData.warning[which].number (which = mjtWarning: 1 CONTACTFULL, 2 CNSTRFULL, 4 BADQPOS, 5 BADQVEL, 6 BADQACC)."""
+        return int(self.L.mjo_warning(self.ptr, int(which)))
 
     def ctrl_noise(self, std, rate, seed, env, step):
         self.L.mjo_ctrl_noise(C.byref(self.desc), self.ptr, std, rate, seed, env, step)

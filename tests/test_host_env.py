@@ -145,6 +145,25 @@ def test_steps_terminate(host, factory):
     env.shutdown()
 
 
+def test_realtime_pacing_without_sim_time(host, factory):
+    """use_sim_time only gates the /clock publication (mujoco_env.cpp:701-703); the loop keeps pacing on data_->time
+    (:466-467, :536, :560).  With realtime_index 1 (100 % real time) the simulation must track the wall clock -- not
+    free-run -- and the /clock value must stay untouched."""
+    m = empty()
+    env = start(host, factory, m, {"unpause": True, "use_sim_time": False, "realtime_index": 1})
+    t0 = time.time()
+    time.sleep(0.5)
+    sim, wall = env.data_time, time.time() - t0
+    assert env.sim_time == 0.0
+    assert 0.2 * wall < sim < 1.5 * wall + 0.05, f"sim {sim:.3f} s vs wall {wall:.3f} s: the loop is not paced"
+    env.shutdown()
+    # the same run with the clock on publishes the time it paces on
+    env = start(host, factory, m, {"unpause": True, "use_sim_time": True, "realtime_index": 1})
+    time.sleep(0.2)
+    assert env.sim_time > 0 and abs(env.sim_time - env.data_time) < 0.1
+    env.shutdown()
+
+
 def test_manual_steps(host, factory):
     """mujoco_env_test.cpp:428-481 incl. "pending manual steps should not change in unpaused mode"."""
     m = pendulum()

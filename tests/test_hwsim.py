@@ -1,6 +1,6 @@
 """Device-side DefaultRobotHWSim::writeSim (reference default_robot_hw_sim.cpp:248-326):
 EFFORT / POSITION / VELOCITY / POSITION_PID / VELOCITY_PID control methods and the e-stop rules, applied on the
-device at the start of every step.  CPU: the oracle restatement behaves as the reference's code reads; GPU: the
+device at the control-callback point of every step (after the position / velocity stages).  CPU: the oracle restatement behaves as the reference's code reads; GPU: the
 in-kernel stage equals the oracle applied before every oracle step."""
 import numpy as np
 import pytest
@@ -53,8 +53,9 @@ def _oracle_rollout(po, model, cfg, qpos, cp, cv, ce, steps, estop_at=None):
         estop = estop_at is not None and k >= estop_at
         if estop_at is not None and k == estop_at:
             hold = cp.copy()
+        d.call("step1")  # the reference's control callback fires after the position / velocity stages (mjcb_control)
         d.hwsim_write(cfg, cp, cv, ce, hold, pid, estop)
-        d.step(1)
+        d.call("step2")
     return d, pid
 
 

@@ -37,8 +37,13 @@ def _worker(rank, world, port, E, K, q):
     _, _, sens = pyoracle.rollout(model, qpos[lo:hi], qvel[lo:hi], K, noise_std=20.0, noise_rate=0.1, seed=12345,
                                   env_offset=lo)
     gathered = sharding.gather_sensordata(torch.from_numpy(np.ascontiguousarray(sens)))
+    # the 16-double metrics vector: [0:8] summed, [8:16] maximised over the ranks (what mjb_metrics hands to the all-reduce)
+    met = torch.zeros(16, dtype=torch.float64)
+    met[0], met[1], met[6] = E * K, rank, E
+    met[8], met[9], met[10] = float(np.abs(sens).max()), 10.0 + rank, K * 0.002
+    sharding.reduce_metrics(met)
     if rank == 0:
-        q.put(gathered.numpy().copy())
+        q.put((gathered.numpy().copy(), met.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,7 +58,7 @@ def test_two_rank_gather_matches_single_process(oracle_built, franka):
     procs = [ctx.Process(target=_worker, args=(r, world, port, E, K, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got, met = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -61,6 +66,12 @@ def test_two_rank_gather_matches_single_process(oracle_built, franka):
     _, _, ref = oracle_built.rollout(franka, qpos, qvel, K, noise_std=20.0, noise_rate=0.1, seed=12345, env_offset=0)
     assert got.shape == (world * E, franka["nsensordata"])
     assert np.array_equal(got, ref)
+    assert met[0] == world * E * K and met[1] == 0 + 1 and met[6] == world * E
+    assert met[8] == np.abs(ref).max() and met[9] == 11.0 and abs(met[10] - K * 0.002) < 1e-15
+    one = torch.arange(16, dtype=torch.float64)
+    assert sharding.reduce_metrics(one) is one and one[5] == 5   # world size 1: no collective
+    with pytest.raises(ValueError):
+        sharding.reduce_metrics(torch.zeros(8, dtype=torch.float64))
     assert sharding.shard_range(1, 2, 4096) == (4096, 8192)
     with pytest.raises(ValueError):
         sharding.shard_range(2, 2, 4096)
