@@ -179,8 +179,6 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		} else {
 			*slots[idx] = off;
 			off += n;
-			// (project_constraint_dense16 parks the packed 16 x 16 triangle of L in the efc_B region)
-			if (idx == MJB_F_efc_B && n > 0 && n < 120) off += 120 - n;
 			if (fi.kind == 0) nstate = off;
 		}
 		idx++;
@@ -210,6 +208,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	off += d.nM;
 	L.qHdi = off;
 	off += d.nv;
+	const bool need_tri = d.nefcmax > 0 && d.solver == MJB_SOL_PGS && d.nv <= 16;
 	const int n_kin = 7 * d.nbody, n_crb = 10 * d.nbody, n_buf = 6 * d.nv < 32 ? 32 : 6 * d.nv, n_c6 = 6 * d.nbody;  // (crbbuf doubles as the 32-double pivot-row scratch of the dense factor)
 	if (compact) {
 		const int a0 = off;
@@ -219,7 +218,9 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		if (!need_post) L.cacc = a0;
 		L.cfrc_body = a0 + n_c6;
 		L.eulerx = a0;
+		L.tri = a0;  // (alive only inside project_constraint_dense16, between the factorisation and comVel)
 		int sz = n_kin;
+		if (need_tri && sz < 120) sz = 120;
 		if (n_crb + n_buf > sz) sz = n_crb + n_buf;
 		if (2 * n_c6 > sz) sz = 2 * n_c6;
 		if (d.nv > sz) sz = d.nv;
@@ -240,6 +241,8 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		off += n_buf;
 		L.eulerx = off;
 		off += d.nv;
+		L.tri = off;
+		off += need_tri ? 120 : 0;
 	}
 	if (off & 1) off++;
 	L.ndouble = off;
@@ -419,10 +422,10 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 			fail(MJB_EUNSUPPORTED, "mjb_compile: unknown solver (PGS = 0, CG = 1, Newton = 2)");
 			return nullptr;
 		}
-		const int rowcap = d.solver != MJB_SOL_PGS ? 256 : 64;
+		const int rowcap = d.solver != MJB_SOL_PGS ? 256 : ((d.cone == MJB_CONE_ELLIPTIC && d.nconmax > 0) ? 64 : 128);
 		if (d.nefcmax > rowcap || d.nv > 64) {
-			fail(MJB_EUNSUPPORTED, "mjb_compile: one env per wavefront: nv <= 64 and nefcmax <= 64 (PGS) / 256 (Newton, up to "
-			                       "4 rows per lane); got nefcmax = %d, nv = %d", d.nefcmax, d.nv);
+			fail(MJB_EUNSUPPORTED, "mjb_compile: one env per wavefront: nv <= 64 and nefcmax <= 128 (PGS; 64 with elliptic cones) / "
+			                       "256 (Newton / CG, up to 4 rows per lane); got nefcmax = %d, nv = %d", d.nefcmax, d.nv);
 			return nullptr;
 		}
 		if (!(d.meaninertia[0] > 0)) {

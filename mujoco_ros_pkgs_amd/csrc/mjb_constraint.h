@@ -1122,7 +1122,7 @@ template <int G> STAGE void project_constraint_dense16(CModel m, CLayout L, cons
 	double *f = e.f;
 	const int nefc = e.fi[L.nefc], nv = m.nv, lane = e.lane;
 	if (nefc == 0) return;
-	double *Ld = f + L.efc_B;
+	double *Ld = f + L.tri;  // (compact layout: inside the region kinematics / crb / rne share -- nobody else is alive here)
 	for (int t = lane; t < 120; t += G) Ld[t] = 0;
 	gsync<G>();
 	for (int en = lane; en < m.nM; en += G) {
@@ -1130,34 +1130,39 @@ template <int G> STAGE void project_constraint_dense16(CModel m, CLayout L, cons
 		if (i != j) Ld[i * (i - 1) / 2 + j] = f[L.qLD + en];
 	}
 	gsync<G>();
-	const bool act = lane < nefc;  // (PGS keeps nefc <= 64)
-	const double *Jr = f + L.efc_J + (act ? lane : 0) * nv, *di = f + L.qLDiagInv;
-	double x[16];
+	const double *di = f + L.qLDiagInv;
+	// one 64-row block per trip (PGS: nefc <= 128); one copy of the substitution in the instruction stream
+#pragma nounroll
+	for (int r0 = 0; r0 < nefc; r0 += 64) {
+		const int r = r0 + lane;
+		const bool act = r < nefc;
+		const double *Jr = f + L.efc_J + (act ? r : 0) * nv;
+		double x[16];
 #pragma unroll
-	for (int k = 0; k < 16; k++) {
-		const double v = Jr[k < nv ? k : 0];
-		x[k] = (k < nv && act) ? v : 0.0;
-	}
-	// x <- L^-T x: once x[i] is final, every x[j < i] takes its share (independent fma)
+		for (int k = 0; k < 16; k++) {
+			const double v = Jr[k < nv ? k : 0];
+			x[k] = (k < nv && act) ? v : 0.0;
+		}
+		// x <- L^-T x: once x[i] is final, every x[j < i] takes its share (independent fma)
 #pragma unroll
-	for (int i = 15; i >= 1; i--) {
+		for (int i = 15; i >= 1; i--) {
 #pragma unroll
-		for (int j = 0; j < i; j++) x[j] -= Ld[i * (i - 1) / 2 + j] * x[i];
-	}
+			for (int j = 0; j < i; j++) x[j] -= Ld[i * (i - 1) / 2 + j] * x[i];
+		}
 #pragma unroll
-	for (int k = 0; k < 16; k++) x[k] *= di[k < nv ? k : 0];
-	// x <- L^-1 x, column by column (same summation order as the row form)
+		for (int k = 0; k < 16; k++) x[k] *= di[k < nv ? k : 0];
+		// x <- L^-1 x, column by column (same summation order as the row form)
 #pragma unroll
-	for (int j = 0; j < 15; j++) {
+		for (int j = 0; j < 15; j++) {
 #pragma unroll
-		for (int i = j + 1; i < 16; i++) x[i] -= Ld[i * (i - 1) / 2 + j] * x[j];
-	}
-	gsync<G>();  // every lane is done with the triangle: the B rows may overwrite it
-	if (act) {
-		double *Br = f + L.efc_B + lane * nv;
+			for (int i = j + 1; i < 16; i++) x[i] -= Ld[i * (i - 1) / 2 + j] * x[j];
+		}
+		if (act) {
+			double *Br = f + L.efc_B + r * nv;
 #pragma unroll
-		for (int k = 0; k < 16; k++)
-			if (k < nv) Br[k] = x[k];
+			for (int k = 0; k < 16; k++)
+				if (k < nv) Br[k] = x[k];
+		}
 	}
 	gsync<G>();
 }
@@ -1472,6 +1477,136 @@ DEVI void pgs_sweep_elliptic(const double (&AR)[64], const int nefc, const int l
 }
 
 // ------------------------------------------------------------------------------------------------
+// A13 PGS beyond 64 rows (64 < nefc <= 128, scalar rows: equality / friction / limit / frictionless / pyramidal).
+// A row of AR no longer fits the lane's registers, so this path is AR-free: row r lives in lane r % 64, slot r / 64, with
+// its b, R, 1 / A_rr, bounds and force in registers; the residual of row i is  b_i + R_i f_i + J_i . w  with
+// w = M^-1 J' f kept one element per lane (lanes 0 .. nv-1) and updated by  w += B_i delta  after every row.  Same
+// fixed point and same sweep order as the register path; ~4x its cost per row update, which is why it only runs for the
+// env-steps whose row count actually exceeds 64 (wave-uniform branch in fwd_constraint_pgs; out of line so that the
+// common path pays neither registers nor instruction-cache lines for it).
+// ------------------------------------------------------------------------------------------------
+template <int G> __device__ __attribute__((noinline)) void fwd_constraint_pgs_large(CModel m, CLayout L, const Env &e)
+{
+	static_assert(G == 64, "the constraint solver maps rows to the 64 lanes of one wavefront");
+	double *f = e.f;
+	int *fi = e.fi;
+	const int lane = e.lane, nv = m.nv, nefc = fi[L.nefc];
+	constexpr int S = 2;
+	const bool warm = !(m.disableflags & MJB_DSBL_WARMSTART);
+	const bool small = nv <= 16;
+	bool act[S];
+	double b[S], Rr[S], ARinv[S], lo[S], hi[S], frc[S];
+#pragma unroll
+	for (int s = 0; s < S; s++) {
+		const int r = lane + 64 * s;
+		act[s] = r < nefc;
+		const int rr = act[s] ? r : 0;
+		const double *Jr = f + L.efc_J + rr * nv, *Br = f + L.efc_B + rr * nv;
+		double jq = 0, jb = 0, jw = 0;
+		for (int k = 0; k < nv; k++) {
+			const double j = Jr[k];
+			jq += j * f[L.qacc_smooth + k];
+			jb += j * Br[k];
+			jw += j * f[L.qacc_warmstart + k];
+		}
+		const double aref = f[L.efc_aref + rr];
+		const bool bilateral = act[s] && fi[L.efc_type + rr] == MJB_CNSTR_EQUALITY;
+		const double floss = (act[s] && m.nfriction > 0) ? f[L.efc_frictionloss + rr] : 0.0;
+		const bool friction = floss > 0;
+		Rr[s] = act[s] ? f[L.efc_R + rr] : 0.0;
+		b[s] = act[s] ? jq - aref : 0.0;
+		ARinv[s] = act[s] ? 1.0 / (jb + Rr[s]) : 0.0;
+		lo[s] = bilateral ? -__builtin_huge_val() : (friction ? -floss : 0.0);
+		hi[s] = friction ? floss : __builtin_huge_val();
+		double fr = 0;
+		if (act[s] && warm) {
+			const double jar = jw - aref;
+			fr = (jar < 0 || bilateral || friction) ? -f[L.efc_D + rr] * jar : 0.0;
+			if (friction) fr = __builtin_fmin(__builtin_fmax(fr, -floss), floss);
+		}
+		frc[s] = fr;
+		if (act[s]) {
+			f[L.efc_b + rr] = b[s];
+			f[L.efc_force + rr] = fr;
+		}
+	}
+	gsync<G>();
+	double *w = f + L.qacc;  // w = M^-1 J' f = B' f parked in the qacc slot between sweeps (qacc = qacc_smooth + w at the end)
+	double wreg = 0;
+	if (lane < nv)
+		for (int i = 0; i < nefc; i++) wreg += f[L.efc_B + i * nv + lane] * f[L.efc_force + i];
+	// cost = 0.5 f'ARf + f'b = sum_r 0.5 f_r (res_r + b_r), res_r = b_r + R_r f_r + J_r . w
+	auto cost_of = [&]() -> double {
+		if (lane < nv) w[lane] = wreg;
+		gsync<G>();
+		double c = 0;
+#pragma unroll
+		for (int s = 0; s < S; s++) {
+			const double *Jr = f + L.efc_J + (act[s] ? lane + 64 * s : 0) * nv;
+			double dot = 0;
+			for (int k = 0; k < nv; k++) dot += Jr[k] * w[k];
+			const double res = b[s] + Rr[s] * frc[s] + dot;
+			c += act[s] ? 0.5 * frc[s] * (res + b[s]) : 0.0;
+		}
+		gsync<G>();
+		return wave_sum(c);
+	};
+	double cost = cost_of();
+	if (cost > 0 || !warm) {
+		frc[0] = frc[1] = 0;
+		wreg = 0;
+		cost = 0;
+	}
+	const double scale = 1.0 / (MP_MEANINERTIA(m, e) * (nv > 1 ? nv : 1));
+	const double tol = m.tolerance[0];
+	int iter = 0;
+	while (iter < m.iterations) {
+#pragma unroll
+		for (int s = 0; s < S; s++) {
+			const int i0 = 64 * s, i1 = nefc < i0 + 64 ? nefc : i0 + 64;
+			double jn = (lane < nv && i0 < i1) ? f[L.efc_J + i0 * nv + lane] : 0.0;
+			double bn = (lane < nv && i0 < i1) ? f[L.efc_B + i0 * nv + lane] : 0.0;
+#pragma nounroll
+			for (int i = i0; i < i1; i++) {
+				const double ji = jn, bi = bn;
+				const int nx = i + 1 < nefc ? i + 1 : i;  // prefetch the next row's entries (off the dependent chain)
+				if (lane < nv) {
+					jn = f[L.efc_J + nx * nv + lane];
+					bn = f[L.efc_B + nx * nv + lane];
+				}
+				const double p = ji * wreg;
+				const double dot = small ? wave_bcast(row_sum<16>(p), 0) : wave_sum(p);
+				const double res = b[s] + Rr[s] * frc[s] + dot;
+				const double fn = __builtin_fmin(__builtin_fmax(frc[s] - res * ARinv[s], lo[s]), hi[s]);
+				const double delta = fn - frc[s];
+				const double du = wave_bcast(delta, i - i0);
+				if (lane == i - i0) frc[s] = fn;
+				wreg += bi * du;
+			}
+		}
+		const double cost1 = cost_of();
+		const double improvement = (cost - cost1) * scale;
+		cost = cost1;
+		iter++;
+		if (improvement < tol) break;
+	}
+	if (lane == 0) fi[L.solver_iter] = iter;
+#pragma unroll
+	for (int s = 0; s < S; s++)
+		if (act[s]) f[L.efc_force + lane + 64 * s] = frc[s];
+	gsync<G>();
+	if (lane < nv) {
+		double sacc = 0;
+		for (int i = 0; i < nefc; i++) sacc += f[L.efc_J + i * nv + lane] * f[L.efc_force + i];
+		f[L.qfrc_constraint + lane] = sacc;
+		const double a = f[L.qacc_smooth + lane] + wreg;
+		f[L.qacc + lane] = a;
+		f[L.qacc_warmstart + lane] = a;
+	}
+	gsync<G>();
+}
+
+// ------------------------------------------------------------------------------------------------
 // A13 constraint solve: warmstart + projected Gauss-Seidel (dual), one env per wavefront
 // ------------------------------------------------------------------------------------------------
 template <int G, bool ELL> STAGE void fwd_constraint_pgs(CModel m, CLayout L, const Env &e)
@@ -1490,6 +1625,11 @@ template <int G, bool ELL> STAGE void fwd_constraint_pgs(CModel m, CLayout L, co
 		}
 		if (lane == 0) fi[L.solver_iter] = 0;
 		gsync<G>();
+		return;
+	}
+	if (!ELL && nefc > 64) {  // (wave-uniform; rare: the register path below holds one row of AR per lane)
+		MJB_KEEP_BRANCH();
+		fwd_constraint_pgs_large<G>(m, L, e);
 		return;
 	}
 	// Row r lives in lane r together with ITS ROW OF AR = J M^-1 J' + diag(R) in registers (64 doubles): a

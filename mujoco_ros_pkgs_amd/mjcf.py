@@ -267,6 +267,14 @@ class _Compiler:
                 self.defaults.load(node)
         for node in root:
             t = node.tag
+            if t == "size":
+                # <size nconmax= njmax=>: MuJoCo's per-mjData capacities = the engine's per-env nconmax / nefcmax (explicit
+                # arguments of the compile call win); -1 (MuJoCo's "arena") leaves the engine's worst-case sizing on
+                if self.nconmax_req is None and int(node.get("nconmax", "-1")) >= 0:
+                    self.nconmax_req = int(node.get("nconmax"))
+                if self.nefcmax_req is None and int(node.get("njmax", "-1")) >= 0:
+                    self.nefcmax_req = int(node.get("njmax"))
+                continue
             if t in ("compiler", "default") or t in IGNORED_TOP:
                 continue
             if t == "option":

@@ -1,0 +1,60 @@
+"""BASELINE configs 3 / 4 and 5 at their full per-GPU size (4096 envs of the Franka-like arm + table +
+cube under PGS; 1024 envs of the Shadow-Hand-like hand + cube under Newton with elliptic cones = the per-GPU shard of the
+8192-env / 8-GPU configs[4]), on bench.py's own workload (same initial states, same on-device OU ctrl noise):
+size-independent properties over the whole batch + oracle parity on sampled envs."""
+import numpy as np
+import pytest
+
+from mujoco_ros_pkgs_amd import mjcf
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(name, nenv, K, sample, tol_q, tol_v, oracle_built):
+    from bench import WORKLOADS, initial_state
+    from mujoco_ros_pkgs_amd import engine
+    model = mjcf.load_asset(name)
+    noise = WORKLOADS[name][1]
+    qpos, qvel = initial_state(name, model, nenv, seed=1000)
+    b = engine.Batch(engine.CompiledModel(model), nenv)
+    b.set("qpos", qpos)
+    b.set("qvel", qvel)
+    b.set_ctrl_noise(noise, 0.1, 12345, 0)
+    b.step(K)
+    q, v, sd, t = b.get("qpos"), b.get("qvel"), b.get("sensordata"), b.get("time")
+    assert np.all(np.isfinite(q)) and np.all(np.isfinite(v)) and np.all(np.isfinite(sd))
+    assert b.warning_count() == 0, "mj_check* reset an env of the bench workload"
+    assert np.allclose(t, K * model["timestep"][0], rtol=0, atol=1e-12)
+    # unit quaternions of the free body, every env
+    ja = [j for j in range(model["njnt"]) if model["jnt_type"][j] == 0][0]
+    qa = model["jnt_qposadr"][ja]
+    assert np.allclose(np.linalg.norm(q[:, qa + 3:qa + 7], axis=1), 1.0, atol=1e-9)
+    # oracle parity on envs spread over the batch (global env index = Philox key)
+    idx = np.linspace(0, nenv - 1, sample).astype(int)
+    for e in idx:
+        oq, ov, osd = oracle_built.rollout(model, qpos[e:e + 1], qvel[e:e + 1], K, noise_std=noise, noise_rate=0.1, seed=12345,
+                                           env_offset=int(e))
+        assert np.abs(q[e] - oq[0]).max() <= tol_q, f"{name} env {e}: qpos {np.abs(q[e] - oq[0]).max():.2e}"
+        assert np.abs(v[e] - ov[0]).max() <= tol_v, f"{name} env {e}: qvel {np.abs(v[e] - ov[0]).max():.2e}"
+    m, _ = b.metrics()
+    assert m["env_steps"] == nenv * K and m["nenv"] == nenv
+    # determinism: a second batch of the same inputs reproduces the first bit for bit
+    b2 = engine.Batch(engine.CompiledModel(model), nenv)
+    b2.set("qpos", qpos)
+    b2.set("qvel", qvel)
+    b2.set_ctrl_noise(noise, 0.1, 12345, 0)
+    b2.step(K)
+    assert np.array_equal(b2.get("qpos"), q) and np.array_equal(b2.get("qvel"), v)
+    b.close()
+    b2.close()
+    return model
+
+
+def test_config3_pgs_4096_envs(oracle_built):
+    m = _run("franka_table", 4096, 60, 24, 1e-7, 1e-5, oracle_built)
+    assert (m["ngeom"], m["nconmax"], m["nefcmax"], m["solver"]) == (14, 16, 73, 0)
+
+
+def test_config5_newton_1024_envs(oracle_built):
+    m = _run("shadow_hand_like", 1024, 40, 16, 1e-7, 1e-4, oracle_built)
+    assert m["solver"] == 2 and m["cone"] == 1
