@@ -511,6 +511,9 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 	}
 	int *cnt = fi + L.iscratch;  // transient per-pair contact counts
 	int base = 0;
+#ifdef MJB_PROFILE_SUB
+	EPROF_BEGIN();
+#endif
 	for (int p0 = 0; p0 < m.ncollpair; p0 += G) {
 		const int p = p0 + lane;
 		RawCon rc[4];
@@ -557,6 +560,9 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 			cnt[p] = n;
 		}
 		gsync<G>();
+#ifdef MJB_PROFILE_SUB
+		EPROF(24);
+#endif
 		if (p < m.ncollpair && n > 0) {
 			int off = base;
 			for (int q = p0; q < p; q++) off += cnt[q];
@@ -613,6 +619,9 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 		const int hi = (p0 + G < m.ncollpair) ? p0 + G : m.ncollpair;
 		for (int q = p0; q < hi; q++) base += cnt[q];
 		gsync<G>();
+#ifdef MJB_PROFILE_SUB
+		EPROF(25);
+#endif
 	}
 	if (lane == 0) {
 		fi[L.ncon] = base < m.nconmax ? base : m.nconmax;
@@ -758,6 +767,9 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const
 	const int nfr = m.nfriction > 0 ? nv + m.ntendon : 0;
 	const int nitem = neq + nfr + m.njnt + nten + ncon;  // item = equality, dof / tendon friction, joint limit, tendon limit or contact -- MuJoCo's row order
 	int *cnt = fi + L.iscratch;              // transient per-item row counts
+#ifdef MJB_PROFILE_SUB
+	EPROF_BEGIN();
+#endif
 	// pass 1: rows per item
 	for (int it = lane; it < nitem; it += G) {
 		int n = 0;
@@ -802,6 +814,9 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const
 		nefc += n;
 	}
 	if (cut < nitem && lane == 0) atomicAdd(s.nwarn + MJB_WARN_CNSTRFULL, 1ull);  // mjWARN_CNSTRFULL (rule: include/mjb.h, mjb_warning)
+#ifdef MJB_PROFILE_SUB
+	EPROF(26);
+#endif
 	// pass 2: row parameters, one item per lane (item order == row order)
 	for (int it0 = 0; it0 < cut; it0 += G) {
 		const int it = it0 + lane;
@@ -980,6 +995,9 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const
 		}
 	}
 	gsync<G>();
+#ifdef MJB_PROFILE_SUB
+	EPROF(27);
+#endif
 	for (int r = lane; r < nefc; r += G) {
 		f[L.efc_D + r] = 1.0 / f[L.efc_R + r];
 		f[L.efc_force + r] = 0;
@@ -1027,6 +1045,9 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const
 			for (int k = 0; k < 3; k++) f[L.efc_J + (adr + 3 + k) * nv + i] = 0.5 * ts * q3[1 + k];
 		}
 	}
+#ifdef MJB_PROFILE_SUB
+	EPROF(28);
+#endif
 	// contact Jacobian rows: one (contact, dof) pair per lane
 	const int npair = ncon * nv;
 	for (int t = lane; t < npair; t += G) {
@@ -1071,6 +1092,9 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const
 		}
 	}
 	gsync<G>();
+#ifdef MJB_PROFILE_SUB
+	EPROF(29);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -35,7 +35,9 @@ def _model(name, solver):
     over = {"solver": solver.split("-")[0]}
     if solver.endswith("-elliptic"):
         over["cone"] = "elliptic"
-    return mjcf.compile_xml_file(os.path.join(mjcf.ASSET_DIR, name + ".xml"), override=over)
+    # (PGS with elliptic cones keeps a contact's rows in consecutive lanes of one wavefront: <= 64 rows = 16 contacts x 3 + 9 limits)
+    kw = {"nefcmax": 57} if solver == "PGS-elliptic" else {}
+    return mjcf.compile_xml_file(os.path.join(mjcf.ASSET_DIR, name + ".xml"), override=over, **kw)
 
 
 def _initial(model, name, nenv):

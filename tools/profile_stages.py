@@ -24,9 +24,13 @@ ap.add_argument("--envs", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--model", default="franka_like")
 ap.add_argument("--solver", default="")
+ap.add_argument("--sub", action="store_true", help="libmjb_prof_sub.so: slots 24-29 = collision / make_constraint sub-stages (PGS runs)")
 a = ap.parse_args()
 
-binding.LIB_PATH = os.path.join(ROOT, "mujoco_ros_pkgs_amd", "csrc", "libmjb_prof.so")
+binding.LIB_PATH = os.path.join(ROOT, "mujoco_ros_pkgs_amd", "csrc", "libmjb_prof_sub.so" if a.sub else "libmjb_prof.so")
+if a.sub:
+    STAGES[24:30] = ["col.cull+narrowphase", "col.offsets+params+stores", "mk.count+cut", "mk.row params (pass 2)", "mk.D + equality J",
+                     "mk.contact J"]
 from mujoco_ros_pkgs_amd import engine, mjcf  # noqa: E402
 
 model = mjcf.load_asset(a.model)
