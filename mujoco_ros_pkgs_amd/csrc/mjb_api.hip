@@ -3,6 +3,7 @@
 // No CPU compute path exists here: every compute entry point needs a HIP device.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -79,6 +80,8 @@ struct mjb_model {
 	std::vector<size_t> ioff, doff;   // offsets of each array inside hint / hdbl (declaration order)
 	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense, body_anc, dof_bodymask;
 	std::vector<int> sens_copy, sens_slow, dof_act_adr, dof_act_id;
+	std::vector<int> pair_i;       // [ncollpair][8]  per candidate pair: g1, g2, type1, type2, condim, friction rule, body1, body2
+	std::vector<double> pair_d;    // [ncollpair][24] size1[3] size2[3] margin gap rbound1 rbound2 solref[2] solimp[5] includemargin pad[7]
 	int sens_ncopy[3] = { 0, 0, 0 }, sens_nslow[3] = { 0, 0, 0 }, sens_ncopy_max = 0;
 	int eulerdamp = 0, maxdepth = 0, kin_rounds = 0, need_rnepost = 0, nfriction = 0;
 	int field_size[MJB_F_COUNT]{};
@@ -165,12 +168,20 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		if (idx == MJB_F_efc_AR) n = 0;  // (the PGS kernel keeps each row of AR in its lane's registers)
 		if (idx == MJB_F_efc_frictionloss && M->nfriction == 0) n = 0;  // no dry-friction rows in this model
 		if (idx == MJB_F_efc_B && d.solver != MJB_SOL_PGS) n = 0;  // the primal solvers need no J M^-1
+		// (nv <= 16: the PGS kernel solves for its row of B in registers; the field only exists in the full layout, for mjb_get)
+		const bool no_B = idx == MJB_F_efc_B && n > 0 && compact && d.nv <= 16 && !(d.cone == MJB_CONE_ELLIPTIC && d.nconmax > 0);
 		if (!compact) M->field_size[idx] = n;
 		if ((idx == MJB_F_cfrc_int || idx == MJB_F_cfrc_ext) && !need_post) n = 0;  // computed only when a sensor needs them
 		// (with rne_post the true cacc is written between fwd_acceleration and Euler, whose rhs shares region A)
 		const bool in_a = compact && (idx == MJB_F_crb || (idx == MJB_F_cacc && !need_post) || idx == MJB_F_cfrc_body);
 		const bool in_b = alias_b && (idx == MJB_F_ximat || idx == MJB_F_cvel || idx == MJB_F_cdof_dot);
 		if (compact && idx == MJB_F_xfrc_applied) n = 0;
+		if (no_B) {
+			if (!compact) M->field_size[idx] = n;
+			*slots[idx] = -1;  // kernels test L.efc_B >= 0
+			idx++;
+			continue;
+		}
 		if (fi.kind == 3) {
 			*slots[idx] = ioff;
 			ioff += n;
@@ -682,6 +693,48 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 	if (!(h.disableflags & MJB_DSBL_FRICTIONLOSS))
 		for (int t = 0; t < h.ntendon; t++)
 			if (h.tendon_frictionloss[t] > 0) M->nfriction++;
+	// per-pair records of the static candidate list: everything mj_collision / mj_contactParam derive from the two geoms'
+	// constants, resolved once (friction stays per env: rule 0 = max of both geoms, 1 = geom1, 2 = geom2)
+	M->pair_i.assign((size_t)8 * (h.ncollpair > 0 ? h.ncollpair : 1), 0);
+	M->pair_d.assign((size_t)24 * (h.ncollpair > 0 ? h.ncollpair : 1), 0.0);
+	for (int p = 0; p < h.ncollpair; p++) {
+		const int g1 = h.collpair_geom[2 * p], g2 = h.collpair_geom[2 * p + 1];
+		int *pi = M->pair_i.data() + 8 * p;
+		double *pd = M->pair_d.data() + 24 * p;
+		pi[0] = g1; pi[1] = g2; pi[2] = h.geom_type[g1]; pi[3] = h.geom_type[g2];
+		pi[6] = h.geom_bodyid[g1]; pi[7] = h.geom_bodyid[g2];
+		for (int k = 0; k < 3; k++) {
+			pd[k] = h.geom_size[3 * g1 + k];
+			pd[3 + k] = h.geom_size[3 * g2 + k];
+		}
+		const double margin = std::max(h.geom_margin[g1], h.geom_margin[g2]), gap = std::max(h.geom_gap[g1], h.geom_gap[g2]);
+		pd[6] = margin; pd[7] = gap; pd[8] = h.geom_rbound[g1]; pd[9] = h.geom_rbound[g2];
+		double *solref = pd + 10, *solimp = pd + 12;
+		const int pr1 = h.geom_priority[g1], pr2 = h.geom_priority[g2];
+		if (pr1 != pr2) {  // mj_contactParam: the geom with the higher priority decides
+			const int g = pr1 > pr2 ? g1 : g2;
+			pi[4] = h.geom_condim[g];
+			pi[5] = pr1 > pr2 ? 1 : 2;
+			for (int k = 0; k < 2; k++) solref[k] = h.geom_solref[2 * g + k];
+			for (int k = 0; k < 5; k++) solimp[k] = h.geom_solimp[5 * g + k];
+		} else {
+			pi[4] = std::max(h.geom_condim[g1], h.geom_condim[g2]);
+			pi[5] = 0;
+			const double s1 = h.geom_solmix[g1], s2 = h.geom_solmix[g2];
+			double mix;
+			if (s1 >= 1e-15 && s2 >= 1e-15) mix = s1 / (s1 + s2);
+			else if (s1 < 1e-15 && s2 < 1e-15) mix = 0.5;
+			else if (s1 < 1e-15) mix = 0.0;
+			else mix = 1.0;
+			const double r10 = h.geom_solref[2 * g1], r20 = h.geom_solref[2 * g2];
+			for (int k = 0; k < 2; k++) {
+				const double a = h.geom_solref[2 * g1 + k], b = h.geom_solref[2 * g2 + k];
+				solref[k] = (r10 > 0 && r20 > 0) ? mix * a + (1 - mix) * b : std::min(a, b);
+			}
+			for (int k = 0; k < 5; k++) solimp[k] = mix * h.geom_solimp[5 * g1 + k] + (1 - mix) * h.geom_solimp[5 * g2 + k];
+		}
+		pd[17] = margin - gap;
+	}
 	compute_layout(M, M->L, false);
 	compute_layout(M, M->Lc, true);
 	build_sensor_tables(M);
@@ -735,6 +788,7 @@ void mjb_free_batch(mjb_batch *b)
 #undef MJB_DI
 	if (b->st.frame_ws) hipFree(b->st.frame_ws);
 	if (b->st.nwarn) hipFree(b->st.nwarn);
+	if (b->st.pgs_B) hipFree(b->st.pgs_B);
 	if (b->metrics_dev) hipFree(b->metrics_dev);
 	if (b->st.prof) hipFree(b->st.prof);
 	if (b->blob) hipFree(b->blob);
@@ -792,9 +846,9 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	size_t nt = M->M_rowdof.size() + M->M_coldof.size() + M->dof_depth.size() + M->dof_jstart.size() +
 	            M->body_rec.size() + M->body_rec2.size() + M->dof_rec.size() + M->fac_ops.size() + M->fac_beg.size() +
 	            M->body_dofmask.size() + M->body_submask.size() + M->M_dense.size() + M->body_anc.size() + M->dof_bodymask.size() + M->sens_copy.size() + M->sens_slow.size() + M->dof_act_adr.size() +
-	            M->dof_act_id.size() + 96;
+	            M->dof_act_id.size() + M->pair_i.size() + 96;
 	size_t bytes_i = ((ni + nt) * sizeof(int) + 15) & ~size_t(15);
-	size_t bytes = bytes_i + nd * sizeof(double) + 16;
+	size_t bytes = bytes_i + (nd + M->pair_d.size()) * sizeof(double) + 16;
 	if (hipMalloc(&b->blob, bytes) != hipSuccess) {
 		fail(MJB_ENOMEM, "mjb_make_batch: hipMalloc(model blob) failed");
 		mjb_free_batch(b);
@@ -815,8 +869,9 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	size_t o_row = put(M->M_rowdof), o_col = put(M->M_coldof), o_dep = put(M->dof_depth), o_js = put(M->dof_jstart);
 	size_t o_br = put(M->body_rec), o_br2 = put(M->body_rec2), o_dr = put(M->dof_rec), o_fo = put(M->fac_ops),
 	       o_fb = put(M->fac_beg), o_dm = put(M->body_dofmask), o_sm = put(M->body_submask), o_md = put(M->M_dense), o_an = put(M->body_anc), o_db = put(M->dof_bodymask), o_sc = put(M->sens_copy), o_ss = put(M->sens_slow),
-	       o_aa = put(M->dof_act_adr), o_ai = put(M->dof_act_id);
+	       o_aa = put(M->dof_act_adr), o_ai = put(M->dof_act_id), o_pi = put(M->pair_i);
 	if (nd) memcpy(hd, M->hdbl.data(), nd * sizeof(double));
+	memcpy(hd + nd, M->pair_d.data(), M->pair_d.size() * sizeof(double));
 	if (hipMemcpy(b->blob, hostblob.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
 		fail(MJB_ENODEVICE, "mjb_make_batch: model upload failed");
 		mjb_free_batch(b);
@@ -859,6 +914,8 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	dm.sens_slow = (mjb_ciptr)(di + o_ss);
 	dm.dof_act_adr = (mjb_ciptr)(di + o_aa);
 	dm.dof_act_id = (mjb_ciptr)(di + o_ai);
+	dm.pair_i = (mjb_ciptr)(di + o_pi);
+	dm.pair_d = (mjb_cdptr)(dd + nd);
 	for (int k = 0; k < 3; k++) {
 		dm.sens_ncopy[k] = M->sens_ncopy[k];
 		dm.sens_nslow[k] = M->sens_nslow[k];
@@ -896,6 +953,11 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	s.env_geom_friction = nullptr;
 	s.env_equality = nullptr;
 	s.env_mass = nullptr;
+	s.pgs_B = nullptr;
+	if (h.solver == MJB_SOL_PGS && h.nv <= 16 && h.nefcmax > 64) {
+		s.pgs_B = dev_alloc<double>((size_t)nenv * h.nefcmax * h.nv);  // (elliptic PGS never exceeds 64 rows: mjb_compile)
+		ok = ok && s.pgs_B;
+	}
 	s.keep_frame = 0;
 	s.pad1 = 0;
 	if (!ok) {

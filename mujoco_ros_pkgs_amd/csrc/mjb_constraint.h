@@ -499,40 +499,53 @@ DEVI int narrowphase(int t1, int t2, const double *pos1, const double *mat1, con
 // ------------------------------------------------------------------------------------------------
 // A4 + A5  collision: one candidate pair per lane, contacts compacted in pair order
 // ------------------------------------------------------------------------------------------------
+// number of set bits of a wave ballot in the lanes below this one
+DEVI int lanes_below(unsigned long long mask)
+{
+	return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+}
+
+// Everything the two geoms' constants decide (types, sizes, margin, bounding radii, mj_contactParam's mixing of condim /
+// solref / solimp) comes from the host-built per-pair record: one level of memory latency per step instead of the
+// pair -> geom -> attribute chain.  Contact slots are assigned without LDS: a pair yields <= 4 contacts, so its offset is
+// sum_k popcount(ballot(n >= k) below this lane).
 template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &e)
 {
+	static_assert(G == 64, "one env per wavefront: pair offsets come from wave ballots");
 	double *f = e.f;
 	int *fi = e.fi;
 	const int lane = e.lane;
-	if (lane == 0) fi[L.ncon] = 0;
 	if (m.nconmax <= 0 || (m.disableflags & (MJB_DSBL_CONSTRAINT | MJB_DSBL_CONTACT))) {
+		if (lane == 0) fi[L.ncon] = 0;
 		gsync<G>();
 		return;
 	}
-	int *cnt = fi + L.iscratch;  // transient per-pair contact counts
-	int base = 0;
 #ifdef MJB_PROFILE_SUB
 	EPROF_BEGIN();
 #endif
+	int base = 0;  // contacts of the earlier rounds (wave-uniform)
 	for (int p0 = 0; p0 < m.ncollpair; p0 += G) {
 		const int p = p0 + lane;
 		RawCon rc[4];
-		int n = 0, g1 = 0, g2 = 0;
-		double margin = 0, gap = 0;
+		int n = 0, g1 = 0, g2 = 0, condim = 1, frisel = 0;
+		double margin = 0, incl = 0;
+		const mjb_cdptr pd = m.pair_d + 24 * (p < m.ncollpair ? p : 0);
 		if (p < m.ncollpair) {
-			g1 = m.collpair_geom[2 * p];
-			g2 = m.collpair_geom[2 * p + 1];
-			const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
-			double pos1[3], pos2[3], mat1[9], mat2[9], size1[3], size2[3];
+			const mjb_ciptr pi = m.pair_i + 8 * p;
+			g1 = pi[0];
+			g2 = pi[1];
+			const int t1 = pi[2], t2 = pi[3];
+			condim = pi[4];
+			frisel = pi[5];
+			double pos1[3], pos2[3], mat1[9], mat2[9];
+			const double size1[3] = { pd[0], pd[1], pd[2] }, size2[3] = { pd[3], pd[4], pd[5] };
+			margin = pd[6];
+			incl = pd[17];
+			const double rb1 = pd[8], rb2 = pd[9];
 			ld3(pos1, f + L.geom_xpos + 3 * g1);
 			ld3(pos2, f + L.geom_xpos + 3 * g2);
 			ld9(mat1, f + L.geom_xmat + 9 * g1);
 			ld9(mat2, f + L.geom_xmat + 9 * g2);
-			ldc3(size1, m.geom_size + 3 * g1);
-			ldc3(size2, m.geom_size + 3 * g2);
-			margin = fmax(m.geom_margin[g1], m.geom_margin[g2]);
-			gap = fmax(m.geom_gap[g1], m.geom_gap[g2]);
-			const double rb1 = m.geom_rbound[g1], rb2 = m.geom_rbound[g2];
 			bool cull = false;
 			const double dv[3] = { pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2] };
 			if (rb1 > 0 && rb2 > 0) {
@@ -557,42 +570,22 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 				}
 				for (int i = 0; i < 4; i++) rc[i] = keep[i];
 			}
-			cnt[p] = n;
 		}
-		gsync<G>();
 #ifdef MJB_PROFILE_SUB
 		EPROF(24);
 #endif
-		if (p < m.ncollpair && n > 0) {
-			int off = base;
-			for (int q = p0; q < p; q++) off += cnt[q];
-			int condim;
-			double solref[2], solimp[5], fri[3];
-			{  // mj_contactParam
-				const int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];
-				if (pr1 != pr2) {
-					const int g = pr1 > pr2 ? g1 : g2;
-					condim = m.geom_condim[g];
-					for (int k = 0; k < 2; k++) solref[k] = m.geom_solref[2 * g + k];
-					for (int k = 0; k < 5; k++) solimp[k] = m.geom_solimp[5 * g + k];
-					for (int k = 0; k < 3; k++) fri[k] = f[L.gfriction + 3 * g + k];
-				} else {
-					const int c1 = m.geom_condim[g1], c2 = m.geom_condim[g2];
-					condim = c1 > c2 ? c1 : c2;
-					const double s1 = m.geom_solmix[g1], s2 = m.geom_solmix[g2];
-					double mix;
-					if (s1 >= MJB_MINVAL && s2 >= MJB_MINVAL) mix = s1 / (s1 + s2);
-					else if (s1 < MJB_MINVAL && s2 < MJB_MINVAL) mix = 0.5;
-					else if (s1 < MJB_MINVAL) mix = 0.0;
-					else mix = 1.0;
-					const double r10 = m.geom_solref[2 * g1], r20 = m.geom_solref[2 * g2];
-					for (int k = 0; k < 2; k++) {
-						const double a = m.geom_solref[2 * g1 + k], b = m.geom_solref[2 * g2 + k];
-						solref[k] = (r10 > 0 && r20 > 0) ? mix * a + (1 - mix) * b : fmin(a, b);
-					}
-					for (int k = 0; k < 5; k++) solimp[k] = mix * m.geom_solimp[5 * g1 + k] + (1 - mix) * m.geom_solimp[5 * g2 + k];
-					for (int k = 0; k < 3; k++) fri[k] = fmax(f[L.gfriction + 3 * g1 + k], f[L.gfriction + 3 * g2 + k]);
-				}
+		int off = base, total = 0;
+#pragma unroll
+		for (int k = 1; k <= 4; k++) {
+			const unsigned long long mk = __ballot(n >= k);
+			off += lanes_below(mk);
+			total += __popcll(mk);
+		}
+		if (n > 0) {
+			double fri[3];
+			for (int k = 0; k < 3; k++) {
+				const double a = f[L.gfriction + 3 * g1 + k], b = f[L.gfriction + 3 * g2 + k];
+				fri[k] = frisel == 0 ? fmax(a, b) : (frisel == 1 ? a : b);
 			}
 			for (int i = 0; i < 4; i++) {
 				if (i >= n) break;
@@ -604,21 +597,19 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 				f[L.contact_dist + c] = rc[i].dist;
 				st3(f + L.contact_pos + 3 * c, rc[i].pos);
 				st9(f + L.contact_frame + 9 * c, fr);
-				f[L.contact_includemargin + c] = margin - gap;
+				f[L.contact_includemargin + c] = incl;
 				double *f5 = f + L.contact_friction + 5 * c;
 				f5[0] = fri[0]; f5[1] = fri[0]; f5[2] = fri[1]; f5[3] = fri[2]; f5[4] = fri[2];
-				f[L.contact_solref + 2 * c] = solref[0];
-				f[L.contact_solref + 2 * c + 1] = solref[1];
-				for (int k = 0; k < 5; k++) f[L.contact_solimp + 5 * c + k] = solimp[k];
+				f[L.contact_solref + 2 * c] = pd[10];
+				f[L.contact_solref + 2 * c + 1] = pd[11];
+				for (int k = 0; k < 5; k++) f[L.contact_solimp + 5 * c + k] = pd[12 + k];
 				fi[L.contact_geom + 2 * c] = g1;
 				fi[L.contact_geom + 2 * c + 1] = g2;
 				fi[L.contact_dim + c] = condim;
 				fi[L.contact_efc_address + c] = -1;
 			}
 		}
-		const int hi = (p0 + G < m.ncollpair) ? p0 + G : m.ncollpair;
-		for (int q = p0; q < hi; q++) base += cnt[q];
-		gsync<G>();
+		base += total;
 #ifdef MJB_PROFILE_SUB
 		EPROF(25);
 #endif
@@ -652,6 +643,16 @@ DEVI void impedance(const double *solimp, double pos, double margin, double &imp
 	if (solimp[4] == 1) {
 		y = x;
 		yP = 1;
+	} else if (solimp[4] == 2) {  // MuJoCo's default power: the same expressions with pow(., 2) / pow(., 1) written out
+		if (x <= solimp[3]) {
+			const double a = 1 / solimp[3];
+			y = a * (x * x);
+			yP = 2 * a * x;
+		} else {
+			const double b = 1 / (1 - solimp[3]);
+			y = 1 - b * ((1 - x) * (1 - x));
+			yP = 2 * b * (1 - x);
+		}
 	} else if (x <= solimp[3]) {
 		const double a = 1 / pow(solimp[3], solimp[4] - 1);
 		y = a * pow(x, solimp[4]);
@@ -665,17 +666,11 @@ DEVI void impedance(const double *solimp, double pos, double margin, double &imp
 	impP = yP * sgn * (solimp[1] - solimp[0]) / solimp[2];
 }
 
-// R and KBIP of one row (mj_makeImpedance)
-DEVI void row_params_x(CModel m, CLayout L, double *f, int i, double pos, double margin, const double *solref_in,
-                       const double *solimp, double diag_approx, double imp_pos);
-DEVI void row_params(CModel m, CLayout L, double *f, int i, double pos, double margin, const double *solref_in,
-                     const double *solimp, double diag_approx)
-{
-	row_params_x(m, L, f, i, pos, margin, solref_in, solimp, diag_approx, pos);
-}
-// imp_pos: the position the impedance is evaluated at (rows of a connect / weld share the norm of their residual)
-DEVI void row_params_x(CModel m, CLayout L, double *f, int i, double pos, double margin, const double *solref_in,
-                       const double *solimp_in, double diag_approx, double imp_pos)
+// K, B, imp, imp' of one row (getsolparam + getimpedance + the reference-acceleration gains of mj_makeImpedance)
+struct RowGain {
+	double K, B, imp, impP;
+};
+DEVI RowGain row_gain(CModel m, const double *solref_in, const double *solimp_in, double imp_pos, double margin)
 {
 	// getsolparam: mixed-sign solref falls back to the default (0.02, 1); refsafe; solimp clamped to its legal ranges
 	double sr0 = solref_in[0], sr1 = solref_in[1];
@@ -686,24 +681,40 @@ DEVI void row_params_x(CModel m, CLayout L, double *f, int i, double pos, double
 	if (!(m.disableflags & MJB_DSBL_REFSAFE) && sr0 > 0) sr0 = fmax(sr0, 2 * m.timestep[0]);
 	const double solimp[5] = { fmin(MJB_MAXIMP, fmax(MJB_MINIMP, solimp_in[0])), fmin(MJB_MAXIMP, fmax(MJB_MINIMP, solimp_in[1])),
 		                       fmax(0.0, solimp_in[2]), fmin(MJB_MAXIMP, fmax(MJB_MINIMP, solimp_in[3])), fmax(1.0, solimp_in[4]) };
-	double imp, impP;
-	impedance(solimp, imp_pos, margin, imp, impP);
-	f[L.efc_R + i] = fmax(MJB_MINVAL, (1 - imp) * diag_approx / imp);
+	RowGain g;
+	impedance(solimp, imp_pos, margin, g.imp, g.impP);
 	const double dmax = solimp[1];
-	double K, B;
 	if (sr0 > 0) {
-		K = 1 / fmax(MJB_MINVAL, dmax * dmax * sr0 * sr0 * sr1 * sr1);
-		B = 2 / fmax(MJB_MINVAL, dmax * sr0);
+		g.K = 1 / fmax(MJB_MINVAL, dmax * dmax * sr0 * sr0 * sr1 * sr1);
+		g.B = 2 / fmax(MJB_MINVAL, dmax * sr0);
 	} else {
-		K = -sr0 / fmax(MJB_MINVAL, dmax * dmax);
-		B = -sr1 / fmax(MJB_MINVAL, dmax);
+		g.K = -sr0 / fmax(MJB_MINVAL, dmax * dmax);
+		g.B = -sr1 / fmax(MJB_MINVAL, dmax);
 	}
-	f[L.efc_KBIP + 4 * i] = K;
-	f[L.efc_KBIP + 4 * i + 1] = B;
-	f[L.efc_KBIP + 4 * i + 2] = imp;
-	f[L.efc_KBIP + 4 * i + 3] = impP;
+	return g;
+}
+DEVI double row_R(const RowGain &g, double diag_approx) { return fmax(MJB_MINVAL, (1 - g.imp) * diag_approx / g.imp); }
+DEVI void row_store(CLayout L, double *f, int i, double pos, double margin, const RowGain &g, double R)
+{
+	f[L.efc_R + i] = R;
+	f[L.efc_KBIP + 4 * i] = g.K;
+	f[L.efc_KBIP + 4 * i + 1] = g.B;
+	f[L.efc_KBIP + 4 * i + 2] = g.imp;
+	f[L.efc_KBIP + 4 * i + 3] = g.impP;
 	f[L.efc_pos + i] = pos;
 	f[L.efc_margin + i] = margin;
+}
+// imp_pos: the position the impedance is evaluated at (rows of a connect / weld share the norm of their residual)
+DEVI void row_params_x(CModel m, CLayout L, double *f, int i, double pos, double margin, const double *solref_in,
+                       const double *solimp_in, double diag_approx, double imp_pos)
+{
+	const RowGain g = row_gain(m, solref_in, solimp_in, imp_pos, margin);
+	row_store(L, f, i, pos, margin, g, row_R(g, diag_approx));
+}
+DEVI void row_params(CModel m, CLayout L, double *f, int i, double pos, double margin, const double *solref_in,
+                     const double *solimp, double diag_approx)
+{
+	row_params_x(m, L, f, i, pos, margin, solref_in, solimp, diag_approx, pos);
 }
 
 // does dof `i` move body `b`?  (bit i of the body's ancestor-dof mask, built on the host; nv <= 64)
@@ -749,8 +760,20 @@ DEVI void eq_geometry(CModel m, CLayout L, const double *f, int e, EqGeom &g)
 // ------------------------------------------------------------------------------------------------
 // A6  make_constraint: rows for equalities (connect / weld / joint), joint limits, then contacts
 // ------------------------------------------------------------------------------------------------
+// inclusive prefix sum over the 64 lanes of a wavefront (Hillis-Steele with ds_bpermute)
+DEVI int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const int y = __shfl_up(v, d, 64);
+		if (lane >= d) v += y;
+	}
+	return v;
+}
+
 template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const Env &e)
 {
+	static_assert(G == 64, "one env per wavefront: row offsets come from a wave prefix sum");
 	double *f = e.f;
 	int *fi = e.fi;
 	const int lane = e.lane, nv = m.nv;
@@ -766,64 +789,62 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const
 	const int nfd = m.nfriction > 0 ? nv : 0;  // dof friction items, then tendon friction items (models without dry friction keep the shorter list)
 	const int nfr = m.nfriction > 0 ? nv + m.ntendon : 0;
 	const int nitem = neq + nfr + m.njnt + nten + ncon;  // item = equality, dof / tendon friction, joint limit, tendon limit or contact -- MuJoCo's row order
-	int *cnt = fi + L.iscratch;              // transient per-item row counts
+	int *adr = fi + L.iscratch;              // first row of every item (-1: no rows / dropped); read by the Jacobian passes
 #ifdef MJB_PROFILE_SUB
 	EPROF_BEGIN();
 #endif
-	// pass 1: rows per item
-	for (int it = lane; it < nitem; it += G) {
-		int n = 0;
-		if (it < neq) {
-			if (f[L.eqparam + 19 * it] != 0) n = m.eq_type[it] == MJB_EQ_CONNECT ? 3 : (m.eq_type[it] == MJB_EQ_WELD ? 6 : 1);  // joint, tendon: 1
-		} else if (it < neq + nfr) {
-			n = (it < neq + nfd ? m.dof_frictionloss[it - neq] : m.tendon_frictionloss[it - neq - nfd]) > 0 ? 1 : 0;
-		} else if (it < neq + nfr + m.njnt) {
-			const int j = it - neq - nfr;
-			if (do_lim && m.jnt_limited[j] && m.jnt_type[j] >= MJB_JNT_SLIDE) {
-				const double value = f[L.qpos + m.jnt_qposadr[j]], margin = m.jnt_margin[j];
-				if (value - m.jnt_range[2 * j] < margin) n++;
-				if (m.jnt_range[2 * j + 1] - value < margin) n++;
-			}
-		} else if (it < neq + nfr + m.njnt + nten) {
-			const int t = it - neq - nfr - m.njnt;
-			if (m.tendon_limited[t]) {
-				const double value = f[L.ten_length + t], margin = m.tendon_margin[t];
-				if (value - m.tendon_range[2 * t] < margin) n++;
-				if (m.tendon_range[2 * t + 1] - value < margin) n++;
-			}
-		} else if (do_con) {
-			const int c = it - neq - nfr - m.njnt - nten;
-			if (f[L.contact_dist + c] < f[L.contact_includemargin + c]) {
-				const int dim = fi[L.contact_dim + c];
-				n = dim == 1 ? 1 : (m.cone == MJB_CONE_ELLIPTIC ? dim : 2 * (dim - 1));
-			}
-		}
-		cnt[it] = n;
-	}
 	if (nfr)
 		for (int r = lane; r < m.nefcmax; r += G) f[L.efc_frictionloss + r] = 0;
-	gsync<G>();
-	// row budget: the first item that does not fit, and everything after it, is dropped
-	int nefc = 0, cut = nitem;
-	for (int it = 0; it < nitem; it++) {
-		const int n = cnt[it];
-		if (nefc + n > m.nefcmax) {
-			cut = it;
-			break;
-		}
-		nefc += n;
-	}
-	if (cut < nitem && lane == 0) atomicAdd(s.nwarn + MJB_WARN_CNSTRFULL, 1ull);  // mjWARN_CNSTRFULL (rule: include/mjb.h, mjb_warning)
-#ifdef MJB_PROFILE_SUB
-	EPROF(26);
-#endif
-	// pass 2: row parameters, one item per lane (item order == row order)
-	for (int it0 = 0; it0 < cut; it0 += G) {
+	// Items in MuJoCo's row order, one per lane, 64 at a time: rows per item -> wave prefix sum -> row parameters.
+	// Row budget: the first item that does not fit, and everything after it, is dropped (mjWARN_CNSTRFULL).
+	int nefc = 0;       // rows so far (wave-uniform)
+	bool full = false;  // an item did not fit: the rest is dropped
+	for (int it0 = 0; it0 < nitem; it0 += G) {
 		const int it = it0 + lane;
-		if (it >= cut) continue;
-		int off = 0;
-		for (int q = 0; q < it; q++) off += cnt[q];
-		const int n = cnt[it];
+		int n = 0;
+		if (it < nitem && !full) {
+			if (it < neq) {
+				if (f[L.eqparam + 19 * it] != 0) n = m.eq_type[it] == MJB_EQ_CONNECT ? 3 : (m.eq_type[it] == MJB_EQ_WELD ? 6 : 1);  // joint, tendon: 1
+			} else if (it < neq + nfr) {
+				n = (it < neq + nfd ? m.dof_frictionloss[it - neq] : m.tendon_frictionloss[it - neq - nfd]) > 0 ? 1 : 0;
+			} else if (it < neq + nfr + m.njnt) {
+				const int j = it - neq - nfr;
+				if (do_lim && m.jnt_limited[j] && m.jnt_type[j] >= MJB_JNT_SLIDE) {
+					const double value = f[L.qpos + m.jnt_qposadr[j]], margin = m.jnt_margin[j];
+					if (value - m.jnt_range[2 * j] < margin) n++;
+					if (m.jnt_range[2 * j + 1] - value < margin) n++;
+				}
+			} else if (it < neq + nfr + m.njnt + nten) {
+				const int t = it - neq - nfr - m.njnt;
+				if (m.tendon_limited[t]) {
+					const double value = f[L.ten_length + t], margin = m.tendon_margin[t];
+					if (value - m.tendon_range[2 * t] < margin) n++;
+					if (m.tendon_range[2 * t + 1] - value < margin) n++;
+				}
+			} else if (do_con) {
+				const int c = it - neq - nfr - m.njnt - nten;
+				if (f[L.contact_dist + c] < f[L.contact_includemargin + c]) {
+					const int dim = fi[L.contact_dim + c];
+					n = dim == 1 ? 1 : (m.cone == MJB_CONE_ELLIPTIC ? dim : 2 * (dim - 1));
+				}
+			}
+		}
+		const int incl = wave_incl_scan(n, lane);
+		int off = nefc + incl - n;
+		const unsigned long long over = __ballot(n > 0 && off + n > m.nefcmax);
+		int round_rows = __builtin_amdgcn_readlane(incl, 63);
+		if (over) {  // (wave-uniform) first lane that does not fit: it and everything after it is dropped
+			const int cutlane = __builtin_ctzll(over);
+			round_rows = __builtin_amdgcn_readlane(incl - n, cutlane);
+			if (lane >= cutlane) n = 0;
+			if (!full && lane == 0) atomicAdd(s.nwarn + MJB_WARN_CNSTRFULL, 1ull);  // mjWARN_CNSTRFULL (rule: include/mjb.h, mjb_warning)
+			full = true;
+		}
+		nefc += round_rows;
+		if (it < nitem) adr[it] = n > 0 ? off : -1;
+#ifdef MJB_PROFILE_SUB
+		EPROF(26);
+#endif
 		if (n == 0) continue;
 		if (it < neq) {
 			const int eq = it, type = m.eq_type[eq], id0 = m.eq_obj1id[eq], id1 = m.eq_obj2id[eq];
@@ -963,34 +984,37 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const
 				fri[k] = f[L.contact_friction + 5 * c + k];
 			}
 			fi[L.contact_efc_address + c] = off;
+			(void)rot;
+			// ONE impedance evaluation per contact: its rows share solref / solimp, and either all of them sit at
+			// (pos, margin) = (dist, includemargin) [frictionless, pyramidal] or the friction rows sit at (0, 0) [elliptic]
+			const RowGain g0 = row_gain(m, solref, solimp, dist, cm);
 			if (dim == 1) {
-				row_params(m, L, f, off, dist, cm, solref, solimp, tran);
+				row_store(L, f, off, dist, cm, g0, row_R(g0, tran));
 				fi[L.efc_id + off] = c;
 				fi[L.efc_type + off] = MJB_CNSTR_CONTACT_FRICTIONLESS;
 			} else if (m.cone == MJB_CONE_ELLIPTIC) {
 				// row 0 = normal (pos = dist), rows 1.. = friction directions (pos = margin = 0);
 				// R_j = R_0 mu^2 / friction_j^2 with mu = friction_0 / sqrt(impratio)
-				for (int k = 0; k < dim; k++) {
-					row_params(m, L, f, off + k, k == 0 ? dist : 0.0, k == 0 ? cm : 0.0, solref, solimp, k < 3 ? tran : rot);
+				const RowGain gf = row_gain(m, solref, solimp, 0.0, 0.0);
+				const double mu = fri[0] / sqrt(fmax(MJB_MINVAL, m.impratio[0]));
+				const double R0 = row_R(g0, tran);
+				for (int k = 0; k < 6; k++) {
+					if (k >= dim) break;
+					if (k == 0) row_store(L, f, off, dist, cm, g0, R0);
+					else row_store(L, f, off + k, 0.0, 0.0, gf, fmax(MJB_MINVAL, R0 * mu * mu / (fri[k - 1] * fri[k - 1])));
 					fi[L.efc_id + off + k] = c;
 					fi[L.efc_type + off + k] = MJB_CNSTR_CONTACT_ELLIPTIC;
 				}
-				const double mu = fri[0] / sqrt(fmax(MJB_MINVAL, m.impratio[0]));
-				const double R0 = f[L.efc_R + off];
-				for (int k = 1; k < dim; k++) f[L.efc_R + off + k] = fmax(MJB_MINVAL, R0 * mu * mu / (fri[k - 1] * fri[k - 1]));
 			} else {
-				int r = off;
-				for (int k = 1; k < dim; k++)
-					for (int sg = 0; sg < 2; sg++) {
-						const double da = tran + fri[k - 1] * fri[k - 1] * ((k - 1) < 2 ? tran : rot);
-						row_params(m, L, f, r, dist, cm, solref, solimp, da);
-						fi[L.efc_id + r] = c;
-						fi[L.efc_type + r] = MJB_CNSTR_CONTACT_PYRAMIDAL;
-						r++;
-					}
+				// pyramidal: every row gets Rpy = 2 mu^2 R(first row), R(first row) from diagApprox = tran + friction_0^2 tran
 				const double mu = fri[0] / sqrt(fmax(MJB_MINVAL, m.impratio[0]));
-				const double Rpy = fmax(MJB_MINVAL, 2 * mu * mu * f[L.efc_R + off]);
-				for (int q = off; q < r; q++) f[L.efc_R + q] = Rpy;
+				const double Rpy = fmax(MJB_MINVAL, 2 * mu * mu * row_R(g0, tran + fri[0] * fri[0] * tran));
+				for (int k = 0; k < 10; k++) {
+					if (k >= 2 * (dim - 1)) break;
+					row_store(L, f, off + k, dist, cm, g0, Rpy);
+					fi[L.efc_id + off + k] = c;
+					fi[L.efc_type + off + k] = MJB_CNSTR_CONTACT_PYRAMIDAL;
+				}
 			}
 		}
 	}
@@ -1009,9 +1033,8 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const
 	for (int t = lane; t < neq * nv; t += G) {
 		const int eq = t / nv, i = t - eq * nv;
 		const int type = m.eq_type[eq];
-		if (eq >= cut || cnt[eq] == 0 || type == MJB_EQ_JOINT || type == MJB_EQ_TENDON) continue;
-		int adr = 0;
-		for (int q = 0; q < eq; q++) adr += cnt[q];
+		const int adr = fi[L.iscratch + eq];  // first row of the equality (-1: inactive / dropped)
+		if (adr < 0 || type == MJB_EQ_JOINT || type == MJB_EQ_TENDON) continue;
 		const int id0 = m.eq_obj1id[eq], id1 = m.eq_obj2id[eq];
 		const bool in0 = dof_moves_body(m, id0, i), in1 = dof_moves_body(m, id1, i);
 		double jp[3] = { 0, 0, 0 }, jr[3] = { 0, 0, 0 };
@@ -1500,6 +1523,38 @@ DEVI void pgs_sweep_elliptic(const double (&AR)[64], const int nefc, const int l
 	}
 }
 
+// x <- M^-1 x for nv <= 16 with x in 16 statically indexed registers: the sparse L'DL factor spread into a packed dense
+// strictly-lower triangle Ld (entry (i, j) at i (i - 1) / 2 + j, zeros where j is no ancestor of i; rows / columns >= nv are
+// zero and x[k >= nv] = 0, so the unrolled sweeps need no guards).  Every L entry is read at a compile-time offset and a
+// wave-uniform address (one LDS broadcast per entry): 240 fma per vector with no load-modify-store chain.
+DEVI void tri_build(CModel m, CLayout L, double *f, double *Ld, int lane)
+{
+	for (int t = lane; t < 120; t += 64) Ld[t] = 0;
+	gsync<64>();
+	for (int en = lane; en < m.nM; en += 64) {
+		const int i = m.M_rowdof[en], j = m.M_coldof[en];
+		if (i != j) Ld[i * (i - 1) / 2 + j] = f[L.qLD + en];
+	}
+	gsync<64>();
+}
+DEVI void tri_solve(double (&x)[16], const double *Ld, const double *di, int nv)
+{
+	// x <- L^-T x: once x[i] is final, every x[j < i] takes its share (independent fma)
+#pragma unroll
+	for (int i = 15; i >= 1; i--) {
+#pragma unroll
+		for (int j = 0; j < i; j++) x[j] -= Ld[i * (i - 1) / 2 + j] * x[i];
+	}
+#pragma unroll
+	for (int k = 0; k < 16; k++) x[k] *= di[k < nv ? k : 0];
+	// x <- L^-1 x, column by column (same summation order as the row form)
+#pragma unroll
+	for (int j = 0; j < 15; j++) {
+#pragma unroll
+		for (int i = j + 1; i < 16; i++) x[i] -= Ld[i * (i - 1) / 2 + j] * x[j];
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // A13 PGS beyond 64 rows (64 < nefc <= 128, scalar rows: equality / friction / limit / frictionless / pyramidal).
 // A row of AR no longer fits the lane's registers, so this path is AR-free: row r lives in lane r % 64, slot r / 64, with
@@ -1509,23 +1564,24 @@ DEVI void pgs_sweep_elliptic(const double (&AR)[64], const int nefc, const int l
 // env-steps whose row count actually exceeds 64 (wave-uniform branch in fwd_constraint_pgs; out of line so that the
 // common path pays neither registers nor instruction-cache lines for it).
 // ------------------------------------------------------------------------------------------------
-template <int G> __device__ __attribute__((noinline)) void fwd_constraint_pgs_large(CModel m, CLayout L, const Env &e)
+template <int G> __device__ __attribute__((noinline)) void fwd_constraint_pgs_large(CModel m, CLayout L, const Env &e, const double *Brows)
 {
 	static_assert(G == 64, "the constraint solver maps rows to the 64 lanes of one wavefront");
 	double *f = e.f;
 	int *fi = e.fi;
-	const int lane = e.lane, nv = m.nv, nefc = fi[L.nefc];
+	const int lane = e.lane, nv = m.nv, nefc = __builtin_amdgcn_readfirstlane(fi[L.nefc]);
 	constexpr int S = 2;
 	const bool warm = !(m.disableflags & MJB_DSBL_WARMSTART);
 	const bool small = nv <= 16;
 	bool act[S];
 	double b[S], Rr[S], ARinv[S], lo[S], hi[S], frc[S];
+	auto b_entry = [&](int i) -> double { return lane < nv ? Brows[i * nv + lane] : 0.0; };  // B_i[lane]
 #pragma unroll
 	for (int s = 0; s < S; s++) {
 		const int r = lane + 64 * s;
 		act[s] = r < nefc;
 		const int rr = act[s] ? r : 0;
-		const double *Jr = f + L.efc_J + rr * nv, *Br = f + L.efc_B + rr * nv;
+		const double *Jr = f + L.efc_J + rr * nv, *Br = Brows + rr * nv;
 		double jq = 0, jb = 0, jw = 0;
 		for (int k = 0; k < nv; k++) {
 			const double j = Jr[k];
@@ -1557,8 +1613,8 @@ template <int G> __device__ __attribute__((noinline)) void fwd_constraint_pgs_la
 	gsync<G>();
 	double *w = f + L.qacc;  // w = M^-1 J' f = B' f parked in the qacc slot between sweeps (qacc = qacc_smooth + w at the end)
 	double wreg = 0;
-	if (lane < nv)
-		for (int i = 0; i < nefc; i++) wreg += f[L.efc_B + i * nv + lane] * f[L.efc_force + i];
+#pragma nounroll
+	for (int i = 0; i < nefc; i++) wreg += b_entry(i) * f[L.efc_force + i];
 	// cost = 0.5 f'ARf + f'b = sum_r 0.5 f_r (res_r + b_r), res_r = b_r + R_r f_r + J_r . w
 	auto cost_of = [&]() -> double {
 		if (lane < nv) w[lane] = wreg;
@@ -1589,15 +1645,13 @@ template <int G> __device__ __attribute__((noinline)) void fwd_constraint_pgs_la
 		for (int s = 0; s < S; s++) {
 			const int i0 = 64 * s, i1 = nefc < i0 + 64 ? nefc : i0 + 64;
 			double jn = (lane < nv && i0 < i1) ? f[L.efc_J + i0 * nv + lane] : 0.0;
-			double bn = (lane < nv && i0 < i1) ? f[L.efc_B + i0 * nv + lane] : 0.0;
+			double bn = i0 < i1 ? b_entry(i0) : 0.0;
 #pragma nounroll
 			for (int i = i0; i < i1; i++) {
 				const double ji = jn, bi = bn;
-				const int nx = i + 1 < nefc ? i + 1 : i;  // prefetch the next row's entries (off the dependent chain)
-				if (lane < nv) {
-					jn = f[L.efc_J + nx * nv + lane];
-					bn = f[L.efc_B + nx * nv + lane];
-				}
+				const int nx = i + 1 < nefc ? i + 1 : i;  // the next row's entries (off the dependent chain)
+				if (lane < nv) jn = f[L.efc_J + nx * nv + lane];
+				bn = b_entry(nx);
 				const double p = ji * wreg;
 				const double dot = small ? wave_bcast(row_sum<16>(p), 0) : wave_sum(p);
 				const double res = b[s] + Rr[s] * frc[s] + dot;
@@ -1633,13 +1687,13 @@ template <int G> __device__ __attribute__((noinline)) void fwd_constraint_pgs_la
 // ------------------------------------------------------------------------------------------------
 // A13 constraint solve: warmstart + projected Gauss-Seidel (dual), one env per wavefront
 // ------------------------------------------------------------------------------------------------
-template <int G, bool ELL> STAGE void fwd_constraint_pgs(CModel m, CLayout L, const Env &e)
+template <int G, bool ELL, bool REGB> STAGE void fwd_constraint_pgs(CModel m, CLayout L, CState s, const Env &e)
 {
 	static_assert(G == 64, "the constraint solver maps rows to the 64 lanes of one wavefront");
 	double *f = e.f;
 	int *fi = e.fi;
 	const int lane = e.lane, nv = m.nv;
-	const int nefc = fi[L.nefc];
+	const int nefc = __builtin_amdgcn_readfirstlane(fi[L.nefc]);  // (wave-uniform by construction: make the compiler see it, so that the branches on it are scalar)
 	if (nefc == 0) {
 		for (int d = lane; d < nv; d += G) {
 			const double a = f[L.qacc_smooth + d];
@@ -1651,18 +1705,56 @@ template <int G, bool ELL> STAGE void fwd_constraint_pgs(CModel m, CLayout L, co
 		gsync<G>();
 		return;
 	}
-	if (!ELL && nefc > 64) {  // (wave-uniform; rare: the register path below holds one row of AR per lane)
-		MJB_KEEP_BRANCH();
-		fwd_constraint_pgs_large<G>(m, L, e);
-		return;
-	}
 	// Row r lives in lane r together with ITS ROW OF AR = J M^-1 J' + diag(R) in registers (64 doubles): a
 	// Gauss-Seidel update of row i is then "every lane proposes the update of its own row from its running residual,
 	// lane i's proposal is broadcast with v_readlane, every lane does res += AR[.][i] * delta" -- no reduction and no
 	// LDS access inside the sweep (the dependent chain per row is ~9 fp64 ops + one readlane pair).
 	const bool rowact = lane < nefc;
 	const int r = rowact ? lane : 0;
-	const double *Jr = f + L.efc_J + r * nv, *Br = f + L.efc_B + r * nv;
+	const double *Jr = f + L.efc_J + r * nv;
+	// REGB (nv <= 16): the row B_r = (M^-1 J_r')' of B = J M^-1 is solved for in this lane's registers (A7,
+	// mj_projectConstraint) and never stored to LDS: AR_ri = B_r . J_i reads J, which has to be in LDS anyway.  Otherwise the
+	// rows of B come from LDS (project_constraint).  Beyond 64 rows (rare; pyramidal / scalar rows only) the rows of B go to
+	// the env's scratch in HBM and the AR-free path takes over.
+	double x[16];
+	const bool large = !ELL && nefc > 64;
+	if constexpr (REGB) {
+		double *Ld = f + L.tri;  // (compact layout: inside the region kinematics / crb / rne share -- nobody else is alive here)
+		tri_build(m, L, f, Ld, lane);
+		double *Bg = s.pgs_B ? s.pgs_B + (size_t)e.env * m.nefcmax * nv : nullptr;
+#pragma nounroll
+		for (int r0 = large ? 64 : 0; r0 >= 0; r0 -= 64) {  // (block 0 last: its row stays in the registers)
+			const int rb = r0 + lane;
+			const bool act = rb < nefc;
+			const double *Jb = f + L.efc_J + (act ? rb : 0) * nv;
+#pragma unroll
+			for (int k = 0; k < 16; k++) {
+				const double v = Jb[k < nv ? k : 0];
+				x[k] = (k < nv && act) ? v : 0.0;
+			}
+			tri_solve(x, Ld, f + L.qLDiagInv, nv);
+			if (L.efc_B >= 0 && act) {  // (full layout only: the field mjb_get serves)
+#pragma unroll
+				for (int k = 0; k < 16; k++)
+					if (k < nv) f[L.efc_B + rb * nv + k] = x[k];
+			} else if (large && act && Bg) {
+#pragma unroll
+				for (int k = 0; k < 16; k++)
+					if (k < nv) Bg[rb * nv + k] = x[k];
+			}
+		}
+		if (large) {
+			MJB_KEEP_BRANCH();
+			__threadfence();  // the rows just written to HBM are read back through the vector cache
+			fwd_constraint_pgs_large<G>(m, L, e, L.efc_B >= 0 ? f + L.efc_B : Bg);
+			return;
+		}
+	} else if (large) {
+		MJB_KEEP_BRANCH();
+		fwd_constraint_pgs_large<G>(m, L, e, f + L.efc_B);
+		return;
+	}
+	const double *Br = f + (REGB ? L.efc_J : L.efc_B) + r * nv;  // (REGB: unused)
 	const bool bilateral = rowact && fi[L.efc_type + r] == MJB_CNSTR_EQUALITY;
 	const double floss = (rowact && m.nfriction > 0) ? f[L.efc_frictionloss + r] : 0.0;  // > 0: dry-friction row (dof or tendon)
 	const bool friction = floss > 0;
@@ -1676,11 +1768,22 @@ template <int G, bool ELL> STAGE void fwd_constraint_pgs(CModel m, CLayout L, co
 	double b = 0, Aii = 1, ARinv = 0, frc = 0;
 	{
 		double jq = 0, jb = 0, jw = 0;
-		for (int k = 0; k < nv; k++) {
-			const double j = Jr[k];
-			jq += j * f[L.qacc_smooth + k];
-			jb += j * Br[k];
-			jw += j * f[L.qacc_warmstart + k];
+		if constexpr (REGB) {
+#pragma unroll
+			for (int k = 0; k < 16; k++) {
+				const int kc = k < nv ? k : 0;
+				const double j = k < nv ? Jr[kc] : 0.0;
+				jq += j * f[L.qacc_smooth + kc];
+				jb += j * x[k];
+				jw += j * f[L.qacc_warmstart + kc];
+			}
+		} else {
+			for (int k = 0; k < nv; k++) {
+				const double j = Jr[k];
+				jq += j * f[L.qacc_smooth + k];
+				jb += j * Br[k];
+				jw += j * f[L.qacc_warmstart + k];
+			}
 		}
 		const double aref = f[L.efc_aref + r], R = f[L.efc_R + r];
 		if (rowact) {
@@ -1720,17 +1823,42 @@ template <int G, bool ELL> STAGE void fwd_constraint_pgs(CModel m, CLayout L, co
 	double AR[64];
 #pragma unroll
 	for (int i = 0; i < 64; i++) AR[i] = 0;
-#pragma nounroll
-	for (int k = 0; k < nv; k++) {
-		const double jk = Jr[k];
-		const double *Bk = f + L.efc_B + k;
+	if constexpr (REGB) {
+		// AR_ri = B_r . J_i (AR is symmetric): B_r from the registers, J_i[k] one LDS broadcast per (i, k)
 #pragma unroll
-		for (int i = 0; i < 64; i++) {
-			if ((i & 3) == 0) {
-				if (i >= nefc) break;
+		for (int k = 0; k < 16; k++) {
+			if (k < nv) {
 				MJB_KEEP_BRANCH();
+				const double xk = x[k];
+				const double *Jk = f + L.efc_J + k;
+#pragma unroll
+				for (int i = 0; i < 64; i += 4) {
+					if (i < nefc) {
+						MJB_KEEP_BRANCH();
+						AR[i] += xk * Jk[i * nv];
+						AR[i + 1] += xk * Jk[(i + 1) * nv];
+						AR[i + 2] += xk * Jk[(i + 2) * nv];
+						AR[i + 3] += xk * Jk[(i + 3) * nv];
+					}
+				}
+#ifdef MJB_EXP_ARFENCE
+				asm volatile("" ::: "memory");  // (the loads of one k in flight together, not those of several k)
+#endif
 			}
-			AR[i] += jk * Bk[i * nv];
+		}
+	} else {
+#pragma nounroll
+		for (int k = 0; k < nv; k++) {
+			const double jk = Jr[k];
+			const double *Bk = f + L.efc_B + k;
+#pragma unroll
+			for (int i = 0; i < 64; i++) {
+				if ((i & 3) == 0) {
+					if (i >= nefc) break;
+					MJB_KEEP_BRANCH();
+				}
+				AR[i] += jk * Bk[i * nv];
+			}
 		}
 	}
 #pragma unroll
@@ -1786,19 +1914,46 @@ template <int G, bool ELL> STAGE void fwd_constraint_pgs(CModel m, CLayout L, co
 	if (rowact) f[L.efc_force + r] = frc;
 	gsync<G>();
 	// qfrc_constraint = J' f,  qacc = qacc_smooth + M^-1 J' f = qacc_smooth + B' f
+	double wk = 0;
+	if constexpr (REGB) {  // B' f: element k = sum over the lanes of B_r[k] f_r
+		// (B_r is solved for a second time instead of being kept alive through the sweeps: the AR row already fills the lane's
+		//  registers there, and the substitution is ~1.5 k cycles against thousands per sweep)
+		asm volatile("" ::: "memory");
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			const double v = Jr[k < nv ? k : 0];
+			x[k] = (k < nv && rowact) ? v : 0.0;
+		}
+		tri_solve(x, f + L.tri, f + L.qLDiagInv, nv);
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			if (k < nv) {
+				MJB_KEEP_BRANCH();
+				const double t = wave_sum(rowact ? x[k] * frc : 0.0);
+				if (lane == k) wk = t;
+			}
+		}
+	}
 	if (lane < nv) {
 		double s = 0, w = 0;
 		for (int i = 0; i < nefc; i++) {
 			const double fr = f[L.efc_force + i];
 			s += f[L.efc_J + i * nv + lane] * fr;
-			w += f[L.efc_B + i * nv + lane] * fr;
+			if constexpr (!REGB) w += f[L.efc_B + i * nv + lane] * fr;
 		}
+		if constexpr (REGB) w = wk;
 		f[L.qfrc_constraint + lane] = s;
 		const double a = f[L.qacc_smooth + lane] + w;
 		f[L.qacc + lane] = a;
 		f[L.qacc_warmstart + lane] = a;
 	}
 	gsync<G>();
+}
+
+// the LDS-B variants (nv > 16) stay out of line: models that small never pay their registers or instruction-cache lines
+template <int G, bool ELL> __device__ __attribute__((noinline)) void fwd_constraint_pgs_ldsB(CModel m, CLayout L, CState s, const Env &e)
+{
+	fwd_constraint_pgs<G, ELL, false>(m, L, s, e);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -66,15 +66,14 @@ DEVI void qmul(double *r, const double *a, const double *b)
 	r[0] = t0; r[1] = t1; r[2] = t2; r[3] = t3;
 }
 DEVI bool quat_is_identity(const double *q) { return q[0] == 1 && q[1] == 0 && q[2] == 0 && q[3] == 0; }
+// (mju_quat2Mat has a shortcut for the exact identity quaternion; the formula below yields exactly I for (1, 0, 0, 0), so the
+//  branch is dropped: with it the compiler merged the two results through a scratch slot -- a scratch round trip per body in
+//  the kinematics chain and the only recurring scratch traffic of the kernels)
 DEVI void quat2mat(double *r, const double *q)
 {
-	if (quat_is_identity(q)) {
-		r[0] = 1; r[1] = 0; r[2] = 0; r[3] = 0; r[4] = 1; r[5] = 0; r[6] = 0; r[7] = 0; r[8] = 1;
-		return;
-	}
-	double q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
-	double q11 = q[1] * q[1], q12 = q[1] * q[2], q13 = q[1] * q[3];
-	double q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
+	const double q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
+	const double q11 = q[1] * q[1], q12 = q[1] * q[2], q13 = q[1] * q[3];
+	const double q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
 	r[0] = q00 + q11 - q22 - q33;
 	r[4] = q00 - q11 + q22 - q33;
 	r[8] = q00 - q11 - q22 + q33;

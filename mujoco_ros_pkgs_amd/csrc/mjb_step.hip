@@ -1700,8 +1700,9 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 		VIEW(P, compact, make_constraint<G>(m, L, s, e));
 		PROF(17);
 		if constexpr (CON == 1 || CON == 5) {
-			if (P->m.nv <= 16) VIEW(P, compact, project_constraint_dense16<G>(m, L, e));
-			else VIEW(P, compact, project_constraint<G>(m, L, e));
+			// (plain PGS, nv <= 16: the rows of B = J M^-1 are solved for inside the PGS stage, in registers)
+			if (P->m.nv > 16) VIEW(P, compact, project_constraint<G>(m, L, e));
+			else if constexpr (CON == 5) VIEW(P, compact, project_constraint_dense16<G>(m, L, e));
 		}
 		PROF(18);
 	}
@@ -1733,7 +1734,12 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 	} else if constexpr (CON >= 6 && CON <= 8 && G == 64) {
 		VIEW(P, compact, fwd_constraint_newton<G, (CON == 6 ? 1 : (CON == 7 ? 2 : 4)), true>(m, L, e));
 	} else if constexpr ((CON == 1 || CON == 5) && G == 64) {
-		VIEW(P, compact, fwd_constraint_pgs<G, (CON == 5)>(m, L, e));
+		if constexpr (CON == 5) {  // elliptic cone blocks: rows of B in LDS (the block code leaves no registers for them)
+			VIEW(P, compact, fwd_constraint_pgs<G, true, false>(m, L, s, e));
+		} else {
+			if (P->m.nv <= 16) VIEW(P, compact, fwd_constraint_pgs<G, false, true>(m, L, s, e));
+			else VIEW(P, compact, fwd_constraint_pgs_ldsB<G, false>(m, L, s, e));
+		}
 	} else {
 		VIEW(P, compact, fwd_constraint<G>(m, L, e));
 	}
@@ -2158,6 +2164,9 @@ int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, in
 {
 	// (the headline kernels are instantiated first so that they sit at the start of the code object whatever happens to the
 	//  size of the constrained ones: their absolute placement is worth ~2 % on config 2)
+#ifdef MJB_DEV_ONLY_CON  // development switch: compile ONE constrained kernel variant (seconds instead of minutes)
+	return launch_g<64, MJB_DEV_ONLY_CON>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+#else
 	if (!constrained) {
 		switch (lanes_per_env) {
 		case 16:
@@ -2180,6 +2189,7 @@ int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, in
 	if (constrained == 7) return launch_g<64, 7>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 	if (constrained == 8) return launch_g<64, 8>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 	return launch_g<64, 1>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+#endif
 }
 
 int mjb_launch_reset(const KernelParams *Pdev, int nenv, const unsigned char *mask_dev, void *stream)
