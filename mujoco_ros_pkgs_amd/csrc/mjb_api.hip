@@ -262,6 +262,8 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		int a = d.ncollpair, b = d.neq + d.nv + d.njnt + 2 * d.ntendon + d.nconmax;
 		ioff += a > b ? a : b;
 	}
+	L.dadr = ioff;
+	ioff += (d.nefcmax > 0 && d.nv <= 16) ? 64 : 0;
 	L.nint = (ioff + 1) & ~1;
 	L.nstate = nstate;
 }

@@ -400,25 +400,34 @@ DEVI int narrowphase(int t1, int t2, const double *pos1, const double *mat1, con
 		} else if (t2 == MJB_GEOM_BOX) {
 			const double dif[3] = { pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2] };
 			const double dist = dot3(dif, nrm);
+			// corners in mjc_PlaneBox's order (bit k of i: sign of axis k); the first four that qualify become contacts
+			unsigned int okmask = 0;
+#pragma unroll
 			for (int i = 0; i < 8; i++) {
-				if (n >= 4) break;
 				const double vec[3] = { (i & 1) ? size2[0] : -size2[0], (i & 2) ? size2[1] : -size2[1],
 					                    (i & 4) ? size2[2] : -size2[2] };
 				double corner[3];
 				matvec3(corner, mat2, vec);
 				const double ldist = dot3(nrm, corner);
-				if (dist + ldist > margin || ldist > 0) continue;
-				RawCon c;
-				c.dist = dist + ldist;
-				c.frame[0] = nrm[0]; c.frame[1] = nrm[1]; c.frame[2] = nrm[2];
-				c.frame[3] = c.frame[4] = c.frame[5] = 0;
-				for (int k = 0; k < 3; k++) c.pos[k] = corner[k] + pos2[k] - nrm[k] * c.dist * 0.5;
-				// (n is lane-varying: select the slot without dynamic register indexing)
-				if (n == 0) rc[0] = c;
-				else if (n == 1) rc[1] = c;
-				else if (n == 2) rc[2] = c;
-				else rc[3] = c;
-				n++;
+				if (!(dist + ldist > margin || ldist > 0)) okmask |= 1u << i;
+			}
+#pragma unroll
+			for (int slot = 0; slot < 4; slot++) {
+				if (okmask) {
+					const int i = __builtin_ctz(okmask);
+					okmask &= okmask - 1;
+					const double vec[3] = { (i & 1) ? size2[0] : -size2[0], (i & 2) ? size2[1] : -size2[1],
+						                    (i & 4) ? size2[2] : -size2[2] };
+					double corner[3];
+					matvec3(corner, mat2, vec);
+					const double ldist = dot3(nrm, corner);
+					RawCon &c = rc[slot];
+					c.dist = dist + ldist;
+					c.frame[0] = nrm[0]; c.frame[1] = nrm[1]; c.frame[2] = nrm[2];
+					c.frame[3] = c.frame[4] = c.frame[5] = 0;
+					for (int k = 0; k < 3; k++) c.pos[k] = corner[k] + pos2[k] - nrm[k] * c.dist * 0.5;
+					n = slot + 1;
+				}
 			}
 		}
 	} else if (t1 == MJB_GEOM_SPHERE) {
@@ -555,21 +564,9 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 				const double nrm[3] = { mat1[2], mat1[5], mat1[8] };
 				cull = dot3(dv, nrm) > margin + rb2;
 			}
-			if (!cull) {
-				const int nr = narrowphase(t1, t2, pos1, mat1, size1, pos2, mat2, size2, margin, rc);
-				// keep contacts with dist < margin, preserving order
-				RawCon keep[4];
-				for (int i = 0; i < 4; i++) {
-					if (i < nr && rc[i].dist < margin) {
-						if (n == 0) keep[0] = rc[i];
-						else if (n == 1) keep[1] = rc[i];
-						else if (n == 2) keep[2] = rc[i];
-						else keep[3] = rc[i];
-						n++;
-					}
-				}
-				for (int i = 0; i < 4; i++) rc[i] = keep[i];
-			}
+			// (every narrow-phase routine returns only contacts with dist <= margin, and mj_collideGeoms adds what its
+			//  collision function returns: no second distance filter)
+			if (!cull) n = narrowphase(t1, t2, pos1, mat1, size1, pos2, mat2, size2, margin, rc);
 		}
 #ifdef MJB_PROFILE_SUB
 		EPROF(24);
@@ -1705,6 +1702,9 @@ template <int G, bool ELL, bool REGB> STAGE void fwd_constraint_pgs(CModel m, CL
 		gsync<G>();
 		return;
 	}
+#ifdef MJB_PROFILE_SUB
+	EPROF_BEGIN();
+#endif
 	// Row r lives in lane r together with ITS ROW OF AR = J M^-1 J' + diag(R) in registers (64 doubles): a
 	// Gauss-Seidel update of row i is then "every lane proposes the update of its own row from its running residual,
 	// lane i's proposal is broadcast with v_readlane, every lane does res += AR[.][i] * delta" -- no reduction and no
@@ -1823,27 +1823,29 @@ template <int G, bool ELL, bool REGB> STAGE void fwd_constraint_pgs(CModel m, CL
 	double AR[64];
 #pragma unroll
 	for (int i = 0; i < 64; i++) AR[i] = 0;
-	if constexpr (REGB) {
-		// AR_ri = B_r . J_i (AR is symmetric): B_r from the registers, J_i[k] one LDS broadcast per (i, k)
-#pragma unroll
-		for (int k = 0; k < 16; k++) {
-			if (k < nv) {
-				MJB_KEEP_BRANCH();
-				const double xk = x[k];
-				const double *Jk = f + L.efc_J + k;
-#pragma unroll
-				for (int i = 0; i < 64; i += 4) {
-					if (i < nefc) {
-						MJB_KEEP_BRANCH();
-						AR[i] += xk * Jk[i * nv];
-						AR[i + 1] += xk * Jk[(i + 1) * nv];
-						AR[i + 2] += xk * Jk[(i + 2) * nv];
-						AR[i + 3] += xk * Jk[(i + 3) * nv];
-					}
-				}
-#ifdef MJB_EXP_ARFENCE
-				asm volatile("" ::: "memory");  // (the loads of one k in flight together, not those of several k)
+#ifdef MJB_PROFILE_SUB
+	EPROF(19);
 #endif
+	if constexpr (REGB) {
+		// AR_ri = B_r . J_i (AR is symmetric): B_r from the registers, row J_i as 16 LDS broadcasts at immediate offsets from
+		// one address; four rows per wave-uniform guard
+#pragma unroll
+		for (int i = 0; i < 64; i += 4) {
+			if (i < nefc) {
+				MJB_KEEP_BRANCH();
+				const double *J0 = f + L.efc_J + i * nv;
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					const double *Ji = J0 + q * nv;
+					double acc0 = 0, acc1 = 0;
+#pragma unroll
+					for (int k = 0; k < 16; k += 2) {  // (the select keeps whatever lies behind a short row -- possibly NaN bits -- out of the sum)
+						const double j0 = Ji[k], j1 = Ji[k + 1];
+						acc0 += x[k] * (k < nv ? j0 : 0.0);
+						acc1 += x[k + 1] * (k + 1 < nv ? j1 : 0.0);
+					}
+					AR[i + q] = acc0 + acc1;
+				}
 			}
 		}
 	} else {
@@ -1870,6 +1872,9 @@ template <int G, bool ELL, bool REGB> STAGE void fwd_constraint_pgs(CModel m, CL
 			if (ell && i >= ri0 && i < ri0 + rdim) Hc[36 * rcon + 6 * (r - ri0) + (i - ri0)] = AR[i];
 		gsync<G>();
 	}
+#ifdef MJB_PROFILE_SUB
+	EPROF(30);
+#endif
 	// residual of the warmstart forces, res = b + AR f, and their cost 0.5 f'ARf + f'b = sum_i 0.5 f_i (res_i + b_i)
 	double res = b;
 #pragma unroll
@@ -1913,41 +1918,46 @@ template <int G, bool ELL, bool REGB> STAGE void fwd_constraint_pgs(CModel m, CL
 	if (lane == 0) fi[L.solver_iter] = iter;
 	if (rowact) f[L.efc_force + r] = frc;
 	gsync<G>();
+#ifdef MJB_PROFILE_SUB
+	EPROF(31);
+	if (e.env == 0 && lane == 0) { mjb_prof_lds[21] += (unsigned long long)iter; mjb_prof_lds[32 + 21] += 1; mjb_prof_lds[22] += (unsigned long long)nefc; mjb_prof_lds[32 + 22] += 1; }
+#endif
 	// qfrc_constraint = J' f,  qacc = qacc_smooth + M^-1 J' f = qacc_smooth + B' f
-	double wk = 0;
-	if constexpr (REGB) {  // B' f: element k = sum over the lanes of B_r[k] f_r
-		// (B_r is solved for a second time instead of being kept alive through the sweeps: the AR row already fills the lane's
-		//  registers there, and the substitution is ~1.5 k cycles against thousands per sweep)
-		asm volatile("" ::: "memory");
-#pragma unroll
-		for (int k = 0; k < 16; k++) {
-			const double v = Jr[k < nv ? k : 0];
-			x[k] = (k < nv && rowact) ? v : 0.0;
-		}
-		tri_solve(x, f + L.tri, f + L.qLDiagInv, nv);
-#pragma unroll
-		for (int k = 0; k < 16; k++) {
-			if (k < nv) {
-				MJB_KEEP_BRANCH();
-				const double t = wave_sum(rowact ? x[k] * frc : 0.0);
-				if (lane == k) wk = t;
-			}
-		}
-	}
 	if (lane < nv) {
-		double s = 0, w = 0;
+		double sj = 0, w = 0;
 		for (int i = 0; i < nefc; i++) {
 			const double fr = f[L.efc_force + i];
-			s += f[L.efc_J + i * nv + lane] * fr;
+			sj += f[L.efc_J + i * nv + lane] * fr;
 			if constexpr (!REGB) w += f[L.efc_B + i * nv + lane] * fr;
 		}
-		if constexpr (REGB) w = wk;
-		f[L.qfrc_constraint + lane] = s;
-		const double a = f[L.qacc_smooth + lane] + w;
-		f[L.qacc + lane] = a;
-		f[L.qacc_warmstart + lane] = a;
+		f[L.qfrc_constraint + lane] = sj;
+		if constexpr (!REGB) {
+			const double a = f[L.qacc_smooth + lane] + w;
+			f[L.qacc + lane] = a;
+			f[L.qacc_warmstart + lane] = a;
+		}
 	}
 	gsync<G>();
+	if constexpr (REGB) {
+		// M^-1 (J' f) by the same dense substitution, the whole nv-vector in the registers of every lane (wave-uniform
+		// addresses: one LDS broadcast per entry; lane k keeps element k)
+		double w[16];
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			const double v = f[L.qfrc_constraint + (k < nv ? k : 0)];
+			w[k] = k < nv ? v : 0.0;
+		}
+		tri_solve(w, f + L.tri, f + L.qLDiagInv, nv);
+		double wk = 0;
+#pragma unroll
+		for (int k = 0; k < 16; k++) wk = lane == k ? w[k] : wk;
+		if (lane < nv) {
+			const double a = f[L.qacc_smooth + lane] + wk;
+			f[L.qacc + lane] = a;
+			f[L.qacc_warmstart + lane] = a;
+		}
+		gsync<G>();
+	}
 }
 
 // the LDS-B variants (nv > 16) stay out of line: models that small never pay their registers or instruction-cache lines

@@ -84,6 +84,7 @@ struct FrameLayout {
 	int kinloc;    // [7*nbody] kinematics: pose of each body in its parent frame (transient)
 	int crbbuf;    // [6*nv]    crb: crb[body(i)] * cdof_i (transient)
 	int eulerx;    // [nv]      Euler: velocity-update right-hand side / solution (transient)
+	int dadr;      // [64 ints] constrained kernels, nv <= 16: packed dense address map of lanes 0-15 (int frame)
 	int tri;       // [120]     PGS, nv <= 16: packed dense triangle of the L'DL factor (project_constraint_dense16; transient)
 	int ndouble;   // doubles per frame
 	int nint;      // ints per frame (follow the doubles)

@@ -297,7 +297,9 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 		gsync<G>();
 	}
 
+#ifndef MJB_PROFILE_SUB  // (slots 21 / 22 carry the PGS sweep / row counts in the sub-stage build)
 	PROF(21);
+#endif
 	// Phase C -- one body per lane: normalise xquat, final xmat, inertial frame
 	for (int b = lane; b < m.nbody; b += G) {
 		double q[4], M[9], p[3];
@@ -330,7 +332,9 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 	}
 	gsync<G>();
 
+#ifndef MJB_PROFILE_SUB
 	PROF(22);
+#endif
 	// Phase D -- joints (anchor / axis to the world frame through the PARENT body's frame), geoms, sites
 	const int nitem = m.njnt + m.ngeom + m.nsite;
 	for (int it = lane; it < nitem; it += G) {
@@ -819,6 +823,24 @@ STAGE void solve_dense16(CModel m, const Env &e, double *x, const double *LD, co
 	} else {
 		MJB_KEEP_BRANCH();
 		solve_dense16_impl<G, false, NVM>(m, e, x, LD, diaginv, x2, LD2, diaginv2, dadr, scr);
+	}
+}
+
+// Constrained kernels (G = 64) keep the dense address map of the register-resident factor / solve out of the registers:
+// lanes 0-15 park their 16 qM addresses (< 255; 255 = none) as 4 packed ints in the frame's int area once per env and
+// unpack them where a dense routine starts (4 LDS reads + 16 v_bfe) -- 16 kernel-lifetime VGPRs were the first thing the
+// allocator spilled to scratch under the solvers' register pressure (reloaded at every factor / solve).
+DEVI void dadr_load(const Env &e, CLayout L, int (&dl)[16])
+{
+	const int *src = e.fi + L.dadr + 4 * (e.lane & 15);
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		const unsigned int w = (unsigned int)src[q];
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int v = (int)((w >> (8 * r)) & 255u);
+			dl[4 * q + r] = (v == 255 || e.lane >= 16) ? -1 : v;
+		}
 	}
 }
 
@@ -1475,9 +1497,12 @@ template <int G, int DENSE> STAGE void fwd_acceleration(CModel m, CLayout L, con
 		solve_dense16<G, DENSE>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual, e.dadr,
 		                        f + L.crbbuf);
 	else if constexpr (DENSE < 0) {  // constrained kernel: a small system is solved by lanes 0-15 of the wavefront
-		if (m.nv <= 16)
-			solve_dense16<G, 16>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual, e.dadr,
+		if (m.nv <= 16) {
+			int dl[16];
+			dadr_load(e, L, dl);
+			solve_dense16<G, 16>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual, dl,
 			                     f + L.crbbuf);
+		}
 		else
 			solve2<G>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual);
 	} else
@@ -1519,8 +1544,12 @@ template <int G, bool CAN16> STAGE void euler(CModel m, CLayout L, const Env &e)
 		for (int d = e.lane; d < m.nv; d += G) x[d] = f[L.qfrc_smooth + d] + f[L.qfrc_constraint + d];
 		gsync<G>();
 		if constexpr (CAN16) {
-			if (m.nv <= 16) solve_dense16<G, 16>(m, e, x, f + L.qH, f + L.qHdi, x, f + L.qH, f + L.qHdi, false, e.dadr, f + L.crbbuf);
-			else solve<G>(m, e, x, f + L.qH, f + L.qHdi);
+			if (m.nv <= 16) {
+				int dl[16];
+				dadr_load(e, L, dl);
+				solve_dense16<G, 16>(m, e, x, f + L.qH, f + L.qHdi, x, f + L.qH, f + L.qHdi, false, dl, f + L.crbbuf);
+			} else
+				solve<G>(m, e, x, f + L.qH, f + L.qHdi);
 		} else
 			solve<G>(m, e, x, f + L.qH, f + L.qHdi);
 	} else {
@@ -1685,8 +1714,12 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 		                                   e.f + L.qHdi, m.eulerdamp != 0, e.dadr, e.f + L.crbbuf));
 	else if constexpr (CON != 0) {
 		if (P->m.nv <= 16)
-			VIEW(P, compact, factor_dense16<G, 16>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH,
-			                                       e.f + L.qHdi, m.eulerdamp != 0, e.dadr, e.f + L.crbbuf));
+			VIEW(P, compact, {
+				int dl[16];
+				dadr_load(e, L, dl);
+				factor_dense16<G, 16>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi,
+				                      m.eulerdamp != 0, dl, e.f + L.crbbuf);
+			});
 		else
 			VIEW(P, compact, factor2<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi,
 			                            m.eulerdamp != 0));
@@ -1978,11 +2011,8 @@ __global__ void __launch_bounds__(256, (CON ? 1 : (G == 64 ? 4 : (G == 32 ? 2 : 
 	if constexpr (DENSE) {
 #pragma unroll
 		for (int i = 0; i < 16; i++) e.dadr[i] = m.M_dense[16 * i + e.lane];
-	} else if constexpr (CON != 0) {
-		// constrained kernels (one env per wavefront): nv <= 16 runs the same register-resident factor / solve on lanes 0-15
-#pragma unroll
-		for (int i = 0; i < 16; i++) e.dadr[i] = (m.nv <= 16 && e.lane < 16) ? m.M_dense[16 * i + (e.lane & 15)] : -1;
 	}
+	// (constrained kernels: the map lives packed in the frame's int area, see dadr_load)
 	if constexpr (DENSE != 0) {  // (tried in the constrained kernels too: no gain, the PGS kernel loses 8 % to register pressure)
 		const int b = e.lane < m.nbody ? e.lane : 0;
 		LaneConst &c = e.lc;
@@ -2038,6 +2068,18 @@ __global__ void __launch_bounds__(256, (CON ? 1 : (G == 64 ? 4 : (G == 32 ? 2 : 
 				for (int k = e.lane; k < L.ndouble; k += G) e.f[k] = 0;
 			for (int k = e.lane; k < L.nint; k += G) e.fi[k] = 0;
 			gsync<G>();
+		}
+		if constexpr (CON != 0) {
+			if (m.nv <= 16 && e.lane < 16) {
+				for (int q = 0; q < 4; q++) {
+					unsigned int w = 0;
+					for (int r = 0; r < 4; r++) {
+						const int a = m.M_dense[16 * (4 * q + r) + e.lane];
+						w |= (unsigned int)(a < 0 ? 255 : a) << (8 * r);
+					}
+					e.fi[L.dadr + 4 * e.lane + q] = (int)w;
+				}
+			}
 		}
 		load_state<G>(m, L, s, e);
 		gsync<G>();

