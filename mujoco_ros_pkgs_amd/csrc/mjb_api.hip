@@ -260,6 +260,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	L.iscratch = ioff;
 	{
 		int a = d.ncollpair, b = d.neq + d.nv + d.njnt + 2 * d.ntendon + d.nconmax;
+		if (newton && d.nefcmax > a) a = d.nefcmax;  // (the primal solvers park one int of row metadata per constraint row here)
 		ioff += a > b ? a : b;
 	}
 	L.dadr = ioff;

@@ -2124,6 +2124,9 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e)
 		fl[i] = (rowact[i] && m.nfriction > 0) ? f[L.efc_frictionloss + r] : 0.0;
 		aref[i] = rowact[i] ? f[L.efc_aref + r] : 0.0;
 		cmu[i] = leader[i] ? f[L.contact_friction + 5 * rcon[i]] / sqrt(fmax(MJB_MINVAL, m.impratio[0])) : 1.0;
+		// what the Hessian build needs to know about the row, in ONE int (read by whichever lane feeds the row to the matrix
+		// cores): -1 = scalar row (weight hw[r]), else first row of its cone | dim << 8 | contact << 12
+		if (rowact[i]) fi[L.iscratch + r] = is_cone ? (fi[L.contact_efc_address + rcon[i]] | (cdim[i] << 8) | (rcon[i] << 12)) : -1;
 	}
 
 
@@ -2319,40 +2322,66 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e)
 		{
 			const int li = lane & 15, lk = lane >> 4;
 			const int ntile = (nv + 15) >> 4;
-			for (int ta = 0; ta < ntile; ta++)
-				for (int tb = 0; tb <= ta; tb++) {
-					mjb_d4 acc = { 0, 0, 0, 0 };
-					const int ca = 16 * ta + li, cb = 16 * tb + li;
-					const bool ina = ca < nv, inb = cb < nv;
-					for (int r0 = 0; r0 < nefc; r0 += 4) {
-						const int r = r0 + lk;
-						double av = 0, bv = 0;
-						if (r < nefc) {
-							const double *Jr = f + L.efc_J + r * nv;
-							if (inb) bv = Jr[cb];
-							if (ina) {
-								if (fi[L.efc_type + r] != MJB_CNSTR_CONTACT_ELLIPTIC) {
-									const double w = hw[r];
-									av = (w != 0) ? w * Jr[ca] : 0.0;
-								} else {
-									const int con = fi[L.efc_id + r], adr = fi[L.contact_efc_address + con];
-									const int dim = fi[L.contact_dim + con];
-									const double *hc = Hc + 36 * con + 6 * (r - adr);
-									for (int s2 = 0; s2 < dim; s2++) {
-										const double w = hc[s2];
-										if (w != 0) av += w * f[L.efc_J + (adr + s2) * nv + ca];
-									}
-								}
-							}
+			// One pass over the 4-row slabs per tile ROW ta: the weighted operand A = (W J)[slab][16 ta + .] is formed once and
+			// multiplied with the column blocks tb <= ta (one accumulator each); the next slab's operands are fetched before
+			// the current slab's MFMAs issue, so the dependent LDS reads (row metadata -> cone block / J) overlap them.
+			auto operands = [&](int r0, int ca, bool ina, double &av, double (&bv)[4], int ta) {
+				const int r = r0 + lk;
+				av = 0;
+#pragma unroll
+				for (int tb = 0; tb < 4; tb++) bv[tb] = 0;
+				if (r < nefc) {
+					const double *Jr = f + L.efc_J + r * nv;
+#pragma unroll
+					for (int tb = 0; tb < 4; tb++)
+						if (tb <= ta && 16 * tb + li < nv) bv[tb] = Jr[16 * tb + li];
+					if (ina) {
+						// branch-free: a scalar row is a 1 x 1 "block" whose weight sits in hw[r]; all loads of the slab leave
+						// together once the row's metadata int has arrived
+						const int meta = fi[L.iscratch + r];
+						const bool cone = meta >= 0;
+						const int adr = cone ? (meta & 255) : r, dim = cone ? ((meta >> 8) & 15) : 1, con = cone ? (meta >> 12) : 0;
+						const double *wp = cone ? Hc + 36 * con + 6 * (r - adr) : hw + r;
+						const double *Jc = f + L.efc_J + adr * nv + ca;
+						double wv[6], jv6[6];
+#pragma unroll
+						for (int s2 = 0; s2 < 6; s2++) {
+							const int sc = s2 < dim ? s2 : 0;
+							wv[s2] = wp[sc];
+							jv6[s2] = Jc[sc * nv];
 						}
-						acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+#pragma unroll
+						for (int s2 = 0; s2 < 6; s2++) av += s2 < dim ? wv[s2] * jv6[s2] : 0.0;
 					}
+				}
+			};
+			for (int ta = 0; ta < ntile; ta++) {
+				mjb_d4 acc[4];
+#pragma unroll
+				for (int tb = 0; tb < 4; tb++) acc[tb] = mjb_d4{ 0, 0, 0, 0 };
+				const int ca = 16 * ta + li;
+				const bool ina = ca < nv;
+				double av, bv[4], an, bn[4];
+				operands(0, ca, ina, av, bv, ta);
+				for (int r0 = 0; r0 < nefc; r0 += 4) {
+					if (r0 + 4 < nefc) operands(r0 + 4, ca, ina, an, bn, ta);
+#pragma unroll
+					for (int tb = 0; tb < 4; tb++)
+						if (tb <= ta) acc[tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[tb], acc[tb], 0, 0, 0);
+					av = an;
+#pragma unroll
+					for (int tb = 0; tb < 4; tb++) bv[tb] = bn[tb];
+				}
+#pragma unroll
+				for (int tb = 0; tb < 4; tb++) {
+					if (tb > ta) continue;
 #pragma unroll
 					for (int q = 0; q < 4; q++) {
 						const int row = 16 * ta + lk + 4 * q, col = 16 * tb + li;
-						if (row < nv && col < nv) H[row * nv + col] = Md[row * nv + col] + acc[q];
+						if (row < nv && col < nv) H[row * nv + col] = Md[row * nv + col] + acc[tb][q];
 					}
 				}
+			}
 		}
 		gsync<G>();
 		EPROF(27);
