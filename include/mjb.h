@@ -166,6 +166,15 @@ int mjb_reset(mjb_batch *b, const uint8_t *mask);
 int mjb_get(mjb_batch *b, int field, int env_lo, int env_hi, double *host);
 int mjb_set(mjb_batch *b, int field, int env_lo, int env_hi, const double *host);
 int mjb_get_int(mjb_batch *b, int field, int env_lo, int env_hi, int *host);
+/* The same for several double fields at once: every copy is enqueued asynchronously on the batch's stream and the call
+ * synchronises ONCE (mjb_get_many) or not at all (mjb_set_many: ordered before the next launch).  This is what the host
+ * runtime moves around a plugin callback round -- the mjData view fields of SURVEY.md 8a row T1 -- instead of one blocking
+ * copy per field.  host[k] has the layout mjb_get / mjb_set use for fields[k].  Page-locking the host buffers
+ * (mjb_host_register) makes the copies true DMA transfers. */
+int mjb_get_many(mjb_batch *b, int n, const int *fields, int env_lo, int env_hi, double *const *host);
+int mjb_set_many(mjb_batch *b, int n, const int *fields, int env_lo, int env_hi, const double *const *host);
+int mjb_host_register(void *host, unsigned long long bytes);   /* hipHostRegister; 0 on success */
+int mjb_host_unregister(void *host);
 
 /* Raw HBM pointer of a state field's env-major array [nenv][field_size] (for RCCL gathers and
  * zero-copy tensor wrappers).  NULL for derived fields. */

@@ -34,6 +34,13 @@ typedef struct mjr_backend {
 	int (*synchronize)(void *self);
 	const char *(*last_error)(void *self);
 	void (*destroy)(void *self);
+	/* optional (NULL: the runtime falls back to one get / set per field): several fields per call, one synchronisation;
+	 * page-locking of the runtime's host mirrors */
+	int (*get_many)(void *self, int n, const int *fields, int env_lo, int env_hi, double *const *host);
+	int (*set_many)(void *self, int n, const int *fields, int env_lo, int env_hi, const double *const *host);
+	int (*host_register)(void *self, void *host, unsigned long long bytes);
+	int (*host_unregister)(void *self, void *host);
+	int (*step_async)(void *self, int nsteps); /* enqueue nsteps fused steps without waiting for them */
 } mjr_backend;
 
 /* creates a backend for (model, nenv, device); NULL on failure */

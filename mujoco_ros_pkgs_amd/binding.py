@@ -167,6 +167,10 @@ def load_library(path=None):
         "mjb_get": (ci, [vp, ci, ci, ci, C.POINTER(cd)]),
         "mjb_set": (ci, [vp, ci, ci, ci, C.POINTER(cd)]),
         "mjb_get_int": (ci, [vp, ci, ci, ci, C.POINTER(ci)]),
+        "mjb_get_many": (ci, [vp, ci, C.POINTER(ci), ci, ci, C.POINTER(C.POINTER(cd))]),
+        "mjb_set_many": (ci, [vp, ci, C.POINTER(ci), ci, ci, C.POINTER(C.POINTER(cd))]),
+        "mjb_host_register": (ci, [vp, C.c_ulonglong]),
+        "mjb_host_unregister": (ci, [vp]),
         "mjb_device_ptr": (vp, [vp, ci]),
         "mjb_set_ctrl_noise": (ci, [vp, cd, cd, C.c_uint64, C.c_int64]),
         "mjb_get_stream": (vp, [vp]),

@@ -1251,6 +1251,81 @@ int mjb_set(mjb_batch *b, int field, int env_lo, int env_hi, const double *host)
 	return MJB_OK;
 }
 
+int mjb_get_many(mjb_batch *b, int n, const int *fields, int env_lo, int env_hi, double *const *host)
+{
+	if (!b || n < 0 || (n && (!fields || !host))) return fail(MJB_EINVAL, "mjb_get_many: bad argument");
+	HIP_TRY(hipSetDevice(b->device));
+	for (int k = 0; k < n; k++) {
+		const int field = fields[k];
+		int rc = check_range(b, field, env_lo, env_hi);
+		if (rc) return rc;
+		if (kFields[field].kind == 3) return fail(MJB_EINVAL, "field %s is an int field; use mjb_get_int", kFields[field].name);
+		const int sz = b->model->field_size[field];
+		if (sz == 0 || env_lo == env_hi) continue;
+		if (!host[k]) return fail(MJB_EINVAL, "null host buffer");
+		if (kFields[field].kind == 0) {
+			HIP_TRY(hipMemcpyAsync(host[k], state_ptr(b, field) + (size_t)env_lo * sz, (size_t)(env_hi - env_lo) * sz * sizeof(double),
+			                       hipMemcpyDeviceToHost, b->stream));
+		} else {
+			if (!b->frame_valid || !b->st.frame_ws)
+				return fail(MJB_EINVAL, "derived field %s is only readable after mjb_forward / mjb_step1 / mjb_step2", kFields[field].name);
+			HIP_TRY(hipMemcpy2DAsync(host[k], (size_t)sz * sizeof(double),
+			                         b->st.frame_ws + (size_t)env_lo * b->st.frame_stride + frame_offset(b, field),
+			                         (size_t)b->st.frame_stride * sizeof(double), (size_t)sz * sizeof(double), (size_t)(env_hi - env_lo),
+			                         hipMemcpyDeviceToHost, b->stream));
+		}
+	}
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	return MJB_OK;
+}
+
+int mjb_set_many(mjb_batch *b, int n, const int *fields, int env_lo, int env_hi, const double *const *host)
+{
+	if (!b || n < 0 || (n && (!fields || !host))) return fail(MJB_EINVAL, "mjb_set_many: bad argument");
+	HIP_TRY(hipSetDevice(b->device));
+	for (int k = 0; k < n; k++) {
+		const int field = fields[k];
+		int rc = check_range(b, field, env_lo, env_hi);
+		if (rc) return rc;
+		const int sz = b->model->field_size[field];
+		if (sz == 0 || env_lo == env_hi) continue;
+		if (!host[k]) return fail(MJB_EINVAL, "null host buffer");
+		if (kFields[field].kind == 0) {
+			HIP_TRY(hipMemcpyAsync(state_ptr(b, field) + (size_t)env_lo * sz, host[k], (size_t)(env_hi - env_lo) * sz * sizeof(double),
+			                       hipMemcpyHostToDevice, b->stream));
+			if (field == MJB_F_xfrc_applied && !b->st.use_xfrc) {
+				b->st.use_xfrc = 1;
+				b->params_dirty = true;
+			}
+		} else {
+			if (field != MJB_F_qfrc_passive)
+				return fail(MJB_EINVAL, "field %s is derived and cannot be set (only state fields and qfrc_passive can)", kFields[field].name);
+			if (!b->frame_valid || !b->st.frame_ws) return fail(MJB_EINVAL, "qfrc_passive can only be modified between mjb_step1 and mjb_step2");
+			HIP_TRY(hipMemcpy2DAsync(b->st.frame_ws + (size_t)env_lo * b->st.frame_stride + frame_offset(b, field),
+			                         (size_t)b->st.frame_stride * sizeof(double), host[k], (size_t)sz * sizeof(double),
+			                         (size_t)sz * sizeof(double), (size_t)(env_hi - env_lo), hipMemcpyHostToDevice, b->stream));
+		}
+	}
+	return MJB_OK;
+}
+
+int mjb_host_register(void *host, unsigned long long bytes)
+{
+	if (!host || !bytes) return fail(MJB_EINVAL, "mjb_host_register: bad argument");
+	if (hipHostRegister(host, (size_t)bytes, hipHostRegisterDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		return fail(MJB_ENODEVICE, "hipHostRegister failed");
+	}
+	return MJB_OK;
+}
+
+int mjb_host_unregister(void *host)
+{
+	if (!host) return MJB_OK;
+	if (hipHostUnregister(host) != hipSuccess) (void)hipGetLastError();
+	return MJB_OK;
+}
+
 void *mjb_device_ptr(mjb_batch *b, int field)
 {
 	if (!b || field < 0 || field >= MJB_F_COUNT || kFields[field].kind != 0) {

@@ -29,6 +29,11 @@ int be_get(void *s, int f, int lo, int hi, double *h) { return mjb_get(B(s)->bat
 int be_set(void *s, int f, int lo, int hi, const double *h) { return mjb_set(B(s)->batch, f, lo, hi, h); }
 int be_noise(void *s, double a, double b, uint64_t seed, int64_t off) { return mjb_set_ctrl_noise(B(s)->batch, a, b, seed, off); }
 int be_sync(void *s) { return mjb_synchronize(B(s)->batch); }
+int be_get_many(void *s, int n, const int *f, int lo, int hi, double *const *h) { return mjb_get_many(B(s)->batch, n, f, lo, hi, h); }
+int be_set_many(void *s, int n, const int *f, int lo, int hi, const double *const *h) { return mjb_set_many(B(s)->batch, n, f, lo, hi, h); }
+int be_host_register(void *, void *h, unsigned long long bytes) { return mjb_host_register(h, bytes); }
+int be_host_unregister(void *, void *h) { return mjb_host_unregister(h); }
+int be_step_async(void *s, int n) { return mjb_step(B(s)->batch, n); }
 const char *be_err(void *) { return mjb_last_error(); }
 void be_destroy(void *s)
 {
@@ -64,7 +69,8 @@ mjr_backend *mjr_make_mjb_backend(const mjb_model_desc *desc, int nenv, int devi
 		return nullptr;
 	}
 	b->vt = mjr_backend{ b, be_nenv, be_field_size, be_step, be_step1, be_step2, be_forward, be_reset, be_get, be_set,
-		                 be_noise, be_sync, be_err, be_destroy };
+		                 be_noise, be_sync, be_err, be_destroy, be_get_many, be_set_many, be_host_register, be_host_unregister,
+		                 be_step_async };
 	return &b->vt;
 }
 

@@ -3,6 +3,8 @@
 // The physics itself is NOT here: every step goes through the mjr_backend vtable (libmjb on the GPU).
 #include "mujoco_env.h"
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstring>
 #include <sstream>
@@ -60,6 +62,7 @@ MujocoEnv::~MujocoEnv()
 	shutdown();
 	cb_ready_plugins_.clear();
 	plugins_.clear();
+	unpinMirrors();
 	if (backend_) backend_->destroy(backend_->self);
 	if (backend_new_) backend_new_->destroy(backend_new_->self);
 }
@@ -177,8 +180,16 @@ void MujocoEnv::prepareReload()
 }
 
 // mujoco_env.cpp:745-769
+void MujocoEnv::unpinMirrors()
+{
+	if (backend_ && backend_->host_unregister)
+		for (void *p : pinned_) backend_->host_unregister(backend_->self, p);
+	pinned_.clear();
+}
+
 void MujocoEnv::loadWithModelAndData()
 {
+	unpinMirrors();  // (the mirrors are reallocated below; their page locks go with the backend that made them)
 	if (backend_) backend_->destroy(backend_->self);
 	backend_ = backend_new_;
 	backend_new_ = nullptr;
@@ -226,6 +237,11 @@ void MujocoEnv::loadWithModelAndData()
 	auto alloc = [&](int f) { host_fields_[f].assign((size_t)nenv_ * std::max(1, backend_->field_size(backend_->self, f)), 0.0); };
 	for (int f : kStateFields) alloc(f);
 	for (int f : kDerivedFields) alloc(f);
+	// page-locked mirrors: the per-step copies around a callback round become DMA transfers (no staging, truly asynchronous)
+	if (backend_->host_register)
+		for (auto &v : host_fields_)
+			if (!v.empty() && backend_->host_register(backend_->self, v.data(), (unsigned long long)v.size() * sizeof(double)) == 0)
+				pinned_.push_back(v.data());
 	views_.assign(nenv_, mjData());
 	for (int e = 0; e < nenv_; e++) bindView(e, views_[e]);
 
@@ -270,26 +286,52 @@ void MujocoEnv::loadPlugins()
 	if (!plugins_.empty()) pullViews(0, 1, false);
 	for (const auto &plugin : plugins_)
 		if (plugin->safe_load(&model_, &views_[0])) cb_ready_plugins_.emplace_back(plugin.get());
+	// what the callback-ready plugins declared: which callbacks exist, which view fields they read
+	cb_mask_ = 0;
+	cb_all_fields_ = false;
+	cb_fields_.clear();
+	for (const auto *plugin : cb_ready_plugins_) {
+		cb_mask_ |= plugin->callbackMask();
+		std::vector<int> fl;
+		if (!plugin->viewFields(fl)) cb_all_fields_ = true;
+		for (int f : fl)
+			if (std::find(cb_fields_.begin(), cb_fields_.end(), f) == cb_fields_.end()) cb_fields_.push_back(f);
+	}
+	if (std::find(cb_fields_.begin(), cb_fields_.end(), (int)MJB_F_time) == cb_fields_.end()) cb_fields_.push_back(MJB_F_time);
 }
 
 // ------------------------------------------------------------------------------------ host <-> device views
+void MujocoEnv::pullFields(const int *fields, int n, int lo, int hi)
+{
+	std::vector<int> fl;
+	std::vector<double *> ptr;
+	for (int k = 0; k < n; k++) {
+		const int f = fields[k], sz = backend_->field_size(backend_->self, f);
+		if (sz <= 0) continue;
+		fl.push_back(f);
+		ptr.push_back(host_fields_[f].data() + (size_t)lo * sz);
+	}
+	if (backend_->get_many) {
+		backend_->get_many(backend_->self, (int)fl.size(), fl.data(), lo, hi, ptr.data());  // async copies, ONE synchronisation
+	} else {
+		for (size_t k = 0; k < fl.size(); k++) backend_->get(backend_->self, fl[k], lo, hi, ptr[k]);
+	}
+	for (int e = lo; e < hi; e++) views_[e].time = host_fields_[MJB_F_time][e];
+}
+
 void MujocoEnv::pullViews(int lo, int hi, bool derived)
 {
 	if (!backend_ || hi <= lo) return;
-	auto pull = [&](int f) {
-		const int n = backend_->field_size(backend_->self, f);
-		if (n <= 0) return;
-		backend_->get(backend_->self, f, lo, hi, host_fields_[f].data() + (size_t)lo * n);
-	};
-	for (int f : kStateFields) pull(f);
-	if (derived)
-		for (int f : kDerivedFields) pull(f);
-	for (int e = lo; e < hi; e++) views_[e].time = host_fields_[MJB_F_time][e];
+	std::vector<int> fl(std::begin(kStateFields), std::end(kStateFields));
+	if (derived) fl.insert(fl.end(), std::begin(kDerivedFields), std::end(kDerivedFields));
+	pullFields(fl.data(), (int)fl.size(), lo, hi);
 }
 
 void MujocoEnv::pushViews(int lo, int hi)
 {
 	if (!backend_ || hi <= lo) return;
+	std::vector<int> fl;
+	std::vector<const double *> ptr;
 	for (int f : kWritableFields) {
 		const int n = backend_->field_size(backend_->self, f);
 		if (n <= 0) continue;
@@ -300,7 +342,13 @@ void MujocoEnv::pushViews(int lo, int hi)
 			if (!any && !xfrc_used_) continue;
 			xfrc_used_ = true;
 		}
-		backend_->set(backend_->self, f, lo, hi, host_fields_[f].data() + (size_t)lo * n);
+		fl.push_back(f);
+		ptr.push_back(host_fields_[f].data() + (size_t)lo * n);
+	}
+	if (backend_->set_many) {
+		backend_->set_many(backend_->self, (int)fl.size(), fl.data(), lo, hi, ptr.data());
+	} else {
+		for (size_t k = 0; k < fl.size(); k++) backend_->set(backend_->self, fl[k], lo, hi, ptr[k]);
 	}
 }
 
@@ -366,6 +414,33 @@ int MujocoEnv::stepBurst(int n, bool count_requests)
 		step_count_ += (unsigned long long)n;
 		if (count_requests) settings_.env_steps_request.fetch_sub(n);
 		if (num_steps_until_exit_ > 0) num_steps_until_exit_ = std::max(0, num_steps_until_exit_ - n);
+		return done;
+	}
+	if (!(cb_mask_ & (MujocoPlugin::CB_CONTROL | MujocoPlugin::CB_PASSIVE))) {
+		// Only end-of-step observers (lastStageCallback / renderCallback, e.g. the sensors plugin): nothing can change the
+		// step from the host, so every step is ONE fused launch (no split, no frame workspace) followed by one batched copy
+		// of the fields the plugins read -- the state fields, or exactly the ones they named.
+		const std::vector<int> all(std::begin(kStateFields), std::end(kStateFields));
+		const std::vector<int> &fl = cb_all_fields_ ? all : cb_fields_;
+		for (int s = 0; s < n; s++) {
+			const double t_before = views_[0].time;
+			if ((backend_->step_async ? backend_->step_async(backend_->self, 1) : backend_->step(backend_->self, 1)) != 0) break;
+			pullFields(fl.data(), (int)fl.size(), 0, ncb);
+			publishSimTime(views_[0].time);
+			for (int e = 0; e < ncb; e++) {
+				cb_view_ = &views_[e];
+				runLastStageCbs();
+				if (settings_.render_offscreen) runRenderCbs(&scn_);
+			}
+			cb_view_ = &views_[0];
+			done++;
+			step_count_ += 1;
+			if (count_requests) settings_.env_steps_request.fetch_sub(1);
+			if (num_steps_until_exit_ > 0) num_steps_until_exit_--;
+			if (views_[0].time < t_before) break;  // "Break if reset"
+			if (count_requests && settings_.env_steps_request.load() <= 0) break;
+			if (settings_.exit_request.load() || num_steps_until_exit_ == 0) break;
+		}
 		return done;
 	}
 	for (int s = 0; s < n; s++) {

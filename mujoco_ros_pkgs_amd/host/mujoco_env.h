@@ -150,6 +150,8 @@ protected:
 	// (mj_step, publishSimTime, runLastStageCbs, render hand-off, counters); returns steps done
 	int stepBurst(int n, bool count_requests);
 	void pullViews(int lo, int hi, bool derived);
+	void pullFields(const int *fields, int n, int lo, int hi);
+	void unpinMirrors();
 	void pushViews(int lo, int hi);
 	void bindView(int env, mjData &d);
 
@@ -178,6 +180,11 @@ protected:
 	int cb_envs_ = -1;
 	mjData *cb_view_ = nullptr;  // env instance the running callback round is for
 	bool xfrc_used_ = false;
+	// what the callback-ready plugins declared (MujocoPlugin::callbackMask / viewFields), resolved in loadPlugins()
+	unsigned cb_mask_ = 0;
+	bool cb_all_fields_ = true;
+	std::vector<int> cb_fields_;       // state fields to mirror after a step when cb_all_fields_ is false
+	std::vector<void *> pinned_;       // host mirrors page-locked through the backend
 	std::vector<double> init_qpos_, init_qvel_, init_qfrc_;
 
 	int num_steps_until_exit_ = -1;

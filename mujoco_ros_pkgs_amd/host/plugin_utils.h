@@ -116,6 +116,16 @@ public:
 	// A geom was changed in the model (plugin_utils.h:135)
 	virtual void onGeomChanged(const mjModel * /*model*/, mjData * /*data*/, const int /*geom_id*/) {}
 
+	// ---- batched-runtime extension (no counterpart in the reference, whose mjData lives in host memory) ----
+	// Which callbacks the plugin overrides, and which mjData fields it reads there.  The defaults -- everything -- keep the
+	// reference's behaviour for a plugin that says nothing: every step is split at the control-callback point and the
+	// whole T1 view is mirrored.  A plugin that only observes the end of a step (MujocoRosSensorsPlugin) lets the runtime
+	// keep fused launches and move only the fields it names.
+	enum : unsigned { CB_CONTROL = 1u, CB_PASSIVE = 2u, CB_RENDER = 4u, CB_LASTSTAGE = 8u, CB_ALL = 15u };
+	virtual unsigned callbackMask() const { return CB_ALL; }
+	// mjb_field ids the plugin reads through mjData in its callbacks; false = "any field of the view"
+	virtual bool viewFields(std::vector<int> & /*fields*/) const { return false; }
+
 protected:
 	virtual bool load(const mjModel *m, mjData *d) = 0;  // plugin_utils.h:146
 	virtual void reset() = 0;                            // plugin_utils.h:151

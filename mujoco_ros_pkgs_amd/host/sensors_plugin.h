@@ -39,6 +39,13 @@ public:
 	bool load(const mjModel *m, mjData *d) override;
 	void reset() override {}
 	void lastStageCallback(const mjModel *model, mjData *data) override;
+	// the plugin observes the end of a step and reads sensordata + time only (lastStageCallback, :175-437)
+	unsigned callbackMask() const override { return CB_LASTSTAGE; }
+	bool viewFields(std::vector<int> &fields) const override
+	{
+		fields = { MJB_F_sensordata, MJB_F_time };
+		return true;
+	}
 
 	// registerNoiseModelsCB (:123-173): returns false ("success = false") on an admin-hash mismatch in eval mode
 	bool registerNoiseModel(const std::string &sensor_name, unsigned char set_flag, const double *mean, const double *std,

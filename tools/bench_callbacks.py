@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Throughput of the plugin / callback path of the host runtime (the path every consumer of the reference takes:
+controlCallback / passiveCallback inside the step, lastStageCallback after it -- mujoco_env.cpp:498-520, callbacks.cpp:131-157).
+
+Drives mujoco_ros::MujocoEnv (libmjr_host.so, HIP backend) with the stepped-mode API `step(n, blocking)` on the Franka-like
+arm (BASELINE configs[1] model) and reports env-steps/s for
+  fused      no plugin: one fused launch per burst
+  sensors    MujocoRosSensorsPlugin on every env (an end-of-step observer: fused single-step launches + one batched copy of the
+             two fields it reads, then its host-side record building per env)
+  control-N  TestPlugin (control + passive + lastStage callbacks) with the callbacks delivered for the first N envs
+             (N = 1, 64, all): split step1 / callbacks / step2 per step, view fields moved with batched asynchronous copies.
+  python tools/bench_callbacks.py [--envs 4096] [--steps 200]        (one JSON line per case on stdout)"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mujoco_ros_pkgs_amd import host_binding, mjcf  # noqa: E402
+
+TEST = [{"type": "mujoco_ros/TestPlugin", "example_param": "example_string", "nested_array_param_1": [{"nested_array_param_2": 1}],
+         "nested_struct_param_1": {"nested_struct_param_2": 2}}]
+SENS = [{"type": "mujoco_ros_sensors/MujocoRosSensorsPlugin", "seed": 7}]
+
+
+def wait(cond, timeout=60.0):
+    t0 = time.time()
+    while not cond():
+        if time.time() - t0 > timeout:
+            raise TimeoutError
+        time.sleep(0.001)
+
+
+def run(model, nenv, nsteps, plugins, cb_envs, label):
+    env = host_binding.HostEnv({"unpause": False, "MujocoPlugins": plugins} if plugins else {"unpause": False})
+    env.queue_model(model, nenv=nenv)
+    env.start()
+    wait(lambda: env.operational_status == 0 and env.model_valid)
+    if cb_envs is not None:
+        env.set_callback_envs(cb_envs)
+    env.step(min(20, nsteps))   # warm-up
+    t0 = time.perf_counter()
+    env.step(nsteps)
+    dt = time.perf_counter() - t0
+    out = {"case": label, "envs": nenv, "callback_envs": nenv if cb_envs is None else cb_envs, "steps": nsteps, "seconds": dt,
+           "steps_per_s": nsteps / dt, "env_steps_per_s": nenv * nsteps / dt, "us_per_step": 1e6 * dt / nsteps}
+    env.shutdown()
+    print(json.dumps(out), flush=True)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=200)
+    a = ap.parse_args()
+    host_binding.load_library()
+    model = mjcf.load_asset("franka_like")
+    run(model, a.envs, 20 * a.steps, None, None, "fused (no plugin)")
+    run(model, a.envs, a.steps, SENS, None, "sensors plugin, all envs")
+    for n in (1, 64, a.envs):
+        run(model, a.envs, a.steps, TEST, n, f"control plugin, callbacks on {n} env(s)")
+
+
+if __name__ == "__main__":
+    main()
