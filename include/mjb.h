@@ -245,13 +245,30 @@ int mjb_sensor_pack(mjb_batch *b, uint64_t seed);
 int mjb_sensor_get(mjb_batch *b, int which, int env_lo, int env_hi, float *host);
 void *mjb_sensor_device_ptr(mjb_batch *b, int which);
 
+/* ---- collision-function overrides (MujocoEnv::registerCollisionFunction, /root/reference mujoco_ros/src/mujoco_env.cpp:163-176) ----
+ * The reference lets a plugin replace MuJoCo's pair function for a geom-type pair (the mjCOLLISIONFUNC table) with a host
+ * callback until the next reload (:950-954).  Host callbacks cannot run inside the fused device step, so the override names
+ * one of the engine's device-side pair functions instead:
+ *   MJB_COLFUNC_DEFAULT  the built-in primitive function of the pair (restores the default)
+ *   MJB_COLFUNC_NONE     the pair type produces no contacts (a collision function that returns 0)
+ *   MJB_COLFUNC_SPHERES  both geoms are replaced by their bounding spheres (planes stay planes): at most one contact
+ * geom_type1 / geom_type2 are mjtGeom values in either order; the override applies to every candidate pair of those types of
+ * this batch from the next launch on. */
+enum { MJB_COLFUNC_DEFAULT = 0, MJB_COLFUNC_NONE = 1, MJB_COLFUNC_SPHERES = 2 };
+int mjb_register_collision(mjb_batch *b, int geom_type1, int geom_type2, int func);
+
 /* ---- per-env model parameters (the subset that needs no mj_setConst) ----
  * The reference mutates its single mjModel through services (setGravity, setGeomProperties friction:
  * /root/reference mujoco_ros/src/callbacks.cpp:462-592, 641-884); in a batch every env may carry its own value (domain
  * randomisation).  Envs never written keep the model's value.  gravity: [env][3]; friction: [env][ngeom][3].
- * (Geom size / type changes are not implemented; masses: mjb_set_env_mass_params below.) */
+ * (masses: mjb_set_env_mass_params below.) */
 int mjb_set_env_gravity(mjb_batch *b, int env_lo, int env_hi, const double *gravity);
 int mjb_set_env_geom_friction(mjb_batch *b, int env_lo, int env_hi, const double *friction);
+/* setGeomProperties' set_size / set_type (callbacks.cpp:555-575) per env: size [env][ngeom][3], type [env][ngeom] (mjtGeom: plane,
+ * sphere, capsule, box).  As in the reference the bounding radii are NOT recomputed ("AABBs are not recomputed", :557-560) and the
+ * candidate pair list stays the model's; a pair whose new types have no pair function yields no contacts. */
+int mjb_set_env_geom_size(mjb_batch *b, int env_lo, int env_hi, const double *size);
+int mjb_set_env_geom_type(mjb_batch *b, int env_lo, int env_hi, const int *type);
 /* setEqualityConstraintParameters (/root/reference mujoco_ros/src/callbacks.cpp:641-884: active flag, solref, solimp and the
  * type's data -- anchor / relpose / torquescale / polycoef) per env: params[env][neq][19] =
  * { active (0 / 1), eq_data[11], solref[2], solimp[5] } for every equality of the model, in model order. */

@@ -41,6 +41,7 @@ typedef struct mjr_backend {
 	int (*host_register)(void *self, void *host, unsigned long long bytes);
 	int (*host_unregister)(void *self, void *host);
 	int (*step_async)(void *self, int nsteps); /* enqueue nsteps fused steps without waiting for them */
+	int (*register_collision)(void *self, int geom_type1, int geom_type2, int func); /* mjb_register_collision */
 } mjr_backend;
 
 /* creates a backend for (model, nenv, device); NULL on failure */
@@ -118,6 +119,10 @@ int mjr_env_num_cb_ready_plugins(mjr_env *e);
 int mjr_env_test_plugin_flag(mjr_env *e, int i, const char *name, int clear);
 int mjr_env_notify_geom_changed(mjr_env *e, int geom_id);
 int mjr_env_set_callback_envs(mjr_env *e, int n);
+/* MujocoEnv::registerCollisionFunction (mujoco_env.cpp:163-176) with a device-side pair function (MJB_COLFUNC_*) in place of
+ * the host callback; returns 1 when an override of this pair type was already registered (the reference warns), 0 when it is
+ * the first, -1 on error.  Overrides are dropped at the next reload (prepareReload, :950-954). */
+int mjr_env_register_collision_function(mjr_env *e, int geom_type1, int geom_type2, int func);
 
 /* ---- sensors plugin ("mujoco_ros_sensors/MujocoRosSensorsPlugin"): the typed records it would publish
  * (reference: mujoco_ros_sensors/src/mujoco_sensor_handler_plugin.cpp:175-436 lastStageCallback, :123-173

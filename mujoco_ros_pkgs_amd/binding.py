@@ -148,6 +148,8 @@ def load_library(path=None):
         "mjb_set_keep_frame": (ci, [vp, ci]),
         "mjb_set_env_gravity": (ci, [vp, ci, ci, C.POINTER(cd)]),
         "mjb_set_env_geom_friction": (ci, [vp, ci, ci, C.POINTER(cd)]),
+        "mjb_set_env_geom_size": (ci, [vp, ci, ci, C.POINTER(cd)]),
+        "mjb_set_env_geom_type": (ci, [vp, ci, ci, C.POINTER(ci)]),
         "mjb_set_env_equality": (ci, [vp, ci, ci, C.POINTER(cd)]),
         "mjb_env_mass_stride": (ci, [vp]),
         "mjb_set_env_mass_params": (ci, [vp, ci, ci, C.POINTER(cd)]),
@@ -167,6 +169,7 @@ def load_library(path=None):
         "mjb_get": (ci, [vp, ci, ci, ci, C.POINTER(cd)]),
         "mjb_set": (ci, [vp, ci, ci, ci, C.POINTER(cd)]),
         "mjb_get_int": (ci, [vp, ci, ci, ci, C.POINTER(ci)]),
+        "mjb_register_collision": (ci, [vp, ci, ci, ci]),
         "mjb_get_many": (ci, [vp, ci, C.POINTER(ci), ci, ci, C.POINTER(C.POINTER(cd))]),
         "mjb_set_many": (ci, [vp, ci, C.POINTER(ci), ci, ci, C.POINTER(C.POINTER(cd))]),
         "mjb_host_register": (ci, [vp, C.c_ulonglong]),

@@ -80,7 +80,7 @@ struct mjb_model {
 	std::vector<size_t> ioff, doff;   // offsets of each array inside hint / hdbl (declaration order)
 	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense, body_anc, dof_bodymask;
 	std::vector<int> sens_copy, sens_slow, dof_act_adr, dof_act_id;
-	std::vector<int> pair_i;       // [ncollpair][8]  per candidate pair: g1, g2, type1, type2, condim, friction rule, body1, body2
+	std::vector<int> pair_i;       // [ncollpair][8]  per candidate pair: g1, g2, type1, type2, condim, friction rule, collision-function override, 0
 	std::vector<double> pair_d;    // [ncollpair][24] size1[3] size2[3] margin gap rbound1 rbound2 solref[2] solimp[5] includemargin pad[7]
 	int sens_ncopy[3] = { 0, 0, 0 }, sens_nslow[3] = { 0, 0, 0 }, sens_ncopy_max = 0;
 	int eulerdamp = 0, maxdepth = 0, kin_rounds = 0, need_rnepost = 0, nfriction = 0;
@@ -104,6 +104,7 @@ struct mjb_batch {
 	unsigned char *mask_dev = nullptr;
 	KernelParams *params_dev = nullptr;  // device copy of {dm, L, st, nz}
 	double *metrics_dev = nullptr;       // [16] mjb_metrics
+	int *pair_i_dev = nullptr;           // device address of the per-pair int records inside the blob (mjb_register_collision patches them)
 	unsigned long long steps_taken = 0;  // steps since the batch was made (step_counter is the 32-bit Philox counter)
 	bool params_dirty = true;
 	// sensors-plugin equivalent (mjb_sensor_*): noise models (host mirror + device copy) and the packed messages
@@ -113,6 +114,8 @@ struct mjb_batch {
 	double *sens_mean_dev = nullptr, *sens_sigma_dev = nullptr;
 	float *sens_value = nullptr, *sens_truth = nullptr;
 	bool sens_dirty = true, sens_packed = false;
+	double *env_geom_size = nullptr;
+	int *env_geom_type = nullptr;
 	double *env_gravity = nullptr, *env_geom_friction = nullptr, *env_equality = nullptr, *env_mass = nullptr;  // per-env model parameter overrides (mjb_set_env_*)
 	// device-side DefaultRobotHWSim (mjb_hwsim_*)
 	HwSim hw{};
@@ -705,7 +708,8 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		int *pi = M->pair_i.data() + 8 * p;
 		double *pd = M->pair_d.data() + 24 * p;
 		pi[0] = g1; pi[1] = g2; pi[2] = h.geom_type[g1]; pi[3] = h.geom_type[g2];
-		pi[6] = h.geom_bodyid[g1]; pi[7] = h.geom_bodyid[g2];
+		pi[6] = MJB_COLFUNC_DEFAULT;  // collision-function override (mjb_register_collision patches the batch's copy)
+		pi[7] = 0;
 		for (int k = 0; k < 3; k++) {
 			pd[k] = h.geom_size[3 * g1 + k];
 			pd[3 + k] = h.geom_size[3 * g2 + k];
@@ -799,6 +803,8 @@ void mjb_free_batch(mjb_batch *b)
 	if (b->params_dev) hipFree(b->params_dev);
 	if (b->env_gravity) hipFree(b->env_gravity);
 	if (b->env_geom_friction) hipFree(b->env_geom_friction);
+	if (b->env_geom_size) hipFree(b->env_geom_size);
+	if (b->env_geom_type) hipFree(b->env_geom_type);
 	if (b->env_equality) hipFree(b->env_equality);
 	if (b->env_mass) hipFree(b->env_mass);
 	if (b->hw_ints) hipFree(b->hw_ints);
@@ -918,6 +924,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	dm.dof_act_adr = (mjb_ciptr)(di + o_aa);
 	dm.dof_act_id = (mjb_ciptr)(di + o_ai);
 	dm.pair_i = (mjb_ciptr)(di + o_pi);
+	b->pair_i_dev = di + o_pi;
 	dm.pair_d = (mjb_cdptr)(dd + nd);
 	for (int k = 0; k < 3; k++) {
 		dm.sens_ncopy[k] = M->sens_ncopy[k];
@@ -954,6 +961,8 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	s.use_xfrc = 0;
 	s.env_gravity = nullptr;
 	s.env_geom_friction = nullptr;
+	s.env_geom_size = nullptr;
+	s.env_geom_type = nullptr;
 	s.env_equality = nullptr;
 	s.env_mass = nullptr;
 	s.pgs_B = nullptr;
@@ -1251,6 +1260,25 @@ int mjb_set(mjb_batch *b, int field, int env_lo, int env_hi, const double *host)
 	return MJB_OK;
 }
 
+int mjb_register_collision(mjb_batch *b, int geom_type1, int geom_type2, int func)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	auto known = [](int t) { return t == MJB_GEOM_PLANE || t == MJB_GEOM_SPHERE || t == MJB_GEOM_CAPSULE || t == MJB_GEOM_BOX; };
+	if (!known(geom_type1) || !known(geom_type2)) return fail(MJB_EINVAL, "mjb_register_collision: geom types must be plane / sphere / capsule / box");
+	if (func < MJB_COLFUNC_DEFAULT || func > MJB_COLFUNC_SPHERES) return fail(MJB_EINVAL, "mjb_register_collision: unknown function %d", func);
+	const mjb_model *M = b->model;
+	const int np = M->h.ncollpair;
+	if (np == 0) return MJB_OK;
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	const int lo = geom_type1 < geom_type2 ? geom_type1 : geom_type2, hi = geom_type1 < geom_type2 ? geom_type2 : geom_type1;
+	for (int p = 0; p < np; p++) {  // (pairs are stored with type1 <= type2)
+		if (M->pair_i[8 * p + 2] != lo || M->pair_i[8 * p + 3] != hi) continue;
+		HIP_TRY(hipMemcpy(b->pair_i_dev + 8 * p + 6, &func, sizeof(int), hipMemcpyHostToDevice));
+	}
+	return MJB_OK;
+}
+
 int mjb_get_many(mjb_batch *b, int n, const int *fields, int env_lo, int env_hi, double *const *host)
 {
 	if (!b || n < 0 || (n && (!fields || !host))) return fail(MJB_EINVAL, "mjb_get_many: bad argument");
@@ -1517,6 +1545,38 @@ int mjb_set_env_geom_friction(mjb_batch *b, int env_lo, int env_hi, const double
 	const mjb_model_desc &h = b->model->h;
 	return env_param(b, &b->env_geom_friction, &b->st.env_geom_friction, h.nconmax > 0 ? 3 * h.ngeom : 0, h.geom_friction, env_lo,
 	                 env_hi, friction, "mjb_set_env_geom_friction");
+}
+
+int mjb_set_env_geom_size(mjb_batch *b, int env_lo, int env_hi, const double *size)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	const mjb_model_desc &h = b->model->h;
+	return env_param(b, &b->env_geom_size, &b->st.env_geom_size, h.nconmax > 0 ? 3 * h.ngeom : 0, h.geom_size, env_lo, env_hi, size,
+	                 "mjb_set_env_geom_size");
+}
+
+int mjb_set_env_geom_type(mjb_batch *b, int env_lo, int env_hi, const int *type)
+{
+	if (!b || !type) return fail(MJB_EINVAL, "mjb_set_env_geom_type: bad argument");
+	const mjb_model_desc &h = b->model->h;
+	if (env_lo < 0 || env_hi > b->nenv || env_lo > env_hi) return fail(MJB_EINVAL, "mjb_set_env_geom_type: bad env range");
+	if (h.nconmax <= 0 || h.ngeom <= 0) return fail(MJB_EINVAL, "mjb_set_env_geom_type: the model has nothing to override");
+	for (size_t k = 0; k < (size_t)(env_hi - env_lo) * h.ngeom; k++)
+		if (type[k] != MJB_GEOM_PLANE && type[k] != MJB_GEOM_SPHERE && type[k] != MJB_GEOM_CAPSULE && type[k] != MJB_GEOM_BOX)
+			return fail(MJB_EUNSUPPORTED, "mjb_set_env_geom_type: geom type %d is not a primitive of the engine", type[k]);
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	if (!b->env_geom_type) {
+		b->env_geom_type = dev_alloc<int>((size_t)b->nenv * h.ngeom);
+		if (!b->env_geom_type) return fail(MJB_ENOMEM, "mjb_set_env_geom_type: allocation failed");
+		std::vector<int> init((size_t)b->nenv * h.ngeom);
+		for (int e = 0; e < b->nenv; e++) memcpy(init.data() + (size_t)e * h.ngeom, h.geom_type, (size_t)h.ngeom * sizeof(int));
+		HIP_TRY(hipMemcpy(b->env_geom_type, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice));
+		b->st.env_geom_type = b->env_geom_type;
+		b->params_dirty = true;
+	}
+	HIP_TRY(hipMemcpy(b->env_geom_type + (size_t)env_lo * h.ngeom, type, (size_t)(env_hi - env_lo) * h.ngeom * sizeof(int), hipMemcpyHostToDevice));
+	return MJB_OK;
 }
 
 int mjb_set_env_equality(mjb_batch *b, int env_lo, int env_hi, const double *params)

@@ -543,14 +543,35 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 			const mjb_ciptr pi = m.pair_i + 8 * p;
 			g1 = pi[0];
 			g2 = pi[1];
-			const int t1 = pi[2], t2 = pi[3];
+			int t1 = pi[2], t2 = pi[3];
 			condim = pi[4];
 			frisel = pi[5];
 			double pos1[3], pos2[3], mat1[9], mat2[9];
-			const double size1[3] = { pd[0], pd[1], pd[2] }, size2[3] = { pd[3], pd[4], pd[5] };
+			double size1[3] = { pd[0], pd[1], pd[2] }, size2[3] = { pd[3], pd[4], pd[5] };
 			margin = pd[6];
 			incl = pd[17];
-			const double rb1 = pd[8], rb2 = pd[9];
+			double rb1 = pd[8], rb2 = pd[9];
+			// per-env geom sizes / types (setGeomProperties per env, mjb_set_env_geom_size / _type): bounding radii stay the
+			// model's, as in the reference; a type change may reverse the pair's (type1 <= type2) order
+			if (s.env_geom_size) {
+				const double *es = s.env_geom_size + (size_t)e.env * 3 * m.ngeom;
+				for (int k = 0; k < 3; k++) {
+					size1[k] = es[3 * g1 + k];
+					size2[k] = es[3 * g2 + k];
+				}
+			}
+			if (s.env_geom_type) {
+				const int *et = s.env_geom_type + (size_t)e.env * m.ngeom;
+				t1 = et[g1];
+				t2 = et[g2];
+				if (t1 > t2) {
+					const int tg = g1; g1 = g2; g2 = tg;
+					const int tt = t1; t1 = t2; t2 = tt;
+					const double tr = rb1; rb1 = rb2; rb2 = tr;
+					for (int k = 0; k < 3; k++) { const double ts = size1[k]; size1[k] = size2[k]; size2[k] = ts; }
+					if (frisel) frisel = 3 - frisel;
+				}
+			}
 			ld3(pos1, f + L.geom_xpos + 3 * g1);
 			ld3(pos2, f + L.geom_xpos + 3 * g2);
 			ld9(mat1, f + L.geom_xmat + 9 * g1);
@@ -566,7 +587,19 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 			}
 			// (every narrow-phase routine returns only contacts with dist <= margin, and mj_collideGeoms adds what its
 			//  collision function returns: no second distance filter)
-			if (!cull) n = narrowphase(t1, t2, pos1, mat1, size1, pos2, mat2, size2, margin, rc);
+			if (!cull) {
+				const int cfun = pi[6];  // MujocoEnv::registerCollisionFunction's override of the pair type (mjb_register_collision)
+				if (cfun == MJB_COLFUNC_DEFAULT) {
+					n = narrowphase(t1, t2, pos1, mat1, size1, pos2, mat2, size2, margin, rc);
+				} else if (cfun == MJB_COLFUNC_SPHERES) {
+					if (t1 == MJB_GEOM_PLANE) {
+						const double nrm[3] = { mat1[2], mat1[5], mat1[8] };
+						n = raw_plane_sphere(rc[0], pos1, nrm, pos2, rb2, margin);
+					} else {
+						n = raw_sphere_sphere(rc[0], pos1, rb1, pos2, rb2, margin);
+					}
+				}  // MJB_COLFUNC_NONE: no contacts
+			}
 		}
 #ifdef MJB_PROFILE_SUB
 		EPROF(24);

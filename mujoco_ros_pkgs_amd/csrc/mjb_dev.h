@@ -40,7 +40,7 @@ struct DevModel {
 	mjb_ciptr sens_slow;     // [3][nsensor] ids of the sensors of each stage that need real work
 	mjb_ciptr dof_act_adr;   // [nv+1] CSR: actuators (joint transmission) driving each dof
 	mjb_ciptr dof_act_id;    // [nu]
-	mjb_ciptr pair_i;        // [ncollpair][8]  candidate-pair records: g1, g2, type1, type2, condim, friction rule (0 max, 1 geom1, 2 geom2), body1, body2
+	mjb_ciptr pair_i;        // [ncollpair][8]  candidate-pair records: g1, g2, type1, type2, condim, friction rule (0 max, 1 geom1, 2 geom2), collision-function override (MJB_COLFUNC_*), 0
 	mjb_cdptr pair_d;        // [ncollpair][24] size1[3] size2[3] margin gap rbound1 rbound2 solref[2] solimp[5] includemargin pad
 	int sens_ncopy[3];       // plain-copy elements per stage
 	int sens_nslow[3];       // complex sensors per stage
@@ -109,6 +109,8 @@ struct DevState {
 	int frame_stride;              // doubles per env in frame_ws
 	const double *env_gravity;       // [nenv][3] per-env gravity override (NULL: the model's)
 	const double *env_geom_friction; // [nenv][ngeom][3] per-env geom friction override (NULL: the model's)
+	const double *env_geom_size;     // [nenv][ngeom][3] per-env geom sizes (NULL: the model's)
+	const int *env_geom_type;        // [nenv][ngeom] per-env geom types (NULL: the model's)
 	const double *env_equality;      // [nenv][neq][19] per-env equality parameters (NULL: the model's)
 	const double *env_mass;          // [nenv][7 nbody + nv + ntendon + 1] per-env inertial constants (NULL: the model's):
 	                                 // body_mass | body_subtreemass | body_inertia[3] | dof_invweight0 | body_invweight0[2] | tendon_invweight0 | meaninertia

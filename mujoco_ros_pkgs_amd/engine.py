@@ -123,6 +123,10 @@ class Batch:
             raise EngineError(self.lib.mjb_last_error().decode())
         return p
 
+    def register_collision(self, geom_type1, geom_type2, func):
+        """registerCollisionFunction's device-side form: func = 0 default, 1 none, 2 bounding spheres (mjb_register_collision)."""
+        _check(self.lib.mjb_register_collision(self.ptr, int(geom_type1), int(geom_type2), int(func)), "mjb_register_collision")
+
     # ---- per-env model parameters ----
     def set_env_gravity(self, gravity, lo=0, hi=None):
         hi = self.nenv if hi is None else hi
@@ -134,6 +138,16 @@ class Batch:
         a = np.ascontiguousarray(friction, dtype=np.float64).reshape(hi - lo, self.cm.model["ngeom"] * 3)
         _check(self.lib.mjb_set_env_geom_friction(self.ptr, lo, hi, a.ctypes.data_as(C.POINTER(C.c_double))),
                "mjb_set_env_geom_friction")
+
+    def set_env_geom_size(self, size, lo=0, hi=None):
+        hi = self.nenv if hi is None else hi
+        a = np.ascontiguousarray(size, dtype=np.float64).reshape(hi - lo, self.cm.model["ngeom"] * 3)
+        _check(self.lib.mjb_set_env_geom_size(self.ptr, lo, hi, a.ctypes.data_as(C.POINTER(C.c_double))), "mjb_set_env_geom_size")
+
+    def set_env_geom_type(self, types, lo=0, hi=None):
+        hi = self.nenv if hi is None else hi
+        a = np.ascontiguousarray(types, dtype=np.int32).reshape(hi - lo, self.cm.model["ngeom"])
+        _check(self.lib.mjb_set_env_geom_type(self.ptr, lo, hi, a.ctypes.data_as(C.POINTER(C.c_int))), "mjb_set_env_geom_type")
 
     def set_env_equality(self, active=None, data=None, solref=None, solimp=None, lo=0, hi=None):
         """Per-env equality parameters (setEqualityConstraintParameters per env).  Each argument is None (the model's

@@ -34,6 +34,7 @@ int be_set_many(void *s, int n, const int *f, int lo, int hi, const double *cons
 int be_host_register(void *, void *h, unsigned long long bytes) { return mjb_host_register(h, bytes); }
 int be_host_unregister(void *, void *h) { return mjb_host_unregister(h); }
 int be_step_async(void *s, int n) { return mjb_step(B(s)->batch, n); }
+int be_register_collision(void *s, int t1, int t2, int f) { return mjb_register_collision(B(s)->batch, t1, t2, f); }
 const char *be_err(void *) { return mjb_last_error(); }
 void be_destroy(void *s)
 {
@@ -70,7 +71,7 @@ mjr_backend *mjr_make_mjb_backend(const mjb_model_desc *desc, int nenv, int devi
 	}
 	b->vt = mjr_backend{ b, be_nenv, be_field_size, be_step, be_step1, be_step2, be_forward, be_reset, be_get, be_set,
 		                 be_noise, be_sync, be_err, be_destroy, be_get_many, be_set_many, be_host_register, be_host_unregister,
-		                 be_step_async };
+		                 be_step_async, be_register_collision };
 	return &b->vt;
 }
 
@@ -260,6 +261,7 @@ int mjr_env_notify_geom_changed(mjr_env *e, int geom_id)
 	e->env->notifyGeomChanged(geom_id);
 	return 0;
 }
+int mjr_env_register_collision_function(mjr_env *e, int t1, int t2, int func) { return e->env->registerCollisionFunction(t1, t2, func); }
 int mjr_env_set_callback_envs(mjr_env *e, int n)
 {
 	e->env->setCallbackEnvs(n);

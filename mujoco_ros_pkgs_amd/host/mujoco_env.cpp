@@ -173,8 +173,26 @@ bool MujocoEnv::initModelFromQueue()
 }
 
 // mujoco_env.cpp:947-961
+// mujoco_env.cpp:163-176.  The reference's duplicate test looks for (type1, type2) AND (type2, type2) -- a typo for the
+// swapped pair; here the pair is unordered, which is what the warning text describes.
+int MujocoEnv::registerCollisionFunction(int geom_type1, int geom_type2, int func)
+{
+	std::lock_guard<MujocoEnvMutex> lock(physics_thread_mutex_);
+	if (!backend_ || !backend_->register_collision) return -1;
+	const std::pair<int, int> key(std::min(geom_type1, geom_type2), std::max(geom_type1, geom_type2));
+	const bool dup = custom_collisions_.count(key) != 0;
+	if (dup)
+		plugin_warnings_.push_back("A user defined collision callback for collisions between geoms of type " + std::to_string(geom_type1) +
+		                           " and " + std::to_string(geom_type2) + " have already been registered. This might lead to unexpected behavior!");
+	if (backend_->register_collision(backend_->self, geom_type1, geom_type2, func) != 0) return -1;
+	custom_collisions_.insert(key);
+	return dup ? 1 : 0;
+}
+
 void MujocoEnv::prepareReload()
 {
+	// "Resetting collision cbs to default" (:949-954): a freshly made backend starts with the built-in pair functions
+	custom_collisions_.clear();
 	cb_ready_plugins_.clear();
 	plugins_.clear();
 }

@@ -14,6 +14,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -120,6 +121,9 @@ public:
 	void runRenderCbs(mjvScene *scene);
 	void runLastStageCbs();
 	void notifyGeomChanged(int geom_id);
+	// mujoco_env.cpp:163-176 with a device-side pair function (MJB_COLFUNC_*) instead of a host mjfCollision: 1 = an override of
+	// this pair type existed (the reference's warning case), 0 = first registration, -1 = refused by the backend
+	int registerCollisionFunction(int geom_type1, int geom_type2, int func);
 
 	// per-env data access for tests / services (host mirror, refreshed from the device on demand)
 	const mjModel *getModelPtr() const { return model_valid_ ? &model_ : nullptr; }
@@ -180,6 +184,7 @@ protected:
 	int cb_envs_ = -1;
 	mjData *cb_view_ = nullptr;  // env instance the running callback round is for
 	bool xfrc_used_ = false;
+	std::set<std::pair<int, int>> custom_collisions_;  // mujoco_env.h:285
 	// what the callback-ready plugins declared (MujocoPlugin::callbackMask / viewFields), resolved in loadPlugins()
 	unsigned cb_mask_ = 0;
 	bool cb_all_fields_ = true;

@@ -67,6 +67,7 @@ def load_library():
         "mjr_env_set_setting": (ci, [vp, cs, ci]),
         "mjr_env_set_ctrl_noise": (ci, [vp, C.c_double, C.c_double]),
         "mjr_env_sim_time": (C.c_double, [vp]),
+        "mjr_env_register_collision_function": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "mjr_env_data_time": (C.c_double, [vp]),
         "mjr_env_step_count": (C.c_ulonglong, [vp]),
         "mjr_env_nenv": (ci, [vp]),
@@ -206,6 +207,10 @@ class HostEnv:
 
     def notify_geom_changed(self, geom_id):
         self.L.mjr_env_notify_geom_changed(self.ptr, geom_id)
+
+    def register_collision_function(self, geom_type1, geom_type2, func):
+        """MujocoEnv::registerCollisionFunction: 0 first registration, 1 duplicate (the reference warns), -1 refused."""
+        return self.L.mjr_env_register_collision_function(self.ptr, int(geom_type1), int(geom_type2), int(func))
 
     def set_callback_envs(self, n):
         self.L.mjr_env_set_callback_envs(self.ptr, n)

@@ -44,6 +44,11 @@ typedef struct mjo_data {
 	/* mjData.warning[].number, accumulated over the life of the data (not cleared by mjo_reset_data -- the engine's batch
 	 * counters, mjb_warning, accumulate the same way) */
 	unsigned long long warning[MJB_NWARNING];
+	/* collision-function override per geom-type pair (mjb_register_collision; index 8 * min(type) + max(type)) */
+	int colfunc[64];
+	/* this env's geom sizes / types (mjb_set_env_geom_size / _type); NULL: the model's */
+	double *env_geom_size;
+	int *env_geom_type;
 	/* scratch for the Euler implicit-damping solve */
 	double *scratch_MM;
 	double *scratch_nv;
@@ -102,6 +107,9 @@ void mjo_hwsim_write(const mjb_model_desc *m, mjo_data *d, int n, const int *joi
                      const double *cmd_eff, const double *cmd_hold, double *pid, int estop);
 void mjo_rne_post_constraint(const mjb_model_desc *m, mjo_data *d);
 int mjo_needs_rne_post(const mjb_model_desc *m);
+void mjo_register_collision(mjo_data *d, int geom_type1, int geom_type2, int func); /* mjb_register_collision */
+void mjo_set_geom_size(const mjb_model_desc *m, mjo_data *d, const double *size);   /* [ngeom][3]; NULL: back to the model's */
+void mjo_set_geom_type(const mjb_model_desc *m, mjo_data *d, const int *type);      /* [ngeom];    NULL: back to the model's */
 unsigned long long mjo_warning(const mjo_data *d, int which); /* mjData.warning[which].number */
 void mjo_energy(const mjb_model_desc *m, mjo_data *d);          /* mj_energyPos + mj_energyVel (mjENBL_ENERGY) */
 void mjo_tendon(const mjb_model_desc *m, mjo_data *d);

@@ -527,6 +527,32 @@ static void contact_param(const mjb_model_desc *m, int g1, int g2, int *condim, 
 	for (int k = 0; k < 3; k++) friction[k] = fmax(m->geom_friction[3 * g1 + k], m->geom_friction[3 * g2 + k]);
 }
 
+void mjo_set_geom_size(const mjb_model_desc *m, mjo_data *d, const double *size)
+{
+	free(d->env_geom_size);
+	d->env_geom_size = NULL;
+	if (size) {
+		d->env_geom_size = (double *)malloc(sizeof(double) * 3 * (size_t)(m->ngeom > 0 ? m->ngeom : 1));
+		memcpy(d->env_geom_size, size, sizeof(double) * 3 * (size_t)m->ngeom);
+	}
+}
+
+void mjo_set_geom_type(const mjb_model_desc *m, mjo_data *d, const int *type)
+{
+	free(d->env_geom_type);
+	d->env_geom_type = NULL;
+	if (type) {
+		d->env_geom_type = (int *)malloc(sizeof(int) * (size_t)(m->ngeom > 0 ? m->ngeom : 1));
+		memcpy(d->env_geom_type, type, sizeof(int) * (size_t)m->ngeom);
+	}
+}
+
+void mjo_register_collision(mjo_data *d, int geom_type1, int geom_type2, int func)
+{
+	int lo = geom_type1 < geom_type2 ? geom_type1 : geom_type2, hi = geom_type1 < geom_type2 ? geom_type2 : geom_type1;
+	if (lo >= 0 && hi < 8) d->colfunc[8 * lo + hi] = func;
+}
+
 /* ------------------------------------------------------------------ A4+A5: mj_collision */
 void mjo_collision(const mjb_model_desc *m, mjo_data *d)
 {
@@ -535,10 +561,15 @@ void mjo_collision(const mjb_model_desc *m, mjo_data *d)
 	int ncon = 0, overflow = 0;
 	for (int p = 0; p < m->ncollpair; p++) {
 		int g1 = m->collpair_geom[2 * p], g2 = m->collpair_geom[2 * p + 1];
-		int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+		int t1 = d->env_geom_type ? d->env_geom_type[g1] : m->geom_type[g1], t2 = d->env_geom_type ? d->env_geom_type[g2] : m->geom_type[g2];
+		if (t1 > t2) { /* a per-env type change reversed the (type1 <= type2) order of the pair */
+			int tg = g1; g1 = g2; g2 = tg;
+			int tt = t1; t1 = t2; t2 = tt;
+		}
 		const double *pos1 = d->geom_xpos + 3 * g1, *pos2 = d->geom_xpos + 3 * g2;
 		const double *mat1 = d->geom_xmat + 9 * g1, *mat2 = d->geom_xmat + 9 * g2;
-		const double *size1 = m->geom_size + 3 * g1, *size2 = m->geom_size + 3 * g2;
+		const double *gsz = d->env_geom_size ? d->env_geom_size : m->geom_size;
+		const double *size1 = gsz + 3 * g1, *size2 = gsz + 3 * g2;
 		double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
 		double gap = fmax(m->geom_gap[g1], m->geom_gap[g2]);
 		/* broad phase: bounding spheres (plane: signed distance of the other geom's sphere) */
@@ -555,6 +586,12 @@ void mjo_collision(const mjb_model_desc *m, mjo_data *d)
 		}
 		rawcon rc[4];
 		int n = 0;
+		const int cfun = d->colfunc[8 * t1 + t2]; /* registerCollisionFunction override (pairs are stored with t1 <= t2) */
+		if (cfun == MJB_COLFUNC_NONE) continue;
+		if (cfun == MJB_COLFUNC_SPHERES) {
+			if (t1 == MJB_GEOM_PLANE) n = raw_plane_sphere(rc, pos1, mat1, pos2, rb2, margin);
+			else n = raw_sphere_sphere(rc, pos1, rb1, pos2, rb2, margin);
+		} else
 		if (t1 == MJB_GEOM_PLANE && t2 == MJB_GEOM_SPHERE) n = raw_plane_sphere(rc, pos1, mat1, pos2, size2[0], margin);
 		else if (t1 == MJB_GEOM_PLANE && t2 == MJB_GEOM_CAPSULE) n = plane_capsule(rc, pos1, mat1, pos2, mat2, size2, margin);
 		else if (t1 == MJB_GEOM_PLANE && t2 == MJB_GEOM_BOX) n = plane_box(rc, pos1, mat1, pos2, mat2, size2, margin);

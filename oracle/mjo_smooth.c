@@ -68,6 +68,8 @@ void mjo_free_data(mjo_data *d)
 #undef MJB_DD
 #undef MJB_DD2
 #undef MJB_DI
+	free(d->env_geom_size);
+	free(d->env_geom_type);
 	free(d->scratch_MM);
 	free(d->scratch_nv);
 	free(d->scratch_nv2);

@@ -52,6 +52,12 @@ def lib(fast=False):
     L.mjo_normal.restype = cd
     L.mjo_normal.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
     L.mjo_ctrl_noise.argtypes = [pd, vp, cd, cd, C.c_uint64, C.c_uint64, C.c_uint32]
+    L.mjo_set_geom_size.argtypes = [pd, vp, C.POINTER(cd)]
+    L.mjo_set_geom_size.restype = None
+    L.mjo_set_geom_type.argtypes = [pd, vp, C.POINTER(ci)]
+    L.mjo_set_geom_type.restype = None
+    L.mjo_register_collision.argtypes = [vp, ci, ci, ci]
+    L.mjo_register_collision.restype = None
     L.mjo_warning.restype = C.c_ulonglong
     L.mjo_warning.argtypes = [vp, ci]
     L.mjo_energy.argtypes = [pd, vp]
@@ -115,6 +121,17 @@ class OracleData:
     def step(self, n=1):
         for _ in range(n):
             self.call("step")
+
+    def set_geom_size(self, size):
+        a = None if size is None else np.ascontiguousarray(size, dtype=np.float64)
+        self.L.mjo_set_geom_size(C.byref(self.desc), self.ptr, None if a is None else a.ctypes.data_as(C.POINTER(C.c_double)))
+
+    def set_geom_type(self, types):
+        a = None if types is None else np.ascontiguousarray(types, dtype=np.int32)
+        self.L.mjo_set_geom_type(C.byref(self.desc), self.ptr, None if a is None else a.ctypes.data_as(C.POINTER(C.c_int)))
+
+    def register_collision(self, geom_type1, geom_type2, func):
+        self.L.mjo_register_collision(self.ptr, int(geom_type1), int(geom_type2), int(func))
 
     def warning(self, which):
         """mjData.warning[which].number (which = mjtWarning: 1 CONTACTFULL, 2 CNSTRFULL, 4 BADQPOS, 5 BADQVEL, 6 BADQACC)."""

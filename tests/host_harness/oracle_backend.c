@@ -66,6 +66,13 @@ static int ob_forward(void *s)
 	for (int e = 0; e < b->nenv; e++) mjo_forward(&b->desc, b->d[e]);
 	return 0;
 }
+static int ob_register_collision(void *s, int t1, int t2, int func)
+{
+	ob *b = (ob *)s;
+	if (func < 0 || func > 2) return -1;
+	for (int e = 0; e < b->nenv; e++) mjo_register_collision(b->d[e], t1, t2, func);
+	return 0;
+}
 static int ob_reset(void *s, const uint8_t *mask)
 {
 	ob *b = (ob *)s;
@@ -120,7 +127,7 @@ mjr_backend *oracle_backend_factory(const mjb_model_desc *desc, int nenv, int de
 	b->d = (mjo_data **)calloc((size_t)nenv, sizeof(mjo_data *));
 	for (int e = 0; e < nenv; e++) b->d[e] = mjo_make_data(&b->desc);
 	mjr_backend vt = { b, ob_nenv, ob_field_size, ob_step, ob_step1, ob_step2, ob_forward, ob_reset, ob_get, ob_set,
-		               ob_noise, ob_sync, ob_err, ob_destroy };
+		               ob_noise, ob_sync, ob_err, ob_destroy, NULL, NULL, NULL, NULL, NULL, ob_register_collision };
 	b->vt = vt;
 	return &b->vt;
 }

@@ -118,3 +118,57 @@ def test_per_env_body_mass(oracle_built, asset, over):
     np.testing.assert_allclose(ref.get("qpos")[0], b.get("qpos")[0], rtol=0, atol=1e-9)  # generic == dense kernel on env 0
     b.close()
     ref.close()
+
+
+def test_per_env_geom_size_and_type(oracle_built):
+    """setGeomProperties' set_size / set_type per env (callbacks.cpp:555-575): env 1 gets a bigger cube, env 2 a cube turned into a
+    sphere, env 3 fingertips turned into boxes (the pair's type order flips), the others keep the model -- each env must match the
+    oracle carrying the same override, and the override must matter."""
+    from mujoco_ros_pkgs_amd import engine
+    from test_gpu_contact import scenario_states
+    path = os.path.join(mjcf.ASSET_DIR, "franka_table.xml")
+    base = mjcf.compile_xml_file(path, override={"solver": "Newton"}, nconmax=32, nefcmax=137)
+    ng = int(base["ngeom"])
+    gid = {n: i for i, n in enumerate(base["names"]["geom"])}
+    nenv = 5
+    qpos, qvel = scenario_states(base, nenv, seed=12)
+    size = np.tile(np.asarray(base["geom_size"], dtype=np.float64).reshape(1, ng, 3), (nenv, 1, 1))
+    gtype = np.tile(np.asarray(base["geom_type"], dtype=np.int32).reshape(1, ng), (nenv, 1))
+    size[1, gid["cube_geom"]] = [0.03, 0.03, 0.03]
+    gtype[2, gid["cube_geom"]] = 2                      # sphere of radius size[0]
+    gtype[3, gid["fingertip1"]] = 6                     # box: (sphere, box) pairs with the cube become (box, box)
+    gtype[3, gid["fingertip2"]] = 6
+    size[3, gid["fingertip1"]] = [0.012, 0.012, 0.012]
+    size[3, gid["fingertip2"]] = [0.012, 0.012, 0.012]
+    b = engine.Batch(engine.CompiledModel(base), nenv)
+    b.set("qpos", qpos)
+    b.set("qvel", qvel)
+    b.set_env_geom_size(size[1:4], 1, 4)
+    b.set_env_geom_type(gtype[2:4], 2, 4)
+    b.forward()
+    ncon, geom, dist, qacc = b.get("ncon"), b.get("contact_geom"), b.get("contact_dist"), b.get("qacc")
+    d = oracle_built.OracleData(base)
+    plain = []
+    for e in range(nenv):
+        d.set_geom_size(size[e] if 1 <= e < 4 else None)
+        d.set_geom_type(gtype[e] if 2 <= e < 4 else None)
+        d.reset(); d.qpos[:] = qpos[e]; d.qvel[:] = qvel[e]; d.forward()
+        n = int(d.ncon[0])
+        assert ncon[e, 0] == n, f"env {e}: {ncon[e, 0]} vs {n} contacts"
+        assert np.array_equal(geom[e][:2 * n], d.contact_geom[:2 * n])
+        assert np.allclose(dist[e][:n], d.contact_dist[:n], rtol=0, atol=1e-11)
+        assert np.allclose(qacc[e], d.qacc, rtol=1e-6, atol=1e-6 * (1 + np.abs(d.qacc).max()))
+        d.set_geom_size(None); d.set_geom_type(None)
+        d.reset(); d.qpos[:] = qpos[e]; d.qvel[:] = qvel[e]; d.forward()
+        plain.append(d.contact_dist[:int(d.ncon[0])].copy())
+    # the bigger cube of env 1 sits deeper in the table than the model's cube would
+    assert dist[1][:4].min() < plain[1][:4].min() - 0.005
+    b.step(20)
+    for e in (1, 2, 3):
+        d.set_geom_size(size[e]); d.set_geom_type(gtype[e] if e >= 2 else None)
+        d.reset(); d.qpos[:] = qpos[e]; d.qvel[:] = qvel[e]
+        d.step(20)
+        assert np.allclose(b.get("qpos")[e], d.qpos, rtol=0, atol=1e-6), f"env {e} rollout"
+    with pytest.raises(engine.EngineError):
+        b.set_env_geom_type(np.full((1, ng), 7, np.int32), 0, 1)   # mesh
+    b.close()
