@@ -77,6 +77,11 @@ int mjr_env_delete_param(mjr_env *e, const char *key);
 /* queue a model (settings_.load_request = 2, main.cpp:150-151); factory NULL = the HIP engine */
 int mjr_env_queue_model(mjr_env *e, const mjb_model_desc *desc, const mjr_names *names, int nenv, int device,
                         mjr_backend_factory factory, void *factory_user);
+/* The same with the batch sharded over several GPUs of the node: env block i of ndev contiguous blocks lives on
+ * devices[i] (a device may be listed more than once); one backend per block behind one composite mjr_backend, launches issued to
+ * all blocks before any is waited for, the ctrl-noise stream keyed by the GLOBAL env index.  The model is replicated. */
+int mjr_env_queue_model_devices(mjr_env *e, const mjb_model_desc *desc, const mjr_names *names, int nenv, const int *devices,
+                                int ndev, mjr_backend_factory factory, void *factory_user);
 int mjr_env_start(mjr_env *e);    /* startPhysicsLoop + startEventLoop (main.cpp:154-155) */
 int mjr_env_shutdown(mjr_env *e); /* exit_request = 1, join both threads                   */
 

@@ -336,35 +336,11 @@ DEVI int box_box(RawCon *rc, const double *pos1, const double *mat1, const doubl
 			nk++;
 		}
 	if (nk == 0) return 0;
-	int pick[4] = { 0, 0, 0, 0 }, npick = 0;
-	if (nk <= 4) {
-		for (int w = 0; w < nk; w++) pick[npick++] = w;
-	} else {
-		int a = 0;
-		for (int w = 1; w < nk; w++)
-			if (tmp[w][2] < tmp[a][2]) a = w;
-		int b = a;
-		double far = -1;
-		for (int w = 0; w < nk; w++) {
-			const double dx = tmp[w][0] - tmp[a][0], dy = tmp[w][1] - tmp[a][1], dd = dx * dx + dy * dy;
-			if (dd > far) { far = dd; b = w; }
-		}
-		int cpos = -1, cneg = -1;
-		double apos = 0, aneg = 0;
-		for (int w = 0; w < nk; w++) {
-			if (w == a || w == b) continue;
-			const double cr = (tmp[b][0] - tmp[a][0]) * (tmp[w][1] - tmp[a][1]) - (tmp[b][1] - tmp[a][1]) * (tmp[w][0] - tmp[a][0]);
-			if (cr > apos) { apos = cr; cpos = w; }
-			if (cr < aneg) { aneg = cr; cneg = w; }
-		}
-		pick[npick++] = a;
-		pick[npick++] = b;
-		if (cpos >= 0) pick[npick++] = cpos;
-		if (cneg >= 0) pick[npick++] = cneg;
-	}
-	for (int w = 0; w < 4; w++) {
+	// every clipped vertex within the margin is a contact: up to 8, as mjc_BoxBox returns
+	const int npick = nk < 8 ? nk : 8;
+	for (int w = 0; w < 8; w++) {
 		if (w >= npick) break;
-		const double *pv = tmp[pick[w]];
+		const double *pv = tmp[w];
 		RawCon c;
 		c.dist = pv[2];
 		for (int q = 0; q < 3; q++) c.frame[q] = ref1 ? nref[q] : -nref[q];
@@ -374,12 +350,16 @@ DEVI int box_box(RawCon *rc, const double *pos1, const double *mat1, const doubl
 		if (w == 0) rc[0] = c;
 		else if (w == 1) rc[1] = c;
 		else if (w == 2) rc[2] = c;
-		else rc[3] = c;
+		else if (w == 3) rc[3] = c;
+		else if (w == 4) rc[4] = c;
+		else if (w == 5) rc[5] = c;
+		else if (w == 6) rc[6] = c;
+		else rc[7] = c;
 	}
 	return npick;
 }
 
-// narrow phase of one candidate pair; returns the number of raw contacts (<= 4)
+// narrow phase of one candidate pair; returns the number of raw contacts (<= 4; box - box: <= 8)
 DEVI int narrowphase(int t1, int t2, const double *pos1, const double *mat1, const double *size1, const double *pos2,
                      const double *mat2, const double *size2, double margin, RawCon *rc)
 {
@@ -516,7 +496,7 @@ DEVI int lanes_below(unsigned long long mask)
 
 // Everything the two geoms' constants decide (types, sizes, margin, bounding radii, mj_contactParam's mixing of condim /
 // solref / solimp) comes from the host-built per-pair record: one level of memory latency per step instead of the
-// pair -> geom -> attribute chain.  Contact slots are assigned without LDS: a pair yields <= 4 contacts, so its offset is
+// pair -> geom -> attribute chain.  Contact slots are assigned without LDS: a pair yields <= 8 contacts, so its offset is
 // sum_k popcount(ballot(n >= k) below this lane).
 template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &e)
 {
@@ -535,7 +515,7 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 	int base = 0;  // contacts of the earlier rounds (wave-uniform)
 	for (int p0 = 0; p0 < m.ncollpair; p0 += G) {
 		const int p = p0 + lane;
-		RawCon rc[4];
+		RawCon rc[8];
 		int n = 0, g1 = 0, g2 = 0, condim = 1, frisel = 0;
 		double margin = 0, incl = 0;
 		const mjb_cdptr pd = m.pair_d + 24 * (p < m.ncollpair ? p : 0);
@@ -606,7 +586,7 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 #endif
 		int off = base, total = 0;
 #pragma unroll
-		for (int k = 1; k <= 4; k++) {
+		for (int k = 1; k <= 8; k++) {
 			const unsigned long long mk = __ballot(n >= k);
 			off += lanes_below(mk);
 			total += __popcll(mk);
@@ -617,7 +597,7 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 				const double a = f[L.gfriction + 3 * g1 + k], b = f[L.gfriction + 3 * g2 + k];
 				fri[k] = frisel == 0 ? fmax(a, b) : (frisel == 1 ? a : b);
 			}
-			for (int i = 0; i < 4; i++) {
+			for (int i = 0; i < 8; i++) {
 				if (i >= n) break;
 				const int c = off + i;
 				if (c >= m.nconmax) break;

@@ -1,6 +1,7 @@
 // host_c_api.cpp — flat C face of mujoco_ros::MujocoEnv (include/mjr_host.h) + the libmjb-backed stepper.
 #include <cstring>
 #include <map>
+#include <algorithm>
 #include <string>
 
 #include "mujoco_env.h"
@@ -45,8 +46,148 @@ void be_destroy(void *s)
 }
 }  // namespace
 
+// ---- composite backend: one child backend per env block / device --------------------------------------
+struct ShardCfg {
+	mjr_backend_factory inner = nullptr;
+	void *inner_user = nullptr;
+	std::vector<int> devices;
+};
+struct Sharded {
+	std::vector<mjr_backend *> kid;
+	std::vector<int> lo;  // first env of every block, plus the total at the end
+	std::string err;
+	mjr_backend vt{};
+};
+#define SH(self) (static_cast<Sharded *>(self))
+template <typename F> int sh_each(Sharded *s, F fn)
+{
+	for (size_t k = 0; k < s->kid.size(); k++) {
+		const int rc = fn(s->kid[k], (int)k);
+		if (rc) {
+			s->err = s->kid[k]->last_error(s->kid[k]->self);
+			return rc;
+		}
+	}
+	return 0;
+}
+// [lo, hi) of the whole batch -> per-block sub-ranges
+template <typename F> int sh_range(Sharded *s, int lo, int hi, F fn)
+{
+	for (size_t k = 0; k < s->kid.size(); k++) {
+		const int a = std::max(lo, s->lo[k]), b = std::min(hi, s->lo[k + 1]);
+		if (a >= b) continue;
+		const int rc = fn(s->kid[k], a - s->lo[k], b - s->lo[k], a - lo);
+		if (rc) {
+			s->err = s->kid[k]->last_error(s->kid[k]->self);
+			return rc;
+		}
+	}
+	return 0;
+}
+int sh_nenv(void *s) { return SH(s)->lo.back(); }
+int sh_field_size(void *s, int f) { return SH(s)->kid[0]->field_size(SH(s)->kid[0]->self, f); }
+int sh_sync(void *s) { return sh_each(SH(s), [](mjr_backend *k, int) { return k->synchronize(k->self); }); }
+int sh_step(void *s, int n)
+{
+	// every block's launch is enqueued before any block is waited for
+	int rc = sh_each(SH(s), [&](mjr_backend *k, int) { return k->step_async ? k->step_async(k->self, n) : k->step(k->self, n); });
+	return rc ? rc : sh_sync(s);
+}
+int sh_step_async(void *s, int n)
+{
+	return sh_each(SH(s), [&](mjr_backend *k, int) { return k->step_async ? k->step_async(k->self, n) : k->step(k->self, n); });
+}
+int sh_step1(void *s) { return sh_each(SH(s), [](mjr_backend *k, int) { return k->step1(k->self); }); }
+int sh_step2(void *s) { return sh_each(SH(s), [](mjr_backend *k, int) { return k->step2(k->self); }); }
+int sh_forward(void *s) { return sh_each(SH(s), [](mjr_backend *k, int) { return k->forward(k->self); }); }
+int sh_reset(void *s, const uint8_t *m)
+{
+	return sh_each(SH(s), [&](mjr_backend *k, int i) { return k->reset(k->self, m ? m + SH(s)->lo[i] : nullptr); });
+}
+int sh_get(void *s, int f, int lo, int hi, double *h)
+{
+	const int sz = sh_field_size(s, f);
+	return sh_range(SH(s), lo, hi, [&](mjr_backend *k, int a, int b, int off) { return k->get(k->self, f, a, b, h + (size_t)off * sz); });
+}
+int sh_set(void *s, int f, int lo, int hi, const double *h)
+{
+	const int sz = sh_field_size(s, f);
+	return sh_range(SH(s), lo, hi, [&](mjr_backend *k, int a, int b, int off) { return k->set(k->self, f, a, b, h + (size_t)off * sz); });
+}
+int sh_get_many(void *s, int n, const int *f, int lo, int hi, double *const *h)
+{
+	return sh_range(SH(s), lo, hi, [&](mjr_backend *k, int a, int b, int off) {
+		std::vector<double *> p(n);
+		for (int q = 0; q < n; q++) p[q] = h[q] + (size_t)off * std::max(0, sh_field_size(s, f[q]));
+		if (k->get_many) return k->get_many(k->self, n, f, a, b, p.data());
+		for (int q = 0; q < n; q++)
+			if (int rc = k->get(k->self, f[q], a, b, p[q])) return rc;
+		return 0;
+	});
+}
+int sh_set_many(void *s, int n, const int *f, int lo, int hi, const double *const *h)
+{
+	return sh_range(SH(s), lo, hi, [&](mjr_backend *k, int a, int b, int off) {
+		std::vector<const double *> p(n);
+		for (int q = 0; q < n; q++) p[q] = h[q] + (size_t)off * std::max(0, sh_field_size(s, f[q]));
+		if (k->set_many) return k->set_many(k->self, n, f, a, b, p.data());
+		for (int q = 0; q < n; q++)
+			if (int rc = k->set(k->self, f[q], a, b, p[q])) return rc;
+		return 0;
+	});
+}
+int sh_noise(void *s, double a, double b, uint64_t seed, int64_t off)
+{
+	// the Philox stream is keyed by the global env index: block i starts at off + lo[i]
+	return sh_each(SH(s), [&](mjr_backend *k, int i) { return k->set_ctrl_noise(k->self, a, b, seed, off + SH(s)->lo[i]); });
+}
+int sh_host_register(void *s, void *h, unsigned long long bytes)
+{
+	mjr_backend *k = SH(s)->kid[0];
+	return k->host_register ? k->host_register(k->self, h, bytes) : -1;
+}
+int sh_host_unregister(void *s, void *h)
+{
+	mjr_backend *k = SH(s)->kid[0];
+	return k->host_unregister ? k->host_unregister(k->self, h) : 0;
+}
+int sh_register_collision(void *s, int t1, int t2, int fn)
+{
+	return sh_each(SH(s), [&](mjr_backend *k, int) { return k->register_collision ? k->register_collision(k->self, t1, t2, fn) : -1; });
+}
+const char *sh_err(void *s) { return SH(s)->err.c_str(); }
+void sh_destroy(void *s)
+{
+	for (mjr_backend *k : SH(s)->kid) k->destroy(k->self);
+	delete SH(s);
+}
+mjr_backend *sharded_factory(const mjb_model_desc *desc, int nenv, int, void *user)
+{
+	const ShardCfg *cfg = static_cast<const ShardCfg *>(user);
+	const int nd = (int)cfg->devices.size();
+	Sharded *sh = new Sharded;
+	sh->lo.push_back(0);
+	for (int i = 0; i < nd; i++) {
+		const int n = nenv / nd + (i < nenv % nd ? 1 : 0);  // contiguous blocks, the remainder on the first ones
+		if (n == 0) continue;
+		mjr_backend *k = cfg->inner(desc, n, cfg->devices[i], cfg->inner_user);
+		if (!k) {
+			for (mjr_backend *q : sh->kid) q->destroy(q->self);
+			delete sh;
+			return nullptr;
+		}
+		sh->kid.push_back(k);
+		sh->lo.push_back(sh->lo.back() + n);
+	}
+	sh->vt = mjr_backend{ sh, sh_nenv, sh_field_size, sh_step, sh_step1, sh_step2, sh_forward, sh_reset, sh_get, sh_set, sh_noise,
+		                  sh_sync, sh_err, sh_destroy, sh_get_many, sh_set_many, sh_host_register, sh_host_unregister, sh_step_async,
+		                  sh_register_collision };
+	return &sh->vt;
+}
+
 struct mjr_env {
 	MujocoEnv *env = nullptr;
+	ShardCfg shard;  // device list of the last mjr_env_queue_model_devices (must outlive the queued factory call)
 };
 
 extern "C" {
@@ -134,6 +275,16 @@ int mjr_env_queue_model(mjr_env *e, const mjb_model_desc *desc, const mjr_names 
 	}
 	e->env->queueModel(desc, n, nenv, device, factory, factory_user);
 	return 0;
+}
+
+int mjr_env_queue_model_devices(mjr_env *e, const mjb_model_desc *desc, const mjr_names *names, int nenv, const int *devices, int ndev,
+                                mjr_backend_factory factory, void *factory_user)
+{
+	if (!e || !desc || !devices || ndev <= 0 || nenv < ndev) return -1;
+	e->shard.inner = factory ? factory : mjr_make_mjb_backend;
+	e->shard.inner_user = factory_user;
+	e->shard.devices.assign(devices, devices + ndev);
+	return mjr_env_queue_model(e, desc, names, nenv, devices[0], sharded_factory, &e->shard);
 }
 
 int mjr_env_start(mjr_env *e)

@@ -50,6 +50,7 @@ def load_library():
         "mjr_env_set_param": (ci, [vp, cs, cs]),
         "mjr_env_delete_param": (ci, [vp, cs]),
         "mjr_env_queue_model": (ci, [vp, C.POINTER(binding.ModelDesc), C.POINTER(Names), ci, ci, vp, vp]),
+        "mjr_env_queue_model_devices": (ci, [vp, C.POINTER(binding.ModelDesc), C.POINTER(Names), ci, C.POINTER(ci), ci, vp, vp]),
         "mjr_env_start": (ci, [vp]),
         "mjr_env_shutdown": (ci, [vp]),
         "mjr_env_operational_status": (ci, [vp]),
@@ -104,7 +105,8 @@ class HostEnv:
         self.model = None
 
     # ---- model
-    def queue_model(self, model, nenv=1, device=0, backend_factory=None):
+    def queue_model(self, model, nenv=1, device=0, backend_factory=None, devices=None):
+        """``devices``: shard the batch over these devices (contiguous env blocks, one backend each)."""
         desc, keep = binding.make_desc(model)
         names = Names()
         for kind in ("body", "joint", "geom", "site", "sensor", "actuator"):
@@ -115,7 +117,11 @@ class HostEnv:
         self._keep += [desc, keep, names]
         self.model = model
         fac = C.cast(backend_factory, C.c_void_p) if backend_factory is not None else None
-        rc = self.L.mjr_env_queue_model(self.ptr, C.byref(desc), C.byref(names), nenv, device, fac, None)
+        if devices is not None:
+            dv = (C.c_int * len(devices))(*[int(x) for x in devices])
+            rc = self.L.mjr_env_queue_model_devices(self.ptr, C.byref(desc), C.byref(names), nenv, dv, len(devices), fac, None)
+        else:
+            rc = self.L.mjr_env_queue_model(self.ptr, C.byref(desc), C.byref(names), nenv, device, fac, None)
         if rc != 0:
             raise RuntimeError("queue_model failed")
 

@@ -1090,7 +1090,7 @@ def _max_contacts(t1, t2):
     table = {
         (GEOM_PLANE, GEOM_SPHERE): 1, (GEOM_PLANE, GEOM_CAPSULE): 2, (GEOM_PLANE, GEOM_BOX): 4,
         (GEOM_SPHERE, GEOM_SPHERE): 1, (GEOM_SPHERE, GEOM_CAPSULE): 1, (GEOM_SPHERE, GEOM_BOX): 1,
-        (GEOM_CAPSULE, GEOM_CAPSULE): 2, (GEOM_CAPSULE, GEOM_BOX): 2, (GEOM_BOX, GEOM_BOX): 4,
+        (GEOM_CAPSULE, GEOM_CAPSULE): 2, (GEOM_CAPSULE, GEOM_BOX): 2, (GEOM_BOX, GEOM_BOX): 8,
     }
     return table.get((int(t1), int(t2)), 0)
 

@@ -456,32 +456,9 @@ static int box_box(rawcon *c, const double *pos1, const double *mat1, const doub
 			nk++;
 		}
 	if (nk == 0) return 0;
-	int pick[4], npick = 0;
-	if (nk <= 4) {
-		for (int w = 0; w < nk; w++) pick[npick++] = w;
-	} else {
-		int a = 0;
-		for (int w = 1; w < nk; w++)
-			if (tmp[w][2] < tmp[a][2]) a = w;
-		int b = a;
-		double far = -1;
-		for (int w = 0; w < nk; w++) {
-			double dx = tmp[w][0] - tmp[a][0], dy = tmp[w][1] - tmp[a][1], dd = dx * dx + dy * dy;
-			if (dd > far) { far = dd; b = w; }
-		}
-		int cpos = -1, cneg = -1;
-		double apos = 0, aneg = 0;
-		for (int w = 0; w < nk; w++) {
-			if (w == a || w == b) continue;
-			double cr = (tmp[b][0] - tmp[a][0]) * (tmp[w][1] - tmp[a][1]) - (tmp[b][1] - tmp[a][1]) * (tmp[w][0] - tmp[a][0]);
-			if (cr > apos) { apos = cr; cpos = w; }
-			if (cr < aneg) { aneg = cr; cneg = w; }
-		}
-		pick[npick++] = a;
-		pick[npick++] = b;
-		if (cpos >= 0) pick[npick++] = cpos;
-		if (cneg >= 0) pick[npick++] = cneg;
-	}
+	/* every clipped vertex within the margin is a contact: up to 8, as mjc_BoxBox returns */
+	int pick[8], npick = 0;
+	for (int w = 0; w < nk && w < 8; w++) pick[npick++] = w;
 	/* geom1 -> geom2 normal */
 	double nrm[3];
 	for (int q = 0; q < 3; q++) nrm[q] = ref1 ? nref[q] : -nref[q];
@@ -584,7 +561,7 @@ void mjo_collision(const mjb_model_desc *m, mjo_data *d)
 			v3_sub(dv, pos2, pos1);
 			if (v3_dot(dv, n) > margin + rb2) continue;
 		}
-		rawcon rc[4];
+		rawcon rc[8];
 		int n = 0;
 		const int cfun = d->colfunc[8 * t1 + t2]; /* registerCollisionFunction override (pairs are stored with t1 <= t2) */
 		if (cfun == MJB_COLFUNC_NONE) continue;

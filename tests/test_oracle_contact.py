@@ -365,7 +365,18 @@ def test_box_box_known_answers(oracle_built):
         '<body name="slab" pos="0 0 0">', '<body name="slab" pos="0 0 0" euler="0.7853981633974483 0 0">'))
     d = oracle_built.OracleData(m)
     d.forward()
-    assert d.ncon[0] <= 4  # geometry-dependent count; the interesting assertions are the physical ones below
+    assert d.ncon[0] <= 8  # geometry-dependent count; the interesting assertions are the physical ones below
+    # a slab no bigger than the box, the box yawed by 45 degrees: the two rectangles overlap in an octagon -- all EIGHT clipped
+    # vertices are contacts (mjc_BoxBox returns up to 8; no reduction to 4)
+    d = oracle_built.OracleData(_boxbox("0 0 0.109", f'euler="0 0 {np.pi / 4}"', bx=0.09, by=0.09))
+    d.forward()
+    n, dist, pos, frame = contacts(d)
+    assert n == 8 and np.allclose(dist, -0.001, atol=1e-12)
+    assert np.all(np.abs(pos[:, :2]).max(axis=1) <= 0.09 + 1e-9)                    # inside the slab's face ...
+    ang = np.pi / 4
+    loc = pos[:, :2] @ np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+    assert np.all(np.abs(loc[:, 0]) <= 0.1 + 1e-9) and np.all(np.abs(loc[:, 1]) <= 0.08 + 1e-9)   # ... and inside the box's
+    assert len({tuple(r) for r in np.round(pos[:, :2], 9)}) == 8
     # out of reach
     d = oracle_built.OracleData(_boxbox("0 0 0.12"))
     d.forward()
