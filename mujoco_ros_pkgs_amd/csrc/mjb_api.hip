@@ -222,7 +222,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	off += d.nM;
 	L.qHdi = off;
 	off += d.nv;
-	const bool need_tri = d.nefcmax > 0 && d.solver == MJB_SOL_PGS && d.nv <= 16;
+	const bool need_tri = (d.nefcmax > 0 && d.solver == MJB_SOL_PGS && d.nv <= 16) || d.nconmax > 0;  // (128-double transient scratch)
 	const int n_kin = 7 * d.nbody, n_crb = 10 * d.nbody, n_buf = 6 * d.nv < 32 ? 32 : 6 * d.nv, n_c6 = 6 * d.nbody;  // (crbbuf doubles as the 32-double pivot-row scratch of the dense factor)
 	if (compact) {
 		const int a0 = off;
@@ -234,7 +234,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		L.eulerx = a0;
 		L.tri = a0;  // (alive only inside project_constraint_dense16, between the factorisation and comVel)
 		int sz = n_kin;
-		if (need_tri && sz < 120) sz = 120;
+		if (need_tri && sz < 128) sz = 128;
 		if (n_crb + n_buf > sz) sz = n_crb + n_buf;
 		if (2 * n_c6 > sz) sz = 2 * n_c6;
 		if (d.nv > sz) sz = d.nv;
@@ -256,7 +256,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		L.eulerx = off;
 		off += d.nv;
 		L.tri = off;
-		off += need_tri ? 120 : 0;
+		off += need_tri ? 128 : 0;
 	}
 	if (off & 1) off++;
 	L.ndouble = off;

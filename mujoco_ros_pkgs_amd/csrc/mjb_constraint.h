@@ -188,9 +188,14 @@ DEVI int capsule_box(RawCon *rc, const double *pos1, const double *mat1, const d
 
 // box - box: same steps as oracle/mjo_constraint.c box_box (separating axes, then either the incident face clipped
 // against the reference face -- up to 4 contacts after reduction -- or one edge-edge contact)
-DEVI int box_box(RawCon *rc, const double *pos1, const double *mat1, const double *size1, const double *pos2,
+// The clipping polygons are indexed dynamically: they (and the up to 8 output contacts, 10 doubles each: dist, pos, normal +
+// tangent hint) live in a 128-double LDS scratch `scr` that ONE lane at a time owns (collision() serialises the box - box
+// lanes) -- private arrays indexed that way would sit in scratch memory and drag every pair's contact registers there too.
+DEVI int box_box(double *scr, const double *pos1, const double *mat1, const double *size1, const double *pos2,
                  const double *mat2, const double *size2, double margin)
 {
+	double (*poly)[3] = reinterpret_cast<double (*)[3]>(scr), (*tmp)[3] = reinterpret_cast<double (*)[3]>(scr + 24);
+	double *out = scr + 48;
 	double A[3][3], B[3][3], C[3][3], Q[3][3], tA[3], tB[3];
 	for (int i = 0; i < 3; i++)
 		for (int k = 0; k < 3; k++) {
@@ -263,12 +268,14 @@ DEVI int box_box(RawCon *rc, const double *pos1, const double *mat1, const doubl
 			xb[q] = pb[q] + be * B[j][q];
 		}
 		const double dv[3] = { xb[0] - xa[0], xb[1] - xa[1], xb[2] - xa[2] };
-		RawCon &c = rc[0];
-		c.dist = dot3(dv, n);
-		if (c.dist > margin) return 0;
-		c.frame[0] = n[0]; c.frame[1] = n[1]; c.frame[2] = n[2];
-		c.frame[3] = c.frame[4] = c.frame[5] = 0;
-		for (int q = 0; q < 3; q++) c.pos[q] = 0.5 * (xa[q] + xb[q]);
+		const double dist = dot3(dv, n);
+		if (dist > margin) return 0;
+		out[0] = dist;
+		for (int q = 0; q < 3; q++) {
+			out[1 + q] = 0.5 * (xa[q] + xb[q]);
+			out[4 + q] = n[q];
+			out[7 + q] = 0;
+		}
 		return 1;
 	}
 	const bool ref1 = code < 3;
@@ -297,7 +304,6 @@ DEVI int box_box(RawCon *rc, const double *pos1, const double *mat1, const doubl
 	}
 	const double fs = dot3(O[k], nref) > 0 ? -1.0 : 1.0;
 	const int u = (k + 1) % 3, v = (k + 2) % 3, sx = (ax + 1) % 3, sy = (ax + 2) % 3;
-	double poly[8][3], tmp[8][3];
 	int np = 4;
 	for (int w = 0; w < 4; w++) {
 		const double su = (w == 0 || w == 3) ? 1.0 : -1.0, sv = (w < 2) ? 1.0 : -1.0;
@@ -338,23 +344,16 @@ DEVI int box_box(RawCon *rc, const double *pos1, const double *mat1, const doubl
 	if (nk == 0) return 0;
 	// every clipped vertex within the margin is a contact: up to 8, as mjc_BoxBox returns
 	const int npick = nk < 8 ? nk : 8;
-	for (int w = 0; w < 8; w++) {
-		if (w >= npick) break;
-		const double *pv = tmp[w];
-		RawCon c;
-		c.dist = pv[2];
-		for (int q = 0; q < 3; q++) c.frame[q] = ref1 ? nref[q] : -nref[q];
-		c.frame[3] = c.frame[4] = c.frame[5] = 0;
+	for (int w = 0; w < npick; w++) {
+		const double pv[3] = { tmp[w][0], tmp[w][1], tmp[w][2] };
+		double *o = out + 10 * w;
+		o[0] = pv[2];
 		const double hgt = hr[ax] + 0.5 * pv[2];
-		for (int q = 0; q < 3; q++) c.pos[q] = pr[q] + pv[0] * R[sx][q] + pv[1] * R[sy][q] + hgt * nref[q];
-		if (w == 0) rc[0] = c;
-		else if (w == 1) rc[1] = c;
-		else if (w == 2) rc[2] = c;
-		else if (w == 3) rc[3] = c;
-		else if (w == 4) rc[4] = c;
-		else if (w == 5) rc[5] = c;
-		else if (w == 6) rc[6] = c;
-		else rc[7] = c;
+		for (int q = 0; q < 3; q++) {
+			o[1 + q] = pr[q] + pv[0] * R[sx][q] + pv[1] * R[sy][q] + hgt * nref[q];
+			o[4 + q] = ref1 ? nref[q] : -nref[q];
+			o[7 + q] = 0;
+		}
 	}
 	return npick;
 }
@@ -424,8 +423,6 @@ DEVI int narrowphase(int t1, int t2, const double *pos1, const double *mat1, con
 		}
 	} else if (t1 == MJB_GEOM_CAPSULE && t2 == MJB_GEOM_BOX) {
 		n = capsule_box(rc, pos1, mat1, size1, pos2, mat2, size2, margin);
-	} else if (t1 == MJB_GEOM_BOX && t2 == MJB_GEOM_BOX) {
-		n = box_box(rc, pos1, mat1, size1, pos2, mat2, size2, margin);
 	} else if (t1 == MJB_GEOM_CAPSULE && t2 == MJB_GEOM_CAPSULE) {
 		const double a1[3] = { mat1[2], mat1[5], mat1[8] }, a2[3] = { mat2[2], mat2[5], mat2[8] };
 		const double dif[3] = { pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2] };
@@ -519,6 +516,9 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 		int n = 0, g1 = 0, g2 = 0, condim = 1, frisel = 0;
 		double margin = 0, incl = 0;
 		const mjb_cdptr pd = m.pair_d + 24 * (p < m.ncollpair ? p : 0);
+		bool boxbox = false;  // an un-culled box - box pair: narrow phase below, one lane at a time
+		double pos1[3], pos2[3], mat1[9], mat2[9];
+		double size1[3] = { pd[0], pd[1], pd[2] }, size2[3] = { pd[3], pd[4], pd[5] };
 		if (p < m.ncollpair) {
 			const mjb_ciptr pi = m.pair_i + 8 * p;
 			g1 = pi[0];
@@ -526,8 +526,6 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 			int t1 = pi[2], t2 = pi[3];
 			condim = pi[4];
 			frisel = pi[5];
-			double pos1[3], pos2[3], mat1[9], mat2[9];
-			double size1[3] = { pd[0], pd[1], pd[2] }, size2[3] = { pd[3], pd[4], pd[5] };
 			margin = pd[6];
 			incl = pd[17];
 			double rb1 = pd[8], rb2 = pd[9];
@@ -570,7 +568,8 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 			if (!cull) {
 				const int cfun = pi[6];  // MujocoEnv::registerCollisionFunction's override of the pair type (mjb_register_collision)
 				if (cfun == MJB_COLFUNC_DEFAULT) {
-					n = narrowphase(t1, t2, pos1, mat1, size1, pos2, mat2, size2, margin, rc);
+					if (t1 == MJB_GEOM_BOX && t2 == MJB_GEOM_BOX) boxbox = true;
+					else n = narrowphase(t1, t2, pos1, mat1, size1, pos2, mat2, size2, margin, rc);
 				} else if (cfun == MJB_COLFUNC_SPHERES) {
 					if (t1 == MJB_GEOM_PLANE) {
 						const double nrm[3] = { mat1[2], mat1[5], mat1[8] };
@@ -579,6 +578,24 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 						n = raw_sphere_sphere(rc[0], pos1, rb1, pos2, rb2, margin);
 					}
 				}  // MJB_COLFUNC_NONE: no contacts
+			}
+		}
+		{
+			unsigned long long bbmask = __ballot(boxbox);
+			while (bbmask) {  // (wave-uniform) the lanes with a live box - box pair take turns at the LDS scratch
+				const int l = __builtin_ctzll(bbmask);
+				bbmask &= bbmask - 1;
+				if (lane == l) {
+					double *scr = f + L.tri;  // (transient scratch: nothing else of the frame's shared region is alive during collision)
+					n = box_box(scr, pos1, mat1, size1, pos2, mat2, size2, margin);
+#pragma unroll
+					for (int i = 0; i < 8; i++) {
+						const double *o = scr + 48 + 10 * (i < n ? i : 0);
+						rc[i].dist = o[0];
+						for (int k = 0; k < 3; k++) rc[i].pos[k] = o[1 + k];
+						for (int k = 0; k < 6; k++) rc[i].frame[k] = o[4 + k];
+					}
+				}
 			}
 		}
 #ifdef MJB_PROFILE_SUB
@@ -597,10 +614,10 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 				const double a = f[L.gfriction + 3 * g1 + k], b = f[L.gfriction + 3 * g2 + k];
 				fri[k] = frisel == 0 ? fmax(a, b) : (frisel == 1 ? a : b);
 			}
-			for (int i = 0; i < 8; i++) {
-				if (i >= n) break;
+#pragma unroll
+			for (int i = 0; i < 8; i++) {  // (fully unrolled, no early exit: rc[] stays in statically indexed registers)
 				const int c = off + i;
-				if (c >= m.nconmax) break;
+				if (i >= n || c >= m.nconmax) continue;
 				double fr[9];
 				for (int k = 0; k < 6; k++) fr[k] = rc[i].frame[k];
 				make_frame(fr);

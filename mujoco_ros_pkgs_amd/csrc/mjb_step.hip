@@ -1985,9 +1985,10 @@ template <int G> STAGE void ctrl_noise(CModel m, CLayout L, CNoise nz, const Env
 // Constrained kernels get the full 512-register budget (1 block of 256 per CU by registers; their frames limit the
 // CU to 1 - 4 envs anyway): no spills, and room for the register-resident AR rows / Hessian rows of the solvers.
 // ROCm 7.2's LLVM can place a spill ahead of an exec restore and lose lanes (tools/check_spill_exec.py, `make lint`
-// guards every build): an earlier revision had to cap these kernels at 256 VGPRs because of it.
+// guards every build): an earlier revision had to cap these kernels at 256 VGPRs because of it, and the CG variants (CON >= 6,
+// not a BASELINE workload) still are -- at 512 the allocator produced exactly that pattern in the 2-rows-per-lane CG kernel.
 template <int G, int CON, int DENSE>
-__global__ void __launch_bounds__(256, (CON ? 1 : (G == 64 ? 4 : (G == 32 ? 2 : 1))))
+__global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? 1 : (G == 64 ? 4 : (G == 32 ? 2 : 1)))))
     mjb_step_kernel(const KernelParams MJB_AS4 *__restrict__ P, const int mode, const int nsteps,
                     const unsigned int step0, const int epb, const int frame_bytes)
 {
