@@ -126,6 +126,11 @@ int mjb_field_is_state(int field);
 const char *mjb_field_name(int field);
 /* Doubles in one per-env LDS frame (all double fields) — layout documented in DESIGN.md. */
 int mjb_frame_doubles(const mjb_model *m);
+/* Bytes of LDS one env occupies (doubles + ints): fused != 0 -> the compact frame of mjb_step, else the full frame of
+ * mjb_forward / mjb_step1 / mjb_step2.  Resident envs per CU = floor(160 KiB / that). */
+int mjb_frame_bytes(const mjb_model *m, int fused);
+/* Diagnostic: offset (doubles; ints for int fields; -1 = absent) of data field `field` in the fused / full frame. */
+int mjb_frame_offset(const mjb_model *m, int field, int fused);
 
 /* Allocate N env instances on HIP device `device`, all at the reset state (qpos = qpos0).
  * Takes the place of `mj_makeData` (mujoco_env.cpp:872), once per env. */

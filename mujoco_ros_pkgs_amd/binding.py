@@ -141,6 +141,8 @@ def load_library(path=None):
         "mjb_field_is_state": (ci, [ci]),
         "mjb_field_name": (C.c_char_p, [ci]),
         "mjb_frame_doubles": (ci, [vp]),
+        "mjb_frame_bytes": (ci, [vp, ci]),
+        "mjb_frame_offset": (ci, [vp, ci, ci]),
         "mjb_make_batch": (vp, [vp, ci, ci]),
         "mjb_free_batch": (None, [vp]),
         "mjb_nenv": (ci, [vp]),

@@ -81,7 +81,7 @@ struct mjb_model {
 	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense, body_anc, dof_bodymask;
 	std::vector<int> sens_copy, sens_slow, dof_act_adr, dof_act_id;
 	std::vector<int> pair_i;       // [ncollpair][8]  per candidate pair: g1, g2, type1, type2, condim, friction rule, collision-function override, 0
-	std::vector<double> pair_d;    // [ncollpair][24] size1[3] size2[3] margin gap rbound1 rbound2 solref[2] solimp[5] includemargin pad[7]
+	std::vector<double> pair_d;    // [ncollpair][24] size1[3] size2[3] margin gap rbound1 rbound2 solref[2] solimp[5] includemargin friction[3] pad[3]
 	int sens_ncopy[3] = { 0, 0, 0 }, sens_nslow[3] = { 0, 0, 0 }, sens_ncopy_max = 0;
 	int eulerdamp = 0, maxdepth = 0, kin_rounds = 0, need_rnepost = 0, nfriction = 0;
 	int field_size[MJB_F_COUNT]{};
@@ -133,6 +133,16 @@ namespace {
 //   region A: kinloc (kinematics)  |  crb + crbbuf (crb)  |  cacc + cfrc_body (rne)  |  eulerx (euler)
 //   region B: ximat (kinematics -> comPos)  |  cvel + cdof_dot (comVel -> rne / vel sensors)
 // which brings the Franka frame from 12.6 KB to 9.3 KB, i.e. from 12 to 16 resident envs per CU.
+//
+// compact AND constrained (nefcmax > 0) -- "lean": the fused step builds the constraint rows AFTER the velocity stage (nothing
+// between collision and the solver reads them; the kernel defers make_constraint whenever it runs on this layout), so
+//   * efc_J overlays everything that is dead by then (region U): regions A and B, cinert, geom_xpos / geom_xmat, xanchor / xaxis,
+//     site_xquat and -- without equalities -- xmat / xquat   [only when no sensor needs rne_post, which re-reads them];
+//   * row bookkeeping shrinks to what the solver reads: efc_pos / efc_margin / efc_KBIP / efc_vel are gone (efc_aref holds
+//     K imp (pos - margin) and efc_b the damping gain until reference_constraint folds them into aref), efc_D is gone for PGS
+//     (1 / R on the fly) and efc_R for the primal solvers;
+//   * contact_solref / contact_solimp are gone (make_constraint reads the pair record the contact came from);
+//   * the PGS triangle scratch sits on the dead contact arrays, the box - box clipping scratch at the start of U.
 void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 {
 	const mjb_model_desc &d = M->h;
@@ -166,6 +176,12 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 			need_post = true;
 	}
 	M->need_rnepost = need_post ? 1 : 0;
+	const bool lean = compact && d.nefcmax > 0;
+	const bool u_ok = lean && !need_post;
+	const bool primal = d.solver == MJB_SOL_NEWTON || d.solver == MJB_SOL_CG;
+	const bool ell_con = d.cone == MJB_CONE_ELLIPTIC && d.nconmax > 0;
+	std::vector<int> u_members;  // field ids overlaid by efc_J, in placement order
+	int fsize[MJB_F_COUNT];
 	for (const FieldInfo &fi : kFields) {
 		int n = dim(fi);
 		if (idx == MJB_F_efc_AR) n = 0;  // (the PGS kernel keeps each row of AR in its lane's registers)
@@ -179,6 +195,24 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		const bool in_a = compact && (idx == MJB_F_crb || (idx == MJB_F_cacc && !need_post) || idx == MJB_F_cfrc_body);
 		const bool in_b = alias_b && (idx == MJB_F_ximat || idx == MJB_F_cvel || idx == MJB_F_cdof_dot);
 		if (compact && idx == MJB_F_xfrc_applied) n = 0;
+		fsize[idx] = n;
+		const bool gone = lean && (idx == MJB_F_efc_pos || idx == MJB_F_efc_margin || idx == MJB_F_efc_KBIP || idx == MJB_F_efc_vel ||
+		                           (idx == MJB_F_efc_D && d.solver == MJB_SOL_PGS && !ell_con) || (idx == MJB_F_efc_R && primal) ||
+		                           idx == MJB_F_contact_solref || idx == MJB_F_contact_solimp);
+		const bool in_u = u_ok && (idx == MJB_F_efc_J || idx == MJB_F_cinert || idx == MJB_F_geom_xpos || idx == MJB_F_geom_xmat ||
+		                           idx == MJB_F_xanchor || idx == MJB_F_xaxis || idx == MJB_F_site_xquat ||
+		                           (d.neq == 0 && (idx == MJB_F_xmat || idx == MJB_F_xquat)));
+		if (gone) {
+			*slots[idx] = -1;  // kernels test the offset
+			idx++;
+			continue;
+		}
+		if (in_u && !in_a && !in_b) {
+			if (idx != MJB_F_efc_J) u_members.push_back(idx);
+			*slots[idx] = -1;  // placed below
+			idx++;
+			continue;
+		}
 		if (no_B) {
 			if (!compact) M->field_size[idx] = n;
 			*slots[idx] = -1;  // kernels test L.efc_B >= 0
@@ -210,16 +244,17 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	off += ((newton || (d.nefcmax > 0 && d.solver == MJB_SOL_PGS)) && d.cone == MJB_CONE_ELLIPTIC) ? 36 * d.nconmax : 0;  // (PGS: the contacts' blocks of AR)
 	L.gravity = off;
 	off += 3;
-	L.gfriction = off;
-	off += d.nconmax > 0 ? 3 * d.ngeom : 0;
+	// (lean frame: collision takes the mixed friction from the pair record, or from the per-env override in HBM)
+	L.gfriction = lean ? -1 : off;
+	off += (d.nconmax > 0 && !lean) ? 3 * d.ngeom : 0;
 	L.eqparam = off;
 	off += 19 * d.neq;
 	L.cwrench = off;
 	off += need_post ? 6 * d.nconmax : 0;
 	L.MhB = off;
 	off += d.nM;
-	L.qH = off;
-	off += d.nM;
+	L.qH = lean ? L.MhB : off;  // (lean frame: factorised in place -- nothing reads M + h B after its factor exists)
+	off += lean ? 0 : d.nM;
 	L.qHdi = off;
 	off += d.nv;
 	const bool need_tri = (d.nefcmax > 0 && d.solver == MJB_SOL_PGS && d.nv <= 16) || d.nconmax > 0;  // (128-double transient scratch)
@@ -232,7 +267,9 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		if (!need_post) L.cacc = a0;
 		L.cfrc_body = a0 + n_c6;
 		L.eulerx = a0;
-		L.tri = a0;  // (alive only inside project_constraint_dense16, between the factorisation and comVel)
+		L.tri = a0;  // (alive only inside the PGS stage: cacc / cfrc_body are dead by then)
+		L.bbscr = a0;
+		L.solvescr = L.crbbuf;
 		int sz = n_kin;
 		if (need_tri && sz < 128) sz = 128;
 		if (n_crb + n_buf > sz) sz = n_crb + n_buf;
@@ -248,6 +285,25 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 			if (n_c6 + 6 * d.nv > szb) szb = n_c6 + 6 * d.nv;
 			off += szb;
 		}
+		if (u_ok) {
+			for (int id : u_members) {
+				*slots[id] = off;
+				off += fsize[id];
+			}
+			L.efc_J = a0;
+			if (off - a0 < fsize[MJB_F_efc_J]) off = a0 + fsize[MJB_F_efc_J];
+			// (efc_J is alive from the end of the velocity stage to the end of the solver: what runs in between -- the dense
+			//  M^-1 solve of fwd_acceleration, the PGS stage's triangle -- takes its scratch, and Euler its right-hand side, from
+			//  the contact arrays nobody reads after make_constraint: dist | pos | frame | includemargin are contiguous, 14
+			//  doubles per contact; friction, which the elliptic solvers read, stays intact)
+			const int late = (need_tri ? 128 : 0) + 32 + d.nv;
+			int ls = off;
+			if (14 * d.nconmax >= late) ls = L.contact_dist;
+			else off += late;
+			L.tri = ls;
+			L.solvescr = ls + (need_tri ? 128 : 0);
+			L.eulerx = L.solvescr + 32;
+		}
 	} else {
 		L.kinloc = off;
 		off += n_kin;
@@ -255,7 +311,9 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		off += n_buf;
 		L.eulerx = off;
 		off += d.nv;
+		L.solvescr = L.crbbuf;
 		L.tri = off;
+		L.bbscr = off;
 		off += need_tri ? 128 : 0;
 	}
 	if (off & 1) off++;
@@ -741,6 +799,10 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 			for (int k = 0; k < 5; k++) solimp[k] = mix * h.geom_solimp[5 * g1 + k] + (1 - mix) * h.geom_solimp[5 * g2 + k];
 		}
 		pd[17] = margin - gap;
+		for (int k = 0; k < 3; k++) {  // mj_contactParam's friction of the MODEL's geoms (per-env overrides are mixed on the device)
+			const double a = h.geom_friction[3 * g1 + k], b = h.geom_friction[3 * g2 + k];
+			pd[18 + k] = pi[5] == 0 ? std::max(a, b) : (pi[5] == 1 ? a : b);
+		}
 	}
 	compute_layout(M, M->L, false);
 	compute_layout(M, M->Lc, true);
@@ -778,6 +840,29 @@ int mjb_field_is_int(int field) { return field >= 0 && field < MJB_F_COUNT && kF
 int mjb_field_is_state(int field) { return field >= 0 && field < MJB_F_COUNT && kFields[field].kind == 0; }
 const char *mjb_field_name(int field) { return field >= 0 && field < MJB_F_COUNT ? kFields[field].name : ""; }
 int mjb_frame_doubles(const mjb_model *m) { return m ? m->L.ndouble + m->L.nint / 2 : fail(MJB_EINVAL, "null model"); }
+int mjb_frame_bytes(const mjb_model *m, int fused)
+{
+	if (!m) return fail(MJB_EINVAL, "null model");
+	const FrameLayout &L = fused ? m->Lc : m->L;
+	return ((L.ndouble * 8 + L.nint * 4) + 15) & ~15;
+}
+int mjb_frame_offset(const mjb_model *m, int field, int fused)
+{
+	if (!m || field < 0 || field >= MJB_F_COUNT) return fail(MJB_EINVAL, "bad model / field");
+	const FrameLayout &L = fused ? m->Lc : m->L;
+	const int *slots[] = {
+#define MJB_DS(name, rows, cols) &L.name,
+#define MJB_DD(name, rows, cols) &L.name,
+#define MJB_DD2(name, rows, cols) &L.name,
+#define MJB_DI(name, rows, cols) &L.name,
+#include "../../include/mjb_data_fields.def"
+#undef MJB_DS
+#undef MJB_DD
+#undef MJB_DD2
+#undef MJB_DI
+	};
+	return *slots[field];
+}
 
 void mjb_free_batch(mjb_batch *b)
 {

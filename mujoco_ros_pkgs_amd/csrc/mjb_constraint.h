@@ -586,7 +586,7 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 				const int l = __builtin_ctzll(bbmask);
 				bbmask &= bbmask - 1;
 				if (lane == l) {
-					double *scr = f + L.tri;  // (transient scratch: nothing else of the frame's shared region is alive during collision)
+					double *scr = f + L.bbscr;  // (transient scratch: nothing else of the frame's shared region is alive during collision)
 					n = box_box(scr, pos1, mat1, size1, pos2, mat2, size2, margin);
 #pragma unroll
 					for (int i = 0; i < 8; i++) {
@@ -610,9 +610,19 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 		}
 		if (n > 0) {
 			double fri[3];
-			for (int k = 0; k < 3; k++) {
-				const double a = f[L.gfriction + 3 * g1 + k], b = f[L.gfriction + 3 * g2 + k];
-				fri[k] = frisel == 0 ? fmax(a, b) : (frisel == 1 ? a : b);
+			if (L.gfriction >= 0) {
+				for (int k = 0; k < 3; k++) {
+					const double a = f[L.gfriction + 3 * g1 + k], b = f[L.gfriction + 3 * g2 + k];
+					fri[k] = frisel == 0 ? fmax(a, b) : (frisel == 1 ? a : b);
+				}
+			} else if (s.env_geom_friction) {  // lean frame, per-env override: straight from HBM
+				const double *gf = s.env_geom_friction + (size_t)e.env * 3 * m.ngeom;
+				for (int k = 0; k < 3; k++) {
+					const double a = gf[3 * g1 + k], b = gf[3 * g2 + k];
+					fri[k] = frisel == 0 ? fmax(a, b) : (frisel == 1 ? a : b);
+				}
+			} else {  // lean frame: the model's geoms, mixed on the host (pair record)
+				for (int k = 0; k < 3; k++) fri[k] = pd[18 + k];
 			}
 #pragma unroll
 			for (int i = 0; i < 8; i++) {  // (fully unrolled, no early exit: rc[] stays in statically indexed registers)
@@ -627,13 +637,17 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 				f[L.contact_includemargin + c] = incl;
 				double *f5 = f + L.contact_friction + 5 * c;
 				f5[0] = fri[0]; f5[1] = fri[0]; f5[2] = fri[1]; f5[3] = fri[2]; f5[4] = fri[2];
-				f[L.contact_solref + 2 * c] = pd[10];
-				f[L.contact_solref + 2 * c + 1] = pd[11];
-				for (int k = 0; k < 5; k++) f[L.contact_solimp + 5 * c + k] = pd[12 + k];
+				if (L.contact_solref >= 0) {
+					f[L.contact_solref + 2 * c] = pd[10];
+					f[L.contact_solref + 2 * c + 1] = pd[11];
+					for (int k = 0; k < 5; k++) f[L.contact_solimp + 5 * c + k] = pd[12 + k];
+				}
 				fi[L.contact_geom + 2 * c] = g1;
 				fi[L.contact_geom + 2 * c + 1] = g2;
 				fi[L.contact_dim + c] = condim;
-				fi[L.contact_efc_address + c] = -1;
+				// no rows yet (< 0).  The lean frame keeps no per-contact solref / solimp: -2 - pair tells make_constraint
+				// which pair record to read them from
+				fi[L.contact_efc_address + c] = L.contact_solref >= 0 ? -1 : -2 - p;
 			}
 		}
 		base += total;
@@ -721,15 +735,23 @@ DEVI RowGain row_gain(CModel m, const double *solref_in, const double *solimp_in
 	return g;
 }
 DEVI double row_R(const RowGain &g, double diag_approx) { return fmax(MJB_MINVAL, (1 - g.imp) * diag_approx / g.imp); }
+// (lean frame of the fused step -- no efc_KBIP / efc_pos / efc_margin: efc_aref takes K imp (pos - margin) and efc_b the damping
+//  gain B until reference_constraint folds them into aref; D or R is absent when the model's solver does not read it)
 DEVI void row_store(CLayout L, double *f, int i, double pos, double margin, const RowGain &g, double R)
 {
-	f[L.efc_R + i] = R;
-	f[L.efc_KBIP + 4 * i] = g.K;
-	f[L.efc_KBIP + 4 * i + 1] = g.B;
-	f[L.efc_KBIP + 4 * i + 2] = g.imp;
-	f[L.efc_KBIP + 4 * i + 3] = g.impP;
-	f[L.efc_pos + i] = pos;
-	f[L.efc_margin + i] = margin;
+	if (L.efc_R >= 0) f[L.efc_R + i] = R;
+	if (L.efc_D >= 0) f[L.efc_D + i] = 1.0 / R;
+	if (L.efc_KBIP >= 0) {
+		f[L.efc_KBIP + 4 * i] = g.K;
+		f[L.efc_KBIP + 4 * i + 1] = g.B;
+		f[L.efc_KBIP + 4 * i + 2] = g.imp;
+		f[L.efc_KBIP + 4 * i + 3] = g.impP;
+		f[L.efc_pos + i] = pos;
+		f[L.efc_margin + i] = margin;
+	} else {
+		f[L.efc_aref + i] = g.K * g.imp * (pos - margin);
+		f[L.efc_b + i] = g.B;
+	}
 }
 // imp_pos: the position the impedance is evaluated at (rows of a connect / weld share the norm of their residual)
 DEVI void row_params_x(CModel m, CLayout L, double *f, int i, double pos, double margin, const double *solref_in,
@@ -1005,11 +1027,18 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const
 			const int b1 = m.geom_bodyid[fi[L.contact_geom + 2 * c]], b2 = m.geom_bodyid[fi[L.contact_geom + 2 * c + 1]];
 			const double tran = MP_BODY_INVW(m, e, 2 * b1) + MP_BODY_INVW(m, e, 2 * b2);
 			const double rot = MP_BODY_INVW(m, e, 2 * b1 + 1) + MP_BODY_INVW(m, e, 2 * b2 + 1);
-			double solref[2] = { f[L.contact_solref + 2 * c], f[L.contact_solref + 2 * c + 1] }, solimp[5], fri[5];
-			for (int k = 0; k < 5; k++) {
-				solimp[k] = f[L.contact_solimp + 5 * c + k];
-				fri[k] = f[L.contact_friction + 5 * c + k];
+			double solref[2], solimp[5], fri[5];
+			if (L.contact_solref >= 0) {
+				solref[0] = f[L.contact_solref + 2 * c];
+				solref[1] = f[L.contact_solref + 2 * c + 1];
+				for (int k = 0; k < 5; k++) solimp[k] = f[L.contact_solimp + 5 * c + k];
+			} else {  // lean frame: the mixed parameters of the pair record this contact came from (collision left -2 - pair)
+				const mjb_cdptr pd = m.pair_d + 24 * (-2 - fi[L.contact_efc_address + c]);
+				solref[0] = pd[10];
+				solref[1] = pd[11];
+				for (int k = 0; k < 5; k++) solimp[k] = pd[12 + k];
 			}
+			for (int k = 0; k < 5; k++) fri[k] = f[L.contact_friction + 5 * c + k];
 			fi[L.contact_efc_address + c] = off;
 			(void)rot;
 			// ONE impedance evaluation per contact: its rows share solref / solimp, and either all of them sit at
@@ -1049,10 +1078,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const
 #ifdef MJB_PROFILE_SUB
 	EPROF(27);
 #endif
-	for (int r = lane; r < nefc; r += G) {
-		f[L.efc_D + r] = 1.0 / f[L.efc_R + r];
-		f[L.efc_force + r] = 0;
-	}
+	for (int r = lane; r < nefc; r += G) f[L.efc_force + r] = 0;
 	if (lane == 0) fi[L.nefc] = nefc;
 	gsync<G>();
 	// connect / weld Jacobian columns: one (equality, dof) pair per lane.  J = body1 - body2 (points differ, so a
@@ -1249,9 +1275,13 @@ template <int G> STAGE void reference_constraint(CModel m, CLayout L, const Env 
 	for (int r = e.lane; r < nefc; r += G) {
 		double s = 0;
 		for (int k = 0; k < nv; k++) s += f[L.efc_J + r * nv + k] * f[L.qvel + k];
-		f[L.efc_vel + r] = s;
-		const double *kb = f + L.efc_KBIP + 4 * r;
-		f[L.efc_aref + r] = -kb[1] * s - kb[0] * kb[2] * (f[L.efc_pos + r] - f[L.efc_margin + r]);
+		if (L.efc_KBIP >= 0) {
+			f[L.efc_vel + r] = s;
+			const double *kb = f + L.efc_KBIP + 4 * r;
+			f[L.efc_aref + r] = -kb[1] * s - kb[0] * kb[2] * (f[L.efc_pos + r] - f[L.efc_margin + r]);
+		} else {
+			f[L.efc_aref + r] = -f[L.efc_b + r] * s - f[L.efc_aref + r];  // (row_store left B and K imp (pos - margin) here)
+		}
 	}
 	gsync<G>();
 }
@@ -1628,7 +1658,7 @@ template <int G> __device__ __attribute__((noinline)) void fwd_constraint_pgs_la
 		double fr = 0;
 		if (act[s] && warm) {
 			const double jar = jw - aref;
-			fr = (jar < 0 || bilateral || friction) ? -f[L.efc_D + rr] * jar : 0.0;
+			fr = (jar < 0 || bilateral || friction) ? -(L.efc_D >= 0 ? f[L.efc_D + rr] : 1.0 / Rr[s]) * jar : 0.0;  // (lean frame: no efc_D)
 			if (friction) fr = __builtin_fmin(__builtin_fmax(fr, -floss), floss);
 		}
 		frc[s] = fr;
@@ -1823,7 +1853,7 @@ template <int G, bool ELL, bool REGB> STAGE void fwd_constraint_pgs(CModel m, CL
 			f[L.efc_b + r] = b;
 			if (!(m.disableflags & MJB_DSBL_WARMSTART)) {
 				const double jar = jw - aref;
-				frc = (jar < 0 || bilateral || friction) ? -f[L.efc_D + r] * jar : 0.0;
+				frc = (jar < 0 || bilateral || friction) ? -(L.efc_D >= 0 ? f[L.efc_D + r] : 1.0 / R) * jar : 0.0;  // (lean frame: no efc_D)
 				if (friction) frc = __builtin_fmin(__builtin_fmax(frc, -floss), floss);
 				if (ellmodel) f[L.efc_force + r] = ell ? jar : frc;  // (cone rows: jar parked for the contact's leader)
 			}

@@ -85,8 +85,9 @@ struct FrameLayout {
 	int crbbuf;    // [6*nv]    crb: crb[body(i)] * cdof_i (transient)
 	int eulerx;    // [nv]      Euler: velocity-update right-hand side / solution (transient)
 	int dadr;      // [64 ints] constrained kernels, nv <= 16: packed dense address map of lanes 0-15 (int frame)
-	int tri;       // [128]     transient scratch: packed dense triangle of the L'DL factor (PGS, nv <= 16: 120 doubles) / box - box
-	               //           clipping polygons + output contacts (models with contacts: 128 doubles)
+	int tri;       // [128]     transient scratch: packed dense triangle of the L'DL factor (PGS, nv <= 16: 120 doubles)
+	int solvescr;  // [32]      pivot-row scratch of the dense M^-1 solves in fwd_acceleration / Euler (the factorisation uses crbbuf)
+	int bbscr;     // [128]     transient scratch of the box - box narrow phase (alive inside collision only)
 	int ndouble;   // doubles per frame
 	int nint;      // ints per frame (follow the doubles)
 	int nstate;    // doubles in the persistent prefix

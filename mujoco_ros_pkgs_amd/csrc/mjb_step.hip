@@ -1495,13 +1495,13 @@ template <int G, int DENSE> STAGE void fwd_acceleration(CModel m, CLayout L, con
 	const bool dual = m.eulerdamp && m.nefcmax == 0;
 	if constexpr (DENSE > 0)
 		solve_dense16<G, DENSE>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual, e.dadr,
-		                        f + L.crbbuf);
+		                        f + L.solvescr);
 	else if constexpr (DENSE < 0) {  // constrained kernel: a small system is solved by lanes 0-15 of the wavefront
 		if (m.nv <= 16) {
 			int dl[16];
 			dadr_load(e, L, dl);
 			solve_dense16<G, 16>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual, dl,
-			                     f + L.crbbuf);
+			                     f + L.solvescr);
 		}
 		else
 			solve2<G>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual);
@@ -1547,7 +1547,7 @@ template <int G, bool CAN16> STAGE void euler(CModel m, CLayout L, const Env &e)
 			if (m.nv <= 16) {
 				int dl[16];
 				dadr_load(e, L, dl);
-				solve_dense16<G, 16>(m, e, x, f + L.qH, f + L.qHdi, x, f + L.qH, f + L.qHdi, false, dl, f + L.crbbuf);
+				solve_dense16<G, 16>(m, e, x, f + L.qH, f + L.qHdi, x, f + L.qH, f + L.qHdi, false, dl, f + L.solvescr);
 			} else
 				solve<G>(m, e, x, f + L.qH, f + L.qHdi);
 		} else
@@ -1608,7 +1608,7 @@ template <int G> STAGE void load_state(CModel m, CLayout L, CState s, const Env 
 	if (e.lane == 0) e.f[L.time] = s.time[env];
 	// this env's gravity / geom friction: the model's values or the per-env overrides (mjb_set_env_*)
 	for (int k = e.lane; k < 3; k += G) e.f[L.gravity + k] = s.env_gravity ? s.env_gravity[env * 3 + k] : m.gravity[k];
-	if (m.nconmax > 0)
+	if (m.nconmax > 0 && L.gfriction >= 0)
 		for (int k = e.lane; k < 3 * m.ngeom; k += G)
 			e.f[L.gfriction + k] = s.env_geom_friction ? s.env_geom_friction[env * 3 * m.ngeom + k] : m.geom_friction[k];
 	// equality parameters (active | data | solref | solimp): the model's or this env's (mjb_set_env_equality)
@@ -1730,27 +1730,43 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 	if constexpr (CON) {
 		VIEW(P, compact, collision<G>(m, L, s, e));
 		PROF(16);
-		VIEW(P, compact, make_constraint<G>(m, L, s, e));
-		PROF(17);
-		if constexpr (CON == 1 || CON == 5) {
-			// (plain PGS, nv <= 16: the rows of B = J M^-1 are solved for inside the PGS stage, in registers)
-			if (P->m.nv > 16) VIEW(P, compact, project_constraint<G>(m, L, e));
-			else if constexpr (CON == 5) VIEW(P, compact, project_constraint_dense16<G>(m, L, e));
-		}
-		PROF(18);
 	}
-	VIEW(P, compact, transmission<G>(m, L, e));
-	VIEW(P, compact, sensors<G>(m, L, e, MJB_STAGE_POS, compact));
-	PROF(4);
-	VIEW(P, compact, com_vel<G, (DENSE != 0)>(m, L, e));
-	PROF(5);
-	VIEW(P, compact, passive<G>(m, L, e));
-	PROF(6);
-	if constexpr (CON) VIEW(P, compact, reference_constraint<G>(m, L, e));
-	VIEW(P, compact, rne<G, (DENSE != 0)>(m, L, e));
-	PROF(7);
-	VIEW(P, compact, sensors<G>(m, L, e, MJB_STAGE_VEL, compact));
-	PROF(8);
+	// Constraint rows (make_constraint + J M^-1 + reference accelerations) read positions, contacts and qvel only and nothing
+	// before the solver reads them: on the compact frame of the fused step they are built AFTER the velocity stage, where
+	// efc_J can overlay what the position / velocity stages no longer need (mjb_api.hip, compute_layout); on the full frame
+	// (mjb_forward / mjb_step1, whose callers may look at efc_* / contacts between the halves) in MuJoCo's place.  ONE copy of
+	// the stages in the instruction stream: a two-trip loop picks the trip they run in.
+	const int con_trip = (CON != 0 && compact) ? 1 : 0;
+#pragma nounroll
+	for (int trip = 0; trip < (CON != 0 ? 2 : 1); trip++) {
+		if constexpr (CON != 0) {
+			if (trip == con_trip) {
+				PROF_BEGIN();
+				VIEW(P, compact, make_constraint<G>(m, L, s, e));
+				PROF(17);
+				if constexpr (CON == 1 || CON == 5) {
+					// (plain PGS, nv <= 16: the rows of B = J M^-1 are solved for inside the PGS stage, in registers)
+					if (P->m.nv > 16) VIEW(P, compact, project_constraint<G>(m, L, e));
+					else if constexpr (CON == 5) VIEW(P, compact, project_constraint_dense16<G>(m, L, e));
+				}
+				VIEW(P, compact, reference_constraint<G>(m, L, e));
+				PROF(18);
+			}
+			if (trip) break;
+		}
+		PROF_BEGIN();
+		VIEW(P, compact, transmission<G>(m, L, e));
+		VIEW(P, compact, sensors<G>(m, L, e, MJB_STAGE_POS, compact));
+		PROF(4);
+		VIEW(P, compact, com_vel<G, (DENSE != 0)>(m, L, e));
+		PROF(5);
+		VIEW(P, compact, passive<G>(m, L, e));
+		PROF(6);
+		VIEW(P, compact, rne<G, (DENSE != 0)>(m, L, e));
+		PROF(7);
+		VIEW(P, compact, sensors<G>(m, L, e, MJB_STAGE_VEL, compact));
+		PROF(8);
+	}
 }
 
 template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams MJB_AS4 *P, const Env &e, int compact)
@@ -1988,7 +2004,10 @@ template <int G> STAGE void ctrl_noise(CModel m, CLayout L, CNoise nz, const Env
 // guards every build): an earlier revision had to cap these kernels at 256 VGPRs because of it, and the CG variants (CON >= 6,
 // not a BASELINE workload) still are -- at 512 the allocator produced exactly that pattern in the 2-rows-per-lane CG kernel.
 template <int G, int CON, int DENSE>
-__global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? 1 : (G == 64 ? 4 : (G == 32 ? 2 : 1)))))
+#ifndef MJB_DEV_OCC
+#define MJB_DEV_OCC 1
+#endif
+__global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G == 64 ? 4 : (G == 32 ? 2 : 1)))))
     mjb_step_kernel(const KernelParams MJB_AS4 *__restrict__ P, const int mode, const int nsteps,
                     const unsigned int step0, const int epb, const int frame_bytes)
 {
@@ -2184,8 +2203,12 @@ int launch_g(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode,
 		epb--;
 		threads = epb * G;
 	}
-	const size_t lds = (size_t)epb * frame_bytes;
+	size_t lds = (size_t)epb * frame_bytes;
 	if ((int)lds > maxlds) return (int)hipErrorInvalidValue;
+	{  // measurement knob: MJB_DEBUG_LDS_BYTES=<n> requests at least n bytes per block, i.e. caps the resident blocks per CU
+		static const int floor_bytes = [] { const char *v = getenv("MJB_DEBUG_LDS_BYTES"); return v ? atoi(v) : 0; }();
+		if (floor_bytes > (int)lds && floor_bytes <= maxlds) lds = floor_bytes;
+	}
 	auto kern = mjb_step_kernel<G, CON, DENSE>;
 	hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
 	                                     (int)lds);
