@@ -1143,8 +1143,15 @@ static int launch(mjb_batch *b, int mode, int nsteps)
 	int prc = sync_params(b);
 	if (prc) return prc;
 	const bool compact = mode == MJB_MODE_STEP && !b->st.use_xfrc && !b->st.keep_frame;
+	int variant = kernel_variant(b->model->h);
+	// plain PGS on the lean frame: when eight envs fit one CU's LDS, the 256-register build runs two waves per SIMD
+	if (variant == 1 && compact && 8 * mjb_frame_bytes(b->model, 1) <= mjb_max_lds_bytes()) variant = 9;
+	{
+		static const int forced = [] { const char *v = getenv("MJB_DEBUG_VARIANT"); return v ? atoi(v) : -1; }();  // measurement knob
+		if (forced >= 0 && variant != 0) variant = forced;
+	}
 	int rc = mjb_launch_step(b->params_dev, compact ? b->model->Lc : b->L, b->nenv, mode, nsteps, b->step_counter, b->lanes,
-	                         b->epb, kernel_variant(b->model->h), (b->lanes == 16 && !b->env_mass && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, b->stream);
+	                         b->epb, variant, (b->lanes == 16 && !b->env_mass && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, b->stream);
 	if (rc != 0) return fail(MJB_ENODEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
 	return MJB_OK;
 }

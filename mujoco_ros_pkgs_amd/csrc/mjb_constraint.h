@@ -1621,7 +1621,9 @@ DEVI void tri_solve(double (&x)[16], const double *Ld, const double *di, int nv)
 // env-steps whose row count actually exceeds 64 (wave-uniform branch in fwd_constraint_pgs; out of line so that the
 // common path pays neither registers nor instruction-cache lines for it).
 // ------------------------------------------------------------------------------------------------
-template <int G> __device__ __attribute__((noinline)) void fwd_constraint_pgs_large(CModel m, CLayout L, const Env &e, const double *Brows)
+// (TAG: the kernel variant this copy belongs to -- out-of-line functions shared by kernels with different register budgets are
+//  compiled for the loosest one, which would cost the capped kernel its second wave per SIMD)
+template <int G, int TAG> __device__ __attribute__((noinline)) void fwd_constraint_pgs_large(CModel m, CLayout L, const Env &e, const double *Brows)
 {
 	static_assert(G == 64, "the constraint solver maps rows to the 64 lanes of one wavefront");
 	double *f = e.f;
@@ -1744,7 +1746,7 @@ template <int G> __device__ __attribute__((noinline)) void fwd_constraint_pgs_la
 // ------------------------------------------------------------------------------------------------
 // A13 constraint solve: warmstart + projected Gauss-Seidel (dual), one env per wavefront
 // ------------------------------------------------------------------------------------------------
-template <int G, bool ELL, bool REGB> STAGE void fwd_constraint_pgs(CModel m, CLayout L, CState s, const Env &e)
+template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CModel m, CLayout L, CState s, const Env &e)
 {
 	static_assert(G == 64, "the constraint solver maps rows to the 64 lanes of one wavefront");
 	double *f = e.f;
@@ -1806,12 +1808,12 @@ template <int G, bool ELL, bool REGB> STAGE void fwd_constraint_pgs(CModel m, CL
 		if (large) {
 			MJB_KEEP_BRANCH();
 			__threadfence();  // the rows just written to HBM are read back through the vector cache
-			fwd_constraint_pgs_large<G>(m, L, e, L.efc_B >= 0 ? f + L.efc_B : Bg);
+			fwd_constraint_pgs_large<G, TAG>(m, L, e, L.efc_B >= 0 ? f + L.efc_B : Bg);
 			return;
 		}
 	} else if (large) {
 		MJB_KEEP_BRANCH();
-		fwd_constraint_pgs_large<G>(m, L, e, f + L.efc_B);
+		fwd_constraint_pgs_large<G, TAG>(m, L, e, f + L.efc_B);
 		return;
 	}
 	const double *Br = f + (REGB ? L.efc_J : L.efc_B) + r * nv;  // (REGB: unused)
@@ -2021,9 +2023,9 @@ template <int G, bool ELL, bool REGB> STAGE void fwd_constraint_pgs(CModel m, CL
 }
 
 // the LDS-B variants (nv > 16) stay out of line: models that small never pay their registers or instruction-cache lines
-template <int G, bool ELL> __device__ __attribute__((noinline)) void fwd_constraint_pgs_ldsB(CModel m, CLayout L, CState s, const Env &e)
+template <int G, bool ELL, int TAG> __device__ __attribute__((noinline)) void fwd_constraint_pgs_ldsB(CModel m, CLayout L, CState s, const Env &e)
 {
-	fwd_constraint_pgs<G, ELL, false>(m, L, s, e);
+	fwd_constraint_pgs<G, ELL, false, TAG>(m, L, s, e);
 }
 
 // ------------------------------------------------------------------------------------------------

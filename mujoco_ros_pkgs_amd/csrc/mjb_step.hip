@@ -1744,7 +1744,7 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 				PROF_BEGIN();
 				VIEW(P, compact, make_constraint<G>(m, L, s, e));
 				PROF(17);
-				if constexpr (CON == 1 || CON == 5) {
+				if constexpr (CON == 1 || CON == 5 || CON == 9) {
 					// (plain PGS, nv <= 16: the rows of B = J M^-1 are solved for inside the PGS stage, in registers)
 					if (P->m.nv > 16) VIEW(P, compact, project_constraint<G>(m, L, e));
 					else if constexpr (CON == 5) VIEW(P, compact, project_constraint_dense16<G>(m, L, e));
@@ -1782,12 +1782,12 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 		VIEW(P, compact, fwd_constraint_newton<G, (CON == 2 ? 1 : (CON == 3 ? 2 : 4))>(m, L, e));
 	} else if constexpr (CON >= 6 && CON <= 8 && G == 64) {
 		VIEW(P, compact, fwd_constraint_newton<G, (CON == 6 ? 1 : (CON == 7 ? 2 : 4)), true>(m, L, e));
-	} else if constexpr ((CON == 1 || CON == 5) && G == 64) {
+	} else if constexpr ((CON == 1 || CON == 5 || CON == 9) && G == 64) {
 		if constexpr (CON == 5) {  // elliptic cone blocks: rows of B in LDS (the block code leaves no registers for them)
-			VIEW(P, compact, fwd_constraint_pgs<G, true, false>(m, L, s, e));
+			VIEW(P, compact, fwd_constraint_pgs<G, true, false, CON>(m, L, s, e));
 		} else {
-			if (P->m.nv <= 16) VIEW(P, compact, fwd_constraint_pgs<G, false, true>(m, L, s, e));
-			else VIEW(P, compact, fwd_constraint_pgs_ldsB<G, false>(m, L, s, e));
+			if (P->m.nv <= 16) VIEW(P, compact, fwd_constraint_pgs<G, false, true, CON>(m, L, s, e));
+			else VIEW(P, compact, fwd_constraint_pgs_ldsB<G, false, CON>(m, L, s, e));
 		}
 	} else {
 		VIEW(P, compact, fwd_constraint<G>(m, L, e));
@@ -1998,8 +1998,10 @@ template <int G> STAGE void ctrl_noise(CModel m, CLayout L, CNoise nz, const Env
 // CON: 0 = model without constraint rows; 1 = PGS (5 = PGS with elliptic cone blocks), 2 / 3 / 4 = Newton with 1 / 2 / 4 rows per lane,
 // 6 / 7 / 8 = CG with 1 / 2 / 4 rows per lane (the Newton solver without its Hessian) (collision / rows / solver stages compiled in;
 // one env per wavefront) -- separate kernels keep each instruction stream and register budget small.
-// Constrained kernels get the full 512-register budget (1 block of 256 per CU by registers; their frames limit the
-// CU to 1 - 4 envs anyway): no spills, and room for the register-resident AR rows / Hessian rows of the solvers.
+// Constrained kernels get the full 512-register budget (one wave per SIMD; most frames limit the CU to 1 - 4 envs anyway):
+// few spills, and room for the register-resident AR rows / Hessian rows of the solvers.  CON == 9 is the plain PGS step again
+// under a 256-register cap, picked when EIGHT lean frames fit one CU's LDS: two waves per SIMD hide each other's dependent
+// chains, which is worth more than the spills cost (config 3: +31 % measured).
 // ROCm 7.2's LLVM can place a spill ahead of an exec restore and lose lanes (tools/check_spill_exec.py, `make lint`
 // guards every build): an earlier revision had to cap these kernels at 256 VGPRs because of it, and the CG variants (CON >= 6,
 // not a BASELINE workload) still are -- at 512 the allocator produced exactly that pattern in the 2-rows-per-lane CG kernel.
@@ -2254,6 +2256,7 @@ int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, in
 	if (constrained == 6) return launch_g<64, 6>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 	if (constrained == 7) return launch_g<64, 7>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 	if (constrained == 8) return launch_g<64, 8>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+	if (constrained == 9) return launch_g<64, 9>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 	return launch_g<64, 1>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
 #endif
 }
