@@ -180,6 +180,14 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	const bool u_ok = lean && !need_post;
 	const bool primal = d.solver == MJB_SOL_NEWTON || d.solver == MJB_SOL_CG;
 	const bool ell_con = d.cone == MJB_CONE_ELLIPTIC && d.nconmax > 0;
+	// kernel variant 4 (Newton, more than 128 rows of capacity), fused frame: the first 64 rows of efc_J only; an env-step with
+	// more rows keeps J in the env's block of DevState::efc_Jg (config 5 never has: what lets two of its envs share a CU's LDS)
+	int jrows = d.nefcmax;
+	if (compact && d.solver == MJB_SOL_NEWTON && d.nefcmax > 128) {
+		jrows = 64;
+		if (const char *v = getenv("MJB_DEBUG_JROWS")) jrows = std::max(4, std::min(64, atoi(v)));  // test knob: force the HBM path
+	}
+	L.jrows = jrows;
 	std::vector<int> u_members;  // field ids overlaid by efc_J, in placement order
 	int fsize[MJB_F_COUNT];
 	for (const FieldInfo &fi : kFields) {
@@ -195,6 +203,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		const bool in_a = compact && (idx == MJB_F_crb || (idx == MJB_F_cacc && !need_post) || idx == MJB_F_cfrc_body);
 		const bool in_b = alias_b && (idx == MJB_F_ximat || idx == MJB_F_cvel || idx == MJB_F_cdof_dot);
 		if (compact && idx == MJB_F_xfrc_applied) n = 0;
+		if (idx == MJB_F_efc_J && n > 0) n = jrows * d.nv;
 		fsize[idx] = n;
 		const bool gone = lean && (idx == MJB_F_efc_pos || idx == MJB_F_efc_margin || idx == MJB_F_efc_KBIP || idx == MJB_F_efc_vel ||
 		                           (idx == MJB_F_efc_D && d.solver == MJB_SOL_PGS && !ell_con) || (idx == MJB_F_efc_R && primal) ||
@@ -881,6 +890,7 @@ void mjb_free_batch(mjb_batch *b)
 	if (b->st.frame_ws) hipFree(b->st.frame_ws);
 	if (b->st.nwarn) hipFree(b->st.nwarn);
 	if (b->st.pgs_B) hipFree(b->st.pgs_B);
+	if (b->st.efc_Jg) hipFree(b->st.efc_Jg);
 	if (b->metrics_dev) hipFree(b->metrics_dev);
 	if (b->st.prof) hipFree(b->st.prof);
 	if (b->blob) hipFree(b->blob);
@@ -1051,6 +1061,11 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	s.env_equality = nullptr;
 	s.env_mass = nullptr;
 	s.pgs_B = nullptr;
+	s.efc_Jg = nullptr;
+	if (h.solver == MJB_SOL_NEWTON && h.nefcmax > 128) {  // kernel variant 4: efc_J of the env-steps beyond the fused frame's 64 rows
+		s.efc_Jg = dev_alloc<double>((size_t)nenv * h.nefcmax * h.nv);
+		ok = ok && s.efc_Jg;
+	}
 	if (h.solver == MJB_SOL_PGS && h.nv <= 16 && h.nefcmax > 64) {
 		s.pgs_B = dev_alloc<double>((size_t)nenv * h.nefcmax * h.nv);  // (elliptic PGS never exceeds 64 rows: mjb_compile)
 		ok = ok && s.pgs_B;

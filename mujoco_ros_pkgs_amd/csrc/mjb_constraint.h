@@ -820,18 +820,31 @@ DEVI int wave_incl_scan(int v, int lane)
 	return v;
 }
 
-template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const Env &e)
+// Wave-uniform values read back from LDS (row / contact counts): telling the compiler so makes the loops on them scalar, which
+// the 512-register kernels profit from (fewer spills, and none of ROCm 7.2's spill-before-exec-restore patterns in the plain PGS
+// kernel) -- and the 256-register PGS variant (TAG 9) does not: its scalar registers are as short as its vector ones.
+template <int TAG> DEVI int wave_uniform(int v) { return TAG == 9 ? v : __builtin_amdgcn_readfirstlane(v); }
+
+// TAG 4 (Newton, up to 256 rows, fused step): the frame holds the first L.jrows rows of efc_J only -- what lets two envs of
+// config 5 share a CU's LDS.  Rows beyond go to the env's block of s.efc_Jg in HBM; an env-step that ends up with more than
+// L.jrows rows (none of config 5's do) copies the leading rows there as well and the solver reads ALL of J from HBM.
+template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState s, const Env &e)
 {
 	static_assert(G == 64, "one env per wavefront: row offsets come from a wave prefix sum");
 	double *f = e.f;
 	int *fi = e.fi;
 	const int lane = e.lane, nv = m.nv;
+	[[maybe_unused]] double *Jg = (TAG == 4 && s.efc_Jg) ? s.efc_Jg + (size_t)e.env * m.nefcmax * nv : nullptr;
+	auto jrow = [&](int r) -> double * {  // row r of efc_J
+		if constexpr (TAG == 4) return r < L.jrows ? f + L.efc_J + r * nv : Jg + (size_t)r * nv;
+		else return f + L.efc_J + r * nv;
+	};
 	if (lane == 0) fi[L.nefc] = 0;
 	if (m.nefcmax <= 0 || (m.disableflags & MJB_DSBL_CONSTRAINT)) {
 		gsync<G>();
 		return;
 	}
-	const int ncon = fi[L.ncon];
+	const int ncon = wave_uniform<TAG>(fi[L.ncon]);
 	const bool do_lim = !(m.disableflags & MJB_DSBL_LIMIT), do_con = !(m.disableflags & MJB_DSBL_CONTACT);
 	const int neq = (m.disableflags & MJB_DSBL_EQUALITY) ? 0 : m.neq;
 	const int nten = do_lim ? m.ntendon : 0;
@@ -905,7 +918,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const
 				for (int k = 0; k < 5; k++) c5[k] = f[L.eqparam + 19 * eq + 1 + k];
 				(void)pc;
 				double poly = c5[0], deriv = 0;
-				double *row = f + L.efc_J + off * nv;
+				double *row = jrow(off);
 				for (int k = 0; k < nv; k++) row[k] = 0;
 				diag[0] = MP_DOF_INVW(m, e, d1);
 				if (id1 >= 0) {
@@ -922,7 +935,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const
 				double c5[5];
 				for (int k = 0; k < 5; k++) c5[k] = f[L.eqparam + 19 * eq + 1 + k];
 				double poly = c5[0], deriv = 0;
-				double *row = f + L.efc_J + off * nv;
+				double *row = jrow(off);
 				for (int k = 0; k < nv; k++) row[k] = 0;
 				diag[0] = MP_TEN_INVW(m, e, id0);
 				if (id1 >= 0) {
@@ -966,7 +979,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const
 			// dry friction (mj_instantiateFriction): J = e_dof or the tendon's moment arms, pos = margin = 0, |force| <= frictionloss
 			const bool isdof = it < neq + nfd;
 			const int i = isdof ? it - neq : it - neq - nfd;
-			double *row = f + L.efc_J + off * nv;
+			double *row = jrow(off);
 			for (int k = 0; k < nv; k++) row[k] = 0;
 			if (isdof) {
 				row[i] = 1;
@@ -992,7 +1005,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const
 			for (int side = -1; side <= 1; side += 2) {
 				const double dist = side * (m.jnt_range[2 * j + (side + 1) / 2] - value);
 				if (dist < margin) {
-					double *row = f + L.efc_J + r * nv;
+					double *row = jrow(r);
 					for (int k = 0; k < nv; k++) row[k] = 0;
 					row[da] = -side;
 					row_params(m, L, f, r, dist, margin, solref, solimp, MP_DOF_INVW(m, e, da));
@@ -1010,7 +1023,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const
 			for (int side = -1; side <= 1; side += 2) {
 				const double dist = side * (m.tendon_range[2 * t + (side + 1) / 2] - value);
 				if (dist < margin) {
-					double *row = f + L.efc_J + r * nv;
+					double *row = jrow(r);
 					for (int k = 0; k < nv; k++) row[k] = 0;
 					for (int w = m.tendon_adr[t]; w < m.tendon_adr[t] + m.tendon_num[t]; w++)
 						row[m.jnt_dofadr[m.wrap_objid[w]]] += -side * m.wrap_prm[w];
@@ -1110,7 +1123,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const
 				for (int k = 0; k < 3; k++) { jp[k] -= c3[k] + cd[3 + k]; jr[k] -= cd[k]; }
 			}
 		}
-		for (int k = 0; k < 3; k++) f[L.efc_J + (adr + k) * nv + i] = jp[k];
+		for (int k = 0; k < 3; k++) jrow(adr + k)[i] = jp[k];
 		if (type == MJB_EQ_WELD) {
 			const double ts = f[L.eqparam + 19 * eq + 1 + 10];
 			const double *q = g.quat1;
@@ -1118,7 +1131,7 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const
 				                   q[0] * jr[1] + q[3] * jr[0] - q[1] * jr[2], q[0] * jr[2] + q[1] * jr[1] - q[2] * jr[0] };
 			double q3[4];
 			qmul(q3, qa, g.quat);
-			for (int k = 0; k < 3; k++) f[L.efc_J + (adr + 3 + k) * nv + i] = 0.5 * ts * q3[1 + k];
+			for (int k = 0; k < 3; k++) jrow(adr + 3 + k)[i] = 0.5 * ts * q3[1 + k];
 		}
 	}
 #ifdef MJB_PROFILE_SUB
@@ -1151,23 +1164,31 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const
 		ld9(fr, f + L.contact_frame + 9 * c);
 		const double j0 = dot3(fr, jdp);
 		if (dim == 1) {
-			f[L.efc_J + adr * nv + i] = j0;
+			jrow(adr)[i] = j0;
 		} else if (m.cone == MJB_CONE_ELLIPTIC) {
-			f[L.efc_J + adr * nv + i] = j0;
+			jrow(adr)[i] = j0;
 			for (int k = 1; k < dim; k++)
-				f[L.efc_J + (adr + k) * nv + i] = k < 3 ? dot3(fr + 3 * k, jdp) : dot3(fr + 3 * (k - 3), jdr);
+				jrow(adr + k)[i] = k < 3 ? dot3(fr + 3 * k, jdp) : dot3(fr + 3 * (k - 3), jdr);
 		} else {
 			int r = adr;
 			for (int k = 1; k < dim; k++) {
 				const double jk = k < 3 ? dot3(fr + 3 * k, jdp) : dot3(fr + 3 * (k - 3), jdr);
 				const double mu = f[L.contact_friction + 5 * c + (k - 1)];
-				f[L.efc_J + r * nv + i] = j0 + mu * jk;
-				f[L.efc_J + (r + 1) * nv + i] = j0 - mu * jk;
+				jrow(r)[i] = j0 + mu * jk;
+				jrow(r + 1)[i] = j0 - mu * jk;
 				r += 2;
 			}
 		}
 	}
 	gsync<G>();
+	if constexpr (TAG == 4) {
+		if (Jg && nefc > L.jrows) {  // (wave-uniform) more rows than the frame holds: the solver reads all of J from HBM
+			MJB_KEEP_BRANCH();
+			for (int t = lane; t < L.jrows * nv; t += G) Jg[t] = f[L.efc_J + t];
+			__threadfence();  // the rows are read back by other lanes through the vector cache
+			gsync<G>();
+		}
+	}
 #ifdef MJB_PROFILE_SUB
 	EPROF(29);
 #endif
@@ -1177,10 +1198,10 @@ template <int G> STAGE void make_constraint(CModel m, CLayout L, CState s, const
 // A7  project: B = (M^-1 J')' row by row -- one ROW per lane, each lane runs the sparse solve serially on
 // its own row (loop structure is wave-uniform: the scalar table loads are shared by all rows)
 // ------------------------------------------------------------------------------------------------
-template <int G> STAGE void project_constraint(CModel m, CLayout L, const Env &e)
+template <int G, int TAG> STAGE void project_constraint(CModel m, CLayout L, const Env &e)
 {
 	double *f = e.f;
-	const int nefc = e.fi[L.nefc], nv = m.nv;
+	const int nefc = wave_uniform<TAG>(e.fi[L.nefc]), nv = m.nv;
 	if (nefc == 0) return;
 	const double *LD = f + L.qLD, *di = f + L.qLDiagInv;
 	for (int r0 = 0; r0 < nefc; r0 += G) {
@@ -1216,11 +1237,11 @@ template <int G> STAGE void project_constraint(CModel m, CLayout L, const Env &e
 // wave-uniform address (one LDS broadcast per entry) and x never leaves the registers: 240 fma per row with no
 // load-modify-store chain, against two dependent LDS round trips per factor entry in the generic version.
 // Rows / columns >= nv of the triangle are zero and x[k >= nv] = 0, so the unrolled sweeps need no guards.
-template <int G> STAGE void project_constraint_dense16(CModel m, CLayout L, const Env &e)
+template <int G, int TAG> STAGE void project_constraint_dense16(CModel m, CLayout L, const Env &e)
 {
 	static_assert(G == 64, "one constraint row per lane of the wavefront");
 	double *f = e.f;
-	const int nefc = e.fi[L.nefc], nv = m.nv, lane = e.lane;
+	const int nefc = wave_uniform<TAG>(e.fi[L.nefc]), nv = m.nv, lane = e.lane;
 	if (nefc == 0) return;
 	double *Ld = f + L.tri;  // (compact layout: inside the region kinematics / crb / rne share -- nobody else is alive here)
 	for (int t = lane; t < 120; t += G) Ld[t] = 0;
@@ -1268,13 +1289,14 @@ template <int G> STAGE void project_constraint_dense16(CModel m, CLayout L, cons
 }
 
 // A8  reference accelerations: efc_vel = J qvel, aref = -B vel - K imp (pos - margin)
-template <int G> STAGE void reference_constraint(CModel m, CLayout L, const Env &e)
+template <int G, int TAG> STAGE void reference_constraint(CModel m, CLayout L, CState st, const Env &e)
 {
 	double *f = e.f;
-	const int nefc = e.fi[L.nefc], nv = m.nv;
+	const int nefc = wave_uniform<TAG>(e.fi[L.nefc]), nv = m.nv;
+	auto rows = [&](const double *Jb) {
 	for (int r = e.lane; r < nefc; r += G) {
 		double s = 0;
-		for (int k = 0; k < nv; k++) s += f[L.efc_J + r * nv + k] * f[L.qvel + k];
+		for (int k = 0; k < nv; k++) s += Jb[r * nv + k] * f[L.qvel + k];
 		if (L.efc_KBIP >= 0) {
 			f[L.efc_vel + r] = s;
 			const double *kb = f + L.efc_KBIP + 4 * r;
@@ -1283,6 +1305,17 @@ template <int G> STAGE void reference_constraint(CModel m, CLayout L, const Env 
 			f[L.efc_aref + r] = -f[L.efc_b + r] * s - f[L.efc_aref + r];  // (row_store left B and K imp (pos - margin) here)
 		}
 	}
+	};
+	if constexpr (TAG == 4) {  // (see make_constraint: all of J sits in HBM when the rows outnumber the frame's share)
+		if (st.efc_Jg && nefc > L.jrows) {
+			MJB_KEEP_BRANCH();
+			rows(st.efc_Jg + (size_t)e.env * m.nefcmax * nv);
+		} else {
+			MJB_KEEP_BRANCH();
+			rows(f + L.efc_J);
+		}
+	} else
+		rows(f + L.efc_J);
 	gsync<G>();
 }
 
@@ -1312,12 +1345,12 @@ DEVI double wave_bcast(double v, int srclane)  // srclane must be wave-uniform
 // clipped to an interval never raises a convex cost; in numbers:) with
 // Aii = J M^-1 J' + R > 0 the unclipped step changes the cost by -0.5 res^2 / Aii and the clipped one by
 // -f (res - 0.5 f Aii) with res >= f Aii, both <= 0 beyond any rounding, so it is not evaluated.
-template <bool BOX>  // BOX: some row has an upper force limit too (dry friction: |f| <= frictionloss)
-DEVI void pgs_sweep(const double (&AR)[64], const int nefc, const double lo, const double hi, const double ARinv, double &res,
+template <bool BOX, int NR>  // BOX: some row has an upper force limit too (dry friction: |f| <= frictionloss); NR: rows held in registers
+DEVI void pgs_sweep(const double (&AR)[NR], const int nefc, const double lo, const double hi, const double ARinv, double &res,
                     const double frc, double &dvec)
 {
 #pragma unroll
-	for (int i = 0; i < 64; i++) {
+	for (int i = 0; i < NR; i++) {
 		if ((i & 3) == 0) {
 			if (i >= nefc) break;  // rows beyond nefc in a group of four propose delta == 0
 			MJB_KEEP_BRANCH();
@@ -1779,13 +1812,16 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 	// rows of B come from LDS (project_constraint).  Beyond 64 rows (rare; pyramidal / scalar rows only) the rows of B go to
 	// the env's scratch in HBM and the AR-free path takes over.
 	double x[16];
-	const bool large = !ELL && nefc > 64;
+	// NR: rows the register path holds (= entries of AR per lane).  (32 for the capped kernel variant was tried: fewer spills, but
+	// the 1 - 6 % of config 3's env-steps with 33 - 64 rows then take the AR-free path and throughput drops 10.3 -> 4.3 M.)
+	constexpr int NR = 64;
+	const bool large = !ELL && nefc > NR;
 	if constexpr (REGB) {
 		double *Ld = f + L.tri;  // (compact layout: inside the region kinematics / crb / rne share -- nobody else is alive here)
 		tri_build(m, L, f, Ld, lane);
 		double *Bg = s.pgs_B ? s.pgs_B + (size_t)e.env * m.nefcmax * nv : nullptr;
 #pragma nounroll
-		for (int r0 = large ? 64 : 0; r0 >= 0; r0 -= 64) {  // (block 0 last: its row stays in the registers)
+		for (int r0 = large ? ((nefc - 1) >> 6) << 6 : 0; r0 >= 0; r0 -= 64) {  // (block 0 last: its row stays in the registers)
 			const int rb = r0 + lane;
 			const bool act = rb < nefc;
 			const double *Jb = f + L.efc_J + (act ? rb : 0) * nv;
@@ -1882,9 +1918,9 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 	}
 	// AR[i] = J_r . B_i: k outermost so that the 64 accumulators are independent (every load of one k is in flight
 	// together); row groups beyond nefc accumulate stale rows and are zeroed afterwards
-	double AR[64];
+	double AR[NR];
 #pragma unroll
-	for (int i = 0; i < 64; i++) AR[i] = 0;
+	for (int i = 0; i < NR; i++) AR[i] = 0;
 #ifdef MJB_PROFILE_SUB
 	EPROF(19);
 #endif
@@ -1892,7 +1928,7 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 		// AR_ri = B_r . J_i (AR is symmetric): B_r from the registers, row J_i as 16 LDS broadcasts at immediate offsets from
 		// one address; four rows per wave-uniform guard
 #pragma unroll
-		for (int i = 0; i < 64; i += 4) {
+		for (int i = 0; i < NR; i += 4) {
 			if (i < nefc) {
 				MJB_KEEP_BRANCH();
 				const double *J0 = f + L.efc_J + i * nv;
@@ -1916,7 +1952,7 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 			const double jk = Jr[k];
 			const double *Bk = f + L.efc_B + k;
 #pragma unroll
-			for (int i = 0; i < 64; i++) {
+			for (int i = 0; i < NR; i++) {
 				if ((i & 3) == 0) {
 					if (i >= nefc) break;
 					MJB_KEEP_BRANCH();
@@ -1926,8 +1962,8 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 		}
 	}
 #pragma unroll
-	for (int i = 0; i < 64; i++) AR[i] = (rowact && i < nefc) ? (lane == i ? Aii : AR[i]) : 0.0;
-	if (ellmodel) {  // the contacts' diagonal blocks, for the block updates: row r of contact c -> Hc[36 c + 6 (r - i0) + .]
+	for (int i = 0; i < NR; i++) AR[i] = (rowact && i < nefc) ? (lane == i ? Aii : AR[i]) : 0.0;
+	if constexpr (ELL) {  // the contacts' diagonal blocks, for the block updates: row r of contact c -> Hc[36 c + 6 (r - i0) + .]
 		MJB_KEEP_BRANCH();
 #pragma unroll
 		for (int i = 0; i < 64; i++)
@@ -1940,7 +1976,7 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 	// residual of the warmstart forces, res = b + AR f, and their cost 0.5 f'ARf + f'b = sum_i 0.5 f_i (res_i + b_i)
 	double res = b;
 #pragma unroll
-	for (int i = 0; i < 64; i++)
+	for (int i = 0; i < NR; i++)
 		if (i < nefc) res += AR[i] * wave_bcast(frc, i);
 	{
 		const double cost = wave_sum(rowact ? 0.5 * frc * (res + b) : 0.0);
@@ -1960,15 +1996,15 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 	int iter = 0;
 	while (iter < m.iterations) {
 		double dvec = 0;
-		if (ellmodel) {
+		if constexpr (ELL) {
 			MJB_KEEP_BRANCH();
 			pgs_sweep_elliptic(AR, nefc, lane, lo, hi, ARinv, rtype, rcon, rdim, res, frc, Hc, f + L.contact_friction);
 		} else if (m.nfriction > 0) {
 			MJB_KEEP_BRANCH();
-			pgs_sweep<true>(AR, nefc, lo, hi, ARinv, res, frc, dvec);
+			pgs_sweep<true, NR>(AR, nefc, lo, hi, ARinv, res, frc, dvec);
 		} else {
 			MJB_KEEP_BRANCH();
-			pgs_sweep<false>(AR, nefc, lo, hi, ARinv, res, frc, dvec);
+			pgs_sweep<false, NR>(AR, nefc, lo, hi, ARinv, res, frc, dvec);
 		}
 		frc += dvec;
 		const double cost1 = wave_sum(0.5 * frc * (res + b));
@@ -2128,14 +2164,17 @@ typedef double mjb_d4 __attribute__((ext_vector_type(4)));
 
 // R = rows per lane: row r lives in lane r % 64, slot r / 64 (nefcmax <= 64 R).  R == 1 is BASELINE config 3,
 // R == 4 covers the ~200 rows of config 5.
-template <int G, int R, bool CGS = false>  // CGS: conjugate gradient (no Hessian; Polak-Ribiere directions preconditioned by M^-1)
-STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e)
+// JG: efc_J is read from the env's block in HBM (Jg) instead of the frame (kernel variant 4, env-steps with more rows than the
+// frame's share of efc_J; see make_constraint)
+template <int G, int R, bool CGS = false, bool JG = false>  // CGS: conjugate gradient (no Hessian; Polak-Ribiere directions preconditioned by M^-1)
+STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e, const double *Jg = nullptr)
 {
 	static_assert(G == 64, "the Newton solver maps rows / Hessian columns to the 64 lanes of one wavefront");
 	double *f = e.f;
 	int *fi = e.fi;
 	const int lane = e.lane, nv = m.nv;
-	const int nefc = fi[L.nefc];
+	const int nefc = __builtin_amdgcn_readfirstlane(fi[L.nefc]);
+	const double *const Jb = JG ? Jg : f + L.efc_J;
 	if (nefc == 0) {
 		for (int d = lane; d < nv; d += G) {
 			const double a = f[L.qacc_smooth + d];
@@ -2198,7 +2237,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e)
 		for (int i = 0; i < R; i++) {
 			out[i] = 0;
 			if (64 * i >= nefc) continue;  // wave-uniform: no row of this slot exists
-			const double *Jr = f + L.efc_J + rr[i] * nv;
+			const double *Jr = Jb + rr[i] * nv;
 			double s = -sub * aref[i];
 #pragma unroll 5
 			for (int c = 0; c < nv; c++) s += Jr[c] * x[c];
@@ -2348,7 +2387,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e)
 		if (dofact) {
 			double s = 0;
 #pragma unroll 4
-			for (int i = 0; i < nefc; i++) s += f[L.efc_J + i * nv + k] * f[L.efc_force + i];
+			for (int i = 0; i < nefc; i++) s += Jb[i * nv + k] * f[L.efc_force + i];
 			f[L.qfrc_constraint + k] = s;
 			gr = ma - f[L.qfrc_smooth + k] - s;
 			grad[k] = gr;
@@ -2393,7 +2432,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e)
 #pragma unroll
 				for (int tb = 0; tb < 4; tb++) bv[tb] = 0;
 				if (r < nefc) {
-					const double *Jr = f + L.efc_J + r * nv;
+					const double *Jr = Jb + r * nv;
 #pragma unroll
 					for (int tb = 0; tb < 4; tb++)
 						if (tb <= ta && 16 * tb + li < nv) bv[tb] = Jr[16 * tb + li];
@@ -2404,7 +2443,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e)
 						const bool cone = meta >= 0;
 						const int adr = cone ? (meta & 255) : r, dim = cone ? ((meta >> 8) & 15) : 1, con = cone ? (meta >> 12) : 0;
 						const double *wp = cone ? Hc + 36 * con + 6 * (r - adr) : hw + r;
-						const double *Jc = f + L.efc_J + adr * nv + ca;
+						const double *Jc = Jb + adr * nv + ca;
 						double wv[6], jv6[6];
 #pragma unroll
 						for (int s2 = 0; s2 < 6; s2++) {

@@ -86,6 +86,7 @@ struct FrameLayout {
 	int eulerx;    // [nv]      Euler: velocity-update right-hand side / solution (transient)
 	int dadr;      // [64 ints] constrained kernels, nv <= 16: packed dense address map of lanes 0-15 (int frame)
 	int tri;       // [128]     transient scratch: packed dense triangle of the L'DL factor (PGS, nv <= 16: 120 doubles)
+	int jrows;     // rows of efc_J the frame holds (nefcmax, except in the fused frame of kernel variant 4: 64, the rest in DevState::efc_Jg)
 	int solvescr;  // [32]      pivot-row scratch of the dense M^-1 solves in fwd_acceleration / Euler (the factorisation uses crbbuf)
 	int bbscr;     // [128]     transient scratch of the box - box narrow phase (alive inside collision only)
 	int ndouble;   // doubles per frame
@@ -116,6 +117,7 @@ struct DevState {
 	const double *env_equality;      // [nenv][neq][19] per-env equality parameters (NULL: the model's)
 	const double *env_mass;          // [nenv][7 nbody + nv + ntendon + 1] per-env inertial constants (NULL: the model's):
 	                                 // body_mass | body_subtreemass | body_inertia[3] | dof_invweight0 | body_invweight0[2] | tendon_invweight0 | meaninertia
+	double *efc_Jg;                  // [nenv][nefcmax * nv] efc_J of the env-steps whose rows outnumber the fused frame's share (kernel variant 4); NULL otherwise
 	double *pgs_B;                   // [nenv][nefcmax * nv] rows of J M^-1 of the PGS steps beyond 64 rows (nv <= 16 models keep them out of LDS); NULL otherwise
 	int use_xfrc;                  // xfrc_applied has ever been written
 	int keep_frame;                // fused mjb_step also dumps the last step's full frame to frame_ws

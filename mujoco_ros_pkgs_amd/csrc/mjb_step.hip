@@ -1742,14 +1742,14 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 		if constexpr (CON != 0) {
 			if (trip == con_trip) {
 				PROF_BEGIN();
-				VIEW(P, compact, make_constraint<G>(m, L, s, e));
+				VIEW(P, compact, make_constraint<G, CON>(m, L, s, e));
 				PROF(17);
 				if constexpr (CON == 1 || CON == 5 || CON == 9) {
 					// (plain PGS, nv <= 16: the rows of B = J M^-1 are solved for inside the PGS stage, in registers)
-					if (P->m.nv > 16) VIEW(P, compact, project_constraint<G>(m, L, e));
-					else if constexpr (CON == 5) VIEW(P, compact, project_constraint_dense16<G>(m, L, e));
+					if (P->m.nv > 16) VIEW(P, compact, project_constraint<G, CON>(m, L, e));
+					else if constexpr (CON == 5) VIEW(P, compact, project_constraint_dense16<G, CON>(m, L, e));
 				}
-				VIEW(P, compact, reference_constraint<G>(m, L, e));
+				VIEW(P, compact, reference_constraint<G, CON>(m, L, s, e));
 				PROF(18);
 			}
 			if (trip) break;
@@ -1778,8 +1778,25 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 	PROF(9);
 	VIEW(P, compact, fwd_acceleration<G, (CON != 0 ? -1 : DENSE)>(m, L, e, s.use_xfrc != 0));
 	PROF(10);
-	if constexpr (CON >= 2 && CON <= 4 && G == 64) {
-		VIEW(P, compact, fwd_constraint_newton<G, (CON == 2 ? 1 : (CON == 3 ? 2 : 4))>(m, L, e));
+	if constexpr (CON == 4 && G == 64) {
+		// up to 256 rows.  The fused step's frame holds the first L.jrows (= 64) rows of efc_J: an env-step within that runs the
+		// one-row-per-lane solver on it, one beyond reads J from the env's block in HBM; the full frame (mjb_forward / mjb_step1 /
+		// mjb_step2) holds all of J
+		VIEW(P, compact, {
+			const int ne = __builtin_amdgcn_readfirstlane(e.fi[L.nefc]);
+			if (L.jrows >= m.nefcmax) {
+				MJB_KEEP_BRANCH();
+				fwd_constraint_newton<G, 4>(m, L, e);
+			} else if (ne <= L.jrows) {
+				MJB_KEEP_BRANCH();
+				fwd_constraint_newton<G, 1>(m, L, e);
+			} else {
+				MJB_KEEP_BRANCH();
+				fwd_constraint_newton<G, 4, false, true>(m, L, e, s.efc_Jg + (size_t)e.env * m.nefcmax * m.nv);
+			}
+		});
+	} else if constexpr (CON >= 2 && CON <= 3 && G == 64) {
+		VIEW(P, compact, fwd_constraint_newton<G, (CON == 2 ? 1 : 2)>(m, L, e));
 	} else if constexpr (CON >= 6 && CON <= 8 && G == 64) {
 		VIEW(P, compact, fwd_constraint_newton<G, (CON == 6 ? 1 : (CON == 7 ? 2 : 4)), true>(m, L, e));
 	} else if constexpr ((CON == 1 || CON == 5 || CON == 9) && G == 64) {
@@ -2073,6 +2090,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 	// grid-stride over env groups so any batch size runs with a bounded grid
 	for (int base = blockIdx.x * epb; base < s.nenv; base += gridDim.x * epb) {
 		e.env = base + slot;
+		if constexpr (G == 64) e.env = __builtin_amdgcn_readfirstlane(e.env);  // (one env per wavefront: keep the index and everything derived from it scalar)
 		if (e.env >= s.nenv) continue;  // whole group idles together (group == slot)
 		if constexpr (DENSE == 0) e.mp = s.env_mass ? s.env_mass + (size_t)e.env * (7 * m.nbody + m.nv + m.ntendon + 1) : nullptr;
 		else e.mp = nullptr;  // (batches with per-env masses never run the dense kernels)

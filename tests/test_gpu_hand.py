@@ -10,15 +10,29 @@ from test_gpu_contact import PRE, ROWS, _close, binding_dim
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["rows<=128", "rows<=256"])
+@pytest.fixture(scope="module", params=["rows<=128", "rows<=256", "rows<=256, J beyond the frame's share in HBM"])
 def setup(request, oracle_built):
+    import os
     from mujoco_ros_pkgs_amd import engine, mjcf, workloads
     kw = {"nefcmax": 128} if request.param == "rows<=128" else {"nefcmax": 160}
     model = mjcf.load_asset("shadow_hand_like", **kw)
+    # Above 128 rows of capacity the fused step's frame holds the first 64 rows of efc_J and an env-step with more rows reads J
+    # from the env's block in HBM.  The grasp states have 20 - 50 rows: the third variant lowers the frame's share
+    # to 8 rows (MJB_DEBUG_JROWS, read when the model is compiled) so that every env-step takes the HBM path.
+    hbm = "HBM" in request.param
+    if hbm:
+        os.environ["MJB_DEBUG_JROWS"] = "8"
+    try:
+        cm = engine.CompiledModel(model)
+    finally:
+        os.environ.pop("MJB_DEBUG_JROWS", None)
+    if hbm:
+        full, fused = cm.lib.mjb_frame_bytes(cm.ptr, 0), cm.lib.mjb_frame_bytes(cm.ptr, 1)
+        assert fused < full - 8 * (160 - 64) * model["nv"], (full, fused)
     # settle on the CPU oracle so that the states carry finger / palm / cube contacts
     qpos, qvel = workloads.hand_grasp_states(model, 24, seed=4)
     qpos, qvel, _ = oracle_built.rollout(model, qpos, qvel, 150, noise_std=0.1, noise_rate=0.1, seed=5, nthreads=8)
-    return model, engine.CompiledModel(model), engine, oracle_built, qpos, qvel
+    return model, cm, engine, oracle_built, qpos, qvel
 
 
 def test_hand_constraint_stages_match_oracle(setup):
