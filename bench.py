@@ -273,7 +273,10 @@ def main():
 
     if rank == 0:
         traffic, fp64 = None, None
-        pmc, pmc_file = _load_json(f"r02_cfg{cfgno}_pmc_summary.json", "r01_pmc_summary.json" if cfgno == 2 else f"r01_cfg{cfgno}_pmc_summary.json")
+        # (the counters belong to ONE kernel variant: a solver override has its own file or none)
+        solver_tag = "" if not args.solver else "_" + args.solver.lower()
+        pmc, pmc_file = _load_json(f"r02_cfg{cfgno}{solver_tag}_pmc_summary.json") if solver_tag else _load_json(
+            f"r02_cfg{cfgno}_pmc_summary.json", "r01_pmc_summary.json" if cfgno == 2 else f"r01_cfg{cfgno}_pmc_summary.json")
         flops, flops_file = _load_json("r02_oracle_flops.json")
         try:  # HBM bytes and executed fp64 flops per launch from the committed rocprofv3 PMC passes (same kernel, same config)
             pm_E, pm_S = pmc.get("envs", default_envs), pmc.get("substeps", default_sub)
