@@ -2243,6 +2243,59 @@ int launch_g(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode,
 
 }  // namespace
 
+// The kernel variants are compiled in slices, one translation unit per slice (-DMJB_GROUP=0..4: minutes of device code
+// generation run in parallel); without MJB_GROUP the whole file is one unit (profiling and development builds).
+//   0: models without constraint rows + the dispatcher   1: PGS (1, 5)   2: Newton 1 / 2 rows per lane   3: Newton 4 rows   4: CG
+//   5: the 256-register PGS variant (9) on its own: out-of-line helpers shared with the 512-register kernels would be compiled
+//      for their budget and cost it its second wave per SIMD, or spills (760 instead of 576 in the same unit as variants 1 / 5)
+#ifndef MJB_GROUP
+#define MJB_GROUP -1
+#endif
+#define MJB_HAS_GROUP(g) (MJB_GROUP < 0 || MJB_GROUP == (g))
+int mjb_launch_group1(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream);
+int mjb_launch_group2(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream);
+int mjb_launch_group3(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream);
+int mjb_launch_group4(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream);
+int mjb_launch_group5(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream);
+
+#if !defined(MJB_DEV_ONLY_CON)
+#if MJB_HAS_GROUP(1)
+int mjb_launch_group1(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream)
+{
+	if (constrained == 5) return launch_g<64, 5>(Pdev, L, nenv, mode, nsteps, step0, epb, stream);
+	return launch_g<64, 1>(Pdev, L, nenv, mode, nsteps, step0, epb, stream);
+}
+#endif
+#if MJB_HAS_GROUP(5)
+int mjb_launch_group5(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream)
+{
+	return launch_g<64, 9>(Pdev, L, nenv, mode, nsteps, step0, epb, stream);
+}
+#endif
+#if MJB_HAS_GROUP(2)
+int mjb_launch_group2(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream)
+{
+	if (constrained == 3) return launch_g<64, 3>(Pdev, L, nenv, mode, nsteps, step0, epb, stream);
+	return launch_g<64, 2>(Pdev, L, nenv, mode, nsteps, step0, epb, stream);
+}
+#endif
+#if MJB_HAS_GROUP(3)
+int mjb_launch_group3(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream)
+{
+	return launch_g<64, 4>(Pdev, L, nenv, mode, nsteps, step0, epb, stream);
+}
+#endif
+#if MJB_HAS_GROUP(4)
+int mjb_launch_group4(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream)
+{
+	if (constrained == 7) return launch_g<64, 7>(Pdev, L, nenv, mode, nsteps, step0, epb, stream);
+	if (constrained == 8) return launch_g<64, 8>(Pdev, L, nenv, mode, nsteps, step0, epb, stream);
+	return launch_g<64, 6>(Pdev, L, nenv, mode, nsteps, step0, epb, stream);
+}
+#endif
+#endif
+
+#if MJB_HAS_GROUP(0)
 int mjb_max_lds_bytes() { return 160 * 1024; }
 
 int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0,
@@ -2267,15 +2320,11 @@ int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, in
 		}
 	}
 	if (lanes_per_env != 64) return (int)hipErrorInvalidValue;
-	if (constrained == 2) return launch_g<64, 2>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
-	if (constrained == 3) return launch_g<64, 3>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
-	if (constrained == 4) return launch_g<64, 4>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
-	if (constrained == 5) return launch_g<64, 5>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
-	if (constrained == 6) return launch_g<64, 6>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
-	if (constrained == 7) return launch_g<64, 7>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
-	if (constrained == 8) return launch_g<64, 8>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
-	if (constrained == 9) return launch_g<64, 9>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
-	return launch_g<64, 1>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+	if (constrained == 2 || constrained == 3) return mjb_launch_group2(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream);
+	if (constrained == 4) return mjb_launch_group3(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream);
+	if (constrained >= 6 && constrained <= 8) return mjb_launch_group4(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream);
+	if (constrained == 9) return mjb_launch_group5(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream);
+	return mjb_launch_group1(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream);
 #endif
 }
 
@@ -2287,3 +2336,4 @@ int mjb_launch_reset(const KernelParams *Pdev, int nenv, const unsigned char *ma
 	                   (const KernelParams MJB_AS4 *)Pdev, mask_dev);
 	return (int)hipGetLastError();
 }
+#endif  // MJB_HAS_GROUP(0)
