@@ -266,7 +266,10 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	off += lean ? 0 : d.nM;
 	L.qHdi = off;
 	off += d.nv;
-	const bool need_tri = (d.nefcmax > 0 && d.solver == MJB_SOL_PGS && d.nv <= 16) || d.nconmax > 0;  // (128-double transient scratch)
+	// transient scratch of the constrained kernels: ntri doubles for the packed dense triangle of the L'DL factor (nv <= 16, PGS:
+	// the J M^-1 rows; 16 < nv <= 32: the M^-1 solves of fwd_acceleration / Euler, solve_tri32), 128 for the box - box narrow phase
+	const int ntri = d.nefcmax <= 0 ? 0 : ((d.nv <= 16 && d.solver == MJB_SOL_PGS) ? 128 : ((d.nv > 16 && d.nv <= 32) ? 496 : 0));
+	const int nbb = d.nconmax > 0 ? 128 : 0;
 	const int n_kin = 7 * d.nbody, n_crb = 10 * d.nbody, n_buf = 6 * d.nv < 32 ? 32 : 6 * d.nv, n_c6 = 6 * d.nbody;  // (crbbuf doubles as the 32-double pivot-row scratch of the dense factor)
 	if (compact) {
 		const int a0 = off;
@@ -276,11 +279,12 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		if (!need_post) L.cacc = a0;
 		L.cfrc_body = a0 + n_c6;
 		L.eulerx = a0;
-		L.tri = a0;  // (alive only inside the PGS stage: cacc / cfrc_body are dead by then)
+		L.tri = a0 + 32;  // (alive inside the PGS stage / the M^-1 solves: cacc / cfrc_body are dead by then; Euler's vector sits below it)
 		L.bbscr = a0;
 		L.solvescr = L.crbbuf;
 		int sz = n_kin;
-		if (need_tri && sz < 128) sz = 128;
+		if (ntri > 0 && sz < 32 + ntri) sz = 32 + ntri;
+		if (nbb > sz) sz = nbb;
 		if (n_crb + n_buf > sz) sz = n_crb + n_buf;
 		if (2 * n_c6 > sz) sz = 2 * n_c6;
 		if (d.nv > sz) sz = d.nv;
@@ -305,12 +309,12 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 			//  M^-1 solve of fwd_acceleration, the PGS stage's triangle -- takes its scratch, and Euler its right-hand side, from
 			//  the contact arrays nobody reads after make_constraint: dist | pos | frame | includemargin are contiguous, 14
 			//  doubles per contact; friction, which the elliptic solvers read, stays intact)
-			const int late = (need_tri ? 128 : 0) + 32 + d.nv;
+			const int late = ntri + 32 + d.nv;
 			int ls = off;
 			if (14 * d.nconmax >= late) ls = L.contact_dist;
 			else off += late;
 			L.tri = ls;
-			L.solvescr = ls + (need_tri ? 128 : 0);
+			L.solvescr = ls + ntri;
 			L.eulerx = L.solvescr + 32;
 		}
 	} else {
@@ -322,8 +326,9 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		off += d.nv;
 		L.solvescr = L.crbbuf;
 		L.tri = off;
+		off += ntri;
 		L.bbscr = off;
-		off += need_tri ? 128 : 0;
+		off += nbb;
 	}
 	if (off & 1) off++;
 	L.ndouble = off;

@@ -85,7 +85,7 @@ struct FrameLayout {
 	int crbbuf;    // [6*nv]    crb: crb[body(i)] * cdof_i (transient)
 	int eulerx;    // [nv]      Euler: velocity-update right-hand side / solution (transient)
 	int dadr;      // [64 ints] constrained kernels, nv <= 16: packed dense address map of lanes 0-15 (int frame)
-	int tri;       // [128]     transient scratch: packed dense triangle of the L'DL factor (PGS, nv <= 16: 120 doubles)
+	int tri;       // transient scratch: packed dense triangle of the L'DL factor (PGS, nv <= 16: 128 doubles; 16 < nv <= 32: 496, solve_tri32)
 	int jrows;     // rows of efc_J the frame holds (nefcmax, except in the fused frame of kernel variant 4: 64, the rest in DevState::efc_Jg)
 	int solvescr;  // [32]      pivot-row scratch of the dense M^-1 solves in fwd_acceleration / Euler (the factorisation uses crbbuf)
 	int bbscr;     // [128]     transient scratch of the box - box narrow phase (alive inside collision only)

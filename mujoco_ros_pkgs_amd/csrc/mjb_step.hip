@@ -849,6 +849,52 @@ template <int G> DEVI void solve(CModel m, const Env &e, double *x, const double
 	solve2<G>(m, e, x, LD, diaginv, x, LD, diaginv, false);
 }
 
+// x <- M^-1 x for 16 < nv <= 32 in the 512-register constrained kernels (one env per wavefront).  The sparse L'DL factor is spread
+// into a packed dense strictly-lower triangle T (entry (i, j), i > j, at i (i - 1) / 2 + j; zero where dof j is no ancestor of dof
+// i) in a 496-double LDS scratch; lane k keeps x_k, COLUMN k of T (for the L' sweep) and ROW k (for the L sweep) in 62 statically
+// indexed registers, and the pivots travel by v_readlane: 62 steps of (readlane pair, fma) instead of the generic solve's
+// ~2 nv LDS round trips -- 37 k -> ~5 k cycles at nv = 30 (BASELINE config 5).  Entries / elements >= nv are zero, so the
+// unrolled sweeps need no guards.  Both sweeps visit the off-diagonal entries of a row in ascending column order.
+template <int G> DEVI void solve_tri32(CModel m, const Env &e, double *x, const double *LD, const double *diaginv, double *T)
+{
+	static_assert(G == 64, "one env per wavefront");
+	const int lane = e.lane, nv = m.nv;
+	for (int t = lane; t < 496; t += G) T[t] = 0;
+	gsync<G>();
+	for (int en = lane; en < m.nM; en += G) {
+		const int i = m.M_rowdof[en], j = m.M_coldof[en];
+		if (i != j) T[i * (i - 1) / 2 + j] = LD[en];
+	}
+	gsync<G>();
+	const int k = lane < 32 ? lane : 0;  // (lanes 32 .. 63 mirror lane 0 and store nothing)
+	double col[32], row[32];
+#pragma unroll
+	for (int i = 1; i < 32; i++) {
+		const double v = T[i * (i - 1) / 2 + (k < i ? k : 0)];
+		col[i] = k < i ? v : 0.0;
+	}
+#pragma unroll
+	for (int j = 0; j < 31; j++) {
+		const double v = T[k > j ? k * (k - 1) / 2 + j : 0];
+		row[j] = k > j ? v : 0.0;
+	}
+	double xk = lane < nv ? x[lane] : 0.0;
+	const double dk = lane < nv ? diaginv[lane] : 0.0;
+#pragma unroll
+	for (int i = 31; i >= 1; i--) {  // x <- inv(L') x
+		const double xi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xk), i), __builtin_amdgcn_readlane(__double2loint(xk), i));
+		xk -= col[i] * xi;
+	}
+	xk *= dk;
+#pragma unroll
+	for (int j = 0; j < 31; j++) {  // x <- inv(L) x, column by column
+		const double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xk), j), __builtin_amdgcn_readlane(__double2loint(xk), j));
+		xk -= row[j] * xj;
+	}
+	if (lane < nv) x[lane] = xk;
+	gsync<G>();
+}
+
 // ------------------------------------------------------------------------------------------------
 // transmission (joint) : actuator_length
 // ------------------------------------------------------------------------------------------------
@@ -1459,7 +1505,7 @@ template <int G> STAGE void fwd_actuation(CModel m, CLayout L, const Env &e)
 	gsync<G>();
 }
 
-template <int G, int DENSE> STAGE void fwd_acceleration(CModel m, CLayout L, const Env &e, bool use_xfrc)
+template <int G, int DENSE, bool TRI32 = false> STAGE void fwd_acceleration(CModel m, CLayout L, const Env &e, bool use_xfrc)
 {
 	double *f = e.f;
 	for (int d = e.lane; d < m.nv; d += G) {
@@ -1502,8 +1548,10 @@ template <int G, int DENSE> STAGE void fwd_acceleration(CModel m, CLayout L, con
 			dadr_load(e, L, dl);
 			solve_dense16<G, 16>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual, dl,
 			                     f + L.solvescr);
-		}
-		else
+		} else if (TRI32 && m.nv <= 32 && !dual) {
+			MJB_KEEP_BRANCH();
+			solve_tri32<G>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.tri);
+		} else
 			solve2<G>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual);
 	} else
 		solve2<G>(m, e, f + L.qacc_smooth, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, dual);
@@ -1532,7 +1580,7 @@ template <int G> STAGE void fwd_constraint(CModel m, CLayout L, const Env &e)
 // ------------------------------------------------------------------------------------------------
 // A16 semi-implicit Euler with implicit joint damping
 // ------------------------------------------------------------------------------------------------
-template <int G, bool CAN16> STAGE void euler(CModel m, CLayout L, const Env &e)
+template <int G, bool CAN16, bool TRI32 = false> STAGE void euler(CModel m, CLayout L, const Env &e)
 {
 	double *f = e.f;
 	const double dt = m.timestep[0];
@@ -1548,6 +1596,9 @@ template <int G, bool CAN16> STAGE void euler(CModel m, CLayout L, const Env &e)
 				int dl[16];
 				dadr_load(e, L, dl);
 				solve_dense16<G, 16>(m, e, x, f + L.qH, f + L.qHdi, x, f + L.qH, f + L.qHdi, false, dl, f + L.solvescr);
+			} else if (TRI32 && m.nv <= 32) {
+				MJB_KEEP_BRANCH();
+				solve_tri32<G>(m, e, x, f + L.qH, f + L.qHdi, f + L.tri);
 			} else
 				solve<G>(m, e, x, f + L.qH, f + L.qHdi);
 		} else
@@ -1776,7 +1827,7 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 	PROF_BEGIN();
 	VIEW(P, compact, fwd_actuation<G>(m, L, e));
 	PROF(9);
-	VIEW(P, compact, fwd_acceleration<G, (CON != 0 ? -1 : DENSE)>(m, L, e, s.use_xfrc != 0));
+	VIEW(P, compact, fwd_acceleration<G, (CON != 0 ? -1 : DENSE), (CON >= 1 && CON <= 5)>(m, L, e, s.use_xfrc != 0));  // (TRI32: the 512-register constrained kernels)
 	PROF(10);
 	if constexpr (CON == 4 && G == 64) {
 		// up to 256 rows.  The fused step's frame holds the first L.jrows (= 64) rows of efc_J: an env-step within that runs the
@@ -2156,7 +2207,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 				reset_frame_state<G>(m, L, s, e, MJB_WARN_BADQACC);
 			}
 			PROF(14);  // whole forward (incl. checks)
-			if (do_euler) VIEW(P, compact, euler<G, (CON != 0)>(m, L, e));
+			if (do_euler) VIEW(P, compact, euler<G, (CON != 0), (CON >= 1 && CON <= 5)>(m, L, e));
 			PROF(15);
 		}
 
