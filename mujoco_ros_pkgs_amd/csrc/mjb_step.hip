@@ -1827,7 +1827,7 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 	PROF_BEGIN();
 	VIEW(P, compact, fwd_actuation<G>(m, L, e));
 	PROF(9);
-	VIEW(P, compact, fwd_acceleration<G, (CON != 0 ? -1 : DENSE), (CON >= 1 && CON <= 5)>(m, L, e, s.use_xfrc != 0));  // (TRI32: the 512-register constrained kernels)
+	VIEW(P, compact, fwd_acceleration<G, (CON != 0 ? -1 : DENSE), (CON >= 2 && CON <= 4)>(m, L, e, s.use_xfrc != 0));  // (TRI32: the Newton kernels -- in the PGS ones its 124 registers bring back the spill-before-exec-restore pattern)
 	PROF(10);
 	if constexpr (CON == 4 && G == 64) {
 		// up to 256 rows.  The fused step's frame holds the first L.jrows (= 64) rows of efc_J: an env-step within that runs the
@@ -2207,7 +2207,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 				reset_frame_state<G>(m, L, s, e, MJB_WARN_BADQACC);
 			}
 			PROF(14);  // whole forward (incl. checks)
-			if (do_euler) VIEW(P, compact, euler<G, (CON != 0), (CON >= 1 && CON <= 5)>(m, L, e));
+			if (do_euler) VIEW(P, compact, euler<G, (CON != 0), (CON >= 2 && CON <= 4)>(m, L, e));
 			PROF(15);
 		}
 
