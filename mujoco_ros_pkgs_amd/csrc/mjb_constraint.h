@@ -2132,27 +2132,22 @@ template <int J0> DEVI void chol_cols16(double (&Hr)[32], const int nv, const in
 {
 #pragma unroll
 	for (int j = J0; j < J0 + 16; j++) {
-		if (j >= nv) continue;  // (`break` here keeps LLVM from unrolling the nest: Hr would land in scratch)
-		MJB_KEEP_BRANCH();
+		// (no guards on nv anywhere in the nest: rows / columns >= nv are zero, so their steps are no-ops, and one straight-line
+		//  block lets the scheduler run a column's rsqrt chain under the previous column's trailing update -- config 5: +7 %)
 		double sj = wave_bcast(Hr[j], j);
 		if (sj < MJB_MINVAL) sj = MJB_MINVAL;
 		const double rinv = rsqrt(sj);
 		const double lkj = (lane == j) ? sj * rinv : Hr[j] * rinv;
 		Hr[j] = lkj;
 		if (lane == j) myrinv = rinv;
-		// groups of four columns: the four v_readlane pairs are issued together, then the four fma (constant loop
-		// bounds -- the nest only unrolls fully that way; entries c >= nv of a group belong to idle lanes: l_cj == 0)
+		// groups of four columns (constant loop bounds -- the nest only unrolls fully that way; entries c >= nv of a group belong to
+		// idle lanes: l_cj == 0)
 #pragma unroll
 		for (int c0 = 0; c0 < 32; c0 += 4) {
 			if (c0 + 3 <= j) continue;
-			if (c0 > j) {
-				if (c0 >= nv) continue;
-				MJB_KEEP_BRANCH();
-			}
 			double l4[4];
 #pragma unroll
 			for (int q = 0; q < 4; q++) l4[q] = wave_bcast(lkj, c0 + q);
-			asm volatile("" : "+s"(l4[0]), "+s"(l4[1]), "+s"(l4[2]), "+s"(l4[3]));
 #pragma unroll
 			for (int q = 0; q < 4; q++)
 				if (c0 + q > j) Hr[c0 + q] -= lkj * l4[q];
@@ -2514,13 +2509,21 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e, const double
 					if (c < nv) H[k * nv + c] = Hr[c];
 			}
 			// search = -H^-1 grad : lane k holds element k
+			// (elements >= nv are zero: no guards inside the halves, see chol_cols16)
 #pragma unroll
-			for (int i = 0; i < 32; i++) {
-				if (i >= nv) continue;  // (not `break`: see chol_cols16)
-				MJB_KEEP_BRANCH();
+			for (int i = 0; i < 16; i++) {
 				const double xi = wave_bcast(x * myrinv, i);
 				if (lane == i) x = xi;
 				else x -= ((dofact && lane > i) ? Hr[i] : 0.0) * xi;
+			}
+			if (nv > 16) {
+				MJB_KEEP_BRANCH();
+#pragma unroll
+				for (int i = 16; i < 32; i++) {
+					const double xi = wave_bcast(x * myrinv, i);
+					if (lane == i) x = xi;
+					else x -= ((dofact && lane > i) ? Hr[i] : 0.0) * xi;
+				}
 			}
 			gsync<G>();
 		} else {
