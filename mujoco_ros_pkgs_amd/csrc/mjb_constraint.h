@@ -2550,12 +2550,32 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e, const double
 			}
 		}
 		EPROF(31);
+		if (nv <= 32) {
+			// backward substitution: column k of L (parked in H by rows) fetched up front -- 31 independent LDS reads -- so that
+			// the dependent chain is (mul, readlane pair, fma) per row; elements >= nv are zero, no guards
+			MJB_KEEP_BRANCH();
+			double colk[32];
+#pragma unroll
+			for (int i = 1; i < 32; i++) {
+				const bool has = dofact && k < i && i < nv;
+				const double v = H[has ? i * nv + k : 0];
+				colk[i] = has ? v : 0.0;
+			}
+#pragma unroll
+			for (int i = 31; i >= 0; i--) {
+				if (i >= 16 && nv <= 16) continue;  // (compile-time half, wave-uniform test)
+				const double xi = wave_bcast(x * myrinv, i);
+				if (k == i) x = xi;
+				else x -= (i > 0 ? colk[i] : 0.0) * xi;
+			}
+		} else {
 #pragma unroll 4
 		for (int i = nv - 1; i >= 0; i--) {
 			const double xi = wave_bcast(x * myrinv, i);
 			const double lik = (dofact && k < i) ? H[i * nv + k] : 0.0;
 			if (k == i) x = xi;
 			else x -= lik * xi;
+		}
 		}
 		}
 		EPROF(28);
