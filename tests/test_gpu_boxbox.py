@@ -54,5 +54,5 @@ def test_box_box_up_to_eight_contacts(oracle_built):
     assert ncon[0, 0] == 8 and max(counts) == 8 and len(counts) >= 3, counts
     bt.step(30)
     oq, ov, _ = oracle_built.rollout(m, qpos, qvel, 30)
-    assert np.allclose(bt.get("qpos"), oq, rtol=0, atol=1e-7) and np.allclose(bt.get("qvel"), ov, rtol=0, atol=1e-5)
+    assert np.allclose(bt.get("qpos"), oq, rtol=0, atol=1e-9) and np.allclose(bt.get("qvel"), ov, rtol=0, atol=1e-7)
     bt.close()

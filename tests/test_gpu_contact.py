@@ -2,9 +2,12 @@
 BASELINE config 3 (Franka-like arm + table + free cube, pyramidal cones, joint limits, PGS).
 
 Tolerances: everything up to the solver inputs (contacts, J, R, D, KBIP, B, aref, b) <= 1e-10*(1+|x|); the
-solver outputs (efc_force, qacc) <= 1e-6 relative because the GPU sweep evaluates the residual AR-free
-(J_i.w + R_i f_i + b_i, w = M^-1 J' f updated incrementally) while the oracle multiplies the explicit
-efc_AR row -- same fixed point, different rounding along <= 100 Gauss-Seidel sweeps."""
+solver outputs (efc_force, qacc) <= 1e-6 relative: PGS stops on a cost improvement below 1e-8, so two correctly
+rounded runs whose last sweep differs (the GPU builds its rows of AR = J M^-1 J' + R in registers with fma
+contraction and a different summation order than the oracle's loops, Newton accumulates J'WJ on the matrix cores)
+agree to that order.  The 50-step rollout bounds (1e-9 qpos / 1e-7 qvel, relative to 1 + |x|) are two to three decades above
+what MI355X measures on these 32 envs (tools/_contact_err.py: PGS 5e-15 / 2e-13, Newton 2e-14 / 6e-13, Newton with elliptic
+cones 1e-11 / 3e-10): room for a sweep count that differs by one in some env, not for a wrong term."""
 import numpy as np
 import pytest
 
@@ -122,8 +125,8 @@ def test_contact_rollout_matches_oracle(setup):
     _close(b.get("qvel"), ov, 1e-8, "qvel after 1 step")
     b.step(49)
     oq, ov, os_ = po.rollout(model, qpos, qvel, 50, noise_std=3.0, noise_rate=0.1, seed=12345)
-    _close(b.get("qpos"), oq, 1e-5, "qpos after 50 steps")
-    _close(b.get("qvel"), ov, 1e-3, "qvel after 50 steps")
+    _close(b.get("qpos"), oq, 1e-9, "qpos after 50 steps")
+    _close(b.get("qvel"), ov, 1e-7, "qvel after 50 steps")
     assert np.allclose(b.get("time"), 50 * model["timestep"][0], atol=1e-12)
     b.close()
 

@@ -51,7 +51,7 @@ def test_friction_rows_match_oracle(oracle_built, solver, n):
     b.step(30)
     oq, ov, _ = oracle_built.rollout(m, qpos, qvel, 30)
     np.testing.assert_allclose(b.get("qpos"), oq, rtol=0, atol=1e-6)
-    np.testing.assert_allclose(b.get("qvel"), ov, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(b.get("qvel"), ov, rtol=0, atol=1e-5)
     b.close()
 
 

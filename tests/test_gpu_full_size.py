@@ -51,10 +51,10 @@ def _run(name, nenv, K, sample, tol_q, tol_v, oracle_built):
 
 
 def test_config3_pgs_4096_envs(oracle_built):
-    m = _run("franka_table", 4096, 60, 24, 1e-7, 1e-5, oracle_built)
+    m = _run("franka_table", 4096, 60, 24, 1e-9, 1e-7, oracle_built)
     assert (m["ngeom"], m["nconmax"], m["nefcmax"], m["solver"]) == (14, 16, 73, 0)
 
 
 def test_config5_newton_1024_envs(oracle_built):
-    m = _run("shadow_hand_like", 1024, 40, 16, 1e-7, 1e-4, oracle_built)
+    m = _run("shadow_hand_like", 1024, 40, 16, 1e-9, 1e-6, oracle_built)
     assert m["solver"] == 2 and m["cone"] == 1

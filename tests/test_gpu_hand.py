@@ -89,8 +89,8 @@ def test_hand_rollout_matches_oracle(setup):
     _close(b.get("qvel"), ov, 1e-7, "qvel after 1 step")
     b.step(19)
     oq, ov, os_ = po.rollout(model, qpos, qvel, 20, noise_std=0.1, noise_rate=0.1, seed=12345)
-    _close(b.get("qpos"), oq, 1e-6, "qpos after 20 steps")
-    _close(b.get("qvel"), ov, 1e-3, "qvel after 20 steps")
+    _close(b.get("qpos"), oq, 1e-8, "qpos after 20 steps")
+    _close(b.get("qvel"), ov, 1e-6, "qvel after 20 steps")
     b.close()
 
 

@@ -47,6 +47,6 @@ def test_limit_rows_match_oracle(oracle_built, solver, n):
             np.testing.assert_allclose(got[:k], ref[:k], rtol=0, atol=tol * (1 + np.abs(ref[:k]).max()), err_msg=f"{f} env {e}")
     b.step(20)
     oq, ov, _ = oracle_built.rollout(m, qpos, qvel, 20)
-    np.testing.assert_allclose(b.get("qpos"), oq, rtol=0, atol=1e-6)
-    np.testing.assert_allclose(b.get("qvel"), ov, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(b.get("qpos"), oq, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(b.get("qvel"), ov, rtol=0, atol=1e-5)
     b.close()
