@@ -1739,6 +1739,14 @@ template <bool ON> DEVI const KernelParams MJB_AS4 *launder_params(const KernelP
 	if (MJB_LAUNDER && ON) asm volatile("" : "+s"(p));
 	return p;
 }
+// (the lane index too: values derived from it -- lane * stride addresses, lane == k predicates of the unrolled register code -- are
+//  otherwise hoisted out of the step loop to the top of the kernel and, at 256 registers, spilled there and reloaded from scratch at
+//  every use: a trip to HBM in place of one integer instruction)
+#ifndef MJB_LAUNDER_LANE_OFF
+#define MJB_LAUNDER_LANE(e) asm volatile("" : "+v"(const_cast<int &>((e).lane)))
+#else
+#define MJB_LAUNDER_LANE(e) do { } while (0)
+#endif
 #define VIEW(P, compact, ...)                                              \
 	do {                                                                   \
 		const KernelParams MJB_AS4 *Pq_ = launder_params<MJB_LAUNDER_HERE>(P); \
@@ -1746,6 +1754,7 @@ template <bool ON> DEVI const KernelParams MJB_AS4 *launder_params(const KernelP
 		CLayout L = (compact) ? Pq_->Lc : Pq_->L;                          \
 		CState s = Pq_->s;                                                 \
 		(void)s;                                                           \
+		MJB_LAUNDER_LANE(e);                                               \
 		__VA_ARGS__;                                                       \
 	} while (0)
 
