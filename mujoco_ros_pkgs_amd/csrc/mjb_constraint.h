@@ -512,7 +512,7 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 	int base = 0;  // contacts of the earlier rounds (wave-uniform)
 	for (int p0 = 0; p0 < m.ncollpair; p0 += G) {
 		const int p = p0 + lane;
-		RawCon rc[8];
+		RawCon rc[4];  // (every primitive pair but box - box yields <= 4 contacts; box - box contacts go from the LDS scratch straight to the frame)
 		int n = 0, g1 = 0, g2 = 0, condim = 1, frisel = 0;
 		double margin = 0, incl = 0;
 		const mjb_cdptr pd = m.pair_d + 24 * (p < m.ncollpair ? p : 0);
@@ -580,36 +580,8 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 				}  // MJB_COLFUNC_NONE: no contacts
 			}
 		}
-		{
-			unsigned long long bbmask = __ballot(boxbox);
-			while (bbmask) {  // (wave-uniform) the lanes with a live box - box pair take turns at the LDS scratch
-				const int l = __builtin_ctzll(bbmask);
-				bbmask &= bbmask - 1;
-				if (lane == l) {
-					double *scr = f + L.bbscr;  // (transient scratch: nothing else of the frame's shared region is alive during collision)
-					n = box_box(scr, pos1, mat1, size1, pos2, mat2, size2, margin);
-#pragma unroll
-					for (int i = 0; i < 8; i++) {
-						const double *o = scr + 48 + 10 * (i < n ? i : 0);
-						rc[i].dist = o[0];
-						for (int k = 0; k < 3; k++) rc[i].pos[k] = o[1 + k];
-						for (int k = 0; k < 6; k++) rc[i].frame[k] = o[4 + k];
-					}
-				}
-			}
-		}
-#ifdef MJB_PROFILE_SUB
-		EPROF(24);
-#endif
-		int off = base, total = 0;
-#pragma unroll
-		for (int k = 1; k <= 8; k++) {
-			const unsigned long long mk = __ballot(n >= k);
-			off += lanes_below(mk);
-			total += __popcll(mk);
-		}
-		if (n > 0) {
-			double fri[3];
+		// this pair's friction (mj_contactParam) and the store of one contact -- shared by the register path and the box - box path
+		auto pair_friction = [&](double (&fri)[3]) {
 			if (L.gfriction >= 0) {
 				for (int k = 0; k < 3; k++) {
 					const double a = f[L.gfriction + 3 * g1 + k], b = f[L.gfriction + 3 * g2 + k];
@@ -624,30 +596,79 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 			} else {  // lean frame: the model's geoms, mixed on the host (pair record)
 				for (int k = 0; k < 3; k++) fri[k] = pd[18 + k];
 			}
+		};
+		auto put_contact = [&](int c, double dist, const double *cpos, const double *frame6, const double (&fri)[3]) {
+			double fr[9];
+			for (int k = 0; k < 6; k++) fr[k] = frame6[k];
+			make_frame(fr);
+			f[L.contact_dist + c] = dist;
+			st3(f + L.contact_pos + 3 * c, cpos);
+			st9(f + L.contact_frame + 9 * c, fr);
+			f[L.contact_includemargin + c] = incl;
+			double *f5 = f + L.contact_friction + 5 * c;
+			f5[0] = fri[0]; f5[1] = fri[0]; f5[2] = fri[1]; f5[3] = fri[2]; f5[4] = fri[2];
+			if (L.contact_solref >= 0) {
+				f[L.contact_solref + 2 * c] = pd[10];
+				f[L.contact_solref + 2 * c + 1] = pd[11];
+				for (int k = 0; k < 5; k++) f[L.contact_solimp + 5 * c + k] = pd[12 + k];
+			}
+			fi[L.contact_geom + 2 * c] = g1;
+			fi[L.contact_geom + 2 * c + 1] = g2;
+			fi[L.contact_dim + c] = condim;
+			// no rows yet (< 0).  The lean frame keeps no per-contact solref / solimp: -2 - pair tells make_constraint
+			// which pair record to read them from
+			fi[L.contact_efc_address + c] = L.contact_solref >= 0 ? -1 : -2 - p;
+		};
+		// contact slot of every lane's pair from the counts known so far: a pair yields <= 8 contacts, so its offset is
+		// sum_k popcount(ballot(n >= k) below this lane)
+		auto slot_of = [&](int &total) {
+			int o = base;
+			total = 0;
 #pragma unroll
-			for (int i = 0; i < 8; i++) {  // (fully unrolled, no early exit: rc[] stays in statically indexed registers)
+			for (int k = 1; k <= 8; k++) {
+				const unsigned long long mk = __ballot(n >= k);
+				o += lanes_below(mk);
+				total += __popcll(mk);
+			}
+			return o;
+		};
+		{
+			// box - box (up to 8 contacts, dynamically indexed clipping polygons): one lane at a time through the LDS scratch, and
+			// from there straight into the frame.  A lane's slot only depends on the pairs before it: the register pairs below it
+			// are counted already, the box - box pairs below it have had their turn, the ones above it still count 0.
+			unsigned long long bbmask = __ballot(boxbox);
+			while (bbmask) {  // (wave-uniform)
+				const int l = __builtin_ctzll(bbmask);
+				bbmask &= bbmask - 1;
+				double *scr = f + L.bbscr;  // (transient scratch: nothing else of the frame's shared region is alive during collision)
+				if (lane == l) n = box_box(scr, pos1, mat1, size1, pos2, mat2, size2, margin);
+				int unused_total;
+				const int offl = slot_of(unused_total);
+				if (lane == l && n > 0) {
+					double fri[3];
+					pair_friction(fri);
+					for (int i = 0; i < n; i++) {
+						const int c = offl + i;
+						if (c >= m.nconmax) break;
+						const double *o = scr + 48 + 10 * i;
+						put_contact(c, o[0], o + 1, o + 4, fri);
+					}
+				}
+			}
+		}
+#ifdef MJB_PROFILE_SUB
+		EPROF(24);
+#endif
+		int total;
+		const int off = slot_of(total);
+		if (n > 0 && !boxbox) {
+			double fri[3];
+			pair_friction(fri);
+#pragma unroll
+			for (int i = 0; i < 4; i++) {  // (fully unrolled, no early exit: rc[] stays in statically indexed registers)
 				const int c = off + i;
 				if (i >= n || c >= m.nconmax) continue;
-				double fr[9];
-				for (int k = 0; k < 6; k++) fr[k] = rc[i].frame[k];
-				make_frame(fr);
-				f[L.contact_dist + c] = rc[i].dist;
-				st3(f + L.contact_pos + 3 * c, rc[i].pos);
-				st9(f + L.contact_frame + 9 * c, fr);
-				f[L.contact_includemargin + c] = incl;
-				double *f5 = f + L.contact_friction + 5 * c;
-				f5[0] = fri[0]; f5[1] = fri[0]; f5[2] = fri[1]; f5[3] = fri[2]; f5[4] = fri[2];
-				if (L.contact_solref >= 0) {
-					f[L.contact_solref + 2 * c] = pd[10];
-					f[L.contact_solref + 2 * c + 1] = pd[11];
-					for (int k = 0; k < 5; k++) f[L.contact_solimp + 5 * c + k] = pd[12 + k];
-				}
-				fi[L.contact_geom + 2 * c] = g1;
-				fi[L.contact_geom + 2 * c + 1] = g2;
-				fi[L.contact_dim + c] = condim;
-				// no rows yet (< 0).  The lean frame keeps no per-contact solref / solimp: -2 - pair tells make_constraint
-				// which pair record to read them from
-				fi[L.contact_efc_address + c] = L.contact_solref >= 0 ? -1 : -2 - p;
+				put_contact(c, rc[i].dist, rc[i].pos, rc[i].frame, fri);
 			}
 		}
 		base += total;

@@ -5,7 +5,8 @@ When a VGPR is spilled (to an AGPR with v_accvgpr_write, or to scratch) at the h
 block, the spill can be placed *before* the `s_or_b64 exec, exec, s[..]` that re-enables the lanes parked
 by the preceding divergent loop / branch.  VALU and scratch stores honour exec, so the parked lanes never
 save (or reload) the value and later read garbage (r01: the Newton kernel lost its qpos address).
-v_writelane (SGPR spills) ignores exec and is harmless there.
+v_writelane (SGPR spills) ignores exec and is harmless there, and so is a spill bracketed by `s_or_saveexec_b64 sX, -1` ...
+`s_mov_b64 exec, sX` (whole-wave mode: how the VGPR that carries spilled SGPRs is itself saved and restored).
 
 usage: check_spill_exec.py file.s     (hipcc -S --cuda-device-only output); exit code 1 when a hazard is found
 """
@@ -18,13 +19,21 @@ def scan(path):
     kernel = None
     pending = []  # exec-sensitive spill instructions seen since the last label, before any exec restore
     in_head = False
+    wwm = None    # scalar register pair holding the saved exec while exec is forced to all ones
     for ln, line in enumerate(open(path), 1):
         s = line.strip()
         m = re.match(r"^(_Z\w+):", s)
         if m:
             kernel = m.group(1)
         if re.match(r"^\.?[\w$.]+:", s):  # any label starts a block
-            pending, in_head = [], True
+            pending, in_head, wwm = [], True, None
+            continue
+        mw = re.match(r"s_or_saveexec_b64\s+(s\[\d+:\d+\]),\s*-1", s)
+        if mw:
+            wwm = mw.group(1)
+            continue
+        if wwm and re.match(r"s_mov_b64\s+exec,\s*" + re.escape(wwm), s):
+            wwm = None
             continue
         if not in_head or not s or s.startswith(";"):
             continue
@@ -36,7 +45,8 @@ def scan(path):
             continue
         if op in ("v_accvgpr_write_b32", "v_accvgpr_read_b32") or (
                 op.startswith(("scratch_", "buffer_")) and ("Spill" in line or "Reload" in line)):
-            pending.append((ln, s))
+            if not wwm:
+                pending.append((ln, s))
             continue
         # anything that is not scalar bookkeeping ends the block head
         if op.startswith(("s_", "v_writelane", "v_readlane")) and not op.startswith(
