@@ -641,7 +641,18 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &
 				const int l = __builtin_ctzll(bbmask);
 				bbmask &= bbmask - 1;
 				double *scr = f + L.bbscr;  // (transient scratch: nothing else of the frame's shared region is alive during collision)
-				if (lane == l) n = box_box(scr, pos1, mat1, size1, pos2, mat2, size2, margin);
+				if (lane == l) {
+					// (the geoms' poses are read again, through laundered pointers: otherwise the 24 doubles loaded for the cull stay
+					//  live across every pair's narrow phase just for this rare path)
+					const double *gx = f + L.geom_xpos, *gm = f + L.geom_xmat;
+					asm volatile("" : "+v"(gx), "+v"(gm));
+					double p1[3], p2[3], m1[9], m2[9];
+					ld3(p1, gx + 3 * g1);
+					ld3(p2, gx + 3 * g2);
+					ld9(m1, gm + 9 * g1);
+					ld9(m2, gm + 9 * g2);
+					n = box_box(scr, p1, m1, size1, p2, m2, size2, margin);
+				}
 				int unused_total;
 				const int offl = slot_of(unused_total);
 				if (lane == l && n > 0) {
