@@ -54,6 +54,25 @@ DEVI int raw_plane_sphere(RawCon &c, const double *pos1, const double *n, const 
 
 DEVI double clipd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+// append `c` to a pair's contact list that holds `n` (0 or 1) entries -- written as selects on both slots: `rc[n] = c`, or a branch
+// the optimiser turns into it, is a dynamically indexed store, which moves ALL of rc[] from registers to scratch memory
+DEVI void rc_append(RawCon *rc, int n, const RawCon &c)
+{
+	const bool first = n == 0;
+	rc[0].dist = first ? c.dist : rc[0].dist;
+	rc[1].dist = first ? rc[1].dist : c.dist;
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		rc[0].pos[k] = first ? c.pos[k] : rc[0].pos[k];
+		rc[1].pos[k] = first ? rc[1].pos[k] : c.pos[k];
+	}
+#pragma unroll
+	for (int k = 0; k < 6; k++) {
+		rc[0].frame[k] = first ? c.frame[k] : rc[0].frame[k];
+		rc[1].frame[k] = first ? rc[1].frame[k] : c.frame[k];
+	}
+}
+
 DEVI int raw_sphere_box(RawCon &c, const double *pos1, double r1, const double *pos2, const double *mat2,
                         const double *size2, double margin)
 {
@@ -178,8 +197,7 @@ DEVI int capsule_box(RawCon *rc, const double *pos1, const double *mat1, const d
 		ctr[0] = pos1[0] + axis[0] * tb; ctr[1] = pos1[1] + axis[1] * tb; ctr[2] = pos1[2] + axis[2] * tb;
 		RawCon c2;
 		if (raw_sphere_box(c2, ctr, r, pos2, mat2, size2, margin)) {
-			if (n == 0) rc[0] = c2;
-			else rc[1] = c2;
+			rc_append(rc, n, c2);
 			n++;
 		}
 	}
@@ -372,8 +390,11 @@ DEVI int narrowphase(int t1, int t2, const double *pos1, const double *mat1, con
 			double p[3] = { pos2[0] + axis[0] * size2[1], pos2[1] + axis[1] * size2[1], pos2[2] + axis[2] * size2[1] };
 			n = raw_plane_sphere(rc[0], pos1, nrm, p, size2[0], margin);
 			p[0] = pos2[0] - axis[0] * size2[1]; p[1] = pos2[1] - axis[1] * size2[1]; p[2] = pos2[2] - axis[2] * size2[1];
-			if (n) n += raw_plane_sphere(rc[1], pos1, nrm, p, size2[0], margin);
-			else n += raw_plane_sphere(rc[0], pos1, nrm, p, size2[0], margin);
+			RawCon c2;
+			if (raw_plane_sphere(c2, pos1, nrm, p, size2[0], margin)) {
+				rc_append(rc, n, c2);
+				n++;
+			}
 			for (int i = 0; i < 2; i++)
 				if (i < n) { rc[i].frame[3] = axis[0]; rc[i].frame[4] = axis[1]; rc[i].frame[5] = axis[2]; }
 		} else if (t2 == MJB_GEOM_BOX) {
@@ -460,7 +481,7 @@ DEVI int narrowphase(int t1, int t2, const double *pos1, const double *mat1, con
 				for (int k = 0; k < 3; k++) p2[k] = pos2[k] + a2[k] * x2;
 				RawCon c;
 				if (raw_sphere_sphere(c, p1, size1[0], p2, size2[0], margin)) {
-					if (n == 0) rc[0] = c; else rc[1] = c;
+					rc_append(rc, n, c);
 					n++;
 				}
 			}
@@ -473,7 +494,7 @@ DEVI int narrowphase(int t1, int t2, const double *pos1, const double *mat1, con
 				for (int k = 0; k < 3; k++) p1[k] = pos1[k] + a1[k] * x1;
 				RawCon c;
 				if (raw_sphere_sphere(c, p1, size1[0], p2, size2[0], margin)) {
-					if (n == 0) rc[0] = c; else rc[1] = c;
+					rc_append(rc, n, c);
 					n++;
 				}
 			}
