@@ -6,7 +6,7 @@ solver outputs (efc_force, qacc) <= 1e-6 relative: PGS stops on a cost improveme
 rounded runs whose last sweep differs (the GPU builds its rows of AR = J M^-1 J' + R in registers with fma
 contraction and a different summation order than the oracle's loops, Newton accumulates J'WJ on the matrix cores)
 agree to that order.  The 50-step rollout bounds (1e-9 qpos / 1e-7 qvel, relative to 1 + |x|) are two to three decades above
-what MI355X measures on these 32 envs (tools/_contact_err.py: PGS 5e-15 / 2e-13, Newton 2e-14 / 6e-13, Newton with elliptic
+what MI355X measures on these 32 envs (tools/contact_err.py: PGS 5e-15 / 2e-13, Newton 2e-14 / 6e-13, Newton with elliptic
 cones 1e-11 / 3e-10): room for a sweep count that differs by one in some env, not for a wrong term."""
 import numpy as np
 import pytest

@@ -1,3 +1,5 @@
+"""Measured GPU-vs-oracle error of the 50-step contact rollout of tests/test_gpu_contact.py, per solver / cone (what its bounds are
+set against)."""
 import os, sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np

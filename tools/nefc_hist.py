@@ -1,3 +1,5 @@
+"""Distribution of the constraint-row / contact counts over the envs of a bench workload (why 64 rows of efc_J in the frame are enough
+for config 5, how many config-3 env-steps exceed 32 rows).  usage: nefc_hist.py [model] [envs]"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np

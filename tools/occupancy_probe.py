@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Scratch experiment: throughput of the config-3 PGS kernel against resident waves per CU.  Capacities are shrunk until 8 envs fit one
+"""Throughput of the config-3 PGS kernel against resident waves per CU.  usage: occupancy_probe.py nconmax njmax [envs].  Capacities are shrunk until 8 envs fit one
 CU's LDS, then MJB_DEBUG_LDS_BYTES (read once per process: run one process per setting) pads the request back up."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
