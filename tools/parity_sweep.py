@@ -22,9 +22,12 @@ ap.add_argument("--steps", type=int, default=30)
 args = ap.parse_args()
 pyoracle.build()
 CASES = [("franka_table", {"solver": s, "cone": c}) for s in ("PGS", "Newton", "CG") for c in ("pyramidal", "elliptic")]
+# (PGS with elliptic cone blocks holds at most 64 rows: the table-size njmax of 73 is for the pyramidal asset)
+CAP = {("PGS", "elliptic"): 64}
 CASES += [("shadow_hand_like", {"solver": s}) for s in ("Newton", "CG")]
 for name, over in CASES:
-    m = mjcf.compile_xml_file(os.path.join(mjcf.ASSET_DIR, name + ".xml"), override=over)
+    cap = CAP.get((over.get("solver"), over.get("cone")))
+    m = mjcf.compile_xml_file(os.path.join(mjcf.ASSET_DIR, name + ".xml"), override=over, **({"nefcmax": cap} if cap else {}))
     n = args.envs if name == "franka_table" else max(16, args.envs // 8)
     if name == "franka_table":
         qpos, qvel = scenario_states(m, n, seed=123)
