@@ -896,6 +896,7 @@ void mjb_free_batch(mjb_batch *b)
 	if (b->st.nwarn) hipFree(b->st.nwarn);
 	if (b->st.pgs_B) hipFree(b->st.pgs_B);
 	if (b->st.efc_Jg) hipFree(b->st.efc_Jg);
+	if (b->st.sched) hipFree(b->st.sched);
 	if (b->metrics_dev) hipFree(b->metrics_dev);
 	if (b->st.prof) hipFree(b->st.prof);
 	if (b->blob) hipFree(b->blob);
@@ -1067,6 +1068,11 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	s.env_mass = nullptr;
 	s.pgs_B = nullptr;
 	s.efc_Jg = nullptr;
+	s.sched = nullptr;
+	if (h.nefcmax > 0) {  // constrained kernels: work queue of the chunked fused launches
+		s.sched = dev_alloc<int>((size_t)nenv + 1);
+		ok = ok && s.sched;
+	}
 	if (h.solver == MJB_SOL_NEWTON && h.nefcmax > 128) {  // kernel variant 4: efc_J of the env-steps beyond the fused frame's 64 rows
 		s.efc_Jg = dev_alloc<double>((size_t)nenv * h.nefcmax * h.nv);
 		ok = ok && s.efc_Jg;
@@ -1170,8 +1176,17 @@ static int launch(mjb_batch *b, int mode, int nsteps)
 		static const int forced = [] { const char *v = getenv("MJB_DEBUG_VARIANT"); return v ? atoi(v) : -1; }();  // measurement knob
 		if (forced >= 0 && variant != 0) variant = forced;
 	}
+	// long fused launches of the constrained kernels hand out (chunk of steps, env) work items dynamically (mjb_step.hip)
+	int chunk = 0;
+	if (mode == MJB_MODE_STEP && variant != 0 && nsteps >= 100 && b->st.sched) {
+		static const bool off = getenv("MJB_DEBUG_NO_CHUNKS") != nullptr;  // measurement knob
+		if (!off) {
+			chunk = std::max(25, (nsteps + 7) / 8);
+			HIP_TRY(hipMemsetAsync(b->st.sched, 0, ((size_t)b->nenv + 1) * sizeof(int), b->stream));
+		}
+	}
 	int rc = mjb_launch_step(b->params_dev, compact ? b->model->Lc : b->L, b->nenv, mode, nsteps, b->step_counter, b->lanes,
-	                         b->epb, variant, (b->lanes == 16 && !b->env_mass && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, b->stream);
+	                         b->epb, variant | (chunk << 8), (b->lanes == 16 && !b->env_mass && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, b->stream);
 	if (rc != 0) return fail(MJB_ENODEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
 	return MJB_OK;
 }

@@ -117,6 +117,7 @@ struct DevState {
 	const double *env_equality;      // [nenv][neq][19] per-env equality parameters (NULL: the model's)
 	const double *env_mass;          // [nenv][7 nbody + nv + ntendon + 1] per-env inertial constants (NULL: the model's):
 	                                 // body_mass | body_subtreemass | body_inertia[3] | dof_invweight0 | body_invweight0[2] | tendon_invweight0 | meaninertia
+	int *sched;                      // [1 + nenv] work counter | chunks done per env, of a chunked fused launch (constrained kernels); NULL otherwise
 	double *efc_Jg;                  // [nenv][nefcmax * nv] efc_J of the env-steps whose rows outnumber the fused frame's share (kernel variant 4); NULL otherwise
 	double *pgs_B;                   // [nenv][nefcmax * nv] rows of J M^-1 of the PGS steps beyond 64 rows (nv <= 16 models keep them out of LDS); NULL otherwise
 	int use_xfrc;                  // xfrc_applied has ever been written

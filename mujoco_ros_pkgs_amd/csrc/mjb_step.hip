@@ -2088,7 +2088,7 @@ template <int G, int CON, int DENSE>
 #endif
 __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G == 64 ? 4 : (G == 32 ? 2 : 1)))))
     mjb_step_kernel(const KernelParams MJB_AS4 *__restrict__ P, const int mode, const int nsteps,
-                    const unsigned int step0, const int epb, const int frame_bytes)
+                    const unsigned int step0, const int epb, const int frame_bytes, const int chunk)
 {
 	// launch parameters live in device memory behind a constant-address-space pointer: every field is
 	// fetched with a scalar load where it is used instead of pinning ~300 SGPRs for the whole kernel
@@ -2147,9 +2147,33 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 	e.f = reinterpret_cast<double *>(smem + (size_t)slot * frame_bytes);
 	e.fi = reinterpret_cast<int *>(e.f + L.ndouble);
 
-	// grid-stride over env groups so any batch size runs with a bounded grid
-	for (int base = blockIdx.x * epb; base < s.nenv; base += gridDim.x * epb) {
-		e.env = base + slot;
+	// Constrained kernels, long fused launches (chunk > 0): the K steps of an env are cut into chunks and every (chunk, env) pair is
+	// a work item handed out from a counter in chunk-major order; an item waits for its env's previous chunk (taken nenv items
+	// earlier by a block that is running or done, so the wait cannot deadlock) and the state crosses HBM between chunks exactly
+	// as it does between launches.  An env's cost varies 2x around the mean and a CU holds few envs: with two envs per slot the
+	// slowest pair sets the launch time, with 2 * nchunk items per slot the slots even out (config 3: +7 %).
+	const bool dyn = CON != 0 && G == 64 && chunk > 0 && mode == MJB_MODE_STEP && s.sched != nullptr;
+	const int nchunk = dyn ? (nsteps + chunk - 1) / chunk : 1;
+	// (otherwise) grid-stride over env groups so any batch size runs with a bounded grid
+	for (int base = blockIdx.x * epb;; base += gridDim.x * epb) {
+		int item_chunk = 0;
+		if (dyn) {
+			int w = 0;
+			if (e.lane == 0) w = atomicAdd(s.sched, 1);
+			w = __builtin_amdgcn_readfirstlane(w);
+			if (w >= s.nenv * nchunk) break;
+			item_chunk = w / s.nenv;
+			e.env = w - item_chunk * s.nenv;
+			if (item_chunk > 0) {
+				int *done = s.sched + 1 + e.env;
+				while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < item_chunk)
+					__builtin_amdgcn_s_sleep(16);
+				__threadfence();  // (the state the previous chunk stored is read through the vector cache)
+			}
+		} else {
+			if (base >= s.nenv) break;
+			e.env = base + slot;
+		}
 		if constexpr (G == 64) e.env = __builtin_amdgcn_readfirstlane(e.env);  // (one env per wavefront: keep the index and everything derived from it scalar)
 		if (e.env >= s.nenv) continue;  // whole group idles together (group == slot)
 		if constexpr (DENSE == 0) e.mp = s.env_mass ? s.env_mass + (size_t)e.env * (7 * m.nbody + m.nv + m.ntendon + 1) : nullptr;
@@ -2189,12 +2213,13 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 		const bool do_first = mode != MJB_MODE_STEP2, do_rest = mode != MJB_MODE_STEP1;
 		const bool do_euler = mode == MJB_MODE_STEP || mode == MJB_MODE_STEP2;
 		const bool checks = mode != MJB_MODE_FORWARD;
-		const int nst = mode == MJB_MODE_STEP ? nsteps : 1;
+		const int st0 = item_chunk * chunk;  // first step of this work item (0 unless the launch is chunked)
+		const int nst = mode == MJB_MODE_STEP ? (dyn ? (nsteps - st0 < chunk ? nsteps - st0 : chunk) : nsteps) : 1;
 		const bool hw_on = do_rest && checks && P->hw.n > 0;  // device-side DefaultRobotHWSim stage registered
 #pragma nounroll
 		for (int st = 0; st < nst; st++) {
 			PROF_BEGIN();
-			if (do_first && checks && nz.enabled) ctrl_noise<G>(m, L, nz, e, step0 + (unsigned int)st);
+			if (do_first && checks && nz.enabled) ctrl_noise<G>(m, L, nz, e, step0 + (unsigned int)(st0 + st));
 			PROF(13);
 			// attempt 1 only runs after mj_checkAcc found a bad qacc: reset, full forward, integrate
 #pragma nounroll
@@ -2205,7 +2230,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 						if (bad) reset_frame_state<G>(m, L, s, e, bad == 1 ? MJB_WARN_BADQPOS : MJB_WARN_BADQVEL);
 					}
 					forward_first<G, CON, DENSE>(P, e, compact);
-					if (st == nst - 1 && P->m.enableflags & MJB_ENBL_ENERGY) VIEW(P, compact, energy<G>(m, L, e));
+					if (st0 + st == (mode == MJB_MODE_STEP ? nsteps : 1) - 1 && P->m.enableflags & MJB_ENBL_ENERGY) VIEW(P, compact, energy<G>(m, L, e));
 				}
 				if (!do_rest) break;
 				// device-side DefaultRobotHWSim::writeSim runs where the reference's control callback fires: after the position
@@ -2227,6 +2252,10 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 			for (int k = e.lane; k < L.ndouble; k += G) ws[k] = e.f[k];
 			int *wsi = reinterpret_cast<int *>(ws + L.ndouble);
 			for (int k = e.lane; k < L.nint; k += G) wsi[k] = e.fi[k];
+		}
+		if (dyn) {  // publish the chunk: the state stores above first
+			__threadfence();
+			if (e.lane == 0) __hip_atomic_store(s.sched + 1 + e.env, item_chunk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 		}
 		gsync<G>();
 	}
@@ -2270,7 +2299,7 @@ __global__ void mjb_reset_kernel(const KernelParams MJB_AS4 *__restrict__ P, con
 
 template <int G, int CON, int DENSE = 0>
 int launch_g(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0,
-             int epb, void *stream)
+             int epb, void *stream, int chunk = 0)
 {
 	const int frame_bytes = ((L.ndouble * 8 + L.nint * 4) + 15) & ~15;
 	const int maxlds = mjb_max_lds_bytes();
@@ -2297,7 +2326,7 @@ int launch_g(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode,
 	const int maxblocks = 256 * 16;
 	if (blocks > maxblocks) blocks = maxblocks;
 	hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, (hipStream_t)stream,
-	                   (const KernelParams MJB_AS4 *)Pdev, mode, nsteps, step0, epb, frame_bytes);
+	                   (const KernelParams MJB_AS4 *)Pdev, mode, nsteps, step0, epb, frame_bytes, CON != 0 ? chunk : 0);
 	return (int)hipGetLastError();
 }
 
@@ -2312,45 +2341,45 @@ int launch_g(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode,
 #define MJB_GROUP -1
 #endif
 #define MJB_HAS_GROUP(g) (MJB_GROUP < 0 || MJB_GROUP == (g))
-int mjb_launch_group1(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream);
-int mjb_launch_group2(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream);
-int mjb_launch_group3(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream);
-int mjb_launch_group4(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream);
-int mjb_launch_group5(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream);
+int mjb_launch_group1(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk);
+int mjb_launch_group2(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk);
+int mjb_launch_group3(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk);
+int mjb_launch_group4(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk);
+int mjb_launch_group5(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk);
 
 #if !defined(MJB_DEV_ONLY_CON)
 #if MJB_HAS_GROUP(1)
-int mjb_launch_group1(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream)
+int mjb_launch_group1(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk)
 {
-	if (constrained == 5) return launch_g<64, 5>(Pdev, L, nenv, mode, nsteps, step0, epb, stream);
-	return launch_g<64, 1>(Pdev, L, nenv, mode, nsteps, step0, epb, stream);
+	if (constrained == 5) return launch_g<64, 5>(Pdev, L, nenv, mode, nsteps, step0, epb, stream, chunk);
+	return launch_g<64, 1>(Pdev, L, nenv, mode, nsteps, step0, epb, stream, chunk);
 }
 #endif
 #if MJB_HAS_GROUP(5)
-int mjb_launch_group5(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream)
+int mjb_launch_group5(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk)
 {
-	return launch_g<64, 9>(Pdev, L, nenv, mode, nsteps, step0, epb, stream);
+	return launch_g<64, 9>(Pdev, L, nenv, mode, nsteps, step0, epb, stream, chunk);
 }
 #endif
 #if MJB_HAS_GROUP(2)
-int mjb_launch_group2(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream)
+int mjb_launch_group2(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk)
 {
-	if (constrained == 3) return launch_g<64, 3>(Pdev, L, nenv, mode, nsteps, step0, epb, stream);
-	return launch_g<64, 2>(Pdev, L, nenv, mode, nsteps, step0, epb, stream);
+	if (constrained == 3) return launch_g<64, 3>(Pdev, L, nenv, mode, nsteps, step0, epb, stream, chunk);
+	return launch_g<64, 2>(Pdev, L, nenv, mode, nsteps, step0, epb, stream, chunk);
 }
 #endif
 #if MJB_HAS_GROUP(3)
-int mjb_launch_group3(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream)
+int mjb_launch_group3(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk)
 {
-	return launch_g<64, 4>(Pdev, L, nenv, mode, nsteps, step0, epb, stream);
+	return launch_g<64, 4>(Pdev, L, nenv, mode, nsteps, step0, epb, stream, chunk);
 }
 #endif
 #if MJB_HAS_GROUP(4)
-int mjb_launch_group4(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream)
+int mjb_launch_group4(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk)
 {
-	if (constrained == 7) return launch_g<64, 7>(Pdev, L, nenv, mode, nsteps, step0, epb, stream);
-	if (constrained == 8) return launch_g<64, 8>(Pdev, L, nenv, mode, nsteps, step0, epb, stream);
-	return launch_g<64, 6>(Pdev, L, nenv, mode, nsteps, step0, epb, stream);
+	if (constrained == 7) return launch_g<64, 7>(Pdev, L, nenv, mode, nsteps, step0, epb, stream, chunk);
+	if (constrained == 8) return launch_g<64, 8>(Pdev, L, nenv, mode, nsteps, step0, epb, stream, chunk);
+	return launch_g<64, 6>(Pdev, L, nenv, mode, nsteps, step0, epb, stream, chunk);
 }
 #endif
 #endif
@@ -2363,8 +2392,10 @@ int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, in
 {
 	// (the headline kernels are instantiated first so that they sit at the start of the code object whatever happens to the
 	//  size of the constrained ones: their absolute placement is worth ~2 % on config 2)
+	const int chunk = constrained >> 8;  // (steps per work item of a chunked launch, 0 = one item per env; mjb_api.hip: launch)
+	constrained &= 255;
 #ifdef MJB_DEV_ONLY_CON  // development switch: compile ONE constrained kernel variant (seconds instead of minutes)
-	return launch_g<64, MJB_DEV_ONLY_CON>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+	return launch_g<64, MJB_DEV_ONLY_CON>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream, chunk);
 #else
 	if (!constrained) {
 		switch (lanes_per_env) {
@@ -2380,11 +2411,11 @@ int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, in
 		}
 	}
 	if (lanes_per_env != 64) return (int)hipErrorInvalidValue;
-	if (constrained == 2 || constrained == 3) return mjb_launch_group2(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream);
-	if (constrained == 4) return mjb_launch_group3(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream);
-	if (constrained >= 6 && constrained <= 8) return mjb_launch_group4(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream);
-	if (constrained == 9) return mjb_launch_group5(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream);
-	return mjb_launch_group1(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream);
+	if (constrained == 2 || constrained == 3) return mjb_launch_group2(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream, chunk);
+	if (constrained == 4) return mjb_launch_group3(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream, chunk);
+	if (constrained >= 6 && constrained <= 8) return mjb_launch_group4(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream, chunk);
+	if (constrained == 9) return mjb_launch_group5(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream, chunk);
+	return mjb_launch_group1(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream, chunk);
 #endif
 }
 

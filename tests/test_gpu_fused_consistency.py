@@ -79,6 +79,31 @@ def test_fused_steps_equal_single_steps(name, solver, lanes, keep):
     assert np.all(np.isfinite(res[0]["qpos"]))
 
 
+@pytest.mark.parametrize("name,solver", [("franka_table", "PGS"), ("franka_table", "Newton"), ("shadow_hand_like", "Newton")])
+def test_chunked_launch_equals_short_launches(name, solver):
+    """Fused launches of >= 100 steps of the constrained kernels hand out (chunk of steps, env) work items from a device-side
+    queue, an item waiting for its env's previous chunk (mjb_step.hip, `dyn`): bit-equal to the same steps as short launches,
+    which run one item per env -- with more envs than the chip holds at once, so that items do wait."""
+    from mujoco_ros_pkgs_amd import engine
+    model = _model(name, solver)
+    cm = engine.CompiledModel(model)
+    nenv, K = (1100 if name == "shadow_hand_like" else 4500), 120
+    qpos, qvel = _initial(model, name, nenv)
+    res = []
+    for plan in ([K], [40, 40, 40]):
+        b = engine.Batch(cm, nenv)
+        b.set("qpos", qpos)
+        b.set("qvel", qvel)
+        b.set_ctrl_noise(0.1 if name == "shadow_hand_like" else 2.0, 0.1, 77, 0)
+        for k in plan:
+            b.step(k)
+        res.append({f: b.get(f).copy() for f in STATE})
+        b.close()
+    for f in STATE:
+        assert np.array_equal(res[0][f], res[1][f]), f"{name}/{solver}: chunked launch differs in {f}: max |d| {np.abs(res[0][f] - res[1][f]).max():.3e}"
+    assert np.all(np.isfinite(res[0]["qpos"]))
+
+
 @pytest.mark.parametrize("name,solver,lanes", [("franka_like", None, 16), ("franka_table", "PGS", 64),
                                                ("franka_table", "Newton", 64)])
 def test_keep_frame_matches_split_step(name, solver, lanes):
