@@ -1990,10 +1990,12 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 					const double *Ji = J0 + q * nv;
 					double acc0 = 0, acc1 = 0;
 #pragma unroll
-					for (int k = 0; k < 16; k += 2) {  // (the select keeps whatever lies behind a short row -- possibly NaN bits -- out of the sum)
-						const double j0 = Ji[k], j1 = Ji[k + 1];
-						acc0 += x[k] * (k < nv ? j0 : 0.0);
-						acc1 += x[k + 1] * (k + 1 < nv ? j1 : 0.0);
+					for (int k = 0; k < 16; k += 2) {
+						// (x[k >= nv] == 0: the clamped address keeps whatever lies behind a short row -- possibly NaN bits -- out of
+						//  the sum without a vector select per element)
+						const double j0 = Ji[k < nv ? k : 0], j1 = Ji[k + 1 < nv ? k + 1 : 0];
+						acc0 += x[k] * j0;
+						acc1 += x[k + 1] * j1;
 					}
 					AR[i + q] = acc0 + acc1;
 				}
