@@ -1,0 +1,46 @@
+"""Residency guard: how many envs one CU's 160 KB of LDS holds is decided by the fused step's frame, and the round-2
+throughput of the contact configs rests on it -- eight lean frames per CU for config 3 (two waves per SIMD with the 256-register PGS
+kernel), two for config 5 (64 rows of efc_J in the frame, the rest of its 200-row capacity in HBM).  Host-side only: mjb_compile needs
+no GPU."""
+import os
+
+from mujoco_ros_pkgs_amd import engine, mjcf
+
+LDS = 160 * 1024
+
+
+def _bytes(model):
+    cm = engine.CompiledModel(model)
+    return cm.lib.mjb_frame_bytes(cm.ptr, 0), cm.lib.mjb_frame_bytes(cm.ptr, 1)
+
+
+def test_config3_lean_frame_fits_eight_per_cu():
+    m = mjcf.load_asset("franka_table")
+    assert (m["nconmax"], m["nefcmax"]) == (16, 73)   # SURVEY.md §8 table size
+    full, fused = _bytes(m)
+    assert fused * 8 <= LDS < fused * 9, (full, fused)
+    assert fused < full // 2          # efc_J overlays dead fields, row bookkeeping cut to what the solver reads
+
+
+def test_config5_lean_frame_fits_two_per_cu():
+    m = mjcf.load_asset("shadow_hand_like")
+    assert (m["nconmax"], m["nefcmax"]) == (48, 200)
+    full, fused = _bytes(m)
+    assert full <= LDS and fused * 2 <= LDS, (full, fused)
+    assert full - fused >= 8 * (200 - 64) * m["nv"]   # at least the rows of efc_J beyond the frame's share
+
+
+def test_unconstrained_compact_frame_unchanged():
+    full, fused = _bytes(mjcf.load_asset("franka_like"))
+    assert fused * 16 <= LDS and fused < full          # config 2: all 4096 envs resident at 16 per CU
+
+
+def test_debug_knob_lowers_the_frames_share_of_J():
+    m = mjcf.load_asset("shadow_hand_like")
+    _, fused = _bytes(m)
+    os.environ["MJB_DEBUG_JROWS"] = "8"
+    try:
+        _, fused8 = _bytes(m)
+    finally:
+        os.environ.pop("MJB_DEBUG_JROWS", None)
+    assert fused8 <= fused      # (the overlay region cannot shrink below the fields efc_J shares it with)
