@@ -873,10 +873,11 @@ DEVI int wave_incl_scan(int v, int lane)
 	return v;
 }
 
-// Wave-uniform values read back from LDS (row / contact counts): telling the compiler so makes the loops on them scalar, which
-// the 512-register kernels profit from (fewer spills, and none of ROCm 7.2's spill-before-exec-restore patterns in the plain PGS
-// kernel) -- and the 256-register PGS variant (TAG 9) does not: its scalar registers are as short as its vector ones.
-template <int TAG> DEVI int wave_uniform(int v) { return TAG == 9 ? v : __builtin_amdgcn_readfirstlane(v); }
+// Wave-uniform values read back from LDS (row / contact counts): telling the compiler so makes the loops on them scalar (fewer
+// spills, and none of ROCm 7.2's spill-before-exec-restore patterns in the plain PGS kernel).  (While loop invariants were still
+// hoisted to the top of the kernel this cost the 256-register PGS variant 400 spills and was switched off for it; with machine
+// LICM off it is neutral there.)
+template <int TAG> DEVI int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // TAG 4 (Newton, up to 256 rows, fused step): the frame holds the first L.jrows rows of efc_J only -- what lets two envs of
 // config 5 share a CU's LDS.  Rows beyond go to the env's block of s.efc_Jg in HBM; an env-step that ends up with more than
