@@ -104,6 +104,40 @@ def test_chunked_launch_equals_short_launches(name, solver):
     assert np.all(np.isfinite(res[0]["qpos"]))
 
 
+def test_chunked_launch_with_hwsim_and_kept_frame():
+    """The same with the device-side hwsim stage (its PID state lives in HBM across the chunks) and with keep_frame (full frame
+    layout, constraint rows built in MuJoCo's place): chunked == short launches, state and derived fields."""
+    from mujoco_ros_pkgs_amd import engine
+    from test_hwsim import _cfg, _commands
+    model = _model("franka_table", "PGS")
+    cm = engine.CompiledModel(model)
+    spec = _cfg(model)
+    nenv, K = 300, 120
+    cp, cv, ce = _commands(len(spec), nenv, 1)
+    qpos, qvel = _initial(model, "franka_table", nenv)
+    res = []
+    for plan in ([K], [40, 40, 40]):
+        b = engine.Batch(cm, nenv)
+        b.set_keep_frame(True)
+        b.hwsim_configure(spec)
+        b.hwsim_set_command("position", cp)
+        b.hwsim_set_command("velocity", cv)
+        b.hwsim_set_command("effort", ce)
+        b.set("qpos", qpos)
+        b.set("qvel", qvel)
+        for k in plan:
+            b.step(k)
+        res.append({f: b.get(f).copy() for f in STATE + ["qfrc_applied", "efc_force", "xpos", "nefc"]})
+        b.close()
+    for f in res[0]:
+        if f == "efc_force":  # (rows beyond nefc are whatever the frame held)
+            for e in range(nenv):
+                k = int(res[0]["nefc"][e, 0])
+                assert np.array_equal(res[0][f][e, :k], res[1][f][e, :k]), f"chunked launch differs in {f}, env {e}"
+        else:
+            assert np.array_equal(res[0][f], res[1][f]), f"chunked launch differs in {f}"
+
+
 @pytest.mark.parametrize("name,solver,lanes", [("franka_like", None, 16), ("franka_table", "PGS", 64),
                                                ("franka_table", "Newton", 64)])
 def test_keep_frame_matches_split_step(name, solver, lanes):
