@@ -1174,7 +1174,7 @@ static int launch(mjb_batch *b, int mode, int nsteps)
 	if (variant == 1 && compact && 8 * mjb_frame_bytes(b->model, 1) <= mjb_max_lds_bytes()) variant = 9;
 	{
 		static const int forced = [] { const char *v = getenv("MJB_DEBUG_VARIANT"); return v ? atoi(v) : -1; }();  // measurement knob
-		if (forced >= 0 && variant != 0) variant = forced;
+		if ((forced == 1 || forced == 9) && (variant == 1 || variant == 9)) variant = forced;  // (only the two builds of the same PGS step are interchangeable)
 	}
 	// long fused launches of the constrained kernels hand out (chunk of steps, env) work items dynamically (mjb_step.hip)
 	int chunk = 0;
