@@ -2103,7 +2103,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 	Env e;
 #ifdef MJB_PROFILE
 	e.prof = s.prof;
-	if (blockIdx.x == 0 && threadIdx.x < 64) mjb_prof_lds[threadIdx.x] = 0;
+	if (threadIdx.x < 64) mjb_prof_lds[threadIdx.x] = 0;  // (every block: with the work queue env 0's items run wherever they land)
 	__syncthreads();
 #endif
 	e.lane = threadIdx.x % G;
@@ -2261,7 +2261,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 	}
 #ifdef MJB_PROFILE
 	__syncthreads();
-	if (blockIdx.x == 0 && threadIdx.x < 64 && s.prof) s.prof[threadIdx.x] += mjb_prof_lds[threadIdx.x];
+	if (threadIdx.x < 64 && s.prof && mjb_prof_lds[threadIdx.x]) atomicAdd(s.prof + threadIdx.x, mjb_prof_lds[threadIdx.x]);
 #endif
 }
 
