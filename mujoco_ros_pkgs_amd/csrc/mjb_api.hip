@@ -269,7 +269,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	// transient scratch of the constrained kernels: ntri doubles for the packed dense triangle of the L'DL factor (nv <= 16, PGS:
 	// the J M^-1 rows; 16 < nv <= 32: the M^-1 solves of fwd_acceleration / Euler, solve_tri32), 128 for the box - box narrow phase
 	const int ntri = d.nefcmax <= 0 ? 0 : ((d.nv <= 16 && d.solver == MJB_SOL_PGS) ? 128 : ((d.nv > 16 && d.nv <= 32) ? 496 : 0));
-	const int nbb = d.nconmax > 0 ? 128 : 0;
+	const int nbb = d.nconmax > 0 ? 216 : 0;  // (MJB_BBSCR of mjb_constraint.h)
 	const int n_kin = 7 * d.nbody, n_crb = 10 * d.nbody, n_buf = 6 * d.nv < 32 ? 32 : 6 * d.nv, n_c6 = 6 * d.nbody;  // (crbbuf doubles as the 32-double pivot-row scratch of the dense factor)
 	if (compact) {
 		const int a0 = off;

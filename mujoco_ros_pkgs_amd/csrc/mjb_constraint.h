@@ -206,15 +206,23 @@ DEVI int capsule_box(RawCon *rc, const double *pos1, const double *mat1, const d
 
 // box - box: same steps as oracle/mjo_constraint.c box_box (separating axes, then either the incident face clipped
 // against the reference face -- up to 4 contacts after reduction -- or one edge-edge contact)
-// The clipping polygons are indexed dynamically: they (and the up to 8 output contacts, 10 doubles each: dist, pos, normal +
-// tangent hint) live in a 128-double LDS scratch `scr` that ONE lane at a time owns (collision() serialises the box - box
-// lanes) -- private arrays indexed that way would sit in scratch memory and drag every pair's contact registers there too.
-DEVI int box_box(double *scr, const double *pos1, const double *mat1, const double *size1, const double *pos2,
-                 const double *mat2, const double *size2, double margin)
+// The clipping polygons, the axis tables and the half sizes are indexed dynamically (separating-axis code, reference face): they
+// (and the up to 8 output contacts, 10 doubles each: dist, pos, normal + tangent hint) live in a MJB_BBSCR-double LDS scratch `scr`
+// that ONE lane at a time owns (collision() serialises the box - box lanes) -- private arrays indexed that way sit in scratch
+// memory, where every access is a trip to L2 / HBM (config 5 runs this every step: the cube lies on the palm plate).
+#define MJB_BBSCR 216
+DEVI int box_box(double *scr, const double *pos1, const double *mat1, const double *size1_in, const double *pos2,
+                 const double *mat2, const double *size2_in, double margin)
 {
 	double (*poly)[3] = reinterpret_cast<double (*)[3]>(scr), (*tmp)[3] = reinterpret_cast<double (*)[3]>(scr + 24);
 	double *out = scr + 48;
-	double A[3][3], B[3][3], C[3][3], Q[3][3], tA[3], tB[3];
+	double (*A)[3] = reinterpret_cast<double (*)[3]>(scr + 128), (*B)[3] = reinterpret_cast<double (*)[3]>(scr + 137);
+	double (*C)[3] = reinterpret_cast<double (*)[3]>(scr + 146), (*Q)[3] = reinterpret_cast<double (*)[3]>(scr + 155);
+	double *tA = scr + 164, *tB = scr + 167, *size1 = scr + 203, *size2 = scr + 206;
+	for (int i = 0; i < 3; i++) {
+		size1[i] = size1_in[i];
+		size2[i] = size2_in[i];
+	}
 	for (int i = 0; i < 3; i++)
 		for (int k = 0; k < 3; k++) {
 			A[i][k] = mat1[3 * k + i];
@@ -298,7 +306,8 @@ DEVI int box_box(double *scr, const double *pos1, const double *mat1, const doub
 	}
 	const bool ref1 = code < 3;
 	const int ax = ref1 ? code : code - 3;
-	double R[3][3], O[3][3], pr[3], po[3], hr[3], ho[3];
+	double (*R)[3] = reinterpret_cast<double (*)[3]>(scr + 170), (*O)[3] = reinterpret_cast<double (*)[3]>(scr + 179);
+	double *pr = scr + 188, *po = scr + 191, *hr = scr + 194, *ho = scr + 197;
 	for (int i = 0; i < 3; i++) {
 		pr[i] = ref1 ? pos1[i] : pos2[i];
 		po[i] = ref1 ? pos2[i] : pos1[i];

@@ -88,7 +88,7 @@ struct FrameLayout {
 	int tri;       // transient scratch: packed dense triangle of the L'DL factor (PGS, nv <= 16: 128 doubles; 16 < nv <= 32: 496, solve_tri32)
 	int jrows;     // rows of efc_J the frame holds (nefcmax, except in the fused frame of kernel variant 4: 64, the rest in DevState::efc_Jg)
 	int solvescr;  // [32]      pivot-row scratch of the dense M^-1 solves in fwd_acceleration / Euler (the factorisation uses crbbuf)
-	int bbscr;     // [128]     transient scratch of the box - box narrow phase (alive inside collision only)
+	int bbscr;     // [216]     transient scratch of the box - box narrow phase (alive inside collision only)
 	int ndouble;   // doubles per frame
 	int nint;      // ints per frame (follow the doubles)
 	int nstate;    // doubles in the persistent prefix
