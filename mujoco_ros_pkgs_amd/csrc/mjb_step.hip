@@ -79,10 +79,24 @@ struct LaneConst {
 	unsigned int d_bmlo, d_bmhi;  // bodies moved by the dof  // d_zero: translational dof of a free joint; d_simple: first joint of its body
 };
 
+// The lane's index inside its env group, re-derived from the hardware lane id at EVERY read (two VALU instructions behind an
+// `asm volatile`): a plain int member is a loop invariant of the K-step loop, and everything computed from it -- lane * stride
+// addresses, the lane == k predicates of the unrolled register code -- gets hoisted to the top of the kernel, kept live across
+// every stage and, in the 256-register kernels, spilled there and reloaded from scratch at each use.
+struct LaneId {
+	int mask;  // G - 1
+	__device__ __forceinline__ operator int() const
+	{
+		int l;
+		asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+		return l & mask;
+	}
+};
+
 struct Env {
 	double *f;  // LDS frame (doubles)
 	int *fi;    // LDS frame (ints)
-	int lane;   // 0..G-1
+	LaneId lane;  // 0..G-1
 	int env;    // batch-local env index
 	int dadr[16];  // dense kernels only: qM address of entry (i, lane) of the joint-space inertia, or -1
 	LaneConst lc;  // one-body-per-lane kernels only
@@ -1742,11 +1756,7 @@ template <bool ON> DEVI const KernelParams MJB_AS4 *launder_params(const KernelP
 // (the lane index too: values derived from it -- lane * stride addresses, lane == k predicates of the unrolled register code -- are
 //  otherwise hoisted out of the step loop to the top of the kernel and, at 256 registers, spilled there and reloaded from scratch at
 //  every use: a trip to HBM in place of one integer instruction)
-#ifndef MJB_LAUNDER_LANE_OFF
-#define MJB_LAUNDER_LANE(e) asm volatile("" : "+v"(const_cast<int &>((e).lane)))
-#else
-#define MJB_LAUNDER_LANE(e) do { } while (0)
-#endif
+#define MJB_LAUNDER_LANE(e) do { } while (0)  // (the lane index launders itself: LaneId)
 #define VIEW(P, compact, ...)                                              \
 	do {                                                                   \
 		const KernelParams MJB_AS4 *Pq_ = launder_params<MJB_LAUNDER_HERE>(P); \
@@ -2106,7 +2116,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 	if (threadIdx.x < 64) mjb_prof_lds[threadIdx.x] = 0;  // (every block: with the work queue env 0's items run wherever they land)
 	__syncthreads();
 #endif
-	e.lane = threadIdx.x % G;
+	e.lane.mask = G - 1;  // (1-D blocks of whole wavefronts: lane in group = hardware lane id & (G - 1))
 	if constexpr (DENSE) {
 #pragma unroll
 		for (int i = 0; i < 16; i++) e.dadr[i] = m.M_dense[16 * i + e.lane];
