@@ -2486,35 +2486,37 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e, const double
 			// One pass over the 4-row slabs per tile ROW ta: the weighted operand A = (W J)[slab][16 ta + .] is formed once and
 			// multiplied with the column blocks tb <= ta (one accumulator each); the next slab's operands are fetched before
 			// the current slab's MFMAs issue, so the dependent LDS reads (row metadata -> cone block / J) overlap them.
+			// (straight-line: rows past nefc and columns past nv read clamped addresses and are zeroed by selects -- with branches
+			//  around the loads the scheduler cannot run a slab's operand fetch under the previous slab's MFMAs)
 			auto operands = [&](int r0, int ca, bool ina, double &av, double (&bv)[4], int ta) {
 				const int r = r0 + lk;
-				av = 0;
+				const bool live = r < nefc;
+				const int rc = live ? r : 0;
+				const double *Jr = Jb + rc * nv;
 #pragma unroll
-				for (int tb = 0; tb < 4; tb++) bv[tb] = 0;
-				if (r < nefc) {
-					const double *Jr = Jb + r * nv;
-#pragma unroll
-					for (int tb = 0; tb < 4; tb++)
-						if (tb <= ta && 16 * tb + li < nv) bv[tb] = Jr[16 * tb + li];
-					if (ina) {
-						// branch-free: a scalar row is a 1 x 1 "block" whose weight sits in hw[r]; all loads of the slab leave
-						// together once the row's metadata int has arrived
-						const int meta = fi[L.iscratch + r];
-						const bool cone = meta >= 0;
-						const int adr = cone ? (meta & 255) : r, dim = cone ? ((meta >> 8) & 15) : 1, con = cone ? (meta >> 12) : 0;
-						const double *wp = cone ? Hc + 36 * con + 6 * (r - adr) : hw + r;
-						const double *Jc = Jb + adr * nv + ca;
-						double wv[6], jv6[6];
-#pragma unroll
-						for (int s2 = 0; s2 < 6; s2++) {
-							const int sc = s2 < dim ? s2 : 0;
-							wv[s2] = wp[sc];
-							jv6[s2] = Jc[sc * nv];
-						}
-#pragma unroll
-						for (int s2 = 0; s2 < 6; s2++) av += s2 < dim ? wv[s2] * jv6[s2] : 0.0;
-					}
+				for (int tb = 0; tb < 4; tb++) {
+					const int col = 16 * tb + li;
+					const double v = Jr[col < nv ? col : 0];
+					bv[tb] = (live && tb <= ta && col < nv) ? v : 0.0;
 				}
+				// a scalar row is a 1 x 1 "block" whose weight sits in hw[r]; all loads of the slab leave together once the
+				// row's metadata int has arrived
+				const int meta = fi[L.iscratch + rc];
+				const bool cone = meta >= 0;
+				const int adr = cone ? (meta & 255) : rc, dim = cone ? ((meta >> 8) & 15) : 1, con = cone ? (meta >> 12) : 0;
+				const double *wp = cone ? Hc + 36 * con + 6 * (rc - adr) : hw + rc;
+				const double *Jc = Jb + adr * nv + (ina ? ca : 0);
+				double wv[6], jv6[6];
+#pragma unroll
+				for (int s2 = 0; s2 < 6; s2++) {
+					const int sc = s2 < dim ? s2 : 0;
+					wv[s2] = wp[sc];
+					jv6[s2] = Jc[sc * nv];
+				}
+				double a = 0;
+#pragma unroll
+				for (int s2 = 0; s2 < 6; s2++) a += s2 < dim ? wv[s2] * jv6[s2] : 0.0;
+				av = (live && ina) ? a : 0.0;
 			};
 			for (int ta = 0; ta < ntile; ta++) {
 				mjb_d4 acc[4];
@@ -2525,7 +2527,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e, const double
 				double av, bv[4], an, bn[4];
 				operands(0, ca, ina, av, bv, ta);
 				for (int r0 = 0; r0 < nefc; r0 += 4) {
-					if (r0 + 4 < nefc) operands(r0 + 4, ca, ina, an, bn, ta);
+					operands(r0 + 4, ca, ina, an, bn, ta);  // (past the last slab: all zero)
 #pragma unroll
 					for (int tb = 0; tb < 4; tb++)
 						if (tb <= ta) acc[tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[tb], acc[tb], 0, 0, 0);
