@@ -122,15 +122,16 @@ struct Env {
 // A1  kinematics: body frames, joint anchors/axes, inertial / geom / site frames
 // ------------------------------------------------------------------------------------------------
 DEVI void local2global(const double *xpos_b, const double *xquat_b, const double *xmat_b, double *opos,
-                       double *omat, const double *pos, const double *quat, int sameframe, double *oquat = nullptr)
+                       double *omat, const double *pos, const double *quat, int sameframe, double *oquat = nullptr, int wq = -1)
 {
+	const bool has_quat = wq < 0 ? oquat != nullptr : wq != 0;  // (wq: the caller's per-lane flag when oquat is always a valid address)
 	if (sameframe) {
 		double p[3], M[9];
 		ld3(p, xpos_b);
 		ld9(M, xmat_b);
 		st3(opos, p);
 		st9(omat, M);
-		if (oquat) {
+		if (has_quat) {
 			double bq[4];
 			ld4(bq, xquat_b);
 			st4(oquat, bq);
@@ -146,7 +147,7 @@ DEVI void local2global(const double *xpos_b, const double *xquat_b, const double
 		quat2mat(r, q);
 		st3(opos, v);
 		st9(omat, r);
-		if (oquat) st4(oquat, q);
+		if (has_quat) st4(oquat, q);
 	}
 }
 
@@ -367,20 +368,22 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 				matvec3(v, M, ax);
 				st3(xaxis + 3 * j, v);
 			}
-		} else if (it < m.njnt + m.ngeom) {
-			const int g = it - m.njnt, b = m.geom_bodyid[g];
-			double pos[3], quat[4];
-			ldc3(pos, m.geom_pos + 3 * g);
-			ldc4(quat, m.geom_quat + 4 * g);
-			local2global(xpos + 3 * b, xquat + 4 * b, xmat + 9 * b, f + L.geom_xpos + 3 * g, f + L.geom_xmat + 9 * g,
-			             pos, quat, m.geom_sameframe[g]);
 		} else {
-			const int st = it - m.njnt - m.ngeom, b = m.site_bodyid[st];
+			// geoms and sites take ONE path (lanes of both kinds run it together: a branch per kind is a second serial pass of
+			// dependent table loads, ~2.5 k cycles per step)
+			const bool isg = it < m.njnt + m.ngeom;
+			const int id = isg ? it - m.njnt : it - m.njnt - m.ngeom;
+			const int b = isg ? m.geom_bodyid[id] : m.site_bodyid[id];
+			const mjb_cdptr ppos = isg ? m.geom_pos + 3 * id : m.site_pos + 3 * id;
+			const mjb_cdptr pquat = isg ? m.geom_quat + 4 * id : m.site_quat + 4 * id;
+			const int same = isg ? m.geom_sameframe[id] : m.site_sameframe[id];
 			double pos[3], quat[4];
-			ldc3(pos, m.site_pos + 3 * st);
-			ldc4(quat, m.site_quat + 4 * st);
-			local2global(xpos + 3 * b, xquat + 4 * b, xmat + 9 * b, f + L.site_xpos + 3 * st, f + L.site_xmat + 9 * st,
-			             pos, quat, m.site_sameframe[st], f + L.site_xquat + 4 * st);
+			ldc3(pos, ppos);
+			ldc4(quat, pquat);
+			double *opos = f + (isg ? L.geom_xpos + 3 * id : L.site_xpos + 3 * id);
+			double *omat = f + (isg ? L.geom_xmat + 9 * id : L.site_xmat + 9 * id);
+			double *oquat = f + L.site_xquat + (isg ? 0 : 4 * id);
+			local2global(xpos + 3 * b, xquat + 4 * b, xmat + 9 * b, opos, omat, pos, quat, same, oquat, isg ? 0 : 1);
 		}
 	}
 	gsync<G>();
