@@ -1179,7 +1179,7 @@ static int launch(mjb_batch *b, int mode, int nsteps)
 	// long fused launches of the constrained kernels hand out (chunk of steps, env) work items dynamically (mjb_step.hip)
 	int chunk = 0;
 	if (mode == MJB_MODE_STEP && variant != 0 && nsteps >= 100 && b->st.sched) {
-		static const bool off = getenv("MJB_DEBUG_NO_CHUNKS") != nullptr;  // measurement knob
+		static const bool off = [] { const char *v = getenv("MJB_DEBUG_NO_CHUNKS"); return v && *v && *v != '0'; }();  // measurement knob
 		if (!off) {
 			static const int forced = [] { const char *v = getenv("MJB_DEBUG_CHUNK"); return v ? atoi(v) : 0; }();
 			chunk = forced > 0 ? forced : std::max(10, (nsteps + 15) / 16);  // (measured: 10 - 40 steps per item are equally good on config 3, 5 - 15 on config 5)
