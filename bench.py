@@ -168,6 +168,7 @@ def main():
     ap.add_argument("--model", default="")
     ap.add_argument("--solver", default="", choices=["", "PGS", "Newton"], help="override the model's constraint solver")
     ap.add_argument("--nefcmax", type=int, default=0, help="override the model's constraint-row capacity")
+    ap.add_argument("--nconmax", type=int, default=0, help="override the model's contact capacity")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -214,7 +215,7 @@ def main():
 
     from mujoco_ros_pkgs_amd import binding, engine, mjcf, sharding
 
-    model = mjcf.load_asset(name, **({"nefcmax": args.nefcmax} if args.nefcmax else {}))
+    model = mjcf.load_asset(name, **({"nefcmax": args.nefcmax} if args.nefcmax else {}), **({"nconmax": args.nconmax} if args.nconmax else {}))
     model = mjcf.Model(dict(model))
     model["enableflags"] = int(model["enableflags"]) | 2  # mjENBL_ENERGY: the metrics vector carries the energies
     if args.solver:

@@ -78,7 +78,7 @@ struct mjb_model {
 	std::vector<int> hint;            // all int arrays, concatenated
 	std::vector<double> hdbl;         // all double arrays, concatenated
 	std::vector<size_t> ioff, doff;   // offsets of each array inside hint / hdbl (declaration order)
-	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense, body_anc, dof_bodymask;
+	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense, body_anc, dof_bodymask, M_sym;
 	std::vector<int> sens_copy, sens_slow, dof_act_adr, dof_act_id;
 	std::vector<int> pair_i;       // [ncollpair][8]  per candidate pair: g1, g2, type1, type2, condim, friction rule, collision-function override, 0
 	std::vector<double> pair_d;    // [ncollpair][24] size1[3] size2[3] margin gap rbound1 rbound2 solref[2] solimp[5] includemargin friction[3] pad[3]
@@ -143,7 +143,8 @@ namespace {
 //     (1 / R on the fly) and efc_R for the primal solvers;
 //   * contact_solref / contact_solimp are gone (make_constraint reads the pair record the contact came from);
 //   * the PGS triangle scratch sits on the dead contact arrays, the box - box clipping scratch at the start of U.
-void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
+// jrows_req > 0: rows of efc_J the fused frame of kernel variant 4 holds (choose_layout picks it); 0 = the default
+void compute_layout(mjb_model *M, FrameLayout &L, bool compact, int jrows_req = 0)
 {
 	const mjb_model_desc &d = M->h;
 	int off = 0, ioff = 0, nstate = 0;
@@ -184,11 +185,21 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	// more rows keeps J in the env's block of DevState::efc_Jg (config 5 never has: what lets two of its envs share a CU's LDS)
 	int jrows = d.nefcmax;
 	if (compact && d.solver == MJB_SOL_NEWTON && d.nefcmax > 128) {
-		jrows = 64;
+		jrows = jrows_req > 0 ? std::max(4, std::min(64, jrows_req)) : 64;
 		if (const char *v = getenv("MJB_DEBUG_JROWS")) jrows = std::max(4, std::min(64, atoi(v)));  // test knob: force the HBM path
 	}
 	L.jrows = jrows;
 	std::vector<int> u_members;  // field ids overlaid by efc_J, in placement order
+	// "X layout" -- lean frames of the Newton kernels (nv <= 32: M lives in registers inside the solver).  One region X is shared by
+	// three generations of data:
+	//   X = [ D | R ],  D = cdof | qM | qLD | qLDiagInv | contact dist / pos / frame / includemargin   (dead once the solver has
+	//                       gathered its rows of M: nothing after make_constraint / fwd_acceleration reads them)
+	//                   R = position / velocity-stage scratch (regions A, B, the U members)           (dead at make_constraint)
+	//   make_constraint .. solver:   efc_J | efc_D | efc_aref | efc_b | efc_force at the END of X
+	//   fwd_acceleration, Euler:     the dense-triangle scratch (tri | solvescr | eulerx) right below efc_J, inside R
+	//   solver only:                 nwt_H | nwt_vec | nwt_row | nwt_hc from the START of X (over D and the head of R)
+	const bool xl = u_ok && d.solver == MJB_SOL_NEWTON && d.nv <= 32;
+	std::vector<int> d_members, p2_members;
 	int fsize[MJB_F_COUNT];
 	for (const FieldInfo &fi : kFields) {
 		int n = dim(fi);
@@ -213,6 +224,19 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		                           (d.neq == 0 && (idx == MJB_F_xmat || idx == MJB_F_xquat)));
 		if (gone) {
 			*slots[idx] = -1;  // kernels test the offset
+			idx++;
+			continue;
+		}
+		if (xl && (idx == MJB_F_cdof || idx == MJB_F_qM || idx == MJB_F_qLD || idx == MJB_F_qLDiagInv || idx == MJB_F_contact_dist ||
+		           idx == MJB_F_contact_pos || idx == MJB_F_contact_frame || idx == MJB_F_contact_includemargin)) {
+			d_members.push_back(idx);
+			*slots[idx] = -1;  // placed below
+			idx++;
+			continue;
+		}
+		if (xl && (idx == MJB_F_efc_D || idx == MJB_F_efc_aref || idx == MJB_F_efc_b || idx == MJB_F_efc_force || idx == MJB_F_efc_frictionloss)) {
+			p2_members.push_back(idx);
+			*slots[idx] = -1;  // placed below
 			idx++;
 			continue;
 		}
@@ -241,8 +265,9 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 		idx++;
 	}
 	const bool newton = d.nefcmax > 0 && (d.solver == MJB_SOL_NEWTON || d.solver == MJB_SOL_CG);  // primal solvers
+	const int off_before_nwt = off;
 	L.nwt_M = off;
-	off += newton ? d.nv * d.nv : 0;
+	off += (newton && d.nv > 32) ? d.nv * d.nv : 0;  // (nv <= 32: the solver keeps row `lane` of M in registers, host table M_sym)
 	L.nwt_H = off;
 	off += newton ? d.nv * d.nv : 0;
 	L.nwt_vec = off;
@@ -250,7 +275,19 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	L.nwt_row = off;
 	off += newton ? 3 * d.nefcmax : 0;
 	L.nwt_hc = off;
-	off += ((newton || (d.nefcmax > 0 && d.solver == MJB_SOL_PGS)) && d.cone == MJB_CONE_ELLIPTIC) ? 36 * d.nconmax : 0;  // (PGS: the contacts' blocks of AR)
+	// cone blocks: the primal solvers size them by the model's largest contact dimension (config 5: condim 4 -> 16 doubles instead
+	// of 36; at least 10, the line-search constants a contact parks there); PGS keeps its 6 x 6 blocks of AR
+	L.hcd = 6;
+	L.hcs = 36;
+	if (newton) {
+		int maxdim = 1;
+		for (int p = 0; p < d.ncollpair; p++) maxdim = std::max(maxdim, M->pair_i[(size_t)8 * p + 4]);
+		L.hcd = std::min(6, maxdim);
+		L.hcs = std::max(L.hcd * L.hcd, 10);
+	}
+	off += ((newton || (d.nefcmax > 0 && d.solver == MJB_SOL_PGS)) && d.cone == MJB_CONE_ELLIPTIC) ? L.hcs * d.nconmax : 0;  // (PGS: the contacts' blocks of AR)
+	const int n_nwt = off - off_before_nwt;  // nwt_M | nwt_H | nwt_vec | nwt_row | nwt_hc
+	if (xl) off = off_before_nwt;            // (X layout: they overlay the head of X, placed below)
 	L.gravity = off;
 	off += 3;
 	// (lean frame: collision takes the mixed friction from the pair record, or from the per-env override in HBM)
@@ -271,7 +308,62 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	const int ntri = d.nefcmax <= 0 ? 0 : ((d.nv <= 16 && d.solver == MJB_SOL_PGS) ? 128 : ((d.nv > 16 && d.nv <= 32) ? 496 : 0));
 	const int nbb = d.nconmax > 0 ? 216 : 0;  // (MJB_BBSCR of mjb_constraint.h)
 	const int n_kin = 7 * d.nbody, n_crb = 10 * d.nbody, n_buf = 6 * d.nv < 32 ? 32 : 6 * d.nv, n_c6 = 6 * d.nbody;  // (crbbuf doubles as the 32-double pivot-row scratch of the dense factor)
-	if (compact) {
+	if (compact && xl) {
+		const int x0 = off;
+		for (int id : d_members) {
+			*slots[id] = off;
+			off += fsize[id];
+		}
+		const int a0 = off;  // start of R
+		L.kinloc = a0;
+		L.crb = a0;
+		L.crbbuf = a0 + n_crb;
+		L.cacc = a0;
+		L.cfrc_body = a0 + n_c6;
+		L.bbscr = a0;
+		{
+			int sz = n_kin;
+			if (nbb > sz) sz = nbb;
+			if (n_crb + n_buf > sz) sz = n_crb + n_buf;
+			if (2 * n_c6 > sz) sz = 2 * n_c6;
+			if (d.nv > sz) sz = d.nv;
+			off += sz;
+		}
+		if (alias_b) {
+			const int b0 = off;
+			L.ximat = b0;
+			L.cvel = b0;
+			L.cdof_dot = b0 + n_c6;
+			int szb = 9 * d.nbody;
+			if (n_c6 + 6 * d.nv > szb) szb = n_c6 + 6 * d.nv;
+			off += szb;
+		}
+		for (int id : u_members) {
+			*slots[id] = off;
+			off += fsize[id];
+		}
+		int n_p2 = fsize[MJB_F_efc_J];
+		for (int id : p2_members) n_p2 += fsize[id];
+		const int n_scr = ntri + 32 + d.nv;
+		int jstart = std::max(x0 + n_nwt, a0 + n_scr);   // the solver's arrays and the triangle scratch both end below efc_J
+		if (jstart + n_p2 > off) off = jstart + n_p2;
+		jstart = off - n_p2;                             // ... which sits at the end of X
+		L.efc_J = jstart;
+		{
+			int o = jstart + fsize[MJB_F_efc_J];
+			for (int id : p2_members) {
+				*slots[id] = o;
+				o += fsize[id];
+			}
+		}
+		L.tri = jstart - n_scr;
+		L.solvescr = L.tri + ntri;
+		L.eulerx = L.solvescr + 32;
+		{
+			const int shift = x0 - off_before_nwt;
+			L.nwt_M += shift; L.nwt_H += shift; L.nwt_vec += shift; L.nwt_row += shift; L.nwt_hc += shift;
+		}
+	} else if (compact) {
 		const int a0 = off;
 		L.kinloc = a0;
 		L.crb = a0;
@@ -342,6 +434,33 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact)
 	ioff += (d.nefcmax > 0 && d.nv <= 16) ? 64 : 0;
 	L.nint = (ioff + 1) & ~1;
 	L.nstate = nstate;
+}
+
+int layout_bytes(const FrameLayout &L) { return ((L.ndouble * 8 + L.nint * 4) + 15) & ~15; }
+
+// The fused frame of kernel variant 4 (Newton, capacity > 128 rows) keeps only `jrows` rows of efc_J in LDS (the rest, and all of J
+// of an env-step with more rows, live in DevState::efc_Jg).  Residency beats the price of the HBM path (measured 10 % on the steps
+// that take it): pick the row count that lets the most envs share a CU's LDS, and the largest such.
+void choose_fused_layout(mjb_model *M)
+{
+	compute_layout(M, M->Lc, true);
+	const mjb_model_desc &d = M->h;
+	if (!(d.solver == MJB_SOL_NEWTON && d.nefcmax > 128) || getenv("MJB_DEBUG_JROWS")) return;
+	auto occ = [&](int jr) {
+		FrameLayout t{};
+		compute_layout(M, t, true, jr);
+		// (gfx950 hands out its 160 KB of LDS in 128 granules of 1280 bytes -- measured: a 54000-byte frame runs two to a CU, a
+		//  50272-byte one three; 512-register kernels: one wave per SIMD, four envs per CU at most)
+		return std::min(4, 128 / ((layout_bytes(t) + 1279) / 1280));
+	};
+	const int best = occ(16);
+	int pick = 64;
+	if (best > occ(64))
+		for (pick = 60; pick > 16 && occ(pick) < best; pick -= 4) {}
+	compute_layout(M, M->Lc, true, pick);
+	if (getenv("MJB_DEBUG_LAYOUT"))  // development knob
+		fprintf(stderr, "mjb fused layout: %d bytes, jrows %d, efc_J @%d, tri @%d, nwt_H @%d, nwt_hc @%d (stride %d), cdof @%d, ndouble %d, nint %d\n",
+		        layout_bytes(M->Lc), M->Lc.jrows, M->Lc.efc_J, M->Lc.tri, M->Lc.nwt_H, M->Lc.nwt_hc, M->Lc.hcs, M->Lc.cdof, M->Lc.ndouble, M->Lc.nint);
 }
 
 // Sensors whose value is a plain copy of frame doubles (joint / actuator scalars, clock, subtree com, global
@@ -731,6 +850,14 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 	M->M_dense.assign(256, -1);
 	if (h.nv <= 16)
 		for (int en = 0; en < h.nM; en++) M->M_dense[16 * M->M_rowdof[en] + M->M_coldof[en]] = en;
+	// symmetric dense address map (nv <= 32): qM address of entry (i, j) = (j, i), -1 where the tree leaves a zero.  The primal
+	// solvers keep row `lane` of M in registers (fwd_constraint_newton) instead of a dense nv x nv copy in the frame.
+	M->M_sym.assign(1024, -1);
+	if (h.nv <= 32)
+		for (int en = 0; en < h.nM; en++) {
+			M->M_sym[32 * M->M_rowdof[en] + M->M_coldof[en]] = en;
+			M->M_sym[32 * M->M_coldof[en] + M->M_rowdof[en]] = en;
+		}
 	// ancestors at distance 2^r for the pointer-jumping kinematics (0 = world or beyond the root)
 	{
 		int maxd = 0;
@@ -819,7 +946,7 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		}
 	}
 	compute_layout(M, M->L, false);
-	compute_layout(M, M->Lc, true);
+	choose_fused_layout(M);
 	build_sensor_tables(M);
 	// actuators per dof (CSR, ascending actuator id)
 	M->dof_act_adr.assign((size_t)h.nv + 1, 0);
@@ -955,7 +1082,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	size_t ni = M->hint.size(), nd = M->hdbl.size();
 	size_t nt = M->M_rowdof.size() + M->M_coldof.size() + M->dof_depth.size() + M->dof_jstart.size() +
 	            M->body_rec.size() + M->body_rec2.size() + M->dof_rec.size() + M->fac_ops.size() + M->fac_beg.size() +
-	            M->body_dofmask.size() + M->body_submask.size() + M->M_dense.size() + M->body_anc.size() + M->dof_bodymask.size() + M->sens_copy.size() + M->sens_slow.size() + M->dof_act_adr.size() +
+	            M->body_dofmask.size() + M->body_submask.size() + M->M_dense.size() + M->M_sym.size() + M->body_anc.size() + M->dof_bodymask.size() + M->sens_copy.size() + M->sens_slow.size() + M->dof_act_adr.size() +
 	            M->dof_act_id.size() + M->pair_i.size() + 96;
 	size_t bytes_i = ((ni + nt) * sizeof(int) + 15) & ~size_t(15);
 	size_t bytes = bytes_i + (nd + M->pair_d.size()) * sizeof(double) + 16;
@@ -978,7 +1105,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	};
 	size_t o_row = put(M->M_rowdof), o_col = put(M->M_coldof), o_dep = put(M->dof_depth), o_js = put(M->dof_jstart);
 	size_t o_br = put(M->body_rec), o_br2 = put(M->body_rec2), o_dr = put(M->dof_rec), o_fo = put(M->fac_ops),
-	       o_fb = put(M->fac_beg), o_dm = put(M->body_dofmask), o_sm = put(M->body_submask), o_md = put(M->M_dense), o_an = put(M->body_anc), o_db = put(M->dof_bodymask), o_sc = put(M->sens_copy), o_ss = put(M->sens_slow),
+	       o_fb = put(M->fac_beg), o_dm = put(M->body_dofmask), o_sm = put(M->body_submask), o_md = put(M->M_dense), o_ms = put(M->M_sym), o_an = put(M->body_anc), o_db = put(M->dof_bodymask), o_sc = put(M->sens_copy), o_ss = put(M->sens_slow),
 	       o_aa = put(M->dof_act_adr), o_ai = put(M->dof_act_id), o_pi = put(M->pair_i);
 	if (nd) memcpy(hd, M->hdbl.data(), nd * sizeof(double));
 	memcpy(hd + nd, M->pair_d.data(), M->pair_d.size() * sizeof(double));
@@ -1016,6 +1143,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	dm.body_dofmask = (mjb_ciptr)(di + o_dm);
 	dm.body_submask = (mjb_ciptr)(di + o_sm);
 	dm.M_dense = (mjb_ciptr)(di + o_md);
+	dm.M_sym = (mjb_ciptr)(di + o_ms);
 	dm.body_anc = (mjb_ciptr)(di + o_an);
 	dm.kin_rounds = M->kin_rounds;
 	dm.dof_bodymask = (mjb_ciptr)(di + o_db);

@@ -2248,22 +2248,54 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e, const double
 	}
 	EPROF_BEGIN();
 	double *Md = f + L.nwt_M, *H = f + L.nwt_H, *Hc = f + L.nwt_hc;
+	const int hcs = L.hcs, hcd = L.hcd;  // cone blocks: hcd x hcd (hcd = the model's largest contact dim), hcs doubles apart
 	double *qa = f + L.nwt_vec, *Ma = qa + nv, *grad = Ma + nv, *srch = grad + nv;
 	double *jar_s = f + L.nwt_row, *jv_s = jar_s + m.nefcmax, *hw = jv_s + m.nefcmax;  // per-row jaref, jv, Hessian weight
 	const bool dofact = lane < nv;
 	const int k = dofact ? lane : 0;
 	const double tol = m.tolerance[0];
 	const double scale = 1.0 / (MP_MEANINERTIA(m, e) * (nv > 1 ? nv : 1));
-	// dense symmetric M from the qM layout (entry per lane)
-	for (int t = lane; t < nv * nv; t += G) Md[t] = 0;
-	gsync<G>();
-	for (int en = lane; en < m.nM; en += G) {
-		const int i = m.M_rowdof[en], j = m.M_coldof[en];
-		const double v = f[L.qM + en];
-		Md[i * nv + j] = v;
-		Md[j * nv + i] = v;
+	// The dense symmetric M.  nv <= 32: lane k keeps ROW k in 32 registers, gathered once from the qM layout through the host table
+	// M_sym (entries the tree leaves zero, and columns >= nv, are +0: products with them leave every sum bit-unchanged) -- the
+	// frame holds no dense copy (900 doubles on config 5) and the three M x products of an iteration read no LDS for M.
+	// nv > 32: a dense copy in the frame (entry per lane).
+	const bool mreg = nv <= 32;
+	double Mrow[32];
+	if (mreg) {
+		MJB_KEEP_BRANCH();
+#pragma unroll
+		for (int c = 0; c < 32; c++) {
+			const int adr = m.M_sym[32 * k + c];
+			const double v = f[L.qM + (adr >= 0 ? adr : 0)];
+			Mrow[c] = (dofact && adr >= 0) ? v : 0.0;
+		}
+	} else {
+		MJB_KEEP_BRANCH();
+#pragma unroll
+		for (int c = 0; c < 32; c++) Mrow[c] = 0.0;
+		for (int t = lane; t < nv * nv; t += G) Md[t] = 0;
+		gsync<G>();
+		for (int en = lane; en < m.nM; en += G) {
+			const int i = m.M_rowdof[en], j = m.M_coldof[en];
+			const double v = f[L.qM + en];
+			Md[i * nv + j] = v;
+			Md[j * nv + i] = v;
+		}
+		gsync<G>();
 	}
-	gsync<G>();
+	// (M x)_k for the lane's dof k (x: nv doubles in LDS); same summation order on both paths
+	auto m_dot = [&](const double *x) -> double {
+		double t = 0;
+		if (mreg) {
+			MJB_KEEP_BRANCH();
+#pragma unroll
+			for (int c = 0; c < 32; c++) t += Mrow[c] * x[c < nv ? c : 0];
+		} else if (dofact) {
+#pragma unroll 5
+			for (int c = 0; c < nv; c++) t += Md[k * nv + c] * x[c];
+		}
+		return t;
+	};
 
 	// row kind: scalar (limit / frictionless / pyramidal), cone leader (first row of an elliptic contact), cone member
 	bool rowact[R], scalar_row[R], leader[R], bilat[R];
@@ -2341,9 +2373,9 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e, const double
 					}
 				}
 				const double N = U[0], T = sqrt(TT);
-				double *hc = Hc + 36 * rcon[i];
+				double *hc = Hc + hcs * rcon[i];
 				if (hess)
-					for (int j = 0; j < 36; j++) hc[j] = 0;
+					for (int j = 0; j < hcd * hcd; j++) hc[j] = 0;
 				if (N >= mu * T) {
 					for (int j = 0; j < 6; j++)
 						if (j < dim) f[L.efc_force + r + j] = 0;
@@ -2352,7 +2384,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e, const double
 						if (j < dim) {
 							f[L.efc_force + r + j] = -Dj[j] * x[j];
 							cost += 0.5 * Dj[j] * x[j] * x[j];
-							if (hess) hc[j * 6 + j] = Dj[j];
+							if (hess) hc[j * hcd + j] = Dj[j];
 						}
 				} else {
 					const double Dm = Dj[0] / (mu * mu * (1 + mu * mu)), NmT = N - mu * T;
@@ -2375,7 +2407,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e, const double
 								double v = Dm * g[j] * g[c2];
 								if (j >= 1 && c2 >= 1)
 									v += -Dm * NmT * mu * cfri[j - 1] * cfri[c2 - 1] * ((j == c2 ? 1.0 / T : 0.0) - U[j] * U[c2] / (T * T * T));
-								hc[j * 6 + c2] = v;
+								hc[j * hcd + c2] = v;
 							}
 				}
 				if (hess)
@@ -2392,11 +2424,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e, const double
 		double best = 0;
 		for (int pass = 0; pass < 2; pass++) {
 			const double *q0 = f + (pass == 0 ? L.qacc_warmstart : L.qacc_smooth);
-			double t = 0;
-			if (dofact) {
-#pragma unroll 5
-				for (int c = 0; c < nv; c++) t += Md[k * nv + c] * q0[c];
-			}
+			const double t = m_dot(q0);
 			const double gk = dofact ? 0.5 * (t - f[L.qfrc_smooth + k]) * (q0[k] - f[L.qacc_smooth + k]) : 0.0;
 			double x[R];
 			row_dots(q0, 1.0, x);
@@ -2425,11 +2453,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e, const double
 	for (;;) {
 		EPROF(30);
 		// Ma = M qacc, jaref = J qacc - aref, forces, cost, gradient
-		double ma = 0;
-		if (dofact) {
-#pragma unroll 5
-			for (int c = 0; c < nv; c++) ma += Md[k * nv + c] * qa[c];
-		}
+		const double ma = m_dot(qa);
 		const double gk = dofact ? 0.5 * (ma - f[L.qfrc_smooth + k]) * (qa[k] - f[L.qacc_smooth + k]) : 0.0;
 		double jaref[R];
 		row_dots(qa, 1.0, jaref);
@@ -2504,7 +2528,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e, const double
 				const int meta = fi[L.iscratch + rc];
 				const bool cone = meta >= 0;
 				const int adr = cone ? (meta & 255) : rc, dim = cone ? ((meta >> 8) & 15) : 1, con = cone ? (meta >> 12) : 0;
-				const double *wp = cone ? Hc + 36 * con + 6 * (rc - adr) : hw + rc;
+				const double *wp = cone ? Hc + hcs * con + hcd * (rc - adr) : hw + rc;
 				const double *Jc = Jb + adr * nv + (ina ? ca : 0);
 				double wv[6], jv6[6];
 #pragma unroll
@@ -2541,7 +2565,8 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e, const double
 #pragma unroll
 					for (int q = 0; q < 4; q++) {
 						const int row = 16 * ta + lk + 4 * q, col = 16 * tb + li;
-						if (row < nv && col < nv) H[row * nv + col] = Md[row * nv + col] + acc[tb][q];
+						// (nv <= 32: H holds J' W J alone; M joins it when the Cholesky loads its row, from the lane's registers)
+						if (row < nv && col < nv) H[row * nv + col] = mreg ? acc[tb][q] : Md[row * nv + col] + acc[tb][q];
 					}
 				}
 			}
@@ -2562,7 +2587,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e, const double
 #pragma unroll
 			for (int c = 0; c < 32; c++) {
 				const double v = H[k * nv + (c < nv ? c : 0)];
-				Hr[c] = (dofact && c < nv) ? v : 0.0;
+				Hr[c] = (dofact && c < nv) ? Mrow[c] + v : 0.0;
 			}
 			// (two half-loops: one 32-column nest exceeds LLVM's pragma-unroll size cap and would leave Hr in scratch)
 			chol_cols16<0>(Hr, nv, lane, myrinv);
@@ -2653,11 +2678,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e, const double
 		if (dofact) srch[k] = sk;
 		gsync<G>();
 		// line search along the Newton direction
-		double mv = 0;
-		if (dofact) {
-#pragma unroll 5
-			for (int c = 0; c < nv; c++) mv += Md[k * nv + c] * srch[c];
-		}
+		const double mv = m_dot(srch);
 		double jv[R];
 		row_dots(srch, 0.0, jv);
 #pragma unroll
@@ -2693,7 +2714,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e, const double
 				if constexpr (R == 1) {
 					cl1 = c;
 				} else {
-					double *o = Hc + 36 * rcon[i];
+					double *o = Hc + hcs * rcon[i];
 					o[0] = c.N0; o[1] = c.N1; o[2] = c.TT; o[3] = c.UV; o[4] = c.VV;
 					o[5] = c.q0b; o[6] = c.q1b; o[7] = c.q2b; o[8] = c.mu; o[9] = c.Dm;
 				}
@@ -2714,7 +2735,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e, const double
 				} else {
 					ConeLine c = cl1;
 					if (leader[i]) {
-						const double *o = Hc + 36 * rcon[i];
+						const double *o = Hc + hcs * rcon[i];
 						c = ConeLine{ o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9] };
 					}
 					ls_row(a, scalar_row[i], bilat[i], leader[i], jaref[i], jv[i], D[i], fl[i], c, c0, c1, c2);

@@ -47,6 +47,7 @@ struct DevModel {
 	int sens_ncopy_max;
 	mjb_ciptr body_dofmask;  // [nbody][2] bit i set: dof i moves the body (ancestor-or-self dofs), nv <= 64
 	mjb_ciptr M_dense;       // [16][16] qM address of entry (i, j) (dof j ancestor-or-self of dof i) or -1; nv <= 16 only
+	mjb_ciptr M_sym;         // [32][32] qM address of the symmetric entry (i, j) or -1; nv <= 32 only (primal solvers: M rows in registers)
 	mjb_ciptr body_anc;      // [kin_rounds + 1][nbody] ancestor at distance 2^r (0 = world / beyond the root)
 	mjb_ciptr dof_bodymask;  // [nv][2] bit b set: dof i moves body b (transpose of body_dofmask), nbody <= 64
 	mjb_ciptr body_submask;  // [nbody][2] bit i set: body i belongs to the body's subtree (incl. itself), nbody <= 64
@@ -75,7 +76,8 @@ struct FrameLayout {
 	int nwt_H;     // [nv*nv] Newton: Hessian / its Cholesky factor
 	int nwt_vec;   // [5*nv]  Newton: qacc, Ma, grad, search, Mv
 	int nwt_row;   // [3*nefcmax] Newton: per-row jaref, jv, Hessian weight
-	int nwt_hc;    // [36*nconmax] Newton: Hessian blocks of the elliptic cones (size 0 unless cone == elliptic)
+	int nwt_hc;    // [hcs*nconmax] Newton: Hessian blocks of the elliptic cones (size 0 unless cone == elliptic); PGS + elliptic: blocks of AR
+	int hcs, hcd;  // cone blocks are hcd x hcd, hcs doubles apart (primal solvers: hcd = the model's largest contact dim, hcs = max(hcd^2, 10); PGS: 36, 6)
 	int iscratch;  // transient int scratch: max(ncollpair, njnt + nconmax)
 	int gravity;   // [3] this env's gravity (model value or per-env override, loaded with the state)
 	int gfriction; // [3*ngeom] this env's geom friction (models with contacts only)
