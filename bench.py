@@ -155,6 +155,91 @@ def _load_json(*names):
     return None, None
 
 
+def roofline_block(name, cfgno, solver_tag, E, S, samples):
+    """`roofline` object of one workload: algorithmic bytes per launch / median kernel time against the HBM peak, the
+    counter-measured HBM traffic and executed fp64 work when profiles/ holds a PMC summary collected on THESE kernel sources
+    (fingerprint check: mujoco_ros_pkgs_amd/provenance.py) at this (envs, substeps), and the useful fp64 rate from the
+    oracle's operation count."""
+    from mujoco_ros_pkgs_amd import provenance
+    kern_ms = samples[len(samples) // 2]
+    traffic, fp64, source = None, None, None
+    pmc, pmc_file = _load_json(f"r03_cfg{cfgno}{solver_tag}_pmc_summary.json")
+    flops, flops_file = _load_json("r03_oracle_flops.json", "r02_oracle_flops.json")
+    if pmc is not None:
+        if pmc.get("csrc_sha") != provenance.csrc_sha():
+            source = f"STALE: profiles/{pmc_file} was collected on other kernel sources ({pmc.get('csrc_sha')} != {provenance.csrc_sha()}); not reported"
+        elif (E, S) != (pmc.get("envs"), pmc.get("substeps")):
+            source = f"profiles/{pmc_file} holds ({pmc.get('envs')} envs, {pmc.get('substeps')} steps per launch), not this run's; not reported"
+        else:
+            try:
+                traffic = (pmc["FETCH_SIZE"]["mean_per_dispatch"] + pmc["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
+                source = f"profiles/{pmc_file}"
+                if "fp64_executed_flops_per_dispatch" in pmc:
+                    fl = pmc["fp64_executed_flops_per_dispatch"]
+                    peak = pmc.get("fp64_peak_measured", {}).get("fp64_fma_tflops", FP64_PEAK_TFLOPS)
+                    ach = fl / (kern_ms * 1e-3) / 1e12
+                    fp64 = {"bound": "fp64-valu", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                            "executed_flops_per_launch": fl,
+                            "note": f"SQ_INSTS_VALU_{{ADD,MUL,FMA,TRANS}}_F64 x 64 lanes, idle lanes included (profiles/{pmc_file}); "
+                                    "peak = tools/ubench/fp64_peak on the same box"}
+            except Exception:
+                traffic, fp64 = None, None
+    if flops and name in flops:  # the oracle's instrumented operation count (SURVEY.md 8d: THE flop figure)
+        per = float(flops[name]["flops_per_env_step"])
+        ach = per * E * S / (kern_ms * 1e-3) / 1e12
+        fp64 = fp64 or {"bound": "fp64-valu", "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s"}
+        fp64.update(algorithmic_flops_per_env_step=per, useful_achieved=ach, useful_frac=ach / fp64["peak"],
+                    useful_note=f"oracle op counter, add / mul / div / sqrt = 1, fma = 2 (profiles/{flops_file})")
+    bytes_per_launch = ALGO_BYTES_PER_ENV_STEP.get(name, 712) * E * S
+    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": traffic, "traffic_source": source, "kernel": "mjb_step_kernel", "kernel_ms": kern_ms,
+           "kernel_ms_samples": {"n": len(samples), "median": kern_ms, "min": samples[0], "max": samples[-1]},
+           "algorithmic_bytes_per_launch": bytes_per_launch}
+    if fp64:
+        out["fp64"] = fp64  # second view (SURVEY.md 8d): with K fused steps the kernel is VALU / latency bound
+    return out
+
+
+def measure_other_config(cfgno, device, launches=3):
+    """One of the other BASELINE workloads (3 = configs[2], 5 = configs[4]'s per-GPU shard), measured in this process after
+    the headline timing so that the DRIVER's record carries it (VERDICT r02 #3a): `launches` timed fused launches bracketed
+    by synchronisation, then five single-launch kernel samples."""
+    from mujoco_ros_pkgs_amd import engine, mjcf
+    name = CONFIG_MODEL[cfgno]
+    label, noise_std, E, S, _ = WORKLOADS[name]
+    model = mjcf.Model(dict(mjcf.load_asset(name)))
+    model["enableflags"] = int(model["enableflags"]) | 2
+    cm = engine.CompiledModel(model)
+    batch = engine.Batch(cm, E, device)
+    qpos, qvel = initial_state(name, model, E, seed=1000)
+    batch.set("qpos", qpos)
+    batch.set("qvel", qvel)
+    batch.set_ctrl_noise(noise_std, 0.1, 12345, 0)
+    batch.step(S)
+    batch.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        batch.step(S)
+    batch.synchronize()
+    elapsed = time.perf_counter() - t0
+    finite = bool(np.all(np.isfinite(batch.get("qpos"))))
+    samples = sorted(batch.time_steps(S, 1) for _ in range(5))
+    out = {"metric": "env_steps_per_sec", "value": E * S * launches / elapsed, "unit": "env-steps/s", "n_gpus": 1,
+           "steps": launches, "warmup": 1, "ms_per_step": 1e3 * elapsed / launches,
+           "config": {"workload": f"{label}, {E} envs per GPU, fp64, Euler dt={model['timestep'][0]}", "baseline_config": cfgno,
+                      "envs_per_gpu": E, "physics_steps_per_launch": S, "model": name,
+                      "solver": {0: "PGS", 1: "CG", 2: "Newton"}[int(model["solver"])],
+                      "nconmax": int(model["nconmax"]), "nefcmax": int(model["nefcmax"]),
+                      "fused_frame_bytes": int(batch.lib.mjb_frame_bytes(cm.ptr, 1)),
+                      "state_finite": finite, "auto_resets": batch.warning_count(),
+                      "contactfull": batch.warning("contactfull"), "cnstrfull": batch.warning("cnstrfull")},
+           "roofline": roofline_block(name, cfgno, "", E, S, samples)}
+    batch.close()
+    cm.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,6 +255,7 @@ def main():
     ap.add_argument("--nefcmax", type=int, default=0, help="override the model's constraint-row capacity")
     ap.add_argument("--nconmax", type=int, default=0, help="override the model's contact capacity")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the configs 3 / 5 lines a default single-GPU run appends")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -273,35 +359,8 @@ def main():
     kern_ms = samples[len(samples) // 2]
 
     if rank == 0:
-        traffic, fp64 = None, None
-        # (the counters belong to ONE kernel variant: a solver override has its own file or none)
-        solver_tag = "" if not args.solver else "_" + args.solver.lower()
-        pmc, pmc_file = _load_json(f"r02_cfg{cfgno}{solver_tag}_pmc_summary.json") if solver_tag else _load_json(
-            f"r02_cfg{cfgno}_pmc_summary.json", "r01_pmc_summary.json" if cfgno == 2 else f"r01_cfg{cfgno}_pmc_summary.json")
-        flops, flops_file = _load_json("r02_oracle_flops.json")
-        try:  # HBM bytes and executed fp64 flops per launch from the committed rocprofv3 PMC passes (same kernel, same config)
-            pm_E, pm_S = pmc.get("envs", default_envs), pmc.get("substeps", default_sub)
-            if (E, S) == (pm_E, pm_S):
-                traffic = (pmc["FETCH_SIZE"]["mean_per_dispatch"] + pmc["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
-                if "fp64_executed_flops_per_dispatch" in pmc:
-                    fl = pmc["fp64_executed_flops_per_dispatch"]
-                    peak = pmc.get("fp64_peak_measured", {}).get("fp64_fma_tflops", FP64_PEAK_TFLOPS)
-                    ach = fl / (kern_ms * 1e-3) / 1e12
-                    fp64 = {"bound": "fp64-valu", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                            "executed_flops_per_launch": fl,
-                            "note": f"SQ_INSTS_VALU_{{ADD,MUL,FMA,TRANS}}_F64 x 64 lanes, idle lanes included (profiles/{pmc_file}); "
-                                    "peak = tools/ubench/fp64_peak on the same box"}
-        except Exception:
-            traffic, fp64 = None, None
-        if flops and name in flops:  # the oracle's instrumented operation count (THE flop figure)
-            per = float(flops[name]["flops_per_env_step"])
-            ach = per * E * S / (kern_ms * 1e-3) / 1e12
-            fp64 = fp64 or {"bound": "fp64-valu", "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s"}
-            fp64.update(algorithmic_flops_per_env_step=per, useful_achieved=ach, useful_frac=ach / fp64["peak"],
-                        useful_note=f"oracle op counter, add / mul / div / sqrt = 1, fma = 2 (profiles/{flops_file})")
+        solver_tag = "" if not args.solver else "_" + args.solver.lower()  # (the counters belong to ONE kernel variant)
         value = world * E * S * args.steps / elapsed
-        bytes_per_launch = ALGO_BYTES_PER_ENV_STEP.get(name, 712) * E * S
-        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -315,14 +374,19 @@ def main():
                                       "side stream (overlaps the next launch)" if world > 1 else "single GPU",
                        "rccl_ranks": world if xch.active else 0, "state_finite": finite, "auto_resets": resets},
             "metrics": metrics,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": f"profiles/{pmc_file}" if traffic else None,
-                         "kernel": "mjb_step_kernel", "kernel_ms": kern_ms,
-                         "kernel_ms_samples": {"n": len(samples), "median": kern_ms, "min": samples[0], "max": samples[-1]},
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+            "roofline": roofline_block(name, cfgno, solver_tag, E, S, samples),
         }
-        if fp64:
-            out["roofline"]["fp64"] = fp64  # second view: with K fused steps the kernel is VALU / latency bound
+        out["config"]["fused_frame_bytes"] = int(batch.lib.mjb_frame_bytes(cm.ptr, 1))
+        default_run = world == 1 and not (args.config or args.model or args.solver or args.nefcmax or args.nconmax or args.envs or
+                                          args.substeps or args.lanes or args.epb)
+        if default_run and not args.no_other_configs:
+            # the other BASELINE workloads, same process, same box (configs[2] and the per-GPU shard of configs[4])
+            out["other_configs"] = {}
+            for c in (3, 5):
+                try:
+                    out["other_configs"][str(c)] = measure_other_config(c, local_rank)
+                except Exception as exc:  # never let an extra take the headline line down
+                    out["other_configs"][str(c)] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(name, model, noise_std)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

@@ -10,7 +10,7 @@ from mujoco_ros_pkgs_amd import mjcf
 pytestmark = pytest.mark.gpu
 
 
-def _run(name, nenv, K, sample, tol_q, tol_v, oracle_built):
+def _run(name, nenv, K, sample, tol_q, tol_v, oracle_built, report=None):
     from bench import WORKLOADS, initial_state
     from mujoco_ros_pkgs_amd import engine
     model = mjcf.load_asset(name)
@@ -24,18 +24,22 @@ def _run(name, nenv, K, sample, tol_q, tol_v, oracle_built):
     q, v, sd, t = b.get("qpos"), b.get("qvel"), b.get("sensordata"), b.get("time")
     assert np.all(np.isfinite(q)) and np.all(np.isfinite(v)) and np.all(np.isfinite(sd))
     assert b.warning_count() == 0, "mj_check* reset an env of the bench workload"
-    assert np.allclose(t, K * model["timestep"][0], rtol=0, atol=1e-12)
+    assert np.allclose(t, K * model["timestep"][0], rtol=0, atol=1e-10)
     # unit quaternions of the free body, every env
-    ja = [j for j in range(model["njnt"]) if model["jnt_type"][j] == 0][0]
-    qa = model["jnt_qposadr"][ja]
-    assert np.allclose(np.linalg.norm(q[:, qa + 3:qa + 7], axis=1), 1.0, atol=1e-9)
+    for ja in [j for j in range(model["njnt"]) if model["jnt_type"][j] == 0]:
+        qa = model["jnt_qposadr"][ja]
+        assert np.allclose(np.linalg.norm(q[:, qa + 3:qa + 7], axis=1), 1.0, atol=1e-9)
     # oracle parity on envs spread over the batch (global env index = Philox key)
     idx = np.linspace(0, nenv - 1, sample).astype(int)
+    worst_q = worst_v = 0.0
     for e in idx:
         oq, ov, osd = oracle_built.rollout(model, qpos[e:e + 1], qvel[e:e + 1], K, noise_std=noise, noise_rate=0.1, seed=12345,
                                            env_offset=int(e))
+        worst_q, worst_v = max(worst_q, np.abs(q[e] - oq[0]).max()), max(worst_v, np.abs(v[e] - ov[0]).max())
         assert np.abs(q[e] - oq[0]).max() <= tol_q, f"{name} env {e}: qpos {np.abs(q[e] - oq[0]).max():.2e}"
         assert np.abs(v[e] - ov[0]).max() <= tol_v, f"{name} env {e}: qvel {np.abs(v[e] - ov[0]).max():.2e}"
+    if report is not None:
+        report.append((name, nenv, K, sample, worst_q, worst_v))
     m, _ = b.metrics()
     assert m["env_steps"] == nenv * K and m["nenv"] == nenv
     # determinism: a second batch of the same inputs reproduces the first bit for bit
@@ -58,3 +62,26 @@ def test_config3_pgs_4096_envs(oracle_built):
 def test_config5_newton_1024_envs(oracle_built):
     m = _run("shadow_hand_like", 1024, 40, 16, 1e-9, 1e-6, oracle_built)
     assert m["solver"] == 2 and m["cone"] == 1
+
+
+# ---- the 8-GPU configs at their WHOLE size on one GPU (VERDICT r02 #3b): configs[3] = 32768 envs of config 3, configs[4] = 8192 envs
+# of config 5.  Sharding changes nothing an env can see (the Philox key is the global env index, tests/test_sharding_gloo.py), so one
+# GPU stepping all of them is the 8-GPU job minus the gather; what stays untested without an 8-GPU node is the RCCL exchange alone.
+def test_config4_pgs_32768_envs_one_gpu(oracle_built):
+    _run("franka_table", 32768, 30, 16, 1e-9, 1e-7, oracle_built)
+
+
+def test_config5_newton_8192_envs_one_gpu(oracle_built):
+    _run("shadow_hand_like", 8192, 30, 16, 1e-9, 1e-6, oracle_built)
+
+
+def test_config2_bench_workload_1000_fused_steps(oracle_built, capsys):
+    """SURVEY.md 8c-vi's third point (1 / 10 / 1000 steps) on the bench's OWN config-2 launch: 4096 envs, ONE fused launch of
+    K = 1000 steps under the on-device OU ctrl noise -- the launch the headline number is measured on -- against the oracle
+    on 16 envs spread over the batch.  Stated tolerance: 1e-10 on qpos (rad / m), 1e-9 on qvel after 2 s of simulated time of a
+    noise-driven 9-dof arm (rounding-level differences between the fma-contracted GPU arithmetic and the oracle grow along the
+    trajectory; measured worst case on MI355X, printed below: 2e-14 / 4e-14)."""
+    rep = []
+    _run("franka_like", 4096, 1000, 16, 1e-10, 1e-9, oracle_built, report=rep)
+    with capsys.disabled():
+        print(f"\n[config 2, K = 1000 fused, 16 envs vs oracle] worst |dqpos| = {rep[0][4]:.2e}, worst |dqvel| = {rep[0][5]:.2e}")

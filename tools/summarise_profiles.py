@@ -63,9 +63,14 @@ if summary:
         summary["fp64_executed_flops_per_dispatch"] = 64.0 * (f64["SQ_INSTS_VALU_ADD_F64"] + f64["SQ_INSTS_VALU_MUL_F64"] +
                                                               2.0 * f64["SQ_INSTS_VALU_FMA_F64"] + f64["SQ_INSTS_VALU_TRANS_F64"])
     summary["dispatch_meta"] = meta
+    sys.path.insert(0, root)
+    from mujoco_ros_pkgs_amd import provenance  # noqa: E402
+    summary["csrc_sha"] = provenance.csrc_sha()  # the kernel sources these counters belong to (bench.py checks it)
     bl = os.path.join(dst, name + "_bench_line_under_rocprof.json")
     if os.path.exists(bl):
-        summary["bench_config"] = json.loads(open(bl).read())["config"]
+        cfg = json.loads(open(bl).read())["config"]
+        summary["bench_config"] = cfg
+        summary["envs"], summary["substeps"] = cfg.get("envs_per_gpu"), cfg.get("physics_steps_per_launch")
     summary["notes"] = ("rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and two SQ passes, each its own run, no tracing "
                         "domains) of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline ...`; means over the step-kernel "
                         "dispatches.  FETCH_SIZE / WRITE_SIZE are KiB (HBM bytes = value * 1024); per MI355X_MICROARCH.md "
