@@ -26,3 +26,33 @@ def test_single_gpu_without_device_fails_loudly():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True,
                        text=True, timeout=300)
     assert p.returncode == 3 and "no CPU fallback" in p.stderr and p.stdout.strip() == ""
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only check of the spawn path")
+def test_config_arguments_reach_every_spawned_rank():
+    """`python bench.py --config 3 --gpus 2 ...`: the self-spawn forwards the whole command line, so both ranks parse
+    `--config 3` (a rank that lost it would still die on "no GPU", so the argument echo is checked through an unknown flag:
+    argparse's error names it on every rank)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "3", "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and p.stderr.count("no GPU visible; the engine has no CPU fallback") == 2, p.stderr[-2000:]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "3", "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--substeps", "7", "--bogus-flag"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "--bogus-flag" in p.stderr  # rejected before any spawn: one parser, one command line
+    assert p.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_forced_single_rank_exchange_line_fields():
+    """On the GPU box: the RCCL path of bench.py with ONE rank (MJB_BENCH_FORCE_GATHER=1) -- init_process_group("nccl"),
+    ExternalStream interop, the side-stream all-gather / all-reduces and the final barrier all run; the line must say so."""
+    import json
+    env = dict(os.environ, MJB_BENCH_FORCE_GATHER="1", MASTER_PORT="29533")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--substeps", "100",
+                        "--no-cpu-baseline", "--no-other-configs"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["metrics"]["env_steps"] == 4096 * 100 * 4 and line["metrics"]["nenv"] == 4096  # reduced over the (one) rank
+    assert "forced single-rank gather: sensordata round trip ok" in p.stderr
