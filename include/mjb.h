@@ -270,7 +270,7 @@ int mjb_register_collision(mjb_batch *b, int geom_type1, int geom_type2, int fun
 int mjb_set_env_gravity(mjb_batch *b, int env_lo, int env_hi, const double *gravity);
 int mjb_set_env_geom_friction(mjb_batch *b, int env_lo, int env_hi, const double *friction);
 /* setGeomProperties' set_size / set_type (callbacks.cpp:555-575) per env: size [env][ngeom][3], type [env][ngeom] (mjtGeom: plane,
- * sphere, capsule, box).  As in the reference the bounding radii are NOT recomputed ("AABBs are not recomputed", :557-560) and the
+ * sphere, capsule, box; ellipsoid / cylinder are accepted and yield no contacts).  As in the reference the bounding radii are NOT recomputed ("AABBs are not recomputed", :557-560) and the
  * candidate pair list stays the model's; a pair whose new types have no pair function yields no contacts. */
 int mjb_set_env_geom_size(mjb_batch *b, int env_lo, int env_hi, const double *size);
 int mjb_set_env_geom_type(mjb_batch *b, int env_lo, int env_hi, const int *type);
@@ -285,6 +285,13 @@ int mjb_set_env_equality(mjb_batch *b, int env_lo, int env_hi, const double *par
  * tendon_invweight0[ntendon] | meaninertia.  (Batches carrying these overrides run the generic kernels.) */
 int mjb_env_mass_stride(const mjb_model *m);
 int mjb_set_env_mass_params(mjb_batch *b, int env_lo, int env_hi, const double *params);
+/* The same without the caller having MuJoCo (or Python) at hand: mj_setConst's derivation is done here, host side, in plain C++
+ * (body Jacobians at qpos0 -> joint-space inertia -> its inverse; mjb_api.hip).  mjb_derive_mass_params fills ONE packed block
+ * (out[mjb_env_mass_stride(model)]) from body_mass[nbody] and body_inertia[nbody][3] (NULL: the model's principal inertias) and
+ * needs no device; mjb_set_env_body_mass derives a block per env (body_mass[env][nbody], body_inertia[env][nbody][3] or NULL)
+ * and uploads them (= callbacks.cpp:244-258: model_->body_mass[id] = mass; mj_setConst). */
+int mjb_derive_mass_params(const mjb_model *m, const double *body_mass, const double *body_inertia, double *out);
+int mjb_set_env_body_mass(mjb_batch *b, int env_lo, int env_hi, const double *body_mass, const double *body_inertia);
 
 /* ---- device-side DefaultRobotHWSim::writeSim ----
  * The reference's ros_control bridge writes the controllers' joint commands into mjData on every control callback

@@ -42,7 +42,19 @@ typedef struct mjr_backend {
 	int (*host_unregister)(void *self, void *host);
 	int (*step_async)(void *self, int nsteps); /* enqueue nsteps fused steps without waiting for them */
 	int (*register_collision)(void *self, int geom_type1, int geom_type2, int func); /* mjb_register_collision */
+	/* optional: per-env model parameters (mjb_set_env_*), what the reference's services change on its single mjModel
+	 * (callbacks.cpp:210-370, 462-592, 641-884).  `what` = MJR_ENV_*; data for envs [env_lo, env_hi), env-major. */
+	int (*set_env_param)(void *self, int what, int env_lo, int env_hi, const void *data);
 } mjr_backend;
+
+enum {
+	MJR_ENV_GRAVITY = 0,       /* double [n][3]                                                               */
+	MJR_ENV_GEOM_FRICTION = 1, /* double [n][ngeom][3]                                                        */
+	MJR_ENV_GEOM_SIZE = 2,     /* double [n][ngeom][3]                                                        */
+	MJR_ENV_GEOM_TYPE = 3,     /* int    [n][ngeom]                                                           */
+	MJR_ENV_EQUALITY = 4,      /* double [n][neq][19]: active | eq_data[11] | solref[2] | solimp[5]           */
+	MJR_ENV_BODY_MASS = 5      /* double [n][nbody]; the backend derives what mj_setConst would (mjb_set_env_body_mass) */
+};
 
 /* creates a backend for (model, nenv, device); NULL on failure */
 typedef mjr_backend *(*mjr_backend_factory)(const mjb_model_desc *desc, int nenv, int device, void *user);
@@ -63,6 +75,8 @@ typedef struct mjr_names {
 	const char *const *site;
 	const char *const *sensor;
 	const char *const *actuator;
+	const char *const *equality; /* may be NULL (then equalities cannot be addressed by name) */
+	const char *const *tendon;   /* may be NULL */
 } mjr_names;
 
 /* MujocoEnv::MujocoEnv(admin_hash) (mujoco_env.cpp:68-161).  `params_json` is a JSON object holding the
@@ -128,6 +142,51 @@ int mjr_env_set_callback_envs(mjr_env *e, int n);
  * the host callback; returns 1 when an override of this pair type was already registered (the reference warns), 0 when it is
  * the first, -1 on error.  Overrides are dropped at the next reload (prepareReload, :950-954). */
 int mjr_env_register_collision_function(mjr_env *e, int geom_type1, int geom_type2, int func);
+
+/* ---- service handlers that read / change the model or one body's state (callbacks.cpp:177-201, 210-592, 641-884), per env
+ * range [env_lo, env_hi) (env_hi < 0: every env -- what the reference does to its single model).  Each returns the service's
+ * `success` (1 / 0; -1 on a bad call) and copies `status_message` into msg[msg_cap] when msg != NULL.  All of them apply the
+ * eval-mode admin-hash gate of the reference.  Poses are {x, y, z, qw, qx, qy, qz}, twists {vx, vy, vz, wx, wy, wz}. */
+typedef struct mjr_body_state {
+	char name[64];
+	double mass;
+	double pose[7];
+	char pose_frame[64];  /* "" or "world": anything else cannot be transformed (no tf here) and is refused as in the reference */
+	double twist[6];
+	char twist_frame[64];
+} mjr_body_state;
+int mjr_env_set_body_state(mjr_env *e, const mjr_body_state *state, int set_pose, int set_twist, int set_mass, int reset_qpos,
+                           const char *admin_hash, int env_lo, int env_hi, char *msg, int msg_cap); /* setBodyStateCB :210-370 */
+int mjr_env_get_body_state(mjr_env *e, const char *name, const char *admin_hash, int env, mjr_body_state *out, char *msg,
+                           int msg_cap); /* getBodyStateCB :372-460 */
+typedef struct mjr_geom_properties {
+	char name[64];
+	int type; /* mjtGeom */
+	double body_mass, friction[3], size[3];
+} mjr_geom_properties;
+int mjr_env_set_geom_properties(mjr_env *e, const mjr_geom_properties *p, int set_type, int set_mass, int set_friction, int set_size,
+                                const char *admin_hash, int env_lo, int env_hi, char *msg, int msg_cap); /* :508-592 */
+int mjr_env_get_geom_properties(mjr_env *e, const char *geom_name, const char *admin_hash, int env, mjr_geom_properties *out,
+                                char *msg, int msg_cap); /* :594-639 */
+int mjr_env_set_gravity(mjr_env *e, const double *gravity3, const char *admin_hash, int env_lo, int env_hi, char *msg, int msg_cap); /* :462-484 */
+int mjr_env_get_gravity(mjr_env *e, const char *admin_hash, int env, double *gravity3, char *msg, int msg_cap);                      /* :486-506 */
+typedef struct mjr_eq_parameters {
+	char name[64], element1[64], element2[64];
+	int type, active; /* mjtEq: 0 connect, 1 weld, 2 joint, 3 tendon */
+	double anchor[3], relpose[7], torquescale, polycoef[5];
+	double dmin, dmax, width, midpoint, power, timeconst, dampratio; /* solverParameters */
+} mjr_eq_parameters;
+int mjr_env_set_eq_parameters(mjr_env *e, const mjr_eq_parameters *params, int n, const char *admin_hash, int env_lo, int env_hi,
+                              char *msg, int msg_cap); /* setEqualityConstraintParametersArrayCB :748-780 */
+/* fills out[k] for every name found (in request order); *nout = how many */
+int mjr_env_get_eq_parameters(mjr_env *e, const char *const *names, int n, const char *admin_hash, int env, mjr_eq_parameters *out,
+                              int *nout, char *msg, int msg_cap); /* getEqualityConstraintParametersArrayCB :862-897 */
+/* reloadCB (:177-201): queue the model, wait until the loading request state is 0 again; success = model_valid, message = load_error_ */
+int mjr_env_reload(mjr_env *e, const mjb_model_desc *desc, const mjr_names *names, int nenv, int device, mjr_backend_factory factory,
+                   void *factory_user, char *msg, int msg_cap);
+/* get_loading_request_state (:72-87): returns getOperationalStatus(); description "Sim ready" / "Loading in progress" / "Loading issued" */
+int mjr_env_loading_request_state(mjr_env *e, char *description, int cap);
+int mjr_env_load_initial_joint_states(mjr_env *e); /* load_initial_joint_states service (:66-71) */
 
 /* ---- sensors plugin ("mujoco_ros_sensors/MujocoRosSensorsPlugin"): the typed records it would publish
  * (reference: mujoco_ros_sensors/src/mujoco_sensor_handler_plugin.cpp:175-436 lastStageCallback, :123-173

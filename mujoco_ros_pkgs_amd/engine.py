@@ -44,6 +44,18 @@ class CompiledModel:
     def field_size(self, name):
         return self.lib.mjb_field_size(self.ptr, Field.ids[name])
 
+    def derive_mass_params(self, body_mass, body_inertia=None):
+        """mj_setConst's constants for new body masses (mjb_derive_mass_params, host-side C++): the packed block of
+        mjb_set_env_mass_params.  Needs no device."""
+        nb = int(self.model["nbody"])
+        bm = np.ascontiguousarray(np.asarray(body_mass, dtype=np.float64).reshape(nb))
+        bi = None if body_inertia is None else np.ascontiguousarray(np.asarray(body_inertia, dtype=np.float64).reshape(nb, 3))
+        out = np.zeros(self.lib.mjb_env_mass_stride(self.ptr))
+        pd = C.POINTER(C.c_double)
+        _check(self.lib.mjb_derive_mass_params(self.ptr, bm.ctypes.data_as(pd), None if bi is None else bi.ctypes.data_as(pd),
+                                               out.ctypes.data_as(pd)), "mjb_derive_mass_params")
+        return out
+
     @property
     def frame_doubles(self):
         return self.lib.mjb_frame_doubles(self.ptr)
@@ -163,18 +175,16 @@ class Batch:
         _check(self.lib.mjb_set_env_equality(self.ptr, lo, hi, p.ctypes.data_as(C.POINTER(C.c_double))), "mjb_set_env_equality")
 
     def set_env_body_mass(self, body_mass, body_inertia=None, lo=0, hi=None):
-        """Per-env body masses [hi-lo, nbody] (and optionally principal inertias [hi-lo, nbody, 3]): derives what
-        mj_setConst would (mjcf.with_body_mass) and hands the packed constants to mjb_set_env_mass_params."""
-        from . import mjcf
+        """Per-env body masses [hi-lo, nbody] (and optionally principal inertias [hi-lo, nbody, 3]): mjb_set_env_body_mass
+        derives what mj_setConst would (in C++, inside libmjb) and uploads the packed constants."""
         hi = self.nenv if hi is None else hi
         n = hi - lo
-        bm = np.asarray(body_mass, dtype=np.float64).reshape(n, -1)
-        bi = None if body_inertia is None else np.asarray(body_inertia, dtype=np.float64).reshape(n, -1, 3)
-        stride = self.lib.mjb_env_mass_stride(self.cm.ptr)
-        p = np.zeros((n, stride))
-        for e in range(n):
-            p[e] = mjcf.mass_params(mjcf.with_body_mass(self.cm.model, bm[e], None if bi is None else bi[e]))
-        _check(self.lib.mjb_set_env_mass_params(self.ptr, lo, hi, p.ctypes.data_as(C.POINTER(C.c_double))), "mjb_set_env_mass_params")
+        nb = int(self.cm.model["nbody"])
+        bm = np.ascontiguousarray(np.asarray(body_mass, dtype=np.float64).reshape(n, nb))
+        bi = None if body_inertia is None else np.ascontiguousarray(np.asarray(body_inertia, dtype=np.float64).reshape(n, nb, 3))
+        pd = C.POINTER(C.c_double)
+        _check(self.lib.mjb_set_env_body_mass(self.ptr, lo, hi, bm.ctypes.data_as(pd), None if bi is None else bi.ctypes.data_as(pd)),
+               "mjb_set_env_body_mass")
 
     # ---- device-side DefaultRobotHWSim (mjb_hwsim_*) ----
     def hwsim_configure(self, joints):

@@ -37,7 +37,7 @@ struct mjModel {
 	    *sensor_reftype;
 	const mjtNum *qpos0, *body_mass, *geom_size, *geom_friction, *sensor_cutoff;
 	// name tables (mj_name2id / mj_id2name)
-	std::vector<std::string> joint_names, body_names, geom_names, site_names, sensor_names, actuator_names;
+	std::vector<std::string> joint_names, body_names, geom_names, site_names, sensor_names, actuator_names, equality_names, tendon_names;
 };
 
 // per-env data view
@@ -53,7 +53,8 @@ struct mjData {
 };
 
 // joint / object name lookup (mj_name2id restated over the name tables); -1 if absent
-enum mjtObjKind { mjOBJ_BODY = 1, mjOBJ_JOINT = 3, mjOBJ_GEOM = 5, mjOBJ_SITE = 6, mjOBJ_ACTUATOR = 18, mjOBJ_SENSOR = 19 };
+enum mjtObjKind { mjOBJ_BODY = 1, mjOBJ_XBODY = 2, mjOBJ_JOINT = 3, mjOBJ_GEOM = 5, mjOBJ_SITE = 6, mjOBJ_TENDON = 17, mjOBJ_ACTUATOR = 18, mjOBJ_SENSOR = 19,
+	              mjOBJ_EQUALITY = 16 };
 int mj_name2id(const mjModel *m, int type, const char *name);
 
 class MujocoEnv;

@@ -36,6 +36,19 @@ int be_host_register(void *, void *h, unsigned long long bytes) { return mjb_hos
 int be_host_unregister(void *, void *h) { return mjb_host_unregister(h); }
 int be_step_async(void *s, int n) { return mjb_step(B(s)->batch, n); }
 int be_register_collision(void *s, int t1, int t2, int f) { return mjb_register_collision(B(s)->batch, t1, t2, f); }
+int be_set_env_param(void *s, int what, int lo, int hi, const void *data)
+{
+	mjb_batch *b = B(s)->batch;
+	switch (what) {
+	case MJR_ENV_GRAVITY: return mjb_set_env_gravity(b, lo, hi, static_cast<const double *>(data));
+	case MJR_ENV_GEOM_FRICTION: return mjb_set_env_geom_friction(b, lo, hi, static_cast<const double *>(data));
+	case MJR_ENV_GEOM_SIZE: return mjb_set_env_geom_size(b, lo, hi, static_cast<const double *>(data));
+	case MJR_ENV_GEOM_TYPE: return mjb_set_env_geom_type(b, lo, hi, static_cast<const int *>(data));
+	case MJR_ENV_EQUALITY: return mjb_set_env_equality(b, lo, hi, static_cast<const double *>(data));
+	case MJR_ENV_BODY_MASS: return mjb_set_env_body_mass(b, lo, hi, static_cast<const double *>(data), nullptr);
+	default: return -1;
+	}
+}
 const char *be_err(void *) { return mjb_last_error(); }
 void be_destroy(void *s)
 {
@@ -56,6 +69,7 @@ struct Sharded {
 	std::vector<mjr_backend *> kid;
 	std::vector<int> lo;  // first env of every block, plus the total at the end
 	std::string err;
+	size_t stride[6] = { 0, 0, 0, 0, 0, 0 };  // bytes per env of each MJR_ENV_* payload
 	mjr_backend vt{};
 };
 #define SH(self) (static_cast<Sharded *>(self))
@@ -155,6 +169,15 @@ int sh_register_collision(void *s, int t1, int t2, int fn)
 {
 	return sh_each(SH(s), [&](mjr_backend *k, int) { return k->register_collision ? k->register_collision(k->self, t1, t2, fn) : -1; });
 }
+int sh_set_env_param(void *s, int what, int lo, int hi, const void *data)
+{
+	// per-env stride of the payload, from the model's sizes (every block holds the same model)
+	Sharded *sh = SH(s);
+	const size_t per = sh->stride[what < 0 || what > 5 ? 0 : what];
+	return sh_range(sh, lo, hi, [&](mjr_backend *k, int a, int b, int off) {
+		return k->set_env_param ? k->set_env_param(k->self, what, a, b, static_cast<const char *>(data) + (size_t)off * per) : -1;
+	});
+}
 const char *sh_err(void *s) { return SH(s)->err.c_str(); }
 void sh_destroy(void *s)
 {
@@ -179,9 +202,14 @@ mjr_backend *sharded_factory(const mjb_model_desc *desc, int nenv, int, void *us
 		sh->kid.push_back(k);
 		sh->lo.push_back(sh->lo.back() + n);
 	}
+	sh->stride[MJR_ENV_GRAVITY] = 3 * sizeof(double);
+	sh->stride[MJR_ENV_GEOM_FRICTION] = sh->stride[MJR_ENV_GEOM_SIZE] = (size_t)3 * desc->ngeom * sizeof(double);
+	sh->stride[MJR_ENV_GEOM_TYPE] = (size_t)desc->ngeom * sizeof(int);
+	sh->stride[MJR_ENV_EQUALITY] = (size_t)19 * desc->neq * sizeof(double);
+	sh->stride[MJR_ENV_BODY_MASS] = (size_t)desc->nbody * sizeof(double);
 	sh->vt = mjr_backend{ sh, sh_nenv, sh_field_size, sh_step, sh_step1, sh_step2, sh_forward, sh_reset, sh_get, sh_set, sh_noise,
 		                  sh_sync, sh_err, sh_destroy, sh_get_many, sh_set_many, sh_host_register, sh_host_unregister, sh_step_async,
-		                  sh_register_collision };
+		                  sh_register_collision, sh_set_env_param };
 	return &sh->vt;
 }
 
@@ -212,7 +240,7 @@ mjr_backend *mjr_make_mjb_backend(const mjb_model_desc *desc, int nenv, int devi
 	}
 	b->vt = mjr_backend{ b, be_nenv, be_field_size, be_step, be_step1, be_step2, be_forward, be_reset, be_get, be_set,
 		                 be_noise, be_sync, be_err, be_destroy, be_get_many, be_set_many, be_host_register, be_host_unregister,
-		                 be_step_async, be_register_collision };
+		                 be_step_async, be_register_collision, be_set_env_param };
 	return &b->vt;
 }
 
@@ -272,6 +300,8 @@ int mjr_env_queue_model(mjr_env *e, const mjb_model_desc *desc, const mjr_names 
 		fill(n.site, names->site, desc->nsite);
 		fill(n.sensor, names->sensor, desc->nsensor);
 		fill(n.actuator, names->actuator, desc->nu);
+		if (names->equality) fill(n.equality, names->equality, desc->neq);
+		if (names->tendon) fill(n.tendon, names->tendon, desc->ntendon);
 	}
 	e->env->queueModel(desc, n, nenv, device, factory, factory_user);
 	return 0;
@@ -417,6 +447,174 @@ int mjr_env_set_callback_envs(mjr_env *e, int n)
 {
 	e->env->setCallbackEnvs(n);
 	return 0;
+}
+
+// ---- model / body-state services (host/services.cpp) ----
+static void put_msg(char *msg, int cap, const std::string &s)
+{
+	if (msg && cap > 0) snprintf(msg, (size_t)cap, "%s", s.c_str());
+}
+static ModelNames names_of(const mjb_model_desc *desc, const mjr_names *names)
+{
+	ModelNames n;
+	auto fill = [](std::vector<std::string> &dst, const char *const *src, int cnt) {
+		for (int i = 0; i < cnt; i++) dst.emplace_back(src && src[i] ? src[i] : "");
+	};
+	if (names) {
+		fill(n.body, names->body, desc->nbody);
+		fill(n.joint, names->joint, desc->njnt);
+		fill(n.geom, names->geom, desc->ngeom);
+		fill(n.site, names->site, desc->nsite);
+		fill(n.sensor, names->sensor, desc->nsensor);
+		fill(n.actuator, names->actuator, desc->nu);
+		if (names->equality) fill(n.equality, names->equality, desc->neq);
+		if (names->tendon) fill(n.tendon, names->tendon, desc->ntendon);
+	}
+	return n;
+}
+int mjr_env_set_body_state(mjr_env *e, const mjr_body_state *st, int set_pose, int set_twist, int set_mass, int reset_qpos,
+                           const char *admin_hash, int env_lo, int env_hi, char *msg, int msg_cap)
+{
+	if (!e || !st) return -1;
+	BodyState b;
+	b.name = st->name;
+	b.mass = st->mass;
+	for (int k = 0; k < 7; k++) b.pose[k] = st->pose[k];
+	for (int k = 0; k < 6; k++) b.twist[k] = st->twist[k];
+	b.pose_frame = st->pose_frame;
+	b.twist_frame = st->twist_frame;
+	auto r = e->env->setBodyStateCB(b, set_pose != 0, set_twist != 0, set_mass != 0, reset_qpos != 0, admin_hash ? admin_hash : "", env_lo, env_hi);
+	put_msg(msg, msg_cap, r.status_message);
+	return r.success ? 1 : 0;
+}
+int mjr_env_get_body_state(mjr_env *e, const char *name, const char *admin_hash, int env, mjr_body_state *out, char *msg, int msg_cap)
+{
+	if (!e || !name || !out) return -1;
+	auto r = e->env->getBodyStateCB(name, admin_hash ? admin_hash : "", env);
+	put_msg(msg, msg_cap, r.status_message);
+	memset(out, 0, sizeof(*out));
+	snprintf(out->name, sizeof(out->name), "%s", r.state.name.c_str());
+	snprintf(out->pose_frame, sizeof(out->pose_frame), "%s", r.state.pose_frame.c_str());
+	snprintf(out->twist_frame, sizeof(out->twist_frame), "%s", r.state.twist_frame.c_str());
+	out->mass = r.state.mass;
+	for (int k = 0; k < 7; k++) out->pose[k] = r.state.pose[k];
+	for (int k = 0; k < 6; k++) out->twist[k] = r.state.twist[k];
+	return r.success ? 1 : 0;
+}
+int mjr_env_set_geom_properties(mjr_env *e, const mjr_geom_properties *p, int set_type, int set_mass, int set_friction, int set_size,
+                                const char *admin_hash, int env_lo, int env_hi, char *msg, int msg_cap)
+{
+	if (!e || !p) return -1;
+	GeomProperties g;
+	g.name = p->name;
+	g.type = p->type;
+	g.body_mass = p->body_mass;
+	for (int k = 0; k < 3; k++) { g.friction[k] = p->friction[k]; g.size[k] = p->size[k]; }
+	auto r = e->env->setGeomPropertiesCB(g, set_type != 0, set_mass != 0, set_friction != 0, set_size != 0, admin_hash ? admin_hash : "", env_lo, env_hi);
+	put_msg(msg, msg_cap, r.status_message);
+	return r.success ? 1 : 0;
+}
+int mjr_env_get_geom_properties(mjr_env *e, const char *geom_name, const char *admin_hash, int env, mjr_geom_properties *out, char *msg,
+                                int msg_cap)
+{
+	if (!e || !geom_name || !out) return -1;
+	auto r = e->env->getGeomPropertiesCB(geom_name, admin_hash ? admin_hash : "", env);
+	put_msg(msg, msg_cap, r.status_message);
+	memset(out, 0, sizeof(*out));
+	snprintf(out->name, sizeof(out->name), "%s", r.properties.name.c_str());
+	out->type = r.properties.type;
+	out->body_mass = r.properties.body_mass;
+	for (int k = 0; k < 3; k++) { out->friction[k] = r.properties.friction[k]; out->size[k] = r.properties.size[k]; }
+	return r.success ? 1 : 0;
+}
+int mjr_env_set_gravity(mjr_env *e, const double *g, const char *admin_hash, int env_lo, int env_hi, char *msg, int msg_cap)
+{
+	if (!e || !g) return -1;
+	auto r = e->env->setGravityCB(g, admin_hash ? admin_hash : "", env_lo, env_hi);
+	put_msg(msg, msg_cap, r.status_message);
+	return r.success ? 1 : 0;
+}
+int mjr_env_get_gravity(mjr_env *e, const char *admin_hash, int env, double *g, char *msg, int msg_cap)
+{
+	if (!e || !g) return -1;
+	auto r = e->env->getGravityCB(admin_hash ? admin_hash : "", env);
+	put_msg(msg, msg_cap, r.status_message);
+	for (int k = 0; k < 3; k++) g[k] = r.gravity[k];
+	return r.success ? 1 : 0;
+}
+static EqualityConstraintParameters eq_in(const mjr_eq_parameters &p)
+{
+	EqualityConstraintParameters q;
+	q.name = p.name; q.element1 = p.element1; q.element2 = p.element2;
+	q.type = p.type;
+	q.active = p.active != 0;
+	for (int k = 0; k < 3; k++) q.anchor[k] = p.anchor[k];
+	for (int k = 0; k < 7; k++) q.relpose[k] = p.relpose[k];
+	q.torquescale = p.torquescale;
+	for (int k = 0; k < 5; k++) q.polycoef[k] = p.polycoef[k];
+	q.solverParameters.dmin = p.dmin; q.solverParameters.dmax = p.dmax; q.solverParameters.width = p.width;
+	q.solverParameters.midpoint = p.midpoint; q.solverParameters.power = p.power; q.solverParameters.timeconst = p.timeconst;
+	q.solverParameters.dampratio = p.dampratio;
+	return q;
+}
+static void eq_out(const EqualityConstraintParameters &q, mjr_eq_parameters *p)
+{
+	memset(p, 0, sizeof(*p));
+	snprintf(p->name, sizeof(p->name), "%s", q.name.c_str());
+	snprintf(p->element1, sizeof(p->element1), "%s", q.element1.c_str());
+	snprintf(p->element2, sizeof(p->element2), "%s", q.element2.c_str());
+	p->type = q.type;
+	p->active = q.active ? 1 : 0;
+	for (int k = 0; k < 3; k++) p->anchor[k] = q.anchor[k];
+	for (int k = 0; k < 7; k++) p->relpose[k] = q.relpose[k];
+	p->torquescale = q.torquescale;
+	for (int k = 0; k < 5; k++) p->polycoef[k] = q.polycoef[k];
+	p->dmin = q.solverParameters.dmin; p->dmax = q.solverParameters.dmax; p->width = q.solverParameters.width;
+	p->midpoint = q.solverParameters.midpoint; p->power = q.solverParameters.power; p->timeconst = q.solverParameters.timeconst;
+	p->dampratio = q.solverParameters.dampratio;
+}
+int mjr_env_set_eq_parameters(mjr_env *e, const mjr_eq_parameters *params, int n, const char *admin_hash, int env_lo, int env_hi, char *msg,
+                              int msg_cap)
+{
+	if (!e || (n > 0 && !params)) return -1;
+	std::vector<EqualityConstraintParameters> v;
+	for (int k = 0; k < n; k++) v.push_back(eq_in(params[k]));
+	auto r = e->env->setEqualityConstraintParametersArrayCB(v, admin_hash ? admin_hash : "", env_lo, env_hi);
+	put_msg(msg, msg_cap, r.status_message);
+	return r.success ? 1 : 0;
+}
+int mjr_env_get_eq_parameters(mjr_env *e, const char *const *names, int n, const char *admin_hash, int env, mjr_eq_parameters *out, int *nout,
+                              char *msg, int msg_cap)
+{
+	if (!e || (n > 0 && (!names || !out))) return -1;
+	std::vector<std::string> v;
+	for (int k = 0; k < n; k++) v.emplace_back(names[k] ? names[k] : "");
+	auto r = e->env->getEqualityConstraintParametersArrayCB(v, admin_hash ? admin_hash : "", env);
+	put_msg(msg, msg_cap, r.status_message);
+	for (size_t k = 0; k < r.parameters.size() && (int)k < n; k++) eq_out(r.parameters[k], out + k);
+	if (nout) *nout = (int)r.parameters.size();
+	return r.success ? 1 : 0;
+}
+int mjr_env_reload(mjr_env *e, const mjb_model_desc *desc, const mjr_names *names, int nenv, int device, mjr_backend_factory factory,
+                   void *factory_user, char *msg, int msg_cap)
+{
+	if (!e) return -1;
+	ModelNames n = desc ? names_of(desc, names) : ModelNames();
+	auto r = e->env->reloadCB(desc, n, nenv, device, factory, factory_user);
+	put_msg(msg, msg_cap, r.status_message);
+	return r.success ? 1 : 0;
+}
+int mjr_env_loading_request_state(mjr_env *e, char *description, int cap)
+{
+	if (!e) return -1;
+	auto st = e->env->getLoadingRequestState();
+	put_msg(description, cap, st.description);
+	return st.value;
+}
+int mjr_env_load_initial_joint_states(mjr_env *e)
+{
+	if (!e) return -1;
+	return e->env->loadInitialJointStatesCB().success ? 1 : 0;
 }
 
 // ---- MujocoRosSensorsPlugin accessors (sensors_plugin.h) ----

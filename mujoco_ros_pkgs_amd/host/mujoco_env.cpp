@@ -248,6 +248,9 @@ void MujocoEnv::loadWithModelAndData()
 	m.sensor_cutoff = d.sensor_cutoff;
 	m.joint_names = current_.names.joint; m.body_names = current_.names.body; m.geom_names = current_.names.geom;
 	m.site_names = current_.names.site; m.sensor_names = current_.names.sensor; m.actuator_names = current_.names.actuator;
+	m.equality_names = current_.names.equality; m.tendon_names = current_.names.tendon;
+	env_gravity_.clear(); env_body_mass_.clear(); env_geom_friction_.clear(); env_geom_size_.clear(); env_equality_.clear();
+	env_geom_type_.clear();  // (a fresh backend starts from the model's values)
 	model_valid_ = true;
 
 	// host mirrors + views

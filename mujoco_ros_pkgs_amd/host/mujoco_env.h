@@ -28,7 +28,30 @@ namespace mujoco_ros {
 using MujocoEnvMutex = std::recursive_mutex;  // mujoco_env.h:90-92
 
 struct ModelNames {
-	std::vector<std::string> body, joint, geom, site, sensor, actuator;
+	std::vector<std::string> body, joint, geom, site, sensor, actuator, equality, tendon;
+};
+
+// ---- request / response payloads of the model-mutation services (mujoco_ros_msgs: BodyState, GeomProperties,
+// EqualityConstraintParameters; poses {x, y, z, qw, qx, qy, qz}, twists {vx, vy, vz, wx, wy, wz})
+struct BodyState {
+	std::string name;
+	double mass = 0;
+	double pose[7] = { 0, 0, 0, 0, 0, 0, 0 };
+	std::string pose_frame;   // header.frame_id: "" / "world", anything else needs tf (absent here -> refused like a failed transform)
+	double twist[6] = { 0, 0, 0, 0, 0, 0 };
+	std::string twist_frame;
+};
+struct GeomProperties {
+	std::string name;
+	int type = 0;  // mjtGeom
+	double body_mass = 0, friction[3] = { 0, 0, 0 }, size[3] = { 0, 0, 0 };
+};
+struct EqualityConstraintParameters {
+	std::string name, element1, element2;
+	int type = 0;  // mjtEq
+	bool active = false;
+	double anchor[3] = { 0, 0, 0 }, relpose[7] = { 0, 0, 0, 0, 0, 0, 0 }, torquescale = 0, polycoef[5] = { 0, 0, 0, 0, 0 };
+	struct { double dmin = 0, dmax = 0, width = 0, midpoint = 0, power = 0, timeconst = 0, dampratio = 0; } solverParameters;
 };
 
 class MujocoEnv {
@@ -114,6 +137,30 @@ public:
 	ServiceResponse setPauseCB(bool paused, const std::string &admin_hash);
 	ServiceResponse shutdownCB();
 	ServiceResponse resetCB();
+	// ---- model / body-state services (callbacks.cpp:177-201, 210-592, 641-897; host/services.cpp).  The reference mutates its ONE
+	// mjModel / mjData; here every handler takes an env range [env_lo, env_hi) (env_hi < 0: all envs) and writes per-env
+	// parameter overrides through the backend (mjb_set_env_*), or reads env `env`.  Gate, lookups, rules and messages as there.
+	ServiceResponse setBodyStateCB(BodyState state, bool set_pose, bool set_twist, bool set_mass, bool reset_qpos,
+	                               const std::string &admin_hash, int env_lo = 0, int env_hi = -1);
+	struct GetBodyStateResponse : ServiceResponse { BodyState state; };
+	GetBodyStateResponse getBodyStateCB(const std::string &name, const std::string &admin_hash, int env = 0);
+	ServiceResponse setGeomPropertiesCB(const GeomProperties &properties, bool set_type, bool set_mass, bool set_friction, bool set_size,
+	                                    const std::string &admin_hash, int env_lo = 0, int env_hi = -1);
+	struct GetGeomPropertiesResponse : ServiceResponse { GeomProperties properties; };
+	GetGeomPropertiesResponse getGeomPropertiesCB(const std::string &geom_name, const std::string &admin_hash, int env = 0);
+	ServiceResponse setGravityCB(const double gravity[3], const std::string &admin_hash, int env_lo = 0, int env_hi = -1);
+	struct GetGravityResponse : ServiceResponse { double gravity[3] = { 0, 0, 0 }; };
+	GetGravityResponse getGravityCB(const std::string &admin_hash, int env = 0);
+	ServiceResponse setEqualityConstraintParametersArrayCB(const std::vector<EqualityConstraintParameters> &parameters,
+	                                                       const std::string &admin_hash, int env_lo = 0, int env_hi = -1);
+	struct GetEqualityResponse : ServiceResponse { std::vector<EqualityConstraintParameters> parameters; };
+	GetEqualityResponse getEqualityConstraintParametersArrayCB(const std::vector<std::string> &names, const std::string &admin_hash, int env = 0);
+	// reloadCB (:177-201): queue, wait for the loading request to drain, success = sim_state_.model_valid, message = load_error_
+	ServiceResponse reloadCB(const mjb_model_desc *desc, const ModelNames &names, int nenv, int device = 0,
+	                         mjr_backend_factory factory = nullptr, void *factory_user = nullptr);
+	struct LoadingRequestState { int value = 0; std::string description; };
+	LoadingRequestState getLoadingRequestState();        // :72-87
+	ServiceResponse loadInitialJointStatesCB();          // :66-71
 
 	// proxies (mujoco_env.h:241-251, callbacks.cpp:131-157)
 	void runControlCbs();
@@ -191,6 +238,16 @@ protected:
 	std::vector<int> cb_fields_;       // state fields to mirror after a step when cb_all_fields_ is false
 	std::vector<void *> pinned_;       // host mirrors page-locked through the backend
 	std::vector<double> init_qpos_, init_qvel_, init_qfrc_;
+
+	// per-env mirrors of the model parameters the services change (allocated on first use; [env][...], initialised from the model)
+	std::vector<double> env_gravity_, env_body_mass_, env_geom_friction_, env_geom_size_, env_equality_;
+	std::vector<int> env_geom_type_;
+	bool setEqualityConstraintParameters(const EqualityConstraintParameters &parameters, int lo, int hi, std::string &note);  // :641-746
+	bool getEqualityConstraintParameters(EqualityConstraintParameters &parameters, int env);                               // :782-860
+	bool authorized(const std::string &admin_hash) const { return !settings_.eval_mode || admin_hash == settings_.admin_hash; }
+	int pushEnvParam(int what, int lo, int hi, const void *data, std::string &err);
+	void ensureMirrors();
+	void applyMassChange(int lo, int hi, std::string &err);  // `mj_setConst` with qpos kept (:244-258): the backend derives the constants
 
 	int num_steps_until_exit_ = -1;
 	std::atomic_int is_physics_running_ = { 0 }, is_event_running_ = { 0 };

@@ -224,6 +224,9 @@ int mj_name2id(const mjModel *m, int type, const char *name)
 	const std::vector<std::string> *tab = nullptr;
 	switch (type) {
 	case mjOBJ_BODY: tab = &m->body_names; break;
+	case mjOBJ_XBODY: tab = &m->body_names; break;
+	case mjOBJ_EQUALITY: tab = &m->equality_names; break;
+	case mjOBJ_TENDON: tab = &m->tendon_names; break;
 	case mjOBJ_JOINT: tab = &m->joint_names; break;
 	case mjOBJ_GEOM: tab = &m->geom_names; break;
 	case mjOBJ_SITE: tab = &m->site_names; break;

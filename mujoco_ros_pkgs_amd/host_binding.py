@@ -16,8 +16,31 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "lib
 OBJ_BODY, OBJ_JOINT, OBJ_GEOM, OBJ_SITE, OBJ_ACTUATOR, OBJ_SENSOR = 1, 3, 5, 6, 18, 19
 
 
+NAME_KINDS = ("body", "joint", "geom", "site", "sensor", "actuator", "equality", "tendon")
+
+
 class Names(C.Structure):
-    _fields_ = [(k, C.POINTER(C.c_char_p)) for k in ("body", "joint", "geom", "site", "sensor", "actuator")]
+    _fields_ = [(k, C.POINTER(C.c_char_p)) for k in NAME_KINDS]
+
+
+class BodyStateC(C.Structure):
+    """mjr_body_state"""
+    _fields_ = [("name", C.c_char * 64), ("mass", C.c_double), ("pose", C.c_double * 7), ("pose_frame", C.c_char * 64),
+                ("twist", C.c_double * 6), ("twist_frame", C.c_char * 64)]
+
+
+class GeomPropertiesC(C.Structure):
+    """mjr_geom_properties"""
+    _fields_ = [("name", C.c_char * 64), ("type", C.c_int), ("body_mass", C.c_double), ("friction", C.c_double * 3),
+                ("size", C.c_double * 3)]
+
+
+class EqParametersC(C.Structure):
+    """mjr_eq_parameters"""
+    _fields_ = [("name", C.c_char * 64), ("element1", C.c_char * 64), ("element2", C.c_char * 64), ("type", C.c_int),
+                ("active", C.c_int), ("anchor", C.c_double * 3), ("relpose", C.c_double * 7), ("torquescale", C.c_double),
+                ("polycoef", C.c_double * 5), ("dmin", C.c_double), ("dmax", C.c_double), ("width", C.c_double),
+                ("midpoint", C.c_double), ("power", C.c_double), ("timeconst", C.c_double), ("dampratio", C.c_double)]
 
 
 class SensorRecord(C.Structure):
@@ -80,6 +103,17 @@ def load_library():
         "mjr_env_test_plugin_flag": (ci, [vp, ci, cs, ci]),
         "mjr_env_notify_geom_changed": (ci, [vp, ci]),
         "mjr_env_set_callback_envs": (ci, [vp, ci]),
+        "mjr_env_set_body_state": (ci, [vp, C.POINTER(BodyStateC), ci, ci, ci, ci, cs, ci, ci, C.c_char_p, ci]),
+        "mjr_env_get_body_state": (ci, [vp, cs, cs, ci, C.POINTER(BodyStateC), C.c_char_p, ci]),
+        "mjr_env_set_geom_properties": (ci, [vp, C.POINTER(GeomPropertiesC), ci, ci, ci, ci, cs, ci, ci, C.c_char_p, ci]),
+        "mjr_env_get_geom_properties": (ci, [vp, cs, cs, ci, C.POINTER(GeomPropertiesC), C.c_char_p, ci]),
+        "mjr_env_set_gravity": (ci, [vp, C.POINTER(C.c_double), cs, ci, ci, C.c_char_p, ci]),
+        "mjr_env_get_gravity": (ci, [vp, cs, ci, C.POINTER(C.c_double), C.c_char_p, ci]),
+        "mjr_env_set_eq_parameters": (ci, [vp, C.POINTER(EqParametersC), ci, cs, ci, ci, C.c_char_p, ci]),
+        "mjr_env_get_eq_parameters": (ci, [vp, C.POINTER(C.c_char_p), ci, cs, ci, C.POINTER(EqParametersC), C.POINTER(ci), C.c_char_p, ci]),
+        "mjr_env_reload": (ci, [vp, C.POINTER(binding.ModelDesc), C.POINTER(Names), ci, ci, vp, vp, C.c_char_p, ci]),
+        "mjr_env_loading_request_state": (ci, [vp, C.c_char_p, ci]),
+        "mjr_env_load_initial_joint_states": (ci, [vp]),
         "mjr_sensors_num_records": (ci, [vp, ci, ci]),
         "mjr_sensors_get_record": (ci, [vp, ci, ci, ci, C.POINTER(SensorRecord)]),
         "mjr_sensors_register_noise": (ci, [vp, ci, cs, ci, C.POINTER(C.c_double), C.POINTER(C.c_double), cs]),
@@ -107,13 +141,7 @@ class HostEnv:
     # ---- model
     def queue_model(self, model, nenv=1, device=0, backend_factory=None, devices=None):
         """``devices``: shard the batch over these devices (contiguous env blocks, one backend each)."""
-        desc, keep = binding.make_desc(model)
-        names = Names()
-        for kind in ("body", "joint", "geom", "site", "sensor", "actuator"):
-            lst = model["names"].get(kind, [])
-            arr = (C.c_char_p * max(1, len(lst)))(*[s.encode() for s in lst])
-            keep.append(arr)
-            setattr(names, kind, C.cast(arr, C.POINTER(C.c_char_p)))
+        desc, names, keep = self._desc_and_names(model)
         self._keep += [desc, keep, names]
         self.model = model
         fac = C.cast(backend_factory, C.c_void_p) if backend_factory is not None else None
@@ -125,8 +153,136 @@ class HostEnv:
         if rc != 0:
             raise RuntimeError("queue_model failed")
 
+    @staticmethod
+    def _desc_and_names(model):
+        desc, keep = binding.make_desc(model)
+        names = Names()
+        for kind in NAME_KINDS:
+            lst = [s or "" for s in model["names"].get(kind, [])]
+            arr = (C.c_char_p * max(1, len(lst)))(*[s.encode() for s in lst])
+            keep.append(arr)
+            setattr(names, kind, C.cast(arr, C.POINTER(C.c_char_p)))
+        return desc, names, keep
+
     def start(self):
         self.L.mjr_env_start(self.ptr)
+
+    # ---- model / body-state services (host/services.cpp <- callbacks.cpp:177-201, 210-592, 641-897); each returns
+    # (success, status_message[, payload]).  env_hi < 0 = every env
+    _MSG = 1024
+
+    def set_body_state(self, name, pose=None, twist=None, mass=None, reset_qpos=False, pose_frame="", twist_frame="",
+                       set_pose=None, set_twist=None, admin_hash="", env_lo=0, env_hi=-1):
+        st = BodyStateC()
+        st.name = name.encode()
+        st.pose_frame, st.twist_frame = pose_frame.encode(), twist_frame.encode()
+        for k, v in enumerate(pose if pose is not None else [0, 0, 0, 0, 0, 0, 0]):
+            st.pose[k] = v
+        for k, v in enumerate(twist if twist is not None else [0] * 6):
+            st.twist[k] = v
+        st.mass = 0.0 if mass is None else mass
+        msg = C.create_string_buffer(self._MSG)
+        ok = self.L.mjr_env_set_body_state(self.ptr, C.byref(st), int(pose is not None if set_pose is None else set_pose),
+                                           int(twist is not None if set_twist is None else set_twist), int(mass is not None),
+                                           int(reset_qpos), admin_hash.encode(), env_lo, env_hi, msg, self._MSG)
+        return bool(ok == 1), msg.value.decode()
+
+    def get_body_state(self, name, admin_hash="", env=0):
+        st = BodyStateC()
+        msg = C.create_string_buffer(self._MSG)
+        ok = self.L.mjr_env_get_body_state(self.ptr, name.encode(), admin_hash.encode(), env, C.byref(st), msg, self._MSG)
+        return bool(ok == 1), msg.value.decode(), dict(name=st.name.decode(), mass=st.mass, pose=np.array(st.pose[:]),
+                                                      twist=np.array(st.twist[:]), pose_frame=st.pose_frame.decode(),
+                                                      twist_frame=st.twist_frame.decode())
+
+    def set_geom_properties(self, name, type=None, body_mass=None, friction=None, size=None, admin_hash="", env_lo=0, env_hi=-1):
+        p = GeomPropertiesC()
+        p.name = name.encode()
+        p.type = 0 if type is None else int(type)
+        p.body_mass = 0.0 if body_mass is None else body_mass
+        for k in range(3):
+            p.friction[k] = 0.0 if friction is None else friction[k]
+            p.size[k] = 0.0 if size is None else size[k]
+        msg = C.create_string_buffer(self._MSG)
+        ok = self.L.mjr_env_set_geom_properties(self.ptr, C.byref(p), int(type is not None), int(body_mass is not None),
+                                                int(friction is not None), int(size is not None), admin_hash.encode(), env_lo, env_hi,
+                                                msg, self._MSG)
+        return bool(ok == 1), msg.value.decode()
+
+    def get_geom_properties(self, name, admin_hash="", env=0):
+        p = GeomPropertiesC()
+        msg = C.create_string_buffer(self._MSG)
+        ok = self.L.mjr_env_get_geom_properties(self.ptr, name.encode(), admin_hash.encode(), env, C.byref(p), msg, self._MSG)
+        return bool(ok == 1), msg.value.decode(), dict(name=p.name.decode(), type=p.type, body_mass=p.body_mass,
+                                                      friction=np.array(p.friction[:]), size=np.array(p.size[:]))
+
+    def set_gravity(self, gravity, admin_hash="", env_lo=0, env_hi=-1):
+        g = (C.c_double * 3)(*[float(x) for x in gravity])
+        msg = C.create_string_buffer(self._MSG)
+        ok = self.L.mjr_env_set_gravity(self.ptr, g, admin_hash.encode(), env_lo, env_hi, msg, self._MSG)
+        return bool(ok == 1), msg.value.decode()
+
+    def get_gravity(self, admin_hash="", env=0):
+        g = (C.c_double * 3)()
+        msg = C.create_string_buffer(self._MSG)
+        ok = self.L.mjr_env_get_gravity(self.ptr, admin_hash.encode(), env, g, msg, self._MSG)
+        return bool(ok == 1), msg.value.decode(), np.array(g[:])
+
+    @staticmethod
+    def _eq_to_c(d):
+        p = EqParametersC()
+        p.name, p.element1, p.element2 = d["name"].encode(), d.get("element1", "").encode(), d.get("element2", "").encode()
+        p.type, p.active = int(d.get("type", 0)), int(bool(d.get("active", False)))
+        for key, n in (("anchor", 3), ("relpose", 7), ("polycoef", 5)):
+            for k, v in enumerate(d.get(key, [0] * n)):
+                getattr(p, key)[k] = v
+        p.torquescale = d.get("torquescale", 0.0)
+        for key in ("dmin", "dmax", "width", "midpoint", "power", "timeconst", "dampratio"):
+            setattr(p, key, float(d.get(key, 0.0)))
+        return p
+
+    def set_eq_parameters(self, params, admin_hash="", env_lo=0, env_hi=-1):
+        arr = (EqParametersC * max(1, len(params)))(*[self._eq_to_c(d) for d in params])
+        msg = C.create_string_buffer(self._MSG)
+        ok = self.L.mjr_env_set_eq_parameters(self.ptr, arr, len(params), admin_hash.encode(), env_lo, env_hi, msg, self._MSG)
+        return bool(ok == 1), msg.value.decode()
+
+    def get_eq_parameters(self, names, admin_hash="", env=0):
+        na = (C.c_char_p * max(1, len(names)))(*[n.encode() for n in names])
+        out = (EqParametersC * max(1, len(names)))()
+        nout = C.c_int(0)
+        msg = C.create_string_buffer(self._MSG)
+        ok = self.L.mjr_env_get_eq_parameters(self.ptr, na, len(names), admin_hash.encode(), env, out, C.byref(nout), msg, self._MSG)
+        res = []
+        for k in range(nout.value):
+            p = out[k]
+            res.append(dict(name=p.name.decode(), element1=p.element1.decode(), element2=p.element2.decode(), type=p.type,
+                            active=bool(p.active), anchor=np.array(p.anchor[:]), relpose=np.array(p.relpose[:]),
+                            torquescale=p.torquescale, polycoef=np.array(p.polycoef[:]), dmin=p.dmin, dmax=p.dmax, width=p.width,
+                            midpoint=p.midpoint, power=p.power, timeconst=p.timeconst, dampratio=p.dampratio))
+        return bool(ok == 1), msg.value.decode(), res
+
+    def reload(self, model, nenv=1, device=0, backend_factory=None):
+        """reloadCB: blocks until the load request has been served; (success, status_message = load_error_)."""
+        msg = C.create_string_buffer(self._MSG)
+        fac = C.cast(backend_factory, C.c_void_p) if backend_factory is not None else None
+        if model is None:
+            ok = self.L.mjr_env_reload(self.ptr, None, None, nenv, device, fac, None, msg, self._MSG)
+        else:
+            desc, names, keep = self._desc_and_names(model)
+            self._keep += [desc, keep, names]
+            ok = self.L.mjr_env_reload(self.ptr, C.byref(desc), C.byref(names), nenv, device, fac, None, msg, self._MSG)
+            if ok == 1:
+                self.model = model
+        return bool(ok == 1), msg.value.decode()
+
+    def loading_request_state(self):
+        buf = C.create_string_buffer(64)
+        v = self.L.mjr_env_loading_request_state(self.ptr, buf, 64)
+        return v, buf.value.decode()
+
+    def load_initial_joint_states(self):
+        return self.L.mjr_env_load_initial_joint_states(self.ptr) == 1
 
     def shutdown(self):
         if self.ptr:

@@ -73,6 +73,25 @@ static int ob_register_collision(void *s, int t1, int t2, int func)
 	for (int e = 0; e < b->nenv; e++) mjo_register_collision(b->d[e], t1, t2, func);
 	return 0;
 }
+/* per-env model parameters: the harness models geom sizes / types (mjo_set_geom_size / _type); the others are accepted and NOT
+ * modelled -- the CPU tests that use this backend check the service handlers' logic (lookups, gates, mirrors, messages), the
+ * physical effect of every override is checked against the oracle on the GPU (tests/test_gpu_env_params.py, test_host_services.py[hip]) */
+static int ob_set_env_param(void *s, int what, int lo, int hi, const void *data)
+{
+	ob *b = (ob *)s;
+	if (lo < 0 || hi > b->nenv || lo > hi || !data) return -1;
+	for (int e = lo; e < hi; e++) {
+		if (what == MJR_ENV_GEOM_SIZE) mjo_set_geom_size(&b->desc, b->d[e], (const double *)data + (size_t)(e - lo) * 3 * b->desc.ngeom);
+		else if (what == MJR_ENV_GEOM_TYPE) {
+			const int *t = (const int *)data + (size_t)(e - lo) * b->desc.ngeom;
+			int ok = 1;
+			for (int g = 0; g < b->desc.ngeom; g++)
+				if (t[g] != 0 && t[g] != 2 && t[g] != 3 && t[g] != 6) ok = 0; /* ellipsoid / cylinder: no pair function, not modelled */
+			if (ok) mjo_set_geom_type(&b->desc, b->d[e], t);
+		}
+	}
+	return what >= MJR_ENV_GRAVITY && what <= MJR_ENV_BODY_MASS ? 0 : -1;
+}
 static int ob_reset(void *s, const uint8_t *mask)
 {
 	ob *b = (ob *)s;
@@ -127,7 +146,7 @@ mjr_backend *oracle_backend_factory(const mjb_model_desc *desc, int nenv, int de
 	b->d = (mjo_data **)calloc((size_t)nenv, sizeof(mjo_data *));
 	for (int e = 0; e < nenv; e++) b->d[e] = mjo_make_data(&b->desc);
 	mjr_backend vt = { b, ob_nenv, ob_field_size, ob_step, ob_step1, ob_step2, ob_forward, ob_reset, ob_get, ob_set,
-		               ob_noise, ob_sync, ob_err, ob_destroy, NULL, NULL, NULL, NULL, NULL, ob_register_collision };
+		               ob_noise, ob_sync, ob_err, ob_destroy, NULL, NULL, NULL, NULL, NULL, ob_register_collision, ob_set_env_param };
 	b->vt = vt;
 	return &b->vt;
 }
