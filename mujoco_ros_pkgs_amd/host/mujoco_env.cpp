@@ -51,7 +51,11 @@ MujocoEnv::MujocoEnv(const std::string &admin_hash, const ParamServer *initial_p
 	params_.param<bool>("unpause", run, true);
 	settings_.run = run;
 	// mujoco_env.cpp:142
-	params_.param<int>("num_steps", num_steps_until_exit_, -1);
+	{
+		int num_steps = -1;
+		params_.param<int>("num_steps", num_steps, -1);
+		num_steps_until_exit_.store(num_steps);
+	}
 	params_.param<int>("realtime_index", settings_.real_time_index, 0);
 	params_.param<double>("ctrl_noise_std", ctrl_noise_std, 0.0);
 	params_.param<double>("ctrl_noise_rate", ctrl_noise_rate, 0.0);
@@ -165,7 +169,7 @@ bool MujocoEnv::initModelFromQueue()
 	backend_new_ = staged_.factory(&staged_.desc, staged_.nenv, staged_.device, staged_.factory_user);
 	if (!backend_new_) {
 		load_error_ = std::string("could not create the step backend: ") + mjr_last_error();
-		sim_state_.model_valid = model_valid_;  // the old model (if any) stays in place
+		sim_state_.model_valid = model_valid_.load();  // the old model (if any) stays in place
 		staged_ = Queued();
 		return false;
 	}
@@ -434,7 +438,7 @@ int MujocoEnv::stepBurst(int n, bool count_requests)
 		done = n;
 		step_count_ += (unsigned long long)n;
 		if (count_requests) settings_.env_steps_request.fetch_sub(n);
-		if (num_steps_until_exit_ > 0) num_steps_until_exit_ = std::max(0, num_steps_until_exit_ - n);
+		if (num_steps_until_exit_.load() > 0) num_steps_until_exit_.store(std::max(0, num_steps_until_exit_.load() - n));
 		return done;
 	}
 	if (!(cb_mask_ & (MujocoPlugin::CB_CONTROL | MujocoPlugin::CB_PASSIVE))) {
@@ -548,7 +552,7 @@ void MujocoEnv::physicsLoop()
 						const double behind = Seconds(Clock::now() - syncCPU).count() / slowdown - (data_time_.load() - syncSim);
 						n = std::max(1, std::min(kFuseChunk, (int)(behind / dt)));
 					}
-					if (num_steps_until_exit_ > 0) n = std::min(n, num_steps_until_exit_);
+					if (num_steps_until_exit_ > 0) n = std::min(n, num_steps_until_exit_.load());
 					const double prev = data_time_.load();
 					if (stepBurst(n, false) == 0) break;
 					if (data_time_.load() < prev) break;  // reset
@@ -560,7 +564,7 @@ void MujocoEnv::physicsLoop()
 				syncSim = data_time_.load();
 				while (settings_.env_steps_request.load() > 0 && !settings_.exit_request.load()) {
 					int n = std::min(settings_.env_steps_request.load(), kFuseChunk);
-					if (num_steps_until_exit_ > 0) n = std::min(n, num_steps_until_exit_);
+					if (num_steps_until_exit_ > 0) n = std::min(n, num_steps_until_exit_.load());
 					if (n <= 0 || stepBurst(n, true) == 0) break;
 					if (data_time_.load() < syncSim) break;
 					if (num_steps_until_exit_ == 0) break;

@@ -112,7 +112,7 @@ public:
 	void shutdown();  // exit_request + join (MujocoEnvTestWrapper::shutdown, mujoco_env_fixture.h:62-70)
 
 	int getOperationalStatus();  // mujoco_env.cpp:740-743
-	int getPendingSteps() const { return num_steps_until_exit_; }
+	int getPendingSteps() const { return num_steps_until_exit_.load(); }
 	int isPhysicsRunning() const { return is_physics_running_; }
 	int isEventRunning() const { return is_event_running_; }
 	const std::string &loadError() const { return load_error_; }
@@ -173,7 +173,7 @@ public:
 	int registerCollisionFunction(int geom_type1, int geom_type2, int func);
 
 	// per-env data access for tests / services (host mirror, refreshed from the device on demand)
-	const mjModel *getModelPtr() const { return model_valid_ ? &model_ : nullptr; }
+	const mjModel *getModelPtr() const { return model_valid_.load() ? &model_ : nullptr; }
 	mjData *getDataPtr(int env = 0);  // pulls the state fields of `env` from the device
 	void commitData(int env = 0);     // pushes qpos / qvel / ctrl / qfrc_applied / xfrc_applied of `env` back
 	int nenv() const { return nenv_; }
@@ -219,7 +219,7 @@ protected:
 	} queued_, current_;
 
 	mjModel model_{};
-	bool model_valid_ = false;
+	std::atomic_bool model_valid_ = { false };  // (read by the physics loop before it takes the mutex: TSan, profiles/r03_sanitizers.txt)
 	int nenv_ = 0;
 	mjr_backend *backend_ = nullptr, *backend_new_ = nullptr;
 	Queued staged_;
@@ -249,7 +249,7 @@ protected:
 	void ensureMirrors();
 	void applyMassChange(int lo, int hi, std::string &err);  // `mj_setConst` with qpos kept (:244-258): the backend derives the constants
 
-	int num_steps_until_exit_ = -1;
+	std::atomic_int num_steps_until_exit_ = { -1 };  // (written by the physics thread, read by getPendingSteps() callers)
 	std::atomic_int is_physics_running_ = { 0 }, is_event_running_ = { 0 };
 	std::atomic<double> sim_time_ = { 0.0 };   // the /clock equivalent: only advances with use_sim_time
 	std::atomic<double> data_time_ = { 0.0 };  // env 0's data->time after the latest step / forward: what the loop paces on

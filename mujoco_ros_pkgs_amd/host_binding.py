@@ -12,6 +12,8 @@ import numpy as np
 from . import binding
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "libmjr_host.so")
+if os.environ.get("MJR_HOST_LIBRARY"):  # another build of the same runtime (libmjr_host_tsan.so / _asan.so: tools/run_sanitizers.sh)
+    LIB_PATH = os.path.abspath(os.environ["MJR_HOST_LIBRARY"])
 
 OBJ_BODY, OBJ_JOINT, OBJ_GEOM, OBJ_SITE, OBJ_ACTUATOR, OBJ_SENSOR = 1, 3, 5, 6, 18, 19
 

@@ -13,7 +13,10 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 
 
 def build(force=False):
-    """Compile oracle/libmjo.so (+ libmjo_fast.so) with gcc via oracle/Makefile."""
+    """Compile oracle/libmjo.so (+ libmjo_fast.so) with gcc via oracle/Makefile.  (MJB_PREBUILT=1: everything was built by the
+    caller -- tools/run_sanitizers.sh, where forking `make` out of a sanitizer-preloaded python is not an option.)"""
+    if os.environ.get("MJB_PREBUILT") == "1" and not force:
+        return
     if force:
         subprocess.check_call(["make", "-s", "-C", _DIR, "clean"])
     subprocess.check_call(["make", "-s", "-C", _DIR, "all"])
