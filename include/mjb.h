@@ -258,7 +258,10 @@ void *mjb_sensor_device_ptr(mjb_batch *b, int which);
  *   MJB_COLFUNC_NONE     the pair type produces no contacts (a collision function that returns 0)
  *   MJB_COLFUNC_SPHERES  both geoms are replaced by their bounding spheres (planes stay planes): at most one contact
  * geom_type1 / geom_type2 are mjtGeom values in either order; the override applies to every candidate pair of those types of
- * this batch from the next launch on. */
+ * this batch from the next launch on.
+ * Limitation (differs from the reference, whose mjCOLLISIONFUNC table is indexed by the geoms' CURRENT types): the override is
+ * filed on the candidate pairs by the MODEL's geom types.  An env whose geom types were changed with mjb_set_env_geom_type keeps,
+ * for each pair, the override registered for the pair's original types. */
 enum { MJB_COLFUNC_DEFAULT = 0, MJB_COLFUNC_NONE = 1, MJB_COLFUNC_SPHERES = 2 };
 int mjb_register_collision(mjb_batch *b, int geom_type1, int geom_type2, int func);
 

@@ -1539,30 +1539,37 @@ int mjb_get_many(mjb_batch *b, int n, const int *fields, int env_lo, int env_hi,
 {
 	if (!b || n < 0 || (n && (!fields || !host))) return fail(MJB_EINVAL, "mjb_get_many: bad argument");
 	HIP_TRY(hipSetDevice(b->device));
+	// every argument is checked BEFORE the first copy is enqueued: a refusal never leaves transfers in flight
 	for (int k = 0; k < n; k++) {
 		const int field = fields[k];
 		int rc = check_range(b, field, env_lo, env_hi);
 		if (rc) return rc;
 		if (kFields[field].kind == 3) return fail(MJB_EINVAL, "field %s is an int field; use mjb_get_int", kFields[field].name);
-		const int sz = b->model->field_size[field];
-		if (sz == 0 || env_lo == env_hi) continue;
+		if (b->model->field_size[field] == 0 || env_lo == env_hi) continue;
 		if (!host[k]) return fail(MJB_EINVAL, "null host buffer");
-		if (kFields[field].kind == 0) {
-			HIP_TRY(hipMemcpyAsync(host[k], state_ptr(b, field) + (size_t)env_lo * sz, (size_t)(env_hi - env_lo) * sz * sizeof(double),
-			                       hipMemcpyDeviceToHost, b->stream));
-		} else {
-			if (!b->frame_valid || !b->st.frame_ws)
-				return fail(MJB_EINVAL, "derived field %s is only readable after mjb_forward / mjb_step1 / mjb_step2", kFields[field].name);
-			HIP_TRY(hipMemcpy2DAsync(host[k], (size_t)sz * sizeof(double),
-			                         b->st.frame_ws + (size_t)env_lo * b->st.frame_stride + frame_offset(b, field),
-			                         (size_t)b->st.frame_stride * sizeof(double), (size_t)sz * sizeof(double), (size_t)(env_hi - env_lo),
-			                         hipMemcpyDeviceToHost, b->stream));
-		}
+		if (kFields[field].kind != 0 && (!b->frame_valid || !b->st.frame_ws))
+			return fail(MJB_EINVAL, "derived field %s is only readable after mjb_forward / mjb_step1 / mjb_step2", kFields[field].name);
 	}
-	HIP_TRY(hipStreamSynchronize(b->stream));
+	hipError_t err = hipSuccess;
+	for (int k = 0; k < n && err == hipSuccess; k++) {
+		const int field = fields[k], sz = b->model->field_size[field];
+		if (sz == 0 || env_lo == env_hi) continue;
+		if (kFields[field].kind == 0)
+			err = hipMemcpyAsync(host[k], state_ptr(b, field) + (size_t)env_lo * sz, (size_t)(env_hi - env_lo) * sz * sizeof(double),
+			                     hipMemcpyDeviceToHost, b->stream);
+		else
+			err = hipMemcpy2DAsync(host[k], (size_t)sz * sizeof(double), b->st.frame_ws + (size_t)env_lo * b->st.frame_stride + frame_offset(b, field),
+			                       (size_t)b->st.frame_stride * sizeof(double), (size_t)sz * sizeof(double), (size_t)(env_hi - env_lo),
+			                       hipMemcpyDeviceToHost, b->stream);
+	}
+	const hipError_t serr = hipStreamSynchronize(b->stream);  // (also after a failed enqueue: the copies before it are drained)
+	if (err != hipSuccess) return fail(MJB_ENODEVICE, "mjb_get_many: %s", hipGetErrorString(err));
+	if (serr != hipSuccess) return fail(MJB_ENODEVICE, "mjb_get_many: %s", hipGetErrorString(serr));
 	return MJB_OK;
 }
 
+// (asynchronous on the batch's stream: the host buffers must stay untouched until the next synchronising call -- mjb_synchronize,
+//  mjb_get*, a blocking mjb_step; page-locked buffers make these true DMA transfers.  MujocoEnv::commitData synchronises.)
 int mjb_set_many(mjb_batch *b, int n, const int *fields, int env_lo, int env_hi, const double *const *host)
 {
 	if (!b || n < 0 || (n && (!fields || !host))) return fail(MJB_EINVAL, "mjb_set_many: bad argument");
@@ -1571,24 +1578,34 @@ int mjb_set_many(mjb_batch *b, int n, const int *fields, int env_lo, int env_hi,
 		const int field = fields[k];
 		int rc = check_range(b, field, env_lo, env_hi);
 		if (rc) return rc;
-		const int sz = b->model->field_size[field];
-		if (sz == 0 || env_lo == env_hi) continue;
+		if (b->model->field_size[field] == 0 || env_lo == env_hi) continue;
 		if (!host[k]) return fail(MJB_EINVAL, "null host buffer");
+		if (kFields[field].kind != 0) {
+			if (field != MJB_F_qfrc_passive)
+				return fail(MJB_EINVAL, "field %s is derived and cannot be set (only state fields and qfrc_passive can)", kFields[field].name);
+			if (!b->frame_valid || !b->st.frame_ws) return fail(MJB_EINVAL, "qfrc_passive can only be modified between mjb_step1 and mjb_step2");
+		}
+	}
+	hipError_t err = hipSuccess;
+	for (int k = 0; k < n && err == hipSuccess; k++) {
+		const int field = fields[k], sz = b->model->field_size[field];
+		if (sz == 0 || env_lo == env_hi) continue;
 		if (kFields[field].kind == 0) {
-			HIP_TRY(hipMemcpyAsync(state_ptr(b, field) + (size_t)env_lo * sz, host[k], (size_t)(env_hi - env_lo) * sz * sizeof(double),
-			                       hipMemcpyHostToDevice, b->stream));
+			err = hipMemcpyAsync(state_ptr(b, field) + (size_t)env_lo * sz, host[k], (size_t)(env_hi - env_lo) * sz * sizeof(double),
+			                     hipMemcpyHostToDevice, b->stream);
 			if (field == MJB_F_xfrc_applied && !b->st.use_xfrc) {
 				b->st.use_xfrc = 1;
 				b->params_dirty = true;
 			}
 		} else {
-			if (field != MJB_F_qfrc_passive)
-				return fail(MJB_EINVAL, "field %s is derived and cannot be set (only state fields and qfrc_passive can)", kFields[field].name);
-			if (!b->frame_valid || !b->st.frame_ws) return fail(MJB_EINVAL, "qfrc_passive can only be modified between mjb_step1 and mjb_step2");
-			HIP_TRY(hipMemcpy2DAsync(b->st.frame_ws + (size_t)env_lo * b->st.frame_stride + frame_offset(b, field),
-			                         (size_t)b->st.frame_stride * sizeof(double), host[k], (size_t)sz * sizeof(double),
-			                         (size_t)sz * sizeof(double), (size_t)(env_hi - env_lo), hipMemcpyHostToDevice, b->stream));
+			err = hipMemcpy2DAsync(b->st.frame_ws + (size_t)env_lo * b->st.frame_stride + frame_offset(b, field),
+			                       (size_t)b->st.frame_stride * sizeof(double), host[k], (size_t)sz * sizeof(double), (size_t)sz * sizeof(double),
+			                       (size_t)(env_hi - env_lo), hipMemcpyHostToDevice, b->stream);
 		}
+	}
+	if (err != hipSuccess) {
+		hipStreamSynchronize(b->stream);  // drain what was enqueued before the failure
+		return fail(MJB_ENODEVICE, "mjb_set_many: %s", hipGetErrorString(err));
 	}
 	return MJB_OK;
 }
@@ -1596,7 +1613,7 @@ int mjb_set_many(mjb_batch *b, int n, const int *fields, int env_lo, int env_hi,
 int mjb_host_register(void *host, unsigned long long bytes)
 {
 	if (!host || !bytes) return fail(MJB_EINVAL, "mjb_host_register: bad argument");
-	if (hipHostRegister(host, (size_t)bytes, hipHostRegisterDefault) != hipSuccess) {
+	if (hipHostRegister(host, (size_t)bytes, hipHostRegisterPortable)  /* every device of a sharded batch may DMA from it */ != hipSuccess) {
 		(void)hipGetLastError();
 		return fail(MJB_ENODEVICE, "hipHostRegister failed");
 	}

@@ -1,6 +1,7 @@
 // host_c_api.cpp — flat C face of mujoco_ros::MujocoEnv (include/mjr_host.h) + the libmjb-backed stepper.
 #include <cstring>
 #include <map>
+#include <memory>
 #include <algorithm>
 #include <string>
 
@@ -70,15 +71,21 @@ struct Sharded {
 	std::vector<int> lo;  // first env of every block, plus the total at the end
 	std::string err;
 	size_t stride[6] = { 0, 0, 0, 0, 0, 0 };  // bytes per env of each MJR_ENV_* payload
+	bool failed = false;                       // a launch failed on one shard: the blocks are out of step
 	mjr_backend vt{};
 };
 #define SH(self) (static_cast<Sharded *>(self))
+// a shard that fails leaves the blocks out of step with each other (the ones before it were already launched): the others are
+// drained and the composite refuses every launch from then on
 template <typename F> int sh_each(Sharded *s, F fn)
 {
+	if (s->failed) return -1;
 	for (size_t k = 0; k < s->kid.size(); k++) {
 		const int rc = fn(s->kid[k], (int)k);
 		if (rc) {
-			s->err = s->kid[k]->last_error(s->kid[k]->self);
+			s->err = std::string("shard ") + std::to_string(k) + ": " + s->kid[k]->last_error(s->kid[k]->self) + " (the sharded backend is now disabled)";
+			for (mjr_backend *q : s->kid) q->synchronize(q->self);
+			s->failed = true;
 			return rc;
 		}
 	}
@@ -215,7 +222,9 @@ mjr_backend *sharded_factory(const mjb_model_desc *desc, int nenv, int, void *us
 
 struct mjr_env {
 	MujocoEnv *env = nullptr;
-	ShardCfg shard;  // device list of the last mjr_env_queue_model_devices (must outlive the queued factory call)
+	// one ShardCfg PER queued request (the deferred factory reads it on the event thread; a second queue_model_devices before the
+	// first is served must not change what the first one sees); they live as long as the env
+	std::vector<std::unique_ptr<ShardCfg>> shards;
 };
 
 extern "C" {
@@ -311,10 +320,12 @@ int mjr_env_queue_model_devices(mjr_env *e, const mjb_model_desc *desc, const mj
                                 mjr_backend_factory factory, void *factory_user)
 {
 	if (!e || !desc || !devices || ndev <= 0 || nenv < ndev) return -1;
-	e->shard.inner = factory ? factory : mjr_make_mjb_backend;
-	e->shard.inner_user = factory_user;
-	e->shard.devices.assign(devices, devices + ndev);
-	return mjr_env_queue_model(e, desc, names, nenv, devices[0], sharded_factory, &e->shard);
+	e->shards.emplace_back(new ShardCfg);
+	ShardCfg *cfg = e->shards.back().get();
+	cfg->inner = factory ? factory : mjr_make_mjb_backend;
+	cfg->inner_user = factory_user;
+	cfg->devices.assign(devices, devices + ndev);
+	return mjr_env_queue_model(e, desc, names, nenv, devices[0], sharded_factory, cfg);
 }
 
 int mjr_env_start(mjr_env *e)

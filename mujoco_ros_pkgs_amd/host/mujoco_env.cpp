@@ -336,11 +336,13 @@ void MujocoEnv::pullFields(const int *fields, int n, int lo, int hi)
 		fl.push_back(f);
 		ptr.push_back(host_fields_[f].data() + (size_t)lo * sz);
 	}
+	int rc = 0;
 	if (backend_->get_many) {
-		backend_->get_many(backend_->self, (int)fl.size(), fl.data(), lo, hi, ptr.data());  // async copies, ONE synchronisation
+		rc = backend_->get_many(backend_->self, (int)fl.size(), fl.data(), lo, hi, ptr.data());  // async copies, ONE synchronisation
 	} else {
-		for (size_t k = 0; k < fl.size(); k++) backend_->get(backend_->self, fl[k], lo, hi, ptr[k]);
+		for (size_t k = 0; k < fl.size() && rc == 0; k++) rc = backend_->get(backend_->self, fl[k], lo, hi, ptr[k]);
 	}
+	if (rc != 0) plugin_warnings_.push_back(std::string("view refresh failed: ") + backend_->last_error(backend_->self));
 	for (int e = lo; e < hi; e++) views_[e].time = host_fields_[MJB_F_time][e];
 }
 
@@ -390,6 +392,7 @@ void MujocoEnv::commitData(int env)
 	std::lock_guard<MujocoEnvMutex> lock(physics_thread_mutex_);
 	if (!model_valid_ || env < 0 || env >= nenv_) return;
 	pushViews(env, env + 1);
+	backend_->synchronize(backend_->self);  // the copies are asynchronous DMA out of the (page-locked) view: the caller may reuse it now
 }
 
 // ------------------------------------------------------------------------------------ callbacks fan-out
@@ -441,12 +444,16 @@ int MujocoEnv::stepBurst(int n, bool count_requests)
 		if (num_steps_until_exit_.load() > 0) num_steps_until_exit_.store(std::max(0, num_steps_until_exit_.load() - n));
 		return done;
 	}
-	if (!(cb_mask_ & (MujocoPlugin::CB_CONTROL | MujocoPlugin::CB_PASSIVE))) {
+	// (the fused observer path below refreshes STATE fields only: a plugin that wants "any field" (viewFields() == false) or names a
+	//  derived one -- xpos, geom_xpos, qfrc_* ... for lastStageCallback / renderCallback -- takes the split path, which pulls them)
+	bool observers_read_state_only = !cb_all_fields_;
+	for (int f : cb_fields_)
+		if (std::find(std::begin(kStateFields), std::end(kStateFields), f) == std::end(kStateFields)) observers_read_state_only = false;
+	if (!(cb_mask_ & (MujocoPlugin::CB_CONTROL | MujocoPlugin::CB_PASSIVE)) && observers_read_state_only) {
 		// Only end-of-step observers (lastStageCallback / renderCallback, e.g. the sensors plugin): nothing can change the
 		// step from the host, so every step is ONE fused launch (no split, no frame workspace) followed by one batched copy
 		// of the fields the plugins read -- the state fields, or exactly the ones they named.
-		const std::vector<int> all(std::begin(kStateFields), std::end(kStateFields));
-		const std::vector<int> &fl = cb_all_fields_ ? all : cb_fields_;
+		const std::vector<int> &fl = cb_fields_;
 		for (int s = 0; s < n; s++) {
 			const double t_before = views_[0].time;
 			if ((backend_->step_async ? backend_->step_async(backend_->self, 1) : backend_->step(backend_->self, 1)) != 0) break;

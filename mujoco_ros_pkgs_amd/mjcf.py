@@ -201,6 +201,7 @@ class _Compiler:
         self.equalities = []
         self.tendons = []
         self.skipped_pairs = []
+        self.notes = []  # compile notes (capacity requests clamped, ...): model["compile_notes"]
         self.nconmax_req = nconmax
         self.nefcmax_req = nefcmax
         self.angle_scale = math.pi / 180.0  # MJCF default: degrees
@@ -316,6 +317,7 @@ class _Compiler:
                 raise MjcfError(f"cannot override option '{k}'")
         m = self._finalize()
         m["skipped_collision_pairs"] = list(self.skipped_pairs)
+        m["compile_notes"] = list(self.notes)
         return m
 
     def _compiler(self, node):
@@ -879,7 +881,9 @@ class _Compiler:
         for g1, g2 in pairs:
             t1, t2 = m["geom_type"][g1], m["geom_type"][g2]
             maxcon += _max_contacts(t1, t2)
-        nconmax = maxcon if self.nconmax_req is None else int(self.nconmax_req)
+        # (a request above the worst case can never be reached: a stock MuJoCo file's <size nconmax="100" njmax="500"/> must neither
+        #  inflate the LDS frame nor trip the solvers' row caps -- the request only ever LOWERS the capacity.  ADVICE r02.)
+        nconmax = maxcon if self.nconmax_req is None else min(int(self.nconmax_req), maxcon)
         nlimit = 0
         for j in range(njnt):
             if m["jnt_limited"][j]:
@@ -902,7 +906,12 @@ class _Compiler:
             neqrow = int(sum({0: 3, 1: 6, 2: 1, 3: 1}[int(t)] for t in m["eq_type"]))
         nfric = 0 if (o["disableflags"] & DISABLE_BITS["frictionloss"]) else int(
             np.count_nonzero(m["dof_frictionloss"] > 0) + np.count_nonzero(m["tendon_frictionloss"] > 0))
-        nefcmax = neqrow + nfric + nlimit + rows_per_con * nconmax if self.nefcmax_req is None else int(self.nefcmax_req)
+        worst_rows = neqrow + nfric + nlimit + rows_per_con * nconmax
+        nefcmax = worst_rows if self.nefcmax_req is None else min(int(self.nefcmax_req), worst_rows)
+        if self.nefcmax_req is not None and int(self.nefcmax_req) > worst_rows:
+            self.notes.append(f"<size njmax={int(self.nefcmax_req)}> exceeds the model's worst case ({worst_rows} rows): capacity set to {worst_rows}")
+        if self.nconmax_req is not None and int(self.nconmax_req) > maxcon:
+            self.notes.append(f"<size nconmax={int(self.nconmax_req)}> exceeds the model's worst case ({maxcon} contacts): capacity set to {maxcon}")
         if o["disableflags"] & (DISABLE_BITS["constraint"]):
             nconmax, nefcmax = 0, 0
         m["nconmax"], m["nefcmax"] = int(nconmax), int(nefcmax)
