@@ -178,6 +178,13 @@ int mjb_get_int(mjb_batch *b, int field, int env_lo, int env_hi, int *host);
  * (mjb_host_register) makes the copies true DMA transfers. */
 int mjb_get_many(mjb_batch *b, int n, const int *fields, int env_lo, int env_hi, double *const *host);
 int mjb_set_many(mjb_batch *b, int n, const int *fields, int env_lo, int env_hi, const double *const *host);
+/* The same through ONE transfer: a device kernel gathers the fields of envs [env_lo, env_hi) into one block laid out field after
+ * field ([env][dim] each, in the order given; zero-sized fields take no room) and a single copy moves it -- what the callback
+ * rounds of the host runtime use (a split step moves ~25 fields out and ~8 back; one copy per field costs more than the step).
+ * mjb_get_packed synchronises; mjb_set_packed is asynchronous on the batch's stream (host_block must stay untouched until the
+ * next synchronising call).  At most 40 fields. */
+int mjb_get_packed(mjb_batch *b, int n, const int *fields, int env_lo, int env_hi, double *host_block);
+int mjb_set_packed(mjb_batch *b, int n, const int *fields, int env_lo, int env_hi, const double *host_block);
 int mjb_host_register(void *host, unsigned long long bytes);   /* hipHostRegister; 0 on success */
 int mjb_host_unregister(void *host);
 

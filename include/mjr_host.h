@@ -45,6 +45,9 @@ typedef struct mjr_backend {
 	/* optional: per-env model parameters (mjb_set_env_*), what the reference's services change on its single mjModel
 	 * (callbacks.cpp:210-370, 462-592, 641-884).  `what` = MJR_ENV_*; data for envs [env_lo, env_hi), env-major. */
 	int (*set_env_param)(void *self, int what, int env_lo, int env_hi, const void *data);
+	/* optional: several fields through ONE transfer (mjb_get_packed / mjb_set_packed): block = field after field, [env][dim] each */
+	int (*get_packed)(void *self, int n, const int *fields, int env_lo, int env_hi, double *host_block);
+	int (*set_packed)(void *self, int n, const int *fields, int env_lo, int env_hi, const double *host_block);
 } mjr_backend;
 
 enum {

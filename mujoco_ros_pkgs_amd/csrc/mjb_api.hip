@@ -114,6 +114,8 @@ struct mjb_batch {
 	double *sens_mean_dev = nullptr, *sens_sigma_dev = nullptr;
 	float *sens_value = nullptr, *sens_truth = nullptr;
 	bool sens_dirty = true, sens_packed = false;
+	double *pack_dev = nullptr;          // staging block of mjb_get_packed / mjb_set_packed
+	size_t pack_cap = 0;
 	double *env_geom_size = nullptr;
 	int *env_geom_type = nullptr;
 	double *env_gravity = nullptr, *env_geom_friction = nullptr, *env_equality = nullptr, *env_mass = nullptr;  // per-env model parameter overrides (mjb_set_env_*)
@@ -1023,6 +1025,7 @@ void mjb_free_batch(mjb_batch *b)
 	if (b->st.nwarn) hipFree(b->st.nwarn);
 	if (b->st.pgs_B) hipFree(b->st.pgs_B);
 	if (b->st.efc_Jg) hipFree(b->st.efc_Jg);
+	if (b->pack_dev) hipFree(b->pack_dev);
 	if (b->st.sched) hipFree(b->st.sched);
 	if (b->metrics_dev) hipFree(b->metrics_dev);
 	if (b->st.prof) hipFree(b->st.prof);
@@ -1608,6 +1611,107 @@ int mjb_set_many(mjb_batch *b, int n, const int *fields, int env_lo, int env_hi,
 		return fail(MJB_ENODEVICE, "mjb_set_many: %s", hipGetErrorString(err));
 	}
 	return MJB_OK;
+}
+
+// ---- several fields in ONE transfer --------------------------------------------------------------------------------------
+// A callback round of the host runtime moves ~25 fields of the callback envs to the host and ~8 back (mujoco_env.cpp stepBurst);
+// one hipMemcpy(2D)Async per field is ~8 us of driver time each, 350 us per split step against ~50 us of kernels
+// (profiles/r02_callback_path.txt).  Here a small kernel gathers the fields into one device block laid out field after field
+// ([env][dim] each, in the order given) and ONE copy moves the block; the reverse for the writes.
+namespace {
+struct PackDesc {
+	double *src;       // env-major source: state array, or the frame workspace + the field's offset
+	long long stride;  // doubles from one env to the next in the source
+	int dim;           // doubles per env
+	long long dst;     // offset of the field's block inside the packed block
+};
+struct PackArgs {
+	PackDesc d[40];
+	int n, nenv;
+};
+__global__ void mjb_pack_kernel(PackArgs a, double *block, int env_lo, int unpack)
+{
+	const int f = blockIdx.y;
+	if (f >= a.n) return;
+	const PackDesc d = a.d[f];
+	const long long total = (long long)a.nenv * d.dim;
+	for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+		const long long e = t / d.dim, k = t - e * d.dim;
+		double *s = d.src + (env_lo + e) * d.stride + k;
+		if (unpack) *s = block[d.dst + t];
+		else block[d.dst + t] = *s;
+	}
+}
+}  // namespace
+
+static int packed_transfer(mjb_batch *b, int n, const int *fields, int env_lo, int env_hi, double *host_block, bool to_host, const char *who)
+{
+	if (!b || n < 0 || n > 40 || (n && (!fields || !host_block))) return fail(MJB_EINVAL, "%s: bad argument (at most 40 fields)", who);
+	HIP_TRY(hipSetDevice(b->device));
+	PackArgs a{};
+	long long total = 0;
+	int maxdim = 1;
+	for (int k = 0; k < n; k++) {
+		const int field = fields[k];
+		int rc = check_range(b, field, env_lo, env_hi);
+		if (rc) return rc;
+		if (kFields[field].kind == 3) return fail(MJB_EINVAL, "%s: field %s is an int field", who, kFields[field].name);
+		const int sz = b->model->field_size[field];
+		PackDesc &d = a.d[a.n];
+		if (kFields[field].kind == 0) {
+			d.src = state_ptr(b, field);
+			d.stride = sz;
+		} else {
+			if (!to_host && field != MJB_F_qfrc_passive)
+				return fail(MJB_EINVAL, "field %s is derived and cannot be set (only state fields and qfrc_passive can)", kFields[field].name);
+			if (!b->frame_valid || !b->st.frame_ws)
+				return fail(MJB_EINVAL, "derived field %s is only accessible after mjb_forward / mjb_step1 / mjb_step2", kFields[field].name);
+			d.src = b->st.frame_ws + frame_offset(b, field);
+			d.stride = b->st.frame_stride;
+		}
+		d.dim = sz;
+		d.dst = total;
+		total += (long long)(env_hi - env_lo) * sz;
+		if (sz > 0) a.n++;
+		if (sz > maxdim) maxdim = sz;
+		if (!to_host && field == MJB_F_xfrc_applied && !b->st.use_xfrc) {
+			b->st.use_xfrc = 1;
+			b->params_dirty = true;
+		}
+	}
+	if (total == 0 || env_lo == env_hi) return MJB_OK;
+	a.nenv = env_hi - env_lo;
+	if ((long long)b->pack_cap < total) {
+		if (b->pack_dev) hipFree(b->pack_dev);
+		b->pack_dev = dev_alloc<double>((size_t)total);
+		if (!b->pack_dev) {
+			b->pack_cap = 0;
+			return fail(MJB_ENOMEM, "%s: staging allocation failed", who);
+		}
+		b->pack_cap = (size_t)total;
+	}
+	const int threads = 256;
+	int bx = (int)std::min<long long>(((long long)a.nenv * maxdim + threads - 1) / threads, 64);
+	if (bx < 1) bx = 1;
+	if (!to_host)
+		HIP_TRY(hipMemcpyAsync(b->pack_dev, host_block, (size_t)total * sizeof(double), hipMemcpyHostToDevice, b->stream));
+	hipLaunchKernelGGL(mjb_pack_kernel, dim3(bx, a.n), dim3(threads), 0, b->stream, a, b->pack_dev, env_lo, to_host ? 0 : 1);
+	HIP_TRY(hipGetLastError());
+	if (to_host) {
+		HIP_TRY(hipMemcpyAsync(host_block, b->pack_dev, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+		HIP_TRY(hipStreamSynchronize(b->stream));
+	}
+	return MJB_OK;
+}
+
+int mjb_get_packed(mjb_batch *b, int n, const int *fields, int env_lo, int env_hi, double *host_block)
+{
+	return packed_transfer(b, n, fields, env_lo, env_hi, host_block, true, "mjb_get_packed");
+}
+
+int mjb_set_packed(mjb_batch *b, int n, const int *fields, int env_lo, int env_hi, const double *host_block)
+{
+	return packed_transfer(b, n, fields, env_lo, env_hi, const_cast<double *>(host_block), false, "mjb_set_packed");
 }
 
 int mjb_host_register(void *host, unsigned long long bytes)

@@ -50,6 +50,8 @@ int be_set_env_param(void *s, int what, int lo, int hi, const void *data)
 	default: return -1;
 	}
 }
+int be_get_packed(void *s, int n, const int *f, int lo, int hi, double *h) { return mjb_get_packed(B(s)->batch, n, f, lo, hi, h); }
+int be_set_packed(void *s, int n, const int *f, int lo, int hi, const double *h) { return mjb_set_packed(B(s)->batch, n, f, lo, hi, h); }
 const char *be_err(void *) { return mjb_last_error(); }
 void be_destroy(void *s)
 {
@@ -216,7 +218,7 @@ mjr_backend *sharded_factory(const mjb_model_desc *desc, int nenv, int, void *us
 	sh->stride[MJR_ENV_BODY_MASS] = (size_t)desc->nbody * sizeof(double);
 	sh->vt = mjr_backend{ sh, sh_nenv, sh_field_size, sh_step, sh_step1, sh_step2, sh_forward, sh_reset, sh_get, sh_set, sh_noise,
 		                  sh_sync, sh_err, sh_destroy, sh_get_many, sh_set_many, sh_host_register, sh_host_unregister, sh_step_async,
-		                  sh_register_collision, sh_set_env_param };
+		                  sh_register_collision, sh_set_env_param, nullptr, nullptr };
 	return &sh->vt;
 }
 
@@ -249,7 +251,7 @@ mjr_backend *mjr_make_mjb_backend(const mjb_model_desc *desc, int nenv, int devi
 	}
 	b->vt = mjr_backend{ b, be_nenv, be_field_size, be_step, be_step1, be_step2, be_forward, be_reset, be_get, be_set,
 		                 be_noise, be_sync, be_err, be_destroy, be_get_many, be_set_many, be_host_register, be_host_unregister,
-		                 be_step_async, be_register_collision, be_set_env_param };
+		                 be_step_async, be_register_collision, be_set_env_param, be_get_packed, be_set_packed };
 	return &b->vt;
 }
 

@@ -326,6 +326,38 @@ void MujocoEnv::loadPlugins()
 }
 
 // ------------------------------------------------------------------------------------ host <-> device views
+// One transfer for all of `fields` of envs [lo, hi) when the backend offers it and the block is small (a latency-bound round:
+// per-field copies cost ~8 us of driver time each; beyond kPackedMaxBytes the copies are bandwidth-bound and the extra host-side
+// scatter would only add to them).  false = not taken, the caller falls back to one copy per field.
+bool MujocoEnv::transferPacked(const std::vector<int> &fields, int lo, int hi, bool to_host)
+{
+	const size_t kPackedMaxBytes = 4u << 20;
+	if ((to_host ? backend_->get_packed == nullptr : backend_->set_packed == nullptr) || fields.size() < 3 || fields.size() > 40 || hi <= lo) return false;
+	size_t total = 0;
+	for (int f : fields) total += (size_t)(hi - lo) * std::max(0, backend_->field_size(backend_->self, f));
+	if (total == 0 || total * sizeof(double) > kPackedMaxBytes) return false;
+	if (pack_host_.size() < kPackedMaxBytes / sizeof(double)) {
+		pack_host_.assign(kPackedMaxBytes / sizeof(double), 0.0);
+		if (backend_->host_register && backend_->host_register(backend_->self, pack_host_.data(), kPackedMaxBytes) == 0) pinned_.push_back(pack_host_.data());
+	}
+	size_t off = 0;
+	if (!to_host) {
+		for (int f : fields) {
+			const size_t sz = (size_t)std::max(0, backend_->field_size(backend_->self, f)), nb = (size_t)(hi - lo) * sz;
+			if (nb) std::memcpy(pack_host_.data() + off, host_fields_[f].data() + (size_t)lo * sz, nb * sizeof(double));
+			off += nb;
+		}
+		return backend_->set_packed(backend_->self, (int)fields.size(), fields.data(), lo, hi, pack_host_.data()) == 0;
+	}
+	if (backend_->get_packed(backend_->self, (int)fields.size(), fields.data(), lo, hi, pack_host_.data()) != 0) return false;
+	for (int f : fields) {
+		const size_t sz = (size_t)std::max(0, backend_->field_size(backend_->self, f)), nb = (size_t)(hi - lo) * sz;
+		if (nb) std::memcpy(host_fields_[f].data() + (size_t)lo * sz, pack_host_.data() + off, nb * sizeof(double));
+		off += nb;
+	}
+	return true;
+}
+
 void MujocoEnv::pullFields(const int *fields, int n, int lo, int hi)
 {
 	std::vector<int> fl;
@@ -335,6 +367,10 @@ void MujocoEnv::pullFields(const int *fields, int n, int lo, int hi)
 		if (sz <= 0) continue;
 		fl.push_back(f);
 		ptr.push_back(host_fields_[f].data() + (size_t)lo * sz);
+	}
+	if (transferPacked(fl, lo, hi, true)) {
+		for (int e = lo; e < hi; e++) views_[e].time = host_fields_[MJB_F_time][e];
+		return;
 	}
 	int rc = 0;
 	if (backend_->get_many) {
@@ -354,7 +390,7 @@ void MujocoEnv::pullViews(int lo, int hi, bool derived)
 	pullFields(fl.data(), (int)fl.size(), lo, hi);
 }
 
-void MujocoEnv::pushViews(int lo, int hi)
+void MujocoEnv::pushViews(int lo, int hi, bool with_passive)
 {
 	if (!backend_ || hi <= lo) return;
 	std::vector<int> fl;
@@ -372,6 +408,11 @@ void MujocoEnv::pushViews(int lo, int hi)
 		fl.push_back(f);
 		ptr.push_back(host_fields_[f].data() + (size_t)lo * n);
 	}
+	if (with_passive && backend_->field_size(backend_->self, MJB_F_qfrc_passive) > 0) {  // (between step1 and step2 only)
+		fl.push_back(MJB_F_qfrc_passive);
+		ptr.push_back(host_fields_[MJB_F_qfrc_passive].data() + (size_t)lo * backend_->field_size(backend_->self, MJB_F_qfrc_passive));
+	}
+	if (transferPacked(fl, lo, hi, false)) return;
 	if (backend_->set_many) {
 		backend_->set_many(backend_->self, (int)fl.size(), fl.data(), lo, hi, ptr.data());
 	} else {
@@ -484,11 +525,7 @@ int MujocoEnv::stepBurst(int n, bool count_requests)
 			runPassiveCbs();
 			runControlCbs();
 		}
-		pushViews(0, ncb);
-		{
-			const int np = backend_->field_size(backend_->self, MJB_F_qfrc_passive);
-			if (np > 0) backend_->set(backend_->self, MJB_F_qfrc_passive, 0, ncb, host_fields_[MJB_F_qfrc_passive].data());
-		}
+		pushViews(0, ncb, true);  // the writable state fields + qfrc_passive (what mjcb_passive adds to), one transfer when small
 		if (backend_->step2(backend_->self) != 0) break;
 		pullViews(0, ncb, false);
 		publishSimTime(views_[0].time);

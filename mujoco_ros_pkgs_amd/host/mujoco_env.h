@@ -203,7 +203,7 @@ protected:
 	void pullViews(int lo, int hi, bool derived);
 	void pullFields(const int *fields, int n, int lo, int hi);
 	void unpinMirrors();
-	void pushViews(int lo, int hi);
+	void pushViews(int lo, int hi, bool with_passive = false);
 	void bindView(int env, mjData &d);
 
 	// queued model
@@ -237,6 +237,10 @@ protected:
 	bool cb_all_fields_ = true;
 	std::vector<int> cb_fields_;       // state fields to mirror after a step when cb_all_fields_ is false
 	std::vector<void *> pinned_;       // host mirrors page-locked through the backend
+	// small callback rounds move their fields through ONE packed transfer each way (mjr_backend::get_packed / set_packed): the
+	// page-locked block they land in, scattered into / gathered from the per-field mirrors on the host
+	std::vector<double> pack_host_;
+	bool transferPacked(const std::vector<int> &fields, int lo, int hi, bool to_host);
 	std::vector<double> init_qpos_, init_qvel_, init_qfrc_;
 
 	// per-env mirrors of the model parameters the services change (allocated on first use; [env][...], initialised from the model)

@@ -26,7 +26,15 @@ bool MujocoRosSensorsPlugin::load(const mjModel *m, mjData * /*d*/)
 	if (rosparam_config_.hasMember("seed")) rand_generator_.seed((unsigned int)rosparam_config_["seed"].asInt());
 	else rand_generator_.seed(std::random_device{}());  // as the reference (mujoco_sensor_handler_plugin.h:94)
 	initSensors(m);
-	records_.assign(env_ptr_ ? (size_t)env_ptr_->nenv() : 1, std::vector<SensorRecord>());
+	model_ = m;
+	const size_t n = env_ptr_ ? (size_t)env_ptr_->nenv() : 1;
+	records_.assign(n, std::vector<SensorRecord>());
+	pending_.assign(n, Pending());
+	sensor_cfg_.assign((size_t)m->nsensor, nullptr);
+	for (int k = 0; k < m->nsensor; k++) {
+		auto it = sensor_map_.find(nameOf(m->sensor_names, k));
+		if (it != sensor_map_.end() && !it->first.empty()) sensor_cfg_[k] = &it->second;
+	}
 	return true;
 }
 
@@ -117,31 +125,51 @@ bool MujocoRosSensorsPlugin::registerNoiseModel(const std::string &sensor_name, 
 const std::vector<SensorRecord> &MujocoRosSensorsPlugin::records(int env) const
 {
 	static const std::vector<SensorRecord> none;
-	return (env >= 0 && env < (int)records_.size()) ? records_[env] : none;
+	if (env < 0 || env >= (int)records_.size()) return none;
+	if (env_ptr_) {  // the mirrors are written by the physics thread between steps
+		std::lock_guard<MujocoEnvMutex> lock(env_ptr_->physics_thread_mutex_);
+		if (pending_[env].stale) build(env);
+	} else if (pending_[env].stale) build(env);
+	return records_[env];
 }
 
-void MujocoRosSensorsPlugin::lastStageCallback(const mjModel *model, mjData *data)
+// lastStageCallback (:175-437): per env and step, O(1) -- the messages are produced by build() when somebody reads them
+void MujocoRosSensorsPlugin::lastStageCallback(const mjModel * /*model*/, mjData *data)
 {
 	const int env = data->env_id;
 	if (env < 0) return;
-	if (env >= (int)records_.size()) records_.resize((size_t)env + 1);
+	if (env >= (int)pending_.size()) {
+		pending_.resize((size_t)env + 1);
+		records_.resize((size_t)env + 1);
+	}
+	Pending &p = pending_[env];
+	p.sensordata = data->sensordata;
+	p.stamp = data->time;
+	p.stale = true;
+}
+
+void MujocoRosSensorsPlugin::build(int env) const
+{
+	const mjModel *model = model_;
+	Pending &p = pending_[env];
+	p.stale = false;
 	std::vector<SensorRecord> &out = records_[env];
 	out.clear();
+	if (!model || !p.sensordata) return;
 	for (int n = 0; n < model->nsensor; n++) {
+		const SensorConfig *cfgp = n < (int)sensor_cfg_.size() ? sensor_cfg_[n] : nullptr;
+		if (!cfgp) continue;
+		const SensorConfig &config = *cfgp;
 		const std::string &sensor_name = nameOf(model->sensor_names, n);
-		if (sensor_name.empty()) continue;
-		auto it = sensor_map_.find(sensor_name);
-		if (it == sensor_map_.end()) continue;
-		SensorConfig &config = it->second;
 		const int adr = model->sensor_adr[n];
 		const double cutoff = model->sensor_cutoff[n] > 0 ? model->sensor_cutoff[n] : 1;
-		const double *sd = data->sensordata + adr;
+		const double *sd = p.sensordata + adr;
 		SensorRecord rec;
 		rec.name = sensor_name;
 		rec.frame_id = config.frame_id;
 		rec.kind = config.kind;
 		rec.env = env;
-		rec.stamp = data->time;
+		rec.stamp = p.stamp;
 		rec.has_truth = !eval_mode_;
 		const int dim = config.kind == SCALAR_STAMPED ? 1 : (config.kind == QUATERNION_STAMPED ? 4 : 3);
 		for (int k = 0; k < dim; k++) rec.truth[k] = static_cast<float>(sd[k] / cutoff);

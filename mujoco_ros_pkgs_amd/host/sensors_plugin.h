@@ -51,15 +51,27 @@ public:
 	bool registerNoiseModel(const std::string &sensor_name, unsigned char set_flag, const double *mean, const double *std,
 	                        const std::string &admin_hash);
 	const std::map<std::string, SensorConfig> &sensorMap() const { return sensor_map_; }
-	// records of the last lastStageCallback of every env, in sensor order
+	// records of the last lastStageCallback of every env, in sensor order.  They are BUILT HERE, on demand: lastStageCallback only
+	// notes that env's step (time stamp + where its sensordata mirror lives) -- building 4096 x nsensor typed records every step
+	// for nobody was the whole cost of the plugin on a batch (1.9 M env-steps/s, profiles/r02_callback_path.txt); the noise of a
+	// record is drawn when it is built, once per step and env at most.
 	const std::vector<SensorRecord> &records(int env) const;
 
 private:
 	void initSensors(const mjModel *model);
+	void build(int env) const;
 	std::map<std::string, SensorConfig> sensor_map_;
-	std::vector<std::vector<SensorRecord>> records_;
-	std::mt19937 rand_generator_;
-	std::normal_distribution<double> noise_dist_{ 0.0, 1.0 };
+	struct Pending {
+		const double *sensordata = nullptr;  // the env's host mirror (valid until the next reload)
+		double stamp = 0;
+		bool stale = false;
+	};
+	mutable std::vector<Pending> pending_;
+	mutable std::vector<std::vector<SensorRecord>> records_;
+	const mjModel *model_ = nullptr;
+	std::vector<const SensorConfig *> sensor_cfg_;  // per sensor id: its config or nullptr (resolved once: no map lookup per step)
+	mutable std::mt19937 rand_generator_;
+	mutable std::normal_distribution<double> noise_dist_{ 0.0, 1.0 };
 	bool eval_mode_ = false;
 };
 
