@@ -108,6 +108,18 @@ struct Env {
 	                   // misaligns their 16-byte scratch accesses -- measured 2 % on config 2.)
 };
 
+// What the OUT-OF-LINE stages (rne_post, reset_frame_state, energy, hwsim_write) get, by value: handing them `const Env &` made the
+// whole Env -- dadr[16], the LaneConst block -- escape to memory, i.e. a private (scratch) segment in every kernel and a store of
+// each member at kernel entry.
+struct EnvLite {
+	double *f;
+	int *fi;
+	LaneId lane;
+	int env;
+	const double *mp;
+};
+DEVI EnvLite lite(const Env &e) { return EnvLite{ e.f, e.fi, e.lane, e.env, e.mp }; }
+
 // per-env inertial constants (what mj_setConst derives from the masses): the env's own block in HBM when the batch carries
 // overrides (mjb_set_env_mass_params; the dense kernels are not used then), else the model's tables
 #define MP_BODY_MASS(m, e, i) ((e).mp ? (e).mp[(i)] : (m).body_mass[(i)])
@@ -1211,7 +1223,7 @@ DEVI void move_force(double *res, const double *vec, const double *newpos, const
 // sums like rne: lane = contact (world wrench), lane = body (cacc, own force), lane = body (subtree sum).
 // ------------------------------------------------------------------------------------------------
 // (rarely used: kept out of line so that it costs the common kernels neither registers nor instruction-cache lines)
-template <int G> __device__ __attribute__((noinline)) void rne_post(CModel m, CLayout L, const Env &e, bool use_xfrc)
+template <int G> __device__ __attribute__((noinline)) void rne_post(CModel m, CLayout L, const EnvLite e, bool use_xfrc)
 {
 	double *f = e.f;
 	int *fi = e.fi;
@@ -1723,7 +1735,7 @@ template <int G> DEVI int any_bad(const Env &e, CLayout L, const double *a, int 
 	return *flag;
 }
 
-template <int G> __device__ __attribute__((noinline)) void reset_frame_state(CModel m, CLayout L, CState s, const Env &e, int warning)
+template <int G> __device__ __attribute__((noinline)) void reset_frame_state(CModel m, CLayout L, CState s, const EnvLite e, int warning)
 {
 	double *f = e.f;
 	for (int k = e.lane; k < L.nstate; k += G) f[k] = 0;  // state prefix starts at offset 0
@@ -1883,7 +1895,7 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 		VIEW(P, compact, fwd_constraint<G>(m, L, e));
 	}
 	PROF(11);
-	VIEW(P, compact, if (m.need_rnepost) rne_post<G>(m, L, e, s.use_xfrc != 0));
+	VIEW(P, compact, if (m.need_rnepost) rne_post<G>(m, L, lite(e), s.use_xfrc != 0));
 	VIEW(P, compact, sensors<G>(m, L, e, MJB_STAGE_ACC, compact));
 	PROF(12);
 }
@@ -1954,7 +1966,7 @@ DEVI double angdist_with_limits(double from, double to, double left, double righ
 // mj_energyPos / mj_energyVel (mjENBL_ENERGY): potential = -sum m g.xipos + joint / tendon spring energy, kinetic =
 // 0.5 qvel' M qvel.  Evaluated for the LAST step of a launch only (intermediate values are not observable), by one lane:
 // a few hundred dependent LDS reads once per launch.
-template <int G> __device__ __attribute__((noinline)) void energy(CModel m, CLayout L, const Env &e)
+template <int G> __device__ __attribute__((noinline)) void energy(CModel m, CLayout L, const EnvLite e)
 {
 	double *f = e.f;
 	if (e.lane == 0) {
@@ -2004,7 +2016,7 @@ template <int G> __device__ __attribute__((noinline)) void energy(CModel m, CLay
 }
 
 // device-side DefaultRobotHWSim::writeSim (include/mjb.h, mjb_hwsim_*): lane = controlled joint
-template <int G> __device__ __attribute__((noinline)) void hwsim_write(CModel m, CLayout L, const HwSim MJB_AS4 &hw, const Env &e)
+template <int G> __device__ __attribute__((noinline)) void hwsim_write(CModel m, CLayout L, const HwSim MJB_AS4 &hw, const EnvLite e)
 {
 	double *f = e.f;
 	const double dt = m.timestep[0];
@@ -2240,18 +2252,18 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 				if (do_first || attempt) {
 					if (attempt == 0 && checks) {
 						const int bad = any_bad<G>(e, L, e.f + L.qpos, m.nq, e.f + L.qvel, m.nv);
-						if (bad) reset_frame_state<G>(m, L, s, e, bad == 1 ? MJB_WARN_BADQPOS : MJB_WARN_BADQVEL);
+						if (bad) reset_frame_state<G>(m, L, s, lite(e), bad == 1 ? MJB_WARN_BADQPOS : MJB_WARN_BADQVEL);
 					}
 					forward_first<G, CON, DENSE>(P, e, compact);
-					if (st0 + st == (mode == MJB_MODE_STEP ? nsteps : 1) - 1 && P->m.enableflags & MJB_ENBL_ENERGY) VIEW(P, compact, energy<G>(m, L, e));
+					if (st0 + st == (mode == MJB_MODE_STEP ? nsteps : 1) - 1 && P->m.enableflags & MJB_ENBL_ENERGY) VIEW(P, compact, energy<G>(m, L, lite(e)));
 				}
 				if (!do_rest) break;
 				// device-side DefaultRobotHWSim::writeSim runs where the reference's control callback fires: after the position
 				// and velocity stages, before actuation (mjcb_control inside mj_forward; mujoco_ros_control_plugin.cpp:153-194)
-				if (hw_on) VIEW(P, compact, hwsim_write<G>(m, L, Pq_->hw, e));
+				if (hw_on) VIEW(P, compact, hwsim_write<G>(m, L, Pq_->hw, lite(e)));
 				forward_rest<G, CON, DENSE>(P, e, compact);
 				if (attempt || !checks || !any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0)) break;
-				reset_frame_state<G>(m, L, s, e, MJB_WARN_BADQACC);
+				reset_frame_state<G>(m, L, s, lite(e), MJB_WARN_BADQACC);
 			}
 			PROF(14);  // whole forward (incl. checks)
 			if (do_euler) VIEW(P, compact, euler<G, (CON != 0), (CON >= 2 && CON <= 4)>(m, L, e));
