@@ -155,6 +155,15 @@ int mjb_step(mjb_batch *b, int nsteps);
  * integration).  step1+step2 == one mjb_step(b,1). */
 int mjb_step1(mjb_batch *b);
 int mjb_step2(mjb_batch *b);
+/* The split for a PREFIX of the batch only -- the envs that have host callbacks (MujocoEnv's callback set): envs [0, ncb) are
+ * stepped in two halves around the control-callback point, envs [ncb, nenv) take the same step as ONE fused launch.  Every env's
+ * arithmetic is independent of the launch that carries it (same Philox key, same kernels): the result equals a whole-batch step.
+ * One step = mjb_step1_prefix(ncb) -> copy the callback envs' fields out -> mjb_step_rest(ncb) [asynchronous: it runs while the
+ * host callbacks do] -> copy their writes back -> mjb_step2_prefix(ncb) [advances the step counter; issues the rest itself if
+ * the caller skipped mjb_step_rest].  Derived fields are readable for envs [0, ncb) only between the two halves. */
+int mjb_step1_prefix(mjb_batch *b, int ncb);
+int mjb_step_rest(mjb_batch *b, int ncb);
+int mjb_step2_prefix(mjb_batch *b, int ncb);
 
 /* Recompute all derived quantities without integrating (mj_forward: mujoco_env.cpp:329, :621;
  * callbacks.cpp:573) and leave the full frame in the HBM workspace for mjb_get. */

@@ -48,6 +48,11 @@ typedef struct mjr_backend {
 	/* optional: several fields through ONE transfer (mjb_get_packed / mjb_set_packed): block = field after field, [env][dim] each */
 	int (*get_packed)(void *self, int n, const int *fields, int env_lo, int env_hi, double *host_block);
 	int (*set_packed)(void *self, int n, const int *fields, int env_lo, int env_hi, const double *host_block);
+	/* optional: the split step for the callback envs [0, ncb) only, the rest taking the same step fused (mjb_step1_prefix /
+	 * mjb_step_rest / mjb_step2_prefix); NULL: every env is split (step1 / step2) */
+	int (*step1_prefix)(void *self, int ncb);
+	int (*step_rest)(void *self, int ncb);
+	int (*step2_prefix)(void *self, int ncb);
 } mjr_backend;
 
 enum {

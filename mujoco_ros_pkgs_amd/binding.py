@@ -155,6 +155,9 @@ def load_library(path=None):
         "mjb_set_env_equality": (ci, [vp, ci, ci, C.POINTER(cd)]),
         "mjb_env_mass_stride": (ci, [vp]),
         "mjb_set_env_mass_params": (ci, [vp, ci, ci, C.POINTER(cd)]),
+        "mjb_step1_prefix": (ci, [vp, ci]),
+        "mjb_step_rest": (ci, [vp, ci]),
+        "mjb_step2_prefix": (ci, [vp, ci]),
         "mjb_get_packed": (ci, [vp, ci, C.POINTER(ci), ci, ci, C.POINTER(cd)]),
         "mjb_set_packed": (ci, [vp, ci, C.POINTER(ci), ci, ci, C.POINTER(cd)]),
         "mjb_derive_mass_params": (ci, [vp, C.POINTER(cd), C.POINTER(cd), C.POINTER(cd)]),

@@ -101,6 +101,9 @@ struct mjb_batch {
 	int lanes = 0, epb = 0;
 	unsigned int step_counter = 0;
 	bool frame_valid = false;
+	int frame_hi = 0;             // the frame workspace is current for envs [0, frame_hi) (a prefix after mjb_step1_prefix)
+	int split_ncb = -1;           // inside a split step of this prefix (mjb_step1_prefix .. mjb_step2_prefix)
+	bool split_rest_done = false;
 	unsigned char *mask_dev = nullptr;
 	KernelParams *params_dev = nullptr;  // device copy of {dm, L, st, nz}
 	double *metrics_dev = nullptr;       // [16] mjb_metrics
@@ -1294,8 +1297,10 @@ static int kernel_variant(const mjb_model_desc &h)
 	return (h.solver == MJB_SOL_CG ? 4 : 0) + (h.nefcmax <= 64 ? 2 : (h.nefcmax <= 128 ? 3 : 4));
 }
 
-static int launch(mjb_batch *b, int mode, int nsteps)
+static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi = -1)
 {
+	if (env_hi < 0) env_hi = b->nenv;
+	const bool whole = env_lo == 0 && env_hi == b->nenv;
 	HIP_TRY(hipSetDevice(b->device));
 	int prc = sync_params(b);
 	if (prc) return prc;
@@ -1309,7 +1314,7 @@ static int launch(mjb_batch *b, int mode, int nsteps)
 	}
 	// long fused launches of the constrained kernels hand out (chunk of steps, env) work items dynamically (mjb_step.hip)
 	int chunk = 0;
-	if (mode == MJB_MODE_STEP && variant != 0 && nsteps >= 100 && b->st.sched) {
+	if (mode == MJB_MODE_STEP && variant != 0 && nsteps >= 100 && b->st.sched && whole) {
 		static const bool off = [] { const char *v = getenv("MJB_DEBUG_NO_CHUNKS"); return v && *v && *v != '0'; }();  // measurement knob
 		if (!off) {
 			static const int forced = [] { const char *v = getenv("MJB_DEBUG_CHUNK"); return v ? atoi(v) : 0; }();
@@ -1317,7 +1322,7 @@ static int launch(mjb_batch *b, int mode, int nsteps)
 			HIP_TRY(hipMemsetAsync(b->st.sched, 0, ((size_t)b->nenv + 1) * sizeof(int), b->stream));
 		}
 	}
-	int rc = mjb_launch_step(b->params_dev, compact ? b->model->Lc : b->L, b->nenv, mode, nsteps, b->step_counter, b->lanes,
+	int rc = mjb_launch_step(b->params_dev, compact ? b->model->Lc : b->L, env_lo, env_hi, mode, nsteps, b->step_counter, b->lanes,
 	                         b->epb, variant | (chunk << 8), (b->lanes == 16 && !b->env_mass && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, b->stream);
 	if (rc != 0) return fail(MJB_ENODEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
 	return MJB_OK;
@@ -1332,6 +1337,7 @@ int mjb_step(mjb_batch *b, int nsteps)
 		b->step_counter += (unsigned int)nsteps;
 		b->steps_taken += (unsigned long long)nsteps;
 		b->frame_valid = b->st.keep_frame != 0;
+		b->frame_hi = b->nenv;
 	}
 	return rc;
 }
@@ -1357,18 +1363,69 @@ int mjb_step1(mjb_batch *b)
 	int rc = ensure_ws(b);
 	if (rc) return rc;
 	rc = launch(b, MJB_MODE_STEP1, 1);
-	if (rc == MJB_OK) b->frame_valid = true;
+	if (rc == MJB_OK) {
+		b->frame_valid = true;
+		b->frame_hi = b->nenv;
+	}
 	return rc;
 }
 
 int mjb_step2(mjb_batch *b)
 {
 	if (!b) return fail(MJB_EINVAL, "null batch");
-	if (!b->frame_valid || !b->st.frame_ws) return fail(MJB_EINVAL, "mjb_step2 without a preceding mjb_step1");
+	if (!b->frame_valid || !b->st.frame_ws || b->frame_hi < b->nenv) return fail(MJB_EINVAL, "mjb_step2 without a preceding mjb_step1");
 	int rc = launch(b, MJB_MODE_STEP2, 1);
 	if (rc == MJB_OK) {
 		b->step_counter += 1;
 		b->steps_taken += 1;
+	}
+	return rc;
+}
+
+// ---- split step for a PREFIX of the batch (the host runtime's callback envs): envs [0, ncb) are stepped in two halves around
+// the control-callback point, envs [ncb, nenv) take the SAME step as one fused launch (same Philox step counter, same results as
+// a whole-batch launch: every env's arithmetic is independent of which launch carries it).  Order of calls for one step:
+//   mjb_step1_prefix(ncb) -> [copy the callback envs' fields out] -> mjb_step_rest(ncb) -> [host callbacks run while it executes]
+//   -> [copy their writes back] -> mjb_step2_prefix(ncb)   (advances the step counter)
+int mjb_step1_prefix(mjb_batch *b, int ncb)
+{
+	if (!b || ncb < 0 || ncb > b->nenv) return fail(MJB_EINVAL, "mjb_step1_prefix: bad argument");
+	int rc = ensure_ws(b);
+	if (rc) return rc;
+	b->split_ncb = ncb;
+	b->split_rest_done = false;
+	if (ncb == 0) return MJB_OK;
+	rc = launch(b, MJB_MODE_STEP1, 1, 0, ncb);
+	if (rc == MJB_OK) {
+		b->frame_valid = true;
+		b->frame_hi = ncb;
+	}
+	return rc;
+}
+
+int mjb_step_rest(mjb_batch *b, int ncb)
+{
+	if (!b || ncb != b->split_ncb) return fail(MJB_EINVAL, "mjb_step_rest: not inside a split step of this prefix (mjb_step1_prefix first)");
+	if (b->split_rest_done) return fail(MJB_EINVAL, "mjb_step_rest: called twice in one split step");
+	b->split_rest_done = true;
+	if (ncb >= b->nenv) return MJB_OK;
+	return launch(b, MJB_MODE_STEP, 1, ncb, b->nenv);
+}
+
+int mjb_step2_prefix(mjb_batch *b, int ncb)
+{
+	if (!b || ncb != b->split_ncb) return fail(MJB_EINVAL, "mjb_step2_prefix without the matching mjb_step1_prefix");
+	int rc = MJB_OK;
+	if (!b->split_rest_done) rc = mjb_step_rest(b, ncb);  // (a caller that skipped it: the rest must not miss the step)
+	if (rc != MJB_OK) return rc;
+	if (ncb > 0) {
+		if (!b->frame_valid || !b->st.frame_ws || b->frame_hi < ncb) return fail(MJB_EINVAL, "mjb_step2_prefix without a preceding mjb_step1_prefix");
+		rc = launch(b, MJB_MODE_STEP2, 1, 0, ncb);
+	}
+	if (rc == MJB_OK) {
+		b->step_counter += 1;
+		b->steps_taken += 1;
+		b->split_ncb = -1;
 	}
 	return rc;
 }
@@ -1379,7 +1436,10 @@ int mjb_forward(mjb_batch *b)
 	int rc = ensure_ws(b);
 	if (rc) return rc;
 	rc = launch(b, MJB_MODE_FORWARD, 1);
-	if (rc == MJB_OK) b->frame_valid = true;
+	if (rc == MJB_OK) {
+		b->frame_valid = true;
+		b->frame_hi = b->nenv;
+	}
 	return rc;
 }
 
@@ -1458,7 +1518,7 @@ int mjb_get(mjb_batch *b, int field, int env_lo, int env_hi, double *host)
 		                  hipMemcpyDeviceToHost));
 		return MJB_OK;
 	}
-	if (!b->frame_valid || !b->st.frame_ws)
+	if (!b->frame_valid || !b->st.frame_ws || env_hi > b->frame_hi)
 		return fail(MJB_EINVAL, "derived field %s is only readable after mjb_forward / mjb_step1 / mjb_step2",
 		            kFields[field].name);
 	const int off = frame_offset(b, field);
@@ -1476,7 +1536,7 @@ int mjb_get_int(mjb_batch *b, int field, int env_lo, int env_hi, int *host)
 	const int n = b->model->field_size[field];
 	if (n == 0 || env_lo == env_hi) return MJB_OK;
 	if (!host) return fail(MJB_EINVAL, "null host buffer");
-	if (!b->frame_valid || !b->st.frame_ws)
+	if (!b->frame_valid || !b->st.frame_ws || env_hi > b->frame_hi)
 		return fail(MJB_EINVAL, "int field %s is only readable after mjb_forward / mjb_step1 / mjb_step2",
 		            kFields[field].name);
 	HIP_TRY(hipSetDevice(b->device));
@@ -1510,7 +1570,7 @@ int mjb_set(mjb_batch *b, int field, int env_lo, int env_hi, const double *host)
 	if (field != MJB_F_qfrc_passive)
 		return fail(MJB_EINVAL, "field %s is derived and cannot be set (only state fields and qfrc_passive can)",
 		            kFields[field].name);
-	if (!b->frame_valid || !b->st.frame_ws)
+	if (!b->frame_valid || !b->st.frame_ws || env_hi > b->frame_hi)
 		return fail(MJB_EINVAL, "qfrc_passive can only be modified between mjb_step1 and mjb_step2");
 	const int off = frame_offset(b, field);
 	HIP_TRY(hipMemcpy2D(b->st.frame_ws + (size_t)env_lo * b->st.frame_stride + off,
@@ -1550,7 +1610,7 @@ int mjb_get_many(mjb_batch *b, int n, const int *fields, int env_lo, int env_hi,
 		if (kFields[field].kind == 3) return fail(MJB_EINVAL, "field %s is an int field; use mjb_get_int", kFields[field].name);
 		if (b->model->field_size[field] == 0 || env_lo == env_hi) continue;
 		if (!host[k]) return fail(MJB_EINVAL, "null host buffer");
-		if (kFields[field].kind != 0 && (!b->frame_valid || !b->st.frame_ws))
+		if (kFields[field].kind != 0 && (!b->frame_valid || !b->st.frame_ws || env_hi > b->frame_hi))
 			return fail(MJB_EINVAL, "derived field %s is only readable after mjb_forward / mjb_step1 / mjb_step2", kFields[field].name);
 	}
 	hipError_t err = hipSuccess;
@@ -1586,7 +1646,7 @@ int mjb_set_many(mjb_batch *b, int n, const int *fields, int env_lo, int env_hi,
 		if (kFields[field].kind != 0) {
 			if (field != MJB_F_qfrc_passive)
 				return fail(MJB_EINVAL, "field %s is derived and cannot be set (only state fields and qfrc_passive can)", kFields[field].name);
-			if (!b->frame_valid || !b->st.frame_ws) return fail(MJB_EINVAL, "qfrc_passive can only be modified between mjb_step1 and mjb_step2");
+			if (!b->frame_valid || !b->st.frame_ws || env_hi > b->frame_hi) return fail(MJB_EINVAL, "qfrc_passive can only be modified between mjb_step1 and mjb_step2");
 		}
 	}
 	hipError_t err = hipSuccess;
@@ -1664,7 +1724,7 @@ static int packed_transfer(mjb_batch *b, int n, const int *fields, int env_lo, i
 		} else {
 			if (!to_host && field != MJB_F_qfrc_passive)
 				return fail(MJB_EINVAL, "field %s is derived and cannot be set (only state fields and qfrc_passive can)", kFields[field].name);
-			if (!b->frame_valid || !b->st.frame_ws)
+			if (!b->frame_valid || !b->st.frame_ws || env_hi > b->frame_hi)
 				return fail(MJB_EINVAL, "derived field %s is only accessible after mjb_forward / mjb_step1 / mjb_step2", kFields[field].name);
 			d.src = b->st.frame_ws + frame_offset(b, field);
 			d.stride = b->st.frame_stride;

@@ -162,7 +162,8 @@ struct KernelParams {
 enum { MJB_MODE_STEP = 0, MJB_MODE_FORWARD = 1, MJB_MODE_STEP1 = 2, MJB_MODE_STEP2 = 3 };
 
 // launches (implemented in mjb_step.hip); returns hipError_t as int
-int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0,
+// (steps envs [env_lo, nenv): the whole batch, or a prefix / the rest for the split steps of the host runtime)
+int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int env_lo, int nenv, int mode, int nsteps, unsigned int step0,
                     int lanes_per_env, int envs_per_block, int constrained, int dense, void *stream);
 int mjb_launch_reset(const KernelParams *Pdev, int nenv, const unsigned char *mask_dev, void *stream);
 int mjb_max_lds_bytes();

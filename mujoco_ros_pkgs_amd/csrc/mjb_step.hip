@@ -1869,10 +1869,10 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 		// mjb_step2) holds all of J
 		VIEW(P, compact, {
 			const int ne = __builtin_amdgcn_readfirstlane(e.fi[L.nefc]);
-			if (L.jrows >= m.nefcmax) {
+			if (L.jrows >= m.nefcmax && ne > 64) {
 				MJB_KEEP_BRANCH();
 				fwd_constraint_newton<G, 4>(m, L, e);
-			} else if (ne <= L.jrows) {
+			} else if (ne <= L.jrows && ne <= 64) {  // (the full frame too: the same instantiation as the fused step's common case)
 				MJB_KEEP_BRANCH();
 				fwd_constraint_newton<G, 1>(m, L, e);
 			} else {
@@ -2113,8 +2113,10 @@ template <int G, int CON, int DENSE>
 #endif
 __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G == 64 ? 4 : (G == 32 ? 2 : 1)))))
     mjb_step_kernel(const KernelParams MJB_AS4 *__restrict__ P, const int mode, const int nsteps,
-                    const unsigned int step0, const int epb, const int frame_bytes, const int chunk)
+                    const unsigned int step0, const int epb, const int frame_bytes, const int chunk, const int env_lo, const int env_hi)
 {
+	// [env_lo, env_hi): the envs this launch steps (the whole batch, or -- split steps of the host runtime -- the callback envs /
+	// the rest; mjb_step1_prefix, mjb_step_rest, mjb_step2_prefix)
 	// launch parameters live in device memory behind a constant-address-space pointer: every field is
 	// fetched with a scalar load where it is used instead of pinning ~300 SGPRs for the whole kernel
 	const DevModel MJB_AS4 &m = P->m;
@@ -2177,10 +2179,10 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 	// earlier by a block that is running or done, so the wait cannot deadlock) and the state crosses HBM between chunks exactly
 	// as it does between launches.  An env's cost varies 2x around the mean and a CU holds few envs: with two envs per slot the
 	// slowest pair sets the launch time, with 2 * nchunk items per slot the slots even out (config 3: +7 %).
-	const bool dyn = CON != 0 && G == 64 && chunk > 0 && mode == MJB_MODE_STEP && s.sched != nullptr;
+	const bool dyn = CON != 0 && G == 64 && chunk > 0 && mode == MJB_MODE_STEP && s.sched != nullptr;  // (whole-batch launches only)
 	const int nchunk = dyn ? (nsteps + chunk - 1) / chunk : 1;
 	// (otherwise) grid-stride over env groups so any batch size runs with a bounded grid
-	for (int base = blockIdx.x * epb;; base += gridDim.x * epb) {
+	for (int base = env_lo + blockIdx.x * epb;; base += gridDim.x * epb) {
 		int item_chunk = 0;
 		if (dyn) {
 			int w = 0;
@@ -2196,11 +2198,11 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 				__threadfence();  // (the state the previous chunk stored is read through the vector cache)
 			}
 		} else {
-			if (base >= s.nenv) break;
+			if (base >= env_hi) break;
 			e.env = base + slot;
 		}
 		if constexpr (G == 64) e.env = __builtin_amdgcn_readfirstlane(e.env);  // (one env per wavefront: keep the index and everything derived from it scalar)
-		if (e.env >= s.nenv) continue;  // whole group idles together (group == slot)
+		if (e.env >= env_hi) continue;  // whole group idles together (group == slot)
 		if constexpr (DENSE == 0) e.mp = s.env_mass ? s.env_mass + (size_t)e.env * (7 * m.nbody + m.nv + m.ntendon + 1) : nullptr;
 		else e.mp = nullptr;  // (batches with per-env masses never run the dense kernels)
 		double *ws = s.frame_ws ? s.frame_ws + (size_t)e.env * s.frame_stride : nullptr;
@@ -2323,9 +2325,10 @@ __global__ void mjb_reset_kernel(const KernelParams MJB_AS4 *__restrict__ P, con
 }
 
 template <int G, int CON, int DENSE = 0>
-int launch_g(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0,
+int launch_g(const KernelParams *Pdev, const FrameLayout &L, int env_lo, int env_hi, int mode, int nsteps, unsigned int step0,
              int epb, void *stream, int chunk = 0)
 {
+	const int nenv = env_hi - env_lo;
 	const int frame_bytes = ((L.ndouble * 8 + L.nint * 4) + 15) & ~15;
 	const int maxlds = mjb_max_lds_bytes();
 	int threads = epb * G;
@@ -2351,7 +2354,7 @@ int launch_g(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode,
 	const int maxblocks = 256 * 16;
 	if (blocks > maxblocks) blocks = maxblocks;
 	hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, (hipStream_t)stream,
-	                   (const KernelParams MJB_AS4 *)Pdev, mode, nsteps, step0, epb, frame_bytes, CON != 0 ? chunk : 0);
+	                   (const KernelParams MJB_AS4 *)Pdev, mode, nsteps, step0, epb, frame_bytes, CON != 0 ? chunk : 0, env_lo, env_hi);
 	return (int)hipGetLastError();
 }
 
@@ -2366,45 +2369,45 @@ int launch_g(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode,
 #define MJB_GROUP -1
 #endif
 #define MJB_HAS_GROUP(g) (MJB_GROUP < 0 || MJB_GROUP == (g))
-int mjb_launch_group1(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk);
-int mjb_launch_group2(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk);
-int mjb_launch_group3(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk);
-int mjb_launch_group4(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk);
-int mjb_launch_group5(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk);
+int mjb_launch_group1(const KernelParams *Pdev, const FrameLayout &L, int env_lo, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk);
+int mjb_launch_group2(const KernelParams *Pdev, const FrameLayout &L, int env_lo, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk);
+int mjb_launch_group3(const KernelParams *Pdev, const FrameLayout &L, int env_lo, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk);
+int mjb_launch_group4(const KernelParams *Pdev, const FrameLayout &L, int env_lo, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk);
+int mjb_launch_group5(const KernelParams *Pdev, const FrameLayout &L, int env_lo, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk);
 
 #if !defined(MJB_DEV_ONLY_CON)
 #if MJB_HAS_GROUP(1)
-int mjb_launch_group1(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk)
+int mjb_launch_group1(const KernelParams *Pdev, const FrameLayout &L, int env_lo, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk)
 {
-	if (constrained == 5) return launch_g<64, 5>(Pdev, L, nenv, mode, nsteps, step0, epb, stream, chunk);
-	return launch_g<64, 1>(Pdev, L, nenv, mode, nsteps, step0, epb, stream, chunk);
+	if (constrained == 5) return launch_g<64, 5>(Pdev, L, env_lo, nenv, mode, nsteps, step0, epb, stream, chunk);
+	return launch_g<64, 1>(Pdev, L, env_lo, nenv, mode, nsteps, step0, epb, stream, chunk);
 }
 #endif
 #if MJB_HAS_GROUP(5)
-int mjb_launch_group5(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk)
+int mjb_launch_group5(const KernelParams *Pdev, const FrameLayout &L, int env_lo, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk)
 {
-	return launch_g<64, 9>(Pdev, L, nenv, mode, nsteps, step0, epb, stream, chunk);
+	return launch_g<64, 9>(Pdev, L, env_lo, nenv, mode, nsteps, step0, epb, stream, chunk);
 }
 #endif
 #if MJB_HAS_GROUP(2)
-int mjb_launch_group2(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk)
+int mjb_launch_group2(const KernelParams *Pdev, const FrameLayout &L, int env_lo, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk)
 {
-	if (constrained == 3) return launch_g<64, 3>(Pdev, L, nenv, mode, nsteps, step0, epb, stream, chunk);
-	return launch_g<64, 2>(Pdev, L, nenv, mode, nsteps, step0, epb, stream, chunk);
+	if (constrained == 3) return launch_g<64, 3>(Pdev, L, env_lo, nenv, mode, nsteps, step0, epb, stream, chunk);
+	return launch_g<64, 2>(Pdev, L, env_lo, nenv, mode, nsteps, step0, epb, stream, chunk);
 }
 #endif
 #if MJB_HAS_GROUP(3)
-int mjb_launch_group3(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk)
+int mjb_launch_group3(const KernelParams *Pdev, const FrameLayout &L, int env_lo, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk)
 {
-	return launch_g<64, 4>(Pdev, L, nenv, mode, nsteps, step0, epb, stream, chunk);
+	return launch_g<64, 4>(Pdev, L, env_lo, nenv, mode, nsteps, step0, epb, stream, chunk);
 }
 #endif
 #if MJB_HAS_GROUP(4)
-int mjb_launch_group4(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk)
+int mjb_launch_group4(const KernelParams *Pdev, const FrameLayout &L, int env_lo, int nenv, int mode, int nsteps, unsigned int step0, int epb, int constrained, void *stream, int chunk)
 {
-	if (constrained == 7) return launch_g<64, 7>(Pdev, L, nenv, mode, nsteps, step0, epb, stream, chunk);
-	if (constrained == 8) return launch_g<64, 8>(Pdev, L, nenv, mode, nsteps, step0, epb, stream, chunk);
-	return launch_g<64, 6>(Pdev, L, nenv, mode, nsteps, step0, epb, stream, chunk);
+	if (constrained == 7) return launch_g<64, 7>(Pdev, L, env_lo, nenv, mode, nsteps, step0, epb, stream, chunk);
+	if (constrained == 8) return launch_g<64, 8>(Pdev, L, env_lo, nenv, mode, nsteps, step0, epb, stream, chunk);
+	return launch_g<64, 6>(Pdev, L, env_lo, nenv, mode, nsteps, step0, epb, stream, chunk);
 }
 #endif
 #endif
@@ -2412,7 +2415,7 @@ int mjb_launch_group4(const KernelParams *Pdev, const FrameLayout &L, int nenv, 
 #if MJB_HAS_GROUP(0)
 int mjb_max_lds_bytes() { return 160 * 1024; }
 
-int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, int mode, int nsteps, unsigned int step0,
+int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int env_lo, int nenv, int mode, int nsteps, unsigned int step0,
                     int lanes_per_env, int envs_per_block, int constrained, int dense, void *stream)
 {
 	// (the headline kernels are instantiated first so that they sit at the start of the code object whatever happens to the
@@ -2420,27 +2423,27 @@ int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int nenv, in
 	const int chunk = constrained >> 8;  // (steps per work item of a chunked launch, 0 = one item per env; mjb_api.hip: launch)
 	constrained &= 255;
 #ifdef MJB_DEV_ONLY_CON  // development switch: compile ONE constrained kernel variant (seconds instead of minutes)
-	return launch_g<64, MJB_DEV_ONLY_CON>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream, chunk);
+	return launch_g<64, MJB_DEV_ONLY_CON>(Pdev, L, env_lo, nenv, mode, nsteps, step0, envs_per_block, stream, chunk);
 #else
 	if (!constrained) {
 		switch (lanes_per_env) {
 		case 16:
-			if (dense == 12) return launch_g<16, 0, 12>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
-			if (dense == 8) return launch_g<16, 0, 8>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
-			if (dense) return launch_g<16, 0, 16>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
-			return launch_g<16, 0>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
-		case 8: return launch_g<8, 0>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
-		case 32: return launch_g<32, 0>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
-		case 64: return launch_g<64, 0>(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, stream);
+			if (dense == 12) return launch_g<16, 0, 12>(Pdev, L, env_lo, nenv, mode, nsteps, step0, envs_per_block, stream);
+			if (dense == 8) return launch_g<16, 0, 8>(Pdev, L, env_lo, nenv, mode, nsteps, step0, envs_per_block, stream);
+			if (dense) return launch_g<16, 0, 16>(Pdev, L, env_lo, nenv, mode, nsteps, step0, envs_per_block, stream);
+			return launch_g<16, 0>(Pdev, L, env_lo, nenv, mode, nsteps, step0, envs_per_block, stream);
+		case 8: return launch_g<8, 0>(Pdev, L, env_lo, nenv, mode, nsteps, step0, envs_per_block, stream);
+		case 32: return launch_g<32, 0>(Pdev, L, env_lo, nenv, mode, nsteps, step0, envs_per_block, stream);
+		case 64: return launch_g<64, 0>(Pdev, L, env_lo, nenv, mode, nsteps, step0, envs_per_block, stream);
 		default: return (int)hipErrorInvalidValue;
 		}
 	}
 	if (lanes_per_env != 64) return (int)hipErrorInvalidValue;
-	if (constrained == 2 || constrained == 3) return mjb_launch_group2(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream, chunk);
-	if (constrained == 4) return mjb_launch_group3(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream, chunk);
-	if (constrained >= 6 && constrained <= 8) return mjb_launch_group4(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream, chunk);
-	if (constrained == 9) return mjb_launch_group5(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream, chunk);
-	return mjb_launch_group1(Pdev, L, nenv, mode, nsteps, step0, envs_per_block, constrained, stream, chunk);
+	if (constrained == 2 || constrained == 3) return mjb_launch_group2(Pdev, L, env_lo, nenv, mode, nsteps, step0, envs_per_block, constrained, stream, chunk);
+	if (constrained == 4) return mjb_launch_group3(Pdev, L, env_lo, nenv, mode, nsteps, step0, envs_per_block, constrained, stream, chunk);
+	if (constrained >= 6 && constrained <= 8) return mjb_launch_group4(Pdev, L, env_lo, nenv, mode, nsteps, step0, envs_per_block, constrained, stream, chunk);
+	if (constrained == 9) return mjb_launch_group5(Pdev, L, env_lo, nenv, mode, nsteps, step0, envs_per_block, constrained, stream, chunk);
+	return mjb_launch_group1(Pdev, L, env_lo, nenv, mode, nsteps, step0, envs_per_block, constrained, stream, chunk);
 #endif
 }
 

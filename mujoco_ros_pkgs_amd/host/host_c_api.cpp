@@ -52,6 +52,9 @@ int be_set_env_param(void *s, int what, int lo, int hi, const void *data)
 }
 int be_get_packed(void *s, int n, const int *f, int lo, int hi, double *h) { return mjb_get_packed(B(s)->batch, n, f, lo, hi, h); }
 int be_set_packed(void *s, int n, const int *f, int lo, int hi, const double *h) { return mjb_set_packed(B(s)->batch, n, f, lo, hi, h); }
+int be_step1_prefix(void *s, int ncb) { return mjb_step1_prefix(B(s)->batch, ncb); }
+int be_step_rest(void *s, int ncb) { return mjb_step_rest(B(s)->batch, ncb); }
+int be_step2_prefix(void *s, int ncb) { return mjb_step2_prefix(B(s)->batch, ncb); }
 const char *be_err(void *) { return mjb_last_error(); }
 void be_destroy(void *s)
 {
@@ -187,6 +190,26 @@ int sh_set_env_param(void *s, int what, int lo, int hi, const void *data)
 		return k->set_env_param ? k->set_env_param(k->self, what, a, b, static_cast<const char *>(data) + (size_t)off * per) : -1;
 	});
 }
+// the callback prefix [0, ncb) of the whole batch, seen from block i: its first clamp(ncb - lo[i], 0, n_i) envs
+template <typename F> int sh_prefix(Sharded *s, int ncb, F fn)
+{
+	return sh_each(s, [&](mjr_backend *k, int i) {
+		const int n = s->lo[i + 1] - s->lo[i], local = std::max(0, std::min(n, ncb - s->lo[i]));
+		return fn(k, local);
+	});
+}
+int sh_step1_prefix(void *s, int ncb)
+{
+	return sh_prefix(SH(s), ncb, [](mjr_backend *k, int c) { return k->step1_prefix ? k->step1_prefix(k->self, c) : k->step1(k->self); });
+}
+int sh_step_rest(void *s, int ncb)
+{
+	return sh_prefix(SH(s), ncb, [](mjr_backend *k, int c) { return k->step_rest ? k->step_rest(k->self, c) : 0; });
+}
+int sh_step2_prefix(void *s, int ncb)
+{
+	return sh_prefix(SH(s), ncb, [](mjr_backend *k, int c) { return k->step2_prefix ? k->step2_prefix(k->self, c) : k->step2(k->self); });
+}
 const char *sh_err(void *s) { return SH(s)->err.c_str(); }
 void sh_destroy(void *s)
 {
@@ -218,7 +241,7 @@ mjr_backend *sharded_factory(const mjb_model_desc *desc, int nenv, int, void *us
 	sh->stride[MJR_ENV_BODY_MASS] = (size_t)desc->nbody * sizeof(double);
 	sh->vt = mjr_backend{ sh, sh_nenv, sh_field_size, sh_step, sh_step1, sh_step2, sh_forward, sh_reset, sh_get, sh_set, sh_noise,
 		                  sh_sync, sh_err, sh_destroy, sh_get_many, sh_set_many, sh_host_register, sh_host_unregister, sh_step_async,
-		                  sh_register_collision, sh_set_env_param, nullptr, nullptr };
+		                  sh_register_collision, sh_set_env_param, nullptr, nullptr, sh_step1_prefix, sh_step_rest, sh_step2_prefix };
 	return &sh->vt;
 }
 
@@ -251,7 +274,8 @@ mjr_backend *mjr_make_mjb_backend(const mjb_model_desc *desc, int nenv, int devi
 	}
 	b->vt = mjr_backend{ b, be_nenv, be_field_size, be_step, be_step1, be_step2, be_forward, be_reset, be_get, be_set,
 		                 be_noise, be_sync, be_err, be_destroy, be_get_many, be_set_many, be_host_register, be_host_unregister,
-		                 be_step_async, be_register_collision, be_set_env_param, be_get_packed, be_set_packed };
+		                 be_step_async, be_register_collision, be_set_env_param, be_get_packed, be_set_packed, be_step1_prefix, be_step_rest,
+		                 be_step2_prefix };
 	return &b->vt;
 }
 

@@ -518,15 +518,20 @@ int MujocoEnv::stepBurst(int n, bool count_requests)
 	}
 	for (int s = 0; s < n; s++) {
 		const double t_before = views_[0].time;
-		if (backend_->step1(backend_->self) != 0) break;
+		// Only the callback envs [0, ncb) are split at the callback point; the others take the same step as one fused launch,
+		// enqueued once the callback envs' fields are on the host so that it runs under the callbacks (backends without the
+		// prefix entry points split every env)
+		const bool prefix = backend_->step1_prefix && backend_->step_rest && backend_->step2_prefix;
+		if ((prefix ? backend_->step1_prefix(backend_->self, ncb) : backend_->step1(backend_->self)) != 0) break;
 		pullViews(0, ncb, true);
+		if (prefix && backend_->step_rest(backend_->self, ncb) != 0) break;
 		for (int e = 0; e < ncb; e++) {  // mjcb_passive then mjcb_control, in registration order per env
 			cb_view_ = &views_[e];
 			runPassiveCbs();
 			runControlCbs();
 		}
 		pushViews(0, ncb, true);  // the writable state fields + qfrc_passive (what mjcb_passive adds to), one transfer when small
-		if (backend_->step2(backend_->self) != 0) break;
+		if ((prefix ? backend_->step2_prefix(backend_->self, ncb) : backend_->step2(backend_->self)) != 0) break;
 		pullViews(0, ncb, false);
 		publishSimTime(views_[0].time);
 		for (int e = 0; e < ncb; e++) {

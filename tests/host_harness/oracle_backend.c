@@ -146,7 +146,7 @@ mjr_backend *oracle_backend_factory(const mjb_model_desc *desc, int nenv, int de
 	b->d = (mjo_data **)calloc((size_t)nenv, sizeof(mjo_data *));
 	for (int e = 0; e < nenv; e++) b->d[e] = mjo_make_data(&b->desc);
 	mjr_backend vt = { b, ob_nenv, ob_field_size, ob_step, ob_step1, ob_step2, ob_forward, ob_reset, ob_get, ob_set,
-		               ob_noise, ob_sync, ob_err, ob_destroy, NULL, NULL, NULL, NULL, NULL, ob_register_collision, ob_set_env_param, NULL, NULL };
+		               ob_noise, ob_sync, ob_err, ob_destroy, NULL, NULL, NULL, NULL, NULL, ob_register_collision, ob_set_env_param, NULL, NULL, NULL, NULL, NULL };
 	b->vt = vt;
 	return &b->vt;
 }

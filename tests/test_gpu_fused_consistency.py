@@ -174,3 +174,45 @@ def test_keep_frame_matches_split_step(name, solver, lanes):
         assert np.array_equal(fused["qfrc_constraint"], split["qfrc_constraint"])
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("asset,ncb", [("franka_like", 0), ("franka_like", 5), ("franka_like", 37), ("franka_table", 3), ("shadow_hand_like", 2)])
+def test_prefix_split_step_equals_whole_batch_steps(asset, ncb):
+    """mjb_step1_prefix / mjb_step_rest / mjb_step2_prefix (the host runtime's split step: only the callback envs [0, ncb) are split,
+    the rest take the same step fused): with nothing written between the halves the batch must end up bit-identical to whole-batch
+    fused steps -- under the OU ctrl noise, i.e. the Philox step counter advances once per step for both groups."""
+    from mujoco_ros_pkgs_amd import engine, mjcf
+    from bench import WORKLOADS, initial_state
+    model = mjcf.load_asset(asset)
+    cm = engine.CompiledModel(model)
+    nenv, K = 37, 6
+    qpos, qvel = initial_state(asset, model, nenv, seed=5)
+    a, b = engine.Batch(cm, nenv), engine.Batch(cm, nenv)
+    for x in (a, b):
+        x.set("qpos", qpos)
+        x.set("qvel", qvel)
+        x.set_ctrl_noise(WORKLOADS[asset][1], 0.1, 99, 0)
+    a.step(K)
+    lib = b.lib
+    for _ in range(K):
+        assert lib.mjb_step1_prefix(b.ptr, ncb) == 0
+        if ncb:
+            assert np.all(np.isfinite(b.get("xpos", 0, ncb)))          # derived fields of the callback envs are readable here
+            with pytest.raises(engine.EngineError):
+                b.get("xpos", 0, nenv) if ncb < nenv else (_ for _ in ()).throw(engine.EngineError("n/a"))
+        assert lib.mjb_step_rest(b.ptr, ncb) == 0
+        assert lib.mjb_step2_prefix(b.ptr, ncb) == 0
+    # (kernel variant 4 -- the hand: Newton, capacity > 128 rows -- runs env-steps of 61 .. 64 rows through different template
+    #  instantiations of the solver on the full and on the fused frame (J in LDS / in HBM): same arithmetic, fma contraction may
+    #  differ in the last bit, so its split envs are compared to 1e-9 instead of bit for bit; the fused rest stays bit-equal)
+    exact = asset != "shadow_hand_like"
+    for f in ("qpos", "qvel", "qacc", "sensordata", "time", "ctrl"):
+        x, y = a.get(f), b.get(f)
+        assert np.array_equal(x[ncb:], y[ncb:]), f
+        assert np.array_equal(x[:ncb], y[:ncb]) if exact else np.allclose(x[:ncb], y[:ncb], rtol=0, atol=1e-9 * (1 + np.abs(x[:ncb]).max())), f
+    # mjb_step2_prefix issues the rest itself when the caller skipped it
+    assert lib.mjb_step1_prefix(b.ptr, ncb) == 0 and lib.mjb_step2_prefix(b.ptr, ncb) == 0
+    a.step(1)
+    assert np.array_equal(a.get("qpos")[ncb:], b.get("qpos")[ncb:])
+    a.close()
+    b.close()
