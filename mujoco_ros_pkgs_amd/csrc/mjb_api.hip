@@ -104,6 +104,9 @@ struct mjb_batch {
 	int frame_hi = 0;             // the frame workspace is current for envs [0, frame_hi) (a prefix after mjb_step1_prefix)
 	int split_ncb = -1;           // inside a split step of this prefix (mjb_step1_prefix .. mjb_step2_prefix)
 	bool split_rest_done = false;
+	hipStream_t rest_stream = nullptr;  // the fused launch of the non-callback envs runs beside the callback envs' second half
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	bool rest_pending = false;
 	unsigned char *mask_dev = nullptr;
 	KernelParams *params_dev = nullptr;  // device copy of {dm, L, st, nz}
 	double *metrics_dev = nullptr;       // [16] mjb_metrics
@@ -1029,6 +1032,12 @@ void mjb_free_batch(mjb_batch *b)
 	if (b->st.pgs_B) hipFree(b->st.pgs_B);
 	if (b->st.efc_Jg) hipFree(b->st.efc_Jg);
 	if (b->pack_dev) hipFree(b->pack_dev);
+	if (b->rest_stream) {
+		hipStreamSynchronize(b->rest_stream);
+		hipStreamDestroy(b->rest_stream);
+		hipEventDestroy(b->ev_fork);
+		hipEventDestroy(b->ev_join);
+	}
 	if (b->st.sched) hipFree(b->st.sched);
 	if (b->metrics_dev) hipFree(b->metrics_dev);
 	if (b->st.prof) hipFree(b->st.prof);
@@ -1297,9 +1306,10 @@ static int kernel_variant(const mjb_model_desc &h)
 	return (h.solver == MJB_SOL_CG ? 4 : 0) + (h.nefcmax <= 64 ? 2 : (h.nefcmax <= 128 ? 3 : 4));
 }
 
-static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi = -1)
+static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi = -1, hipStream_t on = nullptr)
 {
 	if (env_hi < 0) env_hi = b->nenv;
+	hipStream_t stream = on ? on : b->stream;
 	const bool whole = env_lo == 0 && env_hi == b->nenv;
 	HIP_TRY(hipSetDevice(b->device));
 	int prc = sync_params(b);
@@ -1319,11 +1329,11 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 		if (!off) {
 			static const int forced = [] { const char *v = getenv("MJB_DEBUG_CHUNK"); return v ? atoi(v) : 0; }();
 			chunk = forced > 0 ? forced : std::max(10, (nsteps + 15) / 16);  // (measured: 10 - 40 steps per item are equally good on config 3, 5 - 15 on config 5)
-			HIP_TRY(hipMemsetAsync(b->st.sched, 0, ((size_t)b->nenv + 1) * sizeof(int), b->stream));
+			HIP_TRY(hipMemsetAsync(b->st.sched, 0, ((size_t)b->nenv + 1) * sizeof(int), stream));
 		}
 	}
 	int rc = mjb_launch_step(b->params_dev, compact ? b->model->Lc : b->L, env_lo, env_hi, mode, nsteps, b->step_counter, b->lanes,
-	                         b->epb, variant | (chunk << 8), (b->lanes == 16 && !b->env_mass && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, b->stream);
+	                         b->epb, variant | (chunk << 8), (b->lanes == 16 && !b->env_mass && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, stream);
 	if (rc != 0) return fail(MJB_ENODEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
 	return MJB_OK;
 }
@@ -1409,7 +1419,22 @@ int mjb_step_rest(mjb_batch *b, int ncb)
 	if (b->split_rest_done) return fail(MJB_EINVAL, "mjb_step_rest: called twice in one split step");
 	b->split_rest_done = true;
 	if (ncb >= b->nenv) return MJB_OK;
-	return launch(b, MJB_MODE_STEP, 1, ncb, b->nenv);
+	// on its own stream, forked from the batch's stream here and joined in mjb_step2_prefix: the two groups of envs are independent,
+	// so the callback envs' second half does not queue behind this launch
+	HIP_TRY(hipSetDevice(b->device));
+	if (!b->rest_stream) {
+		HIP_TRY(hipStreamCreateWithFlags(&b->rest_stream, hipStreamNonBlocking));
+		HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+	}
+	int prc = sync_params(b);  // (uploads, if any, on the batch's stream BEFORE the fork)
+	if (prc) return prc;
+	HIP_TRY(hipEventRecord(b->ev_fork, b->stream));
+	HIP_TRY(hipStreamWaitEvent(b->rest_stream, b->ev_fork, 0));
+	int rc = launch(b, MJB_MODE_STEP, 1, ncb, b->nenv, b->rest_stream);
+	HIP_TRY(hipEventRecord(b->ev_join, b->rest_stream));
+	b->rest_pending = true;
+	return rc;
 }
 
 int mjb_step2_prefix(mjb_batch *b, int ncb)
@@ -1421,6 +1446,10 @@ int mjb_step2_prefix(mjb_batch *b, int ncb)
 	if (ncb > 0) {
 		if (!b->frame_valid || !b->st.frame_ws || b->frame_hi < ncb) return fail(MJB_EINVAL, "mjb_step2_prefix without a preceding mjb_step1_prefix");
 		rc = launch(b, MJB_MODE_STEP2, 1, 0, ncb);
+	}
+	if (b->rest_pending) {  // join: whatever follows on the batch's stream sees the rest's step too
+		HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_join, 0));
+		b->rest_pending = false;
 	}
 	if (rc == MJB_OK) {
 		b->step_counter += 1;

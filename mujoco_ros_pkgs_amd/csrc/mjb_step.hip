@@ -2209,8 +2209,12 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 
 		if (mode == MJB_MODE_STEP2) {
 			// resume: full frame from the workspace, then the (possibly host-modified) state on top
+			// (eight loads in flight per lane: the copy is a chain of HBM round trips otherwise -- a split step of ONE callback env
+			//  is pure latency, profiles/r03_callback_path.txt)
+#pragma unroll 8
 			for (int k = e.lane; k < L.ndouble; k += G) e.f[k] = ws[k];
 			int *wsi = reinterpret_cast<int *>(ws + L.ndouble);
+#pragma unroll 8
 			for (int k = e.lane; k < L.nint; k += G) e.fi[k] = wsi[k];
 			gsync<G>();
 		} else {
@@ -2276,8 +2280,10 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 		if (P->hw.n > 0)  // the device-side hwsim stage writes qfrc_applied: keep mjData's view of it current
 			copy_out<G>(s.qfrc_applied + (size_t)e.env * m.nv, e.f + L.qfrc_applied, m.nv, e.lane);
 		if (ws && (mode != MJB_MODE_STEP || s.keep_frame)) {
+#pragma unroll 8
 			for (int k = e.lane; k < L.ndouble; k += G) ws[k] = e.f[k];
 			int *wsi = reinterpret_cast<int *>(ws + L.ndouble);
+#pragma unroll 8
 			for (int k = e.lane; k < L.nint; k += G) wsi[k] = e.fi[k];
 		}
 		if (dyn) {  // publish the chunk: the state stores above first

@@ -31,13 +31,14 @@ for ncb in (1, 64):
     N = 300
     for it in range(N + 20):
         t = [time.perf_counter()]
-        lib.mjb_step1(b.ptr); t.append(time.perf_counter())
+        lib.mjb_step1_prefix(b.ptr, ncb); t.append(time.perf_counter())
         lib.mjb_get_packed(b.ptr, len(pull1), arr(pull1), 0, ncb, block.ctypes.data_as(pd)); t.append(time.perf_counter())
+        lib.mjb_step_rest(b.ptr, ncb)
         lib.mjb_set_packed(b.ptr, len(push), arr(push), 0, ncb, block.ctypes.data_as(pd)); t.append(time.perf_counter())
-        lib.mjb_step2(b.ptr); t.append(time.perf_counter())
+        lib.mjb_step2_prefix(b.ptr, ncb); t.append(time.perf_counter())
         lib.mjb_get_packed(b.ptr, len(pull2), arr(pull2), 0, ncb, block.ctypes.data_as(pd)); t.append(time.perf_counter())
         if it >= 20:
             acc[:5] += np.diff(t)
             acc[5] += t[-1] - t[0]
-    names = ["step1 (enqueue)", "get_packed 24 fields (+sync: waits for step1)", "set_packed 5 fields", "step2 (enqueue)", "get_packed 8 fields (+sync: waits for step2)", "total"]
+    names = ["step1_prefix (enqueue)", "get_packed 24 fields (+sync: waits for step1)", "step_rest + set_packed 5 fields (enqueue)", "step2_prefix (enqueue)", "get_packed 8 fields (+sync: waits for step2)", "total"]
     print(f"callback envs {ncb}: " + "; ".join(f"{n} {1e6 * a / N:.0f} us" for n, a in zip(names, acc)))
