@@ -77,6 +77,25 @@ struct LaneConst {
 	// ... and of dof `lane` (nv <= 16): its body, and where the body velocity "before" the dof's joint comes from
 	int d_body, d_zero, d_simple, d_parent;
 	unsigned int d_bmlo, d_bmhi;  // bodies moved by the dof  // d_zero: translational dof of a free joint; d_simple: first joint of its body
+	// ... and what the SMALL stages read per lane and step (round 3): transmission, passive, actuation, the sensors' plain copies and
+	// Euler each cost 1 - 2 k cycles of which the arithmetic is a handful of fma -- the rest is a chain of two or three dependent
+	// loads from the model blob (dof -> actuator list -> actuator -> parameters).  nu, njnt <= 16 (mjb_api.hip picks the kernel).
+	int u_qa, u_da;        // lane = actuator: qpos / dof address of its joint (joint transmission)
+	double u_gear;
+	int a_n, a_id, a_flags;  // lane = dof: number of actuators driving it (a_n > 1: table walk), the single one's id, flags:
+	                         // 1 ctrllimited (and clamping on), 2 affine gain, 4 affine bias, 8 forcelimited
+	double a_clo, a_chi, a_g[3], a_b[3], a_flo, a_fhi, a_gear;
+	int j_type, j_qa, j_da;  // lane = joint
+	double j_stiff, j_spring, j_damp;  // (spring reference / damping of a hinge or slide joint; ball / free joints walk the tables)
+	int sc_dst[3][2], sc_src[3][2];  // lane's plain sensor copies of the three stages in the layout of this launch (-1: none)
+	int j_body, j_root;    // lane = joint: its body and that body's root (comPos: cdof)
+	// lane = item of kinematics' phase D (joint / geom / site; njnt + ngeom + nsite <= 16, else k_kind = -1: table walk)
+	int k_kind, k_id, k_body, k_same;  // kind: 0 joint (k_body = the PARENT of the joint's body; k_same = joint is free), 1 geom, 2 site
+	double k_pos[3], k_quat[4];
+	// lane's qM entries en = lane, lane + 16, lane + 32 (nM <= 48, else q_row[0] = -2: table walk): row / column dof, and for a
+	// diagonal entry its armature and h * damping
+	int q_row[3], q_col[3];
+	double q_arm[3], q_hd[3];
 };
 
 // The lane's index inside its env group, re-derived from the hardware lane id at EVERY read (two VALU instructions behind an
@@ -364,6 +383,29 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 #endif
 	// Phase D -- joints (anchor / axis to the world frame through the PARENT body's frame), geoms, sites
 	const int nitem = m.njnt + m.ngeom + m.nsite;
+	if (CACHE && e.lc.k_kind >= 0) {  // (the lane's item record sits in registers: no table walk)
+		if (e.lc.k_kind == 0 && !e.lc.k_same) {
+			const int j = e.lc.k_id, pid = e.lc.k_body;
+			double M[9], pp[3], an[3], ax[3], v[3];
+			ld9(M, xmat + 9 * pid);
+			ld3(pp, xpos + 3 * pid);
+			ld3(an, xanchor + 3 * j);
+			ld3(ax, xaxis + 3 * j);
+			matvec3(v, M, an);
+			v[0] += pp[0]; v[1] += pp[1]; v[2] += pp[2];
+			st3(xanchor + 3 * j, v);
+			matvec3(v, M, ax);
+			st3(xaxis + 3 * j, v);
+		} else if (e.lc.k_kind == 1 || e.lc.k_kind == 2) {
+			const bool isg = e.lc.k_kind == 1;
+			const int id = e.lc.k_id, b = e.lc.k_body;
+			double pos[3] = { e.lc.k_pos[0], e.lc.k_pos[1], e.lc.k_pos[2] }, quat[4] = { e.lc.k_quat[0], e.lc.k_quat[1], e.lc.k_quat[2], e.lc.k_quat[3] };
+			double *opos = f + (isg ? L.geom_xpos + 3 * id : L.site_xpos + 3 * id);
+			double *omat = f + (isg ? L.geom_xmat + 9 * id : L.site_xmat + 9 * id);
+			double *oquat = f + L.site_xquat + (isg ? 0 : 4 * id);
+			local2global(xpos + 3 * b, xquat + 4 * b, xmat + 9 * b, opos, omat, pos, quat, e.lc.k_same, oquat, isg ? 0 : 1);
+		}
+	} else
 	for (int it = lane; it < nitem; it += G) {
 		if (it < m.njnt) {
 			const int j = it, b = m.jnt_bodyid[j];
@@ -457,10 +499,10 @@ template <int G, bool OBL> STAGE void com_pos(CModel m, CLayout L, const Env &e)
 	}
 	// cdof: one joint per lane
 	for (int j = lane; j < m.njnt; j += G) {
-		const int bi = m.jnt_bodyid[j], jt = m.jnt_type[j];
-		double *cd = f + L.cdof + 6 * m.jnt_dofadr[j];
+		const int bi = OBL ? e.lc.j_body : m.jnt_bodyid[j], jt = OBL ? e.lc.j_type : m.jnt_type[j];
+		double *cd = f + L.cdof + 6 * (OBL ? e.lc.j_da : m.jnt_dofadr[j]);
 		double root[3], an[3], off[3];
-		ld3(root, sc + 3 * m.body_rootid[bi]);
+		ld3(root, sc + 3 * (OBL ? e.lc.j_root : m.body_rootid[bi]));
 		ld3(an, f + L.xanchor + 3 * j);
 		off[0] = root[0] - an[0]; off[1] = root[1] - an[1]; off[2] = root[2] - an[2];
 		if (jt == MJB_JNT_FREE || jt == MJB_JNT_BALL) {
@@ -527,6 +569,20 @@ template <int G, bool OBL> STAGE void crb(CModel m, CLayout L, const Env &e)
 	}
 	gsync<G>();
 	// qM entries, one per lane: M(i,j) = cdof_j . buf_i  (+ armature on the diagonal)
+	if (OBL && e.lc.q_row[0] != -2) {  // (the lane's entries -- row / column dof, armature, h * damping -- sit in registers)
+#pragma unroll
+		for (int q = 0; q < 3; q++) {
+			const int i = e.lc.q_row[q], j = e.lc.q_col[q], en = lane + G * q;
+			if (i < 0) continue;
+			double a[6], b[6];
+			ld6(a, f + L.cdof + 6 * j);
+			ld6(b, buf + 6 * i);
+			double v = e.lc.q_arm[q];
+			v += dot6r(a, b);
+			f[L.qM + en] = v;
+			if (m.eulerdamp) f[L.MhB + en] = (i == j) ? v + e.lc.q_hd[q] : v;
+		}
+	} else
 	for (int en = lane; en < m.nM; en += G) {
 		const int i = m.M_rowdof[en], j = m.M_coldof[en];
 		double a[6], b[6];
@@ -927,8 +983,12 @@ template <int G> DEVI void solve_tri32(CModel m, const Env &e, double *x, const 
 // ------------------------------------------------------------------------------------------------
 // transmission (joint) : actuator_length
 // ------------------------------------------------------------------------------------------------
-template <int G> STAGE void transmission(CModel m, CLayout L, const Env &e)
+template <int G, bool CACHE = false> STAGE void transmission(CModel m, CLayout L, const Env &e)
 {
+	if constexpr (CACHE) {
+		if (e.lane < m.nu) e.f[L.actuator_length + e.lane] = e.f[L.qpos + e.lc.u_qa] * e.lc.u_gear;
+		return;
+	}
 	for (int i = e.lane; i < m.nu; i += G) {
 		const int j = m.actuator_trnid[2 * i];
 		e.f[L.actuator_length + i] = e.f[L.qpos + m.jnt_qposadr[j]] * m.actuator_gear[6 * i];
@@ -995,9 +1055,13 @@ template <int G, bool OBL> STAGE void com_vel(CModel m, CLayout L, const Env &e)
 		}
 		st6(f + L.cdof_dot + 6 * d, r);
 	}
-	for (int i = lane; i < m.nu; i += G) {
-		const int j = m.actuator_trnid[2 * i];
-		f[L.actuator_velocity + i] = m.actuator_gear[6 * i] * qvel[m.jnt_dofadr[j]];
+	if constexpr (OBL) {
+		if (lane < m.nu) f[L.actuator_velocity + lane] = e.lc.u_gear * qvel[e.lc.u_da];
+	} else {
+		for (int i = lane; i < m.nu; i += G) {
+			const int j = m.actuator_trnid[2 * i];
+			f[L.actuator_velocity + i] = m.actuator_gear[6 * i] * qvel[m.jnt_dofadr[j]];
+		}
 	}
 	gsync<G>();
 }
@@ -1005,13 +1069,24 @@ template <int G, bool OBL> STAGE void com_vel(CModel m, CLayout L, const Env &e)
 // ------------------------------------------------------------------------------------------------
 // A8  passive forces: joint springs and dof dampers
 // ------------------------------------------------------------------------------------------------
-template <int G> STAGE void passive(CModel m, CLayout L, const Env &e)
+template <int G, bool CACHE = false> STAGE void passive(CModel m, CLayout L, const Env &e)
 {
 	double *f = e.f;
 	double *qp = f + L.qfrc_passive;
 	const bool off = (m.disableflags & MJB_DSBL_PASSIVE) != 0;
 	for (int j = e.lane; j < m.njnt; j += G) {
-		const int jt = m.jnt_type[j];
+		const int jt = CACHE ? e.lc.j_type : m.jnt_type[j];
+		if constexpr (CACHE) {
+			if (jt == MJB_JNT_HINGE || jt == MJB_JNT_SLIDE) {  // one dof: spring and damper from the lane's registers (same expressions)
+				const int pa1 = e.lc.j_qa, da1 = e.lc.j_da;
+				const double k1 = e.lc.j_stiff;
+				double v = 0;
+				if (k1 != 0 && !off) v = -k1 * (f[L.qpos + pa1] - e.lc.j_spring);
+				if (!off) v -= e.lc.j_damp * f[L.qvel + da1];
+				qp[da1] = v;
+				continue;
+			}
+		}
 		int pa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
 		const int nd = jt == MJB_JNT_FREE ? 6 : (jt == MJB_JNT_BALL ? 3 : 1);
 		double frc[6] = { 0, 0, 0, 0, 0, 0 };
@@ -1328,14 +1403,20 @@ DEVI bool ray_hits_site(CModel m, CLayout L, const double *f, int site, const do
 	return true;
 }
 
-template <int G> STAGE void sensors(CModel m, CLayout L, const Env &e, int stage, int compact)
+template <int G, bool CACHE = false> STAGE void sensors(CModel m, CLayout L, const Env &e, int stage, int compact)
 {
 	if (m.disableflags & MJB_DSBL_SENSOR) return;
 	const int ncopy = m.sens_ncopy[stage - 1], nslow = m.sens_nslow[stage - 1];
 	if (ncopy == 0 && nslow == 0) return;
 	double *f = e.f;
 	// plain copies: host-resolved {dst, src} pairs (table of the layout in use)
-	{
+	if (CACHE && ncopy <= 2 * G) {  // (the pairs of this launch's layout sit in the lane's registers)
+#pragma unroll
+		for (int q = 0; q < 2; q++) {
+			const int dst = e.lc.sc_dst[stage - 1][q];
+			if (dst >= 0) f[L.sensordata + dst] = f[e.lc.sc_src[stage - 1][q]];
+		}
+	} else {
 		const int tb = ((compact ? 3 : 0) + stage - 1) * m.sens_ncopy_max;
 		for (int t = e.lane; t < ncopy; t += G) {
 			const int dst = m.sens_copy[2 * (tb + t)], src = m.sens_copy[2 * (tb + t) + 1];
@@ -1497,13 +1578,35 @@ template <int G> STAGE void sensors(CModel m, CLayout L, const Env &e, int stage
 // ------------------------------------------------------------------------------------------------
 // A12 actuation and smooth acceleration
 // ------------------------------------------------------------------------------------------------
-template <int G> STAGE void fwd_actuation(CModel m, CLayout L, const Env &e)
+template <int G, bool CACHE = false> STAGE void fwd_actuation(CModel m, CLayout L, const Env &e)
 {
 	double *f = e.f;
 	const bool off = m.nu == 0 || (m.disableflags & MJB_DSBL_ACTUATION);
 	// one dof per lane: forces of the actuators driving it (host-built CSR lists, ascending actuator id)
 	for (int d = e.lane; d < m.nv; d += G) {
 		double acc = 0;
+		if constexpr (CACHE) {
+			if (e.lc.a_n <= 1) {  // at most one actuator on this dof: its constants sit in the lane's registers (same expressions)
+				if (e.lc.a_n == 1) {
+					const int i = e.lc.a_id, fl = e.lc.a_flags;
+					double force = 0;
+					if (!off) {
+						double ctrl = f[L.ctrl + i];
+						if (fl & 1) ctrl = ctrl < e.lc.a_clo ? e.lc.a_clo : (ctrl > e.lc.a_chi ? e.lc.a_chi : ctrl);
+						const double len = f[L.actuator_length + i], vel = f[L.actuator_velocity + i];
+						double gain = e.lc.a_g[0], bias = 0;
+						if (fl & 2) gain = e.lc.a_g[0] + e.lc.a_g[1] * len + e.lc.a_g[2] * vel;
+						if (fl & 4) bias = e.lc.a_b[0] + e.lc.a_b[1] * len + e.lc.a_b[2] * vel;
+						force = gain * ctrl + bias;
+						if (fl & 8) force = force < e.lc.a_flo ? e.lc.a_flo : (force > e.lc.a_fhi ? e.lc.a_fhi : force);
+						acc += e.lc.a_gear * force;
+					}
+					f[L.actuator_force + i] = force;
+				}
+				f[L.qfrc_actuator + d] = acc;
+				continue;
+			}
+		}
 		const int t0 = m.dof_act_adr[d], t1 = m.dof_act_adr[d + 1];
 		for (int t = t0; t < t1; t++) {
 			const int i = m.dof_act_id[t];
@@ -1609,7 +1712,7 @@ template <int G> STAGE void fwd_constraint(CModel m, CLayout L, const Env &e)
 // ------------------------------------------------------------------------------------------------
 // A16 semi-implicit Euler with implicit joint damping
 // ------------------------------------------------------------------------------------------------
-template <int G, bool CAN16, bool TRI32 = false> STAGE void euler(CModel m, CLayout L, const Env &e)
+template <int G, bool CAN16, bool TRI32 = false, bool JC = false> STAGE void euler(CModel m, CLayout L, const Env &e)
 {
 	double *f = e.f;
 	const double dt = m.timestep[0];
@@ -1639,8 +1742,8 @@ template <int G, bool CAN16, bool TRI32 = false> STAGE void euler(CModel m, CLay
 	for (int d = e.lane; d < m.nv; d += G) f[L.qvel + d] += dt * x[d];
 	gsync<G>();
 	for (int j = e.lane; j < m.njnt; j += G) {
-		const int jt = m.jnt_type[j];
-		int pa = m.jnt_qposadr[j], va = m.jnt_dofadr[j];
+		const int jt = JC ? e.lc.j_type : m.jnt_type[j];  // (JC: the lane's joint constants sit in registers, njnt <= G)
+		int pa = JC ? e.lc.j_qa : m.jnt_qposadr[j], va = JC ? e.lc.j_da : m.jnt_dofadr[j];
 		if (jt == MJB_JNT_HINGE || jt == MJB_JNT_SLIDE) {
 			f[L.qpos + pa] += dt * f[L.qvel + va];
 		} else {
@@ -1840,16 +1943,16 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 			if (trip) break;
 		}
 		PROF_BEGIN();
-		VIEW(P, compact, transmission<G>(m, L, e));
-		VIEW(P, compact, sensors<G>(m, L, e, MJB_STAGE_POS, compact));
+		VIEW(P, compact, transmission<G, (DENSE != 0)>(m, L, e));
+		VIEW(P, compact, sensors<G, (DENSE != 0)>(m, L, e, MJB_STAGE_POS, compact));
 		PROF(4);
 		VIEW(P, compact, com_vel<G, (DENSE != 0)>(m, L, e));
 		PROF(5);
-		VIEW(P, compact, passive<G>(m, L, e));
+		VIEW(P, compact, passive<G, (DENSE != 0)>(m, L, e));
 		PROF(6);
 		VIEW(P, compact, rne<G, (DENSE != 0)>(m, L, e));
 		PROF(7);
-		VIEW(P, compact, sensors<G>(m, L, e, MJB_STAGE_VEL, compact));
+		VIEW(P, compact, sensors<G, (DENSE != 0)>(m, L, e, MJB_STAGE_VEL, compact));
 		PROF(8);
 	}
 }
@@ -1859,7 +1962,7 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 	constexpr bool MJB_LAUNDER_HERE = MJB_LAUNDER_DENSE || DENSE == 0;
 	[[maybe_unused]] CState s = P->s;  // (profiling macros)
 	PROF_BEGIN();
-	VIEW(P, compact, fwd_actuation<G>(m, L, e));
+	VIEW(P, compact, fwd_actuation<G, (DENSE != 0)>(m, L, e));
 	PROF(9);
 	VIEW(P, compact, fwd_acceleration<G, (CON != 0 ? -1 : DENSE), (CON >= 2 && CON <= 4)>(m, L, e, s.use_xfrc != 0));  // (TRI32: the Newton kernels -- in the PGS ones its 124 registers bring back the spill-before-exec-restore pattern)
 	PROF(10);
@@ -1896,7 +1999,7 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 	}
 	PROF(11);
 	VIEW(P, compact, if (m.need_rnepost) rne_post<G>(m, L, lite(e), s.use_xfrc != 0));
-	VIEW(P, compact, sensors<G>(m, L, e, MJB_STAGE_ACC, compact));
+	VIEW(P, compact, sensors<G, (DENSE != 0)>(m, L, e, MJB_STAGE_ACC, compact));
 	PROF(12);
 }
 
@@ -2170,6 +2273,89 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 		c.d_simple = (m.nv && m.dof_jstart[dd] == m.body_dofadr[c.d_body]) ? 1 : 0;
 		c.d_bmlo = m.nv ? (unsigned int)m.dof_bodymask[2 * dd] : 0u;
 		c.d_bmhi = m.nv ? (unsigned int)m.dof_bodymask[2 * dd + 1] : 0u;
+		{  // lane = actuator
+			const int i = (m.nu && e.lane < m.nu) ? (int)e.lane : 0;
+			const int tj = m.nu ? m.actuator_trnid[2 * i] : 0;
+			c.u_qa = m.nu ? m.jnt_qposadr[tj] : 0;
+			c.u_da = m.nu ? m.jnt_dofadr[tj] : 0;
+			c.u_gear = m.nu ? m.actuator_gear[6 * i] : 0.0;
+		}
+		{  // lane = dof: its actuator
+			const int t0 = m.nv ? m.dof_act_adr[dd] : 0, t1 = m.nv ? m.dof_act_adr[dd + 1] : 0;
+			c.a_n = t1 - t0;
+			const int i = c.a_n > 0 ? m.dof_act_id[t0] : 0;
+			c.a_id = i;
+			const bool has = c.a_n > 0 && m.nu > 0;
+			c.a_flags = 0;
+			if (has && m.actuator_ctrllimited[i] && !(m.disableflags & MJB_DSBL_CLAMPCTRL)) c.a_flags |= 1;
+			if (has && m.actuator_gaintype[i] == MJB_GAIN_AFFINE) c.a_flags |= 2;
+			if (has && m.actuator_biastype[i] == MJB_BIAS_AFFINE) c.a_flags |= 4;
+			if (has && m.actuator_forcelimited[i]) c.a_flags |= 8;
+			c.a_clo = has ? m.actuator_ctrlrange[2 * i] : 0.0;
+			c.a_chi = has ? m.actuator_ctrlrange[2 * i + 1] : 0.0;
+			for (int k = 0; k < 3; k++) {
+				c.a_g[k] = has ? m.actuator_gainprm[3 * i + k] : 0.0;
+				c.a_b[k] = has ? m.actuator_biasprm[3 * i + k] : 0.0;
+			}
+			c.a_flo = has ? m.actuator_forcerange[2 * i] : 0.0;
+			c.a_fhi = has ? m.actuator_forcerange[2 * i + 1] : 0.0;
+			c.a_gear = has ? m.actuator_gear[6 * i] : 0.0;
+		}
+		{  // lane = joint
+			const int jj = (m.njnt && e.lane < m.njnt) ? (int)e.lane : 0;
+			c.j_type = m.njnt ? m.jnt_type[jj] : 0;
+			c.j_qa = m.njnt ? m.jnt_qposadr[jj] : 0;
+			c.j_da = m.njnt ? m.jnt_dofadr[jj] : 0;
+			c.j_stiff = m.njnt ? m.jnt_stiffness[jj] : 0.0;
+			c.j_spring = m.njnt ? m.qpos_spring[c.j_qa] : 0.0;
+			c.j_damp = (m.njnt && m.nv) ? m.dof_damping[c.j_da] : 0.0;
+		}
+		{
+			const int jj = (m.njnt && e.lane < m.njnt) ? (int)e.lane : 0;
+			c.j_body = m.njnt ? m.jnt_bodyid[jj] : 0;
+			c.j_root = m.body_rootid[c.j_body];
+			const int nitem = m.njnt + m.ngeom + m.nsite, it = (int)e.lane;
+			c.k_kind = -1;
+			c.k_id = c.k_body = c.k_same = 0;
+			for (int k = 0; k < 3; k++) c.k_pos[k] = 0;
+			for (int k = 0; k < 4; k++) c.k_quat[k] = 0;
+			if (nitem <= G && it < nitem) {
+				if (it < m.njnt) {
+					c.k_kind = 0;
+					c.k_id = it;
+					c.k_body = m.body_rec[4 * m.jnt_bodyid[it]];
+					c.k_same = m.jnt_type[it] == MJB_JNT_FREE ? 1 : 0;
+				} else {
+					const bool isg = it < m.njnt + m.ngeom;
+					const int id = isg ? it - m.njnt : it - m.njnt - m.ngeom;
+					c.k_kind = isg ? 1 : 2;
+					c.k_id = id;
+					c.k_body = isg ? m.geom_bodyid[id] : m.site_bodyid[id];
+					c.k_same = isg ? m.geom_sameframe[id] : m.site_sameframe[id];
+					for (int k = 0; k < 3; k++) c.k_pos[k] = isg ? m.geom_pos[3 * id + k] : m.site_pos[3 * id + k];
+					for (int k = 0; k < 4; k++) c.k_quat[k] = isg ? m.geom_quat[4 * id + k] : m.site_quat[4 * id + k];
+				}
+			} else if (nitem <= G) {
+				c.k_kind = 3;  // (a lane without an item)
+			}
+			for (int q = 0; q < 3; q++) {
+				const int en = (int)e.lane + G * q;
+				const bool has = m.nM <= 3 * G && en < m.nM;
+				const int i = has ? m.M_rowdof[en] : 0, j = has ? m.M_coldof[en] : 0;
+				c.q_row[q] = has ? i : (m.nM <= 3 * G ? -1 : -2);
+				c.q_col[q] = j;
+				c.q_arm[q] = (has && i == j) ? m.dof_armature[i] : 0.0;
+				c.q_hd[q] = (has && i == j) ? m.timestep[0] * m.dof_damping[i] : 0.0;
+			}
+		}
+		for (int st = 0; st < 3; st++) {  // the sensors' plain copies: {dst, src} pairs of this launch's layout, two per lane and stage
+			const int tb = ((compact ? 3 : 0) + st) * m.sens_ncopy_max, nc = m.sens_ncopy[st];
+			for (int q = 0; q < 2; q++) {
+				const int t = (int)e.lane + G * q;
+				c.sc_dst[st][q] = t < nc ? m.sens_copy[2 * (tb + t)] : -1;
+				c.sc_src[st][q] = t < nc ? m.sens_copy[2 * (tb + t) + 1] : 0;
+			}
+		}
 	}
 	e.f = reinterpret_cast<double *>(smem + (size_t)slot * frame_bytes);
 	e.fi = reinterpret_cast<int *>(e.f + L.ndouble);
@@ -2272,7 +2458,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 				reset_frame_state<G>(m, L, s, lite(e), MJB_WARN_BADQACC);
 			}
 			PROF(14);  // whole forward (incl. checks)
-			if (do_euler) VIEW(P, compact, euler<G, (CON != 0), (CON >= 2 && CON <= 4)>(m, L, e));
+			if (do_euler) VIEW(P, compact, euler<G, (CON != 0), (CON >= 2 && CON <= 4), (DENSE != 0)>(m, L, e));
 			PROF(15);
 		}
 
