@@ -1328,7 +1328,10 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 		static const bool off = [] { const char *v = getenv("MJB_DEBUG_NO_CHUNKS"); return v && *v && *v != '0'; }();  // measurement knob
 		if (!off) {
 			static const int forced = [] { const char *v = getenv("MJB_DEBUG_CHUNK"); return v ? atoi(v) : 0; }();
-			chunk = forced > 0 ? forced : std::max(10, (nsteps + 15) / 16);  // (measured: 10 - 40 steps per item are equally good on config 3, 5 - 15 on config 5)
+			// (measured on MI355X: 10 - 40 steps per item are equally good on config 3; config 5 -- three envs per CU, a few heavy envs
+			//  on the critical path -- likes them finer: 3 - 5 steps per item 3.85 M, 10 steps 3.79 M, 20 steps 3.63 M)
+			const bool newton = variant >= 2 && variant <= 4;
+			chunk = forced > 0 ? forced : (newton ? std::max(5, (nsteps + 19) / 20) : std::max(10, (nsteps + 15) / 16));
 			HIP_TRY(hipMemsetAsync(b->st.sched, 0, ((size_t)b->nenv + 1) * sizeof(int), stream));
 		}
 	}
