@@ -525,7 +525,7 @@ DEVI int lanes_below(unsigned long long mask)
 // solref / solimp) comes from the host-built per-pair record: one level of memory latency per step instead of the
 // pair -> geom -> attribute chain.  Contact slots are assigned without LDS: a pair yields <= 8 contacts, so its offset is
 // sum_k popcount(ballot(n >= k) below this lane).
-template <int G> STAGE void collision(CModel m, CLayout L, CState s, const Env &e)
+template <int G> STAGE void collision(CModel m, CLayout L, CState s, const EnvLite &e)
 {
 	static_assert(G == 64, "one env per wavefront: pair offsets come from wave ballots");
 	double *f = e.f;
@@ -891,7 +891,7 @@ template <int TAG> DEVI int wave_uniform(int v) { return __builtin_amdgcn_readfi
 // TAG 4 (Newton, up to 256 rows, fused step): the frame holds the first L.jrows rows of efc_J only -- what lets two envs of
 // config 5 share a CU's LDS.  Rows beyond go to the env's block of s.efc_Jg in HBM; an env-step that ends up with more than
 // L.jrows rows (none of config 5's do) copies the leading rows there as well and the solver reads ALL of J from HBM.
-template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState s, const Env &e)
+template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState s, const EnvLite &e)
 {
 	static_assert(G == 64, "one env per wavefront: row offsets come from a wave prefix sum");
 	double *f = e.f;
@@ -1261,7 +1261,7 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 // A7  project: B = (M^-1 J')' row by row -- one ROW per lane, each lane runs the sparse solve serially on
 // its own row (loop structure is wave-uniform: the scalar table loads are shared by all rows)
 // ------------------------------------------------------------------------------------------------
-template <int G, int TAG> STAGE void project_constraint(CModel m, CLayout L, const Env &e)
+template <int G, int TAG> STAGE void project_constraint(CModel m, CLayout L, const EnvLite &e)
 {
 	double *f = e.f;
 	const int nefc = wave_uniform<TAG>(e.fi[L.nefc]), nv = m.nv;
@@ -1300,7 +1300,7 @@ template <int G, int TAG> STAGE void project_constraint(CModel m, CLayout L, con
 // wave-uniform address (one LDS broadcast per entry) and x never leaves the registers: 240 fma per row with no
 // load-modify-store chain, against two dependent LDS round trips per factor entry in the generic version.
 // Rows / columns >= nv of the triangle are zero and x[k >= nv] = 0, so the unrolled sweeps need no guards.
-template <int G, int TAG> STAGE void project_constraint_dense16(CModel m, CLayout L, const Env &e)
+template <int G, int TAG> STAGE void project_constraint_dense16(CModel m, CLayout L, const EnvLite &e)
 {
 	static_assert(G == 64, "one constraint row per lane of the wavefront");
 	double *f = e.f;
@@ -1352,7 +1352,7 @@ template <int G, int TAG> STAGE void project_constraint_dense16(CModel m, CLayou
 }
 
 // A8  reference accelerations: efc_vel = J qvel, aref = -B vel - K imp (pos - margin)
-template <int G, int TAG> STAGE void reference_constraint(CModel m, CLayout L, CState st, const Env &e)
+template <int G, int TAG> STAGE void reference_constraint(CModel m, CLayout L, CState st, const EnvLite &e)
 {
 	double *f = e.f;
 	const int nefc = wave_uniform<TAG>(e.fi[L.nefc]), nv = m.nv;
@@ -1719,7 +1719,7 @@ DEVI void tri_solve(double (&x)[16], const double *Ld, const double *di, int nv)
 // ------------------------------------------------------------------------------------------------
 // (TAG: the kernel variant this copy belongs to -- out-of-line functions shared by kernels with different register budgets are
 //  compiled for the loosest one, which would cost the capped kernel its second wave per SIMD)
-template <int G, int TAG> __device__ __attribute__((noinline)) void fwd_constraint_pgs_large(CModel m, CLayout L, const Env &e, const double *Brows)
+template <int G, int TAG> __device__ __attribute__((noinline)) void fwd_constraint_pgs_large(CModel m, CLayout L, const EnvLite e, const double *Brows)
 {
 	static_assert(G == 64, "the constraint solver maps rows to the 64 lanes of one wavefront");
 	double *f = e.f;
@@ -1842,7 +1842,7 @@ template <int G, int TAG> __device__ __attribute__((noinline)) void fwd_constrai
 // ------------------------------------------------------------------------------------------------
 // A13 constraint solve: warmstart + projected Gauss-Seidel (dual), one env per wavefront
 // ------------------------------------------------------------------------------------------------
-template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CModel m, CLayout L, CState s, const Env &e)
+template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CModel m, CLayout L, CState s, const EnvLite &e)
 {
 	static_assert(G == 64, "the constraint solver maps rows to the 64 lanes of one wavefront");
 	double *f = e.f;
@@ -2124,7 +2124,7 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 }
 
 // the LDS-B variants (nv > 16) stay out of line: models that small never pay their registers or instruction-cache lines
-template <int G, bool ELL, int TAG> __device__ __attribute__((noinline)) void fwd_constraint_pgs_ldsB(CModel m, CLayout L, CState s, const Env &e)
+template <int G, bool ELL, int TAG> __device__ __attribute__((noinline)) void fwd_constraint_pgs_ldsB(CModel m, CLayout L, CState s, const EnvLite e)
 {
 	fwd_constraint_pgs<G, ELL, false, TAG>(m, L, s, e);
 }
@@ -2227,7 +2227,7 @@ typedef double mjb_d4 __attribute__((ext_vector_type(4)));
 // JG: efc_J is read from the env's block in HBM (Jg) instead of the frame (kernel variant 4, env-steps with more rows than the
 // frame's share of efc_J; see make_constraint)
 template <int G, int R, bool CGS = false, bool JG = false>  // CGS: conjugate gradient (no Hessian; Polak-Ribiere directions preconditioned by M^-1)
-STAGE void fwd_constraint_newton(CModel m, CLayout L, const Env &e, const double *Jg = nullptr)
+STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const double *Jg = nullptr)
 {
 	static_assert(G == 64, "the Newton solver maps rows / Hessian columns to the 64 lanes of one wavefront");
 	double *f = e.f;

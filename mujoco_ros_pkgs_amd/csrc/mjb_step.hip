@@ -17,6 +17,8 @@
 // Stage functions are named after the MuJoCo 2.3.7 stage whose result they produce.
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "mjb_dev.h"
 #include "mjb_math.h"
 
@@ -112,6 +114,17 @@ struct LaneId {
 	}
 };
 
+// What the OUT-OF-LINE stages (rne_post, reset_frame_state, energy, hwsim_write, the noinline PGS paths) and every stage of
+// mjb_constraint.h get: handing them `const Env &` made the
+// whole Env -- dadr[16], the LaneConst block -- escape to memory, i.e. a private (scratch) segment in every kernel and a store of
+// each member at kernel entry.
+struct EnvLite {
+	double *f;
+	int *fi;
+	LaneId lane;
+	int env;
+	const double *mp;
+};
 struct Env {
 	double *f;  // LDS frame (doubles)
 	int *fi;    // LDS frame (ints)
@@ -125,18 +138,9 @@ struct Env {
 	const double *mp;  // this env's inertial constants (mjb_set_env_mass_params) or nullptr: the model's.  (Last member: the
 	                   // struct is spilled to scratch around the out-of-line stages, and moving the members above by 8 bytes
 	                   // misaligns their 16-byte scratch accesses -- measured 2 % on config 2.)
+	__device__ __forceinline__ operator EnvLite() const { return EnvLite{ f, fi, lane, env, mp }; }
 };
 
-// What the OUT-OF-LINE stages (rne_post, reset_frame_state, energy, hwsim_write) get, by value: handing them `const Env &` made the
-// whole Env -- dadr[16], the LaneConst block -- escape to memory, i.e. a private (scratch) segment in every kernel and a store of
-// each member at kernel entry.
-struct EnvLite {
-	double *f;
-	int *fi;
-	LaneId lane;
-	int env;
-	const double *mp;
-};
 DEVI EnvLite lite(const Env &e) { return EnvLite{ e.f, e.fi, e.lane, e.env, e.mp }; }
 
 // per-env inertial constants (what mj_setConst derives from the masses): the env's own block in HBM when the batch carries
@@ -688,7 +692,7 @@ template <int W> DEVI double row_sum(double v)  // W = 8 or 16 participating lan
 // qacc_smooth = M^-1 f  and, when nothing can change the force in between (no constraint rows), Euler's
 // (M + hB)^-1 f -- the second solve rides on the latency chain of the first.
 template <int G>
-STAGE void solve2(CModel m, const Env &e, double *x, const double *LD, const double *diaginv, double *x2,
+STAGE void solve2(CModel m, const EnvLite &e, double *x, const double *LD, const double *diaginv, double *x2,
                   const double *LD2, const double *diaginv2, bool dual)
 {
 	const int lane = e.lane;
@@ -760,6 +764,28 @@ DEVI double fast_rcp(double x)
 	return r;
 }
 
+// value of lane I of this lane's 16-lane DPP row, one v_mov_b32_dpp row_newbcast per dword: what carries pivots and pivot rows
+// between the lanes of a 16-lane env group (G == 16: group == row; G == 64: the matrix sits in row 0).  Round 3: replaces the
+// LDS publish / wave-uniform read round trip (~110 cycles + two syncs per pivot) the factorisation and both sweeps of the solve
+// went through -- same values, same arithmetic, no memory.
+template <int I> DEVI double row_bcast16(double v)
+{
+	static_assert(I >= 0 && I < 16, "row_newbcast selects one of the 16 lanes of a row");
+	return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + I, 0xF, 0xF, true),
+	                        __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + I, 0xF, 0xF, true));
+}
+// ... one env per wavefront (G == 64, the matrix in lanes 0 - 15): the source lane is wave-uniform, v_readlane puts the value in a
+// scalar register pair that the fma reads directly
+template <int G, int I> DEVI double group_bcast(double v)
+{
+	if constexpr (G == 64)
+		return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), I), __builtin_amdgcn_readlane(__double2loint(v), I));
+	else
+		return row_bcast16<I>(v);
+}
+template <typename F, int... Is> DEVI void static_for_impl(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F> DEVI void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 template <int G, bool DUAL, int NVM>
 DEVI void factor_dense16_impl(CModel m, const Env &e, const double *M, double *LD, double *di, const double *M2, double *LD2,
                               double *di2, const int (&dadr)[16], double *scr)
@@ -775,6 +801,9 @@ DEVI void factor_dense16_impl(CModel m, const Env &e, const double *M, double *L
 		B[i] = a >= 0 ? vb : 0.0;
 	}
 	double myinv = 0, myinv2 = 0;
+	if constexpr (G == 64) {
+	// (one env per wavefront, 256- / 512-register constrained kernels: the LDS round trip stays -- the broadcast forms below cost the
+	//  capped PGS kernel registers, measured 42.9 -> 44.2 ms on config 3)
 #pragma unroll
 	for (int k = NVM - 1; k >= 0; k--) {
 		if (k < nv) {
@@ -811,6 +840,33 @@ DEVI void factor_dense16_impl(CModel m, const Env &e, const double *M, double *L
 				B[k] = lkj2;
 			}
 		}
+	}
+	} else {
+	(void)scr;
+	static_for<NVM>([&](auto kc) {
+		constexpr int k = NVM - 1 - decltype(kc)::value;
+		if (k < nv) {
+			MJB_KEEP_BRANCH();
+			// the pivot row M(k, .) is spread over the lanes (lane i holds M(k, i) in register k): its entries travel by DPP row
+			// broadcasts -- the diagonal first (its reciprocal heads the dependent chain), then one entry per update
+			const double dk = group_bcast<G, k>(A[k]), dk2 = DUAL ? group_bcast<G, k>(B[k]) : 1.0;
+			const double inv = fast_rcp(dk), inv2 = DUAL ? fast_rcp(dk2) : 0.0;
+			const double lkj = A[k] * inv, lkj2 = B[k] * inv2;  // scaled pivot-row entry of this lane's column (lane < k)
+			// (entries above the diagonal -- register i of a lane > i -- are never read or stored: no lane predicate)
+			static_for<k>([&](auto ic) {
+				constexpr int i = decltype(ic)::value;
+				A[i] -= group_bcast<G, i>(A[k]) * lkj;  // unscaled M(k, i), held by lane i
+				if (DUAL) B[i] -= group_bcast<G, i>(B[k]) * lkj2;
+			});
+			if (lane == k) {
+				myinv = inv;
+				myinv2 = inv2;
+			} else {
+				A[k] = lkj;
+				B[k] = lkj2;
+			}
+		}
+	});
 	}
 #pragma unroll
 	for (int i = 0; i < NVM; i++) {
@@ -858,6 +914,7 @@ DEVI void solve_dense16_impl(CModel m, const Env &e, double *x, const double *LD
 	}
 	double xj = act ? x[lane] : 0.0, xj2 = (DUAL && act) ? x2[lane] : 0.0;
 	const double dinv = act ? diaginv[lane] : 0.0, dinv2 = (DUAL && act) ? diaginv2[lane] : 0.0;
+	if constexpr (G == 64) {
 	// x <- inv(L') x : dof i pushes its value down to its ancestors j < i
 #pragma unroll
 	for (int i = NVM - 1; i >= 1; i--) {
@@ -874,6 +931,19 @@ DEVI void solve_dense16_impl(CModel m, const Env &e, double *x, const double *LD
 			xj -= A[i] * xi;  // A[i] == 0 in the lanes >= i
 			if (DUAL) xj2 -= B[i] * xi2;
 		}
+	}
+	} else {
+	// x <- inv(L') x : dof i pushes its value down to its ancestors j < i
+	(void)scr;
+	static_for<NVM - 1>([&](auto ic) {
+		constexpr int i = NVM - 1 - decltype(ic)::value;
+		if (i < nv) {
+			MJB_KEEP_BRANCH();
+			const double xi = group_bcast<G, i>(xj), xi2 = DUAL ? group_bcast<G, i>(xj2) : 0.0;  // x_i from lane i
+			xj -= A[i] * xi;  // A[i] == 0 in the lanes >= i
+			if (DUAL) xj2 -= B[i] * xi2;
+		}
+	});
 	}
 	xj *= dinv;
 	xj2 *= dinv2;
@@ -929,7 +999,7 @@ DEVI void dadr_load(const Env &e, CLayout L, int (&dl)[16])
 	}
 }
 
-template <int G> DEVI void solve(CModel m, const Env &e, double *x, const double *LD, const double *diaginv)
+template <int G> DEVI void solve(CModel m, const EnvLite &e, double *x, const double *LD, const double *diaginv)
 {
 	solve2<G>(m, e, x, LD, diaginv, x, LD, diaginv, false);
 }
