@@ -42,6 +42,33 @@ template <int G> DEVI void gsync()
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// (the `asm volatile("")` inside wave-uniform branches keeps them real scalar branches: without it the compiler
+//  if-converts the unrolled pivots into selects over the whole register matrix)
+#define MJB_KEEP_BRANCH() asm volatile("" ::: "memory")
+
+// value of lane I of this lane's 16-lane DPP row, one v_mov_b32_dpp row_newbcast per dword: what carries pivots and pivot rows
+// between the lanes of a 16-lane env group (G == 16: group == row; G == 64: the matrix sits in row 0).  Round 3: replaces the
+// LDS publish / wave-uniform read round trip (~110 cycles + two syncs per pivot) the factorisation and both sweeps of the solve
+// went through -- same values, same arithmetic, no memory.
+template <int I> DEVI double row_bcast16(double v)
+{
+	static_assert(I >= 0 && I < 16, "row_newbcast selects one of the 16 lanes of a row");
+	return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + I, 0xF, 0xF, true),
+	                        __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + I, 0xF, 0xF, true));
+}
+// ... one env per wavefront (G == 64, the matrix in lanes 0 - 15): the source lane is wave-uniform, v_readlane puts the value in a
+// scalar register pair that the fma reads directly
+template <int G, int I> DEVI double group_bcast(double v)
+{
+	if constexpr (G == 64)
+		return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), I), __builtin_amdgcn_readlane(__double2loint(v), I));
+	else
+		return row_bcast16<I>(v);
+}
+template <typename F, int... Is> DEVI void static_for_impl(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F> DEVI void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+
 // Optional per-stage cycle accounting (build with -DMJB_PROFILE -> libmjb_prof.so): env 0 / lane 0 adds the
 // s_memtime delta of every stage to DevState::prof[stage].
 #ifdef MJB_PROFILE
@@ -90,6 +117,7 @@ struct LaneConst {
 	int j_type, j_qa, j_da;  // lane = joint
 	double j_stiff, j_spring, j_damp;  // (spring reference / damping of a hinge or slide joint; ball / free joints walk the tables)
 	int sc_dst[3][2], sc_src[3][2];  // lane's plain sensor copies of the three stages in the layout of this launch (-1: none)
+	int anc[6];            // lane = body: its ancestors at distance 1, 2, 4, 8, 16 (0 = world or beyond): kinematics' pointer jumping
 	int j_body, j_root;    // lane = joint: its body and that body's root (comPos: cdof)
 	// lane = item of kinematics' phase D (joint / geom / site; njnt + ngeom + nsite <= 16, else k_kind = -1: table walk)
 	int k_kind, k_id, k_body, k_same;  // kind: 0 joint (k_body = the PARENT of the joint's body; k_same = joint is free), 1 geom, 2 site
@@ -282,6 +310,32 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 		double p[3], q[4];
 		ld3(p, loc + 7 * b);
 		ld4(q, loc + 7 * b + 3);
+		if constexpr (CACHE && G == 16) {
+			// one body per lane of a 16-lane env group: the ancestor's pose comes straight out of ITS lane's registers
+			// (ds_bpermute: no LDS storage, no sync), the ancestor indices out of this lane's (LaneConst::anc)
+			static_for<5>([&](auto rc) {
+				constexpr int r = decltype(rc)::value;
+				if (r < m.kin_rounds) {
+					MJB_KEEP_BRANCH();
+					const int A = act ? e.lc.anc[r] : 0;
+					const int addr = (int)(((threadIdx.x & 48u) | (unsigned int)A) << 2);
+					double pa[3], qa[4];
+#pragma unroll
+					for (int k = 0; k < 3; k++)
+						pa[k] = __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, __double2hiint(p[k])), __builtin_amdgcn_ds_bpermute(addr, __double2loint(p[k])));
+#pragma unroll
+					for (int k = 0; k < 4; k++)
+						qa[k] = __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, __double2hiint(q[k])), __builtin_amdgcn_ds_bpermute(addr, __double2loint(q[k])));
+					if (A) {
+						double Ma[9], v[3];
+						quat2mat_nocheck(Ma, qa);
+						matvec3(v, Ma, p);
+						p[0] = pa[0] + v[0]; p[1] = pa[1] + v[1]; p[2] = pa[2] + v[2];
+						qmul(q, qa, q);
+					}
+				}
+			});
+		} else {
 		int A = b ? m.body_anc[b] : 0;
 #pragma nounroll
 		for (int r = 0; r < m.kin_rounds; r++) {
@@ -302,6 +356,7 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 			}
 			A = An;
 			gsync<G>();
+		}
 		}
 		if (act) {
 			st3(xpos + 3 * b, p);
@@ -751,9 +806,6 @@ DEVI double group_bcast16(double v, int src)  // value of lane `src` of this lan
 	                        __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)));
 }
 
-// (the `asm volatile("")` inside wave-uniform branches keeps them real scalar branches: without it the compiler
-//  if-converts the unrolled pivots into selects over the whole register matrix)
-#define MJB_KEEP_BRANCH() asm volatile("" ::: "memory")
 
 // 1 / x to ~1 ulp: hardware seed + two Newton steps (the correctly rounded division costs 12 dependent instructions)
 DEVI double fast_rcp(double x)
@@ -763,28 +815,6 @@ DEVI double fast_rcp(double x)
 	r = fma(fma(-x, r, 1.0), r, r);
 	return r;
 }
-
-// value of lane I of this lane's 16-lane DPP row, one v_mov_b32_dpp row_newbcast per dword: what carries pivots and pivot rows
-// between the lanes of a 16-lane env group (G == 16: group == row; G == 64: the matrix sits in row 0).  Round 3: replaces the
-// LDS publish / wave-uniform read round trip (~110 cycles + two syncs per pivot) the factorisation and both sweeps of the solve
-// went through -- same values, same arithmetic, no memory.
-template <int I> DEVI double row_bcast16(double v)
-{
-	static_assert(I >= 0 && I < 16, "row_newbcast selects one of the 16 lanes of a row");
-	return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + I, 0xF, 0xF, true),
-	                        __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + I, 0xF, 0xF, true));
-}
-// ... one env per wavefront (G == 64, the matrix in lanes 0 - 15): the source lane is wave-uniform, v_readlane puts the value in a
-// scalar register pair that the fma reads directly
-template <int G, int I> DEVI double group_bcast(double v)
-{
-	if constexpr (G == 64)
-		return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), I), __builtin_amdgcn_readlane(__double2loint(v), I));
-	else
-		return row_bcast16<I>(v);
-}
-template <typename F, int... Is> DEVI void static_for_impl(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
-template <int N, typename F> DEVI void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 template <int G, bool DUAL, int NVM>
 DEVI void factor_dense16_impl(CModel m, const Env &e, const double *M, double *LD, double *di, const double *M2, double *LD2,
@@ -2410,6 +2440,11 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 			c.j_damp = (m.njnt && m.nv) ? m.dof_damping[c.j_da] : 0.0;
 		}
 		{
+			for (int r = 0; r < 6; r++) {  // (unconditional load at a clamped row + select: no divergent branch around a load into the cache)
+				const int rr = r < m.kin_rounds + 2 ? r : m.kin_rounds + 1;
+				const int v = m.body_anc[rr * m.nbody + b];
+				c.anc[r] = (b != 0 && r < m.kin_rounds + 2) ? v : 0;
+			}
 			const int jj = (m.njnt && e.lane < m.njnt) ? (int)e.lane : 0;
 			c.j_body = m.njnt ? m.jnt_bodyid[jj] : 0;
 			c.j_root = m.body_rootid[c.j_body];
