@@ -222,6 +222,10 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 	double *xanchor = f + L.xanchor, *xaxis = f + L.xaxis;
 	double *loc = f + L.kinloc;  // [nbody][7] local pose (pos, quat) of each body in its parent's frame
 	const int lane = e.lane;
+	// one body per lane of a 16-lane group (dense kernels): the body's pose travels from phase A through B to C in the lane's
+	// registers -- no LDS round trip, no sync between the phases (other lanes read it by ds_bpermute in phase B)
+	constexpr bool REG = SCAN && CACHE && G == 16;
+	[[maybe_unused]] double kp[3] = { 0, 0, 0 }, kq[4] = { 1, 0, 0, 0 };
 
 	// Phase A -- one body per lane: pose relative to the parent INCLUDING the joint motion, plus joint anchors
 	// and axes in the parent's frame (parked in xanchor / xaxis until phase D).  Also normalises the
@@ -295,10 +299,15 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 				}
 			}
 		}
-		st3(loc + 7 * b, p);
-		st4(loc + 7 * b + 3, q);
+		if constexpr (REG) {
+			for (int k = 0; k < 3; k++) kp[k] = p[k];
+			for (int k = 0; k < 4; k++) kq[k] = q[k];
+		} else {
+			st3(loc + 7 * b, p);
+			st4(loc + 7 * b + 3, q);
+		}
 	}
-	gsync<G>();
+	if constexpr (!REG) gsync<G>();
 	PROF(20);
 
 	if constexpr (SCAN) {
@@ -308,8 +317,13 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 		const bool act = lane < m.nbody;
 		const int b = act ? lane : 0;
 		double p[3], q[4];
-		ld3(p, loc + 7 * b);
-		ld4(q, loc + 7 * b + 3);
+		if constexpr (REG) {
+			for (int k = 0; k < 3; k++) p[k] = kp[k];
+			for (int k = 0; k < 4; k++) q[k] = kq[k];
+		} else {
+			ld3(p, loc + 7 * b);
+			ld4(q, loc + 7 * b + 3);
+		}
 		if constexpr (CACHE && G == 16) {
 			// one body per lane of a 16-lane env group: the ancestor's pose comes straight out of ITS lane's registers
 			// (ds_bpermute: no LDS storage, no sync), the ancestor indices out of this lane's (LaneConst::anc)
@@ -358,11 +372,17 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 			gsync<G>();
 		}
 		}
-		if (act) {
-			st3(xpos + 3 * b, p);
-			st4(xquat + 4 * b, q);
+		if constexpr (REG) {
+			if (act) st3(xpos + 3 * b, p);  // (phase C stores the normalised xquat)
+			for (int k = 0; k < 3; k++) kp[k] = p[k];
+			for (int k = 0; k < 4; k++) kq[k] = q[k];
+		} else {
+			if (act) {
+				st3(xpos + 3 * b, p);
+				st4(xquat + 4 * b, q);
+			}
+			gsync<G>();
 		}
-		gsync<G>();
 	} else {
 		// Phase B -- thin serial chain, replicated in every lane with the running parent pose in registers:
 		// xquat_i = xquat_p * lq_i,  xpos_i = xpos_p + R_p lp_i.  Only xpos / xquat are stored (7 doubles per body);
@@ -408,8 +428,13 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 	// Phase C -- one body per lane: normalise xquat, final xmat, inertial frame
 	for (int b = lane; b < m.nbody; b += G) {
 		double q[4], M[9], p[3];
-		ld4(q, xquat + 4 * b);
-		ld3(p, xpos + 3 * b);
+		if constexpr (REG) {
+			for (int k = 0; k < 3; k++) p[k] = kp[k];
+			for (int k = 0; k < 4; k++) q[k] = kq[k];
+		} else {
+			ld4(q, xquat + 4 * b);
+			ld3(p, xpos + 3 * b);
+		}
 		normalize4(q);
 		quat2mat(M, q);
 		st4(xquat + 4 * b, q);
