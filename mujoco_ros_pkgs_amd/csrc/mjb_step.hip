@@ -102,7 +102,7 @@ __shared__ unsigned long long mjb_prof_lds[64];
 struct LaneConst {
 	unsigned int dmlo, dmhi, smlo, smhi;  // ancestor-dof and subtree-body masks
 	int jntadr, jntnum, jtype, qa, simple, rootid;
-	double bpos[3], bquat[4], jaxis[3], jpos[3], q0, ipos[3], iquat[4], mass, inertia[3];
+	double bpos[3], bquat[4], jaxis[3], jpos[3], q0, ipos[3], iquat[4], mass, stmass, inertia[3];
 	// ... and of dof `lane` (nv <= 16): its body, and where the body velocity "before" the dof's joint comes from
 	int d_body, d_zero, d_simple, d_parent;
 	unsigned int d_bmlo, d_bmhi;  // bodies moved by the dof  // d_zero: translational dof of a free joint; d_simple: first joint of its body
@@ -541,6 +541,35 @@ template <int G, bool OBL> STAGE void com_pos(CModel m, CLayout L, const Env &e)
 	const int lane = e.lane;
 	// lane = body: mass-weighted sum over the bodies of its subtree (host-built mask) -- no walk up the tree, every
 	// lane reads the same xipos / mass sequence (LDS broadcast + scalar loads) and keeps what its mask selects
+	if constexpr (OBL && G == 16) {
+		// one body per lane of a 16-lane group: every body's inertial position and mass come out of ITS lane's registers by DPP row
+		// broadcasts (the same fma in the same order as the loop below: no scalar load per body, no LDS loop)
+		const int b = lane < m.nbody ? (int)lane : 0;
+		double xo[3];
+		ld3(xo, xipos + 3 * b);
+		const double mo = lane < m.nbody ? e.lc.mass : 0.0;
+		const unsigned int lo = e.lc.smlo;
+		double s0 = 0, s1 = 0, s2 = 0;
+		static_for<16>([&](auto ic) {
+			constexpr int i = decltype(ic)::value;
+			if (i < m.nbody) {
+				MJB_KEEP_BRANCH();
+				const double mi = ((lo >> i) & 1u) ? row_bcast16<i>(mo) : 0.0;
+				s0 += row_bcast16<i>(xo[0]) * mi;
+				s1 += row_bcast16<i>(xo[1]) * mi;
+				s2 += row_bcast16<i>(xo[2]) * mi;
+			}
+		});
+		if (lane < m.nbody) {
+			const double stm = e.lc.stmass;
+			if (stm < MJB_MINVAL) {
+				sc[3 * b] = xo[0]; sc[3 * b + 1] = xo[1]; sc[3 * b + 2] = xo[2];
+			} else {
+				const double inv = 1.0 / fmax(MJB_MINVAL, stm);
+				sc[3 * b] = s0 * inv; sc[3 * b + 1] = s1 * inv; sc[3 * b + 2] = s2 * inv;
+			}
+		}
+	} else
 	for (int b = lane; b < m.nbody; b += G) {
 		const unsigned int lo = OBL ? e.lc.smlo : (unsigned int)m.body_submask[2 * b], hi = OBL ? e.lc.smhi : (unsigned int)m.body_submask[2 * b + 1];
 		double s0 = 0, s1 = 0, s2 = 0;
@@ -2418,6 +2447,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 		}
 		c.rootid = m.body_rootid[b];
 		c.mass = m.body_mass[b];
+		c.stmass = m.body_subtreemass[b];
 		for (int k = 0; k < 3; k++) c.inertia[k] = m.body_inertia[3 * b + k];
 		const int dd = e.lane < m.nv ? e.lane : 0;
 		c.d_body = m.nv ? m.dof_bodyid[dd] : 0;
