@@ -34,7 +34,10 @@ ALGO_BYTES_PER_ENV_STEP = {"franka_like": 712, "franka_table": 1072, "shadow_han
 #                      default physics steps per launch, BASELINE config number)
 WORKLOADS = {
     "franka_like": ("BASELINE configs[1]: Franka-Panda-like 9-DoF arm, no contacts", 0.5 * 87.0, 4096, 1000, 2),
-    "franka_table": ("BASELINE configs[2]: Franka-like arm + table + cube contacts", 0.5 * 87.0, 4096, 200, 3),
+    # (1000 steps per launch since r03, like configs[1]: a fused launch ends with its SLOWEST env's serial chain of steps -- envs
+    #  pressing into the table run PGS to its 100-sweep cap for a while, ~300 us per step -- and at 200 steps that tail set the
+    #  launch time; per-launch series and the 200 / 500 / 1000 sweep: profiles/r03_cfg3_launch_length.txt, tools/launch_series.py)
+    "franka_table": ("BASELINE configs[2]: Franka-like arm + table + cube contacts", 0.5 * 87.0, 4096, 1000, 3),
     "shadow_hand_like": ("BASELINE configs[4]: Shadow-Hand-like 24-DoF hand + in-hand cube (Newton, elliptic cones)", 0.1, 1024, 100, 5),
 }
 CONFIG_MODEL = {2: "franka_like", 3: "franka_table", 4: "franka_table", 5: "shadow_hand_like"}

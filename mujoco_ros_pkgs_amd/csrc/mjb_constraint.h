@@ -971,15 +971,20 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 		EPROF(26);
 #endif
 		if (n == 0) continue;
+		// The lanes of a round hold items of different kinds, and a wave runs divergent branches one after the other: the branches
+		// only gather what differs per kind (J row, solver parameters, the position the impedance is evaluated at); the gain
+		// evaluation itself -- getsolparam + getimpedance, a dozen fp64 divisions -- runs ONCE for all kinds, then the stores.
+		double solref[2] = { 0, 0 }, solimp[5] = { 0, 0, 0, 0, 0 }, ipos = 0, imarg = 0;
+		double cpos[6] = { 0, 0, 0, 0, 0, 0 }, diag[6] = { 0, 0, 0, 0, 0, 0 };  // equality rows: residuals, diagApprox
+		double dist2 = 0;   // second side of a limit (both sides active: degenerate range)
+		int idv = 0;        // efc_id of the item's rows
 		if (it < neq) {
 			const int eq = it, type = m.eq_type[eq], id0 = m.eq_obj1id[eq], id1 = m.eq_obj2id[eq];
-			double cpos[6] = { 0, 0, 0, 0, 0, 0 }, diag[6] = { 0, 0, 0, 0, 0, 0 };
+			idv = eq;
 			if (type == MJB_EQ_JOINT) {
 				const int a1 = m.jnt_qposadr[id0], d1 = m.jnt_dofadr[id0];
-				const double *pc = nullptr;
 				double c5[5];
 				for (int k = 0; k < 5; k++) c5[k] = f[L.eqparam + 19 * eq + 1 + k];
-				(void)pc;
 				double poly = c5[0], deriv = 0;
 				double *row = jrow(off);
 				for (int k = 0; k < nv; k++) row[k] = 0;
@@ -1029,19 +1034,15 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 			double nrm = 0;
 			for (int k = 0; k < 6; k++) nrm += cpos[k] * cpos[k];
 			nrm = sqrt(nrm);
-			const double solref[2] = { f[L.eqparam + 19 * eq + 12], f[L.eqparam + 19 * eq + 13] };
-			double solimp[5];
+			solref[0] = f[L.eqparam + 19 * eq + 12];
+			solref[1] = f[L.eqparam + 19 * eq + 13];
 			for (int k = 0; k < 5; k++) solimp[k] = f[L.eqparam + 19 * eq + 14 + k];
-			for (int k = 0; k < 6; k++) {
-				if (k >= n) break;
-				row_params_x(m, L, f, off + k, cpos[k], 0.0, solref, solimp, diag[k], n > 1 ? nrm : cpos[0]);
-				fi[L.efc_id + off + k] = eq;
-				fi[L.efc_type + off + k] = MJB_CNSTR_EQUALITY;
-			}
+			ipos = n > 1 ? nrm : cpos[0];  // (the rows of a connect / weld share the norm of their residual)
 		} else if (it < neq + nfr) {
 			// dry friction (mj_instantiateFriction): J = e_dof or the tendon's moment arms, pos = margin = 0, |force| <= frictionloss
 			const bool isdof = it < neq + nfd;
 			const int i = isdof ? it - neq : it - neq - nfd;
+			idv = i;
 			double *row = jrow(off);
 			for (int k = 0; k < nv; k++) row[k] = 0;
 			if (isdof) {
@@ -1052,58 +1053,42 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 			}
 			const mjb_cdptr sr = isdof ? m.dof_solref + 2 * i : m.tendon_solref_fri + 2 * i;
 			const mjb_cdptr si = isdof ? m.dof_solimp + 5 * i : m.tendon_solimp_fri + 5 * i;
-			const double solref[2] = { sr[0], sr[1] };
-			double solimp[5];
+			solref[0] = sr[0];
+			solref[1] = sr[1];
 			for (int k = 0; k < 5; k++) solimp[k] = si[k];
-			row_params(m, L, f, off, 0.0, 0.0, solref, solimp, isdof ? MP_DOF_INVW(m, e, i) : MP_TEN_INVW(m, e, i));
-			f[L.efc_frictionloss + off] = isdof ? m.dof_frictionloss[i] : m.tendon_frictionloss[i];
-			fi[L.efc_id + off] = i;
-			fi[L.efc_type + off] = isdof ? MJB_CNSTR_FRICTION_DOF : MJB_CNSTR_FRICTION_TENDON;
-		} else if (it < neq + nfr + m.njnt) {
-			const int j = it - neq - nfr, da = m.jnt_dofadr[j];
-			const double value = f[L.qpos + m.jnt_qposadr[j]], margin = m.jnt_margin[j];
-			double solref[2] = { m.jnt_solref[2 * j], m.jnt_solref[2 * j + 1] }, solimp[5];
-			for (int k = 0; k < 5; k++) solimp[k] = m.jnt_solimp[5 * j + k];
-			int r = off;
-			for (int side = -1; side <= 1; side += 2) {
-				const double dist = side * (m.jnt_range[2 * j + (side + 1) / 2] - value);
-				if (dist < margin) {
-					double *row = jrow(r);
-					for (int k = 0; k < nv; k++) row[k] = 0;
-					row[da] = -side;
-					row_params(m, L, f, r, dist, margin, solref, solimp, MP_DOF_INVW(m, e, da));
-					fi[L.efc_id + r] = j;
-					fi[L.efc_type + r] = MJB_CNSTR_LIMIT_JOINT;
-					r++;
-				}
-			}
+			diag[0] = isdof ? MP_DOF_INVW(m, e, i) : MP_TEN_INVW(m, e, i);
 		} else if (it < neq + nfr + m.njnt + nten) {
-			const int t = it - neq - nfr - m.njnt;
-			const double value = f[L.ten_length + t], margin = m.tendon_margin[t];
-			double solref[2] = { m.tendon_solref_lim[2 * t], m.tendon_solref_lim[2 * t + 1] }, solimp[5];
-			for (int k = 0; k < 5; k++) solimp[k] = m.tendon_solimp_lim[5 * t + k];
+			// joint / tendon limit: one row per active side, lower side first
+			const bool isj = it < neq + nfr + m.njnt;
+			const int j = isj ? it - neq - nfr : it - neq - nfr - m.njnt;
+			idv = j;
+			const double value = isj ? f[L.qpos + m.jnt_qposadr[j]] : f[L.ten_length + j];
+			imarg = isj ? m.jnt_margin[j] : m.tendon_margin[j];
+			const mjb_cdptr rng = isj ? m.jnt_range + 2 * j : m.tendon_range + 2 * j;
+			const mjb_cdptr sr = isj ? m.jnt_solref + 2 * j : m.tendon_solref_lim + 2 * j;
+			const mjb_cdptr si = isj ? m.jnt_solimp + 5 * j : m.tendon_solimp_lim + 5 * j;
+			solref[0] = sr[0];
+			solref[1] = sr[1];
+			for (int k = 0; k < 5; k++) solimp[k] = si[k];
+			diag[0] = isj ? MP_DOF_INVW(m, e, m.jnt_dofadr[j]) : MP_TEN_INVW(m, e, j);
+			const double dlo = -1 * (rng[0] - value), dhi = 1 * (rng[1] - value);
 			int r = off;
 			for (int side = -1; side <= 1; side += 2) {
-				const double dist = side * (m.tendon_range[2 * t + (side + 1) / 2] - value);
-				if (dist < margin) {
+				if ((side < 0 ? dlo : dhi) < imarg) {
 					double *row = jrow(r);
 					for (int k = 0; k < nv; k++) row[k] = 0;
-					for (int w = m.tendon_adr[t]; w < m.tendon_adr[t] + m.tendon_num[t]; w++)
-						row[m.jnt_dofadr[m.wrap_objid[w]]] += -side * m.wrap_prm[w];
-					row_params(m, L, f, r, dist, margin, solref, solimp, MP_TEN_INVW(m, e, t));
-					fi[L.efc_id + r] = t;
-					fi[L.efc_type + r] = MJB_CNSTR_LIMIT_TENDON;
+					if (isj) row[m.jnt_dofadr[j]] = -side;
+					else
+						for (int w = m.tendon_adr[j]; w < m.tendon_adr[j] + m.tendon_num[j]; w++)
+							row[m.jnt_dofadr[m.wrap_objid[w]]] += -side * m.wrap_prm[w];
 					r++;
 				}
 			}
+			ipos = dlo < imarg ? dlo : dhi;
+			dist2 = dhi;
 		} else {
 			const int c = it - neq - nfr - m.njnt - nten;
-			const int dim = fi[L.contact_dim + c];
-			const double dist = f[L.contact_dist + c], cm = f[L.contact_includemargin + c];
-			const int b1 = m.geom_bodyid[fi[L.contact_geom + 2 * c]], b2 = m.geom_bodyid[fi[L.contact_geom + 2 * c + 1]];
-			const double tran = MP_BODY_INVW(m, e, 2 * b1) + MP_BODY_INVW(m, e, 2 * b2);
-			const double rot = MP_BODY_INVW(m, e, 2 * b1 + 1) + MP_BODY_INVW(m, e, 2 * b2 + 1);
-			double solref[2], solimp[5], fri[5];
+			idv = c;
 			if (L.contact_solref >= 0) {
 				solref[0] = f[L.contact_solref + 2 * c];
 				solref[1] = f[L.contact_solref + 2 * c + 1];
@@ -1114,12 +1099,45 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 				solref[1] = pd[11];
 				for (int k = 0; k < 5; k++) solimp[k] = pd[12 + k];
 			}
-			for (int k = 0; k < 5; k++) fri[k] = f[L.contact_friction + 5 * c + k];
 			fi[L.contact_efc_address + c] = off;
-			(void)rot;
 			// ONE impedance evaluation per contact: its rows share solref / solimp, and either all of them sit at
 			// (pos, margin) = (dist, includemargin) [frictionless, pyramidal] or the friction rows sit at (0, 0) [elliptic]
-			const RowGain g0 = row_gain(m, solref, solimp, dist, cm);
+			ipos = f[L.contact_dist + c];
+			imarg = f[L.contact_includemargin + c];
+		}
+		const RowGain g0 = row_gain(m, solref, solimp, ipos, imarg);
+		if (it < neq) {
+			for (int k = 0; k < 6; k++) {
+				if (k >= n) break;
+				row_store(L, f, off + k, cpos[k], 0.0, g0, row_R(g0, diag[k]));
+				fi[L.efc_id + off + k] = idv;
+				fi[L.efc_type + off + k] = MJB_CNSTR_EQUALITY;
+			}
+		} else if (it < neq + nfr) {
+			const bool isdof = it < neq + nfd;
+			row_store(L, f, off, 0.0, 0.0, g0, row_R(g0, diag[0]));
+			f[L.efc_frictionloss + off] = isdof ? m.dof_frictionloss[idv] : m.tendon_frictionloss[idv];
+			fi[L.efc_id + off] = idv;
+			fi[L.efc_type + off] = isdof ? MJB_CNSTR_FRICTION_DOF : MJB_CNSTR_FRICTION_TENDON;
+		} else if (it < neq + nfr + m.njnt + nten) {
+			const int type = it < neq + nfr + m.njnt ? MJB_CNSTR_LIMIT_JOINT : MJB_CNSTR_LIMIT_TENDON;
+			row_store(L, f, off, ipos, imarg, g0, row_R(g0, diag[0]));
+			fi[L.efc_id + off] = idv;
+			fi[L.efc_type + off] = type;
+			if (n == 2) {  // both sides within the margin
+				const RowGain g1 = row_gain(m, solref, solimp, dist2, imarg);
+				row_store(L, f, off + 1, dist2, imarg, g1, row_R(g1, diag[0]));
+				fi[L.efc_id + off + 1] = idv;
+				fi[L.efc_type + off + 1] = type;
+			}
+		} else {
+			const int c = idv;
+			const int dim = fi[L.contact_dim + c];
+			const double dist = ipos, cm = imarg;
+			const int b1 = m.geom_bodyid[fi[L.contact_geom + 2 * c]], b2 = m.geom_bodyid[fi[L.contact_geom + 2 * c + 1]];
+			const double tran = MP_BODY_INVW(m, e, 2 * b1) + MP_BODY_INVW(m, e, 2 * b2);
+			double fri[5];
+			for (int k = 0; k < 5; k++) fri[k] = f[L.contact_friction + 5 * c + k];
 			if (dim == 1) {
 				row_store(L, f, off, dist, cm, g0, row_R(g0, tran));
 				fi[L.efc_id + off] = c;

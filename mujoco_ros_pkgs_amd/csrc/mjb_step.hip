@@ -982,6 +982,9 @@ STAGE void factor_dense16(CModel m, const Env &e, const double *M, double *LD, d
 }
 
 // x <- M^-1 x with the factor's columns re-read from LDS into registers; x lives one element per lane
+#ifndef MJB_SOLVE64_LDS
+#define MJB_SOLVE64_LDS 0
+#endif
 template <int G, bool DUAL, int NVM>
 DEVI void solve_dense16_impl(CModel m, const Env &e, double *x, const double *LD, const double *diaginv, double *x2,
                              const double *LD2, const double *diaginv2, const int (&dadr)[16], double *scr)
@@ -998,7 +1001,7 @@ DEVI void solve_dense16_impl(CModel m, const Env &e, double *x, const double *LD
 	}
 	double xj = act ? x[lane] : 0.0, xj2 = (DUAL && act) ? x2[lane] : 0.0;
 	const double dinv = act ? diaginv[lane] : 0.0, dinv2 = (DUAL && act) ? diaginv2[lane] : 0.0;
-	if constexpr (G == 64) {
+	if constexpr (G == 64 && MJB_SOLVE64_LDS) {
 	// x <- inv(L') x : dof i pushes its value down to its ancestors j < i
 #pragma unroll
 	for (int i = NVM - 1; i >= 1; i--) {
