@@ -870,6 +870,9 @@ DEVI double fast_rcp(double x)
 	return r;
 }
 
+#ifndef MJB_FACTOR64_LDS
+#define MJB_FACTOR64_LDS 1  // (0: v_readlane broadcasts -- more issue slots than the LDS round trips the co-resident wave hides: 185.1 -> 186.9 ms on config 3)
+#endif
 template <int G, bool DUAL, int NVM>
 DEVI void factor_dense16_impl(CModel m, const Env &e, const double *M, double *LD, double *di, const double *M2, double *LD2,
                               double *di2, const int (&dadr)[16], double *scr)
@@ -885,7 +888,7 @@ DEVI void factor_dense16_impl(CModel m, const Env &e, const double *M, double *L
 		B[i] = a >= 0 ? vb : 0.0;
 	}
 	double myinv = 0, myinv2 = 0;
-	if constexpr (G == 64) {
+	if constexpr (G == 64 && MJB_FACTOR64_LDS) {
 	// (one env per wavefront, 256- / 512-register constrained kernels: the LDS round trip stays -- the broadcast forms below cost the
 	//  capped PGS kernel registers, measured 42.9 -> 44.2 ms on config 3)
 #pragma unroll
@@ -981,9 +984,89 @@ STAGE void factor_dense16(CModel m, const Env &e, const double *M, double *LD, d
 	}
 }
 
+// ---- the same for 16 < nv <= 32 in the 512-register constrained kernels (one env per wavefront, ONE wave per SIMD: every LDS
+// round trip of the sparse factor2 -- a pivot's round per dof, ~1.3 k cycles each -- is a bare stall there).  Lane c < 32 keeps
+// column c of M (and of M + h B) in 32 + 32 statically indexed registers, gathered through the host table M_sym; the pivot row
+// travels by v_readlane.  The tree's zeros are skipped four columns at a time on the VALUES (a zero multiplier makes the update
+// a no-op, so skipping it is exact): v_cmp -> wave mask -> scalar tests, no table.
+template <int G, bool DUAL>
+DEVI void factor_dense32_impl(CModel m, const Env &e, const double *M, double *LD, double *di, const double *M2, double *LD2,
+                              double *di2)
+{
+	static_assert(G == 64, "one env per wavefront");
+	const int lane = e.lane, nv = m.nv;
+	const int c = lane < 32 ? lane : 0;  // (lanes 32 .. 63 mirror lane 0 and store nothing)
+	double A[32], B[32];
+#pragma unroll
+	for (int i = 0; i < 32; i++) {
+		const int a = m.M_sym[32 * i + c], ac = a >= 0 ? a : 0;
+		const bool has = a >= 0 && i >= c;
+		const double va = M[ac], vb = DUAL ? M2[ac] : 0.0;
+		A[i] = has ? va : 0.0;
+		B[i] = has ? vb : 0.0;
+	}
+	double myinv = 0, myinv2 = 0;
+	static_for<32>([&](auto kc) {
+		constexpr int k = 31 - decltype(kc)::value;
+		if (k < nv) {
+			MJB_KEEP_BRANCH();
+			const double dk = group_bcast<64, k>(A[k]), dk2 = DUAL ? group_bcast<64, k>(B[k]) : 1.0;
+			const double inv = fast_rcp(dk), inv2 = DUAL ? fast_rcp(dk2) : 0.0;
+			const double lkj = A[k] * inv, lkj2 = B[k] * inv2;  // scaled pivot-row entry of this lane's column (lane < k)
+			const unsigned int live = (unsigned int)__ballot(A[k] != 0.0);  // columns i with M(k, i) != 0
+			static_for<(k + 3) / 4>([&](auto gc) {
+				constexpr int i0 = 4 * decltype(gc)::value;
+				if ((live >> i0) & 0xFu) {
+					MJB_KEEP_BRANCH();
+					static_for<4>([&](auto qc) {
+						constexpr int i = i0 + decltype(qc)::value;
+						if constexpr (i < k) {
+							A[i] -= group_bcast<64, i>(A[k]) * lkj;  // unscaled M(k, i), held by lane i
+							if (DUAL) B[i] -= group_bcast<64, i>(B[k]) * lkj2;
+						}
+					});
+				}
+			});
+			if (lane == k) {
+				myinv = inv;
+				myinv2 = inv2;
+			} else {
+				A[k] = lkj;
+				B[k] = lkj2;
+			}
+		}
+	});
+#pragma unroll
+	for (int i = 0; i < 32; i++) {
+		const int a = m.M_sym[32 * i + c];
+		if (a >= 0 && i >= c && lane < 32) {
+			LD[a] = A[i];
+			if (DUAL) LD2[a] = B[i];
+		}
+	}
+	if (lane < nv) {
+		di[lane] = myinv;
+		if (DUAL) di2[lane] = myinv2;
+	}
+	gsync<G>();
+}
+
+template <int G>
+STAGE void factor_dense32(CModel m, const Env &e, const double *M, double *LD, double *di, const double *M2, double *LD2, double *di2,
+                          bool dual)
+{
+	if (dual) {
+		MJB_KEEP_BRANCH();
+		factor_dense32_impl<G, true>(m, e, M, LD, di, M2, LD2, di2);
+	} else {
+		MJB_KEEP_BRANCH();
+		factor_dense32_impl<G, false>(m, e, M, LD, di, M2, LD2, di2);
+	}
+}
+
 // x <- M^-1 x with the factor's columns re-read from LDS into registers; x lives one element per lane
 #ifndef MJB_SOLVE64_LDS
-#define MJB_SOLVE64_LDS 0
+#define MJB_SOLVE64_LDS 0  // (1: the LDS round trips of r02 -- 43.3 -> 42.1 ms per 200 steps of config 3 without them)
 #endif
 template <int G, bool DUAL, int NVM>
 DEVI void solve_dense16_impl(CModel m, const Env &e, double *x, const double *LD, const double *diaginv, double *x2,
@@ -2094,6 +2177,9 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 				factor_dense16<G, 16>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi,
 				                      m.eulerdamp != 0, dl, e.f + L.crbbuf);
 			});
+		else if ((CON >= 2 && CON <= 4) && P->m.nv <= 32)  // (the 512-register Newton kernels, like TRI32 below)
+			VIEW(P, compact, factor_dense32<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi,
+			                                   m.eulerdamp != 0));
 		else
 			VIEW(P, compact, factor2<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi,
 			                            m.eulerdamp != 0));
