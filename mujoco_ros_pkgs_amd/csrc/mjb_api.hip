@@ -207,6 +207,12 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact, int jrows_req = 
 	//   fwd_acceleration, Euler:     the dense-triangle scratch (tri | solvescr | eulerx) right below efc_J, inside R
 	//   solver only:                 nwt_H | nwt_vec | nwt_row | nwt_hc from the START of X (over D and the head of R)
 	const bool xl = u_ok && d.solver == MJB_SOL_NEWTON && d.nv <= 32;
+	// ... and, when the frame holds only `jrows` rows of efc_J (kernel variant 4), every other per-row array is capped at the same
+	// count: an env-step with more rows keeps all of its row data in the env's block of DevState::efc_Jg (mjb_dev.h, RowBlock).
+	// Config 5: 53.0 -> 40.9 KB = four envs per CU, one per SIMD.
+	const int rcap = (xl && jrows < d.nefcmax) ? jrows : d.nefcmax;
+	L.rcap = rcap;
+	L.hcrow = (rcap < d.nefcmax) ? 1 : 0;
 	std::vector<int> d_members, p2_members;
 	int fsize[MJB_F_COUNT];
 	for (const FieldInfo &fi : kFields) {
@@ -223,6 +229,9 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact, int jrows_req = 
 		const bool in_b = alias_b && (idx == MJB_F_ximat || idx == MJB_F_cvel || idx == MJB_F_cdof_dot);
 		if (compact && idx == MJB_F_xfrc_applied) n = 0;
 		if (idx == MJB_F_efc_J && n > 0) n = jrows * d.nv;
+		if (rcap < d.nefcmax && n > 0 && (idx == MJB_F_efc_D || idx == MJB_F_efc_aref || idx == MJB_F_efc_b || idx == MJB_F_efc_force ||
+		                                  idx == MJB_F_efc_frictionloss || idx == MJB_F_efc_type || idx == MJB_F_efc_id))
+			n = n / d.nefcmax * rcap;
 		fsize[idx] = n;
 		const bool gone = lean && (idx == MJB_F_efc_pos || idx == MJB_F_efc_margin || idx == MJB_F_efc_KBIP || idx == MJB_F_efc_vel ||
 		                           (idx == MJB_F_efc_D && d.solver == MJB_SOL_PGS && !ell_con) || (idx == MJB_F_efc_R && primal) ||
@@ -281,7 +290,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact, int jrows_req = 
 	L.nwt_vec = off;
 	off += newton ? 5 * d.nv : 0;  // qacc | M qacc | grad | search | (CG: M^-1 grad)
 	L.nwt_row = off;
-	off += newton ? 3 * d.nefcmax : 0;
+	off += newton ? 3 * rcap : 0;
 	L.nwt_hc = off;
 	// cone blocks: the primal solvers size them by the model's largest contact dimension (config 5: condim 4 -> 16 doubles instead
 	// of 36; at least 10, the line-search constants a contact parks there); PGS keeps its 6 x 6 blocks of AR
@@ -293,7 +302,8 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact, int jrows_req = 
 		L.hcd = std::min(6, maxdim);
 		L.hcs = std::max(L.hcd * L.hcd, 10);
 	}
-	off += ((newton || (d.nefcmax > 0 && d.solver == MJB_SOL_PGS)) && d.cone == MJB_CONE_ELLIPTIC) ? L.hcs * d.nconmax : 0;  // (PGS: the contacts' blocks of AR)
+	// (hcrow: a contact's block sits at hcd * its first row -- rows, not contacts, bound the solver that runs on this frame)
+	off += ((newton || (d.nefcmax > 0 && d.solver == MJB_SOL_PGS)) && d.cone == MJB_CONE_ELLIPTIC) ? (L.hcrow ? L.hcd * rcap : L.hcs * d.nconmax) : 0;  // (PGS: the contacts' blocks of AR)
 	const int n_nwt = off - off_before_nwt;  // nwt_M | nwt_H | nwt_vec | nwt_row | nwt_hc
 	if (xl) off = off_before_nwt;            // (X layout: they overlay the head of X, placed below)
 	L.gravity = off;
@@ -353,7 +363,11 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact, int jrows_req = 
 		int n_p2 = fsize[MJB_F_efc_J];
 		for (int id : p2_members) n_p2 += fsize[id];
 		const int n_scr = ntri + 32 + d.nv;
-		int jstart = std::max(x0 + n_nwt, a0 + n_scr);   // the solver's arrays and the triangle scratch both end below efc_J
+		// (the triangle scratch of fwd_acceleration / Euler: on the contact arrays at the end of D when they are large enough --
+		//  dist | pos | frame | includemargin are contiguous and dead after make_constraint, while qM / qLD next to them are still
+		//  read -- otherwise at the start of R)
+		const bool tri_in_d = 14 * d.nconmax >= n_scr;
+		int jstart = std::max(x0 + n_nwt, tri_in_d ? a0 : a0 + n_scr);  // the solver's arrays and the triangle scratch both end below efc_J, which never reaches into D (make_constraint reads cdof and the contacts while it writes J)
 		if (jstart + n_p2 > off) off = jstart + n_p2;
 		jstart = off - n_p2;                             // ... which sits at the end of X
 		L.efc_J = jstart;
@@ -364,7 +378,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact, int jrows_req = 
 				o += fsize[id];
 			}
 		}
-		L.tri = jstart - n_scr;
+		L.tri = tri_in_d ? L.contact_dist : jstart - n_scr;
 		L.solvescr = L.tri + ntri;
 		L.eulerx = L.solvescr + 32;
 		{
@@ -435,7 +449,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact, int jrows_req = 
 	L.iscratch = ioff;
 	{
 		int a = d.ncollpair, b = d.neq + d.nv + d.njnt + 2 * d.ntendon + d.nconmax;
-		if (newton && d.nefcmax > a) a = d.nefcmax;  // (the primal solvers park one int of row metadata per constraint row here)
+		if (newton && rcap > a) a = rcap;  // (the primal solvers park one int of row metadata per constraint row here)
 		ioff += a > b ? a : b;
 	}
 	L.dadr = ioff;
@@ -446,6 +460,42 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact, int jrows_req = 
 
 int layout_bytes(const FrameLayout &L) { return ((L.ndouble * 8 + L.nint * 4) + 15) & ~15; }
 
+// development knob MJB_DEBUG_LAYOUT: every field's offset in the fused frame, sorted (doubles, then ints)
+void dump_layout(const mjb_model *M, const FrameLayout &L)
+{
+	const int *slots[] = {
+#define MJB_DS(name, rows, cols) &L.name,
+#define MJB_DD(name, rows, cols) &L.name,
+#define MJB_DD2(name, rows, cols) &L.name,
+#define MJB_DI(name, rows, cols) &L.name,
+#include "../../include/mjb_data_fields.def"
+#undef MJB_DS
+#undef MJB_DD
+#undef MJB_DD2
+#undef MJB_DI
+	};
+	std::vector<std::pair<int, std::string>> dd, ii;
+	for (int i = 0; i < MJB_F_COUNT; i++)
+		if (*slots[i] >= 0) (kFields[i].kind == 3 ? ii : dd).push_back({ *slots[i], kFields[i].name });
+	const std::pair<int, const char *> extra[] = { { L.MhB, "MhB" }, { L.qH, "qH" }, { L.qHdi, "qHdi" }, { L.nwt_M, "nwt_M" }, { L.nwt_H, "nwt_H" },
+		{ L.nwt_vec, "nwt_vec" }, { L.nwt_row, "nwt_row" }, { L.nwt_hc, "nwt_hc" }, { L.gravity, "gravity" }, { L.gfriction, "gfriction" },
+		{ L.eqparam, "eqparam" }, { L.cwrench, "cwrench" }, { L.kinloc, "kinloc" }, { L.crbbuf, "crbbuf" }, { L.eulerx, "eulerx" },
+		{ L.tri, "tri" }, { L.solvescr, "solvescr" }, { L.bbscr, "bbscr" } };
+	for (auto &x : extra)
+		if (x.first >= 0) dd.push_back({ x.first, std::string("*") + x.second });
+	ii.push_back({ L.iscratch, "*iscratch" });
+	ii.push_back({ L.dadr, "*dadr" });
+	std::sort(dd.begin(), dd.end());
+	std::sort(ii.begin(), ii.end());
+	fprintf(stderr, "mjb fused layout: %d bytes, jrows %d, hcs %d, hcd %d, ndouble %d, nint %d, nstate %d\n doubles:", layout_bytes(L), L.jrows, L.hcs,
+	        L.hcd, L.ndouble, L.nint, L.nstate);
+	for (auto &x : dd) fprintf(stderr, " %s@%d", x.second.c_str(), x.first);
+	fprintf(stderr, "\n ints:");
+	for (auto &x : ii) fprintf(stderr, " %s@%d", x.second.c_str(), x.first);
+	fprintf(stderr, "\n");
+	(void)M;
+}
+
 // The fused frame of kernel variant 4 (Newton, capacity > 128 rows) keeps only `jrows` rows of efc_J in LDS (the rest, and all of J
 // of an env-step with more rows, live in DevState::efc_Jg).  Residency beats the price of the HBM path (measured 10 % on the steps
 // that take it): pick the row count that lets the most envs share a CU's LDS, and the largest such.
@@ -453,7 +503,10 @@ void choose_fused_layout(mjb_model *M)
 {
 	compute_layout(M, M->Lc, true);
 	const mjb_model_desc &d = M->h;
-	if (!(d.solver == MJB_SOL_NEWTON && d.nefcmax > 128) || getenv("MJB_DEBUG_JROWS")) return;
+	if (!(d.solver == MJB_SOL_NEWTON && d.nefcmax > 128) || getenv("MJB_DEBUG_JROWS")) {
+		if (getenv("MJB_DEBUG_LAYOUT")) dump_layout(M, M->Lc);
+		return;
+	}
 	auto occ = [&](int jr) {
 		FrameLayout t{};
 		compute_layout(M, t, true, jr);
@@ -467,8 +520,7 @@ void choose_fused_layout(mjb_model *M)
 		for (pick = 60; pick > 16 && occ(pick) < best; pick -= 4) {}
 	compute_layout(M, M->Lc, true, pick);
 	if (getenv("MJB_DEBUG_LAYOUT"))  // development knob
-		fprintf(stderr, "mjb fused layout: %d bytes, jrows %d, efc_J @%d, tri @%d, nwt_H @%d, nwt_hc @%d (stride %d), cdof @%d, ndouble %d, nint %d\n",
-		        layout_bytes(M->Lc), M->Lc.jrows, M->Lc.efc_J, M->Lc.tri, M->Lc.nwt_H, M->Lc.nwt_hc, M->Lc.hcs, M->Lc.cdof, M->Lc.ndouble, M->Lc.nint);
+		dump_layout(M, M->Lc);
 }
 
 // Sensors whose value is a plain copy of frame doubles (joint / actuator scalars, clock, subtree com, global
@@ -1216,8 +1268,8 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 		s.sched = dev_alloc<int>((size_t)nenv + 1);
 		ok = ok && s.sched;
 	}
-	if (h.solver == MJB_SOL_NEWTON && h.nefcmax > 128) {  // kernel variant 4: efc_J of the env-steps beyond the fused frame's 64 rows
-		s.efc_Jg = dev_alloc<double>((size_t)nenv * h.nefcmax * h.nv);
+	if (h.solver == MJB_SOL_NEWTON && h.nefcmax > 128) {  // kernel variant 4: row data of the env-steps beyond the fused frame's 64 rows
+		s.efc_Jg = dev_alloc<double>((size_t)nenv * mjb_rowblock_doubles(h.nefcmax, h.nv, h.nconmax, M->Lc.hcs));
 		ok = ok && s.efc_Jg;
 	}
 	if (h.solver == MJB_SOL_PGS && h.nv <= 16 && h.nefcmax > 64) {

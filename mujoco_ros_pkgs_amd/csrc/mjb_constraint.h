@@ -897,10 +897,45 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 	double *f = e.f;
 	int *fi = e.fi;
 	const int lane = e.lane, nv = m.nv;
-	[[maybe_unused]] double *Jg = (TAG == 4 && s.efc_Jg) ? s.efc_Jg + (size_t)e.env * m.nefcmax * nv : nullptr;
+	[[maybe_unused]] RowBlock gb{};
+	if constexpr (TAG == 4)
+		if (s.efc_Jg) gb = mjb_rowblock(s.efc_Jg + (size_t)e.env * mjb_rowblock_doubles(m.nefcmax, nv, m.nconmax, L.hcs), m.nefcmax, nv, m.nconmax, L.hcs);
+	[[maybe_unused]] double *Jg = gb.J;
 	auto jrow = [&](int r) -> double * {  // row r of efc_J
 		if constexpr (TAG == 4) return r < L.jrows ? f + L.efc_J + r * nv : Jg + (size_t)r * nv;
 		else return f + L.efc_J + r * nv;
+	};
+	// the other per-row arrays: rows >= L.rcap (X-layout fused frame of variant 4 only) go to the env's block in HBM
+	auto rstore = [&](int i, double pos, double margin, const RowGain &g, double R) {
+		if constexpr (TAG == 4) {
+			if (i >= L.rcap) {  // (a lean primal frame: D, and aref / b as row_store parks them)
+				gb.D[i] = 1.0 / R;
+				gb.aref[i] = g.K * g.imp * (pos - margin);
+				gb.b[i] = g.B;
+				return;
+			}
+		}
+		row_store(L, f, i, pos, margin, g, R);
+	};
+	auto rtag = [&](int i, int type, int id) {
+		if constexpr (TAG == 4) {
+			if (i >= L.rcap) {
+				gb.type[i] = type;
+				gb.id[i] = id;
+				return;
+			}
+		}
+		fi[L.efc_id + i] = id;
+		fi[L.efc_type + i] = type;
+	};
+	auto rfl = [&](int i, double v) {
+		if constexpr (TAG == 4) {
+			if (i >= L.rcap) {
+				gb.fl[i] = v;
+				return;
+			}
+		}
+		f[L.efc_frictionloss + i] = v;
 	};
 	if (lane == 0) fi[L.nefc] = 0;
 	if (m.nefcmax <= 0 || (m.disableflags & MJB_DSBL_CONSTRAINT)) {
@@ -919,7 +954,7 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 	EPROF_BEGIN();
 #endif
 	if (nfr)
-		for (int r = lane; r < m.nefcmax; r += G) f[L.efc_frictionloss + r] = 0;
+		for (int r = lane; r < m.nefcmax; r += G) rfl(r, 0.0);
 	// Items in MuJoCo's row order, one per lane, 64 at a time: rows per item -> wave prefix sum -> row parameters.
 	// Row budget: the first item that does not fit, and everything after it, is dropped (mjWARN_CNSTRFULL).
 	int nefc = 0;       // rows so far (wave-uniform)
@@ -1109,26 +1144,22 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 		if (it < neq) {
 			for (int k = 0; k < 6; k++) {
 				if (k >= n) break;
-				row_store(L, f, off + k, cpos[k], 0.0, g0, row_R(g0, diag[k]));
-				fi[L.efc_id + off + k] = idv;
-				fi[L.efc_type + off + k] = MJB_CNSTR_EQUALITY;
+				rstore(off + k, cpos[k], 0.0, g0, row_R(g0, diag[k]));
+				rtag(off + k, MJB_CNSTR_EQUALITY, idv);
 			}
 		} else if (it < neq + nfr) {
 			const bool isdof = it < neq + nfd;
-			row_store(L, f, off, 0.0, 0.0, g0, row_R(g0, diag[0]));
-			f[L.efc_frictionloss + off] = isdof ? m.dof_frictionloss[idv] : m.tendon_frictionloss[idv];
-			fi[L.efc_id + off] = idv;
-			fi[L.efc_type + off] = isdof ? MJB_CNSTR_FRICTION_DOF : MJB_CNSTR_FRICTION_TENDON;
+			rstore(off, 0.0, 0.0, g0, row_R(g0, diag[0]));
+			rfl(off, isdof ? m.dof_frictionloss[idv] : m.tendon_frictionloss[idv]);
+			rtag(off, isdof ? MJB_CNSTR_FRICTION_DOF : MJB_CNSTR_FRICTION_TENDON, idv);
 		} else if (it < neq + nfr + m.njnt + nten) {
 			const int type = it < neq + nfr + m.njnt ? MJB_CNSTR_LIMIT_JOINT : MJB_CNSTR_LIMIT_TENDON;
-			row_store(L, f, off, ipos, imarg, g0, row_R(g0, diag[0]));
-			fi[L.efc_id + off] = idv;
-			fi[L.efc_type + off] = type;
+			rstore(off, ipos, imarg, g0, row_R(g0, diag[0]));
+			rtag(off, type, idv);
 			if (n == 2) {  // both sides within the margin
 				const RowGain g1 = row_gain(m, solref, solimp, dist2, imarg);
-				row_store(L, f, off + 1, dist2, imarg, g1, row_R(g1, diag[0]));
-				fi[L.efc_id + off + 1] = idv;
-				fi[L.efc_type + off + 1] = type;
+				rstore(off + 1, dist2, imarg, g1, row_R(g1, diag[0]));
+				rtag(off + 1, type, idv);
 			}
 		} else {
 			const int c = idv;
@@ -1139,9 +1170,8 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 			double fri[5];
 			for (int k = 0; k < 5; k++) fri[k] = f[L.contact_friction + 5 * c + k];
 			if (dim == 1) {
-				row_store(L, f, off, dist, cm, g0, row_R(g0, tran));
-				fi[L.efc_id + off] = c;
-				fi[L.efc_type + off] = MJB_CNSTR_CONTACT_FRICTIONLESS;
+				rstore(off, dist, cm, g0, row_R(g0, tran));
+				rtag(off, MJB_CNSTR_CONTACT_FRICTIONLESS, c);
 			} else if (m.cone == MJB_CONE_ELLIPTIC) {
 				// row 0 = normal (pos = dist), rows 1.. = friction directions (pos = margin = 0);
 				// R_j = R_0 mu^2 / friction_j^2 with mu = friction_0 / sqrt(impratio)
@@ -1150,10 +1180,9 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 				const double R0 = row_R(g0, tran);
 				for (int k = 0; k < 6; k++) {
 					if (k >= dim) break;
-					if (k == 0) row_store(L, f, off, dist, cm, g0, R0);
-					else row_store(L, f, off + k, 0.0, 0.0, gf, fmax(MJB_MINVAL, R0 * mu * mu / (fri[k - 1] * fri[k - 1])));
-					fi[L.efc_id + off + k] = c;
-					fi[L.efc_type + off + k] = MJB_CNSTR_CONTACT_ELLIPTIC;
+					if (k == 0) rstore(off, dist, cm, g0, R0);
+					else rstore(off + k, 0.0, 0.0, gf, fmax(MJB_MINVAL, R0 * mu * mu / (fri[k - 1] * fri[k - 1])));
+					rtag(off + k, MJB_CNSTR_CONTACT_ELLIPTIC, c);
 				}
 			} else {
 				// pyramidal: every row gets Rpy = 2 mu^2 R(first row), R(first row) from diagApprox = tran + friction_0^2 tran
@@ -1161,9 +1190,8 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 				const double Rpy = fmax(MJB_MINVAL, 2 * mu * mu * row_R(g0, tran + fri[0] * fri[0] * tran));
 				for (int k = 0; k < 10; k++) {
 					if (k >= 2 * (dim - 1)) break;
-					row_store(L, f, off + k, dist, cm, g0, Rpy);
-					fi[L.efc_id + off + k] = c;
-					fi[L.efc_type + off + k] = MJB_CNSTR_CONTACT_PYRAMIDAL;
+					rstore(off + k, dist, cm, g0, Rpy);
+					rtag(off + k, MJB_CNSTR_CONTACT_PYRAMIDAL, c);
 				}
 			}
 		}
@@ -1172,7 +1200,15 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 #ifdef MJB_PROFILE_SUB
 	EPROF(27);
 #endif
-	for (int r = lane; r < nefc; r += G) f[L.efc_force + r] = 0;
+	for (int r = lane; r < nefc; r += G) {
+		if constexpr (TAG == 4) {
+			if (r >= L.rcap) {
+				gb.force[r] = 0;
+				continue;
+			}
+		}
+		f[L.efc_force + r] = 0;
+	}
 	if (lane == 0) fi[L.nefc] = nefc;
 	gsync<G>();
 	// connect / weld Jacobian columns: one (equality, dof) pair per lane.  J = body1 - body2 (points differ, so a
@@ -1266,6 +1302,17 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 		if (Jg && nefc > L.jrows) {  // (wave-uniform) more rows than the frame holds: the solver reads all of J from HBM
 			MJB_KEEP_BRANCH();
 			for (int t = lane; t < L.jrows * nv; t += G) Jg[t] = f[L.efc_J + t];
+			if (L.rcap < m.nefcmax) {  // ... and the rest of the row data with it
+				for (int r = lane; r < L.rcap; r += G) {
+					gb.D[r] = f[L.efc_D + r];
+					gb.aref[r] = f[L.efc_aref + r];
+					gb.b[r] = f[L.efc_b + r];
+					gb.force[r] = 0;
+					if (nfr) gb.fl[r] = f[L.efc_frictionloss + r];
+					gb.type[r] = fi[L.efc_type + r];
+					gb.id[r] = fi[L.efc_id + r];
+				}
+			}
 			__threadfence();  // the rows are read back by other lanes through the vector cache
 			gsync<G>();
 		}
@@ -1374,7 +1421,8 @@ template <int G, int TAG> STAGE void reference_constraint(CModel m, CLayout L, C
 {
 	double *f = e.f;
 	const int nefc = wave_uniform<TAG>(e.fi[L.nefc]), nv = m.nv;
-	auto rows = [&](const double *Jb) {
+	// (aref / bg: where row_store parked K imp (pos - margin) and B on a lean frame)
+	auto rows = [&](const double *Jb, double *aref, const double *bg) {
 	for (int r = e.lane; r < nefc; r += G) {
 		double s = 0;
 		for (int k = 0; k < nv; k++) s += Jb[r * nv + k] * f[L.qvel + k];
@@ -1383,20 +1431,23 @@ template <int G, int TAG> STAGE void reference_constraint(CModel m, CLayout L, C
 			const double *kb = f + L.efc_KBIP + 4 * r;
 			f[L.efc_aref + r] = -kb[1] * s - kb[0] * kb[2] * (f[L.efc_pos + r] - f[L.efc_margin + r]);
 		} else {
-			f[L.efc_aref + r] = -f[L.efc_b + r] * s - f[L.efc_aref + r];  // (row_store left B and K imp (pos - margin) here)
+			aref[r] = -bg[r] * s - aref[r];  // (row_store left B and K imp (pos - margin) here)
 		}
 	}
 	};
-	if constexpr (TAG == 4) {  // (see make_constraint: all of J sits in HBM when the rows outnumber the frame's share)
+	if constexpr (TAG == 4) {  // (see make_constraint: all of J -- on a row-capped frame all row data -- sits in HBM when the rows outnumber the frame's share)
 		if (st.efc_Jg && nefc > L.jrows) {
 			MJB_KEEP_BRANCH();
-			rows(st.efc_Jg + (size_t)e.env * m.nefcmax * nv);
+			const RowBlock gb = mjb_rowblock(st.efc_Jg + (size_t)e.env * mjb_rowblock_doubles(m.nefcmax, nv, m.nconmax, L.hcs), m.nefcmax, nv, m.nconmax, L.hcs);
+			if (L.rcap < m.nefcmax) rows(gb.J, gb.aref, gb.b);
+			else rows(gb.J, f + L.efc_aref, f + L.efc_b);
+			__threadfence();
 		} else {
 			MJB_KEEP_BRANCH();
-			rows(f + L.efc_J);
+			rows(f + L.efc_J, f + L.efc_aref, f + L.efc_b);
 		}
 	} else
-		rows(f + L.efc_J);
+		rows(f + L.efc_J, f + L.efc_aref, f + L.efc_b);
 	gsync<G>();
 }
 
@@ -2245,14 +2296,32 @@ typedef double mjb_d4 __attribute__((ext_vector_type(4)));
 // JG: efc_J is read from the env's block in HBM (Jg) instead of the frame (kernel variant 4, env-steps with more rows than the
 // frame's share of efc_J; see make_constraint)
 template <int G, int R, bool CGS = false, bool JG = false>  // CGS: conjugate gradient (no Hessian; Polak-Ribiere directions preconditioned by M^-1)
-STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const double *Jg = nullptr)
+STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *gbase = nullptr)
 {
 	static_assert(G == 64, "the Newton solver maps rows / Hessian columns to the 64 lanes of one wavefront");
 	double *f = e.f;
 	int *fi = e.fi;
 	const int lane = e.lane, nv = m.nv;
 	const int nefc = __builtin_amdgcn_readfirstlane(fi[L.nefc]);
-	const double *const Jb = JG ? Jg : f + L.efc_J;
+	// JG: J -- and, when the frame's other row arrays are capped too (L.rcap < nefcmax), every per-row array, the row metadata and
+	// the cone blocks -- come from the env's block in HBM (mjb_dev.h, RowBlock); the branches fold away in the other instantiations
+	[[maybe_unused]] RowBlock gb{};
+	if constexpr (JG) gb = mjb_rowblock(gbase, m.nefcmax, m.nv, m.nconmax, L.hcs);
+	const bool gall = JG && L.rcap < m.nefcmax;
+	const double *const Jb = JG ? gb.J : f + L.efc_J;
+	const double *const Dp = gall ? gb.D : f + L.efc_D;
+	const double *const arefp = gall ? gb.aref : f + L.efc_aref;
+	const double *const flp = gall ? gb.fl : f + L.efc_frictionloss;
+	double *const forcep = gall ? gb.force : f + L.efc_force;
+	const int *const typep = gall ? gb.type : fi + L.efc_type;
+	const int *const idp = gall ? gb.id : fi + L.efc_id;
+	int *const metap = gall ? gb.meta : fi + L.iscratch;
+	const int rstride = gall ? m.nefcmax : L.rcap;   // jaref | jv | hw are rstride doubles apart
+	const bool hcrow = !gall && L.hcrow;             // cone block of a contact: at hcd * (its first row), or at hcs * contact
+	[[maybe_unused]] auto sync = [&]() {
+		if constexpr (JG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // (row data crosses lanes through HBM)
+		gsync<G>();
+	};
 	if (nefc == 0) {
 		for (int d = lane; d < nv; d += G) {
 			const double a = f[L.qacc_smooth + d];
@@ -2265,10 +2334,11 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 		return;
 	}
 	EPROF_BEGIN();
-	double *Md = f + L.nwt_M, *H = f + L.nwt_H, *Hc = f + L.nwt_hc;
+	double *Md = f + L.nwt_M, *H = f + L.nwt_H, *Hc = gall ? gb.hc : f + L.nwt_hc;
 	const int hcs = L.hcs, hcd = L.hcd;  // cone blocks: hcd x hcd (hcd = the model's largest contact dim), hcs doubles apart
 	double *qa = f + L.nwt_vec, *Ma = qa + nv, *grad = Ma + nv, *srch = grad + nv;
-	double *jar_s = f + L.nwt_row, *jv_s = jar_s + m.nefcmax, *hw = jv_s + m.nefcmax;  // per-row jaref, jv, Hessian weight
+	double *jar_s = gall ? gb.nwt_row : f + L.nwt_row, *jv_s = jar_s + rstride, *hw = jv_s + rstride;  // per-row jaref, jv, Hessian weight
+	auto hcb = [&](int con, int row) -> double * { return Hc + (hcrow ? hcd * row : hcs * con); };
 	const bool dofact = lane < nv;
 	const int k = dofact ? lane : 0;
 	const double tol = m.tolerance[0];
@@ -2292,14 +2362,14 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 #pragma unroll
 		for (int c = 0; c < 32; c++) Mrow[c] = 0.0;
 		for (int t = lane; t < nv * nv; t += G) Md[t] = 0;
-		gsync<G>();
+		sync();
 		for (int en = lane; en < m.nM; en += G) {
 			const int i = m.M_rowdof[en], j = m.M_coldof[en];
 			const double v = f[L.qM + en];
 			Md[i * nv + j] = v;
 			Md[j * nv + i] = v;
 		}
-		gsync<G>();
+		sync();
 	}
 	// (M x)_k for the lane's dof k (x: nv doubles in LDS); same summation order on both paths
 	auto m_dot = [&](const double *x) -> double {
@@ -2324,20 +2394,20 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 		const int r = lane + 64 * i;
 		rowact[i] = r < nefc;
 		rr[i] = rowact[i] ? r : 0;
-		const int rtype = rowact[i] ? fi[L.efc_type + r] : 0;
-		rcon[i] = rowact[i] ? fi[L.efc_id + r] : 0;
+		const int rtype = rowact[i] ? typep[r] : 0;
+		rcon[i] = rowact[i] ? idp[r] : 0;
 		const bool is_cone = rowact[i] && rtype == MJB_CNSTR_CONTACT_ELLIPTIC;
 		scalar_row[i] = rowact[i] && !is_cone;
 		bilat[i] = rowact[i] && rtype == MJB_CNSTR_EQUALITY;
 		leader[i] = is_cone && fi[L.contact_efc_address + rcon[i]] == r;
 		cdim[i] = is_cone ? fi[L.contact_dim + rcon[i]] : 0;
-		D[i] = rowact[i] ? f[L.efc_D + r] : 0.0;
-		fl[i] = (rowact[i] && m.nfriction > 0) ? f[L.efc_frictionloss + r] : 0.0;
-		aref[i] = rowact[i] ? f[L.efc_aref + r] : 0.0;
+		D[i] = rowact[i] ? Dp[r] : 0.0;
+		fl[i] = (rowact[i] && m.nfriction > 0) ? flp[r] : 0.0;
+		aref[i] = rowact[i] ? arefp[r] : 0.0;
 		cmu[i] = leader[i] ? f[L.contact_friction + 5 * rcon[i]] / sqrt(fmax(MJB_MINVAL, m.impratio[0])) : 1.0;
 		// what the Hessian build needs to know about the row, in ONE int (read by whichever lane feeds the row to the matrix
 		// cores): -1 = scalar row (weight hw[r]), else first row of its cone | dim << 8 | contact << 12
-		if (rowact[i]) fi[L.iscratch + r] = is_cone ? (fi[L.contact_efc_address + rcon[i]] | (cdim[i] << 8) | (rcon[i] << 12)) : -1;
+		if (rowact[i]) metap[r] = is_cone ? (fi[L.contact_efc_address + rcon[i]] | (cdim[i] << 8) | (rcon[i] << 12)) : -1;
 	}
 
 
@@ -2366,13 +2436,13 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 			if (scalar_row[i] && fl[i] > 0) {
 				const double x = jar_s[r], rf = fl[i] / D[i];
 				const bool quad = x > -rf && x < rf;
-				f[L.efc_force + r] = quad ? -D[i] * x : (x < 0 ? fl[i] : -fl[i]);
+				forcep[r] = quad ? -D[i] * x : (x < 0 ? fl[i] : -fl[i]);
 				if (hess) hw[r] = quad ? D[i] : 0.0;
 				cost += quad ? 0.5 * D[i] * x * x : fl[i] * (-0.5 * rf + fabs(x));
 			} else if (scalar_row[i]) {
 				const double x = jar_s[r];
 				const bool act = x < 0 || bilat[i];
-				f[L.efc_force + r] = act ? -D[i] * x : 0.0;
+				forcep[r] = act ? -D[i] * x : 0.0;
 				if (hess) hw[r] = act ? D[i] : 0.0;
 				cost += act ? 0.5 * D[i] * x * x : 0.0;
 			} else if (leader[i]) {
@@ -2383,7 +2453,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 				for (int j = 0; j < 6; j++) {
 					if (j < dim) {
 						x[j] = jar_s[r + j];
-						Dj[j] = f[L.efc_D + r + j];
+						Dj[j] = Dp[r + j];
 						U[j] = (j == 0 ? mu : cfri[j > 0 ? j - 1 : 0]) * x[j];
 						if (j > 0) TT += U[j] * U[j];
 					} else {
@@ -2391,16 +2461,16 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 					}
 				}
 				const double N = U[0], T = sqrt(TT);
-				double *hc = Hc + hcs * rcon[i];
+				double *hc = hcb(rcon[i], r);
 				if (hess)
 					for (int j = 0; j < hcd * hcd; j++) hc[j] = 0;
 				if (N >= mu * T) {
 					for (int j = 0; j < 6; j++)
-						if (j < dim) f[L.efc_force + r + j] = 0;
+						if (j < dim) forcep[r + j] = 0;
 				} else if (mu * N + T <= 0) {
 					for (int j = 0; j < 6; j++)
 						if (j < dim) {
-							f[L.efc_force + r + j] = -Dj[j] * x[j];
+							forcep[r + j] = -Dj[j] * x[j];
 							cost += 0.5 * Dj[j] * x[j] * x[j];
 							if (hess) hc[j * hcd + j] = Dj[j];
 						}
@@ -2408,13 +2478,13 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 					const double Dm = Dj[0] / (mu * mu * (1 + mu * mu)), NmT = N - mu * T;
 					cost += 0.5 * Dm * NmT * NmT;
 					const double f0 = -Dm * NmT * mu;
-					f[L.efc_force + r] = f0;
+					forcep[r] = f0;
 					double g[6];
 					g[0] = mu;
 					for (int j = 1; j < 6; j++) {
 						g[j] = 0;
 						if (j < dim) {
-							f[L.efc_force + r + j] = -f0 / T * U[j] * cfri[j - 1];
+							forcep[r + j] = -f0 / T * U[j] * cfri[j - 1];
 							g[j] = -mu * cfri[j - 1] * U[j] / T;
 						}
 					}
@@ -2449,7 +2519,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 #pragma unroll
 			for (int i = 0; i < R; i++)
 				if (rowact[i]) jar_s[rr[i]] = x[i];
-			gsync<G>();
+			sync();
 			const double ck = cone_update(false);
 			const double cost = wave_sum(gk) + wave_sum(ck);
 			bool take;
@@ -2460,7 +2530,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 				take = cost < best;
 			}
 			if (take && dofact) qa[k] = q0[k];
-			gsync<G>();
+			sync();
 		}
 	}
 
@@ -2479,17 +2549,17 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 		for (int i = 0; i < R; i++)
 			if (rowact[i]) jar_s[rr[i]] = jaref[i];
 		if (dofact) Ma[k] = ma;
-		gsync<G>();
+		sync();
 		const double ck = cone_update(true);
 		const double gauss = wave_sum(gk);
 		prev_cost = cost;
 		cost = gauss + wave_sum(ck);
-		gsync<G>();
+		sync();
 		double gr = 0;
 		if (dofact) {
 			double s = 0;
 #pragma unroll 4
-			for (int i = 0; i < nefc; i++) s += Jb[i * nv + k] * f[L.efc_force + i];
+			for (int i = 0; i < nefc; i++) s += Jb[i * nv + k] * forcep[i];
 			f[L.qfrc_constraint + k] = s;
 			gr = ma - f[L.qfrc_smooth + k] - s;
 			grad[k] = gr;
@@ -2506,7 +2576,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 			// max(MINVAL, grad_old.Mgrad_old) clipped at 0, search = -Mgrad + beta search_old
 			double *mg = srch + nv;
 			if (dofact) mg[k] = gr;
-			gsync<G>();
+			sync();
 			solve<G>(m, e, mg, f + L.qLD, f + L.qLDiagInv);
 			const double mgk = dofact ? mg[k] : 0.0;
 			double beta = 0;
@@ -2543,10 +2613,10 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 				}
 				// a scalar row is a 1 x 1 "block" whose weight sits in hw[r]; all loads of the slab leave together once the
 				// row's metadata int has arrived
-				const int meta = fi[L.iscratch + rc];
+				const int meta = metap[rc];
 				const bool cone = meta >= 0;
 				const int adr = cone ? (meta & 255) : rc, dim = cone ? ((meta >> 8) & 15) : 1, con = cone ? (meta >> 12) : 0;
-				const double *wp = cone ? Hc + hcs * con + hcd * (rc - adr) : hw + rc;
+				const double *wp = cone ? hcb(con, adr) + hcd * (rc - adr) : hw + rc;
 				const double *Jc = Jb + adr * nv + (ina ? ca : 0);
 				double wv[6], jv6[6];
 #pragma unroll
@@ -2589,7 +2659,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 				}
 			}
 		}
-		gsync<G>();
+		sync();
 		EPROF(27);
 		// Cholesky, lane = row of H; lane j keeps 1 / L_jj so that the substitutions multiply instead of divide and never
 		// read the diagonal back.  nv <= 32: right-looking with the lane's ROW IN REGISTERS -- column j is scaled in
@@ -2635,7 +2705,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 					else x -= ((dofact && lane > i) ? Hr[i] : 0.0) * xi;
 				}
 			}
-			gsync<G>();
+			sync();
 		} else {
 			for (int j = 0; j < nv; j++) {
 				double s = 0;
@@ -2649,7 +2719,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 				const double rinv = rsqrt(sj);
 				if (dofact && k >= j) H[k * nv + j] = (k == j) ? sj * rinv : s * rinv;
 				if (k == j) myrinv = rinv;
-				gsync<G>();
+				sync();
 			}
 #pragma unroll 4
 			for (int i = 0; i < nv; i++) {
@@ -2694,7 +2764,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 		const double snorm = sqrt(wave_sum(sk * sk));
 		if (snorm < MJB_MINVAL) break;
 		if (dofact) srch[k] = sk;
-		gsync<G>();
+		sync();
 		// line search along the Newton direction
 		const double mv = m_dot(srch);
 		double jv[R];
@@ -2702,7 +2772,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 #pragma unroll
 		for (int i = 0; i < R; i++)
 			if (rowact[i]) jv_s[rr[i]] = jv[i];
-		gsync<G>();
+		sync();
 		// per-contact line-search constants: registers of the leader lane (R == 1), or parked in the contact's cone
 		// block Hc (free once H is built) when a lane owns several rows and registers are scarce
 		ConeLine cl1 = ConeLine{ 0, 0, 0, 0, 0, 0, 0, 0, 1, 0 };
@@ -2718,7 +2788,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 				c.Dm = D[i] / (mu * mu * (1 + mu * mu));
 				for (int j = 0; j < 6; j++) {
 					if (j >= cdim[i]) break;
-					const double xj = jar_s[rr[i] + j], vj = jv_s[rr[i] + j], Dj = f[L.efc_D + rr[i] + j];
+					const double xj = jar_s[rr[i] + j], vj = jv_s[rr[i] + j], Dj = Dp[rr[i] + j];
 					c.q0b += 0.5 * Dj * xj * xj;
 					c.q1b += Dj * xj * vj;
 					c.q2b += 0.5 * Dj * vj * vj;
@@ -2732,7 +2802,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 				if constexpr (R == 1) {
 					cl1 = c;
 				} else {
-					double *o = Hc + hcs * rcon[i];
+					double *o = hcb(rcon[i], rr[i]);
 					o[0] = c.N0; o[1] = c.N1; o[2] = c.TT; o[3] = c.UV; o[4] = c.VV;
 					o[5] = c.q0b; o[6] = c.q1b; o[7] = c.q2b; o[8] = c.mu; o[9] = c.Dm;
 				}
@@ -2753,7 +2823,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 				} else {
 					ConeLine c = cl1;
 					if (leader[i]) {
-						const double *o = Hc + hcs * rcon[i];
+						const double *o = hcb(rcon[i], rr[i]);
 						c = ConeLine{ o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9] };
 					}
 					ls_row(a, scalar_row[i], bilat[i], leader[i], jaref[i], jv[i], D[i], fl[i], c, c0, c1, c2);
@@ -2833,7 +2903,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 		if (alpha == 0) break;
 		if (dofact) qa[k] += alpha * sk;
 		iter++;
-		gsync<G>();
+		sync();
 	}
 	if (lane == 0) fi[L.solver_iter] = iter;
 	if (dofact) {
@@ -2841,5 +2911,5 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, const do
 		f[L.qacc + k] = a;
 		f[L.qacc_warmstart + k] = a;
 	}
-	gsync<G>();
+	sync();
 }

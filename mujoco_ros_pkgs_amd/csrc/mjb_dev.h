@@ -89,6 +89,10 @@ struct FrameLayout {
 	int dadr;      // [64 ints] constrained kernels, nv <= 16: packed dense address map of lanes 0-15 (int frame)
 	int tri;       // transient scratch: packed dense triangle of the L'DL factor (PGS, nv <= 16: 128 doubles; 16 < nv <= 32: 496, solve_tri32)
 	int jrows;     // rows of efc_J the frame holds (nefcmax, except in the fused frame of kernel variant 4: 64, the rest in DevState::efc_Jg)
+	int rcap;      // rows every OTHER per-row array holds (efc_D / aref / b / force / frictionloss / type / id, nwt_row, the row metadata in
+	               // iscratch): nefcmax, except in the X-layout fused frame of kernel variant 4, where it equals jrows (an env-step with
+	               // more rows keeps ALL of its row data in the env's block of DevState::efc_Jg, see RowBlock)
+	int hcrow;     // 1: the cone block of a contact sits at nwt_hc + hcd * (its first row) [hcd * rcap doubles]; 0: at nwt_hc + hcs * contact
 	int solvescr;  // [32]      pivot-row scratch of the dense M^-1 solves in fwd_acceleration / Euler (the factorisation uses crbbuf)
 	int bbscr;     // [216]     transient scratch of the box - box narrow phase (alive inside collision only)
 	int ndouble;   // doubles per frame
@@ -120,12 +124,45 @@ struct DevState {
 	const double *env_mass;          // [nenv][7 nbody + nv + ntendon + 1] per-env inertial constants (NULL: the model's):
 	                                 // body_mass | body_subtreemass | body_inertia[3] | dof_invweight0 | body_invweight0[2] | tendon_invweight0 | meaninertia
 	int *sched;                      // [1 + nenv] work counter | chunks done per env, of a chunked fused launch (constrained kernels); NULL otherwise
-	double *efc_Jg;                  // [nenv][nefcmax * nv] efc_J of the env-steps whose rows outnumber the fused frame's share (kernel variant 4); NULL otherwise
+	double *efc_Jg;                  // [nenv][mjb_rowblock_doubles] row data of the env-steps whose rows outnumber the fused frame's share (kernel variant 4, RowBlock); NULL otherwise
 	double *pgs_B;                   // [nenv][nefcmax * nv] rows of J M^-1 of the PGS steps beyond 64 rows (nv <= 16 models keep them out of LDS); NULL otherwise
 	int use_xfrc;                  // xfrc_applied has ever been written
 	int keep_frame;                // fused mjb_step also dumps the last step's full frame to frame_ws
 	int pad1;
 };
+
+// The env's spill-over block in DevState::efc_Jg (kernel variant 4): efc_J [nefcmax][nv], then -- used only when the frame's row
+// arrays are capped too (FrameLayout::rcap < nefcmax) -- D | aref | b | force | frictionloss | jaref | jv | hw [nefcmax each],
+// the cone blocks [hcs * nconmax], and three int arrays type | id | meta [nefcmax each].
+#if defined(__HIPCC__)
+#define MJB_HD __host__ __device__
+#else
+#define MJB_HD
+#endif
+MJB_HD inline size_t mjb_rowblock_doubles(int nefcmax, int nv, int nconmax, int hcs)
+{
+	return (size_t)nefcmax * nv + (size_t)8 * nefcmax + (size_t)hcs * nconmax + (size_t)2 * nefcmax;
+}
+struct RowBlock {
+	double *J, *D, *aref, *b, *force, *fl, *nwt_row, *hc;
+	int *type, *id, *meta;
+};
+MJB_HD inline RowBlock mjb_rowblock(double *base, int nefcmax, int nv, int nconmax, int hcs)
+{
+	RowBlock g;
+	g.J = base;
+	g.D = base + (size_t)nefcmax * nv;
+	g.aref = g.D + nefcmax;
+	g.b = g.aref + nefcmax;
+	g.force = g.b + nefcmax;
+	g.fl = g.force + nefcmax;
+	g.nwt_row = g.fl + nefcmax;
+	g.hc = g.nwt_row + 3 * nefcmax;
+	g.type = reinterpret_cast<int *>(g.hc + (size_t)hcs * nconmax);
+	g.id = g.type + nefcmax;
+	g.meta = g.id + nefcmax;
+	return g;
+}
 
 struct NoiseCfg {
 	double rate;   // exp(-dt / max(ctrl_noise_rate, mjMINVAL))

@@ -2252,7 +2252,7 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 				fwd_constraint_newton<G, 1>(m, L, e);
 			} else {
 				MJB_KEEP_BRANCH();
-				fwd_constraint_newton<G, 4, false, true>(m, L, e, s.efc_Jg + (size_t)e.env * m.nefcmax * m.nv);
+				fwd_constraint_newton<G, 4, false, true>(m, L, e, s.efc_Jg + (size_t)e.env * mjb_rowblock_doubles(m.nefcmax, m.nv, m.nconmax, L.hcs));
 			}
 		});
 	} else if constexpr (CON >= 2 && CON <= 3 && G == 64) {
