@@ -2630,6 +2630,68 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 				for (int s2 = 0; s2 < 6; s2++) a += s2 < dim ? wv[s2] * jv6[s2] : 0.0;
 				av = (live && ina) ? a : 0.0;
 			};
+			// nv <= 32 (two tile rows): ONE pass over the slabs feeds all three tiles of the lower triangle -- the slab's rows of J,
+			// its metadata and its weights are fetched once instead of once per tile row (21 LDS reads per slab instead of 34;
+			// cone blocks no larger than 4 x 4, config 5: 15), and the three MFMAs of a slab issue back to back.
+			auto one_pass = [&](auto DIMC) {
+				constexpr int DMAX = decltype(DIMC)::value;
+				const int c1 = 16 + li;
+				const bool in1 = c1 < nv, in0 = li < nv;
+				auto fetch = [&](int r0, double &a0, double &a1, double &b0, double &b1) {
+					const int r = r0 + lk;
+					const bool live = r < nefc;
+					const int rc = live ? r : 0;
+					const double *Jr = Jb + rc * nv;
+					const double v0 = Jr[in0 ? li : 0], v1 = Jr[in1 ? c1 : 0];
+					b0 = (live && in0) ? v0 : 0.0;
+					b1 = (live && in1) ? v1 : 0.0;
+					const int meta = metap[rc];
+					const bool cone = meta >= 0;
+					const int adr = cone ? (meta & 255) : rc, dim = cone ? ((meta >> 8) & 15) : 1, con = cone ? (meta >> 12) : 0;
+					const double *wp = cone ? hcb(con, adr) + hcd * (rc - adr) : hw + rc;
+					const double *Jc = Jb + adr * nv;
+					double wv[DMAX], j0[DMAX], j1[DMAX];
+#pragma unroll
+					for (int s2 = 0; s2 < DMAX; s2++) {
+						const int sc = s2 < dim ? s2 : 0;
+						wv[s2] = wp[sc];
+						j0[s2] = Jc[sc * nv + (in0 ? li : 0)];
+						j1[s2] = Jc[sc * nv + (in1 ? c1 : 0)];
+					}
+					double s0 = 0, s1 = 0;
+#pragma unroll
+					for (int s2 = 0; s2 < DMAX; s2++) {
+						s0 += s2 < dim ? wv[s2] * j0[s2] : 0.0;
+						s1 += s2 < dim ? wv[s2] * j1[s2] : 0.0;
+					}
+					a0 = (live && in0) ? s0 : 0.0;
+					a1 = (live && in1) ? s1 : 0.0;
+				};
+				mjb_d4 t00 = mjb_d4{ 0, 0, 0, 0 }, t10 = mjb_d4{ 0, 0, 0, 0 }, t11 = mjb_d4{ 0, 0, 0, 0 };
+				double a0, a1, b0, b1, a0n, a1n, b0n, b1n;
+				fetch(0, a0, a1, b0, b1);
+				for (int r0 = 0; r0 < nefc; r0 += 4) {
+					fetch(r0 + 4, a0n, a1n, b0n, b1n);  // (past the last slab: all zero)
+					t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, t00, 0, 0, 0);
+					t10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, t10, 0, 0, 0);
+					t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, t11, 0, 0, 0);
+					a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
+				}
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					const int row = lk + 4 * q;
+					if (row < nv && li < nv) H[row * nv + li] = t00[q];
+					if (16 + row < nv && li < nv) H[(16 + row) * nv + li] = t10[q];
+					if (16 + row < nv && c1 < nv) H[(16 + row) * nv + c1] = t11[q];
+				}
+			};
+			if (mreg && hcd <= 4) {
+				MJB_KEEP_BRANCH();
+				one_pass(std::integral_constant<int, 4>{});
+			} else if (mreg) {
+				MJB_KEEP_BRANCH();
+				one_pass(std::integral_constant<int, 6>{});
+			} else
 			for (int ta = 0; ta < ntile; ta++) {
 				mjb_d4 acc[4];
 #pragma unroll
