@@ -38,9 +38,9 @@ WORKLOADS = {
     #  pressing into the table run PGS to its 100-sweep cap for a while, ~300 us per step -- and at 200 steps that tail set the
     #  launch time; per-launch series and the 200 / 500 / 1000 sweep: profiles/r03_cfg3_launch_length.txt, tools/launch_series.py)
     "franka_table": ("BASELINE configs[2]: Franka-like arm + table + cube contacts", 0.5 * 87.0, 4096, 1000, 3),
-    # (1000 steps per launch since the four-envs-per-CU frame: 1024 envs = 1024 slots, every env has a slot of its own and a launch
-    #  lasts as long as its slowest env's chain -- over 1000 steps the chains' sums even out; launches under 400 steps keep the
-    #  768-slot schedule, mjb_api.hip: launch.  100 / 1000 steps x 768 / 1024 slots: profiles/r03_cfg5_residency.txt)
+    # (1000 steps per launch like the other configs since the four-envs-per-CU frame: 1024 envs = 1024 slots, every env has a slot of
+    #  its own and a launch lasts as long as its slowest env's chain -- over 1000 steps the chains' sums even out: 4.7 M at 100 steps
+    #  per launch, 5.0 M at 1000.  Slots x launch length x chunking: profiles/r03_cfg5_residency.txt)
     "shadow_hand_like": ("BASELINE configs[4]: Shadow-Hand-like 24-DoF hand + in-hand cube (Newton, elliptic cones)", 0.1, 1024, 1000, 5),
 }
 CONFIG_MODEL = {2: "franka_like", 3: "franka_table", 4: "franka_table", 5: "shadow_hand_like"}

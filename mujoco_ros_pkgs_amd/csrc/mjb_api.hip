@@ -1375,11 +1375,27 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 		if ((forced == 1 || forced == 9) && (variant == 1 || variant == 9)) variant = forced;  // (only the two builds of the same PGS step are interchangeable)
 	}
 	// long fused launches of the constrained kernels hand out (chunk of steps, env) work items dynamically (mjb_step.hip)
+	// ... unless every env gets a slot of its own (envs <= resident envs per CU x CUs): then the queue has nothing to even out, an
+	// item taken by a wave whose env's previous chunk is still running elsewhere only waits, and the launch is fastest with each
+	// env's steps run back to back on its slot.  Measured on config 5 (4 envs per CU = 1024 slots, MI355X), chunked / unchunked:
+	// 1024 envs x 100 steps 4.04 / 4.72 M env-steps/s, x 1000 steps 4.20 / 5.00 M, 768 envs 3.40 / 3.75 M; 1280 envs 5.32 / 3.38 M.
+	bool own_slot = false;
+	if (compact && variant != 0) {
+		static const int ncu = [] {
+			int dev = 0, n = 0;
+			if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+			return n;
+		}();
+		const int granules = (mjb_frame_bytes(b->model, 1) + 1279) / 1280;  // (gfx950: 128 LDS granules of 1280 bytes per CU)
+		const int occ = std::min(variant == 9 ? 8 : 4, 128 / std::max(1, granules));  // (512-register kernels: one wave per SIMD)
+		own_slot = ncu > 0 && b->nenv <= occ * ncu;
+	}
 	int chunk = 0;
-	if (mode == MJB_MODE_STEP && variant != 0 && nsteps >= 100 && b->st.sched && whole) {
+	static const int forced_chunk = [] { const char *v = getenv("MJB_DEBUG_CHUNK"); return v ? atoi(v) : 0; }();  // measurement knob (also overrides own_slot)
+	if (mode == MJB_MODE_STEP && variant != 0 && nsteps >= 100 && b->st.sched && whole && (!own_slot || forced_chunk > 0)) {
 		static const bool off = [] { const char *v = getenv("MJB_DEBUG_NO_CHUNKS"); return v && *v && *v != '0'; }();  // measurement knob
 		if (!off) {
-			static const int forced = [] { const char *v = getenv("MJB_DEBUG_CHUNK"); return v ? atoi(v) : 0; }();
+			const int forced = forced_chunk;
 			// (measured on MI355X: 10 - 40 steps per item are equally good on config 3; config 5 -- three envs per CU, a few heavy envs
 			//  on the critical path -- likes them finer: 3 - 5 steps per item 3.85 M, 10 steps 3.79 M, 20 steps 3.63 M)
 			const bool newton = variant >= 2 && variant <= 4;
@@ -1388,25 +1404,8 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 			HIP_TRY(hipMemsetAsync(b->st.sched, 0, ((size_t)b->nenv + 1) * sizeof(int), stream));
 		}
 	}
-	// One-wave-per-SIMD kernels (the 512-register Newton variants): when every env gets a slot of its own the work queue has nothing
-	// to even out and the launch lasts as long as its slowest env's chain; with a quarter fewer slots than envs the heavy envs' chunks
-	// interleave with the light ones'.  Measured on config 5 (1024 envs, 4 slots per CU = 1024 slots, MI355X): 100-step launches
-	// 3.29 M env-steps/s on 1024 slots, 3.98 M on 768; 1000-step launches (the chains' sums even out) 4.00 M vs 3.86 M.  So short
-	// chunked launches whose envs fit the slots only just take one env per CU less (an LDS request, not a second kernel).
-	int lds_floor_granules = 0;
-	if (chunk > 0 && compact && variant >= 2 && variant <= 4 && nsteps < 400) {
-		static const int ncu = [] {
-			int dev = 0, n = 0;
-			if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-			return n;
-		}();
-		const int granules = (mjb_frame_bytes(b->model, 1) + 1279) / 1280;  // (gfx950: 128 LDS granules of 1280 bytes per CU)
-		const int occ = std::min(4, 128 / std::max(1, granules));
-		static const bool nocap = [] { const char *v = getenv("MJB_DEBUG_NO_SLOT_CAP"); return v && *v && *v != '0'; }();  // measurement knob
-		if (!nocap && ncu > 0 && occ >= 2 && b->nenv <= occ * ncu && b->nenv > (occ - 1) * ncu) lds_floor_granules = 128 / (occ - 1);
-	}
 	int rc = mjb_launch_step(b->params_dev, compact ? b->model->Lc : b->L, env_lo, env_hi, mode, nsteps, b->step_counter, b->lanes,
-	                         b->epb, variant | (chunk << 8) | (lds_floor_granules << 24), (b->lanes == 16 && !b->env_mass && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16 && b->model->h.nu <= 16 && b->model->h.njnt <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, stream);
+	                         b->epb, variant | (chunk << 8), (b->lanes == 16 && !b->env_mass && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16 && b->model->h.nu <= 16 && b->model->h.njnt <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, stream);
 	if (rc != 0) return fail(MJB_ENODEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
 	return MJB_OK;
 }

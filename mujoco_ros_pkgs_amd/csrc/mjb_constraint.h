@@ -2252,7 +2252,7 @@ DEVI void ls_row(double a, bool scalar_row, bool bilateral, bool leader, double 
 			c1 += cl.q1b + 2 * a * cl.q2b;
 			c2 += 2 * cl.q2b;
 		} else {
-			const double NmT = N - cl.mu * T, T1 = (cl.UV + a * cl.VV) / T, T2d = (cl.VV - T1 * T1) / T;
+			const double NmT = N - cl.mu * T, iT = 1.0 / T, T1 = (cl.UV + a * cl.VV) * iT, T2d = (cl.VV - T1 * T1) * iT;
 			const double s1 = cl.N1 - cl.mu * T1;
 			c0 += 0.5 * cl.Dm * NmT * NmT;
 			c1 += cl.Dm * NmT * s1;
@@ -2475,7 +2475,9 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 							if (hess) hc[j * hcd + j] = Dj[j];
 						}
 				} else {
-					const double Dm = Dj[0] / (mu * mu * (1 + mu * mu)), NmT = N - mu * T;
+					// (one reciprocal of T instead of a division per force and per block entry: the middle zone's 16 entries were
+					//  ~20 dependent fp64 divisions in the cone's leader lane, on every iteration's critical path)
+					const double Dm = Dj[0] / (mu * mu * (1 + mu * mu)), NmT = N - mu * T, iT = 1.0 / T, iT3 = iT * iT * iT;
 					cost += 0.5 * Dm * NmT * NmT;
 					const double f0 = -Dm * NmT * mu;
 					forcep[r] = f0;
@@ -2484,8 +2486,8 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 					for (int j = 1; j < 6; j++) {
 						g[j] = 0;
 						if (j < dim) {
-							forcep[r + j] = -f0 / T * U[j] * cfri[j - 1];
-							g[j] = -mu * cfri[j - 1] * U[j] / T;
+							forcep[r + j] = -f0 * iT * U[j] * cfri[j - 1];
+							g[j] = -mu * cfri[j - 1] * U[j] * iT;
 						}
 					}
 					if (hess)
@@ -2494,7 +2496,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 								if (j >= dim || c2 >= dim) continue;
 								double v = Dm * g[j] * g[c2];
 								if (j >= 1 && c2 >= 1)
-									v += -Dm * NmT * mu * cfri[j - 1] * cfri[c2 - 1] * ((j == c2 ? 1.0 / T : 0.0) - U[j] * U[c2] / (T * T * T));
+									v += -Dm * NmT * mu * cfri[j - 1] * cfri[c2 - 1] * ((j == c2 ? iT : 0.0) - U[j] * U[c2] * iT3);
 								hc[j * hcd + c2] = v;
 							}
 				}

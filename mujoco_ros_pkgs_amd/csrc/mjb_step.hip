@@ -2812,9 +2812,6 @@ int launch_g(const KernelParams *Pdev, const FrameLayout &L, int env_lo, int env
 	}
 	size_t lds = (size_t)epb * frame_bytes;
 	if ((int)lds > maxlds) return (int)hipErrorInvalidValue;
-	const int floor_req = (chunk >> 16) * 1280;  // (residency cap requested by the host: see mjb_api.hip, launch)
-	chunk &= 0xffff;
-	if (floor_req > (int)lds && floor_req <= maxlds) lds = floor_req;
 	{  // measurement knob: MJB_DEBUG_LDS_BYTES=<n> requests at least n bytes per block, i.e. caps the resident blocks per CU
 		static const int floor_bytes = [] { const char *v = getenv("MJB_DEBUG_LDS_BYTES"); return v ? atoi(v) : 0; }();
 		if (floor_bytes > (int)lds && floor_bytes <= maxlds) lds = floor_bytes;
@@ -2893,9 +2890,7 @@ int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int env_lo, 
 {
 	// (the headline kernels are instantiated first so that they sit at the start of the code object whatever happens to the
 	//  size of the constrained ones: their absolute placement is worth ~2 % on config 2)
-	// (bits 8-23: steps per work item of a chunked launch, 0 = one item per env; bits 24-30: LDS granules of 1280 bytes the launch
-	//  requests at least, i.e. a cap on the resident envs per CU; mjb_api.hip: launch -- both travel to launch_g in `chunk`)
-	const int chunk = ((constrained >> 8) & 0xffff) | ((constrained >> 24) << 16);
+	const int chunk = constrained >> 8;  // (steps per work item of a chunked launch, 0 = one item per env; mjb_api.hip: launch)
 	constrained &= 255;
 #ifdef MJB_DEV_ONLY_CON  // development switch: compile ONE constrained kernel variant (seconds instead of minutes)
 	return launch_g<64, MJB_DEV_ONLY_CON>(Pdev, L, env_lo, nenv, mode, nsteps, step0, envs_per_block, stream, chunk);

@@ -1,19 +1,19 @@
 #!/bin/bash
-# Config 5 (1024 Shadow-Hand-like envs, Newton): slots per CU x launch length.  4 envs per CU = 1024 slots = one per env (a launch lasts
-# as long as its slowest env's chain); 3 per CU = 768 slots (the work queue evens the chunks out).  Run on the GPU box from the repo root.
+# Config 5 (Shadow-Hand-like envs, Newton): resident envs per CU x launch length x chunked work queue.  4 envs per CU = 1024 slots on
+# an MI355X; with envs <= slots every env has a slot of its own (a launch lasts as long as its slowest env's chain; the host then
+# launches unchunked, mjb_api.hip: launch).  Run on the GPU box from the repo root.
 out=${1:-gpurun_out/cfg5_residency.txt}
+run() { python bench.py --config 5 --envs $1 --substeps $2 --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('%.3f M' % (d['value']/1e6))"; }
 {
-echo "# config 5, one MI355X: env-steps/s by (envs, steps per launch, resident envs per CU).  3 per CU is forced with MJB_DEBUG_LDS_BYTES=53760,"
-echo "# 4 per CU on short launches with MJB_DEBUG_NO_SLOT_CAP=1 (the host caps launches under 400 steps at 3 per CU when every env would get its own slot)."
-for envs in 1024 2048; do for k in 100 1000; do for occ in 3 4; do
-  if [ $occ = 3 ]; then export MJB_DEBUG_LDS_BYTES=53760; unset MJB_DEBUG_NO_SLOT_CAP; else unset MJB_DEBUG_LDS_BYTES; export MJB_DEBUG_NO_SLOT_CAP=1; fi
-  v=$(python bench.py --config 5 --envs $envs --substeps $k --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('%.3f M env-steps/s, kernel %.2f ms' % (d['value']/1e6, d['roofline']['kernel_ms']))")
-  echo "envs $envs  steps/launch $k  envs/CU $occ :  $v"
-done; done; done
-unset MJB_DEBUG_LDS_BYTES MJB_DEBUG_NO_SLOT_CAP
-echo "# defaults (no knobs):"
-for k in 100 1000; do
-  v=$(python bench.py --config 5 --substeps $k --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('%.3f M env-steps/s' % (d['value']/1e6))")
-  echo "envs 1024  steps/launch $k  default :  $v"
-done
+echo "# config 5, one MI355X: M env-steps/s by (envs, steps per launch, resident envs per CU, chunking).  3 per CU is forced with"
+echo "# MJB_DEBUG_LDS_BYTES=53760; 'chunked' forces the work queue with MJB_DEBUG_CHUNK=max(5, steps/20); 'default' is the host's own choice."
+for envs in 768 1024 1280 2048; do for k in 100 1000; do
+  c=$(( k / 20 )); [ $c -lt 5 ] && c=5
+  a=$(MJB_DEBUG_LDS_BYTES=53760 MJB_DEBUG_CHUNK=$c run $envs $k)
+  b=$(MJB_DEBUG_LDS_BYTES=53760 MJB_DEBUG_NO_CHUNKS=1 run $envs $k)
+  d=$(MJB_DEBUG_CHUNK=$c run $envs $k)
+  e=$(MJB_DEBUG_NO_CHUNKS=1 run $envs $k)
+  f=$(run $envs $k)
+  echo "envs $envs steps/launch $k : 3/CU chunked $a | 3/CU unchunked $b | 4/CU chunked $d | 4/CU unchunked $e | default $f"
+done; done
 } | tee $out
