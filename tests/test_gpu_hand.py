@@ -10,7 +10,8 @@ from test_gpu_contact import PRE, ROWS, _close, binding_dim
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["rows<=128", "rows<=256", "rows<=256, J beyond the frame's share in HBM"])
+@pytest.fixture(scope="module", params=["rows<=128", "rows<=256", "rows<=256, J beyond the frame's share in HBM",
+                                        "rows<=256, 24 rows in the frame: HBM and frame paths mixed"])
 def setup(request, oracle_built):
     import os
     from mujoco_ros_pkgs_amd import engine, mjcf, workloads
@@ -19,9 +20,11 @@ def setup(request, oracle_built):
     # Above 128 rows of capacity the fused step's frame holds the first 64 rows of efc_J and an env-step with more rows reads J
     # from the env's block in HBM.  The grasp states have 20 - 50 rows: the third variant lowers the frame's share
     # to 8 rows (MJB_DEBUG_JROWS, read when the model is compiled) so that every env-step takes the HBM path.
+    # (round 3: the cap covers EVERY per-row array of the fused frame, and an env-step beyond it keeps all of its row data in the
+    #  HBM block; the fourth variant puts the cap at 24 rows, inside the grasp states' range, so that one rollout mixes both paths)
     hbm = "HBM" in request.param
     if hbm:
-        os.environ["MJB_DEBUG_JROWS"] = "8"
+        os.environ["MJB_DEBUG_JROWS"] = "24" if "mixed" in request.param else "8"
     try:
         cm = engine.CompiledModel(model)
     finally:
