@@ -2758,11 +2758,17 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 		if (nv <= 32) {
 			MJB_KEEP_BRANCH();
 			double Hr[32];
+			// (32 loads in flight, each pinned where it is issued: left alone, the compiler sinks a load into the select that uses it
+			//  and turns the select into a branch on a lane mask it has spilled -- 32 branches with a full LDS round trip each, a
+			//  quarter of this stage.  `lim`: one vector compare per column instead of a held `dofact && c < nv` mask pair)
+			const int lim = dofact ? nv : 0;
 #pragma unroll
 			for (int c = 0; c < 32; c++) {
-				const double v = H[k * nv + (c < nv ? c : 0)];
-				Hr[c] = (dofact && c < nv) ? Mrow[c] + v : 0.0;
+				Hr[c] = H[k * nv + (c < nv ? c : 0)];
+				asm volatile("" : "+v"(Hr[c]));
 			}
+#pragma unroll
+			for (int c = 0; c < 32; c++) Hr[c] = c < lim ? Mrow[c] + Hr[c] : 0.0;
 			// (two half-loops: one 32-column nest exceeds LLVM's pragma-unroll size cap and would leave Hr in scratch)
 			chol_cols16<0>(Hr, nv, lane, myrinv);
 			if (nv > 16) {
