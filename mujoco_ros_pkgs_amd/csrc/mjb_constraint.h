@@ -2449,7 +2449,11 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 
 	// constraint update at the jaref values parked in jar_s: returns this lane's cost share; forces (and, when
 	// `hess`, the Hessian weights hw / cone blocks Hc) written to LDS
-	auto cone_update = [&](bool hess) -> double {
+	// (cones: straight-line code in the contact's leader lane -- every load of the contact's rows in flight at once through clamped
+	//  indices, the three zones by selects: the leaders of a wave sit in different zones anyway and ran them one after the other,
+	//  with a branch and an LDS round trip per `j < dim` test; DMAX = the model's largest contact dimension rounded up to 4 or 6)
+	auto cone_update_d = [&](auto DIMC, bool hess) -> double {
+		constexpr int DMAX = decltype(DIMC)::value;
 		double cost = 0;
 #pragma unroll
 		for (int i = 0; i < R; i++) {
@@ -2471,63 +2475,70 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 				const int dim = cdim[i];
 				const double mu = cmu[i];
 				const double *cfri = f + L.contact_friction + 5 * rcon[i];
-				double U[6], x[6], Dj[6], TT = 0;
-				for (int j = 0; j < 6; j++) {
-					if (j < dim) {
-						x[j] = jar_s[r + j];
-						Dj[j] = Dp[r + j];
-						U[j] = (j == 0 ? mu : cfri[j > 0 ? j - 1 : 0]) * x[j];
-						if (j > 0) TT += U[j] * U[j];
-					} else {
-						x[j] = 0; Dj[j] = 0; U[j] = 0;
-					}
+				double U[DMAX], x[DMAX], Dj[DMAX], fr[DMAX], TT = 0;
+#pragma unroll
+				for (int j = 0; j < DMAX; j++) {
+					const int jj = j < dim ? j : 0;
+					x[j] = jar_s[r + jj];
+					Dj[j] = Dp[r + jj];
+					fr[j] = cfri[(j > 0 && j < dim) ? j - 1 : 0];
+				}
+#pragma unroll
+				for (int j = 0; j < DMAX; j++) {
+					const bool in = j < dim;
+					x[j] = in ? x[j] : 0.0;
+					Dj[j] = in ? Dj[j] : 0.0;
+					fr[j] = j == 0 ? mu : fr[j];
+					U[j] = fr[j] * x[j];
+					if (j > 0) TT += U[j] * U[j];
 				}
 				const double N = U[0], T = sqrt(TT);
-				double *hc = hcb(rcon[i], r);
-				if (hess)
-					for (int j = 0; j < hcd * hcd; j++) hc[j] = 0;
-				if (N >= mu * T) {
-					for (int j = 0; j < 6; j++)
-						if (j < dim) forcep[r + j] = 0;
-				} else if (mu * N + T <= 0) {
-					for (int j = 0; j < 6; j++)
-						if (j < dim) {
-							forcep[r + j] = -Dj[j] * x[j];
-							cost += 0.5 * Dj[j] * x[j] * x[j];
-							if (hess) hc[j * hcd + j] = Dj[j];
-						}
-				} else {
-					// (one reciprocal of T instead of a division per force and per block entry: the middle zone's 16 entries were
-					//  ~20 dependent fp64 divisions in the cone's leader lane, on every iteration's critical path)
-					const double Dm = Dj[0] / (mu * mu * (1 + mu * mu)), NmT = N - mu * T, iT = 1.0 / T, iT3 = iT * iT * iT;
-					cost += 0.5 * Dm * NmT * NmT;
-					const double f0 = -Dm * NmT * mu;
-					forcep[r] = f0;
-					double g[6];
-					g[0] = mu;
-					for (int j = 1; j < 6; j++) {
-						g[j] = 0;
-						if (j < dim) {
-							forcep[r + j] = -f0 * iT * U[j] * cfri[j - 1];
-							g[j] = -mu * cfri[j - 1] * U[j] * iT;
+				const bool top = N >= mu * T, bottom = !top && mu * N + T <= 0, middle = !top && !bottom;
+				// (middle zone => T > 0; the other zones compute it on T = 1 and discard it)
+				const double Ts = middle ? T : 1.0;
+				const double Dm = Dj[0] / (mu * mu * (1 + mu * mu)), NmT = N - mu * T, iT = 1.0 / Ts, iT3 = iT * iT * iT;
+				const double f0 = -Dm * NmT * mu;
+				double g[DMAX];
+				g[0] = mu;
+#pragma unroll
+				for (int j = 1; j < DMAX; j++) g[j] = j < dim ? -mu * fr[j] * U[j] * iT : 0.0;
+#pragma unroll
+				for (int j = 0; j < DMAX; j++) {
+					cost += (bottom && j < dim) ? 0.5 * Dj[j] * x[j] * x[j] : 0.0;
+					const double fm = j == 0 ? f0 : -f0 * iT * U[j] * fr[j];
+					const double fj = top ? 0.0 : (bottom ? -Dj[j] * x[j] : fm);
+					if (j < dim) forcep[r + j] = fj;
+				}
+				cost += middle ? 0.5 * Dm * NmT * NmT : 0.0;
+				if (hess) {
+					double *hc = hcb(rcon[i], r);
+#pragma unroll
+					for (int j = 0; j < DMAX; j++) {
+#pragma unroll
+						for (int c2 = 0; c2 < DMAX; c2++) {
+							if (j >= hcd || c2 >= hcd) continue;  // (wave-uniform: the block is hcd x hcd)
+							double vm = Dm * g[j] * g[c2];
+							if (j >= 1 && c2 >= 1) vm += -Dm * NmT * mu * fr[j] * fr[c2] * ((j == c2 ? iT : 0.0) - U[j] * U[c2] * iT3);
+							const double vb = j == c2 ? Dj[j] : 0.0;
+							const bool in = j < dim && c2 < dim;
+							hc[j * hcd + c2] = (in && !top) ? (bottom ? vb : vm) : 0.0;
 						}
 					}
-					if (hess)
-						for (int j = 0; j < 6; j++)
-							for (int c2 = 0; c2 < 6; c2++) {
-								if (j >= dim || c2 >= dim) continue;
-								double v = Dm * g[j] * g[c2];
-								if (j >= 1 && c2 >= 1)
-									v += -Dm * NmT * mu * cfri[j - 1] * cfri[c2 - 1] * ((j == c2 ? iT : 0.0) - U[j] * U[c2] * iT3);
-								hc[j * hcd + c2] = v;
-							}
-				}
-				if (hess)
-					for (int j = 0; j < 6; j++)
+#pragma unroll
+					for (int j = 0; j < DMAX; j++)
 						if (j < dim) hw[r + j] = 0;
+				}
 			}
 		}
 		return cost;
+	};
+	auto cone_update = [&](bool hess) -> double {
+		if (hcd <= 4) {
+			MJB_KEEP_BRANCH();
+			return cone_update_d(std::integral_constant<int, 4>{}, hess);
+		}
+		MJB_KEEP_BRANCH();
+		return cone_update_d(std::integral_constant<int, 6>{}, hess);
 	};
 
 	EPROF(24);
@@ -2574,11 +2585,20 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 			if (rowact[i]) jar_s[rr[i]] = jaref[i];
 		if (dofact) Ma[k] = ma;
 		sync();
+#ifdef MJB_PROFILE_NWT
+		EPROF(20);
+#endif
 		const double ck = cone_update(true);
+#ifdef MJB_PROFILE_NWT
+		EPROF(21);
+#endif
 		const double gauss = wave_sum(gk);
 		prev_cost = cost;
 		cost = gauss + wave_sum(ck);
 		sync();
+#ifdef MJB_PROFILE_NWT
+		EPROF(22);
+#endif
 		double gr = 0;
 		if (dofact) {
 			double s = 0;
@@ -2593,6 +2613,9 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 			const double gnorm = scale * sqrt(wave_sum(gr * gr));
 			if (improvement < tol || gnorm < tol || iter >= m.iterations) break;
 		}
+#ifdef MJB_PROFILE_NWT
+		EPROF(23);
+#endif
 		EPROF(26);
 		double x = 0;
 		if constexpr (CGS) {

@@ -27,7 +27,7 @@ ap.add_argument("--solver", default="")
 ap.add_argument("--sub", action="store_true", help="libmjb_prof_sub.so: slots 24-29 = collision / make_constraint sub-stages (PGS runs)")
 a = ap.parse_args()
 
-binding.LIB_PATH = os.path.join(ROOT, "mujoco_ros_pkgs_amd", "csrc", "libmjb_prof_sub.so" if a.sub else "libmjb_prof.so")
+binding.LIB_PATH = os.environ.get("MJB_PROF_LIB") or os.path.join(ROOT, "mujoco_ros_pkgs_amd", "csrc", "libmjb_prof_sub.so" if a.sub else "libmjb_prof.so")
 if a.sub:
     STAGES[19] = "pgs.setup (B row, b, warmstart)"
     STAGES[21], STAGES[22] = "pgs.sweeps per step [count, not cycles]", "pgs.rows per step [count, not cycles]"
