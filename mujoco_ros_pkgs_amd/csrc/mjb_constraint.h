@@ -2447,6 +2447,40 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 		}
 	};
 
+	// nv <= 32: (M x)_k and the lane's J_r . x - sub aref_r in one go -- x crosses from LDS to registers once (broadcast reads shared by
+	// both products), every load of a row of J is in flight at once (clamped columns times an x that is zero beyond nv: exact no-ops)
+	// where the counted loop fetched five at a time; same summation order as m_dot / row_dots
+	// (one row per lane only: with more the 32 extra registers of x cost the 2- / 4-row kernels spills -- config 3 under Newton -3.5 %)
+	auto dots = [&](const double *x, double sub, double &mx, double *out) {
+		if (R == 1 && mreg) {
+			MJB_KEEP_BRANCH();
+			double xz[32];
+#pragma unroll
+			for (int c = 0; c < 32; c++) {
+				const double v = x[c < nv ? c : 0];
+				xz[c] = c < nv ? v : 0.0;
+			}
+			double t = 0;
+#pragma unroll
+			for (int c = 0; c < 32; c++) t += Mrow[c] * xz[c];
+			mx = t;
+#pragma unroll
+			for (int i = 0; i < R; i++) {
+				out[i] = 0;
+				if (64 * i >= nefc) continue;  // wave-uniform: no row of this slot exists
+				const double *Jr = Jb + rr[i] * nv;
+				double s = -sub * aref[i];
+#pragma unroll
+				for (int c = 0; c < 32; c++) s += Jr[c < nv ? c : 0] * xz[c];
+				out[i] = s;
+			}
+		} else {
+			MJB_KEEP_BRANCH();
+			mx = m_dot(x);
+			row_dots(x, sub, out);
+		}
+	};
+
 	// constraint update at the jaref values parked in jar_s: returns this lane's cost share; forces (and, when
 	// `hess`, the Hessian weights hw / cone blocks Hc) written to LDS
 	// (cones: straight-line code in the contact's leader lane -- every load of the contact's rows in flight at once through clamped
@@ -2547,10 +2581,9 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 		double best = 0;
 		for (int pass = 0; pass < 2; pass++) {
 			const double *q0 = f + (pass == 0 ? L.qacc_warmstart : L.qacc_smooth);
-			const double t = m_dot(q0);
+			double t, x[R];
+			dots(q0, 1.0, t, x);
 			const double gk = dofact ? 0.5 * (t - f[L.qfrc_smooth + k]) * (q0[k] - f[L.qacc_smooth + k]) : 0.0;
-			double x[R];
-			row_dots(q0, 1.0, x);
 #pragma unroll
 			for (int i = 0; i < R; i++)
 				if (rowact[i]) jar_s[rr[i]] = x[i];
@@ -2576,10 +2609,9 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 	for (;;) {
 		EPROF(30);
 		// Ma = M qacc, jaref = J qacc - aref, forces, cost, gradient
-		const double ma = m_dot(qa);
+		double ma, jaref[R];
+		dots(qa, 1.0, ma, jaref);
 		const double gk = dofact ? 0.5 * (ma - f[L.qfrc_smooth + k]) * (qa[k] - f[L.qacc_smooth + k]) : 0.0;
-		double jaref[R];
-		row_dots(qa, 1.0, jaref);
 #pragma unroll
 		for (int i = 0; i < R; i++)
 			if (rowact[i]) jar_s[rr[i]] = jaref[i];
@@ -2601,9 +2633,21 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 #endif
 		double gr = 0;
 		if (dofact) {
+			// (blocks of eight rows with every load of a block in flight; rows past nefc: row 0 times a zero force, an exact no-op)
 			double s = 0;
-#pragma unroll 4
-			for (int i = 0; i < nefc; i++) s += Jb[i * nv + k] * forcep[i];
+#pragma nounroll
+			for (int i0 = 0; i0 < nefc; i0 += 8) {
+				double jv8[8], fv8[8];
+#pragma unroll
+				for (int q = 0; q < 8; q++) {
+					const int ii = i0 + q < nefc ? i0 + q : 0;
+					jv8[q] = Jb[ii * nv + k];
+					const double fv = forcep[ii];
+					fv8[q] = i0 + q < nefc ? fv : 0.0;
+				}
+#pragma unroll
+				for (int q = 0; q < 8; q++) s += jv8[q] * fv8[q];
+			}
 			f[L.qfrc_constraint + k] = s;
 			gr = ma - f[L.qfrc_smooth + k] - s;
 			grad[k] = gr;
@@ -2881,9 +2925,8 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 		if (dofact) srch[k] = sk;
 		sync();
 		// line search along the Newton direction
-		const double mv = m_dot(srch);
-		double jv[R];
-		row_dots(srch, 0.0, jv);
+		double mv, jv[R];
+		dots(srch, 0.0, mv, jv);
 #pragma unroll
 		for (int i = 0; i < R; i++)
 			if (rowact[i]) jv_s[rr[i]] = jv[i];
