@@ -321,6 +321,8 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact, int jrows_req = 
 	off += lean ? 0 : d.nM;
 	L.qHdi = off;
 	off += d.nv;
+	L.rk = d.integrator == MJB_INT_RK4 ? off : -1;  // (persistent across the evaluations of one step)
+	off += d.integrator == MJB_INT_RK4 ? d.nq + 4 * d.nv + d.nsensordata : 0;
 	// transient scratch of the constrained kernels: ntri doubles for the packed dense triangle of the L'DL factor (nv <= 16, PGS:
 	// the J M^-1 rows; 16 < nv <= 32: the M^-1 solves of fwd_acceleration / Euler, solve_tri32), 128 for the box - box narrow phase
 	const int ntri = d.nefcmax <= 0 ? 0 : ((d.nv <= 16 && d.solver == MJB_SOL_PGS) ? 128 : ((d.nv > 16 && d.nv <= 32) ? 496 : 0));
@@ -623,8 +625,8 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		fail(MJB_EUNSUPPORTED, "mjb_compile: actuator activations (na > 0) are not supported");
 		return nullptr;
 	}
-	if (d.integrator != MJB_INT_EULER) {
-		fail(MJB_EUNSUPPORTED, "mjb_compile: only the Euler integrator is implemented");
+	if (d.integrator != MJB_INT_EULER && d.integrator != MJB_INT_RK4) {
+		fail(MJB_EUNSUPPORTED, "mjb_compile: only the Euler and RK4 integrators are implemented");
 		return nullptr;
 	}
 	if (!(d.timestep[0] > 0)) {
@@ -1405,7 +1407,7 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 		}
 	}
 	int rc = mjb_launch_step(b->params_dev, compact ? b->model->Lc : b->L, env_lo, env_hi, mode, nsteps, b->step_counter, b->lanes,
-	                         b->epb, variant | (chunk << 8), (b->lanes == 16 && !b->env_mass && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16 && b->model->h.nu <= 16 && b->model->h.njnt <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, stream);
+	                         b->epb, variant | (chunk << 8), (b->lanes == 16 && !b->env_mass && b->model->h.integrator == MJB_INT_EULER && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16 && b->model->h.nu <= 16 && b->model->h.njnt <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, stream);
 	if (rc != 0) return fail(MJB_ENODEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
 	return MJB_OK;
 }

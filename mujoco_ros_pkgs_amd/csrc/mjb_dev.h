@@ -88,6 +88,7 @@ struct FrameLayout {
 	int eulerx;    // [nv]      Euler: velocity-update right-hand side / solution (transient)
 	int dadr;      // [64 ints] constrained kernels, nv <= 16: packed dense address map of lanes 0-15 (int frame)
 	int tri;       // transient scratch: packed dense triangle of the L'DL factor (PGS, nv <= 16: 128 doubles; 16 < nv <= 32: 496, solve_tri32)
+	int rk;        // [nq + 4 nv + nsensordata] RK4 bookkeeping (rk4_stage), -1 under Euler
 	int jrows;     // rows of efc_J the frame holds (nefcmax, except in the fused frame of kernel variant 4: 64, the rest in DevState::efc_Jg)
 	int rcap;      // rows every OTHER per-row array holds (efc_D / aref / b / force / frictionloss / type / id, nwt_row, the row metadata in
 	               // iscratch): nefcmax, except in the X-layout fused frame of kernel variant 4, where it equals jrows (an env-step with

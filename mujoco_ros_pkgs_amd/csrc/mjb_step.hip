@@ -2036,6 +2036,64 @@ template <int G, bool CAN16, bool TRI32 = false, bool JC = false> STAGE void eul
 	gsync<G>();
 }
 
+// mj_RungeKutta(m, d, 4) around the step loop's ONE copy of the forward stages (oracle/mjo_smooth.c mjo_rk4 has the scheme): called after
+// evaluation rk = 0 .. 3 of a step, it folds F_rk = (qvel, qacc) into the weighted sums and either sets the state of evaluation
+// rk + 1 (X0 advanced by h with a_{rk+1} F_rk, positions through the quaternion-aware integration) or, after the last one,
+// advances X0 by h with the sums.  L.rk: q0 [nq] | v0 [nv] | sum B qvel [nv] | sum B qacc [nv] | warmstart [nv] | sensordata [S].
+template <int G> STAGE void rk4_stage(CModel m, CLayout L, const Env &e, int rk)
+{
+	double *f = e.f;
+	const int nq = m.nq, nv = m.nv, ns = m.nsensordata;
+	double *q0 = f + L.rk, *v0 = q0 + nq, *accv = v0 + nv, *acca = accv + nv, *w0 = acca + nv, *sens = w0 + nv;
+	const double h = m.timestep[0];
+	const double B = (rk == 0 || rk == 3) ? 1.0 / 6.0 : 1.0 / 3.0;
+	if (rk == 0) {
+		for (int k = e.lane; k < nq; k += G) q0[k] = f[L.qpos + k];
+		for (int k = e.lane; k < ns; k += G) sens[k] = f[L.sensordata + k];  // (the sub-stage evaluations skip the sensors in the reference)
+	}
+	for (int d = e.lane; d < nv; d += G) {
+		if (rk == 0) v0[d] = f[L.qvel + d];
+		accv[d] = (rk == 0 ? 0.0 : accv[d]) + B * f[L.qvel + d];
+		acca[d] = (rk == 0 ? 0.0 : acca[d]) + B * f[L.qacc + d];
+	}
+	gsync<G>();
+	const bool last = rk == 3;
+	const double a = rk == 2 ? 1.0 : 0.5;
+	// positions first: they read the velocity of evaluation rk (a F_rk) or the weighted sum, before qvel is overwritten
+	for (int j = e.lane; j < m.njnt; j += G) {
+		const int jt = m.jnt_type[j];
+		int pa = m.jnt_qposadr[j], va = m.jnt_dofadr[j];
+		if (jt == MJB_JNT_HINGE || jt == MJB_JNT_SLIDE) {
+			const double v = last ? accv[va] : 0.0 + a * f[L.qvel + va];
+			f[L.qpos + pa] = q0[pa] + h * v;
+		} else {
+			if (jt == MJB_JNT_FREE) {
+				for (int k = 0; k < 3; k++) {
+					const double v = last ? accv[va + k] : 0.0 + a * f[L.qvel + va + k];
+					f[L.qpos + pa + k] = q0[pa + k] + h * v;
+				}
+				pa += 3;
+				va += 3;
+			}
+			double q[4], w[3];
+			ld4(q, q0 + pa);
+			for (int k = 0; k < 3; k++) w[k] = last ? accv[va + k] : 0.0 + a * f[L.qvel + va + k];
+			quat_integrate(q, w, h);
+			st4(f + L.qpos + pa, q);
+		}
+	}
+	gsync<G>();
+	for (int d = e.lane; d < nv; d += G) {
+		f[L.qvel + d] = v0[d] + h * (last ? acca[d] : 0.0 + a * f[L.qacc + d]);
+		if (!last) f[L.qacc_warmstart + d] = w0[d];  // every evaluation of the step starts from the warmstart the step came in with
+	}
+	if (last) {
+		for (int k = e.lane; k < ns; k += G) f[L.sensordata + k] = sens[k];
+		if (e.lane == 0) f[L.time] += h;
+	}
+	gsync<G>();
+}
+
 // ------------------------------------------------------------------------------------------------
 // state <-> HBM, frame <-> HBM workspace
 // ------------------------------------------------------------------------------------------------
@@ -2721,6 +2779,8 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 			if (do_first && checks && nz.enabled) ctrl_noise<G>(m, L, nz, e, step0 + (unsigned int)(st0 + st));
 			PROF(13);
 			// attempt 1 only runs after mj_checkAcc found a bad qacc: reset, full forward, integrate
+			bool rk4 = false;  // (the dense kernels integrate by Euler only: the host picks the generic ones for RK4)
+			if constexpr (DENSE != 0) {
 #pragma nounroll
 			for (int attempt = 0; attempt < 2; attempt++) {
 				if (do_first || attempt) {
@@ -2739,8 +2799,45 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 				if (attempt || !checks || !any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0)) break;
 				reset_frame_state<G>(m, L, s, lite(e), MJB_WARN_BADQACC);
 			}
+			} else {
+			// ... and, with <option integrator="RK4">, the three sub-stage evaluations of mj_RungeKutta run through the same loop (ONE
+			// copy of the forward stages in the instruction stream): rk = evaluation index, rk4_stage() sets the next state
+			rk4 = do_euler && P->m.integrator == MJB_INT_RK4;
+			int rk = 0;
+			bool again = false;
+#pragma nounroll
+			for (;;) {
+				if (do_first || again || rk) {
+					if (!again && !rk && checks) {
+						const int bad = any_bad<G>(e, L, e.f + L.qpos, m.nq, e.f + L.qvel, m.nv);
+						if (bad) reset_frame_state<G>(m, L, s, lite(e), bad == 1 ? MJB_WARN_BADQPOS : MJB_WARN_BADQVEL);
+					}
+					forward_first<G, CON, DENSE>(P, e, compact);
+					if (st0 + st == (mode == MJB_MODE_STEP ? nsteps : 1) - 1 && P->m.enableflags & MJB_ENBL_ENERGY) VIEW(P, compact, energy<G>(m, L, lite(e)));
+				}
+				if (!do_rest) break;
+				if (rk4 && !rk) {  // the warmstart the step came in with (the solvers save qacc as they finish)
+					VIEW(P, compact, {
+						for (int d = e.lane; d < m.nv; d += G) e.f[L.rk + m.nq + 3 * m.nv + d] = e.f[L.qacc_warmstart + d];
+						gsync<G>();
+					});
+				}
+				// device-side DefaultRobotHWSim::writeSim runs where the reference's control callback fires: after the position
+				// and velocity stages, before actuation (mjcb_control inside mj_forward; mujoco_ros_control_plugin.cpp:153-194)
+				if (hw_on) VIEW(P, compact, hwsim_write<G>(m, L, Pq_->hw, lite(e)));
+				forward_rest<G, CON, DENSE>(P, e, compact);
+				if (!rk && !again && checks && any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0)) {
+					reset_frame_state<G>(m, L, s, lite(e), MJB_WARN_BADQACC);
+					again = true;
+					continue;
+				}
+				if (!rk4) break;
+				VIEW(P, compact, rk4_stage<G>(m, L, e, rk));
+				if (++rk == 4) break;
+			}
+			}
 			PROF(14);  // whole forward (incl. checks)
-			if (do_euler) VIEW(P, compact, euler<G, (CON != 0), (CON >= 2 && CON <= 4), (DENSE != 0)>(m, L, e));
+			if (do_euler && !rk4) VIEW(P, compact, euler<G, (CON != 0), (CON >= 2 && CON <= 4), (DENSE != 0)>(m, L, e));
 			PROF(15);
 		}
 

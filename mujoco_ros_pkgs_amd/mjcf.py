@@ -311,6 +311,10 @@ class _Compiler:
                 self.opt["cone"] = {"pyramidal": 0, "elliptic": 1}[v]
             elif k == "solver":
                 self.opt["solver"] = {"PGS": 0, "CG": 1, "Newton": 2}[v]
+            elif k == "integrator":
+                if v not in ("Euler", "RK4"):
+                    raise MjcfError("only the Euler and RK4 integrators are implemented")
+                self.opt["integrator"] = {"Euler": 0, "RK4": 1}[v]
             elif k in ("timestep", "tolerance", "impratio", "iterations"):
                 self.opt[k] = v
             else:
@@ -340,8 +344,9 @@ class _Compiler:
         if "iterations" in a:
             o["iterations"] = int(a["iterations"])
         if "integrator" in a:
-            if a["integrator"] != "Euler":
-                raise MjcfError("only the Euler integrator is implemented")
+            if a["integrator"] not in ("Euler", "RK4"):
+                raise MjcfError("only the Euler and RK4 integrators are implemented (implicit / implicitfast are refused)")
+            o["integrator"] = {"Euler": 0, "RK4": 1}[a["integrator"]]
         if "cone" in a:
             o["cone"] = {"pyramidal": 0, "elliptic": 1}[a["cone"]]
         if "solver" in a:

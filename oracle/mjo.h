@@ -53,6 +53,7 @@ typedef struct mjo_data {
 	double *scratch_MM;
 	double *scratch_nv;
 	double *scratch_nv2;
+	double *rk_warmstart; /* [nv] RK4: the warmstart the step came in with (every sub-stage evaluation starts from it) */
 } mjo_data;
 
 mjo_data *mjo_make_data(const mjb_model_desc *m); /* mj_makeData  */
@@ -77,6 +78,7 @@ void mjo_fwd_actuation(const mjb_model_desc *m, mjo_data *d);    /* A12 mj_fwdAc
 void mjo_fwd_acceleration(const mjb_model_desc *m, mjo_data *d); /* A12 mj_fwdAcceleration*/
 void mjo_sensor(const mjb_model_desc *m, mjo_data *d, int stage); /* A15 mj_sensorPos/Vel/Acc */
 void mjo_euler(const mjb_model_desc *m, mjo_data *d);            /* A16 mj_Euler          */
+void mjo_rk4(const mjb_model_desc *m, mjo_data *d);              /*     mj_RungeKutta(4)  */
 
 /* constraint path (mjo_constraint.c) */
 void mjo_collision(const mjb_model_desc *m, mjo_data *d);         /* A4+A5 mj_collision      */

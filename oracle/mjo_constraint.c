@@ -8,6 +8,7 @@
  * only through mj_step / mj_forward (/root/reference mujoco_ros/src/mujoco_env.cpp:498,552,593,329,621).
  */
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "mjo.h"

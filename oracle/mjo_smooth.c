@@ -51,6 +51,7 @@ mjo_data *mjo_make_data(const mjb_model_desc *m)
 	ALLOC(scratch_MM, 2 * m->nM + m->nv)
 	ALLOC(scratch_nv, m->nv)
 	ALLOC(scratch_nv2, m->nv)
+	ALLOC(rk_warmstart, m->nv)
 #undef ALLOC
 	mjo_reset_data(m, d);
 	return d;
@@ -73,6 +74,7 @@ void mjo_free_data(mjo_data *d)
 	free(d->scratch_MM);
 	free(d->scratch_nv);
 	free(d->scratch_nv2);
+	free(d->rk_warmstart);
 	free(d);
 }
 
@@ -986,16 +988,64 @@ void mjo_forward(const mjb_model_desc *m, mjo_data *d)
 	forward_rest(m, d);
 }
 
+/* mj_RungeKutta(m, d, 4) (MuJoCo 2.3.7 engine_forward.c; the classic tableau A = diag(1/2, 1/2, 1), B = (1/6, 1/3, 1/3, 1/6)):
+ * X0 = (qpos, qvel), F0 = (qvel, qacc) of the step's own mj_forward; stage i = 1..3 starts from X0 advanced by h with the
+ * derivative a_i F_{i-1} (positions through mj_integratePos, i.e. quaternions on the sphere), at time t0 + c_i h, evaluated by
+ * mj_forwardSkip(.., mjSTAGE_NONE, skipsensor = 1); the step then advances X0 by h with sum_j B_j F_j (mj_advance with an explicit
+ * velocity).  The constraint solver's warmstart is the one saved by the previous step's mj_advance for every evaluation, and the
+ * last evaluation's qacc becomes the next one.  (No activations: na == 0 in everything this engine loads.) */
+void mjo_rk4(const mjb_model_desc *m, mjo_data *d)
+{
+	static const double A[3] = { 0.5, 0.5, 1.0 }, B[4] = { 1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0 }, C[3] = { 0.5, 0.5, 1.0 };
+	const int nq = m->nq, nv = m->nv, ns = m->nsensordata;
+	const double h = m->timestep[0], t0 = d->time[0];
+	double *buf = (double *)malloc(sizeof(double) * (size_t)(nq + 5 * nv + ns + 1));
+	double *q0 = buf, *v0 = q0 + nq, *accv = v0 + nv, *acca = accv + nv, *w0 = acca + nv, *dxv = w0 + nv, *sens = dxv + nv;
+	memcpy(q0, d->qpos, sizeof(double) * (size_t)nq);
+	memcpy(v0, d->qvel, sizeof(double) * (size_t)nv);
+	memcpy(sens, d->sensordata, sizeof(double) * (size_t)ns);
+	for (int k = 0; k < nv; k++) {
+		accv[k] = 0.0 + B[0] * d->qvel[k];
+		acca[k] = 0.0 + B[0] * d->qacc[k];
+	}
+	for (int i = 1; i < 4; i++) {
+		/* X_i = X0 (+) h a_i F_{i-1}; the warmstart every evaluation of this step starts from is the one the step came in with --
+		 * the solvers here save qacc as they finish, so it is put back (w0 is taken after the first evaluation restored it below) */
+		for (int k = 0; k < nv; k++) dxv[k] = 0.0 + A[i - 1] * d->qvel[k];
+		const double *qa = d->qacc;
+		memcpy(d->qpos, q0, sizeof(double) * (size_t)nq);
+		integrate_pos(m, d->qpos, dxv, h);
+		for (int k = 0; k < nv; k++) d->qvel[k] = v0[k] + h * (0.0 + A[i - 1] * qa[k]);
+		d->time[0] = t0 + C[i - 1] * h;
+		memcpy(d->qacc_warmstart, d->rk_warmstart, sizeof(double) * (size_t)nv);
+		mjo_forward(m, d);
+		for (int k = 0; k < nv; k++) {
+			accv[k] += B[i] * d->qvel[k];
+			acca[k] += B[i] * d->qacc[k];
+		}
+	}
+	memcpy(d->qpos, q0, sizeof(double) * (size_t)nq);
+	for (int k = 0; k < nv; k++) d->qvel[k] = v0[k] + h * acca[k];
+	integrate_pos(m, d->qpos, accv, h);
+	d->time[0] = t0 + h;
+	memcpy(d->sensordata, sens, sizeof(double) * (size_t)ns);  /* (sensors are skipped in the sub-stage evaluations) */
+	(void)w0;
+	free(buf);
+}
+
 void mjo_step2(const mjb_model_desc *m, mjo_data *d)
 {
+	if (m->integrator == MJB_INT_RK4) memcpy(d->rk_warmstart, d->qacc_warmstart, sizeof(double) * (size_t)m->nv);
 	forward_rest(m, d);
 	/* mj_checkAcc */
 	if (bad(d->qacc, m->nv)) {
 		d->warning[MJB_WARN_BADQACC]++;
 		mjo_reset_data(m, d);
+		if (m->integrator == MJB_INT_RK4) memcpy(d->rk_warmstart, d->qacc_warmstart, sizeof(double) * (size_t)m->nv);
 		mjo_forward(m, d);
 	}
-	mjo_euler(m, d);
+	if (m->integrator == MJB_INT_RK4) mjo_rk4(m, d);
+	else mjo_euler(m, d);
 }
 
 void mjo_step(const mjb_model_desc *m, mjo_data *d)

@@ -61,7 +61,7 @@ def test_compile_rejects_bad_models(lib, franka):
     with pytest.raises(engine.EngineError, match="timestep"):
         engine.CompiledModel(mjcf.Model(bad))
     bad = dict(franka)
-    bad["integrator"] = 1
+    bad["integrator"] = 2   # mjINT_IMPLICIT (0 Euler and 1 RK4 are implemented)
     with pytest.raises(engine.EngineError, match="Euler"):
         engine.CompiledModel(mjcf.Model(bad))
     assert lib.mjb_compile(None) is None
