@@ -2803,12 +2803,12 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 			// ... and, with <option integrator="RK4">, the three sub-stage evaluations of mj_RungeKutta run through the same loop (ONE
 			// copy of the forward stages in the instruction stream): rk = evaluation index, rk4_stage() sets the next state
 			rk4 = do_euler && P->m.integrator == MJB_INT_RK4;
-			int rk = 0;
-			bool again = false;
 #pragma nounroll
-			for (;;) {
-				if (do_first || again || rk) {
-					if (!again && !rk && checks) {
+			for (int rk = 0;;) {
+#pragma nounroll
+			for (int attempt = 0; attempt < 2; attempt++) {
+				if (do_first || attempt || rk) {
+					if (attempt == 0 && !rk && checks) {
 						const int bad = any_bad<G>(e, L, e.f + L.qpos, m.nq, e.f + L.qvel, m.nv);
 						if (bad) reset_frame_state<G>(m, L, s, lite(e), bad == 1 ? MJB_WARN_BADQPOS : MJB_WARN_BADQVEL);
 					}
@@ -2826,12 +2826,10 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 				// and velocity stages, before actuation (mjcb_control inside mj_forward; mujoco_ros_control_plugin.cpp:153-194)
 				if (hw_on) VIEW(P, compact, hwsim_write<G>(m, L, Pq_->hw, lite(e)));
 				forward_rest<G, CON, DENSE>(P, e, compact);
-				if (!rk && !again && checks && any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0)) {
-					reset_frame_state<G>(m, L, s, lite(e), MJB_WARN_BADQACC);
-					again = true;
-					continue;
-				}
-				if (!rk4) break;
+				if (attempt || rk || !checks || !any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0)) break;
+				reset_frame_state<G>(m, L, s, lite(e), MJB_WARN_BADQACC);
+			}
+				if (!rk4 || !do_rest) break;
 				VIEW(P, compact, rk4_stage<G>(m, L, e, rk));
 				if (++rk == 4) break;
 			}
