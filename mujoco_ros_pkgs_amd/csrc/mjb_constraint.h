@@ -558,7 +558,7 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const EnvLi
 		gsync<G>();
 		return;
 	}
-#ifdef MJB_PROFILE_SUB
+#if defined(MJB_PROFILE_SUB) || defined(MJB_PROFILE_COL)
 	EPROF_BEGIN();
 #endif
 	int base = 0;  // contacts of the earlier rounds (wave-uniform)
@@ -684,6 +684,9 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const EnvLi
 			}
 			return o;
 		};
+#ifdef MJB_PROFILE_COL
+		EPROF(20);
+#endif
 		{
 			// box - box (up to 8 contacts, dynamically indexed clipping polygons): one lane at a time through the LDS scratch, and
 			// from there straight into the frame.  A lane's slot only depends on the pairs before it: the register pairs below it
@@ -722,6 +725,9 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const EnvLi
 #ifdef MJB_PROFILE_SUB
 		EPROF(24);
 #endif
+#ifdef MJB_PROFILE_COL
+		EPROF(21);
+#endif
 		int total;
 		const int off = slot_of(total);
 		if (n > 0 && !boxbox) {
@@ -737,6 +743,9 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const EnvLi
 		base += total;
 #ifdef MJB_PROFILE_SUB
 		EPROF(25);
+#endif
+#ifdef MJB_PROFILE_COL
+		EPROF(22);
 #endif
 	}
 	if (lane == 0) {
