@@ -3003,7 +3003,11 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 			if (p.d1 <= 0) p.d1 = MJB_MINVAL;
 		};
 		double alpha;
+#ifdef MJB_PROFILE_NWT  // (slot 19 counts the trial points of the line search: "cycles per call" = evaluations per iteration)
+#define LS_EVAL(P) do { ls_eval(P); if (e.env == 0 && e.lane == 0) mjb_prof_lds[19] += 1; } while (0)
+#else
 #define LS_EVAL(P) ls_eval(P)
+#endif
 		{
 			LsPoint p0, p1, p2, pmid, p1n, p2n;
 			int lsit = 0;
@@ -3067,6 +3071,9 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 		}
 #undef LS_EVAL
 		EPROF(29);
+#ifdef MJB_PROFILE_NWT
+		if (e.env == 0 && e.lane == 0) mjb_prof_lds[32 + 19] += 1;
+#endif
 		if (alpha == 0) break;
 		if (dofact) qa[k] += alpha * sk;
 		iter++;
