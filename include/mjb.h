@@ -164,6 +164,11 @@ int mjb_step2(mjb_batch *b);
 int mjb_step1_prefix(mjb_batch *b, int ncb);
 int mjb_step_rest(mjb_batch *b, int ncb);
 int mjb_step2_prefix(mjb_batch *b, int ncb);
+/* mjb_step2_prefix(ncb) of the split step in flight and mjb_step1_prefix(ncb) of the NEXT step as one launch for the callback envs
+ * (one kernel and one device -> host round trip per step instead of two when steps follow each other: what a caller with control /
+ * passive callbacks only needs -- the state it can read afterwards is the finished step's, the derived fields and the pos / vel
+ * stage sensordata already the next step's).  Same results, bit for bit, as the two calls it replaces. */
+int mjb_step21_prefix(mjb_batch *b, int ncb);
 
 /* Recompute all derived quantities without integrating (mj_forward: mujoco_env.cpp:329, :621;
  * callbacks.cpp:573) and leave the full frame in the HBM workspace for mjb_get. */

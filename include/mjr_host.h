@@ -53,6 +53,8 @@ typedef struct mjr_backend {
 	int (*step1_prefix)(void *self, int ncb);
 	int (*step_rest)(void *self, int ncb);
 	int (*step2_prefix)(void *self, int ncb);
+	/* optional: step2_prefix of the step in flight + step1_prefix of the next one as one launch (mjb_step21_prefix) */
+	int (*step21_prefix)(void *self, int ncb);
 } mjr_backend;
 
 enum {

@@ -1407,7 +1407,7 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 		}
 	}
 	int rc = mjb_launch_step(b->params_dev, compact ? b->model->Lc : b->L, env_lo, env_hi, mode, nsteps, b->step_counter, b->lanes,
-	                         b->epb, variant | (chunk << 8), (b->lanes == 16 && !b->env_mass && b->model->h.integrator == MJB_INT_EULER && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16 && b->model->h.nu <= 16 && b->model->h.njnt <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, stream);
+	                         b->epb, variant | (chunk << 8), (b->lanes == 16 && !b->env_mass && mode != MJB_MODE_STEP21 && b->model->h.integrator == MJB_INT_EULER && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16 && b->model->h.nu <= 16 && b->model->h.njnt <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, stream);
 	if (rc != 0) return fail(MJB_ENODEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
 	return MJB_OK;
 }
@@ -1529,6 +1529,33 @@ int mjb_step2_prefix(mjb_batch *b, int ncb)
 		b->step_counter += 1;
 		b->steps_taken += 1;
 		b->split_ncb = -1;
+	}
+	return rc;
+}
+
+int mjb_step21_prefix(mjb_batch *b, int ncb)
+{
+	if (!b || ncb != b->split_ncb) return fail(MJB_EINVAL, "mjb_step21_prefix without the matching mjb_step1_prefix");
+	int rc = MJB_OK;
+	if (!b->split_rest_done) rc = mjb_step_rest(b, ncb);
+	if (rc != MJB_OK) return rc;
+	if (ncb > 0) {
+		if (!b->frame_valid || !b->st.frame_ws || b->frame_hi < ncb) return fail(MJB_EINVAL, "mjb_step21_prefix without a preceding mjb_step1_prefix");
+		// (trip 1 of the launch -- the next step's first half -- draws its ctrl noise at step_counter + 1, as mjb_step1_prefix would
+		//  after mjb_step2_prefix advanced the counter)
+		rc = launch(b, MJB_MODE_STEP21, 1, 0, ncb);
+	}
+	if (b->rest_pending) {  // join: whatever follows on the batch's stream sees the rest's step too
+		HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_join, 0));
+		b->rest_pending = false;
+	}
+	if (rc == MJB_OK) {
+		b->step_counter += 1;
+		b->steps_taken += 1;
+		b->split_ncb = ncb;  // ... and the next split step is open: its first half has run
+		b->split_rest_done = false;
+		b->frame_valid = true;
+		b->frame_hi = ncb;
 	}
 	return rc;
 }

@@ -197,7 +197,7 @@ struct KernelParams {
 	HwSim hw;
 };
 
-enum { MJB_MODE_STEP = 0, MJB_MODE_FORWARD = 1, MJB_MODE_STEP1 = 2, MJB_MODE_STEP2 = 3 };
+enum { MJB_MODE_STEP = 0, MJB_MODE_FORWARD = 1, MJB_MODE_STEP1 = 2, MJB_MODE_STEP2 = 3, MJB_MODE_STEP21 = 4 /* STEP2 of one step, then STEP1 of the next */ };
 
 // launches (implemented in mjb_step.hip); returns hipError_t as int
 // (steps envs [env_lo, nenv): the whole batch, or a prefix / the rest for the split steps of the host runtime)

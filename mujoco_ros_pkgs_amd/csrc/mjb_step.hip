@@ -2733,7 +2733,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 		else e.mp = nullptr;  // (batches with per-env masses never run the dense kernels)
 		double *ws = s.frame_ws ? s.frame_ws + (size_t)e.env * s.frame_stride : nullptr;
 
-		if (mode == MJB_MODE_STEP2) {
+		if (mode == MJB_MODE_STEP2 || (DENSE == 0 && CON != 9 && mode == MJB_MODE_STEP21)) {
 			// resume: full frame from the workspace, then the (possibly host-modified) state on top
 			// (eight loads in flight per lane: the copy is a chain of HBM round trips otherwise -- a split step of ONE callback env
 			//  is pure latency, profiles/r03_callback_path.txt)
@@ -2767,14 +2767,19 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 
 		// One copy of every stage in the instruction stream (the whole kernel must stay I-cache
 		// resident): modes only switch stage groups on and off.
-		const bool do_first = mode != MJB_MODE_STEP2, do_rest = mode != MJB_MODE_STEP1;
-		const bool do_euler = mode == MJB_MODE_STEP || mode == MJB_MODE_STEP2;
+		// (MJB_MODE_STEP21: the second half of one split step and the first half of the next in one launch -- two trips of the step
+		//  loop, trip 0 = STEP2's stages, trip 1 = STEP1's; the flags below are trip-invariant in every other mode)
+		// (not in the dense kernels nor in the 256-register PGS variant, which only ever runs fused launches: both lose 1 - 2.5 % to the
+		//  extra mode; the host picks the generic / 512-register kernels for this launch)
+		const bool combo = DENSE == 0 && CON != 9 && mode == MJB_MODE_STEP21;
 		const bool checks = mode != MJB_MODE_FORWARD;
 		const int st0 = item_chunk * chunk;  // first step of this work item (0 unless the launch is chunked)
-		const int nst = mode == MJB_MODE_STEP ? (dyn ? (nsteps - st0 < chunk ? nsteps - st0 : chunk) : nsteps) : 1;
-		const bool hw_on = do_rest && checks && P->hw.n > 0;  // device-side DefaultRobotHWSim stage registered
+		const int nst = mode == MJB_MODE_STEP ? (dyn ? (nsteps - st0 < chunk ? nsteps - st0 : chunk) : nsteps) : (combo ? 2 : 1);
 #pragma nounroll
 		for (int st = 0; st < nst; st++) {
+			const bool do_first = combo ? st == 1 : mode != MJB_MODE_STEP2, do_rest = combo ? st == 0 : mode != MJB_MODE_STEP1;
+			const bool do_euler = combo ? st == 0 : (mode == MJB_MODE_STEP || mode == MJB_MODE_STEP2);
+			const bool hw_on = do_rest && checks && P->hw.n > 0;  // device-side DefaultRobotHWSim stage registered
 			PROF_BEGIN();
 			if (do_first && checks && nz.enabled) ctrl_noise<G>(m, L, nz, e, step0 + (unsigned int)(st0 + st));
 			PROF(13);
@@ -2789,7 +2794,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 						if (bad) reset_frame_state<G>(m, L, s, lite(e), bad == 1 ? MJB_WARN_BADQPOS : MJB_WARN_BADQVEL);
 					}
 					forward_first<G, CON, DENSE>(P, e, compact);
-					if (st0 + st == (mode == MJB_MODE_STEP ? nsteps : 1) - 1 && P->m.enableflags & MJB_ENBL_ENERGY) VIEW(P, compact, energy<G>(m, L, lite(e)));
+					if (st0 + st == (mode == MJB_MODE_STEP ? nsteps : nst) - 1 && P->m.enableflags & MJB_ENBL_ENERGY) VIEW(P, compact, energy<G>(m, L, lite(e)));
 				}
 				if (!do_rest) break;
 				// device-side DefaultRobotHWSim::writeSim runs where the reference's control callback fires: after the position
@@ -2813,7 +2818,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 						if (bad) reset_frame_state<G>(m, L, s, lite(e), bad == 1 ? MJB_WARN_BADQPOS : MJB_WARN_BADQVEL);
 					}
 					forward_first<G, CON, DENSE>(P, e, compact);
-					if (st0 + st == (mode == MJB_MODE_STEP ? nsteps : 1) - 1 && P->m.enableflags & MJB_ENBL_ENERGY) VIEW(P, compact, energy<G>(m, L, lite(e)));
+					if (st0 + st == (mode == MJB_MODE_STEP ? nsteps : nst) - 1 && P->m.enableflags & MJB_ENBL_ENERGY) VIEW(P, compact, energy<G>(m, L, lite(e)));
 				}
 				if (!do_rest) break;
 				if (rk4 && !rk) {  // the warmstart the step came in with (the solvers save qacc as they finish)

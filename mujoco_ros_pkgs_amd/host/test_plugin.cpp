@@ -16,6 +16,7 @@ bool TestPlugin::load(const mjModel *m, mjData *d)
 		got_lvl1_nested_struct.store(true);
 		if (rosparam_config_["nested_struct_param_1"].hasMember("nested_struct_param_2")) got_lvl2_nested_struct.store(true);
 	}
+	if (rosparam_config_.hasMember("callbacks") && rosparam_config_["callbacks"].asString() == "control") mask_ = CB_CONTROL | CB_PASSIVE;
 	ctrl_bias = rosparam_config_["ctrl_bias"].asDouble(0.0);
 	passive_bias = rosparam_config_["passive_bias"].asDouble(0.0);
 	bool tmp_fail = false;

@@ -19,6 +19,9 @@ public:
 	void renderCallback(const mjModel *model, mjData *data, mjvScene *scene) override;
 	void lastStageCallback(const mjModel *model, mjData *data) override;
 	void onGeomChanged(const mjModel *model, mjData *data, const int geom_id) override;
+	// config "callbacks": "control" declares the control / passive callbacks only (what a ros_control-style plugin implements,
+	// mujoco_ros_control_plugin.cpp: controlCallback alone) -- the host runtime then chains consecutive split steps
+	unsigned callbackMask() const override { return mask_; }
 
 	std::atomic_bool ran_reset = { false }, ran_control_cb = { false }, ran_passive_cb = { false },
 	                 ran_render_cb = { false }, ran_last_cb = { false }, ran_on_geom_changed_cb = { false };
@@ -29,6 +32,7 @@ public:
 	double ctrl_bias = 0, passive_bias = 0;
 
 private:
+	unsigned mask_ = CB_ALL;
 	const mjModel *m_ = nullptr;
 	mjData *d_ = nullptr;
 };

@@ -214,5 +214,30 @@ def test_prefix_split_step_equals_whole_batch_steps(asset, ncb):
     assert lib.mjb_step1_prefix(b.ptr, ncb) == 0 and lib.mjb_step2_prefix(b.ptr, ncb) == 0
     a.step(1)
     assert np.array_equal(a.get("qpos")[ncb:], b.get("qpos")[ncb:])
+    # chained split steps (mjb_step21_prefix: the second half of a step and the first half of the next in one launch, what the host
+    # runtime issues between two callback rounds): bit-identical to the unchained sequence, derived fields readable in between
+    c = engine.Batch(cm, nenv)
+    c.set("qpos", qpos)
+    c.set("qvel", qvel)
+    c.set_ctrl_noise(WORKLOADS[asset][1], 0.1, 99, 0)
+    assert lib.mjb_step1_prefix(c.ptr, ncb) == 0
+    for k in range(K + 1):
+        assert lib.mjb_step_rest(c.ptr, ncb) == 0
+        if k < K:
+            assert lib.mjb_step21_prefix(c.ptr, ncb) == 0
+            if ncb:
+                assert np.all(np.isfinite(c.get("xpos", 0, ncb)))
+        else:
+            assert lib.mjb_step2_prefix(c.ptr, ncb) == 0
+    # (franka_like: the chained launch runs the generic kernel, the unchained halves the dense one -- same stages, DPP instead of
+    #  loop reductions, so its callback envs agree to rounding; the other models run one kernel both ways: bit for bit)
+    for f in ("qpos", "qvel", "qacc", "time", "ctrl"):
+        x, y = b.get(f), c.get(f)
+        assert np.array_equal(x[ncb:], y[ncb:]), f"chained split steps, fused rest: {f}"
+        if asset == "franka_like" or not exact:
+            assert np.allclose(x[:ncb], y[:ncb], rtol=0, atol=1e-9 * (1 + np.abs(x).max())), f"chained split steps: {f}"
+        else:
+            assert np.array_equal(x[:ncb], y[:ncb]), f"chained split steps: {f}"
     a.close()
     b.close()
+    c.close()

@@ -62,6 +62,10 @@ def main():
     run(model, a.envs, a.steps, SENS, None, "sensors plugin, all envs")
     for n in (1, 64, a.envs):
         run(model, a.envs, a.steps, TEST, n, f"control plugin, callbacks on {n} env(s)")
+    # a plugin with control / passive callbacks only (ros_control's shape): consecutive split steps are chained (mjb_step21_prefix)
+    CTRL = [dict(TEST[0], callbacks="control")]
+    for n in (1, 64):
+        run(model, a.envs, a.steps, CTRL, n, f"control-only plugin (chained split steps), callbacks on {n} env(s)")
 
 
 if __name__ == "__main__":
