@@ -438,21 +438,27 @@ void MujocoEnv::commitData(int env)
 
 // ------------------------------------------------------------------------------------ callbacks fan-out
 // callbacks.cpp:131-157; `cb_view_` is the env instance the current callback round is for
+// (a plugin is called back only for what its callbackMask() declares: the runtime plans launches on the declaration -- fused,
+//  split, chained -- so a callback outside it would see a view the plan did not refresh)
 void MujocoEnv::runControlCbs()
 {
-	for (const auto &plugin : cb_ready_plugins_) plugin->controlCallback(&model_, cb_view_);
+	for (const auto &plugin : cb_ready_plugins_)
+		if (plugin->callbackMask() & MujocoPlugin::CB_CONTROL) plugin->controlCallback(&model_, cb_view_);
 }
 void MujocoEnv::runPassiveCbs()
 {
-	for (const auto &plugin : cb_ready_plugins_) plugin->passiveCallback(&model_, cb_view_);
+	for (const auto &plugin : cb_ready_plugins_)
+		if (plugin->callbackMask() & MujocoPlugin::CB_PASSIVE) plugin->passiveCallback(&model_, cb_view_);
 }
 void MujocoEnv::runRenderCbs(mjvScene *scene)
 {
-	for (const auto &plugin : cb_ready_plugins_) plugin->renderCallback(&model_, cb_view_, scene);
+	for (const auto &plugin : cb_ready_plugins_)
+		if (plugin->callbackMask() & MujocoPlugin::CB_RENDER) plugin->renderCallback(&model_, cb_view_, scene);
 }
 void MujocoEnv::runLastStageCbs()
 {
-	for (const auto &plugin : cb_ready_plugins_) plugin->lastStageCallback(&model_, cb_view_);
+	for (const auto &plugin : cb_ready_plugins_)
+		if (plugin->callbackMask() & MujocoPlugin::CB_LASTSTAGE) plugin->lastStageCallback(&model_, cb_view_);
 }
 void MujocoEnv::notifyGeomChanged(int geom_id)
 {

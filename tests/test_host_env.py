@@ -353,6 +353,32 @@ def test_failed_plugin_load_is_skipped(host, factory):
     env.shutdown()
 
 
+def test_control_only_plugin_chains_split_steps(host, factory):
+    """A plugin that declares control / passive callbacks only ("callbacks": "control": ros_control's shape) lets the runtime chain
+    consecutive split steps (one launch per step between two callback rounds, mjb_step21_prefix; backends without it split as
+    before): every step still delivers one control callback per callback env, the step requests are counted as before, and the
+    trajectory equals the all-callbacks plugin's, whose steps are never chained."""
+    m = mjcf.load_asset("franka_like")
+    nenv, K = 5, 23
+    cfg = {"type": "mujoco_ros/TestPlugin", "ctrl_bias": 1.5, "passive_bias": -0.125}
+    chained = start(host, factory, m, {"unpause": False, "MujocoPlugins": [dict(cfg, callbacks="control")]}, nenv=nenv)
+    plain = start(host, factory, m, {"unpause": False, "MujocoPlugins": [cfg]}, nenv=nenv)
+    for env in (chained, plain):
+        env.set_callback_envs(3)
+        assert env.step(K)
+        assert env.plugin_flag(0, "control_calls") == 3 * K
+    assert not chained.plugin_flag(0, "ran_last_cb") and plain.plugin_flag(0, "ran_last_cb")
+    for e in range(nenv):
+        np.testing.assert_allclose(chained.get_field("qpos", e), plain.get_field("qpos", e), rtol=0, atol=1e-10)
+        np.testing.assert_allclose(chained.get_field("qvel", e), plain.get_field("qvel", e), rtol=0, atol=1e-9)
+        assert abs(chained.get_field("time", e)[0] - K * m["timestep"][0]) < 1e-12
+    # a one-step request after the burst (nothing to chain with) and a reset leave the runtime in step
+    assert chained.step(1) and plain.step(1)
+    np.testing.assert_allclose(chained.get_field("qpos", 0), plain.get_field("qpos", 0), rtol=0, atol=1e-10)
+    for x in (chained, plain):
+        x.shutdown()
+
+
 def test_plugin_data_contract_batched(host, factory):
     """Callbacks run once per env instance per step, see that instance's view, and what they write is used:
     ctrl written in controlCallback drives the actuators, qfrc_passive is ADDED to (plugin_utils.h:91-107)."""
