@@ -984,6 +984,9 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 #ifdef MJB_PROFILE_SUB
 	EPROF_BEGIN();
 #endif
+#ifdef MJB_PROFILE_MK
+	EPROF_BEGIN();
+#endif
 	if (nfr)
 		for (int r = lane; r < m.nefcmax; r += G) rfl(r, 0.0);
 	// Items in MuJoCo's row order, one per lane, 64 at a time: rows per item -> wave prefix sum -> row parameters.
@@ -1035,6 +1038,9 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 		if (it < nitem) adr[it] = n > 0 ? off : -1;
 #ifdef MJB_PROFILE_SUB
 		EPROF(26);
+#endif
+#ifdef MJB_PROFILE_MK
+		EPROF(20);
 #endif
 		if (n == 0) continue;
 		// The lanes of a round hold items of different kinds, and a wave runs divergent branches one after the other: the branches
@@ -1231,6 +1237,9 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 #ifdef MJB_PROFILE_SUB
 	EPROF(27);
 #endif
+#ifdef MJB_PROFILE_MK
+	EPROF(21);
+#endif
 	for (int r = lane; r < nefc; r += G) {
 		if constexpr (TAG == 4) {
 			if (r >= L.rcap) {
@@ -1284,6 +1293,9 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 	}
 #ifdef MJB_PROFILE_SUB
 	EPROF(28);
+#endif
+#ifdef MJB_PROFILE_MK
+	EPROF(22);
 #endif
 	// contact Jacobian rows: one (contact, dof) pair per lane
 	const int npair = ncon * nv;
@@ -1350,6 +1362,9 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 	}
 #ifdef MJB_PROFILE_SUB
 	EPROF(29);
+#endif
+#ifdef MJB_PROFILE_MK
+	EPROF(23);
 #endif
 }
 

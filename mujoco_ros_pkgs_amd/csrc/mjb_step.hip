@@ -308,7 +308,7 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 		}
 	}
 	if constexpr (!REG) gsync<G>();
-#if !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL)  // (slots 20 - 23 carry the sub-stages of the Newton iteration's gradient step / of collision in those builds)
+#if !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL) && !defined(MJB_PROFILE_MK)  // (slots 20 - 23 carry the sub-stages of the Newton iteration's gradient step / of collision in those builds)
 	PROF(20);
 #endif
 
@@ -424,7 +424,7 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 		gsync<G>();
 	}
 
-#if !defined(MJB_PROFILE_SUB) && !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL)  // (slots 21 / 22 carry the PGS sweep / row counts in the sub-stage build)
+#if !defined(MJB_PROFILE_SUB) && !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL) && !defined(MJB_PROFILE_MK) && !defined(MJB_PROFILE_MK)  // (slots 21 / 22 carry the PGS sweep / row counts in the sub-stage build)
 	PROF(21);
 #endif
 	// Phase C -- one body per lane: normalise xquat, final xmat, inertial frame
@@ -464,7 +464,7 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 	}
 	gsync<G>();
 
-#if !defined(MJB_PROFILE_SUB) && !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL)
+#if !defined(MJB_PROFILE_SUB) && !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL) && !defined(MJB_PROFILE_MK) && !defined(MJB_PROFILE_MK)
 	PROF(22);
 #endif
 	// Phase D -- joints (anchor / axis to the world frame through the PARENT body's frame), geoms, sites
@@ -527,7 +527,7 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 		}
 	}
 	gsync<G>();
-#if !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL)
+#if !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL) && !defined(MJB_PROFILE_MK)
 	PROF(23);
 #endif
 }
