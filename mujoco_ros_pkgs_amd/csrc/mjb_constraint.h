@@ -119,12 +119,13 @@ DEVI int raw_sphere_box(RawCon &c, const double *pos1, double r1, const double *
 // the convex axis-to-box distance (the oracle: by bisection on its slope; here: exactly, from the slope's breakpoints), candidate axis points from the closest feature
 // (face: ends of the stretch over the face; inside: ends of the inside stretch; edge / vertex: the minimiser
 // set), each candidate through the sphere-box contact
+#define MJB_CAPBOX_PAR 1e-12  // a direction component below this counts as parallel to that face pair (oracle: MJO_CAPBOX_PAR)
 DEVI double capbox_slope(const double *p0, const double *d, const double *s, double t)
 {
 	double g = 0;
 	for (int i = 0; i < 3; i++) {
 		const double p = p0[i] + t * d[i];
-		g += (p - clipd(p, -s[i], s[i])) * d[i];
+		g += (p - clipd(p, -s[i], s[i])) * (fabs(d[i]) <= MJB_CAPBOX_PAR ? 0.0 : d[i]);
 	}
 	return g;
 }
@@ -147,7 +148,7 @@ DEVI int capsule_box(RawCon *rc, const double *pos1, const double *mat1, const d
 	tk[7] = h;
 #pragma unroll
 	for (int i = 0; i < 3; i++) {
-		const bool par = fabs(d[i]) <= MJB_MINVAL;  // (axis parallel to the face pair: no crossing)
+		const bool par = fabs(d[i]) <= MJB_CAPBOX_PAR;  // (axis parallel to the face pair: no crossing)
 		const double dd = par ? 1.0 : d[i];
 		const double a = (-size2[i] - p0[i]) / dd, b = (size2[i] - p0[i]) / dd;
 		tk[1 + 2 * i] = par ? h : clipd(a, -h, h);

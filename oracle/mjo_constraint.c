@@ -220,12 +220,16 @@ static int sphere_box(rawcon *c, const double *pos1, double r1, const double *po
  *      minimiser set (one point unless the axis is parallel to the edge);
  *   3. each candidate goes through sphere_box(); candidates closer than 1e-6 h collapse into one.
  * The HIP narrow phase (mjb_constraint.h, capsule_box) follows the same steps operation for operation. */
+/* (a direction component below 1e-12 counts as parallel to that face pair: it contributes nothing to the slope.  Without the
+ *  snap an axis that is parallel to a box edge up to rounding gives a slope of +-1e-18 whose SIGN decides between one contact and
+ *  two -- found by tests/test_gpu_capsule_box.py, where the GPU's and this file's rotation matrices differ in the last bit) */
+#define MJO_CAPBOX_PAR 1e-12
 static double capbox_slope(const double *p0, const double *d, const double *s, double t)
 {
 	double g = 0;
 	for (int i = 0; i < 3; i++) {
 		double p = p0[i] + t * d[i];
-		g += (p - clipd(p, -s[i], s[i])) * d[i];
+		g += (p - clipd(p, -s[i], s[i])) * (fabs(d[i]) <= MJO_CAPBOX_PAR ? 0.0 : d[i]);
 	}
 	return g;
 }
