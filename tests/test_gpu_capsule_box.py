@@ -81,3 +81,57 @@ def test_gpu_capsule_box_matches_oracle(oracle_built):
         np.testing.assert_allclose(frame[e][:9 * n], d.contact_frame[:9 * n], rtol=0, atol=1e-8, err_msg=f"pose {e}")
     assert two >= 15 and one >= 50 and none >= 3, (two, one, none)   # every outcome of the routine was exercised
     b.close()
+
+
+XML_CC = f"""
+<mujoco><compiler angle="radian"/>
+<option timestep="0.001" cone="elliptic" solver="Newton"/>
+<worldbody>
+  <body name="fix" pos="0 0 0"><geom name="fix" type="capsule" size="0.025 0.12" margin="{MARGIN}"/></body>
+  <body name="mov" pos="0 0 0.5"><freejoint/><geom name="mov" type="capsule" size="{RAD} {HALF}" mass="0.2" margin="{MARGIN}"/></body>
+</worldbody></mujoco>
+"""
+
+
+def test_gpu_capsule_capsule_matches_oracle(oracle_built):
+    """The same for capsule - capsule (closest points of two segments; the parallel case takes its own branch with up to two
+    contacts): random poses, exactly parallel side by side / offset / overlapping partly, end to end on one line, crossing at right
+    angles, and nearly parallel (1e-9 .. 1e-5 rad) where the determinant of the 2 x 2 system is at the rounding level."""
+    from mujoco_ros_pkgs_amd import engine
+    m = mjcf.compile_xml_string(XML_CC)
+    rng = np.random.default_rng(5)
+    P = []
+    for _ in range(300):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        u = rng.normal(size=3)
+        u /= np.linalg.norm(u)
+        P.append((u * rng.uniform(0.0, 0.025 + RAD + MARGIN + 0.03) + np.array([0, 0, rng.uniform(-0.15, 0.15)]), q))
+    gap = 0.025 + RAD
+    for dz in (-0.01, 0.0, 0.01, 0.05):
+        for zoff in (0.0, 0.05, 0.15, 0.21):                      # parallel: aligned, shifted, partly / barely overlapping
+            P.append((np.array([gap + dz, 0, zoff]), np.array([1.0, 0, 0, 0])))
+        P.append((np.array([0, 0, 0.12 + HALF + gap + dz]), np.array([1.0, 0, 0, 0])))        # end to end on one line
+        P.append((np.array([gap + dz, 0, 0]), _axis_to_quat((0, 1, 0))))                    # crossing at right angles
+        for ang in (1e-9, 1e-8, 1e-7, 1e-6, 1e-5):                 # nearly parallel
+            P.append((np.array([gap + dz, 0, 0.03]), _axis_to_quat((np.sin(ang), 0, np.cos(ang)))))
+    nenv = len(P)
+    qpos = np.array([np.concatenate([p, q]) for p, q in P])
+    b = engine.Batch(engine.CompiledModel(m), nenv)
+    b.set("qpos", qpos)
+    b.forward()
+    ncon, dist, pos, frame = b.get("ncon"), b.get("contact_dist"), b.get("contact_pos"), b.get("contact_frame")
+    d = oracle_built.OracleData(m)
+    counts = [0, 0, 0]
+    for e in range(nenv):
+        d.reset()
+        d.qpos[:] = qpos[e]
+        d.forward()
+        n = int(d.ncon[0])
+        assert ncon[e, 0] == n, f"pose {e}: {ncon[e, 0]} contacts, oracle {n}"
+        counts[min(n, 2)] += 1
+        np.testing.assert_allclose(dist[e][:n], d.contact_dist[:n], rtol=0, atol=1e-10, err_msg=f"pose {e}")
+        np.testing.assert_allclose(pos[e][:3 * n], d.contact_pos[:3 * n], rtol=0, atol=1e-7, err_msg=f"pose {e}")
+        np.testing.assert_allclose(frame[e][:9 * n], d.contact_frame[:9 * n], rtol=0, atol=1e-7, err_msg=f"pose {e}")
+    assert counts[0] >= 3 and counts[1] >= 50 and counts[2] >= 4, counts
+    b.close()
