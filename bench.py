@@ -207,10 +207,11 @@ def roofline_block(name, cfgno, solver_tag, E, S, samples):
     return out
 
 
-def measure_other_config(cfgno, device, launches=3):
+def measure_other_config(cfgno, device, launches=5):
     """One of the other BASELINE workloads (3 = configs[2], 5 = configs[4]'s per-GPU shard), measured in this process after
     the headline timing so that the DRIVER's record carries it (VERDICT r02 #3a): `launches` timed fused launches bracketed
-    by synchronisation, then five single-launch kernel samples."""
+    by synchronisation (five, like the standalone `--config N` run: config 3's first launches after the synthetic start are its
+    heaviest, three of them read 2 % low), then five single-launch kernel samples."""
     from mujoco_ros_pkgs_amd import engine, mjcf
     name = CONFIG_MODEL[cfgno]
     label, noise_std, E, S, _ = WORKLOADS[name]
