@@ -2829,7 +2829,8 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 				}
 				// device-side DefaultRobotHWSim::writeSim runs where the reference's control callback fires: after the position
 				// and velocity stages, before actuation (mjcb_control inside mj_forward; mujoco_ros_control_plugin.cpp:153-194)
-				if (hw_on) VIEW(P, compact, hwsim_write<G>(m, L, Pq_->hw, lite(e)));
+				// (RK4: once per step, at the step's own evaluation -- the PID state advances by one period; its forces stay for the sub-stages)
+				if (hw_on && !rk) VIEW(P, compact, hwsim_write<G>(m, L, Pq_->hw, lite(e)));
 				forward_rest<G, CON, DENSE>(P, e, compact);
 				if (attempt || rk || !checks || !any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0)) break;
 				reset_frame_state<G>(m, L, s, lite(e), MJB_WARN_BADQACC);

@@ -86,9 +86,12 @@ def test_oracle_semantics(oracle_built):
 
 
 @pytest.mark.gpu
-def test_gpu_matches_oracle(oracle_built):
+@pytest.mark.parametrize("integrator", ["Euler", "RK4"])
+def test_gpu_matches_oracle(oracle_built, integrator):
+    """(RK4: the stage runs once per step, at the step's own evaluation -- its PID state advances by one period -- and the forces it
+    wrote stay for the three sub-stage evaluations, on the GPU as in the oracle's rollout.)"""
     from mujoco_ros_pkgs_amd import engine
-    model = mjcf.load_asset("franka_like")
+    model = mjcf.load_asset("franka_like", override={"integrator": integrator})
     spec = _cfg(model)
     cfg = _oracle_cfg(spec)
     nenv, n = 16, len(spec)

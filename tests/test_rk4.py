@@ -87,6 +87,16 @@ def test_gpu_rk4_matches_oracle(kind, oracle_built):
         outs.append((b.get("qpos"), b.get("qvel"), b.get("sensordata"), b.get("time")))
         b.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])   # split == fused, bit for bit
+    # ... and so are chained split steps (second half of one step + first half of the next in one launch, mjb_step21_prefix)
+    b = engine.Batch(cm, nenv)
+    b.set("qpos", qpos)
+    b.set("qvel", qvel)
+    b.set("ctrl", ctrl)
+    assert b.lib.mjb_step1_prefix(b.ptr, nenv) == 0
+    for k in range(K):
+        assert (b.lib.mjb_step21_prefix if k + 1 < K else b.lib.mjb_step2_prefix)(b.ptr, nenv) == 0
+    assert np.array_equal(b.get("qpos"), outs[0][0]) and np.array_equal(b.get("qvel"), outs[0][1])
+    b.close()
     q, v, sd, t = outs[0]
     oq, ov, osd = oracle_built.rollout(model, qpos, qvel, K, ctrl=ctrl)
     tol = 1e-9 if kind == "franka_like" else 1e-7
