@@ -409,8 +409,24 @@ DEVI int box_box(double *scr, const double *pos1, const double *mat1, const doub
 }
 
 // narrow phase of one candidate pair; returns the number of raw contacts (<= 4; box - box: <= 8)
+// (plane - box: up to four contacts that share the plane's normal -- only the ids of the qualifying corners come back, packed three
+//  bits each in `pbc`; collision() rebuilds distance and point of each where it stores them.  Every other pair yields <= 2 contacts
+//  in rc[]: two contact records less to keep in registers across the narrow phase of the 256-register PGS kernel.)
+DEVI void plane_box_contact(int i, const double *pos1, const double *nrm, const double *pos2, const double *mat2, const double *size2,
+                            double &cdist, double *cpos)
+{
+	const double dif[3] = { pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2] };
+	const double dist = dot3(dif, nrm);
+	const double vec[3] = { (i & 1) ? size2[0] : -size2[0], (i & 2) ? size2[1] : -size2[1], (i & 4) ? size2[2] : -size2[2] };
+	double corner[3];
+	matvec3(corner, mat2, vec);
+	const double ldist = dot3(nrm, corner);
+	cdist = dist + ldist;
+	for (int k = 0; k < 3; k++) cpos[k] = corner[k] + pos2[k] - nrm[k] * cdist * 0.5;
+}
+
 DEVI int narrowphase(int t1, int t2, const double *pos1, const double *mat1, const double *size1, const double *pos2,
-                     const double *mat2, const double *size2, double margin, RawCon *rc)
+                     const double *mat2, const double *size2, double margin, RawCon *rc, int &pbc)
 {
 	int n = 0;
 	if (t1 == MJB_GEOM_PLANE) {
@@ -448,16 +464,7 @@ DEVI int narrowphase(int t1, int t2, const double *pos1, const double *mat1, con
 				if (okmask) {
 					const int i = __builtin_ctz(okmask);
 					okmask &= okmask - 1;
-					const double vec[3] = { (i & 1) ? size2[0] : -size2[0], (i & 2) ? size2[1] : -size2[1],
-						                    (i & 4) ? size2[2] : -size2[2] };
-					double corner[3];
-					matvec3(corner, mat2, vec);
-					const double ldist = dot3(nrm, corner);
-					RawCon &c = rc[slot];
-					c.dist = dist + ldist;
-					c.frame[0] = nrm[0]; c.frame[1] = nrm[1]; c.frame[2] = nrm[2];
-					c.frame[3] = c.frame[4] = c.frame[5] = 0;
-					for (int k = 0; k < 3; k++) c.pos[k] = corner[k] + pos2[k] - nrm[k] * c.dist * 0.5;
+					pbc |= i << (3 * slot);
 					n = slot + 1;
 				}
 			}
@@ -565,7 +572,9 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const EnvLi
 	int base = 0;  // contacts of the earlier rounds (wave-uniform)
 	for (int p0 = 0; p0 < m.ncollpair; p0 += G) {
 		const int p = p0 + lane;
-		RawCon rc[4];  // (every primitive pair but box - box yields <= 4 contacts; box - box contacts go from the LDS scratch straight to the frame)
+		RawCon rc[2];  // (<= 2 contacts in registers; plane - box: the corner ids in pbc; box - box: from the LDS scratch straight to the frame)
+		int pbc = 0;
+		bool planebox = false;
 		int n = 0, g1 = 0, g2 = 0, condim = 1, frisel = 0;
 		double margin = 0, incl = 0;
 		const mjb_cdptr pd = m.pair_d + 24 * (p < m.ncollpair ? p : 0);
@@ -622,7 +631,10 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const EnvLi
 				const int cfun = pi[6];  // MujocoEnv::registerCollisionFunction's override of the pair type (mjb_register_collision)
 				if (cfun == MJB_COLFUNC_DEFAULT) {
 					if (t1 == MJB_GEOM_BOX && t2 == MJB_GEOM_BOX) boxbox = true;
-					else n = narrowphase(t1, t2, pos1, mat1, size1, pos2, mat2, size2, margin, rc);
+					else {
+						n = narrowphase(t1, t2, pos1, mat1, size1, pos2, mat2, size2, margin, rc, pbc);
+						planebox = t1 == MJB_GEOM_PLANE && t2 == MJB_GEOM_BOX;
+					}
 				} else if (cfun == MJB_COLFUNC_SPHERES) {
 					if (t1 == MJB_GEOM_PLANE) {
 						const double nrm[3] = { mat1[2], mat1[5], mat1[8] };
@@ -734,11 +746,31 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const EnvLi
 		if (n > 0 && !boxbox) {
 			double fri[3];
 			pair_friction(fri);
+			if (planebox) {
+				// (the plane's and the box's poses are read again, like the box - box path does: kept in registers they would stay live
+				//  across every pair's narrow phase for this one)
+				const double *gx = f + L.geom_xpos, *gm = f + L.geom_xmat;
+				asm volatile("" : "+v"(gx), "+v"(gm));
+				double p1[3], p2[3], m2[9];
+				ld3(p1, gx + 3 * g1);
+				ld3(p2, gx + 3 * g2);
+				ld9(m2, gm + 9 * g2);
+				const double fr6[6] = { gm[9 * g1 + 2], gm[9 * g1 + 5], gm[9 * g1 + 8], 0, 0, 0 };
 #pragma unroll
-			for (int i = 0; i < 4; i++) {  // (fully unrolled, no early exit: rc[] stays in statically indexed registers)
+				for (int i = 0; i < 4; i++) {
+					const int c = off + i;
+					if (i >= n || c >= m.nconmax) continue;
+					double cd, cp[3];
+					plane_box_contact((pbc >> (3 * i)) & 7, p1, fr6, p2, m2, size2, cd, cp);
+					put_contact(c, cd, cp, fr6, fri);
+				}
+			} else {
+#pragma unroll
+			for (int i = 0; i < 2; i++) {  // (fully unrolled, no early exit: rc[] stays in statically indexed registers)
 				const int c = off + i;
 				if (i >= n || c >= m.nconmax) continue;
 				put_contact(c, rc[i].dist, rc[i].pos, rc[i].frame, fri);
+			}
 			}
 		}
 		base += total;
