@@ -1375,6 +1375,7 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 	{
 		static const int forced = [] { const char *v = getenv("MJB_DEBUG_VARIANT"); return v ? atoi(v) : -1; }();  // measurement knob
 		if ((forced == 1 || forced == 9) && (variant == 1 || variant == 9)) variant = forced;  // (only the two builds of the same PGS step are interchangeable)
+		if (mode == MJB_MODE_STEP21 && variant == 9) variant = 1;  // (the 256-register build carries no chained-step mode)
 	}
 	// long fused launches of the constrained kernels hand out (chunk of steps, env) work items dynamically (mjb_step.hip)
 	// ... unless every env gets a slot of its own (envs <= resident envs per CU x CUs): then the queue has nothing to even out, an
