@@ -1838,21 +1838,36 @@ DEVI void tri_build(CModel m, CLayout L, double *f, double *Ld, int lane)
 	}
 	gsync<64>();
 }
+// (the triangle's base address as seen by one stage of the substitution: Ld plus a zero the compiler cannot see through, computed
+//  from an x that is final MJB_TRI_LAG stages earlier.  Left alone, the scheduler issues the loads of ALL stages up front -- 240 registers of
+//  triangle -- and the 256-register PGS kernel spilled and reloaded eight 16-byte loads at both call sites: 16 KB of scratch traffic
+//  per env-step, essentially all of the kernel's write-backs.  With the address dependency MJB_TRI_LAG stages of loads are in flight.)
+#ifndef MJB_TRI_LAG
+#define MJB_TRI_LAG 8  // stages of triangle loads in flight (MI355X, config 3: lag 4 21.7 M, 6 22.0 M, 8 22.3 M, 12 22.0 M env-steps/s; 8 spills each)
+#endif
+DEVI const double *tri_base(const double *Ld, double dep)
+{
+	int z;
+	asm volatile("v_and_b32 %0, 0, %1" : "=v"(z) : "v"(__double2loint(dep)));
+	return Ld + z;
+}
 DEVI void tri_solve(double (&x)[16], const double *Ld, const double *di, int nv)
 {
 	// x <- L^-T x: once x[i] is final, every x[j < i] takes its share (independent fma)
 #pragma unroll
 	for (int i = 15; i >= 1; i--) {
+		const double *Li = i <= 15 - MJB_TRI_LAG ? tri_base(Ld, x[i + MJB_TRI_LAG - 1]) : Ld;  // (x[i + LAG - 1] is final once row i + LAG has been applied)
 #pragma unroll
-		for (int j = 0; j < i; j++) x[j] -= Ld[i * (i - 1) / 2 + j] * x[i];
+		for (int j = 0; j < i; j++) x[j] -= Li[i * (i - 1) / 2 + j] * x[i];
 	}
 #pragma unroll
 	for (int k = 0; k < 16; k++) x[k] *= di[k < nv ? k : 0];
 	// x <- L^-1 x, column by column (same summation order as the row form)
 #pragma unroll
 	for (int j = 0; j < 15; j++) {
+		const double *Lj = j >= MJB_TRI_LAG ? tri_base(Ld, x[j - MJB_TRI_LAG + 1]) : Ld;  // (x[j - LAG + 1] is final once column j - LAG has been applied)
 #pragma unroll
-		for (int i = j + 1; i < 16; i++) x[i] -= Ld[i * (i - 1) / 2 + j] * x[j];
+		for (int i = j + 1; i < 16; i++) x[i] -= Lj[i * (i - 1) / 2 + j] * x[j];
 	}
 }
 
