@@ -348,8 +348,12 @@ void *mjb_hwsim_command_ptr(mjb_batch *b, int which); /* device [nenv][n] */
 int mjb_hwsim_estop(mjb_batch *b, int active);
 
 /* Profiling builds only (libmjb_prof.so): per-stage shader-cycle sums [0..31] and call counts [32..63] of
- * env 0; all zero in the production build. */
+ * env 0; all zero in the production build.  A launch records the TWO probe ids [first_id, first_id + 2) selected by
+ * mjb_debug_profile_window (32 bytes of LDS: the profiled kernel keeps the shipped kernel's residency); the tool
+ * sweeps the window (tools/profile_stages.py).  No reference counterpart (MuJoCo's own mjTIMER_* slots are the
+ * buckets the reference's GUI profiler plots, viewer.cpp:335-346). */
 int mjb_debug_profile(mjb_batch *b, unsigned long long *out64, int clear);
+int mjb_debug_profile_window(mjb_batch *b, int first_id);
 
 /* Timing helper for bench.py: run `nlaunch` launches of mjb_step(b, nsteps) bracketed by HIP
  * events recorded on the batch's stream; returns the mean per-launch duration in milliseconds

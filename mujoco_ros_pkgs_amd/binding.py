@@ -195,6 +195,7 @@ def load_library(path=None):
         "mjb_metrics": (ci, [vp, C.POINTER(cd)]),
         "mjb_metrics_device": (vp, [vp]),
         "mjb_debug_profile": (ci, [vp, C.POINTER(C.c_uint64), ci]),
+        "mjb_debug_profile_window": (ci, [vp, ci]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

@@ -1279,7 +1279,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 		ok = ok && s.pgs_B;
 	}
 	s.keep_frame = 0;
-	s.pad1 = 0;
+	s.prof_base = 0;
 	if (!ok) {
 		fail(MJB_ENOMEM, "mjb_make_batch: hipMalloc(state) failed for %d envs", nenv);
 		mjb_free_batch(b);
@@ -1974,6 +1974,16 @@ int mjb_debug_profile(mjb_batch *b, unsigned long long *out64, int clear)
 	HIP_TRY(hipStreamSynchronize(b->stream));
 	HIP_TRY(hipMemcpy(out64, b->st.prof, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 	if (clear) HIP_TRY(hipMemset(b->st.prof, 0, 64 * sizeof(unsigned long long)));
+	return MJB_OK;
+}
+
+int mjb_debug_profile_window(mjb_batch *b, int first_id)
+{
+	if (!b || first_id < 0 || first_id > 31) return fail(MJB_EINVAL, "mjb_debug_profile_window: bad argument");
+	if (b->st.prof_base != first_id) {
+		b->st.prof_base = first_id;
+		b->params_dirty = true;
+	}
 	return MJB_OK;
 }
 

@@ -2246,7 +2246,7 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 	gsync<G>();
 #ifdef MJB_PROFILE_SUB
 	EPROF(31);
-	if (e.env == 0 && lane == 0) { mjb_prof_lds[21] += (unsigned long long)iter; mjb_prof_lds[32 + 21] += 1; mjb_prof_lds[22] += (unsigned long long)nefc; mjb_prof_lds[32 + 22] += 1; }
+	prof_rec(e.env, lane, 21, (unsigned long long)iter); prof_rec(e.env, lane, 22, (unsigned long long)nefc);
 #endif
 	// qfrc_constraint = J' f,  qacc = qacc_smooth + M^-1 J' f = qacc_smooth + B' f
 	if (lane < nv) {
@@ -3067,7 +3067,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 		};
 		double alpha;
 #ifdef MJB_PROFILE_NWT  // (slot 19 counts the trial points of the line search: "cycles per call" = evaluations per iteration)
-#define LS_EVAL(P) do { ls_eval(P); if (e.env == 0 && e.lane == 0) mjb_prof_lds[19] += 1; } while (0)
+#define LS_EVAL(P) do { ls_eval(P); prof_rec(e.env, e.lane, 19, 1, 0); } while (0)
 #else
 #define LS_EVAL(P) ls_eval(P)
 #endif
@@ -3135,7 +3135,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 #undef LS_EVAL
 		EPROF(29);
 #ifdef MJB_PROFILE_NWT
-		if (e.env == 0 && e.lane == 0) mjb_prof_lds[32 + 19] += 1;
+		prof_rec(e.env, e.lane, 19, 0, 1);
 #endif
 		if (alpha == 0) break;
 		if (dofact) qa[k] += alpha * sk;

@@ -129,7 +129,7 @@ struct DevState {
 	double *pgs_B;                   // [nenv][nefcmax * nv] rows of J M^-1 of the PGS steps beyond 64 rows (nv <= 16 models keep them out of LDS); NULL otherwise
 	int use_xfrc;                  // xfrc_applied has ever been written
 	int keep_frame;                // fused mjb_step also dumps the last step's full frame to frame_ws
-	int pad1;
+	int prof_base;                 // profiling build: first of the two probe ids this launch records (mjb_debug_profile_window)
 };
 
 // The env's spill-over block in DevState::efc_Jg (kernel variant 4): efc_J [nefcmax][nv], then -- used only when the frame's row

@@ -70,16 +70,38 @@ template <int N, typename F> DEVI void static_for(F &&f) { static_for_impl(f, st
 
 
 // Optional per-stage cycle accounting (build with -DMJB_PROFILE -> libmjb_prof.so): env 0 / lane 0 adds the
-// s_memtime delta of every stage to DevState::prof[stage].
+// s_memtime delta of the probes inside the launch's WINDOW (two consecutive probe ids, DevState::prof_base) to DevState::prof.
 #ifdef MJB_PROFILE
-// (sums are kept in LDS by the recording lane and flushed to DevState::prof once per launch: a global
-//  read-modify-write per probe costs ~1 k cycles, more than the small stages it measures)
-__shared__ unsigned long long mjb_prof_lds[64];
+// (sums are kept in LDS by the recording lane and flushed to DevState::prof once per launch: a global read-modify-write per
+//  probe costs ~1 k cycles, more than the small stages it measures.  The LDS block is 32 BYTES -- two probes per launch, the tool
+//  sweeps the window over the ids -- because that is what the lean frames leave of their last LDS granule: config 3's 8 x 20448 B
+//  and config 5's 4 x 40864 B keep their residency, so the kernel profiled is the kernel shipped; round 3's 512-byte block cost
+//  config 5 its fourth env per CU and config 3 its second wave per SIMD.)
+struct ProfLds {
+	unsigned long long sum[2];
+	unsigned int cnt[2];
+	unsigned int base, pad;
+};
+__shared__ ProfLds mjb_prof_lds;
+// (NO lane-divergent branch: every lane of the wave that holds env 0 adds the same -- scalar -- delta to the same address and stores
+//  the same sum.  With `if (env == 0 && lane == 0)` around the update, LLVM threaded the recording lane separately through the
+//  two-trip loop of forward_first -- the stages' cross-lane LDS exchanges assume the wave runs them together -- and the probes at
+//  that loop's edges (windows 8 and 16) ran env 0 into mj_checkAcc resets at every step)
+DEVI void prof_rec(int env, int lane, int id, unsigned long long v, unsigned int n = 1)
+{
+	(void)lane;
+	if (__builtin_amdgcn_readfirstlane(env) != 0) return;  // (G < 64: the wave that holds env 0 holds it in its first lanes)
+	const unsigned int rel = (unsigned int)id - (unsigned int)__builtin_amdgcn_readfirstlane((int)mjb_prof_lds.base);
+	if (rel < 2u) {
+		mjb_prof_lds.sum[rel] += v;
+		mjb_prof_lds.cnt[rel] += n;
+	}
+}
 #define PROF_BEGIN() unsigned long long _t0 = __builtin_readcyclecounter()
 #define PROF(id)                                                                      \
 	do {                                                                              \
 		unsigned long long _t1 = __builtin_readcyclecounter();                        \
-		if (e.env == 0 && e.lane == 0) { mjb_prof_lds[id] += _t1 - _t0; mjb_prof_lds[32 + id] += 1; } \
+		prof_rec(e.env, e.lane, id, _t1 - _t0);                        \
 		_t0 = __builtin_readcyclecounter();                                           \
 	} while (0)
 // sub-stage accounting inside stages that do not see DevState (the solvers)
@@ -87,7 +109,7 @@ __shared__ unsigned long long mjb_prof_lds[64];
 #define EPROF(id)                                                                     \
 	do {                                                                              \
 		unsigned long long _et1 = __builtin_readcyclecounter();                       \
-		if (e.env == 0 && e.lane == 0) { mjb_prof_lds[id] += _et1 - _et0; mjb_prof_lds[32 + id] += 1; } \
+		prof_rec(e.env, e.lane, id, _et1 - _et0);                      \
 		_et0 = __builtin_readcyclecounter();                                          \
 	} while (0)
 #else
@@ -2567,7 +2589,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 	Env e;
 #ifdef MJB_PROFILE
 	e.prof = s.prof;
-	if (threadIdx.x < 64) mjb_prof_lds[threadIdx.x] = 0;  // (every block: with the work queue env 0's items run wherever they land)
+	if (threadIdx.x == 0) mjb_prof_lds = ProfLds{ { 0, 0 }, { 0, 0 }, (unsigned int)s.prof_base, 0 };  // (every block: with the work queue env 0's items run wherever they land)
 	__syncthreads();
 #endif
 	e.lane.mask = G - 1;  // (1-D blocks of whole wavefronts: lane in group = hardware lane id & (G - 1))
@@ -2863,7 +2885,10 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 	}
 #ifdef MJB_PROFILE
 	__syncthreads();
-	if (threadIdx.x < 64 && s.prof && mjb_prof_lds[threadIdx.x]) atomicAdd(s.prof + threadIdx.x, mjb_prof_lds[threadIdx.x]);
+	if (threadIdx.x < 2 && s.prof && mjb_prof_lds.cnt[threadIdx.x] && mjb_prof_lds.base + threadIdx.x < 32) {
+		atomicAdd(s.prof + mjb_prof_lds.base + threadIdx.x, mjb_prof_lds.sum[threadIdx.x]);
+		atomicAdd(s.prof + 32 + mjb_prof_lds.base + threadIdx.x, (unsigned long long)mjb_prof_lds.cnt[threadIdx.x]);
+	}
 #endif
 }
 

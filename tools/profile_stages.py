@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
-"""Per-stage shader-cycle breakdown of the step kernel (profiling build libmjb_prof.so, env 0 / lane 0).
-Usage: python tools/profile_stages.py [--lanes G] [--envs E] [--steps K]"""
+"""Per-stage shader-cycle breakdown of the step kernel (profiling build libmjb_prof*.so, env 0 / lane 0).
+
+The profiling kernel records TWO probe ids per launch in 32 bytes of LDS (mjb_debug_profile_window) -- what the lean frames leave
+of their last LDS granule -- so it runs the SAME kernel variant on the SAME frame at the SAME residency as the shipped library; the
+tool repeats the launch (same initial state) with the window moved over the ids.  The header's env-steps/s is the profiling
+build's own; compare it with the bench line.
+Usage: python tools/profile_stages.py [--model M] [--envs E] [--steps K] [--sub|--nwt|--col|--mk]"""
 import argparse
 import ctypes as C
 import os
@@ -20,48 +25,65 @@ STAGES = ["kinematics", "com_pos", "crb", "factorM", "transm+sens_pos", "com_vel
 ap = argparse.ArgumentParser()
 ap.add_argument("--lanes", type=int, default=0)
 ap.add_argument("--epb", type=int, default=0)
-ap.add_argument("--envs", type=int, default=4096)
-ap.add_argument("--steps", type=int, default=200)
+ap.add_argument("--envs", type=int, default=0, help="default: the bench workload's batch")
+ap.add_argument("--steps", type=int, default=0, help="default: the bench workload's steps per launch")
 ap.add_argument("--model", default="franka_like")
 ap.add_argument("--solver", default="")
 ap.add_argument("--sub", action="store_true", help="libmjb_prof_sub.so: slots 24-29 = collision / make_constraint sub-stages (PGS runs)")
+ap.add_argument("--nwt", action="store_true", help="libmjb_prof_nwt.so: slots 20-23 = parts of the Newton iteration's gradient step, 19 = line-search points")
+ap.add_argument("--only", default="", help="comma-separated probe ids (default: all)")
 a = ap.parse_args()
 
-binding.LIB_PATH = os.environ.get("MJB_PROF_LIB") or os.path.join(ROOT, "mujoco_ros_pkgs_amd", "csrc", "libmjb_prof_sub.so" if a.sub else "libmjb_prof.so")
+tag = "_sub" if a.sub else ("_nwt" if a.nwt else "")
+binding.LIB_PATH = os.environ.get("MJB_PROF_LIB") or os.path.join(ROOT, "mujoco_ros_pkgs_amd", "csrc", f"libmjb_prof{tag}.so")
 if a.sub:
     STAGES[19] = "pgs.setup (B row, b, warmstart)"
     STAGES[21], STAGES[22] = "pgs.sweeps per step [count, not cycles]", "pgs.rows per step [count, not cycles]"
     STAGES[30], STAGES[31] = "pgs.AR build", "pgs.warm residual + sweeps"
     STAGES[24:30] = ["col.cull+narrowphase", "col.offsets+params+stores", "mk.count+cut", "mk.row params (pass 2)", "mk.D + equality J",
                      "mk.contact J"]
+if a.nwt:
+    STAGES[19] = "nwt.ls points /iter [count, not cycles]"
+    STAGES[20:24] = ["nwt.g dots+park", "nwt.g cone_update", "nwt.g cost sums", "nwt.g J'f + stop test"]
 from mujoco_ros_pkgs_amd import engine, mjcf  # noqa: E402
+from bench import WORKLOADS, initial_state  # noqa: E402
 
 model = mjcf.load_asset(a.model)
 if a.solver:
     model = mjcf.Model(dict(model))
     model["solver"] = {"PGS": 0, "Newton": 2}[a.solver]
+wl = WORKLOADS.get(a.model, ("", 1.0, 4096, 200, 0))
+envs, steps = a.envs or wl[2], a.steps or wl[3]
 cm = engine.CompiledModel(model)
-b = engine.Batch(cm, a.envs)
+b = engine.Batch(cm, envs)
 b.set_launch(a.lanes, a.epb)
-rng = np.random.default_rng(0)
-from bench import WORKLOADS, initial_state  # noqa: E402
-qp, qv = initial_state(a.model, model, a.envs, 1000)
-b.set("qpos", qp)
-b.set("qvel", qv)
-b.set_ctrl_noise(WORKLOADS.get(a.model, ("", 1.0, 0))[1], 0.1, 12345, 0)
-print("frame bytes:", 8 * b.lib.mjb_frame_doubles(cm.ptr) if hasattr(b.lib, "mjb_frame_doubles") else "?")
-b.step(a.steps)
-b.synchronize()
+qp, qv = initial_state(a.model, model, envs, 1000)
+print("frame bytes (full / fused):", b.lib.mjb_frame_bytes(cm.ptr, 0), "/", b.lib.mjb_frame_bytes(cm.ptr, 1))
+TOP = set(range(14)) | {15, 16, 17, 18}
+ids = [int(t) for t in a.only.split(",")] if a.only else list(range(32))
 out = (C.c_uint64 * 64)()
-b.lib.mjb_debug_profile(b.ptr, out, 1)
-ms = b.time_steps(a.steps, 2)
-b.lib.mjb_debug_profile(b.ptr, out, 1)
+acc = np.zeros(64, dtype=np.uint64)
+mss = []
+warns = []
+for base in sorted({i & ~1 for i in ids}):
+    b.reset()
+    b.set("qpos", qp)
+    b.set("qvel", qv)
+    b.set_ctrl_noise(wl[1], 0.1, 12345, 0)
+    b.lib.mjb_debug_profile_window(b.ptr, base)
+    b.lib.mjb_debug_profile(b.ptr, out, 1)
+    mss.append(b.time_steps(steps, 1))
+    b.lib.mjb_debug_profile(b.ptr, out, 1)
+    acc += np.frombuffer(out, dtype=np.uint64)
+    warns.append([b.warning(w) for w in range(8)])
+ms = float(np.median(mss))
 tot = 0
-print(f"lanes={a.lanes} envs={a.envs} steps={a.steps}: {ms:.3f} ms/launch -> {a.envs*a.steps/ms/1e3:.1f} M env-steps/s")
+print("mjData.warning[] per window (inertia, contactfull, cnstrfull, vgeomfull, badqpos, badqvel, badqacc, badctrl):", [list(np.diff([[0] * 8] + warns, axis=0)[i]) for i in range(len(warns))] if len(warns) <= 4 else ("total " + str(warns[-1])))
+print(f"lanes={a.lanes} envs={envs} steps={steps}: {ms:.3f} ms/launch (median of {len(mss)} windows, min {min(mss):.3f} max {max(mss):.3f}) -> {envs*steps/ms/1e3:.2f} M env-steps/s")
 for i, n in enumerate(STAGES):
-    cnt = max(1, out[32 + i])
-    cyc = out[i] / cnt
-    if n != "forward(total)":
-        tot += cyc
-    print(f"  {n:18s} {cyc:10.0f} cycles/call  ({out[32+i]} calls)")
-print(f"  sum (excl. total, incl. kin.* sub-phases twice)  {tot:10.0f} shader cycles/step  = {tot/2.4e3:.1f} us at 2.4 GHz")
+    cnt = max(1, int(acc[32 + i]))
+    cyc = int(acc[i]) / cnt
+    if i in TOP:
+        tot += cyc * cnt / steps
+    print(f"  {n:26s} {cyc:10.0f} cycles/call  ({int(acc[32+i])} calls)")
+print(f"  sum of the top-level stages (ids 0-13, 15-18; calls x cycles / steps)  {tot:10.0f} shader cycles/step = {tot/2.4e3:.1f} us at 2.4 GHz")
