@@ -2430,7 +2430,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 	EPROF_BEGIN();
 	double *Md = f + L.nwt_M, *H = f + L.nwt_H, *Hc = gall ? gb.hc : f + L.nwt_hc;
 	const int hcs = L.hcs, hcd = L.hcd;  // cone blocks: hcd x hcd (hcd = the model's largest contact dim), hcs doubles apart
-	double *qa = f + L.nwt_vec, *Ma = qa + nv, *grad = Ma + nv, *srch = grad + nv;
+	double *qa = f + L.nwt_vec, *grad = qa + 2 * nv, *srch = grad + nv;  // (qa + nv: M qacc in the frame's layout -- carried in registers)
 	double *jar_s = gall ? gb.nwt_row : f + L.nwt_row, *jv_s = jar_s + rstride, *hw = jv_s + rstride;  // per-row jaref, jv, Hessian weight
 	auto hcb = [&](int con, int row) -> double * { return Hc + (hcrow ? hcd * row : hcs * con); };
 	const bool dofact = lane < nv;
@@ -2553,12 +2553,12 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 		}
 	};
 
-	// constraint update at the jaref values parked in jar_s: returns this lane's cost share; forces (and, when
+	// constraint update at the jaref values parked in `jar_s` (the argument: jar_s, or jv_s for the second warmstart candidate): returns this lane's cost share; forces (and, when
 	// `hess`, the Hessian weights hw / cone blocks Hc) written to LDS
 	// (cones: straight-line code in the contact's leader lane -- every load of the contact's rows in flight at once through clamped
 	//  indices, the three zones by selects: the leaders of a wave sit in different zones anyway and ran them one after the other,
 	//  with a branch and an LDS round trip per `j < dim` test; DMAX = the model's largest contact dimension rounded up to 4 or 6)
-	auto cone_update_d = [&](auto DIMC, bool hess) -> double {
+	auto cone_update_d = [&](auto DIMC, bool hess, const double *jar_s) -> double {
 		constexpr int DMAX = decltype(DIMC)::value;
 		double cost = 0;
 #pragma unroll
@@ -2638,40 +2638,45 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 		}
 		return cost;
 	};
-	auto cone_update = [&](bool hess) -> double {
+	auto cone_update = [&](bool hess, const double *src) -> double {
 		if (hcd <= 4) {
 			MJB_KEEP_BRANCH();
-			return cone_update_d(std::integral_constant<int, 4>{}, hess);
+			return cone_update_d(std::integral_constant<int, 4>{}, hess, src);
 		}
 		MJB_KEEP_BRANCH();
-		return cone_update_d(std::integral_constant<int, 6>{}, hess);
+		return cone_update_d(std::integral_constant<int, 6>{}, hess, src);
 	};
 
 	EPROF(24);
-	// warmstart: the cheaper of qacc_warmstart and qacc_smooth
+	// warmstart: the cheaper of qacc_warmstart and qacc_smooth.  Both candidates' M q and J q - aref are formed back to back (the
+	// second one parked in jv_s, free until the line search) and the winner's are KEPT: mj_solPrimal computes Ma and jaref once and
+	// from then on moves them along the search direction (Ma += alpha Mv, jaref += alpha jv) -- round 3 multiplied again at the top
+	// of every iteration (3.9 k of the 10 k cycles of its gradient step on config 5).
+	double ma, jaref[R];
 	{
-		double best = 0;
-		for (int pass = 0; pass < 2; pass++) {
-			const double *q0 = f + (pass == 0 ? L.qacc_warmstart : L.qacc_smooth);
-			double t, x[R];
-			dots(q0, 1.0, t, x);
-			const double gk = dofact ? 0.5 * (t - f[L.qfrc_smooth + k]) * (q0[k] - f[L.qacc_smooth + k]) : 0.0;
+		const double *qw = f + L.qacc_warmstart, *qs = f + L.qacc_smooth;
+		double t0, x0[R], t1, x1[R];
+		dots(qw, 1.0, t0, x0);
+		dots(qs, 1.0, t1, x1);
+		const double gk0 = dofact ? 0.5 * (t0 - f[L.qfrc_smooth + k]) * (qw[k] - qs[k]) : 0.0;
+		const double gk1 = dofact ? 0.5 * (t1 - f[L.qfrc_smooth + k]) * (qs[k] - qs[k]) : 0.0;
 #pragma unroll
-			for (int i = 0; i < R; i++)
-				if (rowact[i]) jar_s[rr[i]] = x[i];
-			sync();
-			const double ck = cone_update(false);
-			const double cost = wave_sum(gk) + wave_sum(ck);
-			bool take;
-			if (pass == 0) {
-				best = (m.disableflags & MJB_DSBL_WARMSTART) ? 1e300 : cost;
-				take = true;
-			} else {
-				take = cost < best;
+		for (int i = 0; i < R; i++)
+			if (rowact[i]) {
+				jar_s[rr[i]] = x0[i];
+				jv_s[rr[i]] = x1[i];
 			}
-			if (take && dofact) qa[k] = q0[k];
-			sync();
-		}
+		sync();
+		const double ck0 = cone_update(false, jar_s);
+		const double ck1 = cone_update(false, jv_s);
+		const double cost0 = wave_sum(gk0) + wave_sum(ck0), cost1 = wave_sum(gk1) + wave_sum(ck1);
+		const double best = (m.disableflags & MJB_DSBL_WARMSTART) ? 1e300 : cost0;
+		const bool smooth = cost1 < best;  // (wave-uniform)
+		ma = smooth ? t1 : t0;
+#pragma unroll
+		for (int i = 0; i < R; i++) jaref[i] = smooth ? x1[i] : x0[i];
+		if (dofact) qa[k] = smooth ? qs[k] : qw[k];
+		sync();
 	}
 
 	EPROF(25);
@@ -2680,19 +2685,16 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 	int iter = 0;
 	for (;;) {
 		EPROF(30);
-		// Ma = M qacc, jaref = J qacc - aref, forces, cost, gradient
-		double ma, jaref[R];
-		dots(qa, 1.0, ma, jaref);
+		// forces, cost, gradient at the current Ma = M qacc, jaref = J qacc - aref (carried in registers, see the warmstart)
 		const double gk = dofact ? 0.5 * (ma - f[L.qfrc_smooth + k]) * (qa[k] - f[L.qacc_smooth + k]) : 0.0;
 #pragma unroll
 		for (int i = 0; i < R; i++)
 			if (rowact[i]) jar_s[rr[i]] = jaref[i];
-		if (dofact) Ma[k] = ma;
 		sync();
 #ifdef MJB_PROFILE_NWT
 		EPROF(20);
 #endif
-		const double ck = cone_update(true);
+		const double ck = cone_update(true, jar_s);
 #ifdef MJB_PROFILE_NWT
 		EPROF(21);
 #endif
@@ -3139,6 +3141,9 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 #endif
 		if (alpha == 0) break;
 		if (dofact) qa[k] += alpha * sk;
+		ma += alpha * mv;
+#pragma unroll
+		for (int i = 0; i < R; i++) jaref[i] += alpha * jv[i];
 		iter++;
 		sync();
 	}

@@ -1304,7 +1304,8 @@ void mjo_fwd_constraint(const mjb_model_desc *m, mjo_data *d)
 /* Primal problem: minimise over qacc  0.5 (a - a0)' M (a - a0) + sum_i s_i(J_i a - aref_i),
  * s_i(x) = 0.5 D_i x^2 for x < 0 (limit / pyramidal contact rows), 0 otherwise.
  * Hessian H = M + J' diag(D_i [active]) J is rebuilt and Cholesky-factorised every iteration (MuJoCo updates
- * it incrementally with rank-1 up/down-dates when rows change state: same matrix up to rounding). */
+ * it incrementally with rank-1 up/down-dates when rows change state: same matrix up to rounding).
+ * Ma = M qacc and jaref = J qacc - aref are computed once and then moved along the search direction, as mj_solPrimal does. */
 
 /* res = M * vec with M in qM layout (mj_mulM) */
 static void mul_m(const mjb_model_desc *m, const mjo_data *d, double *res, const double *vec)
@@ -1580,39 +1581,37 @@ static void fwd_constraint_newton(const mjb_model_desc *m, mjo_data *d)
 	                                         * direction is Polak-Ribiere with the preconditioner M^-1 instead of -H^-1 grad */
 	double Mgrad[nv], gradold[nv], Mgradold[nv];
 
-	/* warmstart: qacc_warmstart unless qacc_smooth has the lower cost (engine_forward.c warmstart()) */
+	/* warmstart: qacc_warmstart unless qacc_smooth has the lower cost (engine_forward.c warmstart()).  Ma = M qacc and
+	 * jaref = J qacc - aref of the chosen start are kept: mj_solPrimal computes them once and from then on moves them along the
+	 * search direction (Ma += alpha Mv, jaref += alpha jv below) instead of multiplying again every iteration */
 	double best = 0;
 	for (int pass = 0; pass < 2; pass++) {
 		const double *q0 = pass == 0 ? d->qacc_warmstart : d->qacc_smooth;
-		double tmp[nv], cost = 0;
+		double tmp[nv], x0[nefc > 0 ? nefc : 1], cost = 0;
 		mul_m(m, d, tmp, q0);
 		for (int k = 0; k < nv; k++) cost += 0.5 * (tmp[k] - d->qfrc_smooth[k]) * (q0[k] - d->qacc_smooth[k]);
 		for (int i = 0; i < nefc; i++) {
 			double x = -d->efc_aref[i];
 			for (int k = 0; k < nv; k++) x += d->efc_J[(size_t)i * nv + k] * q0[k];
-			jaref[i] = x;
+			x0[i] = x;
 		}
-		cost += constraint_update(m, d, nefc, jaref, tmpf, NULL, NULL);
-		if (pass == 0) {
+		cost += constraint_update(m, d, nefc, x0, tmpf, NULL, NULL);
+		int take = 1;
+		if (pass == 0) best = (m->disableflags & MJB_DSBL_WARMSTART) ? 1e300 : cost;
+		else take = cost < best;
+		if (take) {
 			memcpy(qacc, q0, sizeof qacc);
-			best = (m->disableflags & MJB_DSBL_WARMSTART) ? 1e300 : cost;
-		} else if (cost < best) {
-			memcpy(qacc, q0, sizeof qacc);
+			memcpy(Ma, tmp, sizeof Ma);
+			memcpy(jaref, x0, nefc * sizeof(double));
 		}
 	}
 
 	double cost = 0, prev_cost;
 	int iter = 0;
 	for (;;) {
-		/* Ma, jaref, constraint update (forces, cost, Hessian weights), gradient */
-		mul_m(m, d, Ma, qacc);
+		/* constraint update at the current Ma / jaref (forces, cost, Hessian weights), gradient */
 		double gauss = 0;
 		for (int k = 0; k < nv; k++) gauss += 0.5 * (Ma[k] - d->qfrc_smooth[k]) * (qacc[k] - d->qacc_smooth[k]);
-		for (int i = 0; i < nefc; i++) {
-			double x = -d->efc_aref[i];
-			for (int k = 0; k < nv; k++) x += d->efc_J[(size_t)i * nv + k] * qacc[k];
-			jaref[i] = x;
-		}
 		prev_cost = cost;
 		cost = gauss + constraint_update(m, d, nefc, jaref, f, hrow, hcone);
 		for (int k = 0; k < nv; k++) {
@@ -1727,7 +1726,11 @@ static void fwd_constraint_newton(const mjb_model_desc *m, mjo_data *d)
 		double gtol = tol * ls_tol * snorm / scale;
 		double alpha = primal_search(&c, gtol, ls_iter);
 		if (alpha == 0) break;
-		for (int k = 0; k < nv; k++) qacc[k] += alpha * search[k];
+		for (int k = 0; k < nv; k++) {
+			qacc[k] += alpha * search[k];
+			Ma[k] += alpha * Mv[k];
+		}
+		for (int i = 0; i < nefc; i++) jaref[i] += alpha * jv[i];
 		iter++;
 	}
 	d->solver_iter[0] = iter;
