@@ -2355,11 +2355,21 @@ DEVI void ls_row(double a, bool scalar_row, bool bilateral, bool leader, double 
 	}
 }
 
-// columns J0 .. J0+15 of the right-looking Cholesky with one row of H per lane in registers (see fwd_constraint_newton)
-template <int J0> DEVI void chol_cols16(double (&Hr)[32], const int nv, const int lane, double &myrinv)
+typedef double mjb_d4 __attribute__((ext_vector_type(4)));
+
+// columns J0 .. J0+15 of the right-looking Cholesky with one row of H per lane in registers (see fwd_constraint_newton).
+// A column's update stays INSIDE the 16-column block: the first block's contribution to the second (rows / columns 16 .. 31) is
+// one 16 x 16 x 16 product, chol_schur16 below.  Round 3 ran all 32 columns right-looking: every entry l_cj a lane multiplies into
+// its row arrives by a v_readlane pair, 1444 v_readlane against 633 v_fma in the stage, issue bound at ~6 cycles each.
+// (`lid`: the self-laundering lane index, read afresh for each column's `lane == j`: as plain loop invariants of the Newton
+//  iteration the 32 + 96 lane masks of the factorisation and the two substitutions were hoisted out of it, spilled -- SGPR pairs
+//  in lanes of a VGPR that was itself parked in an AGPR -- and fetched back at every use: s_or_saveexec, v_accvgpr_read, two
+//  v_readlane, s_nop, where three VALU instructions rebuild the mask)
+template <int J0> DEVI void chol_cols16(double (&Hr)[32], const int nv, const LaneId lid, double &myrinv)
 {
 #pragma unroll
 	for (int j = J0; j < J0 + 16; j++) {
+		const int lane = lid;
 		// (no guards on nv anywhere in the nest: rows / columns >= nv are zero, so their steps are no-ops, and one straight-line
 		//  block lets the scheduler run a column's rsqrt chain under the previous column's trailing update -- config 5: +7 %)
 		double sj = wave_bcast(Hr[j], j);
@@ -2371,7 +2381,7 @@ template <int J0> DEVI void chol_cols16(double (&Hr)[32], const int nv, const in
 		// groups of four columns (constant loop bounds -- the nest only unrolls fully that way; entries c >= nv of a group belong to
 		// idle lanes: l_cj == 0)
 #pragma unroll
-		for (int c0 = 0; c0 < 32; c0 += 4) {
+		for (int c0 = J0; c0 < J0 + 16; c0 += 4) {
 			if (c0 + 3 <= j) continue;
 			double l4[4];
 #pragma unroll
@@ -2383,7 +2393,40 @@ template <int J0> DEVI void chol_cols16(double (&Hr)[32], const int nv, const in
 	}
 }
 
-typedef double mjb_d4 __attribute__((ext_vector_type(4)));
+// H22 -= L21 L21' on the matrix cores (16 < nv <= 32; rows 16 .. 31 sit in lanes 16 .. 31, L21 = their registers 0 .. 15 once the
+// first 16 columns are done): the lanes publish L21 column-major in `S` (272 doubles of scratch: the Hessian's LDS copy, dead while
+// its rows are in registers), lane l feeds A[l & 15][l >> 4] = B[l >> 4][l & 15] = L21[l & 15][4 s + (l >> 4)] to four
+// v_mfma_f64_16x16x4_f64, the product goes back through S (row stride 17: every lane its own bank) and each of the lanes 16 .. 31
+// subtracts its row.  Replaces 376 fma + 752 v_readlane per lane by ~60 instructions and two LDS round trips; the entries of H22
+// now receive the block's sixteen products as one sum instead of sixteen subtractions (rounding only).
+template <typename SYNC> DEVI void chol_schur16(double (&Hr)[32], const int lane, double *S, SYNC &&sync)
+{
+	const bool mine = lane >= 16 && lane < 32;
+	const int i = mine ? lane - 16 : 0;
+	if (mine) {
+#pragma unroll
+		for (int c = 0; c < 16; c++) S[c * 16 + i] = Hr[c];
+	}
+	sync();
+	const int li = lane & 15, lk = lane >> 4;
+	double v[4];
+#pragma unroll
+	for (int q = 0; q < 4; q++) v[q] = S[(4 * q + lk) * 16 + li];
+	mjb_d4 acc = mjb_d4{ 0, 0, 0, 0 };
+#pragma unroll
+	for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[q], v[q], acc, 0, 0, 0);
+	sync();
+#pragma unroll
+	for (int q = 0; q < 4; q++) S[(lk + 4 * q) * 17 + li] = acc[q];
+	sync();
+	if (mine) {
+		double p[16];
+#pragma unroll
+		for (int c = 0; c < 16; c++) p[c] = S[i * 17 + c];
+#pragma unroll
+		for (int c = 0; c < 16; c++) Hr[16 + c] -= p[c];
+	}
+}
 
 // R = rows per lane: row r lives in lane r % 64, slot r / 64 (nefcmax <= 64 R).  R == 1 is BASELINE config 3,
 // R == 4 covers the ~200 rows of config 5.
@@ -2691,18 +2734,18 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 		for (int i = 0; i < R; i++)
 			if (rowact[i]) jar_s[rr[i]] = jaref[i];
 		sync();
-#ifdef MJB_PROFILE_NWT
+#if defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_LS)
 		EPROF(20);
 #endif
 		const double ck = cone_update(true, jar_s);
-#ifdef MJB_PROFILE_NWT
+#if defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_LS)
 		EPROF(21);
 #endif
 		const double gauss = wave_sum(gk);
 		prev_cost = cost;
 		cost = gauss + wave_sum(ck);
 		sync();
-#ifdef MJB_PROFILE_NWT
+#if defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_LS)
 		EPROF(22);
 #endif
 		double gr = 0;
@@ -2731,7 +2774,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 			const double gnorm = scale * sqrt(wave_sum(gr * gr));
 			if (improvement < tol || gnorm < tol || iter >= m.iterations) break;
 		}
-#ifdef MJB_PROFILE_NWT
+#if defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_LS)
 		EPROF(23);
 #endif
 		EPROF(26);
@@ -2832,16 +2875,24 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 					a0 = (live && in0) ? s0 : 0.0;
 					a1 = (live && in1) ? s1 : 0.0;
 				};
+				// (the three accumulators are PINNED in accumulation registers for the whole loop -- inline asm with `a` constraints:
+				//  left to the compiler the loop-carried tiles lived in VGPRs and every slab copied all 24 registers to AGPRs for its
+				//  MFMAs and back, v_accvgpr_write x 24 + v_accvgpr_read x 24 + s_nop 12 per slab, a third of the loop.  The hazard
+				//  recogniser does not look inside inline asm: the s_nop ahead of each MFMA covers a VALU write of its A / B operands
+				//  right before it, successive MFMAs of one slab write different tiles, a tile's next use as SrcC is a whole slab of
+				//  LDS reads later, and the results are read 18+ wait states after the last MFMA (mfma_drain))
 				mjb_d4 t00 = mjb_d4{ 0, 0, 0, 0 }, t10 = mjb_d4{ 0, 0, 0, 0 }, t11 = mjb_d4{ 0, 0, 0, 0 };
+				asm volatile("" : "+a"(t00), "+a"(t10), "+a"(t11));
 				double a0, a1, b0, b1, a0n, a1n, b0n, b1n;
 				fetch(0, a0, a1, b0, b1);
 				for (int r0 = 0; r0 < nefc; r0 += 4) {
 					fetch(r0 + 4, a0n, a1n, b0n, b1n);  // (past the last slab: all zero)
-					t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, t00, 0, 0, 0);
-					t10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, t10, 0, 0, 0);
-					t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, t11, 0, 0, 0);
+					asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %3, %5, %0\n\tv_mfma_f64_16x16x4_f64 %1, %4, %5, %1\n\tv_mfma_f64_16x16x4_f64 %2, %4, %6, %2"
+					             : "+a"(t00), "+a"(t10), "+a"(t11)
+					             : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
 					a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
 				}
+				asm volatile("s_nop 15\n\ts_nop 7" : "+a"(t00), "+a"(t10), "+a"(t11));  // (mfma_drain: XDL write -> VALU read)
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
 					const int row = lk + 4 * q;
@@ -2911,10 +2962,11 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 #pragma unroll
 			for (int c = 0; c < 32; c++) Hr[c] = c < lim ? Mrow[c] + Hr[c] : 0.0;
 			// (two half-loops: one 32-column nest exceeds LLVM's pragma-unroll size cap and would leave Hr in scratch)
-			chol_cols16<0>(Hr, nv, lane, myrinv);
+			chol_cols16<0>(Hr, nv, e.lane, myrinv);
 			if (nv > 16) {
 				MJB_KEEP_BRANCH();
-				chol_cols16<16>(Hr, nv, lane, myrinv);
+				chol_schur16(Hr, lane, H, sync);
+				chol_cols16<16>(Hr, nv, e.lane, myrinv);
 			}
 			if (dofact) {
 #pragma unroll
@@ -2926,16 +2978,18 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 #pragma unroll
 			for (int i = 0; i < 16; i++) {
 				const double xi = wave_bcast(x * myrinv, i);
-				if (lane == i) x = xi;
-				else x -= ((dofact && lane > i) ? Hr[i] : 0.0) * xi;
+				const int ln = e.lane;  // (fresh per step: see chol_cols16)
+				if (ln == i) x = xi;
+				else x -= ((ln < nv && ln > i) ? Hr[i] : 0.0) * xi;
 			}
 			if (nv > 16) {
 				MJB_KEEP_BRANCH();
 #pragma unroll
 				for (int i = 16; i < 32; i++) {
 					const double xi = wave_bcast(x * myrinv, i);
-					if (lane == i) x = xi;
-					else x -= ((dofact && lane > i) ? Hr[i] : 0.0) * xi;
+					const int ln = e.lane;
+					if (ln == i) x = xi;
+					else x -= ((ln < nv && ln > i) ? Hr[i] : 0.0) * xi;
 				}
 			}
 			sync();
@@ -2970,15 +3024,16 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 			double colk[32];
 #pragma unroll
 			for (int i = 1; i < 32; i++) {
-				const bool has = dofact && k < i && i < nv;
-				const double v = H[has ? i * nv + k : 0];
+				const int ln = e.lane;  // (fresh per load: see chol_cols16)
+				const bool has = ln < i && i < nv;
+				const double v = H[has ? i * nv + ln : 0];
 				colk[i] = has ? v : 0.0;
 			}
 #pragma unroll
 			for (int i = 31; i >= 0; i--) {
 				if (i >= 16 && nv <= 16) continue;  // (compile-time half, wave-uniform test)
 				const double xi = wave_bcast(x * myrinv, i);
-				if (k == i) x = xi;
+				if ((int)e.lane == i) x = xi;
 				else x -= (i > 0 ? colk[i] : 0.0) * xi;
 			}
 		} else {
@@ -3005,6 +3060,9 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 		for (int i = 0; i < R; i++)
 			if (rowact[i]) jv_s[rr[i]] = jv[i];
 		sync();
+#ifdef MJB_PROFILE_LS  // (libmjb_prof_ls.so: slots 20 / 21 / 22 = the line search's M v | J v, its per-contact constants + Gauss terms, its trial points)
+		EPROF(20);
+#endif
 		// per-contact line-search constants: registers of the leader lane (R == 1), or parked in the contact's cone
 		// block Hc (free once H is built) when a lane owns several rows and registers are scarce
 		ConeLine cl1 = ConeLine{ 0, 0, 0, 0, 0, 0, 0, 0, 1, 0 };
@@ -3044,6 +3102,9 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 		const double g1 = wave_sum(dofact ? sk * (ma - f[L.qfrc_smooth + k]) : 0.0);
 		const double g2 = wave_sum(dofact ? 0.5 * sk * mv : 0.0);
 		const double gtol = tol * 0.01 * snorm / scale;  // mjOption.ls_tolerance = 0.01
+#ifdef MJB_PROFILE_LS
+		EPROF(21);
+#endif
 		auto ls_eval = [&](LsPoint &p) {
 			const double a = p.alpha;
 			double c0 = 0, c1 = 0, c2 = 0;
@@ -3135,6 +3196,9 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 			}
 		}
 #undef LS_EVAL
+#ifdef MJB_PROFILE_LS
+		EPROF(22);
+#endif
 		EPROF(29);
 #ifdef MJB_PROFILE_NWT
 		prof_rec(e.env, e.lane, 19, 0, 1);

@@ -31,10 +31,11 @@ ap.add_argument("--model", default="franka_like")
 ap.add_argument("--solver", default="")
 ap.add_argument("--sub", action="store_true", help="libmjb_prof_sub.so: slots 24-29 = collision / make_constraint sub-stages (PGS runs)")
 ap.add_argument("--nwt", action="store_true", help="libmjb_prof_nwt.so: slots 20-23 = parts of the Newton iteration's gradient step, 19 = line-search points")
+ap.add_argument("--ls", action="store_true", help="libmjb_prof_ls.so: slots 20-22 = parts of the Newton line search")
 ap.add_argument("--only", default="", help="comma-separated probe ids (default: all)")
 a = ap.parse_args()
 
-tag = "_sub" if a.sub else ("_nwt" if a.nwt else "")
+tag = "_sub" if a.sub else ("_nwt" if a.nwt else ("_ls" if a.ls else ""))
 binding.LIB_PATH = os.environ.get("MJB_PROF_LIB") or os.path.join(ROOT, "mujoco_ros_pkgs_amd", "csrc", f"libmjb_prof{tag}.so")
 if a.sub:
     STAGES[19] = "pgs.setup (B row, b, warmstart)"
@@ -45,6 +46,9 @@ if a.sub:
 if a.nwt:
     STAGES[19] = "nwt.ls points /iter [count, not cycles]"
     STAGES[20:24] = ["nwt.g dots+park", "nwt.g cone_update", "nwt.g cost sums", "nwt.g J'f + stop test"]
+if a.ls:
+    STAGES[19] = "nwt.ls points /iter [count, not cycles]"
+    STAGES[20:24] = ["nwt.ls M v | J v + park", "nwt.ls cone constants + Gauss terms", "nwt.ls trial points", "-"]
 from mujoco_ros_pkgs_amd import engine, mjcf  # noqa: E402
 from bench import WORKLOADS, initial_state  # noqa: E402
 
