@@ -2438,7 +2438,8 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 	static_assert(G == 64, "the Newton solver maps rows / Hessian columns to the 64 lanes of one wavefront");
 	double *f = e.f;
 	int *fi = e.fi;
-	const int lane = e.lane, nv = m.nv;
+	const LaneId lane = e.lane;  // (re-derived at every use: nothing computed from it is hoisted out of the iteration and spilled)
+	const int nv = m.nv;
 	const int nefc = __builtin_amdgcn_readfirstlane(fi[L.nefc]);
 	// JG: J -- and, when the frame's other row arrays are capped too (L.rcap < nefcmax), every per-row array, the row metadata and
 	// the cone blocks -- come from the env's block in HBM (mjb_dev.h, RowBlock); the branches fold away in the other instantiations

@@ -119,34 +119,59 @@ DEVI void prof_rec(int env, int lane, int id, unsigned long long v, unsigned int
 #define EPROF(id) do { } while (0)
 #endif
 
+// Integer members of LaneConst re-launder themselves at every read (like LaneId): as plain values they are invariants of the K-step
+// loop, and every predicate computed from them -- `sc_dst >= 0`, `q_row == q_col`, the bits of the ancestor masks: ~90 lane masks --
+// was hoisted to the top of the kernel, spilled there (183 v_writelane in the prologue of the config-2 kernel) and fetched back with a
+// v_readlane pair + s_nop at every use, where one v_cmp against an immediate rebuilds it.
+struct LInt {
+	int x;
+	__device__ __forceinline__ LInt &operator=(int v) { x = v; return *this; }
+	__device__ __forceinline__ LInt &operator|=(int v) { x |= v; return *this; }
+	__device__ __forceinline__ operator int() const
+	{
+		int v = x;
+		asm volatile("" : "+v"(v));
+		return v;
+	}
+};
+struct LUInt {
+	unsigned int x;
+	__device__ __forceinline__ LUInt &operator=(unsigned int v) { x = v; return *this; }
+	__device__ __forceinline__ operator unsigned int() const
+	{
+		unsigned int v = x;
+		asm volatile("" : "+v"(v));
+		return v;
+	}
+};
 // Model constants of body `lane`, fetched once per kernel by the dense kernels (nbody <= 16 = G; 512 VGPRs to spend) instead of
 // once per stage and step (per-lane table reads are vector-memory loads: ~0.5 us of exposed latency per step each)
 struct LaneConst {
-	unsigned int dmlo, dmhi, smlo, smhi;  // ancestor-dof and subtree-body masks
-	int jntadr, jntnum, jtype, qa, simple, rootid;
+	LUInt dmlo, dmhi, smlo, smhi;  // ancestor-dof and subtree-body masks
+	LInt jntadr, jntnum, jtype, qa, simple, rootid;
 	double bpos[3], bquat[4], jaxis[3], jpos[3], q0, ipos[3], iquat[4], mass, stmass, inertia[3];
 	// ... and of dof `lane` (nv <= 16): its body, and where the body velocity "before" the dof's joint comes from
-	int d_body, d_zero, d_simple, d_parent;
-	unsigned int d_bmlo, d_bmhi;  // bodies moved by the dof  // d_zero: translational dof of a free joint; d_simple: first joint of its body
+	LInt d_body, d_zero, d_simple, d_parent;
+	LUInt d_bmlo, d_bmhi;  // bodies moved by the dof  // d_zero: translational dof of a free joint; d_simple: first joint of its body
 	// ... and what the SMALL stages read per lane and step (round 3): transmission, passive, actuation, the sensors' plain copies and
 	// Euler each cost 1 - 2 k cycles of which the arithmetic is a handful of fma -- the rest is a chain of two or three dependent
 	// loads from the model blob (dof -> actuator list -> actuator -> parameters).  nu, njnt <= 16 (mjb_api.hip picks the kernel).
-	int u_qa, u_da;        // lane = actuator: qpos / dof address of its joint (joint transmission)
+	LInt u_qa, u_da;        // lane = actuator: qpos / dof address of its joint (joint transmission)
 	double u_gear;
-	int a_n, a_id, a_flags;  // lane = dof: number of actuators driving it (a_n > 1: table walk), the single one's id, flags:
+	LInt a_n, a_id, a_flags;  // lane = dof: number of actuators driving it (a_n > 1: table walk), the single one's id, flags:
 	                         // 1 ctrllimited (and clamping on), 2 affine gain, 4 affine bias, 8 forcelimited
 	double a_clo, a_chi, a_g[3], a_b[3], a_flo, a_fhi, a_gear;
-	int j_type, j_qa, j_da;  // lane = joint
+	LInt j_type, j_qa, j_da;  // lane = joint
 	double j_stiff, j_spring, j_damp;  // (spring reference / damping of a hinge or slide joint; ball / free joints walk the tables)
-	int sc_dst[3][2], sc_src[3][2];  // lane's plain sensor copies of the three stages in the layout of this launch (-1: none)
-	int anc[6];            // lane = body: its ancestors at distance 1, 2, 4, 8, 16 (0 = world or beyond): kinematics' pointer jumping
-	int j_body, j_root;    // lane = joint: its body and that body's root (comPos: cdof)
+	LInt sc_dst[3][2], sc_src[3][2];  // lane's plain sensor copies of the three stages in the layout of this launch (-1: none)
+	LInt anc[6];            // lane = body: its ancestors at distance 1, 2, 4, 8, 16 (0 = world or beyond): kinematics' pointer jumping
+	LInt j_body, j_root;    // lane = joint: its body and that body's root (comPos: cdof)
 	// lane = item of kinematics' phase D (joint / geom / site; njnt + ngeom + nsite <= 16, else k_kind = -1: table walk)
-	int k_kind, k_id, k_body, k_same;  // kind: 0 joint (k_body = the PARENT of the joint's body; k_same = joint is free), 1 geom, 2 site
+	LInt k_kind, k_id, k_body, k_same;  // kind: 0 joint (k_body = the PARENT of the joint's body; k_same = joint is free), 1 geom, 2 site
 	double k_pos[3], k_quat[4];
 	// lane's qM entries en = lane, lane + 16, lane + 32 (nM <= 48, else q_row[0] = -2: table walk): row / column dof, and for a
 	// diagonal entry its armature and h * damping
-	int q_row[3], q_col[3];
+	LInt q_row[3], q_col[3];
 	double q_arm[3], q_hd[3];
 };
 
@@ -180,7 +205,7 @@ struct Env {
 	int *fi;    // LDS frame (ints)
 	LaneId lane;  // 0..G-1
 	int env;    // batch-local env index
-	int dadr[16];  // dense kernels only: qM address of entry (i, lane) of the joint-space inertia, or -1
+	LInt dadr[16];  // (self-laundering: the sixteen `dadr[i] >= 0` masks are not hoisted) dense kernels only: qM address of entry (i, lane) of the joint-space inertia, or -1
 	LaneConst lc;  // one-body-per-lane kernels only
 #ifdef MJB_PROFILE
 	unsigned long long *prof;
@@ -899,9 +924,9 @@ DEVI double fast_rcp(double x)
 #ifndef MJB_FACTOR64_LDS
 #define MJB_FACTOR64_LDS 1  // (0: v_readlane broadcasts -- more issue slots than the LDS round trips the co-resident wave hides: 185.1 -> 186.9 ms on config 3)
 #endif
-template <int G, bool DUAL, int NVM>
+template <int G, bool DUAL, int NVM, typename DA>
 DEVI void factor_dense16_impl(CModel m, const Env &e, const double *M, double *LD, double *di, const double *M2, double *LD2,
-                              double *di2, const int (&dadr)[16], double *scr)
+                              double *di2, const DA (&dadr)[16], double *scr)
 {
 	const int lane = e.lane, nv = m.nv;
 	double A[NVM], B[NVM];
@@ -996,9 +1021,9 @@ DEVI void factor_dense16_impl(CModel m, const Env &e, const double *M, double *L
 	gsync<G>();
 }
 
-template <int G, int NVM>
+template <int G, int NVM, typename DA>
 STAGE void factor_dense16(CModel m, const Env &e, const double *M, double *LD, double *di, const double *M2, double *LD2,
-                          double *di2, bool dual, const int (&dadr)[16], double *scr)
+                          double *di2, bool dual, const DA (&dadr)[16], double *scr)
 {
 	static_assert(G == 16 || G == 64, "one matrix column per lane of a 16-lane env group (G == 64: lanes 0-15 of the wavefront)");
 	if (dual) {
@@ -1094,9 +1119,9 @@ STAGE void factor_dense32(CModel m, const Env &e, const double *M, double *LD, d
 #ifndef MJB_SOLVE64_LDS
 #define MJB_SOLVE64_LDS 0  // (1: the LDS round trips of r02 -- 43.3 -> 42.1 ms per 200 steps of config 3 without them)
 #endif
-template <int G, bool DUAL, int NVM>
+template <int G, bool DUAL, int NVM, typename DA>
 DEVI void solve_dense16_impl(CModel m, const Env &e, double *x, const double *LD, const double *diaginv, double *x2,
-                             const double *LD2, const double *diaginv2, const int (&dadr)[16], double *scr)
+                             const double *LD2, const double *diaginv2, const DA (&dadr)[16], double *scr)
 {
 	const int lane = e.lane, nv = m.nv;
 	const bool act = lane < nv;
@@ -1163,9 +1188,9 @@ DEVI void solve_dense16_impl(CModel m, const Env &e, double *x, const double *LD
 	gsync<G>();
 }
 
-template <int G, int NVM>
+template <int G, int NVM, typename DA>
 STAGE void solve_dense16(CModel m, const Env &e, double *x, const double *LD, const double *diaginv, double *x2,
-                         const double *LD2, const double *diaginv2, bool dual, const int (&dadr)[16], double *scr)
+                         const double *LD2, const double *diaginv2, bool dual, const DA (&dadr)[16], double *scr)
 {
 	static_assert(G == 16 || G == 64, "one matrix column per lane of a 16-lane env group (G == 64: lanes 0-15 of the wavefront)");
 	if (dual) {
@@ -2571,7 +2596,7 @@ template <int G, int CON, int DENSE>
 #define MJB_DEV_OCC 1
 #endif
 __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G == 64 ? 4 : (G == 32 ? 2 : 1)))))
-    mjb_step_kernel(const KernelParams MJB_AS4 *__restrict__ P, const int mode, const int nsteps,
+    mjb_step_kernel(const KernelParams MJB_AS4 *__restrict__ P, const int mode_arg, const int nsteps,
                     const unsigned int step0, const int epb, const int frame_bytes, const int chunk, const int env_lo, const int env_hi)
 {
 	// [env_lo, env_hi): the envs this launch steps (the whole batch, or -- split steps of the host runtime -- the callback envs /
@@ -2579,6 +2604,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 	// launch parameters live in device memory behind a constant-address-space pointer: every field is
 	// fetched with a scalar load where it is used instead of pinning ~300 SGPRs for the whole kernel
 	const DevModel MJB_AS4 &m = P->m;
+	const int mode = mode_arg;
 	const int compact = (mode == MJB_MODE_STEP && P->use_compact) ? 1 : 0;
 	const FrameLayout MJB_AS4 &L = compact ? P->Lc : P->L;
 	const DevState MJB_AS4 &s = P->s;
@@ -2793,12 +2819,16 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 		//  loop, trip 0 = STEP2's stages, trip 1 = STEP1's; the flags below are trip-invariant in every other mode)
 		// (not in the dense kernels nor in the 256-register PGS variant, which only ever runs fused launches: both lose 1 - 2.5 % to the
 		//  extra mode; the host picks the generic / 512-register kernels for this launch)
-		const bool combo = DENSE == 0 && CON != 9 && mode == MJB_MODE_STEP21;
-		const bool checks = mode != MJB_MODE_FORWARD;
 		const int st0 = item_chunk * chunk;  // first step of this work item (0 unless the launch is chunked)
-		const int nst = mode == MJB_MODE_STEP ? (dyn ? (nsteps - st0 < chunk ? nsteps - st0 : chunk) : nsteps) : (combo ? 2 : 1);
+		const int nst = mode == MJB_MODE_STEP ? (dyn ? (nsteps - st0 < chunk ? nsteps - st0 : chunk) : nsteps) : ((DENSE == 0 && CON != 9 && mode == MJB_MODE_STEP21) ? 2 : 1);
 #pragma nounroll
 		for (int st = 0; st < nst; st++) {
+			// (the launch mode re-laundered per step: the flags derived from it -- a dozen scalar masks -- are invariants of the step loop
+			//  otherwise, hoisted to the top of the kernel and kept in spilled SGPRs)
+			int mode = mode_arg;
+			asm volatile("" : "+s"(mode));
+			const bool combo = DENSE == 0 && CON != 9 && mode == MJB_MODE_STEP21;
+			const bool checks = mode != MJB_MODE_FORWARD;
 			const bool do_first = combo ? st == 1 : mode != MJB_MODE_STEP2, do_rest = combo ? st == 0 : mode != MJB_MODE_STEP1;
 			const bool do_euler = combo ? st == 0 : (mode == MJB_MODE_STEP || mode == MJB_MODE_STEP2);
 			const bool hw_on = do_rest && checks && P->hw.n > 0;  // device-side DefaultRobotHWSim stage registered
