@@ -240,7 +240,12 @@ def measure_other_config(cfgno, device, launches=5):
                       "nconmax": int(model["nconmax"]), "nefcmax": int(model["nefcmax"]),
                       "fused_frame_bytes": int(batch.lib.mjb_frame_bytes(cm.ptr, 1)),
                       "state_finite": finite, "auto_resets": batch.warning_count(),
-                      "contactfull": batch.warning("contactfull"), "cnstrfull": batch.warning("cnstrfull")},
+                      # (mjWARN_CONTACTFULL / mjWARN_CNSTRFULL events of every env-step this batch ran, warm-up included, and their rate:
+                      #  config 3's 16-contact capacity -- SURVEY.md §8's table, what keeps eight lean frames per CU -- is exceeded
+                      #  by a few env-steps per million; the oracle truncates identically.  tools/overflow_rate.py,
+                      #  profiles/r04_cfg3_overflow.txt; bounded in tests/test_gpu_full_size.py)
+                      "contactfull": batch.warning("contactfull"), "cnstrfull": batch.warning("cnstrfull"),
+                      "overflow_per_env_step": (batch.warning("contactfull") + batch.warning("cnstrfull")) / float(E * S * (launches + 6))},
            "roofline": roofline_block(name, cfgno, "", E, S, samples)}
     batch.close()
     cm.close()

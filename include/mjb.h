@@ -167,7 +167,11 @@ int mjb_step2_prefix(mjb_batch *b, int ncb);
 /* mjb_step2_prefix(ncb) of the split step in flight and mjb_step1_prefix(ncb) of the NEXT step as one launch for the callback envs
  * (one kernel and one device -> host round trip per step instead of two when steps follow each other: what a caller with control /
  * passive callbacks only needs -- the state it can read afterwards is the finished step's, the derived fields and the pos / vel
- * stage sensordata already the next step's).  Same results, bit for bit, as the two calls it replaces. */
+ * stage sensordata already the next step's).  Same results as the two calls it replaces: bit for bit when both run the same
+ * kernel (every constrained model, and unconstrained ones outside the dense kernels' reach); for a model the two halves run through
+ * the register-dense kernels (nv, nbody, nu, njnt <= 16, Euler, no constraint rows -- BASELINE config 2) the chained launch runs the
+ * generic kernel instead, whose factor / solve sum in a different order: equal to rounding (tests/test_gpu_fused_consistency.py
+ * bounds it at 1e-9 over a burst), not to the last bit. */
 int mjb_step21_prefix(mjb_batch *b, int ncb);
 
 /* Recompute all derived quantities without integrating (mj_forward: mujoco_env.cpp:329, :621;

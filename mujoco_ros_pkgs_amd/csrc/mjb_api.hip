@@ -1346,8 +1346,23 @@ static int sync_params(mjb_batch *b)
 		kp.hw = b->hw;
 		// pageable source: the copy is staged before the call returns, so the local may go out of scope
 		HIP_TRY(hipStreamSynchronize(b->stream));
+		// (the fused launch of the non-callback envs, mjb_step_rest, runs on its own non-blocking stream and reads *params_dev lazily
+		//  through scalar loads -- use_compact, use_xfrc, the layouts: an upload between mjb_step_rest and the second half, e.g. the
+		//  first pushViews that carries a non-zero xfrc_applied, must not overtake it)
+		if (b->rest_pending && b->rest_stream) HIP_TRY(hipStreamSynchronize(b->rest_stream));
 		HIP_TRY(hipMemcpy(b->params_dev, &kp, sizeof kp, hipMemcpyHostToDevice));
 		b->params_dirty = false;
+	}
+	return MJB_OK;
+}
+
+// whole-batch operations on the batch's stream wait for a fused launch of the non-callback envs that is still pending on the rest
+// stream (a split step abandoned between mjb_step_rest and its second half -- an error, a reset raised inside a callback)
+static int join_rest(mjb_batch *b)
+{
+	if (b->rest_pending) {
+		HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_join, 0));
+		b->rest_pending = false;
 	}
 	return MJB_OK;
 }
@@ -1417,6 +1432,9 @@ int mjb_step(mjb_batch *b, int nsteps)
 {
 	if (!b || nsteps < 0) return fail(MJB_EINVAL, "mjb_step: bad argument");
 	if (nsteps == 0) return MJB_OK;
+	int jrc = join_rest(b);
+	if (jrc) return jrc;
+	b->split_ncb = -1;  // (an open split step is abandoned)
 	int rc = launch(b, MJB_MODE_STEP, nsteps);
 	if (rc == MJB_OK) {
 		b->step_counter += (unsigned int)nsteps;
@@ -1446,6 +1464,8 @@ int mjb_step1(mjb_batch *b)
 {
 	if (!b) return fail(MJB_EINVAL, "null batch");
 	int rc = ensure_ws(b);
+	if (rc) return rc;
+	rc = join_rest(b);
 	if (rc) return rc;
 	rc = launch(b, MJB_MODE_STEP1, 1);
 	if (rc == MJB_OK) {
@@ -1566,6 +1586,8 @@ int mjb_forward(mjb_batch *b)
 	if (!b) return fail(MJB_EINVAL, "null batch");
 	int rc = ensure_ws(b);
 	if (rc) return rc;
+	rc = join_rest(b);
+	if (rc) return rc;
 	rc = launch(b, MJB_MODE_FORWARD, 1);
 	if (rc == MJB_OK) {
 		b->frame_valid = true;
@@ -1584,7 +1606,10 @@ int mjb_reset(mjb_batch *b, const uint8_t *mask)
 		HIP_TRY(hipMemcpyAsync(b->mask_dev, mask, (size_t)b->nenv, hipMemcpyHostToDevice, b->stream));
 		md = b->mask_dev;
 	}
-	int prc = sync_params(b);
+	int prc = join_rest(b);
+	if (prc) return prc;
+	b->split_ncb = -1;  // (an open split step is abandoned: mjb_step1_prefix starts the next one)
+	prc = sync_params(b);
 	if (prc) return prc;
 	int rc = mjb_launch_reset(b->params_dev, b->nenv, md, b->stream);
 	if (rc != 0) return fail(MJB_ENODEVICE, "reset launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -2422,9 +2447,18 @@ int mjb_set_env_body_mass(mjb_batch *b, int env_lo, int env_hi, const double *bo
 	const mjb_model_desc &h = b->model->h;
 	const int stride = mjb_env_mass_stride(b->model), n = env_hi - env_lo;
 	std::vector<double> packed((size_t)std::max(1, n) * stride);
+	// (the derivation is mj_setConst -- Jacobians of every body, an O(nbody nv^2) mass matrix and its inverse -- and a service call that
+	//  sets one mass on the whole batch, setBodyStateCB with the default env range, hands over nenv identical rows under the physics
+	//  mutex: derived once per DISTINCT row, the block of a row equal to its predecessor is copied)
 	for (int e = 0; e < n; e++) {
-		const int rc = mjb_derive_mass_params(b->model, body_mass + (size_t)e * h.nbody, body_inertia ? body_inertia + (size_t)e * 3 * h.nbody : nullptr,
-		                                      packed.data() + (size_t)e * stride);
+		const double *bm = body_mass + (size_t)e * h.nbody, *bi = body_inertia ? body_inertia + (size_t)e * 3 * h.nbody : nullptr;
+		double *dst = packed.data() + (size_t)e * stride;
+		if (e > 0 && std::memcmp(bm, bm - h.nbody, sizeof(double) * h.nbody) == 0 &&
+		    (!bi || std::memcmp(bi, bi - 3 * h.nbody, sizeof(double) * 3 * h.nbody) == 0)) {
+			std::memcpy(dst, dst - stride, sizeof(double) * stride);
+			continue;
+		}
+		const int rc = mjb_derive_mass_params(b->model, bm, bi, dst);
 		if (rc != MJB_OK) return rc;
 	}
 	return mjb_set_env_mass_params(b, env_lo, env_hi, packed.data());

@@ -472,6 +472,16 @@ int mjr_env_test_plugin_flag(mjr_env *e, int i, const char *name, int clear)
 		if (clear) t->control_calls.store(0);
 		return v;
 	}
+	if (!strcmp(name, "passive_calls")) {
+		int v = t->passive_calls.load();
+		if (clear) t->passive_calls.store(0);
+		return v;
+	}
+	if (!strcmp(name, "last_calls")) {
+		int v = t->last_calls.load();
+		if (clear) t->last_calls.store(0);
+		return v;
+	}
 	if (!strcmp(name, "last_env")) return t->last_env.load();
 	return -1;
 }

@@ -207,6 +207,11 @@ void MujocoEnv::unpinMirrors()
 	if (backend_ && backend_->host_unregister)
 		for (void *p : pinned_) backend_->host_unregister(backend_->self, p);
 	pinned_.clear();
+	// (the packed transfer buffer is page-locked where it is first sized, transferPacked: emptied here so that the next transfer
+	//  sizes and registers it again with the backend that is current then -- left alone, the transfers after a reload ran from
+	//  pageable memory)
+	pack_host_.clear();
+	pack_host_.shrink_to_fit();
 }
 
 void MujocoEnv::loadWithModelAndData()

@@ -234,6 +234,9 @@ int mj_name2id(const mjModel *m, int type, const char *name)
 	case mjOBJ_SENSOR: tab = &m->sensor_names; break;
 	default: return -1;
 	}
+	// (unnamed elements are kept as "" in the tables: mj_name2id never matches them -- an empty name is "not found", as in MuJoCo,
+	//  where setBodyStateCB / getGeomPropertiesCB then fail instead of acting on the first unnamed body or geom)
+	if (!name || !*name) return -1;
 	for (size_t i = 0; i < tab->size(); i++)
 		if ((*tab)[i] == name) return (int)i;
 	return -1;

@@ -27,9 +27,12 @@ public:
 	                 ran_render_cb = { false }, ran_last_cb = { false }, ran_on_geom_changed_cb = { false };
 	std::atomic_bool got_config_param = { false }, got_lvl1_nested_array = { false }, got_lvl2_nested_array = { false },
 	                 got_lvl1_nested_struct = { false }, got_lvl2_nested_struct = { false }, should_fail = { false };
-	std::atomic_int control_calls = { 0 }, last_env = { -1 };
+	std::atomic_int control_calls = { 0 }, passive_calls = { 0 }, last_calls = { 0 }, last_env = { -1 };
 	// optional behaviour for data-path tests: ctrl[i] += ctrl_bias, qfrc_passive[i] += passive_bias
 	double ctrl_bias = 0, passive_bias = 0;
+	// ... and from sim time xfrc_time on, xfrc_applied[6 * xfrc_body + 2] = xfrc_z (a plugin that starts pushing a body in mid-run)
+	double xfrc_time = -1, xfrc_z = 0;
+	int xfrc_body = 1;
 
 private:
 	unsigned mask_ = CB_ALL;

@@ -379,6 +379,34 @@ def test_control_only_plugin_chains_split_steps(host, factory):
         x.shutdown()
 
 
+def test_xfrc_written_mid_run_with_a_callback_prefix(host, factory):
+    """A control callback that starts writing xfrc_applied in mid-run flips the engine's launch parameters (use_xfrc: the fused
+    launches move from the compact to the full frame) while -- with only a PREFIX of the envs carrying callbacks -- the fused launch
+    of the other envs of the same step may still be in flight on its own stream: the upload has to wait for it (ADVICE r03:
+    mjb_api.hip sync_params vs mjb_step_rest).  The trajectory must equal the run in which every env is a callback env (no rest
+    launch exists there), env by env for the callback envs, and the untouched run for the others."""
+    m = mjcf.load_asset("franka_like")
+    nenv, ncb, K = 6, 2, 12
+    t_push = 5 * m["timestep"][0]
+    plug = [{"type": "mujoco_ros/TestPlugin", "xfrc_time": t_push, "xfrc_z": 30.0, "xfrc_body": 4}]
+    pre = start(host, factory, m, {"unpause": False, "MujocoPlugins": plug}, nenv=nenv)
+    full = start(host, factory, m, {"unpause": False, "MujocoPlugins": plug}, nenv=nenv)
+    bare = start(host, factory, m, {"unpause": False}, nenv=nenv)
+    pre.set_callback_envs(ncb)
+    for env in (pre, full, bare):
+        for e in range(nenv):
+            env.set_field("qvel", 0.1 * (e + 1) * np.ones(m["nv"]), env=e)
+        for _ in range(K):   # (one-step requests: every step is a split step of its own, the rest launch runs beside the callbacks)
+            assert env.step(1)
+    for e in range(nenv):
+        want = full if e < ncb else bare
+        np.testing.assert_allclose(pre.get_field("qpos", e), want.get_field("qpos", e), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(pre.get_field("qvel", e), want.get_field("qvel", e), rtol=0, atol=1e-11)
+    assert np.abs(full.get_field("qvel", 0) - bare.get_field("qvel", 0)).max() > 1e-4   # the push does act
+    for x in (pre, full, bare):
+        x.shutdown()
+
+
 def test_plugin_data_contract_batched(host, factory):
     """Callbacks run once per env instance per step, see that instance's view, and what they write is used:
     ctrl written in controlCallback drives the actuators, qfrc_passive is ADDED to (plugin_utils.h:91-107)."""
