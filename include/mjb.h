@@ -173,6 +173,13 @@ int mjb_step2_prefix(mjb_batch *b, int ncb);
  * generic kernel instead, whose factor / solve sum in a different order: equal to rounding (tests/test_gpu_fused_consistency.py
  * bounds it at 1e-9 over a burst), not to the last bit. */
 int mjb_step21_prefix(mjb_batch *b, int ncb);
+/* The second half of an RK4 step (<option integrator="RK4">) cut at the callback points of its four evaluations: MuJoCo's
+ * mj_RungeKutta evaluates mj_forwardSkip -- and with it mjcb_passive / mjcb_control -- once per evaluation (the reason the
+ * reference has lastStageCallback at all, mujoco_ros/include/mujoco_ros/plugin_utils.h:119-125).  After mjb_step1_prefix and the
+ * callbacks of evaluation 0: rk = 0, 1, 2 finish evaluation rk and run the first half of evaluation rk + 1 (its view, at
+ * time = t0 + c h, is readable for the callback envs afterwards); rk = 3 finishes the step (advances the step counter).
+ * Four calls in a row == mjb_step2_prefix of the same model, bit for bit (tests/test_rk4.py). */
+int mjb_step2_rk_prefix(mjb_batch *b, int ncb, int rk);
 
 /* Recompute all derived quantities without integrating (mj_forward: mujoco_env.cpp:329, :621;
  * callbacks.cpp:573) and leave the full frame in the HBM workspace for mjb_get. */

@@ -55,6 +55,10 @@ typedef struct mjr_backend {
 	int (*step2_prefix)(void *self, int ncb);
 	/* optional: step2_prefix of the step in flight + step1_prefix of the next one as one launch (mjb_step21_prefix) */
 	int (*step21_prefix)(void *self, int ncb);
+	/* optional: the second half of an RK4 step cut at the callback points of its four evaluations (mjb_step2_rk_prefix): rk = 0, 1, 2
+	 * finish evaluation rk and run the first half of evaluation rk + 1 for envs [0, ncb) -- ncb < 0: a backend without the prefix
+	 * entry points, all envs --, rk = 3 finishes the step.  NULL: control / passive callbacks of an RK4 model fire once per step. */
+	int (*step2_rk)(void *self, int ncb, int rk);
 } mjr_backend;
 
 enum {

@@ -159,6 +159,7 @@ def load_library(path=None):
         "mjb_step_rest": (ci, [vp, ci]),
         "mjb_step2_prefix": (ci, [vp, ci]),
         "mjb_step21_prefix": (ci, [vp, ci]),
+        "mjb_step2_rk_prefix": (ci, [vp, ci, ci]),
         "mjb_get_packed": (ci, [vp, ci, C.POINTER(ci), ci, ci, C.POINTER(cd)]),
         "mjb_set_packed": (ci, [vp, ci, C.POINTER(ci), ci, ci, C.POINTER(cd)]),
         "mjb_derive_mass_params": (ci, [vp, C.POINTER(cd), C.POINTER(cd), C.POINTER(cd)]),

@@ -322,7 +322,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact, int jrows_req = 
 	L.qHdi = off;
 	off += d.nv;
 	L.rk = d.integrator == MJB_INT_RK4 ? off : -1;  // (persistent across the evaluations of one step)
-	off += d.integrator == MJB_INT_RK4 ? d.nq + 4 * d.nv + d.nsensordata : 0;
+	off += d.integrator == MJB_INT_RK4 ? d.nq + 4 * d.nv + d.nsensordata + 1 : 0;  // X0 | sums | warmstart | the step's sensordata | t0
 	// transient scratch of the constrained kernels: ntri doubles for the packed dense triangle of the L'DL factor (nv <= 16, PGS:
 	// the J M^-1 rows; 16 < nv <= 32: the M^-1 solves of fwd_acceleration / Euler, solve_tri32), 128 for the box - box narrow phase
 	const int ntri = d.nefcmax <= 0 ? 0 : ((d.nv <= 16 && d.solver == MJB_SOL_PGS) ? 128 : ((d.nv > 16 && d.nv <= 32) ? 496 : 0));
@@ -1390,7 +1390,7 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 	{
 		static const int forced = [] { const char *v = getenv("MJB_DEBUG_VARIANT"); return v ? atoi(v) : -1; }();  // measurement knob
 		if ((forced == 1 || forced == 9) && (variant == 1 || variant == 9)) variant = forced;  // (only the two builds of the same PGS step are interchangeable)
-		if (mode == MJB_MODE_STEP21 && variant == 9) variant = 1;  // (the 256-register build carries no chained-step mode)
+		if ((mode == MJB_MODE_STEP21 || mode == MJB_MODE_RKMID || mode == MJB_MODE_RKLAST) && variant == 9) variant = 1;  // (the 256-register build carries no chained-step / cut-RK4 mode)
 	}
 	// long fused launches of the constrained kernels hand out (chunk of steps, env) work items dynamically (mjb_step.hip)
 	// ... unless every env gets a slot of its own (envs <= resident envs per CU x CUs): then the queue has nothing to even out, an
@@ -1577,6 +1577,33 @@ int mjb_step21_prefix(mjb_batch *b, int ncb)
 		b->split_rest_done = false;
 		b->frame_valid = true;
 		b->frame_hi = ncb;
+	}
+	return rc;
+}
+
+// ---- the second half of an RK4 step cut at the callback points of its four evaluations (mj_RungeKutta runs mj_forwardSkip, and with
+// it mjcb_passive / mjcb_control, once per evaluation: plugin_utils.h:119-125 is why lastStageCallback exists).  After
+// mjb_step1_prefix (evaluation 0's first half) and the host's callbacks:  rk = 0, 1, 2 finishes evaluation rk, folds it into the
+// weighted sums, sets the state of evaluation rk + 1 and runs ITS first half -- the host's callbacks then see that evaluation's view
+// (time = t0 + c h); rk = 3 finishes evaluation 3, advances the state and closes the step like mjb_step2_prefix.  The envs beyond
+// the prefix take the whole RK4 step as one fused launch (mjb_step_rest, issued with rk = 0 if the caller did not).
+int mjb_step2_rk_prefix(mjb_batch *b, int ncb, int rk)
+{
+	if (!b || ncb != b->split_ncb || rk < 0 || rk > 3) return fail(MJB_EINVAL, "mjb_step2_rk_prefix without the matching mjb_step1_prefix, or evaluation index outside 0..3");
+	if (b->model->h.integrator != MJB_INT_RK4) return fail(MJB_EINVAL, "mjb_step2_rk_prefix: the model's integrator is not RK4");
+	int rc = MJB_OK;
+	if (!b->split_rest_done) rc = mjb_step_rest(b, ncb);
+	if (rc != MJB_OK) return rc;
+	if (ncb > 0) {
+		if (!b->frame_valid || !b->st.frame_ws || b->frame_hi < ncb) return fail(MJB_EINVAL, "mjb_step2_rk_prefix without a preceding mjb_step1_prefix");
+		rc = launch(b, rk == 3 ? MJB_MODE_RKLAST : MJB_MODE_RKMID, rk, 0, ncb);  // (the evaluation index travels as the kernel's nsteps)
+	}
+	if (rc != MJB_OK || rk < 3) return rc;
+	rc = join_rest(b);
+	if (rc == MJB_OK) {
+		b->step_counter += 1;
+		b->steps_taken += 1;
+		b->split_ncb = -1;
 	}
 	return rc;
 }

@@ -197,7 +197,11 @@ struct KernelParams {
 	HwSim hw;
 };
 
-enum { MJB_MODE_STEP = 0, MJB_MODE_FORWARD = 1, MJB_MODE_STEP1 = 2, MJB_MODE_STEP2 = 3, MJB_MODE_STEP21 = 4 /* STEP2 of one step, then STEP1 of the next */ };
+enum { MJB_MODE_STEP = 0, MJB_MODE_FORWARD = 1, MJB_MODE_STEP1 = 2, MJB_MODE_STEP2 = 3, MJB_MODE_STEP21 = 4 /* STEP2 of one step, then STEP1 of the next */,
+       // STEP2 of an RK4 step cut at the callback points of its evaluations (mjb_step2_rk_prefix; the evaluation index travels in the
+       // kernel's `nsteps` argument): RKMID = second half of evaluation rk, rk4_stage(rk), first half of evaluation rk + 1;
+       // RKLAST = second half of evaluation 3 + the final advance
+       MJB_MODE_RKMID = 5, MJB_MODE_RKLAST = 6 };
 
 // launches (implemented in mjb_step.hip); returns hipError_t as int
 // (steps envs [env_lo, nenv): the whole batch, or a prefix / the rest for the split steps of the host runtime)

@@ -2091,12 +2091,13 @@ template <int G> STAGE void rk4_stage(CModel m, CLayout L, const Env &e, int rk)
 {
 	double *f = e.f;
 	const int nq = m.nq, nv = m.nv, ns = m.nsensordata;
-	double *q0 = f + L.rk, *v0 = q0 + nq, *accv = v0 + nv, *acca = accv + nv, *w0 = acca + nv, *sens = w0 + nv;
+	double *q0 = f + L.rk, *v0 = q0 + nq, *accv = v0 + nv, *acca = accv + nv, *w0 = acca + nv, *sens = w0 + nv, *t0 = sens + ns;
 	const double h = m.timestep[0];
 	const double B = (rk == 0 || rk == 3) ? 1.0 / 6.0 : 1.0 / 3.0;
 	if (rk == 0) {
 		for (int k = e.lane; k < nq; k += G) q0[k] = f[L.qpos + k];
 		for (int k = e.lane; k < ns; k += G) sens[k] = f[L.sensordata + k];  // (the sub-stage evaluations skip the sensors in the reference)
+		if (e.lane == 0) t0[0] = f[L.time];
 	}
 	for (int d = e.lane; d < nv; d += G) {
 		if (rk == 0) v0[d] = f[L.qvel + d];
@@ -2136,8 +2137,11 @@ template <int G> STAGE void rk4_stage(CModel m, CLayout L, const Env &e, int rk)
 	}
 	if (last) {
 		for (int k = e.lane; k < ns; k += G) f[L.sensordata + k] = sens[k];
-		if (e.lane == 0) f[L.time] += h;
 	}
+	gsync<G>();
+	// (mj_RungeKutta evaluates stage i at d->time = t0 + c_i h, c = 1/2, 1/2, 1: what a control / passive callback fired from that
+	//  evaluation reads; nothing in the engine's own arithmetic depends on it)
+	if (e.lane == 0) f[L.time] = t0[0] + (rk < 2 ? 0.5 : 1.0) * h;
 	gsync<G>();
 }
 
@@ -2781,7 +2785,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 		else e.mp = nullptr;  // (batches with per-env masses never run the dense kernels)
 		double *ws = s.frame_ws ? s.frame_ws + (size_t)e.env * s.frame_stride : nullptr;
 
-		if (mode == MJB_MODE_STEP2 || (DENSE == 0 && CON != 9 && mode == MJB_MODE_STEP21)) {
+		if (mode == MJB_MODE_STEP2 || (DENSE == 0 && CON != 9 && (mode == MJB_MODE_STEP21 || mode == MJB_MODE_RKMID || mode == MJB_MODE_RKLAST))) {
 			// resume: full frame from the workspace, then the (possibly host-modified) state on top
 			// (eight loads in flight per lane: the copy is a chain of HBM round trips otherwise -- a split step of ONE callback env
 			//  is pure latency, profiles/r03_callback_path.txt)
@@ -2821,6 +2825,10 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 		//  extra mode; the host picks the generic / 512-register kernels for this launch)
 		const int st0 = item_chunk * chunk;  // first step of this work item (0 unless the launch is chunked)
 		const int nst = mode == MJB_MODE_STEP ? (dyn ? (nsteps - st0 < chunk ? nsteps - st0 : chunk) : nsteps) : ((DENSE == 0 && CON != 9 && mode == MJB_MODE_STEP21) ? 2 : 1);
+		// (an RK4 step cut at its callback points: this launch starts at evaluation rk0 -- whose first half the previous launch ran --
+		//  and stops after ONE rk4_stage, with the next evaluation's first half done)
+		const bool rksplit = DENSE == 0 && CON != 9 && (mode == MJB_MODE_RKMID || mode == MJB_MODE_RKLAST);
+		const int rk0 = rksplit ? nsteps : 0;
 #pragma nounroll
 		for (int st = 0; st < nst; st++) {
 			// (the launch mode re-laundered per step: the flags derived from it -- a dozen scalar masks -- are invariants of the step loop
@@ -2829,8 +2837,9 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 			asm volatile("" : "+s"(mode));
 			const bool combo = DENSE == 0 && CON != 9 && mode == MJB_MODE_STEP21;
 			const bool checks = mode != MJB_MODE_FORWARD;
-			const bool do_first = combo ? st == 1 : mode != MJB_MODE_STEP2, do_rest = combo ? st == 0 : mode != MJB_MODE_STEP1;
-			const bool do_euler = combo ? st == 0 : (mode == MJB_MODE_STEP || mode == MJB_MODE_STEP2);
+			const bool rkmode = mode == MJB_MODE_RKMID || mode == MJB_MODE_RKLAST;
+			const bool do_first = combo ? st == 1 : (mode != MJB_MODE_STEP2 && !rkmode), do_rest = combo ? st == 0 : mode != MJB_MODE_STEP1;
+			const bool do_euler = combo ? st == 0 : (mode == MJB_MODE_STEP || mode == MJB_MODE_STEP2 || rkmode);
 			const bool hw_on = do_rest && checks && P->hw.n > 0;  // device-side DefaultRobotHWSim stage registered
 			PROF_BEGIN();
 			if (do_first && checks && nz.enabled) ctrl_noise<G>(m, L, nz, e, step0 + (unsigned int)(st0 + st));
@@ -2861,10 +2870,10 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 			// copy of the forward stages in the instruction stream): rk = evaluation index, rk4_stage() sets the next state
 			rk4 = do_euler && P->m.integrator == MJB_INT_RK4;
 #pragma nounroll
-			for (int rk = 0;;) {
+			for (int rk = rk0;;) {
 #pragma nounroll
 			for (int attempt = 0; attempt < 2; attempt++) {
-				if (do_first || attempt || rk) {
+				if (do_first || attempt || rk > rk0) {
 					if (attempt == 0 && !rk && checks) {
 						const int bad = any_bad<G>(e, L, e.f + L.qpos, m.nq, e.f + L.qvel, m.nv);
 						if (bad) reset_frame_state<G>(m, L, s, lite(e), bad == 1 ? MJB_WARN_BADQPOS : MJB_WARN_BADQVEL);
@@ -2890,6 +2899,10 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 				if (!rk4 || !do_rest) break;
 				VIEW(P, compact, rk4_stage<G>(m, L, e, rk));
 				if (++rk == 4) break;
+				if (rksplit) {  // the next evaluation's first half, then back to the host for its callbacks
+					forward_first<G, CON, DENSE>(P, e, compact);
+					break;
+				}
 			}
 			}
 			PROF(14);  // whole forward (incl. checks)

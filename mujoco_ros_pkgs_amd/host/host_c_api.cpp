@@ -56,6 +56,7 @@ int be_step1_prefix(void *s, int ncb) { return mjb_step1_prefix(B(s)->batch, ncb
 int be_step_rest(void *s, int ncb) { return mjb_step_rest(B(s)->batch, ncb); }
 int be_step2_prefix(void *s, int ncb) { return mjb_step2_prefix(B(s)->batch, ncb); }
 int be_step21_prefix(void *s, int ncb) { return mjb_step21_prefix(B(s)->batch, ncb); }
+int be_step2_rk(void *s, int ncb, int rk) { return mjb_step2_rk_prefix(B(s)->batch, ncb < 0 ? mjb_nenv(B(s)->batch) : ncb, rk); }
 const char *be_err(void *) { return mjb_last_error(); }
 void be_destroy(void *s)
 {
@@ -242,7 +243,7 @@ mjr_backend *sharded_factory(const mjb_model_desc *desc, int nenv, int, void *us
 	sh->stride[MJR_ENV_BODY_MASS] = (size_t)desc->nbody * sizeof(double);
 	sh->vt = mjr_backend{ sh, sh_nenv, sh_field_size, sh_step, sh_step1, sh_step2, sh_forward, sh_reset, sh_get, sh_set, sh_noise,
 		                  sh_sync, sh_err, sh_destroy, sh_get_many, sh_set_many, sh_host_register, sh_host_unregister, sh_step_async,
-		                  sh_register_collision, sh_set_env_param, nullptr, nullptr, sh_step1_prefix, sh_step_rest, sh_step2_prefix, nullptr };
+		                  sh_register_collision, sh_set_env_param, nullptr, nullptr, sh_step1_prefix, sh_step_rest, sh_step2_prefix, nullptr, nullptr };
 	return &sh->vt;
 }
 
@@ -276,7 +277,7 @@ mjr_backend *mjr_make_mjb_backend(const mjb_model_desc *desc, int nenv, int devi
 	b->vt = mjr_backend{ b, be_nenv, be_field_size, be_step, be_step1, be_step2, be_forward, be_reset, be_get, be_set,
 		                 be_noise, be_sync, be_err, be_destroy, be_get_many, be_set_many, be_host_register, be_host_unregister,
 		                 be_step_async, be_register_collision, be_set_env_param, be_get_packed, be_set_packed, be_step1_prefix, be_step_rest,
-		                 be_step2_prefix, be_step21_prefix };
+		                 be_step2_prefix, be_step21_prefix, be_step2_rk };
 	return &b->vt;
 }
 

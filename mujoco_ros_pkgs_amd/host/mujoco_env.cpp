@@ -533,8 +533,12 @@ int MujocoEnv::stepBurst(int n, bool count_requests)
 	// -- consecutive steps of a burst are CHAINED: the second half of step s and the first half of step s + 1 are one launch
 	// (step21_prefix), one kernel and one device -> host round trip per step instead of two (round 3: 131 -> ~75 us per step).
 	const bool prefix = backend_->step1_prefix && backend_->step_rest && backend_->step2_prefix;
+	// RK4 (<option integrator="RK4">): mj_RungeKutta runs mj_forwardSkip -- and mjcb_passive / mjcb_control inside it -- for each of
+	// its four evaluations, lastStageCallback once per step (plugin_utils.h:119-125 gives exactly this as the reason it exists):
+	// the second half is cut at the evaluations (step2_rk) and the callbacks fire at each, on the view of that evaluation.
+	const bool rk4cb = model_.opt.integrator == MJB_INT_RK4 && backend_->step2_rk != nullptr;
 	const bool can_chain = prefix && backend_->step21_prefix && !(cb_mask_ & (MujocoPlugin::CB_LASTSTAGE | MujocoPlugin::CB_RENDER)) &&
-	                       !settings_.render_offscreen;
+	                       !settings_.render_offscreen && !rk4cb;
 	bool primed = false;        // the first half of this step already ran (in the previous step's chained launch)
 	bool stop_after = false;    // a reset was seen after the chain was committed: finish the primed step, then leave
 	double t_prev = views_[0].time;
@@ -568,7 +572,23 @@ int MujocoEnv::stepBurst(int n, bool count_requests)
 			continue;
 		}
 		primed = false;
-		if ((prefix ? backend_->step2_prefix(backend_->self, ncb) : backend_->step2(backend_->self)) != 0) break;
+		if (rk4cb) {
+			bool failed = false;
+			for (int rk = 0; rk < 3 && !failed; rk++) {
+				if (backend_->step2_rk(backend_->self, prefix ? ncb : -1, rk) != 0) {
+					failed = true;
+					break;
+				}
+				pullViews(0, ncb, true);  // evaluation rk + 1: its state, its derived fields, time = t0 + c h
+				for (int e = 0; e < ncb; e++) {
+					cb_view_ = &views_[e];
+					runPassiveCbs();
+					runControlCbs();
+				}
+				pushViews(0, ncb, true);
+			}
+			if (failed || backend_->step2_rk(backend_->self, prefix ? ncb : -1, 3) != 0) break;
+		} else if ((prefix ? backend_->step2_prefix(backend_->self, ncb) : backend_->step2(backend_->self)) != 0) break;
 		pullViews(0, ncb, false);
 		publishSimTime(views_[0].time);
 		for (int e = 0; e < ncb; e++) {

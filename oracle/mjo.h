@@ -54,6 +54,7 @@ typedef struct mjo_data {
 	double *scratch_nv;
 	double *scratch_nv2;
 	double *rk_warmstart; /* [nv] RK4: the warmstart the step came in with (every sub-stage evaluation starts from it) */
+	double *rk_buf;       /* [nq + 5 nv + nsensordata + 1] RK4 state of a step cut at its callback points (mjo_step2_rk) */
 } mjo_data;
 
 mjo_data *mjo_make_data(const mjb_model_desc *m); /* mj_makeData  */
@@ -95,6 +96,8 @@ void mjo_step(const mjb_model_desc *m, mjo_data *d);    /* mj_step    */
 /* split halves used to emulate the control-callback point: step1 = up to (excl.) mjcb_control */
 void mjo_step1(const mjb_model_desc *m, mjo_data *d);
 void mjo_step2(const mjb_model_desc *m, mjo_data *d);
+/* mjo_step2 of an RK4 step cut at the callback points of its four evaluations (rk = 0..3; four calls in a row == mjo_step2) */
+void mjo_step2_rk(const mjb_model_desc *m, mjo_data *d, int rk);
 
 /* The reference's ctrl-noise injector (mujoco_env.cpp:469-481) with the engine's counter-based
  * normal generator: Philox-4x32-10 keyed by seed, counter (env, step, actuator) + Box-Muller. */

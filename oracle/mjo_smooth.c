@@ -52,6 +52,7 @@ mjo_data *mjo_make_data(const mjb_model_desc *m)
 	ALLOC(scratch_nv, m->nv)
 	ALLOC(scratch_nv2, m->nv)
 	ALLOC(rk_warmstart, m->nv)
+	ALLOC(rk_buf, m->nq + 5 * m->nv + m->nsensordata + 1)
 #undef ALLOC
 	mjo_reset_data(m, d);
 	return d;
@@ -75,6 +76,7 @@ void mjo_free_data(mjo_data *d)
 	free(d->scratch_nv);
 	free(d->scratch_nv2);
 	free(d->rk_warmstart);
+	free(d->rk_buf);
 	free(d);
 }
 
@@ -994,43 +996,82 @@ void mjo_forward(const mjb_model_desc *m, mjo_data *d)
  * mj_forwardSkip(.., mjSTAGE_NONE, skipsensor = 1); the step then advances X0 by h with sum_j B_j F_j (mj_advance with an explicit
  * velocity).  The constraint solver's warmstart is the one saved by the previous step's mj_advance for every evaluation, and the
  * last evaluation's qacc becomes the next one.  (No activations: na == 0 in everything this engine loads.) */
+typedef struct {
+	double *q0, *v0, *accv, *acca, *dxv, *sens, *t0;
+} rk4_state;
+static const double RK_A[3] = { 0.5, 0.5, 1.0 }, RK_B[4] = { 1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0 }, RK_C[3] = { 0.5, 0.5, 1.0 };
+
+static rk4_state rk4_view(const mjb_model_desc *m, double *buf)
+{
+	rk4_state S;
+	S.q0 = buf;
+	S.v0 = S.q0 + m->nq;
+	S.accv = S.v0 + m->nv;
+	S.acca = S.accv + m->nv;
+	S.dxv = S.acca + 2 * m->nv;  /* (one nv block kept free where the kernel parks the warmstart) */
+	S.sens = S.dxv + m->nv;
+	S.t0 = S.sens + m->nsensordata;
+	return S;
+}
+
+/* X0, the sensors and the time of the step, F0 = (qvel, qacc) of its own evaluation into the weighted sums */
+static void rk4_begin(const mjb_model_desc *m, mjo_data *d, rk4_state S)
+{
+	const int nq = m->nq, nv = m->nv, ns = m->nsensordata;
+	memcpy(S.q0, d->qpos, sizeof(double) * (size_t)nq);
+	memcpy(S.v0, d->qvel, sizeof(double) * (size_t)nv);
+	memcpy(S.sens, d->sensordata, sizeof(double) * (size_t)ns);
+	S.t0[0] = d->time[0];
+	for (int k = 0; k < nv; k++) {
+		S.accv[k] = 0.0 + RK_B[0] * d->qvel[k];
+		S.acca[k] = 0.0 + RK_B[0] * d->qacc[k];
+	}
+}
+
+/* X_i = X0 (+) h a_i F_{i-1}; the warmstart every evaluation of this step starts from is the one the step came in with --
+ * the solvers here save qacc as they finish, so it is put back */
+static void rk4_set_stage(const mjb_model_desc *m, mjo_data *d, rk4_state S, int i)
+{
+	const int nq = m->nq, nv = m->nv;
+	const double h = m->timestep[0];
+	for (int k = 0; k < nv; k++) S.dxv[k] = 0.0 + RK_A[i - 1] * d->qvel[k];
+	const double *qa = d->qacc;
+	memcpy(d->qpos, S.q0, sizeof(double) * (size_t)nq);
+	integrate_pos(m, d->qpos, S.dxv, h);
+	for (int k = 0; k < nv; k++) d->qvel[k] = S.v0[k] + h * (0.0 + RK_A[i - 1] * qa[k]);
+	d->time[0] = S.t0[0] + RK_C[i - 1] * h;
+	memcpy(d->qacc_warmstart, d->rk_warmstart, sizeof(double) * (size_t)nv);
+}
+
+static void rk4_accumulate(const mjb_model_desc *m, mjo_data *d, rk4_state S, int i)
+{
+	for (int k = 0; k < m->nv; k++) {
+		S.accv[k] += RK_B[i] * d->qvel[k];
+		S.acca[k] += RK_B[i] * d->qacc[k];
+	}
+}
+
+static void rk4_finish(const mjb_model_desc *m, mjo_data *d, rk4_state S)
+{
+	const int nq = m->nq, nv = m->nv, ns = m->nsensordata;
+	const double h = m->timestep[0];
+	memcpy(d->qpos, S.q0, sizeof(double) * (size_t)nq);
+	for (int k = 0; k < nv; k++) d->qvel[k] = S.v0[k] + h * S.acca[k];
+	integrate_pos(m, d->qpos, S.accv, h);
+	d->time[0] = S.t0[0] + h;
+	memcpy(d->sensordata, S.sens, sizeof(double) * (size_t)ns);  /* (sensors are skipped in the sub-stage evaluations) */
+}
+
 void mjo_rk4(const mjb_model_desc *m, mjo_data *d)
 {
-	static const double A[3] = { 0.5, 0.5, 1.0 }, B[4] = { 1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0 }, C[3] = { 0.5, 0.5, 1.0 };
-	const int nq = m->nq, nv = m->nv, ns = m->nsensordata;
-	const double h = m->timestep[0], t0 = d->time[0];
-	double *buf = (double *)malloc(sizeof(double) * (size_t)(nq + 5 * nv + ns + 1));
-	double *q0 = buf, *v0 = q0 + nq, *accv = v0 + nv, *acca = accv + nv, *w0 = acca + nv, *dxv = w0 + nv, *sens = dxv + nv;
-	memcpy(q0, d->qpos, sizeof(double) * (size_t)nq);
-	memcpy(v0, d->qvel, sizeof(double) * (size_t)nv);
-	memcpy(sens, d->sensordata, sizeof(double) * (size_t)ns);
-	for (int k = 0; k < nv; k++) {
-		accv[k] = 0.0 + B[0] * d->qvel[k];
-		acca[k] = 0.0 + B[0] * d->qacc[k];
-	}
+	const rk4_state S = rk4_view(m, d->rk_buf);
+	rk4_begin(m, d, S);
 	for (int i = 1; i < 4; i++) {
-		/* X_i = X0 (+) h a_i F_{i-1}; the warmstart every evaluation of this step starts from is the one the step came in with --
-		 * the solvers here save qacc as they finish, so it is put back (w0 is taken after the first evaluation restored it below) */
-		for (int k = 0; k < nv; k++) dxv[k] = 0.0 + A[i - 1] * d->qvel[k];
-		const double *qa = d->qacc;
-		memcpy(d->qpos, q0, sizeof(double) * (size_t)nq);
-		integrate_pos(m, d->qpos, dxv, h);
-		for (int k = 0; k < nv; k++) d->qvel[k] = v0[k] + h * (0.0 + A[i - 1] * qa[k]);
-		d->time[0] = t0 + C[i - 1] * h;
-		memcpy(d->qacc_warmstart, d->rk_warmstart, sizeof(double) * (size_t)nv);
+		rk4_set_stage(m, d, S, i);
 		mjo_forward(m, d);
-		for (int k = 0; k < nv; k++) {
-			accv[k] += B[i] * d->qvel[k];
-			acca[k] += B[i] * d->qacc[k];
-		}
+		rk4_accumulate(m, d, S, i);
 	}
-	memcpy(d->qpos, q0, sizeof(double) * (size_t)nq);
-	for (int k = 0; k < nv; k++) d->qvel[k] = v0[k] + h * acca[k];
-	integrate_pos(m, d->qpos, accv, h);
-	d->time[0] = t0 + h;
-	memcpy(d->sensordata, sens, sizeof(double) * (size_t)ns);  /* (sensors are skipped in the sub-stage evaluations) */
-	(void)w0;
-	free(buf);
+	rk4_finish(m, d, S);
 }
 
 void mjo_step2(const mjb_model_desc *m, mjo_data *d)
@@ -1046,6 +1087,40 @@ void mjo_step2(const mjb_model_desc *m, mjo_data *d)
 	}
 	if (m->integrator == MJB_INT_RK4) mjo_rk4(m, d);
 	else mjo_euler(m, d);
+}
+
+/* mjo_step2 of an RK4 step cut at the callback points of its four evaluations -- mj_forwardSkip invokes mjcb_passive / mjcb_control
+ * in every one of them, which is why the reference has lastStageCallback at all (plugin_utils.h:119-125).  Stage rk = 0 .. 2 finishes
+ * evaluation rk (actuation .. acceleration-stage sensors; rk == 0: the warmstart and mj_checkAcc of mjo_step2), folds it into the
+ * weighted sums, sets X_{rk+1} and runs the position / velocity stages of evaluation rk + 1: the caller's callbacks then see that
+ * evaluation's view (time = t0 + c h included).  Stage 3 finishes evaluation 3 and advances.  Stages 0, 1, 2, 3 in a row == mjo_step2. */
+void mjo_step2_rk(const mjb_model_desc *m, mjo_data *d, int rk)
+{
+	const rk4_state S = rk4_view(m, d->rk_buf);
+	if (rk == 0) {
+		memcpy(d->rk_warmstart, d->qacc_warmstart, sizeof(double) * (size_t)m->nv);
+		forward_rest(m, d);
+		if (bad(d->qacc, m->nv)) {
+			d->warning[MJB_WARN_BADQACC]++;
+			mjo_reset_data(m, d);
+			memcpy(d->rk_warmstart, d->qacc_warmstart, sizeof(double) * (size_t)m->nv);
+			mjo_forward(m, d);
+		}
+		rk4_begin(m, d, S);
+	} else {
+		forward_rest(m, d);
+		rk4_accumulate(m, d, S, rk);
+	}
+	if (rk == 3) {
+		rk4_finish(m, d, S);
+		return;
+	}
+	rk4_set_stage(m, d, S, rk + 1);
+	mjo_fwd_position(m, d);
+	mjo_sensor(m, d, MJB_STAGE_POS);
+	mjo_fwd_velocity(m, d);
+	mjo_sensor(m, d, MJB_STAGE_VEL);
+	if (m->enableflags & MJB_ENBL_ENERGY) mjo_energy(m, d);
 }
 
 void mjo_step(const mjb_model_desc *m, mjo_data *d)

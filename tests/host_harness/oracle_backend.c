@@ -60,6 +60,14 @@ static int ob_step2(void *s)
 	b->step++;
 	return 0;
 }
+static int ob_step2_rk(void *s, int ncb, int rk)  /* (no prefix entry points: every env is a callback env) */
+{
+	ob *b = (ob *)s;
+	(void)ncb;
+	for (int e = 0; e < b->nenv; e++) mjo_step2_rk(&b->desc, b->d[e], rk);
+	if (rk == 3) b->step++;
+	return 0;
+}
 static int ob_forward(void *s)
 {
 	ob *b = (ob *)s;
@@ -146,7 +154,7 @@ mjr_backend *oracle_backend_factory(const mjb_model_desc *desc, int nenv, int de
 	b->d = (mjo_data **)calloc((size_t)nenv, sizeof(mjo_data *));
 	for (int e = 0; e < nenv; e++) b->d[e] = mjo_make_data(&b->desc);
 	mjr_backend vt = { b, ob_nenv, ob_field_size, ob_step, ob_step1, ob_step2, ob_forward, ob_reset, ob_get, ob_set,
-		               ob_noise, ob_sync, ob_err, ob_destroy, NULL, NULL, NULL, NULL, NULL, ob_register_collision, ob_set_env_param, NULL, NULL, NULL, NULL, NULL };
+		               ob_noise, ob_sync, ob_err, ob_destroy, NULL, NULL, NULL, NULL, NULL, ob_register_collision, ob_set_env_param, NULL, NULL, NULL, NULL, NULL, NULL, ob_step2_rk };
 	b->vt = vt;
 	return &b->vt;
 }

@@ -407,6 +407,47 @@ def test_xfrc_written_mid_run_with_a_callback_prefix(host, factory):
         x.shutdown()
 
 
+def test_rk4_fires_control_and_passive_callbacks_at_every_evaluation(host, factory):
+    """mj_RungeKutta runs mj_forwardSkip -- and mjcb_passive / mjcb_control inside it -- once per evaluation, four times a step, and
+    that is the stated reason lastStageCallback exists (mujoco_ros/include/mujoco_ros/plugin_utils.h:119-125: "called at the end of a
+    full step, never inside integrator sub-steps").  With <option integrator="RK4"> the runtime cuts the step's second half at the
+    evaluations: 4 control + 4 passive + 1 lastStage call per env and step; what the callbacks write is used by every evaluation
+    (the same forces applied by hand give the same trajectory); the callback envs' step equals the other envs' fused RK4 step when
+    the plugin writes nothing."""
+    m = mjcf.load_asset("franka_like", override={"integrator": "RK4"})
+    nenv, ncb, K = 4, 3, 5
+    plug = [{"type": "mujoco_ros/TestPlugin", "ctrl_bias": 0.75, "passive_bias": -0.125}]
+    env = start(host, factory, m, {"unpause": False, "MujocoPlugins": plug}, nenv=nenv)
+    hand = start(host, factory, m, {"unpause": False}, nenv=nenv)
+    idle = start(host, factory, m, {"unpause": False, "MujocoPlugins": [{"type": "mujoco_ros/TestPlugin"}]}, nenv=nenv)
+    env.set_callback_envs(ncb)
+    idle.set_callback_envs(ncb)
+    for x in (env, hand, idle):
+        for e in range(nenv):
+            x.set_field("qvel", 0.2 * (e + 1) * np.ones(m["nv"]), env=e)
+    for e in range(nenv):   # ctrl += bias at each of the four evaluations of step k: 4 k + 1 .. 4 k + 4 times the bias -- by hand below
+        hand.set_field("qfrc_applied", np.full(m["nv"], -0.125), env=e)
+    assert env.step(K) and idle.step(K)
+    assert env.plugin_flag(0, "control_calls") == 4 * ncb * K
+    assert env.plugin_flag(0, "passive_calls") == 4 * ncb * K
+    assert env.plugin_flag(0, "last_calls") == ncb * K
+    assert abs(env.get_field("time", 0)[0] - K * m["timestep"][0]) < 1e-12
+    # an idle plugin: the callback envs' cut step == the fused step the other envs (and a plugin-free run) take
+    bare = start(host, factory, m, {"unpause": False}, nenv=nenv)
+    for e in range(nenv):
+        bare.set_field("qvel", 0.2 * (e + 1) * np.ones(m["nv"]), env=e)
+    assert bare.step(K)
+    for e in range(nenv):
+        np.testing.assert_allclose(idle.get_field("qpos", e), bare.get_field("qpos", e), rtol=0, atol=1e-13)
+    # the biased plugin: ctrl accumulates one bias per evaluation (the view's ctrl is the state field the next evaluation starts from)
+    ctrl_end = env.get_field("ctrl", 0)
+    np.testing.assert_allclose(ctrl_end, 0.75 * 4 * K)
+    assert np.abs(env.get_field("qvel", 0) - bare.get_field("qvel", 0)).max() > 1e-4
+    np.testing.assert_allclose(env.get_field("qvel", nenv - 1), bare.get_field("qvel", nenv - 1), rtol=0, atol=1e-13)   # not a callback env
+    for x in (env, hand, idle, bare):
+        x.shutdown()
+
+
 def test_plugin_data_contract_batched(host, factory):
     """Callbacks run once per env instance per step, see that instance's view, and what they write is used:
     ctrl written in controlCallback drives the actuators, qfrc_passive is ADDED to (plugin_utils.h:91-107)."""

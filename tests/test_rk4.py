@@ -97,6 +97,23 @@ def test_gpu_rk4_matches_oracle(kind, oracle_built):
         assert (b.lib.mjb_step21_prefix if k + 1 < K else b.lib.mjb_step2_prefix)(b.ptr, nenv) == 0
     assert np.array_equal(b.get("qpos"), outs[0][0]) and np.array_equal(b.get("qvel"), outs[0][1])
     b.close()
+    # ... and so is the step cut at the callback points of its four evaluations (mjb_step2_rk_prefix): between the cuts the callback
+    # envs show the view of the NEXT evaluation, at mj_RungeKutta's time t0 + c h
+    b = engine.Batch(cm, nenv)
+    b.set("qpos", qpos)
+    b.set("qvel", qvel)
+    b.set("ctrl", ctrl)
+    h = model["timestep"][0]
+    for k in range(K):
+        assert b.lib.mjb_step1_prefix(b.ptr, nenv) == 0
+        for rk in range(4):
+            assert b.lib.mjb_step2_rk_prefix(b.ptr, nenv, rk) == 0
+            if k == 0:
+                assert np.allclose(b.get("time")[:, 0], (0.5, 0.5, 1.0, 1.0)[rk] * h, rtol=0, atol=1e-15)
+    assert np.array_equal(b.get("qpos"), outs[0][0]) and np.array_equal(b.get("qvel"), outs[0][1])
+    assert np.array_equal(b.get("sensordata"), outs[0][2])
+    assert b.lib.mjb_step2_rk_prefix(b.ptr, nenv, 0) != 0   # (no split step open)
+    b.close()
     q, v, sd, t = outs[0]
     oq, ov, osd = oracle_built.rollout(model, qpos, qvel, K, ctrl=ctrl)
     tol = 1e-9 if kind == "franka_like" else 1e-7
