@@ -357,6 +357,14 @@ int mjb_hwsim_configure(mjb_batch *b, int n, const mjb_hwsim_joint *joints);
 int mjb_hwsim_set_command(mjb_batch *b, int which, int env_lo, int env_hi, const double *cmd);
 void *mjb_hwsim_command_ptr(mjb_batch *b, int which); /* device [nenv][n] */
 int mjb_hwsim_estop(mjb_batch *b, int active);
+/* The controller cadence MujocoRosControlPlugin::controlCallback wraps around writeSim (mujoco_ros_control/src/
+ * mujoco_ros_control_plugin.cpp:153-194), for the device-side stage: readSim -- the joint state the PIDs see -- every
+ * `control_period` of sim time (ros::Duration arithmetic, first at the first non-zero time: nothing is read or written at t = 0,
+ * :171-176), writeSim at every step after the first update with period = time - last write (:190-193), a time that went
+ * backwards re-arms both stamps (:160-169).  control_period <= 0: a write at every step on the step's own state (default).
+ * The e-stop EDGE of :180-185 restarts the controller manager's controllers -- host-side objects; the PIDs of DefaultRobotHWSim
+ * itself are never reset by the reference, nor here. */
+int mjb_hwsim_set_period(mjb_batch *b, double control_period);
 
 /* Profiling builds only (libmjb_prof.so): per-stage shader-cycle sums [0..31] and call counts [32..63] of
  * env 0; all zero in the production build.  A launch records the TWO probe ids [first_id, first_id + 2) selected by

@@ -168,6 +168,7 @@ def load_library(path=None):
         "mjb_hwsim_set_command": (ci, [vp, ci, ci, ci, C.POINTER(cd)]),
         "mjb_hwsim_command_ptr": (vp, [vp, ci]),
         "mjb_hwsim_estop": (ci, [vp, ci]),
+        "mjb_hwsim_set_period": (ci, [vp, cd]),
         "mjb_sensor_set_noise": (ci, [vp, ci, ci, C.POINTER(cd), C.POINTER(cd)]),
         "mjb_sensor_pack": (ci, [vp, C.c_uint64]),
         "mjb_sensor_get": (ci, [vp, ci, ci, ci, C.POINTER(C.c_float)]),

@@ -131,6 +131,7 @@ struct mjb_batch {
 	double *hw_gains = nullptr;    // [n][8]
 	double *hw_cmd = nullptr;      // pos | vel | eff | hold, [4][nenv][n]
 	double *hw_pid = nullptr;      // [nenv][n][2]
+	double *hw_cad = nullptr;      // [nenv][2 + 2 n] controller cadence (mjb_hwsim_set_period)
 };
 
 namespace {
@@ -1108,6 +1109,7 @@ void mjb_free_batch(mjb_batch *b)
 	if (b->hw_gains) hipFree(b->hw_gains);
 	if (b->hw_cmd) hipFree(b->hw_cmd);
 	if (b->hw_pid) hipFree(b->hw_pid);
+	if (b->hw_cad) hipFree(b->hw_cad);
 	if (b->sens_flag_dev) hipFree(b->sens_flag_dev);
 	if (b->sens_mean_dev) hipFree(b->sens_mean_dev);
 	if (b->sens_sigma_dev) hipFree(b->sens_sigma_dev);
@@ -2509,7 +2511,8 @@ int mjb_hwsim_configure(mjb_batch *b, int n, const mjb_hwsim_joint *joints)
 	if (b->hw_gains) hipFree(b->hw_gains);
 	if (b->hw_cmd) hipFree(b->hw_cmd);
 	if (b->hw_pid) hipFree(b->hw_pid);
-	b->hw_ints = nullptr; b->hw_gains = nullptr; b->hw_cmd = nullptr; b->hw_pid = nullptr;
+	if (b->hw_cad) hipFree(b->hw_cad);
+	b->hw_ints = nullptr; b->hw_gains = nullptr; b->hw_cmd = nullptr; b->hw_pid = nullptr; b->hw_cad = nullptr;
 	b->hw = HwSim{};
 	b->params_dirty = true;
 	if (n == 0) return MJB_OK;
@@ -2557,6 +2560,38 @@ void *mjb_hwsim_command_ptr(mjb_batch *b, int which)
 {
 	if (!b || which < 0 || which > 2 || b->hw.n <= 0) return nullptr;
 	return b->hw_cmd + (size_t)which * b->nenv * b->hw.n;
+}
+
+// MujocoRosControlPlugin::controlCallback's cadence (mujoco_ros_control_plugin.cpp:153-194) for the device-side stage: with a control
+// period the joint state the PIDs see is the one sampled at the last controller update (readSim, every control_period of sim
+// time; first at the first non-zero time), writeSim runs at every step after it with period = time - last write, and nothing is
+// read or written at t = 0.  control_period <= 0 switches back to a write at every step on the step's own state.
+int mjb_hwsim_set_period(mjb_batch *b, double control_period)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	if (b->hw.n <= 0) return fail(MJB_EINVAL, "mjb_hwsim_set_period before mjb_hwsim_configure");
+	if (control_period > 0 && control_period < b->model->h.timestep[0])  // (the reference refuses it too, :100-104)
+		return fail(MJB_EINVAL, "mjb_hwsim_set_period: control period %g below the simulation timestep %g", control_period, b->model->h.timestep[0]);
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	const int n = b->hw.n;
+	if (control_period > 0) {
+		const size_t per = 2 + 2 * (size_t)n;
+		std::vector<double> init((size_t)b->nenv * per, 0.0);
+		for (int e = 0; e < b->nenv; e++)
+			for (int k = 0; k < n; k++) init[(size_t)e * per + 2 + k] = 1.0;  // joint_position_ starts at 1.0 (default_robot_hw_sim.cpp:129)
+		if (!b->hw_cad) b->hw_cad = dev_alloc<double>(init.size());
+		if (!b->hw_cad) return fail(MJB_ENOMEM, "mjb_hwsim_set_period: allocation failed");
+		HIP_TRY(hipMemcpy(b->hw_cad, init.data(), init.size() * sizeof(double), hipMemcpyHostToDevice));
+		const double sec = std::floor(control_period);
+		b->hw.period_ns = (long long)sec * 1000000000LL + (long long)std::floor((control_period - sec) * 1e9 + 0.5);
+		b->hw.cad = b->hw_cad;
+	} else {
+		b->hw.period_ns = 0;
+		b->hw.cad = nullptr;
+	}
+	b->params_dirty = true;
+	return MJB_OK;
 }
 
 int mjb_hwsim_estop(mjb_batch *b, int active)

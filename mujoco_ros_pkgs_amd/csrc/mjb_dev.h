@@ -182,6 +182,10 @@ struct HwSim {
 	const double *gains;                                     // [n][8]: p, i, d, i_max, i_min, effort_limit, lower, upper
 	const double *cmd_pos, *cmd_vel, *cmd_eff, *cmd_hold;    // [nenv][n]; cmd_hold = position commands frozen at e-stop
 	double *pid;                                             // [nenv][n][2]: integral of the error, previous error
+	// controller cadence of MujocoRosControlPlugin::controlCallback (mjb_hwsim_set_period; period_ns == 0: writeSim at every step on
+	// the step's own joint state with the model's timestep, the round-2 behaviour)
+	long long period_ns;                                     // control_period as ros::Duration counts it
+	double *cad;                                             // [nenv][2 + 2 n]: last update / last write [ns], joint_position_[n], joint_velocity_[n]
 };
 
 // Everything a launch needs, resident in device memory (uploaded when it changes); kernels get one

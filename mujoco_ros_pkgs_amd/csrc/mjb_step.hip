@@ -2504,16 +2504,61 @@ template <int G> __device__ __attribute__((noinline)) void energy(CModel m, CLay
 }
 
 // device-side DefaultRobotHWSim::writeSim (include/mjb.h, mjb_hwsim_*): lane = controlled joint
+// ros::Time(double).toNSec(): sec = floor(t), nsec = round((t - sec) 1e9)
+DEVI long long ros_ns(double t)
+{
+	const double sec = floor(t);
+	return (long long)sec * 1000000000LL + (long long)floor((t - sec) * 1e9 + 0.5);
+}
+
 template <int G> __device__ __attribute__((noinline)) void hwsim_write(CModel m, CLayout L, const HwSim MJB_AS4 &hw, const EnvLite e)
 {
 	double *f = e.f;
-	const double dt = m.timestep[0];
+	double dt = m.timestep[0];
 	const bool estop = hw.estop != 0;
+	// MujocoRosControlPlugin::controlCallback around writeSim (mujoco_ros_control_plugin.cpp:153-194; oracle/mjo_hwsim.c
+	// mjo_hwsim_control_callback): the stamps are per env, every lane derives the same decisions from them
+	const bool cadence = hw.period_ns > 0;
+	double *cad = cadence ? hw.cad + (size_t)e.env * (2 + 2 * hw.n) : nullptr;
+	bool update = false;
+	long long lu = 0, lw = 0, t = 0;
+	if (cadence) {
+		t = ros_ns(f[L.time]);
+		lu = (long long)cad[0];
+		lw = (long long)cad[1];
+		if (t < lu) {  // the time went backwards (reset): both stamps re-armed (:160-169)
+			lu = t;
+			lw = t;
+		}
+		const long long sim_period = t - lu;
+		update = sim_period >= hw.period_ns || (lu == 0 && sim_period != 0);  // (:171-176; nothing happens at t = 0)
+		if (update) lu = t;
+		const bool write = lu != 0 && t > lw;                                 // (:190-193)
+		if (update) {  // readSim (default_robot_hw_sim.cpp:229-245): the joint state the PIDs see until the next update
+			for (int k = e.lane; k < hw.n; k += G) {
+				const int j = hw.joint[k];
+				const double position = f[L.qpos + m.jnt_qposadr[j]];
+				double *jp = cad + 2 + k;
+				jp[0] = hw.kind[k] == MJB_HW_PRISMATIC ? position : jp[0] + angdist(jp[0], position);
+				jp[hw.n] = f[L.qvel + m.jnt_dofadr[j]];
+			}
+		}
+		gsync<G>();  // (every lane has read the stamps)
+		if (e.lane == 0) {
+			cad[0] = (double)lu;
+			cad[1] = (double)(write ? t : lw);
+		}
+		if (!write) {
+			gsync<G>();
+			return;
+		}
+		dt = 1e-9 * (double)(t - lw);
+	}
 	for (int k = e.lane; k < hw.n; k += G) {
 		const int j = hw.joint[k], method = hw.method[k], qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
 		const size_t at = (size_t)e.env * hw.n + k;
 		const double *gn = hw.gains + 8 * k;
-		const double pos = f[L.qpos + qa], vel = f[L.qvel + da];
+		const double pos = cadence ? cad[2 + k] : f[L.qpos + qa], vel = cadence ? cad[2 + hw.n + k] : f[L.qvel + da];
 		const double cpos = estop ? hw.cmd_hold[at] : hw.cmd_pos[at];
 		double error = 0;
 		bool pid = false;

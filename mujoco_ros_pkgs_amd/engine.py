@@ -206,6 +206,10 @@ class Batch:
         _check(self.lib.mjb_hwsim_set_command(self.ptr, {"position": 0, "velocity": 1, "effort": 2}[which], lo, hi,
                                               a.ctypes.data_as(C.POINTER(C.c_double))), "mjb_hwsim_set_command")
 
+    def hwsim_set_period(self, control_period):
+        """Controller cadence of MujocoRosControlPlugin::controlCallback (mjb_hwsim_set_period); <= 0 switches it off."""
+        _check(self.lib.mjb_hwsim_set_period(self.ptr, float(control_period)), "mjb_hwsim_set_period")
+
     def hwsim_estop(self, active):
         _check(self.lib.mjb_hwsim_estop(self.ptr, 1 if active else 0), "mjb_hwsim_estop")
 

@@ -110,6 +110,12 @@ void mjo_sensor_pack(const mjb_model_desc *m, const double *sensordata, const in
 void mjo_hwsim_write(const mjb_model_desc *m, mjo_data *d, int n, const int *joint, const int *method, const int *kind,
                      const int *antiwindup, const double *gains, const double *cmd_pos, const double *cmd_vel,
                      const double *cmd_eff, const double *cmd_hold, double *pid, int estop);
+/* MujocoRosControlPlugin::controlCallback around writeSim (mujoco_ros_control_plugin.cpp:153-194): controller-update cadence,
+ * readSim sampling, write period; cad = { last update [ns], last write [ns], joint_position_[n], joint_velocity_[n] } */
+int mjo_hwsim_control_callback(const mjb_model_desc *m, mjo_data *d, int n, const int *joint, const int *method, const int *kind,
+                               const int *antiwindup, const double *gains, const double *cmd_pos, const double *cmd_vel,
+                               const double *cmd_eff, const double *cmd_hold, double *pid, int estop, double *cad,
+                               double control_period);
 void mjo_rne_post_constraint(const mjb_model_desc *m, mjo_data *d);
 int mjo_needs_rne_post(const mjb_model_desc *m);
 void mjo_register_collision(mjo_data *d, int geom_type1, int geom_type2, int func); /* mjb_register_collision */

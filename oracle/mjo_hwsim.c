@@ -4,6 +4,7 @@
  * control method; PID = control_toolbox::Pid::computeCommand (absent dependency, restated from its documented
  * algorithm).  gains[k] = { p, i, d, i_max, i_min, effort_limit, lower, upper }; pid[k] = { integral, last error }. */
 #include <math.h>
+#include <stdlib.h>
 
 #include "mjo.h"
 
@@ -72,15 +73,17 @@ static double angdist_with_limits(double from, double to, double left, double ri
 	return fabs(delta) < fabs(comp) ? delta : comp;
 }
 
-void mjo_hwsim_write(const mjb_model_desc *m, mjo_data *d, int n, const int *joint, const int *method, const int *kind,
-                     const int *antiwindup, const double *gains, const double *cmd_pos, const double *cmd_vel,
-                     const double *cmd_eff, const double *cmd_hold, double *pid, int estop)
+/* writeSim proper.  jpos / jvel: the joint state the PID sees -- DefaultRobotHWSim's joint_position_ / joint_velocity_, what
+ * readSim sampled at the last controller update (NULL: mjData's qpos / qvel of this step); dt: the period writeSim is called with */
+static void hwsim_write_core(const mjb_model_desc *m, mjo_data *d, int n, const int *joint, const int *method, const int *kind,
+                             const int *antiwindup, const double *gains, const double *cmd_pos, const double *cmd_vel,
+                             const double *cmd_eff, const double *cmd_hold, double *pid, int estop, const double *jpos,
+                             const double *jvel, double dt)
 {
-	const double dt = m->timestep[0];
 	for (int k = 0; k < n; k++) {
 		const int j = joint[k], qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
 		const double *gn = gains + 8 * k;
-		const double pos = d->qpos[qa], vel = d->qvel[da];
+		const double pos = jpos ? jpos[k] : d->qpos[qa], vel = jvel ? jvel[k] : d->qvel[da];
 		const double cpos = estop ? cmd_hold[k] : cmd_pos[k];
 		double error = 0;
 		int use_pid = 0;
@@ -129,4 +132,68 @@ void mjo_hwsim_write(const mjb_model_desc *m, mjo_data *d, int n, const int *joi
 			d->qfrc_applied[da] = cmd;
 		}
 	}
+}
+
+void mjo_hwsim_write(const mjb_model_desc *m, mjo_data *d, int n, const int *joint, const int *method, const int *kind,
+                     const int *antiwindup, const double *gains, const double *cmd_pos, const double *cmd_vel,
+                     const double *cmd_eff, const double *cmd_hold, double *pid, int estop)
+{
+	hwsim_write_core(m, d, n, joint, method, kind, antiwindup, gains, cmd_pos, cmd_vel, cmd_eff, cmd_hold, pid, estop, NULL, NULL,
+	                 m->timestep[0]);
+}
+
+/* ros::Time(double).toNSec(): sec = floor(t), nsec = round((t - sec) 1e9) (ros/time.h, TimeBase::fromSec) */
+static long ros_ns(double t)   /* (long: 64 bits on the LP64 hosts this builds for) */
+{
+	const double sec = floor(t);
+	return (long)sec * 1000000000L + (long)floor((t - sec) * 1e9 + 0.5);
+}
+
+/* MujocoRosControlPlugin::controlCallback (/root/reference mujoco_ros_control/src/mujoco_ros_control_plugin.cpp:153-194) around
+ * writeSim, for ONE env at sim time d->time (what ros::Time::now() reads inside the callback: /clock carries the time the step
+ * started at).  cad = { last_update_sim_time [ns], last_write_sim_time [ns], joint_position_[n], joint_velocity_[n] }, initially
+ * { 0, 0, 1.0 .., 0.0 .. } (default_robot_hw_sim.cpp:129-130).
+ *   - a time that went backwards (reset) re-arms both stamps (:160-169);
+ *   - the controllers are updated -- here: readSim samples the joint state the PIDs will see (:229-245; revolute / continuous
+ *     joints unwrapped by shortest_angular_distance) -- when a control period has passed, or on the first call at a non-zero time
+ *     (:171-176): nothing is read or written at t = 0;
+ *   - writeSim runs whenever an update has ever happened and time moved since the last write, with period = time - last write
+ *     (:190-193): every step, also between controller updates, on the joint state of the LAST update;
+ *   - the e-stop edge (:180-185) restarts the controller manager's controllers, which live on the host: the PIDs of
+ *     DefaultRobotHWSim itself (pid_controllers_, :300, :319) are never reset by the reference, and are not here.
+ * Returns 1 when writeSim ran. */
+int mjo_hwsim_control_callback(const mjb_model_desc *m, mjo_data *d, int n, const int *joint, const int *method, const int *kind,
+                               const int *antiwindup, const double *gains, const double *cmd_pos, const double *cmd_vel,
+                               const double *cmd_eff, const double *cmd_hold, double *pid, int estop, double *cad,
+                               double control_period)
+{
+	const long t = ros_ns(d->time[0]), period_ns = ros_ns(control_period);
+	long lu = (long)cad[0], lw = (long)cad[1];
+	double *jp = cad + 2, *jv = jp + n;
+	if (t < lu) {
+		lu = t;
+		lw = t;
+	}
+	const long sim_period = t - lu;
+	const int reset_ctrls = lu == 0;
+	if (sim_period >= period_ns || (reset_ctrls && sim_period != 0)) {
+		lu = t;
+		for (int k = 0; k < n; k++) {  /* readSim */
+			const int j = joint[k];
+			const double position = d->qpos[m->jnt_qposadr[j]];
+			if (kind[k] == MJB_HW_PRISMATIC) jp[k] = position;
+			else jp[k] += angdist(jp[k], position);
+			jv[k] = d->qvel[m->jnt_dofadr[j]];
+		}
+	}
+	int wrote = 0;
+	if (lu != 0 && t > lw) {
+		hwsim_write_core(m, d, n, joint, method, kind, antiwindup, gains, cmd_pos, cmd_vel, cmd_eff, cmd_hold, pid, estop, jp, jv,
+		                 1e-9 * (double)(t - lw));
+		lw = t;
+		wrote = 1;
+	}
+	cad[0] = (double)lu;
+	cad[1] = (double)lw;
+	return wrote;
 }

@@ -65,6 +65,8 @@ def lib(fast=False):
     L.mjo_warning.argtypes = [vp, ci]
     L.mjo_energy.argtypes = [pd, vp]
     L.mjo_energy.restype = None
+    L.mjo_hwsim_control_callback.restype = ci
+    L.mjo_hwsim_control_callback.argtypes = [pd, vp, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)] + [C.POINTER(cd)] * 6 + [ci, C.POINTER(cd), cd]
     L.mjo_hwsim_write.restype = None
     L.mjo_hwsim_write.argtypes = [pd, vp, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)] + [C.POINTER(cd)] * 6 + [ci]
     L.mjo_sensor_pack.restype = None
@@ -152,6 +154,18 @@ class OracleData:
         assert pid.dtype == np.float64 and pid.flags["C_CONTIGUOUS"]
         self.L.mjo_hwsim_write(C.byref(self.desc), self.ptr, len(arrs[0]), *[a.ctypes.data_as(pi) for a in arrs],
                                *[a.ctypes.data_as(pdd) for a in dbl], pid.ctypes.data_as(pdd), int(estop))
+
+    def hwsim_control_callback(self, cfg, cmd_pos, cmd_vel, cmd_eff, cmd_hold, pid, estop, cad, control_period):
+        """MujocoRosControlPlugin::controlCallback around writeSim on this env (controller-update cadence, readSim sampling, write
+        period); cad ([2 + 2 n] float64: last update / last write [ns], joint_position_, joint_velocity_) and pid are updated in
+        place.  Returns True when writeSim ran."""
+        pi, pdd = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        arrs = [np.ascontiguousarray(cfg[k], dtype=np.int32) for k in ("joint", "method", "kind", "antiwindup")]
+        dbl = [np.ascontiguousarray(a, dtype=np.float64) for a in (cfg["gains"], cmd_pos, cmd_vel, cmd_eff, cmd_hold)]
+        assert pid.dtype == np.float64 and pid.flags["C_CONTIGUOUS"] and cad.dtype == np.float64 and cad.flags["C_CONTIGUOUS"]
+        return bool(self.L.mjo_hwsim_control_callback(C.byref(self.desc), self.ptr, len(arrs[0]), *[a.ctypes.data_as(pi) for a in arrs],
+                                                      *[a.ctypes.data_as(pdd) for a in dbl], pid.ctypes.data_as(pdd), int(estop),
+                                                      cad.ctypes.data_as(pdd), float(control_period)))
 
     def solve_m(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64).copy()

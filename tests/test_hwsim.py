@@ -121,3 +121,104 @@ def test_gpu_matches_oracle(oracle_built, integrator):
     b.hwsim_configure([])   # switches the stage off
     b.step(5)
     b.close()
+
+
+# ---- controller cadence around writeSim: MujocoRosControlPlugin::controlCallback (mujoco_ros_control_plugin.cpp:153-194) ----
+def _cadence_rollout(po, model, cfg, qpos, cp, cv, ce, steps, period, reset_at=None):
+    d = po.OracleData(model)
+    d.qpos[:] = qpos
+    n = len(cfg["joint"])
+    pid, hold = np.zeros((n, 2)), np.zeros(n)
+    cad = np.r_[0.0, 0.0, np.ones(n), np.zeros(n)]
+    wrote, stamps = [], []
+    for k in range(steps):
+        if reset_at is not None and k == reset_at:
+            d.reset()
+            d.qpos[:] = qpos
+        d.call("step1")
+        wrote.append(d.hwsim_control_callback(cfg, cp, cv, ce, hold, pid, False, cad, period))
+        stamps.append((cad[0], cad[1]))
+        d.call("step2")
+    return d, pid, cad, wrote, stamps
+
+
+def test_oracle_cadence_semantics(oracle_built):
+    """The reference's rules, read off mujoco_ros_control_plugin.cpp: nothing at t = 0 (:171-176: sim_period = 0 and the stamp is
+    zero), the first update AND the first write at the first non-zero time, then an update -- readSim -- every control_period of ROS
+    time (integer nanoseconds) and a write at every step with period = time - last write (:190-193); a time that went backwards
+    re-arms both stamps (:160-169)."""
+    model = mjcf.load_asset("franka_like")
+    spec = _cfg(model)
+    cfg = _oracle_cfg(spec)
+    n = len(spec)
+    cp, cv, ce = [a[0] for a in _commands(n, 1, 0)]
+    q0 = np.array(model["qpos0"], dtype=np.float64)
+    dt = model["timestep"][0]
+    d, pid, cad, wrote, stamps = _cadence_rollout(oracle_built, model, cfg, q0, cp, cv, ce, 13, 4 * dt)
+    assert wrote == [False] + [True] * 12
+    ns = round(dt * 1e9)
+    upd = [s[0] for s in stamps]
+    assert upd[:10] == [0, ns, ns, ns, ns, 5 * ns, 5 * ns, 5 * ns, 5 * ns, 9 * ns]      # first at t = dt, then every 4 dt
+    assert [s[1] for s in stamps] == [0] + [k * ns for k in range(1, 13)]               # a write per step, stamped with its time
+    da = lambda k: model["jnt_dofadr"][spec[k]["joint"]]
+    qa = lambda k: model["jnt_qposadr"][spec[k]["joint"]]
+    # at t = 0 the EFFORT joint was not written (the round-2 stage without a period writes it at once) ...
+    d1, *_ = _cadence_rollout(oracle_built, model, cfg, q0, cp, cv, ce, 1, 4 * dt)
+    assert d1.qfrc_applied[da(3)] == 0
+    d2, *_ = _cadence_rollout(oracle_built, model, cfg, q0, cp, cv, ce, 2, 4 * dt)
+    assert d2.qfrc_applied[da(3)] == ce[3]
+    # ... and between updates the PID works on the joint state of the LAST update: joint_position_ stays while qpos moves
+    jp = cad[2:2 + n]
+    assert abs(jp[0] - d.qpos[qa(0)]) > 1e-9          # sampled at 9 dt, the state is at 13 dt
+    _, _, cad1, *_ = _cadence_rollout(oracle_built, model, cfg, q0, cp, cv, ce, 10, 4 * dt)
+    assert np.array_equal(jp, cad1[2:2 + n])          # == what readSim saw at the update of the step that started at t = 9 dt
+    # period == timestep: an update at every step after the first -- the PID sees the step's own state, as the stage without a
+    # period does, one step late to start
+    _, _, cad2, wrote2, stamps2 = _cadence_rollout(oracle_built, model, cfg, q0, cp, cv, ce, 6, dt)
+    assert [s[0] for s in stamps2] == [0] + [k * ns for k in range(1, 6)]
+    # reset: time back to 0 -> stamps re-armed, nothing written on the reset step, first write one step later again
+    _, _, _, wrote3, stamps3 = _cadence_rollout(oracle_built, model, cfg, q0, cp, cv, ce, 10, 4 * dt, reset_at=6)
+    assert wrote3 == [False] + [True] * 5 + [False] + [True] * 3 and stamps3[6] == (0, 0) and stamps3[7] == (ns, ns)
+
+
+@pytest.mark.gpu
+def test_gpu_cadence_matches_oracle(oracle_built):
+    from mujoco_ros_pkgs_amd import engine
+    model = mjcf.load_asset("franka_like")
+    spec = _cfg(model)
+    cfg = _oracle_cfg(spec)
+    nenv, n = 8, len(spec)
+    cp, cv, ce = _commands(n, nenv, 2)
+    qpos = np.tile(np.asarray(model["qpos0"], dtype=np.float64), (nenv, 1))
+    dt = model["timestep"][0]
+    cm = engine.CompiledModel(model)
+    b = engine.Batch(cm, nenv)
+    b.hwsim_configure(spec)
+    with pytest.raises(Exception):
+        b.hwsim_set_period(0.5 * dt)     # below the timestep: refused, as the reference's plugin refuses to load
+    b.hwsim_set_period(4 * dt)
+    b.hwsim_set_command("position", cp)
+    b.hwsim_set_command("velocity", cv)
+    b.hwsim_set_command("effort", ce)
+    b.set("qpos", qpos)
+    b.step(1)
+    da3 = model["jnt_dofadr"][spec[3]["joint"]]
+    assert np.all(b.get("qfrc_applied")[:, da3] == 0)      # nothing written at t = 0
+    b.step(60)          # fused: updates at steps 1, 5, 9, ... inside the launch
+    b.step(1)
+    b.step(38)
+    for e in (0, 3, nenv - 1):
+        d, pid, cad, wrote, _ = _cadence_rollout(oracle_built, model, cfg, qpos[e], cp[e], cv[e], ce[e], 100, 4 * dt)
+        np.testing.assert_allclose(b.get("qpos")[e], d.qpos, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(b.get("qvel")[e], d.qvel, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(b.get("qfrc_applied")[e], d.qfrc_applied, rtol=0, atol=1e-6)
+    # a reset re-arms the stamps (time went backwards: nothing is written on the reset step); the PID integrals and the sampled joint
+    # state stay, as DefaultRobotHWSim's members do
+    b.reset()
+    b.set("qpos", qpos)
+    b.step(30)
+    d, *_ = _cadence_rollout(oracle_built, model, cfg, qpos[1], cp[1], cv[1], ce[1], 130, 4 * dt, reset_at=100)
+    np.testing.assert_allclose(b.get("qpos")[1], d.qpos, rtol=0, atol=1e-8)
+    b.hwsim_set_period(0)   # back to a write at every step on the step's own state
+    b.step(3)
+    b.close()
