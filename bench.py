@@ -268,21 +268,178 @@ def main():
     ap.add_argument("--nconmax", type=int, default=0, help="override the model's contact capacity")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the configs 3 / 5 lines a default single-GPU run appends")
+    ap.add_argument("--dist-timeout", type=float, default=180.0, help="seconds a collective may wait for a missing rank before the run fails with an error line")
+    ap.add_argument("--dry-ranks", type=int, default=0, help="CI: run the N-rank control flow (rendezvous, overlapped exchange, fence, max-over-ranks "
+                    "timing, the rank-0 line) under gloo with a stub batch and thread streams -- no GPU, the value means nothing")
+    ap.add_argument("--dry-fail-rank", type=int, default=-1, help="(with --dry-ranks) this rank raises inside the timed region: exercises the error line")
     args = ap.parse_args()
+    if args.dry_ranks:
+        args.gpus = args.dry_ranks
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
     name = args.model or CONFIG_MODEL[args.config or 2]
 
     # ---- one process per GPU: spawn the ranks ourselves when nobody did (bare `python bench.py --gpus N`)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # (also --dry-ranks N)
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd, env=env))
 
+    if args.dry_ranks:
+        sys.exit(guarded(dry_run, args))
+    sys.exit(guarded(gpu_run, args, name))
+
+
+def emit_line(fd, obj):
+    os.write(fd, (json.dumps(obj) + "\n").encode())
+
+
+def guarded(fn, *a):
+    """Run one rank's body; whatever goes wrong -- this rank's own exception, a collective that timed out on a rank that never
+    arrived, the launcher's SIGTERM after another rank died -- ends in ONE JSON line with an "error" key on the real stdout of the
+    job's speaker, rank 0 (a failing rank > 0 leaves its message in a note rank 0 quotes), and a non-zero exit code, never in a hang
+    inside dist.barrier()."""
+    import signal
+    rank = int(os.environ.get("RANK", "0"))
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)  # (RCCL / gloo print banners through C stdio: everything but the line goes to stderr)
+    state = {"done": False}
+
+    note = os.path.join(os.environ.get("TMPDIR", "/tmp"), "mjb_bench_error_%s.txt" % os.environ.get("MASTER_PORT", "0"))  # a failing rank > 0 leaves its message here
+    if rank == 0 and os.path.exists(note):
+        os.remove(note)
+
+    def peer_note():
+        try:
+            time.sleep(0.3)
+            return open(note).read()[:2000]
+        except OSError:
+            return ""
+
+    def on_term(signum, frame):
+        if not state["done"] and rank == 0:
+            emit_line(real_stdout, {"error": ("terminated by the launcher (signal %d): another rank failed or the job was cancelled. " % signum) + peer_note(), "rank": rank})
+        os._exit(1)
+    signal.signal(signal.SIGTERM, on_term)
+    try:
+        rc = fn(args_with_stdout(a[0], real_stdout), *a[1:])
+        state["done"] = True
+        return rc or 0
+    except SystemExit as e:
+        state["done"] = True
+        return e.code
+    except BaseException as exc:  # noqa: BLE001 -- the contract is a line, not a traceback alone
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        collective = type(exc).__name__ in ("DistBackendError", "DistNetworkError", "DistStoreError") or "imeout" in str(exc) or "Connection closed by peer" in str(exc)
+        if rank == 0:
+            emit_line(real_stdout, {"error": (f"{type(exc).__name__}: {exc} " + (peer_note() if collective else ""))[:2000], "rank": rank,
+                                    "n_gpus": int(os.environ.get("WORLD_SIZE", "1"))})
+        elif not collective:  # (rank 0 speaks for the job: it reads this when its collective fails or the launcher stops it)
+            try:
+                with open(note, "w") as fh:
+                    fh.write(f"rank {rank}: {type(exc).__name__}: {exc}")
+            except OSError:
+                pass
+        state["done"] = True
+        os._exit(1)   # (not sys.exit: a process group half torn down can hang in its destructor)
+
+
+def args_with_stdout(args, fd):
+    args.real_stdout = fd
+    return args
+
+
+def timed_region(args, one_step, fence, dist, world, make_tensor):
+    """The contract's timing: W untimed steps, fence, exactly K steps, fence; the MAX over ranks is the job's time, and every rank's
+    own time is gathered so that a weak-scaling loss can be attributed (straggler vs exchange)."""
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step()
+    fence()
+    mine = time.perf_counter() - t0
+    elapsed, per_rank = mine, [mine]
+    if world > 1:
+        t = make_tensor([mine])
+        gathered = [make_tensor([0.0]) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank = [float(g.item()) for g in gathered]
+        tmax = make_tensor([mine])
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    return elapsed, per_rank
+
+
+def dry_run(args):
+    """--dry-ranks N: every line of the N-rank control flow that does not need a GPU -- rendezvous with a timeout, shard ranges, the
+    real OverlappedExchange (thread streams), barrier + synchronise fences, all-gather of the per-rank times, MAX over ranks, the
+    rank-0 line -- with a stub batch whose "launch" writes rank- and launch-dependent sensordata."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    from mujoco_ros_pkgs_amd import sharding
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29512")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=args.dist_timeout))
+    E, S, nsd = 64, args.substeps or 10, 8
+    env_lo, _ = sharding.shard_range(rank, world, E)
+    rt = sharding.ThreadStreams()
+    sens = torch.zeros(E, nsd, dtype=torch.float64)
+    met = torch.zeros(16, dtype=torch.float64)
+    xch = sharding.OverlappedExchange(sens, met, None, torch.device("cpu"), force=True, streams=rt)
+    launches = {"n": 0}
+
+    def launch():
+        launches["n"] += 1
+        k = launches["n"]
+        time.sleep(0.002)
+        sens.copy_(torch.full((E, nsd), float(1000 * k + rank)))
+        met[0] = float(E * S * k)   # env_steps so far (SUM over ranks)
+        met[8] = float(rank)        # a MAX entry
+
+    def one_step():
+        if rank == args.dry_fail_rank and launches["n"] >= args.warmup:
+            raise RuntimeError(f"dry run: injected failure on rank {rank}")
+        rt.enqueue(rt.eng, launch)
+        xch.issue()
+
+    def fence():
+        dist.barrier()
+        rt.synchronize(rt.eng)
+        rt.synchronize(rt.side)
+
+    elapsed, per_rank = timed_region(args, one_step, fence, dist, world, lambda v: torch.tensor(v, dtype=torch.float64))
+    sens_all, m = xch.finish()
+    total = args.warmup + args.steps
+    ok = all(bool((sens_all[r * E:(r + 1) * E] == float(1000 * total + r)).all()) for r in range(world))
+    ok = ok and float(m[0]) == float(world * E * S * total) and float(m[8]) == float(world - 1)
+    if rank == 0:
+        emit_line(args.real_stdout, {
+            "metric": "env_steps_per_sec", "value": world * E * S * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "DRY RUN: stub batch, gloo, thread streams -- no GPU, the value means nothing",
+            "dry_ranks": world, "exchange_ok": ok, "rank_ms_per_step": {"min": 1e3 * min(per_rank) / args.steps, "max": 1e3 * max(per_rank) / args.steps},
+            "exchange_ms": xch.last_ms(), "config": {"workload": "dry run", "rccl_ranks": 0, "gloo_ranks": world, "shard": [env_lo, env_lo + E]}})
+    dist.barrier()
+    rt.close()
+    dist.destroy_process_group()
+    return 0 if ok else 4
+
+
+def gpu_run(args, name):
+    import datetime
     import torch
     import torch.distributed as dist
 
+    real_stdout = args.real_stdout
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -302,14 +459,14 @@ def main():
     # anything Python prints), so everything written to fd 1 from here on goes to stderr and the line is written to the
     # saved descriptor.
     sys.stdout.flush()
-    real_stdout = os.dup(1)
     os.dup2(2, 1)
     if world > 1 or force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        # (a rank that never arrives fails the collectives of the others after --dist-timeout instead of hanging them: guarded())
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=args.dist_timeout))
 
     from mujoco_ros_pkgs_amd import binding, engine, mjcf, sharding
 
@@ -346,18 +503,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed, per_rank = timed_region(args, one_step, fence, dist, world, lambda v: torch.tensor(v, dtype=torch.float64, device=dev))
     sens_all, met = xch.finish()
     met = met.cpu().numpy()
     metrics = dict(zip(binding.METRIC_NAMES, (float(x) for x in met)))
@@ -385,6 +531,10 @@ def main():
                        "parallelism": f"env-sharded x{world}, RCCL all-gather of sensordata + 16-double metrics all-reduce per launch, "
                                       "side stream (overlaps the next launch)" if world > 1 else "single GPU",
                        "rccl_ranks": world if xch.active else 0, "state_finite": finite, "auto_resets": resets},
+            # (attribution of a weak-scaling loss: the slowest and the fastest rank's own time per step, and the duration of the last
+            #  exchange -- staging wait + all-gather + two all-reduces -- measured with an event pair on the side stream)
+            "rank_ms_per_step": {"min": 1e3 * min(per_rank) / args.steps, "max": 1e3 * max(per_rank) / args.steps},
+            "exchange_ms": xch.last_ms(),
             "metrics": metrics,
             "roofline": roofline_block(name, cfgno, solver_tag, E, S, samples),
         }
@@ -401,7 +551,7 @@ def main():
                     out["other_configs"][str(c)] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(name, model, noise_std)
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        emit_line(real_stdout, out)
     if xch.active:
         if force_gather and rank == 0:
             host = torch.from_numpy(batch.get("sensordata")).to(dev)
@@ -413,6 +563,7 @@ def main():
             print(f"forced single-rank gather: sensordata round trip {'ok' if ok else 'MISMATCH'}", file=sys.stderr)
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":

@@ -69,6 +69,15 @@ class DeviceStreams:
     def new_event(self):
         return self.torch.cuda.Event()
 
+    def stamp(self, stream):
+        """A timing mark on `stream` (inside enqueue: the current stream)."""
+        ev = self.torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        return ev
+
+    def between(self, a, b):
+        return float(a.elapsed_time(b))  # ms; both completed (finish() synchronised their stream)
+
     def enqueue(self, stream, fn):
         with self.torch.cuda.stream(stream):
             fn()
@@ -140,6 +149,13 @@ class ThreadStreams:
     def new_event(self):
         return self._Event()
 
+    def stamp(self, stream):
+        import time
+        return time.perf_counter()  # (called from inside the stream's worker)
+
+    def between(self, a, b):
+        return 1e3 * (b - a)
+
     def enqueue(self, stream, fn):
         stream.q.put(fn)
 
@@ -206,13 +222,26 @@ class OverlappedExchange:
             dist.all_reduce(self.metrics[:8], op=dist.ReduceOp.SUM)
             dist.all_reduce(self.metrics[8:], op=dist.ReduceOp.MAX)
 
+    def _timed_collect(self):
+        a = self.rt.stamp(self.side)
+        self._collect()
+        self._marks = (a, self.rt.stamp(self.side))
+
+    def last_ms(self):
+        """Duration of the most recent exchange on the side stream (after finish()); None before the first one."""
+        marks = getattr(self, "_marks", None)
+        if marks is None:
+            return None
+        self.rt.synchronize(self.side)
+        return self.rt.between(*marks)
+
     def issue(self):
         rt = self.rt
         rt.wait(self.eng, self.done)  # the previous exchange has finished reading the staging buffers
         rt.enqueue(self.eng, self._stage)
         rt.record(self.staged, self.eng)
         rt.wait(self.side, self.staged)
-        rt.enqueue(self.side, self._collect)
+        rt.enqueue(self.side, self._timed_collect)
         rt.record(self.done, self.side)
         self.issued += 1
 

@@ -56,3 +56,36 @@ def test_forced_single_rank_exchange_line_fields():
     assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1 and line["value"] > 0 and line["scaling"] == "weak"
     assert line["metrics"]["env_steps"] == 4096 * 100 * 4 and line["metrics"]["nenv"] == 4096  # reduced over the (one) rank
     assert "forced single-rank gather: sensordata round trip ok" in p.stderr
+
+
+# ---- the N-rank control flow without GPUs: `--dry-ranks N` = rendezvous with a timeout, shard ranges, the real
+# OverlappedExchange on thread streams, barrier fences, per-rank times gathered + MAX over ranks, the rank-0 line, exit codes ----
+def _run_bench(*argv, timeout=300):
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, lines
+
+
+@pytest.mark.parametrize("ranks", [1, 2, 4])
+def test_dry_ranks_print_one_line_from_rank_zero(ranks):
+    p, lines = _run_bench("--dry-ranks", str(ranks), "--steps", "3", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1 and p.stdout.count("\n") == 1      # ONE line on stdout (gloo's banners went to stderr)
+    line = lines[0]
+    assert line["n_gpus"] == ranks and line["dry_ranks"] == ranks and line["steps"] == 3 and line["warmup"] == 1
+    assert line["exchange_ok"] is True                        # every rank's shard of the LAST launch arrived, metrics SUM / MAX right
+    assert line["scaling"] == "weak" and line["higher_is_better"] is True and "DRY RUN" in line["data"]
+    assert 0 < line["rank_ms_per_step"]["min"] <= line["rank_ms_per_step"]["max"] <= line["ms_per_step"] * 1.0000001
+    assert line["exchange_ms"] is not None and line["exchange_ms"] >= 0
+    assert abs(line["value"] - ranks * 64 * 10 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]   # whole-job aggregate
+
+
+@pytest.mark.parametrize("bad", [0, 1])
+def test_a_failing_rank_ends_in_one_error_line_not_a_hang(bad):
+    p, lines = _run_bench("--dry-ranks", "2", "--steps", "3", "--warmup", "1", "--dry-fail-rank", str(bad), "--dist-timeout", "20", timeout=120)
+    assert p.returncode != 0
+    assert len(lines) == 1 and "error" in lines[0] and lines[0]["rank"] == 0
+    assert f"injected failure on rank {bad}" in lines[0]["error"]
+    assert "value" not in lines[0]
