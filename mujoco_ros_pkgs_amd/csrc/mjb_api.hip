@@ -81,7 +81,9 @@ struct mjb_model {
 	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense, body_anc, dof_bodymask, M_sym;
 	std::vector<int> sens_copy, sens_slow, dof_act_adr, dof_act_id;
 	std::vector<int> pair_i;       // [ncollpair][8]  per candidate pair: g1, g2, type1, type2, condim, friction rule, collision-function override, 0
-	std::vector<double> pair_d;    // [ncollpair][24] size1[3] size2[3] margin gap rbound1 rbound2 solref[2] solimp[5] includemargin friction[3] pad[3]
+	std::vector<double> pair_d;    // [ncollpair][24] size1[3] size2[3] margin gap rbound1 rbound2 solref[2] solimp[5] includemargin friction[3] tran pad[2]
+	std::vector<double> lim_d;     // [njnt + ntendon][24] limit items in pair_d's slots (mjb_dev.h)
+	std::vector<int> lim_i;        // [njnt + ntendon][4]
 	int sens_ncopy[3] = { 0, 0, 0 }, sens_nslow[3] = { 0, 0, 0 }, sens_ncopy_max = 0;
 	int eulerdamp = 0, maxdepth = 0, kin_rounds = 0, need_rnepost = 0, nfriction = 0;
 	int field_size[MJB_F_COUNT]{};
@@ -132,6 +134,10 @@ struct mjb_batch {
 	double *hw_cmd = nullptr;      // pos | vel | eff | hold, [4][nenv][n]
 	double *hw_pid = nullptr;      // [nenv][n][2]
 	double *hw_cad = nullptr;      // [nenv][2 + 2 n] controller cadence (mjb_hwsim_set_period)
+	double *zbuf = nullptr;        // pre-generated ctrl-noise normals of one fused launch (launch())
+	size_t zcap = 0;               // its capacity in doubles
+	unsigned int *zinfo = nullptr;
+	bool zvalid = false;           // zinfo names a launch: cleared (on the stream) before any step launch that does not regenerate the buffer
 };
 
 namespace {
@@ -1003,9 +1009,36 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 			for (int k = 0; k < 5; k++) solimp[k] = mix * h.geom_solimp[5 * g1 + k] + (1 - mix) * h.geom_solimp[5 * g2 + k];
 		}
 		pd[17] = margin - gap;
+		pd[21] = h.body_invweight0[2 * h.geom_bodyid[g1]] + h.body_invweight0[2 * h.geom_bodyid[g2]];
 		for (int k = 0; k < 3; k++) {  // mj_contactParam's friction of the MODEL's geoms (per-env overrides are mixed on the device)
 			const double a = h.geom_friction[3 * g1 + k], b = h.geom_friction[3 * g2 + k];
 			pd[18 + k] = pi[5] == 0 ? std::max(a, b) : (pi[5] == 1 ? a : b);
+		}
+	}
+	{  // limit records (see mjb_dev.h)
+		const int nl = h.njnt + h.ntendon;
+		M->lim_d.assign((size_t)24 * (nl > 0 ? nl : 1), 0.0);
+		M->lim_i.assign((size_t)4 * (nl > 0 ? nl : 1), 0);
+		for (int j = 0; j < h.njnt; j++) {
+			double *r = M->lim_d.data() + 24 * j;
+			int *ri = M->lim_i.data() + 4 * j;
+			ri[0] = (h.jnt_limited[j] && h.jnt_type[j] >= MJB_JNT_SLIDE) ? 1 : 0;
+			ri[1] = h.jnt_qposadr[j];
+			ri[2] = h.jnt_dofadr[j];
+			r[0] = h.jnt_range[2 * j]; r[1] = h.jnt_range[2 * j + 1]; r[6] = h.jnt_margin[j];
+			r[10] = h.jnt_solref[2 * j]; r[11] = h.jnt_solref[2 * j + 1];
+			for (int k = 0; k < 5; k++) r[12 + k] = h.jnt_solimp[5 * j + k];
+			r[21] = h.dof_invweight0[h.jnt_dofadr[j]];
+		}
+		for (int t = 0; t < h.ntendon; t++) {
+			double *r = M->lim_d.data() + 24 * (h.njnt + t);
+			int *ri = M->lim_i.data() + 4 * (h.njnt + t);
+			ri[0] = h.tendon_limited[t] ? 1 : 0;
+			ri[1] = t;
+			r[0] = h.tendon_range[2 * t]; r[1] = h.tendon_range[2 * t + 1]; r[6] = h.tendon_margin[t];
+			r[10] = h.tendon_solref_lim[2 * t]; r[11] = h.tendon_solref_lim[2 * t + 1];
+			for (int k = 0; k < 5; k++) r[12 + k] = h.tendon_solimp_lim[5 * t + k];
+			r[21] = h.tendon_invweight0[t];
 		}
 	}
 	compute_layout(M, M->L, false);
@@ -1110,6 +1143,8 @@ void mjb_free_batch(mjb_batch *b)
 	if (b->hw_cmd) hipFree(b->hw_cmd);
 	if (b->hw_pid) hipFree(b->hw_pid);
 	if (b->hw_cad) hipFree(b->hw_cad);
+	if (b->zbuf) hipFree(b->zbuf);
+	if (b->zinfo) hipFree(b->zinfo);
 	if (b->sens_flag_dev) hipFree(b->sens_flag_dev);
 	if (b->sens_mean_dev) hipFree(b->sens_mean_dev);
 	if (b->sens_sigma_dev) hipFree(b->sens_sigma_dev);
@@ -1148,15 +1183,14 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	b->nenv = nenv;
 	b->L = M->L;
 	const mjb_model_desc &h = M->h;
-
 	// ---- device model blob: [ints | doubles | derived int tables]
 	size_t ni = M->hint.size(), nd = M->hdbl.size();
 	size_t nt = M->M_rowdof.size() + M->M_coldof.size() + M->dof_depth.size() + M->dof_jstart.size() +
 	            M->body_rec.size() + M->body_rec2.size() + M->dof_rec.size() + M->fac_ops.size() + M->fac_beg.size() +
 	            M->body_dofmask.size() + M->body_submask.size() + M->M_dense.size() + M->M_sym.size() + M->body_anc.size() + M->dof_bodymask.size() + M->sens_copy.size() + M->sens_slow.size() + M->dof_act_adr.size() +
-	            M->dof_act_id.size() + M->pair_i.size() + 96;
+	            M->dof_act_id.size() + M->pair_i.size() + M->lim_i.size() + 104;
 	size_t bytes_i = ((ni + nt) * sizeof(int) + 15) & ~size_t(15);
-	size_t bytes = bytes_i + (nd + M->pair_d.size()) * sizeof(double) + 16;
+	size_t bytes = bytes_i + (nd + M->pair_d.size() + M->lim_d.size()) * sizeof(double) + 16;
 	if (hipMalloc(&b->blob, bytes) != hipSuccess) {
 		fail(MJB_ENOMEM, "mjb_make_batch: hipMalloc(model blob) failed");
 		mjb_free_batch(b);
@@ -1177,9 +1211,10 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	size_t o_row = put(M->M_rowdof), o_col = put(M->M_coldof), o_dep = put(M->dof_depth), o_js = put(M->dof_jstart);
 	size_t o_br = put(M->body_rec), o_br2 = put(M->body_rec2), o_dr = put(M->dof_rec), o_fo = put(M->fac_ops),
 	       o_fb = put(M->fac_beg), o_dm = put(M->body_dofmask), o_sm = put(M->body_submask), o_md = put(M->M_dense), o_ms = put(M->M_sym), o_an = put(M->body_anc), o_db = put(M->dof_bodymask), o_sc = put(M->sens_copy), o_ss = put(M->sens_slow),
-	       o_aa = put(M->dof_act_adr), o_ai = put(M->dof_act_id), o_pi = put(M->pair_i);
+	       o_aa = put(M->dof_act_adr), o_ai = put(M->dof_act_id), o_pi = put(M->pair_i), o_li = put(M->lim_i);
 	if (nd) memcpy(hd, M->hdbl.data(), nd * sizeof(double));
 	memcpy(hd + nd, M->pair_d.data(), M->pair_d.size() * sizeof(double));
+	memcpy(hd + nd + M->pair_d.size(), M->lim_d.data(), M->lim_d.size() * sizeof(double));
 	if (hipMemcpy(b->blob, hostblob.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
 		fail(MJB_ENODEVICE, "mjb_make_batch: model upload failed");
 		mjb_free_batch(b);
@@ -1226,6 +1261,8 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	dm.pair_i = (mjb_ciptr)(di + o_pi);
 	b->pair_i_dev = di + o_pi;
 	dm.pair_d = (mjb_cdptr)(dd + nd);
+	dm.lim_d = (mjb_cdptr)(dd + nd + M->pair_d.size());
+	dm.lim_i = (mjb_ciptr)(di + o_li);
 	for (int k = 0; k < 3; k++) {
 		dm.sens_ncopy[k] = M->sens_ncopy[k];
 		dm.sens_nslow[k] = M->sens_nslow[k];
@@ -1423,6 +1460,39 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 			chunk = std::min(chunk, 65535);
 			HIP_TRY(hipMemsetAsync(b->st.sched, 0, ((size_t)b->nenv + 1) * sizeof(int), stream));
 		}
+	}
+	// ctrl noise of a long fused launch: its normals are generated ahead of the step kernel, on the same stream (mjb_noise_kernel),
+	// when they fit the budget (MJB_NOISE_PREGEN_MB, default 1024; 0: always inside the step kernel -- same values either way)
+	bool zfresh = false;
+	if (mode == MJB_MODE_STEP && whole && b->nz.enabled && nsteps >= 16 && b->model->h.nu > 0 && b->model->h.nu <= b->lanes) {
+		static const size_t cap_doubles = [] { const char *v = getenv("MJB_NOISE_PREGEN_MB"); return (size_t)(v ? atol(v) : 1024) * (1u << 20) / sizeof(double); }();
+		const size_t need = (size_t)nsteps * b->nenv * b->model->h.nu;
+		if (need <= cap_doubles) {
+			if (need > b->zcap) {
+				HIP_TRY(hipStreamSynchronize(stream));
+				if (b->zbuf) hipFree(b->zbuf);
+				b->zbuf = dev_alloc<double>(need);
+				b->zcap = b->zbuf ? need : 0;
+				if (!b->zinfo) {
+					b->zinfo = dev_alloc<unsigned int>(4);
+					if (b->zinfo) HIP_TRY(hipMemset(b->zinfo, 0xff, 4 * sizeof(unsigned int)));
+				}
+				b->st.zbuf = b->zbuf;
+				b->st.zinfo = b->zinfo;
+				b->params_dirty = true;
+				prc = sync_params(b);
+				if (prc) return prc;
+			}
+			if (b->zbuf && b->zinfo) {
+				int nrc = mjb_launch_noise(b->params_dev, b->zbuf, b->zinfo, b->nenv, b->model->h.nu, nsteps, b->step_counter, stream);
+				if (nrc != 0) return fail(MJB_ENODEVICE, "noise kernel launch failed: %s", hipGetErrorString((hipError_t)nrc));
+				zfresh = b->zvalid = true;
+			}
+		}
+	}
+	if (!zfresh && b->zvalid) {  // (a launch that generates its normals itself must not match a buffer left by an earlier one)
+		HIP_TRY(hipMemsetAsync(b->zinfo, 0xff, 4 * sizeof(unsigned int), stream));
+		b->zvalid = false;
 	}
 	int rc = mjb_launch_step(b->params_dev, compact ? b->model->Lc : b->L, env_lo, env_hi, mode, nsteps, b->step_counter, b->lanes,
 	                         b->epb, variant | (chunk << 8), (b->lanes == 16 && !b->env_mass && mode != MJB_MODE_STEP21 && b->model->h.integrator == MJB_INT_EULER && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16 && b->model->h.nu <= 16 && b->model->h.njnt <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, stream);

@@ -1029,24 +1029,30 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 	for (int it0 = 0; it0 < nitem; it0 += G) {
 		const int it = it0 + lane;
 		int n = 0;
+		// The lane's item record -- limit (host table lim_d / lim_i) or contact (the pair record its contact came from) -- in ONE batch
+		// of unconditional loads before the kinds diverge: round 3 walked the model tables inside the divergent branches of both
+		// passes (jnt_limited -> jnt_range / margin / solref / solimp -> dof_invweight0;  contact -> geom -> body -> invweight),
+		// a chain of global-memory round trips per kind, one kind after the other: 10 k cycles for config 3's 19 rows.
+		const int it_lim0 = neq + nfr, it_con0 = neq + nfr + m.njnt + nten;
+		const bool is_lim = it >= it_lim0 && it < it_con0, is_con = it >= it_con0 && it < nitem;
+		const int li = is_lim ? it - it_lim0 : 0;
+		const int lean_pair = (is_con && L.contact_solref < 0) ? -2 - fi[L.contact_efc_address + (it - it_con0)] : 0;
+		const mjb_cdptr rec = is_con ? m.pair_d + 24 * (lean_pair >= 0 && lean_pair < m.ncollpair ? lean_pair : 0) : m.lim_d + 24 * li;
+		const double rc0 = rec[0], rc1 = rec[1], rc6 = rec[6], rc21 = rec[21];
+		double rcs[7];
+#pragma unroll
+		for (int k = 0; k < 7; k++) rcs[k] = rec[10 + k];  // solref[2] | solimp[5]
+		const int lim_on = m.lim_i[4 * li], lim_q = m.lim_i[4 * li + 1], lim_d = m.lim_i[4 * li + 2];
 		if (it < nitem && !full) {
 			if (it < neq) {
 				if (f[L.eqparam + 19 * it] != 0) n = m.eq_type[it] == MJB_EQ_CONNECT ? 3 : (m.eq_type[it] == MJB_EQ_WELD ? 6 : 1);  // joint, tendon: 1
 			} else if (it < neq + nfr) {
 				n = (it < neq + nfd ? m.dof_frictionloss[it - neq] : m.tendon_frictionloss[it - neq - nfd]) > 0 ? 1 : 0;
-			} else if (it < neq + nfr + m.njnt) {
-				const int j = it - neq - nfr;
-				if (do_lim && m.jnt_limited[j] && m.jnt_type[j] >= MJB_JNT_SLIDE) {
-					const double value = f[L.qpos + m.jnt_qposadr[j]], margin = m.jnt_margin[j];
-					if (value - m.jnt_range[2 * j] < margin) n++;
-					if (m.jnt_range[2 * j + 1] - value < margin) n++;
-				}
 			} else if (it < neq + nfr + m.njnt + nten) {
-				const int t = it - neq - nfr - m.njnt;
-				if (m.tendon_limited[t]) {
-					const double value = f[L.ten_length + t], margin = m.tendon_margin[t];
-					if (value - m.tendon_range[2 * t] < margin) n++;
-					if (m.tendon_range[2 * t + 1] - value < margin) n++;
+				if (do_lim && lim_on) {  // (a limited slide / hinge joint, or a limited tendon)
+					const double value = it < neq + nfr + m.njnt ? f[L.qpos + lim_q] : f[L.ten_length + lim_q], margin = rc6;
+					if (value - rc0 < margin) n++;
+					if (rc1 - value < margin) n++;
 				}
 			} else if (do_con) {
 				const int c = it - neq - nfr - m.njnt - nten;
@@ -1167,22 +1173,20 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 			const bool isj = it < neq + nfr + m.njnt;
 			const int j = isj ? it - neq - nfr : it - neq - nfr - m.njnt;
 			idv = j;
-			const double value = isj ? f[L.qpos + m.jnt_qposadr[j]] : f[L.ten_length + j];
-			imarg = isj ? m.jnt_margin[j] : m.tendon_margin[j];
-			const mjb_cdptr rng = isj ? m.jnt_range + 2 * j : m.tendon_range + 2 * j;
-			const mjb_cdptr sr = isj ? m.jnt_solref + 2 * j : m.tendon_solref_lim + 2 * j;
-			const mjb_cdptr si = isj ? m.jnt_solimp + 5 * j : m.tendon_solimp_lim + 5 * j;
-			solref[0] = sr[0];
-			solref[1] = sr[1];
-			for (int k = 0; k < 5; k++) solimp[k] = si[k];
-			diag[0] = isj ? MP_DOF_INVW(m, e, m.jnt_dofadr[j]) : MP_TEN_INVW(m, e, j);
+			const double value = isj ? f[L.qpos + lim_q] : f[L.ten_length + j];
+			imarg = rc6;
+			const double rng[2] = { rc0, rc1 };
+			solref[0] = rcs[0];
+			solref[1] = rcs[1];
+			for (int k = 0; k < 5; k++) solimp[k] = rcs[2 + k];
+			diag[0] = e.mp ? (isj ? MP_DOF_INVW(m, e, lim_d) : MP_TEN_INVW(m, e, j)) : rc21;
 			const double dlo = -1 * (rng[0] - value), dhi = 1 * (rng[1] - value);
 			int r = off;
 			for (int side = -1; side <= 1; side += 2) {
 				if ((side < 0 ? dlo : dhi) < imarg) {
 					double *row = jrow(r);
 					for (int k = 0; k < nv; k++) row[k] = 0;
-					if (isj) row[m.jnt_dofadr[j]] = -side;
+					if (isj) row[lim_d] = -side;
 					else
 						for (int w = m.tendon_adr[j]; w < m.tendon_adr[j] + m.tendon_num[j]; w++)
 							row[m.jnt_dofadr[m.wrap_objid[w]]] += -side * m.wrap_prm[w];
@@ -1198,11 +1202,10 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 				solref[0] = f[L.contact_solref + 2 * c];
 				solref[1] = f[L.contact_solref + 2 * c + 1];
 				for (int k = 0; k < 5; k++) solimp[k] = f[L.contact_solimp + 5 * c + k];
-			} else {  // lean frame: the mixed parameters of the pair record this contact came from (collision left -2 - pair)
-				const mjb_cdptr pd = m.pair_d + 24 * (-2 - fi[L.contact_efc_address + c]);
-				solref[0] = pd[10];
-				solref[1] = pd[11];
-				for (int k = 0; k < 5; k++) solimp[k] = pd[12 + k];
+			} else {  // lean frame: the mixed parameters of the pair record this contact came from (collision left -2 - pair), fetched above
+				solref[0] = rcs[0];
+				solref[1] = rcs[1];
+				for (int k = 0; k < 5; k++) solimp[k] = rcs[2 + k];
 			}
 			fi[L.contact_efc_address + c] = off;
 			// ONE impedance evaluation per contact: its rows share solref / solimp, and either all of them sit at
@@ -1235,8 +1238,11 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 			const int c = idv;
 			const int dim = fi[L.contact_dim + c];
 			const double dist = ipos, cm = imarg;
-			const int b1 = m.geom_bodyid[fi[L.contact_geom + 2 * c]], b2 = m.geom_bodyid[fi[L.contact_geom + 2 * c + 1]];
-			const double tran = MP_BODY_INVW(m, e, 2 * b1) + MP_BODY_INVW(m, e, 2 * b2);
+			double tran = rc21;  // (lean frame, the model's masses: the pair record carries the sum)
+			if (e.mp || L.contact_solref >= 0) {
+				const int b1 = m.geom_bodyid[fi[L.contact_geom + 2 * c]], b2 = m.geom_bodyid[fi[L.contact_geom + 2 * c + 1]];
+				tran = MP_BODY_INVW(m, e, 2 * b1) + MP_BODY_INVW(m, e, 2 * b2);
+			}
 			double fri[5];
 			for (int k = 0; k < 5; k++) fri[k] = f[L.contact_friction + 5 * c + k];
 			if (dim == 1) {

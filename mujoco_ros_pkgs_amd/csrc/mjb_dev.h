@@ -41,7 +41,13 @@ struct DevModel {
 	mjb_ciptr dof_act_adr;   // [nv+1] CSR: actuators (joint transmission) driving each dof
 	mjb_ciptr dof_act_id;    // [nu]
 	mjb_ciptr pair_i;        // [ncollpair][8]  candidate-pair records: g1, g2, type1, type2, condim, friction rule (0 max, 1 geom1, 2 geom2), collision-function override (MJB_COLFUNC_*), 0
-	mjb_cdptr pair_d;        // [ncollpair][24] size1[3] size2[3] margin gap rbound1 rbound2 solref[2] solimp[5] includemargin pad
+	mjb_cdptr pair_d;        // [ncollpair][24] size1[3] size2[3] margin gap rbound1 rbound2 solref[2] solimp[5] includemargin friction[3] tran pad[2]
+	                         //   ([21] tran = body_invweight0[2 b1] + body_invweight0[2 b2] of the two geoms' bodies: the contact rows' diagApprox)
+	// limit items (joints, then tendons) of make_constraint as records in pair_d's slots -- a lane fetches ITS item's record, contact or
+	// limit, with one batch of unconditional loads before the kinds diverge: [0..1] range, [6] margin, [10..11] solref, [12..16] solimp,
+	// [21] dof_invweight0 / tendon_invweight0;  lim_i [4]: limited (and slide / hinge), qpos address (tendon: its id), dof address, pad
+	mjb_cdptr lim_d;         // [njnt + ntendon][24]
+	mjb_ciptr lim_i;         // [njnt + ntendon][4]
 	int sens_ncopy[3];       // plain-copy elements per stage
 	int sens_nslow[3];       // complex sensors per stage
 	int sens_ncopy_max;
@@ -128,6 +134,9 @@ struct DevState {
 	double *efc_Jg;                  // [nenv][mjb_rowblock_doubles] row data of the env-steps whose rows outnumber the fused frame's share (kernel variant 4, RowBlock); NULL otherwise
 	double *pgs_B;                   // [nenv][nefcmax * nv] rows of J M^-1 of the PGS steps beyond 64 rows (nv <= 16 models keep them out of LDS); NULL otherwise
 	int use_xfrc;                  // xfrc_applied has ever been written
+	const double *zbuf;            // [nsteps][nenv][nu] standard normals of the ctrl-noise injector for ONE fused launch, pre-generated by
+	                               // mjb_noise_kernel on the same stream (NULL: generated inside the step kernel)
+	const unsigned int *zinfo;     // { step0, nsteps, nenv } the generator wrote zbuf for: a launch uses the buffer only when they are its own
 	int keep_frame;                // fused mjb_step also dumps the last step's full frame to frame_ws
 	int prof_base;                 // profiling build: first of the two probe ids this launch records (mjb_debug_profile_window)
 };
@@ -209,6 +218,7 @@ enum { MJB_MODE_STEP = 0, MJB_MODE_FORWARD = 1, MJB_MODE_STEP1 = 2, MJB_MODE_STE
 
 // launches (implemented in mjb_step.hip); returns hipError_t as int
 // (steps envs [env_lo, nenv): the whole batch, or a prefix / the rest for the split steps of the host runtime)
+int mjb_launch_noise(const KernelParams *Pdev, double *zbuf, unsigned int *zinfo, int nenv, int nu, int nsteps, unsigned int step0, void *stream);
 int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int env_lo, int nenv, int mode, int nsteps, unsigned int step0,
                     int lanes_per_env, int envs_per_block, int constrained, int dense, void *stream);
 int mjb_launch_reset(const KernelParams *Pdev, int nenv, const unsigned char *mask_dev, void *stream);

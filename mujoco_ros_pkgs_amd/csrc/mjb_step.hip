@@ -35,11 +35,30 @@ typedef const NoiseCfg MJB_AS4 &CNoise;
 #define STAGE static __device__ __forceinline__
 #endif
 
+// (MJB_GSYNC_LOCAL -- the slice of the kernels without constraint rows, whose lanes exchange data through the LDS frame only: the
+//  fences name the LDS address space.  A plain wavefront-scope release fence makes the compiler wait for EVERY outstanding memory
+//  operation, vmcnt(0) included: each stage boundary then also waited for global loads nobody needs yet -- the model-table reads of
+//  the next stage, the next step's ctrl-noise value fetched a step ahead.  The constrained kernels keep the full fence: rows beyond
+//  the frame's share travel between lanes through HBM there.)
+#if !defined(MJB_GSYNC_LOCAL) && defined(MJB_GROUP)
+#if MJB_GROUP == 0 && !defined(MJB_DEV_ONLY_CON)
+#define MJB_GSYNC_LOCAL 1
+#endif
+#endif
+#ifndef MJB_GSYNC_LOCAL
+#define MJB_GSYNC_LOCAL 0
+#endif
 template <int G> DEVI void gsync()
 {
+#if MJB_GSYNC_LOCAL
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+#else
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 }
 
 // (the `asm volatile("")` inside wave-uniform branches keeps them real scalar branches: without it the compiler
@@ -2615,14 +2634,27 @@ template <int G> __device__ __attribute__((noinline)) void hwsim_write(CModel m,
 	gsync<G>();
 }
 
+// (zpre: the lane's normal of this step was fetched from the launch's pre-generated buffer a step ago -- mjb_noise_kernel, same
+//  function, same key: the ~2 k cycles of Philox + Box-Muller leave the step's dependent chain)
 template <int G> STAGE void ctrl_noise(CModel m, CLayout L, CNoise nz, const Env &e,
-                                      unsigned int step)
+                                      unsigned int step, bool zpre = false, double zval = 0)
 {
-	for (int i = e.lane; i < m.nu; i += G) {
-		const double z = philox_normal(nz.seed, (unsigned long long)(nz.env_offset + e.env), step, (unsigned int)i);
-		const double v = nz.rate * e.f[L.ctrlnoise + i] + nz.scale * z;
-		e.f[L.ctrlnoise + i] = v;
-		e.f[L.ctrl + i] = v;
+	if (zpre) {  // (a real branch: as a select the compiler evaluates the generator speculatively)
+		MJB_KEEP_BRANCH();
+		if (e.lane < m.nu) {
+			const int i = e.lane;
+			const double v = nz.rate * e.f[L.ctrlnoise + i] + nz.scale * zval;
+			e.f[L.ctrlnoise + i] = v;
+			e.f[L.ctrl + i] = v;
+		}
+	} else {
+		MJB_KEEP_BRANCH();
+		for (int i = e.lane; i < m.nu; i += G) {
+			const double z = philox_normal(nz.seed, (unsigned long long)(nz.env_offset + e.env), step, (unsigned int)i);
+			const double v = nz.rate * e.f[L.ctrlnoise + i] + nz.scale * z;
+			e.f[L.ctrlnoise + i] = v;
+			e.f[L.ctrl + i] = v;
+		}
 	}
 	gsync<G>();
 }
@@ -2872,6 +2904,11 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 		const int nst = mode == MJB_MODE_STEP ? (dyn ? (nsteps - st0 < chunk ? nsteps - st0 : chunk) : nsteps) : ((DENSE == 0 && CON != 9 && mode == MJB_MODE_STEP21) ? 2 : 1);
 		// (an RK4 step cut at its callback points: this launch starts at evaluation rk0 -- whose first half the previous launch ran --
 		//  and stops after ONE rk4_stage, with the next evaluation's first half done)
+		// ctrl noise from the launch's pre-generated buffer (one value per lane: nu <= G), first value fetched here
+		const bool zpre = mode == MJB_MODE_STEP && nz.enabled && s.zbuf != nullptr && m.nu <= G && s.zinfo[0] == step0 &&
+		                  (int)s.zinfo[1] >= nsteps && (int)s.zinfo[2] == s.nenv;
+		double znext = 0;
+		if (zpre && e.lane < m.nu) znext = s.zbuf[((size_t)st0 * s.nenv + e.env) * m.nu + e.lane];
 		const bool rksplit = DENSE == 0 && CON != 9 && (mode == MJB_MODE_RKMID || mode == MJB_MODE_RKLAST);
 		const int rk0 = rksplit ? nsteps : 0;
 #pragma nounroll
@@ -2887,7 +2924,11 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 			const bool do_euler = combo ? st == 0 : (mode == MJB_MODE_STEP || mode == MJB_MODE_STEP2 || rkmode);
 			const bool hw_on = do_rest && checks && P->hw.n > 0;  // device-side DefaultRobotHWSim stage registered
 			PROF_BEGIN();
-			if (do_first && checks && nz.enabled) ctrl_noise<G>(m, L, nz, e, step0 + (unsigned int)(st0 + st));
+			if (do_first && checks && nz.enabled) {
+				ctrl_noise<G>(m, L, nz, e, step0 + (unsigned int)(st0 + st), zpre, znext);
+				if (zpre && st + 1 < nst && e.lane < m.nu)  // next step's normal: a whole step of work hides the trip to HBM
+					znext = s.zbuf[((size_t)(st0 + st + 1) * s.nenv + e.env) * m.nu + e.lane];
+			}
 			PROF(13);
 			// attempt 1 only runs after mj_checkAcc found a bad qacc: reset, full forward, integrate
 			bool rk4 = false;  // (the dense kernels integrate by Euler only: the host picks the generic ones for RK4)
@@ -3133,6 +3174,40 @@ int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int env_lo, 
 	if (constrained == 9) return mjb_launch_group5(Pdev, L, env_lo, nenv, mode, nsteps, step0, envs_per_block, constrained, stream, chunk);
 	return mjb_launch_group1(Pdev, L, env_lo, nenv, mode, nsteps, step0, envs_per_block, constrained, stream, chunk);
 #endif
+}
+
+// The standard normals the ctrl-noise injector (mujoco_env.cpp:469-481) draws during ONE fused launch, generated ahead of it: element
+// (st, env, i) = philox_normal(seed, env_offset + env, step0 + st, i), the very call the step kernel makes when it has no buffer.
+// A throughput kernel (one value per thread, ~600 k wavefronts for config 2's 4096 x 1000 x 9) in place of a 2 k-cycle link in every
+// step's dependent chain.
+__global__ void mjb_noise_kernel(const KernelParams MJB_AS4 *__restrict__ P, double *__restrict__ z, unsigned int *zinfo, const int nenv,
+                                 const int nu, const int nsteps, const unsigned int step0)
+{
+	const NoiseCfg MJB_AS4 &nz = P->nz;
+	const size_t n = (size_t)nsteps * nenv * nu;
+	for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+		const unsigned int i = (unsigned int)(t % nu);
+		const size_t q = t / nu;
+		const int env = (int)(q % nenv);
+		const unsigned int st = (unsigned int)(q / nenv);
+		z[t] = philox_normal(nz.seed, (unsigned long long)(nz.env_offset + env), step0 + st, i);
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		zinfo[0] = step0;
+		zinfo[1] = (unsigned int)nsteps;
+		zinfo[2] = (unsigned int)nenv;
+	}
+}
+
+int mjb_launch_noise(const KernelParams *Pdev, double *zbuf, unsigned int *zinfo, int nenv, int nu, int nsteps, unsigned int step0, void *stream)
+{
+	const size_t n = (size_t)nsteps * nenv * nu;
+	const int threads = 256;
+	size_t blocks = (n + threads - 1) / threads;
+	if (blocks > 256 * 64) blocks = 256 * 64;
+	hipLaunchKernelGGL(mjb_noise_kernel, dim3((unsigned int)blocks), dim3(threads), 0, (hipStream_t)stream, (const KernelParams MJB_AS4 *)Pdev, zbuf, zinfo,
+	                   nenv, nu, nsteps, step0);
+	return (int)hipGetLastError();
 }
 
 int mjb_launch_reset(const KernelParams *Pdev, int nenv, const unsigned char *mask_dev, void *stream)
