@@ -2576,12 +2576,27 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 	auto dots = [&](const double *x, double sub, double &mx, double *out) {
 		if (R == 1 && mreg) {
 			MJB_KEEP_BRANCH();
+			// (eight columns to a chunk, a REAL wave-uniform branch per chunk: a chunk inside [0, nv) loads at constant offsets, all
+			//  eight in flight; only the chunk that straddles nv clamps and zeroes.  Written as one `c < nv ? .. : ..` per column the
+			//  compiler turned the uniform conditions into 25 branches around single loads, each waited for on its own: 101 s_waitcnt
+			//  for 45 loads, 4.2 k cycles per call -- five to six calls a step on config 5)
 			double xz[32];
+			static_for<4>([&](auto cc) {
+				constexpr int c0 = 8 * decltype(cc)::value;
+				if (c0 + 8 <= nv) {
+					MJB_KEEP_BRANCH();
 #pragma unroll
-			for (int c = 0; c < 32; c++) {
-				const double v = x[c < nv ? c : 0];
-				xz[c] = c < nv ? v : 0.0;
-			}
+					for (int q = 0; q < 8; q++) xz[c0 + q] = x[c0 + q];
+				} else {
+					MJB_KEEP_BRANCH();
+#pragma unroll
+					for (int q = 0; q < 8; q++) {
+						const int cl = c0 + q < nv ? c0 + q : nv - 1;
+						const double v = x[cl];
+						xz[c0 + q] = c0 + q < nv ? v : 0.0;
+					}
+				}
+			});
 			double t = 0;
 #pragma unroll
 			for (int c = 0; c < 32; c++) t += Mrow[c] * xz[c];
@@ -2592,8 +2607,24 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 				if (64 * i >= nefc) continue;  // wave-uniform: no row of this slot exists
 				const double *Jr = Jb + rr[i] * nv;
 				double s = -sub * aref[i];
+				static_for<4>([&](auto cc) {
+					constexpr int c0 = 8 * decltype(cc)::value;
+					if (c0 + 8 <= nv) {
+						MJB_KEEP_BRANCH();
+						double j8[8];
 #pragma unroll
-				for (int c = 0; c < 32; c++) s += Jr[c < nv ? c : 0] * xz[c];
+						for (int q = 0; q < 8; q++) j8[q] = Jr[c0 + q];
+#pragma unroll
+						for (int q = 0; q < 8; q++) s += j8[q] * xz[c0 + q];
+					} else {
+						MJB_KEEP_BRANCH();
+						double j8[8];
+#pragma unroll
+						for (int q = 0; q < 8; q++) j8[q] = Jr[c0 + q < nv ? c0 + q : nv - 1];
+#pragma unroll
+						for (int q = 0; q < 8; q++) s += j8[q] * xz[c0 + q];  // (xz is zero beyond nv: the clamped entries drop out exactly)
+					}
+				});
 				out[i] = s;
 			}
 		} else {
@@ -2762,12 +2793,22 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 #pragma nounroll
 			for (int i0 = 0; i0 < nefc; i0 += 8) {
 				double jv8[8], fv8[8];
+				if (i0 + 8 <= nefc) {  // (a real branch per block: see dots)
+					MJB_KEEP_BRANCH();
 #pragma unroll
-				for (int q = 0; q < 8; q++) {
-					const int ii = i0 + q < nefc ? i0 + q : 0;
-					jv8[q] = Jb[ii * nv + k];
-					const double fv = forcep[ii];
-					fv8[q] = i0 + q < nefc ? fv : 0.0;
+					for (int q = 0; q < 8; q++) {
+						jv8[q] = Jb[(i0 + q) * nv + k];
+						fv8[q] = forcep[i0 + q];
+					}
+				} else {
+					MJB_KEEP_BRANCH();
+#pragma unroll
+					for (int q = 0; q < 8; q++) {
+						const int ii = i0 + q < nefc ? i0 + q : 0;
+						jv8[q] = Jb[ii * nv + k];
+						const double fv = forcep[ii];
+						fv8[q] = i0 + q < nefc ? fv : 0.0;
+					}
 				}
 #pragma unroll
 				for (int q = 0; q < 8; q++) s += jv8[q] * fv8[q];
