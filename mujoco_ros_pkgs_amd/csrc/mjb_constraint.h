@@ -1536,6 +1536,10 @@ template <int G, int TAG> STAGE void reference_constraint(CModel m, CLayout L, C
 	gsync<G>();
 }
 
+DEVI double wave_bcast_c(double v, int srclane)
+{
+	return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), srclane), __builtin_amdgcn_readlane(__double2loint(v), srclane));
+}
 // wave-wide sum (G == 64: the env owns the whole wavefront)
 DEVI double wave_sum(double v)
 {
@@ -1546,6 +1550,32 @@ DEVI double wave_sum(double v)
 		t += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * r),
 		                      __builtin_amdgcn_readlane(__double2loint(v), 16 * r));
 	return t;
+}
+// three wave-wide sums side by side: the butterfly steps of the three values are pinned level by level (left to itself the scheduler
+// runs the three reductions one after the other, each a chain of dpp moves and dependent adds: ~250 cycles apiece in the line search's
+// trial points)
+DEVI void wave_sum3(double &a, double &b, double &c)
+{
+#define MJB_DPP3(ctrl)                            \
+	MJB_DPP_STEP(a, ctrl);                        \
+	MJB_DPP_STEP(b, ctrl);                        \
+	MJB_DPP_STEP(c, ctrl);                        \
+	asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+	MJB_DPP3(0xB1);
+	MJB_DPP3(0x4E);
+	MJB_DPP3(0x141);
+	MJB_DPP3(0x140);
+#undef MJB_DPP3
+	double ta = 0, tb = 0, tc = 0;
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		ta += wave_bcast_c(a, 16 * r);
+		tb += wave_bcast_c(b, 16 * r);
+		tc += wave_bcast_c(c, 16 * r);
+	}
+	a = ta;
+	b = tb;
+	c = tc;
 }
 DEVI double wave_bcast(double v, int srclane)  // srclane must be wave-uniform
 {
@@ -2750,7 +2780,10 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 		sync();
 		const double ck0 = cone_update(false, jar_s);
 		const double ck1 = cone_update(false, jv_s);
-		const double cost0 = wave_sum(gk0) + wave_sum(ck0), cost1 = wave_sum(gk1) + wave_sum(ck1);
+		double sg0 = gk0, sc0 = ck0, sg1 = gk1, sc1 = ck1, sz = 0;
+		wave_sum3(sg0, sc0, sg1);
+		wave_sum3(sc1, sz, sz);
+		const double cost0 = sg0 + sc0, cost1 = sg1 + sc1;
 		const double best = (m.disableflags & MJB_DSBL_WARMSTART) ? 1e300 : cost0;
 		const bool smooth = cost1 < best;  // (wave-uniform)
 		ma = smooth ? t1 : t0;
@@ -2779,9 +2812,10 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 #if defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_LS)
 		EPROF(21);
 #endif
-		const double gauss = wave_sum(gk);
+		double gauss = gk, csum = ck, cz = 0;
+		wave_sum3(gauss, csum, cz);
 		prev_cost = cost;
-		cost = gauss + wave_sum(ck);
+		cost = gauss + csum;
 		sync();
 #if defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_LS)
 		EPROF(22);
@@ -2931,14 +2965,21 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 				//  LDS reads later, and the results are read 18+ wait states after the last MFMA (mfma_drain))
 				mjb_d4 t00 = mjb_d4{ 0, 0, 0, 0 }, t10 = mjb_d4{ 0, 0, 0, 0 }, t11 = mjb_d4{ 0, 0, 0, 0 };
 				asm volatile("" : "+a"(t00), "+a"(t10), "+a"(t11));
-				double a0, a1, b0, b1, a0n, a1n, b0n, b1n;
-				fetch(0, a0, a1, b0, b1);
-				for (int r0 = 0; r0 < nefc; r0 += 4) {
-					fetch(r0 + 4, a0n, a1n, b0n, b1n);  // (past the last slab: all zero)
-					asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %3, %5, %0\n\tv_mfma_f64_16x16x4_f64 %1, %4, %5, %1\n\tv_mfma_f64_16x16x4_f64 %2, %4, %6, %2"
-					             : "+a"(t00), "+a"(t10), "+a"(t11)
-					             : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
-					a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
+				// (two slabs per trip: a slab's operands are the end of a chain -- row metadata, addresses, a dozen LDS reads, the
+				//  weighted sums -- that the three MFMAs of the previous slab (96 cycles) do not cover; two independent chains side
+				//  by side do what one-deep prefetching did not: config 5, 8.2 k -> see profiles/r04 per build)
+#ifndef MJB_H_SLABS
+#define MJB_H_SLABS 2  // slabs per trip (MI355X, config 5: 1 -> 6.47 M, 2 -> 6.54 M env-steps/s)
+#endif
+				for (int r0 = 0; r0 < nefc; r0 += 4 * MJB_H_SLABS) {
+					double av0[MJB_H_SLABS], av1[MJB_H_SLABS], bv0[MJB_H_SLABS], bv1[MJB_H_SLABS];
+#pragma unroll
+					for (int u = 0; u < MJB_H_SLABS; u++) fetch(r0 + 4 * u, av0[u], av1[u], bv0[u], bv1[u]);  // (past the last slab: all zero)
+#pragma unroll
+					for (int u = 0; u < MJB_H_SLABS; u++)
+						asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %3, %5, %0\n\tv_mfma_f64_16x16x4_f64 %1, %4, %5, %1\n\tv_mfma_f64_16x16x4_f64 %2, %4, %6, %2"
+						             : "+a"(t00), "+a"(t10), "+a"(t11)
+						             : "v"(av0[u]), "v"(av1[u]), "v"(bv0[u]), "v"(bv1[u]));
 				}
 				asm volatile("s_nop 15\n\ts_nop 7" : "+a"(t00), "+a"(t10), "+a"(t11));  // (mfma_drain: XDL write -> VALU read)
 #pragma unroll
@@ -3097,7 +3138,9 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 		EPROF(28);
 		const double sk = dofact ? -x : 0.0;
 		cg_sold = sk;
-		const double snorm = sqrt(wave_sum(sk * sk));
+		double ss = sk * sk, g1 = dofact ? sk * (ma - f[L.qfrc_smooth + k]) : 0.0, gz = 0;  // (|search|^2 and the line search's linear Gauss term side by side)
+		wave_sum3(ss, g1, gz);
+		const double snorm = sqrt(ss);
 		if (snorm < MJB_MINVAL) break;
 		if (dofact) srch[k] = sk;
 		sync();
@@ -3147,7 +3190,6 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 			}
 		}
 		const double g0 = gauss;
-		const double g1 = wave_sum(dofact ? sk * (ma - f[L.qfrc_smooth + k]) : 0.0);
 		const double g2 = wave_sum(dofact ? 0.5 * sk * mv : 0.0);
 		const double gtol = tol * 0.01 * snorm / scale;  // mjOption.ls_tolerance = 0.01
 #ifdef MJB_PROFILE_LS
@@ -3170,7 +3212,8 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 					ls_row(a, scalar_row[i], bilat[i], leader[i], jaref[i], jv[i], D[i], fl[i], c, c0, c1, c2);
 				}
 			}
-			const double s0 = wave_sum(c0), s1 = wave_sum(c1), s2 = wave_sum(c2);
+			double s0 = c0, s1 = c1, s2 = c2;
+			wave_sum3(s0, s1, s2);
 			p.cost = a * a * g2 + a * g1 + g0 + s0;
 			p.d0 = 2 * a * g2 + g1 + s1;
 			p.d1 = 2 * g2 + s2;
