@@ -2401,16 +2401,25 @@ typedef double mjb_d4 __attribute__((ext_vector_type(4)));
 //  iteration the 32 + 96 lane masks of the factorisation and the two substitutions were hoisted out of it, spilled -- SGPR pairs
 //  in lanes of a VGPR that was itself parked in an AGPR -- and fetched back at every use: s_or_saveexec, v_accvgpr_read, two
 //  v_readlane, s_nop, where three VALU instructions rebuild the mask)
+// 1 / sqrt(x) for a positive NORMAL x (the pivots are clamped to mjMINVAL): the hardware seed and the refinement of the library's
+// rsqrt, term for term -- same bits -- without its select on the operand's class (zero / infinity / NaN), three dependent
+// instructions on a chain the factorisation walks 32 times
+DEVI double rsqrt_pos(double x)
+{
+	const double y0 = __builtin_amdgcn_rsq(x);
+	const double e = fma(y0 * -x, y0, 1.0);
+	return fma(y0 * e, fma(e, 0.375, 0.5), y0);
+}
 template <int J0> DEVI void chol_cols16(double (&Hr)[32], const int nv, const LaneId lid, double &myrinv)
 {
+	const int lane = lid;  // (once per block of columns)
 #pragma unroll
 	for (int j = J0; j < J0 + 16; j++) {
-		const int lane = lid;
 		// (no guards on nv anywhere in the nest: rows / columns >= nv are zero, so their steps are no-ops, and one straight-line
 		//  block lets the scheduler run a column's rsqrt chain under the previous column's trailing update -- config 5: +7 %)
 		double sj = wave_bcast(Hr[j], j);
 		if (sj < MJB_MINVAL) sj = MJB_MINVAL;
-		const double rinv = rsqrt(sj);
+		const double rinv = rsqrt_pos(sj);
 		const double lkj = (lane == j) ? sj * rinv : Hr[j] * rinv;
 		Hr[j] = lkj;
 		if (lane == j) myrinv = rinv;
@@ -3064,10 +3073,10 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 			}
 			// search = -H^-1 grad : lane k holds element k
 			// (elements >= nv are zero: no guards inside the halves, see chol_cols16)
+			const int ln = e.lane;  // (fresh per substitution, not per Newton solve: see chol_cols16)
 #pragma unroll
 			for (int i = 0; i < 16; i++) {
 				const double xi = wave_bcast(x * myrinv, i);
-				const int ln = e.lane;  // (fresh per step: see chol_cols16)
 				if (ln == i) x = xi;
 				else x -= ((ln < nv && ln > i) ? Hr[i] : 0.0) * xi;
 			}
@@ -3076,7 +3085,6 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 #pragma unroll
 				for (int i = 16; i < 32; i++) {
 					const double xi = wave_bcast(x * myrinv, i);
-					const int ln = e.lane;
 					if (ln == i) x = xi;
 					else x -= ((ln < nv && ln > i) ? Hr[i] : 0.0) * xi;
 				}
@@ -3111,9 +3119,10 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 			// the dependent chain is (mul, readlane pair, fma) per row; elements >= nv are zero, no guards
 			MJB_KEEP_BRANCH();
 			double colk[32];
+			const int lb = e.lane;  // (fresh per substitution)
 #pragma unroll
 			for (int i = 1; i < 32; i++) {
-				const int ln = e.lane;  // (fresh per load: see chol_cols16)
+				const int ln = lb;
 				const bool has = ln < i && i < nv;
 				const double v = H[has ? i * nv + ln : 0];
 				colk[i] = has ? v : 0.0;
@@ -3122,7 +3131,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 			for (int i = 31; i >= 0; i--) {
 				if (i >= 16 && nv <= 16) continue;  // (compile-time half, wave-uniform test)
 				const double xi = wave_bcast(x * myrinv, i);
-				if ((int)e.lane == i) x = xi;
+				if (lb == i) x = xi;
 				else x -= (i > 0 ? colk[i] : 0.0) * xi;
 			}
 		} else {
