@@ -2534,9 +2534,11 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 	double Mrow[32];
 	if (mreg) {
 		MJB_KEEP_BRANCH();
+		int ms[32];
+		msym_row(m, k, ms);
 #pragma unroll
 		for (int c = 0; c < 32; c++) {
-			const int adr = m.M_sym[32 * k + c];
+			const int adr = ms[c];
 			const double v = f[L.qM + (adr >= 0 ? adr : 0)];
 			Mrow[c] = (dofact && adr >= 0) ? v : 0.0;
 		}

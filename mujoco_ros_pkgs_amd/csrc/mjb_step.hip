@@ -1059,6 +1059,19 @@ STAGE void factor_dense16(CModel m, const Env &e, const double *M, double *LD, d
 // column c of M (and of M + h B) in 32 + 32 statically indexed registers, gathered through the host table M_sym; the pivot row
 // travels by v_readlane.  The tree's zeros are skipped four columns at a time on the VALUES (a zero multiplier makes the update
 // a no-op, so skipping it is exact): v_cmp -> wave mask -> scalar tests, no table.
+// row `row` of the host table M_sym (symmetric: row == column) in eight 16-byte loads -- read entry by entry at stride 32 it was 32
+// dependent-latency global loads per lane, twice in the factorisation and once more in the Newton solver's setup
+typedef int mjb_i4 __attribute__((ext_vector_type(4)));
+DEVI void msym_row(CModel m, int row, int (&a)[32])
+{
+	const mjb_i4 MJB_AS4 *p = reinterpret_cast<const mjb_i4 MJB_AS4 *>(m.M_sym + 32 * row);
+#pragma unroll
+	for (int q = 0; q < 8; q++) {
+		const mjb_i4 w = p[q];
+		a[4 * q] = w[0]; a[4 * q + 1] = w[1]; a[4 * q + 2] = w[2]; a[4 * q + 3] = w[3];
+	}
+}
+
 template <int G, bool DUAL>
 DEVI void factor_dense32_impl(CModel m, const Env &e, const double *M, double *LD, double *di, const double *M2, double *LD2,
                               double *di2)
@@ -1067,9 +1080,11 @@ DEVI void factor_dense32_impl(CModel m, const Env &e, const double *M, double *L
 	const int lane = e.lane, nv = m.nv;
 	const int c = lane < 32 ? lane : 0;  // (lanes 32 .. 63 mirror lane 0 and store nothing)
 	double A[32], B[32];
+	int ms[32];
+	msym_row(m, c, ms);
 #pragma unroll
 	for (int i = 0; i < 32; i++) {
-		const int a = m.M_sym[32 * i + c], ac = a >= 0 ? a : 0;
+		const int a = ms[i], ac = a >= 0 ? a : 0;
 		const bool has = a >= 0 && i >= c;
 		const double va = M[ac], vb = DUAL ? M2[ac] : 0.0;
 		A[i] = has ? va : 0.0;
@@ -1088,11 +1103,19 @@ DEVI void factor_dense32_impl(CModel m, const Env &e, const double *M, double *L
 				constexpr int i0 = 4 * decltype(gc)::value;
 				if ((live >> i0) & 0xFu) {
 					MJB_KEEP_BRANCH();
+					// (the group's broadcasts first, then its fma: issued pairwise -- readlane, readlane, fma -- every fma sat behind
+					//  the scalar-write hazard of its own operand, 526 s_nop in the stage)
+					double ba[4], bb[4];
 					static_for<4>([&](auto qc) {
-						constexpr int i = i0 + decltype(qc)::value;
+						constexpr int q = decltype(qc)::value, i = i0 + q;
+						ba[q] = i < k ? group_bcast<64, (i < k ? i : 0)>(A[k]) : 0.0;  // unscaled M(k, i), held by lane i
+						bb[q] = (DUAL && i < k) ? group_bcast<64, (i < k ? i : 0)>(B[k]) : 0.0;
+					});
+					static_for<4>([&](auto qc) {
+						constexpr int q = decltype(qc)::value, i = i0 + q;
 						if constexpr (i < k) {
-							A[i] -= group_bcast<64, i>(A[k]) * lkj;  // unscaled M(k, i), held by lane i
-							if (DUAL) B[i] -= group_bcast<64, i>(B[k]) * lkj2;
+							A[i] -= ba[q] * lkj;
+							if (DUAL) B[i] -= bb[q] * lkj2;
 						}
 					});
 				}
@@ -1108,7 +1131,7 @@ DEVI void factor_dense32_impl(CModel m, const Env &e, const double *M, double *L
 	});
 #pragma unroll
 	for (int i = 0; i < 32; i++) {
-		const int a = m.M_sym[32 * i + c];
+		const int a = ms[i];
 		if (a >= 0 && i >= c && lane < 32) {
 			LD[a] = A[i];
 			if (DUAL) LD2[a] = B[i];
