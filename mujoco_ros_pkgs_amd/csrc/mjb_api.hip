@@ -136,8 +136,13 @@ struct mjb_batch {
 	double *hw_cad = nullptr;      // [nenv][2 + 2 n] controller cadence (mjb_hwsim_set_period)
 	double *zbuf = nullptr;        // pre-generated ctrl-noise normals of one fused launch (launch())
 	size_t zcap = 0;               // its capacity in doubles
-	unsigned int *zinfo = nullptr;
-	bool zvalid = false;           // zinfo names a launch: cleared (on the stream) before any step launch that does not regenerate the buffer
+	unsigned int *zinfo = nullptr; // two records (one per half of zbuf)
+	bool zvalid = false;           // a record names a launch: cleared (on the stream) before any step launch that does not use the buffer
+	hipStream_t noise_stream = nullptr;  // the NEXT launch's normals are generated here while the current launch runs
+	hipEvent_t ev_noise = nullptr, ev_noise_go = nullptr;
+	bool spec_valid = false;       // half `spec_half` holds (or will, once ev_noise fires) the normals of launch (spec_step0, spec_nsteps)
+	int spec_half = 0, spec_nsteps = 0;
+	unsigned int spec_step0 = 0;
 };
 
 namespace {
@@ -1143,6 +1148,12 @@ void mjb_free_batch(mjb_batch *b)
 	if (b->hw_cmd) hipFree(b->hw_cmd);
 	if (b->hw_pid) hipFree(b->hw_pid);
 	if (b->hw_cad) hipFree(b->hw_cad);
+	if (b->noise_stream) {
+		hipStreamSynchronize(b->noise_stream);
+		hipStreamDestroy(b->noise_stream);
+		hipEventDestroy(b->ev_noise);
+		hipEventDestroy(b->ev_noise_go);
+	}
 	if (b->zbuf) hipFree(b->zbuf);
 	if (b->zinfo) hipFree(b->zinfo);
 	if (b->sens_flag_dev) hipFree(b->sens_flag_dev);
@@ -1389,6 +1400,7 @@ static int sync_params(mjb_batch *b)
 		//  through scalar loads -- use_compact, use_xfrc, the layouts: an upload between mjb_step_rest and the second half, e.g. the
 		//  first pushViews that carries a non-zero xfrc_applied, must not overtake it)
 		if (b->rest_pending && b->rest_stream) HIP_TRY(hipStreamSynchronize(b->rest_stream));
+		if (b->spec_valid && b->noise_stream) HIP_TRY(hipStreamSynchronize(b->noise_stream));  // (the side-stream noise generator reads nz)
 		HIP_TRY(hipMemcpy(b->params_dev, &kp, sizeof kp, hipMemcpyHostToDevice));
 		b->params_dirty = false;
 	}
@@ -1463,40 +1475,77 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 	}
 	// ctrl noise of a long fused launch: its normals are generated ahead of the step kernel, on the same stream (mjb_noise_kernel),
 	// when they fit the budget (MJB_NOISE_PREGEN_MB, default 1024; 0: always inside the step kernel -- same values either way)
-	bool zfresh = false;
+	// ctrl noise of a long fused launch: its normals are generated by a throughput kernel (mjb_noise_kernel) instead of inside every
+	// step's dependent chain, when they fit the budget (MJB_NOISE_PREGEN_MB per half, default 1024; 0: always inside the step kernel --
+	// same values either way).  The buffer has two halves: this launch reads one while the other is filled, on a side stream, for the
+	// launch expected next (same length, the step counter this one ends at); a launch that finds its normals ready only waits for
+	// that event, anything else generates them on its own stream first.
+	bool zuse = false;
+	int zhalf_now = 0;
 	if (mode == MJB_MODE_STEP && whole && b->nz.enabled && nsteps >= 16 && b->model->h.nu > 0 && b->model->h.nu <= b->lanes) {
 		static const size_t cap_doubles = [] { const char *v = getenv("MJB_NOISE_PREGEN_MB"); return (size_t)(v ? atol(v) : 1024) * (1u << 20) / sizeof(double); }();
 		const size_t need = (size_t)nsteps * b->nenv * b->model->h.nu;
 		if (need <= cap_doubles) {
 			if (need > b->zcap) {
 				HIP_TRY(hipStreamSynchronize(stream));
+				if (b->noise_stream) HIP_TRY(hipStreamSynchronize(b->noise_stream));
 				if (b->zbuf) hipFree(b->zbuf);
-				b->zbuf = dev_alloc<double>(need);
+				b->zbuf = dev_alloc<double>(2 * need);
 				b->zcap = b->zbuf ? need : 0;
-				if (!b->zinfo) {
-					b->zinfo = dev_alloc<unsigned int>(4);
-					if (b->zinfo) HIP_TRY(hipMemset(b->zinfo, 0xff, 4 * sizeof(unsigned int)));
+				if (!b->zinfo) b->zinfo = dev_alloc<unsigned int>(8);
+				if (b->zinfo) HIP_TRY(hipMemset(b->zinfo, 0xff, 8 * sizeof(unsigned int)));
+				if (!b->noise_stream) {
+					HIP_TRY(hipStreamCreateWithFlags(&b->noise_stream, hipStreamNonBlocking));
+					HIP_TRY(hipEventCreateWithFlags(&b->ev_noise, hipEventDisableTiming));
+					HIP_TRY(hipEventCreateWithFlags(&b->ev_noise_go, hipEventDisableTiming));
 				}
+				b->spec_valid = false;
 				b->st.zbuf = b->zbuf;
 				b->st.zinfo = b->zinfo;
+				b->st.zhalf = (unsigned long long)b->zcap;
 				b->params_dirty = true;
 				prc = sync_params(b);
 				if (prc) return prc;
 			}
 			if (b->zbuf && b->zinfo) {
-				int nrc = mjb_launch_noise(b->params_dev, b->zbuf, b->zinfo, b->nenv, b->model->h.nu, nsteps, b->step_counter, stream);
-				if (nrc != 0) return fail(MJB_ENODEVICE, "noise kernel launch failed: %s", hipGetErrorString((hipError_t)nrc));
-				zfresh = b->zvalid = true;
+				if (b->spec_valid && b->spec_step0 == b->step_counter && b->spec_nsteps == nsteps) {
+					zhalf_now = b->spec_half;
+					HIP_TRY(hipStreamWaitEvent(stream, b->ev_noise, 0));  // generated while the previous launch ran
+				} else {
+					if (b->spec_valid) HIP_TRY(hipStreamWaitEvent(stream, b->ev_noise, 0));  // (a generator still writing its half: let it finish first)
+					zhalf_now = 0;
+					HIP_TRY(hipMemsetAsync(b->zinfo + 4, 0xff, 4 * sizeof(unsigned int), stream));
+					int nrc = mjb_launch_noise(b->params_dev, b->zbuf, b->zinfo, b->nenv, b->model->h.nu, nsteps, b->step_counter, stream);
+					if (nrc != 0) return fail(MJB_ENODEVICE, "noise kernel launch failed: %s", hipGetErrorString((hipError_t)nrc));
+				}
+				b->spec_valid = false;
+				zuse = b->zvalid = true;
 			}
 		}
 	}
-	if (!zfresh && b->zvalid) {  // (a launch that generates its normals itself must not match a buffer left by an earlier one)
-		HIP_TRY(hipMemsetAsync(b->zinfo, 0xff, 4 * sizeof(unsigned int), stream));
+	if (!zuse && b->zvalid) {  // (a launch that generates its normals itself must not match a record left by an earlier one)
+		if (b->spec_valid) HIP_TRY(hipStreamWaitEvent(stream, b->ev_noise, 0));
+		b->spec_valid = false;
+		HIP_TRY(hipMemsetAsync(b->zinfo, 0xff, 8 * sizeof(unsigned int), stream));
 		b->zvalid = false;
 	}
+	if (zuse) HIP_TRY(hipEventRecord(b->ev_noise_go, stream));  // (everything before this launch -- the last reader of the other half -- is done)
 	int rc = mjb_launch_step(b->params_dev, compact ? b->model->Lc : b->L, env_lo, env_hi, mode, nsteps, b->step_counter, b->lanes,
 	                         b->epb, variant | (chunk << 8), (b->lanes == 16 && !b->env_mass && mode != MJB_MODE_STEP21 && b->model->h.integrator == MJB_INT_EULER && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16 && b->model->h.nu <= 16 && b->model->h.njnt <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, stream);
 	if (rc != 0) return fail(MJB_ENODEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+	if (zuse) {  // the next launch's normals, into the half this one does not read, beside it
+		const int other = 1 - zhalf_now;
+		HIP_TRY(hipStreamWaitEvent(b->noise_stream, b->ev_noise_go, 0));
+		int nrc = mjb_launch_noise(b->params_dev, b->zbuf + (size_t)other * b->zcap, b->zinfo + 4 * other, b->nenv, b->model->h.nu, nsteps,
+		                           b->step_counter + (unsigned int)nsteps, b->noise_stream);
+		if (nrc == 0) {
+			HIP_TRY(hipEventRecord(b->ev_noise, b->noise_stream));
+			b->spec_valid = true;
+			b->spec_half = other;
+			b->spec_step0 = b->step_counter + (unsigned int)nsteps;
+			b->spec_nsteps = nsteps;
+		}
+	}
 	return MJB_OK;
 }
 
@@ -2067,6 +2116,14 @@ int mjb_set_ctrl_noise(mjb_batch *b, double ctrl_noise_std, double ctrl_noise_ra
 	b->nz.env_offset = env_offset;
 	b->nz.enabled = ctrl_noise_std > 0;
 	b->params_dirty = true;
+	if (b->zinfo) {  // normals generated under the old key (also the ones a side-stream generator is still writing) are void
+		HIP_TRY(hipSetDevice(b->device));
+		if (b->noise_stream) HIP_TRY(hipStreamSynchronize(b->noise_stream));
+		HIP_TRY(hipStreamSynchronize(b->stream));
+		HIP_TRY(hipMemset(b->zinfo, 0xff, 8 * sizeof(unsigned int)));
+		b->spec_valid = false;
+		b->zvalid = false;
+	}
 	return MJB_OK;
 }
 

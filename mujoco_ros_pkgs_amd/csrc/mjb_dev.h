@@ -136,7 +136,9 @@ struct DevState {
 	int use_xfrc;                  // xfrc_applied has ever been written
 	const double *zbuf;            // [nsteps][nenv][nu] standard normals of the ctrl-noise injector for ONE fused launch, pre-generated by
 	                               // mjb_noise_kernel on the same stream (NULL: generated inside the step kernel)
-	const unsigned int *zinfo;     // { step0, nsteps, nenv } the generator wrote zbuf for: a launch uses the buffer only when they are its own
+	const unsigned int *zinfo;     // two records { step0, nsteps, nenv, - }: what the generator wrote each HALF of zbuf for; a launch uses the half
+	                               // whose record is its own (the other half is being filled for the NEXT launch, on a side stream, meanwhile)
+	unsigned long long zhalf;      // doubles per half
 	int keep_frame;                // fused mjb_step also dumps the last step's full frame to frame_ws
 	int prof_base;                 // profiling build: first of the two probe ids this launch records (mjb_debug_profile_window)
 };

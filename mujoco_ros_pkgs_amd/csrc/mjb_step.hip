@@ -2928,10 +2928,15 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 		// (an RK4 step cut at its callback points: this launch starts at evaluation rk0 -- whose first half the previous launch ran --
 		//  and stops after ONE rk4_stage, with the next evaluation's first half done)
 		// ctrl noise from the launch's pre-generated buffer (one value per lane: nu <= G), first value fetched here
-		const bool zpre = mode == MJB_MODE_STEP && nz.enabled && s.zbuf != nullptr && m.nu <= G && s.zinfo[0] == step0 &&
-		                  (int)s.zinfo[1] >= nsteps && (int)s.zinfo[2] == s.nenv;
+		int zhalf_i = -1;
+		if (mode == MJB_MODE_STEP && nz.enabled && s.zbuf != nullptr && m.nu <= G) {
+			if (s.zinfo[0] == step0 && (int)s.zinfo[1] == nsteps && (int)s.zinfo[2] == s.nenv) zhalf_i = 0;
+			else if (s.zinfo[4] == step0 && (int)s.zinfo[5] == nsteps && (int)s.zinfo[6] == s.nenv) zhalf_i = 1;
+		}
+		const bool zpre = zhalf_i >= 0;
+		const double *const zb = s.zbuf + (zhalf_i > 0 ? s.zhalf : 0ull);
 		double znext = 0;
-		if (zpre && e.lane < m.nu) znext = s.zbuf[((size_t)st0 * s.nenv + e.env) * m.nu + e.lane];
+		if (zpre && e.lane < m.nu) znext = zb[((size_t)st0 * s.nenv + e.env) * m.nu + e.lane];
 		const bool rksplit = DENSE == 0 && CON != 9 && (mode == MJB_MODE_RKMID || mode == MJB_MODE_RKLAST);
 		const int rk0 = rksplit ? nsteps : 0;
 #pragma nounroll
@@ -2950,7 +2955,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 			if (do_first && checks && nz.enabled) {
 				ctrl_noise<G>(m, L, nz, e, step0 + (unsigned int)(st0 + st), zpre, znext);
 				if (zpre && st + 1 < nst && e.lane < m.nu)  // next step's normal: a whole step of work hides the trip to HBM
-					znext = s.zbuf[((size_t)(st0 + st + 1) * s.nenv + e.env) * m.nu + e.lane];
+					znext = zb[((size_t)(st0 + st + 1) * s.nenv + e.env) * m.nu + e.lane];
 			}
 			PROF(13);
 			// attempt 1 only runs after mj_checkAcc found a bad qacc: reset, full forward, integrate

@@ -256,3 +256,33 @@ def test_ball_free_joint_fields_match_oracle(pendulum_setup):
     _close(b.get("qpos"), oq, 1e-7, "pendulum world qpos after 50 steps")
     _close(b.get("qvel"), ov, 1e-6, "pendulum world qvel after 50 steps")
     b.close()
+
+
+def test_pregenerated_ctrl_noise_equals_in_kernel_generation(setup):
+    """Long fused launches read their OU normals from a buffer a throughput kernel filled ahead of them (mjb_noise_kernel) -- the
+    launch expected next is even generated on a side stream while the current one runs -- short ones draw them inside the step
+    kernel: same Philox key, same function, so every split of a rollout into launches gives the same bits.  Covers: a speculation
+    hit (two equal launches), a miss (a different length), a key change in between (mjb_set_ctrl_noise voids what was generated)."""
+    model, cm, engine, po = setup
+    nenv = 48
+    qpos, qvel = random_franka_state(model, nenv, seed=11)
+
+    def run(plan):
+        b = engine.Batch(cm, nenv)
+        b.set("qpos", qpos)
+        b.set("qvel", qvel)
+        b.set_ctrl_noise(5.0, 0.1, 12345, 7)
+        for item in plan:
+            if item == "rekey":
+                b.set_ctrl_noise(3.0, 0.2, 999, 7)
+            else:
+                b.step(item)
+        out = b.get("qpos"), b.get("qvel"), b.get("ctrl")
+        b.close()
+        return out
+
+    fused = run([32, 32, 16, 40, "rekey", 32, 32, 5, 32])
+    single = run([1] * 120 + ["rekey"] + [1] * 101)
+    for a, c in zip(fused, single):
+        assert np.array_equal(a, c)
+    assert np.abs(fused[2]).max() > 0
