@@ -2348,47 +2348,45 @@ struct ConeLine {  // per-contact constants of the line search, held by the cont
 };
 
 // one lane's share of the line-search cost and its first two derivatives at step `a`
+// 1 / sqrt(x) for a positive NORMAL x (the pivots are clamped to mjMINVAL): the hardware seed and the refinement of the library's
+// rsqrt, term for term -- same bits -- without its select on the operand's class (zero / infinity / NaN), three dependent
+// instructions on a chain the factorisation walks 32 times
+DEVI double rsqrt_pos(double x)
+{
+	const double y0 = __builtin_amdgcn_rsq(x);
+	const double e = fma(y0 * -x, y0, 1.0);
+	return fma(y0 * e, fma(e, 0.375, 0.5), y0);
+}
+// One row's (scalar rows) or one contact's (cone leaders) share of the line-search cost and its two derivatives at step a.
+// Straight-line: every lane evaluates the scalar form and the cone form and the row's kind picks by selects -- as nested branches the
+// kinds of a wave ran one after the other (scalar rows, then the leaders' chain of a square root and a division, ~1.2 k cycles per
+// trial point); |T| and 1 / |T| come from ONE reciprocal square root (the oracle takes sqrt, then divides: equal to rounding).
 DEVI void ls_row(double a, bool scalar_row, bool bilateral, bool leader, double jaref, double jv, double D, double fl,
                  const ConeLine &cl, double &c0, double &c1, double &c2)
 {
-	if (scalar_row) {
-		const double x = jaref + a * jv;
-		if (fl > 0) {  // dry friction (Huber): quadratic for |x| < R fl, linear with slope -+fl outside
-			const double rf = fl / D;
-			if (x <= -rf) {
-				c0 += fl * (-0.5 * rf - x);
-				c1 -= fl * jv;
-			} else if (x >= rf) {
-				c0 += fl * (-0.5 * rf + x);
-				c1 += fl * jv;
-			} else {
-				c0 += 0.5 * D * x * x;
-				c1 += D * x * jv;
-				c2 += D * jv * jv;
-			}
-		} else if (x < 0 || bilateral) {
-			c0 += 0.5 * D * x * x;
-			c1 += D * x * jv;
-			c2 += D * jv * jv;
-		}
-	} else if (leader) {
-		const double N = cl.N0 + a * cl.N1;
-		const double T2 = cl.TT + a * (2 * cl.UV + a * cl.VV);
-		const double T = sqrt(T2 > 0 ? T2 : 0.0);
-		if (N >= cl.mu * T) {
-			// top zone: nothing
-		} else if (cl.mu * N + T <= 0) {
-			c0 += cl.q0b + a * (cl.q1b + a * cl.q2b);
-			c1 += cl.q1b + 2 * a * cl.q2b;
-			c2 += 2 * cl.q2b;
-		} else {
-			const double NmT = N - cl.mu * T, iT = 1.0 / T, T1 = (cl.UV + a * cl.VV) * iT, T2d = (cl.VV - T1 * T1) * iT;
-			const double s1 = cl.N1 - cl.mu * T1;
-			c0 += 0.5 * cl.Dm * NmT * NmT;
-			c1 += cl.Dm * NmT * s1;
-			c2 += cl.Dm * (s1 * s1 - NmT * cl.mu * T2d);
-		}
-	}
+	// scalar rows: quadratic when active (x < 0, or an equality), Huber for dry friction (quadratic for |x| < R fl, slope -+fl outside)
+	const double x = jaref + a * jv;
+	const bool fric = fl > 0;
+	const double rf = fric ? fl / D : 0.0;
+	const bool quad = scalar_row && (fric ? (x > -rf && x < rf) : (x < 0 || bilateral));
+	const bool lin = scalar_row && fric && !quad;
+	const double Dx = D * x;
+	const double q0 = 0.5 * Dx * x, q1 = Dx * jv, q2 = D * jv * jv;
+	const double l0 = fl * (-0.5 * rf + fabs(x)), l1 = (x < 0 ? -fl : fl) * jv;
+	// elliptic cone of a contact (evaluated by its first row's lane)
+	const double N = cl.N0 + a * cl.N1;
+	const double T2r = cl.TT + a * (2 * cl.UV + a * cl.VV);
+	const bool tpos = T2r > 1e-290;
+	const double iT = tpos ? rsqrt_pos(tpos ? T2r : 1.0) : 0.0, T = tpos ? T2r * iT : 0.0;
+	const bool top = N >= cl.mu * T, bottom = !top && cl.mu * N + T <= 0;
+	const bool mid = leader && !top && !bottom, bot = leader && bottom;
+	const double b0 = cl.q0b + a * (cl.q1b + a * cl.q2b), b1 = cl.q1b + 2 * a * cl.q2b, b2 = 2 * cl.q2b;
+	const double NmT = N - cl.mu * T, T1 = (cl.UV + a * cl.VV) * iT, T2d = (cl.VV - T1 * T1) * iT;
+	const double s1 = cl.N1 - cl.mu * T1, DN = cl.Dm * NmT;
+	const double m0 = 0.5 * DN * NmT, m1 = DN * s1, m2 = cl.Dm * (s1 * s1 - NmT * cl.mu * T2d);
+	c0 += quad ? q0 : (lin ? l0 : (bot ? b0 : (mid ? m0 : 0.0)));
+	c1 += quad ? q1 : (lin ? l1 : (bot ? b1 : (mid ? m1 : 0.0)));
+	c2 += quad ? q2 : (bot ? b2 : (mid ? m2 : 0.0));
 }
 
 typedef double mjb_d4 __attribute__((ext_vector_type(4)));
@@ -2401,15 +2399,6 @@ typedef double mjb_d4 __attribute__((ext_vector_type(4)));
 //  iteration the 32 + 96 lane masks of the factorisation and the two substitutions were hoisted out of it, spilled -- SGPR pairs
 //  in lanes of a VGPR that was itself parked in an AGPR -- and fetched back at every use: s_or_saveexec, v_accvgpr_read, two
 //  v_readlane, s_nop, where three VALU instructions rebuild the mask)
-// 1 / sqrt(x) for a positive NORMAL x (the pivots are clamped to mjMINVAL): the hardware seed and the refinement of the library's
-// rsqrt, term for term -- same bits -- without its select on the operand's class (zero / infinity / NaN), three dependent
-// instructions on a chain the factorisation walks 32 times
-DEVI double rsqrt_pos(double x)
-{
-	const double y0 = __builtin_amdgcn_rsq(x);
-	const double e = fma(y0 * -x, y0, 1.0);
-	return fma(y0 * e, fma(e, 0.375, 0.5), y0);
-}
 template <int J0> DEVI void chol_cols16(double (&Hr)[32], const int nv, const LaneId lid, double &myrinv)
 {
 	const int lane = lid;  // (once per block of columns)
@@ -2573,7 +2562,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 	// row kind: scalar (limit / frictionless / pyramidal), cone leader (first row of an elliptic contact), cone member
 	bool rowact[R], scalar_row[R], leader[R], bilat[R];
 	int rr[R], cdim[R], rcon[R];
-	double D[R], aref[R], cmu[R], fl[R];  // fl: force limit of a dry-friction row, 0 for every other row
+	double D[R], aref[R], cmu[R], cdmi[R], fl[R];  // fl: force limit of a dry-friction row, 0 for every other row
 #pragma unroll
 	for (int i = 0; i < R; i++) {
 		const int r = lane + 64 * i;
@@ -2590,6 +2579,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 		fl[i] = (rowact[i] && m.nfriction > 0) ? flp[r] : 0.0;
 		aref[i] = rowact[i] ? arefp[r] : 0.0;
 		cmu[i] = leader[i] ? f[L.contact_friction + 5 * rcon[i]] / sqrt(fmax(MJB_MINVAL, m.impratio[0])) : 1.0;
+		cdmi[i] = 1.0 / (cmu[i] * cmu[i] * (1 + cmu[i] * cmu[i]));  // Dm = D_0 / (mu^2 (1 + mu^2)): the divisor once per step, not per update
 		// what the Hessian build needs to know about the row, in ONE int (read by whichever lane feeds the row to the matrix
 		// cores): -1 = scalar row (weight hw[r]), else first row of its cone | dim << 8 | contact << 12
 		if (rowact[i]) metap[r] = is_cone ? (fi[L.contact_efc_address + rcon[i]] | (cdim[i] << 8) | (rcon[i] << 12)) : -1;
@@ -2720,11 +2710,15 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 					U[j] = fr[j] * x[j];
 					if (j > 0) TT += U[j] * U[j];
 				}
-				const double N = U[0], T = sqrt(TT);
+				// (|T| and 1 / |T| from one reciprocal square root -- the oracle takes sqrt, then divides: equal to rounding; Dm from the
+				//  per-contact constant the row setup keeps)
+				const bool tpos = TT > 1e-290;
+				const double iTr = tpos ? rsqrt_pos(tpos ? TT : 1.0) : 0.0;
+				const double N = U[0], T = tpos ? TT * iTr : 0.0;
 				const bool top = N >= mu * T, bottom = !top && mu * N + T <= 0, middle = !top && !bottom;
 				// (middle zone => T > 0; the other zones compute it on T = 1 and discard it)
-				const double Ts = middle ? T : 1.0;
-				const double Dm = Dj[0] / (mu * mu * (1 + mu * mu)), NmT = N - mu * T, iT = 1.0 / Ts, iT3 = iT * iT * iT;
+				const double iT = middle ? iTr : 1.0;
+				const double Dm = Dj[0] * cdmi[i], NmT = N - mu * T, iT3 = iT * iT * iT;
 				const double f0 = -Dm * NmT * mu;
 				double g[DMAX];
 				g[0] = mu;
@@ -3177,7 +3171,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 				c.mu = mu;
 				c.N0 = mu * jaref[i];
 				c.N1 = mu * jv[i];
-				c.Dm = D[i] / (mu * mu * (1 + mu * mu));
+				c.Dm = D[i] * cdmi[i];
 				for (int j = 0; j < 6; j++) {
 					if (j >= cdim[i]) break;
 					const double xj = jar_s[rr[i] + j], vj = jv_s[rr[i] + j], Dj = Dp[rr[i] + j];
