@@ -169,8 +169,16 @@ def roofline_block(name, cfgno, solver_tag, E, S, samples):
     from mujoco_ros_pkgs_amd import provenance
     kern_ms = samples[len(samples) // 2]
     traffic, fp64, source = None, None, None
-    pmc, pmc_file = _load_json(f"r03_cfg{cfgno}{solver_tag}_pmc_summary.json")
-    flops, flops_file = _load_json("r03_oracle_flops.json", "r02_oracle_flops.json")
+    # (the newest round's counter summary of this config; one collected on THESE kernel sources wins)
+    import glob
+    cands = sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_cfg{cfgno}{solver_tag}_pmc_summary.json"))), reverse=True)
+    pmc, pmc_file = _load_json(*cands) if cands else (None, None)
+    for n in cands:
+        cand, _ = _load_json(n)
+        if cand is not None and cand.get("csrc_sha") == provenance.csrc_sha():
+            pmc, pmc_file = cand, n
+            break
+    flops, flops_file = _load_json("r04_oracle_flops.json", "r03_oracle_flops.json", "r02_oracle_flops.json")
     if pmc is not None:
         if pmc.get("csrc_sha") != provenance.csrc_sha():
             source = f"STALE: profiles/{pmc_file} was collected on other kernel sources ({pmc.get('csrc_sha')} != {provenance.csrc_sha()}); not reported"
