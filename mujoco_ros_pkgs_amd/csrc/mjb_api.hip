@@ -78,14 +78,15 @@ struct mjb_model {
 	std::vector<int> hint;            // all int arrays, concatenated
 	std::vector<double> hdbl;         // all double arrays, concatenated
 	std::vector<size_t> ioff, doff;   // offsets of each array inside hint / hdbl (declaration order)
-	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense, body_anc, dof_bodymask, M_sym;
+	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense, body_anc, dof_bodymask, M_sym, body_dofanc;
 	std::vector<int> sens_copy, sens_slow, dof_act_adr, dof_act_id;
 	std::vector<int> pair_i;       // [ncollpair][8]  per candidate pair: g1, g2, type1, type2, condim, friction rule, collision-function override, 0
 	std::vector<double> pair_d;    // [ncollpair][24] size1[3] size2[3] margin gap rbound1 rbound2 solref[2] solimp[5] includemargin friction[3] tran pad[2]
+	std::vector<double> sub_S;     // 0/1 subtree matrix as MFMA A operands (mjb_dev.h)
 	std::vector<double> lim_d;     // [njnt + ntendon][24] limit items in pair_d's slots (mjb_dev.h)
 	std::vector<int> lim_i;        // [njnt + ntendon][4]
 	int sens_ncopy[3] = { 0, 0, 0 }, sens_nslow[3] = { 0, 0, 0 }, sens_ncopy_max = 0;
-	int eulerdamp = 0, maxdepth = 0, kin_rounds = 0, need_rnepost = 0, nfriction = 0;
+	int eulerdamp = 0, maxdepth = 0, kin_rounds = 0, need_rnepost = 0, nfriction = 0, sub_nt = 0, dofanc_max = 0;
 	int field_size[MJB_F_COUNT]{};
 	FrameLayout L{}, Lc{};
 };
@@ -950,6 +951,26 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 				M->body_anc[(size_t)r * h.nbody + b] = a ? M->body_anc[(size_t)(r - 1) * h.nbody + a] : 0;
 			}
 	}
+	// ancestor dof lists for the root-to-leaf sums
+	{
+		M->body_dofanc.assign((size_t)4 * h.nbody, -1);
+		bool aok = h.nv <= 255 && h.nv > 0;
+		int amax = 0;
+		for (int b = 1; b < h.nbody && aok; b++) {
+			int n = 0;
+			for (int i = 0; i < h.nv && i < 64; i++)
+				if ((M->body_dofmask[2 * b + (i >> 5)] >> (i & 31)) & 1) {
+					if (n >= 16) { aok = false; break; }
+					unsigned int w = (unsigned int)M->body_dofanc[4 * b + (n >> 2)];
+					w = (w & ~(0xFFu << (8 * (n & 3)))) | ((unsigned int)i << (8 * (n & 3)));
+					M->body_dofanc[4 * b + (n >> 2)] = (int)w;
+					n++;
+				}
+			if (n > amax) amax = n;
+		}
+		if (h.nv > 64) aok = false;
+		M->dofanc_max = aok ? amax : 0;
+	}
 	// subtree membership masks (subtree com, composite inertia)
 	M->body_submask.assign((size_t)2 * h.nbody, 0);
 	for (int b = 0; b < h.nbody && h.nbody <= 64; b++)
@@ -957,6 +978,15 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 			M->body_submask[2 * a + (b >> 5)] |= (int)(1u << (b & 31));
 			if (a == 0) break;
 		}
+	M->sub_nt = h.nbody <= 16 ? 1 : (h.nbody <= 32 ? 2 : 0);
+	M->sub_S.assign((size_t)(M->sub_nt > 0 ? M->sub_nt * 4 * M->sub_nt * 64 : 1), 0.0);
+	for (int t = 0; t < M->sub_nt; t++)
+		for (int k = 0; k < 4 * M->sub_nt; k++)
+			for (int l = 0; l < 64; l++) {
+				const int a = 16 * t + (l & 15), b = 4 * k + (l >> 4);
+				if (a < h.nbody && b < h.nbody && ((M->body_submask[2 * a + (b >> 5)] >> (b & 31)) & 1))
+					M->sub_S[((size_t)t * 4 * M->sub_nt + k) * 64 + l] = 1.0;
+			}
 	M->dof_bodymask.assign((size_t)2 * (h.nv > 0 ? h.nv : 1), 0);
 	for (int b = 1; b < h.nbody; b++)
 		for (int i = 0; i < h.nv; i++)
@@ -1198,10 +1228,10 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	size_t ni = M->hint.size(), nd = M->hdbl.size();
 	size_t nt = M->M_rowdof.size() + M->M_coldof.size() + M->dof_depth.size() + M->dof_jstart.size() +
 	            M->body_rec.size() + M->body_rec2.size() + M->dof_rec.size() + M->fac_ops.size() + M->fac_beg.size() +
-	            M->body_dofmask.size() + M->body_submask.size() + M->M_dense.size() + M->M_sym.size() + M->body_anc.size() + M->dof_bodymask.size() + M->sens_copy.size() + M->sens_slow.size() + M->dof_act_adr.size() +
+	            M->body_dofmask.size() + M->body_submask.size() + M->M_dense.size() + M->M_sym.size() + M->body_anc.size() + M->dof_bodymask.size() + M->body_dofanc.size() + M->sens_copy.size() + M->sens_slow.size() + M->dof_act_adr.size() +
 	            M->dof_act_id.size() + M->pair_i.size() + M->lim_i.size() + 104;
 	size_t bytes_i = ((ni + nt) * sizeof(int) + 15) & ~size_t(15);
-	size_t bytes = bytes_i + (nd + M->pair_d.size() + M->lim_d.size()) * sizeof(double) + 16;
+	size_t bytes = bytes_i + (nd + M->pair_d.size() + M->lim_d.size() + M->sub_S.size()) * sizeof(double) + 16;
 	if (hipMalloc(&b->blob, bytes) != hipSuccess) {
 		fail(MJB_ENOMEM, "mjb_make_batch: hipMalloc(model blob) failed");
 		mjb_free_batch(b);
@@ -1222,10 +1252,11 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	size_t o_row = put(M->M_rowdof), o_col = put(M->M_coldof), o_dep = put(M->dof_depth), o_js = put(M->dof_jstart);
 	size_t o_br = put(M->body_rec), o_br2 = put(M->body_rec2), o_dr = put(M->dof_rec), o_fo = put(M->fac_ops),
 	       o_fb = put(M->fac_beg), o_dm = put(M->body_dofmask), o_sm = put(M->body_submask), o_md = put(M->M_dense), o_ms = put(M->M_sym), o_an = put(M->body_anc), o_db = put(M->dof_bodymask), o_sc = put(M->sens_copy), o_ss = put(M->sens_slow),
-	       o_aa = put(M->dof_act_adr), o_ai = put(M->dof_act_id), o_pi = put(M->pair_i), o_li = put(M->lim_i);
+	       o_aa = put(M->dof_act_adr), o_ai = put(M->dof_act_id), o_pi = put(M->pair_i), o_li = put(M->lim_i), o_da = put(M->body_dofanc);
 	if (nd) memcpy(hd, M->hdbl.data(), nd * sizeof(double));
 	memcpy(hd + nd, M->pair_d.data(), M->pair_d.size() * sizeof(double));
 	memcpy(hd + nd + M->pair_d.size(), M->lim_d.data(), M->lim_d.size() * sizeof(double));
+	memcpy(hd + nd + M->pair_d.size() + M->lim_d.size(), M->sub_S.data(), M->sub_S.size() * sizeof(double));
 	if (hipMemcpy(b->blob, hostblob.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
 		fail(MJB_ENODEVICE, "mjb_make_batch: model upload failed");
 		mjb_free_batch(b);
@@ -1263,6 +1294,8 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	dm.M_sym = (mjb_ciptr)(di + o_ms);
 	dm.body_anc = (mjb_ciptr)(di + o_an);
 	dm.kin_rounds = M->kin_rounds;
+	dm.body_dofanc = (mjb_ciptr)(di + o_da);
+	dm.dofanc_max = M->dofanc_max;
 	dm.dof_bodymask = (mjb_ciptr)(di + o_db);
 	dm.need_rnepost = M->need_rnepost;
 	dm.sens_copy = (mjb_ciptr)(di + o_sc);
@@ -1273,6 +1306,8 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	b->pair_i_dev = di + o_pi;
 	dm.pair_d = (mjb_cdptr)(dd + nd);
 	dm.lim_d = (mjb_cdptr)(dd + nd + M->pair_d.size());
+	dm.sub_S = (mjb_cdptr)(dd + nd + M->pair_d.size() + M->lim_d.size());
+	dm.sub_nt = M->sub_nt;
 	dm.lim_i = (mjb_ciptr)(di + o_li);
 	for (int k = 0; k < 3; k++) {
 		dm.sens_ncopy[k] = M->sens_ncopy[k];

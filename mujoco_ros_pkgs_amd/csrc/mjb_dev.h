@@ -62,6 +62,13 @@ struct DevModel {
 	int need_rnepost;        // an acceleration-stage sensor needs mj_rnePostConstraint (cacc / cfrc_int / cfrc_ext)
 	int kin_rounds;          // ceil(log2(max body depth)): rounds of the pointer-jumping kinematics
 	int maxdepth;          // max dof_depth
+	// leaf-to-root sums of the smooth stages (subtree com, composite inertia, RNE's backward pass) as a product with the 0/1 subtree
+	// matrix: [sub_nt][4 sub_nt][64] doubles, the A operands of v_mfma_f64_16x16x4_f64 (mjb_step.hip, subtree_sum)
+	mjb_cdptr sub_S;
+	int sub_nt;              // row tiles (1: nbody <= 16, 2: nbody <= 32; 0: larger models keep the flat sums)
+	// root-to-leaf sums (cvel, cacc): [nbody][4] = the body's ancestor-or-self dofs, ASCENDING, one byte each (0xFF = none), at most 16
+	mjb_ciptr body_dofanc;
+	int dofanc_max;          // longest list (0: some body has more than 16 -- or nv > 255 --: the mask loops run instead)
 };
 
 // Offsets (in doubles / ints) of every data field inside one per-env frame.

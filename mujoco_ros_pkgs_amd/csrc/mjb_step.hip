@@ -137,6 +137,23 @@ DEVI void prof_rec(int env, int lane, int id, unsigned long long v, unsigned int
 #define EPROF_BEGIN() do { } while (0)
 #define EPROF(id) do { } while (0)
 #endif
+// libmjb_prof_sm.so: slots 20 - 31 = phases of the smooth stages (com_pos, crb, com_vel, rne, acceleration, euler)
+#ifdef MJB_PROFILE_SM
+#undef EPROF_BEGIN
+#undef EPROF
+#define EPROF_BEGIN() do { } while (0)
+#define EPROF(id) do { } while (0)
+#define SPROF_BEGIN() unsigned long long _st0 = __builtin_readcyclecounter()
+#define SPROF(id)                                                                     \
+	do {                                                                              \
+		unsigned long long _st1 = __builtin_readcyclecounter();                       \
+		prof_rec(e.env, e.lane, id, _st1 - _st0);                                     \
+		_st0 = __builtin_readcyclecounter();                                          \
+	} while (0)
+#else
+#define SPROF_BEGIN() do { } while (0)
+#define SPROF(id) do { } while (0)
+#endif
 
 // Integer members of LaneConst re-launder themselves at every read (like LaneId): as plain values they are invariants of the K-step
 // loop, and every predicate computed from them -- `sc_dst >= 0`, `q_row == q_col`, the bits of the ancestor masks: ~90 lane masks --
@@ -374,7 +391,7 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 		}
 	}
 	if constexpr (!REG) gsync<G>();
-#if !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL) && !defined(MJB_PROFILE_MK)  // (slots 20 - 23 carry the sub-stages of the Newton iteration's gradient step / of collision in those builds)
+#if !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL) && !defined(MJB_PROFILE_MK) && !defined(MJB_PROFILE_SM)  // (slots 20 - 23 carry the sub-stages of the Newton iteration's gradient step / of collision in those builds)
 	PROF(20);
 #endif
 
@@ -490,7 +507,7 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 		gsync<G>();
 	}
 
-#if !defined(MJB_PROFILE_SUB) && !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL) && !defined(MJB_PROFILE_MK) && !defined(MJB_PROFILE_MK)  // (slots 21 / 22 carry the PGS sweep / row counts in the sub-stage build)
+#if !defined(MJB_PROFILE_SUB) && !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL) && !defined(MJB_PROFILE_MK) && !defined(MJB_PROFILE_SM)  // (slots 21 / 22 carry the PGS sweep / row counts in the sub-stage build)
 	PROF(21);
 #endif
 	// Phase C -- one body per lane: normalise xquat, final xmat, inertial frame
@@ -530,7 +547,7 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 	}
 	gsync<G>();
 
-#if !defined(MJB_PROFILE_SUB) && !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL) && !defined(MJB_PROFILE_MK) && !defined(MJB_PROFILE_MK)
+#if !defined(MJB_PROFILE_SUB) && !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL) && !defined(MJB_PROFILE_MK) && !defined(MJB_PROFILE_SM)
 	PROF(22);
 #endif
 	// Phase D -- joints (anchor / axis to the world frame through the PARENT body's frame), geoms, sites
@@ -593,7 +610,7 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 		}
 	}
 	gsync<G>();
-#if !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL) && !defined(MJB_PROFILE_MK)
+#if !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL) && !defined(MJB_PROFILE_MK) && !defined(MJB_PROFILE_SM)
 	PROF(23);
 #endif
 }
@@ -604,11 +621,73 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 // bit i of a 64-bit mask stored as two ints (host-built ancestor-dof / subtree-body masks; nv, nbody <= 64)
 DEVI bool maskbit(unsigned int lo, unsigned int hi, int i) { return ((i < 32 ? lo >> i : hi >> (i - 32)) & 1u) != 0; }
 
+// ---- leaf-to-root sums (subtree com, composite inertia, RNE's backward pass) as ONE product with the model's 0/1 subtree matrix on the
+// matrix cores:  out[a][c] = sum_b S[a][b] x[b][c],  S[a][b] = 1 when body b belongs to body a's subtree  (host table sub_S, laid out
+// as the A operands of v_mfma_f64_16x16x4_f64: [row tile][k block][lane] = S[16 t + (l & 15)][4 k + (l >> 4)]; the blocks left of a
+// tile's diagonal are zero -- children carry larger ids -- and are skipped).  In place in buf [nbody][N]: all of x is in registers
+// before the first result is stored.  The serial walks these stages ran before cost a round trip per BODY (crb: 25 dependent
+// read-add-write steps = 7.5 k cycles on the hand model; rne: 24 masked 6-vector reads per lane = 9.1 k); the products of the 0/1
+// entries are exact, the order of the additions is the matrix core's (k ascending) instead of the tree's.
+typedef double mjb_sd4 __attribute__((ext_vector_type(4)));
+template <int N, int NT, bool KEEP0> DEVI void subtree_sum_tiles(CModel m, double *buf, int lane)
+{
+	static_assert(N <= 16, "one column tile");
+	constexpr int KB = 4 * NT;
+	const int li = lane & 15, lk = lane >> 4;
+	const double MJB_AS4 *S = m.sub_S + lane;
+	double A[NT][KB], B[KB];
+#pragma unroll
+	for (int t = 0; t < NT; t++)
+#pragma unroll
+		for (int k = 4 * t; k < KB; k++) A[t][k] = S[(t * KB + k) * 64];
+#pragma unroll
+	for (int k = 0; k < KB; k++) {
+		const int b = 4 * k + lk;
+		const bool on = li < N && b < m.nbody;
+		const double v = buf[on ? N * b + li : 0];
+		B[k] = on ? v : 0.0;
+	}
+	mjb_sd4 acc[NT];
+#pragma unroll
+	for (int t = 0; t < NT; t++) acc[t] = mjb_sd4{ 0, 0, 0, 0 };
+#pragma unroll
+	for (int k = 0; k < KB; k++)
+#pragma unroll
+		for (int t = 0; t < NT; t++)
+			if (k >= 4 * t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t][k], B[k], acc[t], 0, 0, 0);
+#pragma unroll
+	for (int t = 0; t < NT; t++)
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			const int a = 16 * t + lk + 4 * q;
+			if (li < N && a < m.nbody && !(KEEP0 && a == 0)) buf[N * a + li] = acc[t][q];
+		}
+}
+template <int N, bool KEEP0> DEVI void subtree_sum(CModel m, double *buf, int lane)
+{
+	if (m.sub_nt == 1) {
+		MJB_KEEP_BRANCH();
+		subtree_sum_tiles<N, 1, KEEP0>(m, buf, lane);
+	} else {
+		MJB_KEEP_BRANCH();
+		subtree_sum_tiles<N, 2, KEEP0>(m, buf, lane);
+	}
+}
+// the k-th byte of a 16-byte list held in two words, as the loop shifts it down
+DEVI int list_next(unsigned long long &lo, unsigned long long &hi)
+{
+	const int v = (int)(lo & 0xFFull);
+	lo = (lo >> 8) | (hi << 56);
+	hi = (hi >> 8) | (0xFFull << 56);
+	return v;
+}
+
 template <int G, bool OBL> STAGE void com_pos(CModel m, CLayout L, const Env &e)
 {
 	double *f = e.f;
 	double *sc = f + L.subtree_com, *xipos = f + L.xipos;
 	const int lane = e.lane;
+	SPROF_BEGIN();
 	// lane = body: mass-weighted sum over the bodies of its subtree (host-built mask) -- no walk up the tree, every
 	// lane reads the same xipos / mass sequence (LDS broadcast + scalar loads) and keeps what its mask selects
 	if constexpr (OBL && G == 16) {
@@ -639,6 +718,29 @@ template <int G, bool OBL> STAGE void com_pos(CModel m, CLayout L, const Env &e)
 				sc[3 * b] = s0 * inv; sc[3 * b + 1] = s1 * inv; sc[3 * b + 2] = s2 * inv;
 			}
 		}
+	} else if (G == 64 && !OBL && m.sub_nt > 0) {
+		MJB_KEEP_BRANCH();
+		const bool act = lane < m.nbody;
+		const int b = act ? (int)lane : 0;
+		const double mass = MP_BODY_MASS(m, e, b), stm = MP_SUBTREEMASS(m, e, b);
+		double xo[3], r[3];
+		ld3(xo, xipos + 3 * b);
+		if (act) {
+			for (int k = 0; k < 3; k++) r[k] = xo[k] * mass;
+			st3(sc + 3 * b, r);
+		}
+		gsync<G>();
+		subtree_sum<3, false>(m, sc, lane);
+		gsync<G>();
+		ld3(r, sc + 3 * b);
+		if (act) {
+			if (stm < MJB_MINVAL) {
+				st3(sc + 3 * b, xo);
+			} else {
+				const double inv = 1.0 / fmax(MJB_MINVAL, stm);
+				sc[3 * b] = r[0] * inv; sc[3 * b + 1] = r[1] * inv; sc[3 * b + 2] = r[2] * inv;
+			}
+		}
 	} else
 	for (int b = lane; b < m.nbody; b += G) {
 		const unsigned int lo = OBL ? e.lc.smlo : (unsigned int)m.body_submask[2 * b], hi = OBL ? e.lc.smhi : (unsigned int)m.body_submask[2 * b + 1];
@@ -659,6 +761,7 @@ template <int G, bool OBL> STAGE void com_pos(CModel m, CLayout L, const Env &e)
 		}
 	}
 	gsync<G>();
+	SPROF(20);
 	// cinert: one body per lane
 	for (int b = lane; b < m.nbody; b += G) {
 		double r[10];
@@ -724,6 +827,7 @@ template <int G, bool OBL> STAGE void com_pos(CModel m, CLayout L, const Env &e)
 		f[L.ten_length + t] = len;
 	}
 	gsync<G>();
+	SPROF(21);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -734,6 +838,15 @@ template <int G, bool OBL> STAGE void crb(CModel m, CLayout L, const Env &e)
 	double *f = e.f;
 	double *crbv = f + L.crb, *cinert = f + L.cinert, *buf = f + L.crbbuf;
 	const int lane = e.lane;
+	SPROF_BEGIN();
+	if (G == 64 && !OBL && m.sub_nt > 0) {
+		MJB_KEEP_BRANCH();
+		// (nothing is added to the world body: its row stays what it was)
+		for (int k = lane; k < 10 * m.nbody; k += G) crbv[k] = cinert[k];
+		gsync<G>();
+		subtree_sum<10, true>(m, crbv, lane);
+		gsync<G>();
+	} else
 	for (int c = lane; c < 10; c += G) {
 		for (int i = 0; i < m.nbody; i++) crbv[10 * i + c] = cinert[10 * i + c];
 		for (int i = m.nbody - 1; i > 0; i--) {
@@ -741,7 +854,8 @@ template <int G, bool OBL> STAGE void crb(CModel m, CLayout L, const Env &e)
 			if (p > 0) crbv[10 * p + c] += crbv[10 * i + c];
 		}
 	}
-	gsync<G>();
+	if (!(G == 64 && !OBL && m.sub_nt > 0)) gsync<G>();
+	SPROF(22);
 	// buf_i = crb[body(i)] * cdof_i, one dof per lane
 	for (int i = lane; i < m.nv; i += G) {
 		double I[10], v[6], r[6];
@@ -751,6 +865,7 @@ template <int G, bool OBL> STAGE void crb(CModel m, CLayout L, const Env &e)
 		st6(buf + 6 * i, r);
 	}
 	gsync<G>();
+	SPROF(23);
 	// qM entries, one per lane: M(i,j) = cdof_j . buf_i  (+ armature on the diagonal)
 	if (OBL && e.lc.q_row[0] != -2) {  // (the lane's entries -- row / column dof, armature, h * damping -- sit in registers)
 #pragma unroll
@@ -777,6 +892,7 @@ template <int G, bool OBL> STAGE void crb(CModel m, CLayout L, const Env &e)
 		if (m.eulerdamp) f[L.MhB + en] = (i == j) ? v + m.timestep[0] * m.dof_damping[i] : v;
 	}
 	gsync<G>();
+	SPROF(24);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1356,7 +1472,36 @@ template <int G, bool OBL> STAGE void com_vel(CModel m, CLayout L, const Env &e)
 	double *f = e.f;
 	double *cvel = f + L.cvel, *cdof = f + L.cdof, *qvel = f + L.qvel;
 	const int lane = e.lane;
+	SPROF_BEGIN();
 	// lane = body: cvel = sum of cdof_d qvel_d over the dofs that move the body (ancestor mask, root to leaf order)
+	if (!OBL && m.dofanc_max > 0 && m.nbody <= G) {
+		MJB_KEEP_BRANCH();
+		// (the lane's own ancestor list, ascending, four entries a trip: 7 of the hand's 30 dofs move a fingertip -- the masked loop
+		//  over all dofs read 210 LDS values per lane for the 49 that count; same terms in the same order)
+		const bool act = lane < m.nbody;
+		const int b = act ? (int)lane : 0;
+		const mjb_i4 a4 = reinterpret_cast<const mjb_i4 MJB_AS4 *>(m.body_dofanc)[b];
+		unsigned long long alo = ((unsigned long long)(unsigned int)a4[1] << 32) | (unsigned int)a4[0];
+		unsigned long long ahi = ((unsigned long long)(unsigned int)a4[3] << 32) | (unsigned int)a4[2];
+		double v[6] = { 0, 0, 0, 0, 0, 0 };
+#pragma nounroll
+		for (int k0 = 0; k0 < m.dofanc_max; k0 += 4) {
+			int dd[4];
+			double qd[4], cd[4][6];
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				const int d = list_next(alo, ahi);
+				dd[q] = d != 0xFF ? d : 0;
+				qd[q] = qvel[dd[q]];
+				for (int c = 0; c < 6; c++) cd[q][c] = cdof[6 * dd[q] + c];
+				if (d == 0xFF) qd[q] = 0.0;
+			}
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+				for (int c = 0; c < 6; c++) v[c] += cd[q][c] * qd[q];
+		}
+		if (act) st6(cvel + 6 * b, v);
+	} else
 	for (int b = lane; b < m.nbody; b += G) {
 		const unsigned int lo = OBL ? e.lc.dmlo : (unsigned int)m.body_dofmask[2 * b], hi = OBL ? e.lc.dmhi : (unsigned int)m.body_dofmask[2 * b + 1];
 		double v[6] = { 0, 0, 0, 0, 0, 0 };
@@ -1368,6 +1513,7 @@ template <int G, bool OBL> STAGE void com_vel(CModel m, CLayout L, const Env &e)
 		st6(cvel + 6 * b, v);
 	}
 	gsync<G>();
+	SPROF(25);
 	// cdof_dot: one dof per lane
 	for (int d = lane; d < m.nv; d += G) {
 		double r[6];
@@ -1397,6 +1543,7 @@ template <int G, bool OBL> STAGE void com_vel(CModel m, CLayout L, const Env &e)
 		}
 	}
 	gsync<G>();
+	SPROF(26);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1480,16 +1627,40 @@ template <int G, bool OBL> STAGE void rne(CModel m, CLayout L, const Env &e)
 	double *cacc = f + L.cacc, *cfrc = f + L.cfrc_body, *cdd = f + L.cdof_dot, *qvel = f + L.qvel;
 	const int lane = e.lane;
 	const bool grav = !(m.disableflags & MJB_DSBL_GRAVITY);
+	SPROF_BEGIN();
 	// lane = body: cacc = -gravity + sum of cdof_dot_d qvel_d over the dofs that move the body, then the body's own
 	// inertial force  I a + v x* (I v)   (cfrc_body holds the per-body force, not its subtree sum)
 	[[maybe_unused]] double rkeep[6] = { 0, 0, 0, 0, 0, 0 };  // (dense kernels: the lane's own body force stays in registers for phase 2)
+	const bool anc_list = !OBL && m.dofanc_max > 0 && m.nbody <= G;
 	for (int b = lane; b < m.nbody; b += G) {
-		const unsigned int lo = OBL ? e.lc.dmlo : (unsigned int)m.body_dofmask[2 * b], hi = OBL ? e.lc.dmhi : (unsigned int)m.body_dofmask[2 * b + 1];
 		double a[6] = { 0, 0, 0, grav ? -f[L.gravity] : 0.0, grav ? -f[L.gravity + 1] : 0.0, grav ? -f[L.gravity + 2] : 0.0 };
+		if (anc_list) {  // (the body's ancestor dofs from its list, as in com_vel)
+			MJB_KEEP_BRANCH();
+			const mjb_i4 a4 = reinterpret_cast<const mjb_i4 MJB_AS4 *>(m.body_dofanc)[b];
+			unsigned long long alo = ((unsigned long long)(unsigned int)a4[1] << 32) | (unsigned int)a4[0];
+			unsigned long long ahi = ((unsigned long long)(unsigned int)a4[3] << 32) | (unsigned int)a4[2];
+#pragma nounroll
+			for (int k0 = 0; k0 < m.dofanc_max; k0 += 4) {
+				double qd[4], cd[4][6];
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					const int d = list_next(alo, ahi), dc = d != 0xFF ? d : 0;
+					qd[q] = qvel[dc];
+					for (int c = 0; c < 6; c++) cd[q][c] = cdd[6 * dc + c];
+					if (d == 0xFF) qd[q] = 0.0;
+				}
+#pragma unroll
+				for (int q = 0; q < 4; q++)
+					for (int c = 0; c < 6; c++) a[c] += cd[q][c] * qd[q];
+			}
+		} else {
+			MJB_KEEP_BRANCH();
+			const unsigned int lo = OBL ? e.lc.dmlo : (unsigned int)m.body_dofmask[2 * b], hi = OBL ? e.lc.dmhi : (unsigned int)m.body_dofmask[2 * b + 1];
 #pragma unroll 3
-		for (int d = 0; d < m.nv; d++) {
-			const double qd = maskbit(lo, hi, d) ? qvel[d] : 0.0;
-			for (int c = 0; c < 6; c++) a[c] += cdd[6 * d + c] * qd;
+			for (int d = 0; d < m.nv; d++) {
+				const double qd = maskbit(lo, hi, d) ? qvel[d] : 0.0;
+				for (int c = 0; c < 6; c++) a[c] += cdd[6 * d + c] * qd;
+			}
 		}
 		st6(cacc + 6 * b, a);
 		double r[6];
@@ -1535,6 +1706,23 @@ template <int G, bool OBL> STAGE void rne(CModel m, CLayout L, const Env &e)
 		return;
 	}
 	gsync<G>();
+	SPROF(27);
+	if (G == 64 && !OBL && m.sub_nt > 0) {
+		MJB_KEEP_BRANCH();
+		// mj_rne's backward pass (nothing goes to the world body), then qfrc_bias_d = cdof_d . subtree force of dof d's body
+		const int dbody = m.dof_bodyid[lane < m.nv ? (int)lane : 0];
+		subtree_sum<6, true>(m, cfrc, lane);
+		gsync<G>();
+		for (int d = lane; d < m.nv; d += G) {
+			double a[6], acc[6];
+			ld6(acc, cfrc + 6 * (d < G ? dbody : m.dof_bodyid[d]));
+			ld6(a, f + L.cdof + 6 * d);
+			f[L.qfrc_bias + d] = dot6r(a, acc);
+		}
+		gsync<G>();
+		SPROF(28);
+		return;
+	}
 	// lane = dof: qfrc_bias_d = cdof_d . (sum of the forces of the bodies that dof d moves)
 	for (int d = lane; d < m.nv; d += G) {
 		double acc[6] = { 0, 0, 0, 0, 0, 0 };
@@ -1553,6 +1741,7 @@ template <int G, bool OBL> STAGE void rne(CModel m, CLayout L, const Env &e)
 		f[L.qfrc_bias + d] = dot6r(a, acc);
 	}
 	gsync<G>();
+	SPROF(28);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -32,10 +32,11 @@ ap.add_argument("--solver", default="")
 ap.add_argument("--sub", action="store_true", help="libmjb_prof_sub.so: slots 24-29 = collision / make_constraint sub-stages (PGS runs)")
 ap.add_argument("--nwt", action="store_true", help="libmjb_prof_nwt.so: slots 20-23 = parts of the Newton iteration's gradient step, 19 = line-search points")
 ap.add_argument("--ls", action="store_true", help="libmjb_prof_ls.so: slots 20-22 = parts of the Newton line search")
+ap.add_argument("--sm", action="store_true", help="libmjb_prof_sm.so: slots 20-28 = phases of com_pos / crb / com_vel / rne")
 ap.add_argument("--only", default="", help="comma-separated probe ids (default: all)")
 a = ap.parse_args()
 
-tag = "_sub" if a.sub else ("_nwt" if a.nwt else ("_ls" if a.ls else ""))
+tag = "_sub" if a.sub else ("_nwt" if a.nwt else ("_ls" if a.ls else ("_sm" if a.sm else "")))
 binding.LIB_PATH = os.environ.get("MJB_PROF_LIB") or os.path.join(ROOT, "mujoco_ros_pkgs_amd", "csrc", f"libmjb_prof{tag}.so")
 if a.sub:
     STAGES[19] = "pgs.setup (B row, b, warmstart)"
@@ -43,6 +44,9 @@ if a.sub:
     STAGES[30], STAGES[31] = "pgs.AR build", "pgs.warm residual + sweeps"
     STAGES[24:30] = ["col.cull+narrowphase", "col.offsets+params+stores", "mk.count+cut", "mk.row params (pass 2)", "mk.D + equality J",
                      "mk.contact J"]
+if a.sm:
+    STAGES[20:32] = ["com_pos.subtree com", "com_pos.cinert+cdof+tendon", "crb.accumulate", "crb.buf = I cdof", "crb.qM entries",
+                     "com_vel.cvel", "com_vel.cdof_dot+actuator", "rne.cacc+body force", "rne.qfrc_bias", "-", "-", "-"]
 if a.nwt:
     STAGES[19] = "nwt.ls points /iter [count, not cycles]"
     STAGES[20:24] = ["nwt.g dots+park", "nwt.g cone_update", "nwt.g cost sums", "nwt.g J'f + stop test"]
