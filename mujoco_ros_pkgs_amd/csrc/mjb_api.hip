@@ -78,7 +78,7 @@ struct mjb_model {
 	std::vector<int> hint;            // all int arrays, concatenated
 	std::vector<double> hdbl;         // all double arrays, concatenated
 	std::vector<size_t> ioff, doff;   // offsets of each array inside hint / hdbl (declaration order)
-	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense, body_anc, dof_bodymask, M_sym, body_dofanc;
+	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense, body_anc, dof_bodymask, M_sym, body_dofanc, dof_rec2, jnt_rec;
 	std::vector<int> sens_copy, sens_slow, dof_act_adr, dof_act_id;
 	std::vector<int> pair_i;       // [ncollpair][8]  per candidate pair: g1, g2, type1, type2, condim, friction rule, collision-function override, 0
 	std::vector<double> pair_d;    // [ncollpair][24] size1[3] size2[3] margin gap rbound1 rbound2 solref[2] solimp[5] includemargin friction[3] tran pad[2]
@@ -900,6 +900,21 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		int rec[4] = { h.dof_Madr[dd], M->dof_depth[dd] - 1, h.dof_bodyid[dd], h.dof_parentid[dd] };
 		M->dof_rec.insert(M->dof_rec.end(), rec, rec + 4);
 	}
+	// what the per-dof / per-joint phases of com_vel / com_pos look up, one 16-byte record each (the chains of dependent table reads --
+	// dof -> joint -> type, joint -> body -> root -- cost a trip to L2 per link)
+	for (int dd = 0; dd < h.nv; dd++) {
+		const int j = h.dof_jntid[dd], bd = h.dof_bodyid[dd];
+		int rec[4] = { (h.jnt_type[j] == MJB_JNT_FREE && dd - h.jnt_dofadr[j] < 3) ? 1 : 0, M->dof_jstart[dd] == h.body_dofadr[bd] ? 1 : 0,
+			           h.body_parentid[bd], bd };
+		M->dof_rec2.insert(M->dof_rec2.end(), rec, rec + 4);
+	}
+	for (int j = 0; j < h.njnt; j++) {
+		const int bi = h.jnt_bodyid[j];
+		int rec[4] = { bi, h.jnt_type[j], h.jnt_dofadr[j], h.body_rootid[bi] };
+		M->jnt_rec.insert(M->jnt_rec.end(), rec, rec + 4);
+	}
+	if (M->dof_rec2.empty()) M->dof_rec2.assign(4, 0);
+	if (M->jnt_rec.empty()) M->jnt_rec.assign(4, 0);
 	for (int k = 0; k < h.nv; k++) {
 		M->fac_beg.push_back((int)M->fac_ops.size() / 4);
 		const int kk = h.dof_Madr[k], na = M->dof_depth[k] - 1;
@@ -1228,7 +1243,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	size_t ni = M->hint.size(), nd = M->hdbl.size();
 	size_t nt = M->M_rowdof.size() + M->M_coldof.size() + M->dof_depth.size() + M->dof_jstart.size() +
 	            M->body_rec.size() + M->body_rec2.size() + M->dof_rec.size() + M->fac_ops.size() + M->fac_beg.size() +
-	            M->body_dofmask.size() + M->body_submask.size() + M->M_dense.size() + M->M_sym.size() + M->body_anc.size() + M->dof_bodymask.size() + M->body_dofanc.size() + M->sens_copy.size() + M->sens_slow.size() + M->dof_act_adr.size() +
+	            M->body_dofmask.size() + M->body_submask.size() + M->M_dense.size() + M->M_sym.size() + M->body_anc.size() + M->dof_bodymask.size() + M->body_dofanc.size() + M->dof_rec2.size() + M->jnt_rec.size() + M->sens_copy.size() + M->sens_slow.size() + M->dof_act_adr.size() +
 	            M->dof_act_id.size() + M->pair_i.size() + M->lim_i.size() + 104;
 	size_t bytes_i = ((ni + nt) * sizeof(int) + 15) & ~size_t(15);
 	size_t bytes = bytes_i + (nd + M->pair_d.size() + M->lim_d.size() + M->sub_S.size()) * sizeof(double) + 16;
@@ -1252,7 +1267,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	size_t o_row = put(M->M_rowdof), o_col = put(M->M_coldof), o_dep = put(M->dof_depth), o_js = put(M->dof_jstart);
 	size_t o_br = put(M->body_rec), o_br2 = put(M->body_rec2), o_dr = put(M->dof_rec), o_fo = put(M->fac_ops),
 	       o_fb = put(M->fac_beg), o_dm = put(M->body_dofmask), o_sm = put(M->body_submask), o_md = put(M->M_dense), o_ms = put(M->M_sym), o_an = put(M->body_anc), o_db = put(M->dof_bodymask), o_sc = put(M->sens_copy), o_ss = put(M->sens_slow),
-	       o_aa = put(M->dof_act_adr), o_ai = put(M->dof_act_id), o_pi = put(M->pair_i), o_li = put(M->lim_i), o_da = put(M->body_dofanc);
+	       o_aa = put(M->dof_act_adr), o_ai = put(M->dof_act_id), o_pi = put(M->pair_i), o_li = put(M->lim_i), o_da = put(M->body_dofanc), o_dr2 = put(M->dof_rec2), o_jr = put(M->jnt_rec);
 	if (nd) memcpy(hd, M->hdbl.data(), nd * sizeof(double));
 	memcpy(hd + nd, M->pair_d.data(), M->pair_d.size() * sizeof(double));
 	memcpy(hd + nd + M->pair_d.size(), M->lim_d.data(), M->lim_d.size() * sizeof(double));
@@ -1296,6 +1311,8 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	dm.kin_rounds = M->kin_rounds;
 	dm.body_dofanc = (mjb_ciptr)(di + o_da);
 	dm.dofanc_max = M->dofanc_max;
+	dm.dof_rec2 = (mjb_ciptr)(di + o_dr2);
+	dm.jnt_rec = (mjb_ciptr)(di + o_jr);
 	dm.dof_bodymask = (mjb_ciptr)(di + o_db);
 	dm.need_rnepost = M->need_rnepost;
 	dm.sens_copy = (mjb_ciptr)(di + o_sc);

@@ -34,6 +34,8 @@ struct DevModel {
 	mjb_ciptr body_rec;    // [nbody][4] packed {parentid, dofadr, dofnum, rootid}   (one s_load_dwordx4 per body)
 	mjb_ciptr body_rec2;   // [nbody][4] packed {jntadr, jntnum, sameframe, weldid}
 	mjb_ciptr dof_rec;     // [nv][4]    packed {Madr, nancestor, bodyid, parentid}
+	mjb_ciptr dof_rec2;    // [nv][4]    packed {translational dof of a free joint, first joint of its body, parent of its body, bodyid}
+	mjb_ciptr jnt_rec;     // [njnt][4]  packed {bodyid, type, dofadr, rootid of its body}
 	mjb_ciptr fac_ops;     // [nfac][4]  factorisation micro-ops {dst, srcA, srcB, 0}: LD[dst] -= LD[srcA]/LD[kk]*LD[srcB]
 	mjb_ciptr fac_beg;     // [nv+1]     first micro-op of pivot k
 	mjb_ciptr sens_copy;     // [2][3][sens_ncopy_max][2] (layout full/compact, stage-1): {dst offset in sensordata, src frame offset}

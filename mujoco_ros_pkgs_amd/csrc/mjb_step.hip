@@ -629,17 +629,37 @@ DEVI bool maskbit(unsigned int lo, unsigned int hi, int i) { return ((i < 32 ? l
 // read-add-write steps = 7.5 k cycles on the hand model; rne: 24 masked 6-vector reads per lane = 9.1 k); the products of the 0/1
 // entries are exact, the order of the additions is the matrix core's (k ascending) instead of the tree's.
 typedef double mjb_sd4 __attribute__((ext_vector_type(4)));
-template <int N, int NT, bool KEEP0> DEVI void subtree_sum_tiles(CModel m, double *buf, int lane)
+typedef int mjb_i4 __attribute__((ext_vector_type(4)));
+// (the A operands are fetched by the CALLER ahead of the phase before the product -- a trip to L2 that otherwise sits in front of the
+//  matrix instructions:  [0, 4 NT) = tile 0's blocks, [8, 12) = tile 1's blocks 4 - 7)
+struct SubtreeA {
+	double a[12];
+};
+DEVI SubtreeA subtree_fetch(CModel m, int lane)
+{
+	SubtreeA r;
+	const double MJB_AS4 *S = m.sub_S + lane;
+	if (m.sub_nt == 1) {
+		MJB_KEEP_BRANCH();
+#pragma unroll
+		for (int k = 0; k < 4; k++) r.a[k] = S[k * 64];
+#pragma unroll
+		for (int k = 4; k < 12; k++) r.a[k] = 0;
+	} else {
+		MJB_KEEP_BRANCH();
+#pragma unroll
+		for (int k = 0; k < 8; k++) r.a[k] = S[k * 64];
+#pragma unroll
+		for (int k = 4; k < 8; k++) r.a[4 + k] = S[(8 + k) * 64];
+	}
+	return r;
+}
+template <int N, int NT, bool KEEP0> DEVI void subtree_sum_tiles(CModel m, double *buf, int lane, const SubtreeA &A)
 {
 	static_assert(N <= 16, "one column tile");
 	constexpr int KB = 4 * NT;
 	const int li = lane & 15, lk = lane >> 4;
-	const double MJB_AS4 *S = m.sub_S + lane;
-	double A[NT][KB], B[KB];
-#pragma unroll
-	for (int t = 0; t < NT; t++)
-#pragma unroll
-		for (int k = 4 * t; k < KB; k++) A[t][k] = S[(t * KB + k) * 64];
+	double B[KB];
 #pragma unroll
 	for (int k = 0; k < KB; k++) {
 		const int b = 4 * k + lk;
@@ -654,7 +674,7 @@ template <int N, int NT, bool KEEP0> DEVI void subtree_sum_tiles(CModel m, doubl
 	for (int k = 0; k < KB; k++)
 #pragma unroll
 		for (int t = 0; t < NT; t++)
-			if (k >= 4 * t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t][k], B[k], acc[t], 0, 0, 0);
+			if (k >= 4 * t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A.a[t == 0 ? k : 4 + k], B[k], acc[t], 0, 0, 0);
 #pragma unroll
 	for (int t = 0; t < NT; t++)
 #pragma unroll
@@ -663,14 +683,14 @@ template <int N, int NT, bool KEEP0> DEVI void subtree_sum_tiles(CModel m, doubl
 			if (li < N && a < m.nbody && !(KEEP0 && a == 0)) buf[N * a + li] = acc[t][q];
 		}
 }
-template <int N, bool KEEP0> DEVI void subtree_sum(CModel m, double *buf, int lane)
+template <int N, bool KEEP0> DEVI void subtree_sum(CModel m, double *buf, int lane, const SubtreeA &A)
 {
 	if (m.sub_nt == 1) {
 		MJB_KEEP_BRANCH();
-		subtree_sum_tiles<N, 1, KEEP0>(m, buf, lane);
+		subtree_sum_tiles<N, 1, KEEP0>(m, buf, lane, A);
 	} else {
 		MJB_KEEP_BRANCH();
-		subtree_sum_tiles<N, 2, KEEP0>(m, buf, lane);
+		subtree_sum_tiles<N, 2, KEEP0>(m, buf, lane, A);
 	}
 }
 // the k-th byte of a 16-byte list held in two words, as the loop shifts it down
@@ -722,6 +742,7 @@ template <int G, bool OBL> STAGE void com_pos(CModel m, CLayout L, const Env &e)
 		MJB_KEEP_BRANCH();
 		const bool act = lane < m.nbody;
 		const int b = act ? (int)lane : 0;
+		const SubtreeA SA = subtree_fetch(m, lane);
 		const double mass = MP_BODY_MASS(m, e, b), stm = MP_SUBTREEMASS(m, e, b);
 		double xo[3], r[3];
 		ld3(xo, xipos + 3 * b);
@@ -730,7 +751,7 @@ template <int G, bool OBL> STAGE void com_pos(CModel m, CLayout L, const Env &e)
 			st3(sc + 3 * b, r);
 		}
 		gsync<G>();
-		subtree_sum<3, false>(m, sc, lane);
+		subtree_sum<3, false>(m, sc, lane, SA);
 		gsync<G>();
 		ld3(r, sc + 3 * b);
 		if (act) {
@@ -785,10 +806,12 @@ template <int G, bool OBL> STAGE void com_pos(CModel m, CLayout L, const Env &e)
 	}
 	// cdof: one joint per lane
 	for (int j = lane; j < m.njnt; j += G) {
-		const int bi = OBL ? e.lc.j_body : m.jnt_bodyid[j], jt = OBL ? e.lc.j_type : m.jnt_type[j];
-		double *cd = f + L.cdof + 6 * (OBL ? e.lc.j_da : m.jnt_dofadr[j]);
+		mjb_i4 jr = mjb_i4{ 0, 0, 0, 0 };
+		if constexpr (!OBL) jr = reinterpret_cast<const mjb_i4 MJB_AS4 *>(m.jnt_rec)[j];
+		const int bi = OBL ? e.lc.j_body : jr[0], jt = OBL ? e.lc.j_type : jr[1];
+		double *cd = f + L.cdof + 6 * (OBL ? e.lc.j_da : jr[2]);
 		double root[3], an[3], off[3];
-		ld3(root, sc + 3 * (OBL ? e.lc.j_root : m.body_rootid[bi]));
+		ld3(root, sc + 3 * (OBL ? e.lc.j_root : jr[3]));
 		ld3(an, f + L.xanchor + 3 * j);
 		off[0] = root[0] - an[0]; off[1] = root[1] - an[1]; off[2] = root[2] - an[2];
 		if (jt == MJB_JNT_FREE || jt == MJB_JNT_BALL) {
@@ -842,9 +865,10 @@ template <int G, bool OBL> STAGE void crb(CModel m, CLayout L, const Env &e)
 	if (G == 64 && !OBL && m.sub_nt > 0) {
 		MJB_KEEP_BRANCH();
 		// (nothing is added to the world body: its row stays what it was)
+		const SubtreeA SA = subtree_fetch(m, lane);
 		for (int k = lane; k < 10 * m.nbody; k += G) crbv[k] = cinert[k];
 		gsync<G>();
-		subtree_sum<10, true>(m, crbv, lane);
+		subtree_sum<10, true>(m, crbv, lane, SA);
 		gsync<G>();
 	} else
 	for (int c = lane; c < 10; c += G) {
@@ -1177,7 +1201,6 @@ STAGE void factor_dense16(CModel m, const Env &e, const double *M, double *LD, d
 // a no-op, so skipping it is exact): v_cmp -> wave mask -> scalar tests, no table.
 // row `row` of the host table M_sym (symmetric: row == column) in eight 16-byte loads -- read entry by entry at stride 32 it was 32
 // dependent-latency global loads per lane, twice in the factorisation and once more in the Newton solver's setup
-typedef int mjb_i4 __attribute__((ext_vector_type(4)));
 DEVI void msym_row(CModel m, int row, int (&a)[32])
 {
 	const mjb_i4 MJB_AS4 *p = reinterpret_cast<const mjb_i4 MJB_AS4 *>(m.M_sym + 32 * row);
@@ -1518,16 +1541,17 @@ template <int G, bool OBL> STAGE void com_vel(CModel m, CLayout L, const Env &e)
 	for (int d = lane; d < m.nv; d += G) {
 		double r[6];
 		bool zero;
+		[[maybe_unused]] mjb_i4 dr = mjb_i4{ 0, 0, 0, 0 };
 		if constexpr (OBL) zero = e.lc.d_zero != 0;
 		else {
-			const int j = m.dof_jntid[d];
-			zero = m.jnt_type[j] == MJB_JNT_FREE && d - m.jnt_dofadr[j] < 3;
+			dr = reinterpret_cast<const mjb_i4 MJB_AS4 *>(m.dof_rec2)[d];
+			zero = dr[0] != 0;
 		}
 		if (zero) {
 			for (int k = 0; k < 6; k++) r[k] = 0;
 		} else {
 			double v[6], cd[6];
-			if (OBL && e.lc.d_simple) ld6(v, cvel + 6 * e.lc.d_parent);  // first joint of its body: the parent's velocity
+			if (OBL ? e.lc.d_simple != 0 : dr[1] != 0) ld6(v, cvel + 6 * (OBL ? (int)e.lc.d_parent : dr[2]));  // first joint of its body: the parent's velocity
 			else cvel_before(m, L, f, m.dof_bodyid[d], m.dof_jstart[d], v);
 			ld6(cd, cdof + 6 * d);
 			cross_motion(r, v, cd);
@@ -1632,6 +1656,14 @@ template <int G, bool OBL> STAGE void rne(CModel m, CLayout L, const Env &e)
 	// inertial force  I a + v x* (I v)   (cfrc_body holds the per-body force, not its subtree sum)
 	[[maybe_unused]] double rkeep[6] = { 0, 0, 0, 0, 0, 0 };  // (dense kernels: the lane's own body force stays in registers for phase 2)
 	const bool anc_list = !OBL && m.dofanc_max > 0 && m.nbody <= G;
+	const bool sub_mm = G == 64 && !OBL && m.sub_nt > 0;
+	[[maybe_unused]] SubtreeA SA;
+	[[maybe_unused]] int dbody = 0;
+	if (sub_mm) {  // (operands of the backward pass's product, fetched while the forward pass runs)
+		MJB_KEEP_BRANCH();
+		SA = subtree_fetch(m, lane);
+		dbody = m.dof_bodyid[lane < m.nv ? (int)lane : 0];
+	}
 	for (int b = lane; b < m.nbody; b += G) {
 		double a[6] = { 0, 0, 0, grav ? -f[L.gravity] : 0.0, grav ? -f[L.gravity + 1] : 0.0, grav ? -f[L.gravity + 2] : 0.0 };
 		if (anc_list) {  // (the body's ancestor dofs from its list, as in com_vel)
@@ -1707,11 +1739,10 @@ template <int G, bool OBL> STAGE void rne(CModel m, CLayout L, const Env &e)
 	}
 	gsync<G>();
 	SPROF(27);
-	if (G == 64 && !OBL && m.sub_nt > 0) {
+	if (sub_mm) {
 		MJB_KEEP_BRANCH();
 		// mj_rne's backward pass (nothing goes to the world body), then qfrc_bias_d = cdof_d . subtree force of dof d's body
-		const int dbody = m.dof_bodyid[lane < m.nv ? (int)lane : 0];
-		subtree_sum<6, true>(m, cfrc, lane);
+		subtree_sum<6, true>(m, cfrc, lane, SA);
 		gsync<G>();
 		for (int d = lane; d < m.nv; d += G) {
 			double a[6], acc[6];
