@@ -569,9 +569,73 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const EnvLi
 #if defined(MJB_PROFILE_SUB) || defined(MJB_PROFILE_COL)
 	EPROF_BEGIN();
 #endif
+	// More candidate pairs than lanes: the bounding-sphere / plane cull of ALL pairs first (a record's head, two positions), the
+	// survivors -- a wave mask per round of 64 pairs -- packed into as few narrow-phase rounds as they need, in pair order (so the
+	// contacts come out in the order the uncompacted rounds give).  The hand model's 115 pairs leave ~20: one round of the narrow
+	// phase, slot counting and stores instead of two.  (Per-env geom types can reorder a pair and change what the cull looks at:
+	// those batches keep the plain rounds.)
+	const bool compact = m.ncollpair > G && m.ncollpair <= 4 * G && s.env_geom_type == nullptr;
+	unsigned long long cm0 = 0, cm1 = 0, cm2 = 0, cm3 = 0;
+	int nsurv = 0, cc1 = 0, cc2 = 0, cc3 = 0;  // survivors before round 1 / 2 / 3's
+	if (compact) {
+		MJB_KEEP_BRANCH();
+		auto cull_round = [&](int q) -> unsigned long long {
+			const int p = G * q + lane;
+			const bool valid = p < m.ncollpair;
+			const int pc = valid ? p : 0;
+			const mjb_ciptr pi = m.pair_i + 8 * pc;
+			const mjb_cdptr pd = m.pair_d + 24 * pc;
+			const int g1 = pi[0], g2 = pi[1], t1 = pi[2];
+			const double margin = pd[6], rb1 = pd[8], rb2 = pd[9];
+			double pos1[3], pos2[3];
+			ld3(pos1, f + L.geom_xpos + 3 * g1);
+			ld3(pos2, f + L.geom_xpos + 3 * g2);
+			const double nrm[3] = { f[L.geom_xmat + 9 * g1 + 2], f[L.geom_xmat + 9 * g1 + 5], f[L.geom_xmat + 9 * g1 + 8] };
+			const double dv[3] = { pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2] };
+			bool cull = false;
+			if (rb1 > 0 && rb2 > 0) {
+				const double bound = margin + rb1 + rb2;
+				cull = dot3(dv, dv) > bound * bound;
+			} else if (t1 == MJB_GEOM_PLANE && rb2 > 0) {
+				cull = dot3(dv, nrm) > margin + rb2;
+			}
+			return __ballot(valid && !cull);
+		};
+		cm0 = cull_round(0);
+		cm1 = cull_round(1);
+		if (m.ncollpair > 2 * G) {
+			MJB_KEEP_BRANCH();
+			cm2 = cull_round(2);
+			if (m.ncollpair > 3 * G) {
+				MJB_KEEP_BRANCH();
+				cm3 = cull_round(3);
+			}
+		}
+		cc1 = __popcll(cm0);
+		cc2 = cc1 + __popcll(cm1);
+		cc3 = cc2 + __popcll(cm2);
+		nsurv = cc3 + __popcll(cm3);
+	}
+	const int nitems = compact ? nsurv : m.ncollpair;
 	int base = 0;  // contacts of the earlier rounds (wave-uniform)
-	for (int p0 = 0; p0 < m.ncollpair; p0 += G) {
-		const int p = p0 + lane;
+	for (int p0 = 0; p0 < nitems; p0 += G) {
+		int p = p0 + lane;
+		if (compact) {
+			MJB_KEEP_BRANCH();
+			// the lane's survivor: the (p - cc_q)-th set bit of the round q that holds it (binary search by population counts)
+			const int q = (p >= cc1) + (p >= cc2) + (p >= cc3);
+			unsigned long long mk = q == 0 ? cm0 : (q == 1 ? cm1 : (q == 2 ? cm2 : cm3));
+			int k = p - (q == 0 ? 0 : (q == 1 ? cc1 : (q == 2 ? cc2 : cc3))), pos = 0;
+#pragma unroll
+			for (int w = 32; w >= 1; w >>= 1) {
+				const int c = __popcll((mk >> pos) & ((1ull << w) - 1ull));
+				if (k >= c) {
+					k -= c;
+					pos += w;
+				}
+			}
+			p = p < nsurv ? G * q + pos : m.ncollpair;
+		}
 		RawCon rc[2];  // (<= 2 contacts in registers; plane - box: the corner ids in pbc; box - box: from the LDS scratch straight to the frame)
 		int pbc = 0;
 		bool planebox = false;
