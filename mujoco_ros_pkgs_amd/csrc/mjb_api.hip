@@ -78,7 +78,7 @@ struct mjb_model {
 	std::vector<int> hint;            // all int arrays, concatenated
 	std::vector<double> hdbl;         // all double arrays, concatenated
 	std::vector<size_t> ioff, doff;   // offsets of each array inside hint / hdbl (declaration order)
-	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense, body_anc, dof_bodymask, M_sym, body_dofanc, dof_rec2, jnt_rec;
+	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense, body_anc, dof_bodymask, M_sym, body_dofanc, dof_rec2, jnt_rec, flv_hdr, flv_rec;
 	std::vector<int> sens_copy, sens_slow, dof_act_adr, dof_act_id;
 	std::vector<int> pair_i;       // [ncollpair][8]  per candidate pair: g1, g2, type1, type2, condim, friction rule, collision-function override, 0
 	std::vector<double> pair_d;    // [ncollpair][24] size1[3] size2[3] margin gap rbound1 rbound2 solref[2] solimp[5] includemargin friction[3] tran pad[2]
@@ -86,7 +86,7 @@ struct mjb_model {
 	std::vector<double> lim_d;     // [njnt + ntendon][24] limit items in pair_d's slots (mjb_dev.h)
 	std::vector<int> lim_i;        // [njnt + ntendon][4]
 	int sens_ncopy[3] = { 0, 0, 0 }, sens_nslow[3] = { 0, 0, 0 }, sens_ncopy_max = 0;
-	int eulerdamp = 0, maxdepth = 0, kin_rounds = 0, need_rnepost = 0, nfriction = 0, sub_nt = 0, dofanc_max = 0;
+	int eulerdamp = 0, maxdepth = 0, kin_rounds = 0, need_rnepost = 0, nfriction = 0, sub_nt = 0, dofanc_max = 0, flv_n = 0;
 	int field_size[MJB_F_COUNT]{};
 	FrameLayout L{}, Lc{};
 };
@@ -927,6 +927,86 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		}
 	}
 	M->fac_beg.push_back((int)M->fac_ops.size() / 4);
+	// the same updates scheduled by LEVELS of the elimination tree (= the dof tree): pivots of equal height touch disjoint rows of
+	// their own and only meet in the entries of common ancestors, so a level runs in one round: one lane per contribution
+	// LD[dst] -= LD[srcA] / D_pivot * LD[srcB], the contributions to one entry combined by its first lane in descending pivot order.
+	// flv_hdr [level][4] = { slots, longest list of slot 0 / 1 / 2 };  flv_rec [level][3][64][4] (below).  flv_n == 0 (a level with
+	// more than 192 contributions, a list longer than 6, more than 64 levels): the kernels keep the pivot-by-pivot factorisation
+	{
+		std::vector<int> hgt((size_t)(h.nv > 0 ? h.nv : 1), 0);
+		int nlev = 0, nseg = 0;
+		bool flv_ok = true;
+		for (int k = h.nv - 1; k >= 0; k--) {
+			const int pk = h.dof_parentid[k];
+			if (pk >= 0 && hgt[pk] < hgt[k] + 1) hgt[pk] = hgt[k] + 1;
+			if (hgt[k] + 1 > nlev) nlev = hgt[k] + 1;
+		}
+		for (int lev = 0; lev < nlev; lev++) {
+			std::vector<int> dsts;
+			std::vector<std::vector<int>> lists;
+			for (int k = h.nv - 1; k >= 0; k--) {
+				if (hgt[k] != lev) continue;
+				const int kk = h.dof_Madr[k], na = M->dof_depth[k] - 1;
+				for (int a = 0; a < na; a++) {
+					const int i = M->M_coldof[kk + 1 + a];
+					for (int bb = a; bb < na; bb++) {
+						const int dst = h.dof_Madr[i] + (bb - a);
+						size_t at = 0;
+						while (at < dsts.size() && dsts[at] != dst) at++;
+						if (at == dsts.size()) {
+							dsts.push_back(dst);
+							lists.emplace_back();
+						}
+						lists[at].push_back(kk + 1 + a);
+						lists[at].push_back(kk + 1 + bb);
+						lists[at].push_back(k);
+					}
+				}
+			}
+			// a level's CONTRIBUTIONS at fixed places, one 16-byte word per lane in up to three slots: { dst | (row + 1 of a diagonal
+			// dst) << 16, valid | owner << 1 | list length << 8, srcA | srcB << 16, pivot }.  The contributions to one entry sit in
+			// consecutive lanes of one 16-lane row, the entry's owner first: it collects the others' products by DPP row shifts.
+			// The lists go first (they must not straddle a row), the single contributions fill up.
+			if (dsts.empty()) continue;
+			std::vector<int> W;
+			int tm[3] = { 0, 0, 0 };
+			auto put = [&](size_t it) {
+				const int d = dsts[it], n = (int)lists[it].size() / 3;
+				const int drow1 = M->M_rowdof[d] == M->M_coldof[d] ? M->M_rowdof[d] + 1 : 0;
+				while ((int)(W.size() / 4) % 16 + n > 16) W.insert(W.end(), 4, 0);
+				for (int t = 0; t < n; t++) {
+					const int slot = (int)(W.size() / 4) / 64;
+					if (slot < 3 && n > tm[slot]) tm[slot] = n;
+					int r[4] = { d | (drow1 << 16), 1 | (t == 0 ? 2 : 0) | (n << 8), lists[it][3 * t] | (lists[it][3 * t + 1] << 16), lists[it][3 * t + 2] };
+					W.insert(W.end(), r, r + 4);
+				}
+			};
+			for (size_t it = 0; it < dsts.size(); it++) {
+				if (lists[it].size() / 3 > 6) flv_ok = false;
+				else if (lists[it].size() / 3 > 1) put(it);
+			}
+			for (size_t it = 0; it < dsts.size(); it++)
+				if (lists[it].size() / 3 == 1) put(it);
+			const int nslot = ((int)(W.size() / 4) + 63) / 64;
+			if (nslot > 3) flv_ok = false;
+			W.resize((size_t)3 * 64 * 4, 0);
+			int hdr[4] = { nslot, tm[0], tm[1], tm[2] };
+			M->flv_hdr.insert(M->flv_hdr.end(), hdr, hdr + 4);
+			M->flv_rec.insert(M->flv_rec.end(), W.begin(), W.end());
+			nseg++;
+		}
+		if (h.nM >= 65536 || nseg > 64) flv_ok = false;
+		if (!flv_ok) {
+			nseg = 0;
+			M->flv_hdr.clear();
+			M->flv_rec.clear();
+		}
+		// (three empty levels behind the last: the kernel's look-ahead fetches need no bounds test)
+		M->flv_rec.insert(M->flv_rec.end(), (size_t)3 * (3 * 64 * 4), 0);
+		M->flv_n = nseg;
+		if (M->flv_hdr.empty()) M->flv_hdr.assign(4, 0);
+		if (M->flv_rec.empty()) M->flv_rec.assign(4, 0);
+	}
 	// ancestor-dof bit masks per body (contact Jacobians)
 	M->body_dofmask.assign((size_t)2 * h.nbody, 0);
 	for (int b = 1; b < h.nbody; b++) {
@@ -1243,7 +1323,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	size_t ni = M->hint.size(), nd = M->hdbl.size();
 	size_t nt = M->M_rowdof.size() + M->M_coldof.size() + M->dof_depth.size() + M->dof_jstart.size() +
 	            M->body_rec.size() + M->body_rec2.size() + M->dof_rec.size() + M->fac_ops.size() + M->fac_beg.size() +
-	            M->body_dofmask.size() + M->body_submask.size() + M->M_dense.size() + M->M_sym.size() + M->body_anc.size() + M->dof_bodymask.size() + M->body_dofanc.size() + M->dof_rec2.size() + M->jnt_rec.size() + M->sens_copy.size() + M->sens_slow.size() + M->dof_act_adr.size() +
+	            M->body_dofmask.size() + M->body_submask.size() + M->M_dense.size() + M->M_sym.size() + M->body_anc.size() + M->dof_bodymask.size() + M->body_dofanc.size() + M->dof_rec2.size() + M->jnt_rec.size() + M->flv_hdr.size() + M->flv_rec.size() + M->sens_copy.size() + M->sens_slow.size() + M->dof_act_adr.size() +
 	            M->dof_act_id.size() + M->pair_i.size() + M->lim_i.size() + 104;
 	size_t bytes_i = ((ni + nt) * sizeof(int) + 15) & ~size_t(15);
 	size_t bytes = bytes_i + (nd + M->pair_d.size() + M->lim_d.size() + M->sub_S.size()) * sizeof(double) + 16;
@@ -1267,7 +1347,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	size_t o_row = put(M->M_rowdof), o_col = put(M->M_coldof), o_dep = put(M->dof_depth), o_js = put(M->dof_jstart);
 	size_t o_br = put(M->body_rec), o_br2 = put(M->body_rec2), o_dr = put(M->dof_rec), o_fo = put(M->fac_ops),
 	       o_fb = put(M->fac_beg), o_dm = put(M->body_dofmask), o_sm = put(M->body_submask), o_md = put(M->M_dense), o_ms = put(M->M_sym), o_an = put(M->body_anc), o_db = put(M->dof_bodymask), o_sc = put(M->sens_copy), o_ss = put(M->sens_slow),
-	       o_aa = put(M->dof_act_adr), o_ai = put(M->dof_act_id), o_pi = put(M->pair_i), o_li = put(M->lim_i), o_da = put(M->body_dofanc), o_dr2 = put(M->dof_rec2), o_jr = put(M->jnt_rec);
+	       o_aa = put(M->dof_act_adr), o_ai = put(M->dof_act_id), o_pi = put(M->pair_i), o_li = put(M->lim_i), o_da = put(M->body_dofanc), o_dr2 = put(M->dof_rec2), o_jr = put(M->jnt_rec), o_fh = put(M->flv_hdr), o_fr = put(M->flv_rec);
 	if (nd) memcpy(hd, M->hdbl.data(), nd * sizeof(double));
 	memcpy(hd + nd, M->pair_d.data(), M->pair_d.size() * sizeof(double));
 	memcpy(hd + nd + M->pair_d.size(), M->lim_d.data(), M->lim_d.size() * sizeof(double));
@@ -1313,6 +1393,9 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	dm.dofanc_max = M->dofanc_max;
 	dm.dof_rec2 = (mjb_ciptr)(di + o_dr2);
 	dm.jnt_rec = (mjb_ciptr)(di + o_jr);
+	dm.flv_hdr = (mjb_ciptr)(di + o_fh);
+	dm.flv_rec = (mjb_ciptr)(di + o_fr);
+	dm.flv_n = M->flv_n;
 	dm.dof_bodymask = (mjb_ciptr)(di + o_db);
 	dm.need_rnepost = M->need_rnepost;
 	dm.sens_copy = (mjb_ciptr)(di + o_sc);

@@ -38,6 +38,9 @@ struct DevModel {
 	mjb_ciptr jnt_rec;     // [njnt][4]  packed {bodyid, type, dofadr, rootid of its body}
 	mjb_ciptr fac_ops;     // [nfac][4]  factorisation micro-ops {dst, srcA, srcB, 0}: LD[dst] -= LD[srcA]/LD[kk]*LD[srcB]
 	mjb_ciptr fac_beg;     // [nv+1]     first micro-op of pivot k
+	mjb_ciptr flv_hdr;     // [flv_n][4] the same updates by levels of the elimination tree (mjb_api.hip): { slots, longest list of slot 0 / 1 / 2 }
+	mjb_ciptr flv_rec;     // [flv_n + 3][3][64][4] the levels' contributions, one 16-byte word per lane and slot
+	int flv_n;
 	mjb_ciptr sens_copy;     // [2][3][sens_ncopy_max][2] (layout full/compact, stage-1): {dst offset in sensordata, src frame offset}
 	mjb_ciptr sens_slow;     // [3][nsensor] ids of the sensors of each stage that need real work
 	mjb_ciptr dof_act_adr;   // [nv+1] CSR: actuators (joint transmission) driving each dof

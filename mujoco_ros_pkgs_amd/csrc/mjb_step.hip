@@ -992,6 +992,135 @@ STAGE void factor2(CModel m, const Env &e, const double *M, double *LD, double *
 	gsync<G>();
 }
 
+// ---- the same factorisation scheduled by LEVELS of the elimination tree (host program flv_hdr / flv_rec): one round per level of
+// the dof tree instead of one per pivot -- 7 rounds for the hand model's 30 dofs.  One lane per destination entry applies the
+// level's contributions to it, in descending pivot order; the rounding differs from the pivot-by-pivot order only where pivots of
+// different levels meet in an entry (the entries of common ancestors).
+DEVI double fast_rcp(double x)
+{
+	double r = __builtin_amdgcn_rcp(x);
+	r = fma(fma(-x, r, 1.0), r, r);
+	r = fma(fma(-x, r, 1.0), r, r);
+	return r;
+}
+
+template <int G>
+STAGE void factor_levels(CModel m, const Env &e, const double *M, double *LD, double *di, const double *M2, double *LD2,
+                         double *di2, bool dual)
+{
+	static_assert(G == 64, "a level's items sit at one place per lane of the wavefront");
+	const int lane = e.lane;
+	// only LDS crosses lanes in this stage: its syncs do not wait for the look-ahead fetches (a plain wavefront fence waits vmcnt(0))
+	auto lsync = [&]() {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+	};
+	constexpr int LVSZ = 3 * 64;  // a level's words, in 16-byte units
+	const mjb_i4 MJB_AS4 *recs = reinterpret_cast<const mjb_i4 MJB_AS4 *>(m.flv_rec);
+	struct Lv {
+		mjb_i4 w[3];
+	};
+	auto fetch = [&](int lev) {
+		const mjb_i4 MJB_AS4 *p = recs + (size_t)lev * LVSZ + lane;
+		Lv r;
+#pragma unroll
+		for (int q = 0; q < 3; q++) r.w[q] = p[64 * q];
+		return r;
+	};
+	const mjb_i4 hv = reinterpret_cast<const mjb_i4 MJB_AS4 *>(m.flv_hdr)[lane < m.flv_n ? (int)lane : 0];
+	Lv P0 = fetch(0), P1 = fetch(1);
+	// the inverse diagonals are kept up to date as the levels go: an update  LD[dst] -= LD[a] * (1 / D_k) * LD[b]  costs two
+	// multiplications (a division per contribution -- ~15 instructions of the quarter-rate kind -- was 3/4 of this stage), and the
+	// lane that finishes a diagonal entry writes its reciprocal: a pivot's diagonal is final once the level below it has run
+	for (int en = lane; en < m.nM; en += G) {
+		const double v = M[en], v2 = dual ? M2[en] : 1.0;
+		LD[en] = v;
+		if (dual) LD2[en] = v2;
+		const int row = m.M_rowdof[en];
+		if (m.M_coldof[en] == row) {
+			di[row] = fast_rcp(v);
+			if (dual) di2[row] = fast_rcp(v2);
+		}
+	}
+	// one contribution per lane; an entry's contributions sit in consecutive lanes of a 16-lane row and its first lane (the owner)
+	// subtracts them in order -- its own, then the neighbours' by DPP row shifts
+	auto apply = [&](const mjb_i4 w, int tmax) {
+		const int dst = w[0] & 0xFFFF, drow = (w[0] >> 16) - 1, fl = w[1], sa = w[2] & 0xFFFF, sb = (unsigned int)w[2] >> 16, k = w[3];
+		const bool valid = (fl & 1) != 0, owner = (fl & 2) != 0;
+		const int cnt = fl >> 8;
+		double acc = LD[dst], acc2 = dual ? LD2[dst] : 0.0;
+		const double a = LD[sa], b = LD[sb], d = di[k];
+		const double a2 = dual ? LD2[sa] : 0.0, b2 = dual ? LD2[sb] : 0.0, d2 = dual ? di2[k] : 0.0;
+		double u = a * d * b, u2 = a2 * d2 * b2;
+		u = valid ? u : 0.0;
+		u2 = valid ? u2 : 0.0;
+		acc -= u;
+		acc2 -= u2;
+		static_for<5>([&](auto jc) {
+			constexpr int j = decltype(jc)::value + 1;
+			if (j < tmax) {  // (wave-uniform)
+				MJB_KEEP_BRANCH();
+				const double v = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(u), 0x100 + j, 0xF, 0xF, true),
+				                                  __builtin_amdgcn_update_dpp(0, __double2loint(u), 0x100 + j, 0xF, 0xF, true));
+				acc -= j < cnt ? v : 0.0;
+				if (dual) {
+					const double v2 = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(u2), 0x100 + j, 0xF, 0xF, true),
+					                                   __builtin_amdgcn_update_dpp(0, __double2loint(u2), 0x100 + j, 0xF, 0xF, true));
+					acc2 -= j < cnt ? v2 : 0.0;
+				}
+			}
+		});
+		if (owner) {
+			LD[dst] = acc;
+			if (dual) LD2[dst] = acc2;
+		}
+		if (__ballot(owner && drow >= 0)) {
+			MJB_KEEP_BRANCH();
+			const double r = fast_rcp(acc), r2 = dual ? fast_rcp(acc2) : 0.0;
+			if (owner && drow >= 0) {
+				di[drow] = r;
+				if (dual) di2[drow] = r2;
+			}
+		}
+	};
+	auto level = [&](int lev, const Lv &C) {
+		const int ns = __builtin_amdgcn_readlane(hv[0], lev);
+		apply(C.w[0], __builtin_amdgcn_readlane(hv[1], lev));
+		if (ns > 1) {
+			MJB_KEEP_BRANCH();
+			apply(C.w[1], __builtin_amdgcn_readlane(hv[2], lev));
+			if (ns > 2) {
+				MJB_KEEP_BRANCH();
+				apply(C.w[2], __builtin_amdgcn_readlane(hv[3], lev));
+			}
+		}
+		lsync();
+	};
+	lsync();
+	// (two levels a trip, each refilling its OWN set of registers for the level two ahead: rotating one set into the other by
+	//  copies made every trip wait for the loads it had just issued)
+#pragma nounroll
+	for (int lev = 0; lev < m.flv_n; lev += 2) {
+		level(lev, P0);
+		P0 = fetch(lev + 2);
+		if (lev + 1 < m.flv_n) {
+			MJB_KEEP_BRANCH();
+			level(lev + 1, P1);
+			P1 = fetch(lev + 3);
+		}
+	}
+	// rows scaled at the end, as in factor2:  L(k, a) = U(k, a) / D(k)
+	for (int en = lane; en < m.nM; en += G) {
+		const int row = m.M_rowdof[en];
+		if (m.M_coldof[en] != row) {
+			LD[en] = LD[en] * di[row];
+			if (dual) LD2[en] = LD2[en] * di2[row];
+		}
+	}
+	gsync<G>();
+}
+
 // sum over the 16 lanes of a DPP row; every lane of the row receives the total (butterfly: xor 1, xor 2,
 // half-mirror, mirror)
 DEVI double dpp_add(double v, const int lo2, const int hi2) { return v + __hiloint2double(hi2, lo2); }
@@ -1072,13 +1201,6 @@ DEVI double group_bcast16(double v, int src)  // value of lane `src` of this lan
 
 
 // 1 / x to ~1 ulp: hardware seed + two Newton steps (the correctly rounded division costs 12 dependent instructions)
-DEVI double fast_rcp(double x)
-{
-	double r = __builtin_amdgcn_rcp(x);
-	r = fma(fma(-x, r, 1.0), r, r);
-	r = fma(fma(-x, r, 1.0), r, r);
-	return r;
-}
 
 #ifndef MJB_FACTOR64_LDS
 #define MJB_FACTOR64_LDS 1  // (0: v_readlane broadcasts -- more issue slots than the LDS round trips the co-resident wave hides: 185.1 -> 186.9 ms on config 3)
@@ -2553,8 +2675,15 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 				                      m.eulerdamp != 0, dl, e.f + L.crbbuf);
 			});
 		else if ((CON >= 2 && CON <= 4) && P->m.nv <= 32)  // (the 512-register Newton kernels, like TRI32 below)
-			VIEW(P, compact, factor_dense32<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi,
-			                                   m.eulerdamp != 0));
+			VIEW(P, compact, {
+				if (m.flv_n > 0) {
+					MJB_KEEP_BRANCH();
+					factor_levels<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi, m.eulerdamp != 0);
+				} else {
+					MJB_KEEP_BRANCH();
+					factor_dense32<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi, m.eulerdamp != 0);
+				}
+			});
 		else
 			VIEW(P, compact, factor2<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi,
 			                            m.eulerdamp != 0));
