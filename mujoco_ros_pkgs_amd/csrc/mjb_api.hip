@@ -78,7 +78,7 @@ struct mjb_model {
 	std::vector<int> hint;            // all int arrays, concatenated
 	std::vector<double> hdbl;         // all double arrays, concatenated
 	std::vector<size_t> ioff, doff;   // offsets of each array inside hint / hdbl (declaration order)
-	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense, body_anc, dof_bodymask, M_sym, body_dofanc, dof_rec2, jnt_rec, flv_hdr, flv_rec;
+	std::vector<int> M_rowdof, M_coldof, dof_depth, dof_jstart, body_rec, body_rec2, dof_rec, fac_ops, fac_beg, body_dofmask, body_submask, M_dense, body_anc, dof_bodymask, M_sym, body_dofanc, dof_rec2, jnt_rec, flv_hdr, flv_rec, flv_ent;
 	std::vector<int> sens_copy, sens_slow, dof_act_adr, dof_act_id;
 	std::vector<int> pair_i;       // [ncollpair][8]  per candidate pair: g1, g2, type1, type2, condim, friction rule, collision-function override, 0
 	std::vector<double> pair_d;    // [ncollpair][24] size1[3] size2[3] margin gap rbound1 rbound2 solref[2] solimp[5] includemargin friction[3] tran pad[2]
@@ -1004,6 +1004,9 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		// (three empty levels behind the last: the kernel's look-ahead fetches need no bounds test)
 		M->flv_rec.insert(M->flv_rec.end(), (size_t)3 * (3 * 64 * 4), 0);
 		M->flv_n = nseg;
+		// per qM entry: its row, and whether it is the diagonal one (the first and the last round of factor_levels)
+		M->flv_ent.assign((size_t)((h.nM + 255) / 256 * 256 + 256), 0);
+		for (int en = 0; en < h.nM; en++) M->flv_ent[en] = M->M_rowdof[en] | (M->M_rowdof[en] == M->M_coldof[en] ? 0x10000 : 0);
 		if (M->flv_hdr.empty()) M->flv_hdr.assign(4, 0);
 		if (M->flv_rec.empty()) M->flv_rec.assign(4, 0);
 	}
@@ -1323,7 +1326,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	size_t ni = M->hint.size(), nd = M->hdbl.size();
 	size_t nt = M->M_rowdof.size() + M->M_coldof.size() + M->dof_depth.size() + M->dof_jstart.size() +
 	            M->body_rec.size() + M->body_rec2.size() + M->dof_rec.size() + M->fac_ops.size() + M->fac_beg.size() +
-	            M->body_dofmask.size() + M->body_submask.size() + M->M_dense.size() + M->M_sym.size() + M->body_anc.size() + M->dof_bodymask.size() + M->body_dofanc.size() + M->dof_rec2.size() + M->jnt_rec.size() + M->flv_hdr.size() + M->flv_rec.size() + M->sens_copy.size() + M->sens_slow.size() + M->dof_act_adr.size() +
+	            M->body_dofmask.size() + M->body_submask.size() + M->M_dense.size() + M->M_sym.size() + M->body_anc.size() + M->dof_bodymask.size() + M->body_dofanc.size() + M->dof_rec2.size() + M->jnt_rec.size() + M->flv_hdr.size() + M->flv_rec.size() + M->flv_ent.size() + M->sens_copy.size() + M->sens_slow.size() + M->dof_act_adr.size() +
 	            M->dof_act_id.size() + M->pair_i.size() + M->lim_i.size() + 104;
 	size_t bytes_i = ((ni + nt) * sizeof(int) + 15) & ~size_t(15);
 	size_t bytes = bytes_i + (nd + M->pair_d.size() + M->lim_d.size() + M->sub_S.size()) * sizeof(double) + 16;
@@ -1347,7 +1350,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	size_t o_row = put(M->M_rowdof), o_col = put(M->M_coldof), o_dep = put(M->dof_depth), o_js = put(M->dof_jstart);
 	size_t o_br = put(M->body_rec), o_br2 = put(M->body_rec2), o_dr = put(M->dof_rec), o_fo = put(M->fac_ops),
 	       o_fb = put(M->fac_beg), o_dm = put(M->body_dofmask), o_sm = put(M->body_submask), o_md = put(M->M_dense), o_ms = put(M->M_sym), o_an = put(M->body_anc), o_db = put(M->dof_bodymask), o_sc = put(M->sens_copy), o_ss = put(M->sens_slow),
-	       o_aa = put(M->dof_act_adr), o_ai = put(M->dof_act_id), o_pi = put(M->pair_i), o_li = put(M->lim_i), o_da = put(M->body_dofanc), o_dr2 = put(M->dof_rec2), o_jr = put(M->jnt_rec), o_fh = put(M->flv_hdr), o_fr = put(M->flv_rec);
+	       o_aa = put(M->dof_act_adr), o_ai = put(M->dof_act_id), o_pi = put(M->pair_i), o_li = put(M->lim_i), o_da = put(M->body_dofanc), o_dr2 = put(M->dof_rec2), o_jr = put(M->jnt_rec), o_fh = put(M->flv_hdr), o_fr = put(M->flv_rec), o_fe = put(M->flv_ent);
 	if (nd) memcpy(hd, M->hdbl.data(), nd * sizeof(double));
 	memcpy(hd + nd, M->pair_d.data(), M->pair_d.size() * sizeof(double));
 	memcpy(hd + nd + M->pair_d.size(), M->lim_d.data(), M->lim_d.size() * sizeof(double));
@@ -1396,6 +1399,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	dm.flv_hdr = (mjb_ciptr)(di + o_fh);
 	dm.flv_rec = (mjb_ciptr)(di + o_fr);
 	dm.flv_n = M->flv_n;
+	dm.flv_ent = (mjb_ciptr)(di + o_fe);
 	dm.dof_bodymask = (mjb_ciptr)(di + o_db);
 	dm.need_rnepost = M->need_rnepost;
 	dm.sens_copy = (mjb_ciptr)(di + o_sc);

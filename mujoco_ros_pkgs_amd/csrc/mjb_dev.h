@@ -40,6 +40,7 @@ struct DevModel {
 	mjb_ciptr fac_beg;     // [nv+1]     first micro-op of pivot k
 	mjb_ciptr flv_hdr;     // [flv_n][4] the same updates by levels of the elimination tree (mjb_api.hip): { slots, longest list of slot 0 / 1 / 2 }
 	mjb_ciptr flv_rec;     // [flv_n + 3][3][64][4] the levels' contributions, one 16-byte word per lane and slot
+	mjb_ciptr flv_ent;     // [nM, padded to 4 x 64] row | diagonal << 16 of every qM entry
 	int flv_n;
 	mjb_ciptr sens_copy;     // [2][3][sens_ncopy_max][2] (layout full/compact, stage-1): {dst offset in sensordata, src frame offset}
 	mjb_ciptr sens_slow;     // [3][nsensor] ids of the sensors of each stage that need real work

@@ -1033,14 +1033,34 @@ STAGE void factor_levels(CModel m, const Env &e, const double *M, double *LD, do
 	// the inverse diagonals are kept up to date as the levels go: an update  LD[dst] -= LD[a] * (1 / D_k) * LD[b]  costs two
 	// multiplications (a division per contribution -- ~15 instructions of the quarter-rate kind -- was 3/4 of this stage), and the
 	// lane that finishes a diagonal entry writes its reciprocal: a pivot's diagonal is final once the level below it has run
-	for (int en = lane; en < m.nM; en += G) {
+	// (the entries' row words for four trips of 64 at once -- one trip to the table for the first and the last round)
+	int ent[4];
+#pragma unroll
+	for (int q = 0; q < 4; q++) ent[q] = m.flv_ent[lane + 64 * q];
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		const int en = lane + 64 * q;
+		if (64 * q < m.nM) {  // (wave-uniform)
+			MJB_KEEP_BRANCH();
+			if (en < m.nM) {
+				const double v = M[en], v2 = dual ? M2[en] : 1.0;
+				LD[en] = v;
+				if (dual) LD2[en] = v2;
+				if (ent[q] & 0x10000) {
+					di[ent[q] & 0xFFFF] = fast_rcp(v);
+					if (dual) di2[ent[q] & 0xFFFF] = fast_rcp(v2);
+				}
+			}
+		}
+	}
+	for (int en = lane + 256; en < m.nM; en += G) {
 		const double v = M[en], v2 = dual ? M2[en] : 1.0;
 		LD[en] = v;
 		if (dual) LD2[en] = v2;
-		const int row = m.M_rowdof[en];
-		if (m.M_coldof[en] == row) {
-			di[row] = fast_rcp(v);
-			if (dual) di2[row] = fast_rcp(v2);
+		const int w = m.flv_ent[en];
+		if (w & 0x10000) {
+			di[w & 0xFFFF] = fast_rcp(v);
+			if (dual) di2[w & 0xFFFF] = fast_rcp(v2);
 		}
 	}
 	// one contribution per lane; an entry's contributions sit in consecutive lanes of a 16-lane row and its first lane (the owner)
@@ -1111,11 +1131,22 @@ STAGE void factor_levels(CModel m, const Env &e, const double *M, double *LD, do
 		}
 	}
 	// rows scaled at the end, as in factor2:  L(k, a) = U(k, a) / D(k)
-	for (int en = lane; en < m.nM; en += G) {
-		const int row = m.M_rowdof[en];
-		if (m.M_coldof[en] != row) {
-			LD[en] = LD[en] * di[row];
-			if (dual) LD2[en] = LD2[en] * di2[row];
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		const int en = lane + 64 * q;
+		if (64 * q < m.nM) {  // (wave-uniform)
+			MJB_KEEP_BRANCH();
+			if (en < m.nM && !(ent[q] & 0x10000)) {
+				LD[en] = LD[en] * di[ent[q] & 0xFFFF];
+				if (dual) LD2[en] = LD2[en] * di2[ent[q] & 0xFFFF];
+			}
+		}
+	}
+	for (int en = lane + 256; en < m.nM; en += G) {
+		const int w = m.flv_ent[en];
+		if (!(w & 0x10000)) {
+			LD[en] = LD[en] * di[w & 0xFFFF];
+			if (dual) LD2[en] = LD2[en] * di2[w & 0xFFFF];
 		}
 	}
 	gsync<G>();
