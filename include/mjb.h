@@ -160,7 +160,10 @@ int mjb_step2(mjb_batch *b);
  * arithmetic is independent of the launch that carries it (same Philox key, same kernels): the result equals a whole-batch step.
  * One step = mjb_step1_prefix(ncb) -> copy the callback envs' fields out -> mjb_step_rest(ncb) [asynchronous: it runs while the
  * host callbacks do] -> copy their writes back -> mjb_step2_prefix(ncb) [advances the step counter; issues the rest itself if
- * the caller skipped mjb_step_rest].  Derived fields are readable for envs [0, ncb) only between the two halves. */
+ * the caller skipped mjb_step_rest].  Derived fields are readable for envs [0, ncb) only between the two halves.
+ * Abandoning a split step: before mjb_step_rest, a new mjb_step1_prefix simply restarts it; after mjb_step_rest the other envs have
+ * taken the step already, so only its second half (mjb_step2_prefix / mjb_step21_prefix / mjb_step2_rk_prefix) or a whole-batch
+ * mjb_reset / mjb_step may follow -- mjb_step1_prefix returns MJB_EINVAL. */
 int mjb_step1_prefix(mjb_batch *b, int ncb);
 int mjb_step_rest(mjb_batch *b, int ncb);
 int mjb_step2_prefix(mjb_batch *b, int ncb);
@@ -225,6 +228,10 @@ void *mjb_device_ptr(mjb_batch *b, int field);
  * `env_offset` is the global index of this batch's env 0 (multi-GPU sharding). */
 int mjb_set_ctrl_noise(mjb_batch *b, double ctrl_noise_std, double ctrl_noise_rate, uint64_t seed,
                        int64_t env_offset);
+/* How the LAST fused mjb_step launch obtained the injector's normals (the values are identical in all three): 0 = generated inside the
+ * step kernel, 1 = by mjb_noise_kernel ahead of the step kernel on the same stream, 2 = by mjb_noise_kernel on a side stream while
+ * the previous launch ran (unconstrained kernels only; budget MJB_NOISE_PREGEN_MB).  Measurement aid, no reference counterpart. */
+int mjb_noise_mode(const mjb_batch *b);
 
 /* Stream control: the hipStream_t (as void*) kernels are launched on; default is a stream the
  * batch owns.  mjb_synchronize waits for it. */
@@ -362,6 +369,8 @@ int mjb_hwsim_estop(mjb_batch *b, int active);
  * `control_period` of sim time (ros::Duration arithmetic, first at the first non-zero time: nothing is read or written at t = 0,
  * :171-176), writeSim at every step after the first update with period = time - last write (:190-193), a time that went
  * backwards re-arms both stamps (:160-169).  control_period <= 0: a write at every step on the step's own state (default).
+ * A control_period below the timestep is accepted with a warning on stderr (the reference: ROS_WARN, :100-105) -- the controller
+ * then updates at every step.
  * The e-stop EDGE of :180-185 restarts the controller manager's controllers -- host-side objects; the PIDs of DefaultRobotHWSim
  * itself are never reset by the reference, nor here. */
 int mjb_hwsim_set_period(mjb_batch *b, double control_period);

@@ -136,7 +136,10 @@ struct mjb_batch {
 	double *hw_pid = nullptr;      // [nenv][n][2]
 	double *hw_cad = nullptr;      // [nenv][2 + 2 n] controller cadence (mjb_hwsim_set_period)
 	double *zbuf = nullptr;        // pre-generated ctrl-noise normals of one fused launch (launch())
-	size_t zcap = 0;               // its capacity in doubles
+	size_t zcap = 0;               // its capacity in doubles PER HALF
+	bool zdouble = false;          // two halves allocated (side-stream speculation possible)
+	size_t zfail = (size_t)-1;     // smallest total allocation (doubles) that failed: not retried
+	int noise_mode = 0;            // how the last fused launch got its ctrl-noise normals: 0 in-kernel, 1 same-stream, 2 side-stream (mjb_noise_mode)
 	unsigned int *zinfo = nullptr; // two records (one per half of zbuf)
 	bool zvalid = false;           // a record names a launch: cleared (on the stream) before any step launch that does not use the buffer
 	hipStream_t noise_stream = nullptr;  // the NEXT launch's normals are generated here while the current launch runs
@@ -1612,35 +1615,45 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 			HIP_TRY(hipMemsetAsync(b->st.sched, 0, ((size_t)b->nenv + 1) * sizeof(int), stream));
 		}
 	}
-	// ctrl noise of a long fused launch: its normals are generated ahead of the step kernel, on the same stream (mjb_noise_kernel),
-	// when they fit the budget (MJB_NOISE_PREGEN_MB, default 1024; 0: always inside the step kernel -- same values either way)
 	// ctrl noise of a long fused launch: its normals are generated by a throughput kernel (mjb_noise_kernel) instead of inside every
-	// step's dependent chain, when they fit the budget (MJB_NOISE_PREGEN_MB per half, default 1024; 0: always inside the step kernel --
-	// same values either way).  The buffer has two halves: this launch reads one while the other is filled, on a side stream, for the
-	// launch expected next (same length, the step counter this one ends at); a launch that finds its normals ready only waits for
-	// that event, anything else generates them on its own stream first.
+	// step's dependent chain, when they fit the budget (MJB_NOISE_PREGEN_MB = the TOTAL allocation, default 2048; 0: always inside
+	// the step kernel -- same values either way).  Unconstrained kernels (one wave per SIMD, 320 VGPRs: a second kernel finds room) get
+	// a buffer of two halves: this launch reads one while the other is filled, on a side stream, for the launch expected next (same
+	// length, the step counter this one ends at); a launch that finds its normals ready only waits for that event, anything else
+	// generates them on its own stream first.  The constrained kernels fill the register file (256 / 512 VGPRs at two / one waves per
+	// SIMD): a side-stream generator only finds a slot when the step launch drains (rocprofv3 showed it spanning the whole 130 - 180 ms
+	// launch), so they -- and launches whose two halves exceed the budget -- generate one half on their own stream.
 	bool zuse = false;
 	int zhalf_now = 0;
+	b->noise_mode = 0;
 	if (mode == MJB_MODE_STEP && whole && b->nz.enabled && nsteps >= 16 && b->model->h.nu > 0 && b->model->h.nu <= b->lanes) {
-		static const size_t cap_doubles = [] { const char *v = getenv("MJB_NOISE_PREGEN_MB"); return (size_t)(v ? atol(v) : 1024) * (1u << 20) / sizeof(double); }();
+		static const size_t cap_doubles = [] { const char *v = getenv("MJB_NOISE_PREGEN_MB"); return (size_t)(v ? atol(v) : 2048) * (1u << 20) / sizeof(double); }();
 		const size_t need = (size_t)nsteps * b->nenv * b->model->h.nu;
-		if (need <= cap_doubles) {
-			if (need > b->zcap) {
+		const bool want_double = variant == 0 && 2 * need <= cap_doubles;
+		const size_t total = want_double ? 2 * need : need;
+		if (total <= cap_doubles && total < b->zfail) {
+			if (need > b->zcap || (want_double && !b->zdouble)) {
 				HIP_TRY(hipStreamSynchronize(stream));
 				if (b->noise_stream) HIP_TRY(hipStreamSynchronize(b->noise_stream));
 				if (b->zbuf) hipFree(b->zbuf);
-				b->zbuf = dev_alloc<double>(2 * need);
+				b->spec_valid = false;
+				b->zbuf = dev_alloc<double>(total);
+				if (!b->zbuf) {
+					(void)hipGetLastError();
+					b->zfail = total;  // (remembered: a launch of this size or larger generates in the kernel from now on)
+				}
 				b->zcap = b->zbuf ? need : 0;
+				b->zdouble = b->zbuf && want_double;
 				if (!b->zinfo) b->zinfo = dev_alloc<unsigned int>(8);
 				if (b->zinfo) HIP_TRY(hipMemset(b->zinfo, 0xff, 8 * sizeof(unsigned int)));
-				if (!b->noise_stream) {
+				b->zvalid = false;
+				if (b->zdouble && !b->noise_stream) {
 					HIP_TRY(hipStreamCreateWithFlags(&b->noise_stream, hipStreamNonBlocking));
 					HIP_TRY(hipEventCreateWithFlags(&b->ev_noise, hipEventDisableTiming));
 					HIP_TRY(hipEventCreateWithFlags(&b->ev_noise_go, hipEventDisableTiming));
 				}
-				b->spec_valid = false;
 				b->st.zbuf = b->zbuf;
-				b->st.zinfo = b->zinfo;
+				b->st.zinfo = b->zbuf ? b->zinfo : nullptr;
 				b->st.zhalf = (unsigned long long)b->zcap;
 				b->params_dirty = true;
 				prc = sync_params(b);
@@ -1650,12 +1663,14 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 				if (b->spec_valid && b->spec_step0 == b->step_counter && b->spec_nsteps == nsteps) {
 					zhalf_now = b->spec_half;
 					HIP_TRY(hipStreamWaitEvent(stream, b->ev_noise, 0));  // generated while the previous launch ran
+					b->noise_mode = 2;
 				} else {
 					if (b->spec_valid) HIP_TRY(hipStreamWaitEvent(stream, b->ev_noise, 0));  // (a generator still writing its half: let it finish first)
 					zhalf_now = 0;
 					HIP_TRY(hipMemsetAsync(b->zinfo + 4, 0xff, 4 * sizeof(unsigned int), stream));
 					int nrc = mjb_launch_noise(b->params_dev, b->zbuf, b->zinfo, b->nenv, b->model->h.nu, nsteps, b->step_counter, stream);
 					if (nrc != 0) return fail(MJB_ENODEVICE, "noise kernel launch failed: %s", hipGetErrorString((hipError_t)nrc));
+					b->noise_mode = 1;
 				}
 				b->spec_valid = false;
 				zuse = b->zvalid = true;
@@ -1668,11 +1683,12 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 		HIP_TRY(hipMemsetAsync(b->zinfo, 0xff, 8 * sizeof(unsigned int), stream));
 		b->zvalid = false;
 	}
-	if (zuse) HIP_TRY(hipEventRecord(b->ev_noise_go, stream));  // (everything before this launch -- the last reader of the other half -- is done)
+	const bool zspec = zuse && b->zdouble;
+	if (zspec) HIP_TRY(hipEventRecord(b->ev_noise_go, stream));  // (everything before this launch -- the last reader of the other half -- is done)
 	int rc = mjb_launch_step(b->params_dev, compact ? b->model->Lc : b->L, env_lo, env_hi, mode, nsteps, b->step_counter, b->lanes,
 	                         b->epb, variant | (chunk << 8), (b->lanes == 16 && !b->env_mass && mode != MJB_MODE_STEP21 && b->model->h.integrator == MJB_INT_EULER && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16 && b->model->h.nu <= 16 && b->model->h.njnt <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, stream);
 	if (rc != 0) return fail(MJB_ENODEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-	if (zuse) {  // the next launch's normals, into the half this one does not read, beside it
+	if (zspec) {  // the next launch's normals, into the half this one does not read, beside it
 		const int other = 1 - zhalf_now;
 		HIP_TRY(hipStreamWaitEvent(b->noise_stream, b->ev_noise_go, 0));
 		int nrc = mjb_launch_noise(b->params_dev, b->zbuf + (size_t)other * b->zcap, b->zinfo + 4 * other, b->nenv, b->model->h.nu, nsteps,
@@ -1755,7 +1771,16 @@ int mjb_step2(mjb_batch *b)
 int mjb_step1_prefix(mjb_batch *b, int ncb)
 {
 	if (!b || ncb < 0 || ncb > b->nenv) return fail(MJB_EINVAL, "mjb_step1_prefix: bad argument");
-	int rc = ensure_ws(b);
+	// A split step abandoned AFTER mjb_step_rest: the rest envs already took a step the step counter never recorded (they would redraw
+	// the same Philox step), and their launch may still be running on the rest stream.  Only mjb_step2_prefix / mjb_step21_prefix /
+	// mjb_step2_rk_prefix (finish it) or mjb_reset / mjb_step (abandon it, whole batch) may follow; a split abandoned BEFORE
+	// mjb_step_rest is simply restarted here.
+	if (b->split_ncb >= 0 && b->split_rest_done && b->split_ncb < b->nenv)
+		return fail(MJB_EINVAL, "mjb_step1_prefix: a split step of prefix %d is still open and its other envs already took the step "
+		                        "(finish it with mjb_step2_prefix, or abandon it with mjb_reset / mjb_step)", b->split_ncb);
+	int rc = join_rest(b);
+	if (rc) return rc;
+	rc = ensure_ws(b);
 	if (rc) return rc;
 	b->split_ncb = ncb;
 	b->split_rest_done = false;
@@ -2265,6 +2290,8 @@ int mjb_set_ctrl_noise(mjb_batch *b, double ctrl_noise_std, double ctrl_noise_ra
 	}
 	return MJB_OK;
 }
+
+int mjb_noise_mode(const mjb_batch *b) { return b ? b->noise_mode : 0; }
 
 void *mjb_get_stream(mjb_batch *b) { return b ? (void *)b->stream : nullptr; }
 
@@ -2836,8 +2863,11 @@ int mjb_hwsim_set_period(mjb_batch *b, double control_period)
 {
 	if (!b) return fail(MJB_EINVAL, "null batch");
 	if (b->hw.n <= 0) return fail(MJB_EINVAL, "mjb_hwsim_set_period before mjb_hwsim_configure");
-	if (control_period > 0 && control_period < b->model->h.timestep[0])  // (the reference refuses it too, :100-104)
-		return fail(MJB_EINVAL, "mjb_hwsim_set_period: control period %g below the simulation timestep %g", control_period, b->model->h.timestep[0]);
+	// (a period below the timestep is accepted with a warning, as the reference's load() does, :100-105 -- ROS_WARN and carry on: the
+	//  cadence test `sim_period >= control_period` then holds at every step, i.e. the controller updates every step)
+	if (control_period > 0 && control_period < b->model->h.timestep[0])
+		fprintf(stderr, "mjb_hwsim_set_period: desired controller update period (%g s) is faster than the simulation timestep (%g s)\n",
+		        control_period, b->model->h.timestep[0]);
 	HIP_TRY(hipSetDevice(b->device));
 	HIP_TRY(hipStreamSynchronize(b->stream));
 	const int n = b->hw.n;

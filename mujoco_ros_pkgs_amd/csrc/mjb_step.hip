@@ -3395,6 +3395,8 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 				if (++rk == 4) break;
 				if (rksplit) {  // the next evaluation's first half, then back to the host for its callbacks
 					forward_first<G, CON, DENSE>(P, e, compact);
+					// (mjData.energy follows the evaluation, as in the fused step, mjb_step2_prefix and the oracle's mjo_step2_rk)
+					if (P->m.enableflags & MJB_ENBL_ENERGY) VIEW(P, compact, energy<G>(m, L, lite(e)));
 					break;
 				}
 			}

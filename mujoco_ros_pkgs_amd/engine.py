@@ -245,6 +245,10 @@ class Batch:
         _check(self.lib.mjb_set_ctrl_noise(self.ptr, float(std), float(rate), int(seed), int(env_offset)),
                "mjb_set_ctrl_noise")
 
+    def noise_mode(self):
+        """How the last fused launch got its ctrl-noise normals (mjb_noise_mode)."""
+        return ("in-kernel", "same-stream", "side-stream")[int(self.lib.mjb_noise_mode(self.ptr))]
+
     def time_steps(self, nsteps, nlaunch):
         ms = C.c_double(0)
         _check(self.lib.mjb_time_steps(self.ptr, int(nsteps), int(nlaunch), C.byref(ms)), "mjb_time_steps")

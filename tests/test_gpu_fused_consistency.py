@@ -238,6 +238,19 @@ def test_prefix_split_step_equals_whole_batch_steps(asset, ncb):
             assert np.allclose(x[:ncb], y[:ncb], rtol=0, atol=1e-9 * (1 + np.abs(x).max())), f"chained split steps: {f}"
         else:
             assert np.array_equal(x[:ncb], y[:ncb]), f"chained split steps: {f}"
+    # abandoning a split step: before mjb_step_rest a new mjb_step1_prefix restarts it; after it the other envs have taken
+    # the step, so mjb_step1_prefix is refused until the split is finished or the whole batch is reset / stepped
+    assert lib.mjb_step1_prefix(c.ptr, ncb) == 0 and lib.mjb_step1_prefix(c.ptr, ncb) == 0
+    assert lib.mjb_step_rest(c.ptr, ncb) == 0
+    if ncb < nenv:
+        assert lib.mjb_step1_prefix(c.ptr, ncb) != 0
+    assert lib.mjb_step2_prefix(c.ptr, ncb) == 0
+    b.step(1)
+    assert np.array_equal(b.get("qpos")[ncb:], c.get("qpos")[ncb:])
+    assert lib.mjb_step1_prefix(c.ptr, ncb) == 0 and lib.mjb_step_rest(c.ptr, ncb) == 0
+    c.reset()                                                   # abandons the open split, waits for the rest launch
+    assert lib.mjb_step1_prefix(c.ptr, ncb) == 0 and lib.mjb_step2_prefix(c.ptr, ncb) == 0
+    assert np.all(np.isfinite(c.get("qpos")))
     a.close()
     b.close()
     c.close()

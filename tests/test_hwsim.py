@@ -176,6 +176,9 @@ def test_oracle_cadence_semantics(oracle_built):
     # period does, one step late to start
     _, _, cad2, wrote2, stamps2 = _cadence_rollout(oracle_built, model, cfg, q0, cp, cv, ce, 6, dt)
     assert [s[0] for s in stamps2] == [0] + [k * ns for k in range(1, 6)]
+    # a period BELOW the timestep (the reference only warns, :100-105): sim_period >= control_period at every step -> same cadence
+    _, _, _, wrote4, stamps4 = _cadence_rollout(oracle_built, model, cfg, q0, cp, cv, ce, 6, 0.5 * dt)
+    assert wrote4 == wrote2 and stamps4 == stamps2
     # reset: time back to 0 -> stamps re-armed, nothing written on the reset step, first write one step later again
     _, _, _, wrote3, stamps3 = _cadence_rollout(oracle_built, model, cfg, q0, cp, cv, ce, 10, 4 * dt, reset_at=6)
     assert wrote3 == [False] + [True] * 5 + [False] + [True] * 3 and stamps3[6] == (0, 0) and stamps3[7] == (ns, ns)
@@ -194,8 +197,22 @@ def test_gpu_cadence_matches_oracle(oracle_built):
     cm = engine.CompiledModel(model)
     b = engine.Batch(cm, nenv)
     b.hwsim_configure(spec)
-    with pytest.raises(Exception):
-        b.hwsim_set_period(0.5 * dt)     # below the timestep: refused, as the reference's plugin refuses to load
+    # below the timestep: ACCEPTED with a warning, as the reference's load() does (mujoco_ros_control_plugin.cpp:100-105, ROS_WARN and
+    # carry on) -- the controller then updates at every step after the first: GPU against the oracle's cadence with that period
+    b2 = engine.Batch(cm, nenv)
+    b2.hwsim_configure(spec)
+    b2.hwsim_set_period(0.5 * dt)
+    b2.hwsim_set_command("position", cp)
+    b2.hwsim_set_command("velocity", cv)
+    b2.hwsim_set_command("effort", ce)
+    b2.set("qpos", qpos)
+    b2.step(12)
+    d, _, _, wrote, stamps = _cadence_rollout(oracle_built, model, cfg, qpos[2], cp[2], cv[2], ce[2], 12, 0.5 * dt)
+    ns = round(dt * 1e9)
+    assert wrote == [False] + [True] * 11 and [s[0] for s in stamps] == [0] + [k * ns for k in range(1, 12)]
+    np.testing.assert_allclose(b2.get("qpos")[2], d.qpos, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(b2.get("qfrc_applied")[2], d.qfrc_applied, rtol=0, atol=1e-7)
+    b2.close()
     b.hwsim_set_period(4 * dt)
     b.hwsim_set_command("position", cp)
     b.hwsim_set_command("velocity", cv)

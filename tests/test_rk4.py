@@ -60,10 +60,11 @@ def _model(kind):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["franka_like", "PGS", "Newton"])
 def test_gpu_rk4_matches_oracle(kind, oracle_built):
-    from mujoco_ros_pkgs_amd import engine
+    from mujoco_ros_pkgs_amd import engine, mjcf
     from conftest import random_franka_state
     from test_gpu_contact import scenario_states
-    model = _model(kind)
+    model = mjcf.Model(dict(_model(kind)))
+    model["enableflags"] = int(model["enableflags"]) | 2   # mjENBL_ENERGY: mjData.energy must follow the evaluations on every path
     assert model["integrator"] == 1
     nenv, K = 12, 20
     if kind == "franka_like":
@@ -84,9 +85,10 @@ def test_gpu_rk4_matches_oracle(kind, oracle_built):
                 b.step2()
         else:
             b.step(K)
-        outs.append((b.get("qpos"), b.get("qvel"), b.get("sensordata"), b.get("time")))
+        outs.append((b.get("qpos"), b.get("qvel"), b.get("sensordata"), b.get("time"), b.get("energy")))
         b.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])   # split == fused, bit for bit
+    assert np.array_equal(outs[0][4], outs[1][4]) and np.all(outs[0][4][:, 1] > 0)              # ... mjData.energy included
     # ... and so are chained split steps (second half of one step + first half of the next in one launch, mjb_step21_prefix)
     b = engine.Batch(cm, nenv)
     b.set("qpos", qpos)
@@ -112,9 +114,10 @@ def test_gpu_rk4_matches_oracle(kind, oracle_built):
                 assert np.allclose(b.get("time")[:, 0], (0.5, 0.5, 1.0, 1.0)[rk] * h, rtol=0, atol=1e-15)
     assert np.array_equal(b.get("qpos"), outs[0][0]) and np.array_equal(b.get("qvel"), outs[0][1])
     assert np.array_equal(b.get("sensordata"), outs[0][2])
+    assert np.array_equal(b.get("energy"), outs[0][4])      # the energy of the LAST evaluation, as the fused step leaves it
     assert b.lib.mjb_step2_rk_prefix(b.ptr, nenv, 0) != 0   # (no split step open)
     b.close()
-    q, v, sd, t = outs[0]
+    q, v, sd, t, _ = outs[0]
     oq, ov, osd = oracle_built.rollout(model, qpos, qvel, K, ctrl=ctrl)
     tol = 1e-9 if kind == "franka_like" else 1e-7
     assert np.abs(q - oq).max() < tol and np.abs(v - ov).max() < 100 * tol, (np.abs(q - oq).max(), np.abs(v - ov).max())
