@@ -14,7 +14,9 @@ Rank 0 prints ONE JSON line.
 With N > 1 and no torch.distributed environment the script spawns its own ranks (one process per GPU through
 ``python -m torch.distributed.run`` on 127.0.0.1); under torchrun it uses the environment it is given.
 ``--config`` selects the BASELINE workload: 2 = configs[1] (default, the headline metric), 3 = configs[2]
-(Franka + table + cube, PGS), 5 = configs[4] (Shadow-Hand-like, Newton + elliptic cones; per-GPU shard of 1024 envs).
+(Franka + table + cube, PGS), 5 = configs[4] (Shadow-Hand-like, Newton + elliptic cones, the high-contact POWER GRASP workload since
+round 5; per-GPU shard of 1024 envs).  ``--model shadow_hand_like`` is the round 1 - 4 config-5 workload (cube resting in the half-open
+palm, ~5 contacts / ~20 rows), reported as ``5_light``.
 """
 import argparse
 import json
@@ -29,7 +31,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_ENV_STEP = {"franka_like": 712, "franka_table": 1072, "shadow_hand_like": 2136}  # 8*(2nq+2nv+2nv+nu+S)+8
+ALGO_BYTES_PER_ENV_STEP = {"franka_like": 712, "franka_table": 1072, "shadow_hand_like": 2136, "shadow_hand_grasp": 2136}  # 8*(2nq+2nv+2nv+nu+S)+8
 # per-model workload: (BASELINE config label, OU ctrl-noise std [= 0.5 * ctrlrange of the big actuators], default envs per GPU,
 #                      default physics steps per launch, BASELINE config number)
 WORKLOADS = {
@@ -41,9 +43,16 @@ WORKLOADS = {
     # (1000 steps per launch like the other configs since the four-envs-per-CU frame: 1024 envs = 1024 slots, every env has a slot of
     #  its own and a launch lasts as long as its slowest env's chain -- over 1000 steps the chains' sums even out: 4.7 M at 100 steps
     #  per launch, 5.0 M at 1000.  Slots x launch length x chunking: profiles/r03_cfg5_residency.txt)
-    "shadow_hand_like": ("BASELINE configs[4]: Shadow-Hand-like 24-DoF hand + in-hand cube (Newton, elliptic cones)", 0.1, 1024, 1000, 5),
+    # (round 5, VERDICT r04 #1: configs[4] says "high contact count" -- the power grasp of tools/gen_hand_model.py: fingers servoed
+    #  closed over the cube, mean ncon ~21, mean nefc ~87, p99 ~115, ~85 % of the env-steps beyond 64 rows, i.e. on the 4-rows-per-lane
+    #  Newton solver over the env's HBM row block; every constrained line carries the measured ncon / nefc statistics)
+    "shadow_hand_grasp": ("BASELINE configs[4]: Shadow-Hand-like 24-DoF hand, cube held in a power grasp (high contact count; Newton, elliptic cones)", 0.1, 1024, 1000, 5),
+    # (the round 1 - 4 workload of config 5: the cube RESTS in the half-open palm, mean ncon 4 - 5, ~20 rows -- kept as "5_light")
+    "shadow_hand_like": ("BASELINE configs[4] LIGHT: Shadow-Hand-like 24-DoF hand, cube resting in the half-open palm (Newton, elliptic cones)", 0.1, 1024, 1000, 5),
 }
-CONFIG_MODEL = {2: "franka_like", 3: "franka_table", 4: "franka_table", 5: "shadow_hand_like"}
+CONFIG_MODEL = {2: "franka_like", 3: "franka_table", 4: "franka_table", 5: "shadow_hand_grasp"}
+# key of a workload in `other_configs` and in the profiles/ file names (rNN_cfg<tag>_*)
+WORKLOAD_TAG = {"franka_like": "2", "franka_table": "3", "shadow_hand_grasp": "5", "shadow_hand_like": "5_light"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable)
 FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 vector peak; replaced by the measured fma rate when the profile holds one
 
@@ -83,6 +92,9 @@ def initial_state(name, model, nenv, seed):
     if name == "shadow_hand_like":
         from mujoco_ros_pkgs_amd import workloads
         return workloads.hand_grasp_states(model, nenv, seed)
+    if name == "shadow_hand_grasp":
+        from mujoco_ros_pkgs_amd import workloads
+        return workloads.hand_power_grasp_states(model, nenv, seed)
     return synthetic_state(model, nenv, seed)
 
 
@@ -120,7 +132,7 @@ def _time_oracle(name, model, noise_std, nenv, threads, target_s, pin=False):
     return nenv * nsteps2 / dt, nsteps2, dt
 
 
-def cpu_baseline(name, model, noise_std):
+def cpu_baseline(name, model, noise_std, with_mujoco=True):
     """CPU figures beside the GPU number, all on a bounded sample of the same workload:
     the oracle ("port": from-scratch restatement, gcc -O3 -march=native) on all host threads and on ONE pinned thread,
     and real MuJoCo through $MUJOCO_DIR when that library exists on the box (else the literal NOT MEASURED)."""
@@ -134,6 +146,8 @@ def cpu_baseline(name, model, noise_std):
                      f"(gcc -O3 -march=native), {cores} threads, {dt_all:.1f} s",
            "single_thread": {"value": v_one, "unit": "env-steps/s", "cores": 1,
                              "sample": f"4 envs x {n_one} steps, one thread pinned to one core, {dt_one:.1f} s"}}
+    if not with_mujoco:
+        return out
     try:
         from oracle import mujoco_ref
         out["mujoco"] = mujoco_ref.time_reference(name, noise_std)
@@ -161,7 +175,7 @@ def _load_json(*names):
     return None, None
 
 
-def roofline_block(name, cfgno, solver_tag, E, S, samples):
+def roofline_block(name, tag, solver_tag, E, S, samples):
     """`roofline` object of one workload: algorithmic bytes per launch / median kernel time against the HBM peak, the
     counter-measured HBM traffic and executed fp64 work when profiles/ holds a PMC summary collected on THESE kernel sources
     (fingerprint check: mujoco_ros_pkgs_amd/provenance.py) at this (envs, substeps), and the useful fp64 rate from the
@@ -171,14 +185,19 @@ def roofline_block(name, cfgno, solver_tag, E, S, samples):
     traffic, fp64, source = None, None, None
     # (the newest round's counter summary of this config; one collected on THESE kernel sources wins)
     import glob
-    cands = sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_cfg{cfgno}{solver_tag}_pmc_summary.json"))), reverse=True)
+    cands = sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_cfg{tag}{solver_tag}_pmc_summary.json"))), reverse=True)
     pmc, pmc_file = _load_json(*cands) if cands else (None, None)
     for n in cands:
         cand, _ = _load_json(n)
         if cand is not None and cand.get("csrc_sha") == provenance.csrc_sha():
             pmc, pmc_file = cand, n
             break
-    flops, flops_file = _load_json("r04_oracle_flops.json", "r03_oracle_flops.json", "r02_oracle_flops.json")
+    flops, flops_file = None, None
+    for fn in ("r05_oracle_flops.json", "r04_oracle_flops.json", "r03_oracle_flops.json", "r02_oracle_flops.json"):  # newest file that has this workload
+        cand, _ = _load_json(fn)
+        if cand and name in cand:
+            flops, flops_file = cand, fn
+            break
     if pmc is not None:
         if pmc.get("csrc_sha") != provenance.csrc_sha():
             source = f"STALE: profiles/{pmc_file} was collected on other kernel sources ({pmc.get('csrc_sha')} != {provenance.csrc_sha()}); not reported"
@@ -215,14 +234,23 @@ def roofline_block(name, cfgno, solver_tag, E, S, samples):
     return out
 
 
-def measure_other_config(cfgno, device, launches=5):
-    """One of the other BASELINE workloads (3 = configs[2], 5 = configs[4]'s per-GPU shard), measured in this process after
-    the headline timing so that the DRIVER's record carries it (VERDICT r02 #3a): `launches` timed fused launches bracketed
-    by synchronisation (five, like the standalone `--config N` run: config 3's first launches after the synthetic start are its
-    heaviest, three of them read 2 % low), then five single-launch kernel samples."""
+def workload_stats(batch):
+    """ncon / nefc / solver-iteration statistics of the env-steps the batch ran since set_stats(True) (device-side counters,
+    mjb_set_stats; VERDICT r04 #1: a reader must be able to tell what the contact benchmark asked of the solver)."""
+    st = batch.stats()
+    return {"env_steps_counted": st["evaluations"], "ncon_mean": round(st["ncon_mean"], 3), "ncon_p50": st["ncon_p50"], "ncon_p99": st["ncon_p99"],
+            "ncon_max": st["ncon_max"], "nefc_mean": round(st["nefc_mean"], 3), "nefc_p50": st["nefc_p50"], "nefc_p99": st["nefc_p99"],
+            "nefc_max": st["nefc_max"], "rows_gt64_share": round(st["rows_gt64_share"], 5), "solver_iters_mean": round(st["solver_iter_mean"], 3)}
+
+
+def measure_other_config(name, device, launches=5, with_cpu=True):
+    """One of the other BASELINE workloads (franka_table = configs[2], shadow_hand_grasp = configs[4]'s per-GPU shard, shadow_hand_like =
+    its light predecessor), measured in this process after the headline timing so that the DRIVER's record carries it (VERDICT r02
+    #3a): `launches` timed fused launches bracketed by synchronisation (five, like the standalone `--config N` run: config 3's first
+    launches after the synthetic start are its heaviest, three of them read 2 % low), then five single-launch kernel samples; the
+    device-side ncon / nefc / iteration counters run over exactly the timed launches; the CPU oracle legs on the same workload."""
     from mujoco_ros_pkgs_amd import engine, mjcf
-    name = CONFIG_MODEL[cfgno]
-    label, noise_std, E, S, _ = WORKLOADS[name]
+    label, noise_std, E, S, cfgno = WORKLOADS[name]
     model = mjcf.Model(dict(mjcf.load_asset(name)))
     model["enableflags"] = int(model["enableflags"]) | 2
     cm = engine.CompiledModel(model)
@@ -233,11 +261,15 @@ def measure_other_config(cfgno, device, launches=5):
     batch.set_ctrl_noise(noise_std, 0.1, 12345, 0)
     batch.step(S)
     batch.synchronize()
+    batch.set_stats(True)
     t0 = time.perf_counter()
     for _ in range(launches):
         batch.step(S)
     batch.synchronize()
     elapsed = time.perf_counter() - t0
+    stats = workload_stats(batch)
+    batch.set_stats(False)
+    noise_mode = batch.noise_mode()
     finite = bool(np.all(np.isfinite(batch.get("qpos"))))
     samples = sorted(batch.time_steps(S, 1) for _ in range(5))
     out = {"metric": "env_steps_per_sec", "value": E * S * launches / elapsed, "unit": "env-steps/s", "n_gpus": 1,
@@ -246,7 +278,8 @@ def measure_other_config(cfgno, device, launches=5):
                       "envs_per_gpu": E, "physics_steps_per_launch": S, "model": name,
                       "solver": {0: "PGS", 1: "CG", 2: "Newton"}[int(model["solver"])],
                       "nconmax": int(model["nconmax"]), "nefcmax": int(model["nefcmax"]),
-                      "fused_frame_bytes": int(batch.lib.mjb_frame_bytes(cm.ptr, 1)),
+                      "fused_frame_bytes": batch.fused_frame()[1], "fused_frame": ("default", "default", "wide (128 rows in LDS)")[batch.fused_frame()[0]],
+                      "noise_pregen": noise_mode,
                       "state_finite": finite, "auto_resets": batch.warning_count(),
                       # (mjWARN_CONTACTFULL / mjWARN_CNSTRFULL events of every env-step this batch ran, warm-up included, and their rate:
                       #  config 3's 16-contact capacity -- SURVEY.md §8's table, what keeps eight lean frames per CU -- is exceeded
@@ -254,9 +287,12 @@ def measure_other_config(cfgno, device, launches=5):
                       #  profiles/r04_cfg3_overflow.txt; bounded in tests/test_gpu_full_size.py)
                       "contactfull": batch.warning("contactfull"), "cnstrfull": batch.warning("cnstrfull"),
                       "overflow_per_env_step": (batch.warning("contactfull") + batch.warning("cnstrfull")) / float(E * S * (launches + 6))},
-           "roofline": roofline_block(name, cfgno, "", E, S, samples)}
+           "workload_stats": stats,
+           "roofline": roofline_block(name, WORKLOAD_TAG[name], "", E, S, samples)}
     batch.close()
     cm.close()
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline(name, model, noise_std, with_mujoco=False)
     return out
 
 
@@ -397,6 +433,9 @@ def dry_run(args):
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("WORLD_SIZE", "1")
     dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=args.dist_timeout))
+    if dist.get_world_size() != args.gpus:  # (the same rule as gpu_run: the line reports the process group, and fails when it is not the one asked for)
+        raise RuntimeError(f"--dry-ranks {args.gpus} but the process group has {dist.get_world_size()} rank(s) (WORLD_SIZE={world})")
+    world = dist.get_world_size()
     E, S, nsd = 64, args.substeps or 10, 8
     env_lo, _ = sharding.shard_range(rank, world, E)
     rt = sharding.ThreadStreams()
@@ -435,7 +474,8 @@ def dry_run(args):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "DRY RUN: stub batch, gloo, thread streams -- no GPU, the value means nothing",
             "dry_ranks": world, "exchange_ok": ok, "rank_ms_per_step": {"min": 1e3 * min(per_rank) / args.steps, "max": 1e3 * max(per_rank) / args.steps},
-            "exchange_ms": xch.last_ms(), "config": {"workload": "dry run", "rccl_ranks": 0, "gloo_ranks": world, "shard": [env_lo, env_lo + E]}})
+            "exchange_ms": xch.last_ms(), "cpu_baseline_leg": world == 1 and not args.no_cpu_baseline,  # (gpu_run's guard: rank 0 at N = 1 only)
+            "config": {"workload": "dry run", "rccl_ranks": 0, "gloo_ranks": dist.get_world_size(), "shard": [env_lo, env_lo + E]}})
     dist.barrier()
     rt.close()
     dist.destroy_process_group()
@@ -475,6 +515,11 @@ def gpu_run(args, name):
         os.environ.setdefault("WORLD_SIZE", "1")
         # (a rank that never arrives fails the collectives of the others after --dist-timeout instead of hanging them: guarded())
         dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=args.dist_timeout))
+        # (the line's n_gpus / rccl_ranks are what the process group SAYS, not what the environment promised: a launcher that started
+        #  fewer ranks than --gpus must not produce a line that looks like an N-GPU measurement)
+        if dist.get_world_size() != args.gpus and not force_gather:
+            raise RuntimeError(f"--gpus {args.gpus} but the RCCL process group has {dist.get_world_size()} rank(s) (WORLD_SIZE={world})")
+        world = dist.get_world_size()
 
     from mujoco_ros_pkgs_amd import binding, engine, mjcf, sharding
 
@@ -511,8 +556,22 @@ def gpu_run(args, name):
             dist.barrier()
         torch.cuda.synchronize()
 
+    constrained = int(model["nefcmax"]) > 0
+    if constrained:
+        batch.set_stats(True)    # device-side ncon / nefc / iteration counters over everything this rank runs from here on (warm-up included)
     elapsed, per_rank = timed_region(args, one_step, fence, dist, world, lambda v: torch.tensor(v, dtype=torch.float64, device=dev))
     sens_all, met = xch.finish()
+    noise_mode = batch.noise_mode()
+    noise_modes = [noise_mode]
+    if world > 1:  # every rank's generator mode: eight side-stream generators + RCCL kernels compete for the CUs the step kernel fills
+        code = torch.tensor([("in-kernel", "same-stream", "side-stream").index(noise_mode)], dtype=torch.int32, device=dev)
+        codes = [torch.zeros_like(code) for _ in range(world)]
+        dist.all_gather(codes, code)
+        noise_modes = [("in-kernel", "same-stream", "side-stream")[int(c.item())] for c in codes]
+    stats = None
+    if constrained:
+        stats = workload_stats(batch)
+        batch.set_stats(False)
     met = met.cpu().numpy()
     metrics = dict(zip(binding.METRIC_NAMES, (float(x) for x in met)))
 
@@ -538,25 +597,30 @@ def gpu_run(args, name):
                        "ctrl": f"on-device OU noise (Philox seed 12345, tau 0.1 s, std {noise_std:g})",
                        "parallelism": f"env-sharded x{world}, RCCL all-gather of sensordata + 16-double metrics all-reduce per launch, "
                                       "side stream (overlaps the next launch)" if world > 1 else "single GPU",
-                       "rccl_ranks": world if xch.active else 0, "state_finite": finite, "auto_resets": resets},
+                       "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1) if xch.active else 0,
+                       "noise_pregen": noise_mode if len(set(noise_modes)) == 1 else noise_modes, "state_finite": finite, "auto_resets": resets},
             # (attribution of a weak-scaling loss: the slowest and the fastest rank's own time per step, and the duration of the last
             #  exchange -- staging wait + all-gather + two all-reduces -- measured with an event pair on the side stream)
             "rank_ms_per_step": {"min": 1e3 * min(per_rank) / args.steps, "max": 1e3 * max(per_rank) / args.steps},
             "exchange_ms": xch.last_ms(),
             "metrics": metrics,
-            "roofline": roofline_block(name, cfgno, solver_tag, E, S, samples),
+            "roofline": roofline_block(name, WORKLOAD_TAG.get(name, str(cfgno)), solver_tag, E, S, samples),
         }
-        out["config"]["fused_frame_bytes"] = int(batch.lib.mjb_frame_bytes(cm.ptr, 1))
+        if stats is not None:
+            out["workload_stats"] = stats
+            out["config"]["contactfull"], out["config"]["cnstrfull"] = batch.warning("contactfull"), batch.warning("cnstrfull")
+        out["config"]["fused_frame_bytes"] = batch.fused_frame()[1]
+        out["config"]["fused_frame"] = ("default", "default", "wide (128 rows in LDS)")[batch.fused_frame()[0]]
         default_run = world == 1 and not (args.config or args.model or args.solver or args.nefcmax or args.nconmax or args.envs or
                                           args.substeps or args.lanes or args.epb)
         if default_run and not args.no_other_configs:
             # the other BASELINE workloads, same process, same box (configs[2] and the per-GPU shard of configs[4])
             out["other_configs"] = {}
-            for c in (3, 5):
+            for other in ("franka_table", "shadow_hand_grasp", "shadow_hand_like"):
                 try:
-                    out["other_configs"][str(c)] = measure_other_config(c, local_rank)
+                    out["other_configs"][WORKLOAD_TAG[other]] = measure_other_config(other, local_rank, with_cpu=not args.no_cpu_baseline)
                 except Exception as exc:  # never let an extra take the headline line down
-                    out["other_configs"][str(c)] = {"error": f"{type(exc).__name__}: {exc}"}
+                    out["other_configs"][WORKLOAD_TAG[other]] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(name, model, noise_std)
         emit_line(real_stdout, out)

@@ -127,7 +127,11 @@ const char *mjb_field_name(int field);
 /* Doubles in one per-env LDS frame (all double fields) — layout documented in DESIGN.md. */
 int mjb_frame_doubles(const mjb_model *m);
 /* Bytes of LDS one env occupies (doubles + ints): fused != 0 -> the compact frame of mjb_step, else the full frame of
- * mjb_forward / mjb_step1 / mjb_step2.  Resident envs per CU = floor(160 KiB / that). */
+ * mjb_forward / mjb_step1 / mjb_step2.  Resident envs per CU = floor(160 KiB / that).
+ * fused == 2: the WIDE fused frame of a Newton model with more than 128 rows of capacity (128 rows of efc_J in LDS instead of 64,
+ * two envs per CU instead of four; == the default fused frame for every other model).  A batch switches its long fused launches
+ * to it when more than a quarter of the previous launch's env-steps had more than 64 rows, and back below 5 % (MJB_WIDE_FRAME=0 / 1
+ * pins the choice); mjb_fused_frame(batch) tells which one the last launch ran on. */
 int mjb_frame_bytes(const mjb_model *m, int fused);
 /* Diagnostic: offset (doubles; ints for int fields; -1 = absent) of data field `field` in the fused / full frame. */
 int mjb_frame_offset(const mjb_model *m, int field, int fused);
@@ -232,6 +236,8 @@ int mjb_set_ctrl_noise(mjb_batch *b, double ctrl_noise_std, double ctrl_noise_ra
  * step kernel, 1 = by mjb_noise_kernel ahead of the step kernel on the same stream, 2 = by mjb_noise_kernel on a side stream while
  * the previous launch ran (unconstrained kernels only; budget MJB_NOISE_PREGEN_MB).  Measurement aid, no reference counterpart. */
 int mjb_noise_mode(const mjb_batch *b);
+/* 1 = the default fused frame, 2 = the wide one (mjb_frame_bytes): what the batch's fused launches currently run on. */
+int mjb_fused_frame(const mjb_batch *b);
 
 /* Stream control: the hipStream_t (as void*) kernels are launched on; default is a stream the
  * batch owns.  mjb_synchronize waits for it. */
@@ -254,6 +260,17 @@ int mjb_warning_count(mjb_batch *b, unsigned long long *count);
  *                                same rule.)
  * The other entries stay 0. */
 int mjb_warning(mjb_batch *b, int which, unsigned long long *count);
+
+/* Workload statistics of the constrained kernels, accumulated on the device by every forward evaluation that reaches the constraint
+ * solver (one per env-step under Euler): what the workload actually asks of the solver.  Off by default; mjb_set_stats(b, 1) allocates
+ * and ZEROES the counters, mjb_set_stats(b, 0) stops counting.  Layout of out[MJB_NSTATS] (mjb_get_stats):
+ *   [0] evaluations counted   [1] sum of mjData.solver_iter (PGS sweeps / Newton / CG iterations)
+ *   [2 + r], r = 0..256       histogram of nefc (rows of the evaluation; the last bin collects r >= 256)
+ *   [259 + c], c = 0..128     histogram of ncon
+ * Measurement aid (bench.py's ncon / nefc fields); MuJoCo's counterpart is reading d->ncon, d->nefc, d->solver_iter after mj_step. */
+enum { MJB_NSTATS = 2 + 257 + 129 };
+int mjb_set_stats(mjb_batch *b, int on);
+int mjb_get_stats(mjb_batch *b, unsigned long long *out);
 
 /* Aggregate metrics of the batch (the <= 16-double vector the RCCL all-reduce carries), computed on the
  * device from the state arrays on the batch's stream:

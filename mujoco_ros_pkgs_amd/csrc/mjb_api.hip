@@ -89,6 +89,11 @@ struct mjb_model {
 	int eulerdamp = 0, maxdepth = 0, kin_rounds = 0, need_rnepost = 0, nfriction = 0, sub_nt = 0, dofanc_max = 0, flv_n = 0;
 	int field_size[MJB_F_COUNT]{};
 	FrameLayout L{}, Lc{};
+	// kernel variant 4 (Newton, capacity > 128 rows): a second, WIDE fused frame that holds 128 rows of efc_J and of every per-row
+	// array (two envs per CU instead of four).  A batch whose env-steps mostly exceed 64 rows runs its long launches on it: those steps
+	// take the two-rows-per-lane solver on LDS instead of the four-rows-per-lane one on the env's block in HBM (launch(), wide policy).
+	FrameLayout Lw{};
+	bool has_wide = false;
 };
 
 struct mjb_batch {
@@ -110,9 +115,17 @@ struct mjb_batch {
 	hipStream_t rest_stream = nullptr;  // the fused launch of the non-callback envs runs beside the callback envs' second half
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	bool rest_pending = false;
+	// wide-frame policy of kernel variant 4 (launch()): counters of the last long fused launch -- env-steps, those beyond 64 rows, those
+	// beyond 128 -- copied to pinned host memory behind it; the next long launch waits for that copy (the launch has ended by then or is
+	// about to) and picks its frame from them: deterministic for a given sequence of launches
+	bool wide = false;
+	unsigned int *rowstat_dev = nullptr, *rowstat_host = nullptr;
+	hipEvent_t ev_rowstat = nullptr;
+	bool rowstat_pending = false;
 	unsigned char *mask_dev = nullptr;
 	KernelParams *params_dev = nullptr;  // device copy of {dm, L, st, nz}
 	double *metrics_dev = nullptr;       // [16] mjb_metrics
+	unsigned long long *stats_dev = nullptr;  // [MJB_NSTATS] mjb_set_stats (st.stats points here while counting)
 	int *pair_i_dev = nullptr;           // device address of the per-pair int records inside the blob (mjb_register_collision patches them)
 	unsigned long long steps_taken = 0;  // steps since the batch was made (step_counter is the 32-bit Philox counter)
 	bool params_dirty = true;
@@ -209,7 +222,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact, int jrows_req = 
 	// more rows keeps J in the env's block of DevState::efc_Jg (config 5 never has: what lets two of its envs share a CU's LDS)
 	int jrows = d.nefcmax;
 	if (compact && d.solver == MJB_SOL_NEWTON && d.nefcmax > 128) {
-		jrows = jrows_req > 0 ? std::max(4, std::min(64, jrows_req)) : 64;
+		jrows = jrows_req > 0 ? std::max(4, std::min(128, jrows_req)) : 64;
 		if (const char *v = getenv("MJB_DEBUG_JROWS")) jrows = std::max(4, std::min(64, atoi(v)));  // test knob: force the HBM path
 	}
 	L.jrows = jrows;
@@ -521,6 +534,14 @@ void choose_fused_layout(mjb_model *M)
 {
 	compute_layout(M, M->Lc, true);
 	const mjb_model_desc &d = M->h;
+	M->Lw = M->Lc;
+	M->has_wide = false;
+	if (d.solver == MJB_SOL_NEWTON && d.nefcmax > 128 && getenv("MJB_DEBUG_FRAME_ROWS")) {  // measurement knob: rows of J in THE fused frame
+		compute_layout(M, M->Lc, true, atoi(getenv("MJB_DEBUG_FRAME_ROWS")));
+		M->Lw = M->Lc;
+		if (getenv("MJB_DEBUG_LAYOUT")) dump_layout(M, M->Lc);
+		return;
+	}
 	if (!(d.solver == MJB_SOL_NEWTON && d.nefcmax > 128) || getenv("MJB_DEBUG_JROWS")) {
 		if (getenv("MJB_DEBUG_LAYOUT")) dump_layout(M, M->Lc);
 		return;
@@ -539,6 +560,13 @@ void choose_fused_layout(mjb_model *M)
 	compute_layout(M, M->Lc, true, pick);
 	if (getenv("MJB_DEBUG_LAYOUT"))  // development knob
 		dump_layout(M, M->Lc);
+	// the wide frame: 128 rows (two per lane), when two of them fit a CU's LDS
+	compute_layout(M, M->Lw, true, 128);
+	const int wbytes = ((M->Lw.ndouble * 8 + M->Lw.nint * 4) + 15) & ~15;
+	M->has_wide = M->Lw.jrows > M->Lc.jrows && 2 * ((wbytes + 1279) / 1280) <= 128;
+	if (!M->has_wide) M->Lw = M->Lc;
+	compute_layout(M, M->Lc, true, pick);  // (compute_layout also sets model-wide derived fields: leave them as the default frame's)
+	if (getenv("MJB_DEBUG_LAYOUT") && M->has_wide) dump_layout(M, M->Lw);
 }
 
 // Sensors whose value is a plain copy of frame doubles (joint / actuator scalars, clock, subtree com, global
@@ -546,15 +574,15 @@ void choose_fused_layout(mjb_model *M)
 void build_sensor_tables(mjb_model *M)
 {
 	const mjb_model_desc &h = M->h;
-	std::vector<std::pair<int, int>> cp[2][3];
+	std::vector<std::pair<int, int>> cp[3][3];  // layouts: 0 full, 1 fused, 2 wide fused (== 1 when the model has none)
 	std::vector<int> slow[3];
 	for (int i = 0; i < h.nsensor; i++) {
 		const int st = h.sensor_needstage[i] - 1;
 		if (st < 0 || st > 2) continue;
 		const int type = h.sensor_type[i], id = h.sensor_objid[i], ot = h.sensor_objtype[i];
 		bool simple = h.sensor_cutoff[i] <= 0;
-		for (int lay = 0; lay < 2 && simple; lay++) {
-			const FrameLayout &L = lay ? M->Lc : M->L;
+		for (int lay = 0; lay < 3 && simple; lay++) {
+			const FrameLayout &L = lay == 0 ? M->L : (lay == 1 ? M->Lc : M->Lw);
 			int src = -1, n = 1;
 			switch (type) {
 			case MJB_SENS_JOINTPOS: src = L.qpos + h.jnt_qposadr[id]; break;
@@ -592,8 +620,8 @@ void build_sensor_tables(mjb_model *M)
 		if (M->sens_ncopy[st] > mx) mx = M->sens_ncopy[st];
 	}
 	M->sens_ncopy_max = mx;
-	M->sens_copy.assign((size_t)2 * 3 * (mx ? mx : 1) * 2, 0);
-	for (int lay = 0; lay < 2; lay++)
+	M->sens_copy.assign((size_t)3 * 3 * (mx ? mx : 1) * 2, 0);
+	for (int lay = 0; lay < 3; lay++)
 		for (int st = 0; st < 3; st++)
 			for (size_t k = 0; k < cp[lay][st].size() && (int)k < M->sens_ncopy[st]; k++) {
 				M->sens_copy[((size_t)(lay * 3 + st) * (mx ? mx : 1) + k) * 2] = cp[lay][st][k].first;
@@ -1216,7 +1244,7 @@ int mjb_frame_doubles(const mjb_model *m) { return m ? m->L.ndouble + m->L.nint 
 int mjb_frame_bytes(const mjb_model *m, int fused)
 {
 	if (!m) return fail(MJB_EINVAL, "null model");
-	const FrameLayout &L = fused ? m->Lc : m->L;
+	const FrameLayout &L = fused == 2 ? m->Lw : (fused ? m->Lc : m->L);  // (2: the wide fused frame of kernel variant 4, == 1 when the model has none)
 	return ((L.ndouble * 8 + L.nint * 4) + 15) & ~15;
 }
 int mjb_frame_offset(const mjb_model *m, int field, int fused)
@@ -1253,8 +1281,12 @@ void mjb_free_batch(mjb_batch *b)
 #undef MJB_DI
 	if (b->st.frame_ws) hipFree(b->st.frame_ws);
 	if (b->st.nwarn) hipFree(b->st.nwarn);
+	if (b->stats_dev) hipFree(b->stats_dev);
 	if (b->st.pgs_B) hipFree(b->st.pgs_B);
 	if (b->st.efc_Jg) hipFree(b->st.efc_Jg);
+	if (b->rowstat_dev) hipFree(b->rowstat_dev);
+	if (b->rowstat_host) hipHostFree(b->rowstat_host);
+	if (b->ev_rowstat) hipEventDestroy(b->ev_rowstat);
 	if (b->pack_dev) hipFree(b->pack_dev);
 	if (b->rest_stream) {
 		hipStreamSynchronize(b->rest_stream);
@@ -1444,6 +1476,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 #undef MJB_DI
 	s.nwarn = dev_alloc<unsigned long long>(MJB_NWARNING);
 	ok = ok && s.nwarn;
+	s.stats = nullptr;
 	s.prof = dev_alloc<unsigned long long>(64);
 	ok = ok && s.prof;
 	s.frame_ws = nullptr;
@@ -1465,7 +1498,17 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	if (h.solver == MJB_SOL_NEWTON && h.nefcmax > 128) {  // kernel variant 4: row data of the env-steps beyond the fused frame's 64 rows
 		s.efc_Jg = dev_alloc<double>((size_t)nenv * mjb_rowblock_doubles(h.nefcmax, h.nv, h.nconmax, M->Lc.hcs));
 		ok = ok && s.efc_Jg;
+		if (M->has_wide) {  // row counters of the wide-frame policy (launch())
+			b->rowstat_dev = dev_alloc<unsigned int>(4);
+			ok = ok && b->rowstat_dev && hipHostMalloc((void **)&b->rowstat_host, 4 * sizeof(unsigned int), hipHostMallocDefault) == hipSuccess &&
+			     hipEventCreateWithFlags(&b->ev_rowstat, hipEventDisableTiming) == hipSuccess;
+			if (ok) {
+				memset(b->rowstat_host, 0, 4 * sizeof(unsigned int));
+				ok = hipMemset(b->rowstat_dev, 0, 4 * sizeof(unsigned int)) == hipSuccess;
+			}
+		}
 	}
+	s.rowstat = b->rowstat_dev;
 	if (h.solver == MJB_SOL_PGS && h.nv <= 16 && h.nefcmax > 64) {
 		s.pgs_B = dev_alloc<double>((size_t)nenv * h.nefcmax * h.nv);  // (elliptic PGS never exceeds 64 rows: mjb_compile)
 		ok = ok && s.pgs_B;
@@ -1530,8 +1573,8 @@ static int sync_params(mjb_batch *b)
 		KernelParams kp;
 		kp.m = b->dm;
 		kp.L = b->L;
-		kp.Lc = b->model->Lc;
-		kp.use_compact = (b->st.use_xfrc || b->st.keep_frame) ? 0 : 1;
+		kp.Lc = b->wide ? b->model->Lw : b->model->Lc;
+		kp.use_compact = (b->st.use_xfrc || b->st.keep_frame) ? 0 : (b->wide ? 2 : 1);  // (the value doubles as the layout's index into the host-built copy tables)
 		kp.pad0 = 0;
 		kp.s = b->st;
 		kp.nz = b->nz;
@@ -1574,10 +1617,37 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 	hipStream_t stream = on ? on : b->stream;
 	const bool whole = env_lo == 0 && env_hi == b->nenv;
 	HIP_TRY(hipSetDevice(b->device));
-	int prc = sync_params(b);
-	if (prc) return prc;
 	const bool compact = mode == MJB_MODE_STEP && !b->st.use_xfrc && !b->st.keep_frame;
 	int variant = kernel_variant(b->model->h);
+	// Which fused frame (kernel variant 4 with a wide frame): a long whole-batch launch looks at the row counters of the previous one.
+	// More than a quarter of the env-steps beyond 64 rows: the wide frame (128 rows in LDS, two envs per CU) -- measured on the
+	// power-grasp workload of config 5 (94 % beyond 64 rows): 0.72 -> 2.41 M env-steps/s; fewer than 5 %: back to the default frame
+	// (four envs per CU: the light workload runs 7.8 M on it, 4.2 M on the wide one).  MJB_WIDE_FRAME=0 / 1 pins the choice.
+	bool count_rows = false;
+	if (variant == 4 && b->model->has_wide && b->rowstat_dev) {
+		static const int pinned = [] { const char *v = getenv("MJB_WIDE_FRAME"); return v ? atoi(v) : -1; }();
+		bool want = b->wide;
+		if (pinned >= 0) want = pinned != 0;
+		else if (compact && whole && nsteps >= 100) {
+			if (b->rowstat_pending) {
+				HIP_TRY(hipEventSynchronize(b->ev_rowstat));
+				b->rowstat_pending = false;
+				const double tot = b->rowstat_host[0], gt64 = b->rowstat_host[1];
+				if (tot > 0) {
+					if (!b->wide && gt64 > 0.25 * tot) want = true;
+					else if (b->wide && gt64 < 0.05 * tot) want = false;
+				}
+			}
+			count_rows = true;
+		}
+		if (want != b->wide) {
+			b->wide = want;
+			b->params_dirty = true;
+		}
+	}
+	int prc = sync_params(b);
+	if (prc) return prc;
+	const int fused_id = b->wide ? 2 : 1;
 	// plain PGS on the lean frame: when eight envs fit one CU's LDS, the 256-register build runs two waves per SIMD
 	if (variant == 1 && compact && 8 * mjb_frame_bytes(b->model, 1) <= mjb_max_lds_bytes()) variant = 9;
 	{
@@ -1597,7 +1667,7 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 			if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
 			return n;
 		}();
-		const int granules = (mjb_frame_bytes(b->model, 1) + 1279) / 1280;  // (gfx950: 128 LDS granules of 1280 bytes per CU)
+		const int granules = (mjb_frame_bytes(b->model, fused_id) + 1279) / 1280;  // (gfx950: 128 LDS granules of 1280 bytes per CU)
 		const int occ = std::min(variant == 9 ? 8 : 4, 128 / std::max(1, granules));  // (512-register kernels: one wave per SIMD)
 		own_slot = ncu > 0 && b->nenv <= occ * ncu;
 	}
@@ -1685,9 +1755,15 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 	}
 	const bool zspec = zuse && b->zdouble;
 	if (zspec) HIP_TRY(hipEventRecord(b->ev_noise_go, stream));  // (everything before this launch -- the last reader of the other half -- is done)
-	int rc = mjb_launch_step(b->params_dev, compact ? b->model->Lc : b->L, env_lo, env_hi, mode, nsteps, b->step_counter, b->lanes,
+	if (count_rows) HIP_TRY(hipMemsetAsync(b->rowstat_dev, 0, 4 * sizeof(unsigned int), stream));
+	int rc = mjb_launch_step(b->params_dev, compact ? (b->wide ? b->model->Lw : b->model->Lc) : b->L, env_lo, env_hi, mode, nsteps, b->step_counter, b->lanes,
 	                         b->epb, variant | (chunk << 8), (b->lanes == 16 && !b->env_mass && mode != MJB_MODE_STEP21 && b->model->h.integrator == MJB_INT_EULER && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16 && b->model->h.nu <= 16 && b->model->h.njnt <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, stream);
 	if (rc != 0) return fail(MJB_ENODEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+	if (count_rows) {  // this launch's row counters, to pinned host memory behind it
+		HIP_TRY(hipMemcpyAsync(b->rowstat_host, b->rowstat_dev, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipEventRecord(b->ev_rowstat, stream));
+		b->rowstat_pending = true;
+	}
 	if (zspec) {  // the next launch's normals, into the half this one does not read, beside it
 		const int other = 1 - zhalf_now;
 		HIP_TRY(hipStreamWaitEvent(b->noise_stream, b->ev_noise_go, 0));
@@ -2291,7 +2367,37 @@ int mjb_set_ctrl_noise(mjb_batch *b, double ctrl_noise_std, double ctrl_noise_ra
 	return MJB_OK;
 }
 
+int mjb_set_stats(mjb_batch *b, int on)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	HIP_TRY(hipSetDevice(b->device));
+	int rc = join_rest(b);
+	if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	if (on) {
+		if (!b->stats_dev) b->stats_dev = dev_alloc<unsigned long long>(MJB_NSTATS);
+		if (!b->stats_dev) return fail(MJB_ENOMEM, "mjb_set_stats: allocation failed");
+		HIP_TRY(hipMemset(b->stats_dev, 0, MJB_NSTATS * sizeof(unsigned long long)));
+	}
+	b->st.stats = on ? b->stats_dev : nullptr;
+	b->params_dirty = true;
+	return MJB_OK;
+}
+
+int mjb_get_stats(mjb_batch *b, unsigned long long *out)
+{
+	if (!b || !out) return fail(MJB_EINVAL, "mjb_get_stats: bad argument");
+	if (!b->stats_dev) return fail(MJB_EINVAL, "mjb_get_stats before mjb_set_stats(b, 1)");
+	HIP_TRY(hipSetDevice(b->device));
+	int rc = join_rest(b);
+	if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(b->stream));
+	HIP_TRY(hipMemcpy(out, b->stats_dev, MJB_NSTATS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	return MJB_OK;
+}
+
 int mjb_noise_mode(const mjb_batch *b) { return b ? b->noise_mode : 0; }
+int mjb_fused_frame(const mjb_batch *b) { return b && b->wide ? 2 : 1; }
 
 void *mjb_get_stream(mjb_batch *b) { return b ? (void *)b->stream : nullptr; }
 

@@ -134,6 +134,8 @@ struct DevState {
 	double *frame_ws;              // optional [nenv][ndouble + nint/2 padded] full-frame workspace
 	unsigned long long *nwarn;     // [MJB_NWARNING] mjData.warning[].number summed over the envs (mjb_warning)
 	unsigned long long *prof;      // [64] per-stage cycle sums + call counts (profiling build only), else NULL
+	unsigned long long *stats;     // [MJB_NSTATS] workload statistics (mjb_set_stats), NULL when off
+	unsigned int *rowstat;         // [4] evaluations | beyond 64 rows | beyond 128 rows | - of the current long fused launch (kernel variant 4's wide-frame policy), or NULL
 	int nenv;
 	int frame_stride;              // doubles per env in frame_ws
 	const double *env_gravity;       // [nenv][3] per-env gravity override (NULL: the model's)

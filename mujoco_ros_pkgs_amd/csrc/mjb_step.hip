@@ -2152,7 +2152,7 @@ template <int G, bool CACHE = false> STAGE void sensors(CModel m, CLayout L, con
 			if (dst >= 0) f[L.sensordata + dst] = f[e.lc.sc_src[stage - 1][q]];
 		}
 	} else {
-		const int tb = ((compact ? 3 : 0) + stage - 1) * m.sens_ncopy_max;
+		const int tb = (3 * compact + stage - 1) * m.sens_ncopy_max;
 		for (int t = e.lane; t < ncopy; t += G) {
 			const int dst = m.sens_copy[2 * (tb + t)], src = m.sens_copy[2 * (tb + t) + 1];
 			f[L.sensordata + dst] = f[src];
@@ -2779,12 +2779,20 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 		// mjb_step2) holds all of J
 		VIEW(P, compact, {
 			const int ne = __builtin_amdgcn_readfirstlane(e.fi[L.nefc]);
+			if (s.rowstat != nullptr && e.lane == 0) {  // what the host's wide-frame policy reads after the launch
+				atomicAdd(s.rowstat, 1u);
+				if (ne > 64) atomicAdd(s.rowstat + 1, 1u);
+				if (ne > 128) atomicAdd(s.rowstat + 2, 1u);
+			}
 			if (L.jrows >= m.nefcmax && ne > 64) {
 				MJB_KEEP_BRANCH();
 				fwd_constraint_newton<G, 4>(m, L, e);
 			} else if (ne <= L.jrows && ne <= 64) {  // (the full frame too: the same instantiation as the fused step's common case)
 				MJB_KEEP_BRANCH();
 				fwd_constraint_newton<G, 1>(m, L, e);
+			} else if (ne <= L.jrows && ne <= 128) {  // the wide fused frame: up to 128 rows in LDS, two per lane
+				MJB_KEEP_BRANCH();
+				fwd_constraint_newton<G, 2>(m, L, e);
 			} else {
 				MJB_KEEP_BRANCH();
 				fwd_constraint_newton<G, 4, false, true>(m, L, e, s.efc_Jg + (size_t)e.env * mjb_rowblock_doubles(m.nefcmax, m.nv, m.nconmax, L.hcs));
@@ -2805,6 +2813,21 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 		VIEW(P, compact, fwd_constraint<G>(m, L, e));
 	}
 	PROF(11);
+	if constexpr (CON != 0) {  // workload statistics (mjb_set_stats): what this evaluation asked of the solver -- fire-and-forget atomics
+		if (P->s.stats != nullptr) {
+			MJB_KEEP_BRANCH();
+			VIEW(P, compact, {
+				if (e.lane == 0) {
+					const int ne = e.fi[L.nefc], nc = m.nconmax > 0 ? e.fi[L.ncon] : 0;
+					unsigned long long *st = P->s.stats;
+					atomicAdd(st, 1ull);
+					atomicAdd(st + 1, (unsigned long long)e.fi[L.solver_iter]);
+					atomicAdd(st + 2 + (ne < 256 ? ne : 256), 1ull);
+					atomicAdd(st + 259 + (nc < 128 ? nc : 128), 1ull);
+				}
+			});
+		}
+	}
 	VIEW(P, compact, if (m.need_rnepost) rne_post<G>(m, L, lite(e), s.use_xfrc != 0));
 	VIEW(P, compact, sensors<G, (DENSE != 0)>(m, L, e, MJB_STAGE_ACC, compact));
 	PROF(12);
@@ -3089,7 +3112,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 	// fetched with a scalar load where it is used instead of pinning ~300 SGPRs for the whole kernel
 	const DevModel MJB_AS4 &m = P->m;
 	const int mode = mode_arg;
-	const int compact = (mode == MJB_MODE_STEP && P->use_compact) ? 1 : 0;
+	const int compact = (mode == MJB_MODE_STEP && P->use_compact) ? P->use_compact : 0;  // 0 full frame, 1 fused, 2 wide fused (the host swapped it into P->Lc)
 	const FrameLayout MJB_AS4 &L = compact ? P->Lc : P->L;
 	const DevState MJB_AS4 &s = P->s;
 	const NoiseCfg MJB_AS4 &nz = P->nz;
@@ -3221,7 +3244,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 			}
 		}
 		for (int st = 0; st < 3; st++) {  // the sensors' plain copies: {dst, src} pairs of this launch's layout, two per lane and stage
-			const int tb = ((compact ? 3 : 0) + st) * m.sens_ncopy_max, nc = m.sens_ncopy[st];
+			const int tb = (3 * compact + st) * m.sens_ncopy_max, nc = m.sens_ncopy[st];
 			for (int q = 0; q < 2; q++) {
 				const int t = (int)e.lane + G * q;
 				c.sc_dst[st][q] = t < nc ? m.sens_copy[2 * (tb + t)] : -1;

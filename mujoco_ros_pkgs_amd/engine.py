@@ -245,6 +245,38 @@ class Batch:
         _check(self.lib.mjb_set_ctrl_noise(self.ptr, float(std), float(rate), int(seed), int(env_offset)),
                "mjb_set_ctrl_noise")
 
+    def set_stats(self, on=True):
+        """Start (and zero) / stop the device-side workload statistics of the constrained kernels (mjb_set_stats)."""
+        _check(self.lib.mjb_set_stats(self.ptr, 1 if on else 0), "mjb_set_stats")
+
+    def stats(self):
+        """dict(evaluations, solver_iter_mean, ncon_{mean,p50,p99,max}, nefc_{mean,p50,p99,max}, rows_gt64_share, nefc_hist, ncon_hist)."""
+        out = (C.c_ulonglong * 388)()
+        _check(self.lib.mjb_get_stats(self.ptr, out), "mjb_get_stats")
+        a = np.array(out[:], dtype=np.float64)
+        n = a[0]
+        he, hc = a[2:259], a[259:388]
+
+        def summary(h):
+            tot = h.sum()
+            if tot <= 0:
+                return 0.0, 0, 0, 0
+            c = np.cumsum(h)
+            q = lambda f: int(np.searchsorted(c, f * tot, side="left"))
+            return float((h * np.arange(len(h))).sum() / tot), q(0.5), q(0.99), int(np.nonzero(h)[0].max())
+        em, e50, e99, emx = summary(he)
+        cm, c50, c99, cmx = summary(hc)
+        return {"evaluations": int(n), "solver_iter_mean": float(a[1] / n) if n else 0.0,
+                "ncon_mean": cm, "ncon_p50": c50, "ncon_p99": c99, "ncon_max": cmx,
+                "nefc_mean": em, "nefc_p50": e50, "nefc_p99": e99, "nefc_max": emx,
+                "rows_gt64_share": float(he[65:].sum() / he.sum()) if he.sum() else 0.0,
+                "nefc_hist": he.astype(np.int64), "ncon_hist": hc.astype(np.int64)}
+
+    def fused_frame(self):
+        """(id, bytes) of the fused frame the batch's launches currently run on: 1 default, 2 wide (mjb_fused_frame)."""
+        fid = int(self.lib.mjb_fused_frame(self.ptr))
+        return fid, int(self.lib.mjb_frame_bytes(self.cm.ptr, fid))
+
     def noise_mode(self):
         """How the last fused launch got its ctrl-noise normals (mjb_noise_mode)."""
         return ("in-kernel", "same-stream", "side-stream")[int(self.lib.mjb_noise_mode(self.ptr))]

@@ -68,7 +68,7 @@ def _run_bench(*argv, timeout=300):
     return p, lines
 
 
-@pytest.mark.parametrize("ranks", [1, 2, 4])
+@pytest.mark.parametrize("ranks", [1, 2, 4, 8])
 def test_dry_ranks_print_one_line_from_rank_zero(ranks):
     p, lines = _run_bench("--dry-ranks", str(ranks), "--steps", "3", "--warmup", "1")
     assert p.returncode == 0, p.stderr[-3000:]
@@ -80,6 +80,18 @@ def test_dry_ranks_print_one_line_from_rank_zero(ranks):
     assert 0 < line["rank_ms_per_step"]["min"] <= line["rank_ms_per_step"]["max"] <= line["ms_per_step"] * 1.0000001
     assert line["exchange_ms"] is not None and line["exchange_ms"] >= 0
     assert abs(line["value"] - ranks * 64 * 10 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]   # whole-job aggregate
+    assert line["config"]["gloo_ranks"] == ranks              # what the process group says, not the environment variable
+    assert line["cpu_baseline_leg"] is (ranks == 1)           # the CPU leg runs on rank 0 at N = 1 only
+
+
+def test_world_size_mismatch_fails_the_line():
+    """A launcher that started fewer ranks than --gpus / --dry-ranks asks for must not produce a line that looks like an N-rank one."""
+    import json
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-ranks", "2", "--steps", "2", "--warmup", "1", "--dist-timeout", "20"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode != 0 and len(lines) == 1 and "error" in lines[0] and "process group has 1 rank" in lines[0]["error"]
 
 
 @pytest.mark.parametrize("bad", [0, 1])

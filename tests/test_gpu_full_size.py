@@ -64,6 +64,65 @@ def test_config5_newton_1024_envs(oracle_built):
     assert m["solver"] == 2 and m["cone"] == 1
 
 
+def test_config5_power_grasp_1024_envs(oracle_built, capsys):
+    """BASELINE configs[4] as it is named -- "high contact count": the power-grasp workload (mean ncon ~21, ~87 rows, most env-steps on
+    the 4-rows-per-lane Newton solver over the env's HBM row block), 16 sampled envs against the oracle after K = 40 steps."""
+    rep = []
+    m = _run("shadow_hand_grasp", 1024, 40, 16, 1e-9, 1e-6, oracle_built, report=rep)
+    assert m["solver"] == 2 and m["cone"] == 1 and (m["nconmax"], m["nefcmax"]) == (48, 200)
+    with capsys.disabled():
+        print(f"\n[config 5 power grasp, K = 40, 16 envs vs oracle] worst |dqpos| = {rep[0][4]:.2e}, worst |dqvel| = {rep[0][5]:.2e}")
+
+
+def test_config5_power_grasp_is_the_high_contact_workload(oracle_built):
+    """The statistics the bench line reports, from the device-side counters (mjb_set_stats), over ONE 1000-step launch of the bench's
+    own batch: VERDICT r04 #1's bar (mean ncon >= 15, mean nefc >= 60, p99 nefc >= 100, a stated share beyond 64 rows), no overflow
+    of the 48-contact / 200-row capacities, no reset -- and the counters themselves against the oracle's d->ncon / d->nefc on a
+    sampled env (integers: exact)."""
+    from bench import WORKLOADS, initial_state
+    from mujoco_ros_pkgs_amd import engine
+    name, nenv, K = "shadow_hand_grasp", 1024, 1000
+    model = mjcf.load_asset(name)
+    qpos, qvel = initial_state(name, model, nenv, seed=1000)
+    b = engine.Batch(engine.CompiledModel(model), nenv)
+    b.set("qpos", qpos)
+    b.set("qvel", qvel)
+    b.set_ctrl_noise(WORKLOADS[name][1], 0.1, 12345, 0)
+    b.set_stats(True)
+    b.step(K)
+    st = b.stats()
+    assert st["evaluations"] == nenv * K
+    assert st["ncon_mean"] >= 15 and st["nefc_mean"] >= 60 and st["nefc_p99"] >= 100 and st["rows_gt64_share"] >= 0.5, st
+    assert st["nefc_max"] <= model["nefcmax"] and st["ncon_max"] <= model["nconmax"]
+    assert (b.warning("contactfull"), b.warning("cnstrfull"), b.warning_count()) == (0, 0, 0)
+    assert 1.0 <= st["solver_iter_mean"] <= 10.0
+    b.close()
+    # the counters against the oracle: 4 envs x 25 steps, every evaluation's (ncon, nefc) and the iteration count
+    n2, K2 = 4, 25
+    b = engine.Batch(engine.CompiledModel(model), n2)
+    b.set("qpos", qpos[:n2])
+    b.set("qvel", qvel[:n2])
+    b.set_ctrl_noise(WORKLOADS[name][1], 0.1, 12345, 0)
+    b.set_stats(True)
+    b.step(K2)
+    st = b.stats()
+    hist_e, hist_c, iters = np.zeros(257, dtype=np.int64), np.zeros(129, dtype=np.int64), 0
+    for e in range(n2):
+        d = oracle_built.OracleData(model)
+        d.reset()
+        d.qpos[:] = qpos[e]
+        d.qvel[:] = qvel[e]
+        for k in range(K2):
+            d.ctrl_noise(WORKLOADS[name][1], 0.1, 12345, e, k)
+            d.step()
+            hist_e[int(d.nefc[0])] += 1
+            hist_c[int(d.ncon[0])] += 1
+            iters += int(d.solver_iter[0])
+    assert np.array_equal(st["nefc_hist"], hist_e) and np.array_equal(st["ncon_hist"], hist_c)
+    assert abs(st["solver_iter_mean"] * n2 * K2 - iters) <= 2      # (an iteration count may differ by one where the stop test is a tie)
+    b.close()
+
+
 # ---- the 8-GPU configs at their WHOLE size on one GPU (VERDICT r02 #3b): configs[3] = 32768 envs of config 3, configs[4] = 8192 envs
 # of config 5.  Sharding changes nothing an env can see (the Philox key is the global env index, tests/test_sharding_gloo.py), so one
 # GPU stepping all of them is the 8-GPU job minus the gather; what stays untested without an 8-GPU node is the RCCL exchange alone.
@@ -73,6 +132,10 @@ def test_config4_pgs_32768_envs_one_gpu(oracle_built):
 
 def test_config5_newton_8192_envs_one_gpu(oracle_built):
     _run("shadow_hand_like", 8192, 30, 16, 1e-9, 1e-6, oracle_built)
+
+
+def test_config5_power_grasp_8192_envs_one_gpu(oracle_built):
+    _run("shadow_hand_grasp", 8192, 40, 16, 1e-9, 1e-6, oracle_built)
 
 
 def test_config2_bench_workload_1000_fused_steps(oracle_built, capsys):
@@ -108,6 +171,12 @@ def _overflow(name, nenv, K, launches):
 def test_config5_bench_launches_never_overflow():
     """Config 5 (48 contacts, 200 rows): no mjWARN_CONTACTFULL / mjWARN_CNSTRFULL and no mj_check* reset over the bench's launches."""
     cfull, rfull, resets = _overflow("shadow_hand_like", 1024, 1000, 3)
+    assert (cfull, rfull, resets) == (0, 0, 0)
+
+
+def test_config5_power_grasp_launches_never_overflow():
+    """The power grasp peaks at ~35 contacts / ~135 rows of the 48 / 200 capacity: no overflow, no reset over three bench launches."""
+    cfull, rfull, resets = _overflow("shadow_hand_grasp", 1024, 1000, 3)
     assert (cfull, rfull, resets) == (0, 0, 0)
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Algorithmic flops per env-step of the BASELINE workloads = the CPU oracle's instrumented operation count (SURVEY.md 8d:
 add / mul / div / sqrt = 1, fma = 2), from oracle/libmjo_count.so (oracle/mjo_count.h) on bench.py's own workload (same initial
-states, same OU ctrl noise).  Writes profiles/r04_oracle_flops.json, which bench.py turns into `roofline.fp64.useful_*`.
+states, same OU ctrl noise).  Writes profiles/r05_oracle_flops.json, which bench.py turns into `roofline.fp64.useful_*`.
 Runs on the CPU (no GPU needed):  python tools/count_flops.py [--envs 16] [--steps 400]"""
 import argparse
 import ctypes as C
@@ -44,12 +44,12 @@ def main():
     out = {"definition": "oracle operation count: + - * / sqrt and libm calls = 1 each (a multiply-add = 2); comparisons, negation, "
                          "fabs / fmin / fmax, copies and integer work = 0 (oracle/mjo_count.h)",
            "sample": f"{a.envs} envs x {a.steps} steps of bench.py's workload (seed 1000 initial states, OU ctrl noise seed 12345)"}
-    for name in ("franka_like", "franka_table", "shadow_hand_like"):
+    for name in ("franka_like", "franka_table", "shadow_hand_grasp", "shadow_hand_like"):
         per, model = count(name, a.envs, a.steps, L)
         out[name] = {"flops_per_env_step": per, "solver": {0: "PGS", 1: "CG", 2: "Newton"}[int(model["solver"])] if model["nefcmax"] else "none",
                      "nv": int(model["nv"]), "nefcmax": int(model["nefcmax"])}
         print(f"{name}: {per:.0f} flops / env-step")
-    path = os.path.join(ROOT, "profiles", "r04_oracle_flops.json")
+    path = os.path.join(ROOT, "profiles", "r05_oracle_flops.json")
     json.dump(out, open(path, "w"), indent=1)
     print("wrote", path)
 
