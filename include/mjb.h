@@ -238,6 +238,16 @@ int mjb_set_ctrl_noise(mjb_batch *b, double ctrl_noise_std, double ctrl_noise_ra
 int mjb_noise_mode(const mjb_batch *b);
 /* 1 = the default fused frame, 2 = the wide one (mjb_frame_bytes): what the batch's fused launches currently run on. */
 int mjb_fused_frame(const mjb_batch *b);
+/* The lane = env form of the unconstrained fused step (csrc/mjb_lane_env.hip): one env per LANE, the state of 64 envs in a
+ * wavefront's registers, compiled per model topology (csrc/lane_env_topos.h).  Same step (mj_step, mujoco_env.cpp:498,552,593),
+ * results equal to the generic kernels' to rounding; it pays when the batch is large enough to fill the chip with 64-env
+ * wavefronts.  mode: -1 = automatic (whole-batch fused launches of >= MJB_LANE_ENV_MIN_ENVS envs, default 16384, of a model whose
+ * topology is compiled in, with no per-env model overrides / hwsim stage / xfrc_applied), 0 = never, 1 = whenever eligible.
+ * The environment variable MJB_LANE_ENV (same values) sets the default of new batches.  No reference counterpart. */
+int mjb_set_lane_env(mjb_batch *b, int mode);
+/* Index of the compiled-in topology the batch's model matches, -1 if none (such a model always runs the generic kernels);
+ * *used_last (may be NULL) = 1 when the last fused launch ran the lane = env kernel. */
+int mjb_lane_env_info(const mjb_batch *b, int *used_last);
 
 /* Stream control: the hipStream_t (as void*) kernels are launched on; default is a stream the
  * batch owns.  mjb_synchronize waits for it. */

@@ -190,6 +190,8 @@ def load_library(path=None):
         "mjb_set_ctrl_noise": (ci, [vp, cd, cd, C.c_uint64, C.c_int64]),
         "mjb_noise_mode": (ci, [vp]),
         "mjb_fused_frame": (ci, [vp]),
+        "mjb_set_lane_env": (ci, [vp, ci]),
+        "mjb_lane_env_info": (ci, [vp, C.POINTER(ci)]),
         "mjb_set_stats": (ci, [vp, ci]),
         "mjb_get_stats": (ci, [vp, C.POINTER(C.c_ulonglong)]),
         "mjb_get_stream": (vp, [vp]),

@@ -94,6 +94,7 @@ struct mjb_model {
 	// take the two-rows-per-lane solver on LDS instead of the four-rows-per-lane one on the env's block in HBM (launch(), wide policy).
 	FrameLayout Lw{};
 	bool has_wide = false;
+	int le_topo = -1;  // compiled-in topology of the lane = env kernel the model matches (mjb_lane_env.hip), -1: none
 };
 
 struct mjb_batch {
@@ -152,6 +153,8 @@ struct mjb_batch {
 	size_t zcap = 0;               // its capacity in doubles PER HALF
 	bool zdouble = false;          // two halves allocated (side-stream speculation possible)
 	size_t zfail = (size_t)-1;     // smallest total allocation (doubles) that failed: not retried
+	int lane_env_mode = -1;        // mjb_set_lane_env: -1 automatic, 0 never, 1 whenever eligible
+	bool lane_env_used = false;    // the last fused launch ran the lane = env kernel
 	int noise_mode = 0;            // how the last fused launch got its ctrl-noise normals: 0 in-kernel, 1 same-stream, 2 side-stream (mjb_noise_mode)
 	unsigned int *zinfo = nullptr; // two records (one per half of zbuf)
 	bool zvalid = false;           // a record names a launch: cleared (on the stream) before any step launch that does not use the buffer
@@ -1120,6 +1123,7 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 	for (int b = 1; b < h.nbody; b++)
 		for (int i = 0; i < h.nv; i++)
 			if ((M->body_dofmask[2 * b + (i >> 5)] >> (i & 31)) & 1) M->dof_bodymask[2 * i + (b >> 5)] |= (int)(1u << (b & 31));
+	M->le_topo = mjb_lane_env_match(&h);
 	M->eulerdamp = 0;
 	if (!(h.disableflags & MJB_DSBL_EULERDAMP))
 		for (int i = 0; i < h.nv; i++)
@@ -1756,7 +1760,19 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 	const bool zspec = zuse && b->zdouble;
 	if (zspec) HIP_TRY(hipEventRecord(b->ev_noise_go, stream));  // (everything before this launch -- the last reader of the other half -- is done)
 	if (count_rows) HIP_TRY(hipMemsetAsync(b->rowstat_dev, 0, 4 * sizeof(unsigned int), stream));
-	int rc = mjb_launch_step(b->params_dev, compact ? (b->wide ? b->model->Lw : b->model->Lc) : b->L, env_lo, env_hi, mode, nsteps, b->step_counter, b->lanes,
+	// The lane = env kernel (mjb_lane_env.hip) for fused launches of a model whose topology is compiled in: one env per lane, no frame.
+	// Per-env model overrides, the device hwsim stage, xfrc_applied and frame dumps keep the generic kernels.
+	bool use_le = false;
+	if (mode == MJB_MODE_STEP && compact && variant == 0 && b->model->le_topo >= 0 && b->lane_env_mode != 0 && b->hw.n == 0 && !b->env_mass &&
+	    !b->env_gravity && !b->st.stats) {
+		static const int min_envs = [] { const char *v = getenv("MJB_LANE_ENV_MIN_ENVS"); return v ? atoi(v) : 16384; }();
+		use_le = b->lane_env_mode == 1 || (whole && b->nenv >= min_envs);
+	}
+	b->lane_env_used = use_le;
+	int rc;
+	if (use_le) rc = mjb_launch_lane_env(b->params_dev, b->model->le_topo, env_lo, env_hi, nsteps, b->step_counter, stream);
+	else
+	rc = mjb_launch_step(b->params_dev, compact ? (b->wide ? b->model->Lw : b->model->Lc) : b->L, env_lo, env_hi, mode, nsteps, b->step_counter, b->lanes,
 	                         b->epb, variant | (chunk << 8), (b->lanes == 16 && !b->env_mass && mode != MJB_MODE_STEP21 && b->model->h.integrator == MJB_INT_EULER && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16 && b->model->h.nu <= 16 && b->model->h.njnt <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, stream);
 	if (rc != 0) return fail(MJB_ENODEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
 	if (count_rows) {  // this launch's row counters, to pinned host memory behind it
@@ -2397,6 +2413,17 @@ int mjb_get_stats(mjb_batch *b, unsigned long long *out)
 }
 
 int mjb_noise_mode(const mjb_batch *b) { return b ? b->noise_mode : 0; }
+int mjb_set_lane_env(mjb_batch *b, int mode)
+{
+	if (!b || mode < -1 || mode > 1) return fail(MJB_EINVAL, "mjb_set_lane_env: bad argument");
+	b->lane_env_mode = mode;
+	return MJB_OK;
+}
+int mjb_lane_env_info(const mjb_batch *b, int *used_last)
+{
+	if (used_last) *used_last = b && b->lane_env_used ? 1 : 0;
+	return b ? b->model->le_topo : -1;
+}
 int mjb_fused_frame(const mjb_batch *b) { return b && b->wide ? 2 : 1; }
 
 void *mjb_get_stream(mjb_batch *b) { return b ? (void *)b->stream : nullptr; }

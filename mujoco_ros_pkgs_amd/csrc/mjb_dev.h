@@ -240,6 +240,10 @@ int mjb_launch_step(const KernelParams *Pdev, const FrameLayout &L, int env_lo, 
                     int lanes_per_env, int envs_per_block, int constrained, int dense, void *stream);
 int mjb_launch_reset(const KernelParams *Pdev, int nenv, const unsigned char *mask_dev, void *stream);
 int mjb_max_lds_bytes();
+// lane = env form of the unconstrained fused step (mjb_lane_env.hip)
+int mjb_lane_env_match(const mjb_model_desc *h);
+const char *mjb_lane_env_name(int topo);
+int mjb_launch_lane_env(const KernelParams *Pdev, int topo, int env_lo, int env_hi, int nsteps, unsigned int step0, void *stream);
 // sensors-plugin equivalent (mjb_sensor_pack.hip)
 int mjb_launch_sensor_pack(const KernelParams *Pdev, int nenv, int nsensor, const int *set_flag, const double *mean,
                            const double *sigma, unsigned long long seed, long long env_offset, unsigned int step,

@@ -1,0 +1,626 @@
+// mjb_lane_env.hip -- the LANE = ENV form of the unconstrained fused step (SURVEY.md §7 "measure a 64-envs-per-wave (lane = env)
+// variant for the smooth-dynamics phases and report both").
+//
+// mjb_step_kernel<16, 0, DENSE> spreads ONE env over 16 lanes: every stage is a chain of cross-lane exchanges (DPP, LDS rounds at
+// ~110 cycles each) with a third of the lanes doing fp64 work, one wavefront per SIMD -- 42.8 k cycles per step whatever the batch
+// size (profiles/r03_batch_size.txt: 222 - 230 M env-steps/s from 4096 to 65 536 envs).  Here a lane owns an env:
+//   * no cross-lane traffic at all -- a step is one straight line of fp64 VALU work per wavefront of 64 envs, every fp64 issue slot
+//     does 64 envs' worth of arithmetic;
+//   * the model is the same for every lane, so every model constant is a SCALAR load into SGPRs (one per wavefront) and rides along
+//     as the scalar operand of the VALU instruction that uses it;
+//   * nothing per-env can be indexed at run time (a lane's "arrays" are registers), so the kernel is a template over the model's
+//     INTEGER structure (csrc/lane_env_topos.h, tools/gen_lane_env_topo.py): parent ids, joint kinds and dof ancestry are
+//     compile-time constants, every loop over bodies / dofs is unrolled, zero blocks of qM never exist.  Numeric constants stay
+//     run-time data;
+//   * the state of 64 envs lives in the wavefront's registers for all K fused steps (512 per lane at one wavefront per SIMD);
+//     what does not fit spills to the AGPR half of the file and then to scratch -- `tools/kernel_meta.py` reports both.
+// Same step as the oracle's mjo_step / mj_step (mujoco_env.cpp:498,552,593) for models the topology tables cover: hinge / slide
+// trees without constraint rows, Euler with implicit joint damping, joint-transmission actuators, the sensors listed in
+// gen_lane_env_topo.py, ctrl noise (mujoco_env.cpp:469-481), mj_check* resets, mjENBL_ENERGY.  Arithmetic follows MuJoCo's
+// com-based formulation stage by stage (oracle/mjo_smooth.c); sums over bodies run in ascending instead of leaf-to-root order and
+// reciprocals are Newton-refined hardware seeds, so results agree with the oracle to rounding, not bit for bit (tests/test_gpu_lane_env.py).
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "mjb_dev.h"
+#include "mjb_math.h"
+#include "lane_env_topos.h"
+
+namespace {
+
+template <typename F, int... Is> DEVI void sfor_impl(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F> DEVI void sfor(F &&f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
+
+DEVI double frcp(double x)
+{
+	double r = __builtin_amdgcn_rcp(x);
+	r = fma(fma(-x, r, 1.0), r, r);
+	r = fma(fma(-x, r, 1.0), r, r);
+	return r;
+}
+
+// compile-time queries on a topology
+template <class T> struct Tq {
+	// dof a is dof i or one of its ancestors
+	static constexpr bool anc(int a, int i)
+	{
+		for (int j = i; j >= 0; j = T::dof_parentid[j])
+			if (j == a) return true;
+		return false;
+	}
+	static constexpr bool is_root(int b) { return b > 0 && T::body_rootid[b] == b; }
+	// some sensor of the model needs the pose of this site / body
+	static constexpr bool has_actuator_sensor()
+	{
+		for (int i = 0; i < T::NSENSOR; i++)
+			if (T::sensor_type[i] == MJB_SENS_ACTUATORFRC) return true;
+		return false;
+	}
+};
+
+DEVI void normalize4_sel(double *q)
+{
+	const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+	const bool tiny = n < MJB_MINVAL;
+	const double s = (fabs(n - 1) > MJB_MINVAL) ? frcp(tiny ? 1.0 : n) : 1.0;
+	q[0] = tiny ? 1.0 : q[0] * s;
+	q[1] = tiny ? 0.0 : q[1] * s;
+	q[2] = tiny ? 0.0 : q[2] * s;
+	q[3] = tiny ? 0.0 : q[3] * s;
+}
+
+DEVI bool bad_val(double x) { return !(x == x) || fabs(x) > MJB_MAXVAL; }
+
+template <class T>
+__global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB_AS4 *__restrict__ P, const int nsteps, const unsigned int step0,
+                                                          const int env_lo, const int env_hi)
+{
+	constexpr int NB = T::NBODY, NV = T::NV, NU = T::NU, NJ = T::NJNT;
+	using Q = Tq<T>;
+	const int env = env_lo + (int)(blockIdx.x * 64 + threadIdx.x);
+	if (env >= env_hi) return;
+	const size_t ev = (size_t)env;
+
+	// ---- the env's state, in registers for the whole launch
+	double qpos[NV], qvel[NV], qacc[NV], cn[NU > 0 ? NU : 1];
+	double time, en_pe = 0, en_ke = 0;
+	bool wasreset = false;  // mj_resetData ran inside this launch: ctrl / qfrc_applied read as zero from then on (the frame copy of the generic kernels)
+	{
+		const DevState MJB_AS4 &s = P->s;
+		sfor<NV>([&](auto I) { qpos[I] = s.qpos[ev * NV + I]; qvel[I] = s.qvel[ev * NV + I]; qacc[I] = s.qacc[ev * NV + I]; });
+		sfor<NU>([&](auto I) { cn[I] = s.ctrlnoise[ev * NU + I]; });
+		time = s.time[ev];
+	}
+	const bool nz_on = P->nz.enabled != 0;
+	// ctrl noise from the launch's pre-generated buffer when the host filled one for exactly this launch (mjb_api.hip: launch)
+	int zhalf_i = -1;
+	if (nz_on && P->s.zbuf != nullptr) {
+		const unsigned int *zi = P->s.zinfo;
+		if (zi[0] == step0 && (int)zi[1] == nsteps && (int)zi[2] == P->s.nenv) zhalf_i = 0;
+		else if (zi[4] == step0 && (int)zi[5] == nsteps && (int)zi[6] == P->s.nenv) zhalf_i = 1;
+	}
+	const bool zpre = zhalf_i >= 0;
+
+#pragma nounroll
+	for (int st = 0; st < nsteps; st++) {
+		// (the parameter pointer laundered per step: model constants are re-fetched by scalar loads where they are used instead of
+		//  being hoisted out of the step loop into ~700 SGPRs the wavefront does not have)
+		const KernelParams MJB_AS4 *Pq = P;
+		asm volatile("" : "+s"(Pq));
+		const DevModel MJB_AS4 &m = Pq->m;
+		const DevState MJB_AS4 &s = Pq->s;
+		const bool last = st == nsteps - 1;
+		const double dt = m.timestep[0];
+
+		// ---- H10: the reference's ctrl-noise injector (mujoco_env.cpp:469-481), before the step
+		double ctrl[NU > 0 ? NU : 1];
+		if (nz_on) {
+			const double rate = Pq->nz.rate, scale = Pq->nz.scale;
+			if (zpre) {
+				asm volatile("" ::: "memory");
+				const double *zb = s.zbuf + (zhalf_i > 0 ? s.zhalf : 0ull) + ((size_t)st * s.nenv + ev) * NU;
+				sfor<NU>([&](auto I) { cn[I] = rate * cn[I] + scale * zb[I]; });
+			} else {
+				asm volatile("" ::: "memory");
+				const unsigned long long seed = Pq->nz.seed, genv = (unsigned long long)(Pq->nz.env_offset + env);
+				sfor<NU>([&](auto I) { cn[I] = rate * cn[I] + scale * philox_normal(seed, genv, step0 + (unsigned int)st, (unsigned int)I); });
+			}
+			sfor<NU>([&](auto I) { ctrl[I] = cn[I]; });
+		} else {
+			sfor<NU>([&](auto I) { ctrl[I] = wasreset ? 0.0 : s.ctrl[ev * NU + I]; });
+		}
+
+		// ---- mj_checkPos / mj_checkVel (qpos first: its reset hides a bad qvel)
+		{
+			bool badp = false, badv = false;
+			sfor<NV>([&](auto I) { badp |= bad_val(qpos[I]); badv |= bad_val(qvel[I]); });
+			if (badp || badv) {
+				atomicAdd(s.nwarn + (badp ? MJB_WARN_BADQPOS : MJB_WARN_BADQVEL), 1ull);
+				sfor<NV>([&](auto I) { qpos[I] = m.qpos0[I]; qvel[I] = 0; });
+				sfor<NU>([&](auto I) { cn[I] = 0; ctrl[I] = 0; });
+				time = 0;
+				wasreset = true;
+			}
+		}
+
+		double qaccd[NV];  // the acceleration Euler advances with: (M + h B)^-1 f under implicit joint damping, else qacc
+#pragma nounroll
+		for (int attempt = 0; attempt < 2; attempt++) {
+			const bool e_on = last && (m.enableflags & MJB_ENBL_ENERGY);
+			const bool eg_on = e_on && !(m.disableflags & MJB_DSBL_GRAVITY);
+			const bool sens_on = last && !(m.disableflags & MJB_DSBL_SENSOR);
+			double *sd = s.sensordata + ev * T::NSENSORDATA;
+			double pe = 0;
+
+			// ================= A1 mj_kinematics (+ the position part of comPos per body) =================
+			double xpos[NB][3], xquat[NB][4], xmat[NB][9];
+			double xipos[NB][3], rI[NB][6];
+			double xaxis[NJ][3], xanch[NJ][3];
+			double comw[NB][3];  // per tree root: sum of mass * xipos over the tree
+			sfor<NB>([&](auto B) {
+				constexpr int b = B;
+				if constexpr (b == 0) return;
+				constexpr int p = T::body_parentid[b], j = T::body_jnt[b], r = T::body_rootid[b];
+				double pos[3], quat[4];
+				ldc3(pos, m.body_pos + 3 * b);
+				ldc4(quat, m.body_quat + 4 * b);
+				if constexpr (p != 0) {
+					double v[3], q[4];
+					matvec3(v, xmat[p], pos);
+					for (int k = 0; k < 3; k++) pos[k] = v[k] + xpos[p][k];
+					qmul(q, xquat[p], quat);
+					for (int k = 0; k < 4; k++) quat[k] = q[k];
+				}
+				if constexpr (j >= 0) {
+					double M0[9], ax[3], jp[3], v[3];
+					ldc3(ax, m.jnt_axis + 3 * j);
+					ldc3(jp, m.jnt_pos + 3 * j);
+					quat2mat_nocheck(M0, quat);
+					matvec3(xaxis[j], M0, ax);
+					matvec3(v, M0, jp);
+					for (int k = 0; k < 3; k++) xanch[j][k] = v[k] + pos[k];
+					const double dq = qpos[j] - m.qpos0[j];
+					if constexpr (T::jnt_type[j] == MJB_JNT_SLIDE) {
+						for (int k = 0; k < 3; k++) pos[k] += xaxis[j][k] * dq;
+					} else {
+						double sn, cs, ql[4], q[4];
+						sincos(dq * 0.5, &sn, &cs);
+						ql[0] = cs; ql[1] = ax[0] * sn; ql[2] = ax[1] * sn; ql[3] = ax[2] * sn;
+						qmul(q, quat, ql);
+						for (int k = 0; k < 4; k++) quat[k] = q[k];
+						// correct for off-centre rotation (jnt_pos == 0: the anchor is the body origin, nothing to correct)
+						if (jp[0] != 0 || jp[1] != 0 || jp[2] != 0) {
+							double M1[9];
+							quat2mat_nocheck(M1, quat);
+							matvec3(v, M1, jp);
+							for (int k = 0; k < 3; k++) pos[k] = xanch[j][k] - v[k];
+						} else {
+							for (int k = 0; k < 3; k++) pos[k] = xanch[j][k];
+						}
+					}
+				}
+				normalize4_sel(quat);
+				for (int k = 0; k < 3; k++) xpos[b][k] = pos[k];
+				for (int k = 0; k < 4; k++) xquat[b][k] = quat[k];
+				quat2mat_nocheck(xmat[b], quat);
+				// inertial frame, and the body's inertia rotated into the world frame (the offset-free part of mju_inertCom)
+				double ximat[9];
+				if constexpr (T::body_sameframe[b]) {
+					for (int k = 0; k < 3; k++) xipos[b][k] = xpos[b][k];
+					for (int k = 0; k < 9; k++) ximat[k] = xmat[b][k];
+				} else {
+					double ip[3], iq[4], v[3], q[4];
+					ldc3(ip, m.body_ipos + 3 * b);
+					ldc4(iq, m.body_iquat + 4 * b);
+					matvec3(v, xmat[b], ip);
+					for (int k = 0; k < 3; k++) xipos[b][k] = v[k] + xpos[b][k];
+					qmul(q, xquat[b], iq);
+					quat2mat_nocheck(ximat, q);
+				}
+				{
+					const double i0 = m.body_inertia[3 * b], i1 = m.body_inertia[3 * b + 1], i2 = m.body_inertia[3 * b + 2];
+					const double *mat = ximat;
+					const double t0 = mat[0] * i0, t1 = mat[3] * i0, t2 = mat[6] * i0;
+					const double t3 = mat[1] * i1, t4 = mat[4] * i1, t5 = mat[7] * i1;
+					const double t6 = mat[2] * i2, t7 = mat[5] * i2, t8 = mat[8] * i2;
+					rI[b][0] = mat[0] * t0 + mat[1] * t3 + mat[2] * t6;
+					rI[b][1] = mat[3] * t1 + mat[4] * t4 + mat[5] * t7;
+					rI[b][2] = mat[6] * t2 + mat[7] * t5 + mat[8] * t8;
+					rI[b][3] = mat[0] * t1 + mat[1] * t4 + mat[2] * t7;
+					rI[b][4] = mat[0] * t2 + mat[1] * t5 + mat[2] * t8;
+					rI[b][5] = mat[3] * t2 + mat[4] * t5 + mat[5] * t8;
+				}
+				{
+					const double mass = m.body_mass[b];
+					if constexpr (r == b) for (int k = 0; k < 3; k++) comw[r][k] = mass * xipos[b][k];
+					else for (int k = 0; k < 3; k++) comw[r][k] += mass * xipos[b][k];
+					if (eg_on) pe -= mass * (m.gravity[0] * xipos[b][0] + m.gravity[1] * xipos[b][1] + m.gravity[2] * xipos[b][2]);
+				}
+				// position-stage sensors on this body's frames (the last step's values are the launch's sensordata)
+				if (sens_on) {
+					sfor<T::NSENSOR>([&](auto S) {
+						constexpr int i = S, type = T::sensor_type[i], ot = T::sensor_objtype[i], id = T::sensor_objid[i], adr = T::sensor_adr[i];
+						if constexpr (type == MJB_SENS_FRAMEPOS || type == MJB_SENS_FRAMEQUAT) {
+							constexpr int sb = ot == MJB_OBJ_SITE ? T::site_bodyid[id] : id;
+							if constexpr (sb == b) {
+								double o3[3], o4[4];
+								if constexpr (ot == MJB_OBJ_SITE) {
+									if constexpr (type == MJB_SENS_FRAMEPOS) {
+										if constexpr (T::site_sameframe[id]) {
+											for (int k = 0; k < 3; k++) o3[k] = xpos[b][k];
+										} else {
+											double sp[3], v[3];
+											ldc3(sp, m.site_pos + 3 * id);
+											matvec3(v, xmat[b], sp);
+											for (int k = 0; k < 3; k++) o3[k] = v[k] + xpos[b][k];
+										}
+									} else {
+										double sq[4];
+										ldc4(sq, m.site_quat + 4 * id);
+										qmul(o4, xquat[b], sq);
+									}
+								} else if constexpr (ot == MJB_OBJ_BODY) {
+									if constexpr (type == MJB_SENS_FRAMEPOS) {
+										for (int k = 0; k < 3; k++) o3[k] = xipos[b][k];
+									} else {
+										double iq[4];
+										ldc4(iq, m.body_iquat + 4 * b);
+										qmul(o4, xquat[b], iq);
+									}
+								} else {  // xbody
+									for (int k = 0; k < 3; k++) o3[k] = xpos[b][k];
+									for (int k = 0; k < 4; k++) o4[k] = xquat[b][k];
+								}
+								if constexpr (type == MJB_SENS_FRAMEPOS) {
+									const double cut = m.sensor_cutoff[i];
+									for (int k = 0; k < 3; k++) sd[adr + k] = cut > 0 ? fmin(fmax(o3[k], -cut), cut) : o3[k];
+								} else {
+									for (int k = 0; k < 4; k++) sd[adr + k] = o4[k];
+								}
+							}
+						}
+					});
+				}
+			});
+			// subtree com of every tree root
+			double com[NB][3];
+			sfor<NB>([&](auto B) {
+				constexpr int b = B;
+				if constexpr (Q::is_root(b)) {
+					const double stm = m.body_subtreemass[b];
+					const double inv = frcp(fmax(MJB_MINVAL, stm));
+					for (int k = 0; k < 3; k++) com[b][k] = stm < MJB_MINVAL ? xipos[b][k] : comw[b][k] * inv;
+				}
+			});
+
+			// ================= A1 comPos (cinert, cdof) + A8 comVel + A9 RNE forward pass, one sweep root -> leaf =================
+			double cin[NB][10];  // cinert, then (accumulated leaf -> root) crb
+			double cdof[NV > 0 ? NV : 1][6];
+			double cvel[NB][6], cacc[NB][6], cfrc[NB][6];
+			double grav[3];
+			{
+				const bool g_on = !(m.disableflags & MJB_DSBL_GRAVITY);
+				for (int k = 0; k < 3; k++) grav[k] = g_on ? m.gravity[k] : 0.0;
+			}
+			sfor<NB>([&](auto B) {
+				constexpr int b = B;
+				if constexpr (b == 0) return;
+				constexpr int p = T::body_parentid[b], j = T::body_jnt[b], r = T::body_rootid[b];
+				{
+					const double mass = m.body_mass[b];
+					double dif[3];
+					for (int k = 0; k < 3; k++) dif[k] = xipos[b][k] - com[r][k];
+					double *res = cin[b];
+					res[0] = rI[b][0] + mass * (dif[1] * dif[1] + dif[2] * dif[2]);
+					res[1] = rI[b][1] + mass * (dif[0] * dif[0] + dif[2] * dif[2]);
+					res[2] = rI[b][2] + mass * (dif[0] * dif[0] + dif[1] * dif[1]);
+					res[3] = rI[b][3] - mass * dif[0] * dif[1];
+					res[4] = rI[b][4] - mass * dif[0] * dif[2];
+					res[5] = rI[b][5] - mass * dif[1] * dif[2];
+					res[6] = mass * dif[0];
+					res[7] = mass * dif[1];
+					res[8] = mass * dif[2];
+					res[9] = mass;
+				}
+				// parent's velocity / acceleration (world: zero velocity, -gravity)
+				double pv[6], pa[6];
+				if constexpr (p == 0) {
+					for (int k = 0; k < 6; k++) pv[k] = 0;
+					pa[0] = pa[1] = pa[2] = 0;
+					for (int k = 0; k < 3; k++) pa[3 + k] = -grav[k];
+				} else {
+					for (int k = 0; k < 6; k++) { pv[k] = cvel[p][k]; pa[k] = cacc[p][k]; }
+				}
+				if constexpr (j >= 0) {
+					double *cd = cdof[j];
+					if constexpr (T::jnt_type[j] == MJB_JNT_SLIDE) {
+						cd[0] = cd[1] = cd[2] = 0;
+						for (int k = 0; k < 3; k++) cd[3 + k] = xaxis[j][k];
+					} else {
+						double off[3];
+						for (int k = 0; k < 3; k++) { off[k] = com[r][k] - xanch[j][k]; cd[k] = xaxis[j][k]; }
+						cross3(cd + 3, xaxis[j], off);
+					}
+					const double qv = qvel[j];
+					if constexpr (p == 0) {
+						// cdof_dot = cvel(parent) x cdof = 0
+						for (int k = 0; k < 6; k++) { cvel[b][k] = cd[k] * qv; cacc[b][k] = pa[k]; }
+					} else {
+						double cdd[6];
+						cross_motion(cdd, pv, cd);
+						for (int k = 0; k < 6; k++) { cvel[b][k] = pv[k] + cd[k] * qv; cacc[b][k] = pa[k] + cdd[k] * qv; }
+					}
+				} else {
+					for (int k = 0; k < 6; k++) { cvel[b][k] = pv[k]; cacc[b][k] = pa[k]; }
+				}
+				// cfrc_body = cinert * cacc + cvel x* (cinert * cvel)
+				double t0[6], t1[6];
+				mul_inert_vec(cfrc[b], cin[b], cacc[b]);
+				mul_inert_vec(t0, cin[b], cvel[b]);
+				cross_force(t1, cvel[b], t0);
+				for (int k = 0; k < 6; k++) cfrc[b][k] += t1[k];
+			});
+
+			// ================= A2 mj_crb + A9 RNE backward pass, one sweep leaf -> root =================
+			double qM[NV > 0 ? NV : 1][NV > 0 ? NV : 1];  // [i][a], a = i or an ancestor of i (the other entries never exist)
+			double bias[NV > 0 ? NV : 1];
+			sfor<NB - 1>([&](auto Bi) {
+				constexpr int b = NB - 1 - Bi;
+				constexpr int p = T::body_parentid[b], j = T::body_jnt[b];
+				if constexpr (j >= 0) {
+					double buf[6];
+					bias[j] = dot6r(cdof[j], cfrc[b]);
+					mul_inert_vec(buf, cin[b], cdof[j]);
+					sfor<NV>([&](auto A) {
+						constexpr int a = A;
+						if constexpr (Q::anc(a, j)) qM[j][a] = (a == j ? m.dof_armature[j] : 0.0) + dot6r(cdof[a], buf);
+					});
+				}
+				if constexpr (p > 0) {
+					for (int k = 0; k < 6; k++) cfrc[p][k] += cfrc[b][k];
+					for (int k = 0; k < 10; k++) cin[p][k] += cin[b][k];
+				}
+			});
+			if (e_on) {  // mj_energyVel: 0.5 qvel' M qvel; mj_energyPos: gravity (above) + joint springs
+				double ke = 0;
+				sfor<NV>([&](auto I) {
+					sfor<NV>([&](auto A) {
+						constexpr int i = I, a = A;
+						if constexpr (Q::anc(a, i)) ke += (a == i ? 0.5 : 1.0) * qM[i][a] * qvel[i] * qvel[a];
+					});
+				});
+				if (!(m.disableflags & MJB_DSBL_PASSIVE)) {
+					sfor<NJ>([&](auto J) {
+						const double k = m.jnt_stiffness[J], dq = qpos[J] - m.qpos_spring[J];
+						pe += 0.5 * k * dq * dq;
+					});
+				}
+				en_pe = pe;
+				en_ke = ke;
+			}
+
+			// ================= A8 mj_passive, A12 mj_fwdActuation, qfrc_smooth =================
+			double f[NV > 0 ? NV : 1];
+			{
+				const bool pas_on = !(m.disableflags & MJB_DSBL_PASSIVE);
+				sfor<NV>([&](auto I) {
+					double pas = 0;
+					if (pas_on) {
+						pas = -m.jnt_stiffness[I] * (qpos[I] - m.qpos_spring[I]);
+						pas -= m.dof_damping[I] * qvel[I];
+					}
+					f[I] = pas - bias[I];
+					f[I] += wasreset ? 0.0 : s.qfrc_applied[ev * NV + I];
+				});
+				const bool act_on = !(m.disableflags & MJB_DSBL_ACTUATION);
+				const bool clamp_on = !(m.disableflags & MJB_DSBL_CLAMPCTRL);
+				double fa[NV > 0 ? NV : 1];
+				sfor<NV>([&](auto I) { fa[I] = 0; });
+				sfor<NU>([&](auto U) {
+					constexpr int i = U, j = T::act_jnt[i];
+					double force = 0;
+					const double gear = m.actuator_gear[6 * i];
+					if (act_on) {
+						double c = ctrl[i];
+						if constexpr (T::act_ctrllimited[i]) {
+							if (clamp_on) {
+								const double lo = m.actuator_ctrlrange[2 * i], hi = m.actuator_ctrlrange[2 * i + 1];
+								c = c < lo ? lo : (c > hi ? hi : c);
+							}
+						}
+						const double len = qpos[j] * gear, vel = qvel[j] * gear;
+						double gain = m.actuator_gainprm[3 * i], bs = 0;
+						if constexpr (T::act_gaintype[i] == MJB_GAIN_AFFINE) gain = gain + m.actuator_gainprm[3 * i + 1] * len + m.actuator_gainprm[3 * i + 2] * vel;
+						if constexpr (T::act_biastype[i] == MJB_BIAS_AFFINE) bs = m.actuator_biasprm[3 * i] + m.actuator_biasprm[3 * i + 1] * len + m.actuator_biasprm[3 * i + 2] * vel;
+						force = gain * c + bs;
+						if constexpr (T::act_forcelimited[i]) {
+							const double lo = m.actuator_forcerange[2 * i], hi = m.actuator_forcerange[2 * i + 1];
+							force = force < lo ? lo : (force > hi ? hi : force);
+						}
+						fa[j] += gear * force;
+					}
+					if (sens_on) {
+						sfor<T::NSENSOR>([&](auto S) {
+							constexpr int q = S;
+							if constexpr (T::sensor_objid[q] == i && (T::sensor_type[q] == MJB_SENS_ACTUATORFRC || T::sensor_type[q] == MJB_SENS_ACTUATORPOS || T::sensor_type[q] == MJB_SENS_ACTUATORVEL)) {
+								double v = T::sensor_type[q] == MJB_SENS_ACTUATORFRC ? force : (T::sensor_type[q] == MJB_SENS_ACTUATORPOS ? qpos[j] * gear : qvel[j] * gear);
+								const double cut = m.sensor_cutoff[q];
+								sd[T::sensor_adr[q]] = cut > 0 ? fmin(fmax(v, -cut), cut) : v;
+							}
+						});
+					}
+				});
+				sfor<NV>([&](auto I) { f[I] += fa[I]; });
+			}
+			if (sens_on) {
+				sfor<T::NSENSOR>([&](auto S) {
+					constexpr int q = S, type = T::sensor_type[q];
+					if constexpr (type == MJB_SENS_JOINTPOS || type == MJB_SENS_JOINTVEL || type == MJB_SENS_CLOCK) {
+						const double v = type == MJB_SENS_CLOCK ? time : (type == MJB_SENS_JOINTPOS ? qpos[T::sensor_objid[q] < 0 ? 0 : T::sensor_objid[q]] : qvel[T::sensor_objid[q] < 0 ? 0 : T::sensor_objid[q]]);
+						const double cut = m.sensor_cutoff[q];
+						sd[T::sensor_adr[q]] = cut > 0 ? fmin(fmax(v, -cut), cut) : v;
+					}
+				});
+			}
+
+			// ================= A3 mj_factorM + A12 mj_fwdAcceleration; A16's (M + h B) factor and solve beside them =================
+			// L'DL in place, pivots from the last dof up: row k scaled by 1 / D_k, then row i -= L_ki * (row k restricted to i's ancestors)
+			const bool damp_on = m.eulerdamp != 0;
+			double qH[NV > 0 ? NV : 1][NV > 0 ? NV : 1], dinv[NV > 0 ? NV : 1], hinv[NV > 0 ? NV : 1];
+			sfor<NV>([&](auto I) {
+				sfor<NV>([&](auto A) {
+					constexpr int i = I, a = A;
+					if constexpr (Q::anc(a, i)) qH[i][a] = qM[i][a] + (a == i ? dt * m.dof_damping[i] : 0.0);
+				});
+			});
+			sfor<NV>([&](auto Ki) {
+				constexpr int k = NV - 1 - Ki;
+				dinv[k] = frcp(qM[k][k]);
+				hinv[k] = frcp(qH[k][k]);
+				sfor<NV>([&](auto Ii) {
+					constexpr int i = NV - 1 - Ii;  // ancestors of k, nearest first
+					if constexpr (i < k && Q::anc(i, k)) {
+						const double tm = qM[k][i] * dinv[k], th = qH[k][i] * hinv[k];
+						sfor<NV>([&](auto A) {
+							constexpr int a = A;
+							if constexpr (Q::anc(a, i)) {
+								qM[i][a] -= tm * qM[k][a];
+								qH[i][a] -= th * qH[k][a];
+							}
+						});
+						qM[k][i] = tm;
+						qH[k][i] = th;
+					}
+				});
+			});
+			// x = M^-1 f and y = (M + h B)^-1 f: L' sweep, D, L sweep
+			double x[NV > 0 ? NV : 1], y[NV > 0 ? NV : 1];
+			sfor<NV>([&](auto I) { x[I] = f[I]; y[I] = f[I]; });
+			sfor<NV>([&](auto Ii) {
+				constexpr int i = NV - 1 - Ii;
+				sfor<NV>([&](auto A) {
+					constexpr int a = A;
+					if constexpr (a < i && Q::anc(a, i)) { x[a] -= qM[i][a] * x[i]; y[a] -= qH[i][a] * y[i]; }
+				});
+			});
+			sfor<NV>([&](auto I) { x[I] *= dinv[I]; y[I] *= hinv[I]; });
+			sfor<NV>([&](auto I) {
+				constexpr int i = I;
+				sfor<NV>([&](auto Ai) {
+					constexpr int a = NV - 1 - Ai;  // nearest ancestor first, as mj_solveLD walks them
+					if constexpr (a < i && Q::anc(a, i)) { x[i] -= qM[i][a] * x[a]; y[i] -= qH[i][a] * y[a]; }
+				});
+			});
+			sfor<NV>([&](auto I) { qacc[I] = x[I]; qaccd[I] = damp_on ? y[I] : x[I]; });
+
+			// ---- mj_checkAcc: a bad qacc resets the env and the forward pass runs once more (mj_step)
+			if (attempt) break;
+			bool bada = false;
+			sfor<NV>([&](auto I) { bada |= bad_val(qacc[I]); });
+			if (!__builtin_amdgcn_ballot_w64(bada)) break;  // (wave-uniform: the rare second trip recomputes every lane; the others get the same values)
+			if (bada) {
+				atomicAdd(s.nwarn + MJB_WARN_BADQACC, 1ull);
+				sfor<NV>([&](auto I) { qpos[I] = m.qpos0[I]; qvel[I] = 0; });
+				sfor<NU>([&](auto I) { cn[I] = 0; ctrl[I] = 0; });
+				time = 0;
+				wasreset = true;
+			}
+		}
+
+		// ================= A16 mj_Euler =================
+		sfor<NV>([&](auto I) {
+			qvel[I] += dt * qaccd[I];
+			qpos[I] += dt * qvel[I];
+		});
+		time += dt;
+	}
+
+	// ---- the launch's state back to HBM (store_state of the generic kernels; sensordata went out from the last step)
+	{
+		const DevState MJB_AS4 &s = P->s;
+		sfor<NV>([&](auto I) {
+			s.qpos[ev * NV + I] = qpos[I];
+			s.qvel[ev * NV + I] = qvel[I];
+			s.qacc[ev * NV + I] = qacc[I];
+			s.qacc_warmstart[ev * NV + I] = qacc[I];
+		});
+		sfor<NU>([&](auto I) { s.ctrlnoise[ev * NU + I] = cn[I]; });
+		if (nz_on) sfor<NU>([&](auto I) { s.ctrl[ev * NU + I] = cn[I]; });
+		else if (wasreset) sfor<NU>([&](auto I) { s.ctrl[ev * NU + I] = 0; });
+		s.time[ev] = time;
+		if (P->m.enableflags & MJB_ENBL_ENERGY) {
+			s.energy[2 * ev] = en_pe;
+			s.energy[2 * ev + 1] = en_ke;
+		}
+	}
+}
+
+template <class T> bool topo_matches(const mjb_model_desc &h)
+{
+	if (h.nbody != T::NBODY || h.nq != T::NQ || h.nv != T::NV || h.nu != T::NU || h.njnt != T::NJNT || h.nsite != T::NSITE ||
+	    h.nsensor != T::NSENSOR || h.nsensordata != T::NSENSORDATA || h.nM != T::NM)
+		return false;
+	for (int b = 0; b < h.nbody; b++) {
+		const int jn = h.body_jntnum[b] == 1 ? h.body_jntadr[b] : -1;
+		if (h.body_jntnum[b] > 1 || h.body_parentid[b] != T::body_parentid[b] || h.body_rootid[b] != T::body_rootid[b] || jn != T::body_jnt[b] ||
+		    (h.body_sameframe[b] != 0) != (T::body_sameframe[b] != 0))
+			return false;
+	}
+	for (int j = 0; j < h.njnt; j++)
+		if (h.jnt_type[j] != T::jnt_type[j] || h.jnt_bodyid[j] != T::jnt_bodyid[j] || h.jnt_qposadr[j] != j || h.jnt_dofadr[j] != j) return false;
+	for (int d = 0; d < h.nv; d++)
+		if (h.dof_parentid[d] != T::dof_parentid[d] || h.dof_Madr[d] != T::dof_Madr[d] || h.dof_jntid[d] != d) return false;
+	for (int i = 0; i < h.nu; i++)
+		if (h.actuator_trntype[i] != MJB_TRN_JOINT || h.actuator_dyntype[i] != MJB_DYN_NONE || h.actuator_trnid[2 * i] != T::act_jnt[i] ||
+		    h.actuator_gaintype[i] != T::act_gaintype[i] || h.actuator_biastype[i] != T::act_biastype[i] ||
+		    (h.actuator_ctrllimited[i] != 0) != (T::act_ctrllimited[i] != 0) || (h.actuator_forcelimited[i] != 0) != (T::act_forcelimited[i] != 0))
+			return false;
+	for (int i = 0; i < h.nsite; i++)
+		if (h.site_bodyid[i] != T::site_bodyid[i] || (h.site_sameframe[i] != 0) != (T::site_sameframe[i] != 0)) return false;
+	for (int i = 0; i < h.nsensor; i++)
+		if (h.sensor_type[i] != T::sensor_type[i] || h.sensor_objtype[i] != T::sensor_objtype[i] || h.sensor_objid[i] != T::sensor_objid[i] ||
+		    h.sensor_adr[i] != T::sensor_adr[i] || h.sensor_refid[i] >= 0)
+			return false;
+	return true;
+}
+
+}  // namespace
+
+// Index of the compiled-in topology the model has, or -1 (mjb_compile; the generic kernels run every model).
+int mjb_lane_env_match(const mjb_model_desc *h)
+{
+	if (!h || h->nefcmax > 0 || h->nconmax > 0 || h->integrator != MJB_INT_EULER || h->nmocap > 0 || h->ntendon > 0 || h->neq > 0 || h->na > 0 ||
+	    h->nq != h->nv || h->njnt != h->nv)
+		return -1;
+#define MJB_LE_X(id, T) \
+	if (topo_matches<T>(*h)) return id;
+	MJB_LE_TOPOS(MJB_LE_X)
+#undef MJB_LE_X
+	return -1;
+}
+
+const char *mjb_lane_env_name(int topo)
+{
+#define MJB_LE_X(id, T) \
+	if (topo == id) return T::name;
+	MJB_LE_TOPOS(MJB_LE_X)
+#undef MJB_LE_X
+	return "";
+}
+
+int mjb_launch_lane_env(const KernelParams *Pdev, int topo, int env_lo, int env_hi, int nsteps, unsigned int step0, void *stream)
+{
+	const int n = env_hi - env_lo;
+	if (n <= 0) return 0;
+	const dim3 grid((unsigned int)((n + 63) / 64)), block(64);
+#define MJB_LE_X(id, T)                                                                                                                                   \
+	if (topo == id) {                                                                                                                                      \
+		hipLaunchKernelGGL(mjb_lane_env_kernel<T>, grid, block, 0, (hipStream_t)stream, (const KernelParams MJB_AS4 *)Pdev, nsteps, step0, env_lo, env_hi); \
+		return (int)hipGetLastError();                                                                                                                     \
+	}
+	MJB_LE_TOPOS(MJB_LE_X)
+#undef MJB_LE_X
+	return (int)hipErrorInvalidValue;
+}

@@ -281,6 +281,16 @@ class Batch:
         """How the last fused launch got its ctrl-noise normals (mjb_noise_mode)."""
         return ("in-kernel", "same-stream", "side-stream")[int(self.lib.mjb_noise_mode(self.ptr))]
 
+    def set_lane_env(self, mode):
+        """-1 automatic, 0 never, 1 whenever eligible: the lane = env form of the unconstrained fused step (mjb_set_lane_env)."""
+        _check(self.lib.mjb_set_lane_env(self.ptr, int(mode)), "mjb_set_lane_env")
+
+    def lane_env_info(self):
+        """(compiled-in topology index or -1, the last fused launch ran the lane = env kernel)."""
+        used = C.c_int(0)
+        topo = int(self.lib.mjb_lane_env_info(self.ptr, C.byref(used)))
+        return topo, bool(used.value)
+
     def time_steps(self, nsteps, nlaunch):
         ms = C.c_double(0)
         _check(self.lib.mjb_time_steps(self.ptr, int(nsteps), int(nlaunch), C.byref(ms)), "mjb_time_steps")

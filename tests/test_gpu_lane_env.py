@@ -1,0 +1,197 @@
+"""The lane = env form of the unconstrained fused step (csrc/mjb_lane_env.hip) against the CPU oracle and against the generic
+16-lanes-per-env kernel, through the C-ABI.
+
+Tolerances (fp64): the lane = env kernel sums over bodies in ascending order and refines hardware reciprocal seeds, the oracle walks
+leaf to root and divides, so a step agrees to rounding (<= 1e-11 relative + absolute on qacc / sensordata after one step); rollouts
+of K steps <= 1e-9 on qpos / qvel (the same bound the generic kernels are held to: tests/test_gpu_parity.py).
+"""
+import numpy as np
+import pytest
+
+from conftest import random_franka_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol, what):
+    a, b = np.asarray(a), np.asarray(b)
+    err = np.abs(a - b)
+    bound = tol * (1.0 + np.abs(b))
+    assert np.all(err <= bound), f"{what}: max err {err.max():.3e} (ref scale {np.abs(b).max():.3e})"
+
+
+@pytest.fixture(scope="module")
+def eng(oracle_built):
+    from mujoco_ros_pkgs_amd import engine, mjcf
+    return engine, mjcf, oracle_built
+
+
+def tree_state(model, nenv, seed):
+    rng = np.random.default_rng(seed)
+    qpos = np.tile(np.asarray(model["qpos0"], dtype=np.float64), (nenv, 1))
+    for j in range(model["njnt"]):
+        qpos[:, j] += rng.uniform(-0.6, 0.6, nenv) if model["jnt_type"][j] == 3 else rng.uniform(-0.03, 0.05, nenv)
+    qvel = rng.uniform(-0.5, 0.5, (nenv, model["nv"]))
+    return qpos, qvel
+
+
+def make(engine, cm, nenv, qpos, qvel, mode, ctrl=None):
+    b = engine.Batch(cm, nenv)
+    b.set_lane_env(mode)
+    b.set("qpos", qpos)
+    b.set("qvel", qvel)
+    if ctrl is not None:
+        b.set("ctrl", ctrl)
+    return b
+
+
+@pytest.mark.parametrize("asset", ["franka_like", "lane_env_tree"])
+def test_topology_is_compiled_in(eng, asset):
+    engine, mjcf, _ = eng
+    cm = engine.CompiledModel(mjcf.load_asset(asset))
+    b = engine.Batch(cm, 4)
+    topo, used = b.lane_env_info()
+    assert topo >= 0 and not used
+    b.close()
+    # a model with constraint rows never matches
+    cm3 = engine.CompiledModel(mjcf.load_asset("franka_table"))
+    b3 = engine.Batch(cm3, 4)
+    assert b3.lane_env_info()[0] == -1
+    b3.close()
+
+
+@pytest.mark.parametrize("asset,nenv", [("franka_like", 200), ("lane_env_tree", 77)])
+def test_one_step_matches_oracle_and_generic_kernel(eng, asset, nenv):
+    """Constant ctrl, one step: qpos, qvel, qacc, sensordata, time against the oracle's mjo_step and the 16-lane kernel."""
+    engine, mjcf, po = eng
+    model = mjcf.load_asset(asset)
+    model["enableflags"] = int(model["enableflags"]) | 2
+    cm = engine.CompiledModel(model)
+    qpos, qvel = (random_franka_state if asset == "franka_like" else tree_state)(model, nenv, 3)
+    qvel = qvel * 3
+    ctrl = np.random.default_rng(4).uniform(-3, 3, (nenv, model["nu"]))
+    out = {}
+    for mode in (1, 0):
+        b = make(engine, cm, nenv, qpos, qvel, mode, ctrl)
+        b.step(1)
+        assert b.lane_env_info()[1] == (mode == 1)
+        out[mode] = {f: b.get(f) for f in ("qpos", "qvel", "qacc", "qacc_warmstart", "sensordata", "time", "energy", "ctrl")}
+        b.close()
+    d = po.OracleData(model)
+    for e in range(nenv):
+        d.reset()
+        d.qpos[:] = qpos[e]
+        d.qvel[:] = qvel[e]
+        d.ctrl[:] = ctrl[e]
+        d.step(1)
+        for f in ("qpos", "qvel", "qacc", "sensordata", "energy"):
+            _close(out[1][f][e], d.field(f), 1e-11, f"{asset} {f} env {e} vs oracle")
+    for f in out[1]:
+        _close(out[1][f], out[0][f], 1e-11, f"{asset} {f} vs the generic kernel")
+
+
+@pytest.mark.parametrize("asset,nenv,K,std", [("franka_like", 130, 10, 5.0), ("franka_like", 64, 200, 43.5), ("lane_env_tree", 96, 10, 1.0),
+                                              ("lane_env_tree", 33, 300, 1.5)])
+def test_noise_rollout_matches_oracle(eng, asset, nenv, K, std):
+    """OU ctrl noise on: K < 16 generates the normals inside the kernel, longer launches read the pre-generated buffer."""
+    engine, mjcf, po = eng
+    model = mjcf.load_asset(asset)
+    cm = engine.CompiledModel(model)
+    qpos, qvel = (random_franka_state if asset == "franka_like" else tree_state)(model, nenv, 5)
+    b = make(engine, cm, nenv, qpos, qvel, 1)
+    b.set_ctrl_noise(std, 0.1, 777, 1000)
+    b.step(K)
+    assert b.lane_env_info()[1]
+    q, v, sd = b.get("qpos"), b.get("qvel"), b.get("sensordata")
+    t = b.get("time")
+    b.close()
+    oq, ov, osd = po.rollout(model, qpos, qvel, K, noise_std=std, noise_rate=0.1, seed=777, env_offset=1000, nthreads=8)
+    _close(q, oq, 1e-9, f"{asset} qpos after {K} steps")
+    _close(v, ov, 1e-9, f"{asset} qvel after {K} steps")
+    _close(sd, osd, 1e-9, f"{asset} sensordata after {K} steps")
+    assert np.allclose(t, K * float(np.ravel(model["timestep"])[0]), atol=1e-12)
+
+
+def test_launch_splits_agree(eng):
+    """3 x 40 steps, 120 steps at once and lane = env / generic launches interleaved end in the same state (the Philox counters,
+    the OU state and time travel through HBM exactly as in the generic kernels)."""
+    engine, mjcf, _ = eng
+    model = mjcf.load_asset("franka_like")
+    cm = engine.CompiledModel(model)
+    nenv = 70
+    qpos, qvel = random_franka_state(model, nenv, 9)
+    res = []
+    for plan in ([(1, 120)], [(1, 40), (1, 40), (1, 40)], [(1, 40), (0, 40), (1, 40)], [(0, 120)]):
+        b = make(engine, cm, nenv, qpos, qvel, 1)
+        b.set_ctrl_noise(20.0, 0.1, 5, 0)
+        for mode, k in plan:
+            b.set_lane_env(mode)
+            b.step(k)
+        res.append((b.get("qpos"), b.get("qvel"), b.get("ctrl"), b.get("time")))
+        b.close()
+    for i in (1, 2):
+        for a, c in zip(res[0], res[i]):
+            if i == 1:
+                assert np.array_equal(a, c), "splitting a lane = env launch changed the result"
+            else:
+                _close(a, c, 1e-9, "lane = env / generic interleaved")
+    for a, c in zip(res[0], res[3]):
+        _close(a, c, 1e-9, "lane = env vs generic, 120 steps")
+
+
+def test_bad_state_resets_like_mj_step(eng):
+    """mj_checkPos / mj_checkVel / mj_checkAcc: NaN qpos, a huge qvel and a qacc beyond mjMAXVAL reset the env and count the warning,
+    in the lane = env kernel as in the generic one and in the oracle."""
+    engine, mjcf, po = eng
+    model = mjcf.load_asset("franka_like")
+    cm = engine.CompiledModel(model)
+    nenv = 128
+    qpos, qvel = random_franka_state(model, nenv, 11)
+    qpos[5, 2] = np.nan
+    qvel[17, 0] = 1e12
+    qvel[17, 1] = np.nan
+    qpos[40, 0] = np.inf
+    qvel[90, 3] = 9e9  # fine for mj_checkVel; the damping force makes qacc huge but finite -> no reset unless beyond 1e10
+    ctrl = np.random.default_rng(1).uniform(-5, 5, (nenv, model["nu"]))
+    got = {}
+    for mode in (1, 0):
+        b = make(engine, cm, nenv, qpos, qvel, mode, ctrl)
+        b.step(3)
+        got[mode] = (b.get("qpos"), b.get("qvel"), b.get("ctrl"), b.get("time"), [b.warning(w) for w in range(8)])
+        b.close()
+    assert got[1][4] == got[0][4], f"warning counters differ: {got[1][4]} vs {got[0][4]}"
+    assert got[1][4][4] == 2 and got[1][4][5] == 1 and got[1][4][6] >= 1
+    for a, c in zip(got[1][:4], got[0][:4]):
+        _close(a, c, 1e-9, "state after resets, lane = env vs generic")
+    assert np.all(np.isfinite(got[1][0])) and np.all(got[1][2][5] == 0) and np.all(got[1][2][17] == 0)
+    d = po.OracleData(model)
+    for e in (5, 17, 40, 90):
+        d.reset()
+        d.qpos[:] = qpos[e]
+        d.qvel[:] = qvel[e]
+        d.ctrl[:] = ctrl[e]
+        d.step(3)
+        _close(got[1][0][e], d.field("qpos"), 1e-9, f"env {e} qpos vs oracle")
+        _close(got[1][1][e], d.field("qvel"), 1e-9, f"env {e} qvel vs oracle")
+
+
+def test_automatic_mode_threshold(eng):
+    """mode -1: whole-batch launches of >= MJB_LANE_ENV_MIN_ENVS envs (default 16384) take the lane = env kernel, smaller ones do not."""
+    engine, mjcf, po = eng
+    model = mjcf.load_asset("franka_like")
+    cm = engine.CompiledModel(model)
+    for nenv, expect in ((1024, False), (16384, True)):
+        qpos, qvel = random_franka_state(model, nenv, 2)
+        b = make(engine, cm, nenv, qpos, qvel, -1)
+        b.set_ctrl_noise(10.0, 0.1, 3, 0)
+        b.step(20)
+        assert b.lane_env_info()[1] == expect
+        if expect:
+            idx = np.arange(0, nenv, 1023)
+            q = b.get("qpos")
+            assert np.all(np.isfinite(q))
+            # sampled envs against the oracle (their global env ids key the Philox stream: one rollout call per sampled env)
+            for e in idx[:6]:
+                oq, ov, _ = po.rollout(model, qpos[e:e + 1], qvel[e:e + 1], 20, noise_std=10.0, noise_rate=0.1, seed=3, env_offset=int(e))
+                _close(q[e], oq[0], 1e-9, f"env {e} of {nenv}")
+        b.close()
