@@ -73,23 +73,55 @@ DEVI void normalize4_sel(double *q)
 
 DEVI bool bad_val(double x) { return !(x == x) || fabs(x) > MJB_MAXVAL; }
 
+// LDS of a block (= one wavefront): pair slot q of lane l = the two doubles at (q * 64 + l) * 16 bytes -- one ds_read_b128 /
+// ds_write_b128 per pair, conflict-free.  Slots [0, NV): (qpos_i, qvel_i); then three slots per body whose force the backward
+// sweep reads (cfrc_body): the wavefront's overflow space next to its registers (4 blocks per CU: 40 KB each).
+template <class T> struct Lds {
+	using Q = Tq<T>;
+	// the body's cfrc is consumed by the backward sweep (it, or an ancestor, carries a joint)
+	static constexpr bool needed(int b)
+	{
+		for (int a = b; a > 0; a = T::body_parentid[a])
+			if (T::body_jnt[a] >= 0) return true;
+		return false;
+	}
+	static constexpr int slot(int b)  // first of the body's three pair slots
+	{
+		int n = 0;
+		for (int a = 1; a < b; a++)
+			if (needed(a)) n++;
+		return T::NV + 3 * n;
+	}
+	static constexpr int nslots() { return slot(T::NBODY); }
+	static constexpr int bytes() { return nslots() * 64 * 16; }
+};
+
+struct alignas(16) Pair { double a, b; };
+
 template <class T>
 __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB_AS4 *__restrict__ P, const int nsteps, const unsigned int step0,
                                                           const int env_lo, const int env_hi)
 {
-	constexpr int NB = T::NBODY, NV = T::NV, NU = T::NU, NJ = T::NJNT;
+	constexpr int NB = T::NBODY, NV = T::NV, NU = T::NU;
 	using Q = Tq<T>;
-	const int env = env_lo + (int)(blockIdx.x * 64 + threadIdx.x);
-	if (env >= env_hi) return;
+	using LD = Lds<T>;
+	static_assert(LD::bytes() <= 40960, "lane = env kernel: the topology needs more LDS than a quarter of a CU's");
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_le[];
+	Pair *const lp = reinterpret_cast<Pair *>(smem_le) + threadIdx.x;  // pair slot q of this lane: lp[64 * q]
+	// (a tail lane without an env keeps running on the last env's data and stores nothing: no divergent exit, the wave-uniform
+	//  branches below stay uniform)
+	const int env_raw = env_lo + (int)(blockIdx.x * 64 + threadIdx.x);
+	const bool live = env_raw < env_hi;
+	const int env = live ? env_raw : env_hi - 1;
 	const size_t ev = (size_t)env;
 
-	// ---- the env's state, in registers for the whole launch
-	double qpos[NV], qvel[NV], qacc[NV], cn[NU > 0 ? NU : 1];
+	// ---- the env's state: (qpos, qvel) in LDS, the OU noise state in registers
+	double qacc[NV], cn[NU > 0 ? NU : 1];
 	double time, en_pe = 0, en_ke = 0;
 	bool wasreset = false;  // mj_resetData ran inside this launch: ctrl / qfrc_applied read as zero from then on (the frame copy of the generic kernels)
 	{
 		const DevState MJB_AS4 &s = P->s;
-		sfor<NV>([&](auto I) { qpos[I] = s.qpos[ev * NV + I]; qvel[I] = s.qvel[ev * NV + I]; qacc[I] = s.qacc[ev * NV + I]; });
+		sfor<NV>([&](auto I) { lp[64 * I] = Pair{ s.qpos[ev * NV + I], s.qvel[ev * NV + I] }; qacc[I] = s.qacc[ev * NV + I]; });
 		sfor<NU>([&](auto I) { cn[I] = s.ctrlnoise[ev * NU + I]; });
 		time = s.time[ev];
 	}
@@ -124,8 +156,12 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 				sfor<NU>([&](auto I) { cn[I] = rate * cn[I] + scale * zb[I]; });
 			} else {
 				asm volatile("" ::: "memory");
+				// (one copy of the generator in the instruction stream: the normals go through the cfrc slots, free at this point)
 				const unsigned long long seed = Pq->nz.seed, genv = (unsigned long long)(Pq->nz.env_offset + env);
-				sfor<NU>([&](auto I) { cn[I] = rate * cn[I] + scale * philox_normal(seed, genv, step0 + (unsigned int)st, (unsigned int)I); });
+				double *zl = reinterpret_cast<double *>(smem_le) + 2 * 64 * NV + threadIdx.x;
+#pragma nounroll
+				for (int i = 0; i < NU; i++) zl[64 * i] = philox_normal(seed, genv, step0 + (unsigned int)st, (unsigned int)i);
+				sfor<NU>([&](auto I) { cn[I] = rate * cn[I] + scale * zl[64 * I]; });
 			}
 			sfor<NU>([&](auto I) { ctrl[I] = cn[I]; });
 		} else {
@@ -135,10 +171,10 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 		// ---- mj_checkPos / mj_checkVel (qpos first: its reset hides a bad qvel)
 		{
 			bool badp = false, badv = false;
-			sfor<NV>([&](auto I) { badp |= bad_val(qpos[I]); badv |= bad_val(qvel[I]); });
+			sfor<NV>([&](auto I) { const Pair qv = lp[64 * I]; badp |= bad_val(qv.a); badv |= bad_val(qv.b); });
 			if (badp || badv) {
-				atomicAdd(s.nwarn + (badp ? MJB_WARN_BADQPOS : MJB_WARN_BADQVEL), 1ull);
-				sfor<NV>([&](auto I) { qpos[I] = m.qpos0[I]; qvel[I] = 0; });
+				if (live) atomicAdd(s.nwarn + (badp ? MJB_WARN_BADQPOS : MJB_WARN_BADQVEL), 1ull);
+				sfor<NV>([&](auto I) { lp[64 * I] = Pair{ m.qpos0[I], 0.0 }; });
 				sfor<NU>([&](auto I) { cn[I] = 0; ctrl[I] = 0; });
 				time = 0;
 				wasreset = true;
@@ -150,18 +186,28 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 		for (int attempt = 0; attempt < 2; attempt++) {
 			const bool e_on = last && (m.enableflags & MJB_ENBL_ENERGY);
 			const bool eg_on = e_on && !(m.disableflags & MJB_DSBL_GRAVITY);
-			const bool sens_on = last && !(m.disableflags & MJB_DSBL_SENSOR);
+			const bool sens_on = last && live && !(m.disableflags & MJB_DSBL_SENSOR);
 			double *sd = s.sensordata + ev * T::NSENSORDATA;
 			double pe = 0;
 
-			// ================= A1 mj_kinematics (+ the position part of comPos per body) =================
+			// ============ one sweep root -> leaf: A1 mj_kinematics, comPos (cinert, cdof), A8 comVel, A9 RNE's forward pass ============
+			// Spatial quantities of a tree are taken about the origin of its root body instead of MuJoCo's subtree com (any common point
+			// gives the same qM / qfrc_bias; the com would need every body's pose before the first inertia, i.e. a second sweep with
+			// 15 doubles per body kept across).
 			double xpos[NB][3], xquat[NB][4], xmat[NB][9];
-			double xipos[NB][3], rI[NB][6];
-			double xaxis[NJ][3], xanch[NJ][3];
-			double comw[NB][3];  // per tree root: sum of mass * xipos over the tree
+			double cin[NB][10];  // cinert, then (accumulated leaf -> root) crb
+			double cdof[NV > 0 ? NV : 1][6];
+			double cvel[NB][6], cacc[NB][6];
+			double f[NV > 0 ? NV : 1];  // qfrc_passive + qfrc_applied + qfrc_actuator, then (- qfrc_bias) qfrc_smooth
+			double grav[3];
+			{
+				const bool g_on = !(m.disableflags & MJB_DSBL_GRAVITY);
+				for (int k = 0; k < 3; k++) grav[k] = g_on ? m.gravity[k] : 0.0;
+			}
+			const bool pas_on = !(m.disableflags & MJB_DSBL_PASSIVE);
 			sfor<NB>([&](auto B) {
 				constexpr int b = B;
-				if constexpr (b == 0) return;
+				if constexpr (b > 0) {
 				constexpr int p = T::body_parentid[b], j = T::body_jnt[b], r = T::body_rootid[b];
 				double pos[3], quat[4];
 				ldc3(pos, m.body_pos + 3 * b);
@@ -173,17 +219,21 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 					qmul(q, xquat[p], quat);
 					for (int k = 0; k < 4; k++) quat[k] = q[k];
 				}
+				[[maybe_unused]] double xaxis[3], xanch[3], qp = 0, qv = 0;
 				if constexpr (j >= 0) {
+					const Pair s2 = lp[64 * j];
+					qp = s2.a;
+					qv = s2.b;
 					double M0[9], ax[3], jp[3], v[3];
 					ldc3(ax, m.jnt_axis + 3 * j);
 					ldc3(jp, m.jnt_pos + 3 * j);
 					quat2mat_nocheck(M0, quat);
-					matvec3(xaxis[j], M0, ax);
+					matvec3(xaxis, M0, ax);
 					matvec3(v, M0, jp);
-					for (int k = 0; k < 3; k++) xanch[j][k] = v[k] + pos[k];
-					const double dq = qpos[j] - m.qpos0[j];
+					for (int k = 0; k < 3; k++) xanch[k] = v[k] + pos[k];
+					const double dq = qp - m.qpos0[j];
 					if constexpr (T::jnt_type[j] == MJB_JNT_SLIDE) {
-						for (int k = 0; k < 3; k++) pos[k] += xaxis[j][k] * dq;
+						for (int k = 0; k < 3; k++) pos[k] += xaxis[k] * dq;
 					} else {
 						double sn, cs, ql[4], q[4];
 						sincos(dq * 0.5, &sn, &cs);
@@ -195,49 +245,43 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 							double M1[9];
 							quat2mat_nocheck(M1, quat);
 							matvec3(v, M1, jp);
-							for (int k = 0; k < 3; k++) pos[k] = xanch[j][k] - v[k];
+							for (int k = 0; k < 3; k++) pos[k] = xanch[k] - v[k];
 						} else {
-							for (int k = 0; k < 3; k++) pos[k] = xanch[j][k];
+							for (int k = 0; k < 3; k++) pos[k] = xanch[k];
 						}
+					}
+					// passive + applied forces of the dof, while qpos / qvel are at hand
+					double pas = 0;
+					if (pas_on) {
+						pas = -m.jnt_stiffness[j] * (qp - m.qpos_spring[j]);
+						pas -= m.dof_damping[j] * qv;
+					}
+					f[j] = pas + (wasreset ? 0.0 : s.qfrc_applied[ev * NV + j]);
+					if (e_on && pas_on) {
+						const double dqs = qp - m.qpos_spring[j];
+						pe += 0.5 * m.jnt_stiffness[j] * dqs * dqs;
 					}
 				}
 				normalize4_sel(quat);
 				for (int k = 0; k < 3; k++) xpos[b][k] = pos[k];
 				for (int k = 0; k < 4; k++) xquat[b][k] = quat[k];
 				quat2mat_nocheck(xmat[b], quat);
-				// inertial frame, and the body's inertia rotated into the world frame (the offset-free part of mju_inertCom)
-				double ximat[9];
+				// inertial frame
+				double xipos[3], ximat[9];
 				if constexpr (T::body_sameframe[b]) {
-					for (int k = 0; k < 3; k++) xipos[b][k] = xpos[b][k];
+					for (int k = 0; k < 3; k++) xipos[k] = xpos[b][k];
 					for (int k = 0; k < 9; k++) ximat[k] = xmat[b][k];
 				} else {
 					double ip[3], iq[4], v[3], q[4];
 					ldc3(ip, m.body_ipos + 3 * b);
 					ldc4(iq, m.body_iquat + 4 * b);
 					matvec3(v, xmat[b], ip);
-					for (int k = 0; k < 3; k++) xipos[b][k] = v[k] + xpos[b][k];
+					for (int k = 0; k < 3; k++) xipos[k] = v[k] + xpos[b][k];
 					qmul(q, xquat[b], iq);
 					quat2mat_nocheck(ximat, q);
 				}
-				{
-					const double i0 = m.body_inertia[3 * b], i1 = m.body_inertia[3 * b + 1], i2 = m.body_inertia[3 * b + 2];
-					const double *mat = ximat;
-					const double t0 = mat[0] * i0, t1 = mat[3] * i0, t2 = mat[6] * i0;
-					const double t3 = mat[1] * i1, t4 = mat[4] * i1, t5 = mat[7] * i1;
-					const double t6 = mat[2] * i2, t7 = mat[5] * i2, t8 = mat[8] * i2;
-					rI[b][0] = mat[0] * t0 + mat[1] * t3 + mat[2] * t6;
-					rI[b][1] = mat[3] * t1 + mat[4] * t4 + mat[5] * t7;
-					rI[b][2] = mat[6] * t2 + mat[7] * t5 + mat[8] * t8;
-					rI[b][3] = mat[0] * t1 + mat[1] * t4 + mat[2] * t7;
-					rI[b][4] = mat[0] * t2 + mat[1] * t5 + mat[2] * t8;
-					rI[b][5] = mat[3] * t2 + mat[4] * t5 + mat[5] * t8;
-				}
-				{
-					const double mass = m.body_mass[b];
-					if constexpr (r == b) for (int k = 0; k < 3; k++) comw[r][k] = mass * xipos[b][k];
-					else for (int k = 0; k < 3; k++) comw[r][k] += mass * xipos[b][k];
-					if (eg_on) pe -= mass * (m.gravity[0] * xipos[b][0] + m.gravity[1] * xipos[b][1] + m.gravity[2] * xipos[b][2]);
-				}
+				const double mass = m.body_mass[b];
+				if (eg_on) pe -= mass * (m.gravity[0] * xipos[0] + m.gravity[1] * xipos[1] + m.gravity[2] * xipos[2]);
 				// position-stage sensors on this body's frames (the last step's values are the launch's sensordata)
 				if (sens_on) {
 					sfor<T::NSENSOR>([&](auto S) {
@@ -263,7 +307,7 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 									}
 								} else if constexpr (ot == MJB_OBJ_BODY) {
 									if constexpr (type == MJB_SENS_FRAMEPOS) {
-										for (int k = 0; k < 3; k++) o3[k] = xipos[b][k];
+										for (int k = 0; k < 3; k++) o3[k] = xipos[k];
 									} else {
 										double iq[4];
 										ldc4(iq, m.body_iquat + 4 * b);
@@ -283,145 +327,90 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 						}
 					});
 				}
-			});
-			// subtree com of every tree root
-			double com[NB][3];
-			sfor<NB>([&](auto B) {
-				constexpr int b = B;
-				if constexpr (Q::is_root(b)) {
-					const double stm = m.body_subtreemass[b];
-					const double inv = frcp(fmax(MJB_MINVAL, stm));
-					for (int k = 0; k < 3; k++) com[b][k] = stm < MJB_MINVAL ? xipos[b][k] : comw[b][k] * inv;
-				}
-			});
-
-			// ================= A1 comPos (cinert, cdof) + A8 comVel + A9 RNE forward pass, one sweep root -> leaf =================
-			double cin[NB][10];  // cinert, then (accumulated leaf -> root) crb
-			double cdof[NV > 0 ? NV : 1][6];
-			double cvel[NB][6], cacc[NB][6], cfrc[NB][6];
-			double grav[3];
-			{
-				const bool g_on = !(m.disableflags & MJB_DSBL_GRAVITY);
-				for (int k = 0; k < 3; k++) grav[k] = g_on ? m.gravity[k] : 0.0;
-			}
-			sfor<NB>([&](auto B) {
-				constexpr int b = B;
-				if constexpr (b == 0) return;
-				constexpr int p = T::body_parentid[b], j = T::body_jnt[b], r = T::body_rootid[b];
-				{
-					const double mass = m.body_mass[b];
-					double dif[3];
-					for (int k = 0; k < 3; k++) dif[k] = xipos[b][k] - com[r][k];
-					double *res = cin[b];
-					res[0] = rI[b][0] + mass * (dif[1] * dif[1] + dif[2] * dif[2]);
-					res[1] = rI[b][1] + mass * (dif[0] * dif[0] + dif[2] * dif[2]);
-					res[2] = rI[b][2] + mass * (dif[0] * dif[0] + dif[1] * dif[1]);
-					res[3] = rI[b][3] - mass * dif[0] * dif[1];
-					res[4] = rI[b][4] - mass * dif[0] * dif[2];
-					res[5] = rI[b][5] - mass * dif[1] * dif[2];
-					res[6] = mass * dif[0];
-					res[7] = mass * dif[1];
-					res[8] = mass * dif[2];
-					res[9] = mass;
-				}
-				// parent's velocity / acceleration (world: zero velocity, -gravity)
-				double pv[6], pa[6];
-				if constexpr (p == 0) {
-					for (int k = 0; k < 6; k++) pv[k] = 0;
-					pa[0] = pa[1] = pa[2] = 0;
-					for (int k = 0; k < 3; k++) pa[3 + k] = -grav[k];
-				} else {
-					for (int k = 0; k < 6; k++) { pv[k] = cvel[p][k]; pa[k] = cacc[p][k]; }
-				}
-				if constexpr (j >= 0) {
-					double *cd = cdof[j];
-					if constexpr (T::jnt_type[j] == MJB_JNT_SLIDE) {
-						cd[0] = cd[1] = cd[2] = 0;
-						for (int k = 0; k < 3; k++) cd[3 + k] = xaxis[j][k];
-					} else {
-						double off[3];
-						for (int k = 0; k < 3; k++) { off[k] = com[r][k] - xanch[j][k]; cd[k] = xaxis[j][k]; }
-						cross3(cd + 3, xaxis[j], off);
+				if constexpr (LD::needed(b)) {
+					// cinert about the tree root's origin (mju_inertCom with that offset)
+					{
+						double dif[3];
+						if constexpr (r == b) { dif[0] = xipos[0] - pos[0]; dif[1] = xipos[1] - pos[1]; dif[2] = xipos[2] - pos[2]; }
+						else for (int k = 0; k < 3; k++) dif[k] = xipos[k] - xpos[r][k];
+						const double i0 = m.body_inertia[3 * b], i1 = m.body_inertia[3 * b + 1], i2 = m.body_inertia[3 * b + 2];
+						const double *mat = ximat;
+						const double t0 = mat[0] * i0, t1 = mat[3] * i0, t2 = mat[6] * i0;
+						const double t3 = mat[1] * i1, t4 = mat[4] * i1, t5 = mat[7] * i1;
+						const double t6 = mat[2] * i2, t7 = mat[5] * i2, t8 = mat[8] * i2;
+						double *res = cin[b];
+						res[0] = mat[0] * t0 + mat[1] * t3 + mat[2] * t6 + mass * (dif[1] * dif[1] + dif[2] * dif[2]);
+						res[1] = mat[3] * t1 + mat[4] * t4 + mat[5] * t7 + mass * (dif[0] * dif[0] + dif[2] * dif[2]);
+						res[2] = mat[6] * t2 + mat[7] * t5 + mat[8] * t8 + mass * (dif[0] * dif[0] + dif[1] * dif[1]);
+						res[3] = mat[0] * t1 + mat[1] * t4 + mat[2] * t7 - mass * dif[0] * dif[1];
+						res[4] = mat[0] * t2 + mat[1] * t5 + mat[2] * t8 - mass * dif[0] * dif[2];
+						res[5] = mat[3] * t2 + mat[4] * t5 + mat[5] * t8 - mass * dif[1] * dif[2];
+						res[6] = mass * dif[0];
+						res[7] = mass * dif[1];
+						res[8] = mass * dif[2];
+						res[9] = mass;
 					}
-					const double qv = qvel[j];
+					// parent's velocity / acceleration (world: zero velocity, -gravity)
+					double pv[6], pa[6];
 					if constexpr (p == 0) {
-						// cdof_dot = cvel(parent) x cdof = 0
-						for (int k = 0; k < 6; k++) { cvel[b][k] = cd[k] * qv; cacc[b][k] = pa[k]; }
+						for (int k = 0; k < 6; k++) pv[k] = 0;
+						pa[0] = pa[1] = pa[2] = 0;
+						for (int k = 0; k < 3; k++) pa[3 + k] = -grav[k];
+					} else if constexpr (!LD::needed(p)) {  // a jointless chain down from the world: at rest
+						for (int k = 0; k < 6; k++) pv[k] = 0;
+						pa[0] = pa[1] = pa[2] = 0;
+						for (int k = 0; k < 3; k++) pa[3 + k] = -grav[k];
 					} else {
-						double cdd[6];
-						cross_motion(cdd, pv, cd);
-						for (int k = 0; k < 6; k++) { cvel[b][k] = pv[k] + cd[k] * qv; cacc[b][k] = pa[k] + cdd[k] * qv; }
+						for (int k = 0; k < 6; k++) { pv[k] = cvel[p][k]; pa[k] = cacc[p][k]; }
 					}
-				} else {
-					for (int k = 0; k < 6; k++) { cvel[b][k] = pv[k]; cacc[b][k] = pa[k]; }
+					if constexpr (j >= 0) {
+						double *cd = cdof[j];
+						if constexpr (T::jnt_type[j] == MJB_JNT_SLIDE) {
+							cd[0] = cd[1] = cd[2] = 0;
+							for (int k = 0; k < 3; k++) cd[3 + k] = xaxis[k];
+						} else {
+							double off[3];
+							if constexpr (r == b) for (int k = 0; k < 3; k++) off[k] = pos[k] - xanch[k];
+							else for (int k = 0; k < 3; k++) off[k] = xpos[r][k] - xanch[k];
+							for (int k = 0; k < 3; k++) cd[k] = xaxis[k];
+							cross3(cd + 3, xaxis, off);
+						}
+						if constexpr (p == 0 || !LD::needed(p)) {
+							// cdof_dot = cvel(parent) x cdof = 0
+							for (int k = 0; k < 6; k++) { cvel[b][k] = cd[k] * qv; cacc[b][k] = pa[k]; }
+						} else {
+							double cdd[6];
+							cross_motion(cdd, pv, cd);
+							for (int k = 0; k < 6; k++) { cvel[b][k] = pv[k] + cd[k] * qv; cacc[b][k] = pa[k] + cdd[k] * qv; }
+						}
+					} else {
+						for (int k = 0; k < 6; k++) { cvel[b][k] = pv[k]; cacc[b][k] = pa[k]; }
+					}
+					// cfrc_body = cinert * cacc + cvel x* (cinert * cvel): parked in LDS for the backward sweep
+					double cf[6], t0[6], t1[6];
+					mul_inert_vec(cf, cin[b], cacc[b]);
+					mul_inert_vec(t0, cin[b], cvel[b]);
+					cross_force(t1, cvel[b], t0);
+					constexpr int q0 = LD::slot(b);
+					lp[64 * q0] = Pair{ cf[0] + t1[0], cf[1] + t1[1] };
+					lp[64 * (q0 + 1)] = Pair{ cf[2] + t1[2], cf[3] + t1[3] };
+					lp[64 * (q0 + 2)] = Pair{ cf[4] + t1[4], cf[5] + t1[5] };
 				}
-				// cfrc_body = cinert * cacc + cvel x* (cinert * cvel)
-				double t0[6], t1[6];
-				mul_inert_vec(cfrc[b], cin[b], cacc[b]);
-				mul_inert_vec(t0, cin[b], cvel[b]);
-				cross_force(t1, cvel[b], t0);
-				for (int k = 0; k < 6; k++) cfrc[b][k] += t1[k];
+				__builtin_amdgcn_sched_barrier(0);
+				}
 			});
 
-			// ================= A2 mj_crb + A9 RNE backward pass, one sweep leaf -> root =================
-			double qM[NV > 0 ? NV : 1][NV > 0 ? NV : 1];  // [i][a], a = i or an ancestor of i (the other entries never exist)
-			double bias[NV > 0 ? NV : 1];
-			sfor<NB - 1>([&](auto Bi) {
-				constexpr int b = NB - 1 - Bi;
-				constexpr int p = T::body_parentid[b], j = T::body_jnt[b];
-				if constexpr (j >= 0) {
-					double buf[6];
-					bias[j] = dot6r(cdof[j], cfrc[b]);
-					mul_inert_vec(buf, cin[b], cdof[j]);
-					sfor<NV>([&](auto A) {
-						constexpr int a = A;
-						if constexpr (Q::anc(a, j)) qM[j][a] = (a == j ? m.dof_armature[j] : 0.0) + dot6r(cdof[a], buf);
-					});
-				}
-				if constexpr (p > 0) {
-					for (int k = 0; k < 6; k++) cfrc[p][k] += cfrc[b][k];
-					for (int k = 0; k < 10; k++) cin[p][k] += cin[b][k];
-				}
-			});
-			if (e_on) {  // mj_energyVel: 0.5 qvel' M qvel; mj_energyPos: gravity (above) + joint springs
-				double ke = 0;
-				sfor<NV>([&](auto I) {
-					sfor<NV>([&](auto A) {
-						constexpr int i = I, a = A;
-						if constexpr (Q::anc(a, i)) ke += (a == i ? 0.5 : 1.0) * qM[i][a] * qvel[i] * qvel[a];
-					});
-				});
-				if (!(m.disableflags & MJB_DSBL_PASSIVE)) {
-					sfor<NJ>([&](auto J) {
-						const double k = m.jnt_stiffness[J], dq = qpos[J] - m.qpos_spring[J];
-						pe += 0.5 * k * dq * dq;
-					});
-				}
-				en_pe = pe;
-				en_ke = ke;
-			}
-
-			// ================= A8 mj_passive, A12 mj_fwdActuation, qfrc_smooth =================
-			double f[NV > 0 ? NV : 1];
+			// ================= A12 mj_fwdActuation (needs nothing of the sweeps; here the ctrl registers die) =================
 			{
-				const bool pas_on = !(m.disableflags & MJB_DSBL_PASSIVE);
-				sfor<NV>([&](auto I) {
-					double pas = 0;
-					if (pas_on) {
-						pas = -m.jnt_stiffness[I] * (qpos[I] - m.qpos_spring[I]);
-						pas -= m.dof_damping[I] * qvel[I];
-					}
-					f[I] = pas - bias[I];
-					f[I] += wasreset ? 0.0 : s.qfrc_applied[ev * NV + I];
-				});
 				const bool act_on = !(m.disableflags & MJB_DSBL_ACTUATION);
 				const bool clamp_on = !(m.disableflags & MJB_DSBL_CLAMPCTRL);
-				double fa[NV > 0 ? NV : 1];
-				sfor<NV>([&](auto I) { fa[I] = 0; });
 				sfor<NU>([&](auto U) {
 					constexpr int i = U, j = T::act_jnt[i];
 					double force = 0;
 					const double gear = m.actuator_gear[6 * i];
+					[[maybe_unused]] Pair s2{ 0, 0 };
+					constexpr bool need_qv = T::act_gaintype[i] == MJB_GAIN_AFFINE || T::act_biastype[i] == MJB_BIAS_AFFINE;
+					if constexpr (need_qv) s2 = lp[64 * j];
 					if (act_on) {
 						double c = ctrl[i];
 						if constexpr (T::act_ctrllimited[i]) {
@@ -430,7 +419,7 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 								c = c < lo ? lo : (c > hi ? hi : c);
 							}
 						}
-						const double len = qpos[j] * gear, vel = qvel[j] * gear;
+						const double len = s2.a * gear, vel = s2.b * gear;
 						double gain = m.actuator_gainprm[3 * i], bs = 0;
 						if constexpr (T::act_gaintype[i] == MJB_GAIN_AFFINE) gain = gain + m.actuator_gainprm[3 * i + 1] * len + m.actuator_gainprm[3 * i + 2] * vel;
 						if constexpr (T::act_biastype[i] == MJB_BIAS_AFFINE) bs = m.actuator_biasprm[3 * i] + m.actuator_biasprm[3 * i + 1] * len + m.actuator_biasprm[3 * i + 2] * vel;
@@ -439,30 +428,79 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 							const double lo = m.actuator_forcerange[2 * i], hi = m.actuator_forcerange[2 * i + 1];
 							force = force < lo ? lo : (force > hi ? hi : force);
 						}
-						fa[j] += gear * force;
+						f[j] += gear * force;
 					}
 					if (sens_on) {
 						sfor<T::NSENSOR>([&](auto S) {
 							constexpr int q = S;
 							if constexpr (T::sensor_objid[q] == i && (T::sensor_type[q] == MJB_SENS_ACTUATORFRC || T::sensor_type[q] == MJB_SENS_ACTUATORPOS || T::sensor_type[q] == MJB_SENS_ACTUATORVEL)) {
-								double v = T::sensor_type[q] == MJB_SENS_ACTUATORFRC ? force : (T::sensor_type[q] == MJB_SENS_ACTUATORPOS ? qpos[j] * gear : qvel[j] * gear);
+								const Pair s3 = lp[64 * j];
+								double v = T::sensor_type[q] == MJB_SENS_ACTUATORFRC ? force : (T::sensor_type[q] == MJB_SENS_ACTUATORPOS ? s3.a * gear : s3.b * gear);
 								const double cut = m.sensor_cutoff[q];
 								sd[T::sensor_adr[q]] = cut > 0 ? fmin(fmax(v, -cut), cut) : v;
 							}
 						});
 					}
 				});
-				sfor<NV>([&](auto I) { f[I] += fa[I]; });
 			}
 			if (sens_on) {
 				sfor<T::NSENSOR>([&](auto S) {
 					constexpr int q = S, type = T::sensor_type[q];
 					if constexpr (type == MJB_SENS_JOINTPOS || type == MJB_SENS_JOINTVEL || type == MJB_SENS_CLOCK) {
-						const double v = type == MJB_SENS_CLOCK ? time : (type == MJB_SENS_JOINTPOS ? qpos[T::sensor_objid[q] < 0 ? 0 : T::sensor_objid[q]] : qvel[T::sensor_objid[q] < 0 ? 0 : T::sensor_objid[q]]);
+						constexpr int jj = T::sensor_objid[q] < 0 ? 0 : T::sensor_objid[q];
+						const Pair s3 = lp[64 * jj];
+						const double v = type == MJB_SENS_CLOCK ? time : (type == MJB_SENS_JOINTPOS ? s3.a : s3.b);
 						const double cut = m.sensor_cutoff[q];
 						sd[T::sensor_adr[q]] = cut > 0 ? fmin(fmax(v, -cut), cut) : v;
 					}
 				});
+			}
+			__builtin_amdgcn_sched_barrier(0);
+
+			// ================= A2 mj_crb + A9 RNE backward pass, one sweep leaf -> root =================
+			double qM[NV > 0 ? NV : 1][NV > 0 ? NV : 1];  // [i][a], a = i or an ancestor of i (the other entries never exist)
+			double csum[NB][6];                           // forces of a body's children, summed as the sweep passes them
+			bool cset[NB] = {};
+			sfor<NB - 1>([&](auto Bi) {
+				constexpr int b = NB - 1 - Bi;
+				constexpr int p = T::body_parentid[b], j = T::body_jnt[b];
+				if constexpr (LD::needed(b)) {
+					constexpr int q0 = LD::slot(b);
+					const Pair c0 = lp[64 * q0], c1 = lp[64 * (q0 + 1)], c2 = lp[64 * (q0 + 2)];
+					double cf[6] = { c0.a, c0.b, c1.a, c1.b, c2.a, c2.b };
+					// (children have larger ids: their sums are complete; cset is a compile-time fact after unrolling)
+					constexpr bool has_child = [] { for (int c = b + 1; c < NB; c++) if (T::body_parentid[c] == b && LD::needed(c)) return true; return false; }();
+					if constexpr (has_child) for (int k = 0; k < 6; k++) cf[k] += csum[b][k];
+					if constexpr (j >= 0) {
+						double buf[6];
+						f[j] -= dot6r(cdof[j], cf);
+						mul_inert_vec(buf, cin[b], cdof[j]);
+						sfor<NV>([&](auto A) {
+							constexpr int a = A;
+							if constexpr (Q::anc(a, j)) qM[j][a] = (a == j ? m.dof_armature[j] : 0.0) + dot6r(cdof[a], buf);
+						});
+					}
+					if constexpr (p > 0 && LD::needed(p)) {
+						constexpr bool first = [] { for (int c = b + 1; c < NB; c++) if (T::body_parentid[c] == p && LD::needed(c)) return false; return true; }();
+						if constexpr (first) for (int k = 0; k < 6; k++) csum[p][k] = cf[k];
+						else for (int k = 0; k < 6; k++) csum[p][k] += cf[k];
+						for (int k = 0; k < 10; k++) cin[p][k] += cin[b][k];
+					}
+				}
+				__builtin_amdgcn_sched_barrier(0);
+			});
+			(void)cset;
+			if (e_on) {  // mj_energyVel: 0.5 qvel' M qvel (mj_energyPos was gathered along the sweep)
+				double ke = 0, qv[NV > 0 ? NV : 1];
+				sfor<NV>([&](auto I) { qv[I] = lp[64 * I].b; });
+				sfor<NV>([&](auto I) {
+					sfor<NV>([&](auto A) {
+						constexpr int i = I, a = A;
+						if constexpr (Q::anc(a, i)) ke += (a == i ? 0.5 : 1.0) * qM[i][a] * qv[i] * qv[a];
+					});
+				});
+				en_pe = pe;
+				en_ke = ke;
 			}
 
 			// ================= A3 mj_factorM + A12 mj_fwdAcceleration; A16's (M + h B) factor and solve beside them =================
@@ -521,8 +559,8 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 			sfor<NV>([&](auto I) { bada |= bad_val(qacc[I]); });
 			if (!__builtin_amdgcn_ballot_w64(bada)) break;  // (wave-uniform: the rare second trip recomputes every lane; the others get the same values)
 			if (bada) {
-				atomicAdd(s.nwarn + MJB_WARN_BADQACC, 1ull);
-				sfor<NV>([&](auto I) { qpos[I] = m.qpos0[I]; qvel[I] = 0; });
+				if (live) atomicAdd(s.nwarn + MJB_WARN_BADQACC, 1ull);
+				sfor<NV>([&](auto I) { lp[64 * I] = Pair{ m.qpos0[I], 0.0 }; });
 				sfor<NU>([&](auto I) { cn[I] = 0; ctrl[I] = 0; });
 				time = 0;
 				wasreset = true;
@@ -531,18 +569,21 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 
 		// ================= A16 mj_Euler =================
 		sfor<NV>([&](auto I) {
-			qvel[I] += dt * qaccd[I];
-			qpos[I] += dt * qvel[I];
+			Pair s2 = lp[64 * I];
+			s2.b += dt * qaccd[I];
+			s2.a += dt * s2.b;
+			lp[64 * I] = s2;
 		});
 		time += dt;
 	}
 
 	// ---- the launch's state back to HBM (store_state of the generic kernels; sensordata went out from the last step)
-	{
+	if (live) {
 		const DevState MJB_AS4 &s = P->s;
 		sfor<NV>([&](auto I) {
-			s.qpos[ev * NV + I] = qpos[I];
-			s.qvel[ev * NV + I] = qvel[I];
+			const Pair s2 = lp[64 * I];
+			s.qpos[ev * NV + I] = s2.a;
+			s.qvel[ev * NV + I] = s2.b;
 			s.qacc[ev * NV + I] = qacc[I];
 			s.qacc_warmstart[ev * NV + I] = qacc[I];
 		});
@@ -617,7 +658,7 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, int env_lo, int env_
 	const dim3 grid((unsigned int)((n + 63) / 64)), block(64);
 #define MJB_LE_X(id, T)                                                                                                                                   \
 	if (topo == id) {                                                                                                                                      \
-		hipLaunchKernelGGL(mjb_lane_env_kernel<T>, grid, block, 0, (hipStream_t)stream, (const KernelParams MJB_AS4 *)Pdev, nsteps, step0, env_lo, env_hi); \
+		hipLaunchKernelGGL(mjb_lane_env_kernel<T>, grid, block, Lds<T>::bytes(), (hipStream_t)stream, (const KernelParams MJB_AS4 *)Pdev, nsteps, step0, env_lo, env_hi); \
 		return (int)hipGetLastError();                                                                                                                     \
 	}
 	MJB_LE_TOPOS(MJB_LE_X)
