@@ -95,6 +95,7 @@ struct mjb_model {
 	FrameLayout Lw{};
 	bool has_wide = false;
 	int le_topo = -1;  // compiled-in topology of the lane = env kernel the model matches (mjb_lane_env.hip), -1: none
+	std::vector<double> le_tape;  // its constant tape (mjb_dev.h), empty without a topology
 };
 
 struct mjb_batch {
@@ -1124,6 +1125,10 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		for (int i = 0; i < h.nv; i++)
 			if ((M->body_dofmask[2 * b + (i >> 5)] >> (i & 31)) & 1) M->dof_bodymask[2 * i + (b >> 5)] |= (int)(1u << (b & 31));
 	M->le_topo = mjb_lane_env_match(&h);
+	if (M->le_topo >= 0) {
+		M->le_tape.assign(mjb_lane_env_tape_doubles(&h), 0.0);
+		mjb_lane_env_tape(&h, M->le_tape.data());
+	}
 	M->eulerdamp = 0;
 	if (!(h.disableflags & MJB_DSBL_EULERDAMP))
 		for (int i = 0; i < h.nv; i++)
@@ -1368,7 +1373,10 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	            M->body_dofmask.size() + M->body_submask.size() + M->M_dense.size() + M->M_sym.size() + M->body_anc.size() + M->dof_bodymask.size() + M->body_dofanc.size() + M->dof_rec2.size() + M->jnt_rec.size() + M->flv_hdr.size() + M->flv_rec.size() + M->flv_ent.size() + M->sens_copy.size() + M->sens_slow.size() + M->dof_act_adr.size() +
 	            M->dof_act_id.size() + M->pair_i.size() + M->lim_i.size() + 104;
 	size_t bytes_i = ((ni + nt) * sizeof(int) + 15) & ~size_t(15);
-	size_t bytes = bytes_i + (nd + M->pair_d.size() + M->lim_d.size() + M->sub_S.size()) * sizeof(double) + 16;
+	// (the lane = env tape starts on a 64-byte boundary of the blob: wide scalar loads)
+	size_t o_tape = nd + M->pair_d.size() + M->lim_d.size() + M->sub_S.size();
+	while ((bytes_i + o_tape * sizeof(double)) % 64) o_tape++;
+	size_t bytes = bytes_i + (o_tape + M->le_tape.size()) * sizeof(double) + 16;
 	if (hipMalloc(&b->blob, bytes) != hipSuccess) {
 		fail(MJB_ENOMEM, "mjb_make_batch: hipMalloc(model blob) failed");
 		mjb_free_batch(b);
@@ -1394,6 +1402,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	memcpy(hd + nd, M->pair_d.data(), M->pair_d.size() * sizeof(double));
 	memcpy(hd + nd + M->pair_d.size(), M->lim_d.data(), M->lim_d.size() * sizeof(double));
 	memcpy(hd + nd + M->pair_d.size() + M->lim_d.size(), M->sub_S.data(), M->sub_S.size() * sizeof(double));
+	if (!M->le_tape.empty()) memcpy(hd + o_tape, M->le_tape.data(), M->le_tape.size() * sizeof(double));
 	if (hipMemcpy(b->blob, hostblob.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
 		fail(MJB_ENODEVICE, "mjb_make_batch: model upload failed");
 		mjb_free_batch(b);
@@ -1451,6 +1460,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	dm.lim_d = (mjb_cdptr)(dd + nd + M->pair_d.size());
 	dm.sub_S = (mjb_cdptr)(dd + nd + M->pair_d.size() + M->lim_d.size());
 	dm.sub_nt = M->sub_nt;
+	dm.le_tape = M->le_tape.empty() ? (mjb_cdptr) nullptr : (mjb_cdptr)(dd + o_tape);
 	dm.lim_i = (mjb_ciptr)(di + o_li);
 	for (int k = 0; k < 3; k++) {
 		dm.sens_ncopy[k] = M->sens_ncopy[k];

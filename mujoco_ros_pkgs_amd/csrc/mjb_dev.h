@@ -75,7 +75,21 @@ struct DevModel {
 	// root-to-leaf sums (cvel, cacc): [nbody][4] = the body's ancestor-or-self dofs, ASCENDING, one byte each (0xFF = none), at most 16
 	mjb_ciptr body_dofanc;
 	int dofanc_max;          // longest list (0: some body has more than 16 -- or nv > 255 --: the mask loops run instead)
+	// lane = env kernel (mjb_lane_env.hip): the model's numeric constants as ONE tape in the order the kernel consumes them --
+	// LeTapeHdr, LeTapeBody[nbody], LeTapeAct[nu] -- read by wide scalar loads off a single base address (NULL: no compiled-in topology)
+	mjb_cdptr le_tape;
 };
+
+// (64-byte records: one s_load_dwordx16 per half)
+struct LeTapeHdr { double dt, gravity[3], pad[4]; };
+struct LeTapeBody {
+	// pose half: what mj_kinematics needs of the body and its (single) joint
+	double pos[3], quat[4], jaxis[3], jpos[3], qpos0, stiffness, spring;
+	// inertial half
+	double ipos[3], ibody[6] /* R(iquat) diag(inertia) R(iquat)': xx yy zz xy xz yz */, mass, damping, armature, hdamping /* timestep * damping */, pad[3];
+};
+struct LeTapeAct { double gear, ctrllo, ctrlhi, gain[3], bias[3], forcelo, forcehi, pad[5]; };
+static_assert(sizeof(LeTapeHdr) == 64 && sizeof(LeTapeBody) == 256 && sizeof(LeTapeAct) == 128, "lane = env tape records");
 
 // Offsets (in doubles / ints) of every data field inside one per-env frame.
 struct FrameLayout {
@@ -242,6 +256,8 @@ int mjb_launch_reset(const KernelParams *Pdev, int nenv, const unsigned char *ma
 int mjb_max_lds_bytes();
 // lane = env form of the unconstrained fused step (mjb_lane_env.hip)
 int mjb_lane_env_match(const mjb_model_desc *h);
+size_t mjb_lane_env_tape_doubles(const mjb_model_desc *h);      // size of the constant tape
+void mjb_lane_env_tape(const mjb_model_desc *h, double *tape);  // fills it
 const char *mjb_lane_env_name(int topo);
 int mjb_launch_lane_env(const KernelParams *Pdev, int topo, int env_lo, int env_hi, int nsteps, unsigned int step0, void *stream);
 // sensors-plugin equivalent (mjb_sensor_pack.hip)

@@ -60,18 +60,74 @@ template <class T> struct Tq {
 	}
 };
 
+// 1 / sqrt(x): hardware seed + two Newton steps (x > 0)
+DEVI double frsq(double x)
+{
+	double y = __builtin_amdgcn_rsq(x);
+	y = y * fma(-0.5 * x * y, y, 1.5);
+	y = y * fma(-0.5 * x * y, y, 1.5);
+	return y;
+}
+
+// mju_normalize4: identity for a vanishing quaternion, untouched within mjMINVAL of unit length
 DEVI void normalize4_sel(double *q)
 {
-	const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-	const bool tiny = n < MJB_MINVAL;
-	const double s = (fabs(n - 1) > MJB_MINVAL) ? frcp(tiny ? 1.0 : n) : 1.0;
+	const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+	const bool tiny = n2 < MJB_MINVAL * MJB_MINVAL;
+	const double r = frsq(tiny ? 1.0 : n2), n = n2 * r;
+	const double s = (fabs(n - 1) > MJB_MINVAL) ? r : 1.0;
 	q[0] = tiny ? 1.0 : q[0] * s;
 	q[1] = tiny ? 0.0 : q[1] * s;
 	q[2] = tiny ? 0.0 : q[2] * s;
 	q[3] = tiny ? 0.0 : q[3] * s;
 }
 
+// A loaded value the optimiser must treat as already there: `cond ? k : load` otherwise becomes a per-lane branch around the load.
+DEVI double pinv(double x)
+{
+	asm volatile("" : "+v"(x));
+	return x;
+}
+DEVI double pins(double x)  // the same for a wave-uniform (scalar) value
+{
+	asm volatile("" : "+s"(x));
+	return x;
+}
+// clamp by v_max / v_min, NaN passed through as the ternary chain of mj_fwdActuation passes it
+DEVI double clampd(double c, double lo, double hi)
+{
+	const double v = fmin(fmax(c, lo), hi);
+	return c != c ? c : v;
+}
+
 DEVI bool bad_val(double x) { return !(x == x) || fabs(x) > MJB_MAXVAL; }
+
+// sin and cos of a joint half-angle, branch-free: k = round(x * 2/pi), r = x - k * pi/2 through three fma steps (pi/2 split into
+// 53-bit pieces: exact to rounding while |x| < ~1e6 rad; beyond, the absolute error grows like |x| * 2^-53 * k-independent terms --
+// a hinge wound up that far is not a simulation any more, and mj_check* only stops it at 1e10), then the fdlibm kernel polynomials on
+// [-pi/4, pi/4] and a quadrant swap.  libm's sincos carries a divergent slow path for huge arguments; this kernel must not branch
+// per lane (see the note on divergent control flow at the kernel).
+DEVI void sincos_nb(double x, double *sn, double *cs)
+{
+	const double k = rint(x * 0.63661977236758134308);
+	double r = fma(-k, 1.57079632679489655800e+00, x);
+	r = fma(-k, 6.12323399573676603587e-17, r);
+	r = fma(-k, -1.49738490485916983827e-33, r);
+	const double z = r * r;
+	// __kernel_sin / __kernel_cos (fdlibm), tail argument dropped (|r| <= pi/4 to rounding)
+	const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+	             S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+	const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+	             C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+	const double ps = fma(fma(fma(fma(fma(S6, z, S5), z, S4), z, S3), z, S2), z, S1);
+	const double sr = fma(z * r, ps, r);
+	const double pc = fma(fma(fma(fma(fma(C6, z, C5), z, C4), z, C3), z, C2), z, C1);
+	const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+	const int q = (int)k & 3;
+	const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+	*sn = (q & 2) ? -s0 : s0;
+	*cs = ((q + 1) & 2) ? -c0 : c0;
+}
 
 // LDS of a block (= one wavefront): pair slot q of lane l = the two doubles at (q * 64 + l) * 16 bytes -- one ds_read_b128 /
 // ds_write_b128 per pair, conflict-free.  Slots [0, NV): (qpos_i, qvel_i); then three slots per body whose force the backward
@@ -116,12 +172,12 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 	const size_t ev = (size_t)env;
 
 	// ---- the env's state: (qpos, qvel) in LDS, the OU noise state in registers
-	double qacc[NV], cn[NU > 0 ? NU : 1];
-	double time, en_pe = 0, en_ke = 0;
+	double cn[NU > 0 ? NU : 1];
+	double time;
 	bool wasreset = false;  // mj_resetData ran inside this launch: ctrl / qfrc_applied read as zero from then on (the frame copy of the generic kernels)
 	{
 		const DevState MJB_AS4 &s = P->s;
-		sfor<NV>([&](auto I) { lp[64 * I] = Pair{ s.qpos[ev * NV + I], s.qvel[ev * NV + I] }; qacc[I] = s.qacc[ev * NV + I]; });
+		sfor<NV>([&](auto I) { lp[64 * I] = Pair{ s.qpos[ev * NV + I], s.qvel[ev * NV + I] }; });
 		sfor<NU>([&](auto I) { cn[I] = s.ctrlnoise[ev * NU + I]; });
 		time = s.time[ev];
 	}
@@ -144,7 +200,10 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 		const DevModel MJB_AS4 &m = Pq->m;
 		const DevState MJB_AS4 &s = Pq->s;
 		const bool last = st == nsteps - 1;
-		const double dt = m.timestep[0];
+		// the model's numeric constants: one tape in consumption order (mjb_dev.h), a half record (64 bytes) per scalar load
+		const LeTapeHdr MJB_AS4 *th = reinterpret_cast<const LeTapeHdr MJB_AS4 *>(m.le_tape);
+		const LeTapeBody MJB_AS4 *tb = reinterpret_cast<const LeTapeBody MJB_AS4 *>(th + 1);
+		const double dt = th->dt;
 
 		// ---- H10: the reference's ctrl-noise injector (mujoco_env.cpp:469-481), before the step
 		double ctrl[NU > 0 ? NU : 1];
@@ -165,28 +224,47 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 			}
 			sfor<NU>([&](auto I) { ctrl[I] = cn[I]; });
 		} else {
-			sfor<NU>([&](auto I) { ctrl[I] = wasreset ? 0.0 : s.ctrl[ev * NU + I]; });
+			sfor<NU>([&](auto I) { const double c = pinv(s.ctrl[ev * NU + I]); ctrl[I] = wasreset ? 0.0 : c; });  // (load first: a select around a load becomes a per-lane branch)
 		}
 
 		// ---- mj_checkPos / mj_checkVel (qpos first: its reset hides a bad qvel)
 		{
 			bool badp = false, badv = false;
 			sfor<NV>([&](auto I) { const Pair qv = lp[64 * I]; badp |= bad_val(qv.a); badv |= bad_val(qv.b); });
-			if (badp || badv) {
-				if (live) atomicAdd(s.nwarn + (badp ? MJB_WARN_BADQPOS : MJB_WARN_BADQVEL), 1ull);
-				sfor<NV>([&](auto I) { lp[64 * I] = Pair{ m.qpos0[I], 0.0 }; });
-				sfor<NU>([&](auto I) { cn[I] = 0; ctrl[I] = 0; });
-				time = 0;
-				wasreset = true;
+			// (NO per-lane branch anywhere in this kernel: with ~200 live doubles the register allocator spills around every join, and
+			//  ROCm 7.2's LLVM places such spills ahead of the exec restore -- the parked lanes lose them, tools/check_spill_exec.py.
+			//  A reset is a handful of selects under a wave-uniform test; every lane issues the counter's atomic, with 0 or 1.)
+			const bool bad = badp || badv;
+			if (__builtin_amdgcn_ballot_w64(bad)) {
+				atomicAdd(s.nwarn + MJB_WARN_BADQPOS, (badp && live) ? 1ull : 0ull);
+				atomicAdd(s.nwarn + MJB_WARN_BADQVEL, (!badp && badv && live) ? 1ull : 0ull);
+				sfor<NV>([&](auto I) {
+					const Pair o = lp[64 * I];
+					const double oa = pinv(o.a), ob = pinv(o.b), q0 = pins(tb[T::jnt_bodyid[I]].qpos0);  // (evaluated before the selects, not inside them)
+					lp[64 * I] = Pair{ bad ? q0 : oa, bad ? 0.0 : ob };
+				});
+				sfor<NU>([&](auto I) { cn[I] = bad ? 0.0 : cn[I]; ctrl[I] = bad ? 0.0 : ctrl[I]; });
+				time = bad ? 0.0 : time;
+				wasreset = wasreset || bad;
 			}
 		}
 
-		double qaccd[NV];  // the acceleration Euler advances with: (M + h B)^-1 f under implicit joint damping, else qacc
+		double qacc[NV], qaccd[NV];  // M^-1 f, and the acceleration Euler advances with: (M + h B)^-1 f under implicit joint damping
+		double en_pe = 0, en_ke = 0;
 #pragma nounroll
 		for (int attempt = 0; attempt < 2; attempt++) {
+			// (the tape address laundered per trip: its loads are invariants of this two-trip loop, and the optimiser hoists every one of
+			//  them -- ~350 doubles -- in front of it)
+			{
+				const double MJB_AS4 *tp = m.le_tape;
+				asm volatile("" : "+s"(tp));
+				th = reinterpret_cast<const LeTapeHdr MJB_AS4 *>(tp);
+				tb = reinterpret_cast<const LeTapeBody MJB_AS4 *>(th + 1);
+			}
+			const LeTapeAct MJB_AS4 *const ta = reinterpret_cast<const LeTapeAct MJB_AS4 *>(tb + NB);
 			const bool e_on = last && (m.enableflags & MJB_ENBL_ENERGY);
 			const bool eg_on = e_on && !(m.disableflags & MJB_DSBL_GRAVITY);
-			const bool sens_on = last && live && !(m.disableflags & MJB_DSBL_SENSOR);
+			const bool sens_on = last && !(m.disableflags & MJB_DSBL_SENSOR);  // (a tail lane rewrites the last env's values)
 			double *sd = s.sensordata + ev * T::NSENSORDATA;
 			double pe = 0;
 
@@ -202,16 +280,64 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 			double grav[3];
 			{
 				const bool g_on = !(m.disableflags & MJB_DSBL_GRAVITY);
-				for (int k = 0; k < 3; k++) grav[k] = g_on ? m.gravity[k] : 0.0;
+				for (int k = 0; k < 3; k++) grav[k] = g_on ? th->gravity[k] : 0.0;
 			}
 			const bool pas_on = !(m.disableflags & MJB_DSBL_PASSIVE);
+			// ================= A12 mj_fwdActuation first (joint transmission: it needs qpos / qvel only; the ctrl registers die here) =================
+			{
+				const bool act_on = !(m.disableflags & MJB_DSBL_ACTUATION);
+				const bool clamp_on = !(m.disableflags & MJB_DSBL_CLAMPCTRL);
+				sfor<NV>([&](auto I) { f[I] = 0; });
+				sfor<NU>([&](auto U) {
+					constexpr int i = U, j = T::act_jnt[i];
+					double force = 0;
+					const LeTapeAct MJB_AS4 &A = ta[i];
+					const double gear = A.gear;
+					[[maybe_unused]] Pair s2{ 0, 0 };
+					constexpr bool need_qv = T::act_gaintype[i] == MJB_GAIN_AFFINE || T::act_biastype[i] == MJB_BIAS_AFFINE;
+					if constexpr (need_qv) s2 = lp[64 * j];
+					if (act_on) {
+						double c = ctrl[i];
+						if constexpr (T::act_ctrllimited[i]) {
+							if (clamp_on) {
+								c = clampd(c, A.ctrllo, A.ctrlhi);
+							}
+						}
+						const double len = s2.a * gear, vel = s2.b * gear;
+						double gain = A.gain[0], bs = 0;
+						if constexpr (T::act_gaintype[i] == MJB_GAIN_AFFINE) gain = gain + A.gain[1] * len + A.gain[2] * vel;
+						if constexpr (T::act_biastype[i] == MJB_BIAS_AFFINE) bs = A.bias[0] + A.bias[1] * len + A.bias[2] * vel;
+						force = gain * c + bs;
+						if constexpr (T::act_forcelimited[i]) {
+							force = clampd(force, A.forcelo, A.forcehi);
+						}
+						f[j] += gear * force;
+					}
+					if (sens_on) {
+						sfor<T::NSENSOR>([&](auto S) {
+							constexpr int q = S;
+							if constexpr (T::sensor_objid[q] == i && (T::sensor_type[q] == MJB_SENS_ACTUATORFRC || T::sensor_type[q] == MJB_SENS_ACTUATORPOS || T::sensor_type[q] == MJB_SENS_ACTUATORVEL)) {
+								const Pair s3 = lp[64 * j];
+								double v = T::sensor_type[q] == MJB_SENS_ACTUATORFRC ? force : (T::sensor_type[q] == MJB_SENS_ACTUATORPOS ? s3.a * gear : s3.b * gear);
+								const double cut = m.sensor_cutoff[q];
+								sd[T::sensor_adr[q]] = cut > 0 ? clampd(v, -cut, cut) : v;
+							}
+						});
+					}
+				});
+			}
+			__builtin_amdgcn_sched_barrier(0);
+			// (two scheduling regions per body, each fetching the NEXT region's half record at its top: the scalar loads of a region
+			//  cannot be hoisted beyond it -- left alone, the compiler issues them bodies ahead and parks ~540 SGPRs in VGPR lanes)
+			double hA[NB + 1][16], hB[NB][16];
+			for (int k = 0; k < 16; k++) hA[1][k] = reinterpret_cast<const double MJB_AS4 *>(tb + 1)[k];
 			sfor<NB>([&](auto B) {
 				constexpr int b = B;
 				if constexpr (b > 0) {
 				constexpr int p = T::body_parentid[b], j = T::body_jnt[b], r = T::body_rootid[b];
-				double pos[3], quat[4];
-				ldc3(pos, m.body_pos + 3 * b);
-				ldc4(quat, m.body_quat + 4 * b);
+				for (int k = 0; k < 16; k++) hB[b][k] = reinterpret_cast<const double MJB_AS4 *>(tb + b)[16 + k];
+				const double *const A = hA[b];  // pos[3] quat[4] jaxis[3] jpos[3] qpos0 stiffness spring
+				double pos[3] = { A[0], A[1], A[2] }, quat[4] = { A[3], A[4], A[5], A[6] };
 				if constexpr (p != 0) {
 					double v[3], q[4];
 					matvec3(v, xmat[p], pos);
@@ -220,68 +346,75 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 					for (int k = 0; k < 4; k++) quat[k] = q[k];
 				}
 				[[maybe_unused]] double xaxis[3], xanch[3], qp = 0, qv = 0;
+				[[maybe_unused]] bool offc = false;
 				if constexpr (j >= 0) {
 					const Pair s2 = lp[64 * j];
 					qp = s2.a;
 					qv = s2.b;
-					double M0[9], ax[3], jp[3], v[3];
-					ldc3(ax, m.jnt_axis + 3 * j);
-					ldc3(jp, m.jnt_pos + 3 * j);
-					quat2mat_nocheck(M0, quat);
-					matvec3(xaxis, M0, ax);
-					matvec3(v, M0, jp);
-					for (int k = 0; k < 3; k++) xanch[k] = v[k] + pos[k];
-					const double dq = qp - m.qpos0[j];
-					if constexpr (T::jnt_type[j] == MJB_JNT_SLIDE) {
-						for (int k = 0; k < 3; k++) pos[k] += xaxis[k] * dq;
-					} else {
+					// The joint's world axis is its local axis through the body's FINAL orientation (a hinge turns about it, a slide does not
+					// turn), and a hinge's anchor stays where it was: the frame before the joint motion -- mj_kinematics' xaxis / xanchor
+					// source -- is only needed for an off-centre anchor (jnt_pos != 0, wave-uniform).
+					const double jp[3] = { A[10], A[11], A[12] };
+					offc = jp[0] != 0 || jp[1] != 0 || jp[2] != 0;
+					for (int k = 0; k < 3; k++) xanch[k] = pos[k];
+					if (offc) {
+						double M0[9], v[3];
+						quat2mat_nocheck(M0, quat);
+						matvec3(v, M0, jp);
+						for (int k = 0; k < 3; k++) xanch[k] += v[k];
+					}
+					if constexpr (T::jnt_type[j] == MJB_JNT_HINGE) {
 						double sn, cs, ql[4], q[4];
-						sincos(dq * 0.5, &sn, &cs);
-						ql[0] = cs; ql[1] = ax[0] * sn; ql[2] = ax[1] * sn; ql[3] = ax[2] * sn;
+						sincos_nb((qp - A[13]) * 0.5, &sn, &cs);
+						ql[0] = cs; ql[1] = A[7] * sn; ql[2] = A[8] * sn; ql[3] = A[9] * sn;
 						qmul(q, quat, ql);
 						for (int k = 0; k < 4; k++) quat[k] = q[k];
-						// correct for off-centre rotation (jnt_pos == 0: the anchor is the body origin, nothing to correct)
-						if (jp[0] != 0 || jp[1] != 0 || jp[2] != 0) {
-							double M1[9];
-							quat2mat_nocheck(M1, quat);
-							matvec3(v, M1, jp);
-							for (int k = 0; k < 3; k++) pos[k] = xanch[k] - v[k];
-						} else {
-							for (int k = 0; k < 3; k++) pos[k] = xanch[k];
-						}
 					}
-					// passive + applied forces of the dof, while qpos / qvel are at hand
+					// passive spring force of the dof (the damper follows in the second region), applied force
 					double pas = 0;
-					if (pas_on) {
-						pas = -m.jnt_stiffness[j] * (qp - m.qpos_spring[j]);
-						pas -= m.dof_damping[j] * qv;
-					}
-					f[j] = pas + (wasreset ? 0.0 : s.qfrc_applied[ev * NV + j]);
+					if (pas_on) pas = -A[14] * (qp - A[15]);
+					const double qfa = pinv(s.qfrc_applied[ev * NV + j]);
+					f[j] += pas + (wasreset ? 0.0 : qfa);
 					if (e_on && pas_on) {
-						const double dqs = qp - m.qpos_spring[j];
-						pe += 0.5 * m.jnt_stiffness[j] * dqs * dqs;
+						const double dqs = qp - A[15];
+						pe += 0.5 * A[14] * dqs * dqs;
 					}
 				}
 				normalize4_sel(quat);
-				for (int k = 0; k < 3; k++) xpos[b][k] = pos[k];
 				for (int k = 0; k < 4; k++) xquat[b][k] = quat[k];
 				quat2mat_nocheck(xmat[b], quat);
+				if constexpr (j >= 0) {
+					const double ax[3] = { A[7], A[8], A[9] };
+					matvec3(xaxis, xmat[b], ax);
+					if constexpr (T::jnt_type[j] == MJB_JNT_SLIDE) {
+						const double dq = qp - A[13];
+						for (int k = 0; k < 3; k++) pos[k] += xaxis[k] * dq;
+					} else if (offc) {  // correct for off-centre rotation
+						const double jp[3] = { A[10], A[11], A[12] };
+						double v[3];
+						matvec3(v, xmat[b], jp);
+						for (int k = 0; k < 3; k++) pos[k] = xanch[k] - v[k];
+					}
+				}
+				for (int k = 0; k < 3; k++) xpos[b][k] = pos[k];
+				__builtin_amdgcn_sched_barrier(0);
+				// ---- second region: inertial frame, cinert, velocities, forces; the next body's pose half on its way
+				if constexpr (b + 1 < NB) for (int k = 0; k < 16; k++) hA[b + 1][k] = reinterpret_cast<const double MJB_AS4 *>(tb + b + 1)[k];
+				const double *const Bh = hB[b];  // ipos[3] ibody[6] mass damping armature hdamping
+				if constexpr (j >= 0) {
+					if (pas_on) f[j] -= Bh[10] * qv;
+				}
 				// inertial frame
-				double xipos[3], ximat[9];
+				double xipos[3];
 				if constexpr (T::body_sameframe[b]) {
 					for (int k = 0; k < 3; k++) xipos[k] = xpos[b][k];
-					for (int k = 0; k < 9; k++) ximat[k] = xmat[b][k];
 				} else {
-					double ip[3], iq[4], v[3], q[4];
-					ldc3(ip, m.body_ipos + 3 * b);
-					ldc4(iq, m.body_iquat + 4 * b);
+					double ip[3] = { Bh[0], Bh[1], Bh[2] }, v[3];
 					matvec3(v, xmat[b], ip);
 					for (int k = 0; k < 3; k++) xipos[k] = v[k] + xpos[b][k];
-					qmul(q, xquat[b], iq);
-					quat2mat_nocheck(ximat, q);
 				}
-				const double mass = m.body_mass[b];
-				if (eg_on) pe -= mass * (m.gravity[0] * xipos[0] + m.gravity[1] * xipos[1] + m.gravity[2] * xipos[2]);
+				const double mass = Bh[9];
+				if (eg_on) pe -= mass * (grav[0] * xipos[0] + grav[1] * xipos[1] + grav[2] * xipos[2]);
 				// position-stage sensors on this body's frames (the last step's values are the launch's sensordata)
 				if (sens_on) {
 					sfor<T::NSENSOR>([&](auto S) {
@@ -319,7 +452,7 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 								}
 								if constexpr (type == MJB_SENS_FRAMEPOS) {
 									const double cut = m.sensor_cutoff[i];
-									for (int k = 0; k < 3; k++) sd[adr + k] = cut > 0 ? fmin(fmax(o3[k], -cut), cut) : o3[k];
+									for (int k = 0; k < 3; k++) sd[adr + k] = cut > 0 ? clampd(o3[k], -cut, cut) : o3[k];
 								} else {
 									for (int k = 0; k < 4; k++) sd[adr + k] = o4[k];
 								}
@@ -333,18 +466,23 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 						double dif[3];
 						if constexpr (r == b) { dif[0] = xipos[0] - pos[0]; dif[1] = xipos[1] - pos[1]; dif[2] = xipos[2] - pos[2]; }
 						else for (int k = 0; k < 3; k++) dif[k] = xipos[k] - xpos[r][k];
-						const double i0 = m.body_inertia[3 * b], i1 = m.body_inertia[3 * b + 1], i2 = m.body_inertia[3 * b + 2];
-						const double *mat = ximat;
-						const double t0 = mat[0] * i0, t1 = mat[3] * i0, t2 = mat[6] * i0;
-						const double t3 = mat[1] * i1, t4 = mat[4] * i1, t5 = mat[7] * i1;
-						const double t6 = mat[2] * i2, t7 = mat[5] * i2, t8 = mat[8] * i2;
+						// world inertia X Ib X' with the body-frame inertia matrix Ib = R(iquat) diag(inertia) R(iquat)' from the tape
+						// (mju_inertCom builds the same matrix as ximat diag ximat', ximat = X R(iquat))
+						const double *X = xmat[b];
+						const double ixx = Bh[3], iyy = Bh[4], izz = Bh[5], ixy = Bh[6], ixz = Bh[7], iyz = Bh[8];
+						double Tm[9];
+						for (int rr = 0; rr < 3; rr++) {
+							Tm[3 * rr + 0] = X[3 * rr] * ixx + X[3 * rr + 1] * ixy + X[3 * rr + 2] * ixz;
+							Tm[3 * rr + 1] = X[3 * rr] * ixy + X[3 * rr + 1] * iyy + X[3 * rr + 2] * iyz;
+							Tm[3 * rr + 2] = X[3 * rr] * ixz + X[3 * rr + 1] * iyz + X[3 * rr + 2] * izz;
+						}
 						double *res = cin[b];
-						res[0] = mat[0] * t0 + mat[1] * t3 + mat[2] * t6 + mass * (dif[1] * dif[1] + dif[2] * dif[2]);
-						res[1] = mat[3] * t1 + mat[4] * t4 + mat[5] * t7 + mass * (dif[0] * dif[0] + dif[2] * dif[2]);
-						res[2] = mat[6] * t2 + mat[7] * t5 + mat[8] * t8 + mass * (dif[0] * dif[0] + dif[1] * dif[1]);
-						res[3] = mat[0] * t1 + mat[1] * t4 + mat[2] * t7 - mass * dif[0] * dif[1];
-						res[4] = mat[0] * t2 + mat[1] * t5 + mat[2] * t8 - mass * dif[0] * dif[2];
-						res[5] = mat[3] * t2 + mat[4] * t5 + mat[5] * t8 - mass * dif[1] * dif[2];
+						res[0] = Tm[0] * X[0] + Tm[1] * X[1] + Tm[2] * X[2] + mass * (dif[1] * dif[1] + dif[2] * dif[2]);
+						res[1] = Tm[3] * X[3] + Tm[4] * X[4] + Tm[5] * X[5] + mass * (dif[0] * dif[0] + dif[2] * dif[2]);
+						res[2] = Tm[6] * X[6] + Tm[7] * X[7] + Tm[8] * X[8] + mass * (dif[0] * dif[0] + dif[1] * dif[1]);
+						res[3] = Tm[0] * X[3] + Tm[1] * X[4] + Tm[2] * X[5] - mass * dif[0] * dif[1];
+						res[4] = Tm[0] * X[6] + Tm[1] * X[7] + Tm[2] * X[8] - mass * dif[0] * dif[2];
+						res[5] = Tm[3] * X[6] + Tm[4] * X[7] + Tm[5] * X[8] - mass * dif[1] * dif[2];
 						res[6] = mass * dif[0];
 						res[7] = mass * dif[1];
 						res[8] = mass * dif[2];
@@ -400,49 +538,6 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 				}
 			});
 
-			// ================= A12 mj_fwdActuation (needs nothing of the sweeps; here the ctrl registers die) =================
-			{
-				const bool act_on = !(m.disableflags & MJB_DSBL_ACTUATION);
-				const bool clamp_on = !(m.disableflags & MJB_DSBL_CLAMPCTRL);
-				sfor<NU>([&](auto U) {
-					constexpr int i = U, j = T::act_jnt[i];
-					double force = 0;
-					const double gear = m.actuator_gear[6 * i];
-					[[maybe_unused]] Pair s2{ 0, 0 };
-					constexpr bool need_qv = T::act_gaintype[i] == MJB_GAIN_AFFINE || T::act_biastype[i] == MJB_BIAS_AFFINE;
-					if constexpr (need_qv) s2 = lp[64 * j];
-					if (act_on) {
-						double c = ctrl[i];
-						if constexpr (T::act_ctrllimited[i]) {
-							if (clamp_on) {
-								const double lo = m.actuator_ctrlrange[2 * i], hi = m.actuator_ctrlrange[2 * i + 1];
-								c = c < lo ? lo : (c > hi ? hi : c);
-							}
-						}
-						const double len = s2.a * gear, vel = s2.b * gear;
-						double gain = m.actuator_gainprm[3 * i], bs = 0;
-						if constexpr (T::act_gaintype[i] == MJB_GAIN_AFFINE) gain = gain + m.actuator_gainprm[3 * i + 1] * len + m.actuator_gainprm[3 * i + 2] * vel;
-						if constexpr (T::act_biastype[i] == MJB_BIAS_AFFINE) bs = m.actuator_biasprm[3 * i] + m.actuator_biasprm[3 * i + 1] * len + m.actuator_biasprm[3 * i + 2] * vel;
-						force = gain * c + bs;
-						if constexpr (T::act_forcelimited[i]) {
-							const double lo = m.actuator_forcerange[2 * i], hi = m.actuator_forcerange[2 * i + 1];
-							force = force < lo ? lo : (force > hi ? hi : force);
-						}
-						f[j] += gear * force;
-					}
-					if (sens_on) {
-						sfor<T::NSENSOR>([&](auto S) {
-							constexpr int q = S;
-							if constexpr (T::sensor_objid[q] == i && (T::sensor_type[q] == MJB_SENS_ACTUATORFRC || T::sensor_type[q] == MJB_SENS_ACTUATORPOS || T::sensor_type[q] == MJB_SENS_ACTUATORVEL)) {
-								const Pair s3 = lp[64 * j];
-								double v = T::sensor_type[q] == MJB_SENS_ACTUATORFRC ? force : (T::sensor_type[q] == MJB_SENS_ACTUATORPOS ? s3.a * gear : s3.b * gear);
-								const double cut = m.sensor_cutoff[q];
-								sd[T::sensor_adr[q]] = cut > 0 ? fmin(fmax(v, -cut), cut) : v;
-							}
-						});
-					}
-				});
-			}
 			if (sens_on) {
 				sfor<T::NSENSOR>([&](auto S) {
 					constexpr int q = S, type = T::sensor_type[q];
@@ -451,7 +546,7 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 						const Pair s3 = lp[64 * jj];
 						const double v = type == MJB_SENS_CLOCK ? time : (type == MJB_SENS_JOINTPOS ? s3.a : s3.b);
 						const double cut = m.sensor_cutoff[q];
-						sd[T::sensor_adr[q]] = cut > 0 ? fmin(fmax(v, -cut), cut) : v;
+						sd[T::sensor_adr[q]] = cut > 0 ? clampd(v, -cut, cut) : v;
 					}
 				});
 			}
@@ -477,7 +572,7 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 						mul_inert_vec(buf, cin[b], cdof[j]);
 						sfor<NV>([&](auto A) {
 							constexpr int a = A;
-							if constexpr (Q::anc(a, j)) qM[j][a] = (a == j ? m.dof_armature[j] : 0.0) + dot6r(cdof[a], buf);
+							if constexpr (Q::anc(a, j)) qM[j][a] = (a == j ? tb[b].armature : 0.0) + dot6r(cdof[a], buf);
 						});
 					}
 					if constexpr (p > 0 && LD::needed(p)) {
@@ -510,7 +605,7 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 			sfor<NV>([&](auto I) {
 				sfor<NV>([&](auto A) {
 					constexpr int i = I, a = A;
-					if constexpr (Q::anc(a, i)) qH[i][a] = qM[i][a] + (a == i ? dt * m.dof_damping[i] : 0.0);
+					if constexpr (Q::anc(a, i)) qH[i][a] = qM[i][a] + (a == i ? tb[T::jnt_bodyid[i]].hdamping : 0.0);
 				});
 			});
 			sfor<NV>([&](auto Ki) {
@@ -558,15 +653,27 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 			bool bada = false;
 			sfor<NV>([&](auto I) { bada |= bad_val(qacc[I]); });
 			if (!__builtin_amdgcn_ballot_w64(bada)) break;  // (wave-uniform: the rare second trip recomputes every lane; the others get the same values)
-			if (bada) {
-				if (live) atomicAdd(s.nwarn + MJB_WARN_BADQACC, 1ull);
-				sfor<NV>([&](auto I) { lp[64 * I] = Pair{ m.qpos0[I], 0.0 }; });
-				sfor<NU>([&](auto I) { cn[I] = 0; ctrl[I] = 0; });
-				time = 0;
-				wasreset = true;
-			}
+			atomicAdd(s.nwarn + MJB_WARN_BADQACC, (bada && live) ? 1ull : 0ull);
+			sfor<NV>([&](auto I) {
+				const Pair o = lp[64 * I];
+				const double oa = pinv(o.a), ob = pinv(o.b), q0 = pins(tb[T::jnt_bodyid[I]].qpos0);
+				lp[64 * I] = Pair{ bada ? q0 : oa, bada ? 0.0 : ob };
+			});
+			sfor<NU>([&](auto I) { cn[I] = bada ? 0.0 : cn[I]; ctrl[I] = bada ? 0.0 : ctrl[I]; });
+			time = bada ? 0.0 : time;
+			wasreset = wasreset || bada;
 		}
 
+		if (last) {  // mj_advance's qacc_warmstart = qacc; mjData.energy of the launch's last step
+			sfor<NV>([&](auto I) {
+				s.qacc[ev * NV + I] = qacc[I];
+				s.qacc_warmstart[ev * NV + I] = qacc[I];
+			});
+			if (m.enableflags & MJB_ENBL_ENERGY) {
+				s.energy[2 * ev] = en_pe;
+				s.energy[2 * ev + 1] = en_ke;
+			}
+		}
 		// ================= A16 mj_Euler =================
 		sfor<NV>([&](auto I) {
 			Pair s2 = lp[64 * I];
@@ -578,23 +685,17 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 	}
 
 	// ---- the launch's state back to HBM (store_state of the generic kernels; sensordata went out from the last step)
-	if (live) {
+	{  // (tail lanes store the last env's state a second time)
 		const DevState MJB_AS4 &s = P->s;
 		sfor<NV>([&](auto I) {
 			const Pair s2 = lp[64 * I];
 			s.qpos[ev * NV + I] = s2.a;
 			s.qvel[ev * NV + I] = s2.b;
-			s.qacc[ev * NV + I] = qacc[I];
-			s.qacc_warmstart[ev * NV + I] = qacc[I];
 		});
 		sfor<NU>([&](auto I) { s.ctrlnoise[ev * NU + I] = cn[I]; });
 		if (nz_on) sfor<NU>([&](auto I) { s.ctrl[ev * NU + I] = cn[I]; });
-		else if (wasreset) sfor<NU>([&](auto I) { s.ctrl[ev * NU + I] = 0; });
+		else if (__builtin_amdgcn_ballot_w64(wasreset)) sfor<NU>([&](auto I) { const double c = pinv(s.ctrl[ev * NU + I]); s.ctrl[ev * NU + I] = wasreset ? 0.0 : c; });
 		s.time[ev] = time;
-		if (P->m.enableflags & MJB_ENBL_ENERGY) {
-			s.energy[2 * ev] = en_pe;
-			s.energy[2 * ev + 1] = en_ke;
-		}
 	}
 }
 
@@ -640,6 +741,55 @@ int mjb_lane_env_match(const mjb_model_desc *h)
 	MJB_LE_TOPOS(MJB_LE_X)
 #undef MJB_LE_X
 	return -1;
+}
+
+size_t mjb_lane_env_tape_doubles(const mjb_model_desc *h)
+{
+	return (sizeof(LeTapeHdr) + (size_t)h->nbody * sizeof(LeTapeBody) + (size_t)h->nu * sizeof(LeTapeAct)) / sizeof(double);
+}
+
+void mjb_lane_env_tape(const mjb_model_desc *h, double *tape)
+{
+	LeTapeHdr *th = reinterpret_cast<LeTapeHdr *>(tape);
+	LeTapeBody *tb = reinterpret_cast<LeTapeBody *>(th + 1);
+	LeTapeAct *ta = reinterpret_cast<LeTapeAct *>(tb + h->nbody);
+	th->dt = h->timestep[0];
+	for (int k = 0; k < 3; k++) th->gravity[k] = h->gravity[k];
+	for (int b = 0; b < h->nbody; b++) {
+		LeTapeBody &t = tb[b];
+		for (int k = 0; k < 3; k++) { t.pos[k] = h->body_pos[3 * b + k]; t.ipos[k] = h->body_ipos[3 * b + k]; }
+		for (int k = 0; k < 4; k++) t.quat[k] = h->body_quat[4 * b + k];
+		{  // Ib = R(iquat) diag(inertia) R(iquat)': xx yy zz xy xz yz
+			const double *q = h->body_iquat + 4 * b, *in = h->body_inertia + 3 * b;
+			double R[9];
+			const double q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3], q11 = q[1] * q[1], q12 = q[1] * q[2], q13 = q[1] * q[3],
+			             q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
+			R[0] = q00 + q11 - q22 - q33; R[4] = q00 - q11 + q22 - q33; R[8] = q00 - q11 - q22 + q33;
+			R[1] = 2 * (q12 - q03); R[2] = 2 * (q13 + q02); R[3] = 2 * (q12 + q03); R[5] = 2 * (q23 - q01); R[6] = 2 * (q13 - q02); R[7] = 2 * (q23 + q01);
+			auto e = [&](int r, int c) { return R[3 * r] * in[0] * R[3 * c] + R[3 * r + 1] * in[1] * R[3 * c + 1] + R[3 * r + 2] * in[2] * R[3 * c + 2]; };
+			t.ibody[0] = e(0, 0); t.ibody[1] = e(1, 1); t.ibody[2] = e(2, 2); t.ibody[3] = e(0, 1); t.ibody[4] = e(0, 2); t.ibody[5] = e(1, 2);
+		}
+		t.mass = h->body_mass[b];
+		if (h->body_jntnum[b] == 1) {
+			const int j = h->body_jntadr[b];  // (== its qpos and dof address: mjb_lane_env_match)
+			for (int k = 0; k < 3; k++) { t.jaxis[k] = h->jnt_axis[3 * j + k]; t.jpos[k] = h->jnt_pos[3 * j + k]; }
+			t.qpos0 = h->qpos0[j];
+			t.stiffness = h->jnt_stiffness[j];
+			t.spring = h->qpos_spring[j];
+			t.damping = h->dof_damping[j];
+			t.armature = h->dof_armature[j];
+			t.hdamping = h->timestep[0] * h->dof_damping[j];
+		}
+	}
+	for (int i = 0; i < h->nu; i++) {
+		LeTapeAct &a = ta[i];
+		a.gear = h->actuator_gear[6 * i];
+		a.ctrllo = h->actuator_ctrlrange[2 * i];
+		a.ctrlhi = h->actuator_ctrlrange[2 * i + 1];
+		for (int k = 0; k < 3; k++) { a.gain[k] = h->actuator_gainprm[3 * i + k]; a.bias[k] = h->actuator_biasprm[3 * i + k]; }
+		a.forcelo = h->actuator_forcerange[2 * i];
+		a.forcehi = h->actuator_forcerange[2 * i + 1];
+	}
 }
 
 const char *mjb_lane_env_name(int topo)
