@@ -175,7 +175,7 @@ def _load_json(*names):
     return None, None
 
 
-def roofline_block(name, tag, solver_tag, E, S, samples):
+def roofline_block(name, tag, solver_tag, E, S, samples, kernel="mjb_step_kernel"):
     """`roofline` object of one workload: algorithmic bytes per launch / median kernel time against the HBM peak, the
     counter-measured HBM traffic and executed fp64 work when profiles/ holds a PMC summary collected on THESE kernel sources
     (fingerprint check: mujoco_ros_pkgs_amd/provenance.py) at this (envs, substeps), and the useful fp64 rate from the
@@ -226,7 +226,7 @@ def roofline_block(name, tag, solver_tag, E, S, samples):
     bytes_per_launch = ALGO_BYTES_PER_ENV_STEP.get(name, 712) * E * S
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-           "traffic": traffic, "traffic_source": source, "kernel": "mjb_step_kernel", "kernel_ms": kern_ms,
+           "traffic": traffic, "traffic_source": source, "kernel": kernel, "kernel_ms": kern_ms,
            "kernel_ms_samples": {"n": len(samples), "median": kern_ms, "min": samples[0], "max": samples[-1]},
            "algorithmic_bytes_per_launch": bytes_per_launch}
     if fp64:
@@ -243,7 +243,12 @@ def workload_stats(batch):
             "nefc_max": st["nefc_max"], "rows_gt64_share": round(st["rows_gt64_share"], 5), "solver_iters_mean": round(st["solver_iter_mean"], 3)}
 
 
-def measure_other_config(name, device, launches=5, with_cpu=True):
+def kernel_form(batch):
+    """Which kernel the batch's fused launches ran: the lane = env form (one env per lane, csrc/mjb_lane_env.hip) or the generic one."""
+    return ("mjb_lane_env_kernel", "lane = env (one env per lane)") if batch.lane_env_info()[1] else ("mjb_step_kernel", "generic (G lanes per env, frame in LDS)")
+
+
+def measure_other_config(name, device, launches=5, with_cpu=True, envs=None, substeps=None, lane_env=None, tag=None):
     """One of the other BASELINE workloads (franka_table = configs[2], shadow_hand_grasp = configs[4]'s per-GPU shard, shadow_hand_like =
     its light predecessor), measured in this process after the headline timing so that the DRIVER's record carries it (VERDICT r02
     #3a): `launches` timed fused launches bracketed by synchronisation (five, like the standalone `--config N` run: config 3's first
@@ -251,33 +256,40 @@ def measure_other_config(name, device, launches=5, with_cpu=True):
     device-side ncon / nefc / iteration counters run over exactly the timed launches; the CPU oracle legs on the same workload."""
     from mujoco_ros_pkgs_amd import engine, mjcf
     label, noise_std, E, S, cfgno = WORKLOADS[name]
+    E, S = envs or E, substeps or S
     model = mjcf.Model(dict(mjcf.load_asset(name)))
     model["enableflags"] = int(model["enableflags"]) | 2
     cm = engine.CompiledModel(model)
     batch = engine.Batch(cm, E, device)
+    if lane_env is not None:
+        batch.set_lane_env(lane_env)
     qpos, qvel = initial_state(name, model, E, seed=1000)
     batch.set("qpos", qpos)
     batch.set("qvel", qvel)
     batch.set_ctrl_noise(noise_std, 0.1, 12345, 0)
     batch.step(S)
     batch.synchronize()
-    batch.set_stats(True)
+    constrained = int(model["nefcmax"]) > 0
+    if constrained:
+        batch.set_stats(True)
     t0 = time.perf_counter()
     for _ in range(launches):
         batch.step(S)
     batch.synchronize()
     elapsed = time.perf_counter() - t0
-    stats = workload_stats(batch)
-    batch.set_stats(False)
+    stats = workload_stats(batch) if constrained else None
+    if constrained:
+        batch.set_stats(False)
     noise_mode = batch.noise_mode()
     finite = bool(np.all(np.isfinite(batch.get("qpos"))))
     samples = sorted(batch.time_steps(S, 1) for _ in range(5))
+    kname, kform = kernel_form(batch)
     out = {"metric": "env_steps_per_sec", "value": E * S * launches / elapsed, "unit": "env-steps/s", "n_gpus": 1,
            "steps": launches, "warmup": 1, "ms_per_step": 1e3 * elapsed / launches,
            "config": {"workload": f"{label}, {E} envs per GPU, fp64, Euler dt={model['timestep'][0]}", "baseline_config": cfgno,
                       "envs_per_gpu": E, "physics_steps_per_launch": S, "model": name,
-                      "solver": {0: "PGS", 1: "CG", 2: "Newton"}[int(model["solver"])],
-                      "nconmax": int(model["nconmax"]), "nefcmax": int(model["nefcmax"]),
+                      "solver": {0: "PGS", 1: "CG", 2: "Newton"}[int(model["solver"])] if constrained else "none",
+                      "nconmax": int(model["nconmax"]), "nefcmax": int(model["nefcmax"]), "kernel_form": kform,
                       "fused_frame_bytes": batch.fused_frame()[1], "fused_frame": ("default", "default", "wide (128 rows in LDS)")[batch.fused_frame()[0]],
                       "noise_pregen": noise_mode,
                       "state_finite": finite, "auto_resets": batch.warning_count(),
@@ -287,13 +299,19 @@ def measure_other_config(name, device, launches=5, with_cpu=True):
                       #  profiles/r04_cfg3_overflow.txt; bounded in tests/test_gpu_full_size.py)
                       "contactfull": batch.warning("contactfull"), "cnstrfull": batch.warning("cnstrfull"),
                       "overflow_per_env_step": (batch.warning("contactfull") + batch.warning("cnstrfull")) / float(E * S * (launches + 6))},
-           "workload_stats": stats,
-           "roofline": roofline_block(name, WORKLOAD_TAG[name], "", E, S, samples)}
+           "roofline": roofline_block(name, tag or WORKLOAD_TAG[name], "", E, S, samples, kname)}
+    if stats is not None:
+        out["workload_stats"] = stats
     batch.close()
     cm.close()
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(name, model, noise_std, with_mujoco=False)
     return out
+
+
+# config 2 beside its headline line: the generic 16-lanes-per-env kernel on the same 4096 envs, and the lane = env kernel on a batch that
+# fills the chip with 64-env wavefronts (report both) -- (tag, envs, steps per launch, mjb_set_lane_env mode)
+CONFIG2_EXTRAS = (("2_generic_kernel", 4096, 1000, 0), ("2_lane_env_65536", 65536, 200, 1))
 
 
 def main():
@@ -305,6 +323,9 @@ def main():
     ap.add_argument("--substeps", type=int, default=0, help="physics steps fused into one launch (0 = the config's own)")
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (weak scaling); 0 = the config's own (4096; 1024 for the hand)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per env (0 = engine default)")
+    ap.add_argument("--lane-env", choices=("auto", "on", "off"), default="auto",
+                    help="the lane = env form of the unconstrained fused step (mjb_set_lane_env): auto = the engine's rule (batches of >= 4096 envs "
+                         "of a model whose topology is compiled in)")
     ap.add_argument("--epb", type=int, default=0, help="envs per workgroup (0 = engine default)")
     ap.add_argument("--model", default="")
     ap.add_argument("--solver", default="", choices=["", "PGS", "Newton"], help="override the model's constraint solver")
@@ -533,6 +554,7 @@ def gpu_run(args, name):
     E, S = (args.envs or default_envs), (args.substeps or default_sub)
     batch = engine.Batch(cm, E, local_rank)
     batch.set_launch(args.lanes, args.epb)
+    batch.set_lane_env({"auto": -1, "on": 1, "off": 0}[args.lane_env])
     qpos, qvel = initial_state(name, model, E, seed=1000 + rank)
     batch.set("qpos", qpos)
     batch.set("qvel", qvel)
@@ -582,6 +604,7 @@ def gpu_run(args, name):
     # dominant-kernel duration measured with HIP events on the engine's own stream: 5 single-launch samples
     samples = sorted(batch.time_steps(S, 1) for _ in range(5))
     kern_ms = samples[len(samples) // 2]
+    kname, kform = kernel_form(batch)
 
     if rank == 0:
         solver_tag = "" if not args.solver else "_" + args.solver.lower()  # (the counters belong to ONE kernel variant)
@@ -593,7 +616,7 @@ def gpu_run(args, name):
             "config": {"workload": f"{label}, {E} envs per GPU, fp64, Euler dt={model['timestep'][0]}",
                        "baseline_config": cfgno, "envs_per_gpu": E, "physics_steps_per_launch": S, "model": name,
                        "solver": {0: "PGS", 1: "CG", 2: "Newton"}[int(model["solver"])] if model["nefcmax"] else "none",
-                       "nconmax": int(model["nconmax"]), "nefcmax": int(model["nefcmax"]),
+                       "nconmax": int(model["nconmax"]), "nefcmax": int(model["nefcmax"]), "kernel_form": kform,
                        "ctrl": f"on-device OU noise (Philox seed 12345, tau 0.1 s, std {noise_std:g})",
                        "parallelism": f"env-sharded x{world}, RCCL all-gather of sensordata + 16-double metrics all-reduce per launch, "
                                       "side stream (overlaps the next launch)" if world > 1 else "single GPU",
@@ -604,7 +627,7 @@ def gpu_run(args, name):
             "rank_ms_per_step": {"min": 1e3 * min(per_rank) / args.steps, "max": 1e3 * max(per_rank) / args.steps},
             "exchange_ms": xch.last_ms(),
             "metrics": metrics,
-            "roofline": roofline_block(name, WORKLOAD_TAG.get(name, str(cfgno)), solver_tag, E, S, samples),
+            "roofline": roofline_block(name, WORKLOAD_TAG.get(name, str(cfgno)), solver_tag, E, S, samples, kname),
         }
         if stats is not None:
             out["workload_stats"] = stats
@@ -612,10 +635,15 @@ def gpu_run(args, name):
         out["config"]["fused_frame_bytes"] = batch.fused_frame()[1]
         out["config"]["fused_frame"] = ("default", "default", "wide (128 rows in LDS)")[batch.fused_frame()[0]]
         default_run = world == 1 and not (args.config or args.model or args.solver or args.nefcmax or args.nconmax or args.envs or
-                                          args.substeps or args.lanes or args.epb)
+                                          args.substeps or args.lanes or args.epb or args.lane_env != "auto")
         if default_run and not args.no_other_configs:
             # the other BASELINE workloads, same process, same box (configs[2] and the per-GPU shard of configs[4])
             out["other_configs"] = {}
+            for xtag, xe, xs, xmode in CONFIG2_EXTRAS:
+                try:
+                    out["other_configs"][xtag] = measure_other_config("franka_like", local_rank, with_cpu=False, envs=xe, substeps=xs, lane_env=xmode, tag=xtag)
+                except Exception as exc:
+                    out["other_configs"][xtag] = {"error": f"{type(exc).__name__}: {exc}"}
             for other in ("franka_table", "shadow_hand_grasp", "shadow_hand_like"):
                 try:
                     out["other_configs"][WORKLOAD_TAG[other]] = measure_other_config(other, local_rank, with_cpu=not args.no_cpu_baseline)

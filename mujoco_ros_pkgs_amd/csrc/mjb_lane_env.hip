@@ -131,8 +131,11 @@ DEVI void sincos_nb(double x, double *sn, double *cs)
 
 // LDS of a block (= one wavefront): pair slot q of lane l = the two doubles at (q * 64 + l) * 16 bytes -- one ds_read_b128 /
 // ds_write_b128 per pair, conflict-free.  Slots [0, NV): (qpos_i, qvel_i); then three slots per body whose force the backward
-// sweep reads (cfrc_body): the wavefront's overflow space next to its registers (4 blocks per CU: 40 KB each).
-template <class T> struct Lds {
+// sweep reads (cfrc_body); then, while the budget LP lasts, five per body for its cinert (leaf-most bodies first): the wavefront's
+// overflow space next to its registers.  LP = 40 pair slots (40 KB) when four wavefronts share a CU, 80 / 160 when the batch leaves
+// a CU to two / one (the launcher picks): what does not fit stays in registers, i.e. mostly in their AGPR half, at four moves per
+// double and round trip against one LDS instruction per PAIR and direction.
+template <class T, int LP> struct Lds {
 	using Q = Tq<T>;
 	// the body's cfrc is consumed by the backward sweep (it, or an ancestor, carries a joint)
 	static constexpr bool needed(int b)
@@ -148,20 +151,37 @@ template <class T> struct Lds {
 			if (needed(a)) n++;
 		return T::NV + 3 * n;
 	}
-	static constexpr int nslots() { return slot(T::NBODY); }
+	static constexpr int cin_slot(int b)  // first of the body's five cinert slots, -1: the body's cinert stays in registers
+	{
+		int at = slot(T::NBODY);
+		for (int a = T::NBODY - 1; a >= 1; a--) {
+			if (!needed(a)) continue;
+			if (at + 5 > LP) return -1;
+			if (a == b) return at;
+			at += 5;
+		}
+		return -1;
+	}
+	static constexpr int nslots()
+	{
+		int at = slot(T::NBODY);
+		for (int a = T::NBODY - 1; a >= 1; a--)
+			if (needed(a) && at + 5 <= LP) at += 5;
+		return at;
+	}
 	static constexpr int bytes() { return nslots() * 64 * 16; }
 };
 
 struct alignas(16) Pair { double a, b; };
 
-template <class T>
+template <class T, int LP>
 __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB_AS4 *__restrict__ P, const int nsteps, const unsigned int step0,
                                                           const int env_lo, const int env_hi)
 {
 	constexpr int NB = T::NBODY, NV = T::NV, NU = T::NU;
 	using Q = Tq<T>;
-	using LD = Lds<T>;
-	static_assert(LD::bytes() <= 40960, "lane = env kernel: the topology needs more LDS than a quarter of a CU's");
+	using LD = Lds<T, LP>;
+	static_assert(LD::slot(T::NBODY) <= 40, "lane = env kernel: state and forces of the topology need more LDS than a quarter of a CU's");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_le[];
 	Pair *const lp = reinterpret_cast<Pair *>(smem_le) + threadIdx.x;  // pair slot q of this lane: lp[64 * q]
 	// (a tail lane without an env keeps running on the last env's data and stores nothing: no divergent exit, the wave-uniform
@@ -273,7 +293,7 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 			// gives the same qM / qfrc_bias; the com would need every body's pose before the first inertia, i.e. a second sweep with
 			// 15 doubles per body kept across).
 			double xpos[NB][3], xquat[NB][4], xmat[NB][9];
-			double cin[NB][10];  // cinert, then (accumulated leaf -> root) crb
+			double cin[NB][10];  // cinert of the bodies that found no room in LDS
 			double cdof[NV > 0 ? NV : 1][6];
 			double cvel[NB][6], cacc[NB][6];
 			double f[NV > 0 ? NV : 1];  // qfrc_passive + qfrc_applied + qfrc_actuator, then (- qfrc_bias) qfrc_smooth
@@ -462,6 +482,7 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 				}
 				if constexpr (LD::needed(b)) {
 					// cinert about the tree root's origin (mju_inertCom with that offset)
+					double ci[10];
 					{
 						double dif[3];
 						if constexpr (r == b) { dif[0] = xipos[0] - pos[0]; dif[1] = xipos[1] - pos[1]; dif[2] = xipos[2] - pos[2]; }
@@ -476,7 +497,7 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 							Tm[3 * rr + 1] = X[3 * rr] * ixy + X[3 * rr + 1] * iyy + X[3 * rr + 2] * iyz;
 							Tm[3 * rr + 2] = X[3 * rr] * ixz + X[3 * rr + 1] * iyz + X[3 * rr + 2] * izz;
 						}
-						double *res = cin[b];
+						double *res = ci;
 						res[0] = Tm[0] * X[0] + Tm[1] * X[1] + Tm[2] * X[2] + mass * (dif[1] * dif[1] + dif[2] * dif[2]);
 						res[1] = Tm[3] * X[3] + Tm[4] * X[4] + Tm[5] * X[5] + mass * (dif[0] * dif[0] + dif[2] * dif[2]);
 						res[2] = Tm[6] * X[6] + Tm[7] * X[7] + Tm[8] * X[8] + mass * (dif[0] * dif[0] + dif[1] * dif[1]);
@@ -526,8 +547,14 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 					}
 					// cfrc_body = cinert * cacc + cvel x* (cinert * cvel): parked in LDS for the backward sweep
 					double cf[6], t0[6], t1[6];
-					mul_inert_vec(cf, cin[b], cacc[b]);
-					mul_inert_vec(t0, cin[b], cvel[b]);
+					mul_inert_vec(cf, ci, cacc[b]);
+					mul_inert_vec(t0, ci, cvel[b]);
+					if constexpr (LD::cin_slot(b) >= 0) {
+						constexpr int c0 = LD::cin_slot(b);
+						for (int k = 0; k < 5; k++) lp[64 * (c0 + k)] = Pair{ ci[2 * k], ci[2 * k + 1] };
+					} else {
+						for (int k = 0; k < 10; k++) cin[b][k] = ci[k];
+					}
 					cross_force(t1, cvel[b], t0);
 					constexpr int q0 = LD::slot(b);
 					lp[64 * q0] = Pair{ cf[0] + t1[0], cf[1] + t1[1] };
@@ -554,8 +581,7 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 
 			// ================= A2 mj_crb + A9 RNE backward pass, one sweep leaf -> root =================
 			double qM[NV > 0 ? NV : 1][NV > 0 ? NV : 1];  // [i][a], a = i or an ancestor of i (the other entries never exist)
-			double csum[NB][6];                           // forces of a body's children, summed as the sweep passes them
-			bool cset[NB] = {};
+			double csum[NB][6], crbs[NB][10];             // forces / composite inertias of a body's children, summed as the sweep passes them
 			sfor<NB - 1>([&](auto Bi) {
 				constexpr int b = NB - 1 - Bi;
 				constexpr int p = T::body_parentid[b], j = T::body_jnt[b];
@@ -566,10 +592,22 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 					// (children have larger ids: their sums are complete; cset is a compile-time fact after unrolling)
 					constexpr bool has_child = [] { for (int c = b + 1; c < NB; c++) if (T::body_parentid[c] == b && LD::needed(c)) return true; return false; }();
 					if constexpr (has_child) for (int k = 0; k < 6; k++) cf[k] += csum[b][k];
+					double cb[10];  // composite inertia of the body (mj_crb)
+					if constexpr (LD::cin_slot(b) >= 0) {
+						constexpr int c0 = LD::cin_slot(b);
+						for (int k = 0; k < 5; k++) {
+							const Pair c = lp[64 * (c0 + k)];
+							cb[2 * k] = c.a;
+							cb[2 * k + 1] = c.b;
+						}
+					} else {
+						for (int k = 0; k < 10; k++) cb[k] = cin[b][k];
+					}
+					if constexpr (has_child) for (int k = 0; k < 10; k++) cb[k] += crbs[b][k];
 					if constexpr (j >= 0) {
 						double buf[6];
 						f[j] -= dot6r(cdof[j], cf);
-						mul_inert_vec(buf, cin[b], cdof[j]);
+						mul_inert_vec(buf, cb, cdof[j]);
 						sfor<NV>([&](auto A) {
 							constexpr int a = A;
 							if constexpr (Q::anc(a, j)) qM[j][a] = (a == j ? tb[b].armature : 0.0) + dot6r(cdof[a], buf);
@@ -579,12 +617,12 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 						constexpr bool first = [] { for (int c = b + 1; c < NB; c++) if (T::body_parentid[c] == p && LD::needed(c)) return false; return true; }();
 						if constexpr (first) for (int k = 0; k < 6; k++) csum[p][k] = cf[k];
 						else for (int k = 0; k < 6; k++) csum[p][k] += cf[k];
-						for (int k = 0; k < 10; k++) cin[p][k] += cin[b][k];
+						if constexpr (first) for (int k = 0; k < 10; k++) crbs[p][k] = cb[k];
+						else for (int k = 0; k < 10; k++) crbs[p][k] += cb[k];
 					}
 				}
 				__builtin_amdgcn_sched_barrier(0);
 			});
-			(void)cset;
 			if (e_on) {  // mj_energyVel: 0.5 qvel' M qvel (mj_energyPos was gathered along the sweep)
 				double ke = 0, qv[NV > 0 ? NV : 1];
 				sfor<NV>([&](auto I) { qv[I] = lp[64 * I].b; });
@@ -806,12 +844,33 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, int env_lo, int env_
 	const int n = env_hi - env_lo;
 	if (n <= 0) return 0;
 	const dim3 grid((unsigned int)((n + 63) / 64)), block(64);
-#define MJB_LE_X(id, T)                                                                                                                                   \
-	if (topo == id) {                                                                                                                                      \
-		hipLaunchKernelGGL(mjb_lane_env_kernel<T>, grid, block, Lds<T>::bytes(), (hipStream_t)stream, (const KernelParams MJB_AS4 *)Pdev, nsteps, step0, env_lo, env_hi); \
-		return (int)hipGetLastError();                                                                                                                     \
+	// LDS budget per wavefront from the CUs the launch leaves idle: one wavefront per CU may take all of its LDS
+	static const int ncu = [] {
+		int dev = 0, c = 0;
+		if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 0;
+		return c;
+	}();
+	static const int forced = [] { const char *v = getenv("MJB_LANE_ENV_LDS_KB"); return v ? atoi(v) : 0; }();  // measurement knob: 40 / 80 / 160
+	const int waves = (int)grid.x;
+	int lp = (ncu > 0 && waves <= ncu) ? 160 : ((ncu > 0 && waves <= 2 * ncu) ? 80 : 40);
+	if (forced == 40 || forced == 80 || forced == 160) lp = forced;
+#define MJB_LE_GO(T, LPV)                                                                                                                    \
+	{                                                                                                                                         \
+		auto kern = mjb_lane_env_kernel<T, LPV>;                                                                                              \
+		constexpr int bytes = Lds<T, LPV>::bytes();                                                                                           \
+		static const hipError_t attr = bytes > 65536 ? hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) : hipSuccess; \
+		if (attr != hipSuccess) return (int)attr;                                                                                             \
+		hipLaunchKernelGGL(kern, grid, block, bytes, (hipStream_t)stream, (const KernelParams MJB_AS4 *)Pdev, nsteps, step0, env_lo, env_hi); \
+		return (int)hipGetLastError();                                                                                                        \
+	}
+#define MJB_LE_X(id, T)                      \
+	if (topo == id) {                        \
+		if (lp == 160) MJB_LE_GO(T, 160)     \
+		if (lp == 80) MJB_LE_GO(T, 80)       \
+		MJB_LE_GO(T, 40)                     \
 	}
 	MJB_LE_TOPOS(MJB_LE_X)
 #undef MJB_LE_X
+#undef MJB_LE_GO
 	return (int)hipErrorInvalidValue;
 }

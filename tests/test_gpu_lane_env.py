@@ -176,18 +176,18 @@ def test_bad_state_resets_like_mj_step(eng):
 
 
 def test_automatic_mode_threshold(eng):
-    """mode -1: whole-batch launches of >= MJB_LANE_ENV_MIN_ENVS envs (default 16384) take the lane = env kernel, smaller ones do not."""
+    """mode -1: whole-batch launches of >= MJB_LANE_ENV_MIN_ENVS envs (default 4096) take the lane = env kernel, smaller ones do not."""
     engine, mjcf, po = eng
     model = mjcf.load_asset("franka_like")
     cm = engine.CompiledModel(model)
-    for nenv, expect in ((1024, False), (16384, True)):
+    for nenv, expect in ((1024, False), (4096, True), (16384 + 37, True)):
         qpos, qvel = random_franka_state(model, nenv, 2)
         b = make(engine, cm, nenv, qpos, qvel, -1)
         b.set_ctrl_noise(10.0, 0.1, 3, 0)
         b.step(20)
         assert b.lane_env_info()[1] == expect
         if expect:
-            idx = np.arange(0, nenv, 1023)
+            idx = np.arange(0, nenv, nenv // 6 + 1)
             q = b.get("qpos")
             assert np.all(np.isfinite(q))
             # sampled envs against the oracle (their global env ids key the Philox stream: one rollout call per sampled env)
