@@ -113,7 +113,8 @@ class EngineSource:
 @pytest.fixture(scope="session")
 def selfcheck_dir(tmp_path_factory, oracle_built):
     d = str(tmp_path_factory.mktemp("golden_selfcheck"))
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_mujoco_golden.py"), "--self-check", d, "--only", "franka_like,pendulum_world,equality_world"])
+    # every world of the tool, so that the first real MuJoCo file of ANY of them meets a reader that has been through it
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_mujoco_golden.py"), "--self-check", d])
     return d
 
 
@@ -127,11 +128,24 @@ def test_generator_reports_absence_or_writes(tmp_path):
     print(ABSENT if golden_dir() is None else "MuJoCo golden vectors: " + golden_dir())
 
 
-@pytest.mark.parametrize("name", ["franka_like", "pendulum_world", "equality_world"])
+@pytest.mark.parametrize("name", NAMES)
 def test_reader_on_self_check_files(selfcheck_dir, oracle_built, name):
     """Plumbing only: the oracle against files the tool wrote FROM the oracle (labelled so inside the file)."""
     label = check_against(os.path.join(selfcheck_dir, name + ".npz"), name, gold.OracleSource, const=False)
     assert "SELF-CHECK" in label
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_contact_models_have_contact_states(selfcheck_dir, name):
+    """The writer's guarantee, read back from the files: a model with contacts is in contact in >= 3 of its 8 forward states."""
+    z = np.load(os.path.join(selfcheck_dir, name + ".npz"), allow_pickle=False)
+    kind = dict((n, k) for k, n in gold.WORLDS)[name]
+    model = mjcf.compile_xml_file(gold.world_path(kind, name))
+    sizes = [tuple(int(x) for x in z[f"fwd_sizes_{s}"]) for s in range(gold.NSTATE)]
+    assert gold.contact_states(model, sizes), sizes
+    if model["nconmax"] > 0 and any(model["jnt_type"][j] == 0 for j in range(model["njnt"])):
+        assert all(z[f"fwd_contact_dist_{s}"].size == sizes[s][0] for s in range(gold.NSTATE))
+        assert any(z[f"fwd_efc_force_{s}"].size and np.abs(z[f"fwd_efc_force_{s}"]).max() > 0 for s in range(gold.NCONTACT)), "no contact force in any contact state"
 
 
 @pytest.mark.skipif(golden_dir() is None, reason=ABSENT)
@@ -142,7 +156,7 @@ def test_oracle_matches_mujoco_golden_vectors(oracle_built, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["franka_like", "pendulum_world", "equality_world"])
+@pytest.mark.parametrize("name", NAMES)
 def test_engine_reader_on_self_check_files(selfcheck_dir, oracle_built, name):
     """The HIP engine through the same reader, against the oracle-written files (GPU vs oracle on these worlds, whatever the
     machine): keeps the `-m gpu` consumer of the golden files from rotting while the files themselves are absent."""

@@ -29,11 +29,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 WORLDS = [("asset", "franka_like"), ("asset", "franka_table"), ("asset", "shadow_hand_like"), ("golden", "pendulum_world"),
-          ("golden", "empty_world"), ("golden", "equality_world"), ("golden", "sensors_world"), ("golden", "mocap_world")]
+          ("golden", "empty_world"), ("golden", "equality_world"), ("golden", "sensors_world"), ("golden", "mocap_world"),
+          ("asset", "shadow_hand_grasp"), ("asset", "lane_env_tree")]
 CONST = ("qpos0", "body_mass", "body_inertia", "body_subtreemass", "dof_invweight0", "body_invweight0", "geom_rbound")
 FWD = ("qacc", "qfrc_bias", "qM", "qLD", "qacc_smooth", "qfrc_passive", "xpos", "cvel", "efc_J", "efc_pos", "efc_D", "efc_R",
        "efc_aref", "efc_vel", "efc_force", "contact_dist", "contact_pos", "contact_frame")
 NSTATE, ROLL_STATES, ROLLS, SEED = 8, 2, (1, 10, 100), 5
+NCONTACT = 4  # states 0 .. 3 of a model with contacts are moved INTO contact (seeded_inputs)
 
 
 def world_path(kind, name):
@@ -54,7 +56,55 @@ def seeded_inputs(model):
     qvel = rng.uniform(-0.1, 0.1, (NSTATE, nv))
     ctrl = rng.uniform(-1, 1, (NSTATE, nu))
     ctrl_seq = rng.uniform(-1, 1, (max(ROLLS), nu))
-    return qpos.reshape(NSTATE, nq), qvel, ctrl, ctrl_seq
+    qpos = qpos.reshape(NSTATE, nq)
+    # Contact models: every one of them carries a free body (cube / ball) that rests ABOVE its support at qpos0, so the states above
+    # have ncon = 0 and the forward fields would never compare a contact row.  States 0 .. NCONTACT-1 lower the free bodies, 1 mm at a
+    # time, until the in-repo collision stage (the oracle's: inputs are data, whoever writes the file) reports a contact, then a
+    # seeded 0.5 - 2 mm further.  The states travel in the file (`qpos`); the reader regenerates them and asserts equality.
+    free = [int(model["jnt_qposadr"][j]) for j in range(model["njnt"]) if model["jnt_type"][j] == 0]
+    if model["nconmax"] > 0 and free:
+        from oracle import pyoracle
+        pyoracle.build()
+        d = pyoracle.OracleData(model)
+        extra = rng.uniform(0.0005, 0.002, NCONTACT)
+        # (the Shadow-Hand-like models: qpos0 + U(-0.05, 0.05) puts half the finger joints beyond their lower stop and the servos fling them
+        #  back at thousands of rad/s^2 -- every constraint is satisfied by the free acceleration, all forces are zero.  Their contact states
+        #  start from the bench's grasp poses instead (mujoco_ros_pkgs_amd/workloads.py), the cube lowered onto the palm as everywhere)
+        jn = list(model["names"]["joint"]) if "names" in model else []
+        hand = None
+        if "cube_joint" in jn and "WRJ1" in jn:
+            from mujoco_ros_pkgs_amd import workloads
+            power = any(str(n).startswith("th_pad") or str(n) == "thenar" for n in model["names"].get("geom", [])) or model["ncollpair"] > 120
+            hand = (workloads.hand_power_grasp_states if power else workloads.hand_grasp_states)(model, NCONTACT, seed=SEED)[0]
+        for s in range(NCONTACT):
+            q = (hand[s] if hand is not None else qpos[s]).copy()
+            for _ in range(400):
+                d.reset()
+                d.qpos[:] = q
+                d.forward()
+                if int(d.ncon[0]) > 0:
+                    break
+                for a in free:
+                    q[a + 2] -= 0.001
+            for a in free:
+                q[a + 2] -= extra[s]
+            qpos[s] = q
+            # (slow, weakly actuated: under the full random ctrl -- servo targets a radian away -- the bodies leave the contact
+            #  faster than gravity closes it and every contact force is zero)
+            qvel[s] *= 0.1
+            ctrl[s] *= 0.05
+            for i in range(nu):  # a position servo holds its joint where it is
+                if int(model["actuator_biastype"][i]) == 1 and int(model["actuator_trntype"][i]) == 0:
+                    j = int(np.asarray(model["actuator_trnid"]).reshape(-1, 2)[i, 0])
+                    ctrl[s, i] = q[int(model["jnt_qposadr"][j])] * float(np.asarray(model["actuator_gear"]).reshape(-1, 6)[i, 0])
+    return qpos, qvel, ctrl, ctrl_seq
+
+
+def contact_states(model, sizes):
+    """The writer's guarantee (VERDICT r04 #6): a model with contacts has ncon > 0 in at least 3 of its forward states."""
+    if model["nconmax"] <= 0 or not any(model["jnt_type"][j] == 0 for j in range(model["njnt"])):
+        return True
+    return sum(1 for s in sizes if s[0] > 0) >= 3
 
 
 class MujocoSource:
@@ -136,16 +186,20 @@ def write_one(src_cls, kind, name, outdir, version):
     out = {"version": np.array(version), "source": np.array(src.label), "qpos": qpos, "qvel": qvel, "ctrl": ctrl, "ctrl_seq": ctrl_seq}
     for f in CONST:
         out["const_" + f] = src.const(f)
+    sizes = []
     for s in range(NSTATE):
-        for f, a in src.forward(qpos[s], qvel[s], ctrl[s]).items():
+        fw = src.forward(qpos[s], qvel[s], ctrl[s])
+        sizes.append(tuple(int(x) for x in fw["sizes"]))
+        for f, a in fw.items():
             out[f"fwd_{f}_{s}"] = np.asarray(a)
+    assert contact_states(model, sizes), f"{name}: fewer than 3 of the {NSTATE} forward states are in contact: (ncon, nefc) = {sizes}"
     for s in range(ROLL_STATES):
         for K in ROLLS:
             q, v = src.rollout(qpos[s], qvel[s], ctrl_seq, K)
             out[f"roll_qpos_{K}_{s}"], out[f"roll_qvel_{K}_{s}"] = q, v
     os.makedirs(outdir, exist_ok=True)
     np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
-    return os.path.getsize(os.path.join(outdir, name + ".npz"))
+    return os.path.getsize(os.path.join(outdir, name + ".npz")), sizes
 
 
 def main():
@@ -168,8 +222,8 @@ def main():
     for kind, name in WORLDS:
         if only and name not in only:
             continue
-        n = write_one(src_cls, kind, name, outdir, version)
-        print(f"{name}: {n} bytes -> {os.path.join(outdir, name + '.npz')}")
+        n, sizes = write_one(src_cls, kind, name, outdir, version)
+        print(f"{name}: {n} bytes -> {os.path.join(outdir, name + '.npz')}   (ncon, nefc) per forward state: {sizes}")
     return 0
 
 
