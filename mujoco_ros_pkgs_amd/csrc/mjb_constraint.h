@@ -2364,6 +2364,9 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 		}
 	}
 	gsync<G>();
+#ifdef MJB_PROFILE_SUB
+	EPROF(20);
+#endif
 	if constexpr (REGB) {
 		// M^-1 (J' f) by the same dense substitution, the whole nv-vector in the registers of every lane (wave-uniform
 		// addresses: one LDS broadcast per entry; lane k keeps element k)
@@ -2384,6 +2387,9 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 		}
 		gsync<G>();
 	}
+#ifdef MJB_PROFILE_SUB
+	EPROF(23);
+#endif
 }
 
 // the LDS-B variants (nv > 16) stay out of line: models that small never pay their registers or instruction-cache lines

@@ -88,6 +88,18 @@ DEVI double pinv(double x)
 	asm volatile("" : "+v"(x));
 	return x;
 }
+// "This value has to be HERE": the wait for a prefetched scalar / LDS value is taken at this point, BEFORE the next prefetch is issued.
+// LDS reads and scalar loads share one counter and scalar loads return out of order, so any wait is a wait for everything in
+// flight: a region that issues its successor's fetches first and then touches its own data waits for both.
+DEVI void touch_s(double x) { asm volatile("" ::"s"(x)); }
+DEVI void touch_v(double x) { asm volatile("" ::"v"(x)); }
+// ... and a whole half record: placed at the END of the region that issued its loads, it keeps every one of them inside that region
+// (left alone, the loads of entries first used late in the next region are sunk there and waited for on the spot)
+template <int N> DEVI void touch_rec(const double *h)  // (the N entries the sweep reads)
+{
+	asm volatile("" ::"s"(h[0]), "s"(h[1]), "s"(h[2]), "s"(h[3]), "s"(h[4]), "s"(h[5]), "s"(h[6]), "s"(h[7]), "s"(h[8]), "s"(h[9]));
+	if constexpr (N > 10) asm volatile("" ::"s"(h[10]), "s"(h[11]), "s"(h[12]), "s"(h[13]));
+}
 DEVI double pins(double x)  // the same for a wave-uniform (scalar) value
 {
 	asm volatile("" : "+s"(x));
@@ -225,14 +237,15 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 		const LeTapeBody MJB_AS4 *tb = reinterpret_cast<const LeTapeBody MJB_AS4 *>(th + 1);
 		const double dt = th->dt;
 
-		// ---- H10: the reference's ctrl-noise injector (mujoco_env.cpp:469-481), before the step
-		double ctrl[NU > 0 ? NU : 1];
+		// ---- H10: the reference's ctrl-noise injector (mujoco_env.cpp:469-481): this step's normals are FETCHED here and folded into
+		// the OU state where the forces are assembled, after the root -> leaf sweep -- the trip to HBM hides behind the sweep
+		double z[NU > 0 ? NU : 1];
+		sfor<NU>([&](auto I) { z[I] = 0; });
 		if (nz_on) {
-			const double rate = Pq->nz.rate, scale = Pq->nz.scale;
 			if (zpre) {
 				asm volatile("" ::: "memory");
 				const double *zb = s.zbuf + (zhalf_i > 0 ? s.zhalf : 0ull) + ((size_t)st * s.nenv + ev) * NU;
-				sfor<NU>([&](auto I) { cn[I] = rate * cn[I] + scale * zb[I]; });
+				sfor<NU>([&](auto I) { z[I] = zb[I]; });
 			} else {
 				asm volatile("" ::: "memory");
 				// (one copy of the generator in the instruction stream: the normals go through the cfrc slots, free at this point)
@@ -240,12 +253,10 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 				double *zl = reinterpret_cast<double *>(smem_le) + 2 * 64 * NV + threadIdx.x;
 #pragma nounroll
 				for (int i = 0; i < NU; i++) zl[64 * i] = philox_normal(seed, genv, step0 + (unsigned int)st, (unsigned int)i);
-				sfor<NU>([&](auto I) { cn[I] = rate * cn[I] + scale * zl[64 * I]; });
+				sfor<NU>([&](auto I) { z[I] = zl[64 * I]; });
 			}
-			sfor<NU>([&](auto I) { ctrl[I] = cn[I]; });
-		} else {
-			sfor<NU>([&](auto I) { const double c = pinv(s.ctrl[ev * NU + I]); ctrl[I] = wasreset ? 0.0 : c; });  // (load first: a select around a load becomes a per-lane branch)
 		}
+		bool rs = false;  // mj_resetData ran in THIS step (after the injector wrote ctrl: ctrl and the OU state read zero)
 
 		// ---- mj_checkPos / mj_checkVel (qpos first: its reset hides a bad qvel)
 		{
@@ -263,9 +274,9 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 					const double oa = pinv(o.a), ob = pinv(o.b), q0 = pins(tb[T::jnt_bodyid[I]].qpos0);  // (evaluated before the selects, not inside them)
 					lp[64 * I] = Pair{ bad ? q0 : oa, bad ? 0.0 : ob };
 				});
-				sfor<NU>([&](auto I) { cn[I] = bad ? 0.0 : cn[I]; ctrl[I] = bad ? 0.0 : ctrl[I]; });
 				time = bad ? 0.0 : time;
 				wasreset = wasreset || bad;
+				rs = bad;
 			}
 		}
 
@@ -303,59 +314,25 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 				for (int k = 0; k < 3; k++) grav[k] = g_on ? th->gravity[k] : 0.0;
 			}
 			const bool pas_on = !(m.disableflags & MJB_DSBL_PASSIVE);
-			// ================= A12 mj_fwdActuation first (joint transmission: it needs qpos / qvel only; the ctrl registers die here) =================
-			{
-				const bool act_on = !(m.disableflags & MJB_DSBL_ACTUATION);
-				const bool clamp_on = !(m.disableflags & MJB_DSBL_CLAMPCTRL);
-				sfor<NV>([&](auto I) { f[I] = 0; });
-				sfor<NU>([&](auto U) {
-					constexpr int i = U, j = T::act_jnt[i];
-					double force = 0;
-					const LeTapeAct MJB_AS4 &A = ta[i];
-					const double gear = A.gear;
-					[[maybe_unused]] Pair s2{ 0, 0 };
-					constexpr bool need_qv = T::act_gaintype[i] == MJB_GAIN_AFFINE || T::act_biastype[i] == MJB_BIAS_AFFINE;
-					if constexpr (need_qv) s2 = lp[64 * j];
-					if (act_on) {
-						double c = ctrl[i];
-						if constexpr (T::act_ctrllimited[i]) {
-							if (clamp_on) {
-								c = clampd(c, A.ctrllo, A.ctrlhi);
-							}
-						}
-						const double len = s2.a * gear, vel = s2.b * gear;
-						double gain = A.gain[0], bs = 0;
-						if constexpr (T::act_gaintype[i] == MJB_GAIN_AFFINE) gain = gain + A.gain[1] * len + A.gain[2] * vel;
-						if constexpr (T::act_biastype[i] == MJB_BIAS_AFFINE) bs = A.bias[0] + A.bias[1] * len + A.bias[2] * vel;
-						force = gain * c + bs;
-						if constexpr (T::act_forcelimited[i]) {
-							force = clampd(force, A.forcelo, A.forcehi);
-						}
-						f[j] += gear * force;
-					}
-					if (sens_on) {
-						sfor<T::NSENSOR>([&](auto S) {
-							constexpr int q = S;
-							if constexpr (T::sensor_objid[q] == i && (T::sensor_type[q] == MJB_SENS_ACTUATORFRC || T::sensor_type[q] == MJB_SENS_ACTUATORPOS || T::sensor_type[q] == MJB_SENS_ACTUATORVEL)) {
-								const Pair s3 = lp[64 * j];
-								double v = T::sensor_type[q] == MJB_SENS_ACTUATORFRC ? force : (T::sensor_type[q] == MJB_SENS_ACTUATORPOS ? s3.a * gear : s3.b * gear);
-								const double cut = m.sensor_cutoff[q];
-								sd[T::sensor_adr[q]] = cut > 0 ? clampd(v, -cut, cut) : v;
-							}
-						});
-					}
-				});
-			}
 			__builtin_amdgcn_sched_barrier(0);
 			// (two scheduling regions per body, each fetching the NEXT region's half record at its top: the scalar loads of a region
 			//  cannot be hoisted beyond it -- left alone, the compiler issues them bodies ahead and parks ~540 SGPRs in VGPR lanes)
 			double hA[NB + 1][16], hB[NB][16];
-			for (int k = 0; k < 16; k++) hA[1][k] = reinterpret_cast<const double MJB_AS4 *>(tb + 1)[k];
+			for (int k = 0; k < 14; k++) hA[1][k] = reinterpret_cast<const double MJB_AS4 *>(tb + 1)[k];
+			// ... and the (qpos, qvel) pair of the next jointed body: LDS reads and scalar loads share one counter, so a read issued where
+			// it is needed would wait for the record fetched beside it
+			Pair pq[NB + 1];
+			{
+				constexpr int j1 = [] { for (int c = 1; c < NB; c++) if (T::body_jnt[c] >= 0) return T::body_jnt[c]; return -1; }();
+				if constexpr (j1 >= 0) pq[T::jnt_bodyid[j1]] = lp[64 * j1];
+			}
 			sfor<NB>([&](auto B) {
 				constexpr int b = B;
 				if constexpr (b > 0) {
 				constexpr int p = T::body_parentid[b], j = T::body_jnt[b], r = T::body_rootid[b];
-				for (int k = 0; k < 16; k++) hB[b][k] = reinterpret_cast<const double MJB_AS4 *>(tb + b)[16 + k];
+				touch_s(hA[b][0]);
+				if constexpr (j >= 0) touch_v(pq[b].a);
+				for (int k = 0; k < 10; k++) hB[b][k] = reinterpret_cast<const double MJB_AS4 *>(tb + b)[16 + k];
 				const double *const A = hA[b];  // pos[3] quat[4] jaxis[3] jpos[3] qpos0 stiffness spring
 				double pos[3] = { A[0], A[1], A[2] }, quat[4] = { A[3], A[4], A[5], A[6] };
 				if constexpr (p != 0) {
@@ -368,9 +345,8 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 				[[maybe_unused]] double xaxis[3], xanch[3], qp = 0, qv = 0;
 				[[maybe_unused]] bool offc = false;
 				if constexpr (j >= 0) {
-					const Pair s2 = lp[64 * j];
-					qp = s2.a;
-					qv = s2.b;
+					qp = pq[b].a;
+					qv = pq[b].b;
 					// The joint's world axis is its local axis through the body's FINAL orientation (a hinge turns about it, a slide does not
 					// turn), and a hinge's anchor stays where it was: the frame before the joint motion -- mj_kinematics' xaxis / xanchor
 					// source -- is only needed for an off-centre anchor (jnt_pos != 0, wave-uniform).
@@ -390,14 +366,9 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 						qmul(q, quat, ql);
 						for (int k = 0; k < 4; k++) quat[k] = q[k];
 					}
-					// passive spring force of the dof (the damper follows in the second region), applied force
-					double pas = 0;
-					if (pas_on) pas = -A[14] * (qp - A[15]);
-					const double qfa = pinv(s.qfrc_applied[ev * NV + j]);
-					f[j] += pas + (wasreset ? 0.0 : qfa);
-					if (e_on && pas_on) {
-						const double dqs = qp - A[15];
-						pe += 0.5 * A[14] * dqs * dqs;
+					if (e_on && pas_on) {  // mj_energyPos: the joint spring
+						const double dqs = qp - tb[b].spring;  // (last step only)
+						pe += 0.5 * tb[b].stiffness * dqs * dqs;
 					}
 				}
 				normalize4_sel(quat);
@@ -417,13 +388,16 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 					}
 				}
 				for (int k = 0; k < 3; k++) xpos[b][k] = pos[k];
+				touch_rec<10>(hB[b]);
 				__builtin_amdgcn_sched_barrier(0);
 				// ---- second region: inertial frame, cinert, velocities, forces; the next body's pose half on its way
-				if constexpr (b + 1 < NB) for (int k = 0; k < 16; k++) hA[b + 1][k] = reinterpret_cast<const double MJB_AS4 *>(tb + b + 1)[k];
-				const double *const Bh = hB[b];  // ipos[3] ibody[6] mass damping armature hdamping
-				if constexpr (j >= 0) {
-					if (pas_on) f[j] -= Bh[10] * qv;
+				touch_s(hB[b][0]);
+				if constexpr (b + 1 < NB) for (int k = 0; k < 14; k++) hA[b + 1][k] = reinterpret_cast<const double MJB_AS4 *>(tb + b + 1)[k];
+				{
+					constexpr int nb = [] { for (int c = b + 1; c < NB; c++) if (T::body_jnt[c] >= 0) return c; return -1; }();
+					if constexpr (nb >= 0) pq[nb] = lp[64 * T::body_jnt[nb]];
 				}
+				const double *const Bh = hB[b];  // ipos[3] ibody[6] mass damping armature hdamping
 				// inertial frame
 				double xipos[3];
 				if constexpr (T::body_sameframe[b]) {
@@ -561,10 +535,68 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 					lp[64 * (q0 + 1)] = Pair{ cf[2] + t1[2], cf[3] + t1[3] };
 					lp[64 * (q0 + 2)] = Pair{ cf[4] + t1[4], cf[5] + t1[5] };
 				}
+				if constexpr (b + 1 < NB) touch_rec<14>(hA[b + 1]);
 				__builtin_amdgcn_sched_barrier(0);
 				}
 			});
 
+			// ============ A8 mj_passive, the injector's OU update, A12 mj_fwdActuation (joint transmission), qfrc_applied ============
+			{
+				if (nz_on && attempt == 0) {
+					const double rate = Pq->nz.rate, scale = Pq->nz.scale;
+					sfor<NU>([&](auto I) { const double v = rate * cn[I] + scale * z[I]; cn[I] = rs ? 0.0 : v; });
+				}
+				double ctrl[NU > 0 ? NU : 1];
+				if (nz_on) {
+					sfor<NU>([&](auto I) { ctrl[I] = cn[I]; });
+				} else {
+					sfor<NU>([&](auto I) { const double c = pinv(s.ctrl[ev * NU + I]); ctrl[I] = wasreset ? 0.0 : c; });  // (load first: a select around a load becomes a per-lane branch)
+				}
+				Pair sq[NV > 0 ? NV : 1];
+				sfor<NV>([&](auto I) {
+					constexpr int j = I;
+					sq[j] = lp[64 * j];
+					const double qfa = pinv(s.qfrc_applied[ev * NV + j]);
+					const LeTapeBody MJB_AS4 &tj = tb[T::jnt_bodyid[j]];
+					double pas = 0;
+					if (pas_on) {
+						pas = -tj.stiffness * (sq[j].a - tj.spring);
+						pas -= tj.damping * sq[j].b;
+					}
+					f[j] = pas + (wasreset ? 0.0 : qfa);
+				});
+				const bool act_on = !(m.disableflags & MJB_DSBL_ACTUATION);
+				const bool clamp_on = !(m.disableflags & MJB_DSBL_CLAMPCTRL);
+				sfor<NU>([&](auto U) {
+					constexpr int i = U, j = T::act_jnt[i];
+					double force = 0;
+					const LeTapeAct MJB_AS4 &A = ta[i];
+					const double gear = A.gear;
+					if (act_on) {
+						double c = ctrl[i];
+						if constexpr (T::act_ctrllimited[i]) {
+							if (clamp_on) c = clampd(c, A.ctrllo, A.ctrlhi);
+						}
+						const double len = sq[j].a * gear, vel = sq[j].b * gear;
+						double gain = A.gain[0], bs = 0;
+						if constexpr (T::act_gaintype[i] == MJB_GAIN_AFFINE) gain = gain + A.gain[1] * len + A.gain[2] * vel;
+						if constexpr (T::act_biastype[i] == MJB_BIAS_AFFINE) bs = A.bias[0] + A.bias[1] * len + A.bias[2] * vel;
+						force = gain * c + bs;
+						if constexpr (T::act_forcelimited[i]) force = clampd(force, A.forcelo, A.forcehi);
+						f[j] += gear * force;
+					}
+					if (sens_on) {
+						sfor<T::NSENSOR>([&](auto S) {
+							constexpr int q = S;
+							if constexpr (T::sensor_objid[q] == i && (T::sensor_type[q] == MJB_SENS_ACTUATORFRC || T::sensor_type[q] == MJB_SENS_ACTUATORPOS || T::sensor_type[q] == MJB_SENS_ACTUATORVEL)) {
+								double v = T::sensor_type[q] == MJB_SENS_ACTUATORFRC ? force : (T::sensor_type[q] == MJB_SENS_ACTUATORPOS ? sq[j].a * gear : sq[j].b * gear);
+								const double cut = m.sensor_cutoff[q];
+								sd[T::sensor_adr[q]] = cut > 0 ? clampd(v, -cut, cut) : v;
+							}
+						});
+					}
+				});
+			}
 			if (sens_on) {
 				sfor<T::NSENSOR>([&](auto S) {
 					constexpr int q = S, type = T::sensor_type[q];
@@ -582,24 +614,43 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 			// ================= A2 mj_crb + A9 RNE backward pass, one sweep leaf -> root =================
 			double qM[NV > 0 ? NV : 1][NV > 0 ? NV : 1];  // [i][a], a = i or an ancestor of i (the other entries never exist)
 			double csum[NB][6], crbs[NB][10];             // forces / composite inertias of a body's children, summed as the sweep passes them
+			double pcf[NB][6], pcb[NB][10], parm[NB];     // the NEXT body's force / cinert / joint armature, fetched one region ahead
+			auto fetch_body = [&](auto Bn) {
+				constexpr int nb = Bn;
+				constexpr int q0 = LD::slot(nb);
+				if constexpr (T::body_jnt[nb] >= 0) parm[nb] = tb[nb].armature;
+				const Pair c0 = lp[64 * q0], c1 = lp[64 * (q0 + 1)], c2 = lp[64 * (q0 + 2)];
+				pcf[nb][0] = c0.a; pcf[nb][1] = c0.b; pcf[nb][2] = c1.a; pcf[nb][3] = c1.b; pcf[nb][4] = c2.a; pcf[nb][5] = c2.b;
+				if constexpr (LD::cin_slot(nb) >= 0) {
+					constexpr int cs = LD::cin_slot(nb);
+					for (int k = 0; k < 5; k++) {
+						const Pair c = lp[64 * (cs + k)];
+						pcb[nb][2 * k] = c.a;
+						pcb[nb][2 * k + 1] = c.b;
+					}
+				}
+			};
+			{
+				constexpr int lastb = [] { for (int c = NB - 1; c >= 1; c--) if (LD::needed(c)) return c; return 0; }();
+				if constexpr (lastb > 0) fetch_body(std::integral_constant<int, lastb>{});
+			}
 			sfor<NB - 1>([&](auto Bi) {
 				constexpr int b = NB - 1 - Bi;
 				constexpr int p = T::body_parentid[b], j = T::body_jnt[b];
 				if constexpr (LD::needed(b)) {
-					constexpr int q0 = LD::slot(b);
-					const Pair c0 = lp[64 * q0], c1 = lp[64 * (q0 + 1)], c2 = lp[64 * (q0 + 2)];
-					double cf[6] = { c0.a, c0.b, c1.a, c1.b, c2.a, c2.b };
+					touch_v(pcf[b][0]);
+					if constexpr (j >= 0) touch_s(parm[b]);
+					{
+						constexpr int nb = [] { for (int c = b - 1; c >= 1; c--) if (LD::needed(c)) return c; return 0; }();
+						if constexpr (nb > 0) fetch_body(std::integral_constant<int, nb>{});
+					}
+					double cf[6] = { pcf[b][0], pcf[b][1], pcf[b][2], pcf[b][3], pcf[b][4], pcf[b][5] };
 					// (children have larger ids: their sums are complete; cset is a compile-time fact after unrolling)
 					constexpr bool has_child = [] { for (int c = b + 1; c < NB; c++) if (T::body_parentid[c] == b && LD::needed(c)) return true; return false; }();
 					if constexpr (has_child) for (int k = 0; k < 6; k++) cf[k] += csum[b][k];
 					double cb[10];  // composite inertia of the body (mj_crb)
 					if constexpr (LD::cin_slot(b) >= 0) {
-						constexpr int c0 = LD::cin_slot(b);
-						for (int k = 0; k < 5; k++) {
-							const Pair c = lp[64 * (c0 + k)];
-							cb[2 * k] = c.a;
-							cb[2 * k + 1] = c.b;
-						}
+						for (int k = 0; k < 10; k++) cb[k] = pcb[b][k];
 					} else {
 						for (int k = 0; k < 10; k++) cb[k] = cin[b][k];
 					}
@@ -610,7 +661,7 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 						mul_inert_vec(buf, cb, cdof[j]);
 						sfor<NV>([&](auto A) {
 							constexpr int a = A;
-							if constexpr (Q::anc(a, j)) qM[j][a] = (a == j ? tb[b].armature : 0.0) + dot6r(cdof[a], buf);
+							if constexpr (Q::anc(a, j)) qM[j][a] = (a == j ? parm[b] : 0.0) + dot6r(cdof[a], buf);
 						});
 					}
 					if constexpr (p > 0 && LD::needed(p)) {
@@ -697,7 +748,7 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 				const double oa = pinv(o.a), ob = pinv(o.b), q0 = pins(tb[T::jnt_bodyid[I]].qpos0);
 				lp[64 * I] = Pair{ bada ? q0 : oa, bada ? 0.0 : ob };
 			});
-			sfor<NU>([&](auto I) { cn[I] = bada ? 0.0 : cn[I]; ctrl[I] = bada ? 0.0 : ctrl[I]; });
+			sfor<NU>([&](auto I) { cn[I] = bada ? 0.0 : cn[I]; });
 			time = bada ? 0.0 : time;
 			wasreset = wasreset || bada;
 		}

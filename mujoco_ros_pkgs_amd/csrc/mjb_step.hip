@@ -391,7 +391,7 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 		}
 	}
 	if constexpr (!REG) gsync<G>();
-#if !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL) && !defined(MJB_PROFILE_MK) && !defined(MJB_PROFILE_SM)  // (slots 20 - 23 carry the sub-stages of the Newton iteration's gradient step / of collision in those builds)
+#if !defined(MJB_PROFILE_SUB) && !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL) && !defined(MJB_PROFILE_MK) && !defined(MJB_PROFILE_SM)  // (slots 20 - 23 carry the sub-stages of the Newton iteration's gradient step / of collision / the PGS tail in those builds)
 	PROF(20);
 #endif
 
@@ -610,7 +610,7 @@ template <int G, bool SCAN, bool CACHE> STAGE void kinematics(CModel m, CLayout 
 		}
 	}
 	gsync<G>();
-#if !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL) && !defined(MJB_PROFILE_MK) && !defined(MJB_PROFILE_SM)
+#if !defined(MJB_PROFILE_SUB) && !defined(MJB_PROFILE_NWT) && !defined(MJB_PROFILE_COL) && !defined(MJB_PROFILE_MK) && !defined(MJB_PROFILE_SM)
 	PROF(23);
 #endif
 }

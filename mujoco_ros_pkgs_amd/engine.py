@@ -312,6 +312,8 @@ class Batch:
     def set(self, name, value, lo=0, hi=None):
         hi = self.nenv if hi is None else hi
         n = self.cm.field_size(name)
+        if n == 0:  # (a world without this field -- empty_world has no dof: nothing to write)
+            return
         v = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=np.float64).reshape(-1, n) if np.ndim(value) > 1
                                                  else np.asarray(value, dtype=np.float64), (hi - lo, n)))
         _check(self.lib.mjb_set(self.ptr, Field.ids[name], lo, hi, v.ctypes.data_as(C.POINTER(C.c_double))), "mjb_set")

@@ -41,6 +41,7 @@ binding.LIB_PATH = os.environ.get("MJB_PROF_LIB") or os.path.join(ROOT, "mujoco_
 if a.sub:
     STAGES[19] = "pgs.setup (B row, b, warmstart)"
     STAGES[21], STAGES[22] = "pgs.sweeps per step [count, not cycles]", "pgs.rows per step [count, not cycles]"
+    STAGES[20], STAGES[23] = "pgs.J' f (after the sweeps)", "pgs.M^-1 J' f + qacc stores"
     STAGES[30], STAGES[31] = "pgs.AR build", "pgs.warm residual + sweeps"
     STAGES[24:30] = ["col.cull+narrowphase", "col.offsets+params+stores", "mk.count+cut", "mk.row params (pass 2)", "mk.D + equality J",
                      "mk.contact J"]
