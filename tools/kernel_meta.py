@@ -20,3 +20,16 @@ for f in sorted(glob.glob(os.path.join(root, "mjb_step_g*.s"))):
 print(f"{'kernel <G,CON,DENSE>':24s} {'vgpr':>5s} {'vgpr spills':>11s} {'sgpr spills':>11s} {'private B':>9s}  slice")
 for con, g, dense, v, vs, ss, p, f in sorted(set(rows)):
     print(f"<{g},{con},{dense}>".ljust(24) + f" {v:5d} {vs:11d} {ss:11d} {p:9d}  {f}")
+# the lane = env kernels (csrc/mjb_lane_env.s): one per topology and LDS budget
+f = os.path.join(root, "mjb_lane_env.s")
+if os.path.exists(f):
+    print(f"{'lane = env <topology, LDS KB>':44s} {'vgpr':>5s} {'agpr':>5s} {'vgpr spills':>11s} {'sgpr spills':>11s} {'private B':>9s}")
+    txt = open(f).read()
+    for blk in re.split(r"\n  - \.agpr_count", txt)[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        mm = name and re.search(r"mjb_lane_env_kernelI\d+LeTopo_(\w+?)Li(\d+)E", name.group(1))
+        if not mm:
+            continue
+        get = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1))  # noqa: E731
+        agpr = int(re.match(r":\s+(\d+)", blk).group(1))
+        print(f"<{mm.group(1)}, {mm.group(2)}>".ljust(44) + f" {get('vgpr_count'):5d} {agpr:5d} {get('vgpr_spill_count'):11d} {get('sgpr_spill_count'):11d} {get('private_segment_fixed_size'):9d}")
