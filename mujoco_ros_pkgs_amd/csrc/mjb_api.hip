@@ -1780,7 +1780,7 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 	}
 	b->lane_env_used = use_le;
 	int rc;
-	if (use_le) rc = mjb_launch_lane_env(b->params_dev, b->model->le_topo, env_lo, env_hi, nsteps, b->step_counter, stream);
+	if (use_le) rc = mjb_launch_lane_env(b->params_dev, b->model->le_topo, b->nenv, env_lo, env_hi, nsteps, b->step_counter, stream);
 	else
 	rc = mjb_launch_step(b->params_dev, compact ? (b->wide ? b->model->Lw : b->model->Lc) : b->L, env_lo, env_hi, mode, nsteps, b->step_counter, b->lanes,
 	                         b->epb, variant | (chunk << 8), (b->lanes == 16 && !b->env_mass && mode != MJB_MODE_STEP21 && b->model->h.integrator == MJB_INT_EULER && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16 && b->model->h.nu <= 16 && b->model->h.njnt <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, stream);

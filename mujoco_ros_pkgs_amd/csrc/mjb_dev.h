@@ -259,7 +259,7 @@ int mjb_lane_env_match(const mjb_model_desc *h);
 size_t mjb_lane_env_tape_doubles(const mjb_model_desc *h);      // size of the constant tape
 void mjb_lane_env_tape(const mjb_model_desc *h, double *tape);  // fills it
 const char *mjb_lane_env_name(int topo);
-int mjb_launch_lane_env(const KernelParams *Pdev, int topo, int env_lo, int env_hi, int nsteps, unsigned int step0, void *stream);
+int mjb_launch_lane_env(const KernelParams *Pdev, int topo, int nenv_batch, int env_lo, int env_hi, int nsteps, unsigned int step0, void *stream);
 // sensors-plugin equivalent (mjb_sensor_pack.hip)
 int mjb_launch_sensor_pack(const KernelParams *Pdev, int nenv, int nsensor, const int *set_flag, const double *mean,
                            const double *sigma, unsigned long long seed, long long env_offset, unsigned int step,

@@ -321,6 +321,7 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 			for (int k = 0; k < 14; k++) hA[1][k] = reinterpret_cast<const double MJB_AS4 *>(tb + 1)[k];
 			// ... and the (qpos, qvel) pair of the next jointed body: LDS reads and scalar loads share one counter, so a read issued where
 			// it is needed would wait for the record fetched beside it
+			double qfa[NV > 0 ? NV : 1];  // qfrc_applied: fetched in the sweep's last region, read by the force block behind it
 			Pair pq[NB + 1];
 			{
 				constexpr int j1 = [] { for (int c = 1; c < NB; c++) if (T::body_jnt[c] >= 0) return T::body_jnt[c]; return -1; }();
@@ -536,6 +537,7 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 					lp[64 * (q0 + 2)] = Pair{ cf[4] + t1[4], cf[5] + t1[5] };
 				}
 				if constexpr (b + 1 < NB) touch_rec<14>(hA[b + 1]);
+				if constexpr (b == NB - 1) sfor<NV>([&](auto I) { qfa[I] = s.qfrc_applied[ev * NV + I]; });
 				__builtin_amdgcn_sched_barrier(0);
 				}
 			});
@@ -556,14 +558,13 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 				sfor<NV>([&](auto I) {
 					constexpr int j = I;
 					sq[j] = lp[64 * j];
-					const double qfa = pinv(s.qfrc_applied[ev * NV + j]);
 					const LeTapeBody MJB_AS4 &tj = tb[T::jnt_bodyid[j]];
 					double pas = 0;
 					if (pas_on) {
 						pas = -tj.stiffness * (sq[j].a - tj.spring);
 						pas -= tj.damping * sq[j].b;
 					}
-					f[j] = pas + (wasreset ? 0.0 : qfa);
+					f[j] = pas + (wasreset ? 0.0 : qfa[j]);
 				});
 				const bool act_on = !(m.disableflags & MJB_DSBL_ACTUATION);
 				const bool clamp_on = !(m.disableflags & MJB_DSBL_CLAMPCTRL);
@@ -890,7 +891,7 @@ const char *mjb_lane_env_name(int topo)
 	return "";
 }
 
-int mjb_launch_lane_env(const KernelParams *Pdev, int topo, int env_lo, int env_hi, int nsteps, unsigned int step0, void *stream)
+int mjb_launch_lane_env(const KernelParams *Pdev, int topo, int nenv_batch, int env_lo, int env_hi, int nsteps, unsigned int step0, void *stream)
 {
 	const int n = env_hi - env_lo;
 	if (n <= 0) return 0;
@@ -902,7 +903,10 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, int env_lo, int env_
 		return c;
 	}();
 	static const int forced = [] { const char *v = getenv("MJB_LANE_ENV_LDS_KB"); return v ? atoi(v) : 0; }();  // measurement knob: 40 / 80 / 160
-	const int waves = (int)grid.x;
+	// (from the BATCH's size, not the launch's env range: the instantiations differ in where data waits, and the compiler contracts a
+	//  few multiply-adds differently around that -- results agree to rounding, not bit for bit -- so every launch of one batch, whole or
+	//  a prefix / the rest of a split step, runs the same one)
+	const int waves = (nenv_batch + 63) / 64;
 	int lp = (ncu > 0 && waves <= ncu) ? 160 : ((ncu > 0 && waves <= 2 * ncu) ? 80 : 40);
 	if (forced == 40 || forced == 80 || forced == 160) lp = forced;
 #define MJB_LE_GO(T, LPV)                                                                                                                    \
