@@ -246,9 +246,12 @@ int mjb_fused_frame(const mjb_batch *b);
  * topology is compiled in, with no per-env model overrides / hwsim stage / xfrc_applied), 0 = never, 1 = whenever eligible.
  * The environment variable MJB_LANE_ENV (same values) sets the default of new batches.  No reference counterpart. */
 int mjb_set_lane_env(mjb_batch *b, int mode);
-/* Index of the compiled-in topology the batch's model matches, -1 if none (such a model always runs the generic kernels);
- * *used_last (may be NULL) = 1 when the last fused launch ran the lane = env kernel. */
+/* >= 0: index of the compiled-in topology the batch's model matches; -2: none compiled in, but the model's structure fits the kernel -- its
+ * first eligible launch builds the kernel for it through hiprtc (libhiprtc.so and csrc/mjb_lane_env_kernel.h next to libmjb.so; a few
+ * seconds, cached per process); -3: that build was not possible (mjb_lane_env_error says why) and the generic kernels run; -1: the model does not
+ * fit (constraint rows, free / ball joints, RK4, ...).  *used_last (may be NULL) = 1 when the last fused launch ran the lane = env kernel. */
 int mjb_lane_env_info(const mjb_batch *b, int *used_last);
+const char *mjb_lane_env_error(void);
 
 /* Stream control: the hipStream_t (as void*) kernels are launched on; default is a stream the
  * batch owns.  mjb_synchronize waits for it. */

@@ -94,7 +94,7 @@ struct mjb_model {
 	// take the two-rows-per-lane solver on LDS instead of the four-rows-per-lane one on the env's block in HBM (launch(), wide policy).
 	FrameLayout Lw{};
 	bool has_wide = false;
-	int le_topo = -1;  // compiled-in topology of the lane = env kernel the model matches (mjb_lane_env.hip), -1: none
+	int le_topo = -1;  // compiled-in topology of the lane = env kernel the model matches (mjb_lane_env.hip); -1: none; -2: eligible, built by hiprtc on first use
 	std::vector<double> le_tape;  // its constant tape (mjb_dev.h), empty without a topology
 };
 
@@ -156,6 +156,7 @@ struct mjb_batch {
 	size_t zfail = (size_t)-1;     // smallest total allocation (doubles) that failed: not retried
 	int lane_env_mode = -1;        // mjb_set_lane_env: -1 automatic, 0 never, 1 whenever eligible
 	bool lane_env_used = false;    // the last fused launch ran the lane = env kernel
+	bool le_unavailable = false;   // the model's topology had to be built by hiprtc and that failed (mjb_lane_env_jit_error): generic kernels from then on
 	int noise_mode = 0;            // how the last fused launch got its ctrl-noise normals: 0 in-kernel, 1 same-stream, 2 side-stream (mjb_noise_mode)
 	unsigned int *zinfo = nullptr; // two records (one per half of zbuf)
 	bool zvalid = false;           // a record names a launch: cleared (on the stream) before any step launch that does not use the buffer
@@ -1125,7 +1126,8 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		for (int i = 0; i < h.nv; i++)
 			if ((M->body_dofmask[2 * b + (i >> 5)] >> (i & 31)) & 1) M->dof_bodymask[2 * i + (b >> 5)] |= (int)(1u << (b & 31));
 	M->le_topo = mjb_lane_env_match(&h);
-	if (M->le_topo >= 0) {
+	if (M->le_topo < 0 && mjb_lane_env_eligible(&h)) M->le_topo = MJB_LE_TOPO_JIT;
+	if (M->le_topo != MJB_LE_TOPO_NONE) {
 		M->le_tape.assign(mjb_lane_env_tape_doubles(&h), 0.0);
 		mjb_lane_env_tape(&h, M->le_tape.data());
 	}
@@ -1773,15 +1775,21 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 	// The lane = env kernel (mjb_lane_env.hip) for fused launches of a model whose topology is compiled in: one env per lane, no frame.
 	// Per-env model overrides, the device hwsim stage, xfrc_applied and frame dumps keep the generic kernels.
 	bool use_le = false;
-	if (mode == MJB_MODE_STEP && compact && variant == 0 && b->model->le_topo >= 0 && b->lane_env_mode != 0 && b->hw.n == 0 && !b->env_mass &&
+	if (mode == MJB_MODE_STEP && compact && variant == 0 && b->model->le_topo != MJB_LE_TOPO_NONE && !b->le_unavailable && b->lane_env_mode != 0 && b->hw.n == 0 && !b->env_mass &&
 	    !b->env_gravity && !b->st.stats) {
 		static const int min_envs = [] { const char *v = getenv("MJB_LANE_ENV_MIN_ENVS"); return v ? atoi(v) : 4096; }();
 		use_le = b->lane_env_mode == 1 || (whole && b->nenv >= min_envs);
 	}
 	b->lane_env_used = use_le;
 	int rc;
-	if (use_le) rc = mjb_launch_lane_env(b->params_dev, b->model->le_topo, b->nenv, env_lo, env_hi, nsteps, b->step_counter, stream);
-	else
+	if (use_le) {
+		rc = mjb_launch_lane_env(b->params_dev, b->model->le_topo, &b->model->h, b->nenv, env_lo, env_hi, nsteps, b->step_counter, stream);
+		if (rc == MJB_LE_UNAVAILABLE) {  // (no hiprtc / no kernel header / compile error: remembered, the generic kernel runs -- mjb_lane_env_info says why)
+			b->le_unavailable = true;
+			b->lane_env_used = use_le = false;
+		}
+	}
+	if (!use_le)
 	rc = mjb_launch_step(b->params_dev, compact ? (b->wide ? b->model->Lw : b->model->Lc) : b->L, env_lo, env_hi, mode, nsteps, b->step_counter, b->lanes,
 	                         b->epb, variant | (chunk << 8), (b->lanes == 16 && !b->env_mass && mode != MJB_MODE_STEP21 && b->model->h.integrator == MJB_INT_EULER && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16 && b->model->h.nu <= 16 && b->model->h.njnt <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, stream);
 	if (rc != 0) return fail(MJB_ENODEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -2429,10 +2437,11 @@ int mjb_set_lane_env(mjb_batch *b, int mode)
 	b->lane_env_mode = mode;
 	return MJB_OK;
 }
+const char *mjb_lane_env_error(void) { return mjb_lane_env_jit_error(); }
 int mjb_lane_env_info(const mjb_batch *b, int *used_last)
 {
 	if (used_last) *used_last = b && b->lane_env_used ? 1 : 0;
-	return b ? b->model->le_topo : -1;
+	return b ? (b->le_unavailable ? -3 : b->model->le_topo) : -1;
 }
 int mjb_fused_frame(const mjb_batch *b) { return b && b->wide ? 2 : 1; }
 

@@ -259,7 +259,11 @@ int mjb_lane_env_match(const mjb_model_desc *h);
 size_t mjb_lane_env_tape_doubles(const mjb_model_desc *h);      // size of the constant tape
 void mjb_lane_env_tape(const mjb_model_desc *h, double *tape);  // fills it
 const char *mjb_lane_env_name(int topo);
-int mjb_launch_lane_env(const KernelParams *Pdev, int topo, int nenv_batch, int env_lo, int env_hi, int nsteps, unsigned int step0, void *stream);
+enum { MJB_LE_TOPO_NONE = -1, MJB_LE_TOPO_JIT = -2, MJB_LE_UNAVAILABLE = -1000 };
+int mjb_lane_env_eligible(const mjb_model_desc *h);   // the model's structure fits the kernel (compiled in or not)
+const char *mjb_lane_env_jit_error(void);              // why the last hiprtc build of a topology was not available ("" if none failed)
+int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc *h, int nenv_batch, int env_lo, int env_hi, int nsteps, unsigned int step0,
+                        void *stream);
 // sensors-plugin equivalent (mjb_sensor_pack.hip)
 int mjb_launch_sensor_pack(const KernelParams *Pdev, int nenv, int nsensor, const int *set_flag, const double *mean,
                            const double *sigma, unsigned long long seed, long long env_offset, unsigned int step,

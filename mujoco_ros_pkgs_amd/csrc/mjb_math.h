@@ -3,7 +3,9 @@
 // 10-vector inertias (Ixx Iyy Izz Ixy Ixz Iyz mx my mz m).
 #pragma once
 
+#ifndef __HIPCC_RTC__  // (hiprtc brings its own runtime header)
 #include <hip/hip_runtime.h>
+#endif
 
 #define DEVI static __device__ __forceinline__
 #define MJB_MINVAL 1e-15

@@ -291,6 +291,10 @@ class Batch:
         topo = int(self.lib.mjb_lane_env_info(self.ptr, C.byref(used)))
         return topo, bool(used.value)
 
+    def lane_env_error(self):
+        """Why the hiprtc build of this process's last lane = env topology was not available ('' if none failed)."""
+        return self.lib.mjb_lane_env_error().decode()
+
     def time_steps(self, nsteps, nlaunch):
         ms = C.c_double(0)
         _check(self.lib.mjb_time_steps(self.ptr, int(nsteps), int(nlaunch), C.byref(ms)), "mjb_time_steps")

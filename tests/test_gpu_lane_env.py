@@ -225,3 +225,100 @@ def test_lean_lds_variant_at_full_occupancy(eng):
     _close(small.get("qpos"), q[lo:lo + 256], 1e-12, "160 KB vs 40 KB instantiation, qpos")
     _close(small.get("qvel"), v[lo:lo + 256], 1e-12, "160 KB vs 40 KB instantiation, qvel")
     small.close()
+
+
+JIT_ARM = """
+<mujoco model="jit_arm">
+  <compiler angle="radian"/>
+  <option timestep="0.002" gravity="0 0 -9.81" integrator="Euler"><flag contact="disable"/></option>
+  <default><joint armature="0.05" damping="1.5"/></default>
+  <worldbody>
+    <body name="b1" pos="0 0 0.3">
+      <inertial pos="0 0 0.1" mass="2.0" diaginertia="0.02 0.02 0.01"/>
+      <joint name="j1" type="hinge" axis="0 0 1"/>
+      <body name="b2" pos="0 0 0.25" quat="0.9 0.1 0.4 0.1">
+        <inertial pos="0.1 0 0" quat="0.8 0.2 0.5 0.1" mass="1.2" diaginertia="0.01 0.012 0.006"/>
+        <joint name="j2" type="hinge" axis="0 1 0" pos="0 0.01 -0.02" stiffness="5" springref="0.3"/>
+        <body name="b3" pos="0.3 0 0">
+          <inertial pos="0.1 0 0" mass="0.8" diaginertia="0.004 0.006 0.006"/>
+          <joint name="j3" type="hinge" axis="0 1 0"/>
+          <body name="b4" pos="0.25 0 0">
+            <inertial pos="0.05 0 0" mass="0.3" diaginertia="0.001 0.001 0.001"/>
+            <joint name="j4" type="slide" axis="1 0 0" stiffness="80" damping="6"/>
+            <site name="tool" pos="0.1 0 0" quat="0.7071067811865476 0 0.7071067811865476 0"/>
+          </body>
+          <body name="b5" pos="0.1 0.1 0">
+            <inertial pos="0 0.05 0" mass="0.2" diaginertia="0.0006 0.0004 0.0006"/>
+            <joint name="j5" type="hinge" axis="1 0 0"/>
+          </body>
+        </body>
+      </body>
+    </body>
+  </worldbody>
+  <actuator>
+    <motor joint="j1" ctrllimited="true" ctrlrange="-5 5"/>
+    <position joint="j2" kp="60"/>
+    <motor joint="j3" gear="2"/>
+    <motor joint="j4" forcelimited="true" forcerange="-3 3"/>
+  </actuator>
+  <sensor>
+    <jointpos joint="j5"/>
+    <framepos objtype="site" objname="tool"/>
+    <framequat objtype="site" objname="tool"/>
+    <actuatorfrc actuator="3"/>
+    <clock/>
+  </sensor>
+</mujoco>
+"""
+
+
+def test_topology_built_by_hiprtc(eng):
+    """A model whose structure is NOT among the compiled-in topologies: its first eligible launch builds the kernel for it through hiprtc
+    (mjb_lane_env_info: -2), and the result meets the same bars -- one step vs the oracle, a noise rollout, the reset paths vs the generic kernel."""
+    engine, mjcf, po = eng
+    xml = JIT_ARM.replace('actuator="3"', 'actuator="' + "act3" + '"').replace('<motor joint="j4" forcelimited', '<motor name="act3" joint="j4" forcelimited')
+    model = mjcf.compile_xml_string(xml)
+    model["enableflags"] = int(model["enableflags"]) | 2
+    cm = engine.CompiledModel(model)
+    nenv = 100
+    rng = np.random.default_rng(8)
+    qpos = np.tile(np.asarray(model["qpos0"], dtype=np.float64), (nenv, 1)) + rng.uniform(-0.7, 0.7, (nenv, model["nq"])) * np.where(np.asarray(model["jnt_type"]) == 3, 1.0, 0.05)
+    qvel = rng.uniform(-1, 1, (nenv, model["nv"]))
+    ctrl = rng.uniform(-2, 2, (nenv, model["nu"]))
+    b = make(engine, cm, nenv, qpos, qvel, 1, ctrl)
+    assert b.lane_env_info()[0] == -2
+    b.step(1)
+    topo, used = b.lane_env_info()
+    if topo == -3:
+        pytest.fail("hiprtc build of the lane = env kernel not available on this box: " + b.lane_env_error())
+    assert used
+    out = {f: b.get(f) for f in ("qpos", "qvel", "qacc", "sensordata", "energy")}
+    b.close()
+    d = po.OracleData(model)
+    for e in range(nenv):
+        d.reset()
+        d.qpos[:] = qpos[e]
+        d.qvel[:] = qvel[e]
+        d.ctrl[:] = ctrl[e]
+        d.step(1)
+        for f in out:
+            _close(out[f][e], d.field(f), 1e-11, f"jit arm {f} env {e}")
+    # noise rollout (pre-generated normals) and resets
+    b = make(engine, cm, nenv, qpos, qvel, 1)
+    b.set_ctrl_noise(1.5, 0.1, 31, 500)
+    b.step(150)
+    oq, ov, osd = po.rollout(model, qpos, qvel, 150, noise_std=1.5, noise_rate=0.1, seed=31, env_offset=500, nthreads=8)
+    _close(b.get("qpos"), oq, 1e-9, "jit arm qpos after 150 steps")
+    _close(b.get("sensordata"), osd, 1e-9, "jit arm sensordata after 150 steps")
+    b.close()
+    qb, vb = qpos.copy(), qvel.copy()
+    qb[3, 1] = np.nan
+    vb[70, 2] = 2e11
+    res = {}
+    for mode in (1, 0):
+        b = make(engine, cm, nenv, qb, vb, mode, ctrl)
+        b.step(4)
+        res[mode] = (b.get("qpos"), b.get("qvel"), [b.warning(w) for w in range(8)])
+        b.close()
+    assert res[1][2] == res[0][2] and res[1][2][4] == 1 and res[1][2][5] == 1
+    _close(res[1][0], res[0][0], 1e-9, "jit arm, state after resets vs the generic kernel")
