@@ -322,7 +322,9 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 {
 	const int n = env_hi - env_lo;
 	if (n <= 0) return 0;
-	const dim3 grid((unsigned int)((n + 63) / 64)), block(64);
+	// (measurement knob: envs per wavefront < 64 -- the wavefront starts with its upper lanes off)
+	static const int wl = [] { const char *v = getenv("MJB_LANE_ENV_WAVE_LANES"); const int k = v ? atoi(v) : 64; return (k == 16 || k == 32) ? k : 64; }();
+	const dim3 grid((unsigned int)((n + wl - 1) / wl)), block(wl);
 	// LDS budget per wavefront from the CUs the launch leaves idle: one wavefront per CU may take all of its LDS
 	static const int ncu = [] {
 		int dev = 0, c = 0;
@@ -347,7 +349,7 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 		int a_nsteps = nsteps, a_lo = env_lo, a_hi = env_hi;
 		unsigned int a_step0 = step0;
 		void *args[] = { (void *)&Pd, (void *)&a_nsteps, (void *)&a_step0, (void *)&a_lo, (void *)&a_hi };
-		return (int)hipModuleLaunchKernel(k.fn, grid.x, 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args, nullptr);
+		return (int)hipModuleLaunchKernel(k.fn, grid.x, 1, 1, block.x, 1, 1, 0, (hipStream_t)stream, args, nullptr);
 	}
 #define MJB_LE_GO(T, LPV)                                                                                                                    \
 	{                                                                                                                                         \

@@ -186,7 +186,7 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 	Pair *const lp = reinterpret_cast<Pair *>(smem_le) + threadIdx.x;  // pair slot q of this lane: lp[64 * q]
 	// (a tail lane without an env keeps running on the last env's data and stores nothing: no divergent exit, the wave-uniform
 	//  branches below stay uniform)
-	const int env_raw = env_lo + (int)(blockIdx.x * 64 + threadIdx.x);
+	const int env_raw = env_lo + (int)(blockIdx.x * blockDim.x + threadIdx.x);  // (blockDim.x = 64; fewer: a measurement knob, MJB_LANE_ENV_WAVE_LANES)
 	const bool live = env_raw < env_hi;
 	const int env = live ? env_raw : env_hi - 1;
 	const size_t ev = (size_t)env;

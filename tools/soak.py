@@ -17,8 +17,8 @@ from mujoco_ros_pkgs_amd import engine, mjcf  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--launches", type=int, default=50)
 args = ap.parse_args()
-CASES = [("franka_like", {}, 4096, 1000, 43.5), ("franka_table", {}, 4096, 200, 43.5),
-         ("franka_table", {"solver": "Newton"}, 4096, 200, 43.5), ("shadow_hand_like", {}, 1024, 100, 1.0)]
+CASES = [("franka_like", {}, 4096, 1000, 43.5), ("franka_like", {}, 65536, 250, 43.5), ("franka_table", {}, 4096, 200, 43.5),
+         ("franka_table", {"solver": "Newton"}, 4096, 200, 43.5), ("shadow_hand_like", {}, 1024, 100, 1.0), ("shadow_hand_grasp", {}, 1024, 100, 1.0)]
 for name, over, nenv, K, std in CASES:
     model = mjcf.load_asset(name) if not over else mjcf.compile_xml_file(os.path.join(mjcf.ASSET_DIR, name + ".xml"), override=over)
     noise = bench.WORKLOADS.get(name, (name, std, nenv))[1]
@@ -37,6 +37,6 @@ for name, over, nenv, K, std in CASES:
     out = {"model": name, "override": over, "envs": nenv, "steps_per_env": K * args.launches,
            "env_steps": nenv * K * args.launches, "env_steps_per_s": nenv * K * args.launches / dt,
            "auto_resets": b.warning_count(), "finite": bool(np.isfinite(q).all() and np.isfinite(v).all()),
-           "max_abs_qvel": float(np.abs(v).max()), "sim_time_s": float(b.get("time")[0, 0])}
+           "max_abs_qvel": float(np.abs(v).max()), "sim_time_s": float(b.get("time")[0, 0]), "lane_env_kernel": b.lane_env_info()[1]}
     print(json.dumps(out))
     b.close()
