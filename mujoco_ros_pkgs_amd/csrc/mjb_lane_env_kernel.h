@@ -58,17 +58,17 @@ DEVI double frsq(double x)
 	return y;
 }
 
-// mju_normalize4: identity for a vanishing quaternion, untouched within mjMINVAL of unit length
+// mju_normalize4 of a body's world quaternion: untouched within mjMINVAL of unit length.  (Its identity case for a vanishing quaternion cannot
+// occur here: the argument is a product of the model's unit quaternions and of (cos, axis sin) hinge quaternions.)
 DEVI void normalize4_sel(double *q)
 {
 	const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
-	const bool tiny = n2 < MJB_MINVAL * MJB_MINVAL;
-	const double r = frsq(tiny ? 1.0 : n2), n = n2 * r;
+	const double r = frsq(n2), n = n2 * r;
 	const double s = (fabs(n - 1) > MJB_MINVAL) ? r : 1.0;
-	q[0] = tiny ? 1.0 : q[0] * s;
-	q[1] = tiny ? 0.0 : q[1] * s;
-	q[2] = tiny ? 0.0 : q[2] * s;
-	q[3] = tiny ? 0.0 : q[3] * s;
+	q[0] *= s;
+	q[1] *= s;
+	q[2] *= s;
+	q[3] *= s;
 }
 
 // A loaded value the optimiser must treat as already there: `cond ? k : load` otherwise becomes a per-lane branch around the load.
@@ -101,7 +101,7 @@ DEVI double clampd(double c, double lo, double hi)
 	return c != c ? c : v;
 }
 
-DEVI bool bad_val(double x) { return !(x == x) || fabs(x) > MJB_MAXVAL; }
+DEVI bool bad_val(double x) { return !(fabs(x) <= MJB_MAXVAL); }  // NaN or beyond mjMAXVAL: one unordered compare
 
 // sin and cos of a joint half-angle, branch-free: k = round(x * 2/pi), r = x - k * pi/2 through three fma steps (pi/2 split into
 // 53-bit pieces: exact to rounding while |x| < ~1e6 rad; beyond, the absolute error grows like |x| * 2^-53 * k-independent terms --
@@ -194,10 +194,16 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 	// ---- the env's state: (qpos, qvel) in LDS, the OU noise state in registers
 	double cn[NU > 0 ? NU : 1];
 	double time;
+	bool badp_next = false, badv_next = false;  // mj_checkPos / mj_checkVel verdict on the state the next step starts from
 	bool wasreset = false;  // mj_resetData ran inside this launch: ctrl / qfrc_applied read as zero from then on (the frame copy of the generic kernels)
 	{
 		const DevState MJB_AS4 &s = P->s;
-		sfor<NV>([&](auto I) { lp[64 * I] = Pair{ s.qpos[ev * NV + I], s.qvel[ev * NV + I] }; });
+		sfor<NV>([&](auto I) {
+			const Pair s2{ s.qpos[ev * NV + I], s.qvel[ev * NV + I] };
+			lp[64 * I] = s2;
+			badp_next |= bad_val(s2.a);
+			badv_next |= bad_val(s2.b);
+		});
 		sfor<NU>([&](auto I) { cn[I] = s.ctrlnoise[ev * NU + I]; });
 		time = s.time[ev];
 	}
@@ -248,8 +254,8 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 
 		// ---- mj_checkPos / mj_checkVel (qpos first: its reset hides a bad qvel)
 		{
-			bool badp = false, badv = false;
-			sfor<NV>([&](auto I) { const Pair qv = lp[64 * I]; badp |= bad_val(qv.a); badv |= bad_val(qv.b); });
+			// (the flags were computed where the state was last in registers: at the load, and in the previous step's mj_Euler)
+			const bool badp = badp_next, badv = badv_next;
 			// (NO per-lane branch anywhere in this kernel: with ~200 live doubles the register allocator spills around every join, and
 			//  ROCm 7.2's LLVM places such spills ahead of the exec restore -- the parked lanes lose them, tools/check_spill_exec.py.
 			//  A reset is a handful of selects under a wave-uniform test; every lane issues the counter's atomic, with 0 or 1.)
@@ -753,11 +759,14 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 			}
 		}
 		// ================= A16 mj_Euler =================
+		badp_next = badv_next = false;
 		sfor<NV>([&](auto I) {
 			Pair s2 = lp[64 * I];
 			s2.b += dt * qaccd[I];
 			s2.a += dt * s2.b;
 			lp[64 * I] = s2;
+			badp_next |= bad_val(s2.a);  // the next step's mj_checkPos / mj_checkVel
+			badv_next |= bad_val(s2.b);
 		});
 		time += dt;
 	}
