@@ -242,7 +242,8 @@ int mjb_fused_frame(const mjb_batch *b);
  * wavefront's registers, compiled per model topology (csrc/lane_env_topos.h).  Same step (mj_step, mujoco_env.cpp:498,552,593),
  * results equal to the generic kernels' to rounding (not bit for bit: a batch that mixes fused launches with split steps
  * should pin one form); measured on MI355X it is ahead of the 16-lanes-per-env kernel from 4096 envs (276 vs 227 M env-steps/s) and 12x
- * ahead at 65 536.  mode: -1 = automatic (whole-batch fused launches of >= MJB_LANE_ENV_MIN_ENVS envs, default 4096, of a model whose
+ * ahead at 65 536.  mode: -1 = automatic (fused launches over >= MJB_LANE_ENV_MIN_ENVS envs, default 4096 -- the whole batch, or the non-callback envs of a
+ * split step, mjb_step_rest -- of a model whose
  * topology is compiled in, with no per-env model overrides / hwsim stage / xfrc_applied), 0 = never, 1 = whenever eligible.
  * The environment variable MJB_LANE_ENV (same values) sets the default of new batches.  No reference counterpart. */
 int mjb_set_lane_env(mjb_batch *b, int mode);

@@ -1778,7 +1778,7 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 	if (mode == MJB_MODE_STEP && compact && variant == 0 && b->model->le_topo != MJB_LE_TOPO_NONE && !b->le_unavailable && b->lane_env_mode != 0 && b->hw.n == 0 && !b->env_mass &&
 	    !b->env_gravity && !b->st.stats) {
 		static const int min_envs = [] { const char *v = getenv("MJB_LANE_ENV_MIN_ENVS"); return v ? atoi(v) : 4096; }();
-		use_le = b->lane_env_mode == 1 || (whole && b->nenv >= min_envs);
+		use_le = b->lane_env_mode == 1 || env_hi - env_lo >= min_envs;  // (also the fused launch of a split step's non-callback envs, mjb_step_rest)
 	}
 	b->lane_env_used = use_le;
 	int rc;
