@@ -340,6 +340,20 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 	if (forced == 40 || forced == 80 || forced == 160) lp = forced;
 	if (topo == MJB_LE_TOPO_JIT) {
 		if (!h) return (int)hipErrorInvalidValue;
+		{  // a larger model than the compiled-in ones: the smallest LDS budget its (qpos, qvel) pairs and body forces fit (fewer wavefronts per CU then)
+			int need = h->nv;
+			for (int b = 1; b < h->nbody; b++) {
+				bool moves = false;
+				for (int a = b; a > 0; a = h->body_parentid[a]) moves = moves || h->body_jntnum[a] > 0;
+				if (moves) need += 3;
+			}
+			const int fit = need <= 40 ? 40 : (need <= 80 ? 80 : 160);
+			if (need > 160) {
+				jit_last_error = "the model needs more than 160 KB of LDS per wavefront";
+				return MJB_LE_UNAVAILABLE;
+			}
+			if (fit > lp) lp = fit;
+		}
 		const JitKernel &k = jit_get(*h, lp);
 		if (!k.fn) {
 			jit_last_error = k.error;

@@ -182,7 +182,7 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 	constexpr int NB = T::NBODY, NV = T::NV, NU = T::NU;
 	using Q = Tq<T>;
 	using LD = Lds<T, LP>;
-	static_assert(LD::slot(T::NBODY) <= 40, "lane = env kernel: state and forces of the topology need more LDS than a quarter of a CU's");
+	static_assert(LD::slot(T::NBODY) <= LP, "lane = env kernel: state and forces of the topology need more LDS than this instantiation's budget");
 	Pair *const lp = reinterpret_cast<Pair *>(smem_le) + threadIdx.x;  // pair slot q of this lane: lp[64 * q]
 	// (a tail lane without an env keeps running on the last env's data and stores nothing: no divergent exit, the wave-uniform
 	//  branches below stay uniform)

@@ -322,3 +322,45 @@ def test_topology_built_by_hiprtc(eng):
         b.close()
     assert res[1][2] == res[0][2] and res[1][2][4] == 1 and res[1][2][5] == 1
     _close(res[1][0], res[0][0], 1e-9, "jit arm, state after resets vs the generic kernel")
+
+
+def two_arm_xml(n=7):
+    """Two n-link hinge chains on one base: 2 n dofs, 2 n + 1 bodies -- more state than 40 KB of LDS per wavefront holds."""
+    def chain(tag, y):
+        out, close = "", ""
+        for i in range(n):
+            ax = ("0 0 1", "0 1 0", "1 0 0")[i % 3]
+            out += f'<body name="{tag}{i}" pos="{0.0 if i else 0.1} {y if i == 0 else 0} {0.12 if i else 0.3}" quat="0.96 0.1 0.2 {0.05 * (i % 2)}">'
+            out += f'<inertial pos="0.02 0 0.06" mass="{1.5 - 0.15 * i}" diaginertia="0.004 0.005 0.003"/><joint name="{tag}j{i}" type="hinge" axis="{ax}" damping="0.7" armature="0.02"/>'
+            close += "</body>"
+        return out + close
+    act = "".join(f'<motor joint="{t}j{i}" ctrllimited="true" ctrlrange="-3 3"/>' for t in "LR" for i in range(n))
+    return ('<mujoco model="two_arm"><compiler angle="radian"/><option timestep="0.002" integrator="Euler"><flag contact="disable"/></option><worldbody>'
+            '<body name="base" pos="0 0 0.2"><inertial pos="0 0 0" mass="5" diaginertia="0.1 0.1 0.1"/>' + chain("L", 0.2) + chain("R", -0.2) +
+            '</body></worldbody><actuator>' + act + '</actuator><sensor><jointpos joint="Lj3"/><jointvel joint="Rj6"/></sensor></mujoco>')
+
+
+def test_hiprtc_topology_beyond_the_lean_lds_budget(eng):
+    """A 14-dof two-arm model built by hiprtc: its (qpos, qvel) pairs and body forces need 56 KB of LDS per wavefront, so even a batch that would get 40 KB
+    per wavefront (> 32768 envs) runs the 80 KB instantiation.  Sampled envs against the oracle at both ends of the batch-size range."""
+    engine, mjcf, po = eng
+    model = mjcf.compile_xml_string(two_arm_xml())
+    assert model["nv"] == 14 and model["nbody"] == 16
+    cm = engine.CompiledModel(model)
+    for nenv, K in ((200, 60), (33000, 20)):
+        rng = np.random.default_rng(3)
+        qpos = rng.uniform(-0.8, 0.8, (nenv, model["nq"]))
+        qvel = rng.uniform(-1, 1, (nenv, model["nv"]))
+        b = make(engine, cm, nenv, qpos, qvel, 1)
+        assert b.lane_env_info()[0] == -2
+        b.set_ctrl_noise(1.0, 0.1, 17, 0)
+        b.step(K)
+        topo, used = b.lane_env_info()
+        assert used, f"lane = env kernel not used (info {topo}): {b.lane_env_error()}"
+        q, v = b.get("qpos"), b.get("qvel")
+        b.close()
+        assert np.all(np.isfinite(q))
+        for e in (0, nenv // 2, nenv - 1):
+            oq, ov, _ = po.rollout(model, qpos[e:e + 1], qvel[e:e + 1], K, noise_std=1.0, noise_rate=0.1, seed=17, env_offset=int(e))
+            _close(q[e], oq[0], 1e-9, f"two-arm env {e} of {nenv} qpos")
+            _close(v[e], ov[0], 1e-9, f"two-arm env {e} of {nenv} qvel")

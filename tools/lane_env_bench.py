@@ -15,21 +15,31 @@ from tests.conftest import random_franka_state  # noqa: E402
 
 
 def main():
-    K = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    sizes = [int(a) for a in sys.argv[2:]] or [4096, 16384, 65536, 262144]
-    model = mjcf.load_asset("franka_like")
+    argv = [a for a in sys.argv[1:] if a != "--two-arm"]
+    K = int(argv[0]) if argv else 200
+    sizes = [int(a) for a in argv[1:]] or [4096, 16384, 65536, 262144]
+    if "--two-arm" in sys.argv:  # a 14-dof model that is NOT compiled in: the kernel is built for it by hiprtc at the first launch
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+        from test_gpu_lane_env import two_arm_xml
+        model = mjcf.compile_xml_string(two_arm_xml())
+    else:
+        model = mjcf.load_asset("franka_like")
     model["enableflags"] = int(model["enableflags"]) | 2
     cm = engine.CompiledModel(model)
     rows = []
     for nenv in sizes:
-        qpos, qvel = random_franka_state(model, nenv, 0)
+        if "--two-arm" in sys.argv:
+            rng = np.random.default_rng(0)
+            qpos, qvel = rng.uniform(-0.8, 0.8, (nenv, model["nq"])), rng.uniform(-0.5, 0.5, (nenv, model["nv"]))
+        else:
+            qpos, qvel = random_franka_state(model, nenv, 0)
         row = {"envs": nenv, "steps_per_launch": K}
         for mode, tag in ((0, "lanes16"), (1, "lane_env")):
             b = engine.Batch(cm, nenv)
             b.set_lane_env(mode)
             b.set("qpos", qpos)
             b.set("qvel", qvel)
-            b.set_ctrl_noise(43.5, 0.1, 12345, 0)
+            b.set_ctrl_noise(1.5 if "--two-arm" in sys.argv else 43.5, 0.1, 12345, 0)
             b.step(K)  # warm-up (also allocates the noise buffer)
             b.synchronize()
             ms = b.time_steps(K, 3)
