@@ -2105,6 +2105,13 @@ template <int G, int TAG> __device__ __attribute__((noinline)) void fwd_constrai
 // ------------------------------------------------------------------------------------------------
 // A13 constraint solve: warmstart + projected Gauss-Seidel (dual), one env per wavefront
 // ------------------------------------------------------------------------------------------------
+// MJB_PGS_PRESOLVE (round 5): nv <= 16 -- the stage ends at qfrc_constraint = J' f; the CALLER (forward_rest) then gets
+// qacc = qacc_smooth + M^-1 J' f and Euler's (M + h B)^-1 (qfrc_smooth + qfrc_constraint) from ONE two-right-hand-side run of the
+// DPP-row substitution on lanes 0 - 15 (solve_dense16, dual) in place of this stage's register substitution over the dense triangle
+// (9.1 k cycles per step on config 3) plus Euler's own solve (~5 k).
+#ifndef MJB_PGS_PRESOLVE
+#define MJB_PGS_PRESOLVE 1
+#endif
 template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CModel m, CLayout L, CState s, const EnvLite &e)
 {
 	static_assert(G == 64, "the constraint solver maps rows to the 64 lanes of one wavefront");
@@ -2367,7 +2374,7 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 #ifdef MJB_PROFILE_SUB
 	EPROF(20);
 #endif
-	if constexpr (REGB) {
+	if constexpr (REGB && !MJB_PGS_PRESOLVE) {
 		// M^-1 (J' f) by the same dense substitution, the whole nv-vector in the registers of every lane (wave-uniform
 		// addresses: one LDS broadcast per entry; lane k keeps element k)
 		double w[16];

@@ -2447,13 +2447,15 @@ template <int G> STAGE void fwd_constraint(CModel m, CLayout L, const Env &e)
 // ------------------------------------------------------------------------------------------------
 // A16 semi-implicit Euler with implicit joint damping
 // ------------------------------------------------------------------------------------------------
-template <int G, bool CAN16, bool TRI32 = false, bool JC = false> STAGE void euler(CModel m, CLayout L, const Env &e)
+template <int G, bool CAN16, bool TRI32 = false, bool JC = false, bool PRE = false> STAGE void euler(CModel m, CLayout L, const Env &e)
 {
 	double *f = e.f;
 	const double dt = m.timestep[0];
 	double *x = f + L.eulerx;
 	if (m.eulerdamp && m.nefcmax == 0) {
 		// (M + h B) x = qfrc_smooth was already solved next to qacc_smooth (fwd_acceleration, dual solve)
+	} else if (PRE && m.eulerdamp && m.nv <= 16) {
+		// ... or next to qacc, behind the PGS stage (forward_rest, MJB_PGS_PRESOLVE)
 	} else if (m.eulerdamp) {
 		// (M + h B) x = qfrc_smooth + qfrc_constraint, factor qH prepared next to qLD in fwd_position
 		for (int d = e.lane; d < m.nv; d += G) x[d] = f[L.qfrc_smooth + d] + f[L.qfrc_constraint + d];
@@ -2806,8 +2808,33 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 		if constexpr (CON == 5) {  // elliptic cone blocks: rows of B in LDS (the block code leaves no registers for them)
 			VIEW(P, compact, fwd_constraint_pgs<G, true, false, CON>(m, L, s, e));
 		} else {
-			if (P->m.nv <= 16) VIEW(P, compact, fwd_constraint_pgs<G, false, true, CON>(m, L, s, e));
-			else VIEW(P, compact, fwd_constraint_pgs_ldsB<G, false, CON>(m, L, s, e));
+			if (P->m.nv <= 16) {
+				VIEW(P, compact, fwd_constraint_pgs<G, false, true, CON>(m, L, s, e));
+				if constexpr (MJB_PGS_PRESOLVE) {
+					// qacc = qacc_smooth + M^-1 qfrc_constraint, and -- under implicit joint damping -- Euler's (M + h B)^-1 (qfrc_smooth + qfrc_constraint)
+					// beside it: one dual substitution (both factors were built together in fwd_position); Euler finds its vector solved
+					VIEW(P, compact, {
+						double *f = e.f;
+						const bool damp = m.eulerdamp != 0;
+						if (e.lane < m.nv) {
+							const double c = f[L.qfrc_constraint + e.lane];
+							f[L.qacc + e.lane] = c;
+							f[L.eulerx + e.lane] = f[L.qfrc_smooth + e.lane] + c;
+						}
+						gsync<G>();
+						int dl[16];
+						dadr_load(e, L, dl);
+						solve_dense16<G, 16>(m, e, f + L.qacc, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, damp, dl, f + L.solvescr);
+						if (e.lane < m.nv) {
+							const double a = f[L.qacc_smooth + e.lane] + f[L.qacc + e.lane];
+							f[L.qacc + e.lane] = a;
+							f[L.qacc_warmstart + e.lane] = a;
+						}
+						gsync<G>();
+					});
+				}
+			} else
+				VIEW(P, compact, fwd_constraint_pgs_ldsB<G, false, CON>(m, L, s, e));
 		}
 	} else {
 		VIEW(P, compact, fwd_constraint<G>(m, L, e));
@@ -3425,7 +3452,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 			}
 			}
 			PROF(14);  // whole forward (incl. checks)
-			if (do_euler && !rk4) VIEW(P, compact, euler<G, (CON != 0), (CON >= 2 && CON <= 4), (DENSE != 0)>(m, L, e));
+			if (do_euler && !rk4) VIEW(P, compact, euler<G, (CON != 0), (CON >= 2 && CON <= 4), (DENSE != 0), (MJB_PGS_PRESOLVE && (CON == 1 || CON == 9))>(m, L, e));
 			PROF(15);
 		}
 
