@@ -252,6 +252,8 @@ int mjb_set_lane_env(mjb_batch *b, int mode);
  * seconds, cached per process); -3: that build was not possible (mjb_lane_env_error says why) and the generic kernels run; -1: the model does not
  * fit (constraint rows, free / ball joints, RK4, ...).  *used_last (may be NULL) = 1 when the last fused launch ran the lane = env kernel. */
 int mjb_lane_env_info(const mjb_batch *b, int *used_last);
+/* The same classification for a compiled model, without a batch or a device (>= 0 / -2 / -1 as above). */
+int mjb_model_lane_env(const mjb_model *m);
 const char *mjb_lane_env_error(void);
 
 /* Stream control: the hipStream_t (as void*) kernels are launched on; default is a stream the

@@ -2438,6 +2438,7 @@ int mjb_set_lane_env(mjb_batch *b, int mode)
 	return MJB_OK;
 }
 const char *mjb_lane_env_error(void) { return mjb_lane_env_jit_error(); }
+int mjb_model_lane_env(const mjb_model *m) { return m ? m->le_topo : -1; }
 int mjb_lane_env_info(const mjb_batch *b, int *used_last)
 {
 	if (used_last) *used_last = b && b->lane_env_used ? 1 : 0;

@@ -337,7 +337,7 @@ def two_arm_xml(n=7):
     act = "".join(f'<motor joint="{t}j{i}" ctrllimited="true" ctrlrange="-3 3"/>' for t in "LR" for i in range(n))
     return ('<mujoco model="two_arm"><compiler angle="radian"/><option timestep="0.002" integrator="Euler"><flag contact="disable"/></option><worldbody>'
             '<body name="base" pos="0 0 0.2"><inertial pos="0 0 0" mass="5" diaginertia="0.1 0.1 0.1"/>' + chain("L", 0.2) + chain("R", -0.2) +
-            '</body></worldbody><actuator>' + act + '</actuator><sensor><jointpos joint="Lj3"/><jointvel joint="Rj6"/></sensor></mujoco>')
+            '</body></worldbody><actuator>' + act + f'</actuator><sensor><jointpos joint="Lj{n // 2}"/><jointvel joint="Rj{n - 1}"/></sensor></mujoco>')
 
 
 def test_hiprtc_topology_beyond_the_lean_lds_budget(eng):
