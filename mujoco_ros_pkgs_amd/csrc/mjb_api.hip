@@ -320,7 +320,8 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact, int jrows_req = 
 	L.nwt_M = off;
 	off += (newton && d.nv > 32) ? d.nv * d.nv : 0;  // (nv <= 32: the solver keeps row `lane` of M in registers, host table M_sym)
 	L.nwt_H = off;
-	off += newton ? d.nv * d.nv : 0;
+	// (nv <= 32: the packed lower triangle + one dump slot, mjb_constraint.h MJB_HPACK; 16 < nv: at least chol_schur16's 16 x 17 scratch)
+	off += newton ? (d.nv <= 32 ? std::max(d.nv * (d.nv + 1) / 2 + 1, d.nv > 16 ? 272 : 0) : d.nv * d.nv) : 0;
 	L.nwt_vec = off;
 	off += newton ? 5 * d.nv : 0;  // qacc | M qacc | grad | search | (CG: M^-1 grad)
 	L.nwt_row = off;
@@ -565,8 +566,14 @@ void choose_fused_layout(mjb_model *M)
 	compute_layout(M, M->Lc, true, pick);
 	if (getenv("MJB_DEBUG_LAYOUT"))  // development knob
 		dump_layout(M, M->Lc);
-	// the wide frame: 128 rows (two per lane), when two of them fit a CU's LDS
-	compute_layout(M, M->Lw, true, 128);
+	// the wide frame: up to 128 rows (two per lane) -- the largest multiple of four with which THREE frames share a CU's LDS when at least
+	// 96 rows do (the power grasp of config 5: p99 of nefc = 111, 112 rows fit three times; an env-step beyond them takes the HBM row block),
+	// else 128 when two fit
+	int wrows = 128;
+	for (int jr = 124; jr >= 96; jr -= 4)
+		if (occ(jr) >= 3) { wrows = jr; break; }
+	if (const char *v = getenv("MJB_WIDE_ROWS")) wrows = std::max(68, std::min(128, atoi(v)));  // measurement knob
+	compute_layout(M, M->Lw, true, wrows);
 	const int wbytes = ((M->Lw.ndouble * 8 + M->Lw.nint * 4) + 15) & ~15;
 	M->has_wide = M->Lw.jrows > M->Lc.jrows && 2 * ((wbytes + 1279) / 1280) <= 128;
 	if (!M->has_wide) M->Lw = M->Lc;

@@ -2405,6 +2405,9 @@ template <int G, bool ELL, int TAG> __device__ __attribute__((noinline)) void fw
 	fwd_constraint_pgs<G, ELL, false, TAG>(m, L, s, e);
 }
 
+// packed lower triangle of the nv <= 32 Hessian (FrameLayout::nwt_H holds nv (nv + 1) / 2 + 1 doubles then, at least the 272 of chol_schur16's scratch)
+#define MJB_HPACK(r, c) ((r) * ((r) + 1) / 2 + (c))
+
 // ------------------------------------------------------------------------------------------------
 // A14 Newton solver (primal), one env per wavefront.
 //   minimise over a:  0.5 (a - a0)' M (a - a0) + sum_i s_i(J_i a - aref_i),  s_i(x) = 0.5 D_i x^2 for x < 0
@@ -3065,11 +3068,13 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 				}
 				asm volatile("s_nop 15\n\ts_nop 7" : "+a"(t00), "+a"(t10), "+a"(t11));  // (mfma_drain: XDL write -> VALU read)
 #pragma unroll
+				// (nv <= 32: the Hessian is stored as its packed lower triangle, entry (r, c <= r) at r (r + 1) / 2 + c -- 465 doubles instead of
+				//  900 on config 5, which is what lets THREE wide frames share a CU's LDS; MJB_HPACK below)
 				for (int q = 0; q < 4; q++) {
-					const int row = lk + 4 * q;
-					if (row < nv && li < nv) H[row * nv + li] = t00[q];
-					if (16 + row < nv && li < nv) H[(16 + row) * nv + li] = t10[q];
-					if (16 + row < nv && c1 < nv) H[(16 + row) * nv + c1] = t11[q];
+					const int row = lk + 4 * q, r1 = 16 + row;
+					if (row < nv && li <= row) H[MJB_HPACK(row, li)] = t00[q];
+					if (r1 < nv && li < nv) H[MJB_HPACK(r1, li)] = t10[q];
+					if (r1 < nv && c1 <= r1) H[MJB_HPACK(r1, c1)] = t11[q];
 				}
 			};
 			if (mreg && hcd <= 4) {
@@ -3125,9 +3130,12 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 			//  and turns the select into a branch on a lane mask it has spilled -- 32 branches with a full LDS round trip each, a
 			//  quarter of this stage.  `lim`: one vector compare per column instead of a held `dofact && c < nv` mask pair)
 			const int lim = dofact ? nv : 0;
+			// (packed rows: the entries right of the diagonal are never read back -- the factorisation computes them, nothing uses them --
+			//  so they load the row's first entry instead, and the store below sends them to a dump slot behind the triangle)
+			const int kb = k * (k + 1) / 2;
 #pragma unroll
 			for (int c = 0; c < 32; c++) {
-				Hr[c] = H[k * nv + (c < nv ? c : 0)];
+				Hr[c] = H[kb + (c <= k ? c : 0)];
 				asm volatile("" : "+v"(Hr[c]));
 			}
 #pragma unroll
@@ -3140,9 +3148,10 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 				chol_cols16<16>(Hr, nv, e.lane, myrinv);
 			}
 			if (dofact) {
+				const int dump = nv * (nv + 1) / 2;
 #pragma unroll
 				for (int c = 0; c < 32; c++)
-					if (c < nv) H[k * nv + c] = Hr[c];
+					if (c < nv) H[c <= k ? kb + c : dump] = Hr[c];
 			}
 			// search = -H^-1 grad : lane k holds element k
 			// (elements >= nv are zero: no guards inside the halves, see chol_cols16)
@@ -3197,7 +3206,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 			for (int i = 1; i < 32; i++) {
 				const int ln = lb;
 				const bool has = ln < i && i < nv;
-				const double v = H[has ? i * nv + ln : 0];
+				const double v = H[has ? i * (i + 1) / 2 + ln : 0];
 				colk[i] = has ? v : 0.0;
 			}
 #pragma unroll
