@@ -290,7 +290,7 @@ def measure_other_config(name, device, launches=5, with_cpu=True, envs=None, sub
                       "envs_per_gpu": E, "physics_steps_per_launch": S, "model": name,
                       "solver": {0: "PGS", 1: "CG", 2: "Newton"}[int(model["solver"])] if constrained else "none",
                       "nconmax": int(model["nconmax"]), "nefcmax": int(model["nefcmax"]), "kernel_form": kform,
-                      "fused_frame_bytes": batch.fused_frame()[1], "fused_frame": ("default", "default", "wide (128 rows in LDS)")[batch.fused_frame()[0]],
+                      "fused_frame_bytes": batch.fused_frame()[1], "fused_frame": ("default", "default", "wide (up to 128 rows in LDS, two per lane; as many as let three frames share a CU)")[batch.fused_frame()[0]],
                       "noise_pregen": noise_mode,
                       "state_finite": finite, "auto_resets": batch.warning_count(),
                       # (mjWARN_CONTACTFULL / mjWARN_CNSTRFULL events of every env-step this batch ran, warm-up included, and their rate:
@@ -633,7 +633,7 @@ def gpu_run(args, name):
             out["workload_stats"] = stats
             out["config"]["contactfull"], out["config"]["cnstrfull"] = batch.warning("contactfull"), batch.warning("cnstrfull")
         out["config"]["fused_frame_bytes"] = batch.fused_frame()[1]
-        out["config"]["fused_frame"] = ("default", "default", "wide (128 rows in LDS)")[batch.fused_frame()[0]]
+        out["config"]["fused_frame"] = ("default", "default", "wide (up to 128 rows in LDS, two per lane; as many as let three frames share a CU)")[batch.fused_frame()[0]]
         default_run = world == 1 and not (args.config or args.model or args.solver or args.nefcmax or args.nconmax or args.envs or
                                           args.substeps or args.lanes or args.epb or args.lane_env != "auto")
         if default_run and not args.no_other_configs:

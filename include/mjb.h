@@ -128,8 +128,9 @@ const char *mjb_field_name(int field);
 int mjb_frame_doubles(const mjb_model *m);
 /* Bytes of LDS one env occupies (doubles + ints): fused != 0 -> the compact frame of mjb_step, else the full frame of
  * mjb_forward / mjb_step1 / mjb_step2.  Resident envs per CU = floor(160 KiB / that).
- * fused == 2: the WIDE fused frame of a Newton model with more than 128 rows of capacity (128 rows of efc_J in LDS instead of 64,
- * two envs per CU instead of four; == the default fused frame for every other model).  A batch switches its long fused launches
+ * fused == 2: the WIDE fused frame of a Newton model with more than 128 rows of capacity (up to 128 rows of efc_J and of every per-row
+ * array in LDS instead of 64, two rows per lane: the largest multiple of four >= 96 with which THREE frames share a CU -- 112 on the
+ * Shadow-Hand-like model -- else 128 at two per CU; == the default fused frame for every other model).  A batch switches its long fused launches
  * to it when more than a quarter of the previous launch's env-steps had more than 64 rows, and back below 5 % (MJB_WIDE_FRAME=0 / 1
  * pins the choice); mjb_fused_frame(batch) tells which one the last launch ran on. */
 int mjb_frame_bytes(const mjb_model *m, int fused);
