@@ -245,7 +245,7 @@ def workload_stats(batch):
 
 def kernel_form(batch):
     """Which kernel the batch's fused launches ran: the lane = env form (one env per lane, csrc/mjb_lane_env.hip) or the generic one."""
-    return ("mjb_lane_env_kernel", "lane = env (one env per lane)") if batch.lane_env_info()[1] else ("mjb_step_kernel", "generic (G lanes per env, frame in LDS)")
+    return ("mjb_lane_env_kernel", "lane = env (one env per lane; sensordata evaluated at the last step of a launch)") if batch.lane_env_info()[1] else ("mjb_step_kernel", "generic (G lanes per env, frame in LDS)")
 
 
 def measure_other_config(name, device, launches=5, with_cpu=True, envs=None, substeps=None, lane_env=None, tag=None):
