@@ -245,7 +245,13 @@ def workload_stats(batch):
 
 def kernel_form(batch):
     """Which kernel the batch's fused launches ran: the lane = env form (one env per lane, csrc/mjb_lane_env.hip) or the generic one."""
-    return ("mjb_lane_env_kernel", "lane = env (one env per lane; sensordata evaluated at the last step of a launch)") if batch.lane_env_info()[1] else ("mjb_step_kernel", "generic (G lanes per env, frame in LDS)")
+    if not batch.lane_env_info()[1]:
+        return "mjb_step_kernel", "generic (G lanes per env, frame in LDS)"
+    form = batch.lane_env_last_form()
+    kname = ("mjb_lane_env_kernel", "mjb_lane_env_duo_kernel", "mjb_lane_env_duo2_kernel")[form if form in (0, 1, 2) else 0]
+    how = ("one wavefront per 64 envs", "two wavefronts per 64 envs: position half | velocity half",
+           "two wavefronts per 64 envs, pipelined body by body through LDS: poses | cinert, cdof, velocities, forces")[form if form in (0, 1, 2) else 0]
+    return kname, f"lane = env (one env per lane, {how}; sensordata evaluated at the last step of a launch)"
 
 
 def measure_other_config(name, device, launches=5, with_cpu=True, envs=None, substeps=None, lane_env=None, tag=None):

@@ -256,6 +256,18 @@ int mjb_lane_env_info(const mjb_batch *b, int *used_last);
 /* The same classification for a compiled model, without a batch or a device (>= 0 / -2 / -1 as above). */
 int mjb_model_lane_env(const mjb_model *m);
 const char *mjb_lane_env_error(void);
+/* The lane = env kernel's FORM, process-wide: how many wavefronts share the 64 envs of a block.  0 = one (the whole step in one instruction stream);
+ * 1 = two, the step's position half (poses, cinert, composite inertias, qM, factors, solves, Euler) and velocity half (velocities, forces,
+ * qfrc_smooth) side by side on two SIMDs of a CU, both computing the poses; 2 = two, PIPELINED: one wavefront computes every pose once and
+ * hands it on body by body through LDS (a workgroup barrier per body), the other follows one body behind with cinert, cdof, velocities and
+ * forces and hands cdof / cinert / qfrc_smooth back -- nothing is computed twice.  A lone wavefront on a SIMD issues one instruction every ~4
+ * cycles whatever it is, so while the batch leaves SIMDs idle the step's length is the longest instruction stream: form 2 runs whenever a block has a
+ * CU's LDS to itself (<= 64 x CUs envs: 16 384 on MI355X), form 1 up to twice that, form 0 beyond.  -1 = that rule (default; the environment
+ * variable MJB_LANE_ENV_DUO = 0 / 1 / 2 overrides it).  A forced form that does not fit (LDS) falls back to the next lower one.  Results of the
+ * three forms agree to rounding.  Returns the previous setting.  mjb_lane_env_last_form: the form of this process's last lane = env launch (-1: none yet).
+ * Measurement / test knob, no reference counterpart. */
+int mjb_lane_env_set_form(int form);
+int mjb_lane_env_last_form(void);
 
 /* Stream control: the hipStream_t (as void*) kernels are launched on; default is a stream the
  * batch owns.  mjb_synchronize waits for it. */

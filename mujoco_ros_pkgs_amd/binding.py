@@ -193,6 +193,8 @@ def load_library(path=None):
         "mjb_set_lane_env": (ci, [vp, ci]),
         "mjb_lane_env_info": (ci, [vp, C.POINTER(ci)]),
         "mjb_lane_env_error": (C.c_char_p, []),
+        "mjb_lane_env_set_form": (ci, [ci]),
+        "mjb_lane_env_last_form": (ci, []),
         "mjb_model_lane_env": (ci, [vp]),
         "mjb_set_stats": (ci, [vp, ci]),
         "mjb_get_stats": (ci, [vp, C.POINTER(C.c_ulonglong)]),

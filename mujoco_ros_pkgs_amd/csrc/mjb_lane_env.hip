@@ -43,6 +43,22 @@ __global__ void __launch_bounds__(64) mjb_lane_env_kernel(const KernelParams MJB
 	lane_env_body<T, LP>(P, nsteps, step0, env_lo, env_hi, smem_le);
 }
 
+template <class T, int LP>
+__global__ void __launch_bounds__(128) mjb_lane_env_duo_kernel(const KernelParams MJB_AS4 *__restrict__ P, const int nsteps, const unsigned int step0,
+                                                               const int env_lo, const int env_hi)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_le[];
+	lane_env_duo<T, LP>(P, nsteps, step0, env_lo, env_hi, smem_le);
+}
+
+template <class T>
+__global__ void __launch_bounds__(128) mjb_lane_env_duo2_kernel(const KernelParams MJB_AS4 *__restrict__ P, const int nsteps, const unsigned int step0,
+                                                                const int env_lo, const int env_hi)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_le[];
+	lane_env_duo2<T, 160>(P, nsteps, step0, env_lo, env_hi, smem_le);
+}
+
 template <class T> bool topo_matches(const mjb_model_desc &h)
 {
 	if (h.nbody != T::NBODY || h.nq != T::NQ || h.nv != T::NV || h.nu != T::NU || h.njnt != T::NJNT || h.nsite != T::NSITE ||
@@ -206,12 +222,12 @@ std::string source_dir()
 	return ".";
 }
 
-const JitKernel &jit_get(const mjb_model_desc &h, int lp)
+const JitKernel &jit_get(const mjb_model_desc &h, int lp, int duo)  // duo: 0 solo, 1 two halves, 2 pipelined
 {
 	int dev = 0;
 	(void)hipGetDevice(&dev);
 	const std::string topo = topo_source(h);
-	const std::string key = std::to_string(dev) + "|" + std::to_string(lp) + "|" + topo;
+	const std::string key = std::to_string(dev) + "|" + std::to_string(lp) + (duo == 2 ? "p|" : (duo ? "d|" : "|")) + topo;
 	std::lock_guard<std::mutex> lock(jit_mutex);
 	auto it = jit_cache.find(key);
 	if (it != jit_cache.end()) return it->second;
@@ -221,10 +237,17 @@ const JitKernel &jit_get(const mjb_model_desc &h, int lp)
 	RtcApi &r = rtc();
 	if (!r.ok) { k.error = "libhiprtc.so not found"; return k; }
 	const std::string dir = source_dir();
+	const std::string slp = std::to_string(lp);
 	const std::string src = "#include \"mjb_lane_env_kernel.h\"\n" + topo +
-	                        "extern \"C\" __global__ void __launch_bounds__(64) le_rt(const KernelParams MJB_AS4 *P, int nsteps, unsigned int step0, int lo, int hi)\n{\n"
-	                        "\t__shared__ __attribute__((aligned(16))) unsigned char smem[mjb_le::Lds<LeTopo_rt, " + std::to_string(lp) + ">::bytes()];\n"
-	                        "\tmjb_le::lane_env_body<LeTopo_rt, " + std::to_string(lp) + ">(P, nsteps, step0, lo, hi, smem);\n}\n";
+	                        (duo == 2 ? "extern \"C\" __global__ void __launch_bounds__(128) le_rt(const KernelParams MJB_AS4 *P, int nsteps, unsigned int step0, int lo, int hi)\n{\n"
+	                                    "\t__shared__ __attribute__((aligned(16))) unsigned char smem[mjb_le::duo2_bytes<LeTopo_rt>()];\n"
+	                                    "\tmjb_le::lane_env_duo2<LeTopo_rt, 160>(P, nsteps, step0, lo, hi, smem);\n}\n"
+	                         : duo ? "extern \"C\" __global__ void __launch_bounds__(128) le_rt(const KernelParams MJB_AS4 *P, int nsteps, unsigned int step0, int lo, int hi)\n{\n"
+	                               "\t__shared__ __attribute__((aligned(16))) unsigned char smem[mjb_le::duo_bytes<LeTopo_rt, " + slp + ">()];\n"
+	                               "\tmjb_le::lane_env_duo<LeTopo_rt, " + slp + ">(P, nsteps, step0, lo, hi, smem);\n}\n"
+	                             : "extern \"C\" __global__ void __launch_bounds__(64) le_rt(const KernelParams MJB_AS4 *P, int nsteps, unsigned int step0, int lo, int hi)\n{\n"
+	                               "\t__shared__ __attribute__((aligned(16))) unsigned char smem[mjb_le::Lds<LeTopo_rt, " + slp + ">::bytes()];\n"
+	                               "\tmjb_le::lane_env_body<LeTopo_rt, " + slp + ">(P, nsteps, step0, lo, hi, smem);\n}\n");
 	void *prog = nullptr;
 	if (r.create(&prog, src.c_str(), "mjb_lane_env_rt.hip", 0, nullptr, nullptr) != 0) { k.error = "hiprtcCreateProgram failed"; return k; }
 	const std::string i1 = "-I" + dir, i2 = "-I" + dir + "/../../include";
@@ -256,6 +279,16 @@ const JitKernel &jit_get(const mjb_model_desc &h, int lp)
 }  // namespace
 
 const char *mjb_lane_env_jit_error(void) { return jit_last_error.c_str(); }
+
+// process-wide choice of the kernel's FORM (include/mjb.h): -1 = by batch size (default; MJB_LANE_ENV_DUO overrides), 0 / 1 / 2
+static int le_form_override = -1, le_form_last = -1;
+int mjb_lane_env_set_form(int form)
+{
+	const int prev = le_form_override;
+	le_form_override = (form >= 0 && form <= 2) ? form : -1;
+	return prev;
+}
+int mjb_lane_env_last_form(void) { return le_form_last; }
 
 size_t mjb_lane_env_tape_doubles(const mjb_model_desc *h)
 {
@@ -338,6 +371,15 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 	const int waves = (nenv_batch + 63) / 64;
 	int lp = (ncu > 0 && waves <= ncu) ? 160 : ((ncu > 0 && waves <= 2 * ncu) ? 80 : 40);
 	if (forced == 40 || forced == 80 || forced == 160) lp = forced;
+	// DUO: two wavefronts per 64 envs (mjb_lane_env_kernel.h) while the batch leaves at least every second SIMD idle -- the step's
+	// position half and velocity half side by side.  MJB_LANE_ENV_DUO=0 / 1: never / whenever the LDS budget allows (measurement knob)
+	static const int duo_env = [] { const char *v = getenv("MJB_LANE_ENV_DUO"); return v ? atoi(v) : -1; }();
+	const int duo_mode = le_form_override >= 0 ? le_form_override : duo_env;
+	static const int duo_max_waves = [] { const char *v = getenv("MJB_LANE_ENV_DUO_MAX_WAVES"); return v ? atoi(v) : -1; }();
+	int duo = (wl == 64 && lp >= 80 && duo_mode != 0 && (duo_mode > 0 || waves <= (duo_max_waves >= 0 ? duo_max_waves : 2 * ncu))) ? 1 : 0;
+	// ... pipelined (nothing computed twice) when a workgroup has a CU's LDS to itself.  MJB_LANE_ENV_DUO=1: the two-halves form only
+	if (duo && lp == 160 && duo_mode != 1) duo = 2;
+	if (duo_mode > 0 && lp < 80) lp = 80, duo = 1;  // (a forced two-wavefront form on a batch that would run four wavefronts per CU: two per CU)
 	if (topo == MJB_LE_TOPO_JIT) {
 		if (!h) return (int)hipErrorInvalidValue;
 		{  // a larger model than the compiled-in ones: the smallest LDS budget its (qpos, qvel) pairs and body forces fit (fewer wavefronts per CU then)
@@ -353,8 +395,10 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 				return MJB_LE_UNAVAILABLE;
 			}
 			if (fit > lp) lp = fit;
+			if (duo == 2 && need + 5 * ((need - h->nv) / 3) + 3 * h->nv + 12 + (h->nv + 1) / 2 + 1 > 160) duo = 1;
+			if (duo == 1 && need + (h->nv + 1) / 2 + 1 > lp) duo = 0;
 		}
-		const JitKernel &k = jit_get(*h, lp);
+		const JitKernel &k = jit_get(*h, lp, duo);
 		if (!k.fn) {
 			jit_last_error = k.error;
 			return MJB_LE_UNAVAILABLE;
@@ -363,7 +407,8 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 		int a_nsteps = nsteps, a_lo = env_lo, a_hi = env_hi;
 		unsigned int a_step0 = step0;
 		void *args[] = { (void *)&Pd, (void *)&a_nsteps, (void *)&a_step0, (void *)&a_lo, (void *)&a_hi };
-		return (int)hipModuleLaunchKernel(k.fn, grid.x, 1, 1, block.x, 1, 1, 0, (hipStream_t)stream, args, nullptr);
+		le_form_last = duo;
+		return (int)hipModuleLaunchKernel(k.fn, grid.x, 1, 1, duo ? 128 : block.x, 1, 1, 0, (hipStream_t)stream, args, nullptr);
 	}
 #define MJB_LE_GO(T, LPV)                                                                                                                    \
 	{                                                                                                                                         \
@@ -371,11 +416,35 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 		constexpr int bytes = Lds<T, LPV>::bytes();                                                                                           \
 		static const hipError_t attr = bytes > 65536 ? hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) : hipSuccess; \
 		if (attr != hipSuccess) return (int)attr;                                                                                             \
+		le_form_last = 0;                                                                                                                     \
 		hipLaunchKernelGGL(kern, grid, block, bytes, (hipStream_t)stream, (const KernelParams MJB_AS4 *)Pdev, nsteps, step0, env_lo, env_hi); \
+		return (int)hipGetLastError();                                                                                                        \
+	}
+#define MJB_LE_GO_DUO(T, LPV)                                                                                                                \
+	{                                                                                                                                         \
+		auto kern = mjb_lane_env_duo_kernel<T, LPV>;                                                                                          \
+		constexpr int bytes = duo_bytes<T, LPV>();                                                                                            \
+		static const hipError_t attr = bytes > 65536 ? hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) : hipSuccess; \
+		if (attr != hipSuccess) return (int)attr;                                                                                             \
+		le_form_last = 1;                                                                                                                     \
+		hipLaunchKernelGGL(kern, grid, dim3(128), bytes, (hipStream_t)stream, (const KernelParams MJB_AS4 *)Pdev, nsteps, step0, env_lo, env_hi); \
+		return (int)hipGetLastError();                                                                                                        \
+	}
+#define MJB_LE_GO_DUO2(T)                                                                                                                   \
+	if constexpr (duo2_bytes<T>() <= 160 * 1024) {                                                                                            \
+		auto kern = mjb_lane_env_duo2_kernel<T>;                                                                                              \
+		constexpr int bytes = duo2_bytes<T>();                                                                                                \
+		static const hipError_t attr = bytes > 65536 ? hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) : hipSuccess; \
+		if (attr != hipSuccess) return (int)attr;                                                                                             \
+		le_form_last = 2;                                                                                                                     \
+		hipLaunchKernelGGL(kern, grid, dim3(128), bytes, (hipStream_t)stream, (const KernelParams MJB_AS4 *)Pdev, nsteps, step0, env_lo, env_hi); \
 		return (int)hipGetLastError();                                                                                                        \
 	}
 #define MJB_LE_X(id, T)                      \
 	if (topo == id) {                        \
+		if (duo == 2) MJB_LE_GO_DUO2(T)      \
+		if (duo && lp == 160) MJB_LE_GO_DUO(T, 160) \
+		if (duo && lp == 80) MJB_LE_GO_DUO(T, 80)   \
 		if (lp == 160) MJB_LE_GO(T, 160)     \
 		if (lp == 80) MJB_LE_GO(T, 80)       \
 		MJB_LE_GO(T, 40)                     \
@@ -383,5 +452,7 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 	MJB_LE_TOPOS(MJB_LE_X)
 #undef MJB_LE_X
 #undef MJB_LE_GO
+#undef MJB_LE_GO_DUO
+#undef MJB_LE_GO_DUO2
 	return (int)hipErrorInvalidValue;
 }

@@ -40,6 +40,20 @@ template <class T> struct Tq {
 		return false;
 	}
 	static constexpr bool is_root(int b) { return b > 0 && T::body_rootid[b] == b; }
+	// entry e of MuJoCo's sparse qM (dof_Madr[i] + k: dof i with its k-th ancestor, itself first) -> i, a
+	static constexpr int ent_i(int e)
+	{
+		int i = 0;
+		for (int d = 0; d < T::NV; d++)
+			if (T::dof_Madr[d] <= e) i = d;
+		return i;
+	}
+	static constexpr int ent_a(int e)
+	{
+		int a = ent_i(e);
+		for (int k = T::dof_Madr[ent_i(e)]; k < e; k++) a = T::dof_parentid[a];
+		return a;
+	}
 	// some sensor of the model needs the pose of this site / body
 	static constexpr bool has_actuator_sensor()
 	{
@@ -175,18 +189,38 @@ template <class T, int LP> struct Lds {
 
 struct alignas(16) Pair { double a, b; };
 
-template <class T, int LP>
+// ROLE: 0 = one wavefront runs the whole step of its 64 envs.  1 / 2 = the DUO form, two wavefronts of one workgroup (on two SIMDs of a CU) share
+// the 64 envs of the block: the step's two independent halves -- what depends on qpos alone (poses, cinert, composite inertias, qM, both factors:
+// role 1, "P") and what depends on qvel too (velocities, the bodies' forces, the force block, qfrc_smooth: role 2, "V") -- run side by side, V hands
+// qfrc_smooth over through LDS, P solves and integrates, and hands the new state (which lives in LDS anyway) and the mj_check* verdicts back.  Both
+// compute the poses, cdof and cinert (the shared prefix).  A lone wavefront issues one instruction every ~4 cycles whatever it is, so the step's
+// length is its instruction count: ~6.2 k in one piece, ~max(P, V) + solve + Euler in two.  Pays while the batch leaves SIMDs idle (the launcher).
+// rendezvous of a DUO block's two wavefronts: LDS traffic done, then the barrier.  (__syncthreads() also waits for the wavefront's outstanding GLOBAL
+// loads -- V's ctrl-noise normals and qfrc_applied are fetched a sweep ahead of their use precisely so that nobody waits for HBM)
+DEVI void le_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int NV> struct DuoSlots { static constexpr int n = (NV + 1) / 2 + 1; };  // qfrc_smooth pairs + the mail slot
+template <class T, int LP, int ROLE = 0>
 DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int nsteps, const unsigned int step0, const int env_lo, const int env_hi,
                         unsigned char *const smem_le)
 {
 	constexpr int NB = T::NBODY, NV = T::NV, NU = T::NU;
+	// (roles 3 / 4 = the PIPELINED duo: P computes every pose and cinert ONCE and passes them on body by body -- a workgroup barrier per body, a
+	//  two-deep ring of (xpos, xmat) in LDS -- V follows one body behind with cdof, velocities and forces and passes cdof back for P's composite-inertia
+	//  sweep.  Nothing is computed twice; needs every needed body's cinert and cdof in LDS: Duo2<T>.)
+	constexpr bool DP = ROLE == 0 || ROLE == 1 || ROLE == 3, DV = ROLE == 0 || ROLE == 2 || ROLE == 4, DUO = ROLE != 0;  // this wavefront does the position half / the velocity half
+	constexpr bool PIPE = ROLE >= 3;
+	constexpr bool SENSF = ROLE == 0 || ROLE == 2 || ROLE == 3;  // frame sensors: who holds the poses (and, of two, who has the time)
 	using Q = Tq<T>;
-	using LD = Lds<T, LP>;
-	static_assert(LD::slot(T::NBODY) <= LP, "lane = env kernel: state and forces of the topology need more LDS than this instantiation's budget");
-	Pair *const lp = reinterpret_cast<Pair *>(smem_le) + threadIdx.x;  // pair slot q of this lane: lp[64 * q]
+	constexpr int LPE = PIPE ? (1 << 20) : (DUO ? LP - DuoSlots<NV>::n : LP);
+	using LD = Lds<T, LPE>;
+	static_assert(LD::slot(T::NBODY) <= LPE, "lane = env kernel: state and forces of the topology need more LDS than this instantiation's budget");
+	constexpr int CD0 = LD::nslots(), RING = CD0 + 3 * NV;                          // (PIPE) three pair slots per dof's cdof, then 2 x 6 of the pose ring
+	constexpr int XS = PIPE ? RING + 12 : LD::nslots(), MAIL = XS + (NV + 1) / 2;  // (DUO) pair slots of qfrc_smooth, and of P's verdicts for V
+	const int lane_le = DUO ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
+	Pair *const lp = reinterpret_cast<Pair *>(smem_le) + lane_le;  // pair slot q of this lane: lp[64 * q]
 	// (a tail lane without an env keeps running on the last env's data and stores nothing: no divergent exit, the wave-uniform
 	//  branches below stay uniform)
-	const int env_raw = env_lo + (int)(blockIdx.x * blockDim.x + threadIdx.x);  // (blockDim.x = 64; fewer: a measurement knob, MJB_LANE_ENV_WAVE_LANES)
+	const int env_raw = env_lo + (int)(blockIdx.x * (DUO ? 64u : blockDim.x)) + lane_le;  // (solo: blockDim.x = 64; fewer: a measurement knob, MJB_LANE_ENV_WAVE_LANES)
 	const bool live = env_raw < env_hi;
 	const int env = live ? env_raw : env_hi - 1;
 	const size_t ev = (size_t)env;
@@ -198,14 +232,25 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 	bool wasreset = false;  // mj_resetData ran inside this launch: ctrl / qfrc_applied read as zero from then on (the frame copy of the generic kernels)
 	{
 		const DevState MJB_AS4 &s = P->s;
-		sfor<NV>([&](auto I) {
-			const Pair s2{ s.qpos[ev * NV + I], s.qvel[ev * NV + I] };
-			lp[64 * I] = s2;
-			badp_next |= bad_val(s2.a);
-			badv_next |= bad_val(s2.b);
-		});
-		sfor<NU>([&](auto I) { cn[I] = s.ctrlnoise[ev * NU + I]; });
+		if constexpr (DP) {
+			sfor<NV>([&](auto I) {
+				const Pair s2{ s.qpos[ev * NV + I], s.qvel[ev * NV + I] };
+				lp[64 * I] = s2;
+				badp_next |= bad_val(s2.a);
+				badv_next |= bad_val(s2.b);
+			});
+		}
+		sfor<NU>([&](auto I) { cn[I] = DV ? s.ctrlnoise[ev * NU + I] : 0.0; });
 		time = s.time[ev];
+		if constexpr (DUO) {  // the load is "Euler of step -1": P's verdicts on the loaded state go to V by mail
+			if constexpr (DP) lp[64 * MAIL] = Pair{ (double)((badp_next ? 2 : 0) | (badv_next ? 1 : 0)), 0.0 };
+			le_barrier();
+			if constexpr (!DP) {
+				const int code = (int)lp[64 * MAIL].a;
+				badp_next = (code & 2) != 0;
+				badv_next = (code & 1) != 0;
+			}
+		}
 	}
 	const bool nz_on = P->nz.enabled != 0;
 	// ctrl noise from the launch's pre-generated buffer when the host filled one for exactly this launch (mjb_api.hip: launch)
@@ -217,8 +262,17 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 	}
 	const bool zpre = zhalf_i >= 0;
 
+#ifdef MJB_LE_PROBE  // (measurement build: cycle stamps of the step's phases, summed over the launch, into the env-0 sensordata of the role)
+	unsigned long long pk_t = 0, pk_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#define LE_PK0() pk_t = __builtin_readcyclecounter()
+#define LE_PK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); pk_acc[i] += n_ - pk_t; pk_t = n_; } while (0)
+#else
+#define LE_PK0() do { } while (0)
+#define LE_PK(i) do { } while (0)
+#endif
 #pragma nounroll
 	for (int st = 0; st < nsteps; st++) {
+		LE_PK0();
 		// (the parameter pointer laundered per step: model constants are re-fetched by scalar loads where they are used instead of
 		//  being hoisted out of the step loop into ~700 SGPRs the wavefront does not have)
 		const KernelParams MJB_AS4 *Pq = P;
@@ -235,7 +289,7 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 		// the OU state where the forces are assembled, after the root -> leaf sweep -- the trip to HBM hides behind the sweep
 		double z[NU > 0 ? NU : 1];
 		sfor<NU>([&](auto I) { z[I] = 0; });
-		if (nz_on) {
+		if (DV && nz_on) {
 			if (zpre) {
 				asm volatile("" ::: "memory");
 				const double *zb = s.zbuf + (zhalf_i > 0 ? s.zhalf : 0ull) + ((size_t)st * s.nenv + ev) * NU;
@@ -244,7 +298,7 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 				asm volatile("" ::: "memory");
 				// (one copy of the generator in the instruction stream: the normals go through the cfrc slots, free at this point)
 				const unsigned long long seed = Pq->nz.seed, genv = (unsigned long long)(Pq->nz.env_offset + env);
-				double *zl = reinterpret_cast<double *>(smem_le) + 2 * 64 * NV + threadIdx.x;
+				double *zl = reinterpret_cast<double *>(smem_le) + 2 * 64 * NV + lane_le;
 #pragma nounroll
 				for (int i = 0; i < NU; i++) zl[64 * i] = philox_normal(seed, genv, step0 + (unsigned int)st, (unsigned int)i);
 				sfor<NU>([&](auto I) { z[I] = zl[64 * I]; });
@@ -261,16 +315,19 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 			//  A reset is a handful of selects under a wave-uniform test; every lane issues the counter's atomic, with 0 or 1.)
 			const bool bad = badp || badv;
 			if (__builtin_amdgcn_ballot_w64(bad)) {
-				atomicAdd(s.nwarn + MJB_WARN_BADQPOS, (badp && live) ? 1ull : 0ull);
-				atomicAdd(s.nwarn + MJB_WARN_BADQVEL, (!badp && badv && live) ? 1ull : 0ull);
-				sfor<NV>([&](auto I) {
-					const Pair o = lp[64 * I];
-					const double oa = pinv(o.a), ob = pinv(o.b), q0 = pins(tb[T::jnt_bodyid[I]].qpos0);  // (evaluated before the selects, not inside them)
-					lp[64 * I] = Pair{ bad ? q0 : oa, bad ? 0.0 : ob };
-				});
+				if constexpr (DP) {
+					atomicAdd(s.nwarn + MJB_WARN_BADQPOS, (badp && live) ? 1ull : 0ull);
+					atomicAdd(s.nwarn + MJB_WARN_BADQVEL, (!badp && badv && live) ? 1ull : 0ull);
+					sfor<NV>([&](auto I) {
+						const Pair o = lp[64 * I];
+						const double oa = pinv(o.a), ob = pinv(o.b), q0 = pins(tb[T::jnt_bodyid[I]].qpos0);  // (evaluated before the selects, not inside them)
+						lp[64 * I] = Pair{ bad ? q0 : oa, bad ? 0.0 : ob };
+					});
+				}
 				time = bad ? 0.0 : time;
 				wasreset = wasreset || bad;
 				rs = bad;
+				if constexpr (DUO) le_barrier();  // (both wavefronts hold the same verdicts: both are here) V reads the reset state
 			}
 		}
 
@@ -287,9 +344,10 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 				tb = reinterpret_cast<const LeTapeBody MJB_AS4 *>(th + 1);
 			}
 			const LeTapeAct MJB_AS4 *const ta = reinterpret_cast<const LeTapeAct MJB_AS4 *>(tb + NB);
-			const bool e_on = last && (m.enableflags & MJB_ENBL_ENERGY);
+			const bool e_on = DP && last && (m.enableflags & MJB_ENBL_ENERGY);
 			const bool eg_on = e_on && !(m.disableflags & MJB_DSBL_GRAVITY);
-			const bool sens_on = last && !(m.disableflags & MJB_DSBL_SENSOR);  // (a tail lane rewrites the last env's values)
+			const bool sens_on = DV && last && !(m.disableflags & MJB_DSBL_SENSOR);  // (a tail lane rewrites the last env's values)
+			const bool sensf_on = SENSF && last && !(m.disableflags & MJB_DSBL_SENSOR);
 			double *sd = s.sensordata + ev * T::NSENSORDATA;
 			double pe = 0;
 
@@ -321,9 +379,156 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 				constexpr int j1 = [] { for (int c = 1; c < NB; c++) if (T::body_jnt[c] >= 0) return T::body_jnt[c]; return -1; }();
 				if constexpr (j1 >= 0) pq[T::jnt_bodyid[j1]] = lp[64 * j1];
 			}
+			// position-stage sensors on a body's frames (the last step's values are the launch's sensordata)
+			auto frame_sensors = [&](auto Bq, const double *xipos) {
+				constexpr int b = Bq;
+				if (sensf_on) {
+					sfor<T::NSENSOR>([&](auto S) {
+						constexpr int i = S, type = T::sensor_type[i], ot = T::sensor_objtype[i], id = T::sensor_objid[i], adr = T::sensor_adr[i];
+						if constexpr (type == MJB_SENS_FRAMEPOS || type == MJB_SENS_FRAMEQUAT) {
+							constexpr int sb = ot == MJB_OBJ_SITE ? T::site_bodyid[id] : id;
+							if constexpr (sb == b) {
+								double o3[3], o4[4];
+								if constexpr (ot == MJB_OBJ_SITE) {
+									if constexpr (type == MJB_SENS_FRAMEPOS) {
+										if constexpr (T::site_sameframe[id]) {
+											for (int k = 0; k < 3; k++) o3[k] = xpos[b][k];
+										} else {
+											double sp[3], v[3];
+											ldc3(sp, m.site_pos + 3 * id);
+											matvec3(v, xmat[b], sp);
+											for (int k = 0; k < 3; k++) o3[k] = v[k] + xpos[b][k];
+										}
+									} else {
+										double sq[4];
+										ldc4(sq, m.site_quat + 4 * id);
+										qmul(o4, xquat[b], sq);
+									}
+								} else if constexpr (ot == MJB_OBJ_BODY) {
+									if constexpr (type == MJB_SENS_FRAMEPOS) {
+										for (int k = 0; k < 3; k++) o3[k] = xipos[k];
+									} else {
+										double iq[4];
+										ldc4(iq, m.body_iquat + 4 * b);
+										qmul(o4, xquat[b], iq);
+									}
+								} else {  // xbody
+									for (int k = 0; k < 3; k++) o3[k] = xpos[b][k];
+									for (int k = 0; k < 4; k++) o4[k] = xquat[b][k];
+								}
+								if constexpr (type == MJB_SENS_FRAMEPOS) {
+									const double cut = m.sensor_cutoff[i];
+									for (int k = 0; k < 3; k++) sd[adr + k] = cut > 0 ? clampd(o3[k], -cut, cut) : o3[k];
+								} else {
+									for (int k = 0; k < 4; k++) sd[adr + k] = o4[k];
+								}
+							}
+						}
+					});
+				}
+			};
 			sfor<NB>([&](auto B) {
 				constexpr int b = B;
-				if constexpr (b > 0) {
+				if constexpr (b > 0 && ROLE == 4) {
+					// ---- the pipelined V: body b's pose (position relative to the tree root's origin) and cinert come from P through LDS, one barrier per needed body
+					constexpr int p = T::body_parentid[b], j = T::body_jnt[b];
+					if constexpr (LD::needed(b)) {
+						constexpr int ord = (LD::slot(b) - NV) / 3, rg = RING + 6 * (ord & 1), c0 = LD::cin_slot(b);
+						static_assert(c0 >= 0, "pipelined duo: every needed body's cinert lives in LDS");
+						LE_PK(0);
+						le_barrier();
+						LE_PK(2);
+						double xp[3], xm[9], ci[10];
+						{
+							const Pair a0 = lp[64 * rg], a1 = lp[64 * (rg + 1)], a2 = lp[64 * (rg + 2)], a3 = lp[64 * (rg + 3)], a4 = lp[64 * (rg + 4)], a5 = lp[64 * (rg + 5)];
+							xp[0] = a0.a; xp[1] = a0.b; xp[2] = a1.a; xm[0] = a1.b; xm[1] = a2.a; xm[2] = a2.b; xm[3] = a3.a; xm[4] = a3.b; xm[5] = a4.a; xm[6] = a4.b; xm[7] = a5.a; xm[8] = a5.b;
+						}
+						{
+							// cinert about the tree root's origin, as in the fused sweep: X Ib X' + the com offset's terms; handed to P's composite-inertia sweep
+							const LeTapeBody MJB_AS4 &tj = tb[b];
+							double dif[3] = { xp[0], xp[1], xp[2] };
+							if constexpr (!T::body_sameframe[b]) {
+								const double ip[3] = { tj.ipos[0], tj.ipos[1], tj.ipos[2] };
+								double v[3];
+								matvec3(v, xm, ip);
+								for (int k = 0; k < 3; k++) dif[k] += v[k];
+							}
+							const double mass = tj.mass;
+							const double *X = xm;
+							const double ixx = tj.ibody[0], iyy = tj.ibody[1], izz = tj.ibody[2], ixy = tj.ibody[3], ixz = tj.ibody[4], iyz = tj.ibody[5];
+							double Tm[9];
+							for (int rr = 0; rr < 3; rr++) {
+								Tm[3 * rr + 0] = X[3 * rr] * ixx + X[3 * rr + 1] * ixy + X[3 * rr + 2] * ixz;
+								Tm[3 * rr + 1] = X[3 * rr] * ixy + X[3 * rr + 1] * iyy + X[3 * rr + 2] * iyz;
+								Tm[3 * rr + 2] = X[3 * rr] * ixz + X[3 * rr + 1] * iyz + X[3 * rr + 2] * izz;
+							}
+							ci[0] = Tm[0] * X[0] + Tm[1] * X[1] + Tm[2] * X[2] + mass * (dif[1] * dif[1] + dif[2] * dif[2]);
+							ci[1] = Tm[3] * X[3] + Tm[4] * X[4] + Tm[5] * X[5] + mass * (dif[0] * dif[0] + dif[2] * dif[2]);
+							ci[2] = Tm[6] * X[6] + Tm[7] * X[7] + Tm[8] * X[8] + mass * (dif[0] * dif[0] + dif[1] * dif[1]);
+							ci[3] = Tm[0] * X[3] + Tm[1] * X[4] + Tm[2] * X[5] - mass * dif[0] * dif[1];
+							ci[4] = Tm[0] * X[6] + Tm[1] * X[7] + Tm[2] * X[8] - mass * dif[0] * dif[2];
+							ci[5] = Tm[3] * X[6] + Tm[4] * X[7] + Tm[5] * X[8] - mass * dif[1] * dif[2];
+							ci[6] = mass * dif[0];
+							ci[7] = mass * dif[1];
+							ci[8] = mass * dif[2];
+							ci[9] = mass;
+							for (int k = 0; k < 5; k++) lp[64 * (c0 + k)] = Pair{ ci[2 * k], ci[2 * k + 1] };
+						}
+						double pv[6], pa[6];
+						if constexpr (p == 0 || !LD::needed(p)) {  // the world, or a jointless chain down from it: at rest
+							for (int k = 0; k < 6; k++) pv[k] = 0;
+							pa[0] = pa[1] = pa[2] = 0;
+							for (int k = 0; k < 3; k++) pa[3 + k] = -grav[k];
+						} else {
+							for (int k = 0; k < 6; k++) { pv[k] = cvel[p][k]; pa[k] = cacc[p][k]; }
+						}
+						if constexpr (j >= 0) {
+							const double qv = lp[64 * j].b;
+							const LeTapeBody MJB_AS4 &tj = tb[b];
+							const double ax[3] = { tj.jaxis[0], tj.jaxis[1], tj.jaxis[2] };
+							double xaxis[3];
+							matvec3(xaxis, xm, ax);
+							double *cd = cdof[j];
+							if constexpr (T::jnt_type[j] == MJB_JNT_SLIDE) {
+								cd[0] = cd[1] = cd[2] = 0;
+								for (int k = 0; k < 3; k++) cd[3 + k] = xaxis[k];
+							} else {
+								// (the anchor from the body's FINAL frame: xpos + xmat jnt_pos -- the point mj_kinematics' off-centre correction keeps fixed)
+								const double jp[3] = { tj.jpos[0], tj.jpos[1], tj.jpos[2] };
+								double xanch[3] = { xp[0], xp[1], xp[2] }, off[3];
+								if (jp[0] != 0 || jp[1] != 0 || jp[2] != 0) {
+									double v[3];
+									matvec3(v, xm, jp);
+									for (int k = 0; k < 3; k++) xanch[k] += v[k];
+								}
+								for (int k = 0; k < 3; k++) off[k] = -xanch[k];  // (root origin - anchor)
+								for (int k = 0; k < 3; k++) cd[k] = xaxis[k];
+								cross3(cd + 3, xaxis, off);
+							}
+							for (int k = 0; k < 3; k++) lp[64 * (CD0 + 3 * j + k)] = Pair{ cd[2 * k], cd[2 * k + 1] };
+							if constexpr (p == 0 || !LD::needed(p)) {
+								for (int k = 0; k < 6; k++) { cvel[b][k] = cd[k] * qv; cacc[b][k] = pa[k]; }
+							} else {
+								double cdd[6];
+								cross_motion(cdd, pv, cd);
+								for (int k = 0; k < 6; k++) { cvel[b][k] = pv[k] + cd[k] * qv; cacc[b][k] = pa[k] + cdd[k] * qv; }
+							}
+						} else {
+							for (int k = 0; k < 6; k++) { cvel[b][k] = pv[k]; cacc[b][k] = pa[k]; }
+						}
+						double cf[6], t0[6], t1[6];
+						mul_inert_vec(cf, ci, cacc[b]);
+						mul_inert_vec(t0, ci, cvel[b]);
+						cross_force(t1, cvel[b], t0);
+						constexpr int q0 = LD::slot(b);
+						lp[64 * q0] = Pair{ cf[0] + t1[0], cf[1] + t1[1] };
+						lp[64 * (q0 + 1)] = Pair{ cf[2] + t1[2], cf[3] + t1[3] };
+						lp[64 * (q0 + 2)] = Pair{ cf[4] + t1[4], cf[5] + t1[5] };
+					}
+					if constexpr (b == 1) sfor<NV>([&](auto I) { qfa[I] = s.qfrc_applied[ev * NV + I]; });  // (read by the force block behind the sweep: a trip to HBM)
+					__builtin_amdgcn_sched_barrier(0);
+				}
+				if constexpr (b > 0 && ROLE != 4) {
 				constexpr int p = T::body_parentid[b], j = T::body_jnt[b], r = T::body_rootid[b];
 				touch_s(hA[b][0]);
 				if constexpr (j >= 0) touch_v(pq[b].a);
@@ -404,55 +609,11 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 				}
 				const double mass = Bh[9];
 				if (eg_on) pe -= mass * (grav[0] * xipos[0] + grav[1] * xipos[1] + grav[2] * xipos[2]);
-				// position-stage sensors on this body's frames (the last step's values are the launch's sensordata)
-				if (sens_on) {
-					sfor<T::NSENSOR>([&](auto S) {
-						constexpr int i = S, type = T::sensor_type[i], ot = T::sensor_objtype[i], id = T::sensor_objid[i], adr = T::sensor_adr[i];
-						if constexpr (type == MJB_SENS_FRAMEPOS || type == MJB_SENS_FRAMEQUAT) {
-							constexpr int sb = ot == MJB_OBJ_SITE ? T::site_bodyid[id] : id;
-							if constexpr (sb == b) {
-								double o3[3], o4[4];
-								if constexpr (ot == MJB_OBJ_SITE) {
-									if constexpr (type == MJB_SENS_FRAMEPOS) {
-										if constexpr (T::site_sameframe[id]) {
-											for (int k = 0; k < 3; k++) o3[k] = xpos[b][k];
-										} else {
-											double sp[3], v[3];
-											ldc3(sp, m.site_pos + 3 * id);
-											matvec3(v, xmat[b], sp);
-											for (int k = 0; k < 3; k++) o3[k] = v[k] + xpos[b][k];
-										}
-									} else {
-										double sq[4];
-										ldc4(sq, m.site_quat + 4 * id);
-										qmul(o4, xquat[b], sq);
-									}
-								} else if constexpr (ot == MJB_OBJ_BODY) {
-									if constexpr (type == MJB_SENS_FRAMEPOS) {
-										for (int k = 0; k < 3; k++) o3[k] = xipos[k];
-									} else {
-										double iq[4];
-										ldc4(iq, m.body_iquat + 4 * b);
-										qmul(o4, xquat[b], iq);
-									}
-								} else {  // xbody
-									for (int k = 0; k < 3; k++) o3[k] = xpos[b][k];
-									for (int k = 0; k < 4; k++) o4[k] = xquat[b][k];
-								}
-								if constexpr (type == MJB_SENS_FRAMEPOS) {
-									const double cut = m.sensor_cutoff[i];
-									for (int k = 0; k < 3; k++) sd[adr + k] = cut > 0 ? clampd(o3[k], -cut, cut) : o3[k];
-								} else {
-									for (int k = 0; k < 4; k++) sd[adr + k] = o4[k];
-								}
-							}
-						}
-					});
-				}
+				frame_sensors(B, xipos);
 				if constexpr (LD::needed(b)) {
 					// cinert about the tree root's origin (mju_inertCom with that offset)
-					double ci[10];
-					{
+					[[maybe_unused]] double ci[10];
+					if constexpr (ROLE != 3) {
 						double dif[3];
 						if constexpr (r == b) { dif[0] = xipos[0] - pos[0]; dif[1] = xipos[1] - pos[1]; dif[2] = xipos[2] - pos[2]; }
 						else for (int k = 0; k < 3; k++) dif[k] = xipos[k] - xpos[r][k];
@@ -479,8 +640,9 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 						res[9] = mass;
 					}
 					// parent's velocity / acceleration (world: zero velocity, -gravity)
-					double pv[6], pa[6];
-					if constexpr (p == 0) {
+					[[maybe_unused]] double pv[6], pa[6];
+					if constexpr (!DV) {
+					} else if constexpr (p == 0) {
 						for (int k = 0; k < 6; k++) pv[k] = 0;
 						pa[0] = pa[1] = pa[2] = 0;
 						for (int k = 0; k < 3; k++) pa[3 + k] = -grav[k];
@@ -491,7 +653,8 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 					} else {
 						for (int k = 0; k < 6; k++) { pv[k] = cvel[p][k]; pa[k] = cacc[p][k]; }
 					}
-					if constexpr (j >= 0) {
+					if constexpr (ROLE == 3) {
+					} else if constexpr (j >= 0) {
 						double *cd = cdof[j];
 						if constexpr (T::jnt_type[j] == MJB_JNT_SLIDE) {
 							cd[0] = cd[1] = cd[2] = 0;
@@ -503,7 +666,8 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 							for (int k = 0; k < 3; k++) cd[k] = xaxis[k];
 							cross3(cd + 3, xaxis, off);
 						}
-						if constexpr (p == 0 || !LD::needed(p)) {
+						if constexpr (!DV) {
+						} else if constexpr (p == 0 || !LD::needed(p)) {
 							// cdof_dot = cvel(parent) x cdof = 0
 							for (int k = 0; k < 6; k++) { cvel[b][k] = cd[k] * qv; cacc[b][k] = pa[k]; }
 						} else {
@@ -511,33 +675,67 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 							cross_motion(cdd, pv, cd);
 							for (int k = 0; k < 6; k++) { cvel[b][k] = pv[k] + cd[k] * qv; cacc[b][k] = pa[k] + cdd[k] * qv; }
 						}
-					} else {
+					} else if constexpr (DV) {
 						for (int k = 0; k < 6; k++) { cvel[b][k] = pv[k]; cacc[b][k] = pa[k]; }
 					}
-					// cfrc_body = cinert * cacc + cvel x* (cinert * cvel): parked in LDS for the backward sweep
-					double cf[6], t0[6], t1[6];
-					mul_inert_vec(cf, ci, cacc[b]);
-					mul_inert_vec(t0, ci, cvel[b]);
-					if constexpr (LD::cin_slot(b) >= 0) {
-						constexpr int c0 = LD::cin_slot(b);
-						for (int k = 0; k < 5; k++) lp[64 * (c0 + k)] = Pair{ ci[2 * k], ci[2 * k + 1] };
-					} else {
-						for (int k = 0; k < 10; k++) cin[b][k] = ci[k];
+					if constexpr (DP && ROLE != 3) {  // the composite-inertia sweep reads it back
+						if constexpr (LD::cin_slot(b) >= 0) {
+							constexpr int c0 = LD::cin_slot(b);
+							for (int k = 0; k < 5; k++) lp[64 * (c0 + k)] = Pair{ ci[2 * k], ci[2 * k + 1] };
+						} else {
+							for (int k = 0; k < 10; k++) cin[b][k] = ci[k];
+						}
 					}
-					cross_force(t1, cvel[b], t0);
-					constexpr int q0 = LD::slot(b);
-					lp[64 * q0] = Pair{ cf[0] + t1[0], cf[1] + t1[1] };
-					lp[64 * (q0 + 1)] = Pair{ cf[2] + t1[2], cf[3] + t1[3] };
-					lp[64 * (q0 + 2)] = Pair{ cf[4] + t1[4], cf[5] + t1[5] };
+					if constexpr (DV) {
+						// cfrc_body = cinert * cacc + cvel x* (cinert * cvel): parked in LDS for the backward sweep
+						double cf[6], t0[6], t1[6];
+						mul_inert_vec(cf, ci, cacc[b]);
+						mul_inert_vec(t0, ci, cvel[b]);
+						cross_force(t1, cvel[b], t0);
+						constexpr int q0 = LD::slot(b);
+						lp[64 * q0] = Pair{ cf[0] + t1[0], cf[1] + t1[1] };
+						lp[64 * (q0 + 1)] = Pair{ cf[2] + t1[2], cf[3] + t1[3] };
+						lp[64 * (q0 + 2)] = Pair{ cf[4] + t1[4], cf[5] + t1[5] };
+					}
+					if constexpr (ROLE == 3) {  // the pose to V (its cinert went to the body's own slots above)
+						constexpr int ord = (LD::slot(b) - NV) / 3, rg = RING + 6 * (ord & 1);
+						const double *xm = xmat[b];
+						double xp[3] = { 0, 0, 0 };  // relative to the tree root's origin: what cdof is taken about
+						if constexpr (r != b) for (int k = 0; k < 3; k++) xp[k] = xpos[b][k] - xpos[r][k];
+						lp[64 * rg] = Pair{ xp[0], xp[1] };
+						lp[64 * (rg + 1)] = Pair{ xp[2], xm[0] };
+						lp[64 * (rg + 2)] = Pair{ xm[1], xm[2] };
+						lp[64 * (rg + 3)] = Pair{ xm[3], xm[4] };
+						lp[64 * (rg + 4)] = Pair{ xm[5], xm[6] };
+						lp[64 * (rg + 5)] = Pair{ xm[7], xm[8] };
+						LE_PK(0);
+						le_barrier();
+						LE_PK(2);
+					}
 				}
 				if constexpr (b + 1 < NB) touch_rec<14>(hA[b + 1]);
-				if constexpr (b == NB - 1) sfor<NV>([&](auto I) { qfa[I] = s.qfrc_applied[ev * NV + I]; });
+				if constexpr (DV && b == NB - 1) sfor<NV>([&](auto I) { qfa[I] = s.qfrc_applied[ev * NV + I]; });
 				__builtin_amdgcn_sched_barrier(0);
 				}
 			});
 
+			LE_PK(0);
+			if constexpr (PIPE) {
+				le_barrier();  // (F) V's last cdof is in LDS
+				if constexpr (ROLE == 3) {
+					sfor<NV>([&](auto J) {
+						constexpr int j = J;
+						for (int k = 0; k < 3; k++) {
+							const Pair c = lp[64 * (CD0 + 3 * j + k)];
+							cdof[j][2 * k] = c.a;
+							cdof[j][2 * k + 1] = c.b;
+						}
+					});
+				}
+			}
+			LE_PK(1);
 			// ============ A8 mj_passive, the injector's OU update, A12 mj_fwdActuation (joint transmission), qfrc_applied ============
-			{
+			if constexpr (DV) {
 				if (nz_on && attempt == 0) {
 					const double rate = Pq->nz.rate, scale = Pq->nz.scale;
 					sfor<NU>([&](auto I) { const double v = rate * cn[I] + scale * z[I]; cn[I] = rs ? 0.0 : v; });
@@ -606,6 +804,7 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 			}
 			__builtin_amdgcn_sched_barrier(0);
 
+			LE_PK(2);
 			// ================= A2 mj_crb + A9 RNE backward pass, one sweep leaf -> root =================
 			double qM[NV > 0 ? NV : 1][NV > 0 ? NV : 1];  // [i][a], a = i or an ancestor of i (the other entries never exist)
 			double csum[NB][6], crbs[NB][10];             // forces / composite inertias of a body's children, summed as the sweep passes them
@@ -613,10 +812,12 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 			auto fetch_body = [&](auto Bn) {
 				constexpr int nb = Bn;
 				constexpr int q0 = LD::slot(nb);
-				if constexpr (T::body_jnt[nb] >= 0) parm[nb] = tb[nb].armature;
-				const Pair c0 = lp[64 * q0], c1 = lp[64 * (q0 + 1)], c2 = lp[64 * (q0 + 2)];
-				pcf[nb][0] = c0.a; pcf[nb][1] = c0.b; pcf[nb][2] = c1.a; pcf[nb][3] = c1.b; pcf[nb][4] = c2.a; pcf[nb][5] = c2.b;
-				if constexpr (LD::cin_slot(nb) >= 0) {
+				if constexpr (DP && T::body_jnt[nb] >= 0) parm[nb] = tb[nb].armature;
+				if constexpr (DV) {
+					const Pair c0 = lp[64 * q0], c1 = lp[64 * (q0 + 1)], c2 = lp[64 * (q0 + 2)];
+					pcf[nb][0] = c0.a; pcf[nb][1] = c0.b; pcf[nb][2] = c1.a; pcf[nb][3] = c1.b; pcf[nb][4] = c2.a; pcf[nb][5] = c2.b;
+				}
+				if constexpr (DP && LD::cin_slot(nb) >= 0) {
 					constexpr int cs = LD::cin_slot(nb);
 					for (int k = 0; k < 5; k++) {
 						const Pair c = lp[64 * (cs + k)];
@@ -633,42 +834,76 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 				constexpr int b = NB - 1 - Bi;
 				constexpr int p = T::body_parentid[b], j = T::body_jnt[b];
 				if constexpr (LD::needed(b)) {
-					touch_v(pcf[b][0]);
-					if constexpr (j >= 0) touch_s(parm[b]);
+					if constexpr (DV) touch_v(pcf[b][0]);
+					else if constexpr (DP && LD::cin_slot(b) >= 0) touch_v(pcb[b][0]);
+					if constexpr (DP && j >= 0) touch_s(parm[b]);
 					{
 						constexpr int nb = [] { for (int c = b - 1; c >= 1; c--) if (LD::needed(c)) return c; return 0; }();
 						if constexpr (nb > 0) fetch_body(IC<nb>{});
 					}
-					double cf[6] = { pcf[b][0], pcf[b][1], pcf[b][2], pcf[b][3], pcf[b][4], pcf[b][5] };
+					[[maybe_unused]] double cf[6] = { 0, 0, 0, 0, 0, 0 };
+					if constexpr (DV) for (int k = 0; k < 6; k++) cf[k] = pcf[b][k];
 					// (children have larger ids: their sums are complete; cset is a compile-time fact after unrolling)
 					constexpr bool has_child = [] { for (int c = b + 1; c < NB; c++) if (T::body_parentid[c] == b && LD::needed(c)) return true; return false; }();
-					if constexpr (has_child) for (int k = 0; k < 6; k++) cf[k] += csum[b][k];
-					double cb[10];  // composite inertia of the body (mj_crb)
-					if constexpr (LD::cin_slot(b) >= 0) {
-						for (int k = 0; k < 10; k++) cb[k] = pcb[b][k];
-					} else {
-						for (int k = 0; k < 10; k++) cb[k] = cin[b][k];
+					if constexpr (DV && has_child) for (int k = 0; k < 6; k++) cf[k] += csum[b][k];
+					[[maybe_unused]] double cb[10];  // composite inertia of the body (mj_crb)
+					if constexpr (DP) {
+						if constexpr (LD::cin_slot(b) >= 0) {
+							for (int k = 0; k < 10; k++) cb[k] = pcb[b][k];
+						} else {
+							for (int k = 0; k < 10; k++) cb[k] = cin[b][k];
+						}
+						if constexpr (has_child) for (int k = 0; k < 10; k++) cb[k] += crbs[b][k];
 					}
-					if constexpr (has_child) for (int k = 0; k < 10; k++) cb[k] += crbs[b][k];
 					if constexpr (j >= 0) {
-						double buf[6];
-						f[j] -= dot6r(cdof[j], cf);
-						mul_inert_vec(buf, cb, cdof[j]);
-						sfor<NV>([&](auto A) {
-							constexpr int a = A;
-							if constexpr (Q::anc(a, j)) qM[j][a] = (a == j ? parm[b] : 0.0) + dot6r(cdof[a], buf);
-						});
+						if constexpr (DV) f[j] -= dot6r(cdof[j], cf);
+						if constexpr (DP) {
+							double buf[6];
+							mul_inert_vec(buf, cb, cdof[j]);
+							sfor<NV>([&](auto A) {
+								constexpr int a = A;
+								if constexpr (Q::anc(a, j)) qM[j][a] = (a == j ? parm[b] : 0.0) + dot6r(cdof[a], buf);
+							});
+						}
 					}
 					if constexpr (p > 0 && LD::needed(p)) {
 						constexpr bool first = [] { for (int c = b + 1; c < NB; c++) if (T::body_parentid[c] == p && LD::needed(c)) return false; return true; }();
-						if constexpr (first) for (int k = 0; k < 6; k++) csum[p][k] = cf[k];
-						else for (int k = 0; k < 6; k++) csum[p][k] += cf[k];
-						if constexpr (first) for (int k = 0; k < 10; k++) crbs[p][k] = cb[k];
-						else for (int k = 0; k < 10; k++) crbs[p][k] += cb[k];
+						if constexpr (DV) {
+							if constexpr (first) for (int k = 0; k < 6; k++) csum[p][k] = cf[k];
+							else for (int k = 0; k < 6; k++) csum[p][k] += cf[k];
+						}
+						if constexpr (DP) {
+							if constexpr (first) for (int k = 0; k < 10; k++) crbs[p][k] = cb[k];
+							else for (int k = 0; k < 10; k++) crbs[p][k] += cb[k];
+						}
 					}
 				}
 				__builtin_amdgcn_sched_barrier(0);
 			});
+			LE_PK(3);
+			if constexpr (DUO && DV) {
+				// ---- V's half ends here: qfrc_smooth to P, then P's verdict on the step
+				sfor<(NV + 1) / 2>([&](auto K) {
+					constexpr int k = K;
+					lp[64 * (XS + k)] = Pair{ f[2 * k], 2 * k + 1 < NV ? f[2 * k + 1 < NV ? 2 * k + 1 : 0] : 0.0 };
+				});
+				LE_PK(4);
+				le_barrier();  // (A) qfrc_smooth is in LDS; P's factors are ready
+				LE_PK(5);
+				le_barrier();  // (B) P has solved and either integrated or -- bad qacc -- reset its lanes
+				const int code = (int)lp[64 * MAIL].a;
+				LE_PK(6);
+				if (!(__builtin_amdgcn_readfirstlane(code) & 8)) {  // (bit 3: P's ballot, the same in every lane)
+					badp_next = (code & 2) != 0;
+					badv_next = (code & 1) != 0;
+					break;
+				}
+				const bool bada = (code & 4) != 0;  // mj_checkAcc reset this lane: the forward pass runs once more
+				sfor<NU>([&](auto I) { cn[I] = bada ? 0.0 : cn[I]; });
+				time = bada ? 0.0 : time;
+				wasreset = wasreset || bada;
+				continue;
+			}
 			if (e_on) {  // mj_energyVel: 0.5 qvel' M qvel (mj_energyPos was gathered along the sweep)
 				double ke = 0, qv[NV > 0 ? NV : 1];
 				sfor<NV>([&](auto I) { qv[I] = lp[64 * I].b; });
@@ -685,49 +920,69 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 			// ================= A3 mj_factorM + A12 mj_fwdAcceleration; A16's (M + h B) factor and solve beside them =================
 			// L'DL in place, pivots from the last dof up: row k scaled by 1 / D_k, then row i -= L_ki * (row k restricted to i's ancestors)
 			const bool damp_on = m.eulerdamp != 0;
+			constexpr bool FH = true;
 			double qH[NV > 0 ? NV : 1][NV > 0 ? NV : 1], dinv[NV > 0 ? NV : 1], hinv[NV > 0 ? NV : 1];
-			sfor<NV>([&](auto I) {
-				sfor<NV>([&](auto A) {
-					constexpr int i = I, a = A;
-					if constexpr (Q::anc(a, i)) qH[i][a] = qM[i][a] + (a == i ? tb[T::jnt_bodyid[i]].hdamping : 0.0);
+			if constexpr (FH) {
+				sfor<NV>([&](auto I) {
+					sfor<NV>([&](auto A) {
+						constexpr int i = I, a = A;
+						if constexpr (Q::anc(a, i)) qH[i][a] = qM[i][a] + (a == i ? tb[T::jnt_bodyid[i]].hdamping : 0.0);
+					});
 				});
-			});
+			}
 			sfor<NV>([&](auto Ki) {
 				constexpr int k = NV - 1 - Ki;
 				dinv[k] = frcp(qM[k][k]);
-				hinv[k] = frcp(qH[k][k]);
+				if constexpr (FH) hinv[k] = frcp(qH[k][k]);
 				sfor<NV>([&](auto Ii) {
 					constexpr int i = NV - 1 - Ii;  // ancestors of k, nearest first
 					if constexpr (i < k && Q::anc(i, k)) {
-						const double tm = qM[k][i] * dinv[k], th = qH[k][i] * hinv[k];
+						const double tm = qM[k][i] * dinv[k];
+						[[maybe_unused]] double th = 0;
+						if constexpr (FH) th = qH[k][i] * hinv[k];
 						sfor<NV>([&](auto A) {
 							constexpr int a = A;
 							if constexpr (Q::anc(a, i)) {
 								qM[i][a] -= tm * qM[k][a];
-								qH[i][a] -= th * qH[k][a];
+								if constexpr (FH) qH[i][a] -= th * qH[k][a];
 							}
 						});
 						qM[k][i] = tm;
-						qH[k][i] = th;
+						if constexpr (FH) qH[k][i] = th;
 					}
 				});
 			});
 			// x = M^-1 f and y = (M + h B)^-1 f: L' sweep, D, L sweep
 			double x[NV > 0 ? NV : 1], y[NV > 0 ? NV : 1];
+			if constexpr (DUO && DP && NV > 0) {  // (the factors BEFORE the rendezvous: left alone the compiler sinks them behind it, next to the solves)
+				touch_v(dinv[0]);
+				if constexpr (FH) touch_v(hinv[0]);
+			}
+			LE_PK(4);
+			if constexpr (DUO && DP) {
+				le_barrier();  // (A) V's qfrc_smooth
+				LE_PK(5);
+				sfor<(NV + 1) / 2>([&](auto K) {
+					constexpr int k = K;
+					const Pair v = lp[64 * (XS + k)];
+					f[2 * k] = v.a;
+					if constexpr (2 * k + 1 < NV) f[2 * k + 1] = v.b;
+				});
+			}
 			sfor<NV>([&](auto I) { x[I] = f[I]; y[I] = f[I]; });
 			sfor<NV>([&](auto Ii) {
 				constexpr int i = NV - 1 - Ii;
 				sfor<NV>([&](auto A) {
 					constexpr int a = A;
-					if constexpr (a < i && Q::anc(a, i)) { x[a] -= qM[i][a] * x[i]; y[a] -= qH[i][a] * y[i]; }
+					if constexpr (a < i && Q::anc(a, i)) { x[a] -= qM[i][a] * x[i]; if constexpr (FH) y[a] -= qH[i][a] * y[i]; }
 				});
 			});
-			sfor<NV>([&](auto I) { x[I] *= dinv[I]; y[I] *= hinv[I]; });
+			sfor<NV>([&](auto I) { x[I] *= dinv[I]; if constexpr (FH) y[I] *= hinv[I]; });
 			sfor<NV>([&](auto I) {
 				constexpr int i = I;
 				sfor<NV>([&](auto Ai) {
 					constexpr int a = NV - 1 - Ai;  // nearest ancestor first, as mj_solveLD walks them
-					if constexpr (a < i && Q::anc(a, i)) { x[i] -= qM[i][a] * x[a]; y[i] -= qH[i][a] * y[a]; }
+					if constexpr (a < i && Q::anc(a, i)) { x[i] -= qM[i][a] * x[a]; if constexpr (FH) y[i] -= qH[i][a] * y[a]; }
 				});
 			});
 			sfor<NV>([&](auto I) { qacc[I] = x[I]; qaccd[I] = damp_on ? y[I] : x[I]; });
@@ -746,6 +1001,14 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 			sfor<NU>([&](auto I) { cn[I] = bada ? 0.0 : cn[I]; });
 			time = bada ? 0.0 : time;
 			wasreset = wasreset || bada;
+			if constexpr (DUO && DP) {
+				lp[64 * MAIL] = Pair{ (double)(8 | (bada ? 4 : 0)), 0.0 };
+				le_barrier();  // (B, retry) V runs its half again on the reset state
+			}
+		}
+		if constexpr (DUO && DV) {
+			time += dt;
+			continue;
 		}
 
 		if (last) {  // mj_advance's qacc_warmstart = qacc; mjData.energy of the launch's last step
@@ -769,21 +1032,56 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 			badv_next |= bad_val(s2.b);
 		});
 		time += dt;
+		if constexpr (DUO && DP) {
+			lp[64 * MAIL] = Pair{ (double)((badp_next ? 2 : 0) | (badv_next ? 1 : 0)), 0.0 };
+			LE_PK(6);
+			le_barrier();  // (B) the new state and its verdicts
+			LE_PK(7);
+		}
 	}
+#ifdef MJB_LE_PROBE
+	if (env_raw == env_lo) for (int k = 0; k < 8; k++) P->s.sensordata[(ROLE == 4 || ROLE == 2 ? 8 : 0) + k] = (double)pk_acc[k] / nsteps;
+#endif
 
 	// ---- the launch's state back to HBM (store_state of the generic kernels; sensordata went out from the last step)
 	{  // (tail lanes store the last env's state a second time)
 		const DevState MJB_AS4 &s = P->s;
-		sfor<NV>([&](auto I) {
-			const Pair s2 = lp[64 * I];
-			s.qpos[ev * NV + I] = s2.a;
-			s.qvel[ev * NV + I] = s2.b;
-		});
-		sfor<NU>([&](auto I) { s.ctrlnoise[ev * NU + I] = cn[I]; });
-		if (nz_on) sfor<NU>([&](auto I) { s.ctrl[ev * NU + I] = cn[I]; });
-		else if (__builtin_amdgcn_ballot_w64(wasreset)) sfor<NU>([&](auto I) { const double c = pinv(s.ctrl[ev * NU + I]); s.ctrl[ev * NU + I] = wasreset ? 0.0 : c; });
-		s.time[ev] = time;
+		if constexpr (DP) {
+			sfor<NV>([&](auto I) {
+				const Pair s2 = lp[64 * I];
+				s.qpos[ev * NV + I] = s2.a;
+				s.qvel[ev * NV + I] = s2.b;
+			});
+			s.time[ev] = time;
+		}
+		if constexpr (DV) {
+			sfor<NU>([&](auto I) { s.ctrlnoise[ev * NU + I] = cn[I]; });
+			if (nz_on) sfor<NU>([&](auto I) { s.ctrl[ev * NU + I] = cn[I]; });
+			else if (__builtin_amdgcn_ballot_w64(wasreset)) sfor<NU>([&](auto I) { const double c = pinv(s.ctrl[ev * NU + I]); s.ctrl[ev * NU + I] = wasreset ? 0.0 : c; });
+		}
 	}
+}
+
+// LDS of a DUO block: the solo layout under a budget reduced by the exchange slots, then those
+template <class T, int LP> constexpr int duo_bytes() { return (Lds<T, LP - DuoSlots<T::NV>::n>::nslots() + DuoSlots<T::NV>::n) * 64 * 16; }
+
+// ... and of a pipelined DUO block (roles 3 / 4): every needed body's cinert, every dof's cdof, the pose ring, the exchange slots
+template <class T> constexpr int duo2_bytes() { return (Lds<T, (1 << 20)>::nslots() + 3 * T::NV + 12 + DuoSlots<T::NV>::n) * 64 * 16; }
+template <class T, int LP>
+DEVI void lane_env_duo2(const KernelParams MJB_AS4 *__restrict__ P, const int nsteps, const unsigned int step0, const int env_lo, const int env_hi,
+                        unsigned char *const smem_le)
+{
+	if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64) lane_env_body<T, LP, 3>(P, nsteps, step0, env_lo, env_hi, smem_le);
+	else lane_env_body<T, LP, 4>(P, nsteps, step0, env_lo, env_hi, smem_le);
+}
+
+// the DUO kernel's body: wavefront 0 of the block takes the position half, wavefront 1 the velocity half (blockDim.x = 128)
+template <class T, int LP>
+DEVI void lane_env_duo(const KernelParams MJB_AS4 *__restrict__ P, const int nsteps, const unsigned int step0, const int env_lo, const int env_hi,
+                       unsigned char *const smem_le)
+{
+	if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64) lane_env_body<T, LP, 1>(P, nsteps, step0, env_lo, env_hi, smem_le);
+	else lane_env_body<T, LP, 2>(P, nsteps, step0, env_lo, env_hi, smem_le);
 }
 
 }  // namespace mjb_le

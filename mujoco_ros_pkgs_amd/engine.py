@@ -291,6 +291,13 @@ class Batch:
         topo = int(self.lib.mjb_lane_env_info(self.ptr, C.byref(used)))
         return topo, bool(used.value)
 
+    def set_lane_env_form(self, form):
+        """Process-wide: -1 by batch size, 0 one wavefront per 64 envs, 1 two (position / velocity halves), 2 two, pipelined (mjb_lane_env_set_form)."""
+        return int(self.lib.mjb_lane_env_set_form(int(form)))
+
+    def lane_env_last_form(self):
+        return int(self.lib.mjb_lane_env_last_form())
+
     def lane_env_error(self):
         """Why the hiprtc build of this process's last lane = env topology was not available ('' if none failed)."""
         return self.lib.mjb_lane_env_error().decode()

@@ -26,6 +26,17 @@ def eng(oracle_built):
     return engine, mjcf, oracle_built
 
 
+@pytest.fixture(autouse=True, params=[0, 1, 2], ids=["one_wave", "two_halves", "pipelined"])
+def form(request, eng):
+    """Every test runs on the kernel's three forms (mjb_lane_env_set_form): one wavefront per 64 envs, two wavefronts splitting the step
+    into its position and velocity halves, two wavefronts pipelined body by body.  (A forced form falls back where it does not fit.)"""
+    engine = eng[0]
+    lib = engine.binding.load_library()
+    lib.mjb_lane_env_set_form(request.param)
+    yield request.param
+    lib.mjb_lane_env_set_form(-1)
+
+
 def tree_state(model, nenv, seed):
     rng = np.random.default_rng(seed)
     qpos = np.tile(np.asarray(model["qpos0"], dtype=np.float64), (nenv, 1))
@@ -364,3 +375,26 @@ def test_hiprtc_topology_beyond_the_lean_lds_budget(eng):
             oq, ov, _ = po.rollout(model, qpos[e:e + 1], qvel[e:e + 1], K, noise_std=1.0, noise_rate=0.1, seed=17, env_offset=int(e))
             _close(q[e], oq[0], 1e-9, f"two-arm env {e} of {nenv} qpos")
             _close(v[e], ov[0], 1e-9, f"two-arm env {e} of {nenv} qvel")
+
+
+def test_form_follows_batch_size(eng):
+    """The automatic rule (mjb_lane_env_set_form(-1)): pipelined while a block has a CU's LDS to itself (<= 64 x CUs envs), two halves up to
+    twice that, one wavefront beyond; the three agree with the oracle on sampled envs."""
+    engine, mjcf, po = eng
+    import torch
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    lib = engine.binding.load_library()
+    lib.mjb_lane_env_set_form(-1)
+    model = mjcf.load_asset("franka_like")
+    cm = engine.CompiledModel(model)
+    for nenv, want in ((4096, 2), (64 * ncu, 2), (64 * ncu + 64, 1), (128 * ncu, 1), (128 * ncu + 64, 0)):
+        qpos, qvel = random_franka_state(model, nenv, 5)
+        b = make(engine, cm, nenv, qpos, qvel, 1)
+        b.set_ctrl_noise(10.0, 0.1, 7, 0)
+        b.step(12)
+        assert b.lane_env_info()[1] and lib.mjb_lane_env_last_form() == want, (nenv, lib.mjb_lane_env_last_form(), want)
+        q = b.get("qpos")
+        for e in (0, nenv // 2 + 1, nenv - 1):
+            oq, _, _ = po.rollout(model, qpos[e:e + 1], qvel[e:e + 1], 12, noise_std=10.0, noise_rate=0.1, seed=7, env_offset=int(e))
+            _close(q[e], oq[0], 1e-9, f"env {e} of {nenv}")
+        b.close()

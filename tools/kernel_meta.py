@@ -27,9 +27,12 @@ if os.path.exists(f):
     txt = open(f).read()
     for blk in re.split(r"\n  - \.agpr_count", txt)[1:]:
         name = re.search(r"\.name:\s+(\S+)", blk)
-        mm = name and re.search(r"mjb_lane_env_kernelI\d+LeTopo_(\w+?)Li(\d+)E", name.group(1))
+        mm = name and re.search(r"mjb_lane_env_(duo2_|duo_|)kernelI\d+LeTopo_(\w+?)(?:Li(\d+))?E", name.group(1))
         if not mm:
             continue
+        form = {"": "", "duo_": ", two halves", "duo2_": ", pipelined"}[mm.group(1)]
+        mm = (None, mm.group(2), (mm.group(3) or "-") + form)
+        mm = type("M", (), {"group": lambda self, i, _m=mm: _m[i]})()
         get = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1))  # noqa: E731
         agpr = int(re.match(r":\s+(\d+)", blk).group(1))
         print(f"<{mm.group(1)}, {mm.group(2)}>".ljust(44) + f" {get('vgpr_count'):5d} {agpr:5d} {get('vgpr_spill_count'):11d} {get('sgpr_spill_count'):11d} {get('private_segment_fixed_size'):9d}")

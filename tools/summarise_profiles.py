@@ -41,7 +41,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_f64"):
         continue
     acc = {}
     for row in csv.DictReader(open(cc)):
-        if "mjb_step_kernel" not in row["Kernel_Name"] and "mjb_lane_env_kernel" not in row["Kernel_Name"]:
+        if "mjb_step_kernel" not in row["Kernel_Name"] and "mjb_lane_env_" not in row["Kernel_Name"]:
             continue
         acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
         if meta is None:
