@@ -214,7 +214,8 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 	constexpr int LPE = PIPE ? (1 << 20) : (DUO ? LP - DuoSlots<NV>::n : LP);
 	using LD = Lds<T, LPE>;
 	static_assert(LD::slot(T::NBODY) <= LPE, "lane = env kernel: state and forces of the topology need more LDS than this instantiation's budget");
-	constexpr int CD0 = LD::nslots(), RING = CD0 + 3 * NV;                          // (PIPE) three pair slots per dof's cdof, then 2 x 6 of the pose ring
+	constexpr int LASTB = [] { for (int c = NB - 1; c >= 1; c--) if (LD::needed(c)) return c; return 0; }();  // the leaf the composite-inertia sweep starts at
+	constexpr int RING = LD::nslots();                                              // (PIPE) 2 x 6 pair slots of the pose ring behind the solo layout
 	constexpr int XS = PIPE ? RING + 12 : LD::nslots(), MAIL = XS + (NV + 1) / 2;  // (DUO) pair slots of qfrc_smooth, and of P's verdicts for V
 	const int lane_le = DUO ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
 	Pair *const lp = reinterpret_cast<Pair *>(smem_le) + lane_le;  // pair slot q of this lane: lp[64 * q]
@@ -443,6 +444,15 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 							const Pair a0 = lp[64 * rg], a1 = lp[64 * (rg + 1)], a2 = lp[64 * (rg + 2)], a3 = lp[64 * (rg + 3)], a4 = lp[64 * (rg + 4)], a5 = lp[64 * (rg + 5)];
 							xp[0] = a0.a; xp[1] = a0.b; xp[2] = a1.a; xm[0] = a1.b; xm[1] = a2.a; xm[2] = a2.b; xm[3] = a3.a; xm[4] = a3.b; xm[5] = a4.a; xm[6] = a4.b; xm[7] = a5.a; xm[8] = a5.b;
 						}
+						if constexpr (b == LASTB) {
+							// the LAST needed body's cinert came with its pose: P computes that one itself and goes from its last pose straight into the
+							// composite-inertia sweep, which starts at this body -- it never waits for V's last phase
+							for (int k = 0; k < 5; k++) {
+								const Pair c = lp[64 * (c0 + k)];
+								ci[2 * k] = c.a;
+								ci[2 * k + 1] = c.b;
+							}
+						} else
 						{
 							// cinert about the tree root's origin, as in the fused sweep: X Ib X' + the com offset's terms; handed to P's composite-inertia sweep
 							const LeTapeBody MJB_AS4 &tj = tb[b];
@@ -505,7 +515,6 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 								for (int k = 0; k < 3; k++) cd[k] = xaxis[k];
 								cross3(cd + 3, xaxis, off);
 							}
-							for (int k = 0; k < 3; k++) lp[64 * (CD0 + 3 * j + k)] = Pair{ cd[2 * k], cd[2 * k + 1] };
 							if constexpr (p == 0 || !LD::needed(p)) {
 								for (int k = 0; k < 6; k++) { cvel[b][k] = cd[k] * qv; cacc[b][k] = pa[k]; }
 							} else {
@@ -613,7 +622,7 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 				if constexpr (LD::needed(b)) {
 					// cinert about the tree root's origin (mju_inertCom with that offset)
 					[[maybe_unused]] double ci[10];
-					if constexpr (ROLE != 3) {
+					if constexpr (ROLE != 3 || b == LASTB) {
 						double dif[3];
 						if constexpr (r == b) { dif[0] = xipos[0] - pos[0]; dif[1] = xipos[1] - pos[1]; dif[2] = xipos[2] - pos[2]; }
 						else for (int k = 0; k < 3; k++) dif[k] = xipos[k] - xpos[r][k];
@@ -653,8 +662,7 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 					} else {
 						for (int k = 0; k < 6; k++) { pv[k] = cvel[p][k]; pa[k] = cacc[p][k]; }
 					}
-					if constexpr (ROLE == 3) {
-					} else if constexpr (j >= 0) {
+					if constexpr (j >= 0) {
 						double *cd = cdof[j];
 						if constexpr (T::jnt_type[j] == MJB_JNT_SLIDE) {
 							cd[0] = cd[1] = cd[2] = 0;
@@ -678,7 +686,7 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 					} else if constexpr (DV) {
 						for (int k = 0; k < 6; k++) { cvel[b][k] = pv[k]; cacc[b][k] = pa[k]; }
 					}
-					if constexpr (DP && ROLE != 3) {  // the composite-inertia sweep reads it back
+					if constexpr (DP && (ROLE != 3 || b == LASTB)) {  // the composite-inertia sweep reads it back (pipelined duo: the last body's, which V's force computation reads too)
 						if constexpr (LD::cin_slot(b) >= 0) {
 							constexpr int c0 = LD::cin_slot(b);
 							for (int k = 0; k < 5; k++) lp[64 * (c0 + k)] = Pair{ ci[2 * k], ci[2 * k + 1] };
@@ -720,19 +728,6 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 			});
 
 			LE_PK(0);
-			if constexpr (PIPE) {
-				le_barrier();  // (F) V's last cdof is in LDS
-				if constexpr (ROLE == 3) {
-					sfor<NV>([&](auto J) {
-						constexpr int j = J;
-						for (int k = 0; k < 3; k++) {
-							const Pair c = lp[64 * (CD0 + 3 * j + k)];
-							cdof[j][2 * k] = c.a;
-							cdof[j][2 * k + 1] = c.b;
-						}
-					});
-				}
-			}
 			LE_PK(1);
 			// ============ A8 mj_passive, the injector's OU update, A12 mj_fwdActuation (joint transmission), qfrc_applied ============
 			if constexpr (DV) {
@@ -1066,7 +1061,7 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 template <class T, int LP> constexpr int duo_bytes() { return (Lds<T, LP - DuoSlots<T::NV>::n>::nslots() + DuoSlots<T::NV>::n) * 64 * 16; }
 
 // ... and of a pipelined DUO block (roles 3 / 4): every needed body's cinert, every dof's cdof, the pose ring, the exchange slots
-template <class T> constexpr int duo2_bytes() { return (Lds<T, (1 << 20)>::nslots() + 3 * T::NV + 12 + DuoSlots<T::NV>::n) * 64 * 16; }
+template <class T> constexpr int duo2_bytes() { return (Lds<T, (1 << 20)>::nslots() + 12 + DuoSlots<T::NV>::n) * 64 * 16; }
 template <class T, int LP>
 DEVI void lane_env_duo2(const KernelParams MJB_AS4 *__restrict__ P, const int nsteps, const unsigned int step0, const int env_lo, const int env_hi,
                         unsigned char *const smem_le)
