@@ -261,10 +261,12 @@ const char *mjb_lane_env_error(void);
  * qfrc_smooth) side by side on two SIMDs of a CU, both computing the poses; 2 = two, PIPELINED: one wavefront computes every pose once and
  * hands it on body by body through LDS (a workgroup barrier per body), the other follows one body behind with cinert, cdof, velocities and
  * forces and hands cdof / cinert / qfrc_smooth back -- nothing is computed twice.  A lone wavefront on a SIMD issues one instruction every ~4
- * cycles whatever it is, so while the batch leaves SIMDs idle the step's length is the longest instruction stream: form 2 runs whenever a block has a
- * CU's LDS to itself (<= 64 x CUs envs: 16 384 on MI355X), form 1 up to twice that, form 0 beyond.  -1 = that rule (default; the environment
- * variable MJB_LANE_ENV_DUO = 0 / 1 / 2 overrides it).  A forced form that does not fit (LDS) falls back to the next lower one.  Results of the
- * three forms agree to rounding.  Returns the previous setting.  mjb_lane_env_last_form: the form of this process's last lane = env launch (-1: none yet).
+ * cycles whatever it is, so while the batch leaves SIMDs idle the step's length is the longest instruction stream; 3 = THREE: the first wavefront runs
+ * the pose chain and nothing else, the second follows it with cinert and cdof and then takes the composite inertias, qM, the factors, the solves and
+ * Euler, the third the velocities and forces.  Form 3 runs whenever a block has a CU's LDS to itself (<= 64 x CUs envs: 16 384 on MI355X; form 2 is
+ * the same with two wavefronts, by request only; run-time (hiprtc) topologies take form 2 there), form 1 up to twice that, form 0 beyond.  -1 = that rule (default; the environment
+ * variable MJB_LANE_ENV_DUO = 0 / 1 / 2 / 3 overrides it).  A forced form that does not fit (LDS) falls back to the next lower one.  Results of the
+ * four forms agree to rounding.  Returns the previous setting.  mjb_lane_env_last_form: the form of this process's last lane = env launch (-1: none yet).
  * Measurement / test knob, no reference counterpart. */
 int mjb_lane_env_set_form(int form);
 int mjb_lane_env_last_form(void);

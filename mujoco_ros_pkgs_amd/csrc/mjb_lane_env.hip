@@ -59,6 +59,14 @@ __global__ void __launch_bounds__(128) mjb_lane_env_duo2_kernel(const KernelPara
 	lane_env_duo2<T, 160>(P, nsteps, step0, env_lo, env_hi, smem_le);
 }
 
+template <class T>
+__global__ void __launch_bounds__(192) mjb_lane_env_trio_kernel(const KernelParams MJB_AS4 *__restrict__ P, const int nsteps, const unsigned int step0,
+                                                                const int env_lo, const int env_hi)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_le[];
+	lane_env_trio<T, 160>(P, nsteps, step0, env_lo, env_hi, smem_le);
+}
+
 template <class T> bool topo_matches(const mjb_model_desc &h)
 {
 	if (h.nbody != T::NBODY || h.nq != T::NQ || h.nv != T::NV || h.nu != T::NU || h.njnt != T::NJNT || h.nsite != T::NSITE ||
@@ -222,8 +230,9 @@ std::string source_dir()
 	return ".";
 }
 
-const JitKernel &jit_get(const mjb_model_desc &h, int lp, int duo)  // duo: 0 solo, 1 two halves, 2 pipelined
+const JitKernel &jit_get(const mjb_model_desc &h, int lp, int duo)  // duo: 0 solo, 1 two halves, 2 pipelined (3, the trio, is compiled-in topologies only: pipelined)
 {
+	if (duo > 2) duo = 2;
 	int dev = 0;
 	(void)hipGetDevice(&dev);
 	const std::string topo = topo_source(h);
@@ -285,7 +294,7 @@ static int le_form_override = -1, le_form_last = -1;
 int mjb_lane_env_set_form(int form)
 {
 	const int prev = le_form_override;
-	le_form_override = (form >= 0 && form <= 2) ? form : -1;
+	le_form_override = (form >= 0 && form <= 3) ? form : -1;
 	return prev;
 }
 int mjb_lane_env_last_form(void) { return le_form_last; }
@@ -379,9 +388,12 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 	int duo = (wl == 64 && lp >= 80 && duo_mode != 0 && (duo_mode > 0 || waves <= (duo_max_waves >= 0 ? duo_max_waves : 2 * ncu))) ? 1 : 0;
 	// ... pipelined (nothing computed twice) when a workgroup has a CU's LDS to itself.  MJB_LANE_ENV_DUO=1: the two-halves form only
 	if (duo && lp == 160 && duo_mode != 1) duo = 2;
+	// ... and THREE wavefronts (the pose chain alone on the first) while three SIMDs per block are there: the same LDS layout, so the same bound
+	if (duo == 2 && duo_mode != 2 && 3 * waves <= 4 * ncu) duo = 3;
 	if (duo_mode > 0 && lp < 80) lp = 80, duo = 1;  // (a forced two-wavefront form on a batch that would run four wavefronts per CU: two per CU)
 	if (topo == MJB_LE_TOPO_JIT) {
 		if (!h) return (int)hipErrorInvalidValue;
+		if (duo > 2) duo = 2;  // (run-time topologies: up to the pipelined two-wavefront form)
 		{  // a larger model than the compiled-in ones: the smallest LDS budget its (qpos, qvel) pairs and body forces fit (fewer wavefronts per CU then)
 			int need = h->nv;
 			for (int b = 1; b < h->nbody; b++) {
@@ -395,7 +407,7 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 				return MJB_LE_UNAVAILABLE;
 			}
 			if (fit > lp) lp = fit;
-			if (duo == 2 && need + 5 * ((need - h->nv) / 3) + 3 * h->nv + 12 + (h->nv + 1) / 2 + 1 > 160) duo = 1;
+			if (duo == 2 && need + 5 * ((need - h->nv) / 3) + 12 + (h->nv + 1) / 2 + 1 > 160) duo = 1;
 			if (duo == 1 && need + (h->nv + 1) / 2 + 1 > lp) duo = 0;
 		}
 		const JitKernel &k = jit_get(*h, lp, duo);
@@ -407,6 +419,7 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 		int a_nsteps = nsteps, a_lo = env_lo, a_hi = env_hi;
 		unsigned int a_step0 = step0;
 		void *args[] = { (void *)&Pd, (void *)&a_nsteps, (void *)&a_step0, (void *)&a_lo, (void *)&a_hi };
+		if (duo > 2) duo = 2;
 		le_form_last = duo;
 		return (int)hipModuleLaunchKernel(k.fn, grid.x, 1, 1, duo ? 128 : block.x, 1, 1, 0, (hipStream_t)stream, args, nullptr);
 	}
@@ -440,9 +453,20 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 		hipLaunchKernelGGL(kern, grid, dim3(128), bytes, (hipStream_t)stream, (const KernelParams MJB_AS4 *)Pdev, nsteps, step0, env_lo, env_hi); \
 		return (int)hipGetLastError();                                                                                                        \
 	}
+#define MJB_LE_GO_TRIO(T)                                                                                                                   \
+	if constexpr (duo2_bytes<T>() <= 160 * 1024) {                                                                                            \
+		auto kern = mjb_lane_env_trio_kernel<T>;                                                                                              \
+		constexpr int bytes = duo2_bytes<T>();                                                                                                \
+		static const hipError_t attr = bytes > 65536 ? hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) : hipSuccess; \
+		if (attr != hipSuccess) return (int)attr;                                                                                             \
+		le_form_last = 3;                                                                                                                     \
+		hipLaunchKernelGGL(kern, grid, dim3(192), bytes, (hipStream_t)stream, (const KernelParams MJB_AS4 *)Pdev, nsteps, step0, env_lo, env_hi); \
+		return (int)hipGetLastError();                                                                                                        \
+	}
 #define MJB_LE_X(id, T)                      \
 	if (topo == id) {                        \
-		if (duo == 2) MJB_LE_GO_DUO2(T)      \
+		if (duo == 3) MJB_LE_GO_TRIO(T)      \
+		if (duo >= 2) MJB_LE_GO_DUO2(T)      \
 		if (duo && lp == 160) MJB_LE_GO_DUO(T, 160) \
 		if (duo && lp == 80) MJB_LE_GO_DUO(T, 80)   \
 		if (lp == 160) MJB_LE_GO(T, 160)     \
@@ -454,5 +478,6 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 #undef MJB_LE_GO
 #undef MJB_LE_GO_DUO
 #undef MJB_LE_GO_DUO2
+#undef MJB_LE_GO_TRIO
 	return (int)hipErrorInvalidValue;
 }

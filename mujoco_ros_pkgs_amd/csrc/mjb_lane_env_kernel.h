@@ -207,9 +207,14 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 	// (roles 3 / 4 = the PIPELINED duo: P computes every pose and cinert ONCE and passes them on body by body -- a workgroup barrier per body, a
 	//  two-deep ring of (xpos, xmat) in LDS -- V follows one body behind with cdof, velocities and forces and passes cdof back for P's composite-inertia
 	//  sweep.  Nothing is computed twice; needs every needed body's cinert and cdof in LDS: Duo2<T>.)
-	constexpr bool DP = ROLE == 0 || ROLE == 1 || ROLE == 3, DV = ROLE == 0 || ROLE == 2 || ROLE == 4, DUO = ROLE != 0;  // this wavefront does the position half / the velocity half
+	// (roles 5 / 6 / 7 = the TRIO, three wavefronts per 64 envs: 5 = P runs the pose chain and nothing else; 6 = C follows it through the ring with cinert
+	//  and cdof, then takes the composite-inertia sweep, qM, both factors, the solves and Euler; 7 = V as role 4, with its own cinert of every body.
+	//  P's sweep is the step's critical chain: everything that is not a pose is off it.)
+	constexpr bool DP = ROLE == 0 || ROLE == 1 || ROLE == 3 || ROLE == 6, DV = ROLE == 0 || ROLE == 2 || ROLE == 4 || ROLE == 7, DUO = ROLE != 0;  // this wavefront does the position half (inertias, factors, solves, Euler) / the velocity half
 	constexpr bool PIPE = ROLE >= 3;
-	constexpr bool SENSF = ROLE == 0 || ROLE == 2 || ROLE == 3;  // frame sensors: who holds the poses (and, of two, who has the time)
+	constexpr bool POSE = ROLE <= 3 || ROLE == 5, RINGC = ROLE == 4 || ROLE == 6 || ROLE == 7;  // computes the poses / takes them from the ring
+	constexpr bool EPOS = ROLE == 0 || ROLE == 1 || ROLE == 3 || ROLE == 5;                       // gathers mj_energyPos along its pose sweep
+	constexpr bool SENSF = ROLE == 0 || ROLE == 2 || ROLE == 3 || ROLE == 5;  // frame sensors: who holds the poses (and, of two, who has the time)
 	using Q = Tq<T>;
 	constexpr int LPE = PIPE ? (1 << 20) : (DUO ? LP - DuoSlots<NV>::n : LP);
 	using LD = Lds<T, LPE>;
@@ -346,7 +351,9 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 			}
 			const LeTapeAct MJB_AS4 *const ta = reinterpret_cast<const LeTapeAct MJB_AS4 *>(tb + NB);
 			const bool e_on = DP && last && (m.enableflags & MJB_ENBL_ENERGY);
-			const bool eg_on = e_on && !(m.disableflags & MJB_DSBL_GRAVITY);
+			bool ep_on = e_on;
+			if constexpr (EPOS != DP) ep_on = EPOS && last && (m.enableflags & MJB_ENBL_ENERGY);
+			const bool eg_on = ep_on && !(m.disableflags & MJB_DSBL_GRAVITY);
 			const bool sens_on = DV && last && !(m.disableflags & MJB_DSBL_SENSOR);  // (a tail lane rewrites the last env's values)
 			const bool sensf_on = SENSF && last && !(m.disableflags & MJB_DSBL_SENSOR);
 			double *sd = s.sensordata + ev * T::NSENSORDATA;
@@ -430,8 +437,8 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 			};
 			sfor<NB>([&](auto B) {
 				constexpr int b = B;
-				if constexpr (b > 0 && ROLE == 4) {
-					// ---- the pipelined V: body b's pose (position relative to the tree root's origin) and cinert come from P through LDS, one barrier per needed body
+				if constexpr (b > 0 && RINGC) {
+					// ---- the pipelined V (and the trio's C): body b's pose (position relative to the tree root's origin) and cinert come from P through LDS, one barrier per needed body
 					constexpr int p = T::body_parentid[b], j = T::body_jnt[b];
 					if constexpr (LD::needed(b)) {
 						constexpr int ord = (LD::slot(b) - NV) / 3, rg = RING + 6 * (ord & 1), c0 = LD::cin_slot(b);
@@ -444,7 +451,7 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 							const Pair a0 = lp[64 * rg], a1 = lp[64 * (rg + 1)], a2 = lp[64 * (rg + 2)], a3 = lp[64 * (rg + 3)], a4 = lp[64 * (rg + 4)], a5 = lp[64 * (rg + 5)];
 							xp[0] = a0.a; xp[1] = a0.b; xp[2] = a1.a; xm[0] = a1.b; xm[1] = a2.a; xm[2] = a2.b; xm[3] = a3.a; xm[4] = a3.b; xm[5] = a4.a; xm[6] = a4.b; xm[7] = a5.a; xm[8] = a5.b;
 						}
-						if constexpr (b == LASTB) {
+						if constexpr (ROLE == 4 && b == LASTB) {
 							// the LAST needed body's cinert came with its pose: P computes that one itself and goes from its last pose straight into the
 							// composite-inertia sweep, which starts at this body -- it never waits for V's last phase
 							for (int k = 0; k < 5; k++) {
@@ -482,10 +489,11 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 							ci[7] = mass * dif[1];
 							ci[8] = mass * dif[2];
 							ci[9] = mass;
-							for (int k = 0; k < 5; k++) lp[64 * (c0 + k)] = Pair{ ci[2 * k], ci[2 * k + 1] };
+							if constexpr (ROLE != 7) for (int k = 0; k < 5; k++) lp[64 * (c0 + k)] = Pair{ ci[2 * k], ci[2 * k + 1] };  // (for the composite-inertia sweep of P / of C itself)
 						}
-						double pv[6], pa[6];
-						if constexpr (p == 0 || !LD::needed(p)) {  // the world, or a jointless chain down from it: at rest
+						[[maybe_unused]] double pv[6], pa[6];
+						if constexpr (!DV) {
+						} else if constexpr (p == 0 || !LD::needed(p)) {  // the world, or a jointless chain down from it: at rest
 							for (int k = 0; k < 6; k++) pv[k] = 0;
 							pa[0] = pa[1] = pa[2] = 0;
 							for (int k = 0; k < 3; k++) pa[3 + k] = -grav[k];
@@ -493,7 +501,8 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 							for (int k = 0; k < 6; k++) { pv[k] = cvel[p][k]; pa[k] = cacc[p][k]; }
 						}
 						if constexpr (j >= 0) {
-							const double qv = lp[64 * j].b;
+							[[maybe_unused]] double qv = 0;
+							if constexpr (DV) qv = lp[64 * j].b;
 							const LeTapeBody MJB_AS4 &tj = tb[b];
 							const double ax[3] = { tj.jaxis[0], tj.jaxis[1], tj.jaxis[2] };
 							double xaxis[3];
@@ -515,29 +524,32 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 								for (int k = 0; k < 3; k++) cd[k] = xaxis[k];
 								cross3(cd + 3, xaxis, off);
 							}
-							if constexpr (p == 0 || !LD::needed(p)) {
+							if constexpr (!DV) {
+							} else if constexpr (p == 0 || !LD::needed(p)) {
 								for (int k = 0; k < 6; k++) { cvel[b][k] = cd[k] * qv; cacc[b][k] = pa[k]; }
 							} else {
 								double cdd[6];
 								cross_motion(cdd, pv, cd);
 								for (int k = 0; k < 6; k++) { cvel[b][k] = pv[k] + cd[k] * qv; cacc[b][k] = pa[k] + cdd[k] * qv; }
 							}
-						} else {
+						} else if constexpr (DV) {
 							for (int k = 0; k < 6; k++) { cvel[b][k] = pv[k]; cacc[b][k] = pa[k]; }
 						}
-						double cf[6], t0[6], t1[6];
-						mul_inert_vec(cf, ci, cacc[b]);
-						mul_inert_vec(t0, ci, cvel[b]);
-						cross_force(t1, cvel[b], t0);
-						constexpr int q0 = LD::slot(b);
-						lp[64 * q0] = Pair{ cf[0] + t1[0], cf[1] + t1[1] };
-						lp[64 * (q0 + 1)] = Pair{ cf[2] + t1[2], cf[3] + t1[3] };
-						lp[64 * (q0 + 2)] = Pair{ cf[4] + t1[4], cf[5] + t1[5] };
+						if constexpr (DV) {
+							double cf[6], t0[6], t1[6];
+							mul_inert_vec(cf, ci, cacc[b]);
+							mul_inert_vec(t0, ci, cvel[b]);
+							cross_force(t1, cvel[b], t0);
+							constexpr int q0 = LD::slot(b);
+							lp[64 * q0] = Pair{ cf[0] + t1[0], cf[1] + t1[1] };
+							lp[64 * (q0 + 1)] = Pair{ cf[2] + t1[2], cf[3] + t1[3] };
+							lp[64 * (q0 + 2)] = Pair{ cf[4] + t1[4], cf[5] + t1[5] };
+						}
 					}
-					if constexpr (b == 1) sfor<NV>([&](auto I) { qfa[I] = s.qfrc_applied[ev * NV + I]; });  // (read by the force block behind the sweep: a trip to HBM)
+					if constexpr (DV && b == 1) sfor<NV>([&](auto I) { qfa[I] = s.qfrc_applied[ev * NV + I]; });  // (read by the force block behind the sweep: a trip to HBM)
 					__builtin_amdgcn_sched_barrier(0);
 				}
-				if constexpr (b > 0 && ROLE != 4) {
+				if constexpr (b > 0 && POSE) {
 				constexpr int p = T::body_parentid[b], j = T::body_jnt[b], r = T::body_rootid[b];
 				touch_s(hA[b][0]);
 				if constexpr (j >= 0) touch_v(pq[b].a);
@@ -575,7 +587,7 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 						qmul(q, quat, ql);
 						for (int k = 0; k < 4; k++) quat[k] = q[k];
 					}
-					if (e_on && pas_on) {  // mj_energyPos: the joint spring
+					if (ep_on && pas_on) {  // mj_energyPos: the joint spring
 						const double dqs = qp - tb[b].spring;  // (last step only)
 						pe += 0.5 * tb[b].stiffness * dqs * dqs;
 					}
@@ -622,7 +634,7 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 				if constexpr (LD::needed(b)) {
 					// cinert about the tree root's origin (mju_inertCom with that offset)
 					[[maybe_unused]] double ci[10];
-					if constexpr (ROLE != 3 || b == LASTB) {
+					if constexpr (ROLE <= 2 || (ROLE == 3 && b == LASTB)) {
 						double dif[3];
 						if constexpr (r == b) { dif[0] = xipos[0] - pos[0]; dif[1] = xipos[1] - pos[1]; dif[2] = xipos[2] - pos[2]; }
 						else for (int k = 0; k < 3; k++) dif[k] = xipos[k] - xpos[r][k];
@@ -662,7 +674,8 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 					} else {
 						for (int k = 0; k < 6; k++) { pv[k] = cvel[p][k]; pa[k] = cacc[p][k]; }
 					}
-					if constexpr (j >= 0) {
+					if constexpr (ROLE == 5) {  // (the trio's P: poses only)
+					} else if constexpr (j >= 0) {
 						double *cd = cdof[j];
 						if constexpr (T::jnt_type[j] == MJB_JNT_SLIDE) {
 							cd[0] = cd[1] = cd[2] = 0;
@@ -705,7 +718,7 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 						lp[64 * (q0 + 1)] = Pair{ cf[2] + t1[2], cf[3] + t1[3] };
 						lp[64 * (q0 + 2)] = Pair{ cf[4] + t1[4], cf[5] + t1[5] };
 					}
-					if constexpr (ROLE == 3) {  // the pose to V (its cinert went to the body's own slots above)
+					if constexpr (ROLE == 3 || ROLE == 5) {  // the pose to V (and, of three, to C)
 						constexpr int ord = (LD::slot(b) - NV) / 3, rg = RING + 6 * (ord & 1);
 						const double *xm = xmat[b];
 						double xp[3] = { 0, 0, 0 };  // relative to the tree root's origin: what cdof is taken about
@@ -876,9 +889,10 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 				__builtin_amdgcn_sched_barrier(0);
 			});
 			LE_PK(3);
-			if constexpr (DUO && DV) {
-				// ---- V's half ends here: qfrc_smooth to P, then P's verdict on the step
-				sfor<(NV + 1) / 2>([&](auto K) {
+			if constexpr (ROLE == 5) en_pe = pe;
+			if constexpr (DUO && !DP) {
+				// ---- V's half ends here: qfrc_smooth to P, then P's verdict on the step (the trio's P: the two rendezvous and the verdict)
+				if constexpr (DV) sfor<(NV + 1) / 2>([&](auto K) {
 					constexpr int k = K;
 					lp[64 * (XS + k)] = Pair{ f[2 * k], 2 * k + 1 < NV ? f[2 * k + 1 < NV ? 2 * k + 1 : 0] : 0.0 };
 				});
@@ -908,7 +922,7 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 						if constexpr (Q::anc(a, i)) ke += (a == i ? 0.5 : 1.0) * qM[i][a] * qv[i] * qv[a];
 					});
 				});
-				en_pe = pe;
+				if constexpr (EPOS) en_pe = pe;
 				en_ke = ke;
 			}
 
@@ -1001,7 +1015,10 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 				le_barrier();  // (B, retry) V runs its half again on the reset state
 			}
 		}
-		if constexpr (DUO && DV) {
+		if constexpr (ROLE == 5) {
+			if (last && (m.enableflags & MJB_ENBL_ENERGY)) s.energy[2 * ev] = en_pe;  // (C stores the kinetic half)
+		}
+		if constexpr (DUO && !DP) {
 			time += dt;
 			continue;
 		}
@@ -1012,7 +1029,7 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 				s.qacc_warmstart[ev * NV + I] = qacc[I];
 			});
 			if (m.enableflags & MJB_ENBL_ENERGY) {
-				s.energy[2 * ev] = en_pe;
+				if constexpr (EPOS) s.energy[2 * ev] = en_pe;
 				s.energy[2 * ev + 1] = en_ke;
 			}
 		}
@@ -1035,7 +1052,7 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 		}
 	}
 #ifdef MJB_LE_PROBE
-	if (env_raw == env_lo) for (int k = 0; k < 8; k++) P->s.sensordata[(ROLE == 4 || ROLE == 2 ? 8 : 0) + k] = (double)pk_acc[k] / nsteps;
+	if (env_raw == env_lo) for (int k = 0; k < 8; k++) P->s.sensordata[(ROLE == 4 || ROLE == 2 || ROLE == 6 ? 8 : (ROLE == 7 ? 16 : 0)) + k] = (double)pk_acc[k] / nsteps;
 #endif
 
 	// ---- the launch's state back to HBM (store_state of the generic kernels; sensordata went out from the last step)
@@ -1068,6 +1085,17 @@ DEVI void lane_env_duo2(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 {
 	if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64) lane_env_body<T, LP, 3>(P, nsteps, step0, env_lo, env_hi, smem_le);
 	else lane_env_body<T, LP, 4>(P, nsteps, step0, env_lo, env_hi, smem_le);
+}
+
+// the TRIO: wavefront 0 = the pose chain, 1 = inertias / factors / solves / Euler, 2 = velocities and forces (blockDim.x = 192; the pipelined duo's LDS layout)
+template <class T, int LP>
+DEVI void lane_env_trio(const KernelParams MJB_AS4 *__restrict__ P, const int nsteps, const unsigned int step0, const int env_lo, const int env_hi,
+                        unsigned char *const smem_le)
+{
+	const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6;
+	if (w == 0) lane_env_body<T, LP, 5>(P, nsteps, step0, env_lo, env_hi, smem_le);
+	else if (w == 1) lane_env_body<T, LP, 6>(P, nsteps, step0, env_lo, env_hi, smem_le);
+	else lane_env_body<T, LP, 7>(P, nsteps, step0, env_lo, env_hi, smem_le);
 }
 
 // the DUO kernel's body: wavefront 0 of the block takes the position half, wavefront 1 the velocity half (blockDim.x = 128)

@@ -26,10 +26,11 @@ def eng(oracle_built):
     return engine, mjcf, oracle_built
 
 
-@pytest.fixture(autouse=True, params=[0, 1, 2], ids=["one_wave", "two_halves", "pipelined"])
+@pytest.fixture(autouse=True, params=[0, 1, 2, 3], ids=["one_wave", "two_halves", "pipelined", "trio"])
 def form(request, eng):
-    """Every test runs on the kernel's three forms (mjb_lane_env_set_form): one wavefront per 64 envs, two wavefronts splitting the step
-    into its position and velocity halves, two wavefronts pipelined body by body.  (A forced form falls back where it does not fit.)"""
+    """Every test runs on the kernel's four forms (mjb_lane_env_set_form): one wavefront per 64 envs, two wavefronts splitting the step
+    into its position and velocity halves, two wavefronts pipelined body by body, three (the pose chain alone on the first).  (A forced form
+    falls back where it does not fit.)"""
     engine = eng[0]
     lib = engine.binding.load_library()
     lib.mjb_lane_env_set_form(request.param)
@@ -378,7 +379,7 @@ def test_hiprtc_topology_beyond_the_lean_lds_budget(eng):
 
 
 def test_form_follows_batch_size(eng):
-    """The automatic rule (mjb_lane_env_set_form(-1)): pipelined while a block has a CU's LDS to itself (<= 64 x CUs envs), two halves up to
+    """The automatic rule (mjb_lane_env_set_form(-1)): three wavefronts while a block has a CU's LDS to itself (<= 64 x CUs envs), two halves up to
     twice that, one wavefront beyond; the three agree with the oracle on sampled envs."""
     engine, mjcf, po = eng
     import torch
@@ -387,7 +388,7 @@ def test_form_follows_batch_size(eng):
     lib.mjb_lane_env_set_form(-1)
     model = mjcf.load_asset("franka_like")
     cm = engine.CompiledModel(model)
-    for nenv, want in ((4096, 2), (64 * ncu, 2), (64 * ncu + 64, 1), (128 * ncu, 1), (128 * ncu + 64, 0)):
+    for nenv, want in ((4096, 3), (64 * ncu, 3), (64 * ncu + 64, 1), (128 * ncu, 1), (128 * ncu + 64, 0)):
         qpos, qvel = random_franka_state(model, nenv, 5)
         b = make(engine, cm, nenv, qpos, qvel, 1)
         b.set_ctrl_noise(10.0, 0.1, 7, 0)
