@@ -454,9 +454,9 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 		return (int)hipGetLastError();                                                                                                        \
 	}
 #define MJB_LE_GO_TRIO(T)                                                                                                                   \
-	if constexpr (duo2_bytes<T>() <= 160 * 1024) {                                                                                            \
+	if constexpr (trio_bytes<T>() <= 160 * 1024) {                                                                                            \
 		auto kern = mjb_lane_env_trio_kernel<T>;                                                                                              \
-		constexpr int bytes = duo2_bytes<T>();                                                                                                \
+		constexpr int bytes = trio_bytes<T>();                                                                                                \
 		static const hipError_t attr = bytes > 65536 ? hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) : hipSuccess; \
 		if (attr != hipSuccess) return (int)attr;                                                                                             \
 		le_form_last = 3;                                                                                                                     \

@@ -219,9 +219,16 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 	constexpr int LPE = PIPE ? (1 << 20) : (DUO ? LP - DuoSlots<NV>::n : LP);
 	using LD = Lds<T, LPE>;
 	static_assert(LD::slot(T::NBODY) <= LPE, "lane = env kernel: state and forces of the topology need more LDS than this instantiation's budget");
+	// (trio) body b's half-angle (sin, cos) comes from C: a hinge whose two predecessors in the sweep are needed bodies too (C publishes them two barriers ahead)
+	constexpr auto SCUSE = [](int b) {
+		if (b < 3 || b >= T::NBODY || T::body_jnt[b] < 0) return false;
+		if (T::jnt_type[T::body_jnt[b]] != MJB_JNT_HINGE) return false;
+		return LD::needed(b) && LD::needed(b - 1) && LD::needed(b - 2);
+	};
+	constexpr int RINGN = ROLE >= 5 ? 3 : 2;  // depth of the pose ring (the trio's V reads two bodies behind P)
 	constexpr int LASTB = [] { for (int c = NB - 1; c >= 1; c--) if (LD::needed(c)) return c; return 0; }();  // the leaf the composite-inertia sweep starts at
 	constexpr int RING = LD::nslots();                                              // (PIPE) 2 x 6 pair slots of the pose ring behind the solo layout
-	constexpr int XS = PIPE ? RING + 12 : LD::nslots(), MAIL = XS + (NV + 1) / 2;  // (DUO) pair slots of qfrc_smooth, and of P's verdicts for V
+	constexpr int XS = PIPE ? RING + 6 * RINGN : LD::nslots(), MAIL = XS + (NV + 1) / 2, SC0 = MAIL + 1;  // (trio) SC0 + b: body b's half-angle (sin, cos), from C to P  // (DUO) pair slots of qfrc_smooth, and of P's verdicts for V
 	const int lane_le = DUO ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
 	Pair *const lp = reinterpret_cast<Pair *>(smem_le) + lane_le;  // pair slot q of this lane: lp[64 * q]
 	// (a tail lane without an env keeps running on the last env's data and stores nothing: no divergent exit, the wave-uniform
@@ -387,6 +394,19 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 				constexpr int j1 = [] { for (int c = 1; c < NB; c++) if (T::body_jnt[c] >= 0) return T::body_jnt[c]; return -1; }();
 				if constexpr (j1 >= 0) pq[T::jnt_bodyid[j1]] = lp[64 * j1];
 			}
+			// (the trio's P) a hinge's half-angle sine / cosine one body AHEAD: the two polynomial chains depend on qpos alone, so they run beside the
+			// previous body's pose chain (quaternion product, normalisation, rsqrt, matrix) and fill its dependency stalls instead of lengthening the
+			// critical chain; the body's (qpos, qvel) pair and qpos0 are fetched one more region ahead for that
+			[[maybe_unused]] double psn[NB + 2], pcs[NB + 2], q0n[NB + 2];
+			[[maybe_unused]] Pair pqn[NB + 2], scq[NB + 2];
+			if constexpr (ROLE == 5 && NB > 2) {
+				if constexpr (T::body_jnt[2] >= 0) {
+					if constexpr (T::jnt_type[T::body_jnt[2]] == MJB_JNT_HINGE) {
+						pqn[2] = lp[64 * T::body_jnt[2]];
+						q0n[2] = tb[2].qpos0;
+					}
+				}
+			}
 			// position-stage sensors on a body's frames (the last step's values are the launch's sensordata)
 			auto frame_sensors = [&](auto Bq, const double *xipos) {
 				constexpr int b = Bq;
@@ -435,115 +455,140 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 					});
 				}
 			};
+			// (ring consumers) one body off the ring: its pose (position relative to the tree root's origin), cinert, cdof; V: velocities and the body's force
+			auto consume = [&](auto Bq) {
+				constexpr int b = Bq;
+				constexpr int p = T::body_parentid[b], j = T::body_jnt[b];
+				constexpr int ord = (LD::slot(b) - NV) / 3, rg = RING + 6 * (ord % RINGN), c0 = LD::cin_slot(b);
+				static_assert(c0 >= 0, "pipelined forms: every needed body's cinert lives in LDS");
+				double xp[3], xm[9], ci[10];
+				{
+					const Pair a0 = lp[64 * rg], a1 = lp[64 * (rg + 1)], a2 = lp[64 * (rg + 2)], a3 = lp[64 * (rg + 3)], a4 = lp[64 * (rg + 4)], a5 = lp[64 * (rg + 5)];
+					xp[0] = a0.a; xp[1] = a0.b; xp[2] = a1.a; xm[0] = a1.b; xm[1] = a2.a; xm[2] = a2.b; xm[3] = a3.a; xm[4] = a3.b; xm[5] = a4.a; xm[6] = a4.b; xm[7] = a5.a; xm[8] = a5.b;
+				}
+				if constexpr ((ROLE == 4 && b == LASTB) || ROLE == 7) {
+					// the LAST needed body's cinert came with its pose: P computes that one itself and goes from its last pose straight into the
+					// composite-inertia sweep, which starts at this body -- it never waits for V's last phase
+					for (int k = 0; k < 5; k++) {
+						const Pair c = lp[64 * (c0 + k)];
+						ci[2 * k] = c.a;
+						ci[2 * k + 1] = c.b;
+					}
+				} else
+				{
+					// cinert about the tree root's origin, as in the fused sweep: X Ib X' + the com offset's terms; handed to P's composite-inertia sweep
+					const LeTapeBody MJB_AS4 &tj = tb[b];
+					double dif[3] = { xp[0], xp[1], xp[2] };
+					if constexpr (!T::body_sameframe[b]) {
+						const double ip[3] = { tj.ipos[0], tj.ipos[1], tj.ipos[2] };
+						double v[3];
+						matvec3(v, xm, ip);
+						for (int k = 0; k < 3; k++) dif[k] += v[k];
+					}
+					const double mass = tj.mass;
+					const double *X = xm;
+					const double ixx = tj.ibody[0], iyy = tj.ibody[1], izz = tj.ibody[2], ixy = tj.ibody[3], ixz = tj.ibody[4], iyz = tj.ibody[5];
+					double Tm[9];
+					for (int rr = 0; rr < 3; rr++) {
+						Tm[3 * rr + 0] = X[3 * rr] * ixx + X[3 * rr + 1] * ixy + X[3 * rr + 2] * ixz;
+						Tm[3 * rr + 1] = X[3 * rr] * ixy + X[3 * rr + 1] * iyy + X[3 * rr + 2] * iyz;
+						Tm[3 * rr + 2] = X[3 * rr] * ixz + X[3 * rr + 1] * iyz + X[3 * rr + 2] * izz;
+					}
+					ci[0] = Tm[0] * X[0] + Tm[1] * X[1] + Tm[2] * X[2] + mass * (dif[1] * dif[1] + dif[2] * dif[2]);
+					ci[1] = Tm[3] * X[3] + Tm[4] * X[4] + Tm[5] * X[5] + mass * (dif[0] * dif[0] + dif[2] * dif[2]);
+					ci[2] = Tm[6] * X[6] + Tm[7] * X[7] + Tm[8] * X[8] + mass * (dif[0] * dif[0] + dif[1] * dif[1]);
+					ci[3] = Tm[0] * X[3] + Tm[1] * X[4] + Tm[2] * X[5] - mass * dif[0] * dif[1];
+					ci[4] = Tm[0] * X[6] + Tm[1] * X[7] + Tm[2] * X[8] - mass * dif[0] * dif[2];
+					ci[5] = Tm[3] * X[6] + Tm[4] * X[7] + Tm[5] * X[8] - mass * dif[1] * dif[2];
+					ci[6] = mass * dif[0];
+					ci[7] = mass * dif[1];
+					ci[8] = mass * dif[2];
+					ci[9] = mass;
+					if constexpr (ROLE != 7) for (int k = 0; k < 5; k++) lp[64 * (c0 + k)] = Pair{ ci[2 * k], ci[2 * k + 1] };  // (for the composite-inertia sweep of P / of C itself)
+				}
+				[[maybe_unused]] double pv[6], pa[6];
+				if constexpr (!DV) {
+				} else if constexpr (p == 0 || !LD::needed(p)) {  // the world, or a jointless chain down from it: at rest
+					for (int k = 0; k < 6; k++) pv[k] = 0;
+					pa[0] = pa[1] = pa[2] = 0;
+					for (int k = 0; k < 3; k++) pa[3 + k] = -grav[k];
+				} else {
+					for (int k = 0; k < 6; k++) { pv[k] = cvel[p][k]; pa[k] = cacc[p][k]; }
+				}
+				if constexpr (j >= 0) {
+					[[maybe_unused]] double qv = 0;
+					if constexpr (DV) qv = lp[64 * j].b;
+					const LeTapeBody MJB_AS4 &tj = tb[b];
+					const double ax[3] = { tj.jaxis[0], tj.jaxis[1], tj.jaxis[2] };
+					double xaxis[3];
+					matvec3(xaxis, xm, ax);
+					double *cd = cdof[j];
+					if constexpr (T::jnt_type[j] == MJB_JNT_SLIDE) {
+						cd[0] = cd[1] = cd[2] = 0;
+						for (int k = 0; k < 3; k++) cd[3 + k] = xaxis[k];
+					} else {
+						// (the anchor from the body's FINAL frame: xpos + xmat jnt_pos -- the point mj_kinematics' off-centre correction keeps fixed)
+						const double jp[3] = { tj.jpos[0], tj.jpos[1], tj.jpos[2] };
+						double xanch[3] = { xp[0], xp[1], xp[2] }, off[3];
+						if (jp[0] != 0 || jp[1] != 0 || jp[2] != 0) {
+							double v[3];
+							matvec3(v, xm, jp);
+							for (int k = 0; k < 3; k++) xanch[k] += v[k];
+						}
+						for (int k = 0; k < 3; k++) off[k] = -xanch[k];  // (root origin - anchor)
+						for (int k = 0; k < 3; k++) cd[k] = xaxis[k];
+						cross3(cd + 3, xaxis, off);
+					}
+					if constexpr (!DV) {
+					} else if constexpr (p == 0 || !LD::needed(p)) {
+						for (int k = 0; k < 6; k++) { cvel[b][k] = cd[k] * qv; cacc[b][k] = pa[k]; }
+					} else {
+						double cdd[6];
+						cross_motion(cdd, pv, cd);
+						for (int k = 0; k < 6; k++) { cvel[b][k] = pv[k] + cd[k] * qv; cacc[b][k] = pa[k] + cdd[k] * qv; }
+					}
+				} else if constexpr (DV) {
+					for (int k = 0; k < 6; k++) { cvel[b][k] = pv[k]; cacc[b][k] = pa[k]; }
+				}
+				if constexpr (DV) {
+					double cf[6], t0[6], t1[6];
+					mul_inert_vec(cf, ci, cacc[b]);
+					mul_inert_vec(t0, ci, cvel[b]);
+					cross_force(t1, cvel[b], t0);
+					constexpr int q0 = LD::slot(b);
+					lp[64 * q0] = Pair{ cf[0] + t1[0], cf[1] + t1[1] };
+					lp[64 * (q0 + 1)] = Pair{ cf[2] + t1[2], cf[3] + t1[3] };
+					lp[64 * (q0 + 2)] = Pair{ cf[4] + t1[4], cf[5] + t1[5] };
+				}
+			};
 			sfor<NB>([&](auto B) {
 				constexpr int b = B;
 				if constexpr (b > 0 && RINGC) {
-					// ---- the pipelined V (and the trio's C): body b's pose (position relative to the tree root's origin) and cinert come from P through LDS, one barrier per needed body
-					constexpr int p = T::body_parentid[b], j = T::body_jnt[b];
+					// ---- the pipelined V (and the trio's C): body b's pose and cinert come through LDS, one barrier per needed body.  The trio's V runs TWO bodies
+					// behind P: it takes the cinert C computed one phase earlier instead of computing its own, and never paces the pose chain
 					if constexpr (LD::needed(b)) {
-						constexpr int ord = (LD::slot(b) - NV) / 3, rg = RING + 6 * (ord & 1), c0 = LD::cin_slot(b);
-						static_assert(c0 >= 0, "pipelined duo: every needed body's cinert lives in LDS");
+						if constexpr (ROLE == 6) {
+							// (the trio's C) a hinge's half-angle sine and cosine are a third of the pose chain's instructions and depend on qpos alone: C computes them
+							// two bodies ahead of P, in the time it would wait at this barrier, and P picks them up from LDS
+							constexpr int t2 = [] {
+								int c = b, hops = 0;
+								for (int q = b + 1; q < NB && hops < 2; q++) if (LD::needed(q)) { c = q; hops++; }
+								return hops == 2 ? c : 0;
+							}();
+							if constexpr (t2 > 0 && SCUSE(t2)) {
+								double sn, cs;
+								const double qp2 = lp[64 * T::body_jnt[t2]].a;
+								sincos_nb((qp2 - tb[t2].qpos0) * 0.5, &sn, &cs);
+								lp[64 * (SC0 + t2)] = Pair{ sn, cs };
+							}
+						}
 						LE_PK(0);
 						le_barrier();
 						LE_PK(2);
-						double xp[3], xm[9], ci[10];
-						{
-							const Pair a0 = lp[64 * rg], a1 = lp[64 * (rg + 1)], a2 = lp[64 * (rg + 2)], a3 = lp[64 * (rg + 3)], a4 = lp[64 * (rg + 4)], a5 = lp[64 * (rg + 5)];
-							xp[0] = a0.a; xp[1] = a0.b; xp[2] = a1.a; xm[0] = a1.b; xm[1] = a2.a; xm[2] = a2.b; xm[3] = a3.a; xm[4] = a3.b; xm[5] = a4.a; xm[6] = a4.b; xm[7] = a5.a; xm[8] = a5.b;
-						}
-						if constexpr (ROLE == 4 && b == LASTB) {
-							// the LAST needed body's cinert came with its pose: P computes that one itself and goes from its last pose straight into the
-							// composite-inertia sweep, which starts at this body -- it never waits for V's last phase
-							for (int k = 0; k < 5; k++) {
-								const Pair c = lp[64 * (c0 + k)];
-								ci[2 * k] = c.a;
-								ci[2 * k + 1] = c.b;
-							}
-						} else
-						{
-							// cinert about the tree root's origin, as in the fused sweep: X Ib X' + the com offset's terms; handed to P's composite-inertia sweep
-							const LeTapeBody MJB_AS4 &tj = tb[b];
-							double dif[3] = { xp[0], xp[1], xp[2] };
-							if constexpr (!T::body_sameframe[b]) {
-								const double ip[3] = { tj.ipos[0], tj.ipos[1], tj.ipos[2] };
-								double v[3];
-								matvec3(v, xm, ip);
-								for (int k = 0; k < 3; k++) dif[k] += v[k];
-							}
-							const double mass = tj.mass;
-							const double *X = xm;
-							const double ixx = tj.ibody[0], iyy = tj.ibody[1], izz = tj.ibody[2], ixy = tj.ibody[3], ixz = tj.ibody[4], iyz = tj.ibody[5];
-							double Tm[9];
-							for (int rr = 0; rr < 3; rr++) {
-								Tm[3 * rr + 0] = X[3 * rr] * ixx + X[3 * rr + 1] * ixy + X[3 * rr + 2] * ixz;
-								Tm[3 * rr + 1] = X[3 * rr] * ixy + X[3 * rr + 1] * iyy + X[3 * rr + 2] * iyz;
-								Tm[3 * rr + 2] = X[3 * rr] * ixz + X[3 * rr + 1] * iyz + X[3 * rr + 2] * izz;
-							}
-							ci[0] = Tm[0] * X[0] + Tm[1] * X[1] + Tm[2] * X[2] + mass * (dif[1] * dif[1] + dif[2] * dif[2]);
-							ci[1] = Tm[3] * X[3] + Tm[4] * X[4] + Tm[5] * X[5] + mass * (dif[0] * dif[0] + dif[2] * dif[2]);
-							ci[2] = Tm[6] * X[6] + Tm[7] * X[7] + Tm[8] * X[8] + mass * (dif[0] * dif[0] + dif[1] * dif[1]);
-							ci[3] = Tm[0] * X[3] + Tm[1] * X[4] + Tm[2] * X[5] - mass * dif[0] * dif[1];
-							ci[4] = Tm[0] * X[6] + Tm[1] * X[7] + Tm[2] * X[8] - mass * dif[0] * dif[2];
-							ci[5] = Tm[3] * X[6] + Tm[4] * X[7] + Tm[5] * X[8] - mass * dif[1] * dif[2];
-							ci[6] = mass * dif[0];
-							ci[7] = mass * dif[1];
-							ci[8] = mass * dif[2];
-							ci[9] = mass;
-							if constexpr (ROLE != 7) for (int k = 0; k < 5; k++) lp[64 * (c0 + k)] = Pair{ ci[2 * k], ci[2 * k + 1] };  // (for the composite-inertia sweep of P / of C itself)
-						}
-						[[maybe_unused]] double pv[6], pa[6];
-						if constexpr (!DV) {
-						} else if constexpr (p == 0 || !LD::needed(p)) {  // the world, or a jointless chain down from it: at rest
-							for (int k = 0; k < 6; k++) pv[k] = 0;
-							pa[0] = pa[1] = pa[2] = 0;
-							for (int k = 0; k < 3; k++) pa[3 + k] = -grav[k];
-						} else {
-							for (int k = 0; k < 6; k++) { pv[k] = cvel[p][k]; pa[k] = cacc[p][k]; }
-						}
-						if constexpr (j >= 0) {
-							[[maybe_unused]] double qv = 0;
-							if constexpr (DV) qv = lp[64 * j].b;
-							const LeTapeBody MJB_AS4 &tj = tb[b];
-							const double ax[3] = { tj.jaxis[0], tj.jaxis[1], tj.jaxis[2] };
-							double xaxis[3];
-							matvec3(xaxis, xm, ax);
-							double *cd = cdof[j];
-							if constexpr (T::jnt_type[j] == MJB_JNT_SLIDE) {
-								cd[0] = cd[1] = cd[2] = 0;
-								for (int k = 0; k < 3; k++) cd[3 + k] = xaxis[k];
-							} else {
-								// (the anchor from the body's FINAL frame: xpos + xmat jnt_pos -- the point mj_kinematics' off-centre correction keeps fixed)
-								const double jp[3] = { tj.jpos[0], tj.jpos[1], tj.jpos[2] };
-								double xanch[3] = { xp[0], xp[1], xp[2] }, off[3];
-								if (jp[0] != 0 || jp[1] != 0 || jp[2] != 0) {
-									double v[3];
-									matvec3(v, xm, jp);
-									for (int k = 0; k < 3; k++) xanch[k] += v[k];
-								}
-								for (int k = 0; k < 3; k++) off[k] = -xanch[k];  // (root origin - anchor)
-								for (int k = 0; k < 3; k++) cd[k] = xaxis[k];
-								cross3(cd + 3, xaxis, off);
-							}
-							if constexpr (!DV) {
-							} else if constexpr (p == 0 || !LD::needed(p)) {
-								for (int k = 0; k < 6; k++) { cvel[b][k] = cd[k] * qv; cacc[b][k] = pa[k]; }
-							} else {
-								double cdd[6];
-								cross_motion(cdd, pv, cd);
-								for (int k = 0; k < 6; k++) { cvel[b][k] = pv[k] + cd[k] * qv; cacc[b][k] = pa[k] + cdd[k] * qv; }
-							}
-						} else if constexpr (DV) {
-							for (int k = 0; k < 6; k++) { cvel[b][k] = pv[k]; cacc[b][k] = pa[k]; }
-						}
-						if constexpr (DV) {
-							double cf[6], t0[6], t1[6];
-							mul_inert_vec(cf, ci, cacc[b]);
-							mul_inert_vec(t0, ci, cvel[b]);
-							cross_force(t1, cvel[b], t0);
-							constexpr int q0 = LD::slot(b);
-							lp[64 * q0] = Pair{ cf[0] + t1[0], cf[1] + t1[1] };
-							lp[64 * (q0 + 1)] = Pair{ cf[2] + t1[2], cf[3] + t1[3] };
-							lp[64 * (q0 + 2)] = Pair{ cf[4] + t1[4], cf[5] + t1[5] };
+						if constexpr (ROLE != 7) consume(IC<b>{});
+						else {
+							constexpr int pb = [] { for (int c = b - 1; c >= 1; c--) if (LD::needed(c)) return c; return 0; }();
+							if constexpr (pb > 0) consume(IC<pb>{});
 						}
 					}
 					if constexpr (DV && b == 1) sfor<NV>([&](auto I) { qfa[I] = s.qfrc_applied[ev * NV + I]; });  // (read by the force block behind the sweep: a trip to HBM)
@@ -555,6 +600,11 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 				if constexpr (j >= 0) touch_v(pq[b].a);
 				for (int k = 0; k < 10; k++) hB[b][k] = reinterpret_cast<const double MJB_AS4 *>(tb + b)[16 + k];
 				const double *const A = hA[b];  // pos[3] quat[4] jaxis[3] jpos[3] qpos0 stiffness spring
+				if constexpr (ROLE == 5 && b == 1 && b + 1 < NB) {
+					if constexpr (T::body_jnt[b + 1] >= 0) {
+						if constexpr (T::jnt_type[T::body_jnt[b + 1]] == MJB_JNT_HINGE) sincos_nb((pqn[b + 1].a - q0n[b + 1]) * 0.5, &psn[b + 1], &pcs[b + 1]);
+					}
+				}
 				double pos[3] = { A[0], A[1], A[2] }, quat[4] = { A[3], A[4], A[5], A[6] };
 				if constexpr (p != 0) {
 					double v[3], q[4];
@@ -582,7 +632,9 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 					}
 					if constexpr (T::jnt_type[j] == MJB_JNT_HINGE) {
 						double sn, cs, ql[4], q[4];
-						sincos_nb((qp - A[13]) * 0.5, &sn, &cs);
+						if constexpr (ROLE == 5 && SCUSE(b)) { sn = scq[b].a; cs = scq[b].b; }  // (C's, fetched in the previous body's second region)
+						else if constexpr (ROLE == 5 && b == 2) { sn = psn[b]; cs = pcs[b]; }  // (computed beside the first body's chain)
+						else sincos_nb((qp - A[13]) * 0.5, &sn, &cs);
 						ql[0] = cs; ql[1] = A[7] * sn; ql[2] = A[8] * sn; ql[3] = A[9] * sn;
 						qmul(q, quat, ql);
 						for (int k = 0; k < 4; k++) quat[k] = q[k];
@@ -618,6 +670,7 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 					constexpr int nb = [] { for (int c = b + 1; c < NB; c++) if (T::body_jnt[c] >= 0) return c; return -1; }();
 					if constexpr (nb >= 0) pq[nb] = lp[64 * T::body_jnt[nb]];
 				}
+				if constexpr (ROLE == 5 && SCUSE(b + 1)) scq[b + 1] = lp[64 * (SC0 + b + 1)];
 				const double *const Bh = hB[b];  // ipos[3] ibody[6] mass damping armature hdamping
 				// inertial frame
 				double xipos[3];
@@ -719,7 +772,7 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 						lp[64 * (q0 + 2)] = Pair{ cf[4] + t1[4], cf[5] + t1[5] };
 					}
 					if constexpr (ROLE == 3 || ROLE == 5) {  // the pose to V (and, of three, to C)
-						constexpr int ord = (LD::slot(b) - NV) / 3, rg = RING + 6 * (ord & 1);
+						constexpr int ord = (LD::slot(b) - NV) / 3, rg = RING + 6 * (ord % RINGN);
 						const double *xm = xmat[b];
 						double xp[3] = { 0, 0, 0 };  // relative to the tree root's origin: what cdof is taken about
 						if constexpr (r != b) for (int k = 0; k < 3; k++) xp[k] = xpos[b][k] - xpos[r][k];
@@ -741,6 +794,10 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 			});
 
 			LE_PK(0);
+			if constexpr (ROLE >= 5) {  // (the trio: C's cinert of the last body is in LDS; V takes that body now)
+				le_barrier();
+				if constexpr (ROLE == 7) consume(IC<LASTB>{});
+			}
 			LE_PK(1);
 			// ============ A8 mj_passive, the injector's OU update, A12 mj_fwdActuation (joint transmission), qfrc_applied ============
 			if constexpr (DV) {
@@ -1078,6 +1135,7 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 template <class T, int LP> constexpr int duo_bytes() { return (Lds<T, LP - DuoSlots<T::NV>::n>::nslots() + DuoSlots<T::NV>::n) * 64 * 16; }
 
 // ... and of a pipelined DUO block (roles 3 / 4): every needed body's cinert, every dof's cdof, the pose ring, the exchange slots
+template <class T> constexpr int trio_bytes() { return (Lds<T, (1 << 20)>::nslots() + 18 + DuoSlots<T::NV>::n + T::NBODY) * 64 * 16; }
 template <class T> constexpr int duo2_bytes() { return (Lds<T, (1 << 20)>::nslots() + 12 + DuoSlots<T::NV>::n) * 64 * 16; }
 template <class T, int LP>
 DEVI void lane_env_duo2(const KernelParams MJB_AS4 *__restrict__ P, const int nsteps, const unsigned int step0, const int env_lo, const int env_hi,
