@@ -27,10 +27,10 @@ if os.path.exists(f):
     txt = open(f).read()
     for blk in re.split(r"\n  - \.agpr_count", txt)[1:]:
         name = re.search(r"\.name:\s+(\S+)", blk)
-        mm = name and re.search(r"mjb_lane_env_(duo2_|duo_|)kernelI\d+LeTopo_(\w+?)(?:Li(\d+))?E", name.group(1))
+        mm = name and re.search(r"mjb_lane_env_(duo2_|duo_|trio_|)kernelI\d+LeTopo_(\w+?)(?:Li(\d+))?E", name.group(1))
         if not mm:
             continue
-        form = {"": "", "duo_": ", two halves", "duo2_": ", pipelined"}[mm.group(1)]
+        form = {"": "", "duo_": ", two halves", "duo2_": ", pipelined", "trio_": ", three wavefronts"}[mm.group(1)]
         mm = (None, mm.group(2), (mm.group(3) or "-") + form)
         mm = type("M", (), {"group": lambda self, i, _m=mm: _m[i]})()
         get = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1))  # noqa: E731
