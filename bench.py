@@ -248,7 +248,7 @@ def kernel_form(batch):
     if not batch.lane_env_info()[1]:
         return "mjb_step_kernel", "generic (G lanes per env, frame in LDS)"
     form = batch.lane_env_last_form()
-    kname = ("mjb_lane_env_kernel", "mjb_lane_env_duo_kernel", "mjb_lane_env_duo2_kernel")[form if form in (0, 1, 2) else 0]
+    kname = ("mjb_lane_env_kernel", "mjb_lane_env_duo_kernel", "mjb_lane_env_duo2_kernel", "mjb_lane_env_trio_kernel")[form if form in (0, 1, 2, 3) else 0]
     how = ("one wavefront per 64 envs", "two wavefronts per 64 envs: position half | velocity half",
            "two wavefronts per 64 envs, pipelined body by body through LDS: poses | cinert, cdof, velocities, forces",
            "three wavefronts per 64 envs, pipelined body by body through LDS: poses | cinert, cdof, inertias, factors, solves, Euler | velocities, forces")[form if form in (0, 1, 2, 3) else 0]
