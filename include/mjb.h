@@ -264,7 +264,7 @@ const char *mjb_lane_env_error(void);
  * cycles whatever it is, so while the batch leaves SIMDs idle the step's length is the longest instruction stream; 3 = THREE: the first wavefront runs
  * the pose chain and nothing else, the second follows it with cinert and cdof and then takes the composite inertias, qM, the factors, the solves and
  * Euler, the third the velocities and forces.  Form 3 runs whenever a block has a CU's LDS to itself (<= 64 x CUs envs: 16 384 on MI355X; form 2 is
- * the same with two wavefronts, by request only; run-time (hiprtc) topologies take form 2 there), form 1 up to twice that, form 0 beyond.  -1 = that rule (default; the environment
+ * the same with two wavefronts, by request only), form 1 up to twice that, form 0 beyond.  -1 = that rule (default; the environment
  * variable MJB_LANE_ENV_DUO = 0 / 1 / 2 / 3 overrides it).  A forced form that does not fit (LDS) falls back to the next lower one.  Results of the
  * four forms agree to rounding.  Returns the previous setting.  mjb_lane_env_last_form: the form of this process's last lane = env launch (-1: none yet).
  * Measurement / test knob, no reference counterpart. */

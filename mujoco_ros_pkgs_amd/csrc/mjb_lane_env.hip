@@ -230,13 +230,12 @@ std::string source_dir()
 	return ".";
 }
 
-const JitKernel &jit_get(const mjb_model_desc &h, int lp, int duo)  // duo: 0 solo, 1 two halves, 2 pipelined (3, the trio, is compiled-in topologies only: pipelined)
+const JitKernel &jit_get(const mjb_model_desc &h, int lp, int duo)  // duo: 0 solo, 1 two halves, 2 pipelined, 3 three wavefronts
 {
-	if (duo > 2) duo = 2;
 	int dev = 0;
 	(void)hipGetDevice(&dev);
 	const std::string topo = topo_source(h);
-	const std::string key = std::to_string(dev) + "|" + std::to_string(lp) + (duo == 2 ? "p|" : (duo ? "d|" : "|")) + topo;
+	const std::string key = std::to_string(dev) + "|" + std::to_string(lp) + (duo == 3 ? "t|" : (duo == 2 ? "p|" : (duo ? "d|" : "|"))) + topo;
 	std::lock_guard<std::mutex> lock(jit_mutex);
 	auto it = jit_cache.find(key);
 	if (it != jit_cache.end()) return it->second;
@@ -248,7 +247,10 @@ const JitKernel &jit_get(const mjb_model_desc &h, int lp, int duo)  // duo: 0 so
 	const std::string dir = source_dir();
 	const std::string slp = std::to_string(lp);
 	const std::string src = "#include \"mjb_lane_env_kernel.h\"\n" + topo +
-	                        (duo == 2 ? "extern \"C\" __global__ void __launch_bounds__(128) le_rt(const KernelParams MJB_AS4 *P, int nsteps, unsigned int step0, int lo, int hi)\n{\n"
+	                        (duo == 3 ? "extern \"C\" __global__ void __launch_bounds__(192) le_rt(const KernelParams MJB_AS4 *P, int nsteps, unsigned int step0, int lo, int hi)\n{\n"
+	                                    "\t__shared__ __attribute__((aligned(16))) unsigned char smem[mjb_le::trio_bytes<LeTopo_rt>()];\n"
+	                                    "\tmjb_le::lane_env_trio<LeTopo_rt, 160>(P, nsteps, step0, lo, hi, smem);\n}\n"
+	                         : duo == 2 ? "extern \"C\" __global__ void __launch_bounds__(128) le_rt(const KernelParams MJB_AS4 *P, int nsteps, unsigned int step0, int lo, int hi)\n{\n"
 	                                    "\t__shared__ __attribute__((aligned(16))) unsigned char smem[mjb_le::duo2_bytes<LeTopo_rt>()];\n"
 	                                    "\tmjb_le::lane_env_duo2<LeTopo_rt, 160>(P, nsteps, step0, lo, hi, smem);\n}\n"
 	                         : duo ? "extern \"C\" __global__ void __launch_bounds__(128) le_rt(const KernelParams MJB_AS4 *P, int nsteps, unsigned int step0, int lo, int hi)\n{\n"
@@ -393,7 +395,6 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 	if (duo_mode > 0 && lp < 80) lp = 80, duo = 1;  // (a forced two-wavefront form on a batch that would run four wavefronts per CU: two per CU)
 	if (topo == MJB_LE_TOPO_JIT) {
 		if (!h) return (int)hipErrorInvalidValue;
-		if (duo > 2) duo = 2;  // (run-time topologies: up to the pipelined two-wavefront form)
 		{  // a larger model than the compiled-in ones: the smallest LDS budget its (qpos, qvel) pairs and body forces fit (fewer wavefronts per CU then)
 			int need = h->nv;
 			for (int b = 1; b < h->nbody; b++) {
@@ -407,6 +408,7 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 				return MJB_LE_UNAVAILABLE;
 			}
 			if (fit > lp) lp = fit;
+			if (duo == 3 && need + 5 * ((need - h->nv) / 3) + 18 + (h->nv + 1) / 2 + 1 + h->nbody > 160) duo = 2;
 			if (duo == 2 && need + 5 * ((need - h->nv) / 3) + 12 + (h->nv + 1) / 2 + 1 > 160) duo = 1;
 			if (duo == 1 && need + (h->nv + 1) / 2 + 1 > lp) duo = 0;
 		}
@@ -419,9 +421,8 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 		int a_nsteps = nsteps, a_lo = env_lo, a_hi = env_hi;
 		unsigned int a_step0 = step0;
 		void *args[] = { (void *)&Pd, (void *)&a_nsteps, (void *)&a_step0, (void *)&a_lo, (void *)&a_hi };
-		if (duo > 2) duo = 2;
 		le_form_last = duo;
-		return (int)hipModuleLaunchKernel(k.fn, grid.x, 1, 1, duo ? 128 : block.x, 1, 1, 0, (hipStream_t)stream, args, nullptr);
+		return (int)hipModuleLaunchKernel(k.fn, grid.x, 1, 1, duo == 3 ? 192 : (duo ? 128 : block.x), 1, 1, 0, (hipStream_t)stream, args, nullptr);
 	}
 #define MJB_LE_GO(T, LPV)                                                                                                                    \
 	{                                                                                                                                         \
