@@ -1,11 +1,11 @@
 #!/bin/bash
 # ThreadSanitizer and AddressSanitizer + UBSan runs of the host runtime (libmjr_host: physics thread, event thread and the
 # service / step-request callers around one recursive mutex and a handful of atomics), on the CPU test harness backend:
-#   tools/run_sanitizers.sh            -> profiles/r03_sanitizers.txt
+#   tools/run_sanitizers.sh            -> profiles/r05_sanitizers.txt (OUT=... overrides)
 # SURVEY.md §5 (the reference: mujoco_ros/cmake/Sanitizers.cmake:3-43, ENABLE_SANITIZER_{ADDRESS,THREAD,UNDEFINED_BEHAVIOR}).
 set -u
 cd "$(dirname "$0")/.."
-OUT=profiles/r03_sanitizers.txt
+OUT=${OUT:-profiles/r05_sanitizers.txt}
 TESTS="tests/test_host_env.py tests/test_host_services.py tests/test_host_sharded.py tests/test_host_sensors_plugin.py"
 make -s -C mujoco_ros_pkgs_amd/host sanitizers || exit 1
 make -s -C tests/host_harness || exit 1
