@@ -2814,16 +2814,22 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 				cost += middle ? 0.5 * Dm * NmT * NmT : 0.0;
 				if (hess) {
 					double *hc = hcb(rcon[i], r);
+					// (with hcrow the NEXT contact's block starts hcd * dim doubles further on: a contact of dimension 3 among contacts of dimension 4 owns
+					//  three block rows, not hcd.  The block rows past its dimension -- which nobody reads -- therefore write row 0 once more, with row 0's
+					//  values, instead of zeros into the neighbour's first row; a select on the address and the operands, no per-lane branch.  Round 5: the
+					//  zeros went to the neighbour, tools/replay_reset.py found the env-step of the power grasp at which that made the Hessian indefinite.)
 #pragma unroll
 					for (int j = 0; j < DMAX; j++) {
+						const bool rowin = j < dim;
+						const double gj = rowin ? g[j] : g[0];
 #pragma unroll
 						for (int c2 = 0; c2 < DMAX; c2++) {
 							if (j >= hcd || c2 >= hcd) continue;  // (wave-uniform: the block is hcd x hcd)
-							double vm = Dm * g[j] * g[c2];
-							if (j >= 1 && c2 >= 1) vm += -Dm * NmT * mu * fr[j] * fr[c2] * ((j == c2 ? iT : 0.0) - U[j] * U[c2] * iT3);
-							const double vb = j == c2 ? Dj[j] : 0.0;
-							const bool in = j < dim && c2 < dim;
-							hc[j * hcd + c2] = (in && !top) ? (bottom ? vb : vm) : 0.0;
+							double vm = Dm * gj * g[c2];
+							if (j >= 1 && c2 >= 1) vm += rowin ? -Dm * NmT * mu * fr[j] * fr[c2] * ((j == c2 ? iT : 0.0) - U[j] * U[c2] * iT3) : 0.0;
+							const double vb = rowin ? (j == c2 ? Dj[j] : 0.0) : (c2 == 0 ? Dj[0] : 0.0);
+							const bool in = c2 < dim;
+							hc[(rowin ? j : 0) * hcd + c2] = (in && !top) ? (bottom ? vb : vm) : 0.0;
 						}
 					}
 #pragma unroll

@@ -1,0 +1,110 @@
+"""Elliptic cones of MIXED dimension in one env-step (a condim-3 contact among condim-4 contacts) on the FUSED frames of the Newton kernel.
+
+Round 5: with the cone blocks laid out by row (`hcrow`: block of a contact at hcd * its first row, mjb_dev.h) the dimension-3 contact's
+block writer zeroed the first row of its neighbour's block; the Hessian lost that contact's normal row, the solve went indefinite and
+mj_checkAcc reset the env -- one env-step in 12 M of the power grasp (tools/find_reset.py, tools/replay_reset.py).  The full frame
+(every test that reads efc_* runs on it) lays the blocks out by contact and was never affected.
+
+tests/golden/grasp_env184_step4059.npz: that env-step's state as the GPU held it (qpos, qvel, qacc_warmstart, the step's ctrl):
+12 contacts of dimensions 4 x 10, 3, 4 + 2 limit rows = 49 rows (mujoco_env.cpp:498,552,593: the mj_step it stands for)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+STATE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "grasp_env184_step4059.npz")
+
+
+@pytest.fixture(scope="module")
+def setup(oracle_built):
+    from mujoco_ros_pkgs_amd import engine, mjcf
+    model = mjcf.load_asset("shadow_hand_grasp")
+    return engine, engine.CompiledModel(model), model, oracle_built, np.load(STATE)
+
+
+def copies(st, n, scale, seed=0):
+    rng = np.random.default_rng(seed)
+    qp, qv = np.tile(st["qpos"][None, :], (n, 1)), np.tile(st["qvel"][None, :], (n, 1))
+    qp[1:] += scale * rng.standard_normal(qp[1:].shape)
+    qv[1:] += 10 * scale * rng.standard_normal(qv[1:].shape)
+    return qp, qv
+
+
+def load(b, st, qp, qv):
+    n = qp.shape[0]
+    b.set("qpos", qp)
+    b.set("qvel", qv)
+    b.set("qacc_warmstart", np.tile(st["qacc_warmstart"][None, :], (n, 1)))
+    b.set("ctrl", np.tile(st["ctrl_step"][None, :], (n, 1)))
+
+
+def oracle_step(po, model, st, qp, qv):
+    d = po.OracleData(model)
+    d.reset()
+    d.qpos[:] = qp
+    d.qvel[:] = qv
+    d.qacc_warmstart[:] = st["qacc_warmstart"]
+    d.ctrl[:] = st["ctrl_step"]
+    d.step()
+    dims = np.array(d.contact_dim[: int(d.ncon[0])]).astype(int)
+    return np.array(d.qpos), np.array(d.qvel), dims, int(d.nefc[0])
+
+
+def test_mixed_cone_dimensions_on_the_default_fused_frame(setup):
+    engine, cm, model, po, st = setup
+    n = 64
+    qp, qv = copies(st, n, 1e-3)
+    out = {}
+    for keep in (False, True):
+        b = engine.Batch(cm, n)
+        b.set_keep_frame(keep)
+        load(b, st, qp, qv)
+        b.step(1)
+        out[keep] = (b.get("qpos"), b.get("qvel"), b.warning_count())
+        if not keep:
+            assert b.fused_frame()[0] == 1
+        b.close()
+    assert out[False][2] == 0 and out[True][2] == 0, "mj_checkAcc reset an env"
+    # the fused frame and the full frame run the same solver arithmetic on different LDS layouts
+    assert np.abs(out[False][1] - out[True][1]).max() <= 1e-12
+    mixed = 0
+    for e in (0, 1, 7, 20, 41, 63):
+        oq, ov, dims, nefc = oracle_step(po, model, st, qp[e], qv[e])
+        mixed += int(len(set(dims.tolist()) - {1}) > 1)
+        assert 33 <= nefc <= 64, nefc  # (beyond the rows of the light workload, within the default frame's 64)
+        assert np.abs(out[False][0][e] - oq).max() <= 1e-11 and np.abs(out[False][1][e] - ov).max() <= 1e-8, (e, nefc, dims)
+    assert mixed >= 3, "the fixture no longer holds cones of mixed dimension"
+
+
+def test_mixed_cone_dimensions_on_the_wide_fused_frame(setup):
+    """The wide frame (two rows per lane, the line search's constants parked in the cone blocks) is what a power-grasp batch runs on:
+    two long launches of grasp states switch the batch to it, then the mixed-dimension states take one step there."""
+    from mujoco_ros_pkgs_amd import workloads
+    engine, cm, model, po, st = setup
+    n = 128
+    gq, gv = workloads.hand_power_grasp_states(model, n, seed=3)
+    b = engine.Batch(cm, n)
+    b.set("qpos", gq)
+    b.set("qvel", gv)
+    b.step(100)
+    b.step(100)
+    if b.fused_frame()[0] != 2:
+        pytest.skip("the batch did not switch to the wide frame (row counters below the threshold)")
+    qp, qv = copies(st, n, 1e-3, seed=1)
+    b.reset()
+    load(b, st, qp, qv)
+    b.step(1)
+    assert b.fused_frame()[0] == 2
+    fq, fv, resets = b.get("qpos"), b.get("qvel"), b.warning_count()
+    b.close()
+    r = engine.Batch(cm, n)
+    r.set_keep_frame(True)
+    load(r, st, qp, qv)
+    r.step(1)
+    assert resets == 0 and r.warning_count() == 0
+    assert np.abs(fv - r.get("qvel")).max() <= 1e-12
+    for e in (0, 5, 77, 127):
+        oq, ov, dims, nefc = oracle_step(po, model, st, qp[e], qv[e])
+        assert np.abs(fq[e] - oq).max() <= 1e-11 and np.abs(fv[e] - ov).max() <= 1e-8, (e, nefc, dims)
+    r.close()
