@@ -2623,9 +2623,11 @@ template <int G> STAGE void store_state(CModel m, CLayout L, CState s, const Env
 
 // mj_checkPos / mj_checkVel / mj_checkAcc: NaN or |x| > mjMAXVAL -> flag in the int frame.  Returns 0 (fine), 1 (array a is
 // bad) or 2 (only array b is bad): mj_step checks qpos first and resets on it, so a bad qpos hides a bad qvel.
-template <int G> DEVI int any_bad(const Env &e, CLayout L, const double *a, int na, const double *b, int nb)
+template <int G> DEVI int any_bad(const Env &e, CLayout L, const double *a, int na, const double *b, int nb, const bool keep = false)
 {
+	// (keep: mj_checkAcc runs BEHIND the solver -- mjData.solver_iter is the step's iteration count when mj_step returns, so the word is put back)
 	int *flag = e.fi + L.solver_iter;  // reused as a transient flag; rewritten by fwd_constraint
+	const int old = *flag;
 	if (e.lane == 0) *flag = 0;
 	gsync<G>();
 	bool bad_a = false, bad_b = false;
@@ -2634,7 +2636,12 @@ template <int G> DEVI int any_bad(const Env &e, CLayout L, const double *a, int 
 	if (bad_b) *flag = 2;
 	if (bad_a) *flag = 1;  // (lanes of a group run in lockstep: this store lands after the one above)
 	gsync<G>();
-	return *flag;
+	const int r = *flag;
+	if (keep) {
+		gsync<G>();
+		if (e.lane == 0) *flag = old;
+	}
+	return r;
 }
 
 template <int G> __device__ __attribute__((noinline)) void reset_frame_state(CModel m, CLayout L, CState s, const EnvLite e, int warning)
@@ -3406,7 +3413,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 				// and velocity stages, before actuation (mjcb_control inside mj_forward; mujoco_ros_control_plugin.cpp:153-194)
 				if (hw_on) VIEW(P, compact, hwsim_write<G>(m, L, Pq_->hw, lite(e)));
 				forward_rest<G, CON, DENSE>(P, e, compact);
-				if (attempt || !checks || !any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0)) break;
+				if (attempt || !checks || !any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0, true)) break;
 				reset_frame_state<G>(m, L, s, lite(e), MJB_WARN_BADQACC);
 			}
 			} else {
@@ -3437,7 +3444,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 				// (RK4: once per step, at the step's own evaluation -- the PID state advances by one period; its forces stay for the sub-stages)
 				if (hw_on && !rk) VIEW(P, compact, hwsim_write<G>(m, L, Pq_->hw, lite(e)));
 				forward_rest<G, CON, DENSE>(P, e, compact);
-				if (attempt || rk || !checks || !any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0)) break;
+				if (attempt || rk || !checks || !any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0, true)) break;
 				reset_frame_state<G>(m, L, s, lite(e), MJB_WARN_BADQACC);
 			}
 				if (!rk4 || !do_rest) break;

@@ -48,7 +48,7 @@ def oracle_step(po, model, st, qp, qv):
     d.ctrl[:] = st["ctrl_step"]
     d.step()
     dims = np.array(d.contact_dim[: int(d.ncon[0])]).astype(int)
-    return np.array(d.qpos), np.array(d.qvel), dims, int(d.nefc[0])
+    return np.array(d.qpos), np.array(d.qvel), dims, int(d.nefc[0]), int(d.solver_iter[0])
 
 
 def test_mixed_cone_dimensions_on_the_default_fused_frame(setup):
@@ -61,7 +61,7 @@ def test_mixed_cone_dimensions_on_the_default_fused_frame(setup):
         b.set_keep_frame(keep)
         load(b, st, qp, qv)
         b.step(1)
-        out[keep] = (b.get("qpos"), b.get("qvel"), b.warning_count())
+        out[keep] = (b.get("qpos"), b.get("qvel"), b.warning_count(), b.get("solver_iter")[:, 0].astype(int) if keep else None)
         if not keep:
             assert b.fused_frame()[0] == 1
         b.close()
@@ -70,8 +70,10 @@ def test_mixed_cone_dimensions_on_the_default_fused_frame(setup):
     assert np.abs(out[False][1] - out[True][1]).max() <= 1e-12
     mixed = 0
     for e in (0, 1, 7, 20, 41, 63):
-        oq, ov, dims, nefc = oracle_step(po, model, st, qp[e], qv[e])
+        oq, ov, dims, nefc, iters = oracle_step(po, model, st, qp[e], qv[e])
         mixed += int(len(set(dims.tolist()) - {1}) > 1)
+        # mjData.solver_iter after mj_step is the step's iteration count (round 5: mj_checkAcc's flag word used to leave 0 there)
+        assert out[True][3][e] == iters and iters >= 1, (e, out[True][3][e], iters)
         assert 33 <= nefc <= 64, nefc  # (beyond the rows of the light workload, within the default frame's 64)
         assert np.abs(out[False][0][e] - oq).max() <= 1e-11 and np.abs(out[False][1][e] - ov).max() <= 1e-8, (e, nefc, dims)
     assert mixed >= 3, "the fixture no longer holds cones of mixed dimension"
@@ -105,6 +107,6 @@ def test_mixed_cone_dimensions_on_the_wide_fused_frame(setup):
     assert resets == 0 and r.warning_count() == 0
     assert np.abs(fv - r.get("qvel")).max() <= 1e-12
     for e in (0, 5, 77, 127):
-        oq, ov, dims, nefc = oracle_step(po, model, st, qp[e], qv[e])
+        oq, ov, dims, nefc, _ = oracle_step(po, model, st, qp[e], qv[e])
         assert np.abs(fq[e] - oq).max() <= 1e-11 and np.abs(fv[e] - ov).max() <= 1e-8, (e, nefc, dims)
     r.close()
