@@ -19,7 +19,11 @@ n = int(sys.argv[4]) if len(sys.argv) > 4 else 256
 steps = int(sys.argv[5]) if len(sys.argv) > 5 else 30
 m = mjcf.compile_xml_file(os.path.join(mjcf.ASSET_DIR, name + ".xml"), override={"solver": solver, "cone": cone})
 pyoracle.build()
-qpos, qvel = scenario_states(m, n, seed=123)
+if name == "franka_table":
+    qpos, qvel = scenario_states(m, n, seed=123)
+else:
+    from mujoco_ros_pkgs_amd import workloads
+    qpos, qvel = (workloads.hand_power_grasp_states if name == "shadow_hand_grasp" else workloads.hand_grasp_states)(m, n, seed=123)
 b = engine.Batch(engine.CompiledModel(m), n)
 b.set_keep_frame(bool(os.environ.get("KEEP_FRAME")))
 b.set("qpos", qpos); b.set("qvel", qvel)
@@ -35,7 +39,7 @@ for s in range(steps):
         d.qpos[:] = st["qpos"][e]; d.qvel[:] = st["qvel"][e]; d.qacc_warmstart[:] = st["qacc_warmstart"][e]
         d.step()
         ev = float(np.abs(gv[e] - d.qvel).max())
-        if ev > 1e-10:
+        if ev > float(os.environ.get("SCAN_TOL", "1e-10")):
             nc = int(d.ncon[0])
             print(f"step {s} env {e}: |dqvel| {ev:.2e} |dqpos| {np.abs(gq[e] - d.qpos).max():.2e}  oracle: ncon {nc} nefc {int(d.nefc[0])} iters {int(d.solver_iter[0])}"
                   + (f" (GPU iters {git[e]})" if git is not None else "") + f" dims {np.array(d.contact_dim[:nc]).astype(int).tolist()} max|qacc| {np.abs(d.qacc).max():.2e}", flush=True)
