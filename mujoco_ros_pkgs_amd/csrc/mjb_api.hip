@@ -335,6 +335,9 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact, int jrows_req = 
 		int maxdim = 1;
 		for (int p = 0; p < d.ncollpair; p++) maxdim = std::max(maxdim, M->pair_i[(size_t)8 * p + 4]);
 		L.hcd = std::min(6, maxdim);
+		// (blocks laid out by row on a frame with more than one row per lane: the line search parks its ten constants per contact in the contact's block, and a
+		//  contact of dimension 3 owns 3 x hcd doubles -- nine at hcd = 3.  Round 5, tools/wide_dim3_check.py: the neighbour's first constant was overwritten)
+		if (L.hcrow && rcap > 64 && L.hcd < 4) L.hcd = 4;
 		L.hcs = std::max(L.hcd * L.hcd, 10);
 	}
 	// (hcrow: a contact's block sits at hcd * its first row -- rows, not contacts, bound the solver that runs on this frame)

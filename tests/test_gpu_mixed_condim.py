@@ -110,3 +110,17 @@ def test_mixed_cone_dimensions_on_the_wide_fused_frame(setup):
         oq, ov, dims, nefc, _ = oracle_step(po, model, st, qp[e], qv[e])
         assert np.abs(fq[e] - oq).max() <= 1e-11 and np.abs(fv[e] - ov).max() <= 1e-8, (e, nefc, dims)
     r.close()
+
+
+def test_all_cones_of_dimension_three_on_the_wide_fused_frame(oracle_built):
+    """The sibling defect (round 5, tools/wide_dim3_check.py): a model whose cones are ALL of dimension 3, on the wide frame -- two rows per lane, the
+    line search parks ten constants per contact in the contact's block, which at a block stride of 3 per row is nine doubles.  The power-grasp hand with
+    every condim rewritten to 3; the layout now keeps a stride of 4 there (mjb_api.hip: compute_layout)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import wide_dim3_check
+    fid, worst, vs_oracle, resets = wide_dim3_check.run(n=128, steps=30, verbose=False)
+    if fid != 2:
+        pytest.skip("the batch did not switch to the wide frame")
+    assert resets == (0, 0)
+    assert worst <= 1e-11 and vs_oracle <= 1e-8, (worst, vs_oracle)

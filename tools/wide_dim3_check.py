@@ -1,27 +1,59 @@
 #!/usr/bin/env python3
-"""wide_dim3_check.py -- a Newton / elliptic model whose cones are ALL of dimension 3, with a row capacity beyond 128 (the kernel variant with fused frames that lay the
-cone blocks out by row), stepped on the fused frame against the full frame.  Run under MJB_WIDE_FRAME=1 for the wide frame (two rows per lane: the line search parks ten
-constants per contact in the contact's block -- nine doubles apart at three rows of stride three)."""
+"""wide_dim3_check.py -- the power-grasp hand with EVERY contact of condim 3 (the asset's condim="4" rewritten): Newton / elliptic, 30 dofs, 200 rows of capacity, i.e. the
+kernel variant with a wide fused frame, whose cone blocks are laid out by row (hcrow) -- at the model's largest cone dimension, 3, a contact would own 9 doubles of block
+space, and on the wide frame (two rows per lane) the line search parks TEN constants per contact there.  Two long launches switch the batch to the wide frame; then the fused
+frame is compared with the full frame step by step (state copied before every step), and with the oracle on sampled envs."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import numpy as np
-from mujoco_ros_pkgs_amd import engine, mjcf
-from test_gpu_contact import scenario_states
-m = mjcf.compile_xml_file(os.path.join(mjcf.ASSET_DIR, "franka_table.xml"), override={"solver": "Newton", "cone": "elliptic"}, nefcmax=160, nconmax=32)
-cm = engine.CompiledModel(m)
-n = 128
-qpos, qvel = scenario_states(m, n, seed=5)
-A, B = engine.Batch(cm, n), engine.Batch(cm, n)
-B.set_keep_frame(True)
-for b in (A, B):
-    b.set("qpos", qpos); b.set("qvel", qvel)
-worst = 0.0
-for s in range(40):
-    for k in ("qpos", "qvel", "qacc_warmstart", "time"):
-        A.set(k, B.get(k))
-    A.step(1); B.step(1)
-    worst = max(worst, float(np.abs(A.get("qvel") - B.get("qvel")).max()))
-nefc = B.get("nefc")[:, 0]
-print(f"fused frame id {A.fused_frame()[0]} ({A.fused_frame()[1]} B): worst |dqvel| fused vs full over 40 steps x {n} envs: {worst:.3e}; rows at the end: mean {nefc.mean():.1f} max {nefc.max()}; resets {A.warning_count()} / {B.warning_count()}")
-sys.exit(0 if worst <= 1e-11 else 1)
+from mujoco_ros_pkgs_amd import engine, mjcf, workloads
+from oracle import pyoracle
+
+
+def hand3_model():
+    xml = open(os.path.join(mjcf.ASSET_DIR, "shadow_hand_grasp.xml")).read().replace('condim="4"', 'condim="3"')
+    return mjcf.compile_xml_string(xml)
+
+
+def run(n=128, steps=40, verbose=True):
+    m = hand3_model()
+    cm = engine.CompiledModel(m)
+    qpos, qvel = workloads.hand_power_grasp_states(m, n, seed=3)
+    A, B = engine.Batch(cm, n), engine.Batch(cm, n)
+    B.set_keep_frame(True)
+    A.set("qpos", qpos); A.set("qvel", qvel)
+    A.step(100); A.step(100)
+    fid = A.fused_frame()
+    A.reset()
+    for b in (A, B):
+        b.set("qpos", qpos); b.set("qvel", qvel)
+    worst, rows = 0.0, []
+    for s in range(steps):
+        for k in ("qpos", "qvel", "qacc_warmstart", "time"):
+            A.set(k, B.get(k))
+        A.step(1); B.step(1)
+        worst = max(worst, float(np.abs(A.get("qvel") - B.get("qvel")).max()))
+        rows.append(B.get("nefc")[:, 0].copy())
+    rows = np.concatenate(rows)
+    dims = sorted(set(B.get("contact_dim").reshape(-1).astype(int).tolist()) - {0})
+    # the oracle on a few envs, one step from the batch's current state
+    pyoracle.build()
+    st = {k: B.get(k) for k in ("qpos", "qvel", "qacc_warmstart")}
+    A.set("qpos", st["qpos"]); A.set("qvel", st["qvel"]); A.set("qacc_warmstart", st["qacc_warmstart"])
+    A.step(1)
+    gv = A.get("qvel")
+    d = pyoracle.OracleData(m, fast=False)
+    wo = 0.0
+    for e in (0, n // 3, n - 1):
+        d.reset(); d.qpos[:] = st["qpos"][e]; d.qvel[:] = st["qvel"][e]; d.qacc_warmstart[:] = st["qacc_warmstart"][e]; d.step()
+        wo = max(wo, float(np.abs(gv[e] - d.qvel).max()))
+    if verbose:
+        print(f"fused frame id {fid[0]} ({fid[1]} B); contact dims present {dims}; rows mean {rows.mean():.1f} p99 {np.percentile(rows, 99):.0f}, beyond 64: {100 * (rows > 64).mean():.0f} %; "
+              f"worst |dqvel| fused vs full over {steps} steps x {n} envs: {worst:.3e}; vs the oracle (3 envs, one step): {wo:.3e}; resets {A.warning_count()} / {B.warning_count()}")
+    return fid[0], worst, wo, (A.warning_count(), B.warning_count())
+
+
+if __name__ == "__main__":
+    fid, worst, wo, _ = run()
+    sys.exit(0 if worst <= 1e-11 and wo <= 1e-8 else 1)
