@@ -21,7 +21,9 @@ CASES = [("franka_like", {}), ("lane_env_tree", {}), ("pendulum_world", {}), ("e
          ("franka_table", {}), ("franka_table", {"cone": "elliptic"}), ("franka_table", {"solver": "Newton"}),
          ("franka_table", {"solver": "Newton", "cone": "elliptic"}), ("franka_table", {"solver": "CG", "cone": "elliptic"}),
          ("shadow_hand_like", {}), ("shadow_hand_like", {"cone": "pyramidal"}), ("shadow_hand_like", {"solver": "CG"}),
-         ("shadow_hand_grasp", {}), ("shadow_hand_grasp", {"cone": "pyramidal"})]
+         ("shadow_hand_grasp", {}), ("shadow_hand_grasp", {"cone": "pyramidal"}),
+         ("franka_like", {"integrator": "RK4"}), ("franka_table", {"integrator": "RK4"}), ("franka_table", {"integrator": "RK4", "solver": "Newton", "cone": "elliptic"}),
+         ("shadow_hand_like", {"integrator": "RK4"}), ("equality_world", {"integrator": "RK4"})]
 
 
 @pytest.mark.parametrize("name,over", CASES, ids=[n + ("" if not o else "-" + "-".join(o.values())) for n, o in CASES])
