@@ -2820,7 +2820,7 @@ STAGE void fwd_constraint_newton(CModel m, CLayout L, const EnvLite &e, double *
 					//  zeros went to the neighbour, tools/replay_reset.py found the env-step of the power grasp at which that made the Hessian indefinite.)
 #pragma unroll
 					for (int j = 0; j < DMAX; j++) {
-						const bool rowin = j < dim;
+						const bool rowin = j < 3 || j < dim;  // (an elliptic cone has 3, 4 or 6 rows: only the block rows from the fourth on can lie past it)
 						const double gj = rowin ? g[j] : g[0];
 #pragma unroll
 						for (int c2 = 0; c2 < DMAX; c2++) {
