@@ -44,5 +44,5 @@ for wide in (False, True):
         d.reset(); d.qpos[:] = st["qpos"][e]; d.qvel[:] = st["qvel"][e]; d.qacc_warmstart[:] = st["qacc_warmstart"][e]; d.step()
         wo = max(wo, float(np.abs(gv[e] - d.qvel).max()))
     print(f"pattern {pat}: fused frame {fid}; dims present {sorted(dims - {0})}; rows mean {rows.mean():.1f} max {rows.max()}; fused vs full worst |dqvel| {worst:.3e}; "
-          f"full frame vs oracle (8 envs, one step) {wo:.3e}; resets fused / full {A.warning_count()} / {B.warning_count()}", flush=True)
+          f"full frame vs oracle (8 envs, one step) {wo:.3e}; resets fused / full {A.warning_count()} / {B.warning_count()}; contactfull {A.warning('contactfull')} / {B.warning('contactfull')} cnstrfull {A.warning('cnstrfull')} / {B.warning('cnstrfull')}", flush=True)
     A.close(); B.close()
