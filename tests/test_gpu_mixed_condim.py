@@ -124,3 +124,18 @@ def test_all_cones_of_dimension_three_on_the_wide_fused_frame(oracle_built):
         pytest.skip("the batch did not switch to the wide frame")
     assert resets == (0, 0)
     assert worst <= 1e-11 and vs_oracle <= 1e-8, (worst, vs_oracle)
+
+
+@pytest.mark.parametrize("pattern", ["346436", "666666"])
+def test_rewritten_condim_patterns_on_both_fused_frames(pattern, oracle_built):
+    """The power-grasp hand with its condim attributes rewritten (tools/mixed_condim_hand.py): cones of dimension 3, 4 and 6 in one env-step (block stride
+    hcd = 6), and all of dimension 6 (170 rows on average: most env-steps beyond either fused frame's rows) -- fused frames against the full frame, and the oracle."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import mixed_condim_hand
+    res = mixed_condim_hand.run(pattern, n=64, steps=30, verbose=False)
+    assert res[0]["frame"] == 1
+    for r in res:
+        assert r["resets"] == (0, 0) and r["worst"] <= 1e-11 and r["vs_oracle"] <= 1e-8, r
+    if pattern == "346436":
+        assert res[0]["dims"] == [3, 4, 6], res[0]["dims"]
