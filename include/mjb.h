@@ -246,7 +246,8 @@ int mjb_fused_frame(const mjb_batch *b);
  * ahead at 65 536.  mode: -1 = automatic (fused launches over >= MJB_LANE_ENV_MIN_ENVS envs, default 4096 -- the whole batch, or the non-callback envs of a
  * split step, mjb_step_rest -- of a model whose
  * topology is compiled in, with no per-env model overrides / hwsim stage / xfrc_applied), 0 = never, 1 = whenever eligible.
- * The environment variable MJB_LANE_ENV (same values) sets the default of new batches.  No reference counterpart. */
+ * The environment variable MJB_LANE_ENV (same values) sets the default of new batches (read by mjb_make_batch).  While mjb_set_stats is
+ * counting, fused launches run the generic kernels whatever the mode (the counters live in those).  No reference counterpart. */
 int mjb_set_lane_env(mjb_batch *b, int mode);
 /* >= 0: index of the compiled-in topology the batch's model matches; -2: none compiled in, but the model's structure fits the kernel -- its
  * first eligible launch builds the kernel for it through hiprtc (libhiprtc.so and csrc/mjb_lane_env_kernel.h next to libmjb.so; a few

@@ -121,9 +121,11 @@ struct mjb_batch {
 	// beyond 128 -- copied to pinned host memory behind it; the next long launch waits for that copy (the launch has ended by then or is
 	// about to) and picks its frame from them: deterministic for a given sequence of launches
 	bool wide = false;
-	unsigned int *rowstat_dev = nullptr, *rowstat_host = nullptr;
+	unsigned long long *rowstat_dev = nullptr, *rowstat_host = nullptr;  // (64-bit: envs x steps of one launch may exceed 2^32)
 	hipEvent_t ev_rowstat = nullptr;
 	bool rowstat_pending = false;
+	bool rowstat_ever = false;     // a sample of the CURRENT workload has been looked at (cleared by mjb_reset / a new qpos: the next long launch probes first)
+	bool probe_now = false, decide_now = false;  // mjb_step's probe launch / the launch behind it (launch())
 	unsigned char *mask_dev = nullptr;
 	KernelParams *params_dev = nullptr;  // device copy of {dm, L, st, nz}
 	double *metrics_dev = nullptr;       // [16] mjb_metrics
@@ -1377,6 +1379,10 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	b->device = device;
 	b->nenv = nenv;
 	b->L = M->L;
+	if (const char *v = getenv("MJB_LANE_ENV")) {  // default lane_env_mode of new batches (include/mjb.h, mjb_set_lane_env)
+		const int k = atoi(v);
+		if (k >= -1 && k <= 1) b->lane_env_mode = k;
+	}
 	const mjb_model_desc &h = M->h;
 	// ---- device model blob: [ints | doubles | derived int tables]
 	size_t ni = M->hint.size(), nd = M->hdbl.size();
@@ -1516,25 +1522,29 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	s.env_mass = nullptr;
 	s.pgs_B = nullptr;
 	s.efc_Jg = nullptr;
+	s.efc_Jg_stride = 0;
 	s.sched = nullptr;
 	if (h.nefcmax > 0) {  // constrained kernels: work queue of the chunked fused launches
 		s.sched = dev_alloc<int>((size_t)nenv + 1);
 		ok = ok && s.sched;
 	}
 	if (h.solver == MJB_SOL_NEWTON && h.nefcmax > 128) {  // kernel variant 4: row data of the env-steps beyond the fused frame's 64 rows
-		s.efc_Jg = dev_alloc<double>((size_t)nenv * mjb_rowblock_doubles(h.nefcmax, h.nv, h.nconmax, M->Lc.hcs));
+		// (stride: the kernels index the block with the cone-block stride of the frame THEY run on -- the wide frame of an all-condim-3 model has
+		//  hcs 16 where the default frame has 10: size for the largest of the three layouts)
+		s.efc_Jg_stride = mjb_rowblock_doubles(h.nefcmax, h.nv, h.nconmax, std::max(M->L.hcs, std::max(M->Lc.hcs, M->Lw.hcs)));
+		s.efc_Jg = dev_alloc<double>((size_t)nenv * s.efc_Jg_stride);
 		ok = ok && s.efc_Jg;
 		if (M->has_wide) {  // row counters of the wide-frame policy (launch())
-			b->rowstat_dev = dev_alloc<unsigned int>(4);
-			ok = ok && b->rowstat_dev && hipHostMalloc((void **)&b->rowstat_host, 4 * sizeof(unsigned int), hipHostMallocDefault) == hipSuccess &&
+			b->rowstat_dev = dev_alloc<unsigned long long>(4);
+			ok = ok && b->rowstat_dev && hipHostMalloc((void **)&b->rowstat_host, 4 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess &&
 			     hipEventCreateWithFlags(&b->ev_rowstat, hipEventDisableTiming) == hipSuccess;
 			if (ok) {
-				memset(b->rowstat_host, 0, 4 * sizeof(unsigned int));
-				ok = hipMemset(b->rowstat_dev, 0, 4 * sizeof(unsigned int)) == hipSuccess;
+				memset(b->rowstat_host, 0, 4 * sizeof(unsigned long long));
+				ok = hipMemset(b->rowstat_dev, 0, 4 * sizeof(unsigned long long)) == hipSuccess;
 			}
 		}
 	}
-	s.rowstat = b->rowstat_dev;
+	s.rowstat = nullptr;  // (set by launch() for the launches that count)
 	if (h.solver == MJB_SOL_PGS && h.nv <= 16 && h.nefcmax > 64) {
 		s.pgs_B = dev_alloc<double>((size_t)nenv * h.nefcmax * h.nv);  // (elliptic PGS never exceeds 64 rows: mjb_compile)
 		ok = ok && s.pgs_B;
@@ -1637,6 +1647,16 @@ static int kernel_variant(const mjb_model_desc &h)
 	return (h.solver == MJB_SOL_CG ? 4 : 0) + (h.nefcmax <= 64 ? 2 : (h.nefcmax <= 128 ? 3 : 4));
 }
 
+static bool stream_capturing(hipStream_t st)
+{
+	hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+	if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+		(void)hipGetLastError();
+		return false;
+	}
+	return cs != hipStreamCaptureStatusNone;
+}
+
 static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi = -1, hipStream_t on = nullptr)
 {
 	if (env_hi < 0) env_hi = b->nenv;
@@ -1654,20 +1674,40 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 		static const int pinned = [] { const char *v = getenv("MJB_WIDE_FRAME"); return v ? atoi(v) : -1; }();
 		bool want = b->wide;
 		if (pinned >= 0) want = pinned != 0;
-		else if (compact && whole && nsteps >= 100) {
+		else if (compact && whole && (nsteps >= 100 || b->probe_now || b->decide_now) && !stream_capturing(stream)) {  // (under stream capture nothing can be waited for: the frame stays)
 			if (b->rowstat_pending) {
-				HIP_TRY(hipEventSynchronize(b->ev_rowstat));
-				b->rowstat_pending = false;
-				const double tot = b->rowstat_host[0], gt64 = b->rowstat_host[1];
-				if (tot > 0) {
-					if (!b->wide && gt64 > 0.25 * tot) want = true;
-					else if (b->wide && gt64 < 0.05 * tot) want = false;
-				}
+				// (the newest COMPLETED sample: a launch behind a running counting launch does not wait for it -- back-to-back launches stay
+				//  enqueued ahead of the device -- except right behind mjb_step's probe launch, whose whole point is this decision)
+				// Default: WAIT for the previous counting launch's sample (it has ended or is about to) -- the choice is then a function of the
+				// sequence of launches alone, and a rollout reproduces bit for bit.  MJB_WIDE_POLICY_NOWAIT=1: take it only if it has landed
+				// (back-to-back launches stay enqueued ahead of the device; which launch switches frames then depends on timing, results agree to
+				// rounding).  Right behind mjb_step's probe launch the wait is the point.
+				static const bool nowait = [] { const char *v = getenv("MJB_WIDE_POLICY_NOWAIT"); return v && *v == '1'; }();
+				const hipError_t q = (b->decide_now || !nowait) ? hipEventSynchronize(b->ev_rowstat) : hipEventQuery(b->ev_rowstat);
+				if (q == hipSuccess) {
+					b->rowstat_pending = false;
+					b->rowstat_ever = true;
+					const double tot = (double)b->rowstat_host[0], gt64 = (double)b->rowstat_host[1];
+					if (tot > 0) {
+						if (!b->wide && gt64 > 0.25 * tot) want = true;
+						else if (b->wide && gt64 < 0.05 * tot) want = false;
+					}
+				} else if (q != hipErrorNotReady)
+					return fail(MJB_ENODEVICE, "hipEventQuery(row counters): %s", hipGetErrorString(q));
+				else
+					(void)hipGetLastError();
 			}
-			count_rows = true;
+			count_rows = !b->rowstat_pending;  // (one sample in flight at a time: the pinned words belong to it)
 		}
 		if (want != b->wide) {
 			b->wide = want;
+			b->params_dirty = true;
+		}
+	}
+	{  // the kernels count rows (three atomics per env-step on one address) only in the launches whose counters are read
+		unsigned long long *rs = count_rows ? b->rowstat_dev : nullptr;
+		if (b->st.rowstat != rs) {
+			b->st.rowstat = rs;
 			b->params_dirty = true;
 		}
 	}
@@ -1688,11 +1728,8 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 	// 1024 envs x 100 steps 4.04 / 4.72 M env-steps/s, x 1000 steps 4.20 / 5.00 M, 768 envs 3.40 / 3.75 M; 1280 envs 5.32 / 3.38 M.
 	bool own_slot = false;
 	if (compact && variant != 0) {
-		static const int ncu = [] {
-			int dev = 0, n = 0;
-			if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-			return n;
-		}();
+		int ncu = 0;  // (of THIS batch's device: a process may drive several)
+		if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, b->device) != hipSuccess) ncu = 0;
 		const int granules = (mjb_frame_bytes(b->model, fused_id) + 1279) / 1280;  // (gfx950: 128 LDS granules of 1280 bytes per CU)
 		const int occ = std::min(variant == 9 ? 8 : 4, 128 / std::max(1, granules));  // (512-register kernels: one wave per SIMD)
 		own_slot = ncu > 0 && b->nenv <= occ * ncu;
@@ -1781,7 +1818,7 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 	}
 	const bool zspec = zuse && b->zdouble;
 	if (zspec) HIP_TRY(hipEventRecord(b->ev_noise_go, stream));  // (everything before this launch -- the last reader of the other half -- is done)
-	if (count_rows) HIP_TRY(hipMemsetAsync(b->rowstat_dev, 0, 4 * sizeof(unsigned int), stream));
+	if (count_rows) HIP_TRY(hipMemsetAsync(b->rowstat_dev, 0, 4 * sizeof(unsigned long long), stream));
 	// The lane = env kernel (mjb_lane_env.hip) for fused launches of a model whose topology is compiled in: one env per lane, no frame.
 	// Per-env model overrides, the device hwsim stage, xfrc_applied and frame dumps keep the generic kernels.
 	bool use_le = false;
@@ -1804,7 +1841,7 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 	                         b->epb, variant | (chunk << 8), (b->lanes == 16 && !b->env_mass && mode != MJB_MODE_STEP21 && b->model->h.integrator == MJB_INT_EULER && b->model->h.nefcmax <= 0 && b->model->h.nv <= 16 && b->model->h.nbody <= 16 && b->model->h.nu <= 16 && b->model->h.njnt <= 16) ? (b->model->h.nv <= 8 ? 8 : (b->model->h.nv <= 12 ? 12 : 16)) : 0, stream);
 	if (rc != 0) return fail(MJB_ENODEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
 	if (count_rows) {  // this launch's row counters, to pinned host memory behind it
-		HIP_TRY(hipMemcpyAsync(b->rowstat_host, b->rowstat_dev, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipMemcpyAsync(b->rowstat_host, b->rowstat_dev, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 		HIP_TRY(hipEventRecord(b->ev_rowstat, stream));
 		b->rowstat_pending = true;
 	}
@@ -1831,7 +1868,24 @@ int mjb_step(mjb_batch *b, int nsteps)
 	int jrc = join_rest(b);
 	if (jrc) return jrc;
 	b->split_ncb = -1;  // (an open split step is abandoned)
-	int rc = launch(b, MJB_MODE_STEP, nsteps);
+	// Kernel variant 4 with a wide fused frame: a long launch on a workload nobody has looked at yet (a new batch, after mjb_reset or a new
+	// qpos) starts with a short PROBE launch that counts this state's rows, and picks its frame from that -- the first rollout of a
+	// high-contact batch used to run on the default frame (r05: 1461 ms against 288 ms in steady state).  A launch cut in two is the same
+	// rollout (the state crosses HBM between launches exactly as between the chunks of one).
+	int rc = MJB_OK;
+	if (nsteps >= 100 && b->rowstat_dev && b->model->has_wide && !b->rowstat_ever && !b->rowstat_pending && !b->st.use_xfrc && !b->st.keep_frame) {
+		const int probe = 4;
+		b->probe_now = true;
+		rc = launch(b, MJB_MODE_STEP, probe);
+		b->probe_now = false;
+		if (rc != MJB_OK) return rc;
+		b->step_counter += (unsigned int)probe;
+		b->steps_taken += (unsigned long long)probe;
+		nsteps -= probe;
+		b->decide_now = b->rowstat_pending;
+	}
+	rc = launch(b, MJB_MODE_STEP, nsteps);
+	b->decide_now = false;
 	if (rc == MJB_OK) {
 		b->step_counter += (unsigned int)nsteps;
 		b->steps_taken += (unsigned long long)nsteps;
@@ -2047,6 +2101,7 @@ int mjb_reset(mjb_batch *b, const uint8_t *mask)
 	if (rc != 0) return fail(MJB_ENODEVICE, "reset launch failed: %s", hipGetErrorString((hipError_t)rc));
 	if (mask) HIP_TRY(hipStreamSynchronize(b->stream));
 	b->frame_valid = false;
+	if (!mask) b->rowstat_ever = false;  // (a new workload: the next long launch probes its rows first)
 	return MJB_OK;
 }
 
@@ -2153,6 +2208,7 @@ int mjb_set(mjb_batch *b, int field, int env_lo, int env_hi, const double *host)
 			b->st.use_xfrc = 1;
 			b->params_dirty = true;
 		}
+		if (field == MJB_F_qpos && env_lo == 0 && env_hi == b->nenv) b->rowstat_ever = false;  // (wide-frame policy: a new workload)
 		return MJB_OK;
 	}
 	if (field != MJB_F_qfrc_passive)

@@ -1027,7 +1027,7 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 	const int lane = e.lane, nv = m.nv;
 	[[maybe_unused]] RowBlock gb{};
 	if constexpr (TAG == 4)
-		if (s.efc_Jg) gb = mjb_rowblock(s.efc_Jg + (size_t)e.env * mjb_rowblock_doubles(m.nefcmax, nv, m.nconmax, L.hcs), m.nefcmax, nv, m.nconmax, L.hcs);
+		if (s.efc_Jg) gb = mjb_rowblock(s.efc_Jg + (size_t)e.env * s.efc_Jg_stride, m.nefcmax, nv, m.nconmax, L.hcs);
 	[[maybe_unused]] double *Jg = gb.J;
 	auto jrow = [&](int r) -> double * {  // row r of efc_J
 		if constexpr (TAG == 4) return r < L.jrows ? f + L.efc_J + r * nv : Jg + (size_t)r * nv;
@@ -1587,7 +1587,7 @@ template <int G, int TAG> STAGE void reference_constraint(CModel m, CLayout L, C
 	if constexpr (TAG == 4) {  // (see make_constraint: all of J -- on a row-capped frame all row data -- sits in HBM when the rows outnumber the frame's share)
 		if (st.efc_Jg && nefc > L.jrows) {
 			MJB_KEEP_BRANCH();
-			const RowBlock gb = mjb_rowblock(st.efc_Jg + (size_t)e.env * mjb_rowblock_doubles(m.nefcmax, nv, m.nconmax, L.hcs), m.nefcmax, nv, m.nconmax, L.hcs);
+			const RowBlock gb = mjb_rowblock(st.efc_Jg + (size_t)e.env * st.efc_Jg_stride, m.nefcmax, nv, m.nconmax, L.hcs);
 			if (L.rcap < m.nefcmax) rows(gb.J, gb.aref, gb.b);
 			else rows(gb.J, f + L.efc_aref, f + L.efc_b);
 			__threadfence();

@@ -149,7 +149,7 @@ struct DevState {
 	unsigned long long *nwarn;     // [MJB_NWARNING] mjData.warning[].number summed over the envs (mjb_warning)
 	unsigned long long *prof;      // [64] per-stage cycle sums + call counts (profiling build only), else NULL
 	unsigned long long *stats;     // [MJB_NSTATS] workload statistics (mjb_set_stats), NULL when off
-	unsigned int *rowstat;         // [4] evaluations | beyond 64 rows | beyond 128 rows | - of the current long fused launch (kernel variant 4's wide-frame policy), or NULL
+	unsigned long long *rowstat;         // [4] evaluations | beyond 64 rows | beyond 128 rows | - of the current long fused launch (kernel variant 4's wide-frame policy), or NULL
 	int nenv;
 	int frame_stride;              // doubles per env in frame_ws
 	const double *env_gravity;       // [nenv][3] per-env gravity override (NULL: the model's)
@@ -161,6 +161,7 @@ struct DevState {
 	                                 // body_mass | body_subtreemass | body_inertia[3] | dof_invweight0 | body_invweight0[2] | tendon_invweight0 | meaninertia
 	int *sched;                      // [1 + nenv] work counter | chunks done per env, of a chunked fused launch (constrained kernels); NULL otherwise
 	double *efc_Jg;                  // [nenv][mjb_rowblock_doubles] row data of the env-steps whose rows outnumber the fused frame's share (kernel variant 4, RowBlock); NULL otherwise
+	unsigned long long efc_Jg_stride;  // doubles per env of efc_Jg: sized for the largest cone-block stride of the model's three frame layouts (the kernels lay a block out with the stride of the frame they run on)
 	double *pgs_B;                   // [nenv][nefcmax * nv] rows of J M^-1 of the PGS steps beyond 64 rows (nv <= 16 models keep them out of LDS); NULL otherwise
 	int use_xfrc;                  // xfrc_applied has ever been written
 	const double *zbuf;            // [nsteps][nenv][nu] standard normals of the ctrl-noise injector for ONE fused launch, pre-generated by

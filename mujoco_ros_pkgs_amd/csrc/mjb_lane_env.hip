@@ -23,6 +23,7 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -215,7 +216,22 @@ struct JitKernel {
 };
 std::mutex jit_mutex;
 std::map<std::string, JitKernel> jit_cache;  // key: device | LDS budget | topology text
-std::string jit_last_error;
+std::string jit_last_error;  // guarded by jit_err_mutex; mjb_lane_env_jit_error() hands out a thread-local copy
+std::mutex jit_err_mutex;
+void set_jit_error(const std::string &e)
+{
+	std::lock_guard<std::mutex> lock(jit_err_mutex);
+	jit_last_error = e;
+}
+// gfx target of the device the kernel is built for (the in-tree build's $(ARCH) is gfx950; a hiprtc build follows the device it runs on)
+std::string device_arch(int dev)
+{
+	hipDeviceProp_t p;
+	if (hipGetDeviceProperties(&p, dev) != hipSuccess) return "gfx950";
+	std::string a = p.gcnArchName;
+	const size_t c = a.find(':');
+	return c == std::string::npos ? a : a.substr(0, c);
+}
 
 // directory of the kernel header: next to libmjb.so (the in-tree build), or MJB_LANE_ENV_SRC
 std::string source_dir()
@@ -262,7 +278,8 @@ const JitKernel &jit_get(const mjb_model_desc &h, int lp, int duo)  // duo: 0 so
 	void *prog = nullptr;
 	if (r.create(&prog, src.c_str(), "mjb_lane_env_rt.hip", 0, nullptr, nullptr) != 0) { k.error = "hiprtcCreateProgram failed"; return k; }
 	const std::string i1 = "-I" + dir, i2 = "-I" + dir + "/../../include";
-	const char *opts[] = { "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-mllvm", "-disable-machine-licm", i1.c_str(), i2.c_str() };
+	const std::string archopt = "--offload-arch=" + device_arch(dev);
+	const char *opts[] = { archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=fast", "-mllvm", "-disable-machine-licm", i1.c_str(), i2.c_str() };
 	const int crc = r.compile(prog, (int)(sizeof opts / sizeof *opts), opts);
 	if (crc != 0) {
 		size_t n = 0;
@@ -289,15 +306,48 @@ const JitKernel &jit_get(const mjb_model_desc &h, int lp, int duo)  // duo: 0 so
 
 }  // namespace
 
-const char *mjb_lane_env_jit_error(void) { return jit_last_error.c_str(); }
+namespace {
+// CU count and the kernels' LDS attribute, cached per device (hipFuncSetAttribute acts on the current device's copy of the function)
+int device_cus(int dev)
+{
+	static std::mutex mu;
+	static std::map<int, int> cus;
+	std::lock_guard<std::mutex> lock(mu);
+	auto it = cus.find(dev);
+	if (it != cus.end()) return it->second;
+	int c = 0;
+	if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 0;
+	cus[dev] = c;
+	return c;
+}
+hipError_t lds_attr_once(const void *fn, int bytes, int dev)
+{
+	if (bytes <= 65536) return hipSuccess;
+	static std::mutex mu;
+	static std::map<std::pair<const void *, int>, hipError_t> done;
+	std::lock_guard<std::mutex> lock(mu);
+	auto key = std::make_pair(fn, dev);
+	auto it = done.find(key);
+	if (it != done.end()) return it->second;
+	const hipError_t r = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+	done[key] = r;
+	return r;
+}
+}  // namespace
+
+const char *mjb_lane_env_jit_error(void)
+{
+	thread_local std::string copy;
+	std::lock_guard<std::mutex> lock(jit_err_mutex);
+	copy = jit_last_error;
+	return copy.c_str();
+}
 
 // process-wide choice of the kernel's FORM (include/mjb.h): -1 = by batch size (default; MJB_LANE_ENV_DUO overrides), 0 / 1 / 2
-static int le_form_override = -1, le_form_last = -1;
+static std::atomic<int> le_form_override{ -1 }, le_form_last{ -1 };
 int mjb_lane_env_set_form(int form)
 {
-	const int prev = le_form_override;
-	le_form_override = (form >= 0 && form <= 3) ? form : -1;
-	return prev;
+	return le_form_override.exchange((form >= 0 && form <= 3) ? form : -1);
 }
 int mjb_lane_env_last_form(void) { return le_form_last; }
 
@@ -370,11 +420,10 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 	static const int wl = [] { const char *v = getenv("MJB_LANE_ENV_WAVE_LANES"); const int k = v ? atoi(v) : 64; return (k == 16 || k == 32) ? k : 64; }();
 	const dim3 grid((unsigned int)((n + wl - 1) / wl)), block(wl);
 	// LDS budget per wavefront from the CUs the launch leaves idle: one wavefront per CU may take all of its LDS
-	static const int ncu = [] {
-		int dev = 0, c = 0;
-		if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 0;
-		return c;
-	}();
+	// (per DEVICE: a process may drive several GPUs, one batch each -- ADVICE r05)
+	int cur_dev = 0;
+	(void)hipGetDevice(&cur_dev);
+	const int ncu = device_cus(cur_dev);
 	static const int forced = [] { const char *v = getenv("MJB_LANE_ENV_LDS_KB"); return v ? atoi(v) : 0; }();  // measurement knob: 40 / 80 / 160
 	// (from the BATCH's size, not the launch's env range: the instantiations differ in where data waits, and the compiler contracts a
 	//  few multiply-adds differently around that -- results agree to rounding, not bit for bit -- so every launch of one batch, whole or
@@ -385,7 +434,8 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 	// DUO: two wavefronts per 64 envs (mjb_lane_env_kernel.h) while the batch leaves at least every second SIMD idle -- the step's
 	// position half and velocity half side by side.  MJB_LANE_ENV_DUO=0 / 1: never / whenever the LDS budget allows (measurement knob)
 	static const int duo_env = [] { const char *v = getenv("MJB_LANE_ENV_DUO"); return v ? atoi(v) : -1; }();
-	const int duo_mode = le_form_override >= 0 ? le_form_override : duo_env;
+	const int form_ov = le_form_override.load();
+	const int duo_mode = form_ov >= 0 ? form_ov : duo_env;
 	static const int duo_max_waves = [] { const char *v = getenv("MJB_LANE_ENV_DUO_MAX_WAVES"); return v ? atoi(v) : -1; }();
 	int duo = (wl == 64 && lp >= 80 && duo_mode != 0 && (duo_mode > 0 || waves <= (duo_max_waves >= 0 ? duo_max_waves : 2 * ncu))) ? 1 : 0;
 	// ... pipelined (nothing computed twice) when a workgroup has a CU's LDS to itself.  MJB_LANE_ENV_DUO=1: the two-halves form only
@@ -404,7 +454,7 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 			}
 			const int fit = need <= 40 ? 40 : (need <= 80 ? 80 : 160);
 			if (need > 160) {
-				jit_last_error = "the model needs more than 160 KB of LDS per wavefront";
+				set_jit_error("the model needs more than 160 KB of LDS per wavefront");
 				return MJB_LE_UNAVAILABLE;
 			}
 			if (fit > lp) lp = fit;
@@ -414,7 +464,7 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 		}
 		const JitKernel &k = jit_get(*h, lp, duo);
 		if (!k.fn) {
-			jit_last_error = k.error;
+			set_jit_error(k.error);
 			return MJB_LE_UNAVAILABLE;
 		}
 		const KernelParams MJB_AS4 *Pd = (const KernelParams MJB_AS4 *)Pdev;
@@ -428,7 +478,7 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 	{                                                                                                                                         \
 		auto kern = mjb_lane_env_kernel<T, LPV>;                                                                                              \
 		constexpr int bytes = Lds<T, LPV>::bytes();                                                                                           \
-		static const hipError_t attr = bytes > 65536 ? hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) : hipSuccess; \
+		const hipError_t attr = lds_attr_once(reinterpret_cast<const void *>(kern), bytes, cur_dev);                                          \
 		if (attr != hipSuccess) return (int)attr;                                                                                             \
 		le_form_last = 0;                                                                                                                     \
 		hipLaunchKernelGGL(kern, grid, block, bytes, (hipStream_t)stream, (const KernelParams MJB_AS4 *)Pdev, nsteps, step0, env_lo, env_hi); \
@@ -438,7 +488,7 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 	{                                                                                                                                         \
 		auto kern = mjb_lane_env_duo_kernel<T, LPV>;                                                                                          \
 		constexpr int bytes = duo_bytes<T, LPV>();                                                                                            \
-		static const hipError_t attr = bytes > 65536 ? hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) : hipSuccess; \
+		const hipError_t attr = lds_attr_once(reinterpret_cast<const void *>(kern), bytes, cur_dev);                                          \
 		if (attr != hipSuccess) return (int)attr;                                                                                             \
 		le_form_last = 1;                                                                                                                     \
 		hipLaunchKernelGGL(kern, grid, dim3(128), bytes, (hipStream_t)stream, (const KernelParams MJB_AS4 *)Pdev, nsteps, step0, env_lo, env_hi); \
@@ -448,7 +498,7 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 	if constexpr (duo2_bytes<T>() <= 160 * 1024) {                                                                                            \
 		auto kern = mjb_lane_env_duo2_kernel<T>;                                                                                              \
 		constexpr int bytes = duo2_bytes<T>();                                                                                                \
-		static const hipError_t attr = bytes > 65536 ? hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) : hipSuccess; \
+		const hipError_t attr = lds_attr_once(reinterpret_cast<const void *>(kern), bytes, cur_dev);                                          \
 		if (attr != hipSuccess) return (int)attr;                                                                                             \
 		le_form_last = 2;                                                                                                                     \
 		hipLaunchKernelGGL(kern, grid, dim3(128), bytes, (hipStream_t)stream, (const KernelParams MJB_AS4 *)Pdev, nsteps, step0, env_lo, env_hi); \
@@ -458,7 +508,7 @@ int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc
 	if constexpr (trio_bytes<T>() <= 160 * 1024) {                                                                                            \
 		auto kern = mjb_lane_env_trio_kernel<T>;                                                                                              \
 		constexpr int bytes = trio_bytes<T>();                                                                                                \
-		static const hipError_t attr = bytes > 65536 ? hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) : hipSuccess; \
+		const hipError_t attr = lds_attr_once(reinterpret_cast<const void *>(kern), bytes, cur_dev);                                          \
 		if (attr != hipSuccess) return (int)attr;                                                                                             \
 		le_form_last = 3;                                                                                                                     \
 		hipLaunchKernelGGL(kern, grid, dim3(192), bytes, (hipStream_t)stream, (const KernelParams MJB_AS4 *)Pdev, nsteps, step0, env_lo, env_hi); \

@@ -2789,9 +2789,9 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 		VIEW(P, compact, {
 			const int ne = __builtin_amdgcn_readfirstlane(e.fi[L.nefc]);
 			if (s.rowstat != nullptr && e.lane == 0) {  // what the host's wide-frame policy reads after the launch
-				atomicAdd(s.rowstat, 1u);
-				if (ne > 64) atomicAdd(s.rowstat + 1, 1u);
-				if (ne > 128) atomicAdd(s.rowstat + 2, 1u);
+				atomicAdd(s.rowstat, 1ull);
+				if (ne > 64) atomicAdd(s.rowstat + 1, 1ull);
+				if (ne > 128) atomicAdd(s.rowstat + 2, 1ull);
 			}
 			if (L.jrows >= m.nefcmax && ne > 64) {
 				MJB_KEEP_BRANCH();
@@ -2804,7 +2804,7 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 				fwd_constraint_newton<G, 2>(m, L, e);
 			} else {
 				MJB_KEEP_BRANCH();
-				fwd_constraint_newton<G, 4, false, true>(m, L, e, s.efc_Jg + (size_t)e.env * mjb_rowblock_doubles(m.nefcmax, m.nv, m.nconmax, L.hcs));
+				fwd_constraint_newton<G, 4, false, true>(m, L, e, s.efc_Jg + (size_t)e.env * s.efc_Jg_stride);
 			}
 		});
 	} else if constexpr (CON >= 2 && CON <= 3 && G == 64) {

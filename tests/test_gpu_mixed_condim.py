@@ -126,6 +126,21 @@ def test_all_cones_of_dimension_three_on_the_wide_fused_frame(oracle_built):
     assert worst <= 1e-11 and vs_oracle <= 1e-8, (worst, vs_oracle)
 
 
+def test_row_block_spills_of_the_wide_frame_on_the_all_dimension_three_hand(oracle_built):
+    """the env's spill-over block in HBM (DevState::efc_Jg) was strided by the DEFAULT frame's cone-block stride (hcs 10 on this model)
+    while the kernels on the wide frame laid it out with theirs (hcs 16): the last ~4 % of the envs wrote past the allocation.  A wide frame of 68 rows
+    sends a large share of this workload's env-steps to the block; every env -- the last ones in particular -- against the full frame."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import wide_dim3_check
+    fid, worst, vs_oracle, resets = wide_dim3_check.run(n=256, steps=20, verbose=False, wide_rows=68)
+    if fid != 2:
+        pytest.skip("the batch did not switch to the wide frame")
+    assert wide_dim3_check.run.last["rows_beyond"] >= 0.05, wide_dim3_check.run.last
+    assert resets == (0, 0)
+    assert worst <= 1e-11 and wide_dim3_check.run.last["worst_tail"] <= 1e-11 and vs_oracle <= 1e-8, (worst, vs_oracle)
+
+
 @pytest.mark.parametrize("pattern", ["346436", "666666"])
 def test_rewritten_condim_patterns_on_both_fused_frames(pattern, oracle_built):
     """The power-grasp hand with its condim attributes rewritten (tools/mixed_condim_hand.py): cones of dimension 3, 4 and 6 in one env-step (block stride

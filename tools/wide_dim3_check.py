@@ -16,9 +16,21 @@ def hand3_model():
     return mjcf.compile_xml_string(xml)
 
 
-def run(n=128, steps=40, verbose=True):
+def run(n=128, steps=40, verbose=True, wide_rows=None):
+    """wide_rows: rows of the wide frame (MJB_WIDE_ROWS, read by mjb_compile) -- 68 sends most env-steps of this workload past the frame's rows, to the
+    env's row block in HBM (DevState::efc_Jg, whose per-env stride must cover the WIDE frame's cone-block stride: ADVICE r05)."""
     m = hand3_model()
-    cm = engine.CompiledModel(m)
+    old = os.environ.get("MJB_WIDE_ROWS")
+    if wide_rows is not None:
+        os.environ["MJB_WIDE_ROWS"] = str(wide_rows)
+    try:
+        cm = engine.CompiledModel(m)
+    finally:
+        if wide_rows is not None:
+            if old is None:
+                del os.environ["MJB_WIDE_ROWS"]
+            else:
+                os.environ["MJB_WIDE_ROWS"] = old
     qpos, qvel = workloads.hand_power_grasp_states(m, n, seed=3)
     A, B = engine.Batch(cm, n), engine.Batch(cm, n)
     B.set_keep_frame(True)
@@ -28,12 +40,14 @@ def run(n=128, steps=40, verbose=True):
     A.reset()
     for b in (A, B):
         b.set("qpos", qpos); b.set("qvel", qvel)
-    worst, rows = 0.0, []
+    worst, worst_tail, rows = 0.0, 0.0, []
     for s in range(steps):
         for k in ("qpos", "qvel", "qacc_warmstart", "time"):
             A.set(k, B.get(k))
         A.step(1); B.step(1)
-        worst = max(worst, float(np.abs(A.get("qvel") - B.get("qvel")).max()))
+        dv = np.abs(A.get("qvel") - B.get("qvel"))
+        worst = max(worst, float(dv.max()))
+        worst_tail = max(worst_tail, float(dv[-max(1, n // 16):].max()))  # (the envs whose row blocks sit at the end of efc_Jg)
         rows.append(B.get("nefc")[:, 0].copy())
     rows = np.concatenate(rows)
     dims = sorted(set(B.get("contact_dim").reshape(-1).astype(int).tolist()) - {0})
@@ -51,6 +65,7 @@ def run(n=128, steps=40, verbose=True):
     if verbose:
         print(f"fused frame id {fid[0]} ({fid[1]} B); contact dims present {dims}; rows mean {rows.mean():.1f} p99 {np.percentile(rows, 99):.0f}, beyond 64: {100 * (rows > 64).mean():.0f} %; "
               f"worst |dqvel| fused vs full over {steps} steps x {n} envs: {worst:.3e}; vs the oracle (3 envs, one step): {wo:.3e}; resets {A.warning_count()} / {B.warning_count()}")
+    run.last = {"rows_beyond": float((rows > (wide_rows or 112)).mean()), "worst_tail": worst_tail, "frame_bytes": fid[1]}
     return fid[0], worst, wo, (A.warning_count(), B.warning_count())
 
 
