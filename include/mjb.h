@@ -249,6 +249,22 @@ int mjb_fused_frame(const mjb_batch *b);
  * The environment variable MJB_LANE_ENV (same values) sets the default of new batches (read by mjb_make_batch).  While mjb_set_stats is
  * counting, fused launches run the generic kernels whatever the mode (the counters live in those).  No reference counterpart. */
 int mjb_set_lane_env(mjb_batch *b, int mode);
+/* The SPLIT step of plain-PGS models (csrc/mjb_smooth_kernel.h + mjb_cstep_kernel in csrc/mjb_step.hip): per step, the smooth stages of mj_step
+ * (kinematics .. qacc_smooth) run one env per LANE and hand geom frames, cdof, both L'DL factors,
+ * qfrc_smooth and qacc_smooth to the constraint stages (A4 - A7, A13, A16) through a per-env record in HBM; those run one env per wavefront.  The
+ * batch is cut into slices (MJB_SPLIT_SLICES, default 2) that alternate the two kernels on streams of their own.  Same step (mj_step, mujoco_env.cpp:498,552,593), results equal
+ * to the fused kernel's to rounding.  Eligible: a model whose topology is compiled in (csrc/smooth_topos.h: free / ball / hinge / slide joints, one
+ * per body), PGS with pyramidal or frictionless contacts, nv <= 16, Euler, no tendons / equalities / mocap bodies / activations, position- and
+ * velocity-stage sensors of the lane = env list only, no per-env gravity / mass overrides, no hwsim stage, no xfrc_applied, no frame dump.
+ * mode: -1 = automatic (whole-batch fused launches of >= MJB_SPLIT_MIN_ENVS envs, default 32 768: a launch pair per step ends with the slice's slowest
+ * env, which only averages out over many envs per slice -- measured 33.2 M env-steps/s against 27.5 M fused at 32 768 envs of config 3, 18.7 M against 23.3 M
+ * at 4096), 0 = never, 1 = whenever eligible.
+ * sensordata is that of the launch's LAST step (as in the lane = env kernel).  No reference counterpart. */
+int mjb_set_split_step(mjb_batch *b, int mode);
+/* >= 0: index of the compiled-in topology of the split step the batch's model matches, -1: none.  *used_last (may be NULL) = 1 when the last fused
+ * launch ran as a split step, *slices (may be NULL) = the env slices it was cut into. */
+int mjb_split_step_info(const mjb_batch *b, int *used_last, int *slices);
+int mjb_model_split_step(const mjb_model *m);
 /* >= 0: index of the compiled-in topology the batch's model matches; -2: none compiled in, but the model's structure fits the kernel -- its
  * first eligible launch builds the kernel for it through hiprtc (libhiprtc.so and csrc/mjb_lane_env_kernel.h next to libmjb.so; a few
  * seconds, cached per process); -3: that build was not possible (mjb_lane_env_error says why) and the generic kernels run; -1: the model does not

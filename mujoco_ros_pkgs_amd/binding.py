@@ -196,6 +196,9 @@ def load_library(path=None):
         "mjb_lane_env_set_form": (ci, [ci]),
         "mjb_lane_env_last_form": (ci, []),
         "mjb_model_lane_env": (ci, [vp]),
+        "mjb_set_split_step": (ci, [vp, ci]),
+        "mjb_split_step_info": (ci, [vp, C.POINTER(ci), C.POINTER(ci)]),
+        "mjb_model_split_step": (ci, [vp]),
         "mjb_set_stats": (ci, [vp, ci]),
         "mjb_get_stats": (ci, [vp, C.POINTER(C.c_ulonglong)]),
         "mjb_get_stream": (vp, [vp]),

@@ -96,6 +96,7 @@ struct mjb_model {
 	bool has_wide = false;
 	int le_topo = -1;  // compiled-in topology of the lane = env kernel the model matches (mjb_lane_env.hip); -1: none; -2: eligible, built by hiprtc on first use
 	std::vector<double> le_tape;  // its constant tape (mjb_dev.h), empty without a topology
+	int sm_topo = -1;  // compiled-in topology of the split step's smooth kernel (mjb_smooth.hip) when the model's constraint half fits mjb_cstep_kernel too; -1: none
 };
 
 struct mjb_batch {
@@ -157,6 +158,15 @@ struct mjb_batch {
 	bool zdouble = false;          // two halves allocated (side-stream speculation possible)
 	size_t zfail = (size_t)-1;     // smallest total allocation (doubles) that failed: not retried
 	int lane_env_mode = -1;        // mjb_set_lane_env: -1 automatic, 0 never, 1 whenever eligible
+	// the split step (mjb_set_split_step): smooth half in lane = env form + constraint half per wavefront, alternating on a few streams of env slices
+	int split_mode = -1;           // -1 automatic (whole-batch fused launches of >= MJB_SPLIT_MIN_ENVS envs), 0 never, 1 whenever eligible
+	bool split_used = false;       // the last fused launch ran that way
+	int split_slices_last = 0;
+	std::vector<hipStream_t> split_streams;
+	std::vector<hipEvent_t> split_events;
+	hipEvent_t ev_split_fork = nullptr;
+	double *handoff_dev = nullptr; // DevState::handoff
+	double *reset_step_dev = nullptr;  // DevState::reset_step
 	bool lane_env_used = false;    // the last fused launch ran the lane = env kernel
 	bool le_unavailable = false;   // the model's topology had to be built by hiprtc and that failed (mjb_lane_env_jit_error): generic kernels from then on
 	int noise_mode = 0;            // how the last fused launch got its ctrl-noise normals: 0 in-kernel, 1 same-stream, 2 side-stream (mjb_noise_mode)
@@ -1139,7 +1149,12 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 			if ((M->body_dofmask[2 * b + (i >> 5)] >> (i & 31)) & 1) M->dof_bodymask[2 * i + (b >> 5)] |= (int)(1u << (b & 31));
 	M->le_topo = mjb_lane_env_match(&h);
 	if (M->le_topo < 0 && mjb_lane_env_eligible(&h)) M->le_topo = MJB_LE_TOPO_JIT;
-	if (M->le_topo != MJB_LE_TOPO_NONE) {
+	// the split step (smooth half in lane = env form, constraint half one env per wavefront): the constraint half is kernel variant 9's -- plain PGS,
+	// pyramidal / frictionless contacts, nv <= 16, no stage that needs mj_rnePostConstraint
+	M->sm_topo = -1;
+	if (h.nefcmax > 0 && h.solver == MJB_SOL_PGS && !(h.cone == MJB_CONE_ELLIPTIC && h.nconmax > 0) && h.nv <= 16 && !M->need_rnepost && h.nefcmax <= 128)
+		M->sm_topo = mjb_smooth_match(&h);
+	if (M->le_topo != MJB_LE_TOPO_NONE || M->sm_topo >= 0) {
 		M->le_tape.assign(mjb_lane_env_tape_doubles(&h), 0.0);
 		mjb_lane_env_tape(&h, M->le_tape.data());
 	}
@@ -1308,6 +1323,11 @@ void mjb_free_batch(mjb_batch *b)
 	if (b->st.pgs_B) hipFree(b->st.pgs_B);
 	if (b->st.efc_Jg) hipFree(b->st.efc_Jg);
 	if (b->rowstat_dev) hipFree(b->rowstat_dev);
+	if (b->handoff_dev) hipFree(b->handoff_dev);
+	if (b->reset_step_dev) hipFree(b->reset_step_dev);
+	for (hipStream_t st : b->split_streams) hipStreamDestroy(st);
+	for (hipEvent_t ev : b->split_events) hipEventDestroy(ev);
+	if (b->ev_split_fork) hipEventDestroy(b->ev_split_fork);
 	if (b->rowstat_host) hipHostFree(b->rowstat_host);
 	if (b->ev_rowstat) hipEventDestroy(b->ev_rowstat);
 	if (b->pack_dev) hipFree(b->pack_dev);
@@ -1523,6 +1543,9 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	s.pgs_B = nullptr;
 	s.efc_Jg = nullptr;
 	s.efc_Jg_stride = 0;
+	s.handoff = nullptr;
+	s.handoff_stride = 0;
+	s.reset_step = nullptr;
 	s.sched = nullptr;
 	if (h.nefcmax > 0) {  // constrained kernels: work queue of the chunked fused launches
 		s.sched = dev_alloc<int>((size_t)nenv + 1);
@@ -1657,6 +1680,103 @@ static bool stream_capturing(hipStream_t st)
 	return cs != hipStreamCaptureStatusNone;
 }
 
+// ---- the split step: per step, the smooth half of every env of a slice in lane = env form (mjb_smooth_kernel.h), then the slice's
+// constraint half one env per wavefront (mjb_cstep_kernel).  The smooth kernel is a latency (a few dozen wavefronts, ~20 us), the constraint kernel is
+// the throughput: the batch is cut into slices that alternate the two on streams of their own, so one slice's smooth half runs beside the others'
+// constraint halves.  A slice's launches are ordered by its stream; slices share nothing (no data-path exchange between envs).
+static int split_slices(const mjb_batch *b, int nenv)
+{
+	static const int forced = [] { const char *v = getenv("MJB_SPLIT_SLICES"); return v ? atoi(v) : 0; }();  // measurement knob
+	// (measured on config 3, MI355X, profiles/r06_split_step.txt: two slices are best from 32 768 envs up -- 33.2 M env-steps/s against the fused kernel's
+	//  27.5 M; more slices mean shorter launches, and a launch ends with its slowest env)
+	int n = forced > 0 ? forced : 2;
+	const int waves = (nenv + 63) / 64;
+	if (n > waves) n = waves;
+	if (n > 16) n = 16;
+	(void)b;
+	return n < 1 ? 1 : n;
+}
+
+// the state one step after mj_resetData (mj_checkAcc's reset inside mjb_cstep_kernel), from a one-env batch on the generic kernels
+static int split_reset_state(mjb_batch *b)
+{
+	const mjb_model_desc &h = b->model->h;
+	mjb_batch *t = mjb_make_batch(b->model, 1, b->device);
+	if (!t) return MJB_ENOMEM;
+	t->split_mode = 0;
+	std::vector<double> buf((size_t)h.nq + 2 * h.nv);
+	int rc = mjb_reset(t, nullptr);
+	if (rc == MJB_OK) rc = mjb_step(t, 1);
+	if (rc == MJB_OK) rc = mjb_get(t, MJB_F_qpos, 0, 1, buf.data());
+	if (rc == MJB_OK) rc = mjb_get(t, MJB_F_qvel, 0, 1, buf.data() + h.nq);
+	if (rc == MJB_OK) rc = mjb_get(t, MJB_F_qacc_warmstart, 0, 1, buf.data() + h.nq + h.nv);
+	mjb_free_batch(t);
+	if (rc != MJB_OK) return rc;
+	HIP_TRY(hipSetDevice(b->device));
+	HIP_TRY(hipMalloc((void **)&b->reset_step_dev, buf.size() * sizeof(double)));
+	HIP_TRY(hipMemcpy(b->reset_step_dev, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice));
+	return MJB_OK;
+}
+
+static int split_prepare(mjb_batch *b)
+{
+	const mjb_model_desc &h = b->model->h;
+	if (!b->reset_step_dev) {
+		int rc = split_reset_state(b);
+		if (rc) return rc;
+		b->st.reset_step = b->reset_step_dev;
+		b->params_dirty = true;
+	}
+	if (!b->handoff_dev) {
+		const HandoffLayout hl = mjb_handoff_layout(h.ngeom, h.nv, h.nbody, h.nM);
+		b->handoff_dev = dev_alloc<double>((size_t)b->nenv * hl.stride);
+		if (!b->handoff_dev) return fail(MJB_ENOMEM, "split step: hand-off records");
+		HIP_TRY(hipMemset(b->handoff_dev, 0, (size_t)b->nenv * hl.stride * sizeof(double)));
+		b->st.handoff = b->handoff_dev;
+		b->st.handoff_stride = hl.stride;
+		b->params_dirty = true;
+	}
+	if (!b->ev_split_fork) HIP_TRY(hipEventCreateWithFlags(&b->ev_split_fork, hipEventDisableTiming));
+	return MJB_OK;
+}
+
+static int launch_split(mjb_batch *b, int nsteps, int env_lo, int env_hi, hipStream_t stream)
+{
+	const int nenv = env_hi - env_lo;
+	const int ns = split_slices(b, nenv);
+	while ((int)b->split_streams.size() < ns) {
+		hipStream_t st = nullptr;
+		hipEvent_t ev = nullptr;
+		HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+		b->split_streams.push_back(st);
+		HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+		b->split_events.push_back(ev);
+	}
+	const FrameLayout &Lc = b->model->Lc;
+	const int cflags = b->st.stats ? 1 : 0;
+	// slices of whole wavefronts of the smooth kernel
+	const int waves = (nenv + 63) / 64;
+	HIP_TRY(hipEventRecord(b->ev_split_fork, stream));
+	for (int k = 0; k < ns; k++) {
+		const int w0 = (int)((long long)waves * k / ns), w1 = (int)((long long)waves * (k + 1) / ns);
+		const int lo = env_lo + 64 * w0, hi = std::min(env_hi, env_lo + 64 * w1);
+		if (hi <= lo) continue;
+		hipStream_t st = ns == 1 ? stream : b->split_streams[k];
+		if (ns > 1) HIP_TRY(hipStreamWaitEvent(st, b->ev_split_fork, 0));
+		for (int i = 0; i < nsteps; i++) {
+			int rc = mjb_launch_smooth(b->params_dev, b->model->sm_topo, lo, hi, b->step_counter + (unsigned int)i, i == nsteps - 1 ? 1 : 0, st);
+			if (rc == 0) rc = mjb_launch_cstep(b->params_dev, Lc, lo, hi, b->epb, cflags, st);
+			if (rc != 0) return fail(MJB_ENODEVICE, "split step launch failed: %s", hipGetErrorString((hipError_t)rc));
+		}
+		if (ns > 1) {
+			HIP_TRY(hipEventRecord(b->split_events[k], st));
+			HIP_TRY(hipStreamWaitEvent(stream, b->split_events[k], 0));
+		}
+	}
+	b->split_slices_last = ns;
+	return MJB_OK;
+}
+
 static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi = -1, hipStream_t on = nullptr)
 {
 	if (env_hi < 0) env_hi = b->nenv;
@@ -1704,6 +1824,18 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 			b->params_dirty = true;
 		}
 	}
+	// The split step for plain-PGS models whose smooth stages have a lane = env kernel (config 3): fused launches of the whole batch (or, forced, any range)
+	bool use_split = false;
+	if (mode == MJB_MODE_STEP && compact && variant == 1 && b->model->sm_topo >= 0 && b->split_mode != 0 && b->hw.n == 0 && !b->env_mass && !b->env_gravity &&
+	    !b->env_equality && 8 * mjb_frame_bytes(b->model, 1) <= mjb_max_lds_bytes() && !stream_capturing(stream)) {
+		static const int min_envs = [] { const char *v = getenv("MJB_SPLIT_MIN_ENVS"); return v ? atoi(v) : 32768; }();
+		use_split = b->split_mode == 1 || (whole && b->nenv >= min_envs);
+		if (use_split) {
+			int src = split_prepare(b);
+			if (src) return src;
+		}
+	}
+	b->split_used = use_split;
 	{  // the kernels count rows (three atomics per env-step on one address) only in the launches whose counters are read
 		unsigned long long *rs = count_rows ? b->rowstat_dev : nullptr;
 		if (b->st.rowstat != rs) {
@@ -1713,6 +1845,15 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 	}
 	int prc = sync_params(b);
 	if (prc) return prc;
+	if (use_split) {
+		if (b->zvalid) {  // (the pre-generated ctrl-noise buffer names an older launch: this path draws its normals in the smooth kernel)
+			HIP_TRY(hipMemsetAsync(b->zinfo, 0xff, 8 * sizeof(unsigned int), stream));
+			b->zvalid = false;
+		}
+		b->lane_env_used = false;
+		b->noise_mode = 0;
+		return launch_split(b, nsteps, env_lo, env_hi, stream);
+	}
 	const int fused_id = b->wide ? 2 : 1;
 	// plain PGS on the lean frame: when eight envs fit one CU's LDS, the 256-register build runs two waves per SIMD
 	if (variant == 1 && compact && 8 * mjb_frame_bytes(b->model, 1) <= mjb_max_lds_bytes()) variant = 9;
@@ -2503,6 +2644,19 @@ int mjb_set_lane_env(mjb_batch *b, int mode)
 	b->lane_env_mode = mode;
 	return MJB_OK;
 }
+int mjb_set_split_step(mjb_batch *b, int mode)
+{
+	if (!b || mode < -1 || mode > 1) return fail(MJB_EINVAL, "mjb_set_split_step: bad argument");
+	b->split_mode = mode;
+	return MJB_OK;
+}
+int mjb_split_step_info(const mjb_batch *b, int *used_last, int *slices)
+{
+	if (used_last) *used_last = b && b->split_used ? 1 : 0;
+	if (slices) *slices = b ? b->split_slices_last : 0;
+	return b ? b->model->sm_topo : -1;
+}
+int mjb_model_split_step(const mjb_model *m) { return m ? m->sm_topo : -1; }
 const char *mjb_lane_env_error(void) { return mjb_lane_env_jit_error(); }
 int mjb_model_lane_env(const mjb_model *m) { return m ? m->le_topo : -1; }
 int mjb_lane_env_info(const mjb_batch *b, int *used_last)

@@ -170,6 +170,10 @@ struct DevState {
 	                               // whose record is its own (the other half is being filled for the NEXT launch, on a side stream, meanwhile)
 	unsigned long long zhalf;      // doubles per half
 	int keep_frame;                // fused mjb_step also dumps the last step's full frame to frame_ws
+	double *handoff;               // [nenv][handoff_stride] hand-off records of the split step (HandoffLayout): written by the lane = env smooth kernel
+	                               // (mjb_smooth_kernel.h), read by mjb_cstep_kernel; NULL until the batch first steps that way
+	int handoff_stride;
+	const double *reset_step;      // [nq + nv + nv] qpos | qvel | qacc_warmstart one step after mj_resetData (mj_checkAcc's reset inside the split step), or NULL
 	int prof_base;                 // profiling build: first of the two probe ids this launch records (mjb_debug_profile_window)
 };
 
@@ -204,6 +208,31 @@ MJB_HD inline RowBlock mjb_rowblock(double *base, int nefcmax, int nv, int nconm
 	g.id = g.type + nefcmax;
 	g.meta = g.id + nefcmax;
 	return g;
+}
+
+// The hand-off record of the split step (mjb_smooth_kernel.h -> mjb_cstep_kernel): what the constraint stages read of the smooth stages'
+// results, one contiguous record per env in HBM, in this order.  subtree_com holds, for a tree's ROOT body, the point the tree's spatial
+// quantities (cdof, hence the contact Jacobians) are taken about -- the root body's origin; the other bodies' entries are not written.
+struct HandoffLayout {
+	int geom_xpos, geom_xmat, cdof, subtree_com, qLD, qLDiagInv, qH, qHdi, qfrc_smooth, qacc_smooth, ndouble, stride;
+};
+MJB_HD inline HandoffLayout mjb_handoff_layout(int ngeom, int nv, int nbody, int nM)
+{
+	HandoffLayout h;
+	int o = 0;
+	h.geom_xpos = o; o += 3 * ngeom;
+	h.geom_xmat = o; o += 9 * ngeom;
+	h.cdof = o; o += 6 * nv;
+	h.subtree_com = o; o += 3 * nbody;
+	h.qLD = o; o += nM;
+	h.qLDiagInv = o; o += nv;
+	h.qH = o; o += nM;
+	h.qHdi = o; o += nv;
+	h.qfrc_smooth = o; o += nv;
+	h.qacc_smooth = o; o += nv;
+	h.ndouble = o;
+	h.stride = (o + 7) & ~7;  // records start on 64-byte boundaries
+	return h;
 }
 
 struct NoiseCfg {
@@ -265,6 +294,11 @@ int mjb_lane_env_eligible(const mjb_model_desc *h);   // the model's structure f
 const char *mjb_lane_env_jit_error(void);              // why the last hiprtc build of a topology was not available ("" if none failed)
 int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc *h, int nenv_batch, int env_lo, int env_hi, int nsteps, unsigned int step0,
                         void *stream);
+// the split step (mjb_smooth_kernel.h + mjb_cstep_kernel): one step of envs [env_lo, env_hi) -- smooth half in lane = env form, then the constraint half
+int mjb_smooth_match(const mjb_model_desc *h);  // index of the compiled-in SmTopo the model has, or -1
+const char *mjb_smooth_name(int topo);
+int mjb_launch_smooth(const KernelParams *Pdev, int topo, int env_lo, int env_hi, unsigned int step, int flags, void *stream);
+int mjb_launch_cstep(const KernelParams *Pdev, const FrameLayout &L, int env_lo, int env_hi, int envs_per_block, int flags, void *stream);
 // sensors-plugin equivalent (mjb_sensor_pack.hip)
 int mjb_launch_sensor_pack(const KernelParams *Pdev, int nenv, int nsensor, const int *set_flag, const double *mean,
                            const double *sigma, unsigned long long seed, long long env_offset, unsigned int step,

@@ -379,14 +379,15 @@ void mjb_lane_env_tape(const mjb_model_desc *h, double *tape)
 		}
 		t.mass = h->body_mass[b];
 		if (h->body_jntnum[b] == 1) {
-			const int j = h->body_jntadr[b];  // (== its qpos and dof address: mjb_lane_env_match)
+			const int j = h->body_jntadr[b];
 			for (int k = 0; k < 3; k++) { t.jaxis[k] = h->jnt_axis[3 * j + k]; t.jpos[k] = h->jnt_pos[3 * j + k]; }
-			t.qpos0 = h->qpos0[j];
+			const int qa = h->jnt_qposadr[j], da = h->jnt_dofadr[j];  // (== j for the lane = env topologies; the split step's smooth kernel reads the tape of models with free / ball joints too: their first coordinate)
+			t.qpos0 = h->qpos0[qa];
 			t.stiffness = h->jnt_stiffness[j];
-			t.spring = h->qpos_spring[j];
-			t.damping = h->dof_damping[j];
-			t.armature = h->dof_armature[j];
-			t.hdamping = h->timestep[0] * h->dof_damping[j];
+			t.spring = h->qpos_spring[qa];
+			t.damping = h->dof_damping[da];
+			t.armature = h->dof_armature[da];
+			t.hdamping = h->timestep[0] * h->dof_damping[da];
 		}
 	}
 	for (int i = 0; i < h->nu; i++) {

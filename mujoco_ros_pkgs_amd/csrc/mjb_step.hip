@@ -17,6 +17,9 @@
 // Stage functions are named after the MuJoCo 2.3.7 stage whose result they produce.
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <mutex>
+
 #include <utility>
 
 #include "mjb_dev.h"
@@ -3607,6 +3610,176 @@ int mjb_launch_group4(const KernelParams *Pdev, const FrameLayout &L, int env_lo
 }
 #endif
 #endif
+
+#if MJB_HAS_GROUP(6)
+// ---- the CONSTRAINT half of a split step: the smooth stages of this step ran in lane = env form (mjb_smooth_kernel.h) and left
+// geom frames, cdof, both L'DL factors, qfrc_smooth and qacc_smooth in the env's hand-off record; here one env per wavefront takes them into its
+// lean frame and runs A4 - A7, A13 and A16: collision, make_constraint, the reference accelerations, PGS (nv <= 16: rows of J M^-1 and AR in
+// registers), Euler.  The stage functions and the frame are those of kernel variant 9; what is gone from the instruction stream is every smooth
+// stage, the step loop and the work queue (one launch = one step).  flags bit 0: workload statistics on (mjb_set_stats).
+// one env's constraint half on the wavefront's frame e (e.env set)
+template <int CON> DEVI void cstep_env(const KernelParams MJB_AS4 *__restrict__ P, Env &e, const int flags)
+{
+	constexpr int G = 64;
+	constexpr bool MJB_LAUNDER_HERE = true;
+	const int compact = 1;
+	VIEW(P, compact, {
+		for (int k = e.lane; k < L.nint; k += G) e.fi[k] = 0;
+		gsync<G>();
+		if (e.lane < 16) {
+			for (int q = 0; q < 4; q++) {
+				unsigned int w = 0;
+				for (int r = 0; r < 4; r++) {
+					const int a = m.M_dense[16 * (4 * q + r) + e.lane];
+					w |= (unsigned int)(a < 0 ? 255 : a) << (8 * r);
+				}
+				e.fi[L.dadr + 4 * e.lane + q] = (int)w;
+			}
+		}
+		load_state<G>(m, L, s, e);
+		// the smooth stages' results
+		const HandoffLayout hl = mjb_handoff_layout(m.ngeom, m.nv, m.nbody, m.nM);
+		const double *H = s.handoff + (size_t)e.env * (size_t)s.handoff_stride;
+		double *f = e.f;
+		copy_in<G>(f + L.geom_xpos, H + hl.geom_xpos, 3 * m.ngeom, e.lane);
+		copy_in<G>(f + L.geom_xmat, H + hl.geom_xmat, 9 * m.ngeom, e.lane);
+		copy_in<G>(f + L.cdof, H + hl.cdof, 6 * m.nv, e.lane);
+		copy_in<G>(f + L.subtree_com, H + hl.subtree_com, 3 * m.nbody, e.lane);
+		copy_in<G>(f + L.qLD, H + hl.qLD, m.nM, e.lane);
+		copy_in<G>(f + L.qLDiagInv, H + hl.qLDiagInv, m.nv, e.lane);
+		copy_in<G>(f + L.qH, H + hl.qH, m.nM, e.lane);
+		copy_in<G>(f + L.qHdi, H + hl.qHdi, m.nv, e.lane);
+		copy_in<G>(f + L.qfrc_smooth, H + hl.qfrc_smooth, m.nv, e.lane);
+		copy_in<G>(f + L.qacc_smooth, H + hl.qacc_smooth, m.nv, e.lane);
+		gsync<G>();
+	});
+	VIEW(P, compact, collision<G>(m, L, s, e));
+	VIEW(P, compact, make_constraint<G, CON>(m, L, s, e));
+	VIEW(P, compact, reference_constraint<G, CON>(m, L, s, e));
+	VIEW(P, compact, fwd_constraint_pgs<G, false, true, CON>(m, L, s, e));
+	// qacc = qacc_smooth + M^-1 qfrc_constraint, and -- under implicit joint damping -- Euler's (M + h B)^-1 (qfrc_smooth + qfrc_constraint)
+	// beside it: one dual substitution (forward_rest, MJB_PGS_PRESOLVE)
+	VIEW(P, compact, {
+		double *f = e.f;
+		const bool damp = m.eulerdamp != 0;
+		if (e.lane < m.nv) {
+			const double c = f[L.qfrc_constraint + e.lane];
+			f[L.qacc + e.lane] = c;
+			f[L.eulerx + e.lane] = f[L.qfrc_smooth + e.lane] + c;
+		}
+		gsync<G>();
+		int dl[16];
+		dadr_load(e, L, dl);
+		solve_dense16<G, 16>(m, e, f + L.qacc, f + L.qLD, f + L.qLDiagInv, f + L.eulerx, f + L.qH, f + L.qHdi, damp, dl, f + L.solvescr);
+		if (e.lane < m.nv) {
+			const double a = f[L.qacc_smooth + e.lane] + f[L.qacc + e.lane];
+			f[L.qacc + e.lane] = a;
+			f[L.qacc_warmstart + e.lane] = a;
+		}
+		gsync<G>();
+	});
+	if (flags & 1) {  // workload statistics (mjb_set_stats)
+		VIEW(P, compact, {
+			if (s.stats != nullptr && e.lane == 0) {
+				const int ne = e.fi[L.nefc], nc = m.nconmax > 0 ? e.fi[L.ncon] : 0;
+				unsigned long long *st = s.stats;
+				atomicAdd(st, 1ull);
+				atomicAdd(st + 1, (unsigned long long)e.fi[L.solver_iter]);
+				atomicAdd(st + 2 + (ne < 256 ? ne : 256), 1ull);
+				atomicAdd(st + 259 + (nc < 128 ? nc : 128), 1ull);
+			}
+		});
+	}
+	// mj_checkAcc: a bad qacc resets the env; mj_step then runs the forward pass again on mj_resetData's state and advances it -- the result is the
+	// same state for every env of the model (ctrl reads zero after the reset), computed once by the host: DevState::reset_step
+	bool advanced = false;
+	VIEW(P, compact, {
+		if (any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0, true)) {
+			MJB_KEEP_BRANCH();
+			reset_frame_state<G>(m, L, s, lite(e), MJB_WARN_BADQACC);
+			if (s.reset_step != nullptr) {
+				copy_in<G>(e.f + L.qpos, s.reset_step, m.nq, e.lane);
+				copy_in<G>(e.f + L.qvel, s.reset_step + m.nq, m.nv, e.lane);
+				copy_in<G>(e.f + L.qacc_warmstart, s.reset_step + m.nq + m.nv, m.nv, e.lane);
+				copy_in<G>(e.f + L.qacc, s.reset_step + m.nq + m.nv, m.nv, e.lane);
+				if (e.lane == 0) e.f[L.time] = m.timestep[0];
+			}
+			gsync<G>();
+			// (the reset reaches the arrays this kernel does not otherwise store)
+			copy_out<G>(s.ctrl + (size_t)e.env * m.nu, e.f + L.ctrl, m.nu, e.lane);
+			copy_out<G>(s.ctrlnoise + (size_t)e.env * m.nu, e.f + L.ctrlnoise, m.nu, e.lane);
+			copy_out<G>(s.qfrc_applied + (size_t)e.env * m.nv, e.f + L.qfrc_applied, m.nv, e.lane);
+			advanced = true;
+		}
+	});
+	if (!advanced) VIEW(P, compact, euler<G, true, false, false, true>(m, L, e));
+	VIEW(P, compact, {
+		const size_t env = (size_t)e.env;
+		copy_out<G>(s.qpos + env * m.nq, e.f + L.qpos, m.nq, e.lane);
+		copy_out<G>(s.qvel + env * m.nv, e.f + L.qvel, m.nv, e.lane);
+		copy_out<G>(s.qacc_warmstart + env * m.nv, e.f + L.qacc_warmstart, m.nv, e.lane);
+		copy_out<G>(s.qacc + env * m.nv, e.f + L.qacc, m.nv, e.lane);
+		if (e.lane == 0) s.time[env] = e.f[L.time];
+	});
+	gsync<G>();
+}
+
+template <int CON>
+__global__ void __launch_bounds__(256, 2)
+    mjb_cstep_kernel(const KernelParams MJB_AS4 *__restrict__ P, const int epb, const int frame_bytes, const int env_lo, const int env_hi, const int flags)
+{
+	constexpr int G = 64;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int slot = threadIdx.x / G;
+	Env e;
+#ifdef MJB_PROFILE
+	e.prof = P->s.prof;
+#endif
+	e.lane.mask = G - 1;
+	{
+		const FrameLayout MJB_AS4 &L = P->Lc;
+		e.f = reinterpret_cast<double *>(smem + (size_t)slot * frame_bytes);
+		e.fi = reinterpret_cast<int *>(e.f + L.ndouble);
+	}
+	e.mp = nullptr;
+	for (int base = env_lo + blockIdx.x * epb; base < env_hi; base += gridDim.x * epb) {
+		e.env = __builtin_amdgcn_readfirstlane(base + slot);
+		if (e.env >= env_hi) continue;
+		cstep_env<CON>(P, e, flags);
+	}
+}
+
+int mjb_launch_cstep(const KernelParams *Pdev, const FrameLayout &L, int env_lo, int env_hi, int epb, int flags, void *stream)
+{
+	const int nenv = env_hi - env_lo;
+	if (nenv <= 0) return 0;
+	const int frame_bytes = ((L.ndouble * 8 + L.nint * 4) + 15) & ~15;
+	if (epb > 4) epb = 4;
+	if (epb < 1) epb = 1;
+	const size_t lds = (size_t)epb * frame_bytes;
+	if ((int)lds > 160 * 1024) return (int)hipErrorInvalidValue;
+	auto kern = mjb_cstep_kernel<9>;
+	if (lds > 65536) {  // (four frames of config 3: 80 KB.  Per device and size, not per launch: one launch = one step here)
+		static std::mutex mu;
+		static std::map<std::pair<int, int>, hipError_t> done;
+		int dev = 0;
+		(void)hipGetDevice(&dev);
+		std::lock_guard<std::mutex> lock(mu);
+		auto it = done.find({ dev, (int)lds });
+		hipError_t err;
+		if (it == done.end()) {
+			err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+			done[{ dev, (int)lds }] = err;
+		} else
+			err = it->second;
+		if (err != hipSuccess) return (int)err;
+	}
+	int blocks = (nenv + epb - 1) / epb;
+	if (blocks > 256 * 16) blocks = 256 * 16;
+	hipLaunchKernelGGL(kern, dim3(blocks), dim3(epb * 64), lds, (hipStream_t)stream, (const KernelParams MJB_AS4 *)Pdev, epb, frame_bytes, env_lo, env_hi, flags);
+	return (int)hipGetLastError();
+}
+#endif  // MJB_HAS_GROUP(6)
 
 #if MJB_HAS_GROUP(0)
 int mjb_max_lds_bytes() { return 160 * 1024; }

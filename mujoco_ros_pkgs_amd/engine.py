@@ -291,6 +291,17 @@ class Batch:
         topo = int(self.lib.mjb_lane_env_info(self.ptr, C.byref(used)))
         return topo, bool(used.value)
 
+    def set_split_step(self, mode):
+        """-1 automatic, 0 never, 1 whenever eligible: the split step of plain-PGS models -- smooth stages one env per lane, constraint stages one env
+        per wavefront (mjb_set_split_step)."""
+        _check(self.lib.mjb_set_split_step(self.ptr, int(mode)), "mjb_set_split_step")
+
+    def split_step_info(self):
+        """(topology index or -1, the last fused launch ran as a split step, its env slices)."""
+        used, slices = C.c_int(0), C.c_int(0)
+        topo = int(self.lib.mjb_split_step_info(self.ptr, C.byref(used), C.byref(slices)))
+        return topo, bool(used.value), int(slices.value)
+
     def set_lane_env_form(self, form):
         """Process-wide: -1 by batch size, 0 one wavefront per 64 envs, 1 two (position / velocity halves), 2 two, pipelined (mjb_lane_env_set_form)."""
         return int(self.lib.mjb_lane_env_set_form(int(form)))

@@ -94,7 +94,106 @@ def emit(name, m):
     return s
 
 
+# ---- the SPLIT step's smooth kernel (csrc/mjb_smooth_kernel.h): models WITH constraint rows -- free / ball joints, geoms -- whose constraint
+# half runs one env per wavefront (mjb_cstep_kernel).  BASELINE configs[2]'s arm + table + cube, and a ball / free-joint test tree.
+SMOOTH_MODELS = [
+    ("franka_table", os.path.join(ROOT, "mujoco_ros_pkgs_amd", "assets", "franka_table.xml")),
+    ("split_step_tree", os.path.join(ROOT, "mujoco_ros_pkgs_amd", "assets", "split_step_tree.xml")),
+]
+
+
+def smooth_eligible(m):
+    """None if the model's smooth stages fit mjb_smooth_kernel.h, else the reason (mirrors mjb_smooth_eligible in csrc/mjb_smooth.hip)."""
+    if m["integrator"] != 0:
+        return "integrator"
+    if m["nmocap"] or m["ntendon"] or m["neq"] or m["na"]:
+        return "mocap / tendon / equality / activation"
+    for b in range(m["nbody"]):
+        if m["body_jntnum"][b] > 1:
+            return "two joints on a body"
+    if m["nbody"] > 24 or m["nv"] > 20:
+        return "size"
+    for i in range(m["nsensor"]):
+        if int(m["sensor_type"][i]) not in SUPPORTED_SENSORS:
+            return "sensor type %d" % m["sensor_type"][i]
+        if int(m["sensor_type"][i]) in (23, 24) and (m["sensor_refid"][i] >= 0 or int(m["sensor_objtype"][i]) not in (1, 2, 6)):
+            return "frame sensor with a reference frame / unsupported object"
+    for i in range(m["nu"]):
+        if m["actuator_trntype"][i] != 0 or m["actuator_dyntype"][i] != 0:
+            return "actuator transmission / dynamics"
+        if int(m["jnt_type"][m["actuator_trnid"][i][0]]) not in (2, 3):
+            return "actuator on a ball / free joint"
+    return None
+
+
+def handoff_layout(m):
+    """csrc/mjb_dev.h: mjb_handoff_layout"""
+    o, h = 0, {}
+    for name, n in (("GEOM_XPOS", 3 * m["ngeom"]), ("GEOM_XMAT", 9 * m["ngeom"]), ("CDOF", 6 * m["nv"]), ("SUBTREE_COM", 3 * m["nbody"]), ("QLD", m["nM"]),
+                    ("QLDIAGINV", m["nv"]), ("QH", m["nM"]), ("QHDI", m["nv"]), ("QFRC_SMOOTH", m["nv"]), ("QACC_SMOOTH", m["nv"])):
+        h[name] = o
+        o += n
+    return h
+
+
+def emit_smooth(name, m):
+    why = smooth_eligible(m)
+    if why:
+        raise SystemExit("%s does not fit the smooth kernel: %s" % (name, why))
+    nb = m["nbody"]
+    body_jnt = [int(m["body_jntadr"][b]) if m["body_jntnum"][b] == 1 else -1 for b in range(nb)]
+    s = "struct SmTopo_%s {\n" % name
+    s += '\tstatic constexpr const char *name = "%s";\n' % name
+    for k in ("nbody", "nq", "nv", "nu", "njnt", "ngeom", "nsite", "nsensor", "nsensordata", "nM"):
+        s += "\tstatic constexpr int %s = %d;\n" % (k.upper() if k != "nM" else "NM", m[k])
+    s += arr("body_parentid", m["body_parentid"])
+    s += arr("body_rootid", m["body_rootid"])
+    s += arr("body_jnt", body_jnt)
+    s += arr("body_sameframe", m["body_sameframe"])
+    s += arr("jnt_type", m["jnt_type"])
+    s += arr("jnt_bodyid", m["jnt_bodyid"])
+    s += arr("jnt_qposadr", m["jnt_qposadr"])
+    s += arr("jnt_dofadr", m["jnt_dofadr"])
+    s += arr("dof_parentid", m["dof_parentid"])
+    s += arr("dof_Madr", m["dof_Madr"])
+    s += arr("geom_bodyid", m["geom_bodyid"])
+    s += arr("geom_sameframe", m["geom_sameframe"])
+    s += arr("act_jnt", [m["actuator_trnid"][i][0] for i in range(m["nu"])])
+    s += arr("act_gaintype", m["actuator_gaintype"])
+    s += arr("act_biastype", m["actuator_biastype"])
+    s += arr("act_ctrllimited", m["actuator_ctrllimited"])
+    s += arr("act_forcelimited", m["actuator_forcelimited"])
+    s += arr("site_bodyid", m["site_bodyid"])
+    s += arr("site_sameframe", m["site_sameframe"])
+    s += arr("sensor_type", m["sensor_type"])
+    s += arr("sensor_objtype", m["sensor_objtype"])
+    s += arr("sensor_objid", m["sensor_objid"])
+    s += arr("sensor_adr", m["sensor_adr"])
+    for k, v in handoff_layout(m).items():
+        s += "\tstatic constexpr int H_%s = %d;\n" % (k, v)
+    s += "};\n"
+    return s
+
+
+def main_smooth():
+    out = os.path.join(ROOT, "mujoco_ros_pkgs_amd", "csrc", "smooth_topos.h")
+    text = ("// smooth_topos.h -- GENERATED by tools/gen_lane_env_topo.py: the integer structure of the models the split step's smooth kernel\n"
+            "// (mjb_smooth_kernel.h) is compiled for, and the offsets of the hand-off record (mjb_dev.h: mjb_handoff_layout).\n"
+            "#pragma once\n\n")
+    names = []
+    for name, path in SMOOTH_MODELS:
+        m = mjcf.compile_xml_file(path)
+        text += emit_smooth(name, m) + "\n"
+        names.append(name)
+    text += "#define MJB_SM_TOPOS(X) " + " ".join("X(%d, SmTopo_%s)" % (i, n) for i, n in enumerate(names)) + "\n"
+    text += "#define MJB_SM_NTOPO %d\n" % len(names)
+    with open(out, "w") as f:
+        f.write(text)
+    print("wrote", out)
+
+
 def main():
+    main_smooth()
     out = os.path.join(ROOT, "mujoco_ros_pkgs_amd", "csrc", "lane_env_topos.h")
     text = ("// lane_env_topos.h -- GENERATED by tools/gen_lane_env_topo.py: the integer structure of the models the lane = env kernel is\n"
             "// compiled for (tree, joint kinds, dof ancestry, actuator / sensor wiring).  Numeric model constants are run-time data.\n"
