@@ -65,7 +65,13 @@ enum { /* mjtSensor (subset implemented; values are MuJoCo's) */
 	MJB_SENS_ACTUATORFRC = 14, MJB_SENS_BALLQUAT = 15, MJB_SENS_BALLANGVEL = 16, MJB_SENS_FRAMEPOS = 23,
 	MJB_SENS_FRAMEQUAT = 24, MJB_SENS_FRAMEXAXIS = 25, MJB_SENS_FRAMEYAXIS = 26, MJB_SENS_FRAMEZAXIS = 27,
 	MJB_SENS_FRAMELINVEL = 28, MJB_SENS_FRAMEANGVEL = 29, MJB_SENS_FRAMELINACC = 30, MJB_SENS_FRAMEANGACC = 31,
-	MJB_SENS_SUBTREECOM = 32, MJB_SENS_CLOCK = 35
+	MJB_SENS_SUBTREECOM = 32, MJB_SENS_CLOCK = 35,
+	/* round 6: the rest of the scalar / 3-vector types MujocoRosSensorsPlugin serialises (mujoco_ros_sensors/src/mujoco_sensor_handler_plugin.cpp:76-105) */
+	MJB_SENS_JOINTLIMITPOS = 17, MJB_SENS_JOINTLIMITVEL = 18, MJB_SENS_JOINTLIMITFRC = 19, MJB_SENS_TENDONLIMITPOS = 20,
+	MJB_SENS_TENDONLIMITVEL = 21, MJB_SENS_TENDONLIMITFRC = 22, MJB_SENS_SUBTREELINVEL = 33, MJB_SENS_SUBTREEANGMOM = 34,
+	/* (mjSENS_JOINTACTFRC's value in the pinned MuJoCo release cannot be read here -- the library and its headers are absent -- so the engine uses a
+	 *  value outside mjtSensor's range; a binding that fills mjb_model_desc from a real mjModel maps mjSENS_JOINTACTFRC onto it) */
+	MJB_SENS_JOINTACTFRC = 38
 };
 enum { MJB_STAGE_NONE = 0, MJB_STAGE_POS = 1, MJB_STAGE_VEL = 2, MJB_STAGE_ACC = 3 };
 enum { MJB_EQ_CONNECT = 0, MJB_EQ_WELD = 1, MJB_EQ_JOINT = 2, MJB_EQ_TENDON = 3 }; /* mjtEq (distance not implemented) */
@@ -363,10 +369,8 @@ void *mjb_sensor_device_ptr(mjb_batch *b, int which);
  *   MJB_COLFUNC_NONE     the pair type produces no contacts (a collision function that returns 0)
  *   MJB_COLFUNC_SPHERES  both geoms are replaced by their bounding spheres (planes stay planes): at most one contact
  * geom_type1 / geom_type2 are mjtGeom values in either order; the override applies to every candidate pair of those types of
- * this batch from the next launch on.
- * Limitation (differs from the reference, whose mjCOLLISIONFUNC table is indexed by the geoms' CURRENT types): the override is
- * filed on the candidate pairs by the MODEL's geom types.  An env whose geom types were changed with mjb_set_env_geom_type keeps,
- * for each pair, the override registered for the pair's original types. */
+ * this batch from the next launch on.  As in the reference, whose mjCOLLISIONFUNC table is indexed by the geoms' CURRENT types, an env whose
+ * geom types were changed with mjb_set_env_geom_type gets, for each candidate pair, the override registered for the pair's types in THAT env. */
 enum { MJB_COLFUNC_DEFAULT = 0, MJB_COLFUNC_NONE = 1, MJB_COLFUNC_SPHERES = 2 };
 int mjb_register_collision(mjb_batch *b, int geom_type1, int geom_type2, int func);
 

@@ -252,7 +252,10 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact, int jrows_req = 
 	//   make_constraint .. solver:   efc_J | efc_D | efc_aref | efc_b | efc_force at the END of X
 	//   fwd_acceleration, Euler:     the dense-triangle scratch (tri | solvescr | eulerx) right below efc_J, inside R
 	//   solver only:                 nwt_H | nwt_vec | nwt_row | nwt_hc from the START of X (over D and the head of R)
-	const bool xl = u_ok && d.solver == MJB_SOL_NEWTON && d.nv <= 32;
+	// (a jointlimitfrc / tendonlimitfrc sensor reads efc_force of its row after the solve: such a model keeps every row array whole in the frame)
+	bool row_sensor = false;
+	for (int i = 0; i < d.nsensor; i++) row_sensor = row_sensor || d.sensor_type[i] == MJB_SENS_JOINTLIMITFRC || d.sensor_type[i] == MJB_SENS_TENDONLIMITFRC;
+	const bool xl = u_ok && !row_sensor && d.solver == MJB_SOL_NEWTON && d.nv <= 32;
 	// ... and, when the frame holds only `jrows` rows of efc_J (kernel variant 4), every other per-row array is capped at the same
 	// count: an env-step with more rows keeps all of its row data in the env's block of DevState::efc_Jg (mjb_dev.h, RowBlock).
 	// Config 5: 53.0 -> 40.9 KB = four envs per CU, one per SIMD.
@@ -735,7 +738,9 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 			                      MJB_SENS_ACTUATORPOS, MJB_SENS_ACTUATORVEL, MJB_SENS_ACTUATORFRC, MJB_SENS_BALLQUAT,
 			                      MJB_SENS_BALLANGVEL, MJB_SENS_FRAMEPOS, MJB_SENS_FRAMEQUAT, MJB_SENS_FRAMEXAXIS,
 			                      MJB_SENS_FRAMEYAXIS, MJB_SENS_FRAMEZAXIS, MJB_SENS_FRAMELINVEL, MJB_SENS_FRAMEANGVEL,
-			                      MJB_SENS_FRAMELINACC, MJB_SENS_FRAMEANGACC, MJB_SENS_SUBTREECOM, MJB_SENS_CLOCK };
+			                      MJB_SENS_FRAMELINACC, MJB_SENS_FRAMEANGACC, MJB_SENS_SUBTREECOM, MJB_SENS_CLOCK, MJB_SENS_JOINTLIMITPOS, MJB_SENS_JOINTLIMITVEL,
+			                      MJB_SENS_JOINTLIMITFRC, MJB_SENS_TENDONLIMITPOS, MJB_SENS_TENDONLIMITVEL, MJB_SENS_TENDONLIMITFRC, MJB_SENS_SUBTREELINVEL,
+			                      MJB_SENS_SUBTREEANGMOM, MJB_SENS_JOINTACTFRC };
 		bool found = false;
 		for (int t : ok) found = found || t == d.sensor_type[i];
 		if (!found) {
@@ -874,10 +879,12 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		for (int i = 0; i < h.nsensor && !bad; i++) {
 			const int t = h.sensor_type[i];
 			int cnt;
-			if (t == MJB_SENS_JOINTPOS || t == MJB_SENS_JOINTVEL || t == MJB_SENS_BALLQUAT || t == MJB_SENS_BALLANGVEL) cnt = h.njnt;
-			else if (t == MJB_SENS_TENDONPOS || t == MJB_SENS_TENDONVEL) cnt = h.ntendon;
+			if (t == MJB_SENS_JOINTPOS || t == MJB_SENS_JOINTVEL || t == MJB_SENS_BALLQUAT || t == MJB_SENS_BALLANGVEL || t == MJB_SENS_JOINTACTFRC ||
+			    (t >= MJB_SENS_JOINTLIMITPOS && t <= MJB_SENS_JOINTLIMITFRC))
+				cnt = h.njnt;
+			else if (t == MJB_SENS_TENDONPOS || t == MJB_SENS_TENDONVEL || (t >= MJB_SENS_TENDONLIMITPOS && t <= MJB_SENS_TENDONLIMITFRC)) cnt = h.ntendon;
 			else if (t == MJB_SENS_ACTUATORPOS || t == MJB_SENS_ACTUATORVEL || t == MJB_SENS_ACTUATORFRC) cnt = h.nu;
-			else if (t == MJB_SENS_SUBTREECOM) cnt = h.nbody;
+			else if (t == MJB_SENS_SUBTREECOM || t == MJB_SENS_SUBTREELINVEL || t == MJB_SENS_SUBTREEANGMOM) cnt = h.nbody;
 			else if (t == MJB_SENS_CLOCK) cnt = 1 << 30;
 			else if (t >= MJB_SENS_FRAMEPOS && t <= MJB_SENS_FRAMEANGACC) cnt = objcount(h.sensor_objtype[i]);
 			else cnt = h.nsite;  // touch, accelerometer, velocimeter, gyro, force, torque
@@ -1546,6 +1553,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	s.handoff = nullptr;
 	s.handoff_stride = 0;
 	s.reset_step = nullptr;
+	for (int k = 0; k < 64; k++) s.colfunc[k] = MJB_COLFUNC_DEFAULT;
 	s.sched = nullptr;
 	if (h.nefcmax > 0) {  // constrained kernels: work queue of the chunked fused launches
 		s.sched = dev_alloc<int>((size_t)nenv + 1);
@@ -2376,6 +2384,10 @@ int mjb_register_collision(mjb_batch *b, int geom_type1, int geom_type2, int fun
 	HIP_TRY(hipSetDevice(b->device));
 	HIP_TRY(hipStreamSynchronize(b->stream));
 	const int lo = geom_type1 < geom_type2 ? geom_type1 : geom_type2, hi = geom_type1 < geom_type2 ? geom_type2 : geom_type1;
+	if (b->st.colfunc[8 * lo + hi] != func) {  // the table by current types (read when per-env geom types are in play)
+		b->st.colfunc[8 * lo + hi] = func;
+		b->params_dirty = true;
+	}
 	for (int p = 0; p < np; p++) {  // (pairs are stored with type1 <= type2)
 		if (M->pair_i[8 * p + 2] != lo || M->pair_i[8 * p + 3] != hi) continue;
 		HIP_TRY(hipMemcpy(b->pair_i_dev + 8 * p + 6, &func, sizeof(int), hipMemcpyHostToDevice));

@@ -692,7 +692,9 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const EnvLi
 			// (every narrow-phase routine returns only contacts with dist <= margin, and mj_collideGeoms adds what its
 			//  collision function returns: no second distance filter)
 			if (!cull) {
-				const int cfun = pi[6];  // MujocoEnv::registerCollisionFunction's override of the pair type (mjb_register_collision)
+				// MujocoEnv::registerCollisionFunction's override of the pair type (mjb_register_collision): the pair record carries the one of the
+				// MODEL's types; with per-env geom types the table is read by the geoms' CURRENT types, as mjCOLLISIONFUNC is (mujoco_env.cpp:163-176)
+				const int cfun = s.env_geom_type ? s.colfunc[8 * (t1 & 7) + (t2 & 7)] : pi[6];
 				if (cfun == MJB_COLFUNC_DEFAULT) {
 					if (t1 == MJB_GEOM_BOX && t2 == MJB_GEOM_BOX) boxbox = true;
 					else {

@@ -2295,6 +2295,79 @@ template <int G, bool CACHE = false> STAGE void sensors(CModel m, CLayout L, con
 			out[0] = acc[o]; out[1] = acc[o + 1]; out[2] = acc[o + 2];
 			break;
 		}
+		// ---- round 6: limit sensors -- mj_sensorPos / Vel / Acc report efc_pos - efc_margin, efc_vel, efc_force of the FIRST limit row of the joint / tendon,
+		// zero without one.  Position and velocity are evaluated from the limit's definition (mj_instantiateLimit: lower side first, dist = value - range[0] or
+		// range[1] - value, a row while dist < margin; its Jacobian is -side on the joint's dof): on the fused frames the rows are built after these stages run.
+		case MJB_SENS_JOINTLIMITPOS: case MJB_SENS_JOINTLIMITVEL: case MJB_SENS_TENDONLIMITPOS: case MJB_SENS_TENDONLIMITVEL: {
+			const bool jn = type == MJB_SENS_JOINTLIMITPOS || type == MJB_SENS_JOINTLIMITVEL, pos = type == MJB_SENS_JOINTLIMITPOS || type == MJB_SENS_TENDONLIMITPOS;
+			const bool lim = m.nefcmax > 0 && !(m.disableflags & (MJB_DSBL_LIMIT | MJB_DSBL_CONSTRAINT)) &&
+			                 (jn ? (m.jnt_limited[id] != 0 && m.jnt_type[id] >= MJB_JNT_SLIDE) : (m.tendon_limited[id] != 0));
+			if (lim) {
+				const double value = jn ? f[L.qpos + m.jnt_qposadr[id]] : f[L.ten_length + id];
+				const double vel = jn ? f[L.qvel + m.jnt_dofadr[id]] : f[L.ten_velocity + id];
+				const double margin = jn ? m.jnt_margin[id] : m.tendon_margin[id];
+				const double r0 = jn ? m.jnt_range[2 * id] : m.tendon_range[2 * id], r1 = jn ? m.jnt_range[2 * id + 1] : m.tendon_range[2 * id + 1];
+				if (value - r0 < margin) out[0] = pos ? value - r0 - margin : vel;
+				else if (r1 - value < margin) out[0] = pos ? r1 - value - margin : -vel;
+			}
+			break;
+		}
+		case MJB_SENS_JOINTLIMITFRC: case MJB_SENS_TENDONLIMITFRC: {
+			const int want = type == MJB_SENS_JOINTLIMITFRC ? MJB_CNSTR_LIMIT_JOINT : MJB_CNSTR_LIMIT_TENDON;
+			const int ne = m.nefcmax > 0 ? e.fi[L.nefc] : 0;
+			for (int r = 0; r < ne; r++)
+				if (e.fi[L.efc_type + r] == want && e.fi[L.efc_id + r] == id) {
+					out[0] = f[L.efc_force + r];
+					break;
+				}
+			break;
+		}
+		case MJB_SENS_JOINTACTFRC: out[0] = f[L.qfrc_actuator + m.jnt_dofadr[id]]; break;
+		// ---- mj_subtreeVel's results in closed form: v_c = sum m_b v_b / M over the subtree, L = sum [ I_b w_b + m_b (x_b - c) x (v_b - v_c) ] about the subtree's
+		// com c; a body's com velocity from cvel (taken at the root's subtree com o): v_b = v + w x (x_b - o); I_b w from cinert (about o): I_o w - m d x (w x d), d = x_b - o
+		case MJB_SENS_SUBTREELINVEL: case MJB_SENS_SUBTREEANGMOM: {
+			double c[3], vc[3] = { 0, 0, 0 }, mtot = 0;
+			ld3(c, f + L.subtree_com + 3 * id);
+			for (int pass = 0; pass < (type == MJB_SENS_SUBTREEANGMOM ? 2 : 1); pass++) {
+				for (int b = id; b < m.nbody; b++) {
+					bool in_sub = false;
+					for (int a = b; a >= id; a = m.body_parentid[a]) {
+						if (a == id) { in_sub = true; break; }
+						if (a == 0) break;
+					}
+					if (!in_sub) continue;
+					double ci[10], cv[6], o[3];
+					ld10(ci, f + L.cinert + 10 * b);
+					ld6(cv, f + L.cvel + 6 * b);
+					ld3(o, f + L.subtree_com + 3 * m.body_rootid[b]);
+					const double mass = ci[9];
+					if (!(mass > 0)) continue;
+					const double d[3] = { ci[6] / mass, ci[7] / mass, ci[8] / mass };
+					double wxd[3], vb[3];
+					cross3(wxd, cv, d);
+					for (int k = 0; k < 3; k++) vb[k] = cv[3 + k] + wxd[k];
+					if (pass == 0) {
+						for (int k = 0; k < 3; k++) vc[k] += mass * vb[k];
+						mtot += mass;
+					} else {
+						// I_o w: cinert's rotational block (xx yy zz xy xz yz)
+						const double Iw[3] = { ci[0] * cv[0] + ci[3] * cv[1] + ci[4] * cv[2], ci[3] * cv[0] + ci[1] * cv[1] + ci[5] * cv[2], ci[4] * cv[0] + ci[5] * cv[1] + ci[2] * cv[2] };
+						double dx[3], t[3], rel[3], dv[3], cr[3];
+						cross3(t, d, wxd);
+						for (int k = 0; k < 3; k++) { rel[k] = o[k] + d[k] - c[k]; dv[k] = vb[k] - vc[k]; }
+						cross3(cr, rel, dv);
+						(void)dx;
+						for (int k = 0; k < 3; k++) out[k] += Iw[k] - mass * t[k] + mass * cr[k];
+					}
+				}
+				if (pass == 0) {
+					const double inv = 1.0 / fmax(MJB_MINVAL, mtot);
+					for (int k = 0; k < 3; k++) vc[k] *= inv;
+					if (type == MJB_SENS_SUBTREELINVEL) { out[0] = vc[0]; out[1] = vc[1]; out[2] = vc[2]; }
+				}
+			}
+			break;
+		}
 		default: break;
 		}
 		const double cutoff = m.sensor_cutoff[i];

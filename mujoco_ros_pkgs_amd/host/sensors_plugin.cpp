@@ -63,7 +63,7 @@ void MujocoRosSensorsPlugin::initSensors(const mjModel *model)
 			cfg.kind = VECTOR3_STAMPED;
 			done = true;
 			break;
-		case MJB_SENS_SUBTREECOM:
+		case MJB_SENS_SUBTREECOM: case MJB_SENS_SUBTREELINVEL: case MJB_SENS_SUBTREEANGMOM:  // (:490-501)
 			cfg.kind = VECTOR3_STAMPED;
 			done = global_frame = true;
 			break;
@@ -94,7 +94,8 @@ void MujocoRosSensorsPlugin::initSensors(const mjModel *model)
 			sensor_map_[sensor_name] = cfg;
 			break;
 		case MJB_SENS_TOUCH: case MJB_SENS_JOINTPOS: case MJB_SENS_JOINTVEL: case MJB_SENS_TENDONPOS: case MJB_SENS_TENDONVEL:
-		case MJB_SENS_ACTUATORPOS: case MJB_SENS_ACTUATORVEL: case MJB_SENS_ACTUATORFRC:
+		case MJB_SENS_ACTUATORPOS: case MJB_SENS_ACTUATORVEL: case MJB_SENS_ACTUATORFRC: case MJB_SENS_JOINTACTFRC: case MJB_SENS_JOINTLIMITPOS:
+		case MJB_SENS_JOINTLIMITVEL: case MJB_SENS_JOINTLIMITFRC: case MJB_SENS_TENDONLIMITPOS: case MJB_SENS_TENDONLIMITVEL: case MJB_SENS_TENDONLIMITFRC:  // (:575-590)
 			cfg.kind = SCALAR_STAMPED;
 			cfg.frame_id = frame_id;
 			sensor_map_[sensor_name] = cfg;

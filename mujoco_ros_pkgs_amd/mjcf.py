@@ -44,6 +44,12 @@ SENSORS = {  # name -> (mjtSensor, dim, needstage, default objtype)
     "actuatorfrc": (14, 1, 3, "actuator"),
     "ballquat": (15, 4, 1, "joint"),
     "ballangvel": (16, 3, 2, "joint"),
+    "jointlimitpos": (17, 1, 1, "joint"),
+    "jointlimitvel": (18, 1, 2, "joint"),
+    "jointlimitfrc": (19, 1, 3, "joint"),
+    "tendonlimitpos": (20, 1, 1, "tendon"),
+    "tendonlimitvel": (21, 1, 2, "tendon"),
+    "tendonlimitfrc": (22, 1, 3, "tendon"),
     "framepos": (23, 3, 1, None),
     "framequat": (24, 4, 1, None),
     "framexaxis": (25, 3, 1, None),
@@ -54,6 +60,9 @@ SENSORS = {  # name -> (mjtSensor, dim, needstage, default objtype)
     "framelinacc": (30, 3, 3, None),
     "frameangacc": (31, 3, 3, None),
     "subtreecom": (32, 3, 1, "body"),
+    "subtreelinvel": (33, 3, 2, "body"),
+    "subtreeangmom": (34, 3, 2, "body"),
+    "jointactuatorfrc": (38, 1, 3, "joint"),  # (engine-side value: see include/mjb.h MJB_SENS_JOINTACTFRC)
     "clock": (35, 1, 1, None),
 }
 DISABLE_BITS = {

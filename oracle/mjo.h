@@ -118,6 +118,7 @@ int mjo_hwsim_control_callback(const mjb_model_desc *m, mjo_data *d, int n, cons
                                double control_period);
 void mjo_rne_post_constraint(const mjb_model_desc *m, mjo_data *d);
 int mjo_needs_rne_post(const mjb_model_desc *m);
+void mjo_subtree_vel(const mjb_model_desc *m, const mjo_data *d, int id, double *linvel, double *angmom); /* mj_subtreeVel, one subtree's results */
 void mjo_register_collision(mjo_data *d, int geom_type1, int geom_type2, int func); /* mjb_register_collision */
 void mjo_set_geom_size(const mjb_model_desc *m, mjo_data *d, const double *size);   /* [ngeom][3]; NULL: back to the model's */
 void mjo_set_geom_type(const mjb_model_desc *m, mjo_data *d, const int *type);      /* [ngeom];    NULL: back to the model's */

@@ -706,6 +706,52 @@ static int ray_hits_site(const mjb_model_desc *m, const mjo_data *d, int site, c
 	return 1;
 }
 
+/* mj_subtreeVel (engine_core_smooth.c): linear velocity and angular momentum of every subtree -- body momenta from cvel (taken at the root's
+ * subtree com), linear momenta summed leaf to root and divided by the subtree mass, then the angular momenta about each subtree's own com, leaf to
+ * root, with the two transport terms (body com -> subtree com, child subtree -> parent subtree).  Returns subtree `id`'s pair. */
+void mjo_subtree_vel(const mjb_model_desc *m, const mjo_data *d, int id, double *linvel, double *angmom)
+{
+	int nb = m->nbody;
+	double *bodyvel = (double *)malloc(sizeof(double) * 6 * (size_t)nb), *sl = (double *)malloc(sizeof(double) * 3 * (size_t)nb),
+	       *sa = (double *)malloc(sizeof(double) * 3 * (size_t)nb);
+	for (int i = 0; i < nb; i++) {
+		double dif[3], dv[3], tmp[3], w[3];
+		v3_sub(dif, d->xipos + 3 * i, d->subtree_com + 3 * m->body_rootid[i]);
+		v3_cross(dv, d->cvel + 6 * i, dif);
+		v3_copy(bodyvel + 6 * i, d->cvel + 6 * i);
+		v3_add(bodyvel + 6 * i + 3, d->cvel + 6 * i + 3, dv);
+		v3_scl(sl + 3 * i, bodyvel + 6 * i + 3, m->body_mass[i]);
+		/* body angular momentum: ximat diag(inertia) ximat' w */
+		m3_mulvecT(tmp, d->ximat + 9 * i, bodyvel + 6 * i);
+		for (int k = 0; k < 3; k++) w[k] = tmp[k] * m->body_inertia[3 * i + k];
+		m3_mulvec(sa + 3 * i, d->ximat + 9 * i, w);
+	}
+	for (int i = nb - 1; i >= 0; i--) {
+		if (i) v3_addto(sl + 3 * m->body_parentid[i], sl + 3 * i);
+		v3_scl(sl + 3 * i, sl + 3 * i, 1.0 / fmax(MJO_MINVAL, m->body_subtreemass[i]));
+	}
+	for (int i = nb - 1; i > 0; i--) {
+		int p = m->body_parentid[i];
+		double dx[3], dv[3], dp[3], dL[3];
+		/* momentum of the body about its subtree's com */
+		v3_sub(dx, d->xipos + 3 * i, d->subtree_com + 3 * i);
+		v3_sub(dv, bodyvel + 6 * i + 3, sl + 3 * i);
+		v3_scl(dp, dv, m->body_mass[i]);
+		v3_cross(dL, dx, dp);
+		v3_addto(sa + 3 * i, dL);
+		/* to the parent */
+		v3_addto(sa + 3 * p, sa + 3 * i);
+		v3_sub(dx, d->subtree_com + 3 * i, d->subtree_com + 3 * p);
+		v3_sub(dv, sl + 3 * i, sl + 3 * p);
+		v3_scl(dv, dv, m->body_subtreemass[i]);
+		v3_cross(dL, dx, dv);
+		v3_addto(sa + 3 * p, dL);
+	}
+	v3_copy(linvel, sl + 3 * id);
+	v3_copy(angmom, sa + 3 * id);
+	free(bodyvel); free(sl); free(sa);
+}
+
 void mjo_sensor(const mjb_model_desc *m, mjo_data *d, int stage)
 {
 	if (m->disableflags & MJB_DSBL_SENSOR) return;
@@ -821,6 +867,27 @@ void mjo_sensor(const mjb_model_desc *m, mjo_data *d, int stage)
 			double acc[6];
 			object_acceleration(m, d, ot, id, acc, 0);
 			v3_copy(out, type == MJB_SENS_FRAMELINACC ? acc + 3 : acc);
+			break;
+		}
+		/* mj_sensorPos / mj_sensorVel / mj_sensorAcc, limit sensors: the first limit row of the joint / tendon, zero without one
+		 * (/root/reference mujoco_ros_sensors/src/mujoco_sensor_handler_plugin.cpp:331-343 serialises them as scalars) */
+		case MJB_SENS_JOINTLIMITPOS: case MJB_SENS_JOINTLIMITVEL: case MJB_SENS_JOINTLIMITFRC:
+		case MJB_SENS_TENDONLIMITPOS: case MJB_SENS_TENDONLIMITVEL: case MJB_SENS_TENDONLIMITFRC: {
+			int want = type <= MJB_SENS_JOINTLIMITFRC ? MJB_CNSTR_LIMIT_JOINT : MJB_CNSTR_LIMIT_TENDON;
+			int kind = (type - MJB_SENS_JOINTLIMITPOS) % 3; /* 0 pos, 1 vel, 2 frc */
+			out[0] = 0;
+			for (int r = 0; r < d->nefc[0]; r++)
+				if (d->efc_type[r] == want && d->efc_id[r] == id) {
+					out[0] = kind == 0 ? d->efc_pos[r] - d->efc_margin[r] : (kind == 1 ? d->efc_vel[r] : d->efc_force[r]);
+					break;
+				}
+			break;
+		}
+		case MJB_SENS_JOINTACTFRC: out[0] = d->qfrc_actuator[m->jnt_dofadr[id]]; break;
+		case MJB_SENS_SUBTREELINVEL: case MJB_SENS_SUBTREEANGMOM: {
+			double lin[3], ang[3];
+			mjo_subtree_vel(m, d, id, lin, ang);
+			v3_copy(out, type == MJB_SENS_SUBTREELINVEL ? lin : ang);
 			break;
 		}
 		default: break;

@@ -82,6 +82,53 @@ def test_gpu_override_matches_oracle(oracle_built):
     b.close()
 
 
+@pytest.mark.gpu
+def test_gpu_override_follows_the_current_geom_types(oracle_built):
+    """mjCOLLISIONFUNC is indexed by the geoms' CURRENT types (mujoco_env.cpp:163-176): an env whose cube was turned into a sphere
+    (mjb_set_env_geom_type) takes the override registered for (plane, sphere), the others the one for (plane, box) -- VERDICT r05 #7."""
+    import os
+    from mujoco_ros_pkgs_amd import engine
+    model = mjcf.compile_xml_file(os.path.join(mjcf.ASSET_DIR, "franka_table.xml"), nconmax=32, nefcmax=128)
+    ng = int(model["ngeom"])
+    cube = model["names"]["geom"].index("cube_geom")
+    nenv = 6
+    qpos, qvel = scenario_states(model, nenv, seed=4)
+    qpos[:, 2] = 0.0195   # every cube -- box of half-size 0.02 or sphere of radius 0.02 -- sits half a millimetre inside the table
+    qpos[:, 3:7] = [1, 0, 0, 0]
+    gtype = np.tile(np.asarray(model["geom_type"], dtype=np.int32).reshape(1, ng), (nenv, 1))
+    gtype[1, cube] = gtype[4, cube] = SPHERE
+    b = engine.Batch(engine.CompiledModel(model), nenv)
+    b.set_env_geom_type(gtype, 0, nenv)
+    d = oracle_built.OracleData(model)
+    base = None
+    for over in ([], [(PLANE, SPHERE, NONE)], [(PLANE, BOX, SPHERES)], [(PLANE, SPHERE, DEFAULT), (PLANE, BOX, NONE)]):
+        for t1, t2, f in over:
+            b.register_collision(t1, t2, f)
+            d.register_collision(t1, t2, f)
+        b.reset()
+        b.set("qpos", qpos); b.set("qvel", qvel)
+        b.forward()
+        ncon, geom, dist = b.get("ncon"), b.get("contact_geom"), b.get("contact_dist")
+        table_cube = []
+        for e in range(nenv):
+            d.set_geom_type(gtype[e])
+            d.reset(); d.qpos[:] = qpos[e]; d.qvel[:] = qvel[e]; d.forward()
+            n = int(d.ncon[0])
+            assert ncon[e, 0] == n and np.array_equal(geom[e][:2 * n], d.contact_geom[:2 * n]), (over, e)
+            assert np.allclose(dist[e][:n], d.contact_dist[:n], rtol=0, atol=1e-12)
+            table_cube.append(sum(1 for c in range(n) if geom[e][2 * c] == 0 and geom[e][2 * c + 1] == cube))
+        if not over:
+            base = table_cube
+            assert base[1] == 1 and base[4] == 1 and max(base[k] for k in (0, 2, 3, 5)) >= 3, base   # a sphere: one contact; a box: up to four
+        elif over[0] == (PLANE, SPHERE, NONE):
+            assert table_cube == [base[0], 0, base[2], base[3], 0, base[5]], (table_cube, base)
+        elif over[0] == (PLANE, BOX, SPHERES):
+            assert table_cube[1] == 0 and table_cube[4] == 0 and all(table_cube[k] == min(1, base[k]) for k in (0, 2, 3, 5)), (table_cube, base)
+        else:
+            assert table_cube == [0, base[1], 0, 0, base[4], 0], (table_cube, base)
+    b.close()
+
+
 def test_host_registration_rules(oracle_built):
     """First registration 0, a second one for the same (unordered) pair 1 -- the reference's warning case --, and a reload drops
     every override (prepareReload)."""

@@ -36,14 +36,34 @@ def test_which_models_the_kernel_takes():
     assert classify(mjcf.compile_xml_string(base.replace('integrator="Euler"', 'integrator="RK4"'))) == -1
 
 
+def test_which_models_the_split_step_takes():
+    """mjb_model_split_step: the smooth kernel's compiled-in topologies (csrc/smooth_topos.h) whose constraint half is kernel variant 9's -- plain PGS,
+    pyramidal cones, nv <= 16."""
+    from mujoco_ros_pkgs_amd import engine, mjcf
+
+    def split(model):
+        cm = engine.CompiledModel(model)
+        v = int(cm.lib.mjb_model_split_step(cm.ptr))
+        cm.close()
+        return v
+    assert split(mjcf.load_asset("franka_table")) == 0
+    assert split(mjcf.load_asset("split_step_tree")) == 1
+    assert split(mjcf.load_asset("franka_like")) == -1         # no constraint rows: the lane = env kernel proper takes it
+    assert split(mjcf.load_asset("shadow_hand_grasp")) == -1   # Newton, 30 dofs
+    xml = open(os.path.join(mjcf.ASSET_DIR, "franka_table.xml")).read()
+    assert split(mjcf.compile_xml_string(xml.replace('solver="PGS"', 'solver="Newton"'))) == -1
+    assert split(mjcf.compile_xml_string(xml.replace('cone="pyramidal"', 'cone="elliptic"'))) == -1
+
+
 def test_generated_topology_header_is_current(tmp_path):
     """csrc/lane_env_topos.h is generated from the asset XMLs; a changed asset with a stale header would silently stop matching (the
     model would still run, on hiprtc's build or the generic kernels)."""
-    hdr = os.path.join(ROOT, "mujoco_ros_pkgs_amd", "csrc", "lane_env_topos.h")
-    before = open(hdr).read()
+    hdrs = [os.path.join(ROOT, "mujoco_ros_pkgs_amd", "csrc", n) for n in ("lane_env_topos.h", "smooth_topos.h")]
+    before = [open(h).read() for h in hdrs]
     try:
         subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_lane_env_topo.py")], stdout=subprocess.DEVNULL)
-        after = open(hdr).read()
+        after = [open(h).read() for h in hdrs]
     finally:
-        open(hdr, "w").write(before)
+        for h, t in zip(hdrs, before):
+            open(h, "w").write(t)
     assert after == before, "run tools/gen_lane_env_topo.py and rebuild"

@@ -1,0 +1,219 @@
+"""The scalar / 3-vector sensor types MujocoRosSensorsPlugin serialises that the engine did not evaluate before round 6
+(/root/reference mujoco_ros_sensors/src/mujoco_sensor_handler_plugin.cpp:76-105, :331-343, :490-501, :575-590): jointlimitpos / vel / frc,
+tendonlimitpos / vel / frc, jointactuatorfrc, subtreelinvel, subtreeangmom.  Oracle restatements (mj_sensorPos / Vel / Acc, mj_subtreeVel) pinned
+against their definitions computed independently in numpy; the kernels against the oracle on the fused and the full frame."""
+import numpy as np
+import pytest
+
+from mujoco_ros_pkgs_amd import mjcf
+
+XML = """
+<mujoco model="sensor_types_r06">
+  <compiler angle="radian"/>
+  <option timestep="0.002" solver="{solver}" cone="{cone}" iterations="60" tolerance="1e-10"/>
+  <size nconmax="8" njmax="40"/>
+  <default><joint damping="0.2" armature="0.02"/></default>
+  <worldbody>
+    <geom name="floor" type="plane" size="3 3 0.1"/>
+    <body name="base" pos="0 0 0.8">
+      <joint name="j1" type="hinge" axis="0 1 0" limited="{limited}" range="-0.5 0.6" margin="0.02"/>
+      <geom type="capsule" fromto="0 0 0 0.3 0 0" size="0.03" mass="1.0"/>
+      <body name="fore" pos="0.3 0 0" quat="0.9689124 0 0 0.2474040">
+        <joint name="j2" type="hinge" axis="0 0 1" limited="{limited}" range="-1.0 0.3"/>
+        <geom type="capsule" fromto="0 0 0 0.25 0 0" size="0.025" mass="0.6"/>
+        <body name="tipa" pos="0.25 0 0">
+          <joint name="j3" type="slide" axis="1 0 0" limited="{limited}" range="-0.04 0.04"/>
+          <inertial pos="0.02 0.01 0" quat="0.9238795 0 0.3826834 0" mass="0.2" diaginertia="0.0004 0.0003 0.0002"/>
+          <geom type="sphere" size="0.03" contype="0" conaffinity="0"/>
+        </body>
+        <body name="tipb" pos="0.1 0.05 0">
+          <joint name="j4" type="hinge" axis="1 0 0" pos="0 0.01 0"/>
+          <geom type="box" size="0.03 0.02 0.01" mass="0.15"/>
+        </body>
+      </body>
+    </body>
+    <body name="puck" pos="0.5 0.3 0.05">
+      <freejoint/>
+      <geom type="sphere" size="0.05" mass="0.3"/>
+    </body>
+  </worldbody>
+  <tendon>
+    <fixed name="t1" limited="{limited}" range="-0.3 0.25" margin="0.01">
+      <joint joint="j1" coef="1.0"/>
+      <joint joint="j2" coef="-0.5"/>
+    </fixed>
+  </tendon>
+  <actuator>
+    <motor name="m1" joint="j1" gear="2"/>
+    <position name="p2" joint="j2" kp="8"/>
+    <motor name="m2b" joint="j2" gear="-1.5"/>
+  </actuator>
+  <sensor>
+    <jointlimitpos joint="j1"/>
+    <jointlimitvel joint="j1"/>
+    <jointlimitfrc joint="j1"/>
+    <jointlimitpos joint="j2"/>
+    <jointlimitvel joint="j2"/>
+    <jointlimitfrc joint="j2"/>
+    <jointlimitpos joint="j3"/>
+    <jointlimitfrc joint="j3"/>
+    <jointlimitpos joint="j4"/>
+    <tendonlimitpos tendon="t1"/>
+    <tendonlimitvel tendon="t1"/>
+    <tendonlimitfrc tendon="t1"/>
+    <jointactuatorfrc joint="j2"/>
+    <jointactuatorfrc joint="j1" cutoff="0.5"/>
+    <subtreelinvel body="base"/>
+    <subtreeangmom body="base"/>
+    <subtreelinvel body="fore"/>
+    <subtreeangmom body="fore"/>
+    <subtreeangmom body="puck"/>
+    <subtreelinvel body="tipa"/>
+    <subtreeangmom body="tipa" cutoff="0.001"/>
+  </sensor>
+</mujoco>
+"""
+
+
+def model_of(solver="PGS", cone="pyramidal", limited="true"):
+    return mjcf.compile_xml_string(XML.format(solver=solver, cone=cone, limited=limited))
+
+
+def states(model, n, seed):
+    rng = np.random.default_rng(seed)
+    qpos = np.tile(model["qpos0"], (n, 1))
+    qvel = rng.uniform(-1.5, 1.5, (n, model["nv"]))
+    # hinge / slide coordinates around and beyond their limits (both sides, and inside the margin band)
+    qpos[:, 0] = rng.choice([-0.53, -0.49, 0.0, 0.59, 0.63, 0.3], n) + rng.uniform(-0.005, 0.005, n)
+    qpos[:, 1] = rng.choice([-1.03, -0.5, 0.31, 0.28, 0.0], n) + rng.uniform(-0.005, 0.005, n)
+    qpos[:, 2] = rng.choice([-0.045, 0.0, 0.043, 0.02], n)
+    qpos[:, 3] = rng.uniform(-0.5, 0.5, n)
+    qpos[:, 4:7] += rng.uniform(-0.02, 0.02, (n, 3))
+    q = qpos[:, 7:11] + rng.uniform(-0.2, 0.2, (n, 4))
+    qpos[:, 7:11] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    ctrl = rng.uniform(-1, 1, (n, model["nu"]))
+    return qpos, qvel, ctrl
+
+
+def sens(model, sd, name_or_idx):
+    i = name_or_idx
+    return sd[model["sensor_adr"][i]:model["sensor_adr"][i] + model["sensor_dim"][i]]
+
+
+def test_loader_takes_the_types():
+    m = model_of()
+    assert list(m["sensor_type"][:9]) == [17, 18, 19, 17, 18, 19, 17, 19, 17] and list(m["sensor_type"][9:12]) == [20, 21, 22]
+    assert list(m["sensor_type"][12:14]) == [38, 38] and list(m["sensor_type"][14:]) == [33, 34, 33, 34, 34, 33, 34]
+    assert list(m["sensor_needstage"][:3]) == [1, 2, 3] and list(m["sensor_needstage"][9:12]) == [1, 2, 3] and m["sensor_needstage"][12] == 3
+    assert list(m["sensor_needstage"][14:16]) == [2, 2] and m["nsensordata"] == 14 + 21
+
+
+def test_oracle_sensors_against_their_definitions(oracle_built):
+    """Limit sensors = efc_pos - efc_margin / efc_vel / efc_force of the limit row (and what those are in terms of qpos, qvel, the range); the joint's
+    actuator force; subtree momenta from first principles: v_c = sum m v / M, L = sum I w + m (x - c) x (v - v_c) over the subtree's bodies."""
+    m = model_of()
+    qpos, qvel, ctrl = states(m, 24, 3)
+    d = oracle_built.OracleData(m)
+    nb = m["nbody"]
+    parent = list(m["body_parentid"])
+    seen = {"lower": 0, "upper": 0, "none": 0, "tendon": 0}
+    for e in range(24):
+        d.reset(); d.qpos[:] = qpos[e]; d.qvel[:] = qvel[e]; d.ctrl[:] = ctrl[e]; d.forward()
+        sd = np.array(d.sensordata)
+        ne = int(d.nefc[0])
+        et, ei = np.array(d.efc_type[:ne]), np.array(d.efc_id[:ne])
+        for (j, ip, iv, ifr) in ((0, 0, 1, 2), (1, 3, 4, 5), (2, 6, None, 7)):
+            q, v = d.qpos[m["jnt_qposadr"][j]], d.qvel[m["jnt_dofadr"][j]]
+            r0, r1, mg = m["jnt_range"][j][0], m["jnt_range"][j][1], m["jnt_margin"][j]
+            rows = [r for r in range(ne) if et[r] == 3 and ei[r] == j]
+            if q - r0 < mg:
+                exp_p, exp_v = q - r0 - mg, v
+                seen["lower"] += 1
+            elif r1 - q < mg:
+                exp_p, exp_v = r1 - q - mg, -v
+                seen["upper"] += 1
+            else:
+                exp_p = exp_v = 0.0
+                seen["none"] += 1
+            assert (len(rows) > 0) == (exp_p != 0.0 or q - r0 < mg or r1 - q < mg)
+            assert abs(sens(m, sd, ip)[0] - exp_p) <= 1e-14
+            if iv is not None:
+                assert abs(sens(m, sd, iv)[0] - exp_v) <= 1e-13
+            frc = sens(m, sd, ifr)[0]
+            assert frc == (d.efc_force[rows[0]] if rows else 0.0) and frc >= 0
+        assert sens(m, sd, 8)[0] == 0.0  # an unlimited joint has no limit row
+        L_t = d.qpos[0] - 0.5 * d.qpos[1]
+        if L_t + 0.3 < 0.01 or 0.25 - L_t < 0.01:
+            seen["tendon"] += 1
+            assert sens(m, sd, 9)[0] != 0 and sens(m, sd, 11)[0] >= 0
+        else:
+            assert sens(m, sd, 9)[0] == 0 and sens(m, sd, 10)[0] == 0 and sens(m, sd, 11)[0] == 0
+        # jointactuatorfrc = qfrc_actuator of the joint's dof: two actuators on j2 (gear 1 and -1.5), one on j1 (gear 2, cutoff 0.5)
+        af = np.array(d.actuator_force)
+        assert abs(sens(m, sd, 12)[0] - (af[1] - 1.5 * af[2])) <= 1e-13
+        assert abs(sens(m, sd, 13)[0] - np.clip(2 * af[0], -0.5, 0.5)) <= 1e-13
+        # subtree momenta
+        xipos, ximat = np.array(d.xipos).reshape(nb, 3), np.array(d.ximat).reshape(nb, 3, 3)
+        cvel, scom = np.array(d.cvel).reshape(nb, 6), np.array(d.subtree_com).reshape(nb, 3)
+        mass, inertia = np.array(m["body_mass"]), np.array(m["body_inertia"]).reshape(nb, 3)
+        vb = np.array([cvel[b, 3:] + np.cross(cvel[b, :3], xipos[b] - scom[m["body_rootid"][b]]) for b in range(nb)])
+        for (body, il, ia) in ((1, 14, 15), (2, 16, 17), (5, None, 18), (3, 19, 20)):
+            sub = [b for b in range(nb) if any(a == body for a in _chain(parent, b))]
+            M = mass[sub].sum()
+            vc = (mass[sub, None] * vb[sub]).sum(0) / M
+            c = (mass[sub, None] * xipos[sub]).sum(0) / M
+            assert np.abs(c - scom[body]).max() <= 1e-13
+            Lm = np.zeros(3)
+            for b in sub:
+                Lm += ximat[b] @ (inertia[b] * (ximat[b].T @ cvel[b, :3])) + mass[b] * np.cross(xipos[b] - c, vb[b] - vc)
+            if il is not None:
+                assert np.abs(sens(m, sd, il) - vc).max() <= 1e-13, (e, body)
+            exp = Lm if ia != 20 else np.clip(Lm, -0.001, 0.001)
+            assert np.abs(sens(m, sd, ia) - exp).max() <= 1e-14 + 1e-13 * np.abs(Lm).max(), (e, body)
+    assert min(seen.values()) >= 3, seen
+
+
+def _chain(parent, b):
+    out = [b]
+    while b > 0:
+        b = parent[b]
+        out.append(b)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver,cone,limited", [("PGS", "pyramidal", "true"), ("Newton", "elliptic", "true"), ("CG", "pyramidal", "true"), ("PGS", "pyramidal", "false")])
+def test_gpu_sensors_match_oracle(oracle_built, solver, cone, limited):
+    from mujoco_ros_pkgs_amd import engine
+    m = model_of(solver, cone, limited)
+    n = 32
+    qpos, qvel, ctrl = states(m, n, 5)
+    cm = engine.CompiledModel(m)
+    d = oracle_built.OracleData(m)
+    for path in ("forward", "step", "step5"):
+        b = engine.Batch(cm, n)
+        b.set("qpos", qpos); b.set("qvel", qvel); b.set("ctrl", ctrl)
+        if path == "forward":
+            b.forward()      # full frame
+        else:
+            b.step(1 if path == "step" else 5)   # fused frame: sensordata of the (last) step's forward pass
+        sd = b.get("sensordata")
+        nonzero = np.zeros(m["nsensor"], bool)
+        for e in range(n):
+            d.reset(); d.qpos[:] = qpos[e]; d.qvel[:] = qvel[e]; d.ctrl[:] = ctrl[e]
+            if path == "forward":
+                d.forward()
+            else:
+                d.step(1 if path == "step" else 5)
+            ref = np.array(d.sensordata)
+            # (five steps: rollout parity of the solvers -- CG's stop test sits on its threshold more often)
+            tol = 1e-11 if path != "step5" else (1e-6 if solver == "CG" else 1e-8)
+            for i in range(m["nsensor"]):
+                a, r = sens(m, sd[e], i), sens(m, ref, i)
+                scale = 1 + np.abs(r).max()
+                ftol = tol * (1e3 if m["sensor_type"][i] in (19, 22) else 1)   # limit forces: the solver's tolerance on top
+                assert np.abs(a - r).max() <= ftol * scale, (path, e, i, a, r)
+                nonzero[i] |= bool(np.any(r != 0))
+        if limited == "true" and path == "forward":
+            assert nonzero[[0, 1, 2, 3, 5, 6, 9, 11, 12, 14, 15, 17, 18, 20]].all(), nonzero
+        b.close()
