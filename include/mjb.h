@@ -276,6 +276,9 @@ int mjb_model_split_step(const mjb_model *m);
  * seconds, cached per process); -3: that build was not possible (mjb_lane_env_error says why) and the generic kernels run; -1: the model does not
  * fit (constraint rows, free / ball joints, RK4, ...).  *used_last (may be NULL) = 1 when the last fused launch ran the lane = env kernel. */
 int mjb_lane_env_info(const mjb_batch *b, int *used_last);
+/* hiprtc builds of the lane = env kernel are kept on disk: $MJB_JIT_CACHE (default $XDG_CACHE_HOME/mjb_jit or ~/.cache/mjb_jit; "0" = off), one code
+ * object per (gfx arch, kernel-header fingerprint, LDS budget, form, topology).  Counts of this process: kernels compiled / taken from the cache. */
+void mjb_lane_env_jit_counts(int *compiled, int *disk_hits);
 /* The same classification for a compiled model, without a batch or a device (>= 0 / -2 / -1 as above). */
 int mjb_model_lane_env(const mjb_model *m);
 const char *mjb_lane_env_error(void);

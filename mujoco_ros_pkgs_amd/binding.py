@@ -196,6 +196,7 @@ def load_library(path=None):
         "mjb_lane_env_set_form": (ci, [ci]),
         "mjb_lane_env_last_form": (ci, []),
         "mjb_model_lane_env": (ci, [vp]),
+        "mjb_lane_env_jit_counts": (None, [C.POINTER(ci), C.POINTER(ci)]),
         "mjb_set_split_step": (ci, [vp, ci]),
         "mjb_split_step_info": (ci, [vp, C.POINTER(ci), C.POINTER(ci)]),
         "mjb_model_split_step": (ci, [vp]),

@@ -2670,6 +2670,7 @@ int mjb_split_step_info(const mjb_batch *b, int *used_last, int *slices)
 }
 int mjb_model_split_step(const mjb_model *m) { return m ? m->sm_topo : -1; }
 const char *mjb_lane_env_error(void) { return mjb_lane_env_jit_error(); }
+void mjb_lane_env_jit_counts(int *compiled, int *disk_hits) { mjb_lane_env_jit_stats(compiled, disk_hits); }
 int mjb_model_lane_env(const mjb_model *m) { return m ? m->le_topo : -1; }
 int mjb_lane_env_info(const mjb_batch *b, int *used_last)
 {

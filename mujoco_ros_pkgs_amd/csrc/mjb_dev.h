@@ -293,7 +293,8 @@ void mjb_lane_env_tape(const mjb_model_desc *h, double *tape);  // fills it
 const char *mjb_lane_env_name(int topo);
 enum { MJB_LE_TOPO_NONE = -1, MJB_LE_TOPO_JIT = -2, MJB_LE_UNAVAILABLE = -1000 };
 int mjb_lane_env_eligible(const mjb_model_desc *h);   // the model's structure fits the kernel (compiled in or not)
-const char *mjb_lane_env_jit_error(void);              // why the last hiprtc build of a topology was not available ("" if none failed)
+const char *mjb_lane_env_jit_error(void);
+void mjb_lane_env_jit_stats(int *compiled, int *disk_hits);  // hiprtc builds of this process / builds taken from the disk cache instead              // why the last hiprtc build of a topology was not available ("" if none failed)
 int mjb_launch_lane_env(const KernelParams *Pdev, int topo, const mjb_model_desc *h, int nenv_batch, int env_lo, int env_hi, int nsteps, unsigned int step0,
                         void *stream);
 // the split step (mjb_smooth_kernel.h + mjb_cstep_kernel): one step of envs [env_lo, env_hi) -- smooth half in lane = env form, then the constraint half

@@ -22,6 +22,11 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
 
 #include <atomic>
 #include <map>
@@ -246,6 +251,55 @@ std::string source_dir()
 	return ".";
 }
 
+// ---- on-disk cache of the hiprtc builds: a new model's first eligible launch costs ~3 s of compilation per LDS budget and form; the code
+// object is kept under $MJB_JIT_CACHE (default $XDG_CACHE_HOME/mjb_jit or ~/.cache/mjb_jit; MJB_JIT_CACHE=0 turns it off) in a file named by a hash of
+// everything the build depends on: gfx arch, the TEXT of every header the source includes (the source fingerprint), LDS budget, form, the topology.
+std::atomic<int> jit_compiled{ 0 }, jit_disk_hits{ 0 };
+unsigned long long fnv1a(unsigned long long hsh, const std::string &t)
+{
+	for (unsigned char c : t) {
+		hsh ^= c;
+		hsh *= 1099511628211ull;
+	}
+	return hsh;
+}
+bool read_file(const std::string &path, std::string &out)
+{
+	FILE *f = fopen(path.c_str(), "rb");
+	if (!f) return false;
+	char buf[65536];
+	size_t n;
+	out.clear();
+	while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+	fclose(f);
+	return true;
+}
+std::string cache_dir()
+{
+	if (const char *v = getenv("MJB_JIT_CACHE")) return (*v == '0' && !v[1]) ? std::string() : std::string(v);
+	if (const char *x = getenv("XDG_CACHE_HOME")) if (*x) return std::string(x) + "/mjb_jit";
+	if (const char *hm = getenv("HOME")) if (*hm) return std::string(hm) + "/.cache/mjb_jit";
+	return "/tmp/mjb_jit";
+}
+void make_dirs(const std::string &d)
+{
+	for (size_t k = 1; k <= d.size(); k++)
+		if (k == d.size() || d[k] == '/') (void)mkdir(d.substr(0, k).c_str(), 0755);
+}
+// hash of the headers the generated source pulls in (a changed kernel header or data-field list invalidates every cached build)
+bool source_fingerprint(const std::string &dir, unsigned long long &hsh)
+{
+	static const char *files[] = { "/mjb_lane_env_kernel.h", "/mjb_dev.h", "/mjb_math.h", "/../../include/mjb.h", "/../../include/mjb_model_fields.def",
+		                           "/../../include/mjb_data_fields.def" };
+	hsh = 1469598103934665603ull;
+	std::string text;
+	for (const char *f : files) {
+		if (!read_file(dir + f, text)) return false;
+		hsh = fnv1a(hsh, text);
+	}
+	return true;
+}
+
 const JitKernel &jit_get(const mjb_model_desc &h, int lp, int duo)  // duo: 0 solo, 1 two halves, 2 pipelined, 3 three wavefronts
 {
 	int dev = 0;
@@ -275,6 +329,28 @@ const JitKernel &jit_get(const mjb_model_desc &h, int lp, int duo)  // duo: 0 so
 	                             : "extern \"C\" __global__ void __launch_bounds__(64) le_rt(const KernelParams MJB_AS4 *P, int nsteps, unsigned int step0, int lo, int hi)\n{\n"
 	                               "\t__shared__ __attribute__((aligned(16))) unsigned char smem[mjb_le::Lds<LeTopo_rt, " + slp + ">::bytes()];\n"
 	                               "\tmjb_le::lane_env_body<LeTopo_rt, " + slp + ">(P, nsteps, step0, lo, hi, smem);\n}\n");
+	// the disk cache first
+	std::string cpath;
+	{
+		const std::string cdir = cache_dir();
+		unsigned long long fp = 0;
+		if (!cdir.empty() && source_fingerprint(dir, fp)) {
+			unsigned long long hk = fnv1a(fnv1a(fnv1a(fp, device_arch(dev)), src), "O3 fp-contract=fast no-machine-licm v1");
+			char name[64];
+			snprintf(name, sizeof name, "/le_%016llx.hsaco", hk);
+			cpath = cdir + name;
+			std::string blob;
+			if (read_file(cpath, blob) && blob.size() > 64) {
+				if (hipModuleLoadData(&k.mod, blob.data()) == hipSuccess && hipModuleGetFunction(&k.fn, k.mod, "le_rt") == hipSuccess) {
+					jit_disk_hits++;
+					return k;
+				}
+				(void)hipGetLastError();  // (a truncated or foreign file: rebuilt and overwritten below)
+				k.mod = nullptr;
+				k.fn = nullptr;
+			}
+		}
+	}
 	void *prog = nullptr;
 	if (r.create(&prog, src.c_str(), "mjb_lane_env_rt.hip", 0, nullptr, nullptr) != 0) { k.error = "hiprtcCreateProgram failed"; return k; }
 	const std::string i1 = "-I" + dir, i2 = "-I" + dir + "/../../include";
@@ -295,6 +371,17 @@ const JitKernel &jit_get(const mjb_model_desc &h, int lp, int duo)  // duo: 0 so
 	std::vector<char> code(n);
 	r.code(prog, code.data());
 	r.destroy(&prog);
+	jit_compiled++;
+	if (!cpath.empty()) {  // (written under a temporary name and renamed: a concurrent process never reads half a file)
+		make_dirs(cpath.substr(0, cpath.rfind('/')));
+		const std::string tmp = cpath + "." + std::to_string((long long)getpid()) + ".tmp";
+		FILE *f = fopen(tmp.c_str(), "wb");
+		if (f) {
+			const bool okw = fwrite(code.data(), 1, code.size(), f) == code.size();
+			fclose(f);
+			if (!okw || rename(tmp.c_str(), cpath.c_str()) != 0) (void)remove(tmp.c_str());
+		}
+	}
 	if (hipModuleLoadData(&k.mod, code.data()) != hipSuccess || hipModuleGetFunction(&k.fn, k.mod, "le_rt") != hipSuccess) {
 		(void)hipGetLastError();
 		k.error = "hipModuleLoadData / hipModuleGetFunction failed";
@@ -334,6 +421,12 @@ hipError_t lds_attr_once(const void *fn, int bytes, int dev)
 	return r;
 }
 }  // namespace
+
+void mjb_lane_env_jit_stats(int *compiled, int *disk_hits)
+{
+	if (compiled) *compiled = jit_compiled.load();
+	if (disk_hits) *disk_hits = jit_disk_hits.load();
+}
 
 const char *mjb_lane_env_jit_error(void)
 {

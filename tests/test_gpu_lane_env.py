@@ -399,3 +399,54 @@ def test_form_follows_batch_size(eng):
             oq, _, _ = po.rollout(model, qpos[e:e + 1], qvel[e:e + 1], 12, noise_std=10.0, noise_rate=0.1, seed=7, env_offset=int(e))
             _close(q[e], oq[0], 1e-9, f"env {e} of {nenv}")
         b.close()
+
+
+def test_hiprtc_build_is_cached_on_disk(tmp_path):
+    """the hiprtc build of a topology (~3 s per LDS budget and form) is kept under $MJB_JIT_CACHE, keyed on the gfx arch, the kernel
+    headers' text, the LDS budget, the form and the topology: a SECOND PROCESS loads the code object instead of compiling, and computes the same step."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r'''
+import ctypes as C, json, sys, time
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+import numpy as np
+from mujoco_ros_pkgs_amd import engine, mjcf
+from test_gpu_lane_env import JIT_ARM
+xml = JIT_ARM.replace('actuator="3"', 'actuator="act3"').replace('<motor joint="j4" forcelimited', '<motor name="act3" joint="j4" forcelimited')
+model = mjcf.compile_xml_string(xml)
+cm = engine.CompiledModel(model)
+b = engine.Batch(cm, 64)
+b.set_lane_env(1)
+rng = np.random.default_rng(2)
+b.set("qvel", rng.uniform(-1, 1, (64, model["nv"])))
+t0 = time.perf_counter()
+b.step(3)
+q = b.get("qpos")
+dt = time.perf_counter() - t0
+comp, hits = C.c_int(0), C.c_int(0)
+b.lib.mjb_lane_env_jit_counts(C.byref(comp), C.byref(hits))
+print(json.dumps(dict(used=b.lane_env_info()[1], compiled=comp.value, hits=hits.value, seconds=dt, qsum=float(np.abs(q).sum()), err=b.lane_env_error())))
+''' % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, MJB_JIT_CACHE=str(tmp_path / "jit"))
+    runs = []
+    for _ in range(2):
+        out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        runs.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    first, second = runs
+    if not first["used"]:
+        pytest.skip("hiprtc build not available on this box: " + first["err"])
+    assert first["compiled"] >= 1 and first["hits"] == 0, first
+    assert second["used"] and second["compiled"] == 0 and second["hits"] >= 1, second
+    assert second["qsum"] == first["qsum"]
+    files = list((tmp_path / "jit").glob("le_*.hsaco"))
+    assert len(files) == first["compiled"], files
+    assert second["seconds"] < first["seconds"], (first["seconds"], second["seconds"])
+    # MJB_JIT_CACHE=0: nothing is read or written
+    off = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, MJB_JIT_CACHE="0"), capture_output=True, text=True, timeout=300)
+    r = json.loads(off.stdout.strip().splitlines()[-1])
+    assert r["compiled"] >= 1 and r["hits"] == 0
