@@ -255,7 +255,7 @@ def kernel_form(batch):
     return kname, f"lane = env (one env per lane, {how}; sensordata evaluated at the last step of a launch)"
 
 
-def measure_other_config(name, device, launches=5, with_cpu=True, envs=None, substeps=None, lane_env=None, tag=None):
+def measure_other_config(name, device, launches=5, with_cpu=True, envs=None, substeps=None, lane_env=None, tag=None, sens_every=False, split=None):
     """One of the other BASELINE workloads (franka_table = configs[2], shadow_hand_grasp = configs[4]'s per-GPU shard, shadow_hand_like =
     its light predecessor), measured in this process after the headline timing so that the DRIVER's record carries it (VERDICT r02
     #3a): `launches` timed fused launches bracketed by synchronisation (five, like the standalone `--config N` run: config 3's first
@@ -270,6 +270,10 @@ def measure_other_config(name, device, launches=5, with_cpu=True, envs=None, sub
     batch = engine.Batch(cm, E, device)
     if lane_env is not None:
         batch.set_lane_env(lane_env)
+    if sens_every:
+        batch.set_sensors_every_step(True)
+    if split is not None:
+        batch.set_split_step(split)
     qpos, qvel = initial_state(name, model, E, seed=1000)
     batch.set("qpos", qpos)
     batch.set("qvel", qvel)
@@ -291,6 +295,12 @@ def measure_other_config(name, device, launches=5, with_cpu=True, envs=None, sub
     finite = bool(np.all(np.isfinite(batch.get("qpos"))))
     samples = sorted(batch.time_steps(S, 1) for _ in range(5))
     kname, kform = kernel_form(batch)
+    if sens_every and batch.lane_env_info()[1]:
+        kform = kform.replace("sensordata evaluated at the last step of a launch", "sensordata evaluated at EVERY step: mjb_set_sensors_every_step")
+    if batch.split_step_info()[1]:
+        kname = "mjb_cstep_kernel"
+        kform = (f"split step: smooth stages one env per lane (mjb_smooth_kernel) + constraint stages one env per wavefront (mjb_cstep_kernel), a kernel pair "
+                 f"per step on {batch.split_step_info()[2]} env slices; kernel_ms is the whole launch")
     out = {"metric": "env_steps_per_sec", "value": E * S * launches / elapsed, "unit": "env-steps/s", "n_gpus": 1,
            "steps": launches, "warmup": 1, "ms_per_step": 1e3 * elapsed / launches,
            "config": {"workload": f"{label}, {E} envs per GPU, fp64, Euler dt={model['timestep'][0]}", "baseline_config": cfgno,
@@ -319,6 +329,11 @@ def measure_other_config(name, device, launches=5, with_cpu=True, envs=None, sub
 # config 2 beside its headline line: the generic 16-lanes-per-env kernel on the same 4096 envs, and the lane = env kernel on a batch that
 # fills the chip with 64-env wavefronts (report both) -- (tag, envs, steps per launch, mjb_set_lane_env mode)
 CONFIG2_EXTRAS = (("2_generic_kernel", 4096, 1000, 0), ("2_lane_env_65536", 65536, 200, 1))
+# ... the headline kernel with the sensor stages evaluated at every step (A15's per-step cost on that kernel as a number), and config 3's
+# model on ONE GPU at 32 768 envs, fused kernel against the split step (round 6: smooth stages one env per lane, profiles/r06_split_step.txt)
+R06_EXTRAS = (("2_sensors_every_step", "franka_like", dict(envs=4096, substeps=1000, sens_every=True)),
+              ("3_32768_fused", "franka_table", dict(envs=32768, substeps=500, launches=3, split=0)),
+              ("3_32768_split", "franka_table", dict(envs=32768, substeps=500, launches=3, split=1)))
 
 
 def main():
@@ -649,6 +664,11 @@ def gpu_run(args, name):
             for xtag, xe, xs, xmode in CONFIG2_EXTRAS:
                 try:
                     out["other_configs"][xtag] = measure_other_config("franka_like", local_rank, with_cpu=False, envs=xe, substeps=xs, lane_env=xmode, tag=xtag)
+                except Exception as exc:
+                    out["other_configs"][xtag] = {"error": f"{type(exc).__name__}: {exc}"}
+            for xtag, xname, kw in R06_EXTRAS:
+                try:
+                    out["other_configs"][xtag] = measure_other_config(xname, local_rank, with_cpu=False, tag=xtag, **kw)
                 except Exception as exc:
                     out["other_configs"][xtag] = {"error": f"{type(exc).__name__}: {exc}"}
             for other in ("franka_table", "shadow_hand_grasp", "shadow_hand_like"):

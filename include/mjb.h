@@ -255,6 +255,10 @@ int mjb_fused_frame(const mjb_batch *b);
  * The environment variable MJB_LANE_ENV (same values) sets the default of new batches (read by mjb_make_batch).  While mjb_set_stats is
  * counting, fused launches run the generic kernels whatever the mode (the counters live in those).  No reference counterpart. */
 int mjb_set_lane_env(mjb_batch *b, int mode);
+/* The lane = env kernel evaluates the sensor stages (A15) at the LAST step of a fused launch: sensordata is an output of the launch and nothing inside
+ * it reads the values (the generic kernels evaluate them at every step into the LDS frame).  on = 1 makes it evaluate -- and store -- them at every
+ * step: same results after the launch, and the per-step cost of A15 on that kernel becomes measurable (bench.py: other_configs.2_sensors_every_step). */
+int mjb_set_sensors_every_step(mjb_batch *b, int on);
 /* The SPLIT step of plain-PGS models (csrc/mjb_smooth_kernel.h + mjb_cstep_kernel in csrc/mjb_step.hip): per step, the smooth stages of mj_step
  * (kinematics .. qacc_smooth) run one env per LANE and hand geom frames, cdof, both L'DL factors,
  * qfrc_smooth and qacc_smooth to the constraint stages (A4 - A7, A13, A16) through a per-env record in HBM; those run one env per wavefront.  The
@@ -262,9 +266,10 @@ int mjb_set_lane_env(mjb_batch *b, int mode);
  * to the fused kernel's to rounding.  Eligible: a model whose topology is compiled in (csrc/smooth_topos.h: free / ball / hinge / slide joints, one
  * per body), PGS with pyramidal or frictionless contacts, nv <= 16, Euler, no tendons / equalities / mocap bodies / activations, position- and
  * velocity-stage sensors of the lane = env list only, no per-env gravity / mass overrides, no hwsim stage, no xfrc_applied, no frame dump.
- * mode: -1 = automatic (whole-batch fused launches of >= MJB_SPLIT_MIN_ENVS envs, default 32 768: a launch pair per step ends with the slice's slowest
- * env, which only averages out over many envs per slice -- measured 33.2 M env-steps/s against 27.5 M fused at 32 768 envs of config 3, 18.7 M against 23.3 M
- * at 4096), 0 = never, 1 = whenever eligible.
+ * mode: 1 = whenever eligible, 0 = never, -1 (default) = only when the environment variable MJB_SPLIT_MIN_ENVS names a batch size (whole-batch
+ * fused launches of at least that many envs).  A launch pair per step ends with its slice's slowest env, which only averages out over many envs per
+ * slice: measured on config 3 (profiles/r06_split_step.txt) 33.2 M env-steps/s against the fused kernel's 27.5 M at 32 768 envs in the rollout's
+ * light-contact phase, 26.2 against 23.3 M over steps 1000 - 4000, 23.4 against 24.6 M over steps 500 - 2000, 18.7 against 23.3 M at 4096 envs.
  * sensordata is that of the launch's LAST step (as in the lane = env kernel).  No reference counterpart. */
 int mjb_set_split_step(mjb_batch *b, int mode);
 /* >= 0: index of the compiled-in topology of the split step the batch's model matches, -1: none.  *used_last (may be NULL) = 1 when the last fused

@@ -191,6 +191,7 @@ def load_library(path=None):
         "mjb_noise_mode": (ci, [vp]),
         "mjb_fused_frame": (ci, [vp]),
         "mjb_set_lane_env": (ci, [vp, ci]),
+        "mjb_set_sensors_every_step": (ci, [vp, ci]),
         "mjb_lane_env_info": (ci, [vp, C.POINTER(ci)]),
         "mjb_lane_env_error": (C.c_char_p, []),
         "mjb_lane_env_set_form": (ci, [ci]),

@@ -1553,6 +1553,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	s.handoff = nullptr;
 	s.handoff_stride = 0;
 	s.reset_step = nullptr;
+	s.sens_every_step = 0;
 	for (int k = 0; k < 64; k++) s.colfunc[k] = MJB_COLFUNC_DEFAULT;
 	s.sched = nullptr;
 	if (h.nefcmax > 0) {  // constrained kernels: work queue of the chunked fused launches
@@ -1836,8 +1837,11 @@ static int launch(mjb_batch *b, int mode, int nsteps, int env_lo = 0, int env_hi
 	bool use_split = false;
 	if (mode == MJB_MODE_STEP && compact && variant == 1 && b->model->sm_topo >= 0 && b->split_mode != 0 && b->hw.n == 0 && !b->env_mass && !b->env_gravity &&
 	    !b->env_equality && 8 * mjb_frame_bytes(b->model, 1) <= mjb_max_lds_bytes() && !stream_capturing(stream)) {
-		static const int min_envs = [] { const char *v = getenv("MJB_SPLIT_MIN_ENVS"); return v ? atoi(v) : 32768; }();
-		use_split = b->split_mode == 1 || (whole && b->nenv >= min_envs);
+		// (automatic mode: OFF unless MJB_SPLIT_MIN_ENVS names a batch size.  Measured on config 3 at 32 768 envs, profiles/r06_split_step.txt: +21 % in the
+		//  rollout's light-contact phase, +12 % over steps 1000 - 4000, -5 % over steps 500 - 2000 -- a launch pair per step ends with the slice's slowest env,
+		//  and the heavy phase has the long PGS tails.  Not a rule to apply behind the user's back.)
+		static const int min_envs = [] { const char *v = getenv("MJB_SPLIT_MIN_ENVS"); return v ? atoi(v) : 0; }();
+		use_split = b->split_mode == 1 || (min_envs > 0 && whole && b->nenv >= min_envs);
 		if (use_split) {
 			int src = split_prepare(b);
 			if (src) return src;
@@ -2654,6 +2658,15 @@ int mjb_set_lane_env(mjb_batch *b, int mode)
 {
 	if (!b || mode < -1 || mode > 1) return fail(MJB_EINVAL, "mjb_set_lane_env: bad argument");
 	b->lane_env_mode = mode;
+	return MJB_OK;
+}
+int mjb_set_sensors_every_step(mjb_batch *b, int on)
+{
+	if (!b) return fail(MJB_EINVAL, "null batch");
+	if ((b->st.sens_every_step != 0) != (on != 0)) {
+		b->st.sens_every_step = on ? 1 : 0;
+		b->params_dirty = true;
+	}
 	return MJB_OK;
 }
 int mjb_set_split_step(mjb_batch *b, int mode)

@@ -173,6 +173,7 @@ struct DevState {
 	double *handoff;               // [nenv][handoff_stride] hand-off records of the split step (HandoffLayout): written by the lane = env smooth kernel
 	                               // (mjb_smooth_kernel.h), read by mjb_cstep_kernel; NULL until the batch first steps that way
 	int handoff_stride;
+	int sens_every_step;           // lane = env kernel: evaluate the sensors at every step of a fused launch instead of its last one (mjb_set_sensors_every_step)
 	int colfunc[64];               // mjCOLLISIONFUNC-style table of MujocoEnv::registerCollisionFunction's overrides by (geom type 1, geom type 2), type1 <= type2,
 	                               // index 8 * type1 + type2: read instead of the pair record's copy when per-env geom TYPES are in play (a pair's current types)
 	const double *reset_step;      // [nq + nv + nv] qpos | qvel | qacc_warmstart one step after mj_resetData (mj_checkAcc's reset inside the split step), or NULL

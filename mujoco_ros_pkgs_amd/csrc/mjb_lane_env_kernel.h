@@ -361,8 +361,11 @@ DEVI void lane_env_body(const KernelParams MJB_AS4 *__restrict__ P, const int ns
 			bool ep_on = e_on;
 			if constexpr (EPOS != DP) ep_on = EPOS && last && (m.enableflags & MJB_ENBL_ENERGY);
 			const bool eg_on = ep_on && !(m.disableflags & MJB_DSBL_GRAVITY);
-			const bool sens_on = DV && last && !(m.disableflags & MJB_DSBL_SENSOR);  // (a tail lane rewrites the last env's values)
-			const bool sensf_on = SENSF && last && !(m.disableflags & MJB_DSBL_SENSOR);
+			// (sensordata is an output of the LAUNCH: evaluated at its last step -- or, mjb_set_sensors_every_step, at every step as the generic kernels do:
+			//  what A15 costs per step on this kernel is a bench line, other_configs.2_sensors_every_step)
+			const bool sens_step = last || s.sens_every_step != 0;
+			const bool sens_on = DV && sens_step && !(m.disableflags & MJB_DSBL_SENSOR);  // (a tail lane rewrites the last env's values)
+			const bool sensf_on = SENSF && sens_step && !(m.disableflags & MJB_DSBL_SENSOR);
 			double *sd = s.sensordata + ev * T::NSENSORDATA;
 			double pe = 0;
 

@@ -74,7 +74,7 @@ hipError_t sm_lds_attr(const void *fn, int bytes, int dev)
 // pyramidal cones, nv <= 16, the lean frame eight to a CU -- is the caller's test: mjb_api.hip, split_eligible.)
 int mjb_smooth_match(const mjb_model_desc *h)
 {
-	if (!h || h->integrator != MJB_INT_EULER || h->nmocap > 0 || h->ntendon > 0 || h->neq > 0 || h->na > 0 || (h->enableflags & MJB_ENBL_ENERGY)) return -1;
+	if (!h || h->integrator != MJB_INT_EULER || h->nmocap > 0 || h->ntendon > 0 || h->neq > 0 || h->na > 0) return -1;
 #define MJB_SM_X(id, T) \
 	if (sm_matches<T>(*h)) return id;
 	MJB_SM_TOPOS(MJB_SM_X)

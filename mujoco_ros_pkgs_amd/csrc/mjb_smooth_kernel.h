@@ -147,6 +147,10 @@ DEVI void smooth_lane_env_core(const KernelParams MJB_AS4 *__restrict__ P, const
 		for (int k = 0; k < 3; k++) grav[k] = g_on ? th->gravity[k] : 0.0;
 	}
 	const bool pas_on = !(m.disableflags & MJB_DSBL_PASSIVE);
+	// mjData.energy (mjENBL_ENERGY) of the launch's last step: mj_energyPos gathered along the sweep, mj_energyVel from qM (oracle/mjo_smooth.c mjo_energy)
+	const bool e_on = last && (m.enableflags & MJB_ENBL_ENERGY);
+	const bool eg_on = e_on && !(m.disableflags & MJB_DSBL_GRAVITY);
+	double pe = 0;
 	double f[NV > 0 ? NV : 1];  // qfrc_passive + qfrc_applied + qfrc_actuator, then (- qfrc_bias) qfrc_smooth
 	sfor<NV>([&](auto I) { f[I] = qfa[I] - (pas_on ? m.dof_damping[I] * qvel[I] : 0.0); });
 
@@ -314,6 +318,7 @@ DEVI void smooth_lane_env_core(const KernelParams MJB_AS4 *__restrict__ P, const
 				for (int k = 0; k < 3; k++) xipos[k] = v[k] + pos[k];
 			}
 			frame_sensors(B, xpos[b], xquat[b], xmat[b], xipos);
+			if (eg_on) pe -= t.mass * (grav[0] * xipos[0] + grav[1] * xipos[1] + grav[2] * xipos[2]);
 			if constexpr (Q::needed(b)) {
 				// cinert about the tree root's origin: world inertia X Ib X' (Ib = R(iquat) diag(inertia) R(iquat)' from the tape) + the offset's terms
 				double ci[10];
@@ -415,16 +420,22 @@ DEVI void smooth_lane_env_core(const KernelParams MJB_AS4 *__restrict__ P, const
 			// A8 mj_passive: the joint's spring (dampers were folded into f at the top)
 			if constexpr (jt == MJB_JNT_HINGE || jt == MJB_JNT_SLIDE) {
 				if (pas_on) f[da] -= t.stiffness * (qpos[qa] - t.spring);
+				if (e_on && pas_on) pe += 0.5 * t.stiffness * (qpos[qa] - t.spring) * (qpos[qa] - t.spring);
 			} else if constexpr (jt == MJB_JNT_FREE || jt == MJB_JNT_BALL) {
 				const double kst = m.jnt_stiffness[T::body_jnt[b]];
 				if (pas_on && kst != 0) {  // (wave-uniform)
 					constexpr int qq = qa + (jt == MJB_JNT_FREE ? 3 : 0), dd = da + (jt == MJB_JNT_FREE ? 3 : 0);
 					if constexpr (jt == MJB_JNT_FREE)
-						for (int c = 0; c < 3; c++) f[da + c] -= kst * (qpos[qa + c] - m.qpos_spring[qa + c]);
+						for (int c = 0; c < 3; c++) {
+							const double dq = qpos[qa + c] - m.qpos_spring[qa + c];
+							f[da + c] -= kst * dq;
+							if (e_on) pe += 0.5 * kst * dq * dq;
+						}
 					double qs[4], dif[3];
 					ldc4(qs, m.qpos_spring + qq);
 					quat_sub(dif, qpos + qq, qs);
 					for (int c = 0; c < 3; c++) f[dd + c] -= kst * dif[c];
+					if (e_on) pe += 0.5 * kst * (dif[0] * dif[0] + dif[1] * dif[1] + dif[2] * dif[2]);
 				}
 			}
 			__builtin_amdgcn_sched_barrier(0);
@@ -543,6 +554,17 @@ DEVI void smooth_lane_env_core(const KernelParams MJB_AS4 *__restrict__ P, const
 		__builtin_amdgcn_sched_barrier(0);
 	});
 
+	if (e_on) {  // mj_energyVel: 0.5 qvel' M qvel
+		double ke = 0;
+		sfor<NV>([&](auto I) {
+			sfor<NV>([&](auto A) {
+				constexpr int i = I, a = A;
+				if constexpr (Q::anc(a, i)) ke += (a == i ? 0.5 : 1.0) * qM[i][a] * qvel[i] * qvel[a];
+			});
+		});
+		s.energy[2 * ev] = pe;
+		s.energy[2 * ev + 1] = ke;
+	}
 	// ================= A3 mj_factorM (M and M + h B side by side), A12 mj_fwdAcceleration =================
 	const double dt = th->dt;
 	double qH[NV > 0 ? NV : 1][NV > 0 ? NV : 1], dinv[NV > 0 ? NV : 1], hinv[NV > 0 ? NV : 1];

@@ -291,6 +291,10 @@ class Batch:
         topo = int(self.lib.mjb_lane_env_info(self.ptr, C.byref(used)))
         return topo, bool(used.value)
 
+    def set_sensors_every_step(self, on=True):
+        """The lane = env kernel evaluates the sensor stages at every step of a fused launch instead of its last one (mjb_set_sensors_every_step)."""
+        _check(self.lib.mjb_set_sensors_every_step(self.ptr, 1 if on else 0), "mjb_set_sensors_every_step")
+
     def set_split_step(self, mode):
         """-1 automatic, 0 never, 1 whenever eligible: the split step of plain-PGS models -- smooth stages one env per lane, constraint stages one env
         per wavefront (mjb_set_split_step)."""

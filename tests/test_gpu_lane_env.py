@@ -450,3 +450,23 @@ print(json.dumps(dict(used=b.lane_env_info()[1], compiled=comp.value, hits=hits.
     off = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, MJB_JIT_CACHE="0"), capture_output=True, text=True, timeout=300)
     r = json.loads(off.stdout.strip().splitlines()[-1])
     assert r["compiled"] >= 1 and r["hits"] == 0
+
+
+def test_sensors_every_step_is_the_same_launch(eng):
+    """mjb_set_sensors_every_step: the lane = env kernel evaluates A15 at every step instead of the launch's last -- nothing observable changes."""
+    engine, mjcf, po = eng
+    model = mjcf.load_asset("franka_like")
+    cm = engine.CompiledModel(model)
+    nenv = 192
+    qpos, qvel = random_franka_state(model, nenv, 21)
+    out = []
+    for every in (False, True):
+        b = make(engine, cm, nenv, qpos, qvel, 1)
+        b.set_sensors_every_step(every)
+        b.set_ctrl_noise(3.0, 0.1, 5, 0)
+        b.step(40)
+        assert b.lane_env_info()[1]
+        out.append((b.get("qpos"), b.get("sensordata")))
+        b.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.abs(out[0][1] - out[1][1]).max() <= 1e-13

@@ -29,7 +29,7 @@ def test_split_step_matches_fused_kernel_and_oracle(eng, name, noise, K):
     assert warn == (0, 0)
     # the two forms run the same arithmetic up to the order of a few sums (spatial quantities about the root body's origin instead of the subtree com)
     assert d["qpos"] <= 1e-12 and d["qvel"] <= 1e-11 and d["sensordata"] <= 1e-11 and d["time"] == 0 and d["ctrl"] == 0, d
-    assert d["qacc"] <= 1e-9, d
+    assert d["qacc"] <= 1e-9 and d["energy"] <= 1e-11, d
     assert wo["qpos"] <= 1e-11 and wo["qvel"] <= 1e-10 and wo["sensordata"] <= 1e-10, wo
 
 

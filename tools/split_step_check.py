@@ -32,7 +32,8 @@ def states(name, model, n, seed=1000):
 def run(name="franka_table", n=256, K=20, noise=None, verbose=True):
     from oracle import pyoracle
     pyoracle.build()
-    model = mjcf.load_asset(name)
+    model = mjcf.Model(dict(mjcf.load_asset(name)))
+    model["enableflags"] = int(model["enableflags"]) | 2  # mjENBL_ENERGY: mjData.energy of the last step
     cm = engine.CompiledModel(model)
     if noise is None:
         noise = 2.0 if name == "franka_table" else 0.3
@@ -44,12 +45,12 @@ def run(name="franka_table", n=256, K=20, noise=None, verbose=True):
         b.set("qpos", qpos); b.set("qvel", qvel)
         b.set_ctrl_noise(noise, 0.1, 12345, 0)
         b.step(K)
-        out[mode] = {k: b.get(k) for k in ("qpos", "qvel", "qacc", "qacc_warmstart", "sensordata", "time", "ctrl")}
+        out[mode] = {k: b.get(k) for k in ("qpos", "qvel", "qacc", "qacc_warmstart", "sensordata", "time", "ctrl", "energy")}
         out[mode]["info"] = b.split_step_info()
         out[mode]["warn"] = b.warning_count()
         b.close()
     assert out[1]["info"][1], "the split step did not run: %r" % (out[1]["info"],)
-    d = {k: float(np.abs(out[0][k] - out[1][k]).max()) for k in ("qpos", "qvel", "qacc", "qacc_warmstart", "sensordata", "time", "ctrl")}
+    d = {k: float(np.abs(out[0][k] - out[1][k]).max()) for k in ("qpos", "qvel", "qacc", "qacc_warmstart", "sensordata", "time", "ctrl", "energy")}
     wo = {"qpos": 0.0, "qvel": 0.0, "sensordata": 0.0}
     for e in (0, n // 3, n - 1):
         oq, ov, osd = pyoracle.rollout(model, qpos[e:e + 1], qvel[e:e + 1], K, noise_std=noise, noise_rate=0.1, seed=12345, env_offset=int(e))
