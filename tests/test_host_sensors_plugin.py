@@ -139,3 +139,52 @@ def test_records_per_env(host, factory):
     assert r0["vel_joint2"]["env"] == 0 and r2["vel_joint2"]["env"] == 2
     assert abs(r2["vel_joint2"]["truth"][0] - r0["vel_joint2"]["truth"][0]) > 0.1
     env.shutdown()
+
+
+def test_round6_sensor_types_are_routed_like_the_reference(host, factory):
+    """initSensors (mujoco_sensor_handler_plugin.cpp:490-501, :575-590): subtreelinvel / subtreeangmom are Vector3Stamped in the world frame like subtreecom;
+    jointactuatorfrc and the joint / tendon limit sensors are ScalarStamped."""
+    xml = '''
+<mujoco model="r06_sensor_routing">
+  <compiler angle="radian"/>
+  <option timestep="0.002"/>
+  <size nconmax="4" njmax="16"/>
+  <worldbody>
+    <body name="arm" pos="0 0 0.5">
+      <joint name="j1" type="hinge" axis="0 1 0" limited="true" range="-0.2 0.2" damping="0.1"/>
+      <geom type="capsule" fromto="0 0 0 0.3 0 0" size="0.02" mass="0.5"/>
+      <body name="tip" pos="0.3 0 0">
+        <joint name="j2" type="hinge" axis="0 0 1" damping="0.1"/>
+        <geom type="sphere" size="0.03" mass="0.1"/>
+      </body>
+    </body>
+  </worldbody>
+  <tendon><fixed name="t1" limited="true" range="-0.1 0.1"><joint joint="j1" coef="1"/><joint joint="j2" coef="0.5"/></fixed></tendon>
+  <actuator><motor name="m1" joint="j1"/></actuator>
+  <sensor>
+    <jointlimitpos name="lim_pos" joint="j1"/>
+    <jointlimitvel name="lim_vel" joint="j1"/>
+    <jointlimitfrc name="lim_frc" joint="j1"/>
+    <tendonlimitpos name="tlim_pos" tendon="t1"/>
+    <tendonlimitfrc name="tlim_frc" tendon="t1"/>
+    <jointactuatorfrc name="act_frc" joint="j1"/>
+    <subtreelinvel name="sub_vel" body="arm"/>
+    <subtreeangmom name="sub_mom" body="tip"/>
+  </sensor>
+</mujoco>'''
+    m = mjcf.compile_xml_string(xml)
+    env = start(host, factory, m, {"unpause": False, "MujocoPlugins": SENSORS})
+    q = np.array(m["qpos0"], dtype=np.float64)
+    q[0] = 0.25  # beyond j1's upper limit: the limit sensors report
+    env.set_field("qpos", q)
+    env.set_field("qvel", np.array([0.3, -0.4]))
+    assert env.step(1)
+    rec = env.sensor_records()
+    assert set(rec) == set(m["names"]["sensor"])
+    for n in ("lim_pos", "lim_vel", "lim_frc", "tlim_pos", "tlim_frc", "act_frc"):
+        assert rec[n]["kind"] == "scalar", n
+    for n in ("sub_vel", "sub_mom"):
+        assert rec[n]["kind"] == "vector3" and rec[n]["frame_id"] == "world", n
+    assert rec["lim_pos"]["truth"][0] < 0 and rec["lim_frc"]["truth"][0] > 0 and rec["tlim_pos"]["truth"][0] < 0
+    assert np.abs(np.array(rec["sub_vel"]["truth"])).max() > 0
+    env.shutdown()
