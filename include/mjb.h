@@ -60,7 +60,7 @@ enum { /* mjtObj */
 };
 enum { /* mjtSensor (subset implemented; values are MuJoCo's) */
 	MJB_SENS_TOUCH = 0, MJB_SENS_ACCELEROMETER = 1, MJB_SENS_VELOCIMETER = 2, MJB_SENS_GYRO = 3, MJB_SENS_FORCE = 4,
-	MJB_SENS_TORQUE = 5, MJB_SENS_TENDONPOS = 10, MJB_SENS_TENDONVEL = 11,
+	MJB_SENS_TORQUE = 5, MJB_SENS_MAGNETOMETER = 6, MJB_SENS_RANGEFINDER = 7, MJB_SENS_TENDONPOS = 10, MJB_SENS_TENDONVEL = 11,
 	MJB_SENS_JOINTPOS = 8, MJB_SENS_JOINTVEL = 9, MJB_SENS_ACTUATORPOS = 12, MJB_SENS_ACTUATORVEL = 13,
 	MJB_SENS_ACTUATORFRC = 14, MJB_SENS_BALLQUAT = 15, MJB_SENS_BALLANGVEL = 16, MJB_SENS_FRAMEPOS = 23,
 	MJB_SENS_FRAMEQUAT = 24, MJB_SENS_FRAMEXAXIS = 25, MJB_SENS_FRAMEYAXIS = 26, MJB_SENS_FRAMEZAXIS = 27,

@@ -733,7 +733,7 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 #undef MJB_ARR_I
 #undef MJB_ARR_D
 	for (int i = 0; i < d.nsensor; i++) {
-		static const int ok[] = { MJB_SENS_TOUCH, MJB_SENS_ACCELEROMETER, MJB_SENS_VELOCIMETER, MJB_SENS_GYRO, MJB_SENS_FORCE,
+		static const int ok[] = { MJB_SENS_MAGNETOMETER, MJB_SENS_RANGEFINDER, MJB_SENS_TOUCH, MJB_SENS_ACCELEROMETER, MJB_SENS_VELOCIMETER, MJB_SENS_GYRO, MJB_SENS_FORCE,
 			                      MJB_SENS_TORQUE, MJB_SENS_JOINTPOS, MJB_SENS_JOINTVEL, MJB_SENS_TENDONPOS, MJB_SENS_TENDONVEL,
 			                      MJB_SENS_ACTUATORPOS, MJB_SENS_ACTUATORVEL, MJB_SENS_ACTUATORFRC, MJB_SENS_BALLQUAT,
 			                      MJB_SENS_BALLANGVEL, MJB_SENS_FRAMEPOS, MJB_SENS_FRAMEQUAT, MJB_SENS_FRAMEXAXIS,

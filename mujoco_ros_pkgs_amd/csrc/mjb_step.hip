@@ -2141,7 +2141,58 @@ DEVI bool ray_hits_site(CModel m, CLayout L, const double *f, int site, const do
 	return true;
 }
 
-template <int G, bool CACHE = false> STAGE void sensors(CModel m, CLayout L, const Env &e, int stage, int compact)
+// mju_rayGeom for the engine's primitives (engine_ray.c; oracle/mjo_smooth.c ray_geom): distance along pnt + x vec, -1 for no hit
+DEVI double ray_quad(double a, double b, double c, double &x0, double &x1)
+{
+	double det = b * b - a * c;
+	if (det < MJB_MINVAL) { x0 = x1 = -1; return -1; }
+	det = sqrt(det);
+	x0 = (-b - det) / a;
+	x1 = (-b + det) / a;
+	return x0 >= 0 ? x0 : (x1 >= 0 ? x1 : -1.0);
+}
+DEVI double ray_geom(const double *pos, const double *mat, const double *size, const double *pnt, const double *vec, int type)
+{
+	const double dif[3] = { pnt[0] - pos[0], pnt[1] - pos[1], pnt[2] - pos[2] };
+	double lp[3], lv[3], x0, x1;
+	matTvec3(lp, mat, dif);
+	matTvec3(lv, mat, vec);
+	if (type == MJB_GEOM_PLANE) {
+		if (lv[2] > -MJB_MINVAL) return -1;
+		const double x = -lp[2] / lv[2];
+		if (x < 0) return -1;
+		const double p0 = lp[0] + x * lv[0], p1 = lp[1] + x * lv[1];
+		return ((size[0] <= 0 || fabs(p0) <= size[0]) && (size[1] <= 0 || fabs(p1) <= size[1])) ? x : -1.0;
+	}
+	if (type == MJB_GEOM_SPHERE) return ray_quad(dot3(lv, lv), dot3(lv, lp), dot3(lp, lp) - size[0] * size[0], x0, x1);
+	if (type == MJB_GEOM_CAPSULE) {
+		double x = -1;
+		const double sol = ray_quad(lv[0] * lv[0] + lv[1] * lv[1], lv[0] * lp[0] + lv[1] * lp[1], lp[0] * lp[0] + lp[1] * lp[1] - size[0] * size[0], x0, x1);
+		if (sol >= 0 && fabs(lp[2] + sol * lv[2]) <= size[1]) x = sol;
+		for (int side = 1; side >= -1; side -= 2) {
+			const double ld[3] = { lp[0], lp[1], lp[2] - side * size[1] };
+			ray_quad(dot3(lv, lv), dot3(lv, ld), dot3(ld, ld) - size[0] * size[0], x0, x1);
+			if (x0 >= 0 && side * (lp[2] + x0 * lv[2]) >= size[1] && (x < 0 || x0 < x)) x = x0;
+			if (x1 >= 0 && side * (lp[2] + x1 * lv[2]) >= size[1] && (x < 0 || x1 < x)) x = x1;
+		}
+		return x;
+	}
+	if (type == MJB_GEOM_BOX) {
+		double x = -1;
+		for (int i = 0; i < 3; i++) {
+			if (fabs(lv[i]) <= MJB_MINVAL) continue;
+			const int j = (i + 1) % 3, k = (i + 2) % 3;
+			for (int side = -1; side <= 1; side += 2) {
+				const double sol = (side * size[i] - lp[i]) / lv[i];
+				if (sol >= 0 && fabs(lp[j] + sol * lv[j]) <= size[j] && fabs(lp[k] + sol * lv[k]) <= size[k] && (x < 0 || sol < x)) x = sol;
+			}
+		}
+		return x;
+	}
+	return -1;
+}
+
+template <int G, bool CACHE = false> STAGE void sensors(CModel m, CLayout L, CState st, const Env &e, int stage, int compact)
 {
 	if (m.disableflags & MJB_DSBL_SENSOR) return;
 	const int ncopy = m.sens_ncopy[stage - 1], nslow = m.sens_nslow[stage - 1];
@@ -2323,6 +2374,32 @@ template <int G, bool CACHE = false> STAGE void sensors(CModel m, CLayout L, con
 			break;
 		}
 		case MJB_SENS_JOINTACTFRC: out[0] = f[L.qfrc_actuator + m.jnt_dofadr[id]]; break;
+		case MJB_SENS_MAGNETOMETER: {  // the global magnetic flux in the site's frame
+			double SM[9];
+			const double mg[3] = { m.magnetic[0], m.magnetic[1], m.magnetic[2] };
+			ld9(SM, f + L.site_xmat + 9 * id);
+			matTvec3(out, SM, mg);
+			break;
+		}
+		case MJB_SENS_RANGEFINDER: {  // mj_ray along the site's z axis: every visible geom but those of the site's body; -1: nothing hit
+			double SM[9], sp[3], dist = -1;
+			ld9(SM, f + L.site_xmat + 9 * id);
+			ld3(sp, f + L.site_xpos + 3 * id);
+			const double rv[3] = { SM[2], SM[5], SM[8] };
+			const int skip = m.site_bodyid[id];
+			for (int g = 0; g < m.ngeom; g++) {
+				if (m.geom_bodyid[g] == skip || m.geom_rgba[4 * g + 3] == 0) continue;
+				double gp[3], gm[9], gs[3];
+				ld3(gp, f + L.geom_xpos + 3 * g);
+				ld9(gm, f + L.geom_xmat + 9 * g);
+				for (int k = 0; k < 3; k++) gs[k] = st.env_geom_size ? st.env_geom_size[((size_t)e.env * m.ngeom + g) * 3 + k] : m.geom_size[3 * g + k];
+				const int gt = st.env_geom_type ? st.env_geom_type[(size_t)e.env * m.ngeom + g] : m.geom_type[g];
+				const double x = ray_geom(gp, gm, gs, sp, rv, gt);
+				if (x >= 0 && (x < dist || dist < 0)) dist = x;
+			}
+			out[0] = dist;
+			break;
+		}
 		// ---- mj_subtreeVel's results in closed form: v_c = sum m_b v_b / M over the subtree, L = sum [ I_b w_b + m_b (x_b - c) x (v_b - v_c) ] about the subtree's
 		// com c; a body's com velocity from cvel (taken at the root's subtree com o): v_b = v + w x (x_b - o); I_b w from cinert (about o): I_o w - m d x (w x d), d = x_b - o
 		case MJB_SENS_SUBTREELINVEL: case MJB_SENS_SUBTREEANGMOM: {
@@ -2377,7 +2454,7 @@ template <int G, bool CACHE = false> STAGE void sensors(CModel m, CLayout L, con
 			if (k >= dim) break;
 			double v = out[k];
 			if (cutoff > 0 && real) {
-				if (type == MJB_SENS_TOUCH) v = v > cutoff ? cutoff : v;
+				if (type == MJB_SENS_TOUCH || type == MJB_SENS_RANGEFINDER) v = v > cutoff ? cutoff : v;  // (mjDATATYPE_POSITIVE)
 				else v = v < -cutoff ? -cutoff : (v > cutoff ? cutoff : v);
 			}
 			dst[k] = v;
@@ -2836,7 +2913,7 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 		}
 		PROF_BEGIN();
 		VIEW(P, compact, transmission<G, (DENSE != 0)>(m, L, e));
-		VIEW(P, compact, sensors<G, (DENSE != 0)>(m, L, e, MJB_STAGE_POS, compact));
+		VIEW(P, compact, sensors<G, (DENSE != 0)>(m, L, s, e, MJB_STAGE_POS, compact));
 		PROF(4);
 		VIEW(P, compact, com_vel<G, (DENSE != 0)>(m, L, e));
 		PROF(5);
@@ -2844,7 +2921,7 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 		PROF(6);
 		VIEW(P, compact, rne<G, (DENSE != 0)>(m, L, e));
 		PROF(7);
-		VIEW(P, compact, sensors<G, (DENSE != 0)>(m, L, e, MJB_STAGE_VEL, compact));
+		VIEW(P, compact, sensors<G, (DENSE != 0)>(m, L, s, e, MJB_STAGE_VEL, compact));
 		PROF(8);
 	}
 }
@@ -2939,7 +3016,7 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 		}
 	}
 	VIEW(P, compact, if (m.need_rnepost) rne_post<G>(m, L, lite(e), s.use_xfrc != 0));
-	VIEW(P, compact, sensors<G, (DENSE != 0)>(m, L, e, MJB_STAGE_ACC, compact));
+	VIEW(P, compact, sensors<G, (DENSE != 0)>(m, L, s, e, MJB_STAGE_ACC, compact));
 	PROF(12);
 }
 

@@ -88,12 +88,12 @@ void MujocoRosSensorsPlugin::initSensors(const mjModel *model)
 		frame_id = nameOf(model->body_names, parent_id);
 		switch (type) {
 		case MJB_SENS_ACCELEROMETER: case MJB_SENS_VELOCIMETER: case MJB_SENS_GYRO: case MJB_SENS_FORCE: case MJB_SENS_TORQUE:
-		case MJB_SENS_BALLANGVEL:
+		case MJB_SENS_MAGNETOMETER: case MJB_SENS_BALLANGVEL:
 			cfg.kind = VECTOR3_STAMPED;
 			cfg.frame_id = frame_id;
 			sensor_map_[sensor_name] = cfg;
 			break;
-		case MJB_SENS_TOUCH: case MJB_SENS_JOINTPOS: case MJB_SENS_JOINTVEL: case MJB_SENS_TENDONPOS: case MJB_SENS_TENDONVEL:
+		case MJB_SENS_TOUCH: case MJB_SENS_RANGEFINDER: case MJB_SENS_JOINTPOS: case MJB_SENS_JOINTVEL: case MJB_SENS_TENDONPOS: case MJB_SENS_TENDONVEL:
 		case MJB_SENS_ACTUATORPOS: case MJB_SENS_ACTUATORVEL: case MJB_SENS_ACTUATORFRC: case MJB_SENS_JOINTACTFRC: case MJB_SENS_JOINTLIMITPOS:
 		case MJB_SENS_JOINTLIMITVEL: case MJB_SENS_JOINTLIMITFRC: case MJB_SENS_TENDONLIMITPOS: case MJB_SENS_TENDONLIMITVEL: case MJB_SENS_TENDONLIMITFRC:  // (:575-590)
 			cfg.kind = SCALAR_STAMPED;

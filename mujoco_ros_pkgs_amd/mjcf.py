@@ -35,6 +35,8 @@ SENSORS = {  # name -> (mjtSensor, dim, needstage, default objtype)
     "gyro": (3, 3, 2, "site"),
     "force": (4, 3, 3, "site"),
     "torque": (5, 3, 3, "site"),
+    "magnetometer": (6, 3, 1, "site"),
+    "rangefinder": (7, 1, 1, "site"),
     "tendonpos": (10, 1, 1, "tendon"),
     "tendonvel": (11, 1, 2, "tendon"),
     "jointpos": (8, 1, 1, "joint"),
@@ -225,7 +227,8 @@ class _Compiler:
         self.actuators = []
         self.sensors = []
         self.excludes = []
-        self.opt = dict(timestep=0.002, gravity=np.array([0, 0, -9.81]), tolerance=1e-8, impratio=1.0,
+        self.materials = {}   # <asset><material name rgba>: only the colour's alpha matters here (mj_ray skips invisible geoms)
+        self.opt = dict(magnetic=np.array([0.0, -0.5, 0.0]), timestep=0.002, gravity=np.array([0, 0, -9.81]), tolerance=1e-8, impratio=1.0,
                         integrator=0, cone=0, solver=2, iterations=100, disableflags=0, enableflags=0)
 
     # ---- attribute helpers
@@ -284,6 +287,11 @@ class _Compiler:
                     self.nconmax_req = int(node.get("nconmax"))
                 if self.nefcmax_req is None and int(node.get("njmax", "-1")) >= 0:
                     self.nefcmax_req = int(node.get("njmax"))
+                continue
+            if t == "asset":
+                for mat in node:
+                    if mat.tag == "material" and mat.get("name"):
+                        self.materials[mat.get("name")] = _floats(mat.get("rgba", "1 1 1 1"), 4, "material rgba")
                 continue
             if t in ("compiler", "default") or t in IGNORED_TOP:
                 continue
@@ -350,6 +358,8 @@ class _Compiler:
                 o[k] = float(a[k])
         if "gravity" in a:
             o["gravity"] = _floats(a["gravity"], 3, "option gravity")
+        if "magnetic" in a:
+            o["magnetic"] = _floats(a["magnetic"], 3, "option magnetic")
         if "iterations" in a:
             o["iterations"] = int(a["iterations"])
         if "integrator" in a:
@@ -502,6 +512,11 @@ class _Compiler:
                  solref=_floats(a.get("solref", "0.02 1"), 2, "geom solref"), solimp=_solimp(a.get("solimp")),
                  margin=float(a.get("margin", 0)), gap=float(a.get("gap", 0)),
                  density=float(a.get("density", 1000)), mass=(float(a["mass"]) if "mass" in a else None))
+        # effective colour: the geom's own rgba when it differs from the default, else its material's (mjCGeom: a material overrides the default rgba)
+        rgba = _floats(a.get("rgba", "0.5 0.5 0.5 1"), 4, "geom rgba")
+        if "rgba" not in a and a.get("material") in self.materials:
+            rgba = self.materials[a.get("material")]
+        g["rgba"] = rgba
         if g["condim"] not in (1, 3, 4, 6):
             raise MjcfError("condim must be 1, 3, 4 or 6")
         self.geoms.append(g)
@@ -776,6 +791,7 @@ class _Compiler:
         m["geom_solref"] = np.array([g["solref"] for g in Gm], D).reshape(ngeom, 2)
         m["geom_solimp"] = np.array([g["solimp"] for g in Gm], D).reshape(ngeom, 5)
         m["geom_margin"] = np.array([g["margin"] for g in Gm], D)
+        m["geom_rgba"] = np.array([g["rgba"] for g in Gm], D).reshape(ngeom, 4)
         m["geom_gap"] = np.array([g["gap"] for g in Gm], D)
         rb = np.zeros(ngeom, D)
         for gi, g in enumerate(Gm):
@@ -877,7 +893,7 @@ class _Compiler:
 
         # options
         o = self.opt
-        m.update(timestep=np.array([o["timestep"]], D), gravity=np.asarray(o["gravity"], D),
+        m.update(magnetic=np.asarray(o["magnetic"], D), timestep=np.array([o["timestep"]], D), gravity=np.asarray(o["gravity"], D),
                  tolerance=np.array([o["tolerance"]], D), impratio=np.array([o["impratio"]], D),
                  integrator=o["integrator"], cone=o["cone"], solver=o["solver"], iterations=o["iterations"],
                  disableflags=o["disableflags"], enableflags=o["enableflags"])

@@ -706,6 +706,77 @@ static int ray_hits_site(const mjb_model_desc *m, const mjo_data *d, int site, c
 	return 1;
 }
 
+/* ---- mj_ray / mju_rayGeom (engine_ray.c) for the primitives of the engine: distance along the unit-less ray pnt + x vec to the nearest geom, -1 for none.
+ * ray_quad: the smaller non-negative root of a x^2 + 2 b x + c = 0 (both roots in xx). */
+static double ray_quad(double a, double b, double c, double *xx)
+{
+	double det = b * b - a * c;
+	if (det < MJO_MINVAL) { xx[0] = xx[1] = -1; return -1; }
+	det = sqrt(det);
+	xx[0] = (-b - det) / a;
+	xx[1] = (-b + det) / a;
+	return xx[0] >= 0 ? xx[0] : (xx[1] >= 0 ? xx[1] : -1);
+}
+
+static double ray_geom(const double *pos, const double *mat, const double *size, const double *pnt, const double *vec, int type)
+{
+	double dif[3], lp[3], lv[3], xx[2];
+	v3_sub(dif, pnt, pos);
+	m3_mulvecT(lp, mat, dif);
+	m3_mulvecT(lv, mat, vec);
+	switch (type) {
+	case MJB_GEOM_PLANE: {
+		if (lv[2] > -MJO_MINVAL) return -1; /* only from the front, never parallel */
+		double x = -lp[2] / lv[2];
+		if (x < 0) return -1;
+		double p0 = lp[0] + x * lv[0], p1 = lp[1] + x * lv[1];
+		if ((size[0] <= 0 || fabs(p0) <= size[0]) && (size[1] <= 0 || fabs(p1) <= size[1])) return x;
+		return -1;
+	}
+	case MJB_GEOM_SPHERE: return ray_quad(v3_dot(lv, lv), v3_dot(lv, lp), v3_dot(lp, lp) - size[0] * size[0], xx);
+	case MJB_GEOM_CAPSULE: {
+		double x = -1;
+		double sol = ray_quad(lv[0] * lv[0] + lv[1] * lv[1], lv[0] * lp[0] + lv[1] * lp[1], lp[0] * lp[0] + lp[1] * lp[1] - size[0] * size[0], xx);
+		if (sol >= 0 && fabs(lp[2] + sol * lv[2]) <= size[1]) x = sol;
+		for (int side = 1; side >= -1; side -= 2) { /* top cap, then bottom cap: the half of the sphere beyond the flat side */
+			double ld[3] = { lp[0], lp[1], lp[2] - side * size[1] };
+			ray_quad(v3_dot(lv, lv), v3_dot(lv, ld), v3_dot(ld, ld) - size[0] * size[0], xx);
+			for (int i = 0; i < 2; i++)
+				if (xx[i] >= 0 && side * (lp[2] + xx[i] * lv[2]) >= size[1] && (x < 0 || xx[i] < x)) x = xx[i];
+		}
+		return x;
+	}
+	case MJB_GEOM_BOX: {
+		double x = -1;
+		for (int i = 0; i < 3; i++) {
+			if (fabs(lv[i]) <= MJO_MINVAL) continue;
+			for (int side = -1; side <= 1; side += 2) {
+				double sol = (side * size[i] - lp[i]) / lv[i];
+				if (sol < 0) continue;
+				int j = (i + 1) % 3, k = (i + 2) % 3;
+				if (fabs(lp[j] + sol * lv[j]) <= size[j] && fabs(lp[k] + sol * lv[k]) <= size[k] && (x < 0 || sol < x)) x = sol;
+			}
+		}
+		return x;
+	}
+	default: return -1;
+	}
+}
+
+/* mj_ray(m, d, pnt, vec, geomgroup = NULL, flg_static = 1, bodyexclude, NULL): geoms of bodyexclude and invisible geoms (alpha 0) are skipped */
+static double ray_all(const mjb_model_desc *m, const mjo_data *d, const double *pnt, const double *vec, int bodyexclude)
+{
+	double dist = -1;
+	const double *gsz = d->env_geom_size ? d->env_geom_size : m->geom_size;
+	for (int g = 0; g < m->ngeom; g++) {
+		if (m->geom_bodyid[g] == bodyexclude || m->geom_rgba[4 * g + 3] == 0) continue;
+		int type = d->env_geom_type ? d->env_geom_type[g] : m->geom_type[g];
+		double x = ray_geom(d->geom_xpos + 3 * g, d->geom_xmat + 9 * g, gsz + 3 * g, pnt, vec, type);
+		if (x >= 0 && (x < dist || dist < 0)) dist = x;
+	}
+	return dist;
+}
+
 /* mj_subtreeVel (engine_core_smooth.c): linear velocity and angular momentum of every subtree -- body momenta from cvel (taken at the root's
  * subtree com), linear momenta summed leaf to root and divided by the subtree mass, then the angular momenta about each subtree's own com, leaf to
  * root, with the two transport terms (body com -> subtree com, child subtree -> parent subtree).  Returns subtree `id`'s pair. */
@@ -884,6 +955,13 @@ void mjo_sensor(const mjb_model_desc *m, mjo_data *d, int stage)
 			break;
 		}
 		case MJB_SENS_JOINTACTFRC: out[0] = d->qfrc_actuator[m->jnt_dofadr[id]]; break;
+		case MJB_SENS_MAGNETOMETER: m3_mulvecT(out, d->site_xmat + 9 * id, m->magnetic); break; /* the global flux in the site's frame */
+		case MJB_SENS_RANGEFINDER: { /* along the site's z axis, the site's own body excluded; -1: nothing hit */
+			const double *mt = d->site_xmat + 9 * id;
+			double rv[3] = { mt[2], mt[5], mt[8] };
+			out[0] = ray_all(m, d, d->site_xpos + 3 * id, rv, m->site_bodyid[id]);
+			break;
+		}
 		case MJB_SENS_SUBTREELINVEL: case MJB_SENS_SUBTREEANGMOM: {
 			double lin[3], ang[3];
 			mjo_subtree_vel(m, d, id, lin, ang);
@@ -895,7 +973,7 @@ void mjo_sensor(const mjb_model_desc *m, mjo_data *d, int stage)
 		double cutoff = m->sensor_cutoff[i];
 		if (cutoff > 0 && is_real)
 			for (int k = 0; k < m->sensor_dim[i]; k++) {
-				if (type == MJB_SENS_TOUCH) out[k] = out[k] > cutoff ? cutoff : out[k];
+				if (type == MJB_SENS_TOUCH || type == MJB_SENS_RANGEFINDER) out[k] = out[k] > cutoff ? cutoff : out[k]; /* mjDATATYPE_POSITIVE */
 				else out[k] = out[k] < -cutoff ? -cutoff : (out[k] > cutoff ? cutoff : out[k]);
 			}
 	}

@@ -21,10 +21,13 @@ XML = """
       <body name="fore" pos="0.3 0 0" quat="0.9689124 0 0 0.2474040">
         <joint name="j2" type="hinge" axis="0 0 1" limited="{limited}" range="-1.0 0.3"/>
         <geom type="capsule" fromto="0 0 0 0.25 0 0" size="0.025" mass="0.6"/>
+        <site name="s_fore" pos="0.1 0 -0.03" quat="0 1 0 0"/>
+        <site name="s_box" pos="0.1 -0.2 0" quat="0.7071068 -0.7071068 0 0"/>
         <body name="tipa" pos="0.25 0 0">
           <joint name="j3" type="slide" axis="1 0 0" limited="{limited}" range="-0.04 0.04"/>
           <inertial pos="0.02 0.01 0" quat="0.9238795 0 0.3826834 0" mass="0.2" diaginertia="0.0004 0.0003 0.0002"/>
           <geom type="sphere" size="0.03" contype="0" conaffinity="0"/>
+          <site name="s_tip" pos="0.03 0 0" quat="0.7071068 0 0.7071068 0"/>
         </body>
         <body name="tipb" pos="0.1 0.05 0">
           <joint name="j4" type="hinge" axis="1 0 0" pos="0 0.01 0"/>
@@ -32,6 +35,8 @@ XML = """
         </body>
       </body>
     </body>
+    <site name="s_up" pos="-1 -1 0.2" quat="1 0 0 0"/>
+    <geom name="ghost" type="box" size="0.5 0.5 0.01" pos="-1 -1 0.5" rgba="1 0 0 0" contype="0" conaffinity="0"/>
     <body name="puck" pos="0.5 0.3 0.05">
       <freejoint/>
       <geom type="sphere" size="0.05" mass="0.3"/>
@@ -70,6 +75,11 @@ XML = """
     <subtreeangmom body="puck"/>
     <subtreelinvel body="tipa"/>
     <subtreeangmom body="tipa" cutoff="0.001"/>
+    <magnetometer site="s_tip"/>
+    <rangefinder site="s_tip"/>
+    <rangefinder site="s_fore" cutoff="0.4"/>
+    <rangefinder site="s_up"/>
+    <rangefinder site="s_box"/>
   </sensor>
 </mujoco>
 """
@@ -103,9 +113,9 @@ def sens(model, sd, name_or_idx):
 def test_loader_takes_the_types():
     m = model_of()
     assert list(m["sensor_type"][:9]) == [17, 18, 19, 17, 18, 19, 17, 19, 17] and list(m["sensor_type"][9:12]) == [20, 21, 22]
-    assert list(m["sensor_type"][12:14]) == [38, 38] and list(m["sensor_type"][14:]) == [33, 34, 33, 34, 34, 33, 34]
+    assert list(m["sensor_type"][12:14]) == [38, 38] and list(m["sensor_type"][14:]) == [33, 34, 33, 34, 34, 33, 34, 6, 7, 7, 7, 7]
     assert list(m["sensor_needstage"][:3]) == [1, 2, 3] and list(m["sensor_needstage"][9:12]) == [1, 2, 3] and m["sensor_needstage"][12] == 3
-    assert list(m["sensor_needstage"][14:16]) == [2, 2] and m["nsensordata"] == 14 + 21
+    assert list(m["sensor_needstage"][14:16]) == [2, 2] and m["nsensordata"] == 14 + 21 + 3 + 4
 
 
 def test_oracle_sensors_against_their_definitions(oracle_built):
@@ -117,6 +127,7 @@ def test_oracle_sensors_against_their_definitions(oracle_built):
     nb = m["nbody"]
     parent = list(m["body_parentid"])
     seen = {"lower": 0, "upper": 0, "none": 0, "tendon": 0}
+    seen_rf = {}
     for e in range(24):
         d.reset(); d.qpos[:] = qpos[e]; d.qvel[:] = qvel[e]; d.ctrl[:] = ctrl[e]; d.forward()
         sd = np.array(d.sensordata)
@@ -170,7 +181,66 @@ def test_oracle_sensors_against_their_definitions(oracle_built):
                 assert np.abs(sens(m, sd, il) - vc).max() <= 1e-13, (e, body)
             exp = Lm if ia != 20 else np.clip(Lm, -0.001, 0.001)
             assert np.abs(sens(m, sd, ia) - exp).max() <= 1e-14 + 1e-13 * np.abs(Lm).max(), (e, body)
+        # magnetometer: the global flux (0, -0.5, 0) in the site's frame; rangefinder: brute-force ray marching against the geoms' implicit surfaces
+        smat, spos = np.array(d.site_xmat).reshape(-1, 3, 3), np.array(d.site_xpos).reshape(-1, 3)
+        sid = m["names"]["site"].index("s_tip")
+        assert np.abs(sens(m, sd, 21) - smat[sid].T @ np.array([0, -0.5, 0])).max() <= 1e-15
+        gpos, gmat = np.array(d.geom_xpos).reshape(-1, 3), np.array(d.geom_xmat).reshape(-1, 3, 3)
+        for (sname, idx) in (("s_tip", 22), ("s_fore", 23), ("s_up", 24), ("s_box", 25)):
+            k = m["names"]["site"].index(sname)
+            exp = _ray_march(m, gpos, gmat, spos[k], smat[k][:, 2], int(m["site_bodyid"][k]))
+            got = sens(m, sd, idx)[0]
+            if sname == "s_fore" and exp > 0.4:
+                exp = 0.4   # cutoff of a positive-valued sensor
+            seen_rf[sname] = seen_rf.get(sname, 0) + (got >= 0)
+            assert (got < 0) == (exp < 0) and (got < 0 or abs(got - exp) <= 2e-4), (e, sname, got, exp)
     assert min(seen.values()) >= 3, seen
+    assert seen_rf["s_up"] == 0, "the only geom above s_up is invisible (alpha 0): mj_ray skips it"
+    assert seen_rf["s_fore"] >= 20 and seen_rf["s_tip"] >= 1 and seen_rf["s_box"] >= 1, seen_rf
+
+
+def _inside(m, g, lp):
+    t, sz = int(m["geom_type"][g]), m["geom_size"][g]
+    if t == 0:
+        return lp[2] <= 0 and (sz[0] <= 0 or abs(lp[0]) <= sz[0]) and (sz[1] <= 0 or abs(lp[1]) <= sz[1])
+    if t == 2:
+        return lp @ lp <= sz[0] ** 2
+    if t == 3:
+        z = min(max(lp[2], -sz[1]), sz[1])
+        return lp[0] ** 2 + lp[1] ** 2 + (lp[2] - z) ** 2 <= sz[0] ** 2
+    return bool(np.all(np.abs(lp) <= sz[:3]))
+
+
+def _ray_march(m, gpos, gmat, pnt, vec, bodyexclude, tmax=3.0, n=30000):
+    """First parameter t at which pnt + t vec is inside a visible geom not on `bodyexclude` (resolution tmax / n), -1 if none.  A ray that STARTS
+    inside a geom leaves through its far surface in mj_ray (the smaller non-negative root): such geoms are reported at their exit point."""
+    best = -1.0
+    ts = np.linspace(0, tmax, n + 1)
+    for g in range(m["ngeom"]):
+        if int(m["geom_bodyid"][g]) == bodyexclude or m["geom_rgba"][g][3] == 0:
+            continue
+        lp0 = gmat[g].T @ (pnt - gpos[g])
+        lv = gmat[g].T @ vec
+        ins = np.array([_inside(m, g, lp0 + t * lv) for t in ts[::30]])
+        if not ins.any() or (int(m["geom_type"][g]) == 0 and lv[2] > -1e-15):
+            continue
+        if ins[0]:   # starts inside: the exit
+            if int(m["geom_type"][g]) == 0:
+                continue  # behind a plane: mju_rayGeom's plane case needs lp[2] >= 0 (x = -lp2 / lv2 < 0 otherwise)
+            k = int(np.argmin(ins)) if not ins.all() else -1
+            if k < 0:
+                continue
+            lo = ts[::30][k - 1]
+            fine = np.linspace(lo, lo + 30 * tmax / n, 31)
+            t = next(tt for tt in fine if not _inside(m, g, lp0 + tt * lv))
+        else:
+            k = int(np.argmax(ins))
+            lo = ts[::30][k - 1]
+            fine = np.linspace(lo, lo + 30 * tmax / n, 31)
+            t = next(tt for tt in fine if _inside(m, g, lp0 + tt * lv))
+        if best < 0 or t < best:
+            best = float(t)
+    return best
 
 
 def _chain(parent, b):
