@@ -2111,6 +2111,9 @@ template <int G, int TAG> __device__ __attribute__((noinline)) void fwd_constrai
 // qacc = qacc_smooth + M^-1 J' f and Euler's (M + h B)^-1 (qfrc_smooth + qfrc_constraint) from ONE two-right-hand-side run of the
 // DPP-row substitution on lanes 0 - 15 (solve_dense16, dual) in place of this stage's register substitution over the dense triangle
 // (9.1 k cycles per step on config 3) plus Euler's own solve (~5 k).
+#ifndef MJB_EXTRA_SWEEPS
+#define MJB_EXTRA_SWEEPS 8
+#endif
 #ifndef MJB_PGS_PRESOLVE
 #define MJB_PGS_PRESOLVE 1
 #endif
@@ -2151,7 +2154,7 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 	// the 1 - 6 % of config 3's env-steps with 33 - 64 rows then take the AR-free path and throughput drops 10.3 -> 4.3 M.)
 	constexpr int NR = 64;
 	const bool large = !ELL && nefc > NR;
-	if constexpr (REGB) {
+	if constexpr (REGB) MJB_REP(20) {
 		double *Ld = f + L.tri;  // (compact layout: inside the region kinematics / crb / rne share -- nobody else is alive here)
 		tri_build(m, L, f, Ld, lane);
 		double *Bg = s.pgs_B ? s.pgs_B + (size_t)e.env * m.nefcmax * nv : nullptr;
@@ -2199,7 +2202,7 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 	const int rdim = ell ? fi[L.contact_dim + rcon] : 0, ri0 = ell ? fi[L.contact_efc_address + rcon] : 0;
 	double *Hc = f + L.nwt_hc;  // [36 nconmax] the contacts' diagonal blocks of AR (allocated for PGS + elliptic)
 	double b = 0, Aii = 1, ARinv = 0, frc = 0;
-	{
+	MJB_REP(21) {
 		double jq = 0, jb = 0, jw = 0;
 		if constexpr (REGB) {
 #pragma unroll
@@ -2254,6 +2257,7 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 	// AR[i] = J_r . B_i: k outermost so that the 64 accumulators are independent (every load of one k is in flight
 	// together); row groups beyond nefc accumulate stale rows and are zeroed afterwards
 	double AR[NR];
+	MJB_REP(22) {
 #pragma unroll
 	for (int i = 0; i < NR; i++) AR[i] = 0;
 #ifdef MJB_PROFILE_SUB
@@ -2300,6 +2304,7 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 	}
 #pragma unroll
 	for (int i = 0; i < NR; i++) AR[i] = (rowact && i < nefc) ? (lane == i ? Aii : AR[i]) : 0.0;
+	}
 	if constexpr (ELL) {  // the contacts' diagonal blocks, for the block updates: row r of contact c -> Hc[36 c + 6 (r - i0) + .]
 		MJB_KEEP_BRANCH();
 #pragma unroll
@@ -2350,6 +2355,17 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 		iter++;
 		if (improvement < tol) break;
 	}
+#if MJB_DOUBLE_STAGE == 23  // (measurement builds: MJB_EXTRA_SWEEPS more Gauss-Seidel sweeps behind the stop test: the launch-time difference / that = one sweep)
+	if constexpr (!ELL) {
+#pragma nounroll
+		for (int xs = 0; xs < MJB_EXTRA_SWEEPS; xs++) {
+			double dvec = 0;
+			pgs_sweep<false, NR>(AR, nefc, lo, hi, ARinv, res, frc, dvec);
+			frc += dvec;
+			cost = wave_sum(0.5 * frc * (res + b));
+		}
+	}
+#endif
 	if (lane == 0) fi[L.solver_iter] = iter;
 	if (rowact) f[L.efc_force + r] = frc;
 	gsync<G>();
@@ -2358,7 +2374,7 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 	prof_rec(e.env, lane, 21, (unsigned long long)iter); prof_rec(e.env, lane, 22, (unsigned long long)nefc);
 #endif
 	// qfrc_constraint = J' f,  qacc = qacc_smooth + M^-1 J' f = qacc_smooth + B' f
-	if (lane < nv) {
+	MJB_REP(24) if (lane < nv) {
 		double sj = 0, w = 0;
 		for (int i = 0; i < nefc; i++) {
 			const double fr = f[L.efc_force + i];

@@ -32,6 +32,14 @@ typedef const FrameLayout MJB_AS4 &CLayout;
 typedef const DevState MJB_AS4 &CState;
 typedef const NoiseCfg MJB_AS4 &CNoise;
 
+// Marginal-cost profile of the SHIPPED kernels (tools/stage_marginal.py): a build with -DMJB_DOUBLE_STAGE=<id> runs that stage (every one of them
+// recomputes its outputs from its inputs) TWICE; launch time minus the production build's = what the stage costs in THROUGHPUT on the production register allocation,
+// partner wavefront and all -- the windowed cycle probes measure one wavefront's latency and perturb the 256-register allocation.  -1: production (the loops vanish).
+#ifndef MJB_DOUBLE_STAGE
+#define MJB_DOUBLE_STAGE -1
+#endif
+#define MJB_REP(id) _Pragma("nounroll") for (int rep_ = 0; rep_ < (MJB_DOUBLE_STAGE == (id) ? 2 : 1); rep_++)
+
 #ifdef MJB_STAGE_NOINLINE
 #define STAGE static __device__ __noinline__
 #else
@@ -2850,10 +2858,11 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 	constexpr bool MJB_LAUNDER_HERE = MJB_LAUNDER_DENSE || DENSE == 0;
 	[[maybe_unused]] CState s = P->s;  // (profiling macros)
 	PROF_BEGIN();
-	VIEW(P, compact, kinematics<G, (G == 64 || DENSE != 0), (DENSE != 0)>(m, L, s, e));
+	MJB_REP(0) VIEW(P, compact, kinematics<G, (G == 64 || DENSE != 0), (DENSE != 0)>(m, L, s, e));
 	PROF(0);
-	VIEW(P, compact, com_pos<G, (DENSE != 0)>(m, L, e));
+	MJB_REP(1) VIEW(P, compact, com_pos<G, (DENSE != 0)>(m, L, e));
 	PROF(1);
+	MJB_REP(2) {  // (crb + factorisation together: the lean frame factorises M + h B in place)
 	VIEW(P, compact, crb<G, (DENSE != 0)>(m, L, e));
 	PROF(2);
 	if constexpr (DENSE)
@@ -2883,9 +2892,10 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 	} else
 		VIEW(P, compact, factor2<G>(m, e, e.f + L.qM, e.f + L.qLD, e.f + L.qLDiagInv, e.f + L.MhB, e.f + L.qH, e.f + L.qHdi,
 		                            m.eulerdamp != 0));
+	}
 	PROF(3);
 	if constexpr (CON) {
-		VIEW(P, compact, collision<G>(m, L, s, e));
+		MJB_REP(16) VIEW(P, compact, collision<G>(m, L, s, e));
 		PROF(16);
 	}
 	// Constraint rows (make_constraint + J M^-1 + reference accelerations) read positions, contacts and qvel only and nothing
@@ -2899,6 +2909,7 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 		if constexpr (CON != 0) {
 			if (trip == con_trip) {
 				PROF_BEGIN();
+				MJB_REP(17) {
 				VIEW(P, compact, make_constraint<G, CON>(m, L, s, e));
 				PROF(17);
 				if constexpr (CON == 1 || CON == 5 || CON == 9) {
@@ -2907,19 +2918,20 @@ template <int G, int CON, int DENSE> DEVI void forward_first(const KernelParams 
 					else if constexpr (CON == 5) VIEW(P, compact, project_constraint_dense16<G, CON>(m, L, e));
 				}
 				VIEW(P, compact, reference_constraint<G, CON>(m, L, s, e));
+				}
 				PROF(18);
 			}
 			if (trip) break;
 		}
 		PROF_BEGIN();
-		VIEW(P, compact, transmission<G, (DENSE != 0)>(m, L, e));
+		MJB_REP(4) VIEW(P, compact, transmission<G, (DENSE != 0)>(m, L, e));
 		VIEW(P, compact, sensors<G, (DENSE != 0)>(m, L, s, e, MJB_STAGE_POS, compact));
 		PROF(4);
-		VIEW(P, compact, com_vel<G, (DENSE != 0)>(m, L, e));
+		MJB_REP(5) VIEW(P, compact, com_vel<G, (DENSE != 0)>(m, L, e));
 		PROF(5);
-		VIEW(P, compact, passive<G, (DENSE != 0)>(m, L, e));
+		MJB_REP(6) VIEW(P, compact, passive<G, (DENSE != 0)>(m, L, e));
 		PROF(6);
-		VIEW(P, compact, rne<G, (DENSE != 0)>(m, L, e));
+		MJB_REP(7) VIEW(P, compact, rne<G, (DENSE != 0)>(m, L, e));
 		PROF(7);
 		VIEW(P, compact, sensors<G, (DENSE != 0)>(m, L, s, e, MJB_STAGE_VEL, compact));
 		PROF(8);
@@ -2931,9 +2943,9 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 	constexpr bool MJB_LAUNDER_HERE = MJB_LAUNDER_DENSE || DENSE == 0;
 	[[maybe_unused]] CState s = P->s;  // (profiling macros)
 	PROF_BEGIN();
-	VIEW(P, compact, fwd_actuation<G, (DENSE != 0)>(m, L, e));
+	MJB_REP(9) VIEW(P, compact, fwd_actuation<G, (DENSE != 0)>(m, L, e));
 	PROF(9);
-	VIEW(P, compact, fwd_acceleration<G, (CON != 0 ? -1 : DENSE), (CON >= 2 && CON <= 4)>(m, L, e, s.use_xfrc != 0));  // (TRI32: the Newton kernels -- in the PGS ones its 124 registers bring back the spill-before-exec-restore pattern)
+	MJB_REP(10) VIEW(P, compact, fwd_acceleration<G, (CON != 0 ? -1 : DENSE), (CON >= 2 && CON <= 4)>(m, L, e, s.use_xfrc != 0));  // (TRI32: the Newton kernels -- in the PGS ones its 124 registers bring back the spill-before-exec-restore pattern)
 	PROF(10);
 	if constexpr (CON == 4 && G == 64) {
 		// up to 256 rows.  The fused step's frame holds the first L.jrows (= 64) rows of efc_J: an env-step within that runs the
@@ -2970,7 +2982,7 @@ template <int G, int CON, int DENSE> DEVI void forward_rest(const KernelParams M
 		} else {
 			if (P->m.nv <= 16) {
 				VIEW(P, compact, fwd_constraint_pgs<G, false, true, CON>(m, L, s, e));
-				if constexpr (MJB_PGS_PRESOLVE) {
+				if constexpr (MJB_PGS_PRESOLVE) MJB_REP(25) {
 					// qacc = qacc_smooth + M^-1 qfrc_constraint, and -- under implicit joint damping -- Euler's (M + h B)^-1 (qfrc_smooth + qfrc_constraint)
 					// beside it: one dual substitution (both factors were built together in fwd_position); Euler finds its vector solved
 					VIEW(P, compact, {
@@ -3558,14 +3570,14 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 						const int bad = any_bad<G>(e, L, e.f + L.qpos, m.nq, e.f + L.qvel, m.nv);
 						if (bad) reset_frame_state<G>(m, L, s, lite(e), bad == 1 ? MJB_WARN_BADQPOS : MJB_WARN_BADQVEL);
 					}
-					forward_first<G, CON, DENSE>(P, e, compact);
+					if constexpr (MJB_DOUBLE_STAGE != 99) forward_first<G, CON, DENSE>(P, e, compact);  // (99: measurement build without the forward pass)
 					if (st0 + st == (mode == MJB_MODE_STEP ? nsteps : nst) - 1 && P->m.enableflags & MJB_ENBL_ENERGY) VIEW(P, compact, energy<G>(m, L, lite(e)));
 				}
 				if (!do_rest) break;
 				// device-side DefaultRobotHWSim::writeSim runs where the reference's control callback fires: after the position
 				// and velocity stages, before actuation (mjcb_control inside mj_forward; mujoco_ros_control_plugin.cpp:153-194)
 				if (hw_on) VIEW(P, compact, hwsim_write<G>(m, L, Pq_->hw, lite(e)));
-				forward_rest<G, CON, DENSE>(P, e, compact);
+				if constexpr (MJB_DOUBLE_STAGE != 99) forward_rest<G, CON, DENSE>(P, e, compact);
 				if (attempt || !checks || !any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0, true)) break;
 				reset_frame_state<G>(m, L, s, lite(e), MJB_WARN_BADQACC);
 			}
@@ -3582,7 +3594,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 						const int bad = any_bad<G>(e, L, e.f + L.qpos, m.nq, e.f + L.qvel, m.nv);
 						if (bad) reset_frame_state<G>(m, L, s, lite(e), bad == 1 ? MJB_WARN_BADQPOS : MJB_WARN_BADQVEL);
 					}
-					forward_first<G, CON, DENSE>(P, e, compact);
+					if constexpr (MJB_DOUBLE_STAGE != 99) forward_first<G, CON, DENSE>(P, e, compact);  // (99: measurement build without the forward pass)
 					if (st0 + st == (mode == MJB_MODE_STEP ? nsteps : nst) - 1 && P->m.enableflags & MJB_ENBL_ENERGY) VIEW(P, compact, energy<G>(m, L, lite(e)));
 				}
 				if (!do_rest) break;
@@ -3596,7 +3608,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 				// and velocity stages, before actuation (mjcb_control inside mj_forward; mujoco_ros_control_plugin.cpp:153-194)
 				// (RK4: once per step, at the step's own evaluation -- the PID state advances by one period; its forces stay for the sub-stages)
 				if (hw_on && !rk) VIEW(P, compact, hwsim_write<G>(m, L, Pq_->hw, lite(e)));
-				forward_rest<G, CON, DENSE>(P, e, compact);
+				if constexpr (MJB_DOUBLE_STAGE != 99) forward_rest<G, CON, DENSE>(P, e, compact);
 				if (attempt || rk || !checks || !any_bad<G>(e, L, e.f + L.qacc, m.nv, e.f, 0, true)) break;
 				reset_frame_state<G>(m, L, s, lite(e), MJB_WARN_BADQACC);
 			}
@@ -3604,7 +3616,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 				VIEW(P, compact, rk4_stage<G>(m, L, e, rk));
 				if (++rk == 4) break;
 				if (rksplit) {  // the next evaluation's first half, then back to the host for its callbacks
-					forward_first<G, CON, DENSE>(P, e, compact);
+					if constexpr (MJB_DOUBLE_STAGE != 99) forward_first<G, CON, DENSE>(P, e, compact);  // (99: measurement build without the forward pass)
 					// (mjData.energy follows the evaluation, as in the fused step, mjb_step2_prefix and the oracle's mjo_step2_rk)
 					if (P->m.enableflags & MJB_ENBL_ENERGY) VIEW(P, compact, energy<G>(m, L, lite(e)));
 					break;
