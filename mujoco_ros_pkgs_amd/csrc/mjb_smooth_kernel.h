@@ -7,11 +7,11 @@
 // cdof, velocities, RNE, passive and actuator forces, composite inertias, qM, both L'DL factors (M, and M + h B for Euler's implicit
 // damping), qacc_smooth -- and leaves what the constraint stages read in the env's HAND-OFF record in HBM (mjb_dev.h: hand-off order);
 // mjb_cstep_kernel (mjb_step.hip) picks it up with one env per wavefront: collision, make_constraint, PGS, Euler.  One launch = one step of
-// every env of its range; the host alternates the two kernels on a few streams of env slices, so this kernel's latency hides behind the
-// other slices' constraint stages.
+// every env of its range; the host alternates the two kernels on streams of env slices (two by default), so this kernel's latency hides behind
+// the other slice's constraint stages.  Opt-in (mjb_set_split_step): measurements and the reason in DESIGN.md §11, profiles/r06_split_step.txt.
 //
 // Same template idea as mjb_lane_env_kernel.h (a lane's "arrays" are registers: every index is a compile-time constant of the model's
-// integer structure `T`, a SmTopo_* of csrc/lane_env_topos.h), widened to what config 3 and the reference's own worlds need: free and ball
+// integer structure `T`, a SmTopo_* of csrc/smooth_topos.h), widened to what config 3 and the reference's own worlds need: free and ball
 // joints (pendulum_world.xml:18-38), qpos / dof addresses that differ from the joint index, geoms.  Spatial quantities are taken about the
 // origin of the tree's root body (any common point gives the same qM / qfrc_bias / contact Jacobians; the record's subtree_com entries hold
 // that point).  Arithmetic otherwise follows oracle/mjo_smooth.c stage by stage; reciprocals are Newton-refined hardware seeds, so results
@@ -83,7 +83,7 @@ DEVI void normalize4_full(double *q)
 
 // One step's smooth half of one env per lane.  env: the lane's env (a lane without one -- !live -- recomputes a neighbour's and stores the same
 // values); step: the env's step index (the ctrl-noise key); last: position / velocity sensors go out (wave-uniform); lp: the lane's pair slots
-// (slot q at lp[64 * q]: LDS of the stand-alone kernel, a per-wavefront block of global memory for the flow kernel's smooth workers).
+// (slot q at lp[64 * q]; the kernel keeps them in LDS: cdof, and per moving body its force and its cinert -- Sq<T>).
 template <class T>
 DEVI void smooth_lane_env_core(const KernelParams MJB_AS4 *__restrict__ P, const int env, const bool live, const unsigned int step, const bool last, Pair *const lp)
 {
