@@ -375,7 +375,7 @@ void compute_layout(mjb_model *M, FrameLayout &L, bool compact, int jrows_req = 
 	L.qHdi = off;
 	off += d.nv;
 	L.rk = d.integrator == MJB_INT_RK4 ? off : -1;  // (persistent across the evaluations of one step)
-	off += d.integrator == MJB_INT_RK4 ? d.nq + 4 * d.nv + d.nsensordata + 1 : 0;  // X0 | sums | warmstart | the step's sensordata | t0
+	off += d.integrator == MJB_INT_RK4 ? d.nq + 4 * d.nv + d.nsensordata + 1 + 2 * d.na : 0;  // X0 | sums | warmstart | the step's sensordata | t0 | act0 | sum B act_dot
 	// transient scratch of the constrained kernels: ntri doubles for the packed dense triangle of the L'DL factor (nv <= 16, PGS:
 	// the J M^-1 rows; 16 < nv <= 32: the M^-1 solves of fwd_acceleration / Euler, solve_tri32), 128 for the box - box narrow phase
 	const int ntri = d.nefcmax <= 0 ? 0 : ((d.nv <= 16 && d.solver == MJB_SOL_PGS) ? 128 : ((d.nv > 16 && d.nv <= 32) ? 496 : 0));
@@ -695,9 +695,28 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		fail(MJB_EINVAL, "mjb_compile: negative size");
 		return nullptr;
 	}
-	if (d.na != 0) {
-		fail(MJB_EUNSUPPORTED, "mjb_compile: actuator activations (na > 0) are not supported");
-		return nullptr;
+	{  // activations: one variable per stateful actuator, in actuator order; integrator / filter dynamics
+		int na = 0;
+		for (int i = 0; i < d.nu; i++) {
+			const int dt = d.actuator_dyntype[i];
+			if (dt != MJB_DYN_NONE && dt != MJB_DYN_INTEGRATOR && dt != MJB_DYN_FILTER) {
+				fail(MJB_EUNSUPPORTED, "mjb_compile: actuator dyntype (muscle / user dynamics) is not supported");
+				return nullptr;
+			}
+			if (d.na > 0 && d.actuator_actadr[i] != (dt != MJB_DYN_NONE ? na : -1)) {
+				fail(MJB_EINVAL, "mjb_compile: actuator_actadr must number the stateful actuators in order (-1: stateless)");
+				return nullptr;
+			}
+			if (d.na > 0 && dt != MJB_DYN_NONE && d.actuator_actlimited[i] && !(d.actuator_actrange[2 * i] < d.actuator_actrange[2 * i + 1])) {
+				fail(MJB_EINVAL, "mjb_compile: actlimited actuator with an empty actrange");
+				return nullptr;
+			}
+			na += dt != MJB_DYN_NONE ? 1 : 0;
+		}
+		if (na != d.na) {
+			fail(MJB_EINVAL, "mjb_compile: na does not match the number of stateful actuators");
+			return nullptr;
+		}
 	}
 	if (d.integrator != MJB_INT_EULER && d.integrator != MJB_INT_RK4) {
 		fail(MJB_EUNSUPPORTED, "mjb_compile: only the Euler and RK4 integrators are implemented");
@@ -938,10 +957,8 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 	}
 	for (int i = 0; i < h.nu; i++) {
 		int j = h.actuator_trnid[2 * i];
-		if (h.actuator_trntype[i] != MJB_TRN_JOINT || h.actuator_dyntype[i] != MJB_DYN_NONE || j < 0 || j >= h.njnt ||
-		    h.jnt_type[j] < MJB_JNT_SLIDE) {
-			fail(MJB_EUNSUPPORTED, "mjb_compile: actuator %d: only joint transmission on hinge/slide joints "
-			                       "without activation dynamics is supported", i);
+		if (h.actuator_trntype[i] != MJB_TRN_JOINT || j < 0 || j >= h.njnt || h.jnt_type[j] < MJB_JNT_SLIDE) {
+			fail(MJB_EUNSUPPORTED, "mjb_compile: actuator %d: only joint transmission on hinge/slide joints is supported", i);
 			delete M;
 			return nullptr;
 		}

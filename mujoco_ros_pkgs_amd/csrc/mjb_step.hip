@@ -2519,7 +2519,12 @@ template <int G, bool CACHE = false> STAGE void fwd_actuation(CModel m, CLayout 
 					gain = m.actuator_gainprm[3 * i] + m.actuator_gainprm[3 * i + 1] * len + m.actuator_gainprm[3 * i + 2] * vel;
 				if (m.actuator_biastype[i] == MJB_BIAS_AFFINE)
 					bias = m.actuator_biasprm[3 * i] + m.actuator_biasprm[3 * i + 1] * len + m.actuator_biasprm[3 * i + 2] * vel;
-				force = gain * ctrl + bias;
+				double input = ctrl;
+				if (m.na > 0) {  // a stateful actuator's gain multiplies its activation (mj_fwdActuation)
+					const int ja = m.actuator_actadr[i];
+					if (ja >= 0) input = f[L.act + ja];
+				}
+				force = gain * input + bias;
 				if (m.actuator_forcelimited[i]) {
 					const double lo = m.actuator_forcerange[2 * i], hi = m.actuator_forcerange[2 * i + 1];
 					force = force < lo ? lo : (force > hi ? hi : force);
@@ -2530,7 +2535,39 @@ template <int G, bool CACHE = false> STAGE void fwd_actuation(CModel m, CLayout 
 		}
 		f[L.qfrc_actuator + d] = acc;
 	}
+	if (m.na > 0) {
+		// act_dot of the stateful actuators, from the clamped ctrl: integrator ctrl, filter (ctrl - act) / max(mjMINVAL, dynprm[0])
+		for (int i = e.lane; i < m.nu; i += G) {
+			const int ja = m.actuator_actadr[i];
+			if (ja < 0) continue;
+			double ctrl = f[L.ctrl + i], dot = 0;
+			if (m.actuator_ctrllimited[i] && !(m.disableflags & MJB_DSBL_CLAMPCTRL)) {
+				const double lo = m.actuator_ctrlrange[2 * i], hi = m.actuator_ctrlrange[2 * i + 1];
+				ctrl = ctrl < lo ? lo : (ctrl > hi ? hi : ctrl);
+			}
+			if (!off) {
+				const double tau = m.actuator_dynprm[3 * i];
+				dot = m.actuator_dyntype[i] == MJB_DYN_INTEGRATOR ? ctrl : (ctrl - f[L.act + ja]) / (tau > MJB_MINVAL ? tau : MJB_MINVAL);
+			}
+			f[L.act_dot + ja] = dot;
+		}
+	}
 	gsync<G>();
+}
+
+// mj_advance, activations: act += h act_dot, clamped to actrange when the actuator is actlimited
+template <int G> DEVI void advance_act(CModel m, double *act, const double *act0, const double *act_dot, double h, int lane)
+{
+	for (int i = lane; i < m.nu; i += G) {
+		const int ja = m.actuator_actadr[i];
+		if (ja < 0) continue;
+		double a = act0[ja] + h * act_dot[ja];
+		if (m.actuator_actlimited[i]) {
+			const double lo = m.actuator_actrange[2 * i], hi = m.actuator_actrange[2 * i + 1];
+			a = a < lo ? lo : (a > hi ? hi : a);
+		}
+		act[ja] = a;
+	}
 }
 
 template <int G, int DENSE, bool TRI32 = false> STAGE void fwd_acceleration(CModel m, CLayout L, const Env &e, bool use_xfrc)
@@ -2657,6 +2694,7 @@ template <int G, bool CAN16, bool TRI32 = false, bool JC = false, bool PRE = fal
 			st4(f + L.qpos + pa, q);
 		}
 	}
+	if (m.na > 0) advance_act<G>(m, f + L.act, f + L.act, f + L.act_dot, dt, e.lane);
 	if (e.lane == 0) f[L.time] += dt;
 	gsync<G>();
 }
@@ -2664,12 +2702,13 @@ template <int G, bool CAN16, bool TRI32 = false, bool JC = false, bool PRE = fal
 // mj_RungeKutta(m, d, 4) around the step loop's ONE copy of the forward stages (oracle/mjo_smooth.c mjo_rk4 has the scheme): called after
 // evaluation rk = 0 .. 3 of a step, it folds F_rk = (qvel, qacc) into the weighted sums and either sets the state of evaluation
 // rk + 1 (X0 advanced by h with a_{rk+1} F_rk, positions through the quaternion-aware integration) or, after the last one,
-// advances X0 by h with the sums.  L.rk: q0 [nq] | v0 [nv] | sum B qvel [nv] | sum B qacc [nv] | warmstart [nv] | sensordata [S].
+// advances X0 by h with the sums.  L.rk: q0 [nq] | v0 [nv] | sum B qvel [nv] | sum B qacc [nv] | warmstart [nv] | sensordata [S] | t0 | act0 [na] | sum B act_dot [na].
 template <int G> STAGE void rk4_stage(CModel m, CLayout L, const Env &e, int rk)
 {
 	double *f = e.f;
 	const int nq = m.nq, nv = m.nv, ns = m.nsensordata;
 	double *q0 = f + L.rk, *v0 = q0 + nq, *accv = v0 + nv, *acca = accv + nv, *w0 = acca + nv, *sens = w0 + nv, *t0 = sens + ns;
+	double *a0 = t0 + 1, *acct = a0 + m.na;
 	const double h = m.timestep[0];
 	const double B = (rk == 0 || rk == 3) ? 1.0 / 6.0 : 1.0 / 3.0;
 	if (rk == 0) {
@@ -2682,9 +2721,18 @@ template <int G> STAGE void rk4_stage(CModel m, CLayout L, const Env &e, int rk)
 		accv[d] = (rk == 0 ? 0.0 : accv[d]) + B * f[L.qvel + d];
 		acca[d] = (rk == 0 ? 0.0 : acca[d]) + B * f[L.qacc + d];
 	}
+	for (int k = e.lane; k < m.na; k += G) {
+		if (rk == 0) a0[k] = f[L.act + k];
+		acct[k] = (rk == 0 ? 0.0 : acct[k]) + B * f[L.act_dot + k];
+	}
 	gsync<G>();
 	const bool last = rk == 3;
 	const double a = rk == 2 ? 1.0 : 0.5;
+	if (m.na > 0) {  // activations: X_i = act0 + h a F_{i-1} unclamped; the final advance clamps (mj_advance)
+		if (last) advance_act<G>(m, f + L.act, a0, acct, h, e.lane);
+		else
+			for (int k = e.lane; k < m.na; k += G) f[L.act + k] = a0[k] + h * (0.0 + a * f[L.act_dot + k]);
+	}
 	// positions first: they read the velocity of evaluation rk (a F_rk) or the weighted sum, before qvel is overwritten
 	for (int j = e.lane; j < m.njnt; j += G) {
 		const int jt = m.jnt_type[j];
@@ -3371,7 +3419,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 		}
 		{  // lane = dof: its actuator
 			const int t0 = m.nv ? m.dof_act_adr[dd] : 0, t1 = m.nv ? m.dof_act_adr[dd + 1] : 0;
-			c.a_n = t1 - t0;
+			c.a_n = (m.na > 0 && t1 > t0) ? 2 : t1 - t0;  // (stateful actuators: the table walk, which knows about activations)
 			const int i = c.a_n > 0 ? m.dof_act_id[t0] : 0;
 			c.a_id = i;
 			const bool has = c.a_n > 0 && m.nu > 0;

@@ -45,6 +45,7 @@ struct mjData {
 	int env_id;     // index of this env instance in the batch
 	mjtNum time;
 	mjtNum *qpos, *qvel, *ctrl, *qacc, *qacc_warmstart;
+	mjtNum *act;    // actuator activations [na] (read-only for plugins: the engine integrates them)
 	mjtNum *qfrc_applied, *xfrc_applied, *qfrc_passive;  // callback-writable force fields (plugin_utils.h:91,101)
 	mjtNum *sensordata;
 	mjtNum *mocap_pos, *mocap_quat;  // written by the mocap plugin (mocap_plugin.cpp:102-103)

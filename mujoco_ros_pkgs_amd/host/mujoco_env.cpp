@@ -19,7 +19,7 @@ constexpr float MujocoEnv::percentRealTime[];
 
 namespace {
 // host-mirrored fields handed to plugins through mjData
-const int kStateFields[] = { MJB_F_qpos, MJB_F_qvel, MJB_F_ctrl, MJB_F_qacc, MJB_F_qacc_warmstart, MJB_F_qfrc_applied,
+const int kStateFields[] = { MJB_F_qpos, MJB_F_qvel, MJB_F_act, MJB_F_ctrl, MJB_F_qacc, MJB_F_qacc_warmstart, MJB_F_qfrc_applied,
 	                         MJB_F_xfrc_applied, MJB_F_sensordata, MJB_F_time, MJB_F_mocap_pos, MJB_F_mocap_quat };
 const int kDerivedFields[] = { MJB_F_qfrc_passive, MJB_F_xpos, MJB_F_xquat, MJB_F_xmat, MJB_F_xipos, MJB_F_ximat,
 	                           MJB_F_cvel, MJB_F_subtree_com, MJB_F_site_xpos, MJB_F_site_xmat, MJB_F_geom_xpos,
@@ -295,6 +295,7 @@ void MujocoEnv::bindView(int env, mjData &d)
 	d.geom_xmat = p(MJB_F_geom_xmat); d.actuator_force = p(MJB_F_actuator_force); d.qfrc_bias = p(MJB_F_qfrc_bias);
 	d.qfrc_actuator = p(MJB_F_qfrc_actuator);
 	d.mocap_pos = p(MJB_F_mocap_pos); d.mocap_quat = p(MJB_F_mocap_quat);
+	d.act = p(MJB_F_act);
 }
 
 // mujoco_env.cpp:404-415

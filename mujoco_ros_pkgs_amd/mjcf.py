@@ -572,6 +572,7 @@ class _Compiler:
         gain = np.zeros(3)
         bias = np.zeros(3)
         gaintype, biastype = 0, 0
+        dyntype, dynprm = 0, np.zeros(3)  # mjtDyn: none 0, integrator 1, filter 2 (muscle / user refused)
         if t == "motor":
             gain[0] = 1.0
         elif t == "position":
@@ -586,6 +587,37 @@ class _Compiler:
             gain[0] = kv
             bias[2] = -kv
             biastype = 1
+        elif t == "intvelocity":
+            # integrated-velocity servo (MuJoCo 2.3.0+): the activation is the position set point, act_dot = ctrl; actrange is mandatory
+            kp = float(a.get("kp", 1))
+            gain[0] = kp
+            bias[1] = -kp
+            biastype = 1
+            dyntype = 1
+            if "actrange" not in a:
+                raise MjcfError("<intvelocity> needs actrange")
+            a = dict(a, actlimited="true")
+        elif t == "damper":
+            # active damper: force = -kv * velocity * ctrl, ctrl >= 0 (ctrlrange mandatory, lower bound >= 0)
+            kv = float(a.get("kv", 1))
+            if kv < 0:
+                raise MjcfError("<damper> kv must be >= 0")
+            gaintype = 1
+            gain[2] = -kv
+            if "ctrlrange" not in a or _floats(a["ctrlrange"], 2, "ctrlrange")[0] < 0:
+                raise MjcfError("<damper> needs ctrlrange with a lower bound >= 0")
+            a = dict(a, ctrllimited="true")
+        elif t == "cylinder":
+            # pneumatic / hydraulic cylinder: first-order filter on ctrl (timeconst), gain = area, bias
+            dyntype = 2
+            dynprm[0] = float(a.get("timeconst", 1))
+            area = float(a.get("area", 1))
+            if "diameter" in a:
+                area = np.pi / 4 * float(a["diameter"]) ** 2
+            gain[0] = area
+            bp = _floats(a.get("bias", "0 0 0"))
+            bias[:min(3, bp.size)] = bp[:3]
+            biastype = 1
         elif t == "general":
             gaintype = {"fixed": 0, "affine": 1}[a.get("gaintype", "fixed")]
             biastype = {"none": 0, "affine": 1}[a.get("biastype", "none")]
@@ -593,12 +625,17 @@ class _Compiler:
             bp = _floats(a.get("biasprm", "0"))
             gain[:min(3, gp.size)] = gp[:3]
             bias[:min(3, bp.size)] = bp[:3]
-            if a.get("dyntype", "none") != "none":
-                raise MjcfError("actuator dynamics (dyntype) not supported")
+            dt = a.get("dyntype", "none")
+            if dt not in ("none", "integrator", "filter"):
+                raise MjcfError(f"actuator dyntype '{dt}' is not supported (none / integrator / filter)")
+            dyntype = {"none": 0, "integrator": 1, "filter": 2}[dt]
+            dp = _floats(a.get("dynprm", "1"))
+            dynprm[:min(3, dp.size)] = dp[:3]
         else:
             raise MjcfError(f"actuator type <{t}> not supported")
         cr = _floats(a.get("ctrlrange", "0 0"), 2, "ctrlrange")
         fr = _floats(a.get("forcerange", "0 0"), 2, "forcerange")
+        ar = _floats(a.get("actrange", "0 0"), 2, "actrange")
 
         def lim(key, rng_key):
             v = a.get(key, "auto")
@@ -608,7 +645,10 @@ class _Compiler:
 
         act.update(gear=gear, gainprm=gain, biasprm=bias, gaintype=gaintype, biastype=biastype, ctrlrange=cr,
                    forcerange=fr, ctrllimited=lim("ctrllimited", "ctrlrange"),
-                   forcelimited=lim("forcelimited", "forcerange"))
+                   forcelimited=lim("forcelimited", "forcerange"), dyntype=dyntype, dynprm=dynprm, actrange=ar,
+                   actlimited=lim("actlimited", "actrange") if dyntype else 0)
+        if act["actlimited"] and not ar[0] < ar[1]:
+            raise MjcfError(f"actuator '{act['name']}': actlimited needs actrange[0] < actrange[1]")
         self.actuators.append(act)
 
     def _sensor(self, node):
@@ -851,7 +891,17 @@ class _Compiler:
             trnid[i, 0] = jid
         m["actuator_trnid"] = trnid
         m["actuator_trntype"] = np.zeros(nu, I)
-        m["actuator_dyntype"] = np.zeros(nu, I)
+        m["actuator_dyntype"] = np.array([a["dyntype"] for a in A], I)
+        # one activation variable per stateful actuator, in actuator order (mjModel.actuator_actadr; -1: stateless)
+        actadr, na = [], 0
+        for a in A:
+            actadr.append(na if a["dyntype"] else -1)
+            na += 1 if a["dyntype"] else 0
+        m["na"] = na
+        m["actuator_actadr"] = np.array(actadr, I)
+        m["actuator_actlimited"] = np.array([a["actlimited"] for a in A], I)
+        m["actuator_dynprm"] = np.array([a["dynprm"] for a in A], D).reshape(nu, 3)
+        m["actuator_actrange"] = np.array([a["actrange"] for a in A], D).reshape(nu, 2)
         m["actuator_gaintype"] = np.array([a["gaintype"] for a in A], I)
         m["actuator_biastype"] = np.array([a["biastype"] for a in A], I)
         m["actuator_ctrllimited"] = np.array([a["ctrllimited"] for a in A], I)

@@ -54,7 +54,7 @@ typedef struct mjo_data {
 	double *scratch_nv;
 	double *scratch_nv2;
 	double *rk_warmstart; /* [nv] RK4: the warmstart the step came in with (every sub-stage evaluation starts from it) */
-	double *rk_buf;       /* [nq + 5 nv + nsensordata + 1] RK4 state of a step cut at its callback points (mjo_step2_rk) */
+	double *rk_buf;       /* [nq + 5 nv + nsensordata + 1 + 2 na] RK4 state of a step cut at its callback points (mjo_step2_rk) */
 } mjo_data;
 
 mjo_data *mjo_make_data(const mjb_model_desc *m); /* mj_makeData  */

@@ -52,7 +52,7 @@ mjo_data *mjo_make_data(const mjb_model_desc *m)
 	ALLOC(scratch_nv, m->nv)
 	ALLOC(scratch_nv2, m->nv)
 	ALLOC(rk_warmstart, m->nv)
-	ALLOC(rk_buf, m->nq + 5 * m->nv + m->nsensordata + 1)
+	ALLOC(rk_buf, m->nq + 5 * m->nv + m->nsensordata + 1 + 2 * m->na)
 #undef ALLOC
 	mjo_reset_data(m, d);
 	return d;
@@ -478,6 +478,7 @@ void mjo_fwd_actuation(const mjb_model_desc *m, mjo_data *d)
 	memset(d->qfrc_actuator, 0, sizeof(double) * (size_t)m->nv);
 	if (m->nu == 0 || (m->disableflags & MJB_DSBL_ACTUATION)) {
 		memset(d->actuator_force, 0, sizeof(double) * (size_t)m->nu);
+		memset(d->act_dot, 0, sizeof(double) * (size_t)m->na);  /* (mj_fwdActuation clears act_dot before it returns early) */
 		return;
 	}
 	for (int i = 0; i < m->nu; i++) {
@@ -492,7 +493,18 @@ void mjo_fwd_actuation(const mjb_model_desc *m, mjo_data *d)
 			gain = gp[0] + gp[1] * d->actuator_length[i] + gp[2] * d->actuator_velocity[i];
 		if (m->actuator_biastype[i] == MJB_BIAS_AFFINE)
 			bias = bp[0] + bp[1] * d->actuator_length[i] + bp[2] * d->actuator_velocity[i];
-		double force = gain * ctrl + bias;
+		/* stateful actuators (mj_fwdActuation): act_dot from the clamped ctrl, and the gain multiplies the ACTIVATION */
+		double input = ctrl;
+		const int ja = m->na > 0 ? m->actuator_actadr[i] : -1;
+		if (ja >= 0) {
+			if (m->actuator_dyntype[i] == MJB_DYN_INTEGRATOR) d->act_dot[ja] = ctrl;
+			else {
+				const double tau = m->actuator_dynprm[3 * i] > MJO_MINVAL ? m->actuator_dynprm[3 * i] : MJO_MINVAL;
+				d->act_dot[ja] = (ctrl - d->act[ja]) / tau;
+			}
+			input = d->act[ja];
+		}
+		double force = gain * input + bias;
 		if (m->actuator_forcelimited[i]) {
 			const double *r = m->actuator_forcerange + 2 * i;
 			force = force < r[0] ? r[0] : (force > r[1] ? r[1] : force);
@@ -996,6 +1008,21 @@ static void integrate_pos(const mjb_model_desc *m, double *qpos, const double *q
 	}
 }
 
+/* mj_advance, activations: act += h act_dot, clamped to actrange when the actuator is actlimited */
+static void advance_act(const mjb_model_desc *m, double *act, const double *act_dot, double dt)
+{
+	if (m->na <= 0) return;
+	for (int i = 0; i < m->nu; i++) {
+		const int j = m->actuator_actadr[i];
+		if (j < 0) continue;
+		act[j] += dt * act_dot[j];
+		if (m->actuator_actlimited[i]) {
+			const double lo = m->actuator_actrange[2 * i], hi = m->actuator_actrange[2 * i + 1];
+			act[j] = act[j] < lo ? lo : (act[j] > hi ? hi : act[j]);
+		}
+	}
+}
+
 void mjo_euler(const mjb_model_desc *m, mjo_data *d)
 {
 	int nv = m->nv;
@@ -1016,6 +1043,7 @@ void mjo_euler(const mjb_model_desc *m, mjo_data *d)
 		solve_ld(m, qacc, qH, qHDiagInv);
 	}
 	/* mj_advance */
+	advance_act(m, d->act, d->act_dot, dt);
 	for (int i = 0; i < nv; i++) d->qvel[i] += dt * qacc[i];
 	integrate_pos(m, d->qpos, d->qvel, dt);
 	d->time[0] += dt;
@@ -1140,9 +1168,9 @@ void mjo_forward(const mjb_model_desc *m, mjo_data *d)
  * derivative a_i F_{i-1} (positions through mj_integratePos, i.e. quaternions on the sphere), at time t0 + c_i h, evaluated by
  * mj_forwardSkip(.., mjSTAGE_NONE, skipsensor = 1); the step then advances X0 by h with sum_j B_j F_j (mj_advance with an explicit
  * velocity).  The constraint solver's warmstart is the one saved by the previous step's mj_advance for every evaluation, and the
- * last evaluation's qacc becomes the next one.  (No activations: na == 0 in everything this engine loads.) */
+ * last evaluation's qacc becomes the next one.  Activations are part of X (act) and F (act_dot); only the final advance clamps them. */
 typedef struct {
-	double *q0, *v0, *accv, *acca, *dxv, *sens, *t0;
+	double *q0, *v0, *accv, *acca, *dxv, *sens, *t0, *a0, *acct;  /* a0: act at X0; acct: sum B act_dot */
 } rk4_state;
 static const double RK_A[3] = { 0.5, 0.5, 1.0 }, RK_B[4] = { 1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0 }, RK_C[3] = { 0.5, 0.5, 1.0 };
 
@@ -1156,6 +1184,8 @@ static rk4_state rk4_view(const mjb_model_desc *m, double *buf)
 	S.dxv = S.acca + 2 * m->nv;  /* (one nv block kept free where the kernel parks the warmstart) */
 	S.sens = S.dxv + m->nv;
 	S.t0 = S.sens + m->nsensordata;
+	S.a0 = S.t0 + 1;
+	S.acct = S.a0 + m->na;
 	return S;
 }
 
@@ -1171,6 +1201,10 @@ static void rk4_begin(const mjb_model_desc *m, mjo_data *d, rk4_state S)
 		S.accv[k] = 0.0 + RK_B[0] * d->qvel[k];
 		S.acca[k] = 0.0 + RK_B[0] * d->qacc[k];
 	}
+	for (int k = 0; k < m->na; k++) {
+		S.a0[k] = d->act[k];
+		S.acct[k] = 0.0 + RK_B[0] * d->act_dot[k];
+	}
 }
 
 /* X_i = X0 (+) h a_i F_{i-1}; the warmstart every evaluation of this step starts from is the one the step came in with --
@@ -1184,6 +1218,7 @@ static void rk4_set_stage(const mjb_model_desc *m, mjo_data *d, rk4_state S, int
 	memcpy(d->qpos, S.q0, sizeof(double) * (size_t)nq);
 	integrate_pos(m, d->qpos, S.dxv, h);
 	for (int k = 0; k < nv; k++) d->qvel[k] = S.v0[k] + h * (0.0 + RK_A[i - 1] * qa[k]);
+	for (int k = 0; k < m->na; k++) d->act[k] = S.a0[k] + h * (0.0 + RK_A[i - 1] * d->act_dot[k]);
 	d->time[0] = S.t0[0] + RK_C[i - 1] * h;
 	memcpy(d->qacc_warmstart, d->rk_warmstart, sizeof(double) * (size_t)nv);
 }
@@ -1194,6 +1229,7 @@ static void rk4_accumulate(const mjb_model_desc *m, mjo_data *d, rk4_state S, in
 		S.accv[k] += RK_B[i] * d->qvel[k];
 		S.acca[k] += RK_B[i] * d->qacc[k];
 	}
+	for (int k = 0; k < m->na; k++) S.acct[k] += RK_B[i] * d->act_dot[k];
 }
 
 static void rk4_finish(const mjb_model_desc *m, mjo_data *d, rk4_state S)
@@ -1203,6 +1239,8 @@ static void rk4_finish(const mjb_model_desc *m, mjo_data *d, rk4_state S)
 	memcpy(d->qpos, S.q0, sizeof(double) * (size_t)nq);
 	for (int k = 0; k < nv; k++) d->qvel[k] = S.v0[k] + h * S.acca[k];
 	integrate_pos(m, d->qpos, S.accv, h);
+	memcpy(d->act, S.a0, sizeof(double) * (size_t)m->na);
+	advance_act(m, d->act, S.acct, h);
 	d->time[0] = S.t0[0] + h;
 	memcpy(d->sensordata, S.sens, sizeof(double) * (size_t)ns);  /* (sensors are skipped in the sub-stage evaluations) */
 }
