@@ -35,7 +35,11 @@ extern "C" {
 /* MuJoCo 2.3.7 enum values used in mjb_model_desc (mjtJoint, mjtGeom, ...) */
 enum { MJB_JNT_FREE = 0, MJB_JNT_BALL = 1, MJB_JNT_SLIDE = 2, MJB_JNT_HINGE = 3 };
 enum { MJB_GEOM_PLANE = 0, MJB_GEOM_SPHERE = 2, MJB_GEOM_CAPSULE = 3, MJB_GEOM_BOX = 6 };
-enum { MJB_INT_EULER = 0, MJB_INT_RK4 = 1 };  /* mjtIntegrator (mjINT_EULER, mjINT_RK4); the implicit integrators are refused */
+enum { MJB_INT_EULER = 0, MJB_INT_RK4 = 1, MJB_INT_IMPLICIT = 2, MJB_INT_IMPLICITFAST = 3 };
+/* mjtIntegrator.  implicitfast: qacc = (M - h D)^-1 (qfrc_smooth + qfrc_constraint) with D = d qfrc_smooth / d qvel without the Coriolis terms
+ * (mjd_passive_vel + mjd_actuator_vel) -- accepted when D is a model constant and diagonal: joint damping, and the velocity terms of affine
+ * actuator biases on joint transmissions (a velocity term in an affine GAIN, or tendon damping, makes mjb_compile refuse it).  mjINT_IMPLICIT
+ * (the Coriolis derivatives, an LU factor) is refused. */
 enum { MJB_CONE_PYRAMIDAL = 0, MJB_CONE_ELLIPTIC = 1 };
 enum { MJB_SOL_PGS = 0, MJB_SOL_CG = 1, MJB_SOL_NEWTON = 2 };
 enum { MJB_GAIN_FIXED = 0, MJB_GAIN_AFFINE = 1 };

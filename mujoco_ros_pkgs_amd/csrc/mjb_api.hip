@@ -84,6 +84,7 @@ struct mjb_model {
 	std::vector<double> pair_d;    // [ncollpair][24] size1[3] size2[3] margin gap rbound1 rbound2 solref[2] solimp[5] includemargin friction[3] tran pad[2]
 	std::vector<double> sub_S;     // 0/1 subtree matrix as MFMA A operands (mjb_dev.h)
 	std::vector<double> lim_d;     // [njnt + ntendon][24] limit items in pair_d's slots (mjb_dev.h)
+	std::vector<double> damp_int;  // [nv] -diag(D) of the integrator's implicit matrix M + h diag(.): dof_damping (Euler) / implicitfast's constant velocity derivative
 	std::vector<int> lim_i;        // [njnt + ntendon][4]
 	int sens_ncopy[3] = { 0, 0, 0 }, sens_nslow[3] = { 0, 0, 0 }, sens_ncopy_max = 0;
 	int eulerdamp = 0, maxdepth = 0, kin_rounds = 0, need_rnepost = 0, nfriction = 0, sub_nt = 0, dofanc_max = 0, flv_n = 0;
@@ -718,8 +719,8 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 			return nullptr;
 		}
 	}
-	if (d.integrator != MJB_INT_EULER && d.integrator != MJB_INT_RK4) {
-		fail(MJB_EUNSUPPORTED, "mjb_compile: only the Euler and RK4 integrators are implemented");
+	if (d.integrator != MJB_INT_EULER && d.integrator != MJB_INT_RK4 && d.integrator != MJB_INT_IMPLICITFAST) {
+		fail(MJB_EUNSUPPORTED, "mjb_compile: integrators Euler, RK4 and implicitfast are implemented (implicit is refused)");
 		return nullptr;
 	}
 	if (!(d.timestep[0] > 0)) {
@@ -1183,7 +1184,29 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		mjb_lane_env_tape(&h, M->le_tape.data());
 	}
 	M->eulerdamp = 0;
-	if (!(h.disableflags & MJB_DSBL_EULERDAMP))
+	M->damp_int.assign(h.dof_damping, h.dof_damping + h.nv);
+	if (h.integrator == MJB_INT_IMPLICITFAST) {
+		// mj_implicit, mjINT_IMPLICITFAST: qH = M - h D, D = mjd_passive_vel + mjd_actuator_vel; a model constant on the diagonal here
+		for (int t = 0; t < h.ntendon; t++)
+			if (h.tendon_damping[t] != 0) {
+				fail(MJB_EUNSUPPORTED, "mjb_compile: integrator implicitfast with tendon damping is not supported");
+				delete M;
+				return nullptr;
+			}
+		for (int i = 0; i < h.nv; i++) M->damp_int[i] = (h.disableflags & MJB_DSBL_PASSIVE) ? 0.0 : h.dof_damping[i];
+		for (int i = 0; i < h.nu; i++) {
+			if (h.actuator_gaintype[i] == MJB_GAIN_AFFINE && h.actuator_gainprm[3 * i + 2] != 0) {
+				fail(MJB_EUNSUPPORTED, "mjb_compile: integrator implicitfast with a velocity term in an affine actuator gain is not supported");
+				delete M;
+				return nullptr;
+			}
+			if (h.disableflags & MJB_DSBL_ACTUATION) continue;
+			const double bv = h.actuator_biastype[i] == MJB_BIAS_AFFINE ? h.actuator_biasprm[3 * i + 2] : 0.0, g = h.actuator_gear[6 * i];
+			M->damp_int[h.jnt_dofadr[h.actuator_trnid[2 * i]]] -= g * g * bv;
+		}
+		for (int i = 0; i < h.nv; i++)
+			if (M->damp_int[i] != 0) M->eulerdamp = 1;
+	} else if (!(h.disableflags & MJB_DSBL_EULERDAMP))
 		for (int i = 0; i < h.nv; i++)
 			if (h.dof_damping[i] > 0) M->eulerdamp = 1;
 	M->nfriction = 0;
@@ -1436,7 +1459,8 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	            M->dof_act_id.size() + M->pair_i.size() + M->lim_i.size() + 104;
 	size_t bytes_i = ((ni + nt) * sizeof(int) + 15) & ~size_t(15);
 	// (the lane = env tape starts on a 64-byte boundary of the blob: wide scalar loads)
-	size_t o_tape = nd + M->pair_d.size() + M->lim_d.size() + M->sub_S.size();
+	const size_t o_damp = nd + M->pair_d.size() + M->lim_d.size() + M->sub_S.size();
+	size_t o_tape = o_damp + M->damp_int.size();
 	while ((bytes_i + o_tape * sizeof(double)) % 64) o_tape++;
 	size_t bytes = bytes_i + (o_tape + M->le_tape.size()) * sizeof(double) + 16;
 	if (hipMalloc(&b->blob, bytes) != hipSuccess) {
@@ -1464,6 +1488,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	memcpy(hd + nd, M->pair_d.data(), M->pair_d.size() * sizeof(double));
 	memcpy(hd + nd + M->pair_d.size(), M->lim_d.data(), M->lim_d.size() * sizeof(double));
 	memcpy(hd + nd + M->pair_d.size() + M->lim_d.size(), M->sub_S.data(), M->sub_S.size() * sizeof(double));
+	if (!M->damp_int.empty()) memcpy(hd + o_damp, M->damp_int.data(), M->damp_int.size() * sizeof(double));
 	if (!M->le_tape.empty()) memcpy(hd + o_tape, M->le_tape.data(), M->le_tape.size() * sizeof(double));
 	if (hipMemcpy(b->blob, hostblob.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
 		fail(MJB_ENODEVICE, "mjb_make_batch: model upload failed");
@@ -1521,6 +1546,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	dm.pair_d = (mjb_cdptr)(dd + nd);
 	dm.lim_d = (mjb_cdptr)(dd + nd + M->pair_d.size());
 	dm.sub_S = (mjb_cdptr)(dd + nd + M->pair_d.size() + M->lim_d.size());
+	dm.dof_damping_int = (mjb_cdptr)(dd + o_damp);
 	dm.sub_nt = M->sub_nt;
 	dm.le_tape = M->le_tape.empty() ? (mjb_cdptr) nullptr : (mjb_cdptr)(dd + o_tape);
 	dm.lim_i = (mjb_ciptr)(di + o_li);

@@ -924,7 +924,7 @@ template <int G, bool OBL> STAGE void crb(CModel m, CLayout L, const Env &e)
 		double v = (i == j) ? m.dof_armature[i] : 0.0;
 		v += dot6r(a, b);
 		f[L.qM + en] = v;
-		if (m.eulerdamp) f[L.MhB + en] = (i == j) ? v + m.timestep[0] * m.dof_damping[i] : v;
+		if (m.eulerdamp) f[L.MhB + en] = (i == j) ? v + m.timestep[0] * m.dof_damping_int[i] : v;
 	}
 	gsync<G>();
 	SPROF(24);
@@ -3487,7 +3487,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 				c.q_row[q] = has ? i : (m.nM <= 3 * G ? -1 : -2);
 				c.q_col[q] = j;
 				c.q_arm[q] = (has && i == j) ? m.dof_armature[i] : 0.0;
-				c.q_hd[q] = (has && i == j) ? m.timestep[0] * m.dof_damping[i] : 0.0;
+				c.q_hd[q] = (has && i == j) ? m.timestep[0] * m.dof_damping_int[i] : 0.0;
 			}
 		}
 		for (int st = 0; st < 3; st++) {  // the sensors' plain copies: {dst, src} pairs of this launch's layout, two per lane and stage

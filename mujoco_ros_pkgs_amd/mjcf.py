@@ -363,9 +363,9 @@ class _Compiler:
         if "iterations" in a:
             o["iterations"] = int(a["iterations"])
         if "integrator" in a:
-            if a["integrator"] not in ("Euler", "RK4"):
-                raise MjcfError("only the Euler and RK4 integrators are implemented (implicit / implicitfast are refused)")
-            o["integrator"] = {"Euler": 0, "RK4": 1}[a["integrator"]]
+            if a["integrator"] not in ("Euler", "RK4", "implicitfast"):
+                raise MjcfError("integrator: Euler, RK4 and implicitfast are implemented (implicit is refused)")
+            o["integrator"] = {"Euler": 0, "RK4": 1, "implicitfast": 3}[a["integrator"]]
         if "cone" in a:
             o["cone"] = {"pyramidal": 0, "elliptic": 1}[a["cone"]]
         if "solver" in a:
@@ -950,6 +950,12 @@ class _Compiler:
 
         # fixed tendons, then equality constraints (mjCEquality::Compile, [UPSTREAM] user_objects.cc): ids + eq_data at qpos0
         self._compile_tendons(m)
+        if o["integrator"] == 3:
+            # implicitfast: the engine takes a constant, diagonal velocity derivative (include/mjb.h, MJB_INT_IMPLICITFAST)
+            if np.any(np.asarray(m["tendon_damping"]) != 0):
+                raise MjcfError("integrator implicitfast with tendon damping is not supported")
+            if nu and np.any((m["actuator_gaintype"] == 1) & (m["actuator_gainprm"][:, 2] != 0)):
+                raise MjcfError("integrator implicitfast with a velocity term in an affine actuator gain (<damper>) is not supported")
         self._compile_equalities(m)
 
         # static collision candidates (restates the body/geom filters of MuJoCo's mj_collision)

@@ -1029,15 +1029,33 @@ void mjo_euler(const mjb_model_desc *m, mjo_data *d)
 	double dt = m->timestep[0];
 	double *qacc = d->scratch_nv;
 	int damping = 0;
-	if (!(m->disableflags & MJB_DSBL_EULERDAMP))
-		for (int i = 0; i < nv; i++)
-			if (m->dof_damping[i] > 0) { damping = 1; break; }
+	double *dd = d->scratch_nv2;  /* -diag(D): what the integrator treats implicitly */
+	if (m->integrator == MJB_INT_IMPLICITFAST) {
+		/* mj_implicit, mjINT_IMPLICITFAST: D = mjd_passive_vel + mjd_actuator_vel (no Coriolis terms), symmetrised; with joint dampers and
+		 * joint transmissions it is diagonal: -damping_i + gear^2 (biasprm[2] + gainprm[2] * input).  mjDSBL_EULERDAMP is not consulted. */
+		damping = 1;
+		for (int i = 0; i < nv; i++) dd[i] = (m->disableflags & MJB_DSBL_PASSIVE) ? 0.0 : m->dof_damping[i];
+		for (int i = 0; i < m->nu && !(m->disableflags & MJB_DSBL_ACTUATION); i++) {
+			double bv = m->actuator_biastype[i] == MJB_BIAS_AFFINE ? m->actuator_biasprm[3 * i + 2] : 0.0;
+			if (m->actuator_gaintype[i] == MJB_GAIN_AFFINE) {
+				const int ja = m->na > 0 ? m->actuator_actadr[i] : -1;
+				bv += m->actuator_gainprm[3 * i + 2] * (ja >= 0 ? d->act[ja] : d->ctrl[i]);
+			}
+			const double g = m->actuator_gear[6 * i];
+			dd[m->jnt_dofadr[m->actuator_trnid[2 * i]]] -= g * g * bv;
+		}
+	} else {
+		if (!(m->disableflags & MJB_DSBL_EULERDAMP))
+			for (int i = 0; i < nv; i++)
+				if (m->dof_damping[i] > 0) { damping = 1; break; }
+		for (int i = 0; i < nv; i++) dd[i] = m->dof_damping[i];
+	}
 	if (!damping) {
 		memcpy(qacc, d->qacc, sizeof(double) * (size_t)nv);
 	} else {
 		double *MhB = d->scratch_MM, *qH = d->scratch_MM + m->nM, *qHDiagInv = d->scratch_MM + 2 * m->nM;
 		memcpy(MhB, d->qM, sizeof(double) * (size_t)m->nM);
-		for (int i = 0; i < nv; i++) MhB[m->dof_Madr[i]] += dt * m->dof_damping[i];
+		for (int i = 0; i < nv; i++) MhB[m->dof_Madr[i]] += dt * dd[i];
 		factor_i(m, MhB, qH, qHDiagInv);
 		for (int i = 0; i < nv; i++) qacc[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i];
 		solve_ld(m, qacc, qH, qHDiagInv);
