@@ -183,6 +183,15 @@ def test_gpu_activations_match_oracle(oracle_built, integrator, solver, cone, co
             moved = max(moved, np.abs(np.array(d.act) - act[e]).max())
         assert moved > 1e-3
         b.close()
+    # the split step around the control-callback point (mjb_step1 / mjb_step2) is the same step, activations included
+    b = engine.Batch(cm, n)
+    b.set("qpos", qpos); b.set("qvel", qvel); b.set("ctrl", ctrl); b.set("act", act)
+    for _ in range(30):
+        b.step1()
+        b.step2()
+    for k in ("qpos", "qvel", "act"):
+        assert np.array_equal(b.get(k), got[k]), k
+    b.close()
 
 
 IFAST = """

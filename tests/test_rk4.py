@@ -40,11 +40,12 @@ def test_oracle_rk4_is_fourth_order(oracle_built):
     assert abs(t - 0.4) < 1e-12 and de_rk < 1e-3 * de_eu
 
 
-def test_mjcf_refuses_implicit_integrators():
+def test_mjcf_refuses_the_implicit_integrator():
+    """mjINT_IMPLICIT (Coriolis derivatives, LU factor) is refused; implicitfast is implemented since round 6 (tests/test_activation_states.py)."""
     from mujoco_ros_pkgs_amd import mjcf
-    for integ in ("implicit", "implicitfast"):
-        with pytest.raises(mjcf.MjcfError):
-            mjcf.compile_xml_string(PENDULUM.format(dt=0.002, integ=integ))
+    with pytest.raises(mjcf.MjcfError):
+        mjcf.compile_xml_string(PENDULUM.format(dt=0.002, integ="implicit"))
+    assert mjcf.compile_xml_string(PENDULUM.format(dt=0.002, integ="implicitfast"))["integrator"] == 3
 
 
 def _model(kind):
