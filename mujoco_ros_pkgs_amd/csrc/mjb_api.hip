@@ -909,6 +909,7 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 			else if (t >= MJB_SENS_FRAMEPOS && t <= MJB_SENS_FRAMEANGACC) cnt = objcount(h.sensor_objtype[i]);
 			else cnt = h.nsite;  // touch, accelerometer, velocimeter, gyro, force, torque
 			if (t != MJB_SENS_CLOCK && !in(h.sensor_objid[i], 0, cnt)) bad = "sensor_objid";
+			else if (t >= MJB_SENS_JOINTLIMITPOS && t <= MJB_SENS_JOINTLIMITFRC && h.jnt_type[h.sensor_objid[i]] < MJB_JNT_SLIDE) bad = "sensor_objid (joint limit sensors: hinge / slide joints)";
 			if (h.sensor_refid[i] >= 0 && !in(h.sensor_refid[i], 0, objcount(h.sensor_reftype[i]))) bad = "sensor_refid";
 			if (!in(h.sensor_dim[i], 1, 5) || h.sensor_adr[i] < 0 || h.sensor_adr[i] + h.sensor_dim[i] > h.nsensordata) bad = "sensor_adr / sensor_dim";
 			if (!in(h.sensor_needstage[i], 1, 4)) bad = "sensor_needstage";
@@ -1271,7 +1272,7 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		for (int j = 0; j < h.njnt; j++) {
 			double *r = M->lim_d.data() + 24 * j;
 			int *ri = M->lim_i.data() + 4 * j;
-			ri[0] = (h.jnt_limited[j] && h.jnt_type[j] >= MJB_JNT_SLIDE) ? 1 : 0;
+			ri[0] = !h.jnt_limited[j] ? 0 : (h.jnt_type[j] >= MJB_JNT_SLIDE ? 1 : (h.jnt_type[j] == MJB_JNT_BALL ? 2 : 0));  // (2: a ball joint's angle limit)
 			ri[1] = h.jnt_qposadr[j];
 			ri[2] = h.jnt_dofadr[j];
 			r[0] = h.jnt_range[2 * j]; r[1] = h.jnt_range[2 * j + 1]; r[6] = h.jnt_margin[j];

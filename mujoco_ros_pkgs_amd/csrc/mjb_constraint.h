@@ -1018,6 +1018,32 @@ DEVI int wave_incl_scan(int v, int lane)
 // LICM off it is neutral there.)
 template <int TAG> DEVI int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// A limited BALL joint (mj_instantiateLimit): the rotation angle of the joint quaternion -- mju_quat2Vel(., 1), the angle in (-pi, pi] times the axis, then
+// mju_normalize3 -- against max(range); one row, Jacobian = minus the unit axis on the joint's three dofs.  Out of line: the hinge / slide path of
+// make_constraint keeps its registers, and the trigonometry is only in the instruction stream of the wavefronts that meet such a joint.
+__device__ __attribute__((noinline)) double ball_limit_angle(const double *q, double *aa)
+{
+	double ax[3] = { q[1], q[2], q[3] };
+	const double sn = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+	if (sn < MJB_MINVAL) {
+		ax[0] = 1; ax[1] = 0; ax[2] = 0;
+	} else {
+		const double r = 1 / sn;
+		ax[0] *= r; ax[1] *= r; ax[2] *= r;
+	}
+	double speed = 2 * atan2(sn, q[0]);
+	if (speed > 3.14159265358979323846) speed -= 2 * 3.14159265358979323846;
+	for (int k = 0; k < 3; k++) aa[k] = ax[k] * speed;
+	const double n = sqrt(aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2]);
+	if (n < MJB_MINVAL) {
+		aa[0] = 1; aa[1] = 0; aa[2] = 0;
+	} else {
+		const double r = 1 / n;
+		aa[0] *= r; aa[1] *= r; aa[2] *= r;
+	}
+	return n;
+}
+
 // TAG 4 (Newton, up to 256 rows, fused step): the frame holds the first L.jrows rows of efc_J only -- what lets two envs of
 // config 5 share a CU's LDS.  Rows beyond go to the env's block of s.efc_Jg in HBM; an env-step that ends up with more than
 // L.jrows rows (none of config 5's do) copies the leading rows there as well and the solver reads ALL of J from HBM.
@@ -1115,7 +1141,12 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 			} else if (it < neq + nfr) {
 				n = (it < neq + nfd ? m.dof_frictionloss[it - neq] : m.tendon_frictionloss[it - neq - nfd]) > 0 ? 1 : 0;
 			} else if (it < neq + nfr + m.njnt + nten) {
-				if (do_lim && lim_on) {  // (a limited slide / hinge joint, or a limited tendon)
+				if (do_lim && lim_on == 2) {  // (a limited ball joint: one row when the rotation angle comes within the margin of max(range))
+					MJB_KEEP_BRANCH();
+					double aa[3];
+					const double value = ball_limit_angle(f + L.qpos + lim_q, aa);
+					if (fmax(rc0, rc1) - value < rc6) n = 1;
+				} else if (do_lim && lim_on) {  // (a limited slide / hinge joint, or a limited tendon)
 					const double value = it < neq + nfr + m.njnt ? f[L.qpos + lim_q] : f[L.ten_length + lim_q], margin = rc6;
 					if (value - rc0 < margin) n++;
 					if (rc1 - value < margin) n++;
@@ -1239,6 +1270,20 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 			const bool isj = it < neq + nfr + m.njnt;
 			const int j = isj ? it - neq - nfr : it - neq - nfr - m.njnt;
 			idv = j;
+			if (lim_on == 2) {  // ball joint: row = -axis on its three dofs, pos = max(range) - angle
+				MJB_KEEP_BRANCH();
+				double aa[3];
+				const double ang = ball_limit_angle(f + L.qpos + lim_q, aa);
+				double *row = jrow(off);
+				for (int k = 0; k < nv; k++) row[k] = 0;
+				for (int k = 0; k < 3; k++) row[lim_d + k] = -aa[k];
+				imarg = rc6;
+				solref[0] = rcs[0];
+				solref[1] = rcs[1];
+				for (int k = 0; k < 5; k++) solimp[k] = rcs[2 + k];
+				diag[0] = e.mp ? MP_DOF_INVW(m, e, lim_d) : rc21;
+				ipos = fmax(rc0, rc1) - ang;
+			} else {
 			const double value = isj ? f[L.qpos + lim_q] : f[L.ten_length + j];
 			imarg = rc6;
 			const double rng[2] = { rc0, rc1 };
@@ -1261,6 +1306,7 @@ template <int G, int TAG> STAGE void make_constraint(CModel m, CLayout L, CState
 			}
 			ipos = dlo < imarg ? dlo : dhi;
 			dist2 = dhi;
+			}
 		} else {
 			const int c = it - neq - nfr - m.njnt - nten;
 			idv = c;

@@ -973,9 +973,13 @@ class _Compiler:
         nlimit = 0
         for j in range(njnt):
             if m["jnt_limited"][j]:
-                if jnt_type[j] < JNT_SLIDE:
-                    raise MjcfError("joint limits are only supported on hinge / slide joints")
                 r = m["jnt_range"][j]
+                if jnt_type[j] == JNT_BALL:
+                    # a ball joint's limit is on its rotation angle, against max(range): one row (mj_instantiateLimit)
+                    if max(r[0], r[1]) <= 0:
+                        raise MjcfError("a limited ball joint needs a positive range[1] (its maximum rotation angle)")
+                    nlimit += 1
+                    continue
                 nlimit += 1 if (r[1] - r[0]) > 2 * m["jnt_margin"][j] else 2
         for t in range(m["ntendon"]):
             if m["tendon_limited"][t]:

@@ -879,10 +879,33 @@ void mjo_make_constraint(const mjb_model_desc *m, mjo_data *d)
 			nefc++;
 		}
 	}
-	/* joint limits (mj_instantiateLimit), hinge / slide */
+	/* joint limits (mj_instantiateLimit): hinge / slide, and ball joints (the rotation angle against max(range)) */
 	if (!(m->disableflags & MJB_DSBL_LIMIT)) {
 		for (int j = 0; j < m->njnt; j++) {
-			if (!m->jnt_limited[j] || m->jnt_type[j] < MJB_JNT_SLIDE) continue;
+			if (!m->jnt_limited[j] || m->jnt_type[j] == MJB_JNT_FREE) continue;
+			if (m->jnt_type[j] == MJB_JNT_BALL) {
+				/* axis-angle of the joint quaternion (mju_quat2Vel with dt = 1: the angle in (-pi, pi]), value = its norm, ONE row whose
+				 * Jacobian is minus the unit axis on the joint's three dofs */
+				double aa[3], margin = m->jnt_margin[j];
+				double value = mjo_ball_angle(d->qpos + m->jnt_qposadr[j], aa);
+				double r0 = m->jnt_range[2 * j], r1 = m->jnt_range[2 * j + 1];
+				double dist = (r0 > r1 ? r0 : r1) - value;
+				if (!(dist < margin) || full) continue;
+				if (nefc + 1 > m->nefcmax) {
+					full = 1;
+					continue;
+				}
+				double *row = d->efc_J + (size_t)nefc * nv;
+				memset(row, 0, sizeof(double) * (size_t)nv);
+				for (int k = 0; k < 3; k++) row[m->jnt_dofadr[j] + k] = -aa[k];
+				d->efc_pos[nefc] = dist;
+				d->efc_margin[nefc] = margin;
+				d->efc_type[nefc] = MJB_CNSTR_LIMIT_JOINT;
+				d->efc_id[nefc] = j;
+				row_params(m, d, nefc, m->jnt_solref + 2 * j, m->jnt_solimp + 5 * j, m->dof_invweight0[m->jnt_dofadr[j]]);
+				nefc++;
+				continue;
+			}
 			double value = d->qpos[m->jnt_qposadr[j]], margin = m->jnt_margin[j];
 			int nside = (value - m->jnt_range[2 * j] < margin) + (m->jnt_range[2 * j + 1] - value < margin);
 			if (nside == 0 || full) continue;

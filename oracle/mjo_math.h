@@ -139,6 +139,17 @@ static inline void q_sub(double *res, const double *qa, const double *qb)
 	if (speed > 3.14159265358979323846) speed -= 2 * 3.14159265358979323846;
 	v3_scl(res, axis, speed);
 }
+/* the rotation angle of a ball joint and its unit axis, as mj_instantiateLimit takes them: mju_quat2Vel(aa, quat, 1) -- the angle in (-pi, pi]
+ * times the axis -- then mju_normalize3: the angle's magnitude is returned, aa becomes the (sign-adjusted) unit axis, (1, 0, 0) at zero rotation */
+static inline double mjo_ball_angle(const double *quat, double *aa)
+{
+	double axis[3] = { quat[1], quat[2], quat[3] };
+	double sin_a_2 = v3_normalize(axis);
+	double speed = 2 * atan2(sin_a_2, quat[0]);
+	if (speed > 3.14159265358979323846) speed -= 2 * 3.14159265358979323846;
+	v3_scl(aa, axis, speed);
+	return v3_normalize(aa);
+}
 /* 3x3 products: r = A B, r = A' B, r = A B' */
 static inline void m3_mul(double *r, const double *A, const double *B)
 {
