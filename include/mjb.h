@@ -44,7 +44,7 @@ enum { MJB_CONE_PYRAMIDAL = 0, MJB_CONE_ELLIPTIC = 1 };
 enum { MJB_SOL_PGS = 0, MJB_SOL_CG = 1, MJB_SOL_NEWTON = 2 };
 enum { MJB_GAIN_FIXED = 0, MJB_GAIN_AFFINE = 1 };
 enum { MJB_BIAS_NONE = 0, MJB_BIAS_AFFINE = 1 };
-enum { MJB_TRN_JOINT = 0 };
+enum { MJB_TRN_JOINT = 0, MJB_TRN_TENDON = 3 };  /* mjtTrn: joint and (fixed) tendon transmissions; jointinparent / slidercrank / site are refused */
 enum { MJB_DYN_NONE = 0, MJB_DYN_INTEGRATOR = 1, MJB_DYN_FILTER = 2 };  /* mjtDyn (mjDYN_MUSCLE = 3, mjDYN_USER = 4 are refused) */
 enum { /* mjtDisableBit */
 	MJB_DSBL_CONSTRAINT = 1 << 0, MJB_DSBL_EQUALITY = 1 << 1, MJB_DSBL_FRICTIONLOSS = 1 << 2,

@@ -84,6 +84,8 @@ struct mjb_model {
 	std::vector<double> pair_d;    // [ncollpair][24] size1[3] size2[3] margin gap rbound1 rbound2 solref[2] solimp[5] includemargin friction[3] tran pad[2]
 	std::vector<double> sub_S;     // 0/1 subtree matrix as MFMA A operands (mjb_dev.h)
 	std::vector<double> lim_d;     // [njnt + ntendon][24] limit items in pair_d's slots (mjb_dev.h)
+	std::vector<double> dof_act_mom;  // moment arm of entry t of the per-dof actuator lists (dof_act_adr / dof_act_id)
+	int act_tendon = 0;               // some actuator drives a tendon
 	std::vector<double> damp_int;  // [nv] -diag(D) of the integrator's implicit matrix M + h diag(.): dof_damping (Euler) / implicitfast's constant velocity derivative
 	std::vector<int> lim_i;        // [njnt + ntendon][4]
 	int sens_ncopy[3] = { 0, 0, 0 }, sens_nslow[3] = { 0, 0, 0 }, sens_ncopy_max = 0;
@@ -959,8 +961,10 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 	}
 	for (int i = 0; i < h.nu; i++) {
 		int j = h.actuator_trnid[2 * i];
-		if (h.actuator_trntype[i] != MJB_TRN_JOINT || j < 0 || j >= h.njnt || h.jnt_type[j] < MJB_JNT_SLIDE) {
-			fail(MJB_EUNSUPPORTED, "mjb_compile: actuator %d: only joint transmission on hinge/slide joints is supported", i);
+		const bool okj = h.actuator_trntype[i] == MJB_TRN_JOINT && j >= 0 && j < h.njnt && h.jnt_type[j] >= MJB_JNT_SLIDE;
+		const bool okt = h.actuator_trntype[i] == MJB_TRN_TENDON && j >= 0 && j < h.ntendon;
+		if (!okj && !okt) {
+			fail(MJB_EUNSUPPORTED, "mjb_compile: actuator %d: joint transmission on hinge / slide joints and fixed-tendon transmission are supported", i);
 			delete M;
 			return nullptr;
 		}
@@ -1203,6 +1207,14 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 			}
 			if (h.disableflags & MJB_DSBL_ACTUATION) continue;
 			const double bv = h.actuator_biastype[i] == MJB_BIAS_AFFINE ? h.actuator_biasprm[3 * i + 2] : 0.0, g = h.actuator_gear[6 * i];
+			if (h.actuator_trntype[i] == MJB_TRN_TENDON) {
+				if (bv != 0) {  // (moment' bv moment couples the tendon's joints: not diagonal)
+					fail(MJB_EUNSUPPORTED, "mjb_compile: integrator implicitfast with a velocity-dependent actuator on a tendon is not supported");
+					delete M;
+					return nullptr;
+				}
+				continue;
+			}
 			M->damp_int[h.jnt_dofadr[h.actuator_trnid[2 * i]]] -= g * g * bv;
 		}
 		for (int i = 0; i < h.nv; i++)
@@ -1296,12 +1308,30 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 	build_sensor_tables(M);
 	// actuators per dof (CSR, ascending actuator id)
 	M->dof_act_adr.assign((size_t)h.nv + 1, 0);
-	for (int i = 0; i < h.nu; i++) M->dof_act_adr[h.jnt_dofadr[h.actuator_trnid[2 * i]] + 1]++;
+	// (one entry per (dof, actuator) with the actuator's moment arm on that dof: gear for a joint transmission, gear * coefficient for every
+	//  joint of a fixed tendon)
+	M->act_tendon = 0;
+	auto each_arm = [&](auto &&fn) {
+		for (int i = 0; i < h.nu; i++) {
+			const int id = h.actuator_trnid[2 * i];
+			if (h.actuator_trntype[i] == MJB_TRN_TENDON) {
+				M->act_tendon = 1;
+				for (int w = h.tendon_adr[id]; w < h.tendon_adr[id] + h.tendon_num[id]; w++)
+					fn(h.jnt_dofadr[h.wrap_objid[w]], i, h.actuator_gear[6 * i] * h.wrap_prm[w]);
+			} else
+				fn(h.jnt_dofadr[id], i, h.actuator_gear[6 * i]);
+		}
+	};
+	each_arm([&](int dof, int, double) { M->dof_act_adr[dof + 1]++; });
 	for (int dd = 0; dd < h.nv; dd++) M->dof_act_adr[dd + 1] += M->dof_act_adr[dd];
-	M->dof_act_id.assign((size_t)h.nu, 0);
+	M->dof_act_id.assign((size_t)M->dof_act_adr[h.nv], 0);
+	M->dof_act_mom.assign((size_t)M->dof_act_adr[h.nv], 0.0);
 	{
 		std::vector<int> fill(M->dof_act_adr.begin(), M->dof_act_adr.end() - 1);
-		for (int i = 0; i < h.nu; i++) M->dof_act_id[fill[h.jnt_dofadr[h.actuator_trnid[2 * i]]]++] = i;
+		each_arm([&](int dof, int i, double arm) {
+			M->dof_act_id[fill[dof]] = i;
+			M->dof_act_mom[fill[dof]++] = arm;
+		});
 	}
 	{
 		const int frame_bytes = ((M->L.ndouble * 8 + M->L.nint * 4) + 15) & ~15;
@@ -1461,7 +1491,8 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	size_t bytes_i = ((ni + nt) * sizeof(int) + 15) & ~size_t(15);
 	// (the lane = env tape starts on a 64-byte boundary of the blob: wide scalar loads)
 	const size_t o_damp = nd + M->pair_d.size() + M->lim_d.size() + M->sub_S.size();
-	size_t o_tape = o_damp + M->damp_int.size();
+	const size_t o_mom = o_damp + M->damp_int.size();
+	size_t o_tape = o_mom + M->dof_act_mom.size();
 	while ((bytes_i + o_tape * sizeof(double)) % 64) o_tape++;
 	size_t bytes = bytes_i + (o_tape + M->le_tape.size()) * sizeof(double) + 16;
 	if (hipMalloc(&b->blob, bytes) != hipSuccess) {
@@ -1490,6 +1521,7 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	memcpy(hd + nd + M->pair_d.size(), M->lim_d.data(), M->lim_d.size() * sizeof(double));
 	memcpy(hd + nd + M->pair_d.size() + M->lim_d.size(), M->sub_S.data(), M->sub_S.size() * sizeof(double));
 	if (!M->damp_int.empty()) memcpy(hd + o_damp, M->damp_int.data(), M->damp_int.size() * sizeof(double));
+	if (!M->dof_act_mom.empty()) memcpy(hd + o_mom, M->dof_act_mom.data(), M->dof_act_mom.size() * sizeof(double));
 	if (!M->le_tape.empty()) memcpy(hd + o_tape, M->le_tape.data(), M->le_tape.size() * sizeof(double));
 	if (hipMemcpy(b->blob, hostblob.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
 		fail(MJB_ENODEVICE, "mjb_make_batch: model upload failed");
@@ -1548,6 +1580,8 @@ mjb_batch *mjb_make_batch(const mjb_model *M, int nenv, int device)
 	dm.lim_d = (mjb_cdptr)(dd + nd + M->pair_d.size());
 	dm.sub_S = (mjb_cdptr)(dd + nd + M->pair_d.size() + M->lim_d.size());
 	dm.dof_damping_int = (mjb_cdptr)(dd + o_damp);
+	dm.dof_act_mom = (mjb_cdptr)(dd + o_mom);
+	dm.act_tendon = M->act_tendon;
 	dm.sub_nt = M->sub_nt;
 	dm.le_tape = M->le_tape.empty() ? (mjb_cdptr) nullptr : (mjb_cdptr)(dd + o_tape);
 	dm.lim_i = (mjb_ciptr)(di + o_li);

@@ -53,6 +53,8 @@ struct DevModel {
 	// limit, with one batch of unconditional loads before the kinds diverge: [0..1] range, [6] margin, [10..11] solref, [12..16] solimp,
 	// [21] dof_invweight0 / tendon_invweight0;  lim_i [4]: limited (and slide / hinge), qpos address (tendon: its id), dof address, pad
 	mjb_cdptr lim_d;         // [njnt + ntendon][24]
+	mjb_cdptr dof_act_mom;   // [dof_act_adr[nv]] moment arm of each (dof, actuator) entry: gear (joint transmission) / gear * coefficient (tendon transmission)
+	int act_tendon;          // some actuator drives a fixed tendon (the per-actuator lane caches of the dense kernels stand down)
 	mjb_cdptr dof_damping_int;  // [nv] what the integrator's implicit matrix adds to M's diagonal, per unit of h: dof_damping (Euler), -diag(D) (implicitfast)
 	mjb_ciptr lim_i;         // [njnt + ntendon][4]
 	int sens_ncopy[3];       // plain-copy elements per stage

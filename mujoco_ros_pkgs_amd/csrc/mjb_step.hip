@@ -1622,12 +1622,15 @@ template <int G> DEVI void solve_tri32(CModel m, const Env &e, double *x, const 
 template <int G, bool CACHE = false> STAGE void transmission(CModel m, CLayout L, const Env &e)
 {
 	if constexpr (CACHE) {
-		if (e.lane < m.nu) e.f[L.actuator_length + e.lane] = e.f[L.qpos + e.lc.u_qa] * e.lc.u_gear;
-		return;
+		if (!m.act_tendon) {
+			if (e.lane < m.nu) e.f[L.actuator_length + e.lane] = e.f[L.qpos + e.lc.u_qa] * e.lc.u_gear;
+			return;
+		}
 	}
 	for (int i = e.lane; i < m.nu; i += G) {
 		const int j = m.actuator_trnid[2 * i];
-		e.f[L.actuator_length + i] = e.f[L.qpos + m.jnt_qposadr[j]] * m.actuator_gear[6 * i];
+		if (m.act_tendon && m.actuator_trntype[i] == MJB_TRN_TENDON) e.f[L.actuator_length + i] = e.f[L.ten_length + j] * m.actuator_gear[6 * i];  // (mj_tendon ran in com_pos)
+		else e.f[L.actuator_length + i] = e.f[L.qpos + m.jnt_qposadr[j]] * m.actuator_gear[6 * i];
 	}
 }
 
@@ -1722,12 +1725,18 @@ template <int G, bool OBL> STAGE void com_vel(CModel m, CLayout L, const Env &e)
 		}
 		st6(f + L.cdof_dot + 6 * d, r);
 	}
-	if constexpr (OBL) {
+	if (OBL && !m.act_tendon) {
 		if (lane < m.nu) f[L.actuator_velocity + lane] = e.lc.u_gear * qvel[e.lc.u_da];
 	} else {
 		for (int i = lane; i < m.nu; i += G) {
 			const int j = m.actuator_trnid[2 * i];
-			f[L.actuator_velocity + i] = m.actuator_gear[6 * i] * qvel[m.jnt_dofadr[j]];
+			if (m.act_tendon && m.actuator_trntype[i] == MJB_TRN_TENDON) {  // moment . qvel, moment = gear * the tendon's coefficients
+				double v = 0;
+				for (int w = m.tendon_adr[j]; w < m.tendon_adr[j] + m.tendon_num[j]; w++)
+					v += m.actuator_gear[6 * i] * m.wrap_prm[w] * qvel[m.jnt_dofadr[m.wrap_objid[w]]];
+				f[L.actuator_velocity + i] = v;
+			} else
+				f[L.actuator_velocity + i] = m.actuator_gear[6 * i] * qvel[m.jnt_dofadr[j]];
 		}
 	}
 	gsync<G>();
@@ -2529,7 +2538,7 @@ template <int G, bool CACHE = false> STAGE void fwd_actuation(CModel m, CLayout 
 					const double lo = m.actuator_forcerange[2 * i], hi = m.actuator_forcerange[2 * i + 1];
 					force = force < lo ? lo : (force > hi ? hi : force);
 				}
-				acc += m.actuator_gear[6 * i] * force;
+				acc += m.dof_act_mom[t] * force;
 			}
 			f[L.actuator_force + i] = force;
 		}
@@ -3412,7 +3421,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 		c.d_bmhi = m.nv ? (unsigned int)m.dof_bodymask[2 * dd + 1] : 0u;
 		{  // lane = actuator
 			const int i = (m.nu && e.lane < m.nu) ? (int)e.lane : 0;
-			const int tj = m.nu ? m.actuator_trnid[2 * i] : 0;
+			const int tj = (m.nu && m.actuator_trntype[i] == MJB_TRN_JOINT) ? m.actuator_trnid[2 * i] : 0;  // (tendon transmissions do not use this cache: m.act_tendon)
 			c.u_qa = m.nu ? m.jnt_qposadr[tj] : 0;
 			c.u_da = m.nu ? m.jnt_dofadr[tj] : 0;
 			c.u_gear = m.nu ? m.actuator_gear[6 * i] : 0.0;
@@ -3436,7 +3445,7 @@ __global__ void __launch_bounds__(256, (CON >= 6 ? 2 : (CON ? MJB_DEV_OCC : (G =
 			}
 			c.a_flo = has ? m.actuator_forcerange[2 * i] : 0.0;
 			c.a_fhi = has ? m.actuator_forcerange[2 * i + 1] : 0.0;
-			c.a_gear = has ? m.actuator_gear[6 * i] : 0.0;
+			c.a_gear = has ? m.dof_act_mom[t0] : 0.0;
 		}
 		{  // lane = joint
 			const int jj = (m.njnt && e.lane < m.njnt) ? (int)e.lane : 0;

@@ -563,9 +563,9 @@ class _Compiler:
     def _actuator(self, node):
         a = self._merged(node, None)
         t = node.tag
-        if "joint" not in a:
-            raise MjcfError(f"actuator <{t}> needs joint transmission (only joint transmission supported)")
-        act = dict(name=a.get("name", f"actuator{len(self.actuators)}"), joint=a["joint"])
+        if ("joint" in a) == ("tendon" in a):
+            raise MjcfError(f"actuator <{t}> needs exactly one of joint= / tendon= (joint and fixed-tendon transmissions are supported)")
+        act = dict(name=a.get("name", f"actuator{len(self.actuators)}"), joint=a.get("joint"), tendon=a.get("tendon"))
         gear = np.zeros(6)
         gv = _floats(a.get("gear", "1"))
         gear[:gv.size] = gv
@@ -882,7 +882,15 @@ class _Compiler:
         nu = len(A)
         m["nu"] = nu
         trnid = -np.ones((nu, 2), I)
+        trntype = np.zeros(nu, I)
+        tendon_names = [ta.get("name", f"tendon{k}") for k, (ta, _) in enumerate(self.tendons)]
         for i, a in enumerate(A):
+            if a["tendon"] is not None:   # mjTRN_TENDON: length = gear * ten_length, moment = gear * the tendon's coefficients
+                if a["tendon"] not in tendon_names:
+                    raise MjcfError(f"actuator '{a['name']}': unknown tendon '{a['tendon']}'")
+                trnid[i, 0] = tendon_names.index(a["tendon"])
+                trntype[i] = 3
+                continue
             jid = m.name2id("joint", a["joint"])
             if jid < 0:
                 raise MjcfError(f"actuator '{a['name']}': unknown joint '{a['joint']}'")
@@ -890,7 +898,7 @@ class _Compiler:
                 raise MjcfError("actuators are only supported on hinge/slide joints")
             trnid[i, 0] = jid
         m["actuator_trnid"] = trnid
-        m["actuator_trntype"] = np.zeros(nu, I)
+        m["actuator_trntype"] = trntype
         m["actuator_dyntype"] = np.array([a["dyntype"] for a in A], I)
         # one activation variable per stateful actuator, in actuator order (mjModel.actuator_actadr; -1: stateless)
         actadr, na = [], 0
@@ -954,6 +962,8 @@ class _Compiler:
             # implicitfast: the engine takes a constant, diagonal velocity derivative (include/mjb.h, MJB_INT_IMPLICITFAST)
             if np.any(np.asarray(m["tendon_damping"]) != 0):
                 raise MjcfError("integrator implicitfast with tendon damping is not supported")
+            if nu and np.any((m["actuator_trntype"] == 3) & (m["actuator_biastype"] == 1) & (m["actuator_biasprm"][:, 2] != 0)):
+                raise MjcfError("integrator implicitfast with a velocity-dependent actuator on a tendon is not supported")
             if nu and np.any((m["actuator_gaintype"] == 1) & (m["actuator_gainprm"][:, 2] != 0)):
                 raise MjcfError("integrator implicitfast with a velocity term in an affine actuator gain (<damper>) is not supported")
         self._compile_equalities(m)

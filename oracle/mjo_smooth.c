@@ -345,7 +345,8 @@ void mjo_transmission(const mjb_model_desc *m, mjo_data *d)
 {
 	for (int i = 0; i < m->nu; i++) {
 		int j = m->actuator_trnid[2 * i];
-		d->actuator_length[i] = d->qpos[m->jnt_qposadr[j]] * m->actuator_gear[6 * i];
+		if (m->actuator_trntype[i] == MJB_TRN_TENDON) d->actuator_length[i] = d->ten_length[j] * m->actuator_gear[6 * i];  /* (mj_tendon ran before) */
+		else d->actuator_length[i] = d->qpos[m->jnt_qposadr[j]] * m->actuator_gear[6 * i];
 	}
 }
 
@@ -384,9 +385,16 @@ void mjo_com_vel(const mjb_model_desc *m, mjo_data *d)
 		}
 		memcpy(d->cvel + 6 * i, cvel, sizeof cvel);
 	}
+	/* actuator_velocity = actuator_moment . qvel; a tendon transmission's moment is gear * the tendon's coefficients */
 	for (int i = 0; i < m->nu; i++) {
 		int jn = m->actuator_trnid[2 * i];
-		d->actuator_velocity[i] = m->actuator_gear[6 * i] * d->qvel[m->jnt_dofadr[jn]];
+		if (m->actuator_trntype[i] == MJB_TRN_TENDON) {
+			double v = 0;
+			for (int w = m->tendon_adr[jn]; w < m->tendon_adr[jn] + m->tendon_num[jn]; w++)
+				v += m->actuator_gear[6 * i] * m->wrap_prm[w] * d->qvel[m->jnt_dofadr[m->wrap_objid[w]]];
+			d->actuator_velocity[i] = v;
+		} else
+			d->actuator_velocity[i] = m->actuator_gear[6 * i] * d->qvel[m->jnt_dofadr[jn]];
 	}
 }
 
@@ -514,7 +522,11 @@ void mjo_fwd_actuation(const mjb_model_desc *m, mjo_data *d)
 	/* qfrc_actuator = moment' * force */
 	for (int i = 0; i < m->nu; i++) {
 		int j = m->actuator_trnid[2 * i];
-		d->qfrc_actuator[m->jnt_dofadr[j]] += m->actuator_gear[6 * i] * d->actuator_force[i];
+		if (m->actuator_trntype[i] == MJB_TRN_TENDON) {
+			for (int w = m->tendon_adr[j]; w < m->tendon_adr[j] + m->tendon_num[j]; w++)
+				d->qfrc_actuator[m->jnt_dofadr[m->wrap_objid[w]]] += m->actuator_gear[6 * i] * m->wrap_prm[w] * d->actuator_force[i];
+		} else
+			d->qfrc_actuator[m->jnt_dofadr[j]] += m->actuator_gear[6 * i] * d->actuator_force[i];
 	}
 }
 
@@ -1042,6 +1054,7 @@ void mjo_euler(const mjb_model_desc *m, mjo_data *d)
 				bv += m->actuator_gainprm[3 * i + 2] * (ja >= 0 ? d->act[ja] : d->ctrl[i]);
 			}
 			const double g = m->actuator_gear[6 * i];
+			if (m->actuator_trntype[i] == MJB_TRN_TENDON) continue;  /* (moment' bv moment is not diagonal: the loader refuses bv != 0 there) */
 			dd[m->jnt_dofadr[m->actuator_trnid[2 * i]]] -= g * g * bv;
 		}
 	} else {
