@@ -370,6 +370,10 @@ class _Compiler:
             o["cone"] = {"pyramidal": 0, "elliptic": 1}[a["cone"]]
         if "solver" in a:
             o["solver"] = {"PGS": 0, "CG": 1, "Newton": 2}[a["solver"]]
+        # attributes that would change the physics and are not implemented: refuse them instead of dropping them
+        for k in ("noslip_iterations", "density", "viscosity"):
+            if k in a and float(a[k]) != 0:
+                raise MjcfError(f"option {k} != 0 is not supported ({'the noslip post-solver' if k.startswith('noslip') else 'fluid forces'})")
         if "collision" in a and a["collision"] not in ("all", "dynamic"):
             raise MjcfError("option collision='predefined' is not supported")
         for fl in node:
@@ -396,6 +400,8 @@ class _Compiler:
             b = dict(name=a.get("name", f"body{bid}"), parent=parent,
                      pos=_floats(a.get("pos", "0 0 0"), 3, "body pos"),
                      quat=self._orientation(a, "body"), inertial=None, joints=[], geoms=[], sites=[])
+            if float(a.get("gravcomp", 0)) != 0:
+                raise MjcfError(f"body '{b['name']}': gravcomp is not supported")
             b["mocap"] = a.get("mocap", "false") == "true"
             if b["mocap"] and parent != 0:
                 raise MjcfError(f"mocap body '{b['name']}' must be a child of the world")
@@ -471,6 +477,8 @@ class _Compiler:
                  solimp_fri=_solimp(a.get("solimpfriction")))
         if j["frictionloss"] < 0:
             raise MjcfError("joint frictionloss must be >= 0")
+        if "springdamper" in a and np.any(_floats(a["springdamper"], 2, "springdamper") != 0):
+            raise MjcfError("joint springdamper (stiffness / damping from a time constant, needs the compiler's mass properties) is not supported: give stiffness and damping")
         self.joints.append(j)
         return j
 

@@ -134,3 +134,11 @@ def test_gpu_tendon_actuators_match_oracle(oracle_built, integrator, solver, con
         for k in ("actuator_length", "actuator_velocity", "actuator_force", "qfrc_actuator"):
             np.testing.assert_allclose(b.get(k)[e], np.array(getattr(d, k)), rtol=0, atol=1e-12, err_msg=k)
     b.close()
+
+
+def test_loader_refuses_options_it_would_otherwise_drop():
+    one = '<mujoco><option %s/><worldbody><body><joint type="hinge"/><geom size="0.1"/></body></worldbody></mujoco>'
+    for opt in ('noslip_iterations="3"', 'density="1.2"', 'viscosity="0.001"'):
+        with pytest.raises(mjcf.MjcfError):
+            mjcf.compile_xml_string(one % opt)
+    assert mjcf.compile_xml_string(one % 'noslip_iterations="0" density="0" wind="1 0 0"')["nv"] == 1
