@@ -467,7 +467,7 @@ class _Compiler:
             raise MjcfError("free joint cannot be limited")
         j.update(range=rng, limited=int(limited), stiffness=float(a.get("stiffness", 0)),
                  damping=float(a.get("damping", 0)), armature=float(a.get("armature", 0)),
-                 margin=float(a.get("margin", 0)) * (scale if typ == JNT_HINGE else 1.0),
+                 margin=float(a.get("margin", 0)),  # (not an angle to the compiler: mjCJoint::Compile converts range / ref / springref only)
                  ref=float(a.get("ref", 0)) * (scale if typ == JNT_HINGE else 1.0),
                  springref=float(a.get("springref", 0)) * (scale if typ == JNT_HINGE else 1.0),
                  solref=_floats(a.get("solreflimit", "0.02 1"), 2, "solreflimit"),
