@@ -882,6 +882,9 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		}
 		for (int p = 0; p < 2 * h.ncollpair && !bad; p++)
 			if (!in(h.collpair_geom[p], 0, h.ngeom)) bad = "collpair_geom";
+		for (int p = 0; p < h.ncollpair && !bad; p++)
+			if (h.collpair_explicit[p] && h.collpair_condim[p] > 0 && h.collpair_condim[p] != 1 && h.collpair_condim[p] != 3 && h.collpair_condim[p] != 4 && h.collpair_condim[p] != 6)
+				bad = "collpair_condim (1, 3, 4, 6)";
 		for (int st = 0; st < h.nsite && !bad; st++)
 			if (!in(h.site_bodyid[st], 0, h.nbody)) bad = "site_bodyid";
 		for (int t = 0; t < h.ntendon && !bad; t++)
@@ -1275,6 +1278,20 @@ mjb_model *mjb_compile(const mjb_model_desc *desc)
 		for (int k = 0; k < 3; k++) {  // mj_contactParam's friction of the MODEL's geoms (per-env overrides are mixed on the device)
 			const double a = h.geom_friction[3 * g1 + k], b = h.geom_friction[3 * g2 + k];
 			pd[18 + k] = pi[5] == 0 ? std::max(a, b) : (pi[5] == 1 ? a : b);
+		}
+		if (h.collpair_explicit[p]) {
+			// <contact><pair>: what the pair states goes on top of the geoms' mix (collpair_param: friction[5] solref[2] solimp[5] margin gap, NaN = not stated)
+			const double *pp = h.collpair_param + 14 * p;
+			if (h.collpair_condim[p] > 0) pi[4] = h.collpair_condim[p];
+			if (!std::isnan(pp[5])) { solref[0] = pp[5]; solref[1] = pp[6]; }
+			if (!std::isnan(pp[7])) for (int k = 0; k < 5; k++) solimp[k] = pp[7 + k];
+			if (!std::isnan(pp[12])) pd[6] = pp[12];
+			if (!std::isnan(pp[13])) pd[7] = pp[13];
+			pd[17] = pd[6] - pd[7];
+			if (!std::isnan(pp[0])) {  // the pair's five friction numbers: tangent 1, spin, roll 1 in the slots of the geoms' three; tangent 2, roll 2 in the pads
+				pi[5] = 4;
+				pd[18] = pp[0]; pd[19] = pp[2]; pd[20] = pp[3]; pd[22] = pp[1]; pd[23] = pp[4];
+			}
 		}
 	}
 	{  // limit records (see mjb_dev.h)

@@ -673,7 +673,7 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const EnvLi
 					const int tt = t1; t1 = t2; t2 = tt;
 					const double tr = rb1; rb1 = rb2; rb2 = tr;
 					for (int k = 0; k < 3; k++) { const double ts = size1[k]; size1[k] = size2[k]; size2[k] = ts; }
-					if (frisel) frisel = 3 - frisel;
+					if (frisel == 1 || frisel == 2) frisel = 3 - frisel;
 				}
 			}
 			ld3(pos1, f + L.geom_xpos + 3 * g1);
@@ -713,7 +713,9 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const EnvLi
 		}
 		// this pair's friction (mj_contactParam) and the store of one contact -- shared by the register path and the box - box path
 		auto pair_friction = [&](double (&fri)[3]) {
-			if (L.gfriction >= 0) {
+			if (frisel == 4) {  // <contact><pair friction=...>: the pair's own numbers, a constant of the model (tangent 1, spin, roll 1 here; tangent 2 / roll 2: put_contact)
+				for (int k = 0; k < 3; k++) fri[k] = pd[18 + k];
+			} else if (L.gfriction >= 0) {
 				for (int k = 0; k < 3; k++) {
 					const double a = f[L.gfriction + 3 * g1 + k], b = f[L.gfriction + 3 * g2 + k];
 					fri[k] = frisel == 0 ? fmax(a, b) : (frisel == 1 ? a : b);
@@ -737,7 +739,7 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const EnvLi
 			st9(f + L.contact_frame + 9 * c, fr);
 			f[L.contact_includemargin + c] = incl;
 			double *f5 = f + L.contact_friction + 5 * c;
-			f5[0] = fri[0]; f5[1] = fri[0]; f5[2] = fri[1]; f5[3] = fri[2]; f5[4] = fri[2];
+			f5[0] = fri[0]; f5[1] = frisel == 4 ? pd[22] : fri[0]; f5[2] = fri[1]; f5[3] = fri[2]; f5[4] = frisel == 4 ? pd[23] : fri[2];
 			if (L.contact_solref >= 0) {
 				f[L.contact_solref + 2 * c] = pd[10];
 				f[L.contact_solref + 2 * c + 1] = pd[11];

@@ -44,10 +44,10 @@ struct DevModel {
 	int flv_n;
 	mjb_ciptr sens_copy;     // [2][3][sens_ncopy_max][2] (layout full/compact, stage-1): {dst offset in sensordata, src frame offset}
 	mjb_ciptr sens_slow;     // [3][nsensor] ids of the sensors of each stage that need real work
-	mjb_ciptr dof_act_adr;   // [nv+1] CSR: actuators (joint transmission) driving each dof
-	mjb_ciptr dof_act_id;    // [nu]
-	mjb_ciptr pair_i;        // [ncollpair][8]  candidate-pair records: g1, g2, type1, type2, condim, friction rule (0 max, 1 geom1, 2 geom2), collision-function override (MJB_COLFUNC_*), 0
-	mjb_cdptr pair_d;        // [ncollpair][24] size1[3] size2[3] margin gap rbound1 rbound2 solref[2] solimp[5] includemargin friction[3] tran pad[2]
+	mjb_ciptr dof_act_adr;   // [nv+1] CSR: the actuators driving each dof (a tendon transmission appears under every joint of its tendon)
+	mjb_ciptr dof_act_id;    // [dof_act_adr[nv]]
+	mjb_ciptr pair_i;        // [ncollpair][8]  candidate-pair records: g1, g2, type1, type2, condim, friction rule (0 max, 1 geom1, 2 geom2, 4 the pair's own: <contact><pair friction>), collision-function override (MJB_COLFUNC_*), 0
+	mjb_cdptr pair_d;        // [ncollpair][24] size1[3] size2[3] margin gap rbound1 rbound2 solref[2] solimp[5] includemargin friction[3] tran pad[2] (rule 4: friction = tangent 1, spin, roll 1; pad = tangent 2, roll 2)
 	                         //   ([21] tran = body_invweight0[2 b1] + body_invweight0[2 b2] of the two geoms' bodies: the contact rows' diagApprox)
 	// limit items (joints, then tendons) of make_constraint as records in pair_d's slots -- a lane fetches ITS item's record, contact or
 	// limit, with one batch of unconditional loads before the kinds diverge: [0..1] range, [6] margin, [10..11] solref, [12..16] solimp,

@@ -227,6 +227,7 @@ class _Compiler:
         self.actuators = []
         self.sensors = []
         self.excludes = []
+        self.pairs = []      # <contact><pair>: merged attribute dicts
         self.materials = {}   # <asset><material name rgba>: only the colour's alpha matters here (mj_ray skips invisible geoms)
         self.opt = dict(magnetic=np.array([0.0, -0.5, 0.0]), timestep=0.002, gravity=np.array([0, 0, -9.81]), tolerance=1e-8, impratio=1.0,
                         integrator=0, cone=0, solver=2, iterations=100, disableflags=0, enableflags=0)
@@ -315,6 +316,8 @@ class _Compiler:
                 for c in node:
                     if c.tag == "exclude":
                         self.excludes.append((c.get("body1"), c.get("body2")))
+                    elif c.tag == "pair":
+                        self.pairs.append(self._merged(c, None))
                     else:
                         raise MjcfError(f"<contact><{c.tag}> is not supported")
             else:
@@ -978,8 +981,36 @@ class _Compiler:
 
         # static collision candidates (restates the body/geom filters of MuJoCo's mj_collision)
         pairs = self._collision_pairs(m)
-        m["collpair_geom"] = np.array(pairs, I).reshape(len(pairs), 2)
+        m["collpair_geom"] = np.array([(a, b) for a, b, _ in pairs], I).reshape(len(pairs), 2)
         m["ncollpair"] = len(pairs)
+        expl = np.zeros(len(pairs), I)
+        pcond = -np.ones(len(pairs), I)
+        pprm = np.full((len(pairs), 14), np.nan)
+        for k, (_, _, pa) in enumerate(pairs):
+            if pa is None:
+                continue
+            expl[k] = 1
+            if "condim" in pa:
+                pcond[k] = int(pa["condim"])
+                if pcond[k] not in (1, 3, 4, 6):
+                    raise MjcfError("pair condim must be 1, 3, 4 or 6")
+            if "friction" in pa:   # up to five numbers; the missing ones take MuJoCo's pair defaults
+                fv = _floats(pa["friction"])
+                full = np.array([1.0, 1.0, 0.005, 0.0001, 0.0001])
+                full[:min(5, fv.size)] = fv[:5]
+                if fv.size == 1:
+                    full[1] = fv[0]
+                pprm[k, 0:5] = full
+            if "solref" in pa:
+                pprm[k, 5:7] = _floats(pa["solref"], 2, "pair solref")
+            if "solimp" in pa:
+                pprm[k, 7:12] = _solimp(pa["solimp"])
+            if "margin" in pa:
+                pprm[k, 12] = float(pa["margin"])
+            if "gap" in pa:
+                pprm[k, 13] = float(pa["gap"])
+        m["collpair_explicit"], m["collpair_condim"], m["collpair_param"] = expl, pcond, pprm
+        pairs = [(a, b) for a, b, _ in pairs]
         # capacities: worst case contacts per pair type
         maxcon = 0
         for g1, g2 in pairs:
@@ -1007,7 +1038,7 @@ class _Compiler:
             nlimit = 0
         rows_per_con = 0
         if pairs:
-            maxdim = max(int(max(m["geom_condim"][g1], m["geom_condim"][g2])) for g1, g2 in pairs)
+            maxdim = max(int(pcond[k]) if pcond[k] > 0 else int(max(m["geom_condim"][g1], m["geom_condim"][g2])) for k, (g1, g2) in enumerate(pairs))
             rows_per_con = 1 if maxdim == 1 else (2 * (maxdim - 1) if o["cone"] == 0 else maxdim)
         neqrow = 0
         if not (o["disableflags"] & DISABLE_BITS["equality"]):
@@ -1165,9 +1196,29 @@ class _Compiler:
             excl.add((min(i1, i2), max(i1, i2)))
         filterparent = not (m["disableflags"] & DISABLE_BITS["filterparent"])
         geoms_of = [[g["id"] for g in b["geoms"]] for b in B]
+        # <contact><pair>: taken as named -- no contype / conaffinity, parent-child or <exclude> filter (mj_collision tests the predefined
+        # pairs ahead of the dynamic ones of the same body pair and skips the dynamic twin of a predefined geom pair)
+        explicit = {}
+        for pa in self.pairs:
+            if "geom1" not in pa or "geom2" not in pa:
+                raise MjcfError("<contact><pair> needs geom1 and geom2")
+            i1, i2 = m.name2id("geom", pa["geom1"]), m.name2id("geom", pa["geom2"])
+            if i1 < 0 or i2 < 0:
+                raise MjcfError(f"<contact><pair>: unknown geom '{pa['geom1'] if i1 < 0 else pa['geom2']}'")
+            bb1, bb2 = int(m["geom_bodyid"][i1]), int(m["geom_bodyid"][i2])
+            if weld[bb1] == weld[bb2]:
+                raise MjcfError("<contact><pair>: the two geoms are on the same (welded) body")
+            t1, t2 = m["geom_type"][i1], m["geom_type"][i2]
+            a, b = (i1, i2) if t1 <= t2 else (i2, i1)
+            if _max_contacts(m["geom_type"][a], m["geom_type"][b]) == 0:
+                raise MjcfError(f"<contact><pair>: collision between geom types {m['geom_type'][a]} and {m['geom_type'][b]} is not implemented")
+            explicit.setdefault((min(bb1, bb2), max(bb1, bb2)), []).append((a, b, pa))
         pairs = []
         for b1 in range(nbody):
             for b2 in range(b1 + 1, nbody):
+                mine = explicit.get((b1, b2), [])
+                pairs.extend(mine)
+                taken = {(a, b) for a, b, _ in mine}
                 if not geoms_of[b1] or not geoms_of[b2]:
                     continue
                 if (b1, b2) in excl:
@@ -1197,7 +1248,9 @@ class _Compiler:
                             raise MjcfError(
                                 f"collision between geom types {ta} and {tb} is not implemented; "
                                 "filter the pair with contype/conaffinity or <exclude>")
-                        pairs.append((a, b))
+                        if (a, b) in taken:
+                            continue
+                        pairs.append((a, b, None))
         return pairs
 
 

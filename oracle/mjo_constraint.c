@@ -554,6 +554,10 @@ void mjo_collision(const mjb_model_desc *m, mjo_data *d)
 		const double *size1 = gsz + 3 * g1, *size2 = gsz + 3 * g2;
 		double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
 		double gap = fmax(m->geom_gap[g1], m->geom_gap[g2]);
+		/* <contact><pair>: what the pair states replaces the geoms' mix (friction[5] solref[2] solimp[5] margin gap, NaN = not stated) */
+		const double *pp = m->collpair_explicit[p] ? m->collpair_param + 14 * p : NULL;
+		if (pp && (pp[12] == pp[12])) margin = pp[12];
+		if (pp && (pp[13] == pp[13])) gap = pp[13];
 		/* broad phase: bounding spheres (plane: signed distance of the other geom's sphere) */
 		double rb1 = m->geom_rbound[g1], rb2 = m->geom_rbound[g2];
 		if (rb1 > 0 && rb2 > 0) {
@@ -587,6 +591,13 @@ void mjo_collision(const mjb_model_desc *m, mjo_data *d)
 		int condim;
 		double solref[2], solimp[5], fri[3];
 		contact_param(m, g1, g2, &condim, solref, solimp, fri);
+		double fri5[5] = { fri[0], fri[0], fri[1], fri[2], fri[2] };
+		if (pp) {
+			if (m->collpair_condim[p] > 0) condim = m->collpair_condim[p];
+			if ((pp[0] == pp[0])) memcpy(fri5, pp, sizeof fri5);
+			if ((pp[5] == pp[5])) memcpy(solref, pp + 5, sizeof solref);
+			if ((pp[7] == pp[7])) memcpy(solimp, pp + 7, sizeof solimp);
+		}
 		for (int i = 0; i < n; i++) {  /* (the pair functions return only contacts with dist <= margin; mj_collideGeoms adds them all) */
 			if (ncon >= m->nconmax) {  /* mj_addContact: full -> the contact is dropped, mjWARN_CONTACTFULL */
 				overflow = 1;
@@ -597,8 +608,7 @@ void mjo_collision(const mjb_model_desc *m, mjo_data *d)
 			v3_copy(d->contact_pos + 3 * ncon, rc[i].pos);
 			memcpy(d->contact_frame + 9 * ncon, rc[i].frame, 9 * sizeof(double));
 			d->contact_includemargin[ncon] = margin - gap;
-			double *f5 = d->contact_friction + 5 * ncon;
-			f5[0] = f5[1] = fri[0]; f5[2] = fri[1]; f5[3] = f5[4] = fri[2];
+			memcpy(d->contact_friction + 5 * ncon, fri5, sizeof fri5);
 			memcpy(d->contact_solref + 2 * ncon, solref, sizeof solref);
 			memcpy(d->contact_solimp + 5 * ncon, solimp, sizeof solimp);
 			d->contact_geom[2 * ncon] = g1;

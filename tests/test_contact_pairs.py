@@ -1,0 +1,152 @@
+"""<contact><pair> (mjModel.pair_*; SURVEY.md §8a rows A4 / A5: the candidate list and the contact parameters): a geom pair named by the model
+is tested whatever contype / conaffinity, parent-child or <exclude> filters say, its stated condim / friction[5] / solref / solimp / margin / gap
+replace the geoms' mix (unstated ones keep it), it comes ahead of the dynamic pairs of the same two bodies and replaces its dynamic twin.
+Loader and oracle against these rules, kernels against the oracle."""
+import numpy as np
+import pytest
+
+from mujoco_ros_pkgs_amd import mjcf
+
+XML = """
+<mujoco model="contact_pairs">
+  <compiler angle="radian"/>
+  <option timestep="0.002" solver="{solver}" cone="{cone}" iterations="80" tolerance="1e-10"/>
+  <size nconmax="24" njmax="120"/>
+  <default>
+    <geom friction="0.8 0.01 0.002" solref="0.02 1"/>
+    <pair solimp="0.95 0.99 0.002 0.5 2"/>
+  </default>
+  <worldbody>
+    <geom name="floor" type="plane" size="3 3 0.1"/>
+    <body name="cube" pos="0 0 0.05">
+      <freejoint/>
+      <geom name="cube_g" type="box" size="0.05 0.05 0.05" mass="0.4"/>
+      <geom name="cube_top" type="sphere" size="0.02" pos="0 0 0.06" mass="0.01"/>
+    </body>
+    <body name="ball" pos="0.3 0 0.04">
+      <freejoint/>
+      <geom name="ball_g" type="sphere" size="0.04" mass="0.2" contype="0" conaffinity="0"/>
+    </body>
+    <body name="rod" pos="-0.3 0 0.03">
+      <freejoint/>
+      <geom name="rod_g" type="capsule" fromto="-0.1 0 0 0.1 0 0" size="0.03" mass="0.3" condim="3"/>
+    </body>
+  </worldbody>
+  <contact>
+    <pair name="ball_floor" geom1="ball_g" geom2="floor" condim="6" friction="0.6 0.5 0.01 0.003 0.002" margin="0.01" gap="0.002"/>
+    <pair geom1="floor" geom2="cube_g" solref="0.01 0.8"/>
+    <exclude body1="world" body2="rod"/>
+    <pair geom1="rod_g" geom2="floor" condim="4" friction="0.4"/>
+  </contact>
+</mujoco>
+"""
+
+
+def model_of(solver="Newton", cone="elliptic"):
+    return mjcf.compile_xml_string(XML.format(solver=solver, cone=cone))
+
+
+def test_loader_orders_and_merges_the_pairs():
+    m = model_of()
+    names = m["names"]["geom"]
+    got = [(names[a], names[b], int(e)) for (a, b), e in zip(m["collpair_geom"], m["collpair_explicit"])]
+    # world-cube: the explicit (floor, cube_g) first, its dynamic twin gone, the other geom of the cube still dynamic; world-ball: explicit only
+    # (the ball's contype is 0); world-rod: explicit in spite of the <exclude>; then the dynamic body pairs among cube / ball / rod
+    assert got[:4] == [("floor", "cube_g", 1), ("floor", "cube_top", 0), ("floor", "ball_g", 1), ("floor", "rod_g", 1)], got
+    assert all(e == 0 for _, _, e in got[4:]) and not any("ball_g" in (a, b) for a, b, _ in got[4:])
+    assert ("cube_g", "rod_g", 0) in [(b, a, e) if (a, b) == ("rod_g", "cube_g") else (a, b, e) for a, b, e in got[4:]] or any({"cube_g", "rod_g"} == {a, b} for a, b, _ in got[4:])
+    P, C = m["collpair_param"], m["collpair_condim"]
+    assert list(C[:4]) == [-1, -1, 6, 4]
+    np.testing.assert_allclose(P[2, 0:5], [0.6, 0.5, 0.01, 0.003, 0.002])
+    np.testing.assert_allclose(P[2, 12:14], [0.01, 0.002])
+    np.testing.assert_allclose(P[3, 0:5], [0.4, 0.4, 0.005, 0.0001, 0.0001])      # one number: both tangents; the rest MuJoCo's pair defaults
+    assert np.all(np.isnan(P[0, 0:5])) and np.all(np.isnan(P[1])) and np.isnan(P[3, 5])
+    np.testing.assert_allclose(P[0, 5:7], [0.01, 0.8])
+    np.testing.assert_allclose(P[0, 7:12], [0.95, 0.99, 0.002, 0.5, 2])           # from <default><pair>
+    bad = XML.format(solver="Newton", cone="elliptic")
+    with pytest.raises(mjcf.MjcfError):
+        mjcf.compile_xml_string(bad.replace('geom1="rod_g" geom2="floor"', 'geom1="rod_g" geom2="nope"'))
+    with pytest.raises(mjcf.MjcfError):
+        mjcf.compile_xml_string(bad.replace('geom1="rod_g" geom2="floor"', 'geom1="cube_g" geom2="cube_top"'))
+
+
+def test_oracle_contacts_carry_the_pair_parameters(oracle_built):
+    m = model_of()
+    names = m["names"]["geom"]
+    d = oracle_built.OracleData(m)
+    d.reset()
+    d.qpos[9] = 0.045     # the ball: 5 mm above the floor, inside the pair's margin (0.01) but outside margin - gap?  no: dist 0.005 < 0.008
+    d.forward()
+    n = int(d.ncon[0])
+    con = {}
+    for c in range(n):
+        key = (names[int(d.contact_geom[2 * c])], names[int(d.contact_geom[2 * c + 1])])
+        con.setdefault(key, []).append(c)
+    assert list(con) == [("floor", "cube_g"), ("floor", "ball_g"), ("floor", "rod_g")], con   # contact order = pair order
+    c = con[("floor", "ball_g")][0]
+    assert int(d.contact_dim[c]) == 6
+    np.testing.assert_allclose(d.contact_friction[5 * c:5 * c + 5], [0.6, 0.5, 0.01, 0.003, 0.002])
+    np.testing.assert_allclose(d.contact_includemargin[c], 0.008)
+    np.testing.assert_allclose(d.contact_dist[c], 0.005, atol=1e-12)
+    np.testing.assert_allclose(d.contact_solimp[5 * c:5 * c + 5], [0.95, 0.99, 0.002, 0.5, 2])
+    c = con[("floor", "cube_g")][0]
+    assert len(con[("floor", "cube_g")]) == 4 and int(d.contact_dim[c]) == 3
+    np.testing.assert_allclose(d.contact_solref[2 * c:2 * c + 2], [0.01, 0.8])
+    np.testing.assert_allclose(d.contact_friction[5 * c:5 * c + 5], [0.8, 0.8, 0.01, 0.002, 0.002])    # not stated: the geoms' mix
+    c = con[("floor", "rod_g")][0]
+    assert int(d.contact_dim[c]) == 4
+    np.testing.assert_allclose(d.contact_friction[5 * c:5 * c + 5], [0.4, 0.4, 0.005, 0.0001, 0.0001])
+    np.testing.assert_allclose(d.contact_solref[2 * c:2 * c + 2], [0.02, 1.0])
+    # the ball rests on the floor only because of its pair (contype = conaffinity = 0)
+    d.reset()
+    d.step(400)
+    assert 0.038 < d.qpos[9] < 0.05, d.qpos[9]     # (margin 0.01, gap 0.002: the contact pushes from 8 mm out; without the pair the ball falls through)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver,cone", [("Newton", "elliptic"), ("PGS", "pyramidal"), ("Newton", "pyramidal"), ("CG", "elliptic")])
+def test_gpu_pairs_match_oracle(oracle_built, solver, cone):
+    from mujoco_ros_pkgs_amd import engine
+    m = model_of(solver, cone)
+    n = 48
+    rng = np.random.default_rng(6)
+    qpos = np.tile(np.asarray(m["qpos0"], float), (n, 1))
+    for k in range(3):
+        qpos[:, 7 * k:7 * k + 2] += rng.uniform(-0.05, 0.05, (n, 2))
+        qpos[:, 7 * k + 2] += rng.uniform(-0.003, 0.02, n)
+        q = rng.normal(size=(n, 4)) * 0.15 + np.array([1, 0, 0, 0])
+        qpos[:, 7 * k + 3:7 * k + 7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    qvel = rng.uniform(-0.5, 0.5, (n, m["nv"]))
+    cm = engine.CompiledModel(m)
+    d = oracle_built.OracleData(m)
+    b = engine.Batch(cm, n)
+    b.set("qpos", qpos); b.set("qvel", qvel)
+    b.forward()
+    ncon, fr, dim, geom, incl, sref = b.get("ncon"), b.get("contact_friction"), b.get("contact_dim"), b.get("contact_geom"), b.get("contact_includemargin"), b.get("contact_solref")
+    total = 0
+    for e in range(n):
+        d.reset(); d.qpos[:] = qpos[e]; d.qvel[:] = qvel[e]
+        d.forward()
+        k = int(d.ncon[0])
+        total += k
+        assert int(ncon[e][0]) == k, (e, ncon[e], k)
+        np.testing.assert_array_equal(geom[e][:2 * k], np.array(d.contact_geom)[:2 * k])
+        np.testing.assert_array_equal(dim[e][:k], np.array(d.contact_dim)[:k])
+        np.testing.assert_allclose(fr[e][:5 * k], np.array(d.contact_friction)[:5 * k], rtol=0, atol=0)
+        np.testing.assert_allclose(incl[e][:k], np.array(d.contact_includemargin)[:k], rtol=0, atol=0)
+        np.testing.assert_allclose(sref[e][:2 * k], np.array(d.contact_solref)[:2 * k], rtol=0, atol=0)
+    assert total > 2 * n
+    b.close()
+    for nstep in (1, 40):
+        b = engine.Batch(cm, n)
+        b.set("qpos", qpos); b.set("qvel", qvel)
+        b.step(nstep)
+        q, v = b.get("qpos"), b.get("qvel")
+        # (CG: its stop test sits on the threshold more often than the other solvers', DESIGN.md §2 -- the same allowance as the other CG rollouts)
+        tol = (1e-9 if solver == "CG" else 1e-11) if nstep == 1 else (1e-6 if solver == "CG" else 1e-7)
+        for e in range(n):
+            d.reset(); d.qpos[:] = qpos[e]; d.qvel[:] = qvel[e]
+            d.step(nstep)
+            assert np.abs(q[e] - np.array(d.qpos)).max() <= tol * 10, (nstep, e, np.abs(q[e] - np.array(d.qpos)).max())
+            assert np.abs(v[e] - np.array(d.qvel)).max() <= tol * 1000, (nstep, e, np.abs(v[e] - np.array(d.qvel)).max())
+        b.close()
