@@ -118,6 +118,8 @@ typedef struct mjb_batch mjb_batch; /* N env instances on one GPU */
 
 /* Message of the calling thread's last failed call ("" if none). */
 const char *mjb_last_error(void);
+/* sizeof(mjb_model_desc) of the build: a binding generated from another revision of include/mjb_model_fields.def finds out here, not in a crash. */
+int mjb_model_desc_size(void);
 int mjb_version(void);
 /* Number of usable HIP devices (0 when there is none; never fails). */
 int mjb_device_count(void);

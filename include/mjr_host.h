@@ -77,6 +77,7 @@ typedef mjr_backend *(*mjr_backend_factory)(const mjb_model_desc *desc, int nenv
  * when no GPU is usable — there is no CPU path. */
 mjr_backend *mjr_make_mjb_backend(const mjb_model_desc *desc, int nenv, int device, void *unused);
 const char *mjr_last_error(void);
+int mjr_model_desc_size(void);  /* sizeof(mjb_model_desc) this library was built with */
 
 /* ---- flat face of mujoco_ros::MujocoEnv ---- */
 typedef struct mjr_env mjr_env;

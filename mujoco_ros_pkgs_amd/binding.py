@@ -118,6 +118,18 @@ HW_KINDS = {"revolute": 0, "continuous": 1, "prismatic": 2}
 _lib = None
 
 
+def check_desc_size(lib, fn, path):
+    """A library built from another revision of include/mjb_model_fields.def would read the model desc at the wrong offsets: refuse it."""
+    try:
+        f = getattr(lib, fn)
+    except AttributeError:
+        raise OSError(f"{path} is stale (no {fn}): run `python -c 'import __graft_entry__ as g; g.build()'`")
+    f.restype = C.c_int
+    if f() != C.sizeof(ModelDesc):
+        raise OSError(f"{path} was built with another mjb_model_desc ({f()} bytes, include/mjb_model_fields.def gives {C.sizeof(ModelDesc)}): "
+                      "run `python -c 'import __graft_entry__ as g; g.build()'`")
+
+
 def load_library(path=None):
     """Load libmjb.so and declare every entry point of include/mjb.h.  Raises OSError if missing."""
     global _lib
@@ -129,9 +141,11 @@ def load_library(path=None):
             f"{p} not found: the HIP engine is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback).")
     lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    check_desc_size(lib, "mjb_model_desc_size", p)
     vp, ci, cd = C.c_void_p, C.c_int, C.c_double
     sig = {
         "mjb_last_error": (C.c_char_p, []),
+        "mjb_model_desc_size": (ci, []),
         "mjb_version": (ci, []),
         "mjb_device_count": (ci, []),
         "mjb_compile": (vp, [C.POINTER(ModelDesc)]),

@@ -678,6 +678,7 @@ template <typename T> T *dev_alloc(size_t n)
 extern "C" {
 
 const char *mjb_last_error(void) { return g_err.c_str(); }
+int mjb_model_desc_size(void) { return (int)sizeof(mjb_model_desc); }
 int mjb_version(void) { return MJB_VERSION; }
 
 int mjb_device_count(void)

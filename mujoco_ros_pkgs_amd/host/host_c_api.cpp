@@ -257,6 +257,7 @@ struct mjr_env {
 extern "C" {
 
 const char *mjr_last_error(void) { return g_err.c_str(); }
+int mjr_model_desc_size(void) { return (int)sizeof(mjb_model_desc); }
 
 mjr_backend *mjr_make_mjb_backend(const mjb_model_desc *desc, int nenv, int device, void *)
 {

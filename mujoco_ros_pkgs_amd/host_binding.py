@@ -66,9 +66,11 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise OSError(f"{LIB_PATH} not found; run __graft_entry__.build()")
     L = C.CDLL(LIB_PATH)
+    binding.check_desc_size(L, "mjr_model_desc_size", LIB_PATH)
     vp, ci, cs = C.c_void_p, C.c_int, C.c_char_p
     sig = {
         "mjr_last_error": (cs, []),
+        "mjr_model_desc_size": (ci, []),
         "mjr_make_mjb_backend": (vp, [C.POINTER(binding.ModelDesc), ci, ci, vp]),
         "mjr_env_create": (vp, [cs, cs]),
         "mjr_env_destroy": (None, [vp]),

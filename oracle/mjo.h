@@ -59,6 +59,7 @@ typedef struct mjo_data {
 
 mjo_data *mjo_make_data(const mjb_model_desc *m); /* mj_makeData  */
 void mjo_free_data(mjo_data *d);                  /* mj_deleteData */
+int mjo_model_desc_size(void);                    /* sizeof(mjb_model_desc) this library was built with */
 void mjo_reset_data(const mjb_model_desc *m, mjo_data *d); /* mj_resetData */
 
 /* field access by mjb_field id (NULL if unknown); *n receives the element count */

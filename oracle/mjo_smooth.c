@@ -58,6 +58,8 @@ mjo_data *mjo_make_data(const mjb_model_desc *m)
 	return d;
 }
 
+int mjo_model_desc_size(void) { return (int)sizeof(mjb_model_desc); }
+
 void mjo_free_data(mjo_data *d)
 {
 	if (!d) return;

@@ -33,6 +33,12 @@ def lib(fast=False):
     if not os.path.exists(path):
         build()
     L = C.CDLL(path)
+    try:
+        binding.check_desc_size(L, "mjo_model_desc_size", path)
+    except OSError:   # built from another revision of the field tables: rebuild once
+        build()
+        L = C.CDLL(path)
+        binding.check_desc_size(L, "mjo_model_desc_size", path)
     vp, ci, cd = C.c_void_p, C.c_int, C.c_double
     pd = C.POINTER(binding.ModelDesc)
     L.mjo_make_data.restype = vp
