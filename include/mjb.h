@@ -392,7 +392,8 @@ int mjb_register_collision(mjb_batch *b, int geom_type1, int geom_type2, int fun
  * The reference mutates its single mjModel through services (setGravity, setGeomProperties friction:
  * /root/reference mujoco_ros/src/callbacks.cpp:462-592, 641-884); in a batch every env may carry its own value (domain
  * randomisation).  Envs never written keep the model's value.  gravity: [env][3]; friction: [env][ngeom][3].
- * (masses: mjb_set_env_mass_params below.) */
+ * (masses: mjb_set_env_mass_params below.)  A <contact><pair> that states its friction keeps it: mjModel.pair_friction is a compiled constant
+ * the geoms' frictions do not reach (collpair_param, include/mjb_model_fields.def). */
 int mjb_set_env_gravity(mjb_batch *b, int env_lo, int env_hi, const double *gravity);
 int mjb_set_env_geom_friction(mjb_batch *b, int env_lo, int env_hi, const double *friction);
 /* setGeomProperties' set_size / set_type (callbacks.cpp:555-575) per env: size [env][ngeom][3], type [env][ngeom] (mjtGeom: plane,

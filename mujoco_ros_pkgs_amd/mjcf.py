@@ -574,6 +574,8 @@ class _Compiler:
     def _actuator(self, node):
         a = self._merged(node, None)
         t = node.tag
+        if "jointinparent" in a and "joint" not in a:
+            a = dict(a, joint=a["jointinparent"])   # (identical to joint= for the scalar joints actuators are supported on)
         if ("joint" in a) == ("tendon" in a):
             raise MjcfError(f"actuator <{t}> needs exactly one of joint= / tendon= (joint and fixed-tendon transmissions are supported)")
         act = dict(name=a.get("name", f"actuator{len(self.actuators)}"), joint=a.get("joint"), tendon=a.get("tendon"))
