@@ -377,8 +377,10 @@ class _Compiler:
         for k in ("noslip_iterations", "density", "viscosity"):
             if k in a and float(a[k]) != 0:
                 raise MjcfError(f"option {k} != 0 is not supported ({'the noslip post-solver' if k.startswith('noslip') else 'fluid forces'})")
-        if "collision" in a and a["collision"] not in ("all", "dynamic"):
-            raise MjcfError("option collision='predefined' is not supported")
+        if "collision" in a:
+            if a["collision"] not in ("all", "dynamic", "predefined"):
+                raise MjcfError("option collision must be all, predefined or dynamic")
+            o["collision"] = a["collision"]   # (mjCOL_ALL / PAIR / DYNAMIC: which of the <contact><pair> list and the filtered geom pairs are candidates)
         for fl in node:
             if fl.tag != "flag":
                 raise MjcfError(f"<option><{fl.tag}> not supported")
@@ -1201,7 +1203,8 @@ class _Compiler:
         # <contact><pair>: taken as named -- no contype / conaffinity, parent-child or <exclude> filter (mj_collision tests the predefined
         # pairs ahead of the dynamic ones of the same body pair and skips the dynamic twin of a predefined geom pair)
         explicit = {}
-        for pa in self.pairs:
+        colmode = self.opt.get("collision", "all")
+        for pa in (self.pairs if colmode != "dynamic" else []):
             if "geom1" not in pa or "geom2" not in pa:
                 raise MjcfError("<contact><pair> needs geom1 and geom2")
             i1, i2 = m.name2id("geom", pa["geom1"]), m.name2id("geom", pa["geom2"])
@@ -1221,7 +1224,7 @@ class _Compiler:
                 mine = explicit.get((b1, b2), [])
                 pairs.extend(mine)
                 taken = {(a, b) for a, b, _ in mine}
-                if not geoms_of[b1] or not geoms_of[b2]:
+                if colmode == "predefined" or not geoms_of[b1] or not geoms_of[b2]:
                     continue
                 if (b1, b2) in excl:
                     continue

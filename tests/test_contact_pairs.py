@@ -63,6 +63,12 @@ def test_loader_orders_and_merges_the_pairs():
     assert np.all(np.isnan(P[0, 0:5])) and np.all(np.isnan(P[1])) and np.isnan(P[3, 5])
     np.testing.assert_allclose(P[0, 5:7], [0.01, 0.8])
     np.testing.assert_allclose(P[0, 7:12], [0.95, 0.99, 0.002, 0.5, 2])           # from <default><pair>
+    # <option collision>: predefined = the pair list alone, dynamic = the filtered geom pairs alone
+    base = XML.format(solver="Newton", cone="elliptic")
+    mp = mjcf.compile_xml_string(base.replace('<option ', '<option collision="predefined" '))
+    assert list(mp["collpair_explicit"]) == [1, 1, 1]
+    md = mjcf.compile_xml_string(base.replace('<option ', '<option collision="dynamic" '))
+    assert not md["collpair_explicit"].any() and md["ncollpair"] == m["ncollpair"] - 2    # the ball's and the rod's floor pairs exist only as <pair>s
     bad = XML.format(solver="Newton", cone="elliptic")
     with pytest.raises(mjcf.MjcfError):
         mjcf.compile_xml_string(bad.replace('geom1="rod_g" geom2="floor"', 'geom1="rod_g" geom2="nope"'))
