@@ -125,7 +125,12 @@ DEVI double capbox_slope(const double *p0, const double *d, const double *s, dou
 	double g = 0;
 	for (int i = 0; i < 3; i++) {
 		const double p = p0[i] + t * d[i];
-		g += (p - clipd(p, -s[i], s[i])) * (fabs(d[i]) <= MJB_CAPBOX_PAR ? 0.0 : d[i]);
+		double r = p - clipd(p, -s[i], s[i]);
+		// (t may BE the crossing of this face plane, computed by a division: p then misses +-s by a rounding, and on an axis parallel to the other
+		//  two face pairs that 1e-17 is the whole slope -- its sign decided between the start, the middle and the end of a flat minimiser set: one
+		//  contact where the oracle's bisection finds the set's two ends.  A residual of a few ulps of the half size is the plane itself.)
+		if (fabs(r) <= 4e-15 * s[i]) r = 0;
+		g += r * (fabs(d[i]) <= MJB_CAPBOX_PAR ? 0.0 : d[i]);
 	}
 	return g;
 }
@@ -2131,7 +2136,9 @@ template <int G, int TAG> __device__ __attribute__((noinline)) void fwd_constrai
 			}
 		}
 		const double cost1 = cost_of();
-		const double improvement = (cost - cost1) * scale;
+		// (mj_solPGS adds up the rows' cost changes, each <= 0: its improvement is never negative.  The difference of the two sums is the same number up to
+		//  cancellation noise -- clamped, so that tolerance = 0 means what it means there: every sweep is run)
+		const double improvement = fmax((cost - cost1) * scale, 0.0);
 		cost = cost1;
 		iter++;
 		if (improvement < tol) break;
@@ -2398,7 +2405,9 @@ template <int G, bool ELL, bool REGB, int TAG> STAGE void fwd_constraint_pgs(CMo
 		}
 		frc += dvec;
 		const double cost1 = wave_sum(0.5 * frc * (res + b));
-		const double improvement = (cost - cost1) * scale;
+		// (mj_solPGS adds up the rows' cost changes, each <= 0: its improvement is never negative.  The difference of the two sums is the same number up to
+		//  cancellation noise -- clamped, so that tolerance = 0 means what it means there: every sweep is run)
+		const double improvement = fmax((cost - cost1) * scale, 0.0);
 		cost = cost1;
 		iter++;
 		if (improvement < tol) break;

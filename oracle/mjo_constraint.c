@@ -229,7 +229,9 @@ static double capbox_slope(const double *p0, const double *d, const double *s, d
 	double g = 0;
 	for (int i = 0; i < 3; i++) {
 		double p = p0[i] + t * d[i];
-		g += (p - clipd(p, -s[i], s[i])) * (fabs(d[i]) <= MJO_CAPBOX_PAR ? 0.0 : d[i]);
+		double r = p - clipd(p, -s[i], s[i]);
+		if (fabs(r) <= 4e-15 * s[i]) r = 0; /* (a residual of a few ulps of the half size is the face plane itself: the HIP routine evaluates the slope AT the crossings) */
+		g += r * (fabs(d[i]) <= MJO_CAPBOX_PAR ? 0.0 : d[i]);
 	}
 	return g;
 }

@@ -1,0 +1,185 @@
+"""Differential test over RANDOM models: seeded MJCF trees mixing everything the loader takes -- hinge / slide / ball / free joints with limits,
+springs and dampers, capsule / sphere / box geoms over a floor, fixed tendons (limited), joint / tendon actuators of every supported kind
+(motor, position, velocity, general with filter / integrator dynamics, intvelocity), a joint equality, explicit contact pairs, sensors -- stepped by
+the HIP path and by the oracle from the same states.  What the hand-written worlds of the other tests do not cover is the COMBINATIONS."""
+import numpy as np
+import pytest
+
+from mujoco_ros_pkgs_amd import mjcf
+
+
+def random_model(seed):
+    rng = np.random.default_rng(seed)
+    solver = ["Newton", "PGS", "CG"][seed % 3]
+    cone = ["pyramidal", "elliptic"][(seed // 3) % 2]
+    nbody = int(rng.integers(3, 7))
+    vel_servo = False
+    bodies, joints, scalar = [], [], []
+    xml_body = {}
+    children = {i: [] for i in range(-1, nbody)}
+    for b in range(nbody):
+        parent = -1 if b == 0 else int(rng.integers(-1, b))
+        children[parent].append(b)
+        kind = rng.choice(["hinge", "hinge", "slide", "ball", "free"] if parent == -1 else ["hinge", "hinge", "slide", "ball"])
+        name = f"j{b}"
+        ax = rng.normal(size=3)
+        ax /= np.linalg.norm(ax)
+        att = f'name="{name}" damping="{rng.uniform(0.02, 0.3):.3f}" armature="{rng.uniform(0.001, 0.02):.4f}"'
+        if kind == "free":
+            jx = f'<freejoint name="{name}"/>'
+        elif kind == "ball":
+            lim = f' limited="true" range="0 {rng.uniform(0.5, 1.2):.3f}"' if rng.random() < 0.5 else ""
+            jx = f'<joint type="ball" {att}{lim}/>'
+        else:
+            rg = (-0.05, 0.05) if kind == "slide" else (-rng.uniform(0.3, 1.0), rng.uniform(0.3, 1.0))
+            lim = f' limited="true" range="{rg[0]:.3f} {rg[1]:.3f}" margin="{rng.choice([0, 0.01])}"' if rng.random() < 0.6 else ""
+            st = f' stiffness="{rng.uniform(0, 3):.3f}" springref="{rng.uniform(-0.1, 0.1):.3f}"' if rng.random() < 0.3 else ""
+            fl = f' frictionloss="{rng.uniform(0.01, 0.1):.3f}"' if rng.random() < 0.15 else ""
+            jx = f'<joint type="{kind}" axis="{ax[0]:.4f} {ax[1]:.4f} {ax[2]:.4f}" {att}{lim}{st}{fl}/>'
+            scalar.append(name)
+        joints.append((name, kind))
+        gk = rng.choice(["capsule", "sphere", "box"])
+        L = rng.uniform(0.08, 0.2)
+        if gk == "capsule":
+            gx = f'<geom name="g{b}" type="capsule" fromto="0 0 0 {L:.3f} 0 0" size="{rng.uniform(0.015, 0.03):.3f}" mass="{rng.uniform(0.1, 0.8):.3f}"/>'
+        elif gk == "sphere":
+            gx = f'<geom name="g{b}" type="sphere" size="{rng.uniform(0.03, 0.05):.3f}" pos="{L / 2:.3f} 0 0" mass="{rng.uniform(0.1, 0.8):.3f}"/>'
+        else:
+            gx = f'<geom name="g{b}" type="box" size="{L / 2:.3f} {rng.uniform(0.02, 0.04):.3f} {rng.uniform(0.02, 0.04):.3f}" pos="{L / 2:.3f} 0 0" mass="{rng.uniform(0.1, 0.8):.3f}"/>'
+        site = f'<site name="s{b}" pos="{L / 2:.3f} 0 0.01"/>'
+        pos = (rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), rng.uniform(0.12, 0.5)) if parent == -1 else (L, 0, rng.uniform(-0.02, 0.02))
+        xml_body[b] = (f'<body name="b{b}" pos="{pos[0]:.3f} {pos[1]:.3f} {pos[2]:.3f}">{jx}{gx}{site}', "</body>")
+
+    def emit(b):
+        o, c = xml_body[b]
+        return o + "".join(emit(k) for k in children[b]) + c
+    world = "".join(emit(k) for k in children[-1])
+    tendons, acts, eqs, pairs, sens = [], [], [], [], []
+    if len(scalar) >= 2 and rng.random() < 0.7:
+        a, b2 = rng.choice(len(scalar), 2, replace=False)
+        lim = ' limited="true" range="-0.4 0.4"' if rng.random() < 0.5 else ""
+        tendons.append(f'<fixed name="t0"{lim}><joint joint="{scalar[a]}" coef="{rng.uniform(0.5, 1.5):.3f}"/><joint joint="{scalar[b2]}" coef="{rng.uniform(-1.5, -0.5):.3f}"/></fixed>')
+    for k, jn in enumerate(scalar):
+        r = rng.random()
+        if r < 0.2:
+            acts.append(f'<motor name="a{k}" joint="{jn}" gear="{rng.uniform(0.5, 2):.3f}" ctrllimited="true" ctrlrange="-1 1"/>')
+        elif r < 0.35:
+            acts.append(f'<position name="a{k}" joint="{jn}" kp="{rng.uniform(2, 10):.3f}"/>')
+        elif r < 0.45:
+            acts.append(f'<velocity name="a{k}" joint="{jn}" kv="{rng.uniform(0.1, 1):.3f}"/>')
+            vel_servo = True
+        elif r < 0.6:
+            acts.append(f'<general name="a{k}" joint="{jn}" dyntype="{rng.choice(["filter", "integrator"])}" dynprm="{rng.uniform(0.02, 0.2):.3f}" gainprm="{rng.uniform(0.5, 2):.3f}" '
+                        f'actlimited="true" actrange="-0.5 0.5" forcelimited="true" forcerange="-2 2"/>')
+        elif r < 0.7:
+            acts.append(f'<intvelocity name="a{k}" joint="{jn}" kp="{rng.uniform(2, 10):.3f}" actrange="-0.3 0.3"/>')
+    if tendons and rng.random() < 0.7:
+        acts.append(f'<motor name="at" tendon="t0" gear="{rng.uniform(0.3, 1):.3f}"/>')
+    if len(scalar) >= 2 and rng.random() < 0.3:
+        eqs.append(f'<joint joint1="{scalar[0]}" joint2="{scalar[-1]}" polycoef="0 {rng.uniform(0.5, 1):.3f} 0 0 0"/>')
+    if rng.random() < 0.6:
+        g = int(rng.integers(0, nbody))
+        pairs.append(f'<pair geom1="floor" geom2="g{g}" condim="{rng.choice([1, 3, 4])}" friction="{rng.uniform(0.3, 1):.3f} {rng.uniform(0.3, 1):.3f} 0.01 0.001 0.001"/>')
+    for k, (jn, kind) in enumerate(joints):
+        if kind in ("hinge", "slide") and rng.random() < 0.5:
+            sens.append(f'<jointpos joint="{jn}"/><jointvel joint="{jn}"/>')
+        if kind == "ball":
+            sens.append(f'<ballquat joint="{jn}"/>')
+    sens.append('<framepos objtype="site" objname="s0"/><velocimeter site="s0"/><subtreelinvel body="b0"/>')
+    for k, a in enumerate(acts[:2]):
+        nm = a.split('name="')[1].split('"')[0]
+        sens.append(f'<actuatorfrc actuator="{nm}"/>')
+    integ = ["Euler", "RK4", "implicitfast"][(seed // 6) % 3]
+    if integ == "implicitfast" and vel_servo and any("tendon=" in a for a in acts):
+        integ = "Euler"
+    xml = f'''<mujoco model="random{seed}"><compiler angle="radian"/>
+<option timestep="0.002" solver="{solver}" cone="{cone}" integrator="{integ}" iterations="40" tolerance="0"/>
+<size nconmax="12" njmax="100"/>
+<worldbody><geom name="floor" type="plane" size="3 3 0.1"/>{world}</worldbody>
+<tendon>{"".join(tendons)}</tendon><actuator>{"".join(acts)}</actuator><equality>{"".join(eqs)}</equality>
+<contact>{"".join(pairs)}</contact><sensor>{"".join(sens)}</sensor></mujoco>'''
+    return xml
+
+
+import os
+
+SEEDS = list(range(int(os.environ.get("MJB_RANDOM_MODELS", "64"))))   # (MJB_RANDOM_MODELS=1000: the long hunt, profiles/r06_random_models.txt)
+
+
+def test_random_models_load_and_step_on_the_oracle(oracle_built):
+    """(CPU) every generated model compiles and the oracle takes 20 finite steps from a perturbed state: the generator's own sanity."""
+    kinds = set()
+    for seed in SEEDS:
+        m = mjcf.compile_xml_string(random_model(seed))
+        kinds.update(int(t) for t in m["jnt_type"])
+        d = oracle_built.OracleData(m)
+        d.reset()
+        rng = np.random.default_rng(1000 + seed)
+        d.qvel[:] = rng.uniform(-0.5, 0.5, m["nv"])
+        d.ctrl[:] = rng.uniform(-1, 1, m["nu"])
+        d.step(20)
+        assert np.isfinite(np.array(d.qpos)).all() and np.isfinite(np.array(d.qvel)).all(), seed
+    assert kinds == {0, 1, 2, 3}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", SEEDS)
+def test_gpu_random_model_matches_oracle(oracle_built, seed):
+    from mujoco_ros_pkgs_amd import engine
+    m = mjcf.compile_xml_string(random_model(seed))
+    try:
+        cm = engine.CompiledModel(m)
+    except engine.EngineError as ex:
+        if "one env per wavefront" in str(ex) or "exceeds one CU" in str(ex):
+            pytest.skip(str(ex))
+        raise
+    n = 16
+    rng = np.random.default_rng(500 + seed)
+    qpos = np.tile(np.asarray(m["qpos0"], float), (n, 1))
+    for j in range(m["njnt"]):
+        a, t = int(m["jnt_qposadr"][j]), int(m["jnt_type"][j])
+        if t >= 2:
+            qpos[:, a] += rng.uniform(-0.3, 0.3, n) * (0.1 if t == 2 else 1.0)
+        else:
+            qa = a + (3 if t == 0 else 0)
+            q = rng.normal(size=(n, 4)) * 0.3 + np.array([1, 0, 0, 0])
+            qpos[:, qa:qa + 4] = q / np.linalg.norm(q, axis=1, keepdims=True)
+            if t == 0:
+                qpos[:, a + 2] += rng.uniform(-0.05, 0.1, n)
+    qvel = rng.uniform(-0.5, 0.5, (n, m["nv"]))
+    ctrl = rng.uniform(-1.2, 1.2, (n, m["nu"]))
+    act = rng.uniform(-0.1, 0.1, (n, m["na"]))
+    d = oracle_built.OracleData(m)
+    solver = int(m["solver"])
+    for nstep in (1, 15):
+        b = engine.Batch(cm, n)
+        b.set_lane_env(0)
+        b.set("qpos", qpos); b.set("qvel", qvel); b.set("ctrl", ctrl)
+        if m["na"]:
+            b.set("act", act)
+        b.step(nstep)
+        got = {k: b.get(k) for k in ("qpos", "qvel", "act", "sensordata")}
+        resets = b.warning_count()
+        b.close()
+        tol = (1e-8 if solver == 1 else 1e-10) if nstep == 1 else (1e-5 if solver == 1 else 1e-6)
+        bad_rows, worst = 0, []
+        for e in range(n):
+            d.reset(); d.qpos[:] = qpos[e]; d.qvel[:] = qvel[e]; d.ctrl[:] = ctrl[e]
+            if m["na"]:
+                d.act[:] = act[e]
+            d.step(nstep)
+            for k in got:
+                r = np.array(getattr(d, k))
+                if r.size == 0:
+                    continue
+                err = np.abs(got[k][e] - r).max() / (1 + np.abs(r).max())
+                lim = tol * (100 if k in ("qvel", "sensordata") else 1)
+                if err > lim:
+                    bad_rows += 1
+                    worst.append((e, k, float(err)))
+                    # (the models ask for tolerance 0 -- every solver iteration is run, in both implementations -- because a stop test that sits
+                    #  on its threshold ends the two one iteration apart: seed 982 at tolerance 1e-10, 4 such ties in 16 envs, each with
+                    #  mjData.solver_iter one apart and ~1e-8 in qvel, every env with equal counts at 1e-14.  profiles/r06_random_models.txt)
+                    assert err <= lim * 1e3, (seed, nstep, e, k, err)
+        assert bad_rows == 0, (seed, nstep, bad_rows, worst)
+        assert resets == 0 or not np.isfinite(np.array(d.qpos)).all(), (seed, resets)
