@@ -216,3 +216,21 @@ def test_gpu_random_model_matches_oracle(oracle_built, seed):
         #  and with it the stop-test ties of DESIGN.md §2: up to two envs of sixteen may sit one iteration apart)
         assert bad_rows <= (6 if solver == 1 else 0), (seed, nstep, bad_rows, worst)
         assert resets == 0 or not np.isfinite(np.array(d.qpos)).all(), (seed, resets)
+    # the split step around the callback point (full frame in the HBM workspace) is the fused step (lean frame in LDS), bit for bit
+    outs = []
+    for split in (False, True):
+        b = engine.Batch(cm, n)
+        b.set_lane_env(0)
+        b.set("qpos", qpos); b.set("qvel", qvel); b.set("ctrl", ctrl)
+        if m["na"]:
+            b.set("act", act)
+        if split:
+            for _ in range(3):
+                b.step1()
+                b.step2()
+        else:
+            b.step(3)
+        outs.append((b.get("qpos"), b.get("qvel"), b.get("act")))
+        b.close()
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y), (seed, "split != fused", float(np.abs(x - y).max()))
