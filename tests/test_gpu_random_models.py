@@ -234,6 +234,33 @@ def test_gpu_random_model_matches_oracle(oracle_built, seed):
         b.close()
     for x, y in zip(*outs):
         assert np.array_equal(x, y), (seed, "split != fused", float(np.abs(x - y).max()))
+    # per-env gravity and geom friction (mjb_set_env_*: the reference's setGravity / setGeomProperties services, per env) against the oracle on a model
+    # that carries the env's values in the file; an explicit pair's stated friction stays the pair's
+    if solver != 1:
+        k = 4
+        grav = np.tile(np.asarray(m["gravity"], float), (k, 1)) + rng.uniform(-2, 2, (k, 3))
+        fric = np.tile(np.asarray(m["geom_friction"], float), (k, 1, 1)) * rng.uniform(0.3, 1.5, (k, m["ngeom"], 1))
+        b = engine.Batch(cm, k)
+        b.set_lane_env(0)
+        b.set("qpos", qpos[:k]); b.set("qvel", qvel[:k]); b.set("ctrl", ctrl[:k])
+        if m["na"]:
+            b.set("act", act[:k])
+        b.set_env_gravity(grav)
+        b.set_env_geom_friction(fric)
+        b.step(5)
+        q5, v5 = b.get("qpos"), b.get("qvel")
+        b.close()
+        for e in range(k):
+            me = mjcf.Model(dict(m))
+            me["gravity"] = grav[e].copy()
+            me["geom_friction"] = fric[e].copy()
+            de = oracle_built.OracleData(me)
+            de.reset(); de.qpos[:] = qpos[e]; de.qvel[:] = qvel[e]; de.ctrl[:] = ctrl[e]
+            if m["na"]:
+                de.act[:] = act[e]
+            de.step(5)
+            assert np.abs(q5[e] - np.array(de.qpos)).max() <= 1e-8 and np.abs(v5[e] - np.array(de.qvel)).max() <= 1e-6 * (1 + np.abs(np.array(de.qvel)).max()), \
+                (seed, "env overrides", e, float(np.abs(q5[e] - np.array(de.qpos)).max()), float(np.abs(v5[e] - np.array(de.qvel)).max()))
 
 
 def random_pile(seed):
