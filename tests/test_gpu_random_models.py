@@ -111,6 +111,33 @@ def random_model(seed):
         if kind == "ball":
             sens.append(f'<ballquat joint="{jn}"/>')
     sens.append('<framepos objtype="site" objname="s0"/><velocimeter site="s0"/><subtreelinvel body="b0"/>')
+    # a handful of the other sensor types, on random sites / bodies / joints (relative frames included)
+    for _ in range(int(rng.integers(2, 8))):
+        sb, sb2 = int(rng.integers(0, nbody)), int(rng.integers(0, nbody))
+        kind_s = rng.choice(["touch", "accelerometer", "gyro", "force", "torque", "magnetometer", "rangefinder", "framequat", "framexaxis", "framezaxis", "framelinvel",
+                             "frameangvel", "framelinacc", "frameangacc", "subtreecom", "subtreeangmom", "framepos_rel", "framelinvel_rel", "limit", "tendon", "actpos", "jactfrc"])
+        if kind_s in ("touch", "accelerometer", "gyro", "force", "torque", "magnetometer", "rangefinder"):
+            sens.append(f'<{kind_s} site="s{sb}"/>')
+        elif kind_s in ("framequat", "framexaxis", "framezaxis", "framelinvel", "frameangvel", "framelinacc", "frameangacc"):
+            ot = rng.choice(["site", "body", "xbody", "geom"])
+            on = {"site": f"s{sb}", "body": f"b{sb}", "xbody": f"b{sb}", "geom": f"g{sb}"}[ot]
+            sens.append(f'<{kind_s} objtype="{ot}" objname="{on}"/>')
+        elif kind_s in ("subtreecom", "subtreeangmom"):
+            sens.append(f'<{kind_s} body="b{sb}"/>')
+        elif kind_s == "framepos_rel":
+            sens.append(f'<framepos objtype="site" objname="s{sb}" reftype="body" refname="b{sb2}"/><framequat objtype="body" objname="b{sb}" reftype="site" refname="s{sb2}"/>')
+        elif kind_s == "framelinvel_rel":
+            sens.append(f'<framelinvel objtype="site" objname="s{sb}" reftype="site" refname="s{sb2}"/><frameangvel objtype="xbody" objname="b{sb}" reftype="body" refname="b{sb2}"/>')
+        elif kind_s == "limit" and scalar:
+            jn = scalar[int(rng.integers(0, len(scalar)))]
+            sens.append(f'<jointlimitpos joint="{jn}"/><jointlimitvel joint="{jn}"/><jointlimitfrc joint="{jn}"/>')
+        elif kind_s == "tendon" and tendons:
+            sens.append('<tendonpos tendon="t0"/><tendonvel tendon="t0"/><tendonlimitpos tendon="t0"/><tendonlimitfrc tendon="t0"/>')
+        elif kind_s == "actpos" and acts:
+            nm = acts[int(rng.integers(0, len(acts)))].split('name="')[1].split('"')[0]
+            sens.append(f'<actuatorpos actuator="{nm}"/><actuatorvel actuator="{nm}"/>')
+        elif kind_s == "jactfrc" and scalar:
+            sens.append(f'<jointactuatorfrc joint="{scalar[int(rng.integers(0, len(scalar)))]}"/>')
     for k, a in enumerate(acts[:2]):
         nm = a.split('name="')[1].split('"')[0]
         sens.append(f'<actuatorfrc actuator="{nm}"/>')
