@@ -261,6 +261,17 @@ def test_gpu_random_model_matches_oracle(oracle_built, seed):
         b.close()
     for x, y in zip(*outs):
         assert np.array_equal(x, y), (seed, "split != fused", float(np.abs(x - y).max()))
+    # the reference's ctrl-noise injector on the device (mujoco_env.cpp:469-481; Philox-keyed OU process) against the oracle's, activations starting at rest
+    if solver != 1 and m["nu"] > 0:
+        b = engine.Batch(cm, n)
+        b.set_lane_env(0)
+        b.set("qpos", qpos); b.set("qvel", qvel)
+        b.set_ctrl_noise(0.7, 0.1, 4242 + seed, 0)
+        b.step(6)
+        qn, vn = b.get("qpos"), b.get("qvel")
+        b.close()
+        oq, ov, _ = oracle_built.rollout(m, qpos, qvel, 6, noise_std=0.7, noise_rate=0.1, seed=4242 + seed)
+        assert np.abs(qn - oq).max() <= 1e-8 and np.abs(vn - ov).max() <= 1e-6 * (1 + np.abs(ov).max()), (seed, "ctrl noise", float(np.abs(qn - oq).max()), float(np.abs(vn - ov).max()))
     # per-env gravity and geom friction (mjb_set_env_*: the reference's setGravity / setGeomProperties services, per env) against the oracle on a model
     # that carries the env's values in the file; an explicit pair's stated friction stays the pair's
     if solver != 1:
