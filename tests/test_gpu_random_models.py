@@ -396,3 +396,19 @@ def test_gpu_random_pile_matches_oracle(oracle_built, seed):
             eq = np.abs(q[e] - np.array(d.qpos)).max()
             ev = np.abs(v[e] - np.array(d.qvel)).max() / (1 + np.abs(np.array(d.qvel)).max())
             assert eq <= tol and ev <= 100 * tol, (seed, nstep, e, eq, ev, rows)
+    # per-env geom sizes (setGeomProperties per env: mjb_set_env_geom_size; the bounding radii stay the model's, as in the reference)
+    size = np.tile(np.asarray(m["geom_size"], float), (n, 1, 1))
+    size[:, 2:, :] *= rng.uniform(0.85, 1.0, (n, m["ngeom"] - 2, 1))
+    b = engine.Batch(cm, n)
+    b.set("qpos", qpos); b.set("qvel", qvel)
+    b.set_env_geom_size(size)
+    b.step(3)
+    q3 = b.get("qpos")
+    b.close()
+    for e in range(n):
+        d.reset(); d.qpos[:] = qpos[e]; d.qvel[:] = qvel[e]
+        d.set_geom_size(size[e])
+        d.step(3)
+        if not (d.warning(6) or d.warning(4) or d.warning(5)):
+            assert np.abs(q3[e] - np.array(d.qpos)).max() <= 1e-7, (seed, "geom sizes", e, float(np.abs(q3[e] - np.array(d.qpos)).max()))
+    d.set_geom_size(None)
