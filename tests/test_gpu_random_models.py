@@ -2,6 +2,8 @@
 springs and dampers, capsule / sphere / box geoms over a floor, fixed tendons (limited), joint / tendon actuators of every supported kind
 (motor, position, velocity, general with filter / integrator dynamics, intvelocity), a joint equality, explicit contact pairs, sensors -- stepped by
 the HIP path and by the oracle from the same states.  What the hand-written worlds of the other tests do not cover is the COMBINATIONS."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,7 +14,7 @@ def random_model(seed):
     rng = np.random.default_rng(seed)
     solver = ["Newton", "PGS", "CG"][seed % 3]
     cone = ["pyramidal", "elliptic"][(seed // 3) % 2]
-    nbody = int(rng.integers(3, 10))
+    nbody = int(rng.integers(3, 10)) if "MJB_RANDOM_BODIES" not in os.environ else int(rng.integers(10, int(os.environ["MJB_RANDOM_BODIES"])))   # (the hunt for the nv 17 .. 64 code paths)
     vel_servo = False
     bodies, joints, scalar = [], [], []
     xml_body = {}
@@ -152,8 +154,6 @@ def random_model(seed):
 <contact>{"".join(pairs)}</contact><sensor>{"".join(sens)}</sensor></mujoco>'''
     return xml
 
-
-import os
 
 SEEDS = list(range(int(os.environ.get("MJB_RANDOM_MODELS", "64"))))   # (MJB_RANDOM_MODELS=1000: the long hunt, profiles/r06_random_models.txt)
 
