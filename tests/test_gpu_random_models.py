@@ -261,6 +261,30 @@ def test_gpu_random_model_matches_oracle(oracle_built, seed):
         b.close()
     for x, y in zip(*outs):
         assert np.array_equal(x, y), (seed, "split != fused", float(np.abs(x - y).max()))
+    # the other ways of cutting a step at the callback points -- chained halves (mjb_step21_prefix) and, under RK4, the four evaluations
+    # (mjb_step2_rk_prefix) -- are the same step too
+    b = engine.Batch(cm, n)
+    b.set_lane_env(0)
+    b.set("qpos", qpos); b.set("qvel", qvel); b.set("ctrl", ctrl)
+    if m["na"]:
+        b.set("act", act)
+    assert b.lib.mjb_step1_prefix(b.ptr, n) == 0
+    for k in range(3):
+        assert (b.lib.mjb_step21_prefix if k < 2 else b.lib.mjb_step2_prefix)(b.ptr, n) == 0
+    assert np.array_equal(b.get("qpos"), outs[0][0]) and np.array_equal(b.get("act"), outs[0][2]), (seed, "chained halves")
+    b.close()
+    if int(m["integrator"]) == 1:
+        b = engine.Batch(cm, n)
+        b.set_lane_env(0)
+        b.set("qpos", qpos); b.set("qvel", qvel); b.set("ctrl", ctrl)
+        if m["na"]:
+            b.set("act", act)
+        for k in range(3):
+            assert b.lib.mjb_step1_prefix(b.ptr, n) == 0
+            for rk in range(4):
+                assert b.lib.mjb_step2_rk_prefix(b.ptr, n, rk) == 0
+        assert np.array_equal(b.get("qpos"), outs[0][0]) and np.array_equal(b.get("act"), outs[0][2]), (seed, "rk4 evaluations")
+        b.close()
     # the reference's ctrl-noise injector on the device (mujoco_env.cpp:469-481; Philox-keyed OU process) against the oracle's, activations starting at rest
     if solver != 1 and m["nu"] > 0:
         b = engine.Batch(cm, n)
