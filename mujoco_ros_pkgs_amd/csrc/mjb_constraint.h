@@ -40,6 +40,11 @@ DEVI int raw_sphere_sphere(RawCon &c, const double *p1, double r1, const double 
 	return 1;
 }
 
+// Ties (oracle/mjo_constraint.c, MJO_TIE: the same offset at the same comparisons).  A scene built on a grid puts the narrow phase's comparisons on their knife
+// edge -- the least penetrated of two equal face axes, a vertex ON a side plane, a surface at distance == margin -- and the last bit decides them differently in
+// two implementations of the same steps.  Equal candidates keep the first in order, a point within MJB_TIE of a plane is on it, a distance equal to the margin is
+// inside it.
+#define MJB_TIE 1e-12
 DEVI int raw_plane_sphere(RawCon &c, const double *pos1, const double *n, const double *p, double r, double margin)
 {
 	double tmp[3] = { p[0] - pos1[0], p[1] - pos1[1], p[2] - pos1[2] };
@@ -91,7 +96,7 @@ DEVI int raw_sphere_box(RawCon &c, const double *pos1, double r1, const double *
 		int kk = 0;
 		for (int i = 0; i < 6; i++) {
 			const double fd = fabs(((i % 2) ? 1 : -1) * size2[i / 2] - center[i / 2]);
-			if (closest > fd) {
+			if (closest > fd + MJB_TIE) {
 				closest = fd;
 				kk = i;
 			}
@@ -196,7 +201,7 @@ DEVI int capsule_box(RawCon *rc, const double *pos1, const double *mat1, const d
 	const double ts = 0.5 * (tlo + thi);
 	int nout = 0, face = 0;
 	for (int i = 0; i < 3; i++)
-		if (fabs(p0[i] + ts * d[i]) > size2[i]) {
+		if (fabs(p0[i] + ts * d[i]) > size2[i] + MJB_TIE) {
 			nout++;
 			face = i;
 		}
@@ -270,12 +275,12 @@ DEVI int box_box(double *scr, const double *pos1, const double *mat1, const doub
 	for (int i = 0; i < 3; i++) {
 		const double s = fabs(tA[i]) - (size1[i] + size2[0] * Q[i][0] + size2[1] * Q[i][1] + size2[2] * Q[i][2]);
 		if (s > margin) return 0;
-		if (s > best) { best = s; code = i; }
+		if (s > best + MJB_TIE) { best = s; code = i; }
 	}
 	for (int j = 0; j < 3; j++) {
 		const double s = fabs(tB[j]) - (size2[j] + size1[0] * Q[0][j] + size1[1] * Q[1][j] + size1[2] * Q[2][j]);
 		if (s > margin) return 0;
-		if (s > best) { best = s; code = 3 + j; }
+		if (s > best + MJB_TIE) { best = s; code = 3 + j; }
 	}
 	double ebest = -1e300;
 	int ecode = -1;
@@ -288,7 +293,7 @@ DEVI int box_box(double *scr, const double *pos1, const double *mat1, const doub
 			           (size1[i1] * Q[i2][j] + size1[i2] * Q[i1][j] + size2[j1] * Q[i][j2] + size2[j2] * Q[i][j1]);
 			s /= l;
 			if (s > margin) return 0;
-			if (s > ebest) { ebest = s; ecode = 6 + 3 * i + j; }
+			if (s > ebest + MJB_TIE) { ebest = s; ecode = 6 + 3 * i + j; }
 		}
 	if (ecode >= 0 && ebest > best + 0.05 * fabs(best) + 1e-9) {
 		const int i = (ecode - 6) / 3, j = (ecode - 6) % 3;
@@ -348,14 +353,14 @@ DEVI int box_box(double *scr, const double *pos1, const double *mat1, const doub
 	}
 	double nref[3];
 	{
-		const double sg = (ref1 ? tA[ax] : -tB[ax]) >= 0 ? 1.0 : -1.0;
+		const double sg = (ref1 ? tA[ax] : -tB[ax]) >= -MJB_TIE ? 1.0 : -1.0;  // (centres level along the axis: the + face, whatever the last bit says)
 		for (int q = 0; q < 3; q++) nref[q] = sg * R[ax][q];
 	}
 	int k = 0;
 	double kbest = -1;
 	for (int q = 0; q < 3; q++) {
 		const double a = fabs(dot3(O[q], nref));
-		if (a > kbest) { kbest = a; k = q; }
+		if (a > kbest + MJB_TIE) { kbest = a; k = q; }
 	}
 	const double fs = dot3(O[k], nref) > 0 ? -1.0 : 1.0;
 	const int u = (k + 1) % 3, v = (k + 2) % 3, sx = (ax + 1) % 3, sy = (ax + 2) % 3;
@@ -375,11 +380,11 @@ DEVI int box_box(double *scr, const double *pos1, const double *mat1, const doub
 		for (int w = 0; w < np; w++) {
 			const int w1 = (w + 1 == np) ? 0 : w + 1;
 			const double d0 = sgn * poly[w][cax] - lim, d1 = sgn * poly[w1][cax] - lim;
-			if (d0 <= 0 && nn < 8) {
+			if (d0 <= MJB_TIE && nn < 8) {  // (within MJB_TIE of the side plane: ON it -- kept, and no crossing next to it)
 				for (int q = 0; q < 3; q++) tmp[nn][q] = poly[w][q];
 				nn++;
 			}
-			if (((d0 < 0 && d1 > 0) || (d0 > 0 && d1 < 0)) && nn < 8) {
+			if (((d0 < -MJB_TIE && d1 > MJB_TIE) || (d0 > MJB_TIE && d1 < -MJB_TIE)) && nn < 8) {
 				const double fr = d0 / (d0 - d1);
 				for (int q = 0; q < 3; q++) tmp[nn][q] = poly[w][q] + fr * (poly[w1][q] - poly[w][q]);
 				nn++;
@@ -591,7 +596,7 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const EnvLi
 			const mjb_ciptr pi = m.pair_i + 8 * pc;
 			const mjb_cdptr pd = m.pair_d + 24 * pc;
 			const int g1 = pi[0], g2 = pi[1], t1 = pi[2];
-			const double margin = pd[6], rb1 = pd[8], rb2 = pd[9];
+			const double margin = pd[6] + MJB_TIE, rb1 = pd[8], rb2 = pd[9];  // (the culls and the pair functions test against margin + MJB_TIE)
 			double pos1[3], pos2[3];
 			ld3(pos1, f + L.geom_xpos + 3 * g1);
 			ld3(pos2, f + L.geom_xpos + 3 * g2);
@@ -657,7 +662,7 @@ template <int G> STAGE void collision(CModel m, CLayout L, CState s, const EnvLi
 			int t1 = pi[2], t2 = pi[3];
 			condim = pi[4];
 			frisel = pi[5];
-			margin = pd[6];
+			margin = pd[6] + MJB_TIE;  // (MJB_TIE: a surface at distance == margin is inside it; incl below is the exact margin - gap)
 			incl = pd[17];
 			double rb1 = pd[8], rb2 = pd[9];
 			// per-env geom sizes / types (setGeomProperties per env, mjb_set_env_geom_size / _type): bounding radii stay the

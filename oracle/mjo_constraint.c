@@ -37,6 +37,12 @@ typedef struct {
 
 /* ------------------------------------------------------------------ A5: primitive narrow phase */
 /* sphere-sphere core (mjraw_SphereSphere): centres p1/p2, radii r1/r2 */
+/* Ties.  A scene built on a grid -- boxes stacked with identity orientations, a capsule lying along a box edge, geoms exactly touching -- puts the
+ * narrow phase's comparisons on their knife edge: which face axis is the least penetrated, whether a vertex lies inside a side plane, whether a surface
+ * at distance == margin is a contact.  Decided by the last bit they come out differently in two implementations of the same steps (fma contraction is
+ * enough).  Every such comparison carries this offset: equal candidates keep the first in order, a point on a plane is on it, a distance equal to the
+ * margin is inside it; the knife edges move to where no grid puts a scene.  (csrc/mjb_constraint.h: MJB_TIE, the same places.) */
+#define MJO_TIE 1e-12
 static int raw_sphere_sphere(rawcon *c, const double *p1, double r1, const double *p2, double r2, double margin)
 {
 	double dif[3];
@@ -187,7 +193,7 @@ static int sphere_box(rawcon *c, const double *pos1, double r1, const double *po
 		int k = 0;
 		for (int i = 0; i < 6; i++) {
 			double fd = fabs(((i % 2) ? 1 : -1) * size2[i / 2] - center[i / 2]);
-			if (closest > fd) {
+			if (closest > fd + MJO_TIE) {
 				closest = fd;
 				k = i;
 			}
@@ -272,7 +278,7 @@ static int capsule_box(rawcon *c, const double *pos1, const double *mat1, const 
 	const double ts = 0.5 * (tlo + thi);
 	int nout = 0, face = 0;
 	for (int i = 0; i < 3; i++)
-		if (fabs(p0[i] + ts * d[i]) > size2[i]) {
+		if (fabs(p0[i] + ts * d[i]) > size2[i] + MJO_TIE) {
 			nout++;
 			face = i;
 		}
@@ -341,12 +347,12 @@ static int box_box(rawcon *c, const double *pos1, const double *mat1, const doub
 	for (int i = 0; i < 3; i++) {
 		double s = fabs(tA[i]) - (size1[i] + size2[0] * Q[i][0] + size2[1] * Q[i][1] + size2[2] * Q[i][2]);
 		if (s > margin) return 0;
-		if (s > best) { best = s; code = i; }
+		if (s > best + MJO_TIE) { best = s; code = i; }
 	}
 	for (int j = 0; j < 3; j++) {
 		double s = fabs(tB[j]) - (size2[j] + size1[0] * Q[0][j] + size1[1] * Q[1][j] + size1[2] * Q[2][j]);
 		if (s > margin) return 0;
-		if (s > best) { best = s; code = 3 + j; }
+		if (s > best + MJO_TIE) { best = s; code = 3 + j; }
 	}
 	double ebest = -1e300;
 	int ecode = -1;
@@ -359,7 +365,7 @@ static int box_box(rawcon *c, const double *pos1, const double *mat1, const doub
 			           (size1[i1] * Q[i2][j] + size1[i2] * Q[i1][j] + size2[j1] * Q[i][j2] + size2[j2] * Q[i][j1]);
 			s /= l;
 			if (s > margin) return 0;
-			if (s > ebest) { ebest = s; ecode = 6 + 3 * i + j; }
+			if (s > ebest + MJO_TIE) { ebest = s; ecode = 6 + 3 * i + j; }
 		}
 	if (ecode >= 0 && ebest > best + 0.05 * fabs(best) + 1e-9) {
 		/* 3. edge x edge */
@@ -412,14 +418,14 @@ static int box_box(rawcon *c, const double *pos1, const double *mat1, const doub
 	const double *pr = ref1 ? pos1 : pos2, *po = ref1 ? pos2 : pos1, *hr = ref1 ? size1 : size2, *ho = ref1 ? size2 : size1;
 	double nref[3]; /* outward normal of the reference face, pointing to the incident box */
 	{
-		double sg = (ref1 ? tA[ax] : -tB[ax]) >= 0 ? 1.0 : -1.0;
+		double sg = (ref1 ? tA[ax] : -tB[ax]) >= -MJO_TIE ? 1.0 : -1.0; /* (centres level along the axis: the + face, whatever the last bit says) */
 		for (int q = 0; q < 3; q++) nref[q] = sg * R[ax][q];
 	}
 	int k = 0;
 	double kbest = -1;
 	for (int q = 0; q < 3; q++) {
 		double a = fabs(v3_dot(O[q], nref));
-		if (a > kbest) { kbest = a; k = q; }
+		if (a > kbest + MJO_TIE) { kbest = a; k = q; }
 	}
 	const double fs = v3_dot(O[k], nref) > 0 ? -1.0 : 1.0; /* incident face normal = fs O_k (against nref) */
 	const int u = (k + 1) % 3, v = (k + 2) % 3, sx = (ax + 1) % 3, sy = (ax + 2) % 3;
@@ -440,10 +446,11 @@ static int box_box(rawcon *c, const double *pos1, const double *mat1, const doub
 		for (int w = 0; w < np; w++) {
 			const double *p0 = poly[w], *p1 = poly[(w + 1) % np];
 			double d0 = sgn * p0[cax] - lim, d1 = sgn * p1[cax] - lim;
-			if (d0 <= 0) {
+			/* (a vertex within MJO_TIE of the side plane is ON it: kept, and no crossing is generated next to it) */
+			if (d0 <= MJO_TIE) {
 				if (nn < 8) { memcpy(tmp[nn], p0, sizeof tmp[0]); nn++; }
 			}
-			if ((d0 < 0 && d1 > 0) || (d0 > 0 && d1 < 0)) {
+			if ((d0 < -MJO_TIE && d1 > MJO_TIE) || (d0 > MJO_TIE && d1 < -MJO_TIE)) {
 				double f = d0 / (d0 - d1);
 				if (nn < 8) {
 					for (int q = 0; q < 3; q++) tmp[nn][q] = p0[q] + f * (p1[q] - p0[q]);
@@ -560,35 +567,36 @@ void mjo_collision(const mjb_model_desc *m, mjo_data *d)
 		const double *pp = m->collpair_explicit[p] ? m->collpair_param + 14 * p : NULL;
 		if (pp && (pp[12] == pp[12])) margin = pp[12];
 		if (pp && (pp[13] == pp[13])) gap = pp[13];
+		const double mt = margin + MJO_TIE; /* what the culls and the pair functions test against (MJO_TIE) */
 		/* broad phase: bounding spheres (plane: signed distance of the other geom's sphere) */
 		double rb1 = m->geom_rbound[g1], rb2 = m->geom_rbound[g2];
 		if (rb1 > 0 && rb2 > 0) {
 			double dv[3];
 			v3_sub(dv, pos2, pos1);
-			double bound = margin + rb1 + rb2;
+			double bound = mt + rb1 + rb2;
 			if (v3_dot(dv, dv) > bound * bound) continue;
 		} else if (t1 == MJB_GEOM_PLANE && rb2 > 0) {
 			double n[3] = { mat1[2], mat1[5], mat1[8] }, dv[3];
 			v3_sub(dv, pos2, pos1);
-			if (v3_dot(dv, n) > margin + rb2) continue;
+			if (v3_dot(dv, n) > mt + rb2) continue;
 		}
 		rawcon rc[8];
 		int n = 0;
 		const int cfun = d->colfunc[8 * t1 + t2]; /* registerCollisionFunction override (pairs are stored with t1 <= t2) */
 		if (cfun == MJB_COLFUNC_NONE) continue;
 		if (cfun == MJB_COLFUNC_SPHERES) {
-			if (t1 == MJB_GEOM_PLANE) n = raw_plane_sphere(rc, pos1, mat1, pos2, rb2, margin);
-			else n = raw_sphere_sphere(rc, pos1, rb1, pos2, rb2, margin);
+			if (t1 == MJB_GEOM_PLANE) n = raw_plane_sphere(rc, pos1, mat1, pos2, rb2, mt);
+			else n = raw_sphere_sphere(rc, pos1, rb1, pos2, rb2, mt);
 		} else
-		if (t1 == MJB_GEOM_PLANE && t2 == MJB_GEOM_SPHERE) n = raw_plane_sphere(rc, pos1, mat1, pos2, size2[0], margin);
-		else if (t1 == MJB_GEOM_PLANE && t2 == MJB_GEOM_CAPSULE) n = plane_capsule(rc, pos1, mat1, pos2, mat2, size2, margin);
-		else if (t1 == MJB_GEOM_PLANE && t2 == MJB_GEOM_BOX) n = plane_box(rc, pos1, mat1, pos2, mat2, size2, margin);
-		else if (t1 == MJB_GEOM_SPHERE && t2 == MJB_GEOM_SPHERE) n = raw_sphere_sphere(rc, pos1, size1[0], pos2, size2[0], margin);
-		else if (t1 == MJB_GEOM_SPHERE && t2 == MJB_GEOM_CAPSULE) n = sphere_capsule(rc, pos1, size1[0], pos2, mat2, size2, margin);
-		else if (t1 == MJB_GEOM_SPHERE && t2 == MJB_GEOM_BOX) n = sphere_box(rc, pos1, size1[0], pos2, mat2, size2, margin);
-		else if (t1 == MJB_GEOM_CAPSULE && t2 == MJB_GEOM_CAPSULE) n = capsule_capsule(rc, pos1, mat1, size1, pos2, mat2, size2, margin);
-		else if (t1 == MJB_GEOM_CAPSULE && t2 == MJB_GEOM_BOX) n = capsule_box(rc, pos1, mat1, size1, pos2, mat2, size2, margin);
-		else if (t1 == MJB_GEOM_BOX && t2 == MJB_GEOM_BOX) n = box_box(rc, pos1, mat1, size1, pos2, mat2, size2, margin);
+		if (t1 == MJB_GEOM_PLANE && t2 == MJB_GEOM_SPHERE) n = raw_plane_sphere(rc, pos1, mat1, pos2, size2[0], mt);
+		else if (t1 == MJB_GEOM_PLANE && t2 == MJB_GEOM_CAPSULE) n = plane_capsule(rc, pos1, mat1, pos2, mat2, size2, mt);
+		else if (t1 == MJB_GEOM_PLANE && t2 == MJB_GEOM_BOX) n = plane_box(rc, pos1, mat1, pos2, mat2, size2, mt);
+		else if (t1 == MJB_GEOM_SPHERE && t2 == MJB_GEOM_SPHERE) n = raw_sphere_sphere(rc, pos1, size1[0], pos2, size2[0], mt);
+		else if (t1 == MJB_GEOM_SPHERE && t2 == MJB_GEOM_CAPSULE) n = sphere_capsule(rc, pos1, size1[0], pos2, mat2, size2, mt);
+		else if (t1 == MJB_GEOM_SPHERE && t2 == MJB_GEOM_BOX) n = sphere_box(rc, pos1, size1[0], pos2, mat2, size2, mt);
+		else if (t1 == MJB_GEOM_CAPSULE && t2 == MJB_GEOM_CAPSULE) n = capsule_capsule(rc, pos1, mat1, size1, pos2, mat2, size2, mt);
+		else if (t1 == MJB_GEOM_CAPSULE && t2 == MJB_GEOM_BOX) n = capsule_box(rc, pos1, mat1, size1, pos2, mat2, size2, mt);
+		else if (t1 == MJB_GEOM_BOX && t2 == MJB_GEOM_BOX) n = box_box(rc, pos1, mat1, size1, pos2, mat2, size2, mt);
 		if (n == 0) continue;
 		int condim;
 		double solref[2], solimp[5], fri[3];
