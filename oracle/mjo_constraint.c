@@ -313,14 +313,13 @@ static int capsule_box(rawcon *c, const double *pos1, const double *mat1, const 
 
 /* box - box.  MuJoCo's own routine (engine_collision_box.c, mjc_BoxBox) is not available in this environment; this
  * is the classical separating-axis + face-clipping construction with the same contract (contacts on the feature pair
- * of least penetration, frame normal from geom 1 to geom 2, position midway between the surfaces), capped at 4
- * contacts per pair:
+ * of least penetration, frame normal from geom 1 to geom 2, position midway between the surfaces), up to 8
+ * contacts per pair (mjc_BoxBox's count):
  *   1. separation along the 15 candidate axes (3 + 3 face normals, 9 edge x edge); any separation > margin: no
  *      contact; the axis of least penetration wins, edge axes only when they beat the best face axis by 5 %;
  *   2. face axis: the most anti-parallel face of the other box (4 vertices) is clipped against the side planes of
- *      the reference face (Sutherland-Hodgman, <= 8 vertices); vertices closer than margin to the reference face
- *      become contacts (dist = signed height above the face); more than 4 are reduced to the deepest one, the one
- *      farthest from it, and the two extreme ones on either side of that line;
+ *      the reference face (Sutherland-Hodgman, <= 8 vertices); every clipped vertex closer than margin to the reference
+ *      face becomes a contact (dist = signed height above the face);
  *   3. edge x edge axis: one contact at the closest points of the two supporting edges.
  * The HIP narrow phase (mjb_constraint.h, box_box) follows the same steps operation for operation. */
 static int box_box(rawcon *c, const double *pos1, const double *mat1, const double *size1, const double *pos2,
