@@ -238,7 +238,7 @@ DEVI int capsule_box(RawCon *rc, const double *pos1, const double *mat1, const d
 }
 
 // box - box: same steps as oracle/mjo_constraint.c box_box (separating axes, then either the incident face clipped
-// against the reference face -- up to 4 contacts after reduction -- or one edge-edge contact)
+// against the reference face -- every clipped vertex within the margin is a contact, up to 8 -- or one edge-edge contact)
 // The clipping polygons, the axis tables and the half sizes are indexed dynamically (separating-axis code, reference face): they
 // (and the up to 8 output contacts, 10 doubles each: dist, pos, normal + tangent hint) live in a MJB_BBSCR-double LDS scratch `scr`
 // that ONE lane at a time owns (collision() serialises the box - box lanes) -- private arrays indexed that way sit in scratch
