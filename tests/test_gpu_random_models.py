@@ -285,6 +285,33 @@ def test_gpu_random_model_matches_oracle(oracle_built, seed):
                 assert b.lib.mjb_step2_rk_prefix(b.ptr, n, rk) == 0
         assert np.array_equal(b.get("qpos"), outs[0][0]) and np.array_equal(b.get("act"), outs[0][2]), (seed, "rk4 evaluations")
         b.close()
+    # the device-side DefaultRobotHWSim::writeSim stage (EFFORT / POSITION / VELOCITY / *_PID on random scalar joints) against the oracle's, fused steps
+    sj = [j for j in range(m["njnt"]) if int(m["jnt_type"][j]) >= 2]
+    if solver != 1 and sj:
+        from mujoco_ros_pkgs_amd import binding
+        import test_hwsim as H
+        pick = [int(j) for j in rng.choice(sj, min(len(sj), 4), replace=False)]
+        spec = []
+        for j in pick:
+            meth = str(rng.choice(list(binding.HW_METHODS)))
+            spec.append(dict(joint=j, method=meth, kind=str(rng.choice(["revolute", "continuous", "prismatic"])), p=float(rng.uniform(5, 60)), i=float(rng.uniform(0, 5)),
+                             d=float(rng.uniform(0, 2)), i_max=2.0, i_min=-2.0, antiwindup=int(rng.integers(0, 2)), effort_limit=float(rng.uniform(2, 20)),
+                             lower=float(m["jnt_range"][j][0]) if m["jnt_limited"][j] else -1.0, upper=float(m["jnt_range"][j][1]) if m["jnt_limited"][j] else 1.0))
+        cfg = H._oracle_cfg(spec)
+        k = 4
+        cp, cv, ce = rng.uniform(-0.3, 0.3, (k, len(spec))), rng.uniform(-0.3, 0.3, (k, len(spec))), rng.uniform(-2, 2, (k, len(spec)))
+        b = engine.Batch(cm, k)
+        b.set_lane_env(0)
+        b.hwsim_configure(spec)
+        b.hwsim_set_command("position", cp); b.hwsim_set_command("velocity", cv); b.hwsim_set_command("effort", ce)
+        b.set("qpos", qpos[:k])
+        b.step(12)
+        qh, vh = b.get("qpos"), b.get("qvel")
+        b.close()
+        for e in range(k):
+            dh, _ = H._oracle_rollout(oracle_built, m, cfg, qpos[e], cp[e], cv[e], ce[e], 12)
+            assert np.abs(qh[e] - np.array(dh.qpos)).max() <= 1e-7 and np.abs(vh[e] - np.array(dh.qvel)).max() <= 1e-5 * (1 + np.abs(np.array(dh.qvel)).max()), \
+                (seed, "hwsim", e, [s_["method"] for s_ in spec], float(np.abs(qh[e] - np.array(dh.qpos)).max()), float(np.abs(vh[e] - np.array(dh.qvel)).max()))
     # the reference's ctrl-noise injector on the device (mujoco_env.cpp:469-481; Philox-keyed OU process) against the oracle's, activations starting at rest
     if solver != 1 and m["nu"] > 0:
         b = engine.Batch(cm, n)
