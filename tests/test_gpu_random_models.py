@@ -312,6 +312,32 @@ def test_gpu_random_model_matches_oracle(oracle_built, seed):
             dh, _ = H._oracle_rollout(oracle_built, m, cfg, qpos[e], cp[e], cv[e], ce[e], 12)
             assert np.abs(qh[e] - np.array(dh.qpos)).max() <= 1e-7 and np.abs(vh[e] - np.array(dh.qvel)).max() <= 1e-5 * (1 + np.abs(np.array(dh.qvel)).max()), \
                 (seed, "hwsim", e, [s_["method"] for s_ in spec], float(np.abs(qh[e] - np.array(dh.qpos)).max()), float(np.abs(vh[e] - np.array(dh.qvel)).max()))
+    # the sensors plugin's device-side packing (value / cutoff + per-axis Gaussian noise by set_flag, float32 messages) against the oracle's, random noise models
+    if m["nsensor"]:
+        ns = m["nsensor"]
+        flag, mean, sigma = np.zeros(ns, np.int32), np.zeros((ns, 3)), np.zeros((ns, 3))
+        for i in range(ns):
+            dim = int(m["sensor_dim"][i])
+            if rng.random() < 0.5:
+                flag[i] = int(rng.integers(1, 8)) if dim >= 3 else 1
+                nb = bin(int(flag[i])).count("1")
+                mean[i, :nb], sigma[i, :nb] = rng.uniform(-0.5, 0.5, nb), rng.uniform(0.01, 0.2, nb)
+        b = engine.Batch(cm, n)
+        b.set_lane_env(0)
+        b.set("qpos", qpos); b.set("qvel", qvel); b.set("ctrl", ctrl)
+        b.set_ctrl_noise(0.0, 0.1, 0, 500)
+        b.step(2)
+        for i in range(ns):
+            if flag[i]:
+                nb = bin(int(flag[i])).count("1")
+                b.sensor_set_noise(i, int(flag[i]), mean[i][:nb], sigma[i][:nb])
+        b.sensor_pack(seed=7 + seed)
+        sd, vv, tt = b.get("sensordata"), b.sensor_messages("value"), b.sensor_messages("truth")
+        b.close()
+        for e in (0, n - 1):
+            ov, ot = oracle_built.sensor_pack(m, sd[e], flag, mean.ravel(), sigma.ravel(), 7 + seed, 500 + e, 2)
+            assert np.array_equal(tt[e], ot), (seed, "sensor pack truth", e)
+            assert np.abs(vv[e] - ov).max() <= 1e-6 * (1 + np.abs(ov).max()), (seed, "sensor pack value", e, float(np.abs(vv[e] - ov).max()))
     # the reference's ctrl-noise injector on the device (mujoco_env.cpp:469-481; Philox-keyed OU process) against the oracle's, activations starting at rest
     if solver != 1 and m["nu"] > 0:
         b = engine.Batch(cm, n)
